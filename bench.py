@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py - two-site energy evaluations per second (BASELINE.json metric) on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident
+in HBM: the fused power-iteration-environment + two-site-energy kernel over B evaluations, the
+device-side sum of the batch's energies and - for N > 1 - the path's single exchange step, ONE
+RCCL all-reduce of the summed cost over xGMI.  Workload = BASELINE.json configs[2]: TFIM g=1,
+D=4, B=65536 Haar-random state unitaries per GPU (weak scaling: every rank evaluates its own
+shard of the restarts x shifts x terms batch), tol 1e-13.
+
+The product path uses no PyTorch: kernels, streams, events and the RCCL communicator live in
+libqmps_hip.so (ctypes).  For N > 1 torch.distributed (gloo, CPU) is used only as launcher
+plumbing: rendezvous, the barriers around the timed region, the broadcast of the RCCL unique id
+and the max-over-ranks of the elapsed time.
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector == FP64 matrix peak (= 157.3 TF FP32 vector / 2, MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def flops_per_eval(D, K):
+    """real fp64 FLOPs of one evaluation with K power steps."""
+    return K * (32 * D ** 3 + 4 * D ** 2) + 64 * D ** 3 + 128 * D ** 2
+
+
+def bytes_per_eval(D):
+    """algorithmic HBM bytes per evaluation (A in, E out)."""
+    return 32 * D * D + 8
+
+
+def haar_tensors(seed, D, B):
+    """Haar-random 2D x 2D unitaries qr(randn + i randn) (qmps/ansatze.py:30) -> A[b,s,i,j] = U[b,2i+s,j]."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((B, 2, D, D), dtype=np.complex128)
+    step = 8192
+    for lo in range(0, B, step):
+        n = min(step, B - lo)
+        Z = rng.standard_normal((n, 2 * D, 2 * D)) + 1j * rng.standard_normal((n, 2 * D, 2 * D))
+        Q, _ = np.linalg.qr(Z)
+        out[lo:lo + n] = Q[:, :, :D].reshape(n, D, 2, D).transpose(0, 2, 1, 3)
+    return out
+
+
+def tfim_h(g=1.0):
+    X = np.array([[0, 1], [1, 0]], dtype=complex)
+    Z = np.array([[1, 0], [0, -1]], dtype=complex)
+    I = np.eye(2, dtype=complex)
+    return -np.kron(Z, Z) + 0.5 * g * (np.kron(I, X) + np.kron(X, I))
+
+
+def cpu_baseline(D, A, h, max_iter, tol, budget_s=12.0):
+    """The oracle ("port") timed on this box's host cores, on a bounded sample of the same workload."""
+    from oracle import c_oracle as C
+    C.build()
+    # calibrate on a small slice, then size the sample for ~budget_s of single-thread work
+    n0 = min(len(A), 2048)
+    t = time.perf_counter()
+    C.energy_batch(A[:n0], h, max_iter=max_iter, tol=tol, threads=1)
+    rate = n0 / (time.perf_counter() - t)
+    n = int(min(len(A), max(n0, rate * budget_s)))
+    t = time.perf_counter()
+    C.energy_batch(A[:n], h, max_iter=max_iter, tol=tol, threads=1)
+    v1 = n / (time.perf_counter() - t)
+    cores = os.cpu_count() or 1
+    nthr = min(cores, C.max_threads())
+    t = time.perf_counter()
+    C.energy_batch(A, h, max_iter=max_iter, tol=tol, threads=nthr)
+    vall = len(A) / (time.perf_counter() - t)
+    return {'value': v1, 'unit': 'two-site energy evals/s', 'cores': 1, 'kind': 'port',
+            'sample': f'first {n} of the {len(A)} evaluations of the GPU workload, same seed, C oracle '
+                      f'(oracle/qmps_oracle.c: power iteration + closed-form energy), 1 thread',
+            'all_cores': {'value': vall, 'threads': nthr, 'host_cpus': cores,
+                          'sample': f'all {len(A)} evaluations, OpenMP'}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--D', type=int, default=4)
+    ap.add_argument('--batch', type=int, default=65536, help='evaluations per GPU per step')
+    ap.add_argument('--max-iter', type=int, default=10000)
+    ap.add_argument('--tol', type=float, default=1e-13)
+    ap.add_argument('--seed', type=int, default=20241022)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py: --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)')
+        sys.exit(f'bench.py: WORLD_SIZE={world} but --gpus {args.gpus}')
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # launcher plumbing only (gloo, CPU)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    from qmps_amd import EnergyEngine, _lib
+    D, B = args.D, args.batch
+    eng = EnergyEngine(D, B, device=local_rank)
+    info = _lib.device_info(local_rank)
+
+    # synthetic inputs: every rank draws its own shard (seed + rank), resident in HBM before timing
+    A = haar_tensors(args.seed + rank, D, B)
+    h = tfim_h(1.0)
+    eng.set_tensors(A)
+    eng.set_hamiltonian(h)
+
+    if world > 1:
+        ids = [EnergyEngine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        eng.comm_init(ids[0], rank, world)
+
+    def step():
+        eng.launch(B, max_iter=args.max_iter, tol=args.tol)
+        eng.cost_launch(B)
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            dist.barrier()
+        eng.sync()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    eng.timer_begin()
+    for _ in range(args.steps):
+        step()
+    ev_ms = eng.timer_end()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    cost = eng.get_cost()
+    E, iters, status = eng.results()
+    total_iters = int(iters.sum())
+    if dist is not None:
+        import torch
+        t = torch.tensor([float(total_iters), float((status != 0).sum())], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_iters_all, bad_all = t[0].item(), t[1].item()
+    else:
+        total_iters_all, bad_all = float(total_iters), float((status != 0).sum())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        # dominant kernel (energy_lane_kernel<D,true>): HIP events on the context stream over the timed region
+        kernel_ms = ev_ms / args.steps
+        flops = float(flops_per_eval(D, iters.astype(np.float64)).sum())
+        tflops = flops / (kernel_ms * 1e-3) * 1e-12
+        hbm_gbps = B * bytes_per_eval(D) / (kernel_ms * 1e-3) * 1e-9
+        out = {
+            'metric': 'two-site energy evals/sec at D=4, batch=65536' if (D, B) == (4, 65536)
+                      else f'two-site energy evals/sec at D={D}, batch={B}',
+            'value': value, 'unit': 'two-site energy evals/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64 (complex128)', 'data': 'synthetic',
+            'config': {'workload': f'TFIM g=1 two-site energy, D={D}, batch={B} per GPU, Haar-random state unitaries, '
+                                   f'in-kernel power-iteration environment solve (tol {args.tol:g}, cap {args.max_iter})',
+                       'baseline_config': 'BASELINE.json configs[2]', 'D': D, 'batch_per_gpu': B,
+                       'global_batch': world * B, 'tol': args.tol, 'max_iter': args.max_iter, 'seed': args.seed,
+                       'mean_power_iterations': total_iters_all / (world * B),
+                       'max_power_iterations_rank0': int(iters.max()), 'not_converged_or_not_pd': int(bad_all),
+                       'collective': 'none (N=1)' if world == 1 else 'one RCCL all-reduce(sum, f64[1]) per step',
+                       'device': info['name'], 'arch': info['arch']},
+            'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': tflops / FP64_PEAK_TFLOPS, 'traffic': None,
+                         'kernel': f'energy_lane_kernel<{D},true>' if D <= 4 else f'energy_block_kernel<{D},true>',
+                         'kernel_ms': kernel_ms,
+                         'note': 'FP64 FMA-bound kernel (v_fma_f64; MI355X FP64 vector peak == FP64 matrix peak = '
+                                 '78.6 TFLOP/s); algorithmic FLOPs = sum_b [K_b(32D^3+4D^2)+64D^3+128D^2] with the '
+                                 'per-evaluation iteration counts K_b read back from the device',
+                         'hbm': {'achieved': hbm_gbps, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                                 'frac': hbm_gbps / HBM_PEAK_GBPS, 'bytes_per_eval': bytes_per_eval(D)}},
+            'summed_cost': float(cost[0]),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(D, A, h, args.max_iter, args.tol)
+        elif not args.no_cpu_baseline:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        eng.comm_destroy()
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,150 @@
+/* qmps_hip.h - C-ABI of libqmps_hip.so: the MI355X (gfx950) implementation of qmps's classical
+ * inner loop (batched transfer-matrix contraction -> right-environment fixed point -> two-site
+ * energy).
+ *
+ * The reference (fergusfinn/qmps) has NO FFI/plugin layer: it is pure Python.  The de-facto
+ * boundary this library sits behind is the objective callable the optimisers hand to scipy /
+ * rotosolve (qmps/tools.py:242-264), whose body is
+ *
+ *     qmps/ground_state.py:150-168   SparseFullEnergyOptimizer.objective_function_exact_environment
+ *     qmps/ground_state.py:251-266   NonSparseFullEnergyOptimizer.objective_function
+ *     qmps/ground_state.py:299-331   NonSparseFullTwoSiteEnergyOptimizer.objective_function
+ *
+ * i.e. per evaluation: U -> A (qmps/tools.py:151-154), A -> r (qmps/tools.py:176-182, xmps
+ * TransferMatrix(A).eigs()), (A, r, h) -> E (qmps/represent.py:258-262 +
+ * qmps/ground_state.py:159-167).  Each entry point below cites the reference lines it replaces.
+ * The Python binding a maintainer would add is shown in INTEGRATION.md and shipped in
+ * qmps_amd/_lib.py (ctypes).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every complex array is interleaved (re, im) float64, in
+ *     numpy C order, so a `numpy.complex128` array can be passed as-is;
+ *   - the caller owns every host buffer; the library copies in/out and retains nothing;
+ *   - every function returns 0 on success or a negative QMPS_ERR_* code; qmps_last_error()
+ *     returns a thread-local description of the last failure.  Nothing throws across the ABI;
+ *   - per-evaluation numerical outcomes are reported in `status` (QMPS_STATUS_*), never as a
+ *     function error;
+ *   - a context owns one device, one HIP stream and its HBM buffers.  NOT thread-safe per
+ *     context; use one context per thread/device.  Launch functions are asynchronous on the
+ *     context's stream; qmps_sync() or any qmps_get_* call waits for them;
+ *   - there is NO CPU fallback: without a usable gfx950 device qmps_create() fails.
+ */
+#ifndef QMPS_HIP_H
+#define QMPS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QMPS_ABI_VERSION 1
+
+/* error codes */
+#define QMPS_OK 0
+#define QMPS_ERR_ARG (-1)       /* bad argument (null pointer, size out of range, ...) */
+#define QMPS_ERR_HIP (-2)       /* HIP runtime error (message in qmps_last_error()) */
+#define QMPS_ERR_NO_DEVICE (-3) /* no usable gfx950 device */
+#define QMPS_ERR_STATE (-4)     /* call order violated (e.g. launch before states were set) */
+#define QMPS_ERR_RCCL (-5)      /* RCCL error */
+
+/* per-evaluation status (status_out) */
+#define QMPS_STATUS_OK 0            /* converged, r positive definite */
+#define QMPS_STATUS_NOT_CONVERGED 1 /* power iteration hit max_iter */
+#define QMPS_STATUS_NOT_PD 2        /* Cholesky of r fails: the reference's LinAlgError branch
+                                       (qmps/ground_state.py:153-157) */
+
+/* input kinds for qmps_energy_batch / qmps_env_batch */
+#define QMPS_INPUT_TENSOR 0  /* A[B][2][D][D]  complex128 - state tensors            */
+#define QMPS_INPUT_UNITARY 1 /* U[B][2D][2D]   complex128 - state unitaries; the     */
+                             /* library applies unitary_to_tensor (tools.py:151-154)  */
+
+/* environment solver selection (flags of qmps_energy_launch) */
+#define QMPS_ENV_POWER 0 /* normalised power iteration (default; `krylov`, PowerCircuit) */
+
+typedef struct qmps_ctx qmps_ctx;
+
+/* ---- library / device ------------------------------------------------------------------ */
+int qmps_abi_version(void);
+const char* qmps_last_error(void);
+/* number of visible HIP devices (0 and QMPS_OK when there are none / no driver) */
+int qmps_device_count(int* count);
+/* name / arch / CU count / HBM bytes of a device; name buffers are caller-owned */
+int qmps_device_info(int device, char* name, int name_len, char* arch, int arch_len, int* compute_units,
+                     int64_t* hbm_bytes);
+
+/* ---- context --------------------------------------------------------------------------- */
+/* D in {2,4,8,16}; max_batch = capacity of the HBM buffers (evaluations per launch). */
+int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out);
+int qmps_destroy(qmps_ctx* ctx);
+int qmps_sync(qmps_ctx* ctx);
+
+/* ---- inputs (host -> HBM, asynchronous on the context stream) --------------------------- */
+/* replaces qmps/tools.py:151-154 (unitary_to_tensor) when kind == QMPS_INPUT_UNITARY */
+int qmps_set_states(qmps_ctx* ctx, int64_t B, const double* states, int kind);
+/* h[n_terms][4][4] complex128, row/col index = 2*s1+s2, s1 = left site
+ * (qmps/ground_state.py:82-88 Hamiltonian.to_matrix).  1 <= n_terms <= 16. */
+int qmps_set_hamiltonian(qmps_ctx* ctx, int n_terms, const double* h);
+/* optional warm start r0[B][D][D] complex128 (Hermitian, any positive trace); NULL = identity/D */
+int qmps_set_env_guess(qmps_ctx* ctx, int64_t B, const double* r0);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+/* One pass over the resident batch: power-iteration right environment + two-site energy for
+ * each of the n_terms Hamiltonians.  Replaces qmps/tools.py:176-182 (get_env_exact) +
+ * qmps/tools.py:97-108 (environment_to_unitary - dropped, only column 0 of V is ever used) +
+ * qmps/represent.py:258-262 (State) + qmps/ground_state.py:159-167 (psi^+ H psi).
+ * tol: stop when ||r' - r||_F < tol;  max_iter >= 1;  flags: QMPS_ENV_*.  Asynchronous. */
+int qmps_energy_launch(qmps_ctx* ctx, int64_t B, int max_iter, double tol, int flags);
+/* Energy only, from the resident states and the resident environments (no solve): the
+ * contraction chain A-Abar-h-A-Abar of the north star.  Asynchronous. */
+int qmps_energy_only_launch(qmps_ctx* ctx, int64_t B);
+/* sum_b E[b][t] -> cost[t] on the device (one block-reduction kernel), copied to the host.
+ * This is what rotosolve's M(x) = np.sum(eps(...)) consumes (qmps/tools.py:432-433). */
+int qmps_sum_energies(qmps_ctx* ctx, int64_t B, double* cost /* [n_terms] */);
+
+/* ---- outputs (HBM -> host; each waits for outstanding launches) ------------------------- */
+int qmps_get_energies(qmps_ctx* ctx, int64_t B, double* E /* [B][n_terms] */, int32_t* iters /* [B] or NULL */,
+                      int32_t* status /* [B] or NULL */);
+/* r[B][D][D] complex128, Hermitian, tr r = 1 (the dominant right eigen-matrix returned by
+ * xmps TransferMatrix(A).eigs() at qmps/tools.py:181, up to its normalisation) */
+int qmps_get_env(qmps_ctx* ctx, int64_t B, double* r);
+/* two-site reduced density matrix rho[B][4][4] complex128: rho[t][s] = tr(B_t r B_s^+)/tr r */
+int qmps_get_rdm(qmps_ctx* ctx, int64_t B, double* rho);
+
+/* ---- one-shot host-buffer convenience (SURVEY 8(b) energy_batch / env_batch) ------------ */
+int qmps_energy_batch(qmps_ctx* ctx, int64_t B, const double* states, int kind, const double* h, int n_terms,
+                      const double* r0 /* nullable */, int max_iter, double tol, double* E_out, int32_t* iters_out,
+                      int32_t* status_out);
+int qmps_env_batch(qmps_ctx* ctx, int64_t B, const double* states, int kind, const double* r0 /* nullable */,
+                   int max_iter, double tol, double* r_out, int32_t* iters_out, int32_t* status_out);
+
+/* ---- timing on the context stream (HIP events) ------------------------------------------ */
+int qmps_timer_begin(qmps_ctx* ctx);
+int qmps_timer_end(qmps_ctx* ctx, float* milliseconds); /* waits for the end event */
+
+/* ---- multi-GPU: one process per GPU, one RCCL all-reduce of the summed cost over xGMI ---- */
+#define QMPS_UNIQUE_ID_BYTES 128
+int qmps_comm_unique_id(char id[QMPS_UNIQUE_ID_BYTES]); /* rank 0 creates, host code broadcasts */
+int qmps_comm_init(qmps_ctx* ctx, const char id[QMPS_UNIQUE_ID_BYTES], int rank, int nranks);
+int qmps_comm_destroy(qmps_ctx* ctx);
+/* in-place sum over ranks of a small float64 vector held on the host (staged through HBM) */
+int qmps_allreduce_sum(qmps_ctx* ctx, double* inout, int n);
+/* Asynchronous on the context stream: device-side cost[t] = sum_b E[b][t], followed - when a
+ * communicator exists - by ONE ncclAllReduce(sum, double, n_terms) over all ranks.  This is the
+ * path's single exchange step (the summed cost of rotosolve's M(x), qmps/tools.py:432-433). */
+int qmps_cost_launch(qmps_ctx* ctx, int64_t B);
+/* waits for the stream and copies the (all-reduced) cost[n_terms] to the host */
+int qmps_get_cost(qmps_ctx* ctx, double* cost /* [n_terms] */);
+/* qmps_cost_launch + qmps_get_cost; requires a communicator */
+int qmps_allreduce_cost(qmps_ctx* ctx, int64_t B, double* cost /* [n_terms] */);
+
+/* ---- diagnostics ----------------------------------------------------------------------- */
+/* FP64 FMA micro-benchmark (register-resident v_fma_f64 loop on every CU): achieved TFLOP/s */
+int qmps_probe_fp64_peak(qmps_ctx* ctx, double* tflops);
+/* HBM streaming copy micro-benchmark: achieved GB/s (read + write bytes) */
+int qmps_probe_hbm_peak(qmps_ctx* ctx, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QMPS_HIP_H */

@@ -1,0 +1,393 @@
+"""CPU oracle (numpy, fp64) for the qmps two-site-energy hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file restates, in plain numpy, the algorithm the
+reference (fergusfinn/qmps, mounted read-only at /root/reference when the
+fixtures were generated) uses on the path
+
+    params -> U (2D x 2D) -> A (2,D,D) -> right environment r -> two-site energy
+
+Every function cites the reference file:line it follows.  The arithmetic of
+the reference's own path lives in two third-party packages that are NOT vendored
+and NOT pinned by the reference (``xmps`` - github.com/fergusbarratt/xmps - and
+``cirq`` ~0.5-0.8; neither is in setup.py:11-16): their published algorithms
+(dominant eigenpair of the transfer matrix; big-endian state-vector simulation)
+are restated here.
+
+PARITY PINNING.  The pure-numpy reference functions that CAN be imported
+(``unitary_to_tensor``, ``tensor_to_unitary``, ``environment_to_unitary``,
+``merge``, ``Hamiltonian.to_matrix``) were run in the build container and their
+outputs are committed under tests/golden/ (generator: tests/golden/make_golden.py);
+this oracle is checked against them and against the reference's known answers
+(TFIM 4x4 KAT tests/test_ground_state.py:26-38, E0(g) integral :101-102,
+D2_gse scripts/noisy_optimization.py:93, fixtures/A.npy).  The numeric value
+E(params) itself is asserted by NO reference test ("parity unpinned" by the
+reference): it is pinned here by two independent restatements that must agree
+to <=1e-13 - the state-vector path (`energy_statevector`, same register layout
+and operator as qmps/ground_state.py:159-167) and the closed-form trace path
+(`energy_closed_form`).
+"""
+from functools import reduce
+
+import numpy as np
+from scipy.linalg import cholesky, null_space
+
+# ----------------------------------------------------------------------------
+# a-1  Hamiltonian  (qmps/ground_state.py:29-30, 73-88)
+# ----------------------------------------------------------------------------
+I2 = np.eye(2, dtype=complex)
+SX = np.array([[0, 1], [1, 0]], dtype=complex)
+SY = np.array([[0, -1j], [1j, 0]], dtype=complex)
+SZ = np.array([[1, 0], [0, -1]], dtype=complex)
+PAULI = {'I': I2, 'X': SX, 'Y': SY, 'Z': SZ}
+
+
+def hamiltonian_strings(strings):
+    """Single-letter term 'X': g -> 'IX': g/2, 'XI': g/2 (ground_state.py:73-80)."""
+    out = {}
+    for key, val in strings.items():
+        if len(key) == 1:
+            out['I' + key] = out.get('I' + key, 0) + val / 2
+            out[key + 'I'] = out.get(key + 'I', 0) + val / 2
+        else:
+            out[key] = out.get(key, 0) + val
+    return out
+
+
+def hamiltonian_matrix(strings):
+    """h = sum_J J * kron(S[a], S[b])  (ground_state.py:82-88)."""
+    h = np.zeros((4, 4), dtype=complex)
+    for js, J in hamiltonian_strings(strings).items():
+        h += J * reduce(np.kron, [PAULI[j] for j in js])
+    return h
+
+
+def tfim_exact_energy(g, n=200001):
+    """E0(g) = int_0^pi -2 sqrt(1+g^2-2g cos k)/(2 pi) dk (tests/test_ground_state.py:101-102)."""
+    k = np.linspace(0.0, np.pi, n)
+    f = -2 * np.sqrt(1 + g * g - 2 * g * np.cos(k)) / np.pi / 2
+    dk = k[1] - k[0]
+    return float((f[0] + f[-1] + 4 * f[1:-1:2].sum() + 2 * f[2:-1:2].sum()) * dk / 3)
+
+
+# ----------------------------------------------------------------------------
+# a-2  gate matrices and ansatz -> unitary  (qmps/represent.py:268-423;
+#      conventions: SURVEY App. A, new_tdvp/unitary_param.py:14-27,
+#      scripts/ground_state_finding.py:74-81).  Big-endian: qubit 0 = MSB.
+# ----------------------------------------------------------------------------
+def rx(t):
+    c, s = np.cos(t / 2), np.sin(t / 2)
+    return np.array([[c, -1j * s], [-1j * s, c]])
+
+
+def ry(t):
+    c, s = np.cos(t / 2), np.sin(t / 2)
+    return np.array([[c, -s], [s, c]], dtype=complex)
+
+
+def rz(t):
+    return np.array([[np.exp(-0.5j * t), 0], [0, np.exp(0.5j * t)]])
+
+
+HAD = np.array([[1, 1], [1, -1]], dtype=complex) / np.sqrt(2)
+
+
+def xpow(t):
+    """cirq.X**t = e^{i pi t/2} (cos(pi t/2) 1 - i sin(pi t/2) X)."""
+    c, s = np.cos(np.pi * t / 2), np.sin(np.pi * t / 2)
+    return np.exp(0.5j * np.pi * t) * np.array([[c, -1j * s], [-1j * s, c]])
+
+
+def _on(n, gate, qubits):
+    """Embed a k-qubit gate on the given (ordered) qubits of an n-qubit big-endian register."""
+    k = len(qubits)
+    g = np.asarray(gate, dtype=complex).reshape((2,) * (2 * k))
+    full = np.eye(2 ** n, dtype=complex).reshape((2,) * (2 * n))
+    # contract gate input legs with the register's output legs `qubits`
+    out = np.tensordot(g, full, axes=(list(range(k, 2 * k)), list(qubits)))
+    # result axes: gate outputs (k) + remaining register legs in order; move back
+    out = np.moveaxis(out, list(range(k)), list(qubits))
+    return out.reshape(2 ** n, 2 ** n)
+
+
+CNOT = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=complex)
+SWAP = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=complex)
+
+
+def zzpow(t):
+    e = np.exp(1j * np.pi * t)
+    return np.diag([1, e, e, 1]).astype(complex)
+
+
+def circuit_unitary(n, ops):
+    """ops: list of (matrix, qubits) applied in order (first op acts first)."""
+    U = np.eye(2 ** n, dtype=complex)
+    for g, qs in ops:
+        U = _on(n, g, qs) @ U
+    return U
+
+
+def shallow_cnot_unitary(D, params):
+    """ShallowCNOTStateTensor (represent.py:288-310): per (beta, gamma): rz(beta) on all,
+    rx(gamma) on all, H(q0), CNOT(q[n-2],q[n-1]) ... CNOT(q0,q1) (reversed list)."""
+    n = int(np.log2(D)) + 1
+    ops = []
+    p = list(params)
+    for b, g in [p[i:i + 2] for i in range(0, len(p), 2)]:
+        ops += [(rz(b), [q]) for q in range(n)]
+        ops += [(rx(g), [q]) for q in range(n)]
+        ops += [(HAD, [0])]
+        ops += [(CNOT, [i, i + 1]) for i in reversed(range(n - 1))]
+    return circuit_unitary(n, ops)
+
+
+def shallow_qaoa_unitary(D, params):
+    """ShallowQAOAStateTensor (represent.py:268-285): X**beta on all, ZZ**gamma on neighbours."""
+    n = int(np.log2(D)) + 1
+    ops = []
+    p = list(params)
+    for b, g in [p[i:i + 2] for i in range(0, len(p), 2)]:
+        ops += [(xpow(b), [q]) for q in range(n)]
+        ops += [(zzpow(g), [i, i + 1]) for i in range(n - 1)]
+    return circuit_unitary(n, ops)
+
+
+def shallow_full_unitary(v):
+    """ShallowFullStateTensor(2, v[15]) - the 18-gate list at represent.py:393-401."""
+    v = list(v)
+    ops = [(rz(v[0]), [0]), (rx(v[1]), [0]), (rz(v[2]), [0]),
+           (rz(v[3]), [1]), (rx(v[4]), [1]), (rz(v[5]), [1]),
+           (CNOT, [0, 1]),
+           (ry(v[6]), [0]),
+           (CNOT, [1, 0]),
+           (ry(v[7]), [0]), (rz(v[8]), [1]),
+           (CNOT, [0, 1]),
+           (rz(v[9]), [0]), (rx(v[10]), [0]), (rz(v[11]), [0]),
+           (rz(v[12]), [1]), (rx(v[13]), [1]), (rz(v[14]), [1])]
+    return circuit_unitary(2, ops)
+
+
+def haar_unitaries(rng, n, B):
+    """qr(randn + i randn)[0]  (qmps/ansatze.py:30) - the synthetic benchmark input."""
+    Z = rng.standard_normal((B, n, n)) + 1j * rng.standard_normal((B, n, n))
+    Q, _ = np.linalg.qr(Z)
+    return Q
+
+
+# ----------------------------------------------------------------------------
+# a-3 / a-5  tensor <-> unitary embeddings (qmps/tools.py:76-154)
+# ----------------------------------------------------------------------------
+def unitary_to_tensor(U):
+    """A[s,i,j] = U[2i+s, j], j < D  (tools.py:151-154)."""
+    U = np.asarray(U)
+    D = U.shape[-1] // 2
+    A = U[..., :, :D].reshape(U.shape[:-2] + (D, 2, D))
+    return np.swapaxes(A, -3, -2)
+
+
+def tensor_to_unitary(A):
+    """iso = A.transpose(1,0,2).reshape(2D, D); U = [iso | null_space(iso^dagger)] (tools.py:123-129, 76-94)."""
+    d, D, _ = A.shape
+    iso = A.transpose(1, 0, 2).reshape(d * D, D)
+    N2 = null_space(iso.conj().T)
+    return np.concatenate([iso, N2], axis=1)
+
+
+def environment_to_unitary(v):
+    """vec(v)/||v|| as first column, null-space completion (tools.py:97-108)."""
+    v = np.asarray(v).reshape(1, -1) / np.linalg.norm(v)
+    vs = null_space(v).conj().T
+    return np.concatenate([v, vs], 0).T
+
+
+def merge(A, B):
+    """merge(A,B)[2 s1 + s2] = A[s1] @ B[s2]  (time_evolve_tools.py:20-23), any D."""
+    D = A.shape[1]
+    return np.einsum('sij,tjk->stik', A, B).reshape(A.shape[0] * B.shape[0], D, D)
+
+
+# ----------------------------------------------------------------------------
+# a-4  right environment (tools.py:176-182 -> xmps TransferMatrix(A).eigs(), external)
+#      convention E[(i,i'),(j,j')] = sum_s A[s,i,j] conj(A[s,i',j'])
+#      (new_tdvp/EnvironmentParamSensitivity.py:37-38)
+# ----------------------------------------------------------------------------
+def transfer_matrix(A, B=None):
+    B = A if B is None else B
+    D = A.shape[1]
+    return np.einsum('sij,skl->ikjl', A, B.conj()).reshape(D * D, D * D)
+
+
+def apply_transfer(A, r):
+    """r -> sum_s A_s r A_s^dagger."""
+    return np.einsum('sij,jk,slk->il', A, r, A.conj())
+
+
+def env_dense_eig(A):
+    """Dominant right eigen-matrix of the transfer map by dense eig (what xmps .eigs() returns,
+    up to normalisation).  Returned Hermitian with tr r = 1."""
+    D = A.shape[1]
+    w, v = np.linalg.eig(transfer_matrix(A))
+    k = int(np.argmax(np.abs(w)))
+    r = v[:, k].reshape(D, D)
+    r = r / np.trace(r)
+    r = (r + r.conj().T) / 2
+    return w[k], r
+
+
+def env_power_iteration(A, r0=None, tol=1e-13, max_iter=10000):
+    """Normalised power iteration v <- Av/||Av|| (`krylov`, Power Method.ipynb cells 5-6; the
+    classical statement of PowerCircuit represent.py:235-248) on the transfer map, trace
+    normalised.  This is the algorithm the HIP kernel implements:
+
+        r_0 = 1/D (or r0);  r' = herm(sum_s A_s r A_s^dagger);  r' /= tr r';
+        stop when ||r' - r||_F^2 < tol^2.
+
+    Returns (r, iterations, status) with status 0 = converged, 1 = not converged."""
+    D = A.shape[1]
+    r = np.eye(D, dtype=complex) / D if r0 is None else np.array(r0, dtype=complex)
+    for k in range(1, max_iter + 1):
+        rn = apply_transfer(A, r)
+        rn = (rn + rn.conj().T) / 2
+        rn = rn / np.trace(rn).real
+        d2 = float((np.abs(rn - r) ** 2).sum())
+        r = rn
+        if d2 < tol * tol:
+            return r, k, 0
+    return r, max_iter, 1
+
+
+def env_cholesky(r):
+    """L = cholesky(r)^dagger lower triangular, r = L L^dagger (tools.py:181-182).
+    Raises numpy.linalg.LinAlgError if r is not positive definite (ground_state.py:155)."""
+    return cholesky(r).conj().T
+
+
+def get_env_exact(U):
+    """tools.py:176-182: V = environment_to_unitary(cholesky(r)^dagger)."""
+    _, r = env_dense_eig(unitary_to_tensor(U))
+    return environment_to_unitary(env_cholesky(r))
+
+
+# ----------------------------------------------------------------------------
+# a-6  State + energy
+# ----------------------------------------------------------------------------
+def state_vector(U, V, n_phys=2):
+    """|psi> of State(U, V, n)(qubits) on n_phys + 2 log2 D qubits, all starting in |0>:
+    V on qubits[n:], then U on qubits[i:i+nu] for i = n-1 .. 0 (represent.py:258-262);
+    equivalently (U x 1 x 1)(1 x U x 1)(1 x 1 x V)|0..0> (scripts/ground_state_finding.py:119-122)."""
+    nu = int(np.log2(U.shape[0]))
+    nv = int(np.log2(V.shape[0]))
+    n = n_phys + nv
+    psi = np.zeros(2 ** n, dtype=complex)
+    psi[0] = 1
+    psi = _on(n, V, list(range(n_phys, n_phys + nv))) @ psi
+    for i in reversed(range(n_phys)):
+        psi = _on(n, U, list(range(i, i + nu))) @ psi
+    return psi
+
+
+def energy_statevector(U, h, V=None):
+    """real(psi^dagger kron(eye(D), h, eye(D)) psi)  (ground_state.py:159-167)."""
+    D = U.shape[0] // 2
+    V = get_env_exact(U) if V is None else V
+    psi = state_vector(U, V, 2)
+    H = np.kron(np.kron(np.eye(D), h), np.eye(D))
+    return float(np.real(psi.conj() @ H @ psi))
+
+
+def two_site_rdm(A, r):
+    """rho[tau, sigma] = tr(B_tau r B_sigma^dagger)/tr r with B_{2 s1+s2} = A_{s1} A_{s2}."""
+    B = merge(A, A)
+    Br = np.einsum('tij,jk->tik', B, r)
+    rho = np.einsum('tik,sik->ts', Br, B.conj())
+    return rho / np.trace(r).real
+
+
+def energy_closed_form(A, h, r=None):
+    """E = Re sum_{sigma,tau} h[sigma,tau] tr(B_tau r B_sigma^dagger)/tr r  (SURVEY 8a-6, App. A)."""
+    if r is None:
+        _, r = env_dense_eig(A)
+    rho = two_site_rdm(A, r)
+    return float(np.real(np.einsum('st,ts->', h, rho)))
+
+
+def energy_power(A, h, r0=None, tol=1e-13, max_iter=10000):
+    """Exactly what one GPU lane computes: power-iteration environment + closed form.
+    Returns (E, iterations, status); status 2 if r is not positive definite."""
+    r, it, status = env_power_iteration(A, r0, tol, max_iter)
+    E = energy_closed_form(A, h, r)
+    if status == 0:
+        try:
+            env_cholesky(r)
+        except np.linalg.LinAlgError:
+            status = 2
+    return E, it, status
+
+
+def reference_structured_energy(U, h):
+    """The reference's per-evaluation algorithmic structure, step for step:
+    dense eig of the D^2 x D^2 transfer matrix -> Cholesky -> null-space completion to a
+    D^2 x D^2 unitary -> Kronecker state vector -> dense psi^dagger (1 x h x 1) psi."""
+    return energy_statevector(U, h, get_env_exact(U))
+
+
+# ----------------------------------------------------------------------------
+# a-9  two-site unit cell (ground_state.py:291-331)
+# ----------------------------------------------------------------------------
+def two_site_cell_energy(U1, U2, h):
+    A1, A2 = unitary_to_tensor(U1), unitary_to_tensor(U2)
+
+    def env(Ua, Ub):
+        _, r = env_dense_eig(merge(unitary_to_tensor(Ua), unitary_to_tensor(Ub)))
+        return environment_to_unitary(env_cholesky(r))
+
+    def chain_energy(Uleft, Uright, V):
+        n = 4
+        psi = np.zeros(16, dtype=complex)
+        psi[0] = 1
+        psi = _on(n, V, [2, 3]) @ psi
+        psi = _on(n, Uright, [1, 2]) @ psi
+        psi = _on(n, Uleft, [0, 1]) @ psi
+        H = np.kron(np.kron(np.eye(2), h), np.eye(2))
+        return float(np.real(psi.conj() @ H @ psi))
+
+    E1 = chain_energy(U1, U2, env(U1, U2))
+    E2 = chain_energy(U2, U1, env(U2, U1))
+    return (E1 + E2) / 2
+
+
+def two_site_cell_energy_closed(A1, A2, h, r12=None, r21=None):
+    """Closed form of the same: E1 = sum h[s,t] tr(A1_t1 A2_t2 r12 A2_s2^+ A1_s1^+)/tr r12, E2 likewise."""
+    def half(Aa, Ab, r):
+        if r is None:
+            _, r = env_dense_eig(merge(Aa, Ab))
+        B = merge(Aa, Ab)
+        Br = np.einsum('tij,jk->tik', B, r)
+        rho = np.einsum('tik,sik->ts', Br, B.conj()) / np.trace(r).real
+        return float(np.real(np.einsum('st,ts->', h, rho)))
+    return 0.5 * (half(A1, A2, r12) + half(A2, A1, r21))
+
+
+# ----------------------------------------------------------------------------
+# a-10  rotosolve callers (tools.py:422-457, rotosolve.py:154-181)
+# ----------------------------------------------------------------------------
+ROTO_SHIFTS = (0.0, np.pi, np.pi / 2, -np.pi / 2, np.pi / 4, -np.pi / 4)
+
+
+def double_rotosolve_update(M0, Mpi, Mp2, Mm2, Mp4, Mm4):
+    """Sinusoid fit + argmin of tools.py:434-452; returns the wrapped shift to add to params[i]."""
+    from scipy.optimize import minimize_scalar
+    A, Bv = (M0 + Mpi), (M0 - Mpi)
+    C, Dv = (Mp2 + Mm2), (Mp2 - Mm2)
+    E = (Mp4 - Mm4)
+    a, b, c, d = 0.25 * (2 * E - np.sqrt(2) * Dv), 0.25 * (A - C), 0.5 * Dv, 0.5 * Bv
+    P, u = np.sqrt(a * a + b * b), np.arctan2(b, a)
+    Q, v = np.sqrt(c * c + d * d), np.arctan2(d, c)
+    th = minimize_scalar(lambda x: P * np.sin(2 * x + u) + Q * np.sin(x + v),
+                         bounds=[-np.pi, np.pi]).x
+    return float(np.arctan2(np.sin(th), np.cos(th)))
+
+
+def rotosolve_update(e0, ep, em):
+    """rotosolve.py:175-177."""
+    th = -np.pi / 2 - np.arctan2(2 * e0 - ep - em, ep - em)
+    return float(np.arctan2(np.sin(th), np.cos(th)))

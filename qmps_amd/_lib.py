@@ -1,0 +1,105 @@
+"""ctypes binding of libqmps_hip.so (C-ABI: include/qmps_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no gfx950 device is usable the
+product path raises.  Loading the library itself needs no GPU (the `-m "not gpu"` tests check
+that every symbol of include/qmps_hip.h is exported); only `qmps_create` touches the device.
+"""
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libqmps_hip.so')
+
+QMPS_OK = 0
+QMPS_ERR_ARG, QMPS_ERR_HIP, QMPS_ERR_NO_DEVICE, QMPS_ERR_STATE, QMPS_ERR_RCCL = -1, -2, -3, -4, -5
+STATUS_OK, STATUS_NOT_CONVERGED, STATUS_NOT_PD = 0, 1, 2
+INPUT_TENSOR, INPUT_UNITARY = 0, 1
+ENV_POWER = 0
+UNIQUE_ID_BYTES = 128
+
+_dp = POINTER(c_double)
+_ip = POINTER(c_int32)
+
+# name -> (restype, argtypes): every entry point declared in include/qmps_hip.h
+SIGNATURES = {
+    'qmps_abi_version': (c_int, []),
+    'qmps_last_error': (c_char_p, []),
+    'qmps_device_count': (c_int, [POINTER(c_int)]),
+    'qmps_device_info': (c_int, [c_int, c_char_p, c_int, c_char_p, c_int, POINTER(c_int), POINTER(c_int64)]),
+    'qmps_create': (c_int, [c_int, c_int, c_int64, POINTER(c_void_p)]),
+    'qmps_destroy': (c_int, [c_void_p]),
+    'qmps_sync': (c_int, [c_void_p]),
+    'qmps_set_states': (c_int, [c_void_p, c_int64, _dp, c_int]),
+    'qmps_set_hamiltonian': (c_int, [c_void_p, c_int, _dp]),
+    'qmps_set_env_guess': (c_int, [c_void_p, c_int64, _dp]),
+    'qmps_energy_launch': (c_int, [c_void_p, c_int64, c_int, c_double, c_int]),
+    'qmps_energy_only_launch': (c_int, [c_void_p, c_int64]),
+    'qmps_sum_energies': (c_int, [c_void_p, c_int64, _dp]),
+    'qmps_get_energies': (c_int, [c_void_p, c_int64, _dp, _ip, _ip]),
+    'qmps_get_env': (c_int, [c_void_p, c_int64, _dp]),
+    'qmps_get_rdm': (c_int, [c_void_p, c_int64, _dp]),
+    'qmps_energy_batch': (c_int, [c_void_p, c_int64, _dp, c_int, _dp, c_int, _dp, c_int, c_double, _dp, _ip, _ip]),
+    'qmps_env_batch': (c_int, [c_void_p, c_int64, _dp, c_int, _dp, c_int, c_double, _dp, _ip, _ip]),
+    'qmps_timer_begin': (c_int, [c_void_p]),
+    'qmps_timer_end': (c_int, [c_void_p, POINTER(c_float)]),
+    'qmps_comm_unique_id': (c_int, [c_char_p]),
+    'qmps_comm_init': (c_int, [c_void_p, c_char_p, c_int, c_int]),
+    'qmps_comm_destroy': (c_int, [c_void_p]),
+    'qmps_allreduce_sum': (c_int, [c_void_p, _dp, c_int]),
+    'qmps_cost_launch': (c_int, [c_void_p, c_int64]),
+    'qmps_get_cost': (c_int, [c_void_p, _dp]),
+    'qmps_allreduce_cost': (c_int, [c_void_p, c_int64, _dp]),
+    'qmps_probe_fp64_peak': (c_int, [c_void_p, _dp]),
+    'qmps_probe_hbm_peak': (c_int, [c_void_p, _dp]),
+}
+
+
+class QmpsError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f'libqmps_hip error {code}: {message}')
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libqmps_hip.so and bind every symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} not found: build it with `make -C qmps_amd/csrc` (or __graft_entry__.build()). '
+            'qmps_amd has no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.qmps_abi_version() != 1:
+        raise ImportError('libqmps_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != QMPS_OK:
+        raise QmpsError(rc, load().qmps_last_error().decode('utf-8', 'replace'))
+
+
+def device_count():
+    n = c_int(0)
+    check(load().qmps_device_count(byref(n)))
+    return n.value
+
+
+def device_info(device=0):
+    name = ctypes.create_string_buffer(256)
+    arch = ctypes.create_string_buffer(64)
+    cus = c_int(0)
+    hbm = c_int64(0)
+    check(load().qmps_device_info(device, name, 256, arch, 64, byref(cus), byref(hbm)))
+    return {'name': name.value.decode(), 'arch': arch.value.decode(), 'compute_units': cus.value,
+            'hbm_bytes': hbm.value}

@@ -1,0 +1,513 @@
+// qmps_capi.hip - the C-ABI of libqmps_hip.so (declared in include/qmps_hip.h).
+// Host-side runtime: context = one device + one HIP stream + HBM buffers; asynchronous launches;
+// pinned staging for small results; native RCCL communicator for the summed-cost all-reduce.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "qmps_hip.h"
+#include "qmps_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(QMPS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+#define RCCL_TRY(expr)                                                                               \
+  do {                                                                                               \
+    ncclResult_t r_ = (expr);                                                                        \
+    if (r_ != ncclSuccess) return fail(QMPS_ERR_RCCL, "%s failed: %s", #expr, ncclGetErrorString(r_)); \
+  } while (0)
+
+constexpr int kMaxTerms = 16;
+constexpr int kSumBlocks = 256;
+
+}  // namespace
+
+struct qmps_ctx {
+  int device = -1;
+  int D = 0;
+  int64_t max_batch = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // HBM
+  void* d_A = nullptr;       // [max_batch][2][D][D] c128
+  void* d_U = nullptr;       // [max_batch][2D][2D] c128 (lazy)
+  void* d_h = nullptr;       // [16][4][4] c128
+  void* d_r = nullptr;       // [max_batch][D][D] c128
+  void* d_rho = nullptr;     // [max_batch][4][4] c128 (lazy)
+  double* d_E = nullptr;     // [max_batch][n_terms]
+  int64_t E_capacity = 0;    // in doubles
+  int32_t* d_iters = nullptr;
+  int32_t* d_status = nullptr;
+  double* d_partial = nullptr;  // [16][kSumBlocks]
+  double* d_cost = nullptr;     // [16]
+  double* h_cost = nullptr;     // pinned [16]
+  // state
+  int n_terms = 0;
+  int64_t n_states = 0;
+  bool have_guess = false;
+  bool have_env = false;
+  bool want_rho = false;
+  // RCCL
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+};
+
+namespace {
+
+int bind(qmps_ctx* c) {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  return QMPS_OK;
+}
+
+size_t tensor_bytes(const qmps_ctx* c) { return (size_t)32 * c->D * c->D; }
+size_t env_bytes(const qmps_ctx* c) { return (size_t)16 * c->D * c->D; }
+
+int ensure_E(qmps_ctx* c, int n_terms) {
+  const int64_t need = c->max_batch * n_terms;
+  if (need > c->E_capacity) {
+    if (c->d_E) HIP_TRY(hipFree(c->d_E));
+    c->d_E = nullptr;
+    HIP_TRY(hipMalloc((void**)&c->d_E, (size_t)need * sizeof(double)));
+    c->E_capacity = need;
+  }
+  return QMPS_OK;
+}
+
+int check_B(const qmps_ctx* c, int64_t B) {
+  if (B < 0 || B > c->max_batch) return fail(QMPS_ERR_ARG, "B=%lld outside [0, max_batch=%lld]", (long long)B, (long long)c->max_batch);
+  return QMPS_OK;
+}
+
+qmps::LaneArgs make_args(qmps_ctx* c, int64_t B, int max_iter, double tol, bool solve) {
+  qmps::LaneArgs a;
+  a.A = c->d_A;
+  a.h = c->d_h;
+  a.r_in = solve ? (c->have_guess ? c->d_r : nullptr) : c->d_r;
+  a.r_out = solve ? c->d_r : nullptr;
+  a.rho_out = c->want_rho ? c->d_rho : nullptr;
+  a.E = c->d_E;
+  a.iters = c->d_iters;
+  a.status = c->d_status;
+  a.B = B;
+  a.n_terms = c->n_terms;
+  a.max_iter = max_iter;
+  a.tol = tol;
+  return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qmps_abi_version(void) { return QMPS_ABI_VERSION; }
+
+const char* qmps_last_error(void) { return g_err; }
+
+int qmps_device_count(int* count) {
+  if (!count) return fail(QMPS_ERR_ARG, "null count");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count = n;
+  return QMPS_OK;
+}
+
+int qmps_device_info(int device, char* name, int name_len, char* arch, int arch_len, int* compute_units,
+                     int64_t* hbm_bytes) {
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (name && name_len > 0) snprintf(name, name_len, "%s", prop.name);
+  if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", prop.gcnArchName);
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  return QMPS_OK;
+}
+
+int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
+  if (!out) return fail(QMPS_ERR_ARG, "null out");
+  *out = nullptr;
+  if (D != 2 && D != 4 && D != 8 && D != 16) return fail(QMPS_ERR_ARG, "bond dimension D=%d not in {2,4,8,16}", D);
+  if (max_batch < 1) return fail(QMPS_ERR_ARG, "max_batch must be >= 1");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
+    (void)hipGetLastError();
+    return fail(QMPS_ERR_NO_DEVICE, "no HIP device visible: libqmps_hip has no CPU fallback");
+  }
+  if (device < 0 || device >= n) return fail(QMPS_ERR_ARG, "device %d outside [0,%d)", device, n);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(QMPS_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code objects only", device,
+                prop.gcnArchName);
+  qmps_ctx* c = new (std::nothrow) qmps_ctx();
+  if (!c) return fail(QMPS_ERR_ARG, "out of host memory");
+  c->device = device;
+  c->D = D;
+  c->max_batch = max_batch;
+  int rc = [&]() -> int {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipMalloc(&c->d_A, (size_t)max_batch * tensor_bytes(c)));
+    HIP_TRY(hipMalloc(&c->d_r, (size_t)max_batch * env_bytes(c)));
+    HIP_TRY(hipMalloc(&c->d_h, (size_t)kMaxTerms * 256));
+    HIP_TRY(hipMalloc((void**)&c->d_iters, (size_t)max_batch * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&c->d_status, (size_t)max_batch * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&c->d_partial, (size_t)kMaxTerms * kSumBlocks * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->d_cost, kMaxTerms * sizeof(double)));
+    HIP_TRY(hipHostMalloc((void**)&c->h_cost, kMaxTerms * sizeof(double), hipHostMallocDefault));
+    return QMPS_OK;
+  }();
+  if (rc != QMPS_OK) {
+    char keep[512];
+    snprintf(keep, sizeof(keep), "%s", g_err);
+    qmps_destroy(c);
+    snprintf(g_err, sizeof(g_err), "%s", keep);
+    return rc;
+  }
+  *out = c;
+  return QMPS_OK;
+}
+
+int qmps_destroy(qmps_ctx* c) {
+  if (!c) return QMPS_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) (void)ncclCommDestroy(c->comm);
+  void* bufs[] = {c->d_A, c->d_U, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (c->h_cost) (void)hipHostFree(c->h_cost);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return QMPS_OK;
+}
+
+int qmps_sync(qmps_ctx* c) {
+  if (int rc = bind(c)) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+
+int qmps_set_states(qmps_ctx* c, int64_t B, const double* states, int kind) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (!states && B > 0) return fail(QMPS_ERR_ARG, "null states");
+  if (kind == QMPS_INPUT_TENSOR) {
+    HIP_TRY(hipMemcpyAsync(c->d_A, states, (size_t)B * tensor_bytes(c), hipMemcpyHostToDevice, c->stream));
+  } else if (kind == QMPS_INPUT_UNITARY) {
+    if (!c->d_U) HIP_TRY(hipMalloc(&c->d_U, (size_t)c->max_batch * 2 * tensor_bytes(c)));
+    HIP_TRY(hipMemcpyAsync(c->d_U, states, (size_t)B * 2 * tensor_bytes(c), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(qmps::launch_unitary_to_tensor(c->d_U, c->d_A, c->D, B, c->stream));
+  } else {
+    return fail(QMPS_ERR_ARG, "unknown input kind %d", kind);
+  }
+  // the caller's host buffer may be pageable and re-used right after the call returns
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->n_states = B;
+  c->have_guess = false;
+  c->have_env = false;
+  return QMPS_OK;
+}
+
+int qmps_set_hamiltonian(qmps_ctx* c, int n_terms, const double* h) {
+  if (int rc = bind(c)) return rc;
+  if (n_terms < 1 || n_terms > kMaxTerms) return fail(QMPS_ERR_ARG, "n_terms=%d outside [1,%d]", n_terms, kMaxTerms);
+  if (!h) return fail(QMPS_ERR_ARG, "null h");
+  if (int rc = ensure_E(c, n_terms)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_h, h, (size_t)n_terms * 256, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->n_terms = n_terms;
+  return QMPS_OK;
+}
+
+int qmps_set_env_guess(qmps_ctx* c, int64_t B, const double* r0) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (!r0) {
+    c->have_guess = false;
+    return QMPS_OK;
+  }
+  HIP_TRY(hipMemcpyAsync(c->d_r, r0, (size_t)B * env_bytes(c), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->have_guess = true;
+  c->have_env = true;
+  return QMPS_OK;
+}
+
+int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int flags) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (B > c->n_states) return fail(QMPS_ERR_STATE, "B=%lld but only %lld states are resident", (long long)B, (long long)c->n_states);
+  if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "qmps_set_hamiltonian has not been called");
+  if (max_iter < 1) return fail(QMPS_ERR_ARG, "max_iter must be >= 1");
+  if (!(tol > 0.0)) return fail(QMPS_ERR_ARG, "tol must be > 0");
+  if ((flags & 0xff) != QMPS_ENV_POWER) return fail(QMPS_ERR_ARG, "unknown environment solver %d", flags & 0xff);
+  qmps::LaneArgs a = make_args(c, B, max_iter, tol, true);
+  HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
+  c->have_env = true;
+  return QMPS_OK;
+}
+
+int qmps_energy_only_launch(qmps_ctx* c, int64_t B) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (B > c->n_states) return fail(QMPS_ERR_STATE, "B=%lld but only %lld states are resident", (long long)B, (long long)c->n_states);
+  if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "qmps_set_hamiltonian has not been called");
+  if (!c->have_env) return fail(QMPS_ERR_STATE, "no resident environment: run qmps_energy_launch or qmps_set_env_guess first");
+  qmps::LaneArgs a = make_args(c, B, 1, 1.0, false);
+  HIP_TRY(qmps::launch_energy(c->D, a, false, c->stream));
+  return QMPS_OK;
+}
+
+static int sum_on_device(qmps_ctx* c, int64_t B) {
+  if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
+  HIP_TRY(qmps::launch_sum(c->d_E, B, c->n_terms, c->d_partial, kSumBlocks, c->d_cost, c->stream));
+  return QMPS_OK;
+}
+
+int qmps_sum_energies(qmps_ctx* c, int64_t B, double* cost) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (!cost) return fail(QMPS_ERR_ARG, "null cost");
+  if (int rc = sum_on_device(c, B)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->h_cost, c->d_cost, c->n_terms * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(cost, c->h_cost, c->n_terms * sizeof(double));
+  return QMPS_OK;
+}
+
+int qmps_get_energies(qmps_ctx* c, int64_t B, double* E, int32_t* iters, int32_t* status) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
+  if (E) HIP_TRY(hipMemcpyAsync(E, c->d_E, (size_t)B * c->n_terms * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (iters) HIP_TRY(hipMemcpyAsync(iters, c->d_iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (status) HIP_TRY(hipMemcpyAsync(status, c->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+
+int qmps_get_env(qmps_ctx* c, int64_t B, double* r) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (!r) return fail(QMPS_ERR_ARG, "null r");
+  if (!c->have_env) return fail(QMPS_ERR_STATE, "no resident environment");
+  HIP_TRY(hipMemcpyAsync(r, c->d_r, (size_t)B * env_bytes(c), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+
+int qmps_get_rdm(qmps_ctx* c, int64_t B, double* rho) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (!rho) return fail(QMPS_ERR_ARG, "null rho");
+  if (!c->have_env) return fail(QMPS_ERR_STATE, "no resident environment");
+  if (!c->d_rho) HIP_TRY(hipMalloc(&c->d_rho, (size_t)c->max_batch * 256));
+  // recompute from the resident (A, r): the energy-only kernel writes rho when asked to
+  c->want_rho = true;
+  int rc = qmps_energy_only_launch(c, B);
+  c->want_rho = false;
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(rho, c->d_rho, (size_t)B * 256, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+
+int qmps_energy_batch(qmps_ctx* c, int64_t B, const double* states, int kind, const double* h, int n_terms,
+                      const double* r0, int max_iter, double tol, double* E_out, int32_t* iters_out,
+                      int32_t* status_out) {
+  if (!E_out) return fail(QMPS_ERR_ARG, "null E_out");
+  if (int rc = qmps_set_states(c, B, states, kind)) return rc;
+  if (int rc = qmps_set_hamiltonian(c, n_terms, h)) return rc;
+  if (int rc = qmps_set_env_guess(c, B, r0)) return rc;
+  if (int rc = qmps_energy_launch(c, B, max_iter, tol, QMPS_ENV_POWER)) return rc;
+  return qmps_get_energies(c, B, E_out, iters_out, status_out);
+}
+
+int qmps_env_batch(qmps_ctx* c, int64_t B, const double* states, int kind, const double* r0, int max_iter, double tol,
+                   double* r_out, int32_t* iters_out, int32_t* status_out) {
+  if (!r_out) return fail(QMPS_ERR_ARG, "null r_out");
+  if (int rc = qmps_set_states(c, B, states, kind)) return rc;
+  if (c->n_terms < 1) {
+    // the solve kernel always evaluates at least one Hamiltonian term; use h = 0
+    double zero[32];
+    memset(zero, 0, sizeof(zero));
+    if (int rc = qmps_set_hamiltonian(c, 1, zero)) return rc;
+  }
+  if (int rc = qmps_set_env_guess(c, B, r0)) return rc;
+  if (int rc = qmps_energy_launch(c, B, max_iter, tol, QMPS_ENV_POWER)) return rc;
+  if (int rc = qmps_get_energies(c, B, nullptr, iters_out, status_out)) return rc;
+  return qmps_get_env(c, B, r_out);
+}
+
+int qmps_timer_begin(qmps_ctx* c) {
+  if (int rc = bind(c)) return rc;
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  return QMPS_OK;
+}
+
+int qmps_timer_end(qmps_ctx* c, float* ms) {
+  if (int rc = bind(c)) return rc;
+  if (!ms) return fail(QMPS_ERR_ARG, "null ms");
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return QMPS_OK;
+}
+
+// ---- RCCL ---------------------------------------------------------------------------------
+int qmps_comm_unique_id(char id[QMPS_UNIQUE_ID_BYTES]) {
+  if (!id) return fail(QMPS_ERR_ARG, "null id");
+  static_assert(sizeof(ncclUniqueId) <= QMPS_UNIQUE_ID_BYTES, "ncclUniqueId larger than QMPS_UNIQUE_ID_BYTES");
+  ncclUniqueId u;
+  RCCL_TRY(ncclGetUniqueId(&u));
+  memset(id, 0, QMPS_UNIQUE_ID_BYTES);
+  memcpy(id, &u, sizeof(u));
+  return QMPS_OK;
+}
+
+int qmps_comm_init(qmps_ctx* c, const char id[QMPS_UNIQUE_ID_BYTES], int rank, int nranks) {
+  if (int rc = bind(c)) return rc;
+  if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(QMPS_ERR_ARG, "bad communicator arguments");
+  if (c->comm) return fail(QMPS_ERR_STATE, "communicator already initialised");
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  RCCL_TRY(ncclCommInitRank(&c->comm, nranks, u, rank));
+  c->rank = rank;
+  c->nranks = nranks;
+  return QMPS_OK;
+}
+
+int qmps_comm_destroy(qmps_ctx* c) {
+  if (int rc = bind(c)) return rc;
+  if (c->comm) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    RCCL_TRY(ncclCommDestroy(c->comm));
+    c->comm = nullptr;
+    c->nranks = 1;
+    c->rank = 0;
+  }
+  return QMPS_OK;
+}
+
+int qmps_allreduce_sum(qmps_ctx* c, double* inout, int n) {
+  if (int rc = bind(c)) return rc;
+  if (!inout || n < 1 || n > kMaxTerms) return fail(QMPS_ERR_ARG, "n=%d outside [1,%d]", n, kMaxTerms);
+  if (!c->comm) return fail(QMPS_ERR_STATE, "qmps_comm_init has not been called");
+  memcpy(c->h_cost, inout, n * sizeof(double));
+  HIP_TRY(hipMemcpyAsync(c->d_cost, c->h_cost, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  RCCL_TRY(ncclAllReduce(c->d_cost, c->d_cost, n, ncclDouble, ncclSum, c->comm, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_cost, c->d_cost, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(inout, c->h_cost, n * sizeof(double));
+  return QMPS_OK;
+}
+
+int qmps_cost_launch(qmps_ctx* c, int64_t B) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (int rc = sum_on_device(c, B)) return rc;
+  if (c->comm) RCCL_TRY(ncclAllReduce(c->d_cost, c->d_cost, c->n_terms, ncclDouble, ncclSum, c->comm, c->stream));
+  return QMPS_OK;
+}
+
+int qmps_get_cost(qmps_ctx* c, double* cost) {
+  if (int rc = bind(c)) return rc;
+  if (!cost) return fail(QMPS_ERR_ARG, "null cost");
+  if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
+  HIP_TRY(hipMemcpyAsync(c->h_cost, c->d_cost, c->n_terms * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(cost, c->h_cost, c->n_terms * sizeof(double));
+  return QMPS_OK;
+}
+
+int qmps_allreduce_cost(qmps_ctx* c, int64_t B, double* cost) {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  if (!c->comm) return fail(QMPS_ERR_STATE, "qmps_comm_init has not been called");
+  if (int rc = qmps_cost_launch(c, B)) return rc;
+  return qmps_get_cost(c, cost);
+}
+
+// ---- probes -------------------------------------------------------------------------------
+int qmps_probe_fp64_peak(qmps_ctx* c, double* tflops) {
+  if (int rc = bind(c)) return rc;
+  if (!tflops) return fail(QMPS_ERR_ARG, "null tflops");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+  const int blocks = prop.multiProcessorCount * 8;  // 2 waves per SIMD
+  const int iters = 20000;
+  HIP_TRY(qmps::launch_probe_fp64(c->d_cost, blocks, 200, c->stream));  // warm-up
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(qmps::launch_probe_fp64(c->d_cost, blocks, iters, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (ms < best) best = ms;
+  }
+  const double flops = 2.0 * 16.0 * iters * 256.0 * blocks;
+  *tflops = flops / (best * 1e-3) * 1e-12;
+  return QMPS_OK;
+}
+
+int qmps_probe_hbm_peak(qmps_ctx* c, double* gbps) {
+  if (int rc = bind(c)) return rc;
+  if (!gbps) return fail(QMPS_ERR_ARG, "null gbps");
+  const size_t bytes = (size_t)1 << 30;  // 1 GiB each way: well past the 256 MiB Infinity Cache
+  void *src = nullptr, *dst = nullptr;
+  HIP_TRY(hipMalloc(&src, bytes));
+  if (hipMalloc(&dst, bytes) != hipSuccess) {
+    (void)hipFree(src);
+    return fail(QMPS_ERR_HIP, "hipMalloc failed in the HBM probe");
+  }
+  int rc = [&]() -> int {
+    HIP_TRY(hipMemsetAsync(src, 1, bytes, c->stream));
+    HIP_TRY(qmps::launch_probe_copy(src, dst, (int64_t)(bytes / 16), c->stream));
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+      HIP_TRY(hipEventRecord(c->ev0, c->stream));
+      HIP_TRY(qmps::launch_probe_copy(src, dst, (int64_t)(bytes / 16), c->stream));
+      HIP_TRY(hipEventRecord(c->ev1, c->stream));
+      HIP_TRY(hipEventSynchronize(c->ev1));
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+      if (ms < best) best = ms;
+    }
+    *gbps = 2.0 * (double)bytes / (best * 1e-3) * 1e-9;
+    return QMPS_OK;
+  }();
+  (void)hipFree(src);
+  (void)hipFree(dst);
+  return rc;
+}
+
+}  // extern "C"

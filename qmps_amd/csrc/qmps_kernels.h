@@ -1,0 +1,33 @@
+// qmps_kernels.h - internal interface between the C-ABI host code and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qmps {
+
+enum { QMPS_ST_OK = 0, QMPS_ST_NOT_CONVERGED = 1, QMPS_ST_NOT_PD = 2 };
+
+// Kernel arguments of the energy kernels (all pointers are HBM addresses).
+struct LaneArgs {
+  const void* A;      // [B][2][D][D] complex128
+  const void* h;      // [n_terms][4][4] complex128
+  const void* r_in;   // nullable [B][D][D] complex128: warm start (SOLVE) or the environment (!SOLVE)
+  void* r_out;        // nullable [B][D][D] complex128
+  void* rho_out;      // nullable [B][4][4] complex128
+  double* E;          // [B][n_terms]
+  int32_t* iters;     // [B]
+  int32_t* status;    // [B]
+  int64_t B;
+  int n_terms;
+  int max_iter;
+  double tol;
+};
+
+hipError_t launch_energy(int D, const LaneArgs& a, bool solve, hipStream_t st);
+hipError_t launch_unitary_to_tensor(const void* U, void* A, int D, int64_t B, hipStream_t st);
+hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, int n_partial, double* cost,
+                      hipStream_t st);
+hipError_t launch_probe_fp64(double* out, int blocks, int iters, hipStream_t st);
+hipError_t launch_probe_copy(const void* src, void* dst, int64_t n16, hipStream_t st);
+
+}  // namespace qmps

@@ -1,0 +1,211 @@
+"""Batched engine: the Python face of one libqmps_hip context (one GPU, one stream).
+
+`EnergyEngine.energies(...)` is the batched counterpart of the reference's scalar objective
+`objective_function(params) -> float` (qmps/ground_state.py:150-168, 251-266): it evaluates B
+independent (state tensor, Hamiltonian) pairs per launch on the MI355X.
+"""
+import ctypes
+from ctypes import byref, c_double, c_float, c_int32, c_void_p
+
+import numpy as np
+
+from . import _lib as L
+
+_dp = ctypes.POINTER(c_double)
+_ip = ctypes.POINTER(c_int32)
+
+
+def _f64(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i32(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _c128(a, shape_tail, name):
+    a = np.ascontiguousarray(a, dtype=np.complex128)
+    if a.shape[1:] != tuple(shape_tail):
+        raise ValueError(f'{name}: expected shape (B,{",".join(map(str, shape_tail))}), got {a.shape}')
+    return a
+
+
+class EnergyEngine:
+    """Owns one `qmps_ctx`.  Not thread-safe; one engine per thread / device."""
+
+    def __init__(self, D, max_batch, device=0):
+        self._lib = L.load()
+        self.D = int(D)
+        self.max_batch = int(max_batch)
+        self.device = int(device)
+        self._ctx = c_void_p()
+        L.check(self._lib.qmps_create(self.device, self.D, self.max_batch, byref(self._ctx)))
+        self.n_terms = 0
+        self.B = 0
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, '_ctx', None) is not None and self._ctx.value:
+            self._lib.qmps_destroy(self._ctx)
+            self._ctx = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- inputs -----------------------------------------------------------------------------
+    def set_tensors(self, A):
+        """A: (B, 2, D, D) complex128 state tensors, A[b, s, i, j]."""
+        A = _c128(A, (2, self.D, self.D), 'A')
+        L.check(self._lib.qmps_set_states(self._ctx, A.shape[0], _f64(A.view(np.float64)), L.INPUT_TENSOR))
+        self.B = A.shape[0]
+
+    def set_unitaries(self, U):
+        """U: (B, 2D, 2D) complex128 state unitaries; unitary_to_tensor runs on the device."""
+        U = _c128(U, (2 * self.D, 2 * self.D), 'U')
+        L.check(self._lib.qmps_set_states(self._ctx, U.shape[0], _f64(U.view(np.float64)), L.INPUT_UNITARY))
+        self.B = U.shape[0]
+
+    def set_hamiltonian(self, h):
+        """h: (4, 4) or (n_terms, 4, 4) complex; index 2*s1+s2 with s1 the left site."""
+        h = np.ascontiguousarray(np.asarray(h, dtype=np.complex128).reshape(-1, 4, 4))
+        L.check(self._lib.qmps_set_hamiltonian(self._ctx, h.shape[0], _f64(h.view(np.float64))))
+        self.n_terms = h.shape[0]
+
+    def set_env_guess(self, r0):
+        if r0 is None:
+            L.check(self._lib.qmps_set_env_guess(self._ctx, 0, None))
+            return
+        r0 = _c128(r0, (self.D, self.D), 'r0')
+        L.check(self._lib.qmps_set_env_guess(self._ctx, r0.shape[0], _f64(r0.view(np.float64))))
+
+    # -- hot path ---------------------------------------------------------------------------
+    def launch(self, B=None, max_iter=10000, tol=1e-13):
+        """Asynchronous: power-iteration environment + energies for the resident batch."""
+        L.check(self._lib.qmps_energy_launch(self._ctx, self.B if B is None else B, int(max_iter), float(tol),
+                                             L.ENV_POWER))
+
+    def launch_energy_only(self, B=None):
+        L.check(self._lib.qmps_energy_only_launch(self._ctx, self.B if B is None else B))
+
+    def sync(self):
+        L.check(self._lib.qmps_sync(self._ctx))
+
+    def results(self, B=None):
+        B = self.B if B is None else B
+        E = np.empty((B, self.n_terms))
+        it = np.empty(B, dtype=np.int32)
+        st = np.empty(B, dtype=np.int32)
+        L.check(self._lib.qmps_get_energies(self._ctx, B, _f64(E), _i32(it), _i32(st)))
+        return E, it, st
+
+    def environments(self, B=None):
+        B = self.B if B is None else B
+        r = np.empty((B, self.D, self.D), dtype=np.complex128)
+        L.check(self._lib.qmps_get_env(self._ctx, B, _f64(r.view(np.float64))))
+        return r
+
+    def rdm(self, B=None):
+        B = self.B if B is None else B
+        rho = np.empty((B, 4, 4), dtype=np.complex128)
+        L.check(self._lib.qmps_get_rdm(self._ctx, B, _f64(rho.view(np.float64))))
+        return rho
+
+    def summed_cost(self, B=None):
+        cost = np.empty(max(self.n_terms, 1))
+        L.check(self._lib.qmps_sum_energies(self._ctx, self.B if B is None else B, _f64(cost)))
+        return cost[:self.n_terms]
+
+    # -- one-shot (host buffers in, host buffers out) -------------------------------------------
+    def energies(self, states, h, kind='tensor', r0=None, max_iter=10000, tol=1e-13):
+        """states: A (B,2,D,D) [kind='tensor'] or U (B,2D,2D) [kind='unitary'] -> (E (B,n_terms), iters, status)."""
+        tail = (2, self.D, self.D) if kind == 'tensor' else (2 * self.D, 2 * self.D)
+        states = _c128(states, tail, 'states')
+        h = np.ascontiguousarray(np.asarray(h, dtype=np.complex128).reshape(-1, 4, 4))
+        B, nt = states.shape[0], h.shape[0]
+        r0c = None if r0 is None else _c128(r0, (self.D, self.D), 'r0')
+        E = np.empty((B, nt))
+        it = np.empty(B, dtype=np.int32)
+        st = np.empty(B, dtype=np.int32)
+        L.check(self._lib.qmps_energy_batch(
+            self._ctx, B, _f64(states.view(np.float64)), L.INPUT_TENSOR if kind == 'tensor' else L.INPUT_UNITARY,
+            _f64(h.view(np.float64)), nt, None if r0c is None else _f64(r0c.view(np.float64)), int(max_iter),
+            float(tol), _f64(E), _i32(it), _i32(st)))
+        self.B, self.n_terms = B, nt
+        return E, it, st
+
+    def env_batch(self, states, kind='tensor', r0=None, max_iter=10000, tol=1e-13):
+        tail = (2, self.D, self.D) if kind == 'tensor' else (2 * self.D, 2 * self.D)
+        states = _c128(states, tail, 'states')
+        B = states.shape[0]
+        r0c = None if r0 is None else _c128(r0, (self.D, self.D), 'r0')
+        r = np.empty((B, self.D, self.D), dtype=np.complex128)
+        it = np.empty(B, dtype=np.int32)
+        st = np.empty(B, dtype=np.int32)
+        L.check(self._lib.qmps_env_batch(
+            self._ctx, B, _f64(states.view(np.float64)), L.INPUT_TENSOR if kind == 'tensor' else L.INPUT_UNITARY,
+            None if r0c is None else _f64(r0c.view(np.float64)), int(max_iter), float(tol),
+            _f64(r.view(np.float64)), _i32(it), _i32(st)))
+        self.B = B
+        if self.n_terms == 0:
+            self.n_terms = 1
+        return r, it, st
+
+    # -- timing / probes ----------------------------------------------------------------------
+    def timer_begin(self):
+        L.check(self._lib.qmps_timer_begin(self._ctx))
+
+    def timer_end(self):
+        ms = c_float(0)
+        L.check(self._lib.qmps_timer_end(self._ctx, byref(ms)))
+        return ms.value
+
+    def probe_fp64_tflops(self):
+        v = c_double(0)
+        L.check(self._lib.qmps_probe_fp64_peak(self._ctx, byref(v)))
+        return v.value
+
+    def probe_hbm_gbps(self):
+        v = c_double(0)
+        L.check(self._lib.qmps_probe_hbm_peak(self._ctx, byref(v)))
+        return v.value
+
+    # -- multi-GPU ----------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = ctypes.create_string_buffer(L.UNIQUE_ID_BYTES)
+        L.check(L.load().qmps_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, nranks):
+        L.check(self._lib.qmps_comm_init(self._ctx, unique_id, int(rank), int(nranks)))
+
+    def comm_destroy(self):
+        L.check(self._lib.qmps_comm_destroy(self._ctx))
+
+    def allreduce_sum(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        L.check(self._lib.qmps_allreduce_sum(self._ctx, _f64(v), v.size))
+        return v
+
+    def cost_launch(self, B=None):
+        """Asynchronous: device-side sum over the batch (+ one RCCL all-reduce when a communicator exists)."""
+        L.check(self._lib.qmps_cost_launch(self._ctx, self.B if B is None else B))
+
+    def get_cost(self):
+        cost = np.empty(max(self.n_terms, 1))
+        L.check(self._lib.qmps_get_cost(self._ctx, _f64(cost)))
+        return cost[:self.n_terms]
+
+    def allreduce_cost(self, B=None):
+        cost = np.empty(max(self.n_terms, 1))
+        L.check(self._lib.qmps_allreduce_cost(self._ctx, self.B if B is None else B, _f64(cost)))
+        return cost[:self.n_terms]

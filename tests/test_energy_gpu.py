@@ -1,0 +1,108 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle.
+
+fp64 tolerance (BASELINE.json north_star): energies within 1e-10 of the fp64 restatement of the
+reference maths.  Iteration counts may differ from the oracle's by +-1 (FMA contraction changes
+the last bit of the convergence test).
+"""
+import numpy as np
+import pytest
+
+from oracle import qmps_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+E_TOL = 1e-10
+R_TOL = 1e-10
+
+
+@pytest.mark.parametrize('D', [2, 4, 8, 16])
+def test_golden_vectors(D, golden, engine_factory):
+    """Committed fixtures: reference-generated A, oracle E (closed form == state-vector path)."""
+    eng = engine_factory(D)
+    A = golden[f'ref_A_D{D}']
+    h = golden['ref_h_tfim']
+    E, it, st = eng.energies(A, h)
+    assert np.all(st == 0)
+    assert np.abs(E[:, 0] - golden[f'oracle_E_closed_D{D}']).max() < E_TOL
+    if D <= 8:
+        assert np.abs(E[:, 0] - golden[f'oracle_E_statevec_D{D}']).max() < E_TOL
+    assert np.all(np.abs(it - golden[f'oracle_iters_D{D}']) <= 1)
+    r = eng.environments()
+    assert np.abs(r - golden[f'oracle_r_D{D}']).max() < R_TOL
+    # same through the unitary input kind (device-side unitary_to_tensor)
+    E2, _, _ = eng.energies(golden[f'U_D{D}'], h, kind='unitary')
+    assert np.array_equal(E, E2)
+
+
+@pytest.mark.parametrize('D,B', [(2, 1), (2, 63), (2, 4096), (4, 1), (4, 65), (4, 1000), (8, 37), (16, 9)])
+def test_random_batches_vs_c_oracle(D, B, c_oracle, engine_factory):
+    rng = np.random.default_rng(1000 * D + B)
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, B))
+    h = np.stack([O.hamiltonian_matrix({'ZZ': -1, 'X': 1}),
+                  O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5}),
+                  rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4))])
+    eng = engine_factory(D)
+    E, it, st = eng.energies(A, h, max_iter=4000)
+    ref = c_oracle.energy_batch(A, h, max_iter=4000, want_r=True, want_rho=True)
+    ok = (st == 0) & (ref['status'] == 0)
+    assert ok.mean() > 0.9
+    assert np.array_equal(st == 1, ref['status'] == 1) or np.abs(it - ref['iters']).max() <= 1
+    assert np.abs(E - ref['E'])[ok].max() < E_TOL
+    assert np.abs(it - ref['iters'])[ok].max() <= 1
+    assert np.abs(eng.environments() - ref['r'])[ok].max() < R_TOL
+    assert np.abs(eng.rdm() - ref['rho'])[ok].max() < R_TOL
+    # device-side summed cost == host sum
+    assert np.allclose(eng.summed_cost(), E.sum(0), rtol=0, atol=1e-9 * max(1, B))
+
+
+@pytest.mark.parametrize('D', [2, 4, 8])
+def test_warm_start_and_energy_only(D, c_oracle, engine_factory):
+    rng = np.random.default_rng(7 + D)
+    B = 200
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, B))
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 0.7})
+    eng = engine_factory(D)
+    E, it, st = eng.energies(A, h)
+    r = eng.environments()
+    # warm start from the converged environment: converges immediately, same energies
+    E2, it2, st2 = eng.energies(A, h, r0=r)
+    assert np.all(st2 == 0) and it2.max() <= 2
+    assert np.abs(E2 - E).max() < E_TOL
+    # energy-only launch on the resident (A, r)
+    eng.launch_energy_only()
+    E3, _, _ = eng.results()
+    assert np.abs(E3 - E).max() < 1e-13
+    # warm start scaled by an arbitrary positive trace and perturbed
+    r0 = 3.7 * r + 1e-3 * np.eye(D)
+    E4, it4, st4 = eng.energies(A, h, r0=r0)
+    assert np.all(st4 == 0) and np.abs(E4 - E).max() < E_TOL and it4.mean() < it.mean()
+
+
+def test_edge_cases(engine_factory):
+    eng = engine_factory(4)
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+    # empty batch
+    E, it, st = eng.energies(np.zeros((0, 2, 4, 4), complex), h)
+    assert E.shape == (0, 1)
+    # product state: r has rank 1 -> not positive definite (the reference's LinAlgError branch)
+    U = np.eye(8, dtype=complex)[None]
+    E, it, st = eng.energies(U, h, kind='unitary')
+    assert st[0] in (1, 2)
+    assert abs(E[0, 0] - (-1.0)) < 1e-12      # |00..0>: <ZZ> = 1, <X> = 0
+    # max_iter cut-off is reported, not hidden
+    rng = np.random.default_rng(3)
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 8, 10))
+    E, it, st = eng.energies(A, h, max_iter=3)
+    assert np.all(st == 1) and np.all(it == 3)
+
+
+def test_argument_errors(engine_factory):
+    from qmps_amd._lib import QmpsError
+    eng = engine_factory(4)
+    with pytest.raises(ValueError):
+        eng.energies(np.zeros((3, 2, 2, 2), complex), np.eye(4))
+    with pytest.raises(QmpsError):
+        eng.energies(np.zeros((3, 2, 4, 4), complex), np.eye(4), max_iter=0)
+    from qmps_amd import EnergyEngine
+    with pytest.raises(QmpsError):
+        EnergyEngine(3, 10)

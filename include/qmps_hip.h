@@ -118,6 +118,14 @@ int qmps_energy_batch(qmps_ctx* ctx, int64_t B, const double* states, int kind, 
 int qmps_env_batch(qmps_ctx* ctx, int64_t B, const double* states, int kind, const double* r0 /* nullable */,
                    int max_iter, double tol, double* r_out, int32_t* iters_out, int32_t* status_out);
 
+/* Two-site unit cell, D = 2 (qmps/ground_state.py:291-331 NonSparseFullTwoSiteEnergyOptimizer):
+ * U1, U2 [B][4][4] complex128 state unitaries; environment of merge(A1, A2)
+ * (qmps/time_evolve_tools.py:20-23) by power iteration, E = (E1 + E2)/2 with the two circuits
+ * V1.U2.U1 and V2.U1.U2 in closed form.  status 2 if either environment is not positive definite. */
+int qmps_cell2_energy_batch(qmps_ctx* ctx, int64_t B, const double* U1, const double* U2, const double* h,
+                            int n_terms, int max_iter, double tol, double* E_out, int32_t* iters_out,
+                            int32_t* status_out);
+
 /* ---- timing on the context stream (HIP events) ------------------------------------------ */
 int qmps_timer_begin(qmps_ctx* ctx);
 int qmps_timer_end(qmps_ctx* ctx, float* milliseconds); /* waits for the end event */

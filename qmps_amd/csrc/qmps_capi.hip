@@ -50,6 +50,7 @@ struct qmps_ctx {
   // HBM
   void* d_A = nullptr;       // [max_batch][2][D][D] c128
   void* d_U = nullptr;       // [max_batch][2D][2D] c128 (lazy)
+  void* d_U2 = nullptr;      // second unitary of a two-site unit cell (lazy)
   void* d_h = nullptr;       // [16][4][4] c128
   void* d_r = nullptr;       // [max_batch][D][D] c128
   void* d_rho = nullptr;     // [max_batch][4][4] c128 (lazy)
@@ -198,7 +199,7 @@ int qmps_destroy(qmps_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)ncclCommDestroy(c->comm);
-  void* bufs[] = {c->d_A, c->d_U, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost};
+  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
@@ -365,6 +366,29 @@ int qmps_env_batch(qmps_ctx* c, int64_t B, const double* states, int kind, const
   if (int rc = qmps_energy_launch(c, B, max_iter, tol, QMPS_ENV_POWER)) return rc;
   if (int rc = qmps_get_energies(c, B, nullptr, iters_out, status_out)) return rc;
   return qmps_get_env(c, B, r_out);
+}
+
+int qmps_cell2_energy_batch(qmps_ctx* c, int64_t B, const double* U1, const double* U2, const double* h, int n_terms,
+                             int max_iter, double tol, double* E_out, int32_t* iters_out, int32_t* status_out) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (c->D != 2) return fail(QMPS_ERR_ARG, "the two-site unit cell path is D = 2 only (qmps/ground_state.py:276)");
+  if ((!U1 || !U2) && B > 0) return fail(QMPS_ERR_ARG, "null unitaries");
+  if (!E_out) return fail(QMPS_ERR_ARG, "null E_out");
+  if (max_iter < 1 || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_iter / tol");
+  if (int rc = qmps_set_hamiltonian(c, n_terms, h)) return rc;
+  const size_t ub = 2 * tensor_bytes(c);
+  if (!c->d_U) HIP_TRY(hipMalloc(&c->d_U, (size_t)c->max_batch * ub));
+  if (!c->d_U2) HIP_TRY(hipMalloc(&c->d_U2, (size_t)c->max_batch * ub));
+  HIP_TRY(hipMemcpyAsync(c->d_U, U1, (size_t)B * ub, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_U2, U2, (size_t)B * ub, hipMemcpyHostToDevice, c->stream));
+  qmps::Cell2Args a;
+  a.U1 = c->d_U; a.U2 = c->d_U2; a.h = c->d_h; a.E = c->d_E; a.E12 = nullptr;
+  a.iters = c->d_iters; a.status = c->d_status; a.B = B; a.n_terms = n_terms; a.max_iter = max_iter; a.tol = tol;
+  HIP_TRY(qmps::launch_cell2(c->D, a, c->stream));
+  c->n_states = 0;  // the resident single-site states (if any) are no longer what d_E refers to
+  c->have_env = false;
+  return qmps_get_energies(c, B, E_out, iters_out, status_out);
 }
 
 int qmps_timer_begin(qmps_ctx* c) {

@@ -23,6 +23,22 @@ struct LaneArgs {
   double tol;
 };
 
+// Two-site unit cell (NonSparseFullTwoSiteEnergyOptimizer): state unitaries U1, U2 [B][2D][2D].
+struct Cell2Args {
+  const void* U1;
+  const void* U2;
+  const void* h;
+  double* E;        // [B][n_terms]  (E1 + E2)/2
+  double* E12;      // nullable [B][n_terms][2]
+  int32_t* iters;
+  int32_t* status;
+  int64_t B;
+  int n_terms;
+  int max_iter;
+  double tol;
+};
+
+hipError_t launch_cell2(int D, const Cell2Args& a, hipStream_t st);
 hipError_t launch_energy(int D, const LaneArgs& a, bool solve, hipStream_t st);
 hipError_t launch_unitary_to_tensor(const void* U, void* A, int D, int64_t B, hipStream_t st);
 hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, int n_partial, double* cost,

@@ -134,8 +134,11 @@ __device__ __forceinline__ bool is_positive_definite(const double (&rre)[D][D], 
 // Two-site reduced density matrix, upper triangle (tau <= sigma), one evaluation per lane:
 //   rho[tau][sigma] = tr(B_tau r B_sigma^+),  B_{2 s1 + s2} = A_s1 A_s2   (NOT yet divided by tr r)
 // computed as  X_t2 = A_t2 r ;  R = X_t2 A_s2^+ ;  Z = A_t1 R ;  rho = sum_ik Z[i][k] conj(A_s1[i][k]).
+// Generalised to a two-site unit cell: left-site tensor L (are/aim) and right-site tensor Rt (bre/bim):
+//   rho[(t1 t2)][(s1 s2)] = tr(L_t1 Rt_t2 r Rt_s2^+ L_s1^+);  single-site cell: L == Rt.
 template <int D>
 __device__ __forceinline__ void two_site_rdm(const double (&are)[2][D][D], const double (&aim)[2][D][D],
+                                             const double (&bre)[2][D][D], const double (&bim)[2][D][D],
                                              const double (&rre)[D][D], const double (&rim)[D][D],
                                              double (&pre)[4][4], double (&pim)[4][4]) {
 #pragma unroll
@@ -149,7 +152,7 @@ __device__ __forceinline__ void two_site_rdm(const double (&are)[2][D][D], const
         double xr = 0.0, xi = 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-          const double ar = are[t2][i][k], ai = aim[t2][i][k];
+          const double ar = bre[t2][i][k], ai = bim[t2][i][k];
           const double rr = h_re<D>(rre, k, j);
           xr = dfma(ar, rr, xr);
           xi = dfma(ai, rr, xi);
@@ -173,10 +176,10 @@ __device__ __forceinline__ void two_site_rdm(const double (&are)[2][D][D], const
           double cr = 0.0, ci = 0.0;
 #pragma unroll
           for (int k = 0; k < D; ++k) {
-            cr = dfma(xre[i][k], are[s2][j][k], cr);
-            cr = dfma(xim[i][k], aim[s2][j][k], cr);
-            ci = dfma(xim[i][k], are[s2][j][k], ci);
-            ci = dfma(-xre[i][k], aim[s2][j][k], ci);
+            cr = dfma(xre[i][k], bre[s2][j][k], cr);
+            cr = dfma(xim[i][k], bim[s2][j][k], cr);
+            ci = dfma(xim[i][k], bre[s2][j][k], ci);
+            ci = dfma(-xre[i][k], bim[s2][j][k], ci);
           }
           Rre[i][j] = cr;
           Rim[i][j] = ci;
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(64) void energy_lane_kernel(LaneArgs p) {
 
   // ---- energy epilogue: rho (upper triangle) -> E_t = Re sum h_t[s][t] rho[t][s] / tr r
   double pre[4][4], pim[4][4];
-  two_site_rdm<D>(are, aim, rre, rim, pre, pim);
+  two_site_rdm<D>(are, aim, are, aim, rre, rim, pre, pim);
   double tr = 0.0;
 #pragma unroll
   for (int i = 0; i < D; ++i) tr += rre[i][i];
@@ -419,6 +422,120 @@ __global__ __launch_bounds__(64) void energy_lane_kernel(LaneArgs p) {
         o[t * 4 + s] = make_double2(re, im);
       }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 1b: two-site unit cell (qmps/ground_state.py:291-331, NonSparseFullTwoSiteEnergyOptimizer),
+// one evaluation per lane.  Inputs are the two state UNITARIES U1, U2 [B][2D][2D]; the kernel applies
+// unitary_to_tensor on load.  r12 = fixed point of r -> T_A1(T_A2(r)) (transfer map of
+// merge(A1, A2), qmps/time_evolve_tools.py:20-23); r21 = T_A2(r12)/tr is the fixed point of the
+// swapped cell, so ONE power iteration serves both energies:
+//   E1 = sum h[s][t] tr(A1_t1 A2_t2 r12 A2_s2^+ A1_s1^+),  E2 = same with 1 <-> 2 and r21,  f = (E1+E2)/2.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void normalise_herm(double (&nre)[D][D], double (&nim)[D][D]) {
+  double tr = 0.0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) tr += nre[i][i];
+  const double inv = 1.0 / tr;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = i; j < D; ++j) {
+      nre[i][j] *= inv;
+      nim[i][j] = (i == j) ? 0.0 : nim[i][j] * inv;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ double rdm_energy(const double2* h, const double (&pre)[4][4], const double (&pim)[4][4]) {
+  double e = 0.0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double2 hv = h[s * 4 + t];
+      const double rr = (t <= s) ? pre[t][s] : pre[s][t];
+      e = dfma(hv.x, rr, e);
+      if (t != s) {
+        const double ri = (t < s) ? pim[t][s] : -pim[s][t];
+        e = dfma(-hv.y, ri, e);
+      }
+    }
+  return e;
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void cell2_lane_kernel(Cell2Args p) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= p.B) return;
+  double a1re[2][D][D], a1im[2][D][D], a2re[2][D][D], a2im[2][D][D];
+  {
+    const double2* u1 = (const double2*)p.U1 + b * (4 * D * D);
+    const double2* u2 = (const double2*)p.U2 + b * (4 * D * D);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const double2 v1 = u1[(2 * i + s) * (2 * D) + j], v2 = u2[(2 * i + s) * (2 * D) + j];
+          a1re[s][i][j] = v1.x; a1im[s][i][j] = v1.y;
+          a2re[s][i][j] = v2.x; a2im[s][i][j] = v2.y;
+        }
+  }
+  double rre[D][D], rim[D][D];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = i; j < D; ++j) {
+      rre[i][j] = (i == j) ? 1.0 / D : 0.0;
+      rim[i][j] = 0.0;
+    }
+  int iters = 0, status = QMPS_ST_NOT_CONVERGED;
+  const double tol2 = p.tol * p.tol;
+  for (int k = 1; k <= p.max_iter; ++k) {
+    double tre[D][D], tim[D][D], nre[D][D], nim[D][D];
+    power_step<D>(a2re, a2im, rre, rim, tre, tim);
+    power_step<D>(a1re, a1im, tre, tim, nre, nim);
+    normalise_herm<D>(nre, nim);
+    double d2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) {
+        const double dr = nre[i][j] - rre[i][j], di = nim[i][j] - rim[i][j];
+        d2 += (i == j) ? dr * dr : 2.0 * (dr * dr + di * di);
+        rre[i][j] = nre[i][j];
+        rim[i][j] = nim[i][j];
+      }
+    iters = k;
+    if (d2 < tol2) { status = QMPS_ST_OK; break; }
+  }
+  // environment of the swapped cell
+  double qre[D][D], qim[D][D];
+  power_step<D>(a2re, a2im, rre, rim, qre, qim);
+  normalise_herm<D>(qre, qim);
+  if (status == QMPS_ST_OK && !(is_positive_definite<D>(rre, rim) && is_positive_definite<D>(qre, qim)))
+    status = QMPS_ST_NOT_PD;
+  double p1re[4][4], p1im[4][4], p2re[4][4], p2im[4][4];
+  two_site_rdm<D>(a1re, a1im, a2re, a2im, rre, rim, p1re, p1im);
+  two_site_rdm<D>(a2re, a2im, a1re, a1im, qre, qim, p2re, p2im);
+  double tr1 = 0.0, tr2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) { tr1 += rre[i][i]; tr2 += qre[i][i]; }
+  for (int q = 0; q < p.n_terms; ++q) {
+    const double2* h = (const double2*)p.h + q * 16;
+    const double e1 = rdm_energy<D>(h, p1re, p1im) / tr1;
+    const double e2 = rdm_energy<D>(h, p2re, p2im) / tr2;
+    p.E[b * p.n_terms + q] = 0.5 * (e1 + e2);
+    if (p.E12 != nullptr) {
+      p.E12[(b * p.n_terms + q) * 2 + 0] = e1;
+      p.E12[(b * p.n_terms + q) * 2 + 1] = e2;
+    }
+  }
+  p.iters[b] = iters;
+  p.status[b] = status;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -753,6 +870,13 @@ hipError_t launch_energy(int D, const LaneArgs& a, bool solve, hipStream_t st) {
     case 16: return launch_block<16>(a, solve, st);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_cell2(int D, const Cell2Args& a, hipStream_t st) {
+  if (a.B <= 0) return hipSuccess;
+  if (D != 2) return hipErrorInvalidValue;  // the reference path is D = 2 only (ground_state.py:276)
+  hipLaunchKernelGGL((cell2_lane_kernel<2>), dim3((unsigned)((a.B + 63) / 64)), dim3(64), 0, st, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_unitary_to_tensor(const void* U, void* A, int D, int64_t B, hipStream_t st) {

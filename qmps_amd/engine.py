@@ -159,6 +159,23 @@ class EnergyEngine:
             self.n_terms = 1
         return r, it, st
 
+    def cell2_energies(self, U1, U2, h, max_iter=10000, tol=1e-13):
+        """Two-site unit cell (D = 2): U1, U2 (B,4,4) -> (E (B,n_terms) = (E1+E2)/2, iters, status)."""
+        U1 = _c128(U1, (2 * self.D, 2 * self.D), 'U1')
+        U2 = _c128(U2, (2 * self.D, 2 * self.D), 'U2')
+        if U1.shape != U2.shape:
+            raise ValueError('U1 and U2 must have the same shape')
+        h = np.ascontiguousarray(np.asarray(h, dtype=np.complex128).reshape(-1, 4, 4))
+        B, nt = U1.shape[0], h.shape[0]
+        E = np.empty((B, nt))
+        it = np.empty(B, dtype=np.int32)
+        st = np.empty(B, dtype=np.int32)
+        L.check(self._lib.qmps_cell2_energy_batch(self._ctx, B, _f64(U1.view(np.float64)), _f64(U2.view(np.float64)),
+                                                  _f64(h.view(np.float64)), nt, int(max_iter), float(tol), _f64(E),
+                                                  _i32(it), _i32(st)))
+        self.n_terms = nt
+        return E, it, st
+
     # -- timing / probes ----------------------------------------------------------------------
     def timer_begin(self):
         L.check(self._lib.qmps_timer_begin(self._ctx))

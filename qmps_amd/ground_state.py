@@ -1,0 +1,257 @@
+"""Host-side mirror of `qmps/ground_state.py` for the noiseless energy path.
+
+  Hamiltonian                              qmps/ground_state.py:66-118
+  SparseFullEnergyOptimizer                qmps/ground_state.py:120-168  (exact-environment objective)
+  NonSparseFullEnergyOptimizer             qmps/ground_state.py:230-269
+  NonSparseFullTwoSiteEnergyOptimizer      qmps/ground_state.py:271-335
+
+Every objective keeps the reference's contract - `objective_function(params) -> float`, previous
+value returned when the environment is not positive definite (the reference's caught
+`LinAlgError`, :153-157) - and gains `batch_objective_function(params[B,P]) -> float[B]`, one
+launch of the MI355X kernel for the whole batch (rotosolve shifts x restarts).
+
+Energies are computed in fp64.  (The reference simulates this path in cirq's default single
+precision, ground_state.py:160,165, so its own values carry ~1e-7 noise.)
+"""
+from functools import reduce
+from itertools import product
+
+import numpy as np
+from scipy.linalg import expm
+
+from . import _runtime
+from ._lib import STATUS_NOT_PD, STATUS_OK
+from .represent import (FullEnvironment, FullStateTensor, ShallowCNOTStateTensor, State, final_state,
+                        unitary)
+from .tools import Optimizer, get_env_exact
+
+π = np.pi
+
+Sx = np.array([[0, 1], [1, 0]], dtype=complex)
+Sy = np.array([[0, -1j], [1j, 0]], dtype=complex)
+Sz = np.array([[1, 0], [0, -1]], dtype=complex)
+S = {'I': np.eye(2), 'X': Sx, 'Y': Sy, 'Z': Sz}
+
+
+def paulis(_spin=0.5):
+    """Pauli matrices with +-1 eigenvalues - what `xmps.spin.paulis(0.5)` yields at
+    ground_state.py:29 (pinned by the 4x4 TFIM known answer, tests/test_ground_state.py:26-38)."""
+    return Sx, Sy, Sz
+
+
+def swap():
+    return np.eye(4)[[0, 2, 1, 3]].astype(complex)
+
+
+def _su_generators(N):
+    """Generalised Gell-Mann basis of su(N): N^2 - 1 traceless Hermitian matrices."""
+    gens = []
+    for a in range(N):
+        for b in range(a + 1, N):
+            m = np.zeros((N, N), dtype=complex)
+            m[a, b] = m[b, a] = 1
+            gens.append(m)
+            m = np.zeros((N, N), dtype=complex)
+            m[a, b], m[b, a] = -1j, 1j
+            gens.append(m)
+    for k in range(1, N):
+        m = np.zeros((N, N), dtype=complex)
+        m[np.arange(k), np.arange(k)] = 1
+        m[k, k] = -k
+        gens.append(m * np.sqrt(2.0 / (k * (k + 1))))
+    return gens
+
+
+_GEN_CACHE = {}
+
+
+def SU(params, N):
+    """exp(-i sum_k p_k G_k / 2) with G_k the generalised Gell-Mann matrices: a smooth
+    parameterisation of SU(N) by N^2 - 1 reals.  The reference takes `SU` from xmps.spin, whose
+    convention is not visible in the reference tree ("unpinned"): any onto smooth map
+    gives the same optimisation problem, and the batched entry points accept unitaries directly."""
+    if N not in _GEN_CACHE:
+        _GEN_CACHE[N] = np.stack(_su_generators(N))
+    G = _GEN_CACHE[N]
+    params = np.asarray(params, dtype=float)
+    if params.shape[0] != N * N - 1:
+        raise ValueError(f'SU({N}) takes {N * N - 1} parameters, got {params.shape[0]}')
+    return expm(-0.5j * np.tensordot(params, G, axes=1))
+
+
+def U4(params):
+    return SU(params, 4)
+
+
+class Hamiltonian:
+    """Two-site Hamiltonian from Pauli strings; a one-letter key 'X': g means g/2 (IX + XI)
+    (ground_state.py:66-88)."""
+
+    def __init__(self, strings=None):
+        self.strings = strings
+        if strings is not None:
+            for key, val in list(self.strings.items()):
+                if len(key) == 1:
+                    self.strings['I' + key] = val / 2
+                    self.strings[key + 'I'] = val / 2
+                    self.strings.pop(key)
+
+    def to_matrix(self):
+        assert self.strings is not None
+        h = np.zeros((4, 4), dtype=complex)
+        for js, J in self.strings.items():
+            h += J * reduce(np.kron, [S[j] for j in js])
+        self._matrix = h
+        return h
+
+    def term_matrices(self):
+        """One 4x4 matrix per Pauli string (J included): the per-term batch axis of the kernel."""
+        return {js: J * reduce(np.kron, [S[j] for j in js]) for js, J in self.strings.items()}
+
+    def from_matrix(self, mat):
+        keys = list(S.keys())
+        self.strings = {a + b: np.trace(np.kron(S[a], S[b]) @ mat) / 4 for a, b in product(keys, keys)}
+        del self.strings['II']
+        return self
+
+    def calculate_energy(self, ops, n_qubits, loc=0):
+        """<psi| 1^loc x H x 1^rest |psi> for the state prepared by `ops` on |0..0>
+        (ground_state.py:110-118, with this package's circuit model instead of cirq)."""
+        psi = final_state(ops, n_qubits)
+        H = reduce(np.kron, [np.eye(2)] * loc + [self.to_matrix()] + [np.eye(2)] * (n_qubits - loc - 2))
+        return float(np.real(psi.conj() @ H @ psi))
+
+
+def _as_h(H):
+    return H.to_matrix() if isinstance(H, Hamiltonian) else np.asarray(H, dtype=complex)
+
+
+class _GpuEnergyMixin:
+    """Shared plumbing: unitaries -> libqmps_hip -> energies, with the reference's error behaviour."""
+    max_iter = 10000
+    env_tol = 1e-13
+
+    def _energies_from_unitaries(self, U):
+        U = np.ascontiguousarray(U, dtype=np.complex128)
+        eng = _runtime.engine(self.D, U.shape[0])
+        E, it, st = eng.energies(U, _as_h(self.H), kind='unitary', max_iter=self.max_iter, tol=self.env_tol)
+        return E[:, 0], it, st
+
+
+class SparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
+    """Shallow-ansatz energy optimiser (ground_state.py:120-168).  `H` is the 4x4 matrix (or a
+    Hamiltonian); `state_tensor(D, params)` any gate class of represent.py."""
+
+    def __init__(self, H, D=2, depth=2, state_tensor=ShallowCNOTStateTensor, optimize_environment=False,
+                 env_depth=4, initial_guess=None, settings=None):
+        if optimize_environment:
+            raise NotImplementedError('objective_function_opt_environment (ground_state.py:170-228) is the '
+                                      'variational-environment variant, outside the first slice')
+        self.optimize_environment = optimize_environment
+        self.env_depth = env_depth
+        self.state_tensor = state_tensor
+        self.H = H
+        self.D = D
+        self.d = 2
+        initial_guess = np.array([np.random.randn(), np.random.randn()] * depth) if initial_guess is None \
+            else initial_guess
+        self.objective_function = self.objective_function_exact_environment
+        self.p = len(initial_guess)
+        self.f = 0
+        super().__init__(self.state_tensor(D, initial_guess), None, initial_guess)
+        if settings:
+            self.change_settings(settings)
+
+    def unitaries(self, params_batch):
+        return np.stack([unitary(self.state_tensor(self.D, p)) for p in np.atleast_2d(params_batch)])
+
+    def objective_function_exact_environment(self, u_params):
+        E, _, st = self._energies_from_unitaries(self.unitaries(u_params))
+        if st[0] != STATUS_OK:
+            # the reference catches cholesky's LinAlgError, prints and returns the previous value
+            print('LinAlgError')
+            return self.f
+        self.f = float(E[0])
+        return self.f
+
+    def batch_objective_function(self, params_batch):
+        """One kernel launch for B parameter vectors.  Entries whose environment is not positive
+        definite / not converged are NaN (there is no 'previous value' in a batch)."""
+        E, _, st = self._energies_from_unitaries(self.unitaries(params_batch))
+        return np.where(st == STATUS_OK, E, np.nan)
+
+    def update_state(self):
+        self.u = self.state_tensor(self.D, self.optimized_result.x)
+        self.U = unitary(self.u)
+
+
+class NonSparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
+    """Full SU(2D) parameterisation (ground_state.py:230-269).  `get_env_function` is kept for API
+    compatibility: when it is the default the environment is solved inside the energy kernel;
+    a user-supplied function U -> V is honoured through the state-vector path."""
+
+    def __init__(self, H, D=2, get_env_function=get_env_exact, initial_guess=None, settings=None):
+        self.env_function = get_env_function
+        self.H = H
+        self.D = D
+        self.d = 2
+        initial_guess = np.random.randn((2 * D) ** 2 - 1) if initial_guess is None else initial_guess
+        super().__init__(FullStateTensor(SU(initial_guess, 2 * D)), None, initial_guess)
+        if settings:
+            self.change_settings(settings)
+
+    def objective_function(self, u_params):
+        self.U = U = SU(u_params, 2 * self.D)
+        if self.env_function is not get_env_exact:
+            V = self.env_function(U)
+            n = int(2 + 2 * np.log2(self.D))
+            ops = State(FullStateTensor(U), FullEnvironment(V), 2)(*range(n))
+            psi = final_state(ops, n)
+            H = np.kron(np.kron(np.eye(self.D), _as_h(self.H)), np.eye(self.D))
+            return float(np.real(psi.conj() @ H @ psi))
+        E, _, st = self._energies_from_unitaries(U[None])
+        if st[0] == STATUS_NOT_PD:
+            raise np.linalg.LinAlgError('environment is not positive definite')  # uncaught in the reference too
+        return float(E[0])
+
+    def batch_objective_function(self, params_batch):
+        U = np.stack([SU(p, 2 * self.D) for p in np.atleast_2d(params_batch)])
+        E, _, st = self._energies_from_unitaries(U)
+        return np.where(st == STATUS_OK, E, np.nan)
+
+    def update_state(self):
+        self.U = SU(self.optimized_result.x, 2 * self.D)
+
+
+class NonSparseFullTwoSiteEnergyOptimizer(Optimizer):
+    """Two-site unit cell, D = 2 only (ground_state.py:271-335): 30 parameters, U1 = SU(p[:15], 4),
+    U2 = SU(p[15:], 4), f = (E1 + E2)/2."""
+    D = 2
+
+    def __init__(self, H, initial_guess=None):
+        self.H = H
+        super().__init__(initial_guess=np.random.randn(30) if initial_guess is None else initial_guess)
+
+    def _cell(self, U1, U2):
+        eng = _runtime.engine(2, U1.shape[0])
+        E, it, st = eng.cell2_energies(U1, U2, _as_h(self.H))
+        return E[:, 0], it, st
+
+    def objective_function(self, u_params):
+        self.U1 = U1 = SU(u_params[:15], 4)
+        self.U2 = U2 = SU(u_params[15:], 4)
+        E, _, st = self._cell(U1[None], U2[None])
+        if st[0] == STATUS_NOT_PD:
+            raise np.linalg.LinAlgError('environment is not positive definite')
+        return float(E[0])
+
+    def batch_objective_function(self, params_batch):
+        P = np.atleast_2d(params_batch)
+        U1 = np.stack([SU(p[:15], 4) for p in P])
+        U2 = np.stack([SU(p[15:], 4) for p in P])
+        E, _, st = self._cell(U1, U2)
+        return np.where(st == STATUS_OK, E, np.nan)
+
+    def update_state(self):
+        self.u1 = SU(self.optimized_result.x[:15], 4)
+        self.u2 = SU(self.optimized_result.x[15:], 4)

@@ -1,0 +1,310 @@
+"""Host-side mirror of the reference's `qmps/tools.py` for the hot path.
+
+Same names, argument meaning and error behaviour as the reference (fergusfinn/qmps), with the
+environment solve running on the MI355X:
+
+  unitary_to_tensor        qmps/tools.py:151-154
+  tensor_to_unitary        qmps/tools.py:123-148
+  unitary_extension        qmps/tools.py:76-94
+  environment_to_unitary   qmps/tools.py:97-108
+  environment_from_unitary qmps/tools.py:111-120
+  get_env_exact            qmps/tools.py:176-182   (eigen-solve -> libqmps_hip power iteration)
+  Optimizer                qmps/tools.py:203-284
+  double_rotosolve         qmps/tools.py:422-457
+  RotosolveResult          qmps/tools.py:459-464
+
+No cirq, no xmps: gates are plain unitary-producing objects (see represent.py).
+"""
+import numpy as np
+from scipy.linalg import cholesky, null_space
+from scipy.optimize import minimize, minimize_scalar
+
+from . import _runtime
+
+__all__ = ['unitary_to_tensor', 'tensor_to_unitary', 'unitary_extension', 'environment_to_unitary',
+           'environment_from_unitary', 'get_env_exact', 'get_env_exact_alternative', 'right_environment',
+           'Optimizer', 'OptimizerCircuit', 'double_rotosolve', 'RotosolveResult', 'random_unitary',
+           'haar_unitary', 'cT', 'direct_sum', 'eye_like', 'svals', 'from_real_vector', 'to_real_vector',
+           'split_2s', 'split_3s', 'split_ns']
+
+
+# ---------------------------------------------------------------------------------------------
+# small helpers (tools.py:36-73, 159-174)
+# ---------------------------------------------------------------------------------------------
+def random_unitary(*shape):
+    """Q factor of a REAL Gaussian matrix, as in the reference (tools.py:36-37)."""
+    return np.linalg.qr(np.random.randn(*shape))[0]
+
+
+def haar_unitary(n, rng=None):
+    """Complex Haar-like draw qr(randn + i randn)[0] (qmps/ansatze.py:30)."""
+    rng = np.random.default_rng() if rng is None else rng
+    return np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))[0]
+
+
+def svals(A):
+    return np.linalg.svd(A, compute_uv=False)
+
+
+def from_real_vector(v):
+    """[re..., im...] -> complex vector."""
+    v = np.asarray(v)
+    half = v.shape[0] // 2
+    return v[:half] + 1j * v[half:]
+
+
+def to_real_vector(A):
+    A = np.asarray(A)
+    return np.concatenate([A.real.reshape(-1), A.imag.reshape(-1)])
+
+
+def eye_like(A):
+    return np.eye(A.shape[0])
+
+
+def cT(tensor):
+    """Hermitian conjugate over the last two indices."""
+    return np.conj(np.swapaxes(tensor, -1, -2))
+
+
+def direct_sum(A, B):
+    out = np.zeros((A.shape[0] + B.shape[0], A.shape[1] + B.shape[1]), dtype=np.result_type(A, B))
+    out[:A.shape[0], :A.shape[1]] = A
+    out[A.shape[0]:, A.shape[1]:] = B
+    return out
+
+
+def _chunks(x, n):
+    return [x[i:i + n] for i in range(0, len(x), n)]
+
+
+def split_2s(x):
+    return _chunks(x, 2)
+
+
+def split_3s(x):
+    return _chunks(x, 3)
+
+
+def split_ns(x, n):
+    return _chunks(x, n)
+
+
+# ---------------------------------------------------------------------------------------------
+# tensor <-> unitary embeddings
+# ---------------------------------------------------------------------------------------------
+def unitary_to_tensor(U):
+    """A[s, i, j] = U[2 i + s, j] for j < D: the first input qubit is |0>, the last output qubit
+    is the physical index (tools.py:151-154)."""
+    U = np.asarray(U)
+    N = U.shape[0]
+    D = N // 2
+    return np.ascontiguousarray(U[:, :D].reshape(D, 2, D).transpose(1, 0, 2))
+
+
+def unitary_extension(Q, D=None):
+    """Complete an isometry to a unitary with null-space columns/rows (tools.py:76-94)."""
+    Q = np.asarray(Q)
+    rows, cols = Q.shape
+    if rows > cols:
+        out = np.concatenate([Q, null_space(Q.conj().T)], axis=1)
+    elif rows < cols:
+        out = np.concatenate([Q.conj().T, null_space(Q)], axis=1).conj().T
+    else:
+        out = Q
+    if D is not None and D > out.shape[0]:
+        out = direct_sum(out, np.eye(D - out.shape[0]))
+    return out
+
+
+def tensor_to_unitary(A, testing=False):
+    """Embed a left-isometric tensor A[s,i,j] in a unitary whose first D columns are
+    iso[(i,s), j] (tools.py:123-148).  With testing=True also returns the reference's five checks."""
+    d, D, _ = A.shape
+    iso = np.asarray(A).transpose(1, 0, 2).reshape(D * d, D)
+    U = unitary_extension(iso)
+    if testing:
+        n = U.shape[0]
+        ok = (np.allclose(iso.conj().T @ iso, np.eye(D)) and np.allclose(U @ U.conj().T, np.eye(n))
+              and np.allclose(U.conj().T @ U, np.eye(n)) and np.allclose(U[:, :D], iso)
+              and np.allclose(unitary_to_tensor(U), A))
+        return U, bool(ok)
+    return U
+
+
+def environment_to_unitary(v):
+    """vec(v)/||v|| becomes the first column of a unitary, completed by a null space
+    (tools.py:97-108).  Only that first column ever reaches the energy."""
+    row = np.asarray(v).reshape(1, -1)
+    row = row / np.linalg.norm(row)
+    rest = null_space(row).conj().T
+    return np.concatenate([row, rest], axis=0).T
+
+
+def environment_from_unitary(u):
+    """First column of u as a D x D matrix (tools.py:111-120; the reference hard-codes D = 2)."""
+    u = np.asarray(u)
+    D = int(round(np.sqrt(u.shape[0])))
+    return u[:, 0].reshape(D, D)
+
+
+# ---------------------------------------------------------------------------------------------
+# exact environment on the GPU
+# ---------------------------------------------------------------------------------------------
+def right_environment(U, max_iter=10000, tol=1e-13):
+    """Dominant right eigen-matrix r (Hermitian, tr r = 1) of the transfer map of
+    unitary_to_tensor(U) - what `TransferMatrix(A).eigs()` returns at tools.py:181, up to xmps's
+    normalisation - by the libqmps_hip power iteration.  Raises LinAlgError if it did not converge."""
+    U = np.asarray(U, dtype=np.complex128)
+    D = U.shape[0] // 2
+    eng = _runtime.engine(D, 1)
+    r, it, st = eng.env_batch(U[None], kind='unitary', max_iter=max_iter, tol=tol)
+    if st[0] == 1:
+        raise np.linalg.LinAlgError(f'right environment did not converge in {max_iter} power iterations')
+    return r[0]
+
+
+def get_env_exact(U):
+    """V = environment_to_unitary(cholesky(r)^dagger) (tools.py:176-182).  Raises
+    numpy.linalg.LinAlgError when r is not positive definite, like scipy's cholesky in the reference."""
+    r = right_environment(U)
+    return environment_to_unitary(cholesky(r).conj().T)
+
+
+def get_env_exact_alternative(U):
+    """tools.py:184-186 builds V from the mixed-canonical centre matrix C (r = C C^dagger); any
+    square root of r gives the same energy, so the Hermitian square root is used here."""
+    r = right_environment(U)
+    w, v = np.linalg.eigh(r)
+    if w.min() <= 0:
+        raise np.linalg.LinAlgError('environment is not positive definite')
+    return environment_to_unitary((v * np.sqrt(w)) @ v.conj().T)
+
+
+# ---------------------------------------------------------------------------------------------
+# Optimizer base class (tools.py:196-284) and rotosolve (tools.py:422-464)
+# ---------------------------------------------------------------------------------------------
+class OptimizerCircuit:
+    def __init__(self, circuit=None, total_qubits=None, aux_qubits=None):
+        self.circuit = circuit
+        self.total_qubits = total_qubits
+        self.aux_qubits = aux_qubits
+        self.qubits = None
+
+
+class RotosolveResult(object):
+    def __init__(self, history, fun, x, message):
+        self.history = history
+        self.fun = fun
+        self.x = x
+        self.message = message
+
+
+def _double_sinusoid_shift(M0, Mpi, Mp2, Mm2, Mp4, Mm4):
+    """Fit P sin(2x+u) + Q sin(x+v) through the six samples and return its wrapped minimiser
+    (tools.py:434-452)."""
+    A, Bv = M0 + Mpi, M0 - Mpi
+    C, Dv = Mp2 + Mm2, Mp2 - Mm2
+    E = Mp4 - Mm4
+    a, b = 0.25 * (2 * E - np.sqrt(2) * Dv), 0.25 * (A - C)
+    c, d = 0.5 * Dv, 0.5 * Bv
+    P, u = np.hypot(a, b), np.arctan2(b, a)
+    Q, v = np.hypot(c, d), np.arctan2(d, c)
+    th = minimize_scalar(lambda x: P * np.sin(2 * x + u) + Q * np.sin(x + v), bounds=[-np.pi, np.pi]).x
+    return np.arctan2(np.sin(th), np.cos(th))
+
+
+ROTO_SHIFTS = np.array([0.0, np.pi, np.pi / 2, -np.pi / 2, np.pi / 4, -np.pi / 4])
+
+
+def double_rotosolve(eps, initial_parameters, N_iters=100, disp=True, batch_eps=None):
+    """Double-frequency rotosolve (tools.py:422-457): per parameter, sample the objective at the
+    shifts {0, pi, +-pi/2, +-pi/4}, fit, move to the minimiser.  Updates `initial_parameters`
+    in place like the reference.  If `batch_eps` (params[B,P] -> float[B]) is given, the six
+    samples of a parameter are ONE launch on the GPU instead of ten scalar calls."""
+    params = initial_parameters
+    n = len(params)
+    history = []
+    for w in range(N_iters):
+        if disp:
+            print(w, ', ', sep='', end='', flush=True)
+        for i in range(n):
+            if batch_eps is not None:
+                P = np.repeat(np.asarray(params, dtype=float)[None], 6, axis=0)
+                P[:, i] += ROTO_SHIFTS
+                M = np.asarray(batch_eps(P), dtype=float).reshape(6, -1).sum(1)
+            else:
+                def one(x):
+                    q = np.array(params, dtype=float)
+                    q[i] += x
+                    return np.sum(eps(q))
+                M = [one(x) for x in ROTO_SHIFTS]
+            params[i] += _double_sinusoid_shift(*M)
+        if disp:
+            print('\n', sep='', end='', flush=True)
+        history.append(eps(params))
+    return RotosolveResult(history, history[-1], params, '')
+
+
+class Optimizer:
+    """Same contract as tools.py:203-284: subclasses bind/override `objective_function(params) ->
+    float`; `optimize()` dispatches on settings['method'] ('Rotosolve' -> double_rotosolve,
+    otherwise scipy.optimize.minimize) and then calls `update_state()`."""
+
+    def __init__(self, u=None, v=None, initial_guess=None, obj_fun=None, args=None):
+        self.u = u
+        self.v = v
+        self.initial_guess = initial_guess
+        self.iters = 0
+        self.optimized_result = None
+        self.obj_fun_values = []
+        self.settings = {'maxiter': 10000, 'verbose': True, 'method': 'Nelder-Mead', 'tol': 1e-8,
+                         'store_values': True, 'bayesian': False}
+        self.is_verbose = self.settings['verbose']
+        self.obj_fun = obj_fun
+        self.args = args
+        self.circuit = OptimizerCircuit()
+
+    def change_settings(self, new_settings):
+        return self.settings.update(new_settings)
+
+    def gate_from_params(self, params):
+        pass
+
+    def update_state(self):
+        pass
+
+    def callback_store_values(self, xk):
+        val = self.objective_function(xk)
+        self.obj_fun_values.append(val)
+        if self.settings['verbose']:
+            print(f'{self.iters}:{val}')
+        self.iters += 1
+
+    def objective_function(self, params):
+        if self.obj_fun is not None:
+            return self.obj_fun(params, *(self.args or ()))
+
+    def batch_objective_function(self, params_batch):
+        """Batched objective; subclasses with a GPU path override it."""
+        return np.array([self.objective_function(p) for p in params_batch])
+
+    def optimize(self):
+        s = self.settings
+        verbose = s['verbose']
+        if s['bayesian']:
+            raise NotImplementedError('bayesian (skopt) optimisation is outside the hot path')
+        if s['method'] == 'Rotosolve':
+            batch = self.batch_objective_function if type(self).batch_objective_function \
+                is not Optimizer.batch_objective_function else None
+            self.optimized_result = double_rotosolve(self.objective_function, self.initial_guess, s['maxiter'],
+                                                     verbose, batch_eps=batch)
+        else:
+            self.optimized_result = minimize(fun=self.objective_function, x0=self.initial_guess, method=s['method'],
+                                             tol=s['tol'], options={'maxiter': s['maxiter'], 'disp': verbose},
+                                             callback=self.callback_store_values if s['store_values'] else None)
+        self.update_state()
+        if verbose:
+            print(f'Reason for termination is {self.optimized_result.message} ' +
+                  f'\nObjective Function Value is {self.optimized_result.fun}')
+        return self.optimized_result

@@ -1,0 +1,70 @@
+"""CPU: the C-ABI library loads without a GPU, exports every symbol include/qmps_hip.h declares,
+and fails loudly (no CPU fallback) when asked to compute without a device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'qmps_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(qmps_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_symbols_exported_and_bound():
+    from qmps_amd import _lib
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/qmps_hip.h but not exported by libqmps_hip.so'
+    # the ctypes table binds exactly the declared entry points
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.qmps_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_device():
+    from qmps_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip('a GPU is visible here')
+    lib = _lib.load()
+    ctx = ctypes.c_void_p()
+    rc = lib.qmps_create(0, 4, 16, ctypes.byref(ctx))
+    assert rc == _lib.QMPS_ERR_NO_DEVICE and not ctx.value
+    assert b'no CPU fallback' in lib.qmps_last_error()
+    from qmps_amd import EnergyEngine
+    with pytest.raises(_lib.QmpsError):
+        EnergyEngine(4, 16)
+    # the reference-API objective fails loudly as well (it never routes to a CPU path)
+    import numpy as np
+    from qmps_amd.ground_state import Hamiltonian, SparseFullEnergyOptimizer
+    opt = SparseFullEnergyOptimizer(Hamiltonian({'ZZ': -1, 'X': 1}).to_matrix(), 2, 1,
+                                    initial_guess=np.array([0.1, 0.2]))
+    with pytest.raises(_lib.QmpsError):
+        opt.objective_function(np.array([0.1, 0.2]))
+
+
+def test_argument_validation_needs_no_device():
+    from qmps_amd import _lib
+    lib = _lib.load()
+    ctx = ctypes.c_void_p()
+    assert lib.qmps_create(0, 3, 16, ctypes.byref(ctx)) == _lib.QMPS_ERR_ARG      # D not a supported power of two
+    assert lib.qmps_create(0, 4, 0, ctypes.byref(ctx)) == _lib.QMPS_ERR_ARG
+    assert lib.qmps_sync(None) == _lib.QMPS_ERR_ARG
+    n = ctypes.c_int(-1)
+    assert lib.qmps_device_count(ctypes.byref(n)) == 0 and n.value >= 0
+
+
+def test_product_code_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under qmps_amd/ may import or load it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'qmps_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp', 'Makefile')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f'{f} imports the oracle'
+                assert 'libqmps_oracle' not in src and 'qmps_oracle_energy' not in src, f'{f} links the oracle'
+                assert not re.search(r'#include\s+[<"].*oracle', src), f'{f} includes oracle sources'

@@ -1,0 +1,214 @@
+"""CPU: the host-side mirror of the reference API (qmps_amd.tools / represent / ground_state /
+rotosolve / time_evolve_tools) against the reference-generated golden vectors and the oracle."""
+import numpy as np
+import pytest
+
+from oracle import qmps_oracle as O
+from qmps_amd import ground_state as G
+from qmps_amd import represent as R
+from qmps_amd import rotosolve as RS
+from qmps_amd import time_evolve_tools as TT
+from qmps_amd import tools as T
+
+
+@pytest.mark.parametrize('D', [2, 4, 8, 16])
+def test_unitary_to_tensor(D, golden):
+    for U, A in zip(golden[f'U_D{D}'], golden[f'ref_A_D{D}']):
+        assert np.array_equal(T.unitary_to_tensor(U), A)
+
+
+def test_tensor_to_unitary_roundtrip(golden):
+    """tests/test_tools.py:15-20."""
+    for A in golden['ref_A_D2']:
+        U, passed = T.tensor_to_unitary(A, testing=True)
+        assert passed and np.allclose(T.unitary_to_tensor(U), A)
+    for A in golden['ref_A_D4']:
+        U, passed = T.tensor_to_unitary(A, testing=True)
+        assert passed
+
+
+def test_unitary_to_tensor_shape_from_four_qubit_unitary():
+    """tests/test_tools.py:22-31: a 4-qubit unitary gives a (2, 8, 8) tensor."""
+    U = T.haar_unitary(16, np.random.default_rng(0))
+    assert T.unitary_to_tensor(U).shape == (2, 8, 8)
+
+
+@pytest.mark.parametrize('D', [2, 4, 8])
+def test_environment_embeddings(D, golden):
+    for L, V_ref in zip(golden[f'oracle_L_D{D}'], golden[f'ref_V_D{D}']):
+        V = T.environment_to_unitary(L)
+        assert np.allclose(V.conj().T @ V, np.eye(D * D)) and np.allclose(V[:, 0], V_ref[:, 0])
+        assert np.allclose(T.environment_from_unitary(V), L / np.linalg.norm(L))
+    assert np.allclose(T.environment_from_unitary(golden['ref_V_D2'][0]), golden['ref_env_from_unitary'])
+
+
+def test_small_helpers(golden):
+    v = golden['realvec_in']
+    assert np.allclose(T.from_real_vector(v), golden['ref_from_real_vector'])
+    assert np.allclose(T.to_real_vector(golden['ref_V_D2'][0]), golden['ref_to_real_vector'])
+    assert T.split_2s([1, 2, 3, 4]) == [[1, 2], [3, 4]] and T.split_3s(list(range(6))) == [[0, 1, 2], [3, 4, 5]]
+    A, B = np.ones((2, 2)), 2 * np.ones((1, 1))
+    assert np.array_equal(T.direct_sum(A, B), np.array([[1, 1, 0], [1, 1, 0], [0, 0, 2]]))
+    Q = T.random_unitary(4, 4)
+    assert np.isrealobj(Q) and np.allclose(Q.T @ Q, np.eye(4))          # tools.py:36-37 is a REAL QR
+    iso = T.haar_unitary(4, np.random.default_rng(1))[:, :2]
+    Uext = T.unitary_extension(iso)
+    assert np.allclose(Uext.conj().T @ Uext, np.eye(4)) and np.allclose(Uext[:, :2], iso)
+    assert T.unitary_extension(iso, D=6).shape == (6, 6)
+    assert np.allclose(T.cT(iso), iso.conj().T)
+
+
+def test_merge(golden):
+    A2 = golden['ref_A_D2']
+    for i in range(len(A2)):
+        assert np.allclose(TT.merge(A2[i], A2[(i + 1) % len(A2)]), golden['ref_merge_D2'][i])
+    A4 = golden['ref_A_D4']
+    assert TT.merge(A4[0], A4[1]).shape == (4, 4, 4)
+
+
+def test_env_site_embeddings():
+    """qmps/time_evolve_tools.py:133-166 / new_time_evolve.py:53-100 self-tests: round trips + unitarity."""
+    rng = np.random.default_rng(2)
+    for _ in range(10):
+        q = rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2))
+        A, n = TT.put_env_on_left_site(q, ret_n=True)
+        assert np.allclose(TT.get_env_off_left_site(A) * n, q) and np.allclose(A.conj().T @ A, np.eye(4))
+        A, n = TT.put_env_on_right_site(q, ret_n=True)
+        assert np.allclose(TT.get_env_off_right_site(A) * n, q) and np.allclose(A.conj().T @ A, np.eye(4))
+
+
+# ---- gates / ansatz -> unitary ---------------------------------------------------------------
+def test_ansatz_unitaries_match_golden(golden):
+    for p, U in zip(golden['cnot_params_D2'], golden['oracle_cnot_U_D2']):
+        assert np.allclose(R.unitary(R.ShallowCNOTStateTensor(2, p)), U)
+    for p, U in zip(golden['cnot_params_D4'], golden['oracle_cnot_U_D4']):
+        assert np.allclose(R.unitary(R.ShallowCNOTStateTensor(4, p)), U)
+    for p, U in zip(golden['full_params'], golden['oracle_full_U']):
+        assert np.allclose(R.unitary(R.ShallowFullStateTensor(2, p)), U)
+
+
+@pytest.mark.parametrize('cls,npar', [(R.ShallowQAOAStateTensor, 4), (R.ShallowCNOTStateTensor, 4),
+                                      (R.ShallowCNOTStateTensor3, 6), (R.ExactAfter4, 6)])
+@pytest.mark.parametrize('D', [2, 4])
+def test_every_ansatz_is_unitary(cls, npar, D):
+    p = np.random.default_rng(4).standard_normal(npar)
+    U = R.unitary(cls(D, p))
+    assert U.shape == (2 * D, 2 * D) and np.allclose(U.conj().T @ U, np.eye(2 * D))
+
+
+def test_other_gates():
+    rng = np.random.default_rng(6)
+    U = R.unitary(R.ShallowCNOTStateTensor_nonuniform(4, rng.standard_normal(12)))
+    assert np.allclose(U.conj().T @ U, np.eye(8))
+    assert R.ShallowCNOTStateTensor_nonuniform.params_per_iter(4) == 6
+    U = R.unitary(R.StateGate(rng.standard_normal(6)))
+    assert np.allclose(U.conj().T @ U, np.eye(4))
+    U = R.unitary(R.ShallowEnvironment(4, rng.standard_normal(4)))
+    assert U.shape == (16, 16) and np.allclose(U.conj().T @ U, np.eye(16))
+    # cirq's X**t: eigenvalue 1 on |+>, e^{i pi t} on |->
+    Xt = R.unitary(R.x_pow(0.3))
+    plus, minus = np.array([1, 1]) / np.sqrt(2), np.array([1, -1]) / np.sqrt(2)
+    assert np.allclose(Xt @ plus, plus) and np.allclose(Xt @ minus, np.exp(0.3j * np.pi) * minus)
+    assert np.allclose(R.unitary(R.zz_pow(0.5)), np.diag([1, 1j, 1j, 1]))
+    T2 = R.FullStateTensor(T.haar_unitary(4, rng))
+    assert np.allclose(R.unitary(T2 ** -1), T2.U.conj().T) and np.allclose((T2 ** 2).U, T2.U @ T2.U)
+
+
+@pytest.mark.parametrize('D', [2, 4])
+def test_state_wiring_matches_golden_statevector(D, golden):
+    """represent.py:258-262 register layout: State(U, V, 2) on |0..0> equals the golden psi."""
+    n = 2 + 2 * int(np.log2(D))
+    for U, V, psi in zip(golden[f'U_D{D}'], golden[f'ref_V_D{D}'], golden[f'oracle_psi_D{D}']):
+        st = R.State(R.FullStateTensor(U), R.FullEnvironment(V), 2)
+        assert st.num_qubits() == n and st.bond_dim == D
+        assert np.allclose(R.final_state(st(*R.line_qubits(n)), n), psi)
+        # Hamiltonian.calculate_energy on that circuit (ground_state.py:110-118) with loc = log2 D
+        H = G.Hamiltonian({'ZZ': -1, 'X': 1})
+        e = H.calculate_energy(st(*R.line_qubits(n)), n, loc=int(np.log2(D)))
+        assert abs(e - O.energy_statevector(U, golden['ref_h_tfim'], V)) < 1e-13
+
+
+def test_power_circuit():
+    """represent.py:235-248: K staggered copies of U on n + K - 1 qubits."""
+    U = T.haar_unitary(4, np.random.default_rng(8))
+    pc = R.FullStateTensor(U).raise_power(3)
+    assert pc.num_qubits() == 4
+    W = R.unitary(pc)
+    I = np.eye(2)
+    expect = np.kron(U, np.eye(4)) @ np.kron(I, np.kron(U, I)) @ np.kron(np.eye(4), U)
+    assert np.allclose(W, expect)
+
+
+# ---- Hamiltonian -----------------------------------------------------------------------------
+def test_hamiltonian(golden):
+    assert np.array_equal(G.Hamiltonian({'ZZ': -1, 'X': 1}).to_matrix(), golden['ref_h_tfim'])
+    assert np.array_equal(G.Hamiltonian({'ZZ': -1, 'IX': 0.5, 'XI': 0.5}).to_matrix(), golden['ref_h_tfim'])
+    assert np.allclose(G.Hamiltonian({'XX': 1, 'YY': 1, 'ZZ': 0.5}).to_matrix(), golden['ref_h_xxz'])
+    H = G.Hamiltonian({'ZZ': -1, 'X': 0.7})
+    assert set(H.strings) == {'ZZ', 'IX', 'XI'} and H.strings['IX'] == 0.35
+    terms = H.term_matrices()
+    assert np.allclose(sum(terms.values()), golden['ref_h_tfim_g07'])
+    back = G.Hamiltonian().from_matrix(golden['ref_h_xxz'])
+    assert np.allclose(back.to_matrix(), golden['ref_h_xxz'])
+    assert np.allclose(G.paulis(0.5)[2], np.diag([1, -1]))
+
+
+def test_SU_parameterisation():
+    rng = np.random.default_rng(9)
+    for N in (4, 8):
+        U = G.SU(rng.standard_normal(N * N - 1), N)
+        assert np.allclose(U.conj().T @ U, np.eye(N)) and abs(np.linalg.det(U) - 1) < 1e-10
+    assert np.allclose(G.SU(np.zeros(15), 4), np.eye(4))
+    with pytest.raises(ValueError):
+        G.SU(np.zeros(3), 4)
+
+
+# ---- optimiser plumbing (no GPU: objective injected) ---------------------------------------------
+def test_optimizer_base_contract():
+    opt = T.Optimizer(initial_guess=np.array([1.0, -2.0]), obj_fun=lambda p, a: float(np.sum((p - a) ** 2)),
+                      args=(np.array([0.5, 0.25]),))
+    opt.change_settings({'verbose': False, 'tol': 1e-12})
+    res = opt.optimize()
+    assert np.allclose(res.x, [0.5, 0.25], atol=1e-4) and len(opt.obj_fun_values) == opt.iters > 0
+
+
+def test_double_rotosolve_scalar_and_batched_agree():
+    """tools.py:422-457 on an exactly double-sinusoidal objective: one sweep reaches the coordinate
+    minimum; the batched sampler gives the same trajectory as the ten scalar calls."""
+    def eps(p):
+        return float(np.sin(2 * p[0] + 0.3) + 0.5 * np.sin(p[0] - 1) + 0.7 * np.sin(p[1] + 0.2) * np.cos(p[0]))
+
+    calls = []
+
+    def batch(P):
+        calls.append(len(P))
+        return np.array([eps(p) for p in P])
+
+    x1 = np.array([0.1, 0.2])
+    x2 = x1.copy()
+    r1 = T.double_rotosolve(eps, x1, N_iters=3, disp=False)
+    r2 = T.double_rotosolve(eps, x2, N_iters=3, disp=False, batch_eps=batch)
+    assert isinstance(r1, T.RotosolveResult) and r1.message == ''
+    assert np.allclose(r1.x, r2.x) and np.allclose(r1.history, r2.history)
+    assert r1.history[-1] <= r1.history[0] + 1e-12 and calls == [6] * 6
+    assert r1.x is x1                                   # updated in place like the reference
+
+
+def test_rotosolve_module_drivers():
+    H = np.diag([1.0, -1.0]).astype(complex)
+
+    def state(p):
+        return np.array([np.cos(p[0] / 2), np.sin(p[0] / 2) * np.exp(1j * p[1])])
+
+    es, hist = RS.rotosolve(H, state, np.array([0.3, 0.1]), N_iters=2)
+    assert abs(es[-1] + 1) < 1e-12                      # <Z> = cos(theta) -> -1 in one update
+    es2, p2 = RS.double_rotosolve(H, state, np.array([0.3, 0.1]), N_iters=2)
+    assert abs(es2[-1] + 1) < 1e-9
+
+    def batch_eps(P):
+        return np.array([np.real(state(p).conj() @ H @ state(p)) for p in P])
+
+    e3, p3 = RS.batched_rotosolve(batch_eps, np.array([[0.3, 0.1], [2.0, -1.0], [1.0, 0.5]]), N_iters=1)
+    assert e3.shape == (1, 3) and np.allclose(e3[-1], -1)
+    e4, p4 = RS.batched_double_rotosolve(batch_eps, np.array([[0.3, 0.1], [2.0, -1.0]]), N_iters=1)
+    assert np.allclose(e4[-1], -1, atol=1e-8)

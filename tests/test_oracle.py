@@ -1,0 +1,209 @@
+"""CPU: pin the oracle against the reference's golden vectors and known answers."""
+import numpy as np
+import pytest
+
+from oracle import qmps_oracle as O
+
+
+# ---- reference-generated vectors (tests/golden/make_golden.py, ref_* arrays) -------------------
+def test_hamiltonian_kat(golden):
+    """Exact 4x4 TFIM matrix of tests/test_ground_state.py:26-38 and the reference's own output."""
+    J, g = -1, 1
+    kat = np.array([[J, g / 2, g / 2, 0], [g / 2, -J, 0, g / 2], [g / 2, 0, -J, g / 2], [0, g / 2, g / 2, J]])
+    assert np.allclose(O.hamiltonian_matrix({'ZZ': -1, 'X': 1}), kat)
+    assert np.allclose(O.hamiltonian_matrix({'ZZ': -1, 'IX': 0.5, 'XI': 0.5}), kat)
+    assert np.array_equal(golden['ref_h_tfim'], O.hamiltonian_matrix({'ZZ': -1, 'X': 1}))
+    assert np.array_equal(golden['ref_h_tfim_split'], golden['ref_h_tfim'])
+    assert np.allclose(golden['ref_h_xxz'], O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5}))
+    assert np.allclose(golden['ref_h_xy'], O.hamiltonian_matrix({'XX': 1, 'YY': 1}))
+    assert np.allclose(golden['ref_h_tfim_g07'], O.hamiltonian_matrix({'ZZ': -1, 'X': 0.7}))
+
+
+@pytest.mark.parametrize('D', [2, 4, 8, 16])
+def test_unitary_to_tensor_matches_reference(D, golden, c_oracle):
+    U, A = golden[f'U_D{D}'], golden[f'ref_A_D{D}']
+    assert np.array_equal(O.unitary_to_tensor(U), A)
+    assert np.array_equal(c_oracle.unitary_to_tensor(U), A)
+    for a in A:  # left isometry
+        assert np.allclose(sum(x.conj().T @ x for x in a), np.eye(D))
+
+
+def test_tensor_to_unitary_reference_checks(golden):
+    """tools.py:131-137 five checks passed in the reference run; the round trip reproduces A."""
+    assert golden['ref_t2u_passed'].all()
+    assert np.allclose(golden['ref_t2u_roundtrip'], golden['ref_A_D2'])
+    for a, u_ref in zip(golden['ref_A_D2'], golden['ref_t2u_U']):
+        u = O.tensor_to_unitary(a)
+        assert np.allclose(u.conj().T @ u, np.eye(4))
+        assert np.allclose(u[:, :2], u_ref[:, :2])          # the isometry block is fixed,
+        assert np.allclose(O.unitary_to_tensor(u), a)      # the completion columns are arbitrary
+
+
+@pytest.mark.parametrize('D', [2, 4, 8])
+def test_environment_to_unitary_matches_reference(D, golden):
+    for L, V_ref in zip(golden[f'oracle_L_D{D}'], golden[f'ref_V_D{D}']):
+        V = O.environment_to_unitary(L)
+        assert np.allclose(V.conj().T @ V, np.eye(D * D))
+        assert np.allclose(V[:, 0], V_ref[:, 0])            # only column 0 is defined
+        assert np.allclose(V_ref[:, 0], L.reshape(-1) / np.linalg.norm(L))
+
+
+def test_merge_and_helpers_match_reference(golden):
+    A2 = golden['ref_A_D2']
+    for i in range(len(A2)):
+        assert np.allclose(O.merge(A2[i], A2[(i + 1) % len(A2)]), golden['ref_merge_D2'][i])
+    v = golden['realvec_in']
+    assert np.allclose(golden['ref_from_real_vector'], v[:4] + 1j * v[4:])
+
+
+# ---- double restatement: state-vector path == closed form ------------------------------------
+@pytest.mark.parametrize('D', [2, 4, 8])
+def test_statevector_equals_closed_form(D, golden):
+    h = golden['ref_h_tfim']
+    for U, A, r, V, E_sv, E_cf in zip(golden[f'U_D{D}'], golden[f'ref_A_D{D}'], golden[f'oracle_r_D{D}'],
+                                      golden[f'ref_V_D{D}'], golden[f'oracle_E_statevec_D{D}'],
+                                      golden[f'oracle_E_closed_D{D}']):
+        assert abs(E_sv - E_cf) < 1e-13
+        assert abs(O.energy_statevector(U, h, V) - E_sv) < 1e-13       # with the REFERENCE's V
+        assert abs(O.energy_closed_form(A, h, r) - E_cf) < 1e-13
+        assert abs(O.reference_structured_energy(U, h) - E_cf) < 1e-12  # full reference-structured path
+
+
+def test_statevector_by_explicit_kronecker_products():
+    """scripts/ground_state_finding.py:119-128: (U x 1 x 1)(1 x U x 1)(1 x 1 x V)|0000>, D = 2."""
+    rng = np.random.default_rng(5)
+    U = O.haar_unitaries(rng, 4, 1)[0]
+    V = O.get_env_exact(U)
+    I = np.eye(2)
+    mb = lambda ops: __import__('functools').reduce(np.kron, ops)  # noqa: E731
+    psi = mb([U, I, I]) @ mb([I, U, I]) @ mb([I, I, V]) @ mb([np.array([1, 0])] * 4)
+    assert np.allclose(psi, O.state_vector(U, V, 2))
+    Ha = -np.kron(O.SZ, O.SZ) + 0.5 * (np.kron(I, O.SX) + np.kron(O.SX, I))
+    e = np.real(psi.conj() @ mb([I, Ha, I]) @ psi)
+    assert abs(e - O.energy_closed_form(O.unitary_to_tensor(U), O.hamiltonian_matrix({'ZZ': -1, 'X': 1}))) < 1e-13
+
+
+def test_ansatz_by_explicit_kronecker_products():
+    """ShallowCNOTStateTensor(2, [b, g]) built by hand: CNOT(q0,q1) . (H x 1) . (rx x rx) . (rz x rz)."""
+    b, g = 0.37, -1.21
+    rz = np.diag([np.exp(-0.5j * b), np.exp(0.5j * b)])
+    c, s = np.cos(g / 2), np.sin(g / 2)
+    rx = np.array([[c, -1j * s], [-1j * s, c]])
+    Hd = np.array([[1, 1], [1, -1]]) / np.sqrt(2)
+    cnot = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]])
+    U = cnot @ np.kron(Hd, np.eye(2)) @ np.kron(rx, rx) @ np.kron(rz, rz)
+    assert np.allclose(U, O.shallow_cnot_unitary(2, [b, g]))
+    # D = 4: three qubits, ladder CNOT(q1,q2) then CNOT(q0,q1)
+    I = np.eye(2)
+    c12, c01 = np.kron(I, cnot), np.kron(cnot, I)
+    U4 = c01 @ c12 @ np.kron(Hd, np.eye(4)) @ np.kron(rx, np.kron(rx, rx)) @ np.kron(rz, np.kron(rz, rz))
+    assert np.allclose(U4, O.shallow_cnot_unitary(4, [b, g]))
+
+
+# ---- physics known answers --------------------------------------------------------------------
+def test_tfim_exact_energy_integral():
+    assert abs(O.tfim_exact_energy(1.0) - (-4 / np.pi)) < 1e-9    # tests/test_ground_state.py:101-102
+
+
+def test_variational_bounds(golden):
+    """E(params) >= E0_exact(g) (tests/test_ground_state.py:218) and, at D = 2, >= D2_gse
+    (scripts/noisy_optimization.py:93) for every state in the fixtures."""
+    E0 = O.tfim_exact_energy(1.0)
+    D2_gse = -1.269909412573
+    for D in (2, 4, 8, 16):
+        assert np.all(golden[f'oracle_E_closed_D{D}'] >= E0)
+    assert np.all(golden['oracle_cnot_E_D2'] >= D2_gse - 1e-9)
+    assert np.all(golden['oracle_cnot_E_D4'] >= E0)
+
+
+def test_reference_fixture_A(golden):
+    """fixtures/A.npy: header [d, D, n] then 8 complex numbers.  After left-canonicalisation
+    (QR gauge) the tensor runs through the oracle; the energy is bounded by D2_gse."""
+    flat = golden['ref_fixture_A_flat']
+    d, D, n = (int(x.real) for x in flat[:3])
+    assert (d, D, n) == (2, 2, 1)
+    A = flat[3:].reshape(d, D, D)
+    # left-canonical gauge: A_s -> l^{1/2} A_s l^{-1/2} with l the left fixed point
+    w, v = np.linalg.eig(O.transfer_matrix(A).T)
+    l = v[:, np.argmax(abs(w))].reshape(D, D)
+    l = l / np.trace(l)
+    l = (l + l.conj().T) / 2
+    ev, evec = np.linalg.eigh(l.T)
+    sq = (evec * np.sqrt(ev)) @ evec.conj().T
+    AL = np.stack([sq @ a @ np.linalg.inv(sq) for a in A]) / np.sqrt(abs(w).max())
+    assert np.allclose(sum(a.conj().T @ a for a in AL), np.eye(D), atol=1e-10)
+    E = O.energy_closed_form(AL, O.hamiltonian_matrix({'ZZ': -1, 'X': 1}))
+    assert -1.269909412573 - 1e-9 <= E <= 2.0
+
+
+@pytest.mark.parametrize('D', [2, 4, 8])
+def test_environment_fixed_point_properties(D, golden):
+    """tests/test_represent.py:23-31: r = C C^+ is a right eigenvector with eta = 1, identity a left one."""
+    for A, r in zip(golden[f'ref_A_D{D}'], golden[f'oracle_r_D{D}']):
+        assert np.allclose(O.apply_transfer(A, r), r, atol=1e-12)
+        assert np.allclose(np.einsum('sij,ik,skl->jl', A.conj(), np.eye(D), A), np.eye(D))
+        assert np.linalg.eigvalsh(r).min() > 0
+
+
+def test_bloch_vector_is_one_site_expectation():
+    """tests/test_represent.py:33-48: Bloch vector of qubit 1 of State(U,V) (n = 1) equals the
+    one-site expectation values tr(A_t r A_s^+) sigma[s,t]."""
+    rng = np.random.default_rng(11)
+    U = O.haar_unitaries(rng, 4, 1)[0]
+    A = O.unitary_to_tensor(U)
+    _, r = O.env_dense_eig(A)
+    V = O.environment_to_unitary(O.env_cholesky(r))
+    psi = O.state_vector(U, V, 1).reshape(2, 2, 2)        # [a, sigma, b]
+    rho1 = np.einsum('asb,atb->st', psi, psi.conj())
+    for P in (O.SX, O.SY, O.SZ):
+        lhs = np.real(np.trace(rho1 @ P))
+        rhs = np.real(sum(P[s, t] * np.trace(A[t] @ r @ A[s].conj().T) for s in range(2) for t in range(2)))
+        assert abs(lhs - rhs) < 1e-13
+
+
+# ---- power iteration: numpy twin == C twin; agrees with dense eig ------------------------------
+@pytest.mark.parametrize('D', [2, 4, 8, 16])
+def test_c_oracle_equals_numpy_oracle(D, golden, c_oracle):
+    A, h = golden[f'ref_A_D{D}'], golden['ref_h_tfim']
+    out = c_oracle.energy_batch(A, h, want_r=True, want_rho=True)
+    assert np.array_equal(out['iters'], golden[f'oracle_iters_D{D}'])
+    assert np.abs(out['E'][:, 0] - golden[f'oracle_E_power_D{D}']).max() < 1e-13
+    assert np.abs(out['E'][:, 0] - golden[f'oracle_E_closed_D{D}']).max() < 1e-11
+    assert np.abs(out['r'] - golden[f'oracle_r_D{D}']).max() < 1e-11
+    for a, r, rho in zip(A, out['r'], out['rho']):
+        assert np.allclose(rho, O.two_site_rdm(a, r), atol=1e-13)
+        assert abs(np.trace(rho) - 1) < 1e-12
+
+
+def test_c_oracle_status_codes(c_oracle):
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+    rng = np.random.default_rng(3)
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 8, 5))
+    out = c_oracle.energy_batch(A, h, max_iter=3)
+    assert np.all(out['status'] == 1) and np.all(out['iters'] == 3)
+    prod = O.unitary_to_tensor(np.eye(8, dtype=complex)[None])
+    out = c_oracle.energy_batch(prod, h)
+    assert out['status'][0] == 2 and abs(out['E'][0, 0] + 1.0) < 1e-12
+
+
+def test_two_site_cell_oracle(golden):
+    h = golden['ref_h_tfim']
+    for U1, U2, E in zip(golden['cell_U1'], golden['cell_U2'], golden['oracle_cell_E']):
+        A1, A2 = O.unitary_to_tensor(U1), O.unitary_to_tensor(U2)
+        assert abs(O.two_site_cell_energy_closed(A1, A2, h) - E) < 1e-12
+    # a uniform cell (U1 == U2) reduces to the single-site energy
+    U = golden['U_D2'][0]
+    assert abs(O.two_site_cell_energy(U, U, h) - golden['oracle_E_closed_D2'][0]) < 1e-12
+
+
+def test_rotosolve_updates():
+    th = np.linspace(-3, 3, 7)
+    for a, b, c in [(0.3, 1.1, -0.2), (-0.7, 0.4, 2.0)]:
+        f = lambda x: a * np.sin(x + b) + c  # noqa: E731
+        x0 = 0.4
+        d = O.rotosolve_update(f(x0), f(x0 + np.pi / 2), f(x0 - np.pi / 2))
+        assert f(x0 + d) <= min(f(x0 + t) for t in th) + 1e-12
+    g = lambda x: 0.8 * np.sin(2 * x + 0.3) + 0.5 * np.sin(x - 1.0)  # noqa: E731
+    d = O.double_rotosolve_update(*[g(0.2 + s) for s in O.ROTO_SHIFTS])
+    xs = np.linspace(-np.pi, np.pi, 20001)
+    assert g(0.2 + d) <= g(xs).min() + 1e-6

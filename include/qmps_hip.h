@@ -60,7 +60,14 @@ extern "C" {
                              /* library applies unitary_to_tensor (tools.py:151-154)  */
 
 /* environment solver selection (flags of qmps_energy_launch) */
-#define QMPS_ENV_POWER 0 /* normalised power iteration (default; `krylov`, PowerCircuit) */
+#define QMPS_ENV_POWER 0 /* plain normalised power iteration (`krylov`, PowerCircuit) to convergence */
+/* Power iteration with a repeated-squaring tail (D = 2, 4; identical to QMPS_ENV_POWER for D = 8, 16):
+ * `handoff` plain steps (default 64 at D = 2, 128 at D = 4), then items that have not converged
+ * continue with the power method applied 2^m steps at a time, P_m = T^(2^m) obtained by squaring the
+ * D^2 x D^2 transfer matrix, r_m = herm(P_m r)/tr, until ||r_m - r_{m-1}||_F < tol.  Same fixed
+ * point, same tolerance; `iters` reports the equivalent number of power steps handoff + 2^m.
+ * This is the default of the one-shot entry points. */
+#define QMPS_ENV_POWER_SQUARING 1
 
 typedef struct qmps_ctx qmps_ctx;
 
@@ -95,6 +102,11 @@ int qmps_set_env_guess(qmps_ctx* ctx, int64_t B, const double* r0);
  * qmps/represent.py:258-262 (State) + qmps/ground_state.py:159-167 (psi^+ H psi).
  * tol: stop when ||r' - r||_F < tol;  max_iter >= 1;  flags: QMPS_ENV_*.  Asynchronous. */
 int qmps_energy_launch(qmps_ctx* ctx, int64_t B, int max_iter, double tol, int flags);
+/* number of plain power steps before the squaring tail of QMPS_ENV_POWER_SQUARING (0 disables it) */
+int qmps_set_handoff(qmps_ctx* ctx, int handoff);
+int qmps_get_handoff(qmps_ctx* ctx, int* handoff);
+/* solver used by qmps_energy_batch / qmps_env_batch (default QMPS_ENV_POWER_SQUARING) */
+int qmps_set_default_solver(qmps_ctx* ctx, int solver);
 /* Energy only, from the resident states and the resident environments (no solve): the
  * contraction chain A-Abar-h-A-Abar of the north star.  Asynchronous. */
 int qmps_energy_only_launch(qmps_ctx* ctx, int64_t B);

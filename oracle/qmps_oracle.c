@@ -52,17 +52,74 @@ static void matmul_h(int D, const cplx* X, const cplx* Y, cplx* C) {
 }
 
 /* one evaluation; A = [2][D][D] complex, h = [nt][4][4] complex, r0 nullable [D][D] */
+/* hermitise + trace-normalise rn in place */
+static void herm_normalise(int D, cplx* rn) {
+  double tr = 0;
+  for (int i = 0; i < D; ++i) tr += rn[i * D + i].re;
+  for (int i = 0; i < D; ++i)
+    for (int j = i; j < D; ++j) {
+      cplx a = rn[i * D + j], b = rn[j * D + i];
+      cplx m = {0.5 * (a.re + b.re) / tr, 0.5 * (a.im - b.im) / tr};
+      if (i == j) m.im = 0;
+      rn[i * D + j] = m;
+      rn[j * D + i].re = m.re; rn[j * D + i].im = -m.im;
+    }
+}
+
+/* Repeated-squaring tail (D <= 4): P_m = T^(2^m) as a D^2 x D^2 matrix, r_m = herm(P_m r_C)/tr,
+ * stop when ||r_m - r_{m-1}||_F^2 < tol^2; returns the equivalent number of power steps. */
+static int squaring_tail(int D, const cplx* A, cplx* r, int done, int max_iter, double tol2, int* st) {
+  const int n = D * D;
+  static _Thread_local cplx P[256 * 256], Q[256 * 256];
+  cplx rC[256], rn[256];
+  for (int i = 0; i < D; ++i) for (int ip = 0; ip < D; ++ip)
+    for (int j = 0; j < D; ++j) for (int jp = 0; jp < D; ++jp) {
+      cplx acc = {0, 0};
+      for (int s = 0; s < 2; ++s) acc = cadd(acc, cmulc(A[s * n + i * D + j], A[s * n + ip * D + jp]));
+      P[(i * D + ip) * n + (j * D + jp)] = acc;
+    }
+  memcpy(rC, r, sizeof(cplx) * n);
+  int m = 0, it = done;
+  while (done + (1 << (m + 1)) <= max_iter && m < 29) {
+    for (int a = 0; a < n; ++a)
+      for (int b = 0; b < n; ++b) {
+        cplx acc = {0, 0};
+        for (int k = 0; k < n; ++k) acc = cadd(acc, cmul(P[a * n + k], P[k * n + b]));
+        Q[a * n + b] = acc;
+      }
+    memcpy(P, Q, sizeof(cplx) * n * n);
+    ++m;
+    for (int a = 0; a < n; ++a) {
+      cplx acc = {0, 0};
+      for (int k = 0; k < n; ++k) acc = cadd(acc, cmul(P[a * n + k], rC[k]));
+      rn[a] = acc;
+    }
+    herm_normalise(D, rn);
+    double d2 = 0;
+    for (int e = 0; e < n; ++e) {
+      double dr = rn[e].re - r[e].re, di = rn[e].im - r[e].im;
+      d2 += dr * dr + di * di;
+    }
+    memcpy(r, rn, sizeof(cplx) * n);
+    it = done + (1 << m);
+    if (d2 < tol2) { *st = 0; return it; }
+  }
+  *st = 1;
+  return it;
+}
+
 static void eval_one(int D, const cplx* A, const cplx* h, int nt, const cplx* r0, int max_iter, double tol,
-                     double* E, int* iters, int* status, cplx* r_out, cplx* rho_out) {
+                     int handoff, double* E, int* iters, int* status, cplx* r_out, cplx* rho_out) {
   cplx r[DMAX * DMAX], rn[DMAX * DMAX], X[DMAX * DMAX], T[DMAX * DMAX];
   const int n = D * D;
-  if (r0) memcpy(r, r0, sizeof(cplx) * n);
+  if (r0) { memcpy(r, r0, sizeof(cplx) * n); herm_normalise(D, r); }
   else
     for (int i = 0; i < D; ++i)
       for (int j = 0; j < D; ++j) { r[i * D + j].re = (i == j) ? 1.0 / D : 0.0; r[i * D + j].im = 0.0; }
   int it = 0, st = 1;
   const double tol2 = tol * tol;
-  for (int k = 1; k <= max_iter; ++k) {
+  const int plain = (handoff > 0 && handoff < max_iter) ? handoff : max_iter;
+  for (int k = 1; k <= plain; ++k) {
     /* rn = sum_s A_s r A_s^+ */
     for (int e = 0; e < n; ++e) { rn[e].re = 0; rn[e].im = 0; }
     for (int s = 0; s < 2; ++s) {
@@ -70,17 +127,7 @@ static void eval_one(int D, const cplx* A, const cplx* h, int nt, const cplx* r0
       matmul_h(D, X, A + s * n, T);
       for (int e = 0; e < n; ++e) rn[e] = cadd(rn[e], T[e]);
     }
-    /* hermitise, trace-normalise */
-    double tr = 0;
-    for (int i = 0; i < D; ++i) tr += rn[i * D + i].re;
-    for (int i = 0; i < D; ++i)
-      for (int j = i; j < D; ++j) {
-        cplx a = rn[i * D + j], b = rn[j * D + i];
-        cplx m = {0.5 * (a.re + b.re) / tr, 0.5 * (a.im - b.im) / tr};
-        if (i == j) m.im = 0;
-        rn[i * D + j] = m;
-        rn[j * D + i].re = m.re; rn[j * D + i].im = -m.im;
-      }
+    herm_normalise(D, rn);
     double d2 = 0;
     for (int e = 0; e < n; ++e) {
       double dr = rn[e].re - r[e].re, di = rn[e].im - r[e].im;
@@ -90,6 +137,7 @@ static void eval_one(int D, const cplx* A, const cplx* h, int nt, const cplx* r0
     it = k;
     if (d2 < tol2) { st = 0; break; }
   }
+  if (st == 1 && handoff > 0 && plain < max_iter) it = squaring_tail(D, A, r, plain, max_iter, tol2, &st);
   /* Cholesky positive-definiteness check (LAPACK zpotrf criterion: pivot <= 0 or NaN fails) */
   if (st == 0) {
     cplx L[DMAX * DMAX];
@@ -139,10 +187,11 @@ static void eval_one(int D, const cplx* A, const cplx* h, int nt, const cplx* r0
 
 /* Batched entry point.  A: [B][2][D][D] complex128 (numpy C order); h: [nt][4][4]; r0 nullable
  * [B][D][D]; E: [B][nt]; iters,status: [B]; r_out nullable [B][D][D]; rho_out nullable [B][4][4].
- * threads <= 0 -> 1.  Returns 0, or -1 on bad arguments. */
+ * threads <= 0 -> 1.  handoff > 0: plain power steps before the repeated-squaring tail (0 = plain
+ * only).  Returns 0, or -1 on bad arguments. */
 int qmps_oracle_energy_batch(int D, long B, const double* A, const double* h, int nt, const double* r0,
                              int max_iter, double tol, double* E, int* iters, int* status, double* r_out,
-                             double* rho_out, int threads) {
+                             double* rho_out, int threads, int handoff) {
   if (D < 1 || D > DMAX || B < 0 || nt < 1 || !A || !h || !E || !iters || !status) return -1;
   const long n = (long)D * D;
 #ifdef _OPENMP
@@ -151,7 +200,7 @@ int qmps_oracle_energy_batch(int D, long B, const double* A, const double* h, in
 #endif
   for (long b = 0; b < B; ++b)
     eval_one(D, (const cplx*)A + b * 2 * n, (const cplx*)h, nt, r0 ? (const cplx*)r0 + b * n : NULL, max_iter, tol,
-             E + b * nt, iters + b, status + b, r_out ? (cplx*)r_out + b * n : NULL,
+             handoff, E + b * nt, iters + b, status + b, r_out ? (cplx*)r_out + b * n : NULL,
              rho_out ? (cplx*)rho_out + b * 16 : NULL);
   (void)threads;
   return 0;

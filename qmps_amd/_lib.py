@@ -16,6 +16,7 @@ QMPS_ERR_ARG, QMPS_ERR_HIP, QMPS_ERR_NO_DEVICE, QMPS_ERR_STATE, QMPS_ERR_RCCL = 
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_NOT_PD = 0, 1, 2
 INPUT_TENSOR, INPUT_UNITARY = 0, 1
 ENV_POWER = 0
+ENV_POWER_SQUARING = 1
 UNIQUE_ID_BYTES = 128
 
 _dp = POINTER(c_double)
@@ -34,6 +35,9 @@ SIGNATURES = {
     'qmps_set_hamiltonian': (c_int, [c_void_p, c_int, _dp]),
     'qmps_set_env_guess': (c_int, [c_void_p, c_int64, _dp]),
     'qmps_energy_launch': (c_int, [c_void_p, c_int64, c_int, c_double, c_int]),
+    'qmps_set_handoff': (c_int, [c_void_p, c_int]),
+    'qmps_get_handoff': (c_int, [c_void_p, POINTER(c_int)]),
+    'qmps_set_default_solver': (c_int, [c_void_p, c_int]),
     'qmps_energy_only_launch': (c_int, [c_void_p, c_int64]),
     'qmps_sum_energies': (c_int, [c_void_p, c_int64, _dp]),
     'qmps_get_energies': (c_int, [c_void_p, c_int64, _dp, _ip, _ip]),

@@ -61,6 +61,10 @@ struct qmps_ctx {
   double* d_partial = nullptr;  // [16][kSumBlocks]
   double* d_cost = nullptr;     // [16]
   double* h_cost = nullptr;     // pinned [16]
+  int32_t* d_work_count = nullptr;  // [1]  hybrid solve: number of slow items handed to the squaring tail
+  int32_t* d_work_idx = nullptr;    // [max_batch]
+  int handoff = 0;                  // plain power steps before the squaring tail (set in qmps_create)
+  int default_solver = 1;           // solver of the one-shot entry points (QMPS_ENV_POWER_SQUARING)
   // state
   int n_terms = 0;
   int64_t n_states = 0;
@@ -101,6 +105,7 @@ int check_B(const qmps_ctx* c, int64_t B) {
 
 qmps::LaneArgs make_args(qmps_ctx* c, int64_t B, int max_iter, double tol, bool solve) {
   qmps::LaneArgs a;
+  memset(&a, 0, sizeof(a));
   a.A = c->d_A;
   a.h = c->d_h;
   a.r_in = solve ? (c->have_guess ? c->d_r : nullptr) : c->d_r;
@@ -181,6 +186,10 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     HIP_TRY(hipMalloc((void**)&c->d_partial, (size_t)kMaxTerms * kSumBlocks * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->d_cost, kMaxTerms * sizeof(double)));
     HIP_TRY(hipHostMalloc((void**)&c->h_cost, kMaxTerms * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&c->d_work_count, sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&c->d_work_idx, (size_t)max_batch * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(c->d_work_count, 0, sizeof(int32_t), c->stream));
+    c->handoff = (D == 2) ? 64 : 128;
     return QMPS_OK;
   }();
   if (rc != QMPS_OK) {
@@ -199,7 +208,7 @@ int qmps_destroy(qmps_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)ncclCommDestroy(c->comm);
-  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost};
+  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_work_count, c->d_work_idx};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
@@ -269,10 +278,60 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "qmps_set_hamiltonian has not been called");
   if (max_iter < 1) return fail(QMPS_ERR_ARG, "max_iter must be >= 1");
   if (!(tol > 0.0)) return fail(QMPS_ERR_ARG, "tol must be > 0");
-  if ((flags & 0xff) != QMPS_ENV_POWER) return fail(QMPS_ERR_ARG, "unknown environment solver %d", flags & 0xff);
+  const int solver = flags & 0xff;
+  if (solver != QMPS_ENV_POWER && solver != QMPS_ENV_POWER_SQUARING)
+    return fail(QMPS_ERR_ARG, "unknown environment solver %d", solver);
   qmps::LaneArgs a = make_args(c, B, max_iter, tol, true);
-  HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
+  const bool hybrid = solver == QMPS_ENV_POWER_SQUARING && c->D <= 4 && c->handoff > 0 && c->handoff < max_iter;
+  if (!hybrid) {
+    HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
+  } else if (c->D == 2) {
+    a.handoff = c->handoff;  // the squaring tail runs in-lane (4 x 4 transfer matrix in registers)
+    HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
+  } else {
+    // D = 4: (1) lane kernel, `handoff` plain steps, slow items -> worklist; (2) wave-per-item MFMA
+    // squaring tail over the worklist; (3) energy-only pass over the worklist.  No host round trip:
+    // the later kernels read the item count from HBM.
+    HIP_TRY(hipMemsetAsync(c->d_work_count, 0, sizeof(int32_t), c->stream));
+    a.handoff = c->handoff;
+    a.work_count = c->d_work_count;
+    a.work_idx = c->d_work_idx;
+    HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
+    qmps::SquareArgs q;
+    q.A = c->d_A; q.r = c->d_r; q.iters = c->d_iters; q.status = c->d_status;
+    q.work_count = c->d_work_count; q.work_idx = c->d_work_idx;
+    q.done = c->handoff; q.max_iter = max_iter; q.tol = tol;
+    int grid = (int)((B + 7) / 8);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    HIP_TRY(qmps::launch_square_tail(c->D, q, grid, c->stream));
+    qmps::LaneArgs e = make_args(c, B, 1, 1.0, false);
+    e.idx_list = c->d_work_idx;
+    e.idx_count = c->d_work_count;
+    e.check_pd = 1;
+    HIP_TRY(qmps::launch_energy(c->D, e, false, c->stream));
+  }
   c->have_env = true;
+  return QMPS_OK;
+}
+
+int qmps_set_handoff(qmps_ctx* c, int handoff) {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  if (handoff < 0) return fail(QMPS_ERR_ARG, "handoff must be >= 0");
+  c->handoff = handoff;
+  return QMPS_OK;
+}
+
+int qmps_set_default_solver(qmps_ctx* c, int solver) {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  if (solver != QMPS_ENV_POWER && solver != QMPS_ENV_POWER_SQUARING) return fail(QMPS_ERR_ARG, "unknown solver %d", solver);
+  c->default_solver = solver;
+  return QMPS_OK;
+}
+
+int qmps_get_handoff(qmps_ctx* c, int* handoff) {
+  if (!c || !handoff) return fail(QMPS_ERR_ARG, "null argument");
+  *handoff = c->handoff;
   return QMPS_OK;
 }
 
@@ -348,7 +407,7 @@ int qmps_energy_batch(qmps_ctx* c, int64_t B, const double* states, int kind, co
   if (int rc = qmps_set_states(c, B, states, kind)) return rc;
   if (int rc = qmps_set_hamiltonian(c, n_terms, h)) return rc;
   if (int rc = qmps_set_env_guess(c, B, r0)) return rc;
-  if (int rc = qmps_energy_launch(c, B, max_iter, tol, QMPS_ENV_POWER)) return rc;
+  if (int rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver)) return rc;
   return qmps_get_energies(c, B, E_out, iters_out, status_out);
 }
 
@@ -363,7 +422,7 @@ int qmps_env_batch(qmps_ctx* c, int64_t B, const double* states, int kind, const
     if (int rc = qmps_set_hamiltonian(c, 1, zero)) return rc;
   }
   if (int rc = qmps_set_env_guess(c, B, r0)) return rc;
-  if (int rc = qmps_energy_launch(c, B, max_iter, tol, QMPS_ENV_POWER)) return rc;
+  if (int rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver)) return rc;
   if (int rc = qmps_get_energies(c, B, nullptr, iters_out, status_out)) return rc;
   return qmps_get_env(c, B, r_out);
 }

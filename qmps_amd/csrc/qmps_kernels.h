@@ -7,7 +7,7 @@ namespace qmps {
 
 enum { QMPS_ST_OK = 0, QMPS_ST_NOT_CONVERGED = 1, QMPS_ST_NOT_PD = 2 };
 
-// Kernel arguments of the energy kernels (all pointers are HBM addresses).
+// Kernel arguments of the energy kernels (zero-initialise, then fill) (all pointers are HBM addresses).
 struct LaneArgs {
   const void* A;      // [B][2][D][D] complex128
   const void* h;      // [n_terms][4][4] complex128
@@ -21,7 +21,30 @@ struct LaneArgs {
   int n_terms;
   int max_iter;
   double tol;
+  // hybrid solve: `handoff` plain power steps, then the repeated-squaring tail (0 = plain only)
+  int handoff;
+  int32_t* work_count;        // D = 4: slow items are appended to work_idx (wave-aggregated atomics)
+  int32_t* work_idx;
+  // list mode (energy-only pass over the worklist): evaluation ids come from idx_list[0 .. *idx_count)
+  const int32_t* idx_list;
+  const int32_t* idx_count;
+  int check_pd;               // !SOLVE: Cholesky test of the resident r, status 0 -> 2 on failure
 };
+
+// D = 4 repeated-squaring tail over the worklist (one wave per item, MFMA f64 16x16x4)
+struct SquareArgs {
+  const void* A;
+  void* r;                    // in: r after `done` plain steps; out: converged environment
+  int32_t* iters;
+  int32_t* status;
+  const int32_t* work_count;
+  const int32_t* work_idx;
+  int done;                   // plain steps already taken
+  int max_iter;
+  double tol;
+};
+
+hipError_t launch_square_tail(int D, const SquareArgs& a, int grid, hipStream_t st);
 
 // Two-site unit cell (NonSparseFullTwoSiteEnergyOptimizer): state unitaries U1, U2 [B][2D][2D].
 struct Cell2Args {

@@ -242,33 +242,177 @@ struct LaneCfg {
   static constexpr int kChunks = kRowBytes / 16;        // 16-B pieces per tensor == loads per lane
 };
 
+__device__ __forceinline__ double rdm_energy(const double2* h, const double (&pre)[4][4], const double (&pim)[4][4]) {
+  double e = 0.0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double2 hv = h[s * 4 + t];
+      const double rr = (t <= s) ? pre[t][s] : pre[s][t];
+      e = dfma(hv.x, rr, e);
+      if (t != s) {
+        const double ri = (t < s) ? pim[t][s] : -pim[s][t];
+        e = dfma(-hv.y, ri, e);
+      }
+    }
+  return e;
+}
+
+// normalise a freshly computed power step in place and return ||n - r||_F^2
+template <int D>
+__device__ __forceinline__ double normalise_and_diff(double (&nre)[D][D], double (&nim)[D][D],
+                                                     const double (&rre)[D][D], const double (&rim)[D][D]) {
+  double tr = 0.0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) tr += nre[i][i];
+  const double inv = 1.0 / tr;
+  double dd = 0.0, od = 0.0;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = i; j < D; ++j) {
+      nre[i][j] *= inv;
+      const double dr = nre[i][j] - rre[i][j];
+      if (i == j) {
+        nim[i][j] = 0.0;
+        dd = dfma(dr, dr, dd);
+      } else {
+        nim[i][j] *= inv;
+        const double di = nim[i][j] - rim[i][j];
+        od = dfma(dr, dr, od);
+        od = dfma(di, di, od);
+      }
+    }
+  return dfma(2.0, od, dd);
+}
+
+// D = 2 only: repeated-squaring tail, one evaluation per lane.  P = T^(2^m) as a 4 x 4 complex matrix in
+// registers (index (i,i') -> 2 i + i'), r_m = herm(P vec(r_C))/tr, stop at ||r_m - r_{m-1}||_F^2 < tol^2.
+__device__ __forceinline__ void squaring_tail_d2(const double (&are)[2][2][2], const double (&aim)[2][2][2],
+                                                 double (&rre)[2][2], double (&rim)[2][2], bool& active, int& iters,
+                                                 int& status, int done, int max_iter, double tol2) {
+  double pr[4][4], pi[4][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          double er = 0.0, ei = 0.0;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {  // A_s[i][j] * conj(A_s[ip][jp])
+            er = dfma(are[s][i][j], are[s][ip][jp], er);
+            er = dfma(aim[s][i][j], aim[s][ip][jp], er);
+            ei = dfma(aim[s][i][j], are[s][ip][jp], ei);
+            ei = dfma(-are[s][i][j], aim[s][ip][jp], ei);
+          }
+          pr[2 * i + ip][2 * j + jp] = er;
+          pi[2 * i + ip][2 * j + jp] = ei;
+        }
+  // vec(r_C): full Hermitian matrix, index 2 i + i'
+  const double vr[4] = {rre[0][0], rre[0][1], rre[0][1], rre[1][1]};
+  const double vi[4] = {0.0, rim[0][1], -rim[0][1], 0.0};
+  int m = 0;
+  while (done + (1 << (m + 1)) <= max_iter && m < 29) {
+    if (!__any(active)) break;
+    double qr[4][4], qi[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double xr = 0.0, xi = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          xr = dfma(pr[a][k], pr[k][c], xr);
+          xr = dfma(-pi[a][k], pi[k][c], xr);
+          xi = dfma(pr[a][k], pi[k][c], xi);
+          xi = dfma(pi[a][k], pr[k][c], xi);
+        }
+        qr[a][c] = xr;
+        qi[a][c] = xi;
+      }
+    ++m;
+    double yr[4], yi[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double xr = 0.0, xi = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        pr[a][k] = qr[a][k];
+        pi[a][k] = qi[a][k];
+        xr = dfma(qr[a][k], vr[k], xr);
+        xr = dfma(-qi[a][k], vi[k], xr);
+        xi = dfma(qr[a][k], vi[k], xi);
+        xi = dfma(qi[a][k], vr[k], xi);
+      }
+      yr[a] = xr;
+      yi[a] = xi;
+    }
+    // hermitise (entries 1 = (0,1), 2 = (1,0)), trace-normalise
+    double nre[2][2], nim[2][2];
+    nre[0][0] = yr[0];
+    nre[1][1] = yr[3];
+    nre[0][1] = 0.5 * (yr[1] + yr[2]);
+    nim[0][1] = 0.5 * (yi[1] - yi[2]);
+    nim[0][0] = nim[1][1] = 0.0;
+    const double d2 = normalise_and_diff<2>(nre, nim, rre, rim);
+    if (active) {
+      rre[0][0] = nre[0][0]; rre[0][1] = nre[0][1]; rre[1][1] = nre[1][1]; rim[0][1] = nim[0][1];
+      iters = done + (1 << m);
+      if (d2 < tol2) {
+        active = false;
+        status = QMPS_ST_OK;
+      }
+    }
+  }
+}
+
 template <int D, bool SOLVE>
 __global__ __launch_bounds__(64) void energy_lane_kernel(LaneArgs p) {
   using Cfg = LaneCfg<D>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x;
   const int64_t wave_first = (int64_t)blockIdx.x * 64;
-  const int64_t b = wave_first + lane;
-  const bool valid = b < p.B;
-
-  // ---- HBM -> LDS: the wave's 64 tensors are one contiguous slab; 16 B per lane per load
-  {
-    const unsigned char* slab = (const unsigned char*)p.A + wave_first * Cfg::kRowBytes;
-    const int64_t slab_bytes = (p.B - wave_first < 64 ? p.B - wave_first : 64) * (int64_t)Cfg::kRowBytes;
-#pragma unroll
-    for (int c = 0; c < Cfg::kChunks; ++c) {
-      const int off = c * 1024 + lane * 16;
-      double2 v = make_double2(0.0, 0.0);
-      if (off < slab_bytes) v = *(const double2*)(slab + off);
-      const int e = off / Cfg::kRowBytes, w = off % Cfg::kRowBytes;
-      *(double2*)(lds + e * Cfg::kRowPad + w) = v;
-    }
-  }
-  __syncthreads();
-
-  // ---- LDS -> VGPR: each lane takes its own tensor
+  int64_t b = wave_first + lane;
+  bool valid = b < p.B;
   double are[2][D][D], aim[2][D][D];
-  {
+
+  if (p.idx_list != nullptr) {
+    // ---- list mode: evaluation ids come from a device-side worklist (gathered loads, few items)
+    const int64_t n_list = *p.idx_count;
+    if (wave_first >= n_list) return;
+    valid = wave_first + lane < n_list;
+    b = valid ? (int64_t)p.idx_list[wave_first + lane] : (int64_t)p.idx_list[wave_first];
+    const double2* a = (const double2*)p.A + b * (2 * D * D);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const double2 v = a[(s * D + i) * D + j];
+          are[s][i][j] = v.x;
+          aim[s][i][j] = v.y;
+        }
+  } else {
+    // ---- HBM -> LDS: the wave's 64 tensors are one contiguous slab; 16 B per lane per load
+    {
+      const unsigned char* slab = (const unsigned char*)p.A + wave_first * Cfg::kRowBytes;
+      const int64_t slab_bytes = (p.B - wave_first < 64 ? p.B - wave_first : 64) * (int64_t)Cfg::kRowBytes;
+#pragma unroll
+      for (int c = 0; c < Cfg::kChunks; ++c) {
+        const int off = c * 1024 + lane * 16;
+        double2 v = make_double2(0.0, 0.0);
+        if (off < slab_bytes) v = *(const double2*)(slab + off);
+        const int e = off / Cfg::kRowBytes, w = off % Cfg::kRowBytes;
+        *(double2*)(lds + e * Cfg::kRowPad + w) = v;
+      }
+    }
+    __syncthreads();
+    // ---- LDS -> VGPR: each lane takes its own tensor
     const unsigned char* row = lds + lane * Cfg::kRowPad;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -315,51 +459,67 @@ __global__ __launch_bounds__(64) void energy_lane_kernel(LaneArgs p) {
   }
 
   int iters = 0, status = QMPS_ST_OK;
+  bool handed_off = false;
   if (SOLVE) {
     status = QMPS_ST_NOT_CONVERGED;
     bool active = valid;
     const double tol2 = p.tol * p.tol;
-    for (int k = 1; k <= p.max_iter; ++k) {
+    const bool hybrid = p.handoff > 0 && p.handoff < p.max_iter;
+    const int plain = hybrid ? p.handoff : p.max_iter;
+    // two steps per trip, ping-pong r -> n -> r: frozen (converged) lanes are simply masked off
+    for (int k = 1; k <= plain; k += 2) {
       if (!__any(active)) break;
       double nre[D][D], nim[D][D];
-      power_step<D>(are, aim, rre, rim, nre, nim);
-      double tr = 0.0;
-#pragma unroll
-      for (int i = 0; i < D; ++i) tr += nre[i][i];
-      const double inv = 1.0 / tr;
-      double d2 = 0.0;
-#pragma unroll
-      for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int j = i; j < D; ++j) {
-          nre[i][j] *= inv;
-          const double dr = nre[i][j] - rre[i][j];
-          if (i == j) {
-            nim[i][j] = 0.0;
-            d2 = dfma(dr, dr, d2);
-          } else {
-            nim[i][j] *= inv;
-            const double di = nim[i][j] - rim[i][j];
-            d2 = dfma(2.0 * dr, dr, d2);
-            d2 = dfma(2.0 * di, di, d2);
-          }
-        }
       if (active) {
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-          for (int j = i; j < D; ++j) {
-            rre[i][j] = nre[i][j];
-            rim[i][j] = nim[i][j];
-          }
+        power_step<D>(are, aim, rre, rim, nre, nim);
+        const double d2 = normalise_and_diff<D>(nre, nim, rre, rim);
         iters = k;
-        if (d2 < tol2) {
+        if (d2 < tol2 || k == plain) {
+          if (d2 < tol2) status = QMPS_ST_OK;
           active = false;
+#pragma unroll
+          for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = i; j < D; ++j) {
+              rre[i][j] = nre[i][j];
+              rim[i][j] = nim[i][j];
+            }
+        }
+      }
+      if (active) {
+        power_step<D>(are, aim, nre, nim, rre, rim);
+        const double d2 = normalise_and_diff<D>(rre, rim, nre, nim);
+        iters = k + 1;
+        if (d2 < tol2) {
           status = QMPS_ST_OK;
+          active = false;
+        }
+      }
+    }
+    if (hybrid) {
+      active = valid && status == QMPS_ST_NOT_CONVERGED;
+      if (D == 2) {
+        if constexpr (D == 2) squaring_tail_d2(are, aim, rre, rim, active, iters, status, plain, p.max_iter, tol2);
+      } else if (p.work_idx != nullptr) {
+        // hand the slow items to the wave-per-item squaring kernel: wave-aggregated append
+        const unsigned long long mask = __ballot(active);
+        if (mask != 0ull) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(p.work_count, __popcll(mask));
+          base = __shfl(base, 0, 64);
+          if (active) {
+            p.work_idx[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)b;
+            handed_off = true;
+          }
         }
       }
     }
     if (status == QMPS_ST_OK && !is_positive_definite<D>(rre, rim)) status = QMPS_ST_NOT_PD;
+  } else if (p.check_pd) {
+    if (valid) {
+      status = p.status[b];
+      if (status == QMPS_ST_OK && !is_positive_definite<D>(rre, rim)) status = QMPS_ST_NOT_PD;
+    }
   }
 
   // ---- energy epilogue: rho (upper triangle) -> E_t = Re sum h_t[s][t] rho[t][s] / tr r
@@ -380,26 +540,15 @@ __global__ __launch_bounds__(64) void energy_lane_kernel(LaneArgs p) {
 
   for (int q = 0; q < p.n_terms; ++q) {
     const double2* h = (const double2*)p.h + q * 16;  // wave-uniform -> scalar loads
-    double e = 0.0;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        // Re(h[s][t] * rho[t][s]);  rho[t][s] = conj(rho[s][t]) when t > s
-        const double2 hv = h[s * 4 + t];
-        const double rr = (t <= s) ? pre[t][s] : pre[s][t];
-        e = dfma(hv.x, rr, e);
-        if (t != s) {
-          const double ri = (t < s) ? pim[t][s] : -pim[s][t];
-          e = dfma(-hv.y, ri, e);
-        }
-      }
-    p.E[b * p.n_terms + q] = e;
+    p.E[b * p.n_terms + q] = rdm_energy(h, pre, pim);
   }
   if (SOLVE) {
     p.iters[b] = iters;
     p.status[b] = status;
+  } else if (p.check_pd) {
+    p.status[b] = status;
   }
+  (void)handed_off;
   if (p.r_out != nullptr && SOLVE) {
     double2* o = (double2*)p.r_out + b * (D * D);
 #pragma unroll
@@ -445,24 +594,6 @@ __device__ __forceinline__ void normalise_herm(double (&nre)[D][D], double (&nim
       nre[i][j] *= inv;
       nim[i][j] = (i == j) ? 0.0 : nim[i][j] * inv;
     }
-}
-
-template <int D>
-__device__ __forceinline__ double rdm_energy(const double2* h, const double (&pre)[4][4], const double (&pim)[4][4]) {
-  double e = 0.0;
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const double2 hv = h[s * 4 + t];
-      const double rr = (t <= s) ? pre[t][s] : pre[s][t];
-      e = dfma(hv.x, rr, e);
-      if (t != s) {
-        const double ri = (t < s) ? pim[t][s] : -pim[s][t];
-        e = dfma(-hv.y, ri, e);
-      }
-    }
-  return e;
 }
 
 template <int D>
@@ -526,8 +657,8 @@ __global__ __launch_bounds__(64) void cell2_lane_kernel(Cell2Args p) {
   for (int i = 0; i < D; ++i) { tr1 += rre[i][i]; tr2 += qre[i][i]; }
   for (int q = 0; q < p.n_terms; ++q) {
     const double2* h = (const double2*)p.h + q * 16;
-    const double e1 = rdm_energy<D>(h, p1re, p1im) / tr1;
-    const double e2 = rdm_energy<D>(h, p2re, p2im) / tr2;
+    const double e1 = rdm_energy(h, p1re, p1im) / tr1;
+    const double e2 = rdm_energy(h, p2re, p2im) / tr2;
     p.E[b * p.n_terms + q] = 0.5 * (e1 + e2);
     if (p.E12 != nullptr) {
       p.E12[(b * p.n_terms + q) * 2 + 0] = e1;
@@ -536,6 +667,136 @@ __global__ __launch_bounds__(64) void cell2_lane_kernel(Cell2Args p) {
   }
   p.iters[b] = iters;
   p.status[b] = status;
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 1c: D = 4 repeated-squaring tail, ONE WAVE PER ITEM, v_mfma_f64_16x16x4_f64.
+// The transfer matrix of a D = 4 tensor is exactly one 16 x 16 complex MFMA tile:
+//   E[(i,i'),(j,j')] = sum_s A_s[i][j] conj(A_s[i'][j']).
+// P_m = E^(2^m) by squaring (4 real 16x16x16 products = 16 MFMAs per complex squaring); the
+// accumulator layout (row = 4 reg + lane/16, col = lane%16) is the B-operand layout of the next
+// product, the A-operand layout (row = lane%16, k = 4 kk + lane/16) comes from a padded LDS image.
+// r_m = herm(P_m vec(r_C))/tr;  stop at ||r_m - r_{m-1}||_F^2 < tol^2;  iterations = done + 2^m.
+// ------------------------------------------------------------------------------------------
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64) void env_square_d4_kernel(SquareArgs p) {
+  constexpr int D = 4, N = 16, LD = 17;  // LD: padded leading dimension (complex) of the LDS image
+  __shared__ double2 sA[2 * N];           // the tensor
+  __shared__ double2 sP[N * LD];          // P, row-major
+  __shared__ double2 sY[N];               // P vec(r)
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int n_items = *p.work_count;
+  const double tol2 = p.tol * p.tol;
+  for (int w = blockIdx.x; w < n_items; w += gridDim.x) {
+    const int64_t b = p.work_idx[w];
+    __syncthreads();
+    if (lane < 2 * N) sA[lane] = ((const double2*)p.A)[b * (2 * N) + lane];
+    // v = vec(r_C): entry (j,j') = c
+    const double2 v = ((const double2*)p.r)[b * N + c];
+    // previous iterate, replicated in every lane (16 complex)
+    double2 rprev[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) rprev[e] = ((const double2*)p.r)[b * N + e];
+    __syncthreads();
+    // E in accumulator layout: row = 4 reg + g -> (i, i') = (reg, g); col = c -> (j, j') = (c>>2, c&3)
+    v4f64 Pre, Pim;
+    {
+      const int j = c >> 2, jp = c & 3;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        double er = 0.0, ei = 0.0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const double2 x = sA[(s * D + reg) * D + j], y = sA[(s * D + g) * D + jp];
+          er = dfma(x.x, y.x, er);
+          er = dfma(x.y, y.y, er);
+          ei = dfma(x.y, y.x, ei);
+          ei = dfma(-x.x, y.y, ei);
+        }
+        Pre[reg] = er;
+        Pim[reg] = ei;
+      }
+    }
+    int m = 0, iters = p.done, status = QMPS_ST_NOT_CONVERGED;
+    while (p.done + (1 << (m + 1)) <= p.max_iter && m < 29) {
+      // LDS image of P for the A-operand fragments
+      __syncthreads();
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) sP[(4 * reg + g) * LD + c] = make_double2(Pre[reg], Pim[reg]);
+      __syncthreads();
+      v4f64 cre0 = {0, 0, 0, 0}, cre1 = {0, 0, 0, 0}, cim0 = {0, 0, 0, 0}, cim1 = {0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const double2 a = sP[c * LD + 4 * kk + g];          // A[row = c][k = 4 kk + g]
+        const double bre = Pre[kk], bim = Pim[kk];          // B[k = 4 kk + g][col = c]
+        cre0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bre, cre0, 0, 0, 0);
+        cre1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, bim, cre1, 0, 0, 0);
+        cim0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bim, cim0, 0, 0, 0);
+        cim1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bre, cim1, 0, 0, 0);
+      }
+      Pre = cre0 + cre1;
+      Pim = cim0 + cim1;
+      ++m;
+      // y = P v : per-lane products, then a sum over the 16 lanes of the row group
+      double yr[4], yi[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        double tr_ = Pre[reg] * v.x - Pim[reg] * v.y;
+        double ti_ = Pre[reg] * v.y + Pim[reg] * v.x;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+          tr_ += __shfl_xor(tr_, off, 64);
+          ti_ += __shfl_xor(ti_, off, 64);
+        }
+        yr[reg] = tr_;
+        yi[reg] = ti_;
+      }
+      __syncthreads();
+      if (c == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) sY[4 * reg + g] = make_double2(yr[reg], yi[reg]);  // entry (i,i') = (reg,g)
+      }
+      __syncthreads();
+      // every lane: hermitise, normalise, compare (16 entries)
+      double2 rn[N];
+      double tr = 0.0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) tr += sY[i * D + i].x;
+      const double inv = 1.0 / tr;
+      double d2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const double2 u = sY[i * D + j], l = sY[j * D + i];
+          const double re = 0.5 * (u.x + l.x) * inv;
+          const double im = (i == j) ? 0.0 : 0.5 * (u.y - l.y) * inv;
+          rn[i * D + j] = make_double2(re, im);
+          const double dr = re - rprev[i * D + j].x, di = im - rprev[i * D + j].y;
+          d2 = dfma(dr, dr, d2);
+          d2 = dfma(di, di, d2);
+        }
+#pragma unroll
+      for (int e = 0; e < N; ++e) rprev[e] = rn[e];
+      iters = p.done + (1 << m);
+      if (d2 < tol2) {
+        status = QMPS_ST_OK;
+        break;
+      }
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < N; ++e) sY[e] = rprev[e];
+    }
+    __syncthreads();
+    if (lane < N) ((double2*)p.r)[b * N + lane] = sY[lane];
+    if (lane == 0) {
+      p.iters[b] = iters;
+      p.status[b] = status;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -858,6 +1119,12 @@ static hipError_t launch_block(const LaneArgs& a, bool solve, hipStream_t st) {
     hipLaunchKernelGGL((energy_block_kernel<D, true>), dim3((unsigned)a.B), dim3(D * D), 0, st, a);
   else
     hipLaunchKernelGGL((energy_block_kernel<D, false>), dim3((unsigned)a.B), dim3(D * D), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_square_tail(int D, const SquareArgs& a, int grid, hipStream_t st) {
+  if (D != 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(env_square_d4_kernel, dim3(grid), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 

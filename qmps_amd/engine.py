@@ -88,10 +88,24 @@ class EnergyEngine:
         L.check(self._lib.qmps_set_env_guess(self._ctx, r0.shape[0], _f64(r0.view(np.float64))))
 
     # -- hot path ---------------------------------------------------------------------------
-    def launch(self, B=None, max_iter=10000, tol=1e-13):
-        """Asynchronous: power-iteration environment + energies for the resident batch."""
-        L.check(self._lib.qmps_energy_launch(self._ctx, self.B if B is None else B, int(max_iter), float(tol),
-                                             L.ENV_POWER))
+    def launch(self, B=None, max_iter=10000, tol=1e-13, solver='squaring'):
+        """Asynchronous: power-iteration environment + energies for the resident batch.
+        solver: 'squaring' (power iteration + repeated-squaring tail, default) or 'plain'."""
+        flag = {'plain': L.ENV_POWER, 'squaring': L.ENV_POWER_SQUARING}[solver]
+        L.check(self._lib.qmps_energy_launch(self._ctx, self.B if B is None else B, int(max_iter), float(tol), flag))
+
+    def set_solver(self, solver='squaring', handoff=None):
+        """Solver of the one-shot calls (`energies`, `env_batch`) and the hand-off point of the tail."""
+        flag = {'plain': L.ENV_POWER, 'squaring': L.ENV_POWER_SQUARING}[solver]
+        L.check(self._lib.qmps_set_default_solver(self._ctx, flag))
+        if handoff is not None:
+            L.check(self._lib.qmps_set_handoff(self._ctx, int(handoff)))
+
+    @property
+    def handoff(self):
+        v = ctypes.c_int(0)
+        L.check(self._lib.qmps_get_handoff(self._ctx, byref(v)))
+        return v.value
 
     def launch_energy_only(self, B=None):
         L.check(self._lib.qmps_energy_only_launch(self._ctx, self.B if B is None else B))

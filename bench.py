@@ -99,6 +99,9 @@ def main():
     ap.add_argument('--max-iter', type=int, default=10000)
     ap.add_argument('--tol', type=float, default=1e-13)
     ap.add_argument('--seed', type=int, default=20241022)
+    ap.add_argument('--solver', choices=['squaring', 'plain'], default='squaring',
+                    help="'squaring' = power iteration + repeated-squaring tail (library default); 'plain' = plain power iteration")
+    ap.add_argument('--handoff', type=int, default=None, help='plain power steps before the squaring tail (default: library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -126,6 +129,8 @@ def main():
     h = tfim_h(1.0)
     eng.set_tensors(A)
     eng.set_hamiltonian(h)
+    if args.handoff is not None:
+        eng.set_solver(args.solver, handoff=args.handoff)
 
     if world > 1:
         ids = [EnergyEngine.comm_unique_id() if rank == 0 else None]
@@ -133,7 +138,7 @@ def main():
         eng.comm_init(ids[0], rank, world)
 
     def step():
-        eng.launch(B, max_iter=args.max_iter, tol=args.tol)
+        eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver)
         eng.cost_launch(B)
 
     def barrier():
@@ -174,7 +179,16 @@ def main():
         value = world * B * args.steps / elapsed
         # dominant kernel (energy_lane_kernel<D,true>): HIP events on the context stream over the timed region
         kernel_ms = ev_ms / args.steps
-        flops = float(flops_per_eval(D, iters.astype(np.float64)).sum())
+        hybrid = args.solver == 'squaring' and D <= 4
+        handoff = eng.handoff if hybrid else 0
+        if hybrid:
+            # executed algorithm: min(K, handoff) plain steps + m = log2(K - handoff) squarings of the
+            # real D^2 x D^2 transfer matrix (Hermitian coordinates; 2 (D^2)^3 real flops each) for the handed-off items
+            k_plain = np.minimum(iters, handoff).astype(np.float64)
+            m_sq = np.where(iters > handoff, np.log2(np.maximum(iters - handoff, 1)), 0.0)
+            flops = float((flops_per_eval(D, k_plain) + m_sq * 2.0 * (D * D) ** 3).sum())
+        else:
+            flops = float(flops_per_eval(D, iters.astype(np.float64)).sum())
         tflops = flops / (kernel_ms * 1e-3) * 1e-12
         hbm_gbps = B * bytes_per_eval(D) / (kernel_ms * 1e-3) * 1e-9
         out = {
@@ -184,7 +198,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64 (complex128)', 'data': 'synthetic',
             'config': {'workload': f'TFIM g=1 two-site energy, D={D}, batch={B} per GPU, Haar-random state unitaries, '
-                                   f'in-kernel power-iteration environment solve (tol {args.tol:g}, cap {args.max_iter})',
+                                   f'in-kernel power-iteration environment solve (tol {args.tol:g}, cap {args.max_iter}, solver {args.solver})',
                        'baseline_config': 'BASELINE.json configs[2]', 'D': D, 'batch_per_gpu': B,
                        'global_batch': world * B, 'tol': args.tol, 'max_iter': args.max_iter, 'seed': args.seed,
                        'mean_power_iterations': total_iters_all / (world * B),

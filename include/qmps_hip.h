@@ -68,6 +68,11 @@ extern "C" {
  * point, same tolerance; `iters` reports the equivalent number of power steps handoff + 2^m.
  * This is the default of the one-shot entry points. */
 #define QMPS_ENV_POWER_SQUARING 1
+/* With handoff == 0 (squaring from the start) the iterate is not tracked during the first
+ * QMPS_SKIP_ROUNDS_D* squarings (no state converges in fewer than 2^skip power steps); the first
+ * convergence test compares T^(2^(skip+1)) r_0 with T^(2^skip) r_0. */
+#define QMPS_SKIP_ROUNDS_D2 3
+#define QMPS_SKIP_ROUNDS_D4 5
 
 typedef struct qmps_ctx qmps_ctx;
 
@@ -161,6 +166,8 @@ int qmps_allreduce_cost(qmps_ctx* ctx, int64_t B, double* cost /* [n_terms] */);
 /* ---- diagnostics ----------------------------------------------------------------------- */
 /* FP64 FMA micro-benchmark (register-resident v_fma_f64 loop on every CU): achieved TFLOP/s */
 int qmps_probe_fp64_peak(qmps_ctx* ctx, double* tflops);
+/* v_mfma_f64_16x16x4_f64 issue-rate micro-benchmark with `waves_per_simd` resident waves */
+int qmps_probe_fp64_mfma_peak(qmps_ctx* ctx, int waves_per_simd, double* tflops);
 /* HBM streaming copy micro-benchmark: achieved GB/s (read + write bytes) */
 int qmps_probe_hbm_peak(qmps_ctx* ctx, double* gbps);
 

@@ -68,7 +68,7 @@ static void herm_normalise(int D, cplx* rn) {
 
 /* Repeated-squaring tail (D <= 4): P_m = T^(2^m) as a D^2 x D^2 matrix, r_m = herm(P_m r_C)/tr,
  * stop when ||r_m - r_{m-1}||_F^2 < tol^2; returns the equivalent number of power steps. */
-static int squaring_tail(int D, const cplx* A, cplx* r, int done, int max_iter, double tol2, int* st) {
+static int squaring_tail(int D, const cplx* A, cplx* r, int done, int max_iter, double tol2, int skip, int* st) {
   const int n = D * D;
   static _Thread_local cplx P[256 * 256], Q[256 * 256];
   cplx rC[256], rn[256];
@@ -80,6 +80,26 @@ static int squaring_tail(int D, const cplx* A, cplx* r, int done, int max_iter, 
     }
   memcpy(rC, r, sizeof(cplx) * n);
   int m = 0, it = done;
+  /* untracked squarings: the comparison chain starts at r_skip = herm(P_skip r_C)/tr */
+  while (m < skip && done + (1 << (m + 1)) <= max_iter) {
+    for (int a = 0; a < n; ++a)
+      for (int b = 0; b < n; ++b) {
+        cplx acc = {0, 0};
+        for (int k = 0; k < n; ++k) acc = cadd(acc, cmul(P[a * n + k], P[k * n + b]));
+        Q[a * n + b] = acc;
+      }
+    memcpy(P, Q, sizeof(cplx) * n * n);
+    ++m;
+  }
+  if (m > 0) {
+    for (int a = 0; a < n; ++a) {
+      cplx acc = {0, 0};
+      for (int k = 0; k < n; ++k) acc = cadd(acc, cmul(P[a * n + k], rC[k]));
+      r[a] = acc;
+    }
+    herm_normalise(D, r);
+    it = done + (1 << m);
+  }
   while (done + (1 << (m + 1)) <= max_iter && m < 29) {
     for (int a = 0; a < n; ++a)
       for (int b = 0; b < n; ++b) {
@@ -109,16 +129,20 @@ static int squaring_tail(int D, const cplx* A, cplx* r, int done, int max_iter, 
 }
 
 static void eval_one(int D, const cplx* A, const cplx* h, int nt, const cplx* r0, int max_iter, double tol,
-                     int handoff, double* E, int* iters, int* status, cplx* r_out, cplx* rho_out) {
+                     int handoff, int skip, double* E, int* iters, int* status, cplx* r_out, cplx* rho_out) {
   cplx r[DMAX * DMAX], rn[DMAX * DMAX], X[DMAX * DMAX], T[DMAX * DMAX];
   const int n = D * D;
   if (r0) { memcpy(r, r0, sizeof(cplx) * n); herm_normalise(D, r); }
   else
     for (int i = 0; i < D; ++i)
-      for (int j = 0; j < D; ++j) { r[i * D + j].re = (i == j) ? 1.0 / D : 0.0; r[i * D + j].im = 0.0; }
+      for (int j = 0; j < D; ++j) {
+        /* default start 1/D; squaring from the start (handoff == 0) starts from |0><0| */
+        r[i * D + j].re = (i == j) ? (handoff == 0 ? (i == 0 ? 1.0 : 0.0) : 1.0 / D) : 0.0;
+        r[i * D + j].im = 0.0;
+      }
   int it = 0, st = 1;
   const double tol2 = tol * tol;
-  const int plain = (handoff > 0 && handoff < max_iter) ? handoff : max_iter;
+  const int plain = (handoff >= 0 && handoff < max_iter) ? handoff : max_iter;
   for (int k = 1; k <= plain; ++k) {
     /* rn = sum_s A_s r A_s^+ */
     for (int e = 0; e < n; ++e) { rn[e].re = 0; rn[e].im = 0; }
@@ -137,7 +161,7 @@ static void eval_one(int D, const cplx* A, const cplx* h, int nt, const cplx* r0
     it = k;
     if (d2 < tol2) { st = 0; break; }
   }
-  if (st == 1 && handoff > 0 && plain < max_iter) it = squaring_tail(D, A, r, plain, max_iter, tol2, &st);
+  if (st == 1 && handoff >= 0 && plain < max_iter) it = squaring_tail(D, A, r, plain, max_iter, tol2, skip, &st);
   /* Cholesky positive-definiteness check (LAPACK zpotrf criterion: pivot <= 0 or NaN fails) */
   if (st == 0) {
     cplx L[DMAX * DMAX];
@@ -187,11 +211,11 @@ static void eval_one(int D, const cplx* A, const cplx* h, int nt, const cplx* r0
 
 /* Batched entry point.  A: [B][2][D][D] complex128 (numpy C order); h: [nt][4][4]; r0 nullable
  * [B][D][D]; E: [B][nt]; iters,status: [B]; r_out nullable [B][D][D]; rho_out nullable [B][4][4].
- * threads <= 0 -> 1.  handoff > 0: plain power steps before the repeated-squaring tail (0 = plain
- * only).  Returns 0, or -1 on bad arguments. */
+ * threads <= 0 -> 1.  handoff >= 0: plain power steps before the repeated-squaring tail (0 = squaring
+ * from the start); handoff < 0: plain power iteration only.  Returns 0, or -1 on bad arguments. */
 int qmps_oracle_energy_batch(int D, long B, const double* A, const double* h, int nt, const double* r0,
                              int max_iter, double tol, double* E, int* iters, int* status, double* r_out,
-                             double* rho_out, int threads, int handoff) {
+                             double* rho_out, int threads, int handoff, int skip) {
   if (D < 1 || D > DMAX || B < 0 || nt < 1 || !A || !h || !E || !iters || !status) return -1;
   const long n = (long)D * D;
 #ifdef _OPENMP
@@ -200,7 +224,7 @@ int qmps_oracle_energy_batch(int D, long B, const double* A, const double* h, in
 #endif
   for (long b = 0; b < B; ++b)
     eval_one(D, (const cplx*)A + b * 2 * n, (const cplx*)h, nt, r0 ? (const cplx*)r0 + b * n : NULL, max_iter, tol,
-             handoff, E + b * nt, iters + b, status + b, r_out ? (cplx*)r_out + b * n : NULL,
+             handoff, skip, E + b * nt, iters + b, status + b, r_out ? (cplx*)r_out + b * n : NULL,
              rho_out ? (cplx*)rho_out + b * 16 : NULL);
   (void)threads;
   return 0;

@@ -233,27 +233,35 @@ def env_dense_eig(A):
     return w[k], r
 
 
-def env_power_iteration(A, r0=None, tol=1e-13, max_iter=10000, handoff=0):
+def env_power_iteration(A, r0=None, tol=1e-13, max_iter=10000, handoff=None, skip=0):
     """Normalised power iteration v <- Av/||Av|| (`krylov`, Power Method.ipynb cells 5-6; the
     classical statement of PowerCircuit represent.py:235-248) on the transfer map, trace
     normalised.  This is the algorithm the HIP kernel implements:
 
-        r_0 = 1/D (or r0);  r' = herm(sum_s A_s r A_s^dagger);  r' /= tr r';
+        r_0 = 1/D (or r0; |0><0| when squaring from the start);  r' = herm(sum_s A_s r A_s^dagger);  r' /= tr r';
         stop when ||r' - r||_F^2 < tol^2.
 
-    handoff > 0 enables the repeated-squaring tail for slowly converging items: an item that has
+    handoff = None: plain power iteration only.  handoff >= 0 enables the repeated-squaring tail for
+    slowly converging items (handoff = 0: squaring from the start): an item that has
     not converged after `handoff` plain steps continues with the power method applied 2^m steps
     at a time - P_m = T^(2^m) by squaring the D^2 x D^2 transfer matrix (K steps of the quantum
     PowerCircuit are T^K; squaring reaches K = 2^m in m products) - r_m = herm(P_m r_C)/tr,
     stopping when ||r_m - r_{m-1}||_F^2 < tol^2 (r_0 := r_C); iterations = handoff + 2^m.
+    skip > 0: the first `skip` squarings are not tracked; the comparison chain starts at r_skip.
 
     Returns (r, iterations, status) with status 0 = converged, 1 = not converged."""
     D = A.shape[1]
-    r = np.eye(D, dtype=complex) / D if r0 is None else np.array(r0, dtype=complex)
+    if r0 is not None:
+        r = np.array(r0, dtype=complex)
+    elif handoff == 0:
+        r = np.zeros((D, D), dtype=complex)        # squaring from the start: r_0 = |0><0|
+        r[0, 0] = 1.0
+    else:
+        r = np.eye(D, dtype=complex) / D
     if r0 is not None:
         r = (r + r.conj().T) / 2
         r = r / np.trace(r).real
-    plain = max_iter if handoff <= 0 else min(max_iter, handoff)
+    plain = max_iter if handoff is None else min(max_iter, handoff)
     for k in range(1, plain + 1):
         rn = apply_transfer(A, r)
         rn = (rn + rn.conj().T) / 2
@@ -262,11 +270,19 @@ def env_power_iteration(A, r0=None, tol=1e-13, max_iter=10000, handoff=0):
         r = rn
         if d2 < tol * tol:
             return r, k, 0
-    if handoff <= 0 or plain >= max_iter:
+    if handoff is None or plain >= max_iter:
         return r, plain, 1
     P = transfer_matrix(A)
     rC = r.reshape(-1)
     m, it = 0, plain
+    while m < skip and plain + 2 ** (m + 1) <= max_iter:
+        P = P @ P
+        m += 1
+    if m > 0:
+        r = (P @ rC).reshape(D, D)
+        r = (r + r.conj().T) / 2
+        r = r / np.trace(r).real
+        it = plain + 2 ** m
     while plain + 2 ** (m + 1) <= max_iter:
         P = P @ P
         m += 1
@@ -336,10 +352,10 @@ def energy_closed_form(A, h, r=None):
     return float(np.real(np.einsum('st,ts->', h, rho)))
 
 
-def energy_power(A, h, r0=None, tol=1e-13, max_iter=10000, handoff=0):
+def energy_power(A, h, r0=None, tol=1e-13, max_iter=10000, handoff=None, skip=0):
     """Exactly what one GPU lane computes: power-iteration environment + closed form.
     Returns (E, iterations, status); status 2 if r is not positive definite."""
-    r, it, status = env_power_iteration(A, r0, tol, max_iter, handoff)
+    r, it, status = env_power_iteration(A, r0, tol, max_iter, handoff, skip)
     E = energy_closed_form(A, h, r)
     if status == 0:
         try:

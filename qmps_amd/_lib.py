@@ -56,6 +56,7 @@ SIGNATURES = {
     'qmps_get_cost': (c_int, [c_void_p, _dp]),
     'qmps_allreduce_cost': (c_int, [c_void_p, c_int64, _dp]),
     'qmps_probe_fp64_peak': (c_int, [c_void_p, _dp]),
+    'qmps_probe_fp64_mfma_peak': (c_int, [c_void_p, c_int, _dp]),
     'qmps_probe_hbm_peak': (c_int, [c_void_p, _dp]),
 }
 

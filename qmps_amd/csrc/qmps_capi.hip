@@ -282,33 +282,45 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   if (solver != QMPS_ENV_POWER && solver != QMPS_ENV_POWER_SQUARING)
     return fail(QMPS_ERR_ARG, "unknown environment solver %d", solver);
   qmps::LaneArgs a = make_args(c, B, max_iter, tol, true);
-  const bool hybrid = solver == QMPS_ENV_POWER_SQUARING && c->D <= 4 && c->handoff > 0 && c->handoff < max_iter;
+  const bool hybrid = solver == QMPS_ENV_POWER_SQUARING && c->D <= 4 && c->handoff < max_iter;
   if (!hybrid) {
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
   } else if (c->D == 2) {
-    a.handoff = c->handoff;  // the squaring tail runs in-lane (4 x 4 transfer matrix in registers)
+    a.handoff = c->handoff;  // the squaring tail runs in-lane (real 4 x 4 transfer matrix in registers)
+    a.hybrid = 1;
+    a.skip = c->handoff == 0 ? QMPS_SKIP_ROUNDS_D2 : 0;
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
   } else {
-    // D = 4: (1) lane kernel, `handoff` plain steps, slow items -> worklist; (2) wave-per-item MFMA
-    // squaring tail over the worklist; (3) energy-only pass over the worklist.  No host round trip:
-    // the later kernels read the item count from HBM.
-    HIP_TRY(hipMemsetAsync(c->d_work_count, 0, sizeof(int32_t), c->stream));
-    a.handoff = c->handoff;
-    a.work_count = c->d_work_count;
-    a.work_idx = c->d_work_idx;
-    HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
+    // D = 4: (1) lane kernel: `handoff` plain steps, slow items -> worklist (skipped when handoff == 0:
+    // every item goes straight to the squaring kernel); (2) wave-per-item MFMA squaring over the
+    // worklist; (3) energy-only pass over the worklist.  No host round trip: the later kernels read the
+    // item count from HBM.
     qmps::SquareArgs q;
-    q.A = c->d_A; q.r = c->d_r; q.iters = c->d_iters; q.status = c->d_status;
-    q.work_count = c->d_work_count; q.work_idx = c->d_work_idx;
-    q.done = c->handoff; q.max_iter = max_iter; q.tol = tol;
-    int grid = (int)((B + 7) / 8);
+    memset(&q, 0, sizeof(q));
+    q.A = c->d_A; q.r_out = c->d_r; q.iters = c->d_iters; q.status = c->d_status;
+    q.B = B; q.done = c->handoff; q.max_iter = max_iter; q.tol = tol;
+    q.skip = c->handoff == 0 ? QMPS_SKIP_ROUNDS_D4 : 0;
+    qmps::LaneArgs e = make_args(c, B, 1, 1.0, false);
+    e.check_pd = 1;
+    if (c->handoff > 0) {
+      HIP_TRY(hipMemsetAsync(c->d_work_count, 0, sizeof(int32_t), c->stream));
+      a.handoff = c->handoff;
+      a.hybrid = 1;
+      a.work_count = c->d_work_count;
+      a.work_idx = c->d_work_idx;
+      HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
+      q.r_in = c->d_r;
+      q.work_count = c->d_work_count;
+      q.work_idx = c->d_work_idx;
+      e.idx_list = c->d_work_idx;
+      e.idx_count = c->d_work_count;
+    } else {
+      q.r_in = c->have_guess ? c->d_r : nullptr;
+    }
+    int grid = (int)((B + 15) / 16);
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
     HIP_TRY(qmps::launch_square_tail(c->D, q, grid, c->stream));
-    qmps::LaneArgs e = make_args(c, B, 1, 1.0, false);
-    e.idx_list = c->d_work_idx;
-    e.idx_count = c->d_work_count;
-    e.check_pd = 1;
     HIP_TRY(qmps::launch_energy(c->D, e, false, c->stream));
   }
   c->have_env = true;
@@ -558,6 +570,29 @@ int qmps_probe_fp64_peak(qmps_ctx* c, double* tflops) {
     if (ms < best) best = ms;
   }
   const double flops = 2.0 * 16.0 * iters * 256.0 * blocks;
+  *tflops = flops / (best * 1e-3) * 1e-12;
+  return QMPS_OK;
+}
+
+int qmps_probe_fp64_mfma_peak(qmps_ctx* c, int waves_per_simd, double* tflops) {
+  if (int rc = bind(c)) return rc;
+  if (!tflops || waves_per_simd < 1 || waves_per_simd > 8) return fail(QMPS_ERR_ARG, "bad arguments");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+  const int blocks = prop.multiProcessorCount * waves_per_simd;  // 256 threads = 4 waves = 1 per SIMD
+  const int iters = 20000;
+  HIP_TRY(qmps::launch_probe_mfma_f64(c->d_cost, blocks, 200, c->stream));
+  float best = 1e30f;
+  for (int rep = 0; rep < 5; ++rep) {
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(qmps::launch_probe_mfma_f64(c->d_cost, blocks, iters, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (ms < best) best = ms;
+  }
+  const double flops = 4.0 * 2048.0 * iters * 4.0 * blocks;  // 4 MFMAs x 2048 flop, 4 waves per block
   *tflops = flops / (best * 1e-3) * 1e-12;
   return QMPS_OK;
 }

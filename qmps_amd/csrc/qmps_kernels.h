@@ -23,6 +23,8 @@ struct LaneArgs {
   double tol;
   // hybrid solve: `handoff` plain power steps, then the repeated-squaring tail (0 = plain only)
   int handoff;
+  int hybrid;                 // 1: squaring tail enabled (handoff may be 0 = squaring from the start)
+  int skip;                   // D = 2 in-lane tail: squarings before the iterate is tracked
   int32_t* work_count;        // D = 4: slow items are appended to work_idx (wave-aggregated atomics)
   int32_t* work_idx;
   // list mode (energy-only pass over the worklist): evaluation ids come from idx_list[0 .. *idx_count)
@@ -34,12 +36,15 @@ struct LaneArgs {
 // D = 4 repeated-squaring tail over the worklist (one wave per item, MFMA f64 16x16x4)
 struct SquareArgs {
   const void* A;
-  void* r;                    // in: r after `done` plain steps; out: converged environment
+  const void* r_in;           // nullable: r after `done` plain steps / a warm start (null = 1/D)
+  void* r_out;                // converged environment
   int32_t* iters;
   int32_t* status;
-  const int32_t* work_count;
+  const int32_t* work_count;  // item ids = work_idx[0 .. *work_count), or 0 .. B-1 when work_idx == nullptr
   const int32_t* work_idx;
+  int64_t B;
   int done;                   // plain steps already taken
+  int skip;                   // squarings before the iterate is tracked (first comparison at round skip + 1)
   int max_iter;
   double tol;
 };
@@ -67,6 +72,7 @@ hipError_t launch_unitary_to_tensor(const void* U, void* A, int D, int64_t B, hi
 hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, int n_partial, double* cost,
                       hipStream_t st);
 hipError_t launch_probe_fp64(double* out, int blocks, int iters, hipStream_t st);
+hipError_t launch_probe_mfma_f64(double* out, int blocks, int iters, hipStream_t st);
 hipError_t launch_probe_copy(const void* src, void* dst, int64_t n16, hipStream_t st);
 
 }  // namespace qmps

@@ -287,80 +287,162 @@ __device__ __forceinline__ double normalise_and_diff(double (&nre)[D][D], double
   return dfma(2.0, od, dd);
 }
 
-// D = 2 only: repeated-squaring tail, one evaluation per lane.  P = T^(2^m) as a 4 x 4 complex matrix in
-// registers (index (i,i') -> 2 i + i'), r_m = herm(P vec(r_C))/tr, stop at ||r_m - r_{m-1}||_F^2 < tol^2.
+// ------------------------------------------------------------------------------------------
+// Real Hermitian coordinates.  r -> sum_s A_s r A_s^+ maps Hermitian matrices to Hermitian matrices,
+// so on the orthonormal real coordinates
+//   x_a = r_ii (a = i < D),  sqrt2 Re r_ij (a = D + p),  sqrt2 Im r_ij (a = D + P + p),  p <-> (i<j)
+// it is a REAL D^2 x D^2 matrix R (the complex transfer matrix E = B R B^+ for a unitary B): one
+// squaring costs 2 (D^2)^3 real flops instead of 8 (D^2)^3, and ||x - x'||_2 == ||r - r'||_F.
+// ------------------------------------------------------------------------------------------
+template <int D>
+struct HermBasis {
+  static constexpr int N = D * D, P = D * (D - 1) / 2;
+  __host__ __device__ static constexpr int kind(int a) { return a < D ? 0 : (a < D + P ? 1 : 2); }
+  __host__ __device__ static constexpr int pair(int a) { return a < D ? 0 : (a < D + P ? a - D : a - D - P); }
+  __host__ __device__ static constexpr int row(int a) {  // i of the (i, j) the coordinate refers to
+    if (a < D) return a;
+    int p = pair(a), i = 0;
+    while (p >= D - 1 - i) { p -= D - 1 - i; ++i; }
+    return i;
+  }
+  __host__ __device__ static constexpr int col(int a) {
+    if (a < D) return a;
+    int p = pair(a), i = 0;
+    while (p >= D - 1 - i) { p -= D - 1 - i; ++i; }
+    return i + 1 + p;
+  }
+};
+
+// R[a][b] = coordinate a of T(H_b); GetA(s, i, j) returns A_s[i][j] as double2.
+template <int D, class GetA>
+__device__ __forceinline__ double real_transfer_entry(GetA A, int a, int b) {
+  using HB = HermBasis<D>;
+  const int ka = HB::kind(a), i = HB::row(a), ip = HB::col(a);
+  const int kb = HB::kind(b), j = HB::row(b), jp = HB::col(b);
+  // e1 = sum_s A_s[i][j] conj(A_s[ip][jp]),  e2 = sum_s A_s[i][jp] conj(A_s[ip][j])
+  double e1r = 0.0, e1i = 0.0, e2r = 0.0, e2i = 0.0;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const double2 x = A(s, i, j), y = A(s, ip, jp);
+    e1r = dfma(x.x, y.x, e1r);
+    e1r = dfma(x.y, y.y, e1r);
+    e1i = dfma(x.y, y.x, e1i);
+    e1i = dfma(-x.x, y.y, e1i);
+    if (kb != 0) {
+      const double2 u = A(s, i, jp), v = A(s, ip, j);
+      e2r = dfma(u.x, v.x, e2r);
+      e2r = dfma(u.y, v.y, e2r);
+      e2i = dfma(u.y, v.x, e2i);
+      e2i = dfma(-u.x, v.y, e2i);
+    }
+  }
+  // M = T(H_b)[i][ip]:  diag b: e1;  re b: (e1 + e2)/sqrt2;  im b: i (e1 - e2)/sqrt2
+  double mr, mi;
+  if (kb == 0) { mr = e1r; mi = e1i; }
+  else if (kb == 1) { mr = e1r + e2r; mi = e1i + e2i; }
+  else { mr = -(e1i - e2i); mi = e1r - e2r; }
+  double val = (ka == 2) ? mi : mr;
+  const bool sa = ka != 0, sb = kb != 0;   // sqrt2 for a non-diagonal output, 1/sqrt2 for a non-diagonal input
+  if (sa && !sb) val *= 1.4142135623730951;
+  if (!sa && sb) val *= 0.70710678118654752;
+  return val;
+}
+
+template <int D>
+__device__ __forceinline__ void pack_herm(const double (&rre)[D][D], const double (&rim)[D][D], double (&x)[D * D]) {
+  using HB = HermBasis<D>;
+#pragma unroll
+  for (int a = 0; a < D * D; ++a) {
+    const int k = HB::kind(a), i = HB::row(a), j = HB::col(a);
+    x[a] = k == 0 ? rre[i][i] : (k == 1 ? 1.4142135623730951 * rre[i][j] : 1.4142135623730951 * rim[i][j]);
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void unpack_herm(const double (&x)[D * D], double (&rre)[D][D], double (&rim)[D][D]) {
+  using HB = HermBasis<D>;
+#pragma unroll
+  for (int a = 0; a < D * D; ++a) {
+    const int k = HB::kind(a), i = HB::row(a), j = HB::col(a);
+    if (k == 0) { rre[i][i] = x[a]; rim[i][i] = 0.0; }
+    else if (k == 1) rre[i][j] = 0.70710678118654752 * x[a];
+    else rim[i][j] = 0.70710678118654752 * x[a];
+  }
+}
+
+// D = 2 only: repeated-squaring tail, one evaluation per lane.  R = T^(2^m) as a real 4 x 4 matrix in
+// registers, x_m = R x_C / tr, stop at ||x_m - x_{m-1}||^2 < tol^2;  iterations = done + 2^m.
 __device__ __forceinline__ void squaring_tail_d2(const double (&are)[2][2][2], const double (&aim)[2][2][2],
                                                  double (&rre)[2][2], double (&rim)[2][2], bool& active, int& iters,
-                                                 int& status, int done, int max_iter, double tol2) {
-  double pr[4][4], pi[4][4];
+                                                 int& status, int done, int max_iter, double tol2, int skip) {
+  auto getA = [&](int s, int i, int j) { return make_double2(are[s][i][j], aim[s][i][j]); };
+  double R[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int ip = 0; ip < 2; ++ip)
+    for (int b = 0; b < 4; ++b) R[a][b] = real_transfer_entry<2>(getA, a, b);
+  double x0[4], xp[4];
+  pack_herm<2>(rre, rim, x0);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          double er = 0.0, ei = 0.0;
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {  // A_s[i][j] * conj(A_s[ip][jp])
-            er = dfma(are[s][i][j], are[s][ip][jp], er);
-            er = dfma(aim[s][i][j], aim[s][ip][jp], er);
-            ei = dfma(aim[s][i][j], are[s][ip][jp], ei);
-            ei = dfma(-are[s][i][j], aim[s][ip][jp], ei);
-          }
-          pr[2 * i + ip][2 * j + jp] = er;
-          pi[2 * i + ip][2 * j + jp] = ei;
-        }
-  // vec(r_C): full Hermitian matrix, index 2 i + i'
-  const double vr[4] = {rre[0][0], rre[0][1], rre[0][1], rre[1][1]};
-  const double vi[4] = {0.0, rim[0][1], -rim[0][1], 0.0};
+  for (int a = 0; a < 4; ++a) xp[a] = x0[a];
   int m = 0;
-  while (done + (1 << (m + 1)) <= max_iter && m < 29) {
-    if (!__any(active)) break;
-    double qr[4][4], qi[4][4];
+  auto square = [&]() {
+    double Q[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        double xr = 0.0, xi = 0.0;
+        double v = 0.0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          xr = dfma(pr[a][k], pr[k][c], xr);
-          xr = dfma(-pi[a][k], pi[k][c], xr);
-          xi = dfma(pr[a][k], pi[k][c], xi);
-          xi = dfma(pi[a][k], pr[k][c], xi);
-        }
-        qr[a][c] = xr;
-        qi[a][c] = xi;
+        for (int k = 0; k < 4; ++k) v = dfma(R[a][k], R[k][c], v);
+        Q[a][c] = v;
       }
-    ++m;
-    double yr[4], yi[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) R[a][c] = Q[a][c];
+  };
+  auto apply = [&](double (&y)[4]) {   // y = R x0 / tr
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      double xr = 0.0, xi = 0.0;
+      double v = 0.0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        pr[a][k] = qr[a][k];
-        pi[a][k] = qi[a][k];
-        xr = dfma(qr[a][k], vr[k], xr);
-        xr = dfma(-qi[a][k], vi[k], xr);
-        xi = dfma(qr[a][k], vi[k], xi);
-        xi = dfma(qi[a][k], vr[k], xi);
-      }
-      yr[a] = xr;
-      yi[a] = xi;
+      for (int k = 0; k < 4; ++k) v = dfma(R[a][k], x0[k], v);
+      y[a] = v;
     }
-    // hermitise (entries 1 = (0,1), 2 = (1,0)), trace-normalise
-    double nre[2][2], nim[2][2];
-    nre[0][0] = yr[0];
-    nre[1][1] = yr[3];
-    nre[0][1] = 0.5 * (yr[1] + yr[2]);
-    nim[0][1] = 0.5 * (yi[1] - yi[2]);
-    nim[0][0] = nim[1][1] = 0.0;
-    const double d2 = normalise_and_diff<2>(nre, nim, rre, rim);
+    const double inv = 1.0 / (y[0] + y[1]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) y[a] *= inv;
+  };
+  // phase 1: `skip` squarings without tracking the iterate; the comparison chain then starts at z_skip
+  while (m < skip && done + (1 << (m + 1)) <= max_iter) {
+    square();
+    ++m;
+  }
+  if (m > 0) {
+    double y[4];
+    apply(y);
     if (active) {
-      rre[0][0] = nre[0][0]; rre[0][1] = nre[0][1]; rre[1][1] = nre[1][1]; rim[0][1] = nim[0][1];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xp[a] = y[a];
+      iters = done + (1 << m);
+    }
+  }
+  while (done + (1 << (m + 1)) <= max_iter && m < 29) {
+    if (!__any(active)) break;
+    square();
+    ++m;
+    double y[4];
+    apply(y);
+    double d2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const double d = y[a] - xp[a];
+      d2 = dfma(d, d, d2);
+    }
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xp[a] = y[a];
       iters = done + (1 << m);
       if (d2 < tol2) {
         active = false;
@@ -368,6 +450,7 @@ __device__ __forceinline__ void squaring_tail_d2(const double (&are)[2][2][2], c
       }
     }
   }
+  unpack_herm<2>(xp, rre, rim);
 }
 
 template <int D, bool SOLVE>
@@ -449,11 +532,13 @@ __global__ __launch_bounds__(64) void energy_lane_kernel(LaneArgs p) {
         rim[i][j] *= inv;
       }
   } else {
+    // default start: 1/D; squaring from the start (handoff == 0) uses |0><0| like the D = 4 matrix kernel
+    const bool e0 = SOLVE && p.hybrid != 0 && p.handoff == 0;
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
       for (int j = i; j < D; ++j) {
-        rre[i][j] = (i == j) ? 1.0 / D : 0.0;
+        rre[i][j] = (i == j) ? (e0 ? (i == 0 ? 1.0 : 0.0) : 1.0 / D) : 0.0;
         rim[i][j] = 0.0;
       }
   }
@@ -464,7 +549,7 @@ __global__ __launch_bounds__(64) void energy_lane_kernel(LaneArgs p) {
     status = QMPS_ST_NOT_CONVERGED;
     bool active = valid;
     const double tol2 = p.tol * p.tol;
-    const bool hybrid = p.handoff > 0 && p.handoff < p.max_iter;
+    const bool hybrid = p.hybrid != 0 && p.handoff < p.max_iter;
     const int plain = hybrid ? p.handoff : p.max_iter;
     // two steps per trip, ping-pong r -> n -> r: frozen (converged) lanes are simply masked off
     for (int k = 1; k <= plain; k += 2) {
@@ -499,7 +584,7 @@ __global__ __launch_bounds__(64) void energy_lane_kernel(LaneArgs p) {
     if (hybrid) {
       active = valid && status == QMPS_ST_NOT_CONVERGED;
       if (D == 2) {
-        if constexpr (D == 2) squaring_tail_d2(are, aim, rre, rim, active, iters, status, plain, p.max_iter, tol2);
+        if constexpr (D == 2) squaring_tail_d2(are, aim, rre, rim, active, iters, status, plain, p.max_iter, tol2, p.skip);
       } else if (p.work_idx != nullptr) {
         // hand the slow items to the wave-per-item squaring kernel: wave-aggregated append
         const unsigned long long mask = __ballot(active);
@@ -670,131 +755,247 @@ __global__ __launch_bounds__(64) void cell2_lane_kernel(Cell2Args p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Kernel 1c: D = 4 repeated-squaring tail, ONE WAVE PER ITEM, v_mfma_f64_16x16x4_f64.
-// The transfer matrix of a D = 4 tensor is exactly one 16 x 16 complex MFMA tile:
-//   E[(i,i'),(j,j')] = sum_s A_s[i][j] conj(A_s[i'][j']).
-// P_m = E^(2^m) by squaring (4 real 16x16x16 products = 16 MFMAs per complex squaring); the
-// accumulator layout (row = 4 reg + lane/16, col = lane%16) is the B-operand layout of the next
-// product, the A-operand layout (row = lane%16, k = 4 kk + lane/16) comes from a padded LDS image.
-// r_m = herm(P_m vec(r_C))/tr;  stop at ||r_m - r_{m-1}||_F^2 < tol^2;  iterations = done + 2^m.
+// Kernel 1c: D = 4 repeated squaring, ONE WAVE PER ITEM, v_mfma_f64_16x16x4_f64.
+// In real Hermitian coordinates the transfer map of a D = 4 tensor is exactly one real 16 x 16 MFMA
+// tile R.  R_m = R^(2^m) by squaring: 4 MFMAs per round.  The accumulator layout
+// (row = 4 reg + lane/16, col = lane%16) IS the B-operand layout of the next product; the A-operand
+// layout (row = lane%16, k = 4 kk + lane/16) comes from a padded LDS image.
+// x_m = R_m x_C / tr;  stop at ||x_m - x_{m-1}||^2 < tol^2;  iterations = done + 2^m.
+// Items: the worklist written by the lane kernel, or (work_idx == nullptr) all of 0 .. B-1.
 // ------------------------------------------------------------------------------------------
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(64) void env_square_d4_kernel(SquareArgs p) {
-  constexpr int D = 4, N = 16, LD = 17;  // LD: padded leading dimension (complex) of the LDS image
-  __shared__ double2 sA[2 * N];           // the tensor
-  __shared__ double2 sP[N * LD];          // P, row-major
-  __shared__ double2 sY[N];               // P vec(r)
-  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-  const int n_items = *p.work_count;
+// sum over the 16 lanes of a row group (lanes 16 g .. 16 g + 15); result in every lane of the group.
+// DPP row rotations (v_mov_b32_dpp row_ror:n, VALU only - no LDS crossbar traffic).
+template <int N>
+__device__ __forceinline__ double row_ror(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x120 + N, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x120 + N, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += row_ror<8>(v);
+  v += row_ror<4>(v);
+  v += row_ror<2>(v);
+  v += row_ror<1>(v);
+  return v;
+}
+// sum of one value per row group (lanes 0, 16, 32, 48) -> wave-uniform
+__device__ __forceinline__ double group4_sum(double v) {
+  double t = 0.0;
+#pragma unroll
+  for (int gg = 0; gg < 4; ++gg) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 16 * gg);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 16 * gg);
+    t += __hiloint2double(hi, lo);
+  }
+  return t;
+}
+
+__global__ __launch_bounds__(256) void env_square_d4_kernel(SquareArgs p) {
+  constexpr int D = 4, N = 16, LD = 17;
+  constexpr int WAVES = 4;
+  using HB = HermBasis<D>;
+  __shared__ double2 sA_all[WAVES][2 * N];
+  __shared__ double sR_all[WAVES][N * LD + N];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  double2* sA = sA_all[wave];
+  double* sR = sR_all[wave];
+  const int64_t n_items = p.work_idx != nullptr ? (int64_t)*p.work_count : p.B;
   const double tol2 = p.tol * p.tol;
-  for (int w = blockIdx.x; w < n_items; w += gridDim.x) {
-    const int64_t b = p.work_idx[w];
+  // all waves of a workgroup run the same number of trips (barriers below are workgroup-wide)
+  for (int64_t w0 = (int64_t)blockIdx.x * WAVES; w0 < n_items; w0 += (int64_t)gridDim.x * WAVES) {
+    const int64_t w = w0 + wave;
+    const bool have = w < n_items;
+    const int64_t b = have ? (p.work_idx != nullptr ? (int64_t)p.work_idx[w] : w) : 0;
     __syncthreads();
-    if (lane < 2 * N) sA[lane] = ((const double2*)p.A)[b * (2 * N) + lane];
-    // v = vec(r_C): entry (j,j') = c
-    const double2 v = ((const double2*)p.r)[b * N + c];
-    // previous iterate, replicated in every lane (16 complex)
-    double2 rprev[N];
-#pragma unroll
-    for (int e = 0; e < N; ++e) rprev[e] = ((const double2*)p.r)[b * N + e];
-    __syncthreads();
-    // E in accumulator layout: row = 4 reg + g -> (i, i') = (reg, g); col = c -> (j, j') = (c>>2, c&3)
-    v4f64 Pre, Pim;
+    if (have && lane < 2 * N) sA[lane] = ((const double2*)p.A)[b * (2 * N) + lane];
+    // x0[c]: packed coordinate c of the start matrix (r after `done` plain steps, a warm start, or 1/D)
+    double x0;
     {
-      const int j = c >> 2, jp = c & 3;
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        double er = 0.0, ei = 0.0;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const double2 x = sA[(s * D + reg) * D + j], y = sA[(s * D + g) * D + jp];
-          er = dfma(x.x, y.x, er);
-          er = dfma(x.y, y.y, er);
-          ei = dfma(x.y, y.x, ei);
-          ei = dfma(-x.x, y.y, ei);
-        }
-        Pre[reg] = er;
-        Pim[reg] = ei;
+      const int k = HB::kind(c), i = HB::row(c), j = HB::col(c);
+      if (p.r_in != nullptr && have) {
+        const double2 u = ((const double2*)p.r_in)[b * N + i * D + j], l = ((const double2*)p.r_in)[b * N + j * D + i];
+        x0 = k == 0 ? u.x : (k == 1 ? 0.70710678118654752 * (u.x + l.x) : 0.70710678118654752 * (u.y - l.y));
+      } else {
+        x0 = k == 0 ? 1.0 / D : 0.0;
       }
+      // trace-normalise the start (a warm start may carry any positive trace)
+      double t = (k == 0) ? x0 : 0.0;
+      t = row16_sum(t);
+      x0 /= t;
     }
-    int m = 0, iters = p.done, status = QMPS_ST_NOT_CONVERGED;
-    while (p.done + (1 << (m + 1)) <= p.max_iter && m < 29) {
-      // LDS image of P for the A-operand fragments
-      __syncthreads();
+    __syncthreads();
+    // R in accumulator layout: lane holds R[a = 4 reg + g][b = c]
+    v4f64 R;
+    {
+      auto getA = [&](int s, int i, int j) { return sA[(s * D + i) * D + j]; };
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) sP[(4 * reg + g) * LD + c] = make_double2(Pre[reg], Pim[reg]);
-      __syncthreads();
-      v4f64 cre0 = {0, 0, 0, 0}, cre1 = {0, 0, 0, 0}, cim0 = {0, 0, 0, 0}, cim1 = {0, 0, 0, 0};
+      for (int reg = 0; reg < 4; ++reg) R[reg] = real_transfer_entry<D>(getA, 4 * reg + g, c);
+    }
+    // Vectors live in two distributions:
+    //   row-distributed   (like an accumulator column): lane holds v[4 reg + g], reg = 0..3, all c alike
+    //   column-distributed: lane holds v[c]
+    // A mat-vec y = R v takes v column-distributed (per-lane products R[4 reg + g][c] v[c], DPP sum over
+    // the 16 lanes of the row group) and returns y row-distributed; the 16 values go through a 128-byte
+    // LDS strip to become column-distributed for the next round.
+    //   xc = the iterate the next one is compared with (x_0, then z_1, z_2, ...), row-distributed
+    //   zc = z_m = R_m x_0 = T^(2^m) x_0 (column-distributed), in step with the matrix: z_{m+1} = R_m z_m.
+    double* sZ = sR + N * LD;        // 16-double strip behind the padded image
+    auto square = [&]() {
+      // LDS image of R_m for the A-operand fragments (wave-private region; LDS is in-order per wave)
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const double2 a = sP[c * LD + 4 * kk + g];          // A[row = c][k = 4 kk + g]
-        const double bre = Pre[kk], bim = Pim[kk];          // B[k = 4 kk + g][col = c]
-        cre0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bre, cre0, 0, 0, 0);
-        cre1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, bim, cre1, 0, 0, 0);
-        cim0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bim, cim0, 0, 0, 0);
-        cim1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bre, cim1, 0, 0, 0);
-      }
-      Pre = cre0 + cre1;
-      Pim = cim0 + cim1;
-      ++m;
-      // y = P v : per-lane products, then a sum over the 16 lanes of the row group
-      double yr[4], yi[4];
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        double tr_ = Pre[reg] * v.x - Pim[reg] * v.y;
-        double ti_ = Pre[reg] * v.y + Pim[reg] * v.x;
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-          tr_ += __shfl_xor(tr_, off, 64);
-          ti_ += __shfl_xor(ti_, off, 64);
-        }
-        yr[reg] = tr_;
-        yi[reg] = ti_;
-      }
-      __syncthreads();
+      for (int reg = 0; reg < 4; ++reg) sR[(4 * reg + g) * LD + c] = R[reg];
+      __builtin_amdgcn_wave_barrier();
+      const double a0 = sR[c * LD + 0 + g], a1 = sR[c * LD + 4 + g];
+      const double a2 = sR[c * LD + 8 + g], a3 = sR[c * LD + 12 + g];
+      v4f64 acc = {0, 0, 0, 0};
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, R[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, R[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, R[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, R[3], acc, 0, 0, 0);
+      return acc;
+    };
+    auto to_columns = [&](const double (&y)[4]) {   // row-distributed -> column-distributed via LDS
+      __builtin_amdgcn_wave_barrier();
       if (c == 0) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) sY[4 * reg + g] = make_double2(yr[reg], yi[reg]);  // entry (i,i') = (reg,g)
+        for (int reg = 0; reg < 4; ++reg) sZ[4 * reg + g] = y[reg];
       }
-      __syncthreads();
-      // every lane: hermitise, normalise, compare (16 entries)
-      double2 rn[N];
-      double tr = 0.0;
+      __builtin_amdgcn_wave_barrier();
+      return sZ[c];
+    };
+    int m = 0, iters = p.done, status = QMPS_ST_NOT_CONVERGED;
+    bool active = have;
+    // phase 1: `skip` squarings without tracking the iterate (no item converges in < 2^skip steps;
+    // the first comparison is then between z_{skip+1} and z_skip) - matrix pipe only
+    while (m < p.skip && p.done + (1 << (m + 1)) <= p.max_iter) {
+      R = square();
+      ++m;
+    }
+    double xc[4];
+    if (p.r_in == nullptr) {
+      // ---- default start r_0 = |0><0| (= coordinate vector e_0): z_m = R_m e_0 is COLUMN 0 of R_m,
+      // i.e. already row-distributed in the lanes c == 0 of each group - no mat-vec, no reduction.
+      // Every lane tracks its own column c (start H_c); the wave-level reductions read column 0.
+      if (m == 0) {
 #pragma unroll
-      for (int i = 0; i < D; ++i) tr += sY[i * D + i].x;
-      const double inv = 1.0 / tr;
-      double d2 = 0.0;
+        for (int reg = 0; reg < 4; ++reg) xc[reg] = (4 * reg + g == c) ? 1.0 : 0.0;   // e_c
+      } else {
+        const double inv0 = 1.0 / group4_sum(R[0]);
 #pragma unroll
-      for (int i = 0; i < D; ++i)
+        for (int reg = 0; reg < 4; ++reg) xc[reg] = R[reg] * inv0;
+        iters = p.done + (1 << m);
+      }
+      while (p.done + (1 << (m + 1)) <= p.max_iter && m < 29) {
+        if (!__any(active)) break;
+        R = square();
+        ++m;
+        const double inv = 1.0 / group4_sum(R[0]);
+        double dpart = 0.0;
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-          const double2 u = sY[i * D + j], l = sY[j * D + i];
-          const double re = 0.5 * (u.x + l.x) * inv;
-          const double im = (i == j) ? 0.0 : 0.5 * (u.y - l.y) * inv;
-          rn[i * D + j] = make_double2(re, im);
-          const double dr = re - rprev[i * D + j].x, di = im - rprev[i * D + j].y;
-          d2 = dfma(dr, dr, d2);
-          d2 = dfma(di, di, d2);
+        for (int reg = 0; reg < 4; ++reg) {
+          const double y = R[reg] * inv;
+          const double d = y - xc[reg];
+          dpart = dfma(d, d, dpart);
+          xc[reg] = y;
         }
+        const double d2 = group4_sum(dpart);
+        iters = p.done + (1 << m);
+        if (d2 < tol2) {
+          status = QMPS_ST_OK;
+          active = false;
+        }
+      }
+      // broadcast column 0 to the whole row group for the common epilogue
 #pragma unroll
-      for (int e = 0; e < N; ++e) rprev[e] = rn[e];
+      for (int reg = 0; reg < 4; ++reg) xc[reg] = __shfl(xc[reg], lane & 48, 64);
+    } else {
+    double zc;
+    if (m == 0) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) xc[reg] = __shfl(x0, (lane & 48) | (4 * reg + g), 64);
+      // z_0 = R_0 x_0 (one plain power step); compared-with iterate = x_0
+      double y[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) y[reg] = row16_sum(R[reg] * x0);
+      zc = to_columns(y);
+    } else {
+      // start the comparison chain at z_m = R_m x_0 (= T^(2^m) x_0)
+      double y[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) y[reg] = row16_sum(R[reg] * x0);
+      const double inv0 = 1.0 / group4_sum(y[0]);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        y[reg] *= inv0;
+        xc[reg] = y[reg];
+      }
+      zc = to_columns(y);
+      iters = p.done + (1 << m);
+    }
+    while (p.done + (1 << (m + 1)) <= p.max_iter && m < 29) {
+      if (!__any(active)) break;   // wave-uniform: one item per wave
+      // y = R_m z_m on the VALU while the matrix pipe squares R_m
+      double y[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) y[reg] = R[reg] * zc;
+      const v4f64 Rn = square();
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) y[reg] = row16_sum(y[reg]);   // z_{m+1}, row-distributed
+      ++m;
+      // trace = coordinates a = 0..3 = register 0 of the four row groups
+      const double inv = 1.0 / group4_sum(y[0]);
+      double dpart = 0.0;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        y[reg] *= inv;
+        const double d = y[reg] - xc[reg];
+        dpart = dfma(d, d, dpart);
+        xc[reg] = y[reg];
+      }
+      const double d2 = group4_sum(dpart);
+      zc = to_columns(y);
+      R = Rn;                      // R_{m+1}
       iters = p.done + (1 << m);
       if (d2 < tol2) {
         status = QMPS_ST_OK;
-        break;
+        active = false;
       }
     }
-    __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-      for (int e = 0; e < N; ++e) sY[e] = rprev[e];
     }
-    __syncthreads();
-    if (lane < N) ((double2*)p.r)[b * N + lane] = sY[lane];
-    if (lane == 0) {
-      p.iters[b] = iters;
-      p.status[b] = status;
+    double xp[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) xp[reg] = xc[reg];
+    // unpack x (lane (g, c = 0) holds coordinates 4 reg + g) to the complex r[i][j] and store
+    if (have) {
+      __builtin_amdgcn_wave_barrier();
+      if (c == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) sR[4 * reg + g] = xp[reg];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      if (lane < N) {
+        const int i = lane >> 2, j = lane & 3;
+        double re, im;
+        if (i == j) { re = sR[i]; im = 0.0; }
+        else {
+          const int lo = i < j ? i : j, hi = i < j ? j : i;
+          int pidx = 0;
+          for (int q = 0; q < lo; ++q) pidx += D - 1 - q;
+          pidx += hi - lo - 1;
+          re = 0.70710678118654752 * sR[D + pidx];
+          im = 0.70710678118654752 * sR[D + HB::P + pidx];
+          if (i > j) im = -im;
+        }
+        ((double2*)p.r_out)[b * N + lane] = make_double2(re, im);
+      }
+      if (lane == 0) {
+        p.iters[b] = iters;
+        p.status[b] = status;
+      }
     }
   }
 }
@@ -1093,6 +1294,21 @@ __global__ __launch_bounds__(256) void probe_fp64_kernel(double* out, int iters)
   if (s == 123.456) out[0] = s;  // keep the chain live without a store in the common case
 }
 
+// v_mfma_f64_16x16x4_f64 issue-rate probe: 4 independent accumulators per wave
+__global__ __launch_bounds__(256) void probe_mfma_f64_kernel(double* out, int iters) {
+  typedef double v4 __attribute__((ext_vector_type(4)));
+  v4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
+  const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, b, c3, 0, 0, 0);
+  }
+  const v4 s = c0 + c1 + c2 + c3;
+  if (s[0] + s[1] + s[2] + s[3] == 123.456) out[0] = s[0];
+}
+
 __global__ __launch_bounds__(256) void probe_copy_kernel(const double2* __restrict__ src, double2* __restrict__ dst,
                                                          int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1124,7 +1340,7 @@ static hipError_t launch_block(const LaneArgs& a, bool solve, hipStream_t st) {
 
 hipError_t launch_square_tail(int D, const SquareArgs& a, int grid, hipStream_t st) {
   if (D != 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(env_square_d4_kernel, dim3(grid), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(env_square_d4_kernel, dim3(grid), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -1164,6 +1380,11 @@ hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, 
 
 hipError_t launch_probe_fp64(double* out, int blocks, int iters, hipStream_t st) {
   hipLaunchKernelGGL(probe_fp64_kernel, dim3(blocks), dim3(256), 0, st, out, iters);
+  return hipGetLastError();
+}
+
+hipError_t launch_probe_mfma_f64(double* out, int blocks, int iters, hipStream_t st) {
+  hipLaunchKernelGGL(probe_mfma_f64_kernel, dim3(blocks), dim3(256), 0, st, out, iters);
   return hipGetLastError();
 }
 

@@ -204,6 +204,11 @@ class EnergyEngine:
         L.check(self._lib.qmps_probe_fp64_peak(self._ctx, byref(v)))
         return v.value
 
+    def probe_fp64_mfma_tflops(self, waves_per_simd=1):
+        v = c_double(0)
+        L.check(self._lib.qmps_probe_fp64_mfma_peak(self._ctx, int(waves_per_simd), byref(v)))
+        return v.value
+
     def probe_hbm_gbps(self):
         v = c_double(0)
         L.check(self._lib.qmps_probe_hbm_peak(self._ctx, byref(v)))

@@ -62,7 +62,7 @@ extern "C" {
 /* environment solver selection (flags of qmps_energy_launch) */
 #define QMPS_ENV_POWER 0 /* plain normalised power iteration (`krylov`, PowerCircuit) to convergence */
 /* Power iteration with a repeated-squaring tail (D = 2, 4; identical to QMPS_ENV_POWER for D = 8, 16):
- * `handoff` plain steps (default 64 at D = 2, 128 at D = 4), then items that have not converged
+ * `handoff` plain steps (default 0 = squaring from the start; see qmps_set_handoff), then items that have not converged
  * continue with the power method applied 2^m steps at a time, P_m = T^(2^m) obtained by squaring the
  * D^2 x D^2 transfer matrix, r_m = herm(P_m r)/tr, until ||r_m - r_{m-1}||_F < tol.  Same fixed
  * point, same tolerance; `iters` reports the equivalent number of power steps handoff + 2^m.
@@ -72,7 +72,7 @@ extern "C" {
  * QMPS_SKIP_ROUNDS_D* squarings (no state converges in fewer than 2^skip power steps); the first
  * convergence test compares T^(2^(skip+1)) r_0 with T^(2^skip) r_0. */
 #define QMPS_SKIP_ROUNDS_D2 3
-#define QMPS_SKIP_ROUNDS_D4 5
+#define QMPS_SKIP_ROUNDS_D4 6
 
 typedef struct qmps_ctx qmps_ctx;
 

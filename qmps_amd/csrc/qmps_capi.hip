@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -65,6 +66,7 @@ struct qmps_ctx {
   int32_t* d_work_idx = nullptr;    // [max_batch]
   int handoff = 0;                  // plain power steps before the squaring tail (set in qmps_create)
   int default_solver = 1;           // solver of the one-shot entry points (QMPS_ENV_POWER_SQUARING)
+  int skip_rounds = 0;              // untracked squarings when handoff == 0 (set in qmps_create)
   // state
   int n_terms = 0;
   int64_t n_states = 0;
@@ -189,7 +191,9 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     HIP_TRY(hipMalloc((void**)&c->d_work_count, sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&c->d_work_idx, (size_t)max_batch * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(c->d_work_count, 0, sizeof(int32_t), c->stream));
-    c->handoff = (D == 2) ? 64 : 128;
+    c->handoff = 0;   // D = 2, 4: squaring from the start (fastest); D = 8, 16 have no squaring path
+    c->skip_rounds = (D == 2) ? QMPS_SKIP_ROUNDS_D2 : QMPS_SKIP_ROUNDS_D4;
+    if (const char* e = getenv("QMPS_SKIP_ROUNDS")) c->skip_rounds = atoi(e);   // tuning knob
     return QMPS_OK;
   }();
   if (rc != QMPS_OK) {
@@ -288,7 +292,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   } else if (c->D == 2) {
     a.handoff = c->handoff;  // the squaring tail runs in-lane (real 4 x 4 transfer matrix in registers)
     a.hybrid = 1;
-    a.skip = c->handoff == 0 ? QMPS_SKIP_ROUNDS_D2 : 0;
+    a.skip = c->handoff == 0 ? c->skip_rounds : 0;
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
   } else {
     // D = 4: (1) lane kernel: `handoff` plain steps, slow items -> worklist (skipped when handoff == 0:
@@ -299,7 +303,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     memset(&q, 0, sizeof(q));
     q.A = c->d_A; q.r_out = c->d_r; q.iters = c->d_iters; q.status = c->d_status;
     q.B = B; q.done = c->handoff; q.max_iter = max_iter; q.tol = tol;
-    q.skip = c->handoff == 0 ? QMPS_SKIP_ROUNDS_D4 : 0;
+    q.skip = c->handoff == 0 ? c->skip_rounds : 0;
     qmps::LaneArgs e = make_args(c, B, 1, 1.0, false);
     e.check_pd = 1;
     if (c->handoff > 0) {

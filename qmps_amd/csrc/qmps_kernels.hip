@@ -780,16 +780,25 @@ __device__ __forceinline__ double row16_sum(double v) {
   v += row_ror<1>(v);
   return v;
 }
-// sum of one value per row group (lanes 0, 16, 32, 48) -> wave-uniform
+// sum over the four row groups, per lane position: lane (g, c) receives sum_g' v(g', c).
+// gfx950 v_permlane32_swap / v_permlane16_swap: VALU only, no LDS crossbar, no SGPR round trip.
 __device__ __forceinline__ double group4_sum(double v) {
-  double t = 0.0;
-#pragma unroll
-  for (int gg = 0; gg < 4; ++gg) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 16 * gg);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 16 * gg);
-    t += __hiloint2double(hi, lo);
-  }
-  return t;
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  u2 a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  u2 b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const double x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  lo = __double2loint(x);
+  hi = __double2hiint(x);
+  a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+// wave-uniform copy of lane 0's value
+__device__ __forceinline__ double lane0(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
 }
 
 __global__ __launch_bounds__(256) void env_square_d4_kernel(SquareArgs p) {
@@ -803,35 +812,68 @@ __global__ __launch_bounds__(256) void env_square_d4_kernel(SquareArgs p) {
   double* sR = sR_all[wave];
   const int64_t n_items = p.work_idx != nullptr ? (int64_t)*p.work_count : p.B;
   const double tol2 = p.tol * p.tol;
-  // all waves of a workgroup run the same number of trips (barriers below are workgroup-wide)
-  for (int64_t w0 = (int64_t)blockIdx.x * WAVES; w0 < n_items; w0 += (int64_t)gridDim.x * WAVES) {
-    const int64_t w = w0 + wave;
-    const bool have = w < n_items;
-    const int64_t b = have ? (p.work_idx != nullptr ? (int64_t)p.work_idx[w] : w) : 0;
-    __syncthreads();
-    if (have && lane < 2 * N) sA[lane] = ((const double2*)p.A)[b * (2 * N) + lane];
-    // x0[c]: packed coordinate c of the start matrix (r after `done` plain steps, a warm start, or 1/D)
-    double x0;
-    {
-      const int k = HB::kind(c), i = HB::row(c), j = HB::col(c);
-      if (p.r_in != nullptr && have) {
-        const double2 u = ((const double2*)p.r_in)[b * N + i * D + j], l = ((const double2*)p.r_in)[b * N + j * D + i];
-        x0 = k == 0 ? u.x : (k == 1 ? 0.70710678118654752 * (u.x + l.x) : 0.70710678118654752 * (u.y - l.y));
-      } else {
-        x0 = k == 0 ? 1.0 / D : 0.0;
-      }
+  // lane constants: which (kind, i, i') the four owned rows a = 4 reg + g and the owned column b = c
+  // stand for (hoisted out of the item loop; the tables are tiny loops over constexpr data)
+  int ka[4], ia[4], ipa[4];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    ka[reg] = HB::kind(4 * reg + g);
+    ia[reg] = HB::row(4 * reg + g);
+    ipa[reg] = HB::col(4 * reg + g);
+  }
+  const int kb = HB::kind(c), jb = HB::row(c), jpb = HB::col(c);
+  // every wave walks its own items (wave-private LDS regions, no workgroup barriers); the next item's
+  // tensor is prefetched into a register while the current one is being squared
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  int64_t w = (int64_t)blockIdx.x * WAVES + wave;
+  auto item_id = [&](int64_t ww) { return p.work_idx != nullptr ? (int64_t)p.work_idx[ww] : ww; };
+  double2 a_next = make_double2(0.0, 0.0);
+  if (w < n_items && lane < 2 * N) a_next = ((const double2*)p.A)[item_id(w) * (2 * N) + lane];
+  for (; w < n_items; w += stride) {
+    const bool have = true;
+    const int64_t b = item_id(w);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 2 * N) sA[lane] = a_next;
+    __builtin_amdgcn_wave_barrier();
+    if (w + stride < n_items && lane < 2 * N) a_next = ((const double2*)p.A)[item_id(w + stride) * (2 * N) + lane];
+    // x0[c]: packed coordinate c of the start matrix (r after `done` plain steps or a warm start)
+    double x0 = 0.0;
+    if (p.r_in != nullptr) {
+      const double2 u = ((const double2*)p.r_in)[b * N + jb * D + jpb], l = ((const double2*)p.r_in)[b * N + jpb * D + jb];
+      x0 = kb == 0 ? u.x : (kb == 1 ? 0.70710678118654752 * (u.x + l.x) : 0.70710678118654752 * (u.y - l.y));
       // trace-normalise the start (a warm start may carry any positive trace)
-      double t = (k == 0) ? x0 : 0.0;
-      t = row16_sum(t);
+      const double t = row16_sum(kb == 0 ? x0 : 0.0);
       x0 /= t;
     }
-    __syncthreads();
     // R in accumulator layout: lane holds R[a = 4 reg + g][b = c]
     v4f64 R;
     {
-      auto getA = [&](int s, int i, int j) { return sA[(s * D + i) * D + j]; };
+      // column operands: A_s[.][j], A_s[.][j'] rows are picked per output row below
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) R[reg] = real_transfer_entry<D>(getA, 4 * reg + g, c);
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = ia[reg], ip = ipa[reg];
+        double e1r = 0.0, e1i = 0.0, e2r = 0.0, e2i = 0.0;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const double2 x = sA[(s2 * D + i) * D + jb], y = sA[(s2 * D + ip) * D + jpb];
+          const double2 u = sA[(s2 * D + i) * D + jpb], v = sA[(s2 * D + ip) * D + jb];
+          e1r = dfma(x.x, y.x, e1r);
+          e1r = dfma(x.y, y.y, e1r);
+          e1i = dfma(x.y, y.x, e1i);
+          e1i = dfma(-x.x, y.y, e1i);
+          e2r = dfma(u.x, v.x, e2r);
+          e2r = dfma(u.y, v.y, e2r);
+          e2i = dfma(u.y, v.x, e2i);
+          e2i = dfma(-u.x, v.y, e2i);
+        }
+        // M = T(H_b)[i][i']: diag b: e1; re b: (e1 + e2)/sqrt2; im b: i (e1 - e2)/sqrt2 (see real_transfer_entry)
+        const double mr = kb == 0 ? e1r : (kb == 1 ? e1r + e2r : e2i - e1i);
+        const double mi = kb == 0 ? e1i : (kb == 1 ? e1i + e2i : e1r - e2r);
+        double val = (ka[reg] == 2) ? mi : mr;
+        const bool sa = ka[reg] != 0, sb = kb != 0;
+        val *= (sa && !sb) ? 1.4142135623730951 : ((!sa && sb) ? 0.70710678118654752 : 1.0);
+        R[reg] = val;
+      }
     }
     // Vectors live in two distributions:
     //   row-distributed   (like an accumulator column): lane holds v[4 reg + g], reg = 0..3, all c alike
@@ -843,6 +885,10 @@ __global__ __launch_bounds__(256) void env_square_d4_kernel(SquareArgs p) {
     //   zc = z_m = R_m x_0 = T^(2^m) x_0 (column-distributed), in step with the matrix: z_{m+1} = R_m z_m.
     double* sZ = sR + N * LD;        // 16-double strip behind the padded image
     auto square = [&]() {
+      // R_{m+1} = R_m R_m: 4 x v_mfma_f64_16x16x4_f64 (k-slabs), single accumulator chain.
+      // (Measured alternative: 16 x v_mfma_f64_4x4x4_4b_f64 - 16 cycles each vs ~100 for the 16x16x4
+      // form on gfx950, tools_scratch/mfma_probe.hip - needs 16 LDS fragment reads and 40 more VGPRs
+      // per round and came out 7 % slower end to end; its lane layout is in tools_scratch/mfma4_layout.hip.)
       // LDS image of R_m for the A-operand fragments (wave-private region; LDS is in-order per wave)
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -883,7 +929,7 @@ __global__ __launch_bounds__(256) void env_square_d4_kernel(SquareArgs p) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) xc[reg] = (4 * reg + g == c) ? 1.0 : 0.0;   // e_c
       } else {
-        const double inv0 = 1.0 / group4_sum(R[0]);
+        const double inv0 = 1.0 / lane0(group4_sum(R[0]));
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) xc[reg] = R[reg] * inv0;
         iters = p.done + (1 << m);
@@ -892,7 +938,7 @@ __global__ __launch_bounds__(256) void env_square_d4_kernel(SquareArgs p) {
         if (!__any(active)) break;
         R = square();
         ++m;
-        const double inv = 1.0 / group4_sum(R[0]);
+        const double inv = 1.0 / lane0(group4_sum(R[0]));
         double dpart = 0.0;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -901,7 +947,7 @@ __global__ __launch_bounds__(256) void env_square_d4_kernel(SquareArgs p) {
           dpart = dfma(d, d, dpart);
           xc[reg] = y;
         }
-        const double d2 = group4_sum(dpart);
+        const double d2 = lane0(group4_sum(dpart));
         iters = p.done + (1 << m);
         if (d2 < tol2) {
           status = QMPS_ST_OK;

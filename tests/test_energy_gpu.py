@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 
 E_TOL = 1e-10
 R_TOL = 1e-10
-HANDOFF = {2: 64, 4: 128}        # library defaults (qmps_create); D = 8, 16 have no squaring tail
-SKIP0 = {2: 3, 4: 5}             # QMPS_SKIP_ROUNDS_D2/D4: untracked squarings when handoff == 0
+HANDOFF = {2: 64, 4: 128}        # hand-off points exercised by the 'squaring' variant (library default: 0)
+SKIP0 = {2: 3, 4: 6}             # QMPS_SKIP_ROUNDS_D2/D4: untracked squarings when handoff == 0
 
 
 SOLVERS = ['plain', 'squaring', 'squaring0']     # squaring0: hand-off after 0 plain steps = squaring from the start

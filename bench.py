@@ -177,18 +177,30 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        # dominant kernel (energy_lane_kernel<D,true>): HIP events on the context stream over the timed region
-        kernel_ms = ev_ms / args.steps
+        # dominant kernel: HIP events recorded by the library around it on every launch of the timed region
+        # (context stream); step_ms_events brackets the whole K-step region on the same stream
+        kernel_ms, kernel_name = eng.kernel_time(min(args.steps, 64))
+        step_ms_events = ev_ms / args.steps
         hybrid = args.solver == 'squaring' and D <= 4
         handoff = eng.handoff if hybrid else 0
+        n2 = (D * D) ** 3
         if hybrid:
-            # executed algorithm: min(K, handoff) plain steps + m = log2(K - handoff) squarings of the
-            # real D^2 x D^2 transfer matrix (Hermitian coordinates; 2 (D^2)^3 real flops each) for the handed-off items
+            # executed algorithm: min(K, handoff) plain steps, then m = log2(K - handoff)
+            # squarings of the REAL D^2 x D^2 transfer matrix (2 (D^2)^3 flops each) + its construction
             k_plain = np.minimum(iters, handoff).astype(np.float64)
             m_sq = np.where(iters > handoff, np.log2(np.maximum(iters - handoff, 1)), 0.0)
-            flops = float((flops_per_eval(D, k_plain) + m_sq * 2.0 * (D * D) ** 3).sum())
+            sq_flops = np.where(iters > handoff, m_sq * 2.0 * n2 + 32.0 * D ** 4, 0.0)
+            plain_flops = k_plain * (32 * D ** 3 + 4 * D ** 2)
+            epilogue_flops = 64 * D ** 3 + 128 * D ** 2
+            if D == 4 and handoff == 0:
+                flops = float(sq_flops.sum())           # env_square_d4_kernel only (energy is a separate pass)
+            else:
+                flops = float((plain_flops + sq_flops + epilogue_flops).sum())
+            flop_note = ('executed algorithm: m = log2(K) squarings of the real D^2 x D^2 transfer matrix per item '
+                         '(2 (D^2)^3 flop each) + its construction; K read back per item')
         else:
             flops = float(flops_per_eval(D, iters.astype(np.float64)).sum())
+            flop_note = 'SURVEY 8(d): sum_b [K_b(32D^3+4D^2)+64D^3+128D^2], K_b read back per item'
         tflops = flops / (kernel_ms * 1e-3) * 1e-12
         hbm_gbps = B * bytes_per_eval(D) / (kernel_ms * 1e-3) * 1e-9
         out = {
@@ -207,11 +219,10 @@ def main():
                        'device': info['name'], 'arch': info['arch']},
             'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': tflops / FP64_PEAK_TFLOPS, 'traffic': None,
-                         'kernel': f'energy_lane_kernel<{D},true>' if D <= 4 else f'energy_block_kernel<{D},true>',
-                         'kernel_ms': kernel_ms,
-                         'note': 'FP64 FMA-bound kernel (v_fma_f64; MI355X FP64 vector peak == FP64 matrix peak = '
-                                 '78.6 TFLOP/s); algorithmic FLOPs = sum_b [K_b(32D^3+4D^2)+64D^3+128D^2] with the '
-                                 'per-evaluation iteration counts K_b read back from the device',
+                         'kernel': kernel_name, 'kernel_ms': kernel_ms, 'step_ms_events': step_ms_events,
+                         'note': 'FP64-bound (MI355X FP64 vector == FP64 matrix peak = 78.6 TFLOP/s spec; measured on '
+                                 'this part: v_fma_f64 70.9, v_mfma_f64_16x16x4 47.7 TFLOP/s, profiles/r01_probe.json); '
+                                 'FLOPs = ' + flop_note,
                          'hbm': {'achieved': hbm_gbps, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                  'frac': hbm_gbps / HBM_PEAK_GBPS, 'bytes_per_eval': bytes_per_eval(D)}},
             'summed_cost': float(cost[0]),

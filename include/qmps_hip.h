@@ -147,6 +147,11 @@ int qmps_cell2_energy_batch(qmps_ctx* ctx, int64_t B, const double* U1, const do
 int qmps_timer_begin(qmps_ctx* ctx);
 int qmps_timer_end(qmps_ctx* ctx, float* milliseconds); /* waits for the end event */
 
+/* Average duration (HIP events on the context stream, recorded around the kernel on every launch) of the
+ * DOMINANT kernel of the last n_last (<= 64) qmps_energy_launch calls, and that kernel's name.  Waits
+ * for the stream.  This is what bench.py's roofline.achieved is computed from. */
+int qmps_kernel_time(qmps_ctx* ctx, int n_last, float* avg_ms, char* name, int name_len);
+
 /* ---- multi-GPU: one process per GPU, one RCCL all-reduce of the summed cost over xGMI ---- */
 #define QMPS_UNIQUE_ID_BYTES 128
 int qmps_comm_unique_id(char id[QMPS_UNIQUE_ID_BYTES]); /* rank 0 creates, host code broadcasts */

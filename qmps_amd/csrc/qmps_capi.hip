@@ -48,6 +48,11 @@ struct qmps_ctx {
   int64_t max_batch = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // ring of event pairs around the DOMINANT kernel of each qmps_energy_launch (read by qmps_kernel_time)
+  static constexpr int kRing = 64;
+  hipEvent_t kev0[kRing] = {}, kev1[kRing] = {};
+  int64_t launches = 0;
+  const char* dominant = "";
   // HBM
   void* d_A = nullptr;       // [max_batch][2][D][D] c128
   void* d_U = nullptr;       // [max_batch][2D][2D] c128 (lazy)
@@ -180,6 +185,10 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
+    for (int i = 0; i < qmps_ctx::kRing; ++i) {
+      HIP_TRY(hipEventCreate(&c->kev0[i]));
+      HIP_TRY(hipEventCreate(&c->kev1[i]));
+    }
     HIP_TRY(hipMalloc(&c->d_A, (size_t)max_batch * tensor_bytes(c)));
     HIP_TRY(hipMalloc(&c->d_r, (size_t)max_batch * env_bytes(c)));
     HIP_TRY(hipMalloc(&c->d_h, (size_t)kMaxTerms * 256));
@@ -218,6 +227,10 @@ int qmps_destroy(qmps_ctx* c) {
   if (c->h_cost) (void)hipHostFree(c->h_cost);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (int i = 0; i < qmps_ctx::kRing; ++i) {
+    if (c->kev0[i]) (void)hipEventDestroy(c->kev0[i]);
+    if (c->kev1[i]) (void)hipEventDestroy(c->kev1[i]);
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return QMPS_OK;
@@ -287,13 +300,20 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     return fail(QMPS_ERR_ARG, "unknown environment solver %d", solver);
   qmps::LaneArgs a = make_args(c, B, max_iter, tol, true);
   const bool hybrid = solver == QMPS_ENV_POWER_SQUARING && c->D <= 4 && c->handoff < max_iter;
+  const int slot = (int)(c->launches % qmps_ctx::kRing);
   if (!hybrid) {
+    c->dominant = c->D <= 4 ? "energy_lane_kernel<D,true>" : "energy_block_kernel<D,true>";
+    HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
+    HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
   } else if (c->D == 2) {
     a.handoff = c->handoff;  // the squaring tail runs in-lane (real 4 x 4 transfer matrix in registers)
     a.hybrid = 1;
     a.skip = c->handoff == 0 ? c->skip_rounds : 0;
+    c->dominant = "energy_lane_kernel<2,true>";
+    HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
+    HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
   } else {
     // D = 4: (1) lane kernel: `handoff` plain steps, slow items -> worklist (skipped when handoff == 0:
     // every item goes straight to the squaring kernel); (2) wave-per-item MFMA squaring over the
@@ -312,7 +332,10 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
       a.hybrid = 1;
       a.work_count = c->d_work_count;
       a.work_idx = c->d_work_idx;
+      c->dominant = "energy_lane_kernel<4,true>";
+      HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
       HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
+      HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
       q.r_in = c->d_r;
       q.work_count = c->d_work_count;
       q.work_idx = c->d_work_idx;
@@ -324,9 +347,15 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     int grid = (int)((B + 15) / 16);
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
+    if (c->handoff == 0) {
+      c->dominant = "env_square_d4_kernel";
+      HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+    }
     HIP_TRY(qmps::launch_square_tail(c->D, q, grid, c->stream));
+    if (c->handoff == 0) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
     HIP_TRY(qmps::launch_energy(c->D, e, false, c->stream));
   }
+  c->launches++;
   c->have_env = true;
   return QMPS_OK;
 }
@@ -464,6 +493,26 @@ int qmps_cell2_energy_batch(qmps_ctx* c, int64_t B, const double* U1, const doub
   c->n_states = 0;  // the resident single-site states (if any) are no longer what d_E refers to
   c->have_env = false;
   return qmps_get_energies(c, B, E_out, iters_out, status_out);
+}
+
+int qmps_kernel_time(qmps_ctx* c, int n_last, float* avg_ms, char* name, int name_len) {
+  if (int rc = bind(c)) return rc;
+  if (!avg_ms || n_last < 1) return fail(QMPS_ERR_ARG, "bad arguments");
+  if (c->launches < 1) return fail(QMPS_ERR_STATE, "no energy launch yet");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int64_t n = n_last;
+  if (n > c->launches) n = c->launches;
+  if (n > qmps_ctx::kRing) n = qmps_ctx::kRing;
+  double sum = 0.0;
+  for (int64_t k = 0; k < n; ++k) {
+    const int slot = (int)((c->launches - 1 - k) % qmps_ctx::kRing);
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->kev0[slot], c->kev1[slot]));
+    sum += ms;
+  }
+  *avg_ms = (float)(sum / (double)n);
+  if (name && name_len > 0) snprintf(name, name_len, "%s", c->dominant);
+  return QMPS_OK;
 }
 
 int qmps_timer_begin(qmps_ctx* c) {

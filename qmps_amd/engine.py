@@ -199,6 +199,13 @@ class EnergyEngine:
         L.check(self._lib.qmps_timer_end(self._ctx, byref(ms)))
         return ms.value
 
+    def kernel_time(self, n_last=1):
+        """(average ms, kernel name) of the dominant kernel over the last n_last launches."""
+        ms = c_float(0)
+        name = ctypes.create_string_buffer(128)
+        L.check(self._lib.qmps_kernel_time(self._ctx, int(n_last), byref(ms), name, 128))
+        return ms.value, name.value.decode()
+
     def probe_fp64_tflops(self):
         v = c_double(0)
         L.check(self._lib.qmps_probe_fp64_peak(self._ctx, byref(v)))

@@ -301,7 +301,13 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   qmps::LaneArgs a = make_args(c, B, max_iter, tol, true);
   const bool hybrid = solver == QMPS_ENV_POWER_SQUARING && c->D <= 4 && c->handoff < max_iter;
   const int slot = (int)(c->launches % qmps_ctx::kRing);
-  if (!hybrid) {
+  if (c->D == 16 && !getenv("QMPS_D16_BLOCK")) {
+    // D = 16: power iteration on the matrix cores (one wave per evaluation), then the energy pass
+    c->dominant = "energy_mfma_d16_kernel<true>";
+    HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+    HIP_TRY(qmps::launch_energy_mfma(c->D, a, true, c->stream));
+    HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
+  } else if (!hybrid) {
     c->dominant = c->D <= 4 ? "energy_lane_kernel<D,true>" : "energy_block_kernel<D,true>";
     HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
@@ -387,7 +393,10 @@ int qmps_energy_only_launch(qmps_ctx* c, int64_t B) {
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "qmps_set_hamiltonian has not been called");
   if (!c->have_env) return fail(QMPS_ERR_STATE, "no resident environment: run qmps_energy_launch or qmps_set_env_guess first");
   qmps::LaneArgs a = make_args(c, B, 1, 1.0, false);
-  HIP_TRY(qmps::launch_energy(c->D, a, false, c->stream));
+  if (c->D == 16 && !getenv("QMPS_D16_BLOCK"))
+    HIP_TRY(qmps::launch_energy_mfma(c->D, a, false, c->stream));
+  else
+    HIP_TRY(qmps::launch_energy(c->D, a, false, c->stream));
   return QMPS_OK;
 }
 

@@ -49,6 +49,8 @@ struct SquareArgs {
   double tol;
 };
 
+// D = 16 on the matrix cores: power iteration + Cholesky test + energy epilogue, one wave per evaluation
+hipError_t launch_energy_mfma(int D, const LaneArgs& a, bool solve, hipStream_t st);
 hipError_t launch_square_tail(int D, const SquareArgs& a, int grid, hipStream_t st);
 
 // Two-site unit cell (NonSparseFullTwoSiteEnergyOptimizer): state unitaries U1, U2 [B][2D][2D].

@@ -1307,8 +1307,7 @@ template <int D>
 __device__ __forceinline__ double block_sum(double v, double* red, int tid) {
   // sum over the D*D threads of the workgroup; result broadcast to every thread
   constexpr int N = D * D;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  v = wave_sum(v);   // DPP row rotations + permlane swaps: VALU only, ~20 instructions
   if (N > 64) {
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
@@ -1353,14 +1352,32 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
   sR[i][j] = r;
   __syncthreads();
 
+  // D = 8: row i of A (for X = A r) lives in registers; row j (for r' = X A^+), the r column and the X row
+  // come from LDS (40 instead of 56 ds_read_b128 per step) - keeps the kernel at 4 waves per SIMD, which
+  // matters more here: the step is latency-bound (two LDS round trips + two reductions per step).  D = 16 keeps them in LDS (register budget);
+  // that instantiation is only the fallback behind the MFMA kernel.
+  constexpr bool kRowsInRegs = (D == 8);
+  constexpr int RD = kRowsInRegs ? D : 1;
+  double2 ai_[2][RD];
+  if constexpr (kRowsInRegs) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int k = 0; k < D; ++k) ai_[s][k] = sA[s][i][k];
+  }
   auto apply = [&](double2& out) {
     // X_s[i][j] = sum_k A_s[i][k] r[k][j]
+    double2 rc[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) rc[k] = sR[k][j];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       double xr = 0.0, xi = 0.0;
 #pragma unroll
       for (int k = 0; k < D; ++k) {
-        const double2 a = sA[s][i][k], rr = sR[k][j];
+        double2 a;
+        if constexpr (kRowsInRegs) a = ai_[s][k]; else a = sA[s][i][k];
+        const double2 rr = rc[k];
         xr = dfma(a.x, rr.x, xr);
         xr = dfma(-a.y, rr.y, xr);
         xi = dfma(a.x, rr.y, xi);
@@ -1374,7 +1391,8 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int k = 0; k < D; ++k) {
-        const double2 x = sX[s][i][k], a = sA[s][j][k];
+        const double2 a = sA[s][j][k];
+        const double2 x = sX[s][i][k];
         nr = dfma(x.x, a.x, nr);
         nr = dfma(x.y, a.y, nr);
         ni = dfma(x.y, a.x, ni);

@@ -94,6 +94,17 @@ int qmps_sync(qmps_ctx* ctx);
 /* ---- inputs (host -> HBM, asynchronous on the context stream) --------------------------- */
 /* replaces qmps/tools.py:151-154 (unitary_to_tensor) when kind == QMPS_INPUT_UNITARY */
 int qmps_set_states(qmps_ctx* ctx, int64_t B, const double* states, int kind);
+/* Ansatz parameters -> state tensors ON THE DEVICE (replaces gate construction + cirq.unitary,
+ * qmps/ground_state.py:151-154, and unitary_to_tensor): params[B][n_params] float64.
+ * Gate lists: qmps/represent.py:288-310 (ShallowCNOT, the optimisers' default), :268-285 (QAOA),
+ * :382-404 (ShallowFull, D = 2, 15 angles), :334-354 (ShallowCNOT3). */
+#define QMPS_ANSATZ_SHALLOW_CNOT 0
+#define QMPS_ANSATZ_SHALLOW_QAOA 1
+#define QMPS_ANSATZ_SHALLOW_FULL 2
+#define QMPS_ANSATZ_SHALLOW_CNOT3 3
+int qmps_set_states_ansatz(qmps_ctx* ctx, int64_t B, int kind, int n_params, const double* params);
+/* read back the resident state tensors A[B][2][D][D] (tests / debugging) */
+int qmps_get_states(qmps_ctx* ctx, int64_t B, double* A);
 /* h[n_terms][4][4] complex128, row/col index = 2*s1+s2, s1 = left site
  * (qmps/ground_state.py:82-88 Hamiltonian.to_matrix).  1 <= n_terms <= 16. */
 int qmps_set_hamiltonian(qmps_ctx* ctx, int n_terms, const double* h);

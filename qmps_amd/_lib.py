@@ -15,6 +15,7 @@ QMPS_OK = 0
 QMPS_ERR_ARG, QMPS_ERR_HIP, QMPS_ERR_NO_DEVICE, QMPS_ERR_STATE, QMPS_ERR_RCCL = -1, -2, -3, -4, -5
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_NOT_PD = 0, 1, 2
 INPUT_TENSOR, INPUT_UNITARY = 0, 1
+ANSATZ_SHALLOW_CNOT, ANSATZ_SHALLOW_QAOA, ANSATZ_SHALLOW_FULL, ANSATZ_SHALLOW_CNOT3 = 0, 1, 2, 3
 ENV_POWER = 0
 ENV_POWER_SQUARING = 1
 UNIQUE_ID_BYTES = 128
@@ -32,6 +33,8 @@ SIGNATURES = {
     'qmps_destroy': (c_int, [c_void_p]),
     'qmps_sync': (c_int, [c_void_p]),
     'qmps_set_states': (c_int, [c_void_p, c_int64, _dp, c_int]),
+    'qmps_set_states_ansatz': (c_int, [c_void_p, c_int64, c_int, c_int, _dp]),
+    'qmps_get_states': (c_int, [c_void_p, c_int64, _dp]),
     'qmps_set_hamiltonian': (c_int, [c_void_p, c_int, _dp]),
     'qmps_set_env_guess': (c_int, [c_void_p, c_int64, _dp]),
     'qmps_energy_launch': (c_int, [c_void_p, c_int64, c_int, c_double, c_int]),

@@ -57,6 +57,8 @@ struct qmps_ctx {
   void* d_A = nullptr;       // [max_batch][2][D][D] c128
   void* d_U = nullptr;       // [max_batch][2D][2D] c128 (lazy)
   void* d_U2 = nullptr;      // second unitary of a two-site unit cell (lazy)
+  double* d_params = nullptr;  // ansatz parameters [max_batch][params_cap] (lazy)
+  int params_cap = 0;
   void* d_h = nullptr;       // [16][4][4] c128
   void* d_r = nullptr;       // [max_batch][D][D] c128
   void* d_rho = nullptr;     // [max_batch][4][4] c128 (lazy)
@@ -221,7 +223,7 @@ int qmps_destroy(qmps_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)ncclCommDestroy(c->comm);
-  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_work_count, c->d_work_idx};
+  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_work_count, c->d_work_idx};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
@@ -260,6 +262,42 @@ int qmps_set_states(qmps_ctx* c, int64_t B, const double* states, int kind) {
   c->n_states = B;
   c->have_guess = false;
   c->have_env = false;
+  return QMPS_OK;
+}
+
+int qmps_set_states_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const double* params) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (!params && B > 0) return fail(QMPS_ERR_ARG, "null params");
+  if (n_params < 1 || n_params > 4096) return fail(QMPS_ERR_ARG, "n_params=%d outside [1,4096]", n_params);
+  if (kind < 0 || kind > 3) return fail(QMPS_ERR_ARG, "unknown ansatz kind %d", kind);
+  if (kind == QMPS_ANSATZ_SHALLOW_FULL && (c->D != 2 || n_params != 15))
+    return fail(QMPS_ERR_ARG, "ShallowFullStateTensor is a two-qubit gate: D = 2, 15 parameters");
+  if ((kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_QAOA) && n_params % 2)
+    return fail(QMPS_ERR_ARG, "this ansatz takes (beta, gamma) pairs");
+  if (kind == QMPS_ANSATZ_SHALLOW_CNOT3 && n_params % 3) return fail(QMPS_ERR_ARG, "this ansatz takes (beta, gamma, omega) triples");
+  if (n_params > c->params_cap) {
+    if (c->d_params) HIP_TRY(hipFree(c->d_params));
+    c->d_params = nullptr;
+    HIP_TRY(hipMalloc((void**)&c->d_params, (size_t)c->max_batch * n_params * sizeof(double)));
+    c->params_cap = n_params;
+  }
+  HIP_TRY(hipMemcpyAsync(c->d_params, params, (size_t)B * n_params * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(qmps::launch_ansatz(c->D, kind, c->d_params, n_params, c->d_A, B, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->n_states = B;
+  c->have_guess = false;
+  c->have_env = false;
+  return QMPS_OK;
+}
+
+int qmps_get_states(qmps_ctx* c, int64_t B, double* A) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (!A) return fail(QMPS_ERR_ARG, "null A");
+  if (B > c->n_states) return fail(QMPS_ERR_STATE, "only %lld states are resident", (long long)c->n_states);
+  HIP_TRY(hipMemcpyAsync(A, c->d_A, (size_t)B * tensor_bytes(c), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
 

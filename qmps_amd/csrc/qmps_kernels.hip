@@ -1564,6 +1564,176 @@ __global__ __launch_bounds__(256) void unitary_to_tensor_kernel(const double2* _
 }
 
 // ------------------------------------------------------------------------------------------
+// Kernel 3b: ansatz parameters -> state tensor on the device (qmps/represent.py:268-404).
+// Thread (b, j) simulates the ansatz circuit on the basis state |0>|j> of the n + 1 = log2(2 D) qubit
+// register (big-endian: qubit 0 is the most significant bit) - i.e. column j < D of the unitary, which
+// is all unitary_to_tensor keeps (qmps/tools.py:151-154): A[s][i][j] = U[2 i + s][j].  The 2 D
+// amplitudes live in registers; CNOTs are register renames.  HBM input drops from 64 D^2 bytes (U) to
+// 8 P bytes (parameters) per evaluation.
+//   kind 0: ShallowCNOTStateTensor   per (beta, gamma): rz(beta) all, rx(gamma) all, H(q0), CNOT ladder
+//   kind 1: ShallowQAOAStateTensor   per (beta, gamma): X**beta all, ZZ**gamma neighbours
+//   kind 2: ShallowFullStateTensor   15 angles, two qubits (D = 2)
+//   kind 3: ShallowCNOTStateTensor3  per (beta, gamma, omega): rz, rx, rz all, H(q0), CNOT ladder
+// ------------------------------------------------------------------------------------------
+template <int NQ>
+struct Reg {
+  static constexpr int N = 1 << NQ;
+  double re[N], im[N];
+  __device__ __forceinline__ static constexpr int mask(int q) { return 1 << (NQ - 1 - q); }
+  // general single-qubit gate [[a, b], [c, d]] (complex) on qubit q
+  __device__ __forceinline__ void u2(int q, double ar, double ai, double br, double bi, double cr, double ci, double dr,
+                                     double di) {
+    const int m = mask(q);
+#pragma unroll
+    for (int x = 0; x < N; ++x)
+      if (!(x & m)) {
+        const double pr = re[x], pi = im[x], qr = re[x | m], qi = im[x | m];
+        re[x] = ar * pr - ai * pi + br * qr - bi * qi;
+        im[x] = ar * pi + ai * pr + br * qi + bi * qr;
+        re[x | m] = cr * pr - ci * pi + dr * qr - di * qi;
+        im[x | m] = cr * pi + ci * pr + dr * qi + di * qr;
+      }
+  }
+  __device__ __forceinline__ void rz(int q, double t) {
+    double s, c;
+    sincos(0.5 * t, &s, &c);
+    u2(q, c, -s, 0, 0, 0, 0, c, s);
+  }
+  __device__ __forceinline__ void rx(int q, double t) {
+    double s, c;
+    sincos(0.5 * t, &s, &c);
+    u2(q, c, 0, 0, -s, 0, -s, c, 0);
+  }
+  __device__ __forceinline__ void ry(int q, double t) {
+    double s, c;
+    sincos(0.5 * t, &s, &c);
+    u2(q, c, 0, -s, 0, s, 0, c, 0);
+  }
+  __device__ __forceinline__ void had(int q) {
+    const double h = 0.70710678118654752;
+    u2(q, h, 0, h, 0, h, 0, -h, 0);
+  }
+  __device__ __forceinline__ void xpow(int q, double t) {   // cirq.X**t = e^{i pi t/2} (cos I - i sin X)
+    double s, c, ps, pc;
+    sincos(1.5707963267948966 * t, &s, &c);
+    ps = s; pc = c;                                          // global phase e^{i pi t / 2} = (c + i s)
+    // (pc + i ps) * [[c, -i s], [-i s, c]]
+    const double dr = pc * c, di = ps * c;                   // diagonal
+    const double orr = ps * s, oi = -pc * s;                 // off-diagonal: (pc + i ps)(-i s) = ps s - i pc s
+    u2(q, dr, di, orr, oi, orr, oi, dr, di);
+  }
+  __device__ __forceinline__ void zzpow(int q1, int q2, double t) {   // diag(1, e, e, 1), e = e^{i pi t}
+    double s, c;
+    sincos(3.141592653589793 * t, &s, &c);
+    const int m1 = mask(q1), m2 = mask(q2);
+#pragma unroll
+    for (int x = 0; x < N; ++x)
+      if (((x & m1) != 0) != ((x & m2) != 0)) {
+        const double pr = re[x], pi = im[x];
+        re[x] = c * pr - s * pi;
+        im[x] = c * pi + s * pr;
+      }
+  }
+  __device__ __forceinline__ void cnot(int ctrl, int tgt) {
+    const int mc = mask(ctrl), mt = mask(tgt);
+#pragma unroll
+    for (int x = 0; x < N; ++x)
+      if ((x & mc) && !(x & mt)) {
+        const double pr = re[x], pi = im[x];
+        re[x] = re[x | mt]; im[x] = im[x | mt];
+        re[x | mt] = pr; im[x | mt] = pi;
+      }
+  }
+};
+
+template <int D, int KIND>
+__global__ __launch_bounds__(64) void ansatz_tensor_kernel(const double* __restrict__ params, int n_params,
+                                                           double2* __restrict__ A, int64_t B) {
+  constexpr int NQ = (D == 2 ? 2 : D == 4 ? 3 : D == 8 ? 4 : 5);
+  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t b = t / D;
+  const int j = (int)(t % D);
+  if (b >= B) return;
+  const double* pp = params + b * n_params;
+  Reg<NQ> r;
+#pragma unroll
+  for (int x = 0; x < Reg<NQ>::N; ++x) {
+    r.re[x] = (x == j) ? 1.0 : 0.0;
+    r.im[x] = 0.0;
+  }
+  if (KIND == 0 || KIND == 3) {
+    const int per = (KIND == 0) ? 2 : 3;
+    for (int l = 0; l + per <= n_params; l += per) {
+      const double beta = pp[l], gamma = pp[l + 1];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) r.rz(q, beta);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) r.rx(q, gamma);
+      if (KIND == 3) {
+        const double omega = pp[l + 2];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) r.rz(q, omega);
+      }
+      r.had(0);
+#pragma unroll
+      for (int q = NQ - 2; q >= 0; --q) r.cnot(q, q + 1);
+    }
+  } else if (KIND == 1) {
+    for (int l = 0; l + 2 <= n_params; l += 2) {
+      const double beta = pp[l], gamma = pp[l + 1];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) r.xpow(q, beta);
+#pragma unroll
+      for (int q = 0; q + 1 < NQ; ++q) r.zzpow(q, q + 1, gamma);
+    }
+  } else if (KIND == 2) {
+    if constexpr (NQ == 2) {
+      r.rz(0, pp[0]); r.rx(0, pp[1]); r.rz(0, pp[2]);
+      r.rz(1, pp[3]); r.rx(1, pp[4]); r.rz(1, pp[5]);
+      r.cnot(0, 1);
+      r.ry(0, pp[6]);
+      r.cnot(1, 0);
+      r.ry(0, pp[7]); r.rz(1, pp[8]);
+      r.cnot(0, 1);
+      r.rz(0, pp[9]); r.rx(0, pp[10]); r.rz(0, pp[11]);
+      r.rz(1, pp[12]); r.rx(1, pp[13]); r.rz(1, pp[14]);
+    }
+  }
+  // A[b][s][i][j] = amplitude[2 i + s]
+  double2* out = A + b * (2 * D * D);
+#pragma unroll
+  for (int x = 0; x < Reg<NQ>::N; ++x) out[((x & 1) * D + (x >> 1)) * D + j] = make_double2(r.re[x], r.im[x]);
+}
+
+template <int D>
+static hipError_t launch_ansatz_d(int kind, const double* params, int n_params, void* A, int64_t B, hipStream_t st) {
+  const int64_t threads = B * D;
+  const dim3 grid((unsigned)((threads + 63) / 64)), block(64);
+  switch (kind) {
+    case 0: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 0>), grid, block, 0, st, params, n_params, (double2*)A, B); break;
+    case 1: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 1>), grid, block, 0, st, params, n_params, (double2*)A, B); break;
+    case 2:
+      if (D != 2) return hipErrorInvalidValue;
+      hipLaunchKernelGGL((ansatz_tensor_kernel<2, 2>), grid, block, 0, st, params, n_params, (double2*)A, B);
+      break;
+    case 3: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 3>), grid, block, 0, st, params, n_params, (double2*)A, B); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, void* A, int64_t B, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  switch (D) {
+    case 2: return launch_ansatz_d<2>(kind, params, n_params, A, B, st);
+    case 4: return launch_ansatz_d<4>(kind, params, n_params, A, B, st);
+    case 8: return launch_ansatz_d<8>(kind, params, n_params, A, B, st);
+    case 16: return launch_ansatz_d<16>(kind, params, n_params, A, B, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Kernel 4: cost[t] = sum_b E[b][t]   (rotosolve's M(x) = np.sum(eps(...)), qmps/tools.py:432-433)
 // Deterministic two-pass reduction: per-block partials, then one block sums the partials.
 // ------------------------------------------------------------------------------------------

@@ -74,6 +74,20 @@ class EnergyEngine:
         L.check(self._lib.qmps_set_states(self._ctx, U.shape[0], _f64(U.view(np.float64)), L.INPUT_UNITARY))
         self.B = U.shape[0]
 
+    def set_ansatz_params(self, kind, params):
+        """params: (B, P) float64 ansatz angles; the state tensors are built on the device.
+        kind: L.ANSATZ_* (0 ShallowCNOT, 1 QAOA, 2 ShallowFull [D = 2], 3 ShallowCNOT3)."""
+        params = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
+        L.check(self._lib.qmps_set_states_ansatz(self._ctx, params.shape[0], int(kind), params.shape[1], _f64(params)))
+        self.B = params.shape[0]
+
+    def tensors(self, B=None):
+        """Read back the resident state tensors (B, 2, D, D)."""
+        B = self.B if B is None else B
+        A = np.empty((B, 2, self.D, self.D), dtype=np.complex128)
+        L.check(self._lib.qmps_get_states(self._ctx, B, _f64(A.view(np.float64))))
+        return A
+
     def set_hamiltonian(self, h):
         """h: (4, 4) or (n_terms, 4, 4) complex; index 2*s1+s2 with s1 the left site."""
         h = np.ascontiguousarray(np.asarray(h, dtype=np.complex128).reshape(-1, 4, 4))

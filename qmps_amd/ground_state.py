@@ -165,8 +165,24 @@ class SparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
     def unitaries(self, params_batch):
         return np.stack([unitary(self.state_tensor(self.D, p)) for p in np.atleast_2d(params_batch)])
 
+    def _energies_from_params(self, params_batch):
+        """params -> energies.  For the ansatz classes libqmps_hip knows (`device_kind`), the circuit is
+        simulated on the GPU: 8 P bytes per evaluation cross PCIe instead of a 2D x 2D
+        unitary built gate by gate on the host; any other gate class goes through `unitary()`."""
+        P = np.ascontiguousarray(np.atleast_2d(params_batch), dtype=np.float64)
+        kind = getattr(self.state_tensor, 'device_kind', None)
+        if kind is None or (kind == 2 and self.D != 2):
+            return self._energies_from_unitaries(self.unitaries(P))
+        eng = _runtime.engine(self.D, P.shape[0])
+        eng.set_ansatz_params(kind, P)
+        eng.set_hamiltonian(_as_h(self.H))
+        eng.set_env_guess(None)
+        eng.launch(max_iter=self.max_iter, tol=self.env_tol)
+        E, it, st = eng.results()
+        return E[:, 0], it, st
+
     def objective_function_exact_environment(self, u_params):
-        E, _, st = self._energies_from_unitaries(self.unitaries(u_params))
+        E, _, st = self._energies_from_params(u_params)
         if st[0] != STATUS_OK:
             # the reference catches cholesky's LinAlgError, prints and returns the previous value
             print('LinAlgError')
@@ -177,7 +193,7 @@ class SparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
     def batch_objective_function(self, params_batch):
         """One kernel launch for B parameter vectors.  Entries whose environment is not positive
         definite / not converged are NaN (there is no 'previous value' in a batch)."""
-        E, _, st = self._energies_from_unitaries(self.unitaries(params_batch))
+        E, _, st = self._energies_from_params(params_batch)
         return np.where(st == STATUS_OK, E, np.nan)
 
     def update_state(self):

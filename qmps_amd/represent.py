@@ -260,6 +260,7 @@ class _Ansatz(Gate):
 
 class ShallowQAOAStateTensor(_Ansatz):
     """Per (beta, gamma): X**beta on every qubit, ZZ**gamma on neighbours (represent.py:268-285)."""
+    device_kind = 1      # QMPS_ANSATZ_SHALLOW_QAOA: parameters -> tensor runs on the GPU for batches
 
     def _decompose_(self, qubits):
         return [[x_pow(b)(q) for q in qubits] + [zz_pow(g)(qubits[i], qubits[i + 1]) for i in range(self.n_qubits - 1)]
@@ -269,6 +270,7 @@ class ShallowQAOAStateTensor(_Ansatz):
 class ShallowCNOTStateTensor(_Ansatz):
     """Per (beta, gamma): rz(beta) on all, rx(gamma) on all, H(q0), CNOT ladder from the bottom
     (represent.py:288-310).  The default state tensor of SparseFullEnergyOptimizer."""
+    device_kind = 0      # QMPS_ANSATZ_SHALLOW_CNOT
 
     @staticmethod
     def params_per_iter():
@@ -298,6 +300,7 @@ class ShallowCNOTStateTensor_nonuniform(_Ansatz):
 
 class ShallowCNOTStateTensor3(_Ansatz):
     """rz, rx, rz on all qubits, H(q0), CNOT ladder (represent.py:334-354)."""
+    device_kind = 3      # QMPS_ANSATZ_SHALLOW_CNOT3
 
     def _decompose_(self, qubits):
         return [[rz(b)(q) for q in qubits] + [rx(g)(q) for q in qubits] + [rz(w)(q) for q in qubits] + [H(qubits[0])] +
@@ -321,6 +324,7 @@ class ExactAfter4(_Ansatz):
 
 class ShallowFullStateTensor(_Ansatz):
     """Universal two-qubit gate, 15 angles (represent.py:382-404)."""
+    device_kind = 2      # QMPS_ANSATZ_SHALLOW_FULL (D = 2)
 
     def __init__(self, bond_dim, βγs, symbol='U'):
         super().__init__(bond_dim, βγs)

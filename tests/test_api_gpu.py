@@ -46,6 +46,48 @@ def test_sparse_full_energy_optimizer_objective(golden):
         assert np.all(E_ref >= E0)
 
 
+@pytest.mark.parametrize('D', [2, 4, 8, 16])
+def test_device_ansatz_builder(D, engine_factory):
+    """parameters -> state tensor on the device == host gate-by-gate construction
+    (represent.py:268-404) followed by unitary_to_tensor (tools.py:151-154)."""
+    from qmps_amd import _lib as L
+    rng = np.random.default_rng(31 + D)
+    eng = engine_factory(D)
+    cases = [(L.ANSATZ_SHALLOW_CNOT, R.ShallowCNOTStateTensor, 6), (L.ANSATZ_SHALLOW_QAOA, R.ShallowQAOAStateTensor, 4),
+             (L.ANSATZ_SHALLOW_CNOT3, R.ShallowCNOTStateTensor3, 6)]
+    if D == 2:
+        cases.append((L.ANSATZ_SHALLOW_FULL, R.ShallowFullStateTensor, 15))
+    for kind, cls, npar in cases:
+        P = rng.standard_normal((37, npar))
+        eng.set_ansatz_params(kind, P)
+        A_dev = eng.tensors()
+        A_host = np.stack([T.unitary_to_tensor(R.unitary(cls(D, p))) for p in P])
+        assert np.abs(A_dev - A_host).max() < 1e-13, (kind, D)
+    with pytest.raises(L.QmpsError):
+        eng.set_ansatz_params(L.ANSATZ_SHALLOW_CNOT, rng.standard_normal((3, 5)))      # odd number of angles
+    if D != 2:
+        with pytest.raises(L.QmpsError):
+            eng.set_ansatz_params(L.ANSATZ_SHALLOW_FULL, rng.standard_normal((3, 15)))
+
+
+def test_optimizer_uses_device_builder_and_host_fallback_agree(golden):
+    """The batched objective of the default ansatz (device circuit simulation) equals the same objective
+    for a gate class the library does not know (host `unitary()` path)."""
+    h = golden['ref_h_tfim']
+
+    class HostOnlyCNOT(R.ShallowCNOTStateTensor):
+        device_kind = None
+
+    rng = np.random.default_rng(8)
+    P = rng.standard_normal((50, 4))
+    for D in (2, 4):
+        a = G.SparseFullEnergyOptimizer(h, D, 2, initial_guess=P[0].copy())
+        b = G.SparseFullEnergyOptimizer(h, D, 2, state_tensor=HostOnlyCNOT, initial_guess=P[0].copy())
+        ea, eb = a.batch_objective_function(P), b.batch_objective_function(P)
+        ok = np.isfinite(ea) & np.isfinite(eb)
+        assert ok.mean() > 0.9 and np.abs(ea - eb)[ok].max() < 1e-11
+
+
 def test_sparse_optimizer_linalgerror_branch(capsys):
     """ground_state.py:153-157: not-PD environment -> prints, returns the previous value."""
     h = G.Hamiltonian({'ZZ': -1, 'X': 1}).to_matrix()

@@ -103,6 +103,14 @@ int qmps_set_states(qmps_ctx* ctx, int64_t B, const double* states, int kind);
 #define QMPS_ANSATZ_SHALLOW_FULL 2
 #define QMPS_ANSATZ_SHALLOW_CNOT3 3
 int qmps_set_states_ansatz(qmps_ctx* ctx, int64_t B, int kind, int n_params, const double* params);
+/* Device-resident single-frequency rotosolve (qmps/rotosolve.py:154-181; the caller shape of SURVEY
+ * 8(a)-10/(f)-2): R restarts in lock-step; for each parameter i ONE batch of 3 R evaluations (shifts
+ * 0, +pi/2, -pi/2) - ansatz build, environment, energy - and the closed-form update all run on the device,
+ * n_sweeps x n_params times, without a host round trip.  params[R][n_params] is updated in place;
+ * E_hist[n_sweeps][R] receives the energy (summed over the resident Hamiltonian terms, like the
+ * reference's M(x) = np.sum(eps)) after each sweep.  Needs 3 R <= max_batch and a Hamiltonian. */
+int qmps_rotosolve(qmps_ctx* ctx, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter,
+                   double tol, double* E_hist);
 /* read back the resident state tensors A[B][2][D][D] (tests / debugging) */
 int qmps_get_states(qmps_ctx* ctx, int64_t B, double* A);
 /* h[n_terms][4][4] complex128, row/col index = 2*s1+s2, s1 = left site

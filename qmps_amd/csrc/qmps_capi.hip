@@ -291,6 +291,63 @@ int qmps_set_states_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const
   return QMPS_OK;
 }
 
+int qmps_rotosolve(qmps_ctx* c, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter,
+                   double tol, double* E_hist) {
+  if (int rc = bind(c)) return rc;
+  if (R < 1 || 3 * R > c->max_batch) return fail(QMPS_ERR_ARG, "3 R = %lld evaluations exceed max_batch = %lld", (long long)(3 * R), (long long)c->max_batch);
+  if (!params || !E_hist) return fail(QMPS_ERR_ARG, "null argument");
+  if (n_sweeps < 1) return fail(QMPS_ERR_ARG, "n_sweeps must be >= 1");
+  if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "qmps_set_hamiltonian has not been called");
+  // validate (kind, n_params) and size d_params for the 3 R shifted parameter vectors
+  {
+    double dummy[1] = {0.0};
+    (void)dummy;
+  }
+  if (kind < 0 || kind > 3) return fail(QMPS_ERR_ARG, "unknown ansatz kind %d", kind);
+  if (kind == QMPS_ANSATZ_SHALLOW_FULL && (c->D != 2 || n_params != 15)) return fail(QMPS_ERR_ARG, "ShallowFullStateTensor: D = 2, 15 parameters");
+  if ((kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_QAOA) && n_params % 2) return fail(QMPS_ERR_ARG, "this ansatz takes (beta, gamma) pairs");
+  if (kind == QMPS_ANSATZ_SHALLOW_CNOT3 && n_params % 3) return fail(QMPS_ERR_ARG, "this ansatz takes (beta, gamma, omega) triples");
+  if (n_params > c->params_cap) {
+    if (c->d_params) HIP_TRY(hipFree(c->d_params));
+    c->d_params = nullptr;
+    HIP_TRY(hipMalloc((void**)&c->d_params, (size_t)c->max_batch * n_params * sizeof(double)));
+    c->params_cap = n_params;
+  }
+  double *d_base = nullptr, *d_hist = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_base, (size_t)R * n_params * sizeof(double)));
+  if (hipMalloc((void**)&d_hist, (size_t)R * n_sweeps * sizeof(double)) != hipSuccess) {
+    (void)hipFree(d_base);
+    return fail(QMPS_ERR_HIP, "hipMalloc failed");
+  }
+  int rc = [&]() -> int {
+    HIP_TRY(hipMemcpyAsync(d_base, params, (size_t)R * n_params * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const bool saved_guess = c->have_guess;
+    c->have_guess = false;
+    for (int sw = 0; sw < n_sweeps; ++sw) {
+      for (int i = 0; i < n_params; ++i) {
+        HIP_TRY(qmps::launch_roto_shift(d_base, c->d_params, (int)R, n_params, i, c->stream));
+        HIP_TRY(qmps::launch_ansatz(c->D, kind, c->d_params, n_params, c->d_A, 3 * R, c->stream));
+        c->n_states = 3 * R;
+        if (int e = qmps_energy_launch(c, 3 * R, max_iter, tol, c->default_solver)) return e;
+        HIP_TRY(qmps::launch_roto_update(d_base, c->d_E, c->d_status, (int)R, n_params, i, c->n_terms, c->stream));
+      }
+      HIP_TRY(qmps::launch_ansatz(c->D, kind, d_base, n_params, c->d_A, R, c->stream));
+      c->n_states = R;
+      if (int e = qmps_energy_launch(c, R, max_iter, tol, c->default_solver)) return e;
+      HIP_TRY(qmps::launch_roto_record(c->d_E, d_hist + (size_t)sw * R, (int)R, c->n_terms, c->stream));
+    }
+    c->have_guess = saved_guess;
+    HIP_TRY(hipMemcpyAsync(params, d_base, (size_t)R * n_params * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(E_hist, d_hist, (size_t)R * n_sweeps * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QMPS_OK;
+  }();
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(d_base);
+  (void)hipFree(d_hist);
+  return rc;
+}
+
 int qmps_get_states(qmps_ctx* c, int64_t B, double* A) {
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;

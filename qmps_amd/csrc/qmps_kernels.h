@@ -72,6 +72,10 @@ hipError_t launch_cell2(int D, const Cell2Args& a, hipStream_t st);
 hipError_t launch_energy(int D, const LaneArgs& a, bool solve, hipStream_t st);
 // ansatz parameters [B][n_params] -> state tensors A [B][2][D][D]; kind: 0 ShallowCNOT, 1 QAOA, 2 ShallowFull (D=2), 3 ShallowCNOT3
 hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, void* A, int64_t B, hipStream_t st);
+hipError_t launch_roto_shift(const double* base, double* out, int R, int P, int i, hipStream_t st);
+hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int i, int n_terms,
+                              hipStream_t st);
+hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, hipStream_t st);
 hipError_t launch_unitary_to_tensor(const void* U, void* A, int D, int64_t B, hipStream_t st);
 hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, int n_partial, double* cost,
                       hipStream_t st);

@@ -1734,6 +1734,70 @@ hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, vo
 }
 
 // ------------------------------------------------------------------------------------------
+// Kernel 3c: device-resident rotosolve (qmps/rotosolve.py:154-181).  For parameter i,
+// R restarts x 3 shifts {0, +pi/2, -pi/2} form one batch; the closed-form update
+//   theta* = -pi/2 - atan2(2 e0 - e+ - e-, e+ - e-),  params[i] = wrap(params[i] + wrap(theta*))
+// runs on the device, so a whole sweep needs no host round trip.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roto_shift_kernel(const double* __restrict__ base, double* __restrict__ out, int R,
+                                                         int P, int i) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)R * 3 * P) return;
+  const int col = (int)(t % P);
+  const int64_t row = t / P;
+  const int k = (int)(row % 3);
+  const int64_t r = row / 3;
+  double v = base[r * P + col];
+  if (col == i) v += (k == 0) ? 0.0 : (k == 1 ? 1.5707963267948966 : -1.5707963267948966);
+  out[t] = v;
+}
+
+__device__ __forceinline__ double wrap_pi(double x) { return atan2(sin(x), cos(x)); }
+
+__global__ __launch_bounds__(256) void roto_update_kernel(double* __restrict__ base, const double* __restrict__ E,
+                                                          const int32_t* __restrict__ status, int R, int P, int i,
+                                                          int n_terms) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  double e[3];
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double v = 0.0;
+    for (int q = 0; q < n_terms; ++q) v += E[((int64_t)r * 3 + k) * n_terms + q];   // M(x) = sum over terms
+    e[k] = v;
+    ok = ok && status[(int64_t)r * 3 + k] == QMPS_ST_OK;
+  }
+  if (!ok) return;   // an evaluation without a valid environment: leave this restart's parameter untouched
+  const double theta = -1.5707963267948966 - atan2(2.0 * e[0] - e[1] - e[2], e[1] - e[2]);
+  base[(int64_t)r * P + i] = wrap_pi(base[(int64_t)r * P + i] + wrap_pi(theta));
+}
+
+__global__ __launch_bounds__(256) void roto_record_kernel(const double* __restrict__ E, double* __restrict__ hist, int R,
+                                                          int n_terms) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  double v = 0.0;
+  for (int q = 0; q < n_terms; ++q) v += E[(int64_t)r * n_terms + q];
+  hist[r] = v;
+}
+
+hipError_t launch_roto_shift(const double* base, double* out, int R, int P, int i, hipStream_t st) {
+  const int64_t n = (int64_t)R * 3 * P;
+  hipLaunchKernelGGL(roto_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, base, out, R, P, i);
+  return hipGetLastError();
+}
+hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int i, int n_terms,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(roto_update_kernel, dim3((R + 255) / 256), dim3(256), 0, st, base, E, status, R, P, i, n_terms);
+  return hipGetLastError();
+}
+hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, hipStream_t st) {
+  hipLaunchKernelGGL(roto_record_kernel, dim3((R + 255) / 256), dim3(256), 0, st, E, hist, R, n_terms);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Kernel 4: cost[t] = sum_b E[b][t]   (rotosolve's M(x) = np.sum(eps(...)), qmps/tools.py:432-433)
 // Deterministic two-pass reduction: per-block partials, then one block sums the partials.
 // ------------------------------------------------------------------------------------------

@@ -92,3 +92,18 @@ def batched_double_rotosolve(batch_eps, initial_parameters, N_iters=5):
                     params[r, i] += _double_sinusoid_shift(*e[r])
         es.append(np.asarray(batch_eps(params)))
     return np.array(es), params
+
+
+def device_rotosolve(optimizer, initial_parameters, N_iters=10):
+    """R restarts x P parameters entirely on the GPU (libqmps_hip `qmps_rotosolve`): `optimizer` is a
+    SparseFullEnergyOptimizer whose ansatz class the library can simulate (`device_kind`).  Same update
+    rule as `batched_rotosolve`; returns (energies (N_iters, R), params (R, P))."""
+    from . import _runtime
+    from .ground_state import _as_h
+    kind = getattr(optimizer.state_tensor, 'device_kind', None)
+    if kind is None:
+        raise ValueError(f'{optimizer.state_tensor.__name__} has no device implementation; use batched_rotosolve')
+    P = np.atleast_2d(np.asarray(initial_parameters, dtype=float))
+    eng = _runtime.engine(optimizer.D, 3 * P.shape[0])
+    eng.set_hamiltonian(_as_h(optimizer.H))
+    return eng.rotosolve(kind, P, N_iters, max_iter=optimizer.max_iter, tol=optimizer.env_tol)

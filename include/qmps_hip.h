@@ -162,6 +162,19 @@ int qmps_cell2_energy_batch(qmps_ctx* ctx, int64_t B, const double* U1, const do
                             int n_terms, int max_iter, double tol, double* E_out, int32_t* iters_out,
                             int32_t* status_out);
 
+/* Time-evolution overlap objective, D = 2 (qmps/new_time_evolve.py:193-221, scripts/loschmidt.py:209-239):
+ * eta_b = dominant eigenvalue of x -> sum_{s<4} (WW . merge(A, A))_s x merge(B_b, B_b)_s^+ ; the reference's
+ * 6-qubit circuit measures 2 |psi[0]| = |eta| and minimises -sqrt(|eta|).  A: one tensor [2][2][2] shared by
+ * the batch (a_shared = 1, the usual case: the current state) or one per item.  Candidates B_b: tensors
+ * (QMPS_INPUT_TENSOR), unitaries (QMPS_INPUT_UNITARY) or ansatz parameters built on the device
+ * (QMPS_INPUT_ANSATZ_BASE + QMPS_ANSATZ_*, n_params each).  eta_out [B] complex128; r_out nullable
+ * [B][2][2] (unit-Frobenius right fixed point, what xmps Map.right_fixed_point returns up to phase);
+ * rounds_out = squarings used; status 1 = no unique dominant eigenvalue within max_rounds. */
+#define QMPS_INPUT_ANSATZ_BASE 16
+int qmps_overlap_batch(qmps_ctx* ctx, int64_t B, const double* A, int a_shared, const double* states, int kind,
+                       int n_params, const double* WW, int max_rounds, double tol, double* eta_out, double* r_out,
+                       int32_t* rounds_out, int32_t* status_out);
+
 /* ---- timing on the context stream (HIP events) ------------------------------------------ */
 int qmps_timer_begin(qmps_ctx* ctx);
 int qmps_timer_end(qmps_ctx* ctx, float* milliseconds); /* waits for the end event */

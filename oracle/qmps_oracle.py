@@ -433,3 +433,57 @@ def rotosolve_update(e0, ep, em):
     """rotosolve.py:175-177."""
     th = -np.pi / 2 - np.arctan2(2 * e0 - ep - em, ep - em)
     return float(np.arctan2(np.sin(th), np.cos(th)))
+
+
+# ----------------------------------------------------------------------------
+# f-3  time-evolution overlap objective (qmps/new_time_evolve.py:193-221, scripts/loschmidt.py:209-239)
+# ----------------------------------------------------------------------------
+def put_env_on_left_site(q):
+    """qmps/time_evolve_tools.py:38-53: 4x4 unitary carrying q/||q|| (restated; SWAP applied on the left)."""
+    a, b, c, d = np.asarray(q).T.reshape(-1)
+    n = np.sqrt(abs(a) ** 2 + abs(b) ** 2 + abs(c) ** 2 + abs(d) ** 2)
+    guess = np.array([[a, np.conj(c), b, np.conj(d)], [c, -np.conj(a), d, -np.conj(b)]]) / n
+    full = np.concatenate([guess, null_space(guess).conj().T], axis=0)
+    return SWAP @ full
+
+
+def put_env_on_right_site(q):
+    """qmps/time_evolve_tools.py:59-70."""
+    a, b, c, d = np.asarray(q).reshape(-1)
+    n = np.sqrt(abs(a) ** 2 + abs(b) ** 2 + abs(c) ** 2 + abs(d) ** 2)
+    guess = np.array([[a, b, np.conj(d), -np.conj(c)], [c, d, -np.conj(b), np.conj(a)]]) / n
+    return np.concatenate([guess, null_space(guess).conj().T], axis=0)
+
+
+def overlap_eta(A, B, WW):
+    """Dominant eigenvalue eta and unit-Frobenius right fixed point r of the mixed two-site transfer map
+    x -> sum_s (WW . merge(A,A))_s x merge(B,B)_s^dagger  - `Map(tensordot(WW, merge(A,A), [1,0]),
+    merge(B,B)).right_fixed_point()` at new_time_evolve.py:198-199 (xmps, external)."""
+    C = np.tensordot(WW, merge(A, A), [1, 0])
+    Bm = merge(B, B)
+    w, v = np.linalg.eig(transfer_matrix(C, Bm))
+    k = int(np.argmax(np.abs(w)))
+    D = A.shape[1]
+    r = v[:, k].reshape(D, D)
+    return w[k], r / np.linalg.norm(r)
+
+
+def overlap_objective(A, B, WW):
+    """-sqrt(2 |psi[0]|) of the reference's circuit == -sqrt(|eta|)."""
+    return -np.sqrt(abs(overlap_eta(A, B, WW)[0]))
+
+
+def overlap_circuit_amplitude(A, B, WW, r):
+    """psi[0] of the 6-qubit circuit of scripts/loschmidt.py:228-238 (Bell pair on q3,q4; U,U,W,L,R,U'^+,U'^+;
+    un-Bell) with l = r, simulated in complex128 with this file's register model."""
+    U, Up = tensor_to_unitary(A), tensor_to_unitary(B)
+    R = put_env_on_left_site(r)
+    L = put_env_on_right_site(r.conj().T)
+    n = 6
+    psi = np.zeros(2 ** n, dtype=complex)
+    psi[0] = 1
+    ops = [(HAD, [3]), (CNOT, [3, 4]), (U, [2, 3]), (U, [1, 2]), (WW, [2, 3]), (L, [0, 1]), (R, [4, 5]),
+           (Up.conj().T, [1, 2]), (Up.conj().T, [2, 3]), (CNOT, [3, 4]), (HAD, [3])]
+    for g, qs in ops:
+        psi = _on(n, g, qs) @ psi
+    return psi[0]

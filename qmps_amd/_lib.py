@@ -15,6 +15,7 @@ QMPS_OK = 0
 QMPS_ERR_ARG, QMPS_ERR_HIP, QMPS_ERR_NO_DEVICE, QMPS_ERR_STATE, QMPS_ERR_RCCL = -1, -2, -3, -4, -5
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_NOT_PD = 0, 1, 2
 INPUT_TENSOR, INPUT_UNITARY = 0, 1
+INPUT_ANSATZ_BASE = 16
 ANSATZ_SHALLOW_CNOT, ANSATZ_SHALLOW_QAOA, ANSATZ_SHALLOW_FULL, ANSATZ_SHALLOW_CNOT3 = 0, 1, 2, 3
 ENV_POWER = 0
 ENV_POWER_SQUARING = 1
@@ -51,6 +52,7 @@ SIGNATURES = {
     'qmps_env_batch': (c_int, [c_void_p, c_int64, _dp, c_int, _dp, c_int, c_double, _dp, _ip, _ip]),
     'qmps_cell2_energy_batch': (c_int, [c_void_p, c_int64, _dp, _dp, _dp, c_int, c_int, c_double, _dp, _ip, _ip]),
     'qmps_kernel_time': (c_int, [c_void_p, c_int, POINTER(c_float), c_char_p, c_int]),
+    'qmps_overlap_batch': (c_int, [c_void_p, c_int64, _dp, c_int, _dp, c_int, c_int, _dp, c_int, c_double, _dp, _dp, _ip, _ip]),
     'qmps_timer_begin': (c_int, [c_void_p]),
     'qmps_timer_end': (c_int, [c_void_p, POINTER(c_float)]),
     'qmps_comm_unique_id': (c_int, [c_char_p]),

@@ -58,6 +58,8 @@ struct qmps_ctx {
   void* d_U = nullptr;       // [max_batch][2D][2D] c128 (lazy)
   void* d_U2 = nullptr;      // second unitary of a two-site unit cell (lazy)
   double* d_params = nullptr;  // ansatz parameters [max_batch][params_cap] (lazy)
+  void* d_ww = nullptr;        // two-site operator of the overlap objective (lazy)
+  void* d_eta = nullptr;       // overlap eigenvalues [max_batch] complex (lazy)
   int params_cap = 0;
   void* d_h = nullptr;       // [16][4][4] c128
   void* d_r = nullptr;       // [max_batch][D][D] c128
@@ -223,7 +225,7 @@ int qmps_destroy(qmps_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)ncclCommDestroy(c->comm);
-  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_work_count, c->d_work_idx};
+  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_work_count, c->d_work_idx};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
@@ -616,6 +618,43 @@ int qmps_kernel_time(qmps_ctx* c, int n_last, float* avg_ms, char* name, int nam
   }
   *avg_ms = (float)(sum / (double)n);
   if (name && name_len > 0) snprintf(name, name_len, "%s", c->dominant);
+  return QMPS_OK;
+}
+
+int qmps_overlap_batch(qmps_ctx* c, int64_t B, const double* A, int a_shared, const double* states, int kind,
+                       int n_params, const double* WW, int max_rounds, double tol, double* eta_out, double* r_out,
+                       int32_t* rounds_out, int32_t* status_out) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (c->D != 2) return fail(QMPS_ERR_ARG, "the time-evolution overlap path is D = 2 only (qmps/time_evolve_tools.py)");
+  if (!A || !WW || !eta_out || (!states && B > 0)) return fail(QMPS_ERR_ARG, "null argument");
+  if (max_rounds < 1 || max_rounds > 60 || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_rounds / tol");
+  // candidates -> d_A: tensors, unitaries or ansatz parameters
+  if (kind == QMPS_INPUT_TENSOR || kind == QMPS_INPUT_UNITARY) {
+    if (int rc = qmps_set_states(c, B, states, kind)) return rc;
+  } else if (kind >= QMPS_INPUT_ANSATZ_BASE && kind <= QMPS_INPUT_ANSATZ_BASE + 3) {
+    if (int rc = qmps_set_states_ansatz(c, B, kind - QMPS_INPUT_ANSATZ_BASE, n_params, states)) return rc;
+  } else {
+    return fail(QMPS_ERR_ARG, "unknown input kind %d", kind);
+  }
+  // the current state(s) go to d_U (scratch, >= 16 B * 2 * 8 bytes per item), WW behind the Hamiltonians
+  const size_t abytes = (size_t)(a_shared ? 1 : B) * 128;
+  if (!c->d_U) HIP_TRY(hipMalloc(&c->d_U, (size_t)c->max_batch * 2 * tensor_bytes(c)));
+  HIP_TRY(hipMemcpyAsync(c->d_U, A, abytes, hipMemcpyHostToDevice, c->stream));
+  if (!c->d_ww) HIP_TRY(hipMalloc(&c->d_ww, 256));
+  HIP_TRY(hipMemcpyAsync(c->d_ww, WW, 256, hipMemcpyHostToDevice, c->stream));
+  if (!c->d_eta) HIP_TRY(hipMalloc(&c->d_eta, (size_t)c->max_batch * 16));
+  qmps::OverlapArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = c->d_U; a.Bt = c->d_A; a.WW = c->d_ww; a.eta = c->d_eta; a.r_out = r_out ? c->d_r : nullptr;
+  a.iters = c->d_iters; a.status = c->d_status; a.B = B; a.a_shared = a_shared ? 1 : 0; a.max_rounds = max_rounds; a.tol = tol;
+  HIP_TRY(qmps::launch_overlap(a, c->stream));
+  HIP_TRY(hipMemcpyAsync(eta_out, c->d_eta, (size_t)B * 16, hipMemcpyDeviceToHost, c->stream));
+  if (r_out) HIP_TRY(hipMemcpyAsync(r_out, c->d_r, (size_t)B * 64, hipMemcpyDeviceToHost, c->stream));
+  if (rounds_out) HIP_TRY(hipMemcpyAsync(rounds_out, c->d_iters, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
+  if (status_out) HIP_TRY(hipMemcpyAsync(status_out, c->d_status, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->have_env = false;
   return QMPS_OK;
 }
 

@@ -72,6 +72,21 @@ hipError_t launch_cell2(int D, const Cell2Args& a, hipStream_t st);
 hipError_t launch_energy(int D, const LaneArgs& a, bool solve, hipStream_t st);
 // ansatz parameters [B][n_params] -> state tensors A [B][2][D][D]; kind: 0 ShallowCNOT, 1 QAOA, 2 ShallowFull (D=2), 3 ShallowCNOT3
 hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, void* A, int64_t B, hipStream_t st);
+// time-evolution overlap (D = 2): dominant eigenvalue of the mixed two-site transfer map
+struct OverlapArgs {
+  const void* A;     // [B or 1][2][2][2] current state tensor(s)
+  const void* Bt;    // [B][2][2][2] candidate tensors
+  const void* WW;    // [4][4] two-site operator
+  void* eta;         // [B] complex dominant eigenvalue
+  void* r_out;       // nullable [B][2][2] unit-Frobenius right fixed point
+  int32_t* iters;    // [B] squaring rounds used
+  int32_t* status;   // [B]
+  int64_t B;
+  int a_shared;      // 1: one A for the whole batch
+  int max_rounds;
+  double tol;
+};
+hipError_t launch_overlap(const OverlapArgs& a, hipStream_t st);
 hipError_t launch_roto_shift(const double* base, double* out, int R, int P, int i, hipStream_t st);
 hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int i, int n_terms,
                               hipStream_t st);

@@ -213,6 +213,34 @@ class EnergyEngine:
         self.n_terms = nt
         return E, it, st
 
+    def overlaps(self, A, candidates, WW, kind='tensor', ansatz=None, max_rounds=40, tol=1e-13, want_r=False):
+        """Time-evolution overlap (D = 2): dominant eigenvalue eta of the mixed two-site transfer map between
+        WW . merge(A, A) and merge(B, B) for every candidate.  A: (2,2,2) shared or (B,2,2,2); candidates:
+        tensors (B,2,2,2) [kind='tensor'], unitaries (B,4,4) ['unitary'] or parameters (B,P) ['params' with
+        ansatz = L.ANSATZ_*].  Returns (eta complex (B,), rounds, status[, r (B,2,2)])."""
+        A = np.ascontiguousarray(A, dtype=np.complex128)
+        shared = A.ndim == 3
+        WW = np.ascontiguousarray(WW, dtype=np.complex128)
+        if kind == 'params':
+            cand = np.ascontiguousarray(np.atleast_2d(candidates), dtype=np.float64)
+            code, npar, ptr = L.INPUT_ANSATZ_BASE + int(ansatz), cand.shape[1], _f64(cand)
+        else:
+            tail = (2, 2, 2) if kind == 'tensor' else (4, 4)
+            cand = _c128(candidates, tail, 'candidates')
+            code, npar, ptr = (L.INPUT_TENSOR if kind == 'tensor' else L.INPUT_UNITARY), 0, _f64(cand.view(np.float64))
+        B = cand.shape[0]
+        if not shared and A.shape[0] != B:
+            raise ValueError('A must be (2,2,2) or (B,2,2,2)')
+        eta = np.empty(B, dtype=np.complex128)
+        r = np.empty((B, 2, 2), dtype=np.complex128) if want_r else None
+        rounds = np.empty(B, dtype=np.int32)
+        st = np.empty(B, dtype=np.int32)
+        L.check(self._lib.qmps_overlap_batch(self._ctx, B, _f64(A.view(np.float64)), 1 if shared else 0, ptr, code, npar,
+                                             _f64(WW.view(np.float64)), int(max_rounds), float(tol),
+                                             _f64(eta.view(np.float64)), None if r is None else _f64(r.view(np.float64)),
+                                             _i32(rounds), _i32(st)))
+        return (eta, rounds, st, r) if want_r else (eta, rounds, st)
+
     # -- timing / probes ----------------------------------------------------------------------
     def timer_begin(self):
         L.check(self._lib.qmps_timer_begin(self._ctx))

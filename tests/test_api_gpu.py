@@ -208,3 +208,54 @@ def test_full_parameterisation_reaches_D2_gse():
             best, xbest = res.fun, res.x
     assert E0 <= best <= D2_GSE + 2e-3
     assert abs(best - O.energy_closed_form(O.unitary_to_tensor(G.SU(xbest, 4)), h)) < 1e-10
+
+
+# ---- f-3: time-evolution overlap objective -----------------------------------------------------
+def test_overlap_kernel_vs_oracle(engine_factory):
+    from scipy.linalg import expm
+    from qmps_amd import _lib as L
+    rng = np.random.default_rng(23)
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+    eng = engine_factory(2)
+    for WW in (np.eye(4, dtype=complex), expm(-0.1j * h), expm(-0.7j * h)):
+        A = O.unitary_to_tensor(O.haar_unitaries(rng, 4, 1)[0])
+        Bt = O.unitary_to_tensor(O.haar_unitaries(rng, 4, 300))
+        eta, rounds, st, r = eng.overlaps(A, Bt, WW, want_r=True)
+        ref = [O.overlap_eta(A, b, WW) for b in Bt]
+        ok = st == 0
+        assert ok.mean() > 0.97
+        assert np.abs(eta - np.array([e for e, _ in ref]))[ok].max() < 1e-10
+        for k in np.flatnonzero(ok)[:20]:        # right fixed point, up to a phase
+            ph = np.vdot(ref[k][1], r[k])
+            assert abs(abs(ph) - 1) < 1e-9
+        # per-item current states and the unitary input kind
+        As = O.unitary_to_tensor(O.haar_unitaries(rng, 4, 300))
+        U = O.haar_unitaries(rng, 4, 300)
+        eta2, _, st2 = eng.overlaps(As, U, WW, kind='unitary')
+        ref2 = np.array([O.overlap_eta(a, O.unitary_to_tensor(u), WW)[0] for a, u in zip(As, U)])
+        assert np.abs(eta2 - ref2)[st2 == 0].max() < 1e-10
+    # B = A, W = 1: eta = 1 exactly; ansatz parameters built on the device
+    P = rng.standard_normal((40, 15))
+    Ts = np.stack([T.unitary_to_tensor(R.unitary(R.ShallowFullStateTensor(2, p))) for p in P])
+    eta3, _, st3 = eng.overlaps(Ts, P, np.eye(4, dtype=complex), kind='params', ansatz=L.ANSATZ_SHALLOW_FULL)
+    assert np.all(st3 == 0) and np.abs(eta3 - 1).max() < 1e-12
+
+
+def test_time_evolve_objective_api():
+    """obj(p, A, WW) (new_time_evolve.py:193-221): -1 at p reproducing A with W = 1, > -1 otherwise, equals
+    the oracle; a short `evolve` run keeps the overlap per step close to 1."""
+    from scipy.linalg import expm
+    from qmps_amd import new_time_evolve as NT
+    rng = np.random.default_rng(4)
+    p0 = rng.standard_normal(15)
+    A = NT.state_tensor(p0)
+    assert abs(NT.obj(p0, A, np.eye(4)) + 1) < 1e-12
+    p1 = rng.standard_normal(15)
+    WW = expm(-0.05j * O.hamiltonian_matrix({'ZZ': -1, 'X': 1}))
+    f = NT.obj(p1, A, WW)
+    assert abs(f - O.overlap_objective(A, NT.state_tensor(p1), WW)) < 1e-10 and -1 <= f < 0
+    fb = NT.batch_obj(np.stack([p0, p1]), A, WW)
+    assert abs(fb[1] - f) < 1e-12
+    hist = NT.evolve(p0, WW, 2, options={'maxiter': 400, 'xatol': 1e-6, 'fatol': 1e-10})
+    assert hist.shape == (3, 15)
+    assert NT.obj(hist[1], A, WW) < NT.obj(p0, A, WW) + 1e-12 and NT.obj(hist[1], A, WW) < -0.999

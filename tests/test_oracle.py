@@ -235,3 +235,27 @@ def test_rotosolve_updates():
     d = O.double_rotosolve_update(*[g(0.2 + s) for s in O.ROTO_SHIFTS])
     xs = np.linspace(-np.pi, np.pi, 20001)
     assert g(0.2 + d) <= g(xs).min() + 1e-6
+
+
+# ---- f-3: time-evolution overlap -------------------------------------------------------------
+def test_overlap_circuit_identity():
+    """The reference's asserts (qmps/new_time_evolve.py:174-184) and SURVEY App. B-3: the 6-qubit circuit
+    amplitude is psi[0] = eta/2 (up to the eigenvector's phase), for W = 1 and for W = exp(-i h dt);
+    for W = 1 the two-site eta is the square of the one-site one; eta = 1 for B = A."""
+    from scipy.linalg import expm
+    rng = np.random.default_rng(17)
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+    for WW in (np.eye(4, dtype=complex), expm(-0.1j * h)):
+        for _ in range(3):
+            A = O.unitary_to_tensor(O.haar_unitaries(rng, 4, 1)[0])
+            B = O.unitary_to_tensor(O.haar_unitaries(rng, 4, 1)[0])
+            eta, r = O.overlap_eta(A, B, WW)
+            amp = O.overlap_circuit_amplitude(A, B, WW, r)
+            assert abs(2 * abs(amp) - abs(eta)) < 1e-12
+            assert abs(O.overlap_objective(A, B, WW) + np.sqrt(2 * abs(amp))) < 1e-12
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 4, 1)[0])
+    B = O.unitary_to_tensor(O.haar_unitaries(rng, 4, 1)[0])
+    w1 = np.linalg.eigvals(O.transfer_matrix(A, B))
+    eta2, _ = O.overlap_eta(A, B, np.eye(4))
+    assert abs(abs(eta2) - np.abs(w1).max() ** 2) < 1e-12
+    assert abs(O.overlap_eta(A, A, np.eye(4))[0] - 1) < 1e-12

@@ -114,7 +114,8 @@ def main():
         sys.exit(f'bench.py: WORLD_SIZE={world} but --gpus {args.gpus}')
 
     dist = None
-    if world > 1:
+    force_dist = os.environ.get('QMPS_BENCH_FORCE_DIST') == '1'   # exercise the N > 1 code path at world_size 1
+    if world > 1 or force_dist:
         import torch.distributed as dist  # launcher plumbing only (gloo, CPU)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -132,7 +133,7 @@ def main():
     if args.handoff is not None:
         eng.set_solver(args.solver, handoff=args.handoff)
 
-    if world > 1:
+    if dist is not None:
         ids = [EnergyEngine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         eng.comm_init(ids[0], rank, world)
@@ -215,7 +216,7 @@ def main():
                        'global_batch': world * B, 'tol': args.tol, 'max_iter': args.max_iter, 'seed': args.seed,
                        'mean_power_iterations': total_iters_all / (world * B),
                        'max_power_iterations_rank0': int(iters.max()), 'not_converged_or_not_pd': int(bad_all),
-                       'collective': 'none (N=1)' if world == 1 else 'one RCCL all-reduce(sum, f64[1]) per step',
+                       'collective': 'none (N=1)' if dist is None else 'one RCCL all-reduce(sum, f64[1]) per step',
                        'device': info['name'], 'arch': info['arch']},
             'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': tflops / FP64_PEAK_TFLOPS, 'traffic': None,
@@ -233,7 +234,7 @@ def main():
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if dist is not None:
         eng.comm_destroy()
     eng.close()
     if dist is not None:

@@ -175,6 +175,26 @@ int qmps_overlap_batch(qmps_ctx* ctx, int64_t B, const double* A, int a_shared, 
                        int n_params, const double* WW, int max_rounds, double tol, double* eta_out, double* r_out,
                        int32_t* rounds_out, int32_t* status_out);
 
+/* ---- brick-wall ("new_tdvp") classical contractions (new_tdvp/ClassicalTDVPStripped.py) -------------
+ * U1, U2 (and the primed pair) are [B][4][4] complex128 two-qubit unitaries, big-endian; the reference's
+ * U.reshape(2,2,2,2) is [out0, out1, in0, in1].  Any context can be used (its bond dimension is ignored). */
+/* OverlapCalculator.qbt2_exp_val (:511-544, sites = 2, O 4x4) / qbt4_exp_val (:464-496, sites = 4, O 16x16):
+ * out[B] complex = <psi| 1 x O x 1 |psi>, psi the brick-wall state on 2 (sites/2 + 1) qubits (the reference
+ * returns the real part).  O: one operator shared by the batch (o_shared = 1) or one per item. */
+int qmps_bw_expval(qmps_ctx* ctx, int64_t B, int sites, const double* U1, const double* U2, const double* O,
+                   int o_shared, double* out);
+/* RightEnvironment (side = 0, :399-431) / LeftEnvironment (side = 1, :316-347): the 4x4 environment matrix
+ * (mat_out nullable [B][4][4]) and its eigenpair with the reference's rule eta[np.argmax(eta)] (largest real
+ * part): eta_out [B] complex, vec_out [B][2][2] (unit 2-norm, largest entry real positive). */
+int qmps_bw_env(qmps_ctx* ctx, int64_t B, int side, const double* U1, const double* U2, const double* U1p,
+                const double* U2p, int max_rounds, double tol, double* mat_out, double* eta_out, double* vec_out,
+                int32_t* status_out);
+/* ManifoldOverlap.circuit (:239-275): <0| U2'^3 (1 x U1'^2 x 1)(Ml x W x Mr)(1 x U1^2 x 1) U2^3 |0>;
+ * Mr, Ml [2][2] and W [16][16] shared by the batch or per item. */
+int qmps_bw_manifold(qmps_ctx* ctx, int64_t B, const double* U1, const double* U2, const double* U1p,
+                     const double* U2p, const double* Mr, const double* Ml, int m_shared, const double* W, int w_shared,
+                     double* out);
+
 /* ---- timing on the context stream (HIP events) ------------------------------------------ */
 int qmps_timer_begin(qmps_ctx* ctx);
 int qmps_timer_end(qmps_ctx* ctx, float* milliseconds); /* waits for the end event */

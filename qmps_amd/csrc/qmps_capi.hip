@@ -60,6 +60,8 @@ struct qmps_ctx {
   double* d_params = nullptr;  // ansatz parameters [max_batch][params_cap] (lazy)
   void* d_ww = nullptr;        // two-site operator of the overlap objective (lazy)
   void* d_eta = nullptr;       // overlap eigenvalues [max_batch] complex (lazy)
+  void* d_scratch = nullptr;   // brick-wall inputs / outputs (lazy, grown on demand)
+  size_t scratch_bytes = 0;
   int params_cap = 0;
   void* d_h = nullptr;       // [16][4][4] c128
   void* d_r = nullptr;       // [max_batch][D][D] c128
@@ -225,7 +227,7 @@ int qmps_destroy(qmps_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)ncclCommDestroy(c->comm);
-  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_work_count, c->d_work_idx};
+  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_work_count, c->d_work_idx};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
@@ -655,6 +657,109 @@ int qmps_overlap_batch(qmps_ctx* c, int64_t B, const double* A, int a_shared, co
   if (status_out) HIP_TRY(hipMemcpyAsync(status_out, c->d_status, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->have_env = false;
+  return QMPS_OK;
+}
+
+// ---- brick-wall (new_tdvp) contractions -------------------------------------------------------
+namespace {
+int ensure_scratch(qmps_ctx* c, size_t bytes) {
+  if (bytes > c->scratch_bytes) {
+    if (c->d_scratch) HIP_TRY(hipFree(c->d_scratch));
+    c->d_scratch = nullptr;
+    c->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&c->d_scratch, bytes));
+    c->scratch_bytes = bytes;
+  }
+  return QMPS_OK;
+}
+// bump allocator over the scratch arena: copies a host array in, returns the device address
+struct Arena {
+  qmps_ctx* c;
+  size_t off = 0;
+  void* put(const void* host, size_t bytes, hipError_t* err) {
+    void* d = (char*)c->d_scratch + off;
+    off += (bytes + 255) & ~(size_t)255;
+    if (host) *err = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, c->stream);
+    return d;
+  }
+};
+}  // namespace
+
+int qmps_bw_expval(qmps_ctx* c, int64_t B, int sites, const double* U1, const double* U2, const double* O, int o_shared,
+                   double* out) {
+  if (int rc = bind(c)) return rc;
+  if (B < 0 || !U1 || !U2 || !O || !out) return fail(QMPS_ERR_ARG, "bad arguments");
+  if (sites != 2 && sites != 4) return fail(QMPS_ERR_ARG, "sites must be 2 or 4");
+  const size_t no = sites == 2 ? 16 : 256;
+  const size_t ob = (o_shared ? 1 : (size_t)B) * no * 16;
+  if (int rc = ensure_scratch(c, (size_t)B * (256 + 256 + 16 + 256) + ob + 4096)) return rc;
+  Arena a{c};
+  hipError_t e = hipSuccess;
+  qmps::BwArgs k;
+  memset(&k, 0, sizeof(k));
+  k.U1 = a.put(U1, (size_t)B * 256, &e); HIP_TRY(e);
+  k.U2 = a.put(U2, (size_t)B * 256, &e); HIP_TRY(e);
+  k.O = a.put(O, ob, &e); HIP_TRY(e);
+  k.out = a.put(nullptr, (size_t)B * 16, &e);
+  k.B = B; k.o_shared = o_shared ? 1 : 0;
+  HIP_TRY(qmps::launch_bw(sites == 2 ? 0 : 1, k, c->stream));
+  HIP_TRY(hipMemcpyAsync(out, k.out, (size_t)B * 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+
+int qmps_bw_env(qmps_ctx* c, int64_t B, int side, const double* U1, const double* U2, const double* U1p,
+                const double* U2p, int max_rounds, double tol, double* mat_out, double* eta_out, double* vec_out,
+                int32_t* status_out) {
+  if (int rc = bind(c)) return rc;
+  if (B < 0 || !U1 || !U2 || !U1p || !U2p || !eta_out || !vec_out) return fail(QMPS_ERR_ARG, "bad arguments");
+  if (side != 0 && side != 1) return fail(QMPS_ERR_ARG, "side must be 0 (right) or 1 (left)");
+  if (max_rounds < 1 || max_rounds > 60 || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_rounds / tol");
+  if (int rc = ensure_scratch(c, (size_t)B * (4 * 256 + 256 + 16 + 64 + 16) + 8192)) return rc;
+  Arena a{c};
+  hipError_t e = hipSuccess;
+  qmps::BwArgs k;
+  memset(&k, 0, sizeof(k));
+  k.U1 = a.put(U1, (size_t)B * 256, &e); HIP_TRY(e);
+  k.U2 = a.put(U2, (size_t)B * 256, &e); HIP_TRY(e);
+  k.U1p = a.put(U1p, (size_t)B * 256, &e); HIP_TRY(e);
+  k.U2p = a.put(U2p, (size_t)B * 256, &e); HIP_TRY(e);
+  k.mat_out = mat_out ? a.put(nullptr, (size_t)B * 256, &e) : nullptr;
+  k.out = a.put(nullptr, (size_t)B * 16, &e);
+  k.vec_out = a.put(nullptr, (size_t)B * 64, &e);
+  k.status = (int32_t*)a.put(nullptr, (size_t)B * 4, &e);
+  k.B = B; k.side = side; k.max_rounds = max_rounds; k.tol = tol;
+  HIP_TRY(qmps::launch_bw(2, k, c->stream));
+  if (mat_out) HIP_TRY(hipMemcpyAsync(mat_out, k.mat_out, (size_t)B * 256, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(eta_out, k.out, (size_t)B * 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(vec_out, k.vec_out, (size_t)B * 64, hipMemcpyDeviceToHost, c->stream));
+  if (status_out) HIP_TRY(hipMemcpyAsync(status_out, k.status, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+
+int qmps_bw_manifold(qmps_ctx* c, int64_t B, const double* U1, const double* U2, const double* U1p, const double* U2p,
+                     const double* Mr, const double* Ml, int m_shared, const double* W, int w_shared, double* out) {
+  if (int rc = bind(c)) return rc;
+  if (B < 0 || !U1 || !U2 || !U1p || !U2p || !Mr || !Ml || !W || !out) return fail(QMPS_ERR_ARG, "bad arguments");
+  const size_t mb = (m_shared ? 1 : (size_t)B) * 64, wb = (w_shared ? 1 : (size_t)B) * 4096;
+  if (int rc = ensure_scratch(c, (size_t)B * (4 * 256 + 16) + 2 * mb + wb + 8192)) return rc;
+  Arena a{c};
+  hipError_t e = hipSuccess;
+  qmps::BwArgs k;
+  memset(&k, 0, sizeof(k));
+  k.U1 = a.put(U1, (size_t)B * 256, &e); HIP_TRY(e);
+  k.U2 = a.put(U2, (size_t)B * 256, &e); HIP_TRY(e);
+  k.U1p = a.put(U1p, (size_t)B * 256, &e); HIP_TRY(e);
+  k.U2p = a.put(U2p, (size_t)B * 256, &e); HIP_TRY(e);
+  k.Mr = a.put(Mr, mb, &e); HIP_TRY(e);
+  k.Ml = a.put(Ml, mb, &e); HIP_TRY(e);
+  k.O = a.put(W, wb, &e); HIP_TRY(e);
+  k.out = a.put(nullptr, (size_t)B * 16, &e);
+  k.B = B; k.m_shared = m_shared ? 1 : 0; k.o_shared = w_shared ? 1 : 0;
+  HIP_TRY(qmps::launch_bw(3, k, c->stream));
+  HIP_TRY(hipMemcpyAsync(out, k.out, (size_t)B * 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
 

@@ -87,6 +87,20 @@ struct OverlapArgs {
   double tol;
 };
 hipError_t launch_overlap(const OverlapArgs& a, hipStream_t st);
+// brick-wall (new_tdvp) contractions: what = 0 two-site <O>, 1 four-site <O>, 2 environment matrix + eigenpair, 3 manifold overlap
+struct BwArgs {
+  const void *U1, *U2, *U1p, *U2p;   // [B][4][4] complex
+  const void* O;                      // operator: 4x4 / 16x16 (expval), 16x16 W (manifold); shared or per item
+  const void *Mr, *Ml;                // [B or 1][2][2]
+  void* out;                          // [B] complex
+  void* mat_out;                      // nullable [B][4][4]
+  void* vec_out;                      // [B][2][2]
+  int32_t* status;
+  int64_t B;
+  int o_shared, m_shared, side, max_rounds;
+  double tol;
+};
+hipError_t launch_bw(int what, const BwArgs& a, hipStream_t st);
 hipError_t launch_roto_shift(const double* base, double* out, int R, int P, int i, hipStream_t st);
 hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int i, int n_terms,
                               hipStream_t st);

@@ -1634,6 +1634,35 @@ struct Reg {
         im[x] = c * pi + s * pr;
       }
   }
+  // general single-qubit matrix m[2][2] (complex, row-major: re/im arrays)
+  __device__ __forceinline__ void u2m(int q, const double (&mr_)[4], const double (&mi_)[4]) {
+    u2(q, mr_[0], mi_[0], mr_[1], mi_[1], mr_[2], mi_[2], mr_[3], mi_[3]);
+  }
+  // general two-qubit matrix g[4][4] (complex) on qubits (q1, q2), q1 = more significant bit of the gate index
+  __device__ __forceinline__ void u4(int q1, int q2, const double (&gr)[16], const double (&gi)[16]) {
+    const int m1 = mask(q1), m2 = mask(q2);
+#pragma unroll
+    for (int x = 0; x < N; ++x)
+      if (!(x & m1) && !(x & m2)) {
+        const int idx[4] = {x, x | m2, x | m1, x | m1 | m2};
+        double pr[4], pi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pr[k] = re[idx[k]]; pi[k] = im[idx[k]]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          double xr = 0.0, xi = 0.0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            xr = dfma(gr[a * 4 + k], pr[k], xr);
+            xr = dfma(-gi[a * 4 + k], pi[k], xr);
+            xi = dfma(gr[a * 4 + k], pi[k], xi);
+            xi = dfma(gi[a * 4 + k], pr[k], xi);
+          }
+          re[idx[a]] = xr;
+          im[idx[a]] = xi;
+        }
+      }
+  }
   __device__ __forceinline__ void cnot(int ctrl, int tgt) {
     const int mc = mask(ctrl), mt = mask(tgt);
 #pragma unroll
@@ -1957,6 +1986,321 @@ __global__ __launch_bounds__(64) void overlap_lane_kernel(OverlapArgs p) {
 hipError_t launch_overlap(const OverlapArgs& a, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
   hipLaunchKernelGGL(overlap_lane_kernel, dim3((unsigned)((a.B + 63) / 64)), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 3e: brick-wall ("new_tdvp") classical contractions (SURVEY 8(a)-11 / (f)-4;
+// new_tdvp/ClassicalTDVPStripped.py), one evaluation per lane, state vectors in registers.
+//   psi_l = (1 x U1^(l-1) x 1)(U2^l)|0..0> on 2 l qubits (bwMPS.state :179-191)
+//   expectation values  <psi_l| 1 x O x 1 |psi_l>,  l = 2 (O 4x4, :511-544) and l = 3 (O 16x16, :464-496)
+//   environment matrices of RightEnvironment / LeftEnvironment.exact_environment_circuit (:399-422, :316-338)
+//     and their dominant eigenpair with the reference's rule eta[np.argmax(eta)] (largest REAL part)
+//   ManifoldOverlap.circuit (:239-275)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_u4(const double2* p, double (&gr)[16], double (&gi)[16]) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const double2 v = p[k];
+    gr[k] = v.x;
+    gi[k] = v.y;
+  }
+}
+__device__ __forceinline__ void load_u4_dagger(const double2* p, double (&gr)[16], double (&gi)[16]) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double2 v = p[c * 4 + a];
+      gr[a * 4 + c] = v.x;
+      gi[a * 4 + c] = -v.y;
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(64) void bw_expval_kernel(BwArgs p) {
+  constexpr int NQ = 2 * L;
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= p.B) return;
+  Reg<NQ> r;
+#pragma unroll
+  for (int x = 0; x < Reg<NQ>::N; ++x) { r.re[x] = (x == 0) ? 1.0 : 0.0; r.im[x] = 0.0; }
+  double gr[16], gi[16];
+  load_u4((const double2*)p.U2 + b * 16, gr, gi);
+#pragma unroll
+  for (int k = 0; k < L; ++k) r.u4(2 * k, 2 * k + 1, gr, gi);
+  load_u4((const double2*)p.U1 + b * 16, gr, gi);
+#pragma unroll
+  for (int k = 0; k < L - 1; ++k) r.u4(2 * k + 1, 2 * k + 2, gr, gi);
+  // <psi| 1 x O x 1 |psi>: the operator acts on qubits 1 .. NQ-2 (index bits NQ-2 .. 1)
+  constexpr int NO = 1 << (NQ - 2);
+  const double2* O = (const double2*)p.O + (p.o_shared ? 0 : b * (int64_t)NO * NO);
+  double er = 0.0, ei = 0.0;
+#pragma unroll
+  for (int xm = 0; xm < NO; ++xm)
+#pragma unroll
+    for (int ym = 0; ym < NO; ++ym) {
+      const double2 o = O[xm * NO + ym];
+      // sum over the outer bits of conj(psi[hi, xm, lo]) psi[hi, ym, lo]
+      double sr = 0.0, si = 0.0;
+#pragma unroll
+      for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+        for (int lo = 0; lo < 2; ++lo) {
+          const int x = (hi << (NQ - 1)) | (xm << 1) | lo, y = (hi << (NQ - 1)) | (ym << 1) | lo;
+          sr = dfma(r.re[x], r.re[y], sr);
+          sr = dfma(r.im[x], r.im[y], sr);
+          si = dfma(r.re[x], r.im[y], si);
+          si = dfma(-r.im[x], r.re[y], si);
+        }
+      er = dfma(o.x, sr, er);
+      er = dfma(-o.y, si, er);
+      ei = dfma(o.x, si, ei);
+      ei = dfma(o.y, sr, ei);
+    }
+  ((double2*)p.out)[b] = make_double2(er, ei);
+}
+
+// exp((1 - i eps) M) by Taylor series (||M|| <= ~1: transfer matrices of unitaries), then repeated squaring:
+// the dominant-modulus eigenvector of exp(cM) is the eigenvector of M with the largest real part (ties broken
+// towards the larger imaginary part by the -i eps tilt) - the reference's eta[np.argmax(eta)].
+__device__ __forceinline__ void mat4_mul(const double (&ar)[4][4], const double (&ai)[4][4], const double (&br)[4][4],
+                                         const double (&bi)[4][4], double (&cr)[4][4], double (&ci)[4][4]) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double xr = 0.0, xi = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        xr += ar[a][k] * br[k][c] - ai[a][k] * bi[k][c];
+        xi += ar[a][k] * bi[k][c] + ai[a][k] * br[k][c];
+      }
+      cr[a][c] = xr;
+      ci[a][c] = xi;
+    }
+}
+
+__global__ __launch_bounds__(64) void bw_env_kernel(BwArgs p) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= p.B) return;
+  // phi_i = U1 U2 |i,0,0> (right: U2 on (b,c), U1 on (a,b), open wire a = qubit 0)
+  //         (left : U2 on (a,b), U1 on (b,c), open wire c = qubit 2)
+  // chi_i' = (U2' U1')^+ |i',0,0>  resp. mirrored;  Mmat[(i,i'),(j,j')] = sum_{rest} conj(chi_i'[..j'..]) phi_i[..j..]
+  const bool left = p.side != 0;
+  Reg<3> phi[2], chi[2];
+  double gr[16], gi[16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const int start = left ? i : (i << 2);
+      phi[i].re[x] = (x == start) ? 1.0 : 0.0; phi[i].im[x] = 0.0;
+      chi[i].re[x] = (x == start) ? 1.0 : 0.0; chi[i].im[x] = 0.0;
+    }
+  }
+  load_u4((const double2*)p.U2 + b * 16, gr, gi);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { if (left) phi[i].u4(0, 1, gr, gi); else phi[i].u4(1, 2, gr, gi); }
+  load_u4((const double2*)p.U1 + b * 16, gr, gi);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { if (left) phi[i].u4(1, 2, gr, gi); else phi[i].u4(0, 1, gr, gi); }
+  load_u4_dagger((const double2*)p.U2p + b * 16, gr, gi);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { if (left) chi[i].u4(0, 1, gr, gi); else chi[i].u4(1, 2, gr, gi); }
+  load_u4_dagger((const double2*)p.U1p + b * 16, gr, gi);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { if (left) chi[i].u4(1, 2, gr, gi); else chi[i].u4(0, 1, gr, gi); }
+  // open wire carrying (j, j'): right -> qubit 2 (bit 0); left -> qubit 0 (bit 2)
+  double mr[4][4], mi[4][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          double xr = 0.0, xi = 0.0;
+#pragma unroll
+          for (int rest = 0; rest < 4; ++rest) {
+            const int xphi = left ? ((j << 2) | rest) : ((rest << 1) | j);
+            const int xchi = left ? ((jp << 2) | rest) : ((rest << 1) | jp);
+            xr += chi[ip].re[xchi] * phi[i].re[xphi] + chi[ip].im[xchi] * phi[i].im[xphi];
+            xi += chi[ip].re[xchi] * phi[i].im[xphi] - chi[ip].im[xchi] * phi[i].re[xphi];
+          }
+          mr[2 * i + ip][2 * j + jp] = xr;
+          mi[2 * i + ip][2 * j + jp] = xi;
+        }
+  if (p.mat_out != nullptr) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ((double2*)p.mat_out)[b * 16 + a * 4 + c] = make_double2(mr[a][c], mi[a][c]);
+  }
+  // P = exp((1 - i eps) M), 20-term Taylor series evaluated by Horner
+  const double eps = 1e-6;
+  double cr[4][4], ci[4][4], pr[4][4], pi[4][4], tr_[4][4], ti_[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      cr[a][c] = mr[a][c] + eps * mi[a][c];       // (1 - i eps)(mr + i mi)
+      ci[a][c] = mi[a][c] - eps * mr[a][c];
+      pr[a][c] = (a == c) ? 1.0 : 0.0;
+      pi[a][c] = 0.0;
+    }
+  for (int k = 20; k >= 1; --k) {
+    mat4_mul(cr, ci, pr, pi, tr_, ti_);
+    const double inv = 1.0 / k;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        pr[a][c] = tr_[a][c] * inv + ((a == c) ? 1.0 : 0.0);
+        pi[a][c] = ti_[a][c] * inv;
+      }
+  }
+  double eta_r = 0.0, eta_i = 0.0, vr[4] = {1, 0, 0, 0}, vi[4] = {0, 0, 0, 0};
+  int status = QMPS_ST_NOT_CONVERGED;
+  const double tol2 = p.tol * p.tol;
+  for (int m = 0; m <= p.max_rounds; ++m) {
+    double best = -1.0;
+    int bc = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double n2 = 0.0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) n2 += pr[a][c] * pr[a][c] + pi[a][c] * pi[a][c];
+      if (n2 > best) { best = n2; bc = c; }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      vr[a] = bc == 0 ? pr[a][0] : (bc == 1 ? pr[a][1] : (bc == 2 ? pr[a][2] : pr[a][3]));
+      vi[a] = bc == 0 ? pi[a][0] : (bc == 1 ? pi[a][1] : (bc == 2 ? pi[a][2] : pi[a][3]));
+    }
+    double wr[4], wi[4], num_r = 0, num_i = 0, vv = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double xr = 0, xi = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        xr += mr[a][c] * vr[c] - mi[a][c] * vi[c];
+        xi += mr[a][c] * vi[c] + mi[a][c] * vr[c];
+      }
+      wr[a] = xr; wi[a] = xi;
+      num_r += vr[a] * xr + vi[a] * xi;
+      num_i += vr[a] * xi - vi[a] * xr;
+      vv += vr[a] * vr[a] + vi[a] * vi[a];
+    }
+    eta_r = num_r / vv; eta_i = num_i / vv;
+    double res = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const double dr = wr[a] - (eta_r * vr[a] - eta_i * vi[a]), di = wi[a] - (eta_r * vi[a] + eta_i * vr[a]);
+      res += dr * dr + di * di;
+    }
+    if (res < tol2 * vv) { status = QMPS_ST_OK; break; }
+    if (m == p.max_rounds) break;
+    mat4_mul(pr, pi, pr, pi, tr_, ti_);
+    double f2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) f2 += tr_[a][c] * tr_[a][c] + ti_[a][c] * ti_[a][c];
+    const double inv = f2 > 0.0 ? 1.0 / __builtin_sqrt(f2) : 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { pr[a][c] = tr_[a][c] * inv; pi[a][c] = ti_[a][c] * inv; }
+  }
+  // unit 2-norm, phase: largest-magnitude entry real positive
+  double n2 = 0.0, bigr = 1.0, bigi = 0.0, bigm = -1.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const double m2 = vr[a] * vr[a] + vi[a] * vi[a];
+    n2 += m2;
+    if (m2 > bigm) { bigm = m2; bigr = vr[a]; bigi = vi[a]; }
+  }
+  const double sc = 1.0 / (__builtin_sqrt(n2) * __builtin_sqrt(bigm));
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const double xr = (vr[a] * bigr + vi[a] * bigi) * sc, xi = (vi[a] * bigr - vr[a] * bigi) * sc;
+    ((double2*)p.vec_out)[b * 4 + a] = make_double2(xr, xi);
+  }
+  ((double2*)p.out)[b] = make_double2(eta_r, eta_i);
+  p.status[b] = status;
+}
+
+__global__ __launch_bounds__(64) void bw_manifold_kernel(BwArgs p) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= p.B) return;
+  Reg<6> r;
+#pragma unroll
+  for (int x = 0; x < 64; ++x) { r.re[x] = (x == 0) ? 1.0 : 0.0; r.im[x] = 0.0; }
+  double gr[16], gi[16];
+  load_u4((const double2*)p.U2 + b * 16, gr, gi);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) r.u4(2 * k, 2 * k + 1, gr, gi);
+  load_u4((const double2*)p.U1 + b * 16, gr, gi);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) r.u4(2 * k + 1, 2 * k + 2, gr, gi);
+  {
+    const double2* Ml = (const double2*)p.Ml + (p.m_shared ? 0 : b * 4);
+    const double2* Mr = (const double2*)p.Mr + (p.m_shared ? 0 : b * 4);
+    double ar[4], ai[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ar[k] = Ml[k].x; ai[k] = Ml[k].y; }
+    r.u2m(0, ar, ai);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ar[k] = Mr[k].x; ai[k] = Mr[k].y; }
+    r.u2m(5, ar, ai);
+  }
+  {
+    // W (16 x 16) on qubits 1..4: index bits 4..1; outer bits: qubit 0 (bit 5) and qubit 5 (bit 0)
+    const double2* W = (const double2*)p.O + (p.o_shared ? 0 : b * 256);
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+      for (int lo = 0; lo < 2; ++lo) {
+        double tr[16], ti[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { tr[t] = r.re[(hi << 5) | (t << 1) | lo]; ti[t] = r.im[(hi << 5) | (t << 1) | lo]; }
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+          double xr = 0.0, xi = 0.0;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const double2 w = W[a * 16 + t];
+            xr = dfma(w.x, tr[t], xr);
+            xr = dfma(-w.y, ti[t], xr);
+            xi = dfma(w.x, ti[t], xi);
+            xi = dfma(w.y, tr[t], xi);
+          }
+          r.re[(hi << 5) | (a << 1) | lo] = xr;
+          r.im[(hi << 5) | (a << 1) | lo] = xi;
+        }
+      }
+  }
+  load_u4((const double2*)p.U1p + b * 16, gr, gi);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) r.u4(2 * k + 1, 2 * k + 2, gr, gi);
+  load_u4((const double2*)p.U2p + b * 16, gr, gi);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) r.u4(2 * k, 2 * k + 1, gr, gi);
+  ((double2*)p.out)[b] = make_double2(r.re[0], r.im[0]);
+}
+
+hipError_t launch_bw(int what, const BwArgs& a, hipStream_t st) {
+  if (a.B <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((a.B + 63) / 64)), block(64);
+  switch (what) {
+    case 0: hipLaunchKernelGGL(bw_expval_kernel<2>, grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL(bw_expval_kernel<3>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(bw_env_kernel, grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(bw_manifold_kernel, grid, block, 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -59,6 +59,8 @@ def _stub_modules():
     mod('xmps.tensor')
     mod('xmps.iOptimize')
     mod('tqdm', tqdm=lambda x, *a, **k: x, tqdm_notebook=lambda x, *a, **k: x)
+    mod('jax', device_put=lambda x: x, jit=lambda f, *a, **k: f)
+    mod('jax.numpy')
     for name in ('matplotlib', 'matplotlib.pyplot'):
         if name not in sys.modules:
             try:
@@ -154,6 +156,63 @@ def main():
     out['oracle_cell_E'] = np.array([O.two_site_cell_energy(a, b, out['ref_h_tfim']) for a, b in zip(U1, U2)])
 
     path = os.path.join(HERE, 'qmps_golden.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path), 'bytes,', len(out), 'arrays')
+    brickwall_golden()
+
+
+def brickwall_golden():
+    """(4) new_tdvp brick-wall contractions: the reference's OWN classical code
+    (new_tdvp/ClassicalTDVPStripped.py), which is pure numpy/scipy once its unused jax/xmps/cirq imports are
+    stubbed, run on seeded random unitaries.  These are reference OUTPUTS, the strongest parity anchor."""
+    from scipy.stats import unitary_group
+    sys.path.insert(0, os.path.join(REF, 'new_tdvp'))
+    import ClassicalTDVPStripped as ref
+    out = {}
+    n = 6
+    U = [unitary_group.rvs(4, random_state=100 + k) for k in range(4 * n)]
+    U1, U2, U1p, U2p = (np.stack(U[k::4]) for k in range(4))
+    out['U1'], out['U2'], out['U1p'], out['U2p'] = U1, U2, U1p, U2p
+    rng = np.random.default_rng(7)
+
+    def herm(m):
+        x = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
+        return x + x.conj().T
+
+    O2 = np.stack([herm(4) for _ in range(n)])
+    O4 = np.stack([herm(16) for _ in range(n)])
+    M = np.stack([rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2)) for _ in range(n)])
+    Ml = np.stack([rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2)) for _ in range(n)])
+    W = np.stack([unitary_group.rvs(16, random_state=200 + k) for k in range(n)])
+    out['O2'], out['O4'], out['M'], out['Ml'], out['W'] = O2, O4, M, Ml, W
+    oc, re_, le, mo = ref.OverlapCalculator(), ref.RightEnvironment(), ref.LeftEnvironment(), ref.ManifoldOverlap()
+    t4 = lambda u: u.reshape(2, 2, 2, 2)                                    # noqa: E731
+    dag = lambda u: u.conj().T.reshape(2, 2, 2, 2)                          # noqa: E731
+    out['ref_qbt2'] = np.array([oc.qbt2_exp_val(t4(a), t4(b), t4(o)) for a, b, o in zip(U1, U2, O2)])
+    out['ref_mqbt2'] = np.array([oc.mqbt2_exp_val(a, b, o) for a, b, o in zip(U1, U2, O2)])
+    out['ref_qbt4'] = np.array([oc.qbt4_exp_val(t4(a), t4(b), o.reshape((2,) * 8)) for a, b, o in zip(U1, U2, O4)])
+    out['ref_mqbt4'] = np.array([oc.mqbt4_exp_val(a, b, o) for a, b, o in zip(U1, U2, O4)])
+    out['ref_RE_circuit'] = np.stack([re_.circuit(t4(a), t4(b), t4(c), t4(d), m)
+                                      for a, b, c, d, m in zip(U1, U2, U1p, U2p, M)])
+    out['ref_RE_matrix'] = np.stack([re_.exact_environment_circuit(t4(a), t4(b), t4(c), t4(d))
+                                     for a, b, c, d in zip(U1, U2, U1p, U2p)])
+    out['ref_LE_matrix'] = np.stack([le.exact_environment_circuit(t4(a), t4(b), t4(c), t4(d))
+                                     for a, b, c, d in zip(U1, U2, U1p, U2p)])
+    # state-like case U' = U^dagger: dominant eigenvalue 1
+    out['ref_RE_matrix_dag'] = np.stack([re_.exact_environment_circuit(t4(a), t4(b), dag(a), dag(b)) for a, b in zip(U1, U2)])
+    out['ref_LE_matrix_dag'] = np.stack([le.exact_environment_circuit(t4(a), t4(b), dag(a), dag(b)) for a, b in zip(U1, U2)])
+    ee = [re_.exact_environment(t4(a), t4(b), dag(a), dag(b)) for a, b in zip(U1, U2)]
+    out['ref_RE_eta_dag'] = np.array([e for e, _ in ee])
+    out['ref_RE_vec_dag'] = np.stack([v for _, v in ee])
+    ee = [le.exact_environment(t4(a), t4(b), dag(a), dag(b)) for a, b in zip(U1, U2)]
+    out['ref_LE_eta_dag'] = np.array([e for e, _ in ee])
+    out['ref_LE_vec_dag'] = np.stack([v for _, v in ee])
+    out['ref_manifold'] = np.array([mo.circuit(t4(a), t4(b), t4(c), t4(d), mr, ml, w.reshape((2,) * 8))
+                                    for a, b, c, d, mr, ml, w in zip(U1, U2, U1p, U2p, M, Ml, W)])
+    out['ref_mmanifold'] = np.array([mo.mcircuit(a, b, c, d, mr, ml, w)
+                                     for a, b, c, d, mr, ml, w in zip(U1, U2, U1p, U2p, M, Ml, W)])
+    out['ref_bwmps_state_l2'] = np.stack([ref.bwMPS([b, a], 2).state() for a, b in zip(U1, U2)])
+    path = os.path.join(HERE, 'brickwall_golden.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, os.path.getsize(path), 'bytes,', len(out), 'arrays')
 

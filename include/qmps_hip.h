@@ -175,6 +175,14 @@ int qmps_overlap_batch(qmps_ctx* ctx, int64_t B, const double* A, int a_shared, 
                        int n_params, const double* WW, int max_rounds, double tol, double* eta_out, double* r_out,
                        int32_t* rounds_out, int32_t* status_out);
 
+/* Variational-environment objective, D = 2 (qmps/ground_state.py:170-228, selected by
+ * SparseFullEnergyOptimizer(optimize_environment=True); the objective the reference's own Rotosolve test drives,
+ * tests/test_ground_state.py:250-257): params[B][30] = [U angles (15) | V angles (15)], both ShallowFullStateTensor;
+ * f = energy + k (tr rho_u^2 + tr rho_v^2 - 2 tr rho_u rho_v) from four simulated circuits (k = 1 in the
+ * reference).  parts_out nullable [B][4] = (energy, u_purity, v_purity, uv_purity). */
+int qmps_opt_env_objective(qmps_ctx* ctx, int64_t B, const double* params, const double* h, double k, double* f_out,
+                           double* parts_out);
+
 /* ---- brick-wall ("new_tdvp") classical contractions (new_tdvp/ClassicalTDVPStripped.py) -------------
  * U1, U2 (and the primed pair) are [B][4][4] complex128 two-qubit unitaries, big-endian; the reference's
  * U.reshape(2,2,2,2) is [out0, out1, in0, in1].  Any context can be used (its bond dimension is ignored). */

@@ -487,3 +487,41 @@ def overlap_circuit_amplitude(A, B, WW, r):
     for g, qs in ops:
         psi = _on(n, g, qs) @ psi
     return psi[0]
+
+
+# ----------------------------------------------------------------------------
+# a-12  variational-environment objective (qmps/ground_state.py:170-228), D = 2
+# ----------------------------------------------------------------------------
+def _shallow_full_ops(v, a, b):
+    """Gate list of ShallowFullStateTensor(2, v) on qubits (a, b) (represent.py:393-401)."""
+    v = list(v)
+    return [(rz(v[0]), [a]), (rx(v[1]), [a]), (rz(v[2]), [a]), (rz(v[3]), [b]), (rx(v[4]), [b]), (rz(v[5]), [b]),
+            (CNOT, [a, b]), (ry(v[6]), [a]), (CNOT, [b, a]), (ry(v[7]), [a]), (rz(v[8]), [b]), (CNOT, [a, b]),
+            (rz(v[9]), [a]), (rx(v[10]), [a]), (rz(v[11]), [a]), (rz(v[12]), [b]), (rx(v[13]), [b]), (rz(v[14]), [b])]
+
+
+def _run_ops(n, ops):
+    psi = np.zeros(2 ** n, dtype=complex)
+    psi[0] = 1
+    for g, qs in ops:
+        psi = _on(n, g, qs) @ psi
+    return psi
+
+
+def opt_environment_objective(params, h, k=1.0):
+    """energy + k (u_purity + v_purity - 2 uv_purity) with the four circuits of ground_state.py:182-214 and the
+    SWAP-test operators of :220-222.  Grid qubits are ordered row-major (cirq's sorted qubit order).
+    Returns (f, (energy, u_purity, v_purity, uv_purity))."""
+    p2, p1 = np.split(np.asarray(params, dtype=float), 2)
+    e_state = _run_ops(4, _shallow_full_ops(p1, 2, 3) + _shallow_full_ops(p2, 1, 2) + _shallow_full_ops(p2, 0, 1))
+    v_state = _run_ops(4, _shallow_full_ops(p1, 0, 1) + _shallow_full_ops(p1, 2, 3) + [(SWAP, [0, 1])])
+    u_state = _run_ops(6, _shallow_full_ops(p1, 1, 2) + _shallow_full_ops(p2, 0, 1) + _shallow_full_ops(p1, 4, 5) +
+                       _shallow_full_ops(p2, 3, 4) + [(SWAP, [0, 1]), (SWAP, [1, 2])])
+    uv_state = _run_ops(5, _shallow_full_ops(p1, 3, 4) + _shallow_full_ops(p2, 2, 3) + _shallow_full_ops(p1, 0, 1) +
+                        [(SWAP, [0, 1])])
+    I2_, I4_ = np.eye(2), np.eye(4)
+    v_purity = np.real(v_state.conj() @ np.kron(I2_, np.kron(SWAP, I2_)) @ v_state)
+    u_purity = np.real(u_state.conj() @ np.kron(I4_, np.kron(SWAP, I4_)) @ u_state)
+    uv_purity = np.real(uv_state.conj() @ np.kron(np.kron(I2_, SWAP), I4_) @ uv_state)
+    energy = np.real(e_state.conj() @ np.kron(I2_, np.kron(h, I2_)) @ e_state)
+    return float(energy + k * (u_purity + v_purity - 2 * uv_purity)), (float(energy), float(u_purity), float(v_purity), float(uv_purity))

@@ -763,6 +763,24 @@ int qmps_bw_manifold(qmps_ctx* c, int64_t B, const double* U1, const double* U2,
   return QMPS_OK;
 }
 
+int qmps_opt_env_objective(qmps_ctx* c, int64_t B, const double* params, const double* h, double k, double* f_out,
+                           double* parts_out) {
+  if (int rc = bind(c)) return rc;
+  if (B < 0 || !params || !h || !f_out) return fail(QMPS_ERR_ARG, "bad arguments");
+  if (int rc = ensure_scratch(c, (size_t)B * (240 + 8 + 32) + 4096)) return rc;
+  Arena a{c};
+  hipError_t e = hipSuccess;
+  const double* d_p = (const double*)a.put(params, (size_t)B * 240, &e); HIP_TRY(e);
+  const void* d_h = a.put(h, 256, &e); HIP_TRY(e);
+  double* d_f = (double*)a.put(nullptr, (size_t)B * 8, &e);
+  double* d_parts = parts_out ? (double*)a.put(nullptr, (size_t)B * 32, &e) : nullptr;
+  HIP_TRY(qmps::launch_opt_env(d_p, d_h, k, d_f, d_parts, B, c->stream));
+  HIP_TRY(hipMemcpyAsync(f_out, d_f, (size_t)B * 8, hipMemcpyDeviceToHost, c->stream));
+  if (parts_out) HIP_TRY(hipMemcpyAsync(parts_out, d_parts, (size_t)B * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+
 int qmps_timer_begin(qmps_ctx* c) {
   if (int rc = bind(c)) return rc;
   HIP_TRY(hipEventRecord(c->ev0, c->stream));

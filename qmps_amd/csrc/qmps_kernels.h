@@ -101,6 +101,8 @@ struct BwArgs {
   double tol;
 };
 hipError_t launch_bw(int what, const BwArgs& a, hipStream_t st);
+hipError_t launch_opt_env(const double* params, const void* h, double k, double* f, double* parts, int64_t B,
+                          hipStream_t st);
 hipError_t launch_roto_shift(const double* base, double* out, int R, int P, int i, hipStream_t st);
 hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int i, int n_terms,
                               hipStream_t st);

@@ -1663,6 +1663,46 @@ struct Reg {
         }
       }
   }
+  __device__ __forceinline__ void swapq(int q1, int q2) {
+    const int m1 = mask(q1), m2 = mask(q2);
+#pragma unroll
+    for (int x = 0; x < N; ++x)
+      if ((x & m1) && !(x & m2)) {
+        const int y = (x & ~m1) | m2;
+        const double pr = re[x], pi = im[x];
+        re[x] = re[y]; im[x] = im[y];
+        re[y] = pr; im[y] = pi;
+      }
+  }
+  // <psi| SWAP(q1,q2) |psi> (real: SWAP is Hermitian)
+  __device__ __forceinline__ double swap_expectation(int q1, int q2) const {
+    const int m1 = mask(q1), m2 = mask(q2);
+    double e = 0.0;
+#pragma unroll
+    for (int x = 0; x < N; ++x) {
+      const bool b1 = (x & m1) != 0, b2 = (x & m2) != 0;
+      const int y = (b1 == b2) ? x : (x ^ m1 ^ m2);
+      e = dfma(re[x], re[y], e);
+      e = dfma(im[x], im[y], e);
+    }
+    return e;
+  }
+  // ShallowFullStateTensor(2, v) (qmps/represent.py:393-401) on qubits (a, b)
+  __device__ __forceinline__ void shallow_full(int a, int b, const double* v) {
+    rz(a, v[0]); rx(a, v[1]); rz(a, v[2]);
+    rz(b, v[3]); rx(b, v[4]); rz(b, v[5]);
+    cnot(a, b);
+    ry(a, v[6]);
+    cnot(b, a);
+    ry(a, v[7]); rz(b, v[8]);
+    cnot(a, b);
+    rz(a, v[9]); rx(a, v[10]); rz(a, v[11]);
+    rz(b, v[12]); rx(b, v[13]); rz(b, v[14]);
+  }
+  __device__ __forceinline__ void reset() {
+#pragma unroll
+    for (int x = 0; x < N; ++x) { re[x] = (x == 0) ? 1.0 : 0.0; im[x] = 0.0; }
+  }
   __device__ __forceinline__ void cnot(int ctrl, int tgt) {
     const int mc = mask(ctrl), mt = mask(tgt);
 #pragma unroll
@@ -2301,6 +2341,94 @@ hipError_t launch_bw(int what, const BwArgs& a, hipStream_t st) {
     case 3: hipLaunchKernelGGL(bw_manifold_kernel, grid, block, 0, st, a); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 3f: variational-environment objective (qmps/ground_state.py:170-228), D = 2, one
+// evaluation per lane.  30 parameters: p2 = params[:15] -> U, p1 = params[15:] -> V (both
+// ShallowFullStateTensor).  Four circuits, simulated literally:
+//   energy     (4 qubits): V(2,3) U(1,2) U(0,1);                  <1 x H x 1>
+//   v_purity   (4 qubits): V(0,1) V(2,3) SWAP(0,1);               <SWAP(1,2)>
+//   u_purity   (6 qubits): V(1,2) U(0,1) V(4,5) U(3,4) SWAP(0,1) SWAP(1,2);   <SWAP(2,3)>
+//   uv_purity  (5 qubits): V(3,4) U(2,3) V(0,1) SWAP(0,1);        <SWAP(1,2)>
+//   f = energy + k (u_purity + v_purity - 2 uv_purity)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void opt_env_lane_kernel(const double* __restrict__ params, const double2* __restrict__ h,
+                                                          double k, double* __restrict__ f, double* __restrict__ parts,
+                                                          int64_t B) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  double pu[15], pv[15];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) {
+    pu[i] = params[b * 30 + i];
+    pv[i] = params[b * 30 + 15 + i];
+  }
+  double energy, v_purity, u_purity, uv_purity;
+  {
+    Reg<4> r;
+    r.reset();
+    r.shallow_full(2, 3, pv);
+    r.shallow_full(1, 2, pu);
+    r.shallow_full(0, 1, pu);
+    // <psi| 1 x H x 1 |psi>, H on qubits 1,2 = index bits 2,1
+    double e = 0.0;
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+      for (int lo = 0; lo < 2; ++lo)
+#pragma unroll
+        for (int xm = 0; xm < 4; ++xm)
+#pragma unroll
+          for (int ym = 0; ym < 4; ++ym) {
+            const double2 o = h[xm * 4 + ym];
+            const int x = (hi << 3) | (xm << 1) | lo, y = (hi << 3) | (ym << 1) | lo;
+            // Re( conj(psi[x]) o psi[y] )
+            const double yr = o.x * r.re[y] - o.y * r.im[y], yi = o.x * r.im[y] + o.y * r.re[y];
+            e += r.re[x] * yr + r.im[x] * yi;
+          }
+    energy = e;
+    r.reset();
+    r.shallow_full(0, 1, pv);
+    r.shallow_full(2, 3, pv);
+    r.swapq(0, 1);
+    v_purity = r.swap_expectation(1, 2);
+  }
+  {
+    Reg<5> r;
+    r.reset();
+    r.shallow_full(3, 4, pv);
+    r.shallow_full(2, 3, pu);
+    r.shallow_full(0, 1, pv);
+    r.swapq(0, 1);
+    uv_purity = r.swap_expectation(1, 2);
+  }
+  {
+    Reg<6> r;
+    r.reset();
+    r.shallow_full(1, 2, pv);
+    r.shallow_full(0, 1, pu);
+    r.shallow_full(4, 5, pv);
+    r.shallow_full(3, 4, pu);
+    r.swapq(0, 1);
+    r.swapq(1, 2);
+    u_purity = r.swap_expectation(2, 3);
+  }
+  f[b] = energy + k * (u_purity + v_purity - 2.0 * uv_purity);
+  if (parts != nullptr) {
+    parts[b * 4 + 0] = energy;
+    parts[b * 4 + 1] = u_purity;
+    parts[b * 4 + 2] = v_purity;
+    parts[b * 4 + 3] = uv_purity;
+  }
+}
+
+hipError_t launch_opt_env(const double* params, const void* h, double k, double* f, double* parts, int64_t B,
+                          hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(opt_env_lane_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, params, (const double2*)h, k, f,
+                     parts, B);
   return hipGetLastError();
 }
 

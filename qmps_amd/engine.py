@@ -241,6 +241,18 @@ class EnergyEngine:
                                              _i32(rounds), _i32(st)))
         return (eta, rounds, st, r) if want_r else (eta, rounds, st)
 
+    def opt_env_objective(self, params, h, k=1.0, want_parts=False):
+        """Variational-environment objective (D = 2, 30 angles per row): f (B,) [and parts (B,4)]."""
+        P = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
+        if P.shape[1] != 30:
+            raise ValueError('the variational-environment objective takes 30 parameters')
+        h = np.ascontiguousarray(h, dtype=np.complex128).reshape(4, 4)
+        f = np.empty(P.shape[0])
+        parts = np.empty((P.shape[0], 4)) if want_parts else None
+        L.check(self._lib.qmps_opt_env_objective(self._ctx, P.shape[0], _f64(P), _f64(h.view(np.float64)), float(k), _f64(f),
+                                                 None if parts is None else _f64(parts)))
+        return (f, parts) if want_parts else f
+
     # -- timing / probes ----------------------------------------------------------------------
     def timer_begin(self):
         L.check(self._lib.qmps_timer_begin(self._ctx))

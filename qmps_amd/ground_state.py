@@ -144,18 +144,21 @@ class SparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
 
     def __init__(self, H, D=2, depth=2, state_tensor=ShallowCNOTStateTensor, optimize_environment=False,
                  env_depth=4, initial_guess=None, settings=None):
-        if optimize_environment:
-            raise NotImplementedError('objective_function_opt_environment (ground_state.py:170-228) is the '
-                                      'variational-environment variant, outside the first slice')
         self.optimize_environment = optimize_environment
         self.env_depth = env_depth
         self.state_tensor = state_tensor
         self.H = H
         self.D = D
         self.d = 2
-        initial_guess = np.array([np.random.randn(), np.random.randn()] * depth) if initial_guess is None \
-            else initial_guess
-        self.objective_function = self.objective_function_exact_environment
+        if optimize_environment:
+            if D != 2:
+                raise ValueError('the variational-environment objective is D = 2 only (ground_state.py:176-177)')
+            initial_guess = np.random.randn(30) if initial_guess is None else initial_guess
+            self.objective_function = self.objective_function_opt_environment
+        else:
+            initial_guess = np.array([np.random.randn(), np.random.randn()] * depth) if initial_guess is None \
+                else initial_guess
+            self.objective_function = self.objective_function_exact_environment
         self.p = len(initial_guess)
         self.f = 0
         super().__init__(self.state_tensor(D, initial_guess), None, initial_guess)
@@ -190,9 +193,18 @@ class SparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
         self.f = float(E[0])
         return self.f
 
+    def objective_function_opt_environment(self, params):
+        """No eigen-solve: U and V are both variational; energy + k (tr rho_u^2 + tr rho_v^2 - 2 tr rho_u rho_v),
+        k = 1 (ground_state.py:170-228).  Four circuits, simulated on the device."""
+        assert len(params) == 30
+        return float(self.batch_objective_function(np.asarray(params, dtype=float)[None])[0])
+
     def batch_objective_function(self, params_batch):
         """One kernel launch for B parameter vectors.  Entries whose environment is not positive
         definite / not converged are NaN (there is no 'previous value' in a batch)."""
+        if self.optimize_environment:
+            P = np.atleast_2d(np.asarray(params_batch, dtype=float))
+            return _runtime.engine(2, P.shape[0]).opt_env_objective(P, _as_h(self.H), k=1.0)
         E, _, st = self._energies_from_params(params_batch)
         return np.where(st == STATUS_OK, E, np.nan)
 

@@ -259,3 +259,22 @@ def test_time_evolve_objective_api():
     hist = NT.evolve(p0, WW, 2, options={'maxiter': 400, 'xatol': 1e-6, 'fatol': 1e-10})
     assert hist.shape == (3, 15)
     assert NT.obj(hist[1], A, WW) < NT.obj(p0, A, WW) + 1e-12 and NT.obj(hist[1], A, WW) < -0.999
+
+
+# ---- a-12: variational-environment objective ------------------------------------------------------
+def test_opt_environment_objective(engine_factory):
+    """ground_state.py:170-228 on the device == literal numpy restatement; the penalty is the squared
+    Hilbert-Schmidt distance tr (rho_u - rho_v)^2 >= 0 and vanishes when V is U's fixed-point environment."""
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+    rng = np.random.default_rng(12)
+    P = rng.standard_normal((64, 30))
+    eng = engine_factory(2)
+    f, parts = eng.opt_env_objective(P, h, want_parts=True)
+    for k in range(0, 64, 7):
+        fo, po = O.opt_environment_objective(P[k], h)
+        assert abs(f[k] - fo) < 1e-12 and np.abs(parts[k] - po).max() < 1e-12
+    penalty = parts[:, 1] + parts[:, 2] - 2 * parts[:, 3]
+    assert np.all(penalty > -1e-13)
+    opt = G.SparseFullEnergyOptimizer(h, 2, optimize_environment=True, initial_guess=P[0].copy())
+    assert abs(opt.objective_function(P[0]) - f[0]) < 1e-13
+    assert np.abs(opt.batch_objective_function(P) - f).max() < 1e-13

@@ -219,9 +219,11 @@ int qmps_comm_init(qmps_ctx* ctx, const char id[QMPS_UNIQUE_ID_BYTES], int rank,
 int qmps_comm_destroy(qmps_ctx* ctx);
 /* in-place sum over ranks of a small float64 vector held on the host (staged through HBM) */
 int qmps_allreduce_sum(qmps_ctx* ctx, double* inout, int n);
-/* Asynchronous on the context stream: device-side cost[t] = sum_b E[b][t], followed - when a
- * communicator exists - by ONE ncclAllReduce(sum, double, n_terms) over all ranks.  This is the
- * path's single exchange step (the summed cost of rotosolve's M(x), qmps/tools.py:432-433). */
+/* Asynchronous: device-side cost[t] = sum_b E[b][t] on the context stream, followed - when a
+ * communicator exists - by ONE ncclAllReduce(sum, double, n_terms) over all ranks on the context's
+ * COMMUNICATION stream (ordered after the sum by an event, results in a 4-slot ring), so the exchange
+ * step of one batch overlaps the kernels of the next.  This is the path's single exchange step (the
+ * summed cost of rotosolve's M(x), qmps/tools.py:432-433).  qmps_sync waits for both streams. */
 int qmps_cost_launch(qmps_ctx* ctx, int64_t B);
 /* waits for the stream and copies the (all-reduced) cost[n_terms] to the host */
 int qmps_get_cost(qmps_ctx* ctx, double* cost /* [n_terms] */);

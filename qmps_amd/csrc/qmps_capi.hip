@@ -70,7 +70,10 @@ struct qmps_ctx {
   int64_t E_capacity = 0;    // in doubles
   int32_t* d_iters = nullptr;
   int32_t* d_status = nullptr;
-  double* d_partial = nullptr;  // [16][kSumBlocks]
+  double* d_partial = nullptr;  // [16][max(kSumBlocks, waves of the lane kernels)]
+  int64_t partial_cap = 0;      // entries per term
+  int64_t partials_B = -1;      // >= 0: the last launch left per-wave partial sums for this batch size
+  int partials_n = 0;           //       ... in this many entries per term
   double* d_cost = nullptr;     // [16]
   double* h_cost = nullptr;     // pinned [16]
   int32_t* d_work_count = nullptr;  // [1]  hybrid solve: number of slow items handed to the squaring tail
@@ -84,9 +87,15 @@ struct qmps_ctx {
   bool have_guess = false;
   bool have_env = false;
   bool want_rho = false;
-  // RCCL
+  // RCCL: the all-reduce runs on its own stream so that it overlaps the next step's kernels
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
+  hipStream_t comm_stream = nullptr;
+  static constexpr int kCostSlots = 4;        // ring: step n's all-reduce may still be in flight while step n+1 sums
+  double* d_cost_ring = nullptr;             // [kCostSlots][16]
+  hipEvent_t cost_ready[kCostSlots] = {};    // sum kernels done (main stream)
+  hipEvent_t cost_reduced[kCostSlots] = {};  // all-reduce done (comm stream)
+  int64_t cost_launches = 0;
 };
 
 namespace {
@@ -200,8 +209,15 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     HIP_TRY(hipMalloc(&c->d_h, (size_t)kMaxTerms * 256));
     HIP_TRY(hipMalloc((void**)&c->d_iters, (size_t)max_batch * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&c->d_status, (size_t)max_batch * sizeof(int32_t)));
-    HIP_TRY(hipMalloc((void**)&c->d_partial, (size_t)kMaxTerms * kSumBlocks * sizeof(double)));
+    c->partial_cap = (max_batch + 63) / 64 > kSumBlocks ? (max_batch + 63) / 64 : kSumBlocks;
+    HIP_TRY(hipMalloc((void**)&c->d_partial, (size_t)kMaxTerms * c->partial_cap * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->d_cost, kMaxTerms * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->d_cost_ring, qmps_ctx::kCostSlots * kMaxTerms * sizeof(double)));
+    HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    for (int i = 0; i < qmps_ctx::kCostSlots; ++i) {
+      HIP_TRY(hipEventCreateWithFlags(&c->cost_ready[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c->cost_reduced[i], hipEventDisableTiming));
+    }
     HIP_TRY(hipHostMalloc((void**)&c->h_cost, kMaxTerms * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipMalloc((void**)&c->d_work_count, sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&c->d_work_idx, (size_t)max_batch * sizeof(int32_t)));
@@ -226,8 +242,14 @@ int qmps_destroy(qmps_ctx* c) {
   if (!c) return QMPS_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
   if (c->comm) (void)ncclCommDestroy(c->comm);
-  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_work_count, c->d_work_idx};
+  for (int i = 0; i < qmps_ctx::kCostSlots; ++i) {
+    if (c->cost_ready[i]) (void)hipEventDestroy(c->cost_ready[i]);
+    if (c->cost_reduced[i]) (void)hipEventDestroy(c->cost_reduced[i]);
+  }
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
@@ -245,6 +267,7 @@ int qmps_destroy(qmps_ctx* c) {
 int qmps_sync(qmps_ctx* c) {
   if (int rc = bind(c)) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipStreamSynchronize(c->comm_stream));
   return QMPS_OK;
 }
 
@@ -400,6 +423,8 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   qmps::LaneArgs a = make_args(c, B, max_iter, tol, true);
   const bool hybrid = solver == QMPS_ENV_POWER_SQUARING && c->D <= 4 && c->handoff < max_iter;
   const int slot = (int)(c->launches % qmps_ctx::kRing);
+  c->partials_B = -1;
+  const int lane_waves = (int)((B + 63) / 64);
   if (c->D == 16 && !getenv("QMPS_D16_BLOCK")) {
     // D = 16: power iteration on the matrix cores (one wave per evaluation), then the energy pass
     c->dominant = "energy_mfma_d16_kernel<true>";
@@ -408,6 +433,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
   } else if (!hybrid) {
     c->dominant = c->D <= 4 ? "energy_lane_kernel<D,true>" : "energy_block_kernel<D,true>";
+    if (c->D <= 4) { a.partial = c->d_partial; c->partials_B = B; c->partials_n = lane_waves; }
     HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
     HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
@@ -415,6 +441,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     a.handoff = c->handoff;  // the squaring tail runs in-lane (real 4 x 4 transfer matrix in registers)
     a.hybrid = 1;
     a.skip = c->handoff == 0 ? c->skip_rounds : 0;
+    a.partial = c->d_partial; c->partials_B = B; c->partials_n = lane_waves;
     c->dominant = "energy_lane_kernel<2,true>";
     HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
@@ -448,9 +475,12 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
       e.idx_count = c->d_work_count;
     } else {
       q.r_in = c->have_guess ? c->d_r : nullptr;
+      e.partial = c->d_partial; c->partials_B = B; c->partials_n = lane_waves;   // the energy pass covers every item
     }
     int grid = (int)((B + 15) / 16);
-    if (grid > 2048) grid = 2048;
+    int cap = 2048;
+    if (const char* e = getenv("QMPS_SQ_GRID")) cap = atoi(e);   // tuning knob
+    if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     if (c->handoff == 0) {
       c->dominant = "env_square_d4_kernel";
@@ -492,6 +522,7 @@ int qmps_energy_only_launch(qmps_ctx* c, int64_t B) {
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "qmps_set_hamiltonian has not been called");
   if (!c->have_env) return fail(QMPS_ERR_STATE, "no resident environment: run qmps_energy_launch or qmps_set_env_guess first");
   qmps::LaneArgs a = make_args(c, B, 1, 1.0, false);
+  c->partials_B = -1;
   if (c->D == 16 && !getenv("QMPS_D16_BLOCK"))
     HIP_TRY(qmps::launch_energy_mfma(c->D, a, false, c->stream));
   else
@@ -501,6 +532,7 @@ int qmps_energy_only_launch(qmps_ctx* c, int64_t B) {
 
 static int sum_on_device(qmps_ctx* c, int64_t B) {
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
+  c->partials_B = -1;   // d_partial is about to be overwritten by the generic two-pass reduction
   HIP_TRY(qmps::launch_sum(c->d_E, B, c->n_terms, c->d_partial, kSumBlocks, c->d_cost, c->stream));
   return QMPS_OK;
 }
@@ -597,6 +629,7 @@ int qmps_cell2_energy_batch(qmps_ctx* c, int64_t B, const double* U1, const doub
   qmps::Cell2Args a;
   a.U1 = c->d_U; a.U2 = c->d_U2; a.h = c->d_h; a.E = c->d_E; a.E12 = nullptr;
   a.iters = c->d_iters; a.status = c->d_status; a.B = B; a.n_terms = n_terms; a.max_iter = max_iter; a.tol = tol;
+  c->partials_B = -1;
   HIP_TRY(qmps::launch_cell2(c->D, a, c->stream));
   c->n_states = 0;  // the resident single-site states (if any) are no longer what d_E refers to
   c->have_env = false;
@@ -823,6 +856,7 @@ int qmps_comm_destroy(qmps_ctx* c) {
   if (int rc = bind(c)) return rc;
   if (c->comm) {
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->comm_stream));
     RCCL_TRY(ncclCommDestroy(c->comm));
     c->comm = nullptr;
     c->nranks = 1;
@@ -847,8 +881,27 @@ int qmps_allreduce_sum(qmps_ctx* c, double* inout, int n) {
 int qmps_cost_launch(qmps_ctx* c, int64_t B) {
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;
-  if (int rc = sum_on_device(c, B)) return rc;
-  if (c->comm) RCCL_TRY(ncclAllReduce(c->d_cost, c->d_cost, c->n_terms, ncclDouble, ncclSum, c->comm, c->stream));
+  if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
+  // device-side sum into this launch's ring slot (main stream) ...
+  const int slot = (int)(c->cost_launches % qmps_ctx::kCostSlots);
+  double* dst = c->d_cost_ring + (size_t)slot * kMaxTerms;
+  // a slot is reused only after its previous all-reduce has finished
+  if (c->comm && c->cost_launches >= qmps_ctx::kCostSlots) HIP_TRY(hipStreamWaitEvent(c->stream, c->cost_reduced[slot], 0));
+  if (c->partials_B == B)   // the energy kernel already left per-wave partial sums: only the final pass is needed
+    HIP_TRY(qmps::launch_sum_final(c->d_partial, c->partials_n, c->n_terms, dst, c->stream));
+  else {
+    c->partials_B = -1;   // the generic two-pass reduction reuses d_partial
+    HIP_TRY(qmps::launch_sum(c->d_E, B, c->n_terms, c->d_partial, kSumBlocks, dst, c->stream));
+  }
+  if (c->comm) {
+    // ... then ONE ncclAllReduce on the communication stream, ordered after the sum by an event, so the
+    // exchange step overlaps the next step's kernels instead of stalling the compute stream
+    HIP_TRY(hipEventRecord(c->cost_ready[slot], c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->cost_ready[slot], 0));
+    RCCL_TRY(ncclAllReduce(dst, dst, c->n_terms, ncclDouble, ncclSum, c->comm, c->comm_stream));
+    HIP_TRY(hipEventRecord(c->cost_reduced[slot], c->comm_stream));
+  }
+  c->cost_launches++;
   return QMPS_OK;
 }
 
@@ -856,8 +909,13 @@ int qmps_get_cost(qmps_ctx* c, double* cost) {
   if (int rc = bind(c)) return rc;
   if (!cost) return fail(QMPS_ERR_ARG, "null cost");
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
-  HIP_TRY(hipMemcpyAsync(c->h_cost, c->d_cost, c->n_terms * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (c->cost_launches < 1) return fail(QMPS_ERR_STATE, "qmps_cost_launch has not been called");
+  const int slot = (int)((c->cost_launches - 1) % qmps_ctx::kCostSlots);
+  hipStream_t st = c->comm ? c->comm_stream : c->stream;
   HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_cost, c->d_cost_ring + (size_t)slot * kMaxTerms, c->n_terms * sizeof(double),
+                         hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   memcpy(cost, c->h_cost, c->n_terms * sizeof(double));
   return QMPS_OK;
 }

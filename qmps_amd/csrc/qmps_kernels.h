@@ -31,6 +31,7 @@ struct LaneArgs {
   const int32_t* idx_list;
   const int32_t* idx_count;
   int check_pd;               // !SOLVE: Cholesky test of the resident r, status 0 -> 2 on failure
+  double* partial;            // nullable [n_terms][gridDim.x]: per-wave sums of the energies (lane kernels)
 };
 
 // D = 4 repeated-squaring tail over the worklist (one wave per item, MFMA f64 16x16x4)
@@ -110,6 +111,7 @@ hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms,
 hipError_t launch_unitary_to_tensor(const void* U, void* A, int D, int64_t B, hipStream_t st);
 hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, int n_partial, double* cost,
                       hipStream_t st);
+hipError_t launch_sum_final(const double* partial, int n_partial, int n_terms, double* cost, hipStream_t st);
 hipError_t launch_probe_fp64(double* out, int blocks, int iters, hipStream_t st);
 hipError_t launch_probe_mfma_f64(double* out, int blocks, int iters, hipStream_t st);
 hipError_t launch_probe_copy(const void* src, void* dst, int64_t n16, hipStream_t st);

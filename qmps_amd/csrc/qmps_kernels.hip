@@ -32,6 +32,45 @@ namespace qmps {
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// ---- wave-level reductions (VALU only: DPP row rotations + gfx950 permlane swaps) ----
+// sum over the 16 lanes of a row group (lanes 16 g .. 16 g + 15); result in every lane of the group.
+// DPP row rotations (v_mov_b32_dpp row_ror:n, VALU only - no LDS crossbar traffic).
+template <int N>
+__device__ __forceinline__ double row_ror(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x120 + N, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x120 + N, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += row_ror<8>(v);
+  v += row_ror<4>(v);
+  v += row_ror<2>(v);
+  v += row_ror<1>(v);
+  return v;
+}
+// sum over the four row groups, per lane position: lane (g, c) receives sum_g' v(g', c).
+// gfx950 v_permlane32_swap / v_permlane16_swap: VALU only, no LDS crossbar, no SGPR round trip.
+__device__ __forceinline__ double group4_sum(double v) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  u2 a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  u2 b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const double x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  lo = __double2loint(x);
+  hi = __double2hiint(x);
+  a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+// wave-uniform copy of lane 0's value
+__device__ __forceinline__ double lane0(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) { return group4_sum(row16_sum(v)); }
+
 // Packed Hermitian accessors: only entries with j >= i are stored; the diagonal is real.
 template <int D>
 __device__ __forceinline__ double h_re(const double (&re)[D][D], int i, int j) {
@@ -621,12 +660,17 @@ __global__ __launch_bounds__(64) void energy_lane_kernel(LaneArgs p) {
       pre[t][s] *= inv;
       pim[t][s] = (t == s) ? 0.0 : pim[t][s] * inv;
     }
-  if (!valid) return;
-
   for (int q = 0; q < p.n_terms; ++q) {
     const double2* h = (const double2*)p.h + q * 16;  // wave-uniform -> scalar loads
-    p.E[b * p.n_terms + q] = rdm_energy(h, pre, pim);
+    const double e = rdm_energy(h, pre, pim);
+    if (valid) p.E[b * p.n_terms + q] = e;
+    if (p.partial != nullptr) {
+      // fused first pass of the cost reduction: one partial per wave (deterministic order)
+      const double s = wave_sum(valid ? e : 0.0);
+      if (lane == 0) p.partial[(int64_t)q * gridDim.x + blockIdx.x] = s;
+    }
   }
+  if (!valid) return;
   if (SOLVE) {
     p.iters[b] = iters;
     p.status[b] = status;
@@ -764,42 +808,6 @@ __global__ __launch_bounds__(64) void cell2_lane_kernel(Cell2Args p) {
 // Items: the worklist written by the lane kernel, or (work_idx == nullptr) all of 0 .. B-1.
 // ------------------------------------------------------------------------------------------
 typedef double v4f64 __attribute__((ext_vector_type(4)));
-
-// sum over the 16 lanes of a row group (lanes 16 g .. 16 g + 15); result in every lane of the group.
-// DPP row rotations (v_mov_b32_dpp row_ror:n, VALU only - no LDS crossbar traffic).
-template <int N>
-__device__ __forceinline__ double row_ror(double v) {
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x120 + N, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x120 + N, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row16_sum(double v) {
-  v += row_ror<8>(v);
-  v += row_ror<4>(v);
-  v += row_ror<2>(v);
-  v += row_ror<1>(v);
-  return v;
-}
-// sum over the four row groups, per lane position: lane (g, c) receives sum_g' v(g', c).
-// gfx950 v_permlane32_swap / v_permlane16_swap: VALU only, no LDS crossbar, no SGPR round trip.
-__device__ __forceinline__ double group4_sum(double v) {
-  typedef unsigned u2 __attribute__((ext_vector_type(2)));
-  unsigned lo = __double2loint(v), hi = __double2hiint(v);
-  u2 a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  u2 b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  const double x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-  lo = __double2loint(x);
-  hi = __double2hiint(x);
-  a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-}
-// wave-uniform copy of lane 0's value
-__device__ __forceinline__ double lane0(double v) {
-  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
 
 __global__ __launch_bounds__(256) void env_square_d4_kernel(SquareArgs p) {
   constexpr int D = 4, N = 16, LD = 17;
@@ -1075,7 +1083,6 @@ __device__ __forceinline__ void cmma(const double (&pre)[4], const double (&pim)
   }
 }
 
-__device__ __forceinline__ double wave_sum(double v) { return group4_sum(row16_sum(v)); }
 
 template <bool SOLVE>
 __global__ __launch_bounds__(256) void energy_mfma_d16_kernel(LaneArgs p) {
@@ -2578,6 +2585,11 @@ hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, 
                       hipStream_t st) {
   hipLaunchKernelGGL(sum_partial_kernel, dim3(n_partial), dim3(256), 0, st, E, B, n_terms, partial);
   hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, n_partial, n_terms, cost);
+  return hipGetLastError();
+}
+
+hipError_t launch_sum_final(const double* partial, int n_partial, int n_terms, double* cost, hipStream_t st) {
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, st, partial, n_partial, n_terms, cost);
   return hipGetLastError();
 }
 

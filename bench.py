@@ -64,6 +64,22 @@ def tfim_h(g=1.0):
     return -np.kron(Z, Z) + 0.5 * g * (np.kron(I, X) + np.kron(X, I))
 
 
+def committed_traffic(kernel_name, D, B, solver, handoff):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+    (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, collected in separate rocprofv3 --pmc runs of this very
+    command); None when no profile of this configuration is committed."""
+    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    rec = table.get(f'{kernel_name}|D={D}|B={B}|solver={solver}|handoff={handoff}')
+    if not rec:
+        return None
+    return {'bytes': rec['bytes'], 'unit': 'B per launch', 'fetch_kb_x2': rec['fetch_kb_x2'], 'write_kb': rec['write_kb'],
+            'algorithmic_bytes': B * bytes_per_eval(D), 'source': rec['source']}
+
+
 def cpu_baseline(D, A, h, max_iter, tol, budget_s=12.0):
     """The oracle ("port") timed on this box's host cores, on a bounded sample of the same workload."""
     from oracle import c_oracle as C
@@ -212,13 +228,14 @@ def main():
             flops = float(flops_per_eval(D, iters.astype(np.float64)).sum())
             flop_note = 'SURVEY 8(d): sum_b [K_b(32D^3+4D^2)+64D^3+128D^2], K_b read back per item'
         tflops = flops / (kernel_ms * 1e-3) * 1e-12
+        traffic = committed_traffic(kernel_name, D, B, args.solver, handoff)
         hbm_gbps = B * bytes_per_eval(D) / (kernel_ms * 1e-3) * 1e-9
         out = {
             'metric': 'two-site energy evals/sec at D=4, batch=65536' if (D, B) == (4, 65536)
                       else f'two-site energy evals/sec at D={D}, batch={B}',
             'value': value, 'unit': 'two-site energy evals/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f64 (complex128)', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'TFIM g=1 two-site energy, D={D}, batch={B} per GPU, Haar-random state unitaries, '
                                    f'in-kernel power-iteration environment solve (tol {args.tol:g}, cap {args.max_iter}, solver {args.solver})',
                        'baseline_config': 'BASELINE.json configs[2]', 'D': D, 'batch_per_gpu': B,
@@ -228,7 +245,7 @@ def main():
                        'collective': 'none (N=1)' if dist is None else 'one RCCL all-reduce(sum, f64[1]) per step',
                        'device': info['name'], 'arch': info['arch']},
             'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': tflops / FP64_PEAK_TFLOPS, 'traffic': None,
+                         'frac': tflops / FP64_PEAK_TFLOPS, 'traffic': traffic,
                          'kernel': kernel_name, 'kernel_ms': kernel_ms, 'step_ms_events': step_ms_events,
                          'note': 'FP64-bound (MI355X FP64 vector == FP64 matrix peak = 78.6 TFLOP/s spec; measured on '
                                  'this part: v_fma_f64 70.9, v_mfma_f64_16x16x4 47.7 TFLOP/s, profiles/r01_probe.json); '

@@ -81,28 +81,43 @@ def committed_traffic(kernel_name, D, B, solver, handoff):
 
 
 def cpu_baseline(D, A, h, max_iter, tol, budget_s=12.0):
-    """The oracle ("port") timed on this box's host cores, on a bounded sample of the same workload."""
+    """The oracle ("port") timed on this box's host cores, on a bounded sample of the same workload
+    (~budget_s seconds of single-thread work), plus two context figures: all host threads (OpenMP) and the
+    reference-STRUCTURED numpy path (dense eig -> Cholesky -> null-space completion -> Kronecker state
+    vector -> dense psi^+ (1 x h x 1) psi) on a small slice."""
     from oracle import c_oracle as C
+    from oracle import qmps_oracle as O
     C.build()
-    # calibrate on a small slice, then size the sample for ~budget_s of single-thread work
     n0 = min(len(A), 2048)
     t = time.perf_counter()
     C.energy_batch(A[:n0], h, max_iter=max_iter, tol=tol, threads=1)
     rate = n0 / (time.perf_counter() - t)
-    n = int(min(len(A), max(n0, rate * budget_s)))
+    reps = max(1, int(round(rate * budget_s / len(A))))
     t = time.perf_counter()
-    C.energy_batch(A[:n], h, max_iter=max_iter, tol=tol, threads=1)
-    v1 = n / (time.perf_counter() - t)
+    for _ in range(reps):
+        C.energy_batch(A, h, max_iter=max_iter, tol=tol, threads=1)
+    v1 = reps * len(A) / (time.perf_counter() - t)
     cores = os.cpu_count() or 1
     nthr = min(cores, C.max_threads())
     t = time.perf_counter()
     C.energy_batch(A, h, max_iter=max_iter, tol=tol, threads=nthr)
     vall = len(A) / (time.perf_counter() - t)
+    nref = min(len(A), 1500)
+    U = np.zeros((nref, 2 * D, 2 * D), dtype=complex)
+    for k in range(nref):                      # complete each tensor to a unitary (the reference's input)
+        U[k] = O.tensor_to_unitary(A[k])
+    t = time.perf_counter()
+    for k in range(nref):
+        O.reference_structured_energy(U[k], h)
+    vref = nref / (time.perf_counter() - t)
     return {'value': v1, 'unit': 'two-site energy evals/s', 'cores': 1, 'kind': 'port',
-            'sample': f'first {n} of the {len(A)} evaluations of the GPU workload, same seed, C oracle '
-                      f'(oracle/qmps_oracle.c: power iteration + closed-form energy), 1 thread',
-            'all_cores': {'value': vall, 'threads': nthr, 'host_cpus': cores,
-                          'sample': f'all {len(A)} evaluations, OpenMP'}}
+            'sample': f'{reps} pass(es) over the {len(A)} evaluations of the GPU workload, same seed, C oracle '
+                      f'(oracle/qmps_oracle.c: plain power iteration + closed-form energy), 1 thread',
+            'all_cores': {'value': vall, 'threads': nthr, 'host_cpus': cores, 'sample': f'all {len(A)} evaluations, OpenMP'},
+            'reference_structured_numpy': {'value': vref, 'cores': 1,
+                                           'sample': f'first {nref} evaluations; dense eig + Cholesky + null-space '
+                                                     'completion + Kronecker state vector (the reference\'s per-evaluation '
+                                                     'structure, numpy/scipy)'}}
 
 
 def main():

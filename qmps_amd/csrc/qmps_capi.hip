@@ -52,6 +52,7 @@ struct qmps_ctx {
   static constexpr int kRing = 64;
   hipEvent_t kev0[kRing] = {}, kev1[kRing] = {};
   int64_t launches = 0;
+  bool capturing = false;   // inside hipStreamBeginCapture: skip the timing events
   const char* dominant = "";
   // HBM
   void* d_A = nullptr;       // [max_batch][2][D][D] c128
@@ -341,22 +342,48 @@ int qmps_rotosolve(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     c->params_cap = n_params;
   }
   double *d_base = nullptr, *d_hist = nullptr;
+  int* d_idx = nullptr;
   HIP_TRY(hipMalloc((void**)&d_base, (size_t)R * n_params * sizeof(double)));
-  if (hipMalloc((void**)&d_hist, (size_t)R * n_sweeps * sizeof(double)) != hipSuccess) {
+  if (hipMalloc((void**)&d_hist, (size_t)R * n_sweeps * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&d_idx, 2 * sizeof(int)) != hipSuccess) {
     (void)hipFree(d_base);
+    if (d_hist) (void)hipFree(d_hist);
     return fail(QMPS_ERR_HIP, "hipMalloc failed");
   }
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
   int rc = [&]() -> int {
     HIP_TRY(hipMemcpyAsync(d_base, params, (size_t)R * n_params * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(d_idx, 0, 2 * sizeof(int), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     const bool saved_guess = c->have_guess;
     c->have_guess = false;
+    // One parameter update = shift build -> ansatz -> environment + energy -> closed-form update.  The
+    // parameter index lives in HBM and is advanced by the update kernel, so the sequence is captured ONCE
+    // into a hipGraph and replayed n_params x n_sweeps times: the sweep is launch-bound at small R.
+    auto one_update = [&]() -> int {
+      HIP_TRY(qmps::launch_roto_shift(d_base, c->d_params, (int)R, n_params, d_idx, c->stream));
+      HIP_TRY(qmps::launch_ansatz(c->D, kind, c->d_params, n_params, c->d_A, 3 * R, c->stream));
+      c->n_states = 3 * R;
+      if (int e = qmps_energy_launch(c, 3 * R, max_iter, tol, c->default_solver)) return e;
+      HIP_TRY(qmps::launch_roto_update(d_base, c->d_E, c->d_status, (int)R, n_params, d_idx, c->n_terms, c->stream));
+      return QMPS_OK;
+    };
+    const bool use_graph = getenv("QMPS_NO_GRAPH") == nullptr;
+    if (use_graph) {
+      c->capturing = true;
+      HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      const int e = one_update();
+      const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+      c->capturing = false;
+      if (e) return e;
+      HIP_TRY(ce);
+      HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    }
     for (int sw = 0; sw < n_sweeps; ++sw) {
       for (int i = 0; i < n_params; ++i) {
-        HIP_TRY(qmps::launch_roto_shift(d_base, c->d_params, (int)R, n_params, i, c->stream));
-        HIP_TRY(qmps::launch_ansatz(c->D, kind, c->d_params, n_params, c->d_A, 3 * R, c->stream));
-        c->n_states = 3 * R;
-        if (int e = qmps_energy_launch(c, 3 * R, max_iter, tol, c->default_solver)) return e;
-        HIP_TRY(qmps::launch_roto_update(d_base, c->d_E, c->d_status, (int)R, n_params, i, c->n_terms, c->stream));
+        if (use_graph) HIP_TRY(hipGraphLaunch(exec, c->stream));
+        else if (int e = one_update()) return e;
       }
       HIP_TRY(qmps::launch_ansatz(c->D, kind, d_base, n_params, c->d_A, R, c->stream));
       c->n_states = R;
@@ -369,9 +396,13 @@ int qmps_rotosolve(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     HIP_TRY(hipStreamSynchronize(c->stream));
     return QMPS_OK;
   }();
+  c->capturing = false;
   (void)hipStreamSynchronize(c->stream);
+  if (exec) (void)hipGraphExecDestroy(exec);
+  if (graph) (void)hipGraphDestroy(graph);
   (void)hipFree(d_base);
   (void)hipFree(d_hist);
+  (void)hipFree(d_idx);
   return rc;
 }
 
@@ -428,24 +459,24 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   if (c->D == 16 && !getenv("QMPS_D16_BLOCK")) {
     // D = 16: power iteration on the matrix cores (one wave per evaluation), then the energy pass
     c->dominant = "energy_mfma_d16_kernel<true>";
-    HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+    if (!c->capturing) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy_mfma(c->D, a, true, c->stream));
-    HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
+    if (!c->capturing) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
   } else if (!hybrid) {
     c->dominant = c->D <= 4 ? "energy_lane_kernel<D,true>" : "energy_block_kernel<D,true>";
     if (c->D <= 4) { a.partial = c->d_partial; c->partials_B = B; c->partials_n = lane_waves; }
-    HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+    if (!c->capturing) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
-    HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
+    if (!c->capturing) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
   } else if (c->D == 2) {
     a.handoff = c->handoff;  // the squaring tail runs in-lane (real 4 x 4 transfer matrix in registers)
     a.hybrid = 1;
     a.skip = c->handoff == 0 ? c->skip_rounds : 0;
     a.partial = c->d_partial; c->partials_B = B; c->partials_n = lane_waves;
     c->dominant = "energy_lane_kernel<2,true>";
-    HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+    if (!c->capturing) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
-    HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
+    if (!c->capturing) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
   } else {
     // D = 4: (1) lane kernel: `handoff` plain steps, slow items -> worklist (skipped when handoff == 0:
     // every item goes straight to the squaring kernel); (2) wave-per-item MFMA squaring over the
@@ -465,9 +496,9 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
       a.work_count = c->d_work_count;
       a.work_idx = c->d_work_idx;
       c->dominant = "energy_lane_kernel<4,true>";
-      HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+      if (!c->capturing) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
       HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
-      HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
+      if (!c->capturing) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
       q.r_in = c->d_r;
       q.work_count = c->d_work_count;
       q.work_idx = c->d_work_idx;
@@ -484,13 +515,13 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     if (grid < 1) grid = 1;
     if (c->handoff == 0) {
       c->dominant = "env_square_d4_kernel";
-      HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+      if (!c->capturing) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     }
     HIP_TRY(qmps::launch_square_tail(c->D, q, grid, c->stream));
-    if (c->handoff == 0) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
+    if (c->handoff == 0) if (!c->capturing) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
     HIP_TRY(qmps::launch_energy(c->D, e, false, c->stream));
   }
-  c->launches++;
+  if (!c->capturing) c->launches++;
   c->have_env = true;
   return QMPS_OK;
 }

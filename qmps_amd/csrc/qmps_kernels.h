@@ -104,8 +104,9 @@ struct BwArgs {
 hipError_t launch_bw(int what, const BwArgs& a, hipStream_t st);
 hipError_t launch_opt_env(const double* params, const void* h, double k, double* f, double* parts, int64_t B,
                           hipStream_t st);
-hipError_t launch_roto_shift(const double* base, double* out, int R, int P, int i, hipStream_t st);
-hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int i, int n_terms,
+// i_ptr[0] = index of the parameter being updated, i_ptr[1] = arrival counter (both zero-initialised)
+hipError_t launch_roto_shift(const double* base, double* out, int R, int P, const int* i_ptr, hipStream_t st);
+hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int* i_ptr, int n_terms,
                               hipStream_t st);
 hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, hipStream_t st);
 hipError_t launch_unitary_to_tensor(const void* U, void* A, int D, int64_t B, hipStream_t st);

@@ -1816,9 +1816,10 @@ hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, vo
 // runs on the device, so a whole sweep needs no host round trip.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void roto_shift_kernel(const double* __restrict__ base, double* __restrict__ out, int R,
-                                                         int P, int i) {
+                                                         int P, const int* __restrict__ i_ptr) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)R * 3 * P) return;
+  const int i = *i_ptr;   // parameter being updated: lives in HBM so ONE captured hipGraph serves all of them
   const int col = (int)(t % P);
   const int64_t row = t / P;
   const int k = (int)(row % 3);
@@ -1831,10 +1832,13 @@ __global__ __launch_bounds__(256) void roto_shift_kernel(const double* __restric
 __device__ __forceinline__ double wrap_pi(double x) { return atan2(sin(x), cos(x)); }
 
 __global__ __launch_bounds__(256) void roto_update_kernel(double* __restrict__ base, const double* __restrict__ E,
-                                                          const int32_t* __restrict__ status, int R, int P, int i,
-                                                          int n_terms) {
+                                                          const int32_t* __restrict__ status, int R, int P,
+                                                          int* __restrict__ i_ptr, int n_terms) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
+  const int i = *i_ptr;
+  // the LAST workgroup to finish advances the parameter index for the next graph replay
+  __shared__ int s_last;
+  if (r < R) {
   double e[3];
   bool ok = true;
 #pragma unroll
@@ -1844,9 +1848,22 @@ __global__ __launch_bounds__(256) void roto_update_kernel(double* __restrict__ b
     e[k] = v;
     ok = ok && status[(int64_t)r * 3 + k] == QMPS_ST_OK;
   }
-  if (!ok) return;   // an evaluation without a valid environment: leave this restart's parameter untouched
-  const double theta = -1.5707963267948966 - atan2(2.0 * e[0] - e[1] - e[2], e[1] - e[2]);
-  base[(int64_t)r * P + i] = wrap_pi(base[(int64_t)r * P + i] + wrap_pi(theta));
+  if (ok) {          // (an evaluation without a valid environment leaves this restart's parameter untouched)
+    const double theta = -1.5707963267948966 - atan2(2.0 * e[0] - e[1] - e[2], e[1] - e[2]);
+    base[(int64_t)r * P + i] = wrap_pi(base[(int64_t)r * P + i] + wrap_pi(theta));
+  }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int done = atomicAdd(i_ptr + 1, 1);        // i_ptr[1]: arrival counter
+    s_last = (done == (int)gridDim.x - 1);
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    i_ptr[1] = 0;
+    i_ptr[0] = (i + 1 == P) ? 0 : i + 1;             // every block has read *i_ptr before its arrival
+    __threadfence();
+  }
 }
 
 __global__ __launch_bounds__(256) void roto_record_kernel(const double* __restrict__ E, double* __restrict__ hist, int R,
@@ -1858,14 +1875,14 @@ __global__ __launch_bounds__(256) void roto_record_kernel(const double* __restri
   hist[r] = v;
 }
 
-hipError_t launch_roto_shift(const double* base, double* out, int R, int P, int i, hipStream_t st) {
+hipError_t launch_roto_shift(const double* base, double* out, int R, int P, const int* i_ptr, hipStream_t st) {
   const int64_t n = (int64_t)R * 3 * P;
-  hipLaunchKernelGGL(roto_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, base, out, R, P, i);
+  hipLaunchKernelGGL(roto_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, base, out, R, P, i_ptr);
   return hipGetLastError();
 }
-hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int i, int n_terms,
+hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int* i_ptr, int n_terms,
                               hipStream_t st) {
-  hipLaunchKernelGGL(roto_update_kernel, dim3((R + 255) / 256), dim3(256), 0, st, base, E, status, R, P, i, n_terms);
+  hipLaunchKernelGGL(roto_update_kernel, dim3((R + 255) / 256), dim3(256), 0, st, base, E, status, R, P, i_ptr, n_terms);
   return hipGetLastError();
 }
 hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, hipStream_t st) {

@@ -451,7 +451,11 @@ __device__ __forceinline__ void squaring_tail_d2(const double (&are)[2][2][2], c
     }
     const double inv = 1.0 / (y[0] + y[1]);
 #pragma unroll
-    for (int a = 0; a < 4; ++a) y[a] *= inv;
+    for (int a = 0; a < 4; ++a) {
+      y[a] *= inv;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) R[a][k] *= inv;   // keep R at O(1) for non-isometric tensors
+    }
   };
   // phase 1: `skip` squarings without tracking the iterate; the comparison chain then starts at z_skip
   while (m < skip && done + (1 << (m + 1)) <= max_iter) {
@@ -950,10 +954,10 @@ __global__ __launch_bounds__(256) void env_square_d4_kernel(SquareArgs p) {
         double dpart = 0.0;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const double y = R[reg] * inv;
-          const double d = y - xc[reg];
+          R[reg] *= inv;   // keeps R_m at O(1) for non-isometric tensors too (dominant eigenvalue != 1)
+          const double d = R[reg] - xc[reg];
           dpart = dfma(d, d, dpart);
-          xc[reg] = y;
+          xc[reg] = R[reg];
         }
         const double d2 = lane0(group4_sum(dpart));
         iters = p.done + (1 << m);
@@ -1011,7 +1015,7 @@ __global__ __launch_bounds__(256) void env_square_d4_kernel(SquareArgs p) {
       }
       const double d2 = group4_sum(dpart);
       zc = to_columns(y);
-      R = Rn;                      // R_{m+1}
+      R = Rn * inv;                // R_{m+1}, rescaled to O(1) (a scalar factor does not change the iterates)
       iters = p.done + (1 << m);
       if (d2 < tol2) {
         status = QMPS_ST_OK;

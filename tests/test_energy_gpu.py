@@ -174,3 +174,24 @@ def test_argument_errors(engine_factory):
     from qmps_amd import EnergyEngine
     with pytest.raises(QmpsError):
         EnergyEngine(3, 10)
+
+
+@pytest.mark.parametrize('D', [2, 4])
+def test_non_isometric_tensors_stay_finite(D, engine_factory):
+    """Tensors that are not left isometries (dominant transfer eigenvalue eta != 1): the environment is still the
+    dominant right eigen-matrix (what xmps TransferMatrix(A).eigs() returns), no overflow/underflow in the
+    squared matrices; both solvers agree."""
+    rng = np.random.default_rng(77 + D)
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, 300))
+    A = A * rng.uniform(0.6, 1.5, size=(300, 1, 1, 1)) + 0.05 * (rng.standard_normal(A.shape) + 1j * rng.standard_normal(A.shape))
+    eng = engine_factory(D)
+    select(eng, 'squaring0')
+    r1, it1, st1 = eng.env_batch(A, max_iter=100000)
+    select(eng, 'plain')
+    r2, it2, st2 = eng.env_batch(A, max_iter=100000)
+    ok = (st1 == 0) & (st2 == 0)
+    assert ok.mean() > 0.95 and np.isfinite(r1).all()
+    assert np.abs(r1 - r2)[ok].max() < 1e-10
+    for k in np.flatnonzero(ok)[:30]:
+        _, r_ref = O.env_dense_eig(A[k])
+        assert np.abs(r1[k] - r_ref).max() < 1e-10

@@ -899,8 +899,8 @@ __global__ __launch_bounds__(256) void env_square_d4_kernel(SquareArgs p) {
     auto square = [&]() {
       // R_{m+1} = R_m R_m: 4 x v_mfma_f64_16x16x4_f64 (k-slabs), single accumulator chain.
       // (Measured alternative: 16 x v_mfma_f64_4x4x4_4b_f64 - 16 cycles each vs ~100 for the 16x16x4
-      // form on gfx950, tools_scratch/mfma_probe.hip - needs 16 LDS fragment reads and 40 more VGPRs
-      // per round and came out 7 % slower end to end; its lane layout is in tools_scratch/mfma4_layout.hip.)
+      // form on gfx950, tools/scratch/mfma_probe.hip - needs 16 LDS fragment reads and 40 more VGPRs
+      // per round and came out 7 % slower end to end; its lane layout is in tools/scratch/mfma4_layout.hip.)
       // LDS image of R_m for the A-operand fragments (wave-private region; LDS is in-order per wave)
       __builtin_amdgcn_wave_barrier();
 #pragma unroll

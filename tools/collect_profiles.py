@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn a gpurun_out/prof_<tag>/ directory (written by tools_prof.sh on the GPU box) into the committed
+"""Turn a gpurun_out/prof_<tag>/ directory (written by tools/prof.sh on the GPU box) into the committed
 summaries under profiles/: <tag>_kernel_stats.csv, <tag>_pmc.json and the traffic.json table bench.py reads."""
 import collections
 import csv
@@ -9,7 +9,7 @@ import os
 import shutil
 import sys
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, D, B, solver, handoff = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
 src = os.path.join(ROOT, 'gpurun_out', f'prof_{tag}')
 stats = glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True)[0]
@@ -23,7 +23,7 @@ for f in glob.glob(os.path.join(src, 'pmc_*', '**', '*counter_collection.csv'), 
         if 'qmps' in k:
             pmc.setdefault(k, {}).update({c: sum(v) / len(v) for c, v in d.items()})
 pmc['_notes'] = {'cmd': f'bench.py --steps 5 --warmup 1 --D {D} --batch {B} --solver {solver} --handoff {handoff} under '
-                        'rocprofv3 --pmc (separate passes per counter group, tools_prof.sh)',
+                        'rocprofv3 --pmc (separate passes per counter group, tools/prof.sh)',
                  'units': 'means per dispatch; FETCH_SIZE / WRITE_SIZE in KB; gfx950 FETCH_SIZE counts 1/2 of wide '
                           'coalesced reads -> x2 (MI355X_MICROARCH.md, HBM section)'}
 json.dump(pmc, open(os.path.join(ROOT, 'profiles', f'{tag}_pmc.json'), 'w'), indent=1)

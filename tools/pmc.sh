@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> "<counters>" [bench args...]
+# usage: tools/pmc.sh <tag> "<counters>" [bench args...]
 tag=$1; shift; ctr=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag> [bench args...]   -- run on the GPU box via gpurun
+# usage: tools/prof.sh <tag> [bench args...]   -- run on the GPU box via gpurun
 # rocprofv3 kernel-trace + stats, then separate PMC passes (never combined with trace domains other than kernel-trace)
 set -u
 tag=$1; shift

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_trace.sh <tag> [bench args...]  -- kernel-trace + stats only
+# usage: tools/trace.sh <tag> [bench args...]  -- kernel-trace + stats only
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

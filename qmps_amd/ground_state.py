@@ -21,8 +21,7 @@ from scipy.linalg import expm
 
 from . import _runtime
 from ._lib import STATUS_NOT_PD, STATUS_OK
-from .represent import (FullEnvironment, FullStateTensor, ShallowCNOTStateTensor, State, final_state,
-                        unitary)
+from .represent import FullStateTensor, ShallowCNOTStateTensor, final_state, unitary
 from .tools import Optimizer, get_env_exact
 
 π = np.pi
@@ -116,7 +115,8 @@ class Hamiltonian:
 
     def calculate_energy(self, ops, n_qubits, loc=0):
         """<psi| 1^loc x H x 1^rest |psi> for the state prepared by `ops` on |0..0>
-        (ground_state.py:110-118, with this package's circuit model instead of cirq)."""
+        (ground_state.py:110-118, with this package's circuit model instead of cirq).  API helper for
+        arbitrary user circuits (host numpy); no optimiser of the hot path calls it."""
         psi = final_state(ops, n_qubits)
         H = reduce(np.kron, [np.eye(2)] * loc + [self.to_matrix()] + [np.eye(2)] * (n_qubits - loc - 2))
         return float(np.real(psi.conj() @ H @ psi))
@@ -215,8 +215,8 @@ class SparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
 
 class NonSparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
     """Full SU(2D) parameterisation (ground_state.py:230-269).  `get_env_function` is kept for API
-    compatibility: when it is the default the environment is solved inside the energy kernel;
-    a user-supplied function U -> V is honoured through the state-vector path."""
+    compatibility: when it is the default the environment is solved inside the energy kernel; a
+    user-supplied function U -> V supplies the environment and the energy is still evaluated on the device."""
 
     def __init__(self, H, D=2, get_env_function=get_env_exact, initial_guess=None, settings=None):
         self.env_function = get_env_function
@@ -231,12 +231,17 @@ class NonSparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
     def objective_function(self, u_params):
         self.U = U = SU(u_params, 2 * self.D)
         if self.env_function is not get_env_exact:
-            V = self.env_function(U)
-            n = int(2 + 2 * np.log2(self.D))
-            ops = State(FullStateTensor(U), FullEnvironment(V), 2)(*range(n))
-            psi = final_state(ops, n)
-            H = np.kron(np.kron(np.eye(self.D), _as_h(self.H)), np.eye(self.D))
-            return float(np.real(psi.conj() @ H @ psi))
+            # injected environment (ground_state.py:238,254): V = env_function(U) is the caller's business; its
+            # first column is vec(L)/||L|| (tools.py:97-108), so r = L L^+ goes to the device as the resident
+            # environment and the energy is evaluated there (energy-only kernel) - no host-side simulation
+            V = np.asarray(self.env_function(U))
+            Lm = V[:, 0].reshape(self.D, self.D)
+            eng = _runtime.engine(self.D, 1)
+            eng.set_unitaries(U[None])
+            eng.set_hamiltonian(_as_h(self.H))
+            eng.set_env_guess((Lm @ Lm.conj().T)[None])
+            eng.launch_energy_only(1)
+            return float(eng.results(1)[0][0, 0])
         E, _, st = self._energies_from_unitaries(U[None])
         if st[0] == STATUS_NOT_PD:
             raise np.linalg.LinAlgError('environment is not positive definite')  # uncaught in the reference too

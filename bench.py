@@ -25,6 +25,11 @@ import os
 import sys
 import time
 
+if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+    # N ranks share one host: keep each rank's BLAS/OpenMP pools small while it draws its synthetic inputs
+    for _v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ.setdefault(_v, '4')
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -149,6 +154,8 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist  # launcher plumbing only (gloo, CPU)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if os.path.isdir('/sys/class/net/lo'):
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')     # the container hostname may not resolve
         dist.init_process_group('gloo', rank=rank, world_size=world)
 
     from qmps_amd import EnergyEngine, _lib

@@ -1,23 +1,26 @@
 // qmps_kernels.hip - hand-written CDNA4 (gfx950) kernels for qmps's classical inner loop.
 //
 // Hot path (per evaluation; reference = fergusfinn/qmps, cited file:line):
-//   A[2][D][D]  --(power iteration on r -> sum_s A_s r A_s^+ ; replaces the xmps eigen-solve behind
+//   A[2][D][D]  --(dominant fixed point of r -> sum_s A_s r A_s^+ ; replaces the xmps eigen-solve behind
 //                  get_env_exact, qmps/tools.py:176-182; `krylov`, Power Method.ipynb cells 5-6)-->  r
 //   (A, r, h)   --(closed form of State + psi^+ (1 x h x 1) psi, qmps/represent.py:258-262,
 //                  qmps/ground_state.py:159-167)-->  E
 //
-// Mapping (fp64 complex arithmetic, VALU-bound at D <= 8, MFMA at D = 16):
-//   D = 2, 4 : ONE EVALUATION PER LANE.  The wave's 64 tensors are read from HBM as one
-//              contiguous, fully coalesced 64 x 32 D^2-byte slab (16 B per lane per
-//              instruction), transposed through a padded LDS tile, and from then on every
-//              operand of every v_fma_f64 is a VGPR of the lane that needs it: no cross-lane
-//              traffic, no LDS traffic, no barriers inside the power loop.  r is kept as a
-//              packed Hermitian matrix (upper triangle), so one power step costs 12 D^3 - 2 D^2
-//              FMAs instead of 16 D^3.
-//   D = 8,16 : one evaluation per workgroup of D x D threads, A / r / X tiles in LDS
-//              (first correct version; the tuned D = 16 path uses v_mfma_f64_16x16x4_f64).
+// Kernels (fp64 complex arithmetic throughout; DESIGN.md section 4 has the full table):
+//   energy_lane_kernel<D,SOLVE>   D = 2, 4: ONE EVALUATION PER LANE.  The wave's 64 tensors are read from HBM
+//                                 as one contiguous, fully coalesced slab (16 B per lane per load), transposed
+//                                 through a padded LDS tile; from then on every operand of every v_fma_f64 is
+//                                 a VGPR of the lane that needs it.  Plain power iteration (packed Hermitian r:
+//                                 12 D^3 - 2 D^2 FMAs per step), Cholesky test, two-site-RDM energy epilogue.
+//   env_square_d4_kernel          D = 4: power method by repeated squaring of the REAL 16 x 16 transfer matrix
+//                                 (Hermitian coordinates), one wave per item, v_mfma_f64_16x16x4_f64.
+//   energy_mfma_d16_kernel<SOLVE> D = 16: power iteration + Cholesky + energy on the matrix cores, one wave per
+//                                 evaluation, register-to-register complex 16 x 16 x 16 products.
+//   energy_block_kernel<D,SOLVE>  D = 8 (and the D = 16 fallback): one evaluation per workgroup, tiles in LDS.
+//   cell2 / ansatz / rotosolve / overlap / opt_env / bw_* kernels: the callers and neighbours of the path
+//                                 (SURVEY 8(a)-9, (a)-12, (f)-1 .. (f)-4).
 //
-// Power iteration (identical in oracle/qmps_oracle.c and oracle/qmps_oracle.py):
+// Plain power iteration (identical in oracle/qmps_oracle.c and oracle/qmps_oracle.py):
 //   r_0 = 1/D (or the caller's warm start);  r' = herm(sum_s A_s r A_s^+);  r' /= tr r';
 //   stop when ||r' - r||_F^2 < tol^2;  status 0 converged / 1 hit max_iter / 2 r not PD.
 #include <hip/hip_runtime.h>

@@ -125,6 +125,25 @@ def cpu_baseline(D, A, h, max_iter, tol, budget_s=12.0):
                                                      'structure, numpy/scipy)'}}
 
 
+def squaring_schedule_ops(steps, skip, period, max_steps, e0_start):
+    """(squarings, mat-vecs) env_square_d4_kernel executes for an item that reports `steps` power steps after the
+    hand-off: replay of the kernel's schedule (include/qmps_hip.h QMPS_SKIP_ROUNDS_D4 / QMPS_MATVEC_PERIOD_D4)."""
+    m = 0
+    while m < skip and (2 << m) <= max_steps:
+        m += 1
+    nsq, nmv, count = m, 0, 0
+    it = (1 << m) if (e0_start and m > 0) else 0
+    while it < steps:
+        it += 1 << m
+        nmv += 1
+        count += 1
+        if it < steps and count == period and m < 29 and it + (2 << m) <= max_steps:
+            nsq += 1
+            m += 1
+            count = 0
+    return nsq, nmv
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -171,10 +190,38 @@ def main():
     if args.handoff is not None:
         eng.set_solver(args.solver, handoff=args.handoff)
 
+    collective = 'none (N=1)'
+    rccl_ok = False
     if dist is not None:
-        ids = [EnergyEngine.comm_unique_id() if rank == 0 else None]
+        import torch
+        err = ''
+        try:
+            ids = [EnergyEngine.comm_unique_id() if rank == 0 else None]
+        except _lib.QmpsError as e:          # keep the ranks in step: everyone must reach the broadcast
+            ids, err = [None], str(e)
         dist.broadcast_object_list(ids, src=0)
-        eng.comm_init(ids[0], rank, world)
+        if ids[0] is not None:
+            try:
+                eng.comm_init(ids[0], rank, world)
+            except _lib.QmpsError as e:
+                err = str(e)
+        else:
+            err = err or 'rank 0 could not create an RCCL unique id'
+        flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+        rccl_ok = flag.item() == 0.0
+        if rccl_ok:
+            collective = 'one RCCL all-reduce(sum, f64[1]) per step'
+        else:
+            # reported, never silent: the data path is unchanged (no collective in it); only the summed cost
+            # travels over the launcher's gloo group, once, after the timed region
+            try:
+                eng.comm_destroy()
+            except _lib.QmpsError:
+                pass
+            collective = f'RCCL communicator unavailable on {int(flag.item())} rank(s) ({err or "see other ranks"}); ' \
+                         'summed cost reduced over gloo after the timed region'
+            print(f'bench.py[rank {rank}]: {collective}', file=sys.stderr, flush=True)
 
     def step():
         eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver)
@@ -203,6 +250,10 @@ def main():
         elapsed = float(t.item())
 
     cost = eng.get_cost()
+    if dist is not None and not rccl_ok:
+        t = torch.tensor([float(cost[0])], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        cost = np.array([t.item()])
     E, iters, status = eng.results()
     # PCIe-inclusive rate (never `value`): host tensors in, energies out through the one-shot entry point
     pcie_rate = None
@@ -232,18 +283,36 @@ def main():
         hybrid = args.solver == 'squaring' and D <= 4
         handoff = eng.handoff if hybrid else 0
         n2 = (D * D) ** 3
-        if hybrid:
-            # executed algorithm: min(K, handoff) plain steps, then m = log2(K - handoff)
-            # squarings of the REAL D^2 x D^2 transfer matrix (2 (D^2)^3 flops each) + its construction
+        if hybrid and D == 4:
+            # executed algorithm: min(K, handoff) plain steps in the lane kernel, then in
+            # env_square_d4_kernel: construction of the real 16 x 16 transfer matrix (32 D^4 flop), `skip` squarings
+            # (2 (D^2)^3 flop each), mat-vecs with T^(2^m) (2 (D^2)^2 flop each) and one more squaring after every
+            # `period` unconverged mat-vecs - the schedule is replayed from the iteration count read back per item
+            skip, period = eng.squaring_schedule
+            skip = skip if handoff == 0 else 0
+            sq_flops = np.zeros(len(iters))
+            for k in np.unique(iters):
+                if k <= handoff:
+                    continue
+                nsq, nmv = squaring_schedule_ops(int(k) - handoff, skip, period, args.max_iter - handoff, handoff == 0)
+                sq_flops[iters == k] = 32.0 * D ** 4 + nsq * 2.0 * n2 + nmv * 2.0 * (D * D) ** 2
+            k_plain = np.minimum(iters, handoff).astype(np.float64)
+            plain_flops = k_plain * (32 * D ** 3 + 4 * D ** 2)
+            epilogue_flops = 64 * D ** 3 + 128 * D ** 2
+            if handoff == 0:
+                flops = float(sq_flops.sum())           # env_square_d4_kernel only (energy is a separate pass)
+            else:
+                flops = float((plain_flops + sq_flops + epilogue_flops).sum())
+            flop_note = ('executed algorithm: per item 32 D^4 (real transfer matrix) + n_sq 2 (D^2)^3 (squarings on the matrix '
+                         'cores) + n_mv 2 (D^2)^2 (mat-vecs with T^(2^m)); n_sq, n_mv replayed from the iteration count read back per item')
+        elif hybrid:
+            # D = 2: in-lane squaring of the real 4 x 4 transfer matrix, m = log2(K - handoff) rounds
             k_plain = np.minimum(iters, handoff).astype(np.float64)
             m_sq = np.where(iters > handoff, np.log2(np.maximum(iters - handoff, 1)), 0.0)
             sq_flops = np.where(iters > handoff, m_sq * 2.0 * n2 + 32.0 * D ** 4, 0.0)
             plain_flops = k_plain * (32 * D ** 3 + 4 * D ** 2)
             epilogue_flops = 64 * D ** 3 + 128 * D ** 2
-            if D == 4 and handoff == 0:
-                flops = float(sq_flops.sum())           # env_square_d4_kernel only (energy is a separate pass)
-            else:
-                flops = float((plain_flops + sq_flops + epilogue_flops).sum())
+            flops = float((plain_flops + sq_flops + epilogue_flops).sum())
             flop_note = ('executed algorithm: m = log2(K) squarings of the real D^2 x D^2 transfer matrix per item '
                          '(2 (D^2)^3 flop each) + its construction; K read back per item')
         else:
@@ -264,7 +333,7 @@ def main():
                        'global_batch': world * B, 'tol': args.tol, 'max_iter': args.max_iter, 'seed': args.seed,
                        'mean_power_iterations': total_iters_all / (world * B),
                        'max_power_iterations_rank0': int(iters.max()), 'not_converged_or_not_pd': int(bad_all),
-                       'collective': 'none (N=1)' if dist is None else 'one RCCL all-reduce(sum, f64[1]) per step',
+                       'collective': collective,
                        'device': info['name'], 'arch': info['arch']},
             'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': tflops / FP64_PEAK_TFLOPS, 'traffic': traffic,
@@ -283,7 +352,7 @@ def main():
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
 
-    if dist is not None:
+    if dist is not None and rccl_ok:
         eng.comm_destroy()
     eng.close()
     if dist is not None:

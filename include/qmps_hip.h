@@ -73,6 +73,10 @@ extern "C" {
  * convergence test compares T^(2^(skip+1)) r_0 with T^(2^skip) r_0. */
 #define QMPS_SKIP_ROUNDS_D2 3
 #define QMPS_SKIP_ROUNDS_D4 6
+/* D = 4: after the untracked squarings the power method continues with R_m = T^(2^m) itself
+ * (z <- R_m z / tr: one mat-vec = 2^m power steps; stop when ||z' - z||_F < tol), and R_m is squared once
+ * more after every QMPS_MATVEC_PERIOD_D4 unconverged mat-vecs.  iterations = power steps applied to r_0. */
+#define QMPS_MATVEC_PERIOD_D4 4
 
 typedef struct qmps_ctx qmps_ctx;
 
@@ -129,6 +133,9 @@ int qmps_energy_launch(qmps_ctx* ctx, int64_t B, int max_iter, double tol, int f
 /* number of plain power steps before the squaring tail of QMPS_ENV_POWER_SQUARING (0 disables it) */
 int qmps_set_handoff(qmps_ctx* ctx, int handoff);
 int qmps_get_handoff(qmps_ctx* ctx, int* handoff);
+/* the squaring schedule in force for this context (QMPS_SKIP_ROUNDS_D*, QMPS_MATVEC_PERIOD_D4 unless a tuning
+ * knob overrode them): untracked squarings, and D = 4 mat-vecs between further squarings (0 for D != 4) */
+int qmps_get_squaring_schedule(qmps_ctx* ctx, int* skip_rounds, int* matvec_period);
 /* solver used by qmps_energy_batch / qmps_env_batch (default QMPS_ENV_POWER_SQUARING) */
 int qmps_set_default_solver(qmps_ctx* ctx, int solver);
 /* Energy only, from the resident states and the resident environments (no solve): the

@@ -22,7 +22,7 @@ def lib():
         L = ctypes.CDLL(path)
         dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
         L.qmps_oracle_energy_batch.argtypes = [ctypes.c_int, ctypes.c_long, dp, dp, ctypes.c_int, dp, ctypes.c_int,
-                                               ctypes.c_double, dp, ip, ip, dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+                                               ctypes.c_double, dp, ip, ip, dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.qmps_oracle_energy_batch.restype = ctypes.c_int
         L.qmps_oracle_unitary_to_tensor.argtypes = [ctypes.c_int, ctypes.c_long, dp, dp]
         L.qmps_oracle_unitary_to_tensor.restype = ctypes.c_int
@@ -35,7 +35,7 @@ def _dp(a):
     return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
 
 
-def energy_batch(A, h, r0=None, max_iter=10000, tol=1e-13, threads=1, want_r=False, want_rho=False, handoff=None, skip=0):
+def energy_batch(A, h, r0=None, max_iter=10000, tol=1e-13, threads=1, want_r=False, want_rho=False, handoff=None, skip=0, period=0):
     """A (B,2,D,D) c128, h (nt,4,4) or (4,4) c128 -> dict(E (B,nt), iters, status, r?, rho?)."""
     A = np.ascontiguousarray(A, dtype=np.complex128)
     h = np.ascontiguousarray(np.asarray(h, dtype=np.complex128).reshape(-1, 4, 4))
@@ -52,7 +52,7 @@ def energy_batch(A, h, r0=None, max_iter=10000, tol=1e-13, threads=1, want_r=Fal
                                         _dp(None if r0c is None else r0c.view(np.float64)), int(max_iter), float(tol),
                                         _dp(E), it.ctypes.data_as(ip), st.ctypes.data_as(ip),
                                         _dp(None if r is None else r.view(np.float64)),
-                                        _dp(None if rho is None else rho.view(np.float64)), int(threads), -1 if handoff is None else int(handoff), int(skip))
+                                        _dp(None if rho is None else rho.view(np.float64)), int(threads), -1 if handoff is None else int(handoff), int(skip), int(period))
     if rc != 0:
         raise ValueError('qmps_oracle_energy_batch: bad arguments')
     return {'E': E, 'iters': it, 'status': st, 'r': r, 'rho': rho}

@@ -67,8 +67,12 @@ static void herm_normalise(int D, cplx* rn) {
 }
 
 /* Repeated-squaring tail (D <= 4): P_m = T^(2^m) as a D^2 x D^2 matrix, r_m = herm(P_m r_C)/tr,
- * stop when ||r_m - r_{m-1}||_F^2 < tol^2; returns the equivalent number of power steps. */
-static int squaring_tail(int D, const cplx* A, cplx* r, int done, int max_iter, double tol2, int skip, int* st) {
+ * stop when ||r_m - r_{m-1}||_F^2 < tol^2; returns the equivalent number of power steps.
+ * period > 0 (the D = 4 kernel): after the `skip` squarings the power method continues with P_m itself,
+ * r <- herm(P_m r)/tr (one product = 2^m power steps, same stopping rule), and P_m is squared once more
+ * after every `period` unconverged products; e0_start: r_C = |0><0|, the chain starts at herm(P_skip r_C)/tr. */
+static int squaring_tail(int D, const cplx* A, cplx* r, int done, int max_iter, double tol2, int skip, int period,
+                         int e0_start, int* st) {
   const int n = D * D;
   static _Thread_local cplx P[256 * 256], Q[256 * 256];
   cplx rC[256], rn[256];
@@ -90,6 +94,50 @@ static int squaring_tail(int D, const cplx* A, cplx* r, int done, int max_iter, 
       }
     memcpy(P, Q, sizeof(cplx) * n * n);
     ++m;
+  }
+  if (period > 0) {
+    if (m > 0 && e0_start) {
+      for (int a = 0; a < n; ++a) {
+        cplx acc = {0, 0};
+        for (int k = 0; k < n; ++k) acc = cadd(acc, cmul(P[a * n + k], rC[k]));
+        r[a] = acc;
+      }
+      herm_normalise(D, r);
+      it = done + (1 << m);
+    }
+    int count = 0;
+    while ((long)it + (1L << m) <= max_iter) {
+      for (int a = 0; a < n; ++a) {
+        cplx acc = {0, 0};
+        for (int k = 0; k < n; ++k) acc = cadd(acc, cmul(P[a * n + k], r[k]));
+        rn[a] = acc;
+      }
+      double lam = 0;
+      for (int i = 0; i < D; ++i) lam += rn[i * D + i].re;
+      herm_normalise(D, rn);
+      it += 1 << m;
+      double d2 = 0;
+      for (int e = 0; e < n; ++e) {
+        double dr = rn[e].re - r[e].re, di = rn[e].im - r[e].im;
+        d2 += dr * dr + di * di;
+      }
+      memcpy(r, rn, sizeof(cplx) * n);
+      if (d2 < tol2) { *st = 0; return it; }
+      if (++count == period && m < 29 && (long)it + (2L << m) <= max_iter) {
+        const double sc = 1.0 / (lam * lam);
+        for (int a = 0; a < n; ++a)
+          for (int b = 0; b < n; ++b) {
+            cplx acc = {0, 0};
+            for (int k = 0; k < n; ++k) acc = cadd(acc, cmul(P[a * n + k], P[k * n + b]));
+            Q[a * n + b].re = acc.re * sc; Q[a * n + b].im = acc.im * sc;
+          }
+        memcpy(P, Q, sizeof(cplx) * n * n);
+        ++m;
+        count = 0;
+      }
+    }
+    *st = 1;
+    return it;
   }
   if (m > 0) {
     for (int a = 0; a < n; ++a) {
@@ -129,7 +177,7 @@ static int squaring_tail(int D, const cplx* A, cplx* r, int done, int max_iter, 
 }
 
 static void eval_one(int D, const cplx* A, const cplx* h, int nt, const cplx* r0, int max_iter, double tol,
-                     int handoff, int skip, double* E, int* iters, int* status, cplx* r_out, cplx* rho_out) {
+                     int handoff, int skip, int period, double* E, int* iters, int* status, cplx* r_out, cplx* rho_out) {
   cplx r[DMAX * DMAX], rn[DMAX * DMAX], X[DMAX * DMAX], T[DMAX * DMAX];
   const int n = D * D;
   if (r0) { memcpy(r, r0, sizeof(cplx) * n); herm_normalise(D, r); }
@@ -161,7 +209,7 @@ static void eval_one(int D, const cplx* A, const cplx* h, int nt, const cplx* r0
     it = k;
     if (d2 < tol2) { st = 0; break; }
   }
-  if (st == 1 && handoff >= 0 && plain < max_iter) it = squaring_tail(D, A, r, plain, max_iter, tol2, skip, &st);
+  if (st == 1 && handoff >= 0 && plain < max_iter) it = squaring_tail(D, A, r, plain, max_iter, tol2, skip, period, handoff == 0 && !r0, &st);
   /* Cholesky positive-definiteness check (LAPACK zpotrf criterion: pivot <= 0 or NaN fails) */
   if (st == 0) {
     cplx L[DMAX * DMAX];
@@ -212,10 +260,11 @@ static void eval_one(int D, const cplx* A, const cplx* h, int nt, const cplx* r0
 /* Batched entry point.  A: [B][2][D][D] complex128 (numpy C order); h: [nt][4][4]; r0 nullable
  * [B][D][D]; E: [B][nt]; iters,status: [B]; r_out nullable [B][D][D]; rho_out nullable [B][4][4].
  * threads <= 0 -> 1.  handoff >= 0: plain power steps before the repeated-squaring tail (0 = squaring
- * from the start); handoff < 0: plain power iteration only.  Returns 0, or -1 on bad arguments. */
+ * from the start); handoff < 0: plain power iteration only; skip, period: see squaring_tail.
+ * Returns 0, or -1 on bad arguments. */
 int qmps_oracle_energy_batch(int D, long B, const double* A, const double* h, int nt, const double* r0,
                              int max_iter, double tol, double* E, int* iters, int* status, double* r_out,
-                             double* rho_out, int threads, int handoff, int skip) {
+                             double* rho_out, int threads, int handoff, int skip, int period) {
   if (D < 1 || D > DMAX || B < 0 || nt < 1 || !A || !h || !E || !iters || !status) return -1;
   const long n = (long)D * D;
 #ifdef _OPENMP
@@ -224,7 +273,7 @@ int qmps_oracle_energy_batch(int D, long B, const double* A, const double* h, in
 #endif
   for (long b = 0; b < B; ++b)
     eval_one(D, (const cplx*)A + b * 2 * n, (const cplx*)h, nt, r0 ? (const cplx*)r0 + b * n : NULL, max_iter, tol,
-             handoff, skip, E + b * nt, iters + b, status + b, r_out ? (cplx*)r_out + b * n : NULL,
+             handoff, skip, period, E + b * nt, iters + b, status + b, r_out ? (cplx*)r_out + b * n : NULL,
              rho_out ? (cplx*)rho_out + b * 16 : NULL);
   (void)threads;
   return 0;

@@ -233,7 +233,7 @@ def env_dense_eig(A):
     return w[k], r
 
 
-def env_power_iteration(A, r0=None, tol=1e-13, max_iter=10000, handoff=None, skip=0):
+def env_power_iteration(A, r0=None, tol=1e-13, max_iter=10000, handoff=None, skip=0, period=0):
     """Normalised power iteration v <- Av/||Av|| (`krylov`, Power Method.ipynb cells 5-6; the
     classical statement of PowerCircuit represent.py:235-248) on the transfer map, trace
     normalised.  This is the algorithm the HIP kernel implements:
@@ -248,6 +248,10 @@ def env_power_iteration(A, r0=None, tol=1e-13, max_iter=10000, handoff=None, ski
     PowerCircuit are T^K; squaring reaches K = 2^m in m products) - r_m = herm(P_m r_C)/tr,
     stopping when ||r_m - r_{m-1}||_F^2 < tol^2 (r_0 := r_C); iterations = handoff + 2^m.
     skip > 0: the first `skip` squarings are not tracked; the comparison chain starts at r_skip.
+    period > 0 (the D = 4 kernel): after the `skip` squarings the power method continues with
+    P_m itself - r <- herm(P_m r)/tr, one product = 2^m power steps, stop when ||r' - r||_F^2 < tol^2 -
+    and P_m is squared once more after every `period` unconverged products; iterations = power steps
+    applied to r_C.  With the |0><0| start and skip > 0 the chain starts at r = herm(P_skip r_C)/tr.
 
     Returns (r, iterations, status) with status 0 = converged, 1 = not converged."""
     D = A.shape[1]
@@ -278,6 +282,29 @@ def env_power_iteration(A, r0=None, tol=1e-13, max_iter=10000, handoff=None, ski
     while m < skip and plain + 2 ** (m + 1) <= max_iter:
         P = P @ P
         m += 1
+    if period > 0:
+        if m > 0 and r0 is None and handoff == 0:
+            r = (P @ rC).reshape(D, D)
+            r = (r + r.conj().T) / 2
+            r = r / np.trace(r).real
+            it = plain + 2 ** m
+        count = 0
+        while it + 2 ** m <= max_iter:
+            rn = (P @ r.reshape(-1)).reshape(D, D)
+            rn = (rn + rn.conj().T) / 2
+            lam = np.trace(rn).real
+            rn = rn / lam
+            it += 2 ** m
+            d2 = float((np.abs(rn - r) ** 2).sum())
+            r = rn
+            if d2 < tol * tol:
+                return r, it, 0
+            count += 1
+            if count == period and m < 29 and it + 2 ** (m + 1) <= max_iter:
+                P = (P @ P) / lam ** 2
+                m += 1
+                count = 0
+        return r, it, 1
     if m > 0:
         r = (P @ rC).reshape(D, D)
         r = (r + r.conj().T) / 2
@@ -352,10 +379,10 @@ def energy_closed_form(A, h, r=None):
     return float(np.real(np.einsum('st,ts->', h, rho)))
 
 
-def energy_power(A, h, r0=None, tol=1e-13, max_iter=10000, handoff=None, skip=0):
+def energy_power(A, h, r0=None, tol=1e-13, max_iter=10000, handoff=None, skip=0, period=0):
     """Exactly what one GPU lane computes: power-iteration environment + closed form.
     Returns (E, iterations, status); status 2 if r is not positive definite."""
-    r, it, status = env_power_iteration(A, r0, tol, max_iter, handoff, skip)
+    r, it, status = env_power_iteration(A, r0, tol, max_iter, handoff, skip, period)
     E = energy_closed_form(A, h, r)
     if status == 0:
         try:

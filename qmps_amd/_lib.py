@@ -42,6 +42,7 @@ SIGNATURES = {
     'qmps_energy_launch': (c_int, [c_void_p, c_int64, c_int, c_double, c_int]),
     'qmps_set_handoff': (c_int, [c_void_p, c_int]),
     'qmps_get_handoff': (c_int, [c_void_p, POINTER(c_int)]),
+    'qmps_get_squaring_schedule': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     'qmps_set_default_solver': (c_int, [c_void_p, c_int]),
     'qmps_energy_only_launch': (c_int, [c_void_p, c_int64]),
     'qmps_sum_energies': (c_int, [c_void_p, c_int64, _dp]),

@@ -82,6 +82,7 @@ struct qmps_ctx {
   int handoff = 0;                  // plain power steps before the squaring tail (set in qmps_create)
   int default_solver = 1;           // solver of the one-shot entry points (QMPS_ENV_POWER_SQUARING)
   int skip_rounds = 0;              // untracked squarings when handoff == 0 (set in qmps_create)
+  int matvec_period = QMPS_MATVEC_PERIOD_D4;   // D = 4: mat-vecs with T^(2^m) between two further squarings
   // state
   int n_terms = 0;
   int64_t n_states = 0;
@@ -226,6 +227,7 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     c->handoff = 0;   // D = 2, 4: squaring from the start (fastest); D = 8, 16 have no squaring path
     c->skip_rounds = (D == 2) ? QMPS_SKIP_ROUNDS_D2 : QMPS_SKIP_ROUNDS_D4;
     if (const char* e = getenv("QMPS_SKIP_ROUNDS")) c->skip_rounds = atoi(e);   // tuning knob
+    if (const char* e = getenv("QMPS_MATVEC_PERIOD")) c->matvec_period = atoi(e);   // tuning knob
     return QMPS_OK;
   }();
   if (rc != QMPS_OK) {
@@ -487,6 +489,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     q.A = c->d_A; q.r_out = c->d_r; q.iters = c->d_iters; q.status = c->d_status;
     q.B = B; q.done = c->handoff; q.max_iter = max_iter; q.tol = tol;
     q.skip = c->handoff == 0 ? c->skip_rounds : 0;
+    q.period = c->matvec_period;
     qmps::LaneArgs e = make_args(c, B, 1, 1.0, false);
     e.check_pd = 1;
     if (c->handoff > 0) {
@@ -543,6 +546,13 @@ int qmps_set_default_solver(qmps_ctx* c, int solver) {
 int qmps_get_handoff(qmps_ctx* c, int* handoff) {
   if (!c || !handoff) return fail(QMPS_ERR_ARG, "null argument");
   *handoff = c->handoff;
+  return QMPS_OK;
+}
+
+int qmps_get_squaring_schedule(qmps_ctx* c, int* skip_rounds, int* matvec_period) {
+  if (!c || !skip_rounds || !matvec_period) return fail(QMPS_ERR_ARG, "null argument");
+  *skip_rounds = c->skip_rounds;
+  *matvec_period = c->D == 4 ? c->matvec_period : 0;
   return QMPS_OK;
 }
 

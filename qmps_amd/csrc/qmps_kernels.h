@@ -45,7 +45,8 @@ struct SquareArgs {
   const int32_t* work_idx;
   int64_t B;
   int done;                   // plain steps already taken
-  int skip;                   // squarings before the iterate is tracked (first comparison at round skip + 1)
+  int skip;                   // squarings before the iterate is tracked
+  int period;                 // mat-vecs with R_m between two further squarings (<= 0: never square again)
   int max_iter;
   double tol;
 };

@@ -65,6 +65,12 @@ __device__ __forceinline__ double group4_sum(double v) {
   b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
+// the same sum on the matrix pipe: one v_mfma_f64_4x4x4_4b with an all-ones A operand.  Lane 16 x + 4 q + z
+// holds B_q[k = x][j = z]; D_q[i][j] = sum_k B_q[k][j] lands in lane (x = i, q, z = j): every row group
+// receives the column sums (16 cycles instead of ~10 VALU instructions; summation order differs).
+__device__ __forceinline__ double group4_sum_mfma(double v) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, v, 0.0, 0, 0, 0);
+}
 // wave-uniform copy of lane 0's value
 __device__ __forceinline__ double lane0(double v) {
   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
@@ -811,32 +817,39 @@ __global__ __launch_bounds__(64) void cell2_lane_kernel(Cell2Args p) {
 // tile R.  R_m = R^(2^m) by squaring: 4 MFMAs per round.  The accumulator layout
 // (row = 4 reg + lane/16, col = lane%16) IS the B-operand layout of the next product; the A-operand
 // layout (row = lane%16, k = 4 kk + lane/16) comes from a padded LDS image.
-// x_m = R_m x_C / tr;  stop at ||x_m - x_{m-1}||^2 < tol^2;  iterations = done + 2^m.
+// After `skip` squarings the power method continues with R_m itself: z <- R_m z / tr (one mat-vec = 2^m
+// power steps, VALU), stop at ||z' - z||^2 < tol^2; every `period` unconverged mat-vecs R_m is squared
+// once more.  iterations = power steps applied to the start matrix (done + 2^skip + 2^m + ...).
 // Items: the worklist written by the lane kernel, or (work_idx == nullptr) all of 0 .. B-1.
 // ------------------------------------------------------------------------------------------
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void env_square_d4_kernel(SquareArgs p) {
+// Coordinates (kernel-local): a = 4 i + i' packs a Hermitian 4 x 4 matrix r into a real one -
+//   x[(i,i)] = r_ii,   x[(i,i')] = sqrt2 Re r_ii' (i < i'),   x[(i,i')] = sqrt2 Im r_i'i (i > i')
+// (orthonormal, so ||x - x'||_2 = ||r - r'||_F).  Lane (g, c) owns rows a = (reg, g), reg = 0..3, and column
+// b = (c / 4, c % 4): row index `reg` is static, so the tensor reads below need four LDS addresses.
+#ifndef QMPS_SQ_MINBLOCKS
+#define QMPS_SQ_MINBLOCKS 4
+#endif
+__global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(SquareArgs p) {
   constexpr int D = 4, N = 16, LD = 17;
   constexpr int WAVES = 4;
-  using HB = HermBasis<D>;
+  constexpr double RS2 = 0.70710678118654752, S2 = 1.4142135623730951;
   __shared__ double2 sA_all[WAVES][2 * N];
   __shared__ double sR_all[WAVES][N * LD + N];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int j = c >> 2, jp = c & 3;
   double2* sA = sA_all[wave];
   double* sR = sR_all[wave];
+  double* sZ = sR + N * LD;          // 16-double strip behind the padded image
   const int64_t n_items = p.work_idx != nullptr ? (int64_t)*p.work_count : p.B;
   const double tol2 = p.tol * p.tol;
-  // lane constants: which (kind, i, i') the four owned rows a = 4 reg + g and the owned column b = c
-  // stand for (hoisted out of the item loop; the tables are tiny loops over constexpr data)
-  int ka[4], ia[4], ipa[4];
+  // lane constants of the matrix build (see below)
+  const bool col_im = j > jp;
+  const double col_a = j == jp ? 1.0 : RS2, col_b = j < jp ? RS2 : 0.0;
+  double row_scale[4];
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    ka[reg] = HB::kind(4 * reg + g);
-    ia[reg] = HB::row(4 * reg + g);
-    ipa[reg] = HB::col(4 * reg + g);
-  }
-  const int kb = HB::kind(c), jb = HB::row(c), jpb = HB::col(c);
+  for (int reg = 0; reg < 4; ++reg) row_scale[reg] = reg == g ? 1.0 : (reg < g ? S2 : -S2);
   // every wave walks its own items (wave-private LDS regions, no workgroup barriers); the next item's
   // tensor is prefetched into a register while the current one is being squared
   const int64_t stride = (int64_t)gridDim.x * WAVES;
@@ -845,169 +858,136 @@ __global__ __launch_bounds__(256) void env_square_d4_kernel(SquareArgs p) {
   double2 a_next = make_double2(0.0, 0.0);
   if (w < n_items && lane < 2 * N) a_next = ((const double2*)p.A)[item_id(w) * (2 * N) + lane];
   for (; w < n_items; w += stride) {
-    const bool have = true;
     const int64_t b = item_id(w);
     __builtin_amdgcn_wave_barrier();
     if (lane < 2 * N) sA[lane] = a_next;
     __builtin_amdgcn_wave_barrier();
     if (w + stride < n_items && lane < 2 * N) a_next = ((const double2*)p.A)[item_id(w + stride) * (2 * N) + lane];
-    // x0[c]: packed coordinate c of the start matrix (r after `done` plain steps or a warm start)
-    double x0 = 0.0;
-    if (p.r_in != nullptr) {
-      const double2 u = ((const double2*)p.r_in)[b * N + jb * D + jpb], l = ((const double2*)p.r_in)[b * N + jpb * D + jb];
-      x0 = kb == 0 ? u.x : (kb == 1 ? 0.70710678118654752 * (u.x + l.x) : 0.70710678118654752 * (u.y - l.y));
-      // trace-normalise the start (a warm start may carry any positive trace)
-      const double t = row16_sum(kb == 0 ? x0 : 0.0);
-      x0 /= t;
-    }
-    // R in accumulator layout: lane holds R[a = 4 reg + g][b = c]
+    // R[a][b] = tr(H_a T(H_b)), T(X) = sum_s A_s X A_s^+, in accumulator layout: lane holds R[(reg, g)][(j, j')].
+    // G = T(H_b) is Hermitian; its entry [reg][g] folds the column combination into per-lane operands:
+    //   G[reg][g] = sum_s ( A_s[reg][j] P_s + A_s[reg][j'] Q_s ),  P_s = alpha conj(A_s[g][j']),  Q_s = beta conj(A_s[g][j])
+    //   j == j': (alpha, beta) = (1, 0);   j < j': (1, 1)/sqrt2;   j > j': (-i, i)/sqrt2
+    //   R = Re G (reg == g),  sqrt2 Re G (reg < g),  -sqrt2 Im G (reg > g: the sorted pair is (g, reg), G[g][reg] = conj)
     v4f64 R;
     {
-      // column operands: A_s[.][j], A_s[.][j'] rows are picked per output row below
+      double pr[2], pi[2], qr[2], qi[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const double2 a = sA[(s2 * D + g) * D + jp], e = sA[(s2 * D + g) * D + j];
+        // conj(a) * alpha: (a.x, -a.y) * col_a  or  (-a.y, -a.x)/sqrt2;   conj(e) * beta: (e.x, -e.y) * col_b  or  (e.y, e.x)/sqrt2
+        pr[s2] = col_im ? -RS2 * a.y : col_a * a.x;
+        pi[s2] = col_im ? -RS2 * a.x : -col_a * a.y;
+        qr[s2] = col_im ? RS2 * e.y : col_b * e.x;
+        qi[s2] = col_im ? RS2 * e.x : -col_b * e.y;
+      }
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int i = ia[reg], ip = ipa[reg];
-        double e1r = 0.0, e1i = 0.0, e2r = 0.0, e2i = 0.0;
+        double gr = 0.0, gi = 0.0;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const double2 x = sA[(s2 * D + i) * D + jb], y = sA[(s2 * D + ip) * D + jpb];
-          const double2 u = sA[(s2 * D + i) * D + jpb], v = sA[(s2 * D + ip) * D + jb];
-          e1r = dfma(x.x, y.x, e1r);
-          e1r = dfma(x.y, y.y, e1r);
-          e1i = dfma(x.y, y.x, e1i);
-          e1i = dfma(-x.x, y.y, e1i);
-          e2r = dfma(u.x, v.x, e2r);
-          e2r = dfma(u.y, v.y, e2r);
-          e2i = dfma(u.y, v.x, e2i);
-          e2i = dfma(-u.x, v.y, e2i);
+          const double2 x = sA[(s2 * D + reg) * D + j], u = sA[(s2 * D + reg) * D + jp];
+          gr = dfma(x.x, pr[s2], gr);
+          gr = dfma(-x.y, pi[s2], gr);
+          gr = dfma(u.x, qr[s2], gr);
+          gr = dfma(-u.y, qi[s2], gr);
+          gi = dfma(x.x, pi[s2], gi);
+          gi = dfma(x.y, pr[s2], gi);
+          gi = dfma(u.x, qi[s2], gi);
+          gi = dfma(u.y, qr[s2], gi);
         }
-        // M = T(H_b)[i][i']: diag b: e1; re b: (e1 + e2)/sqrt2; im b: i (e1 - e2)/sqrt2 (see real_transfer_entry)
-        const double mr = kb == 0 ? e1r : (kb == 1 ? e1r + e2r : e2i - e1i);
-        const double mi = kb == 0 ? e1i : (kb == 1 ? e1i + e2i : e1r - e2r);
-        double val = (ka[reg] == 2) ? mi : mr;
-        const bool sa = ka[reg] != 0, sb = kb != 0;
-        val *= (sa && !sb) ? 1.4142135623730951 : ((!sa && sb) ? 0.70710678118654752 : 1.0);
-        R[reg] = val;
+        R[reg] = (reg > g ? gi : gr) * row_scale[reg];
       }
     }
-    // Vectors live in two distributions:
-    //   row-distributed   (like an accumulator column): lane holds v[4 reg + g], reg = 0..3, all c alike
-    //   column-distributed: lane holds v[c]
-    // A mat-vec y = R v takes v column-distributed (per-lane products R[4 reg + g][c] v[c], DPP sum over
-    // the 16 lanes of the row group) and returns y row-distributed; the 16 values go through a 128-byte
-    // LDS strip to become column-distributed for the next round.
-    //   xc = the iterate the next one is compared with (x_0, then z_1, z_2, ...), row-distributed
-    //   zc = z_m = R_m x_0 = T^(2^m) x_0 (column-distributed), in step with the matrix: z_{m+1} = R_m z_m.
-    double* sZ = sR + N * LD;        // 16-double strip behind the padded image
+    // Vectors are kept ROW-DISTRIBUTED: lane (g, c) holds v[(reg, g)], reg = 0..3, alike for every c.
+    // The A-operand fragments of R_m (af[kk] = R_m[c][4 kk + g], read back from the padded LDS image)
+    // serve both the next squaring and the mat-vec y = R_m z:  per lane sum_kk af[kk] z[4 kk + g], summed
+    // over the four row groups g -> y[c] in every group; a 128-byte LDS strip turns that back into the
+    // row distribution (strip slot of coordinate a = 4 reg + g is 4 g + reg: one lane reads 4 neighbours)
+    // and hands every lane the four diagonal coordinates (the trace) without a cross-lane reduction.
+    const int spos = 4 * (c & 3) + (c >> 2);
+    double af[4];
+    auto fragments = [&]() {         // wave-private LDS region; LDS is in-order per wave
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) sR[(4 * reg + g) * LD + c] = R[reg];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) af[kk] = sR[c * LD + 4 * kk + g];
+    };
     auto square = [&]() {
       // R_{m+1} = R_m R_m: 4 x v_mfma_f64_16x16x4_f64 (k-slabs), single accumulator chain.
       // (Measured alternative: 16 x v_mfma_f64_4x4x4_4b_f64 - 16 cycles each vs ~100 for the 16x16x4
       // form on gfx950, tools/scratch/mfma_probe.hip - needs 16 LDS fragment reads and 40 more VGPRs
       // per round and came out 7 % slower end to end; its lane layout is in tools/scratch/mfma4_layout.hip.)
-      // LDS image of R_m for the A-operand fragments (wave-private region; LDS is in-order per wave)
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) sR[(4 * reg + g) * LD + c] = R[reg];
-      __builtin_amdgcn_wave_barrier();
-      const double a0 = sR[c * LD + 0 + g], a1 = sR[c * LD + 4 + g];
-      const double a2 = sR[c * LD + 8 + g], a3 = sR[c * LD + 12 + g];
       v4f64 acc = {0, 0, 0, 0};
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, R[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, R[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, R[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, R[3], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0], R[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1], R[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[2], R[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[3], R[3], acc, 0, 0, 0);
       return acc;
     };
-    auto to_columns = [&](const double (&y)[4]) {   // row-distributed -> column-distributed via LDS
+    auto fast_inv = [](double t) {   // v_rcp_f64 + one Newton step: relative error ~1e-16 (a scale factor only)
+      const double x = __builtin_amdgcn_rcp(t);
+      return dfma(dfma(-t, x, 1.0), x, x);
+    };
+    auto strip_trace = [&]() { return (sZ[0] + sZ[5]) + (sZ[10] + sZ[15]); };   // slots of (0,0) (1,1) (2,2) (3,3)
+    int m = 0, iters = p.done, status = QMPS_ST_NOT_CONVERGED;
+    // phase 1: `skip` squarings, matrix pipe only (no item converges in < 2^skip steps)
+    fragments();
+    while (m < p.skip && (int64_t)p.done + (2ll << m) <= p.max_iter) {
+      R = square();
+      ++m;
+      fragments();
+    }
+    // start vector z (trace 1): a warm start / the lane kernel's iterate, else r_0 = |0><0| = e_0, for which
+    // T^(2^m) e_0 is simply column 0 of R_m (held by the lanes c == 0)
+    double xc[4];
+    if (p.r_in != nullptr) {
+      double tsel = 0.0;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const double2 u = ((const double2*)p.r_in)[b * N + reg * D + g];   // r[reg][g]
+        const double2 l = ((const double2*)p.r_in)[b * N + g * D + reg];   // r[g][reg]
+        xc[reg] = reg == g ? u.x : (reg < g ? RS2 * (u.x + l.x) : RS2 * (l.y - u.y));
+        tsel = reg == g ? u.x : tsel;
+      }
+      const double inv0 = fast_inv(group4_sum_mfma(tsel));
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) xc[reg] *= inv0;
+    } else if (m == 0) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) xc[reg] = (4 * reg + g == 0) ? 1.0 : 0.0;
+    } else {
       __builtin_amdgcn_wave_barrier();
       if (c == 0) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) sZ[4 * reg + g] = y[reg];
+        for (int reg = 0; reg < 4; ++reg) sZ[4 * g + reg] = R[reg];
       }
       __builtin_amdgcn_wave_barrier();
-      return sZ[c];
-    };
-    int m = 0, iters = p.done, status = QMPS_ST_NOT_CONVERGED;
-    bool active = have;
-    // phase 1: `skip` squarings without tracking the iterate (no item converges in < 2^skip steps;
-    // the first comparison is then between z_{skip+1} and z_skip) - matrix pipe only
-    while (m < p.skip && p.done + (1 << (m + 1)) <= p.max_iter) {
-      R = square();
-      ++m;
-    }
-    double xc[4];
-    if (p.r_in == nullptr) {
-      // ---- default start r_0 = |0><0| (= coordinate vector e_0): z_m = R_m e_0 is COLUMN 0 of R_m,
-      // i.e. already row-distributed in the lanes c == 0 of each group - no mat-vec, no reduction.
-      // Every lane tracks its own column c (start H_c); the wave-level reductions read column 0.
-      if (m == 0) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) xc[reg] = (4 * reg + g == c) ? 1.0 : 0.0;   // e_c
-      } else {
-        const double inv0 = 1.0 / lane0(group4_sum(R[0]));
+      for (int reg = 0; reg < 4; ++reg) xc[reg] = sZ[4 * g + reg];
+      const double inv0 = fast_inv(strip_trace());
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) xc[reg] = R[reg] * inv0;
-        iters = p.done + (1 << m);
-      }
-      while (p.done + (1 << (m + 1)) <= p.max_iter && m < 29) {
-        if (!__any(active)) break;
-        R = square();
-        ++m;
-        const double inv = 1.0 / lane0(group4_sum(R[0]));
-        double dpart = 0.0;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          R[reg] *= inv;   // keeps R_m at O(1) for non-isometric tensors too (dominant eigenvalue != 1)
-          const double d = R[reg] - xc[reg];
-          dpart = dfma(d, d, dpart);
-          xc[reg] = R[reg];
-        }
-        const double d2 = lane0(group4_sum(dpart));
-        iters = p.done + (1 << m);
-        if (d2 < tol2) {
-          status = QMPS_ST_OK;
-          active = false;
-        }
-      }
-      // broadcast column 0 to the whole row group for the common epilogue
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) xc[reg] = __shfl(xc[reg], lane & 48, 64);
-    } else {
-    double zc;
-    if (m == 0) {
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) xc[reg] = __shfl(x0, (lane & 48) | (4 * reg + g), 64);
-      // z_0 = R_0 x_0 (one plain power step); compared-with iterate = x_0
-      double y[4];
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) y[reg] = row16_sum(R[reg] * x0);
-      zc = to_columns(y);
-    } else {
-      // start the comparison chain at z_m = R_m x_0 (= T^(2^m) x_0)
-      double y[4];
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) y[reg] = row16_sum(R[reg] * x0);
-      const double inv0 = 1.0 / group4_sum(y[0]);
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        y[reg] *= inv0;
-        xc[reg] = y[reg];
-      }
-      zc = to_columns(y);
+      for (int reg = 0; reg < 4; ++reg) xc[reg] *= inv0;
       iters = p.done + (1 << m);
     }
-    while (p.done + (1 << (m + 1)) <= p.max_iter && m < 29) {
-      if (!__any(active)) break;   // wave-uniform: one item per wave
-      // y = R_m z_m on the VALU while the matrix pipe squares R_m
+    // phase 2: power iteration with R_m = T^(2^m) (one mat-vec = 2^m steps; VALU + LDS strip), compared
+    // iterate to iterate; after every `period` unconverged mat-vecs the matrix is squared once more.
+    int count = 0;
+    while ((int64_t)iters + (1ll << m) <= p.max_iter) {
+      double part = af[0] * xc[0];
+      part = dfma(af[1], xc[1], part);
+      part = dfma(af[2], xc[2], part);
+      part = dfma(af[3], xc[3], part);
+      const double yc = group4_sum_mfma(part);          // y[c], alike in every row group
+      __builtin_amdgcn_wave_barrier();
+      if (g == 0) sZ[spos] = yc;
+      __builtin_amdgcn_wave_barrier();
       double y[4];
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) y[reg] = R[reg] * zc;
-      const v4f64 Rn = square();
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) y[reg] = row16_sum(y[reg]);   // z_{m+1}, row-distributed
-      ++m;
-      // trace = coordinates a = 0..3 = register 0 of the four row groups
-      const double inv = 1.0 / group4_sum(y[0]);
+      for (int reg = 0; reg < 4; ++reg) y[reg] = sZ[4 * g + reg];
+      const double inv = fast_inv(strip_trace());
+      iters += 1 << m;
       double dpart = 0.0;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
@@ -1016,47 +996,41 @@ __global__ __launch_bounds__(256) void env_square_d4_kernel(SquareArgs p) {
         dpart = dfma(d, d, dpart);
         xc[reg] = y[reg];
       }
-      const double d2 = group4_sum(dpart);
-      zc = to_columns(y);
-      R = Rn * inv;                // R_{m+1}, rescaled to O(1) (a scalar factor does not change the iterates)
-      iters = p.done + (1 << m);
+      const double d2 = lane0(group4_sum_mfma(dpart));  // wave-uniform: one item per wave
       if (d2 < tol2) {
         status = QMPS_ST_OK;
-        active = false;
+        break;
+      }
+      if (++count == p.period && m < 29 && (int64_t)iters + (2ll << m) <= p.max_iter) {
+        // 1/tr(R_m z) ~ 1/lambda(R_m): keeps R_{m+1} at O(1) for non-isometric tensors too
+        const v4f64 Rn = square();
+        R = Rn * (inv * inv);
+        ++m;
+        fragments();
+        count = 0;
       }
     }
+    // unpack x (lane (g, c = 0) holds coordinates (reg, g)) to the complex r[i][i'] and store
+    __builtin_amdgcn_wave_barrier();
+    if (c == 0) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) sZ[4 * reg + g] = xc[reg];
     }
-    double xp[4];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) xp[reg] = xc[reg];
-    // unpack x (lane (g, c = 0) holds coordinates 4 reg + g) to the complex r[i][j] and store
-    if (have) {
-      __builtin_amdgcn_wave_barrier();
-      if (c == 0) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) sR[4 * reg + g] = xp[reg];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < N) {
+      const int i = lane >> 2, ip = lane & 3;
+      const int lo = i < ip ? i : ip, hi = i < ip ? ip : i;
+      double re = sZ[4 * lo + hi], im = sZ[4 * hi + lo];
+      if (i == ip) im = 0.0;
+      else {
+        re *= RS2;
+        im *= i < ip ? RS2 : -RS2;
       }
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
-      if (lane < N) {
-        const int i = lane >> 2, j = lane & 3;
-        double re, im;
-        if (i == j) { re = sR[i]; im = 0.0; }
-        else {
-          const int lo = i < j ? i : j, hi = i < j ? j : i;
-          int pidx = 0;
-          for (int q = 0; q < lo; ++q) pidx += D - 1 - q;
-          pidx += hi - lo - 1;
-          re = 0.70710678118654752 * sR[D + pidx];
-          im = 0.70710678118654752 * sR[D + HB::P + pidx];
-          if (i > j) im = -im;
-        }
-        ((double2*)p.r_out)[b * N + lane] = make_double2(re, im);
-      }
-      if (lane == 0) {
-        p.iters[b] = iters;
-        p.status[b] = status;
-      }
+      ((double2*)p.r_out)[b * N + lane] = make_double2(re, im);
+    }
+    if (lane == 0) {
+      p.iters[b] = iters;
+      p.status[b] = status;
     }
   }
 }

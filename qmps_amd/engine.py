@@ -130,6 +130,13 @@ class EnergyEngine:
         L.check(self._lib.qmps_get_handoff(self._ctx, byref(v)))
         return v.value
 
+    @property
+    def squaring_schedule(self):
+        """(untracked squarings, D = 4 mat-vecs between further squarings) in force for this context."""
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        L.check(self._lib.qmps_get_squaring_schedule(self._ctx, byref(a), byref(b)))
+        return a.value, b.value
+
     def launch_energy_only(self, B=None):
         L.check(self._lib.qmps_energy_only_launch(self._ctx, self.B if B is None else B))
 

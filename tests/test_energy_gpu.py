@@ -15,6 +15,7 @@ E_TOL = 1e-10
 R_TOL = 1e-10
 HANDOFF = {2: 64, 4: 128}        # hand-off points exercised by the 'squaring' variant (library default: 0)
 SKIP0 = {2: 3, 4: 6}             # QMPS_SKIP_ROUNDS_D2/D4: untracked squarings when handoff == 0
+PERIOD = {2: 0, 4: 4}            # QMPS_MATVEC_PERIOD_D4: D = 4 continues with mat-vecs of T^(2^m), squaring every 4th
 
 
 SOLVERS = ['plain', 'squaring', 'squaring0']     # squaring0: hand-off after 0 plain steps = squaring from the start
@@ -53,7 +54,12 @@ def test_golden_vectors(D, solver, golden, engine_factory):
         assert eng.handoff == ho
         slow = golden[f'oracle_iters_D{D}'] > ho + 1
         assert np.all(it[slow] > ho) and np.all(np.abs(it - golden[f'oracle_iters_D{D}'])[~slow] <= 1)
-        assert np.all(np.log2(it[slow] - ho) % 1 == 0)          # handoff + 2^m
+        if PERIOD[D] == 0:
+            assert np.all(np.log2(it[slow] - ho) % 1 == 0)          # handoff + 2^m
+        else:
+            exp = np.array([O.env_power_iteration(a, handoff=ho, skip=SKIP0[D] if ho == 0 else 0, period=PERIOD[D])[1]
+                            for a in A])
+            assert (it == exp).mean() > 0.9 and np.all(np.abs(it - exp)[slow] <= np.minimum(it, exp)[slow] - ho)
     r = eng.environments()
     assert np.abs(r - golden[f'oracle_r_D{D}']).max() < R_TOL
     # same through the unitary input kind (device-side unitary_to_tensor)
@@ -72,12 +78,13 @@ def test_random_batches_vs_c_oracle(D, B, solver, c_oracle, engine_factory):
     eng = engine_factory(D)
     select(eng, solver)
     E, it, st = eng.energies(A, h, max_iter=4000)
-    ref = c_oracle.energy_batch(A, h, max_iter=4000, want_r=True, want_rho=True, handoff=oracle_handoff(D, solver), skip=SKIP0[D] if oracle_handoff(D, solver) == 0 else 0)
+    ref = c_oracle.energy_batch(A, h, max_iter=4000, want_r=True, want_rho=True, handoff=oracle_handoff(D, solver), skip=SKIP0[D] if oracle_handoff(D, solver) == 0 else 0,
+                                period=PERIOD.get(D, 0))
     ok = (st == 0) & (ref['status'] == 0)
     assert ok.mean() > 0.9
     assert np.array_equal(st == 1, ref['status'] == 1) or np.abs(it - ref['iters']).max() <= 1
     assert np.abs(E - ref['E'])[ok].max() < E_TOL
-    # plain steps: +-1 (FMA contraction flips a borderline convergence test); in the squaring tail such a
+    # plain steps: +-1 (FMA contraction flips a borderline convergence test); in the D = 2 squaring tail such a
     # flip doubles/halves 2^m; an item on the hand-off boundary may land on either side of it
     ho = oracle_handoff(D, solver)
     di = np.abs(it - ref['iters'])
@@ -87,6 +94,8 @@ def test_random_batches_vs_c_oracle(D, B, solver, c_oracle, engine_factory):
         with np.errstate(divide='ignore', invalid='ignore'):
             ratio = (it - ho) / (ref['iters'] - ho).astype(float)
         good |= (lo > ho) & ((ratio == 2) | (ratio == 0.5))
+        if PERIOD[D] > 0:      # a flipped test costs one more product with T^(2^m) (2^m <= steps taken so far)
+            good |= (lo > ho) & (di <= lo - ho)
         good |= (lo >= ho - 1) & (hi <= ho + 2)
     assert good[ok].all() and (di[ok] == 0).mean() > 0.95
     # the two solvers agree with each other far inside the tolerance
@@ -111,7 +120,7 @@ def test_warm_start_and_energy_only(D, c_oracle, engine_factory):
     r = eng.environments()
     # warm start from the converged environment: converges immediately, same energies
     E2, it2, st2 = eng.energies(A, h, r0=r)
-    assert np.all(st2 == 0) and it2.max() <= 2
+    assert np.all(st2 == 0) and it2.max() <= (8 if D == 4 else 2)   # D = 4: the fixed point of the squared matrix sits ~1e-14 off
     assert np.abs(E2 - E).max() < E_TOL
     # energy-only launch on the resident (A, r)
     eng.launch_energy_only()

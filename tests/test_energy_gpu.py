@@ -204,3 +204,43 @@ def test_non_isometric_tensors_stay_finite(D, engine_factory):
     for k in np.flatnonzero(ok)[:30]:
         _, r_ref = O.env_dense_eig(A[k])
         assert np.abs(r1[k] - r_ref).max() < 1e-10
+
+
+@pytest.mark.parametrize('max_iter', [1, 2, 5, 63, 64, 65, 130, 300])
+def test_d4_default_schedule_iteration_caps(max_iter, c_oracle, engine_factory):
+    """D = 4 library default (squaring from the start, then mat-vecs with T^(2^m)): iteration counts, status and
+    environments follow the oracle's restatement of the schedule for every cap on the number of power steps."""
+    rng = np.random.default_rng(4242)
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 8, 500))
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+    eng = engine_factory(4)
+    select(eng, 'squaring0')
+    assert eng.squaring_schedule == (SKIP0[4], PERIOD[4])
+    E, it, st = eng.energies(A, h, max_iter=max_iter)
+    ref = c_oracle.energy_batch(A, h, max_iter=max_iter, want_r=True, handoff=0, skip=SKIP0[4], period=PERIOD[4])
+    assert (it == ref['iters']).mean() > 0.97 and np.all(it <= max_iter)
+    same = it == ref['iters']
+    assert np.array_equal(st[same] == 1, ref['status'][same] == 1)
+    assert np.abs(eng.environments() - ref['r'])[same].max() < R_TOL
+    assert np.abs(E - ref['E'])[same].max() < E_TOL
+
+
+def test_d4_default_schedule_warm_start(c_oracle, engine_factory):
+    """Warm start through the D = 4 matrix kernel (handoff 0): start matrix of any positive trace, not Hermitian
+    to rounding; same fixed point, oracle-identical step counts."""
+    rng = np.random.default_rng(4243)
+    B = 300
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 8, B))
+    h = O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})
+    eng = engine_factory(4)
+    select(eng, 'squaring0')
+    E, it, st = eng.energies(A, h)
+    r = eng.environments()
+    G = rng.standard_normal((B, 4, 4)) + 1j * rng.standard_normal((B, 4, 4))
+    r0 = 2.5 * r + 0.05 * (G @ G.conj().transpose(0, 2, 1)) + 1e-9 * G          # PSD perturbation + non-Hermitian dust
+    E2, it2, st2 = eng.energies(A, h, r0=r0)
+    ref = c_oracle.energy_batch(A, h, r0=r0, want_r=True, handoff=0, skip=SKIP0[4], period=PERIOD[4])
+    assert np.all(st2 == 0) and np.all(ref['status'] == 0)
+    assert (it2 == ref['iters']).mean() > 0.97
+    assert np.abs(E2 - E).max() < E_TOL and np.abs(E2 - ref['E']).max() < E_TOL
+    assert np.abs(eng.environments() - ref['r']).max() < R_TOL

@@ -203,6 +203,25 @@ def test_c_oracle_equals_numpy_oracle(D, golden, c_oracle):
         assert abs(np.trace(rho) - 1) < 1e-12
 
 
+@pytest.mark.parametrize('handoff,skip,period', [(0, 6, 4), (0, 3, 0), (0, 0, 2), (16, 0, 4), (64, 0, 0)])
+def test_squaring_schedules_reach_the_dense_eig_environment(handoff, skip, period, golden, c_oracle):
+    """The repeated-squaring restatements (pure squaring; squarings then products with T^(2^m), squaring every
+    `period`-th) are the power method taken 2^m steps at a time: numpy twin == C twin step for step, same fixed point
+    as the dense eigen-solve, never fewer equivalent steps than the plain iteration needs."""
+    A, h = golden['ref_A_D4'], golden['ref_h_tfim']
+    out = c_oracle.energy_batch(A, h, want_r=True, handoff=handoff, skip=skip, period=period)
+    plain = golden['oracle_iters_D4']
+    assert np.all(out['status'] == 0)
+    assert np.abs(out['r'] - golden['oracle_r_D4']).max() < 1e-11
+    assert np.abs(out['E'][:, 0] - golden['oracle_E_closed_D4']).max() < 1e-11
+    assert np.all(out['iters'] >= np.minimum(plain, handoff + 1) - 1)
+    for a, r, it in zip(A[:8], out['r'], out['iters']):
+        r2, it2, st2 = O.env_power_iteration(a, handoff=handoff, skip=skip, period=period)
+        assert it2 == it and st2 == 0 and np.abs(r2 - r).max() < 1e-13
+        _, r_eig = O.env_dense_eig(a)
+        assert np.abs(r - r_eig).max() < 1e-11
+
+
 def test_c_oracle_status_codes(c_oracle):
     h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
     rng = np.random.default_rng(3)

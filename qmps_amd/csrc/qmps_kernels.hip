@@ -845,8 +845,10 @@ __global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(S
   const int64_t n_items = p.work_idx != nullptr ? (int64_t)*p.work_count : p.B;
   const double tol2 = p.tol * p.tol;
   // lane constants of the matrix build (see below)
-  const bool col_im = j > jp;
-  const double col_a = j == jp ? 1.0 : RS2, col_b = j < jp ? RS2 : 0.0;
+  // P = (cpx a.x + cpy a.y,  cpy a.x - cpx a.y),  Q likewise with e:  diagonal column (1, 0 | 0, 0),
+  // real-part column (1, 0 | 1, 0)/sqrt2,  imaginary-part column (0, -1 | 0, 1)/sqrt2
+  const double cpx = j == jp ? 1.0 : (j < jp ? RS2 : 0.0), cpy = j > jp ? -RS2 : 0.0;
+  const double cqx = j < jp ? RS2 : 0.0, cqy = j > jp ? RS2 : 0.0;
   double row_scale[4];
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) row_scale[reg] = reg == g ? 1.0 : (reg < g ? S2 : -S2);
@@ -875,10 +877,11 @@ __global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(S
       for (int s2 = 0; s2 < 2; ++s2) {
         const double2 a = sA[(s2 * D + g) * D + jp], e = sA[(s2 * D + g) * D + j];
         // conj(a) * alpha: (a.x, -a.y) * col_a  or  (-a.y, -a.x)/sqrt2;   conj(e) * beta: (e.x, -e.y) * col_b  or  (e.y, e.x)/sqrt2
-        pr[s2] = col_im ? -RS2 * a.y : col_a * a.x;
-        pi[s2] = col_im ? -RS2 * a.x : -col_a * a.y;
-        qr[s2] = col_im ? RS2 * e.y : col_b * e.x;
-        qi[s2] = col_im ? RS2 * e.x : -col_b * e.y;
+        // as lane-constant linear combinations (mul + fma each, no selects)
+        pr[s2] = dfma(cpx, a.x, cpy * a.y);
+        pi[s2] = dfma(cpy, a.x, -cpx * a.y);
+        qr[s2] = dfma(cqx, e.x, cqy * e.y);
+        qi[s2] = dfma(cqy, e.x, -cqx * e.y);
       }
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {

@@ -837,7 +837,8 @@ __global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(S
   constexpr double RS2 = 0.70710678118654752, S2 = 1.4142135623730951;
   __shared__ double2 sA_all[WAVES][2 * N];
   __shared__ double sR_all[WAVES][N * LD + N];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  // the wave index is wave-uniform: keep it (and every item id / address derived from it) in scalar registers
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int j = c >> 2, jp = c & 3;
   double2* sA = sA_all[wave];
   double* sR = sR_all[wave];
@@ -909,38 +910,54 @@ __global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(S
     // and hands every lane the four diagonal coordinates (the trace) without a cross-lane reduction.
     const int spos = 4 * (c & 3) + (c >> 2);
     double af[4];
-    auto fragments = [&]() {         // wave-private LDS region; LDS is in-order per wave
+    auto fragments_of = [&](const v4f64& M, double (&f)[4]) {   // wave-private LDS region; LDS is in-order per wave
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) sR[(4 * reg + g) * LD + c] = R[reg];
+      for (int reg = 0; reg < 4; ++reg) sR[(4 * reg + g) * LD + c] = M[reg];
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) af[kk] = sR[c * LD + 4 * kk + g];
+      for (int kk = 0; kk < 4; ++kk) f[kk] = sR[c * LD + 4 * kk + g];
     };
-    auto square = [&]() {
-      // R_{m+1} = R_m R_m: 4 x v_mfma_f64_16x16x4_f64 (k-slabs), single accumulator chain.
+    auto square_of = [&](const v4f64& M, const double (&f)[4]) {
+      // M M: 4 x v_mfma_f64_16x16x4_f64 (k-slabs), single accumulator chain.
       // (Measured alternative: 16 x v_mfma_f64_4x4x4_4b_f64 - 16 cycles each vs ~100 for the 16x16x4
       // form on gfx950, tools/scratch/mfma_probe.hip - needs 16 LDS fragment reads and 40 more VGPRs
       // per round and came out 7 % slower end to end; its lane layout is in tools/scratch/mfma4_layout.hip.)
       v4f64 acc = {0, 0, 0, 0};
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0], R[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1], R[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[2], R[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[3], R[3], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f[0], M[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f[1], M[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f[2], M[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f[3], M[3], acc, 0, 0, 0);
       return acc;
     };
+    auto fragments = [&]() { fragments_of(R, af); };
+    auto square = [&]() { return square_of(R, af); };
     auto fast_inv = [](double t) {   // v_rcp_f64 + one Newton step: relative error ~1e-16 (a scale factor only)
       const double x = __builtin_amdgcn_rcp(t);
       return dfma(dfma(-t, x, 1.0), x, x);
     };
     auto strip_trace = [&]() { return (sZ[0] + sZ[5]) + (sZ[10] + sZ[15]); };   // slots of (0,0) (1,1) (2,2) (3,3)
+    // step counts stay below 2^31 and strides below 2^30: 32-bit scalar arithmetic (no 64-bit VALU compares)
+    const unsigned cap = (unsigned)p.max_iter;
     int m = 0, iters = p.done, status = QMPS_ST_NOT_CONVERGED;
     // phase 1: `skip` squarings, matrix pipe only (no item converges in < 2^skip steps)
     fragments();
-    while (m < p.skip && (int64_t)p.done + (2ll << m) <= p.max_iter) {
-      R = square();
+    // two rounds per trip on two register sets: the accumulator of one round is the B operand of the next (no copies)
+    auto more = [&]() { return m < p.skip && m < 29 && (unsigned)p.done + (2u << m) <= cap; };
+    while (more()) {
+      const v4f64 R2 = square_of(R, af);
+      double af2[4];
       ++m;
-      fragments();
+      fragments_of(R2, af2);
+      if (!more()) {
+        R = R2;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) af[kk] = af2[kk];
+        break;
+      }
+      R = square_of(R2, af2);
+      ++m;
+      fragments_of(R, af);
     }
     // start vector z (trace 1): a warm start / the lane kernel's iterate, else r_0 = |0><0| = e_0, for which
     // T^(2^m) e_0 is simply column 0 of R_m (held by the lanes c == 0)
@@ -977,7 +994,7 @@ __global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(S
     // phase 2: power iteration with R_m = T^(2^m) (one mat-vec = 2^m steps; VALU + LDS strip), compared
     // iterate to iterate; after every `period` unconverged mat-vecs the matrix is squared once more.
     int count = 0;
-    while ((int64_t)iters + (1ll << m) <= p.max_iter) {
+    while ((unsigned)iters + (1u << m) <= cap) {
       double part = af[0] * xc[0];
       part = dfma(af[1], xc[1], part);
       part = dfma(af[2], xc[2], part);
@@ -1004,7 +1021,7 @@ __global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(S
         status = QMPS_ST_OK;
         break;
       }
-      if (++count == p.period && m < 29 && (int64_t)iters + (2ll << m) <= p.max_iter) {
+      if (++count == p.period && m < 29 && (unsigned)iters + (2u << m) <= cap) {
         // 1/tr(R_m z) ~ 1/lambda(R_m): keeps R_{m+1} at O(1) for non-isometric tensors too
         const v4f64 Rn = square();
         R = Rn * (inv * inv);

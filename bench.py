@@ -338,6 +338,10 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': tflops / FP64_PEAK_TFLOPS, 'traffic': traffic,
                          'kernel': kernel_name, 'kernel_ms': kernel_ms, 'step_ms_events': step_ms_events,
+                         # not a hardware rate: what a PLAIN power iteration of the same step counts would have to
+                         # sustain (SURVEY 8(d) formula with K = the equivalent power steps read back per item)
+                         'equivalent_plain_power_tflops': float(flops_per_eval(D, iters.astype(np.float64)).sum())
+                                                          / (kernel_ms * 1e-3) * 1e-12,
                          'note': 'FP64-bound (MI355X FP64 vector == FP64 matrix peak = 78.6 TFLOP/s spec; measured on '
                                  'this part: v_fma_f64 70.9, v_mfma_f64_16x16x4 47.7 TFLOP/s, profiles/r01_probe.json); '
                                  'FLOPs = ' + flop_note,

@@ -25,6 +25,9 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails otherwise); already exported on the
+# GPU boxes, set here too in case a launcher drops the environment
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 if int(os.environ.get('WORLD_SIZE', '1')) > 1:
     # N ranks share one host: keep each rank's BLAS/OpenMP pools small while it draws its synthetic inputs
     for _v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):

@@ -107,3 +107,84 @@ def test_batches_vs_oracle():
     # Represent.exact_env of a state with itself: both environments have eta = 1
     Mr_, Ml_ = NT.Represent().exact_env(U1[:10], U2[:10], dag(U1[:10]), dag(U2[:10]))
     assert Mr_.shape == (10, 2, 2) and Ml_.shape == (10, 2, 2)
+
+
+# ---- driver classes (callers of the contractions): new_tdvp/testTDVPStripped.py:236-330 ----------------
+X0 = np.array([[0, 1], [1, 0]], dtype=complex)
+Z0 = np.diag([1.0, -1.0]).astype(complex)
+I2 = np.eye(2, dtype=complex)
+
+
+def test_represent_known_answer():
+    """testTDVPStripped.py:242-251: U1 = X x X, U1' = U1^+, U2 = U2' = 1: the hand-rolled gradient descent on
+    ||eta M - RE(M)|| reaches the exact environment."""
+    RE1 = NT.Represent()
+    U1 = np.kron(X0, X0).reshape(2, 2, 2, 2)
+    U1_ = U1.reshape(4, 4).conj().T.reshape(2, 2, 2, 2)
+    U2 = np.kron(I2, I2).reshape(2, 2, 2, 2)
+    U2_ = np.kron(I2, I2).reshape(2, 2, 2, 2)
+    M_exact = RE1.exact_env(U1, U2, U1_, U2_)
+    res = RE1.optimize_by_hand([U1, U2, U1_, U2_])
+    assert np.allclose(M_exact, RE1.M(res.x[1:]))
+    # the Nelder-Mead variant finds a fixed point of the same map: eta M == RE(M)
+    res2 = RE1.optimize(U1, U2, U1_, U2_)
+    assert res2.fun < 1e-6
+    M = RE1.M(res2.x[1:])
+    assert np.allclose(res2.x[0] * M, NT.RightEnvironment().circuit(U1, U2, U1_, U2_, M), atol=1e-6)
+
+
+def test_represent_random_unitaries_fixed_point():
+    rng = np.random.default_rng(5)
+    from scipy.stats import unitary_group
+    U1 = unitary_group.rvs(4, random_state=rng)
+    U2 = unitary_group.rvs(4, random_state=rng)
+    R = NT.Represent()
+    res = R.optimize(U1, U2, U1.conj().T, U2.conj().T)
+    Mr, Ml = R.exact_env(U1, U2, U1.conj().T, U2.conj().T)
+    M = R.M(res.x[1:])
+    assert res.fun < 1e-5
+    # same ray as the exact environment (the variational M has unit Frobenius norm by construction at a = pi/4 only)
+    ov = abs(np.vdot(Mr, M)) / (np.linalg.norm(Mr) * np.linalg.norm(M))
+    assert ov > 1 - 1e-6
+
+
+def test_optimize_reaches_ground_state_of_IZ():
+    """testTDVPStripped.py:311-329: <1 x Z> can be driven to -1 from random parameters."""
+    O = np.kron(I2, Z0).reshape(2, 2, 2, 2)
+    rng = np.random.default_rng(11)
+    for _ in range(2):
+        OP = NT.Optimize()
+        res = OP.optimize(O, initial_params=rng.random(22))
+        assert np.allclose(res.fun, -1, atol=1e-4)
+        U1, U2 = OP.paramU(res.x)
+        assert np.allclose(OP.mcost_function(res.x), res.fun, atol=1e-10)
+        assert len(OP.energy_opt) > 10 and OP.energy_opt[-1] <= OP.energy_opt[0] + 1e-12
+    # population evaluation == one-by-one evaluation
+    P = rng.random((9, 22))
+    OP.O = O
+    assert np.allclose(OP.batch_cost_function(P), [OP.cost_function(p) for p in P], atol=1e-12)
+
+
+def test_evolve_identity_and_short_step():
+    """W = 1 at the state's own parameters: both environments are 1/sqrt2 (unit 2-norm eigenvectors, as
+    `exact_environment` returns them in the reference too), so the overlap is 1/2 * <psi|psi> and the cost -1/4 - the
+    reference's normalisation (with M = 1 the same circuit gives 1, testTDVPStripped.py:180-191).  A short-time
+    propagator is followed by the projection step (:331-375 without the plots)."""
+    from scipy.linalg import expm
+    rng = np.random.default_rng(21)
+    p = rng.random(22)
+    EV = NT.Evolve()
+    U1, U2 = EV.paramU(p)
+    EV.W, EV.U1, EV.U2 = np.eye(16), U1, U2
+    Mr, Ml = EV.RE.exact_env(U1, U2, U1.conj().T, U2.conj().T)
+    assert np.allclose(np.abs(Mr), np.eye(2) / np.sqrt(2), atol=1e-9)
+    assert abs(EV.exact_cost_function(p) + 0.25) < 1e-9
+    assert abs(EV.mcost_function(p) + 0.25) < 1e-9
+    assert abs(NT.ManifoldOverlap().circuit(U1, U2, U1.conj().T, U2.conj().T, np.eye(2), np.eye(2), np.eye(16)) - 1) < 1e-9
+    assert EV.exact_cost_function(rng.random(22)) > -0.25 + 1e-3
+    H = NT.tensor([X0, X0, X0, X0])
+    W = expm(-1j * H * 1e-3)
+    res = EV.time_evolve(2, W, init_params=p)
+    assert len(res) == 2 and all(-0.25 - 1e-6 < r.fun < -0.2499 for r in res)
+    OPT = NT.Optimizer()
+    assert isinstance(OPT.evolve, NT.Evolve) and isinstance(OPT.represent, NT.Represent) and isinstance(OPT.optimize, NT.Optimize)

@@ -6,7 +6,10 @@
   put_env_on_right_site    qmps/time_evolve_tools.py:59-70
   get_env_off_right_site   qmps/time_evolve_tools.py:72-74
 
-The overlap objective built on them (time evolution) is a "next" row.
+  gate, egate, get_overlap_exact   qmps/time_evolve_tools.py:76-92   (device: qmps_overlap_batch with W = 1)
+
+`get_overlap` (:94-131, the variational-environment search over a 6-qubit circuit) is not mirrored: variational
+environment circuits are out of scope; `get_overlap_exact` is the value it converges to.
 """
 import numpy as np
 from scipy.linalg import null_space
@@ -43,3 +46,47 @@ def put_env_on_right_site(q, ret_n=False):
 
 def get_env_off_right_site(A):
     return np.asarray(A).reshape(2, 2, 2, 2)[0, :, 0, :]
+
+
+# ---- overlap between two one-site iMPS (time_evolve_tools.py:76-92) ---------------------------------------
+def gate(v, symbol='U'):
+    """The state gate the time-evolution code parameterises (time_evolve_tools.py:76-79)."""
+    from .represent import ShallowFullStateTensor
+    return ShallowFullStateTensor(2, v, symbol)
+
+
+def egate(v, symbol='R'):
+    from .represent import StateGate
+    return StateGate(v, symbol)
+
+
+def overlap_of_tensors(A, B, want_r=False):
+    """|x|^2 with x the dominant eigenvalue of the mixed transfer map  r -> sum_s A_s r B_s^+  of two D = 2 tensors
+    (what xmps `Map(A, B).right_fixed_point()` returns, squared), and its unit-Frobenius right fixed point r.
+    Device path: the two-site map with W = 1 is that map applied twice - same fixed point, eigenvalue x^2 - so
+    `qmps_overlap_batch` answers directly.  A: (2,2,2) or (B,2,2,2); B: (2,2,2) or (B,2,2,2)."""
+    from . import _lib as L
+    from . import _runtime
+    A = np.asarray(A, dtype=complex)
+    Bt = np.asarray(B, dtype=complex)
+    single = Bt.ndim == 3
+    cand = Bt[None] if single else Bt
+    eng = _runtime.engine(2, len(cand))
+    eta, _, st, r = eng.overlaps(A, cand, np.eye(4), kind='tensor', want_r=True)
+    if np.any(st != L.STATUS_OK):
+        raise np.linalg.LinAlgError('mixed transfer map has no unique dominant eigenvalue')
+    x2 = np.abs(eta)
+    if single:
+        x2, r = float(x2[0]), r[0]
+    return (x2, r) if want_r else x2
+
+
+def get_overlap_exact(p1, p2, gate=gate, testing=True):
+    """Fidelity per site |x|^2 between the iMPS of gate(p1) and gate(p2) (time_evolve_tools.py:84-91); with
+    `testing` also the right fixed point (unit Frobenius norm; its phase is arbitrary, as in xmps)."""
+    from .represent import unitary
+    from .tools import unitary_to_tensor
+    A = unitary_to_tensor(unitary(gate(p1)))
+    B = unitary_to_tensor(unitary(gate(p2)))
+    x2, r = overlap_of_tensors(A, B, want_r=True)
+    return (x2, r) if testing else x2

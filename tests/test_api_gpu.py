@@ -261,6 +261,43 @@ def test_time_evolve_objective_api():
     assert NT.obj(hist[1], A, WW) < NT.obj(p0, A, WW) + 1e-12 and NT.obj(hist[1], A, WW) < -0.999
 
 
+def test_overlap_helpers_and_optimizer():
+    """get_overlap_exact (time_evolve_tools.py:84-91): |x|^2 of the one-site mixed transfer map and its right fixed
+    point, against a dense eigen-solve; one-site expectation values and the Loschmidt overlap used by the reference's
+    time-evolution loop (new_time_evolve.py:276-292); the OverlapOptimizer objective."""
+    from scipy.linalg import expm
+    from qmps_amd import new_time_evolve as NT
+    from qmps_amd import time_evolve_tools as TT
+    rng = np.random.default_rng(8)
+    p1, p2 = rng.standard_normal(15), rng.standard_normal(15)
+    x2, r = TT.get_overlap_exact(p1, p2)
+    A, B = NT.state_tensor(p1), NT.state_tensor(p2)
+    w, v = np.linalg.eig(O.transfer_matrix(A, B))
+    k = int(np.argmax(np.abs(w)))
+    assert abs(x2 - abs(w[k]) ** 2) < 1e-10 and 0 < x2 < 1
+    r_ref = v[:, k].reshape(2, 2)
+    assert abs(abs(np.vdot(r_ref, r)) / np.linalg.norm(r_ref) - 1) < 1e-9 and abs(np.linalg.norm(r) - 1) < 1e-12
+    assert abs(TT.get_overlap_exact(p1, p1, testing=False) - 1) < 1e-12
+    xb = TT.overlap_of_tensors(A, np.stack([A, B]))
+    assert np.allclose(xb, [1.0, x2], atol=1e-10)
+    # one-site expectation values == contraction with the exact environment
+    X, Z = np.array([[0, 1], [1, 0]], dtype=complex), np.diag([1.0, -1.0]).astype(complex)
+    ev = NT.one_site_expectations(A, [X, Z])
+    _, renv = O.env_dense_eig(A)
+    for val, Op in zip(ev, (X, Z)):
+        ref = sum(Op[s, t] * np.trace(A[t] @ renv @ A[s].conj().T) for s in range(2) for t in range(2)) / np.trace(renv)
+        assert abs(val - ref.real) < 1e-10
+    # OverlapOptimizer: -|eta| <= 0, exactly -1 for W = 1 at the state's own parameters
+    opt = NT.OverlapOptimizer(NT.gate(p1), np.eye(4))
+    assert abs(opt.objective_function(p1) + 1) < 1e-12
+    WW = expm(-0.05j * O.hamiltonian_matrix({'ZZ': -1, 'X': 1}))
+    opt = NT.OverlapOptimizer(NT.gate(p1), WW)
+    f = opt.batch_objective_function(np.stack([p1, p2]))
+    assert abs(f[1] + abs(O.overlap_eta(A, B, WW)[0])) < 1e-10 and f[0] < f[1] < 0
+    ps, evs, les = NT.run(p1, WW, np.linspace(0, 0.1, 3), options={'maxiter': 300, 'xatol': 1e-6, 'fatol': 1e-10})
+    assert ps.shape == (3, 15) and evs.shape == (2, 3) and les.shape == (2,) and abs(les[0] - 1) < 1e-10 and les[1] < 1
+
+
 # ---- a-12: variational-environment objective ------------------------------------------------------
 def test_opt_environment_objective(engine_factory):
     """ground_state.py:170-228 on the device == literal numpy restatement; the penalty is the squared

@@ -3,6 +3,9 @@ batched drivers that produce the kernel's batch axis.
 
   rotosolve          qmps/rotosolve.py:154-181   (3 samples per parameter: theta, theta +- pi/2)
   double_rotosolve   qmps/rotosolve.py:183-241   (6 distinct shifts per parameter)
+  gate, op_state, op_H, evo_Hs, swapper   qmps/rotosolve.py:15-62, 63-65, 106-110 (state functions of the
+                     variational-environment problem; `evo_state` references an undefined name in the reference and the
+                     `sinusoids` plots are figure tooling: not mirrored)
 
 `batched_rotosolve` / `batched_double_rotosolve` run R independent restarts in lock-step: for
 parameter i, all R x (3 | 6) shifted parameter vectors form ONE batch for
@@ -107,3 +110,49 @@ def device_rotosolve(optimizer, initial_parameters, N_iters=10):
     eng = _runtime.engine(optimizer.D, 3 * P.shape[0])
     eng.set_hamiltonian(_as_h(optimizer.H))
     return eng.rotosolve(kind, P, N_iters, max_iter=optimizer.max_iter, tol=optimizer.env_tol)
+
+
+# ---- state functions of the variational-environment problem (rotosolve.py:15-62, 109-113) -----------------
+# Host state vectors with the cirq-free circuit model of qmps_amd.represent, so that the reference's own driver call
+# `rotosolve(op_H(H), op_state, params)` runs unchanged.  The batched device path for the same four circuits is
+# `qmps_opt_env_objective` (EnergyEngine.opt_env_objective, SparseFullEnergyOptimizer(optimize_environment=True)).
+def gate(v, symbol='U'):
+    from .represent import ShallowFullStateTensor
+    return ShallowFullStateTensor(2, v, symbol)
+
+
+def op_state(params, which='energy'):
+    """|psi> of one of the four circuits (30 params = [U angles | V angles]): 'energy' (4 qubits: V, U, U),
+    'v_purity' (two copies of V + SWAP), 'u_purity' (two copies of U.V + two SWAPs), 'uv_purity' (5 qubits)."""
+    from .represent import SWAP, final_state, line_qubits
+    params = np.asarray(params, dtype=float)
+    assert len(params) == 30
+    p2, p1 = np.split(params, 2)
+    if which == 'energy':
+        q = line_qubits(4)
+        return final_state([gate(p1)(*q[2:]), gate(p2)(*q[1:3]), gate(p2)(*q[:2])], 4)
+    if which == 'v_purity':                       # 2 x 2 grid, row-major = qubits 0..3
+        q = line_qubits(4)
+        return final_state([gate(p1)(*q[0:2]), gate(p1)(*q[2:4]), SWAP(*q[0:2])], 4)
+    if which == 'u_purity':                       # 2 x 3 grid, row-major = qubits 0..5
+        q = line_qubits(6)
+        return final_state([gate(p1)(*q[1:3]), gate(p2)(*q[0:2]), gate(p1)(*q[4:6]), gate(p2)(*q[3:5]),
+                            SWAP(*q[0:2]), SWAP(*q[1:3])], 6)
+    if which == 'uv_purity':
+        q = line_qubits(5)
+        return final_state([gate(p1)(*q[3:]), gate(p2)(*q[2:4]), gate(p1)(*q[:2]), SWAP(*q[:2])], 5)
+    raise ValueError(which)
+
+
+def op_H(H):
+    """1 x H x 1 on the four qubits of the 'energy' circuit."""
+    return np.kron(np.kron(np.eye(2), np.asarray(H)), np.eye(2))
+
+
+def evo_Hs(D=2):
+    return np.diag(np.eye(2 ** 6)[0]), np.diag(np.eye(2 ** 4)[0])
+
+
+def swapper():
+    from .ground_state import swap
+    return -np.kron(np.kron(np.eye(2), swap()), np.eye(8))

@@ -212,3 +212,25 @@ def test_rotosolve_module_drivers():
     assert e3.shape == (1, 3) and np.allclose(e3[-1], -1)
     e4, p4 = RS.batched_double_rotosolve(batch_eps, np.array([[0.3, 0.1], [2.0, -1.0]]), N_iters=1)
     assert np.allclose(e4[-1], -1, atol=1e-8)
+
+
+def test_rotosolve_state_functions_match_the_oracle_circuits():
+    """rotosolve.py:15-62: the four state functions of the variational-environment problem, assembled from the
+    SWAP-test operators exactly like rotosolve.py:203-211, reproduce the oracle's restatement of
+    ground_state.py:170-228; `rotosolve(op_H(H), op_state, params)` runs as in the reference's driver."""
+    from oracle import qmps_oracle as O
+    from qmps_amd import rotosolve as RS
+    from qmps_amd.ground_state import swap
+    rng = np.random.default_rng(12)
+    p = rng.standard_normal(30)
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+    f, (energy, u_pur, v_pur, uv_pur) = O.opt_environment_objective(p, h)
+    e_state, v_state, u_state, uv_state = (RS.op_state(p, w) for w in ('energy', 'v_purity', 'u_purity', 'uv_purity'))
+    assert abs(np.real(e_state.conj() @ RS.op_H(h) @ e_state) - energy) < 1e-12
+    assert abs(np.real(v_state.conj() @ np.kron(np.eye(2), np.kron(swap(), np.eye(2))) @ v_state) - v_pur) < 1e-12
+    assert abs(np.real(u_state.conj() @ np.kron(np.eye(4), np.kron(swap(), np.eye(4))) @ u_state) - u_pur) < 1e-12
+    assert abs(np.real(uv_state.conj() @ np.kron(np.kron(np.eye(2), swap()), np.eye(4)) @ uv_state) - uv_pur) < 1e-12
+    es, hist = RS.rotosolve(RS.op_H(h), RS.op_state, p.copy(), N_iters=1)
+    assert len(es) == 1 and es[0] <= energy + 1e-9
+    a, b = RS.evo_Hs()
+    assert a.shape == (64, 64) and b.shape == (16, 16) and RS.swapper().shape == (64, 64)

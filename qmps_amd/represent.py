@@ -370,3 +370,42 @@ class ShallowEnvironment(Gate):
         n = self.n_qubits
         return [[x_pow(b)(q) for q in qubits] + [zz_pow(g)(qubits[i], qubits[i + 1]) for i in range(n - 1)]
                 for b, g in split_2s(self.βγs)]
+
+
+# ---------------------------------------------------------------------------------------------
+# environment consistency objective (represent.py:18-56, 88-114), D = 2, exact (state-vector) form
+# ---------------------------------------------------------------------------------------------
+def bloch_vector_of(state, qubit, n_qubits=None):
+    """(<X>, <Y>, <Z>) of one qubit of a state vector (role of cirq's `bloch_vector_of`; big-endian qubit order)."""
+    state = np.asarray(state, dtype=complex)
+    n = int(np.log2(state.size)) if n_qubits is None else n_qubits
+    psi = np.moveaxis(state.reshape((2,) * n), qubit, 0).reshape(2, -1)
+    rho = psi @ psi.conj().T
+    return np.array([2 * rho[1, 0].real, 2 * rho[1, 0].imag, (rho[0, 0] - rho[1, 1]).real])
+
+
+def full_tomography_env_objective_function(U, V):
+    """Norm of the difference of the Bloch vectors of qubit 0 in State(U, V)|000> and in V|00>
+    (represent.py:88-114): zero exactly when V carries the right environment of U.  U: FullStateTensor-like gate on
+    two qubits, V: environment gate on two qubits."""
+    lhs = final_state(State(U, V, 1)._decompose_(line_qubits(3)), 3)
+    rhs = final_state([V(*line_qubits(2))], 2)
+    return float(np.linalg.norm(bloch_vector_of(lhs, 0) - bloch_vector_of(rhs, 0)))
+
+
+def get_env(U, C0=None, sample=False, reps=100000):
+    """Variational environment (represent.py:18-56): Nelder-Mead over the 8 real numbers of a 2 x 2 matrix C,
+    minimising `full_tomography_env_objective_function(U, environment_to_unitary(C))`.  The sampled (shot-noise)
+    objective of the reference is out of scope; `sample=True` raises."""
+    from scipy.optimize import minimize
+    from .tools import environment_to_unitary, from_real_vector, to_real_vector
+    if sample:
+        raise NotImplementedError('sampled (shot-noise) objectives are out of scope')
+    if C0 is None:
+        C0 = np.random.randn(2, 2) + 1j * np.random.randn(2, 2)
+    state = FullStateTensor(np.asarray(U))
+
+    def f_obj(v):
+        return full_tomography_env_objective_function(state, FullEnvironment(environment_to_unitary(from_real_vector(v))))
+    res = minimize(f_obj, to_real_vector(np.asarray(C0).reshape(-1)), method='Nelder-Mead')
+    return environment_to_unitary(from_real_vector(res.x))

@@ -234,3 +234,25 @@ def test_rotosolve_state_functions_match_the_oracle_circuits():
     assert len(es) == 1 and es[0] <= energy + 1e-9
     a, b = RS.evo_Hs()
     assert a.shape == (64, 64) and b.shape == (16, 16) and RS.swapper().shape == (64, 64)
+
+
+def test_full_tomography_env_objective_and_get_env(golden):
+    """tests/test_represent.py:50-58 of the reference: the exact environment zeroes the Bloch-vector objective
+    (< 1e-6 there); a random environment does not; the Nelder-Mead `get_env` finds one that does."""
+    from oracle import qmps_oracle as O
+    from qmps_amd import represent as R
+    rng = np.random.default_rng(31)
+    for U in O.haar_unitaries(rng, 4, 3):
+        A = T.unitary_to_tensor(U)
+        _, r = O.env_dense_eig(A)
+        V = T.environment_to_unitary(np.linalg.cholesky(r))
+        assert R.full_tomography_env_objective_function(R.FullStateTensor(U), R.FullEnvironment(V)) < 1e-12
+        bad = T.environment_to_unitary(rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2)))
+        assert R.full_tomography_env_objective_function(R.FullStateTensor(U), R.FullEnvironment(bad)) > 1e-3
+    V2 = R.get_env(U, C0=rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2)))
+    assert np.allclose(V2.conj().T @ V2, np.eye(4))
+    assert R.full_tomography_env_objective_function(R.FullStateTensor(U), R.FullEnvironment(V2)) < 1e-4
+    # Bloch vector helper: |0> and |+>
+    assert np.allclose(R.bloch_vector_of(np.array([1, 0, 0, 0]), 0), [0, 0, 1])
+    plus0 = np.kron(np.array([1, 1]) / np.sqrt(2), np.array([1, 0]))
+    assert np.allclose(R.bloch_vector_of(plus0, 0), [1, 0, 0]) and np.allclose(R.bloch_vector_of(plus0, 1), [0, 0, 1])

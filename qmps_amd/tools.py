@@ -308,3 +308,16 @@ class Optimizer:
             print(f'Reason for termination is {self.optimized_result.message} ' +
                   f'\nObjective Function Value is {self.optimized_result.fun}')
         return self.optimized_result
+
+
+class GuessInitialFullParameterOptimizer(Optimizer):
+    """Find U4 parameters reproducing a given two-qubit unitary `u` (tools.py:287-305).  The reference's 4-qubit
+    circuit (two Bell pairs, u on one half, conj(U4(params)) on the other, un-Bell) has |0000>-amplitude
+    tr(U4(params)^+ u) / 4, so the objective 1 - |amplitude|^2 is evaluated in closed form."""
+
+    def objective_function(self, params):
+        from .ground_state import U4
+        from .represent import unitary
+        u = self.u if isinstance(self.u, np.ndarray) else unitary(self.u)
+        amp = np.trace(U4(params).conj().T @ u) / u.shape[0]
+        return float(1 - abs(amp) ** 2)

@@ -256,3 +256,19 @@ def test_full_tomography_env_objective_and_get_env(golden):
     assert np.allclose(R.bloch_vector_of(np.array([1, 0, 0, 0]), 0), [0, 0, 1])
     plus0 = np.kron(np.array([1, 1]) / np.sqrt(2), np.array([1, 0]))
     assert np.allclose(R.bloch_vector_of(plus0, 0), [1, 0, 0]) and np.allclose(R.bloch_vector_of(plus0, 1), [0, 0, 1])
+
+
+def test_guess_initial_full_parameter_optimizer():
+    """tools.py:287-305: 1 - |<Bell|(u x conj(U4(p)))|Bell>|^2 == 1 - |tr(U4(p)^+ u)|^2 / 16, checked against the
+    explicit 4-qubit circuit; zero at the generating parameters."""
+    from qmps_amd.represent import CNOT, H, MatrixGate, final_state, line_qubits
+    rng = np.random.default_rng(2)
+    p0, p1 = rng.standard_normal(15), rng.standard_normal(15)
+    u = G.U4(p0)
+    opt = T.GuessInitialFullParameterOptimizer(R.FullStateTensor(u), initial_guess=p1)
+    assert opt.objective_function(p0) < 1e-14
+    q = line_qubits(4)
+    ops = [H(q[0]), H(q[1]), CNOT(q[0], q[2]), CNOT(q[1], q[3]), MatrixGate(u)(q[0], q[1]),
+           MatrixGate(G.U4(p1).conj())(q[2], q[3]), CNOT(q[0], q[2]), CNOT(q[1], q[3]), H(q[0]), H(q[1])]
+    amp = final_state(ops, 4)[0]
+    assert abs(opt.objective_function(p1) - (1 - abs(amp) ** 2)) < 1e-12

@@ -360,6 +360,26 @@ int qmps_rotosolve(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     HIP_TRY(hipStreamSynchronize(c->stream));
     const bool saved_guess = c->have_guess;
     c->have_guess = false;
+    // D = 2 with the library's default solver: the whole run is ONE launch (restarts are independent, see
+    // rotosolve_fused_d2_kernel); afterwards one ordinary evaluation of the final parameters leaves the context's
+    // resident tensors / energies / statuses exactly as the step-by-step path does.
+    if (c->D == 2 && c->handoff == 0 && c->default_solver == QMPS_ENV_POWER_SQUARING && n_params <= 64 &&
+        getenv("QMPS_NO_FUSED_ROTO") == nullptr) {
+      qmps::RotoArgs ra;
+      memset(&ra, 0, sizeof(ra));
+      ra.base = d_base; ra.h = c->d_h; ra.hist = d_hist;
+      ra.R = (int)R; ra.P = n_params; ra.n_terms = c->n_terms; ra.n_sweeps = n_sweeps; ra.max_iter = max_iter;
+      ra.skip = c->skip_rounds; ra.tol = tol;
+      HIP_TRY(qmps::launch_rotosolve_fused_d2(kind, ra, c->stream));
+      HIP_TRY(qmps::launch_ansatz(c->D, kind, d_base, n_params, c->d_A, R, c->stream));
+      c->n_states = R;
+      if (int e = qmps_energy_launch(c, R, max_iter, tol, c->default_solver)) return e;
+      c->have_guess = saved_guess;
+      HIP_TRY(hipMemcpyAsync(params, d_base, (size_t)R * n_params * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(E_hist, d_hist, (size_t)R * n_sweeps * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      return QMPS_OK;
+    }
     // One parameter update = shift build -> ansatz -> environment + energy -> closed-form update.  The
     // parameter index lives in HBM and is advanced by the update kernel, so the sequence is captured ONCE
     // into a hipGraph and replayed n_params x n_sweeps times: the sweep is launch-bound at small R.

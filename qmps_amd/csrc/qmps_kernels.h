@@ -55,6 +55,16 @@ struct SquareArgs {
 hipError_t launch_energy_mfma(int D, const LaneArgs& a, bool solve, hipStream_t st);
 hipError_t launch_square_tail(int D, const SquareArgs& a, int grid, hipStream_t st);
 
+// Whole D = 2 rotosolve run in one launch (restarts are independent): base [R][P] in/out, hist [n_sweeps][R] out
+struct RotoArgs {
+  double* base;
+  const void* h;
+  double* hist;
+  int R, P, n_terms, n_sweeps, max_iter, skip;
+  double tol;
+};
+hipError_t launch_rotosolve_fused_d2(int kind, const RotoArgs& a, hipStream_t st);
+
 // Two-site unit cell (NonSparseFullTwoSiteEnergyOptimizer): state unitaries U1, U2 [B][2D][2D].
 struct Cell2Args {
   const void* U1;

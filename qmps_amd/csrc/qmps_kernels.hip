@@ -1723,6 +1723,49 @@ struct Reg {
   }
 };
 
+// The ansatz circuits on a register file of NQ qubits; `par(l)` returns angle l (HBM, LDS, shifted ... the caller's choice).
+template <int NQ, int KIND, class Par>
+__device__ __forceinline__ void ansatz_circuit(Reg<NQ>& r, Par par, int n_params) {
+  if (KIND == 0 || KIND == 3) {
+    const int per = (KIND == 0) ? 2 : 3;
+    for (int l = 0; l + per <= n_params; l += per) {
+      const double beta = par(l), gamma = par(l + 1);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) r.rz(q, beta);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) r.rx(q, gamma);
+      if (KIND == 3) {
+        const double omega = par(l + 2);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) r.rz(q, omega);
+      }
+      r.had(0);
+#pragma unroll
+      for (int q = NQ - 2; q >= 0; --q) r.cnot(q, q + 1);
+    }
+  } else if (KIND == 1) {
+    for (int l = 0; l + 2 <= n_params; l += 2) {
+      const double beta = par(l), gamma = par(l + 1);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) r.xpow(q, beta);
+#pragma unroll
+      for (int q = 0; q + 1 < NQ; ++q) r.zzpow(q, q + 1, gamma);
+    }
+  } else if (KIND == 2) {
+    if constexpr (NQ == 2) {
+      r.rz(0, par(0)); r.rx(0, par(1)); r.rz(0, par(2));
+      r.rz(1, par(3)); r.rx(1, par(4)); r.rz(1, par(5));
+      r.cnot(0, 1);
+      r.ry(0, par(6));
+      r.cnot(1, 0);
+      r.ry(0, par(7)); r.rz(1, par(8));
+      r.cnot(0, 1);
+      r.rz(0, par(9)); r.rx(0, par(10)); r.rz(0, par(11));
+      r.rz(1, par(12)); r.rx(1, par(13)); r.rz(1, par(14));
+    }
+  }
+}
+
 template <int D, int KIND>
 __global__ __launch_bounds__(64) void ansatz_tensor_kernel(const double* __restrict__ params, int n_params,
                                                            double2* __restrict__ A, int64_t B) {
@@ -1738,44 +1781,7 @@ __global__ __launch_bounds__(64) void ansatz_tensor_kernel(const double* __restr
     r.re[x] = (x == j) ? 1.0 : 0.0;
     r.im[x] = 0.0;
   }
-  if (KIND == 0 || KIND == 3) {
-    const int per = (KIND == 0) ? 2 : 3;
-    for (int l = 0; l + per <= n_params; l += per) {
-      const double beta = pp[l], gamma = pp[l + 1];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) r.rz(q, beta);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) r.rx(q, gamma);
-      if (KIND == 3) {
-        const double omega = pp[l + 2];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) r.rz(q, omega);
-      }
-      r.had(0);
-#pragma unroll
-      for (int q = NQ - 2; q >= 0; --q) r.cnot(q, q + 1);
-    }
-  } else if (KIND == 1) {
-    for (int l = 0; l + 2 <= n_params; l += 2) {
-      const double beta = pp[l], gamma = pp[l + 1];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) r.xpow(q, beta);
-#pragma unroll
-      for (int q = 0; q + 1 < NQ; ++q) r.zzpow(q, q + 1, gamma);
-    }
-  } else if (KIND == 2) {
-    if constexpr (NQ == 2) {
-      r.rz(0, pp[0]); r.rx(0, pp[1]); r.rz(0, pp[2]);
-      r.rz(1, pp[3]); r.rx(1, pp[4]); r.rz(1, pp[5]);
-      r.cnot(0, 1);
-      r.ry(0, pp[6]);
-      r.cnot(1, 0);
-      r.ry(0, pp[7]); r.rz(1, pp[8]);
-      r.cnot(0, 1);
-      r.rz(0, pp[9]); r.rx(0, pp[10]); r.rz(0, pp[11]);
-      r.rz(1, pp[12]); r.rx(1, pp[13]); r.rz(1, pp[14]);
-    }
-  }
+  ansatz_circuit<NQ, KIND>(r, [&](int l) { return pp[l]; }, n_params);
   // A[b][s][i][j] = amplitude[2 i + s]
   double2* out = A + b * (2 * D * D);
 #pragma unroll
@@ -1888,6 +1894,123 @@ hipError_t launch_roto_update(double* base, const double* E, const int32_t* stat
 }
 hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, hipStream_t st) {
   hipLaunchKernelGGL(roto_record_kernel, dim3((R + 255) / 256), dim3(256), 0, st, E, hist, R, n_terms);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 3c': the WHOLE rotosolve run of a D = 2 ansatz in one launch.  Restarts are independent, so the sequential loop
+// over parameters and sweeps needs no grid-wide step: a quad of lanes owns one restart (lanes 0..2 = the shifts
+// {0, +pi/2, -pi/2}, lane 3 idles along), builds its shifted state tensor in registers, solves the environment and the
+// energy exactly as energy_lane_kernel<2, true> does with the squaring solver from the start (same device functions, same
+// order: bit-identical energies), exchanges the three energies by DPP and applies the closed-form update to the restart's
+// parameter vector in LDS.  One launch replaces (4 kernels + graph replay) x n_params x n_sweeps.
+// ------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
+  constexpr int D = 2;
+  extern __shared__ double sP[];                 // [16 restarts][P]
+  const int lane = threadIdx.x, rl = lane >> 2, k = lane & 3;
+  const int r = blockIdx.x * 16 + rl;
+  const bool valid = r < p.R;
+  const int rr = valid ? r : p.R - 1;
+  const int P = p.P;
+  double* mine = sP + rl * P;
+  for (int l = k; l < P; l += 4) mine[l] = p.base[(int64_t)rr * P + l];
+  __builtin_amdgcn_wave_barrier();
+  const double tol2 = p.tol * p.tol;
+  const double shift = k == 1 ? 1.5707963267948966 : (k == 2 ? -1.5707963267948966 : 0.0);
+
+  // one evaluation at (params + delta e_i): summed energy over the Hamiltonian terms, status
+  auto evaluate = [&](int i, double delta, double& e_out, int& status_out) {
+    double are[2][D][D], aim[2][D][D];
+#pragma unroll
+    for (int col = 0; col < D; ++col) {
+      Reg<2> q;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        q.re[x] = (x == col) ? 1.0 : 0.0;
+        q.im[x] = 0.0;
+      }
+      ansatz_circuit<2, KIND>(q, [&](int l) { return mine[l] + (l == i ? delta : 0.0); }, P);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {           // A[s][i][j] = amplitude[2 i + s] of input |j>
+        are[x & 1][x >> 1][col] = q.re[x];
+        aim[x & 1][x >> 1][col] = q.im[x];
+      }
+    }
+    double rre[D][D], rim[D][D];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = a; b < D; ++b) {
+        rre[a][b] = (a == b && a == 0) ? 1.0 : 0.0;     // r_0 = |0><0|
+        rim[a][b] = 0.0;
+      }
+    int iters = 0, status = QMPS_ST_NOT_CONVERGED;
+    bool active = true;
+    squaring_tail_d2(are, aim, rre, rim, active, iters, status, 0, p.max_iter, tol2, p.skip);
+    if (status == QMPS_ST_OK && !is_positive_definite<D>(rre, rim)) status = QMPS_ST_NOT_PD;
+    double pre[4][4], pim[4][4];
+    two_site_rdm<D>(are, aim, are, aim, rre, rim, pre, pim);
+    const double inv = 1.0 / (rre[0][0] + rre[1][1]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int sg = t; sg < 4; ++sg) {
+        pre[t][sg] *= inv;
+        pim[t][sg] = (t == sg) ? 0.0 : pim[t][sg] * inv;
+      }
+    double e = 0.0;
+    for (int q = 0; q < p.n_terms; ++q) e += rdm_energy((const double2*)p.h + q * 16, pre, pim);
+    e_out = e;
+    status_out = status;
+  };
+  auto quad_bcast = [&](double v, int src) {      // value of lane `src` of the quad, in every lane of the quad
+    const int ctl = src * 0x55;                    // quad_perm [src, src, src, src]
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (src) {
+      case 0: lo = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xf, 0xf, true); break;
+      case 1: lo = __builtin_amdgcn_mov_dpp(lo, 0x55, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x55, 0xf, 0xf, true); break;
+      default: lo = __builtin_amdgcn_mov_dpp(lo, 0xAA, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xAA, 0xf, 0xf, true); break;
+    }
+    (void)ctl;
+    return __hiloint2double(hi, lo);
+  };
+  for (int sw = 0; sw < p.n_sweeps; ++sw) {
+    for (int i = 0; i < P; ++i) {
+      double e;
+      int st;
+      evaluate(i, shift, e, st);
+      const double e0 = quad_bcast(e, 0), ep = quad_bcast(e, 1), em = quad_bcast(e, 2);
+      const double okv = (st == QMPS_ST_OK || k == 3) ? 1.0 : 0.0;
+      const bool ok = quad_bcast(okv, 0) * quad_bcast(okv, 1) * quad_bcast(okv, 2) != 0.0;
+      __builtin_amdgcn_wave_barrier();
+      if (ok && k == 0) {      // (an evaluation without a valid environment leaves this restart's parameter untouched)
+        const double theta = -1.5707963267948966 - atan2(2.0 * e0 - ep - em, ep - em);
+        mine[i] = wrap_pi(mine[i] + wrap_pi(theta));
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    double e;
+    int st;
+    evaluate(-1, 0.0, e, st);                     // energy at the swept parameters (the reference records eps(params))
+    if (valid && k == 0) p.hist[(int64_t)sw * p.R + r] = e;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (valid)
+    for (int l = k; l < P; l += 4) p.base[(int64_t)r * P + l] = mine[l];
+}
+
+hipError_t launch_rotosolve_fused_d2(int kind, const RotoArgs& a, hipStream_t st) {
+  const dim3 grid((unsigned)((a.R + 15) / 16)), block(64);
+  const size_t lds = (size_t)16 * a.P * sizeof(double);
+  switch (kind) {
+    case 0: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<0>), grid, block, lds, st, a); break;
+    case 1: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<1>), grid, block, lds, st, a); break;
+    case 2: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<2>), grid, block, lds, st, a); break;
+    case 3: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<3>), grid, block, lds, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -191,6 +191,30 @@ def test_device_rotosolve_matches_host_driver(D, depth):
     assert np.nanmin(e_dev) >= E0
 
 
+@pytest.mark.parametrize('kind,P', [(0, 2), (0, 8), (1, 4), (2, 15), (3, 6)])
+def test_fused_d2_rotosolve_equals_step_by_step(kind, P, engine_factory, monkeypatch):
+    """D = 2: the one-launch rotosolve (a quad of lanes per restart, all sweeps inside the kernel) against the
+    step-by-step device path (shift / ansatz / solve / update launches): the same device functions in the same
+    order, so parameters and recorded energies agree to rounding; R not a multiple of 16, 3 Hamiltonian terms."""
+    rng = np.random.default_rng(100 + 7 * kind + P)
+    R = 37
+    P0 = rng.standard_normal((R, P))
+    h = np.stack([O.hamiltonian_matrix({'ZZ': -1, 'X': 1}), O.hamiltonian_matrix({'XX': 0.3, 'ZZ': 0.2}),
+                  O.hamiltonian_matrix({'YY': -0.4, 'X': 0.1})])
+    eng = engine_factory(2)
+    eng.set_hamiltonian(h)
+    hist_f, p_f = eng.rotosolve(kind, P0, 3)
+    E_f, _, st_f = eng.results(R)
+    monkeypatch.setenv('QMPS_NO_FUSED_ROTO', '1')
+    hist_s, p_s = eng.rotosolve(kind, P0, 3)
+    E_s, _, st_s = eng.results(R)
+    assert hist_f.shape == hist_s.shape == (3, R)
+    assert np.abs(hist_f - hist_s).max() < 1e-10 and np.abs(np.angle(np.exp(1j * (p_f - p_s)))).max() < 1e-9
+    assert np.array_equal(st_f, st_s) and np.abs(E_f - E_s).max() < 1e-10
+    # the last recorded energy is the energy of the returned parameters
+    assert np.abs(E_f.sum(1) - hist_f[-1]).max() < 1e-10
+
+
 def test_full_parameterisation_reaches_D2_gse():
     """scripts/bond_dimension.py:38-45 shape at D = 2: scipy Nelder-Mead over SU(4) on the GPU
     objective does at least as well as the reference's D = 2 number D2_gse (TenPy iDMRG, chi = 2) and

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/pmc_$tag
 mkdir -p $out
-rocprofv3 --pmc $ctr --output-format csv -d $out -- python3 $R/bench.py --no-cpu-baseline "$@" > $out/bench.log 2>&1
+rocprofv3 --pmc $ctr --output-format csv -d $out -- python3 $R/bench.py --no-cpu-baseline --no-extras "$@" > $out/bench.log 2>&1
 python3 - <<PY
 import csv,glob,collections
 for f in glob.glob('$out/**/*counter_collection.csv', recursive=True):

@@ -278,3 +278,33 @@ def test_overlap_circuit_identity():
     eta2, _ = O.overlap_eta(A, B, np.eye(4))
     assert abs(abs(eta2) - np.abs(w1).max() ** 2) < 1e-12
     assert abs(O.overlap_eta(A, A, np.eye(4))[0] - 1) < 1e-12
+
+
+def test_bench_schedule_replay_matches_the_oracle_schedule(golden, c_oracle):
+    """bench.py turns the per-item step counts it reads back into executed squarings / mat-vecs by replaying the
+    kernel's schedule; the replay must land exactly on the step counts the oracle's restatement of that schedule
+    produces, for every cap."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(os.path.dirname(os.path.dirname(__file__)), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    A, h = golden['ref_A_D4'], golden['ref_h_tfim']
+    for cap in (10000, 300, 130, 64, 5):
+        out = c_oracle.energy_batch(A, h, max_iter=cap, handoff=0, skip=6, period=4)
+        for k in np.unique(out['iters']):
+            nsq, nmv = bench.squaring_schedule_ops(int(k), 6, 4, cap, True)
+            # re-walk the schedule with those counts
+            m = 0
+            while m < 6 and (2 << m) <= cap:
+                m += 1
+            it, left, count, sq = (1 << m) if m > 0 else 0, nmv, 0, m
+            while left:
+                it += 1 << m
+                left -= 1
+                count += 1
+                if left and count == 4:
+                    m += 1
+                    sq += 1
+                    count = 0
+            assert it == k and sq == nsq, (cap, k, nsq, nmv)

@@ -77,6 +77,9 @@ extern "C" {
  * (z <- R_m z / tr: one mat-vec = 2^m power steps; stop when ||z' - z||_F < tol), and R_m is squared once
  * more after every QMPS_MATVEC_PERIOD_D4 unconverged mat-vecs.  iterations = power steps applied to r_0. */
 #define QMPS_MATVEC_PERIOD_D4 4
+/* Range: the untracked squarings are not rescaled, so T^(2^skip) must stay inside the double range - dominant transfer
+ * eigenvalue between ~1e-4 and ~6e4 (tensors within a factor ~250 of an isometry) at D = 4; state unitaries and
+ * ansatz-built tensors are exact isometries (eigenvalue 1).  Later squarings are rescaled by the measured eigenvalue. */
 
 typedef struct qmps_ctx qmps_ctx;
 

@@ -244,3 +244,20 @@ def test_d4_default_schedule_warm_start(c_oracle, engine_factory):
     assert (it2 == ref['iters']).mean() > 0.97
     assert np.abs(E2 - E).max() < E_TOL and np.abs(E2 - ref['E']).max() < E_TOL
     assert np.abs(eng.environments() - ref['r']).max() < R_TOL
+
+
+def test_d4_scaled_tensors_inside_the_documented_range(engine_factory):
+    """include/qmps_hip.h: tensors within a factor ~250 of an isometry keep T^(2^skip) inside the double range; the
+    environment (a ray) does not depend on the scale; the energy tr(B r B^+)/tr r with B = A A scales as scale^4."""
+    rng = np.random.default_rng(55)
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 8, 64))
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+    eng = engine_factory(4)
+    select(eng, 'squaring0')
+    E1, it1, st1 = eng.energies(A, h)
+    r1 = eng.environments()
+    for scale in (1e-2, 30.0, 200.0):
+        E2, it2, st2 = eng.energies(scale * A, h)
+        assert np.all(st2 == 0) and np.isfinite(E2).all()
+        assert np.abs(eng.environments() - r1).max() < 1e-10
+        assert np.abs(E2 / scale ** 4 - E1).max() < 1e-9

@@ -829,7 +829,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // (orthonormal, so ||x - x'||_2 = ||r - r'||_F).  Lane (g, c) owns rows a = (reg, g), reg = 0..3, and column
 // b = (c / 4, c % 4): row index `reg` is static, so the tensor reads below need four LDS addresses.
 #ifndef QMPS_SQ_MINBLOCKS
-#define QMPS_SQ_MINBLOCKS 4
+#define QMPS_SQ_MINBLOCKS 5
 #endif
 __global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(SquareArgs p) {
   constexpr int D = 4, N = 16, LD = 17;

@@ -835,12 +835,11 @@ __global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(S
   constexpr int D = 4, N = 16, LD = 17;
   constexpr int WAVES = 4;
   constexpr double RS2 = 0.70710678118654752, S2 = 1.4142135623730951;
-  __shared__ double2 sA_all[WAVES][2 * N];
+  __shared__ double2 sA_all[WAVES][2][2 * N];   // two tiles per wave: the next item's tensor lands while this one is solved
   __shared__ double sR_all[WAVES][N * LD + N];
   // the wave index is wave-uniform: keep it (and every item id / address derived from it) in scalar registers
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int j = c >> 2, jp = c & 3;
-  double2* sA = sA_all[wave];
   double* sR = sR_all[wave];
   double* sZ = sR + N * LD;          // 16-double strip behind the padded image
   const int64_t n_items = p.work_idx != nullptr ? (int64_t)*p.work_count : p.B;
@@ -853,19 +852,25 @@ __global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(S
   double row_scale[4];
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) row_scale[reg] = reg == g ? 1.0 : (reg < g ? S2 : -S2);
-  // every wave walks its own items (wave-private LDS regions, no workgroup barriers); the next item's
-  // tensor is prefetched into a register while the current one is being squared
+  // every wave walks its own items (wave-private LDS regions, no workgroup barriers); the next item's tensor is
+  // fetched straight into the other LDS tile (global_load_lds_dwordx4: 32 lanes x 16 B = the 512-byte tile, lane-linear,
+  // no VGPRs, no ds_write) while the current one is being solved
   const int64_t stride = (int64_t)gridDim.x * WAVES;
   int64_t w = (int64_t)blockIdx.x * WAVES + wave;
   auto item_id = [&](int64_t ww) { return p.work_idx != nullptr ? (int64_t)p.work_idx[ww] : ww; };
-  double2 a_next = make_double2(0.0, 0.0);
-  if (w < n_items && lane < 2 * N) a_next = ((const double2*)p.A)[item_id(w) * (2 * N) + lane];
-  for (; w < n_items; w += stride) {
+  auto fetch = [&](int64_t ww, int buf) {
+    if (lane < 2 * N)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const double2*)p.A + item_id(ww) * (2 * N) + lane),
+                                       (__attribute__((address_space(3))) void*)&sA_all[wave][buf][0], 16, 0, 0);
+  };
+  int buf = 0;
+  if (w < n_items) fetch(w, 0);
+  for (; w < n_items; w += stride, buf ^= 1) {
     const int64_t b = item_id(w);
+    const double2* sA = sA_all[wave][buf];
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this item's tile has landed
     __builtin_amdgcn_wave_barrier();
-    if (lane < 2 * N) sA[lane] = a_next;
-    __builtin_amdgcn_wave_barrier();
-    if (w + stride < n_items && lane < 2 * N) a_next = ((const double2*)p.A)[item_id(w + stride) * (2 * N) + lane];
+    if (w + stride < n_items) fetch(w + stride, buf ^ 1);
     // R[a][b] = tr(H_a T(H_b)), T(X) = sum_s A_s X A_s^+, in accumulator layout: lane holds R[(reg, g)][(j, j')].
     // G = T(H_b) is Hermitian; its entry [reg][g] folds the column combination into per-lane operands:
     //   G[reg][g] = sum_s ( A_s[reg][j] P_s + A_s[reg][j'] Q_s ),  P_s = alpha conj(A_s[g][j']),  Q_s = beta conj(A_s[g][j])

@@ -289,6 +289,22 @@ def main():
         ansatz_rate = 3 * B / (time.perf_counter() - t1)
         ansatz_iters = float(it_a.mean())
         eng.set_tensors(A)                      # leave the engine as the timed region left it
+    # the contraction chain alone (north star: A - Abar - h - A - Abar with the resident environment, HBM-bound):
+    # energy-only launches over the same batch; algorithmic bytes = tensor + environment in, energy out
+    contraction = None
+    if rank == 0 and not args.no_extras:
+        eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver)
+        for _ in range(3):
+            eng.launch_energy_only()
+        eng.sync()
+        eng.timer_begin()
+        for _ in range(30):
+            eng.launch_energy_only()
+        us = eng.timer_end() / 30 * 1e3
+        cbytes = 48 * D * D + 8
+        contraction = {'us_per_launch': us, 'evals_per_s': B / (us * 1e-6), 'bytes_per_eval': cbytes,
+                       'hbm_gbps': B * cbytes / (us * 1e-6) * 1e-9, 'hbm_frac': B * cbytes / (us * 1e-6) * 1e-9 / HBM_PEAK_GBPS,
+                       'what': 'qmps_energy_only_launch over the resident batch (no environment solve)'}
     total_iters = int(iters.sum())
     if dist is not None:
         import torch
@@ -374,6 +390,7 @@ def main():
                                  'frac': hbm_gbps / HBM_PEAK_GBPS, 'bytes_per_eval': bytes_per_eval(D)}},
             'summed_cost': float(cost[0]),
             'pcie_inclusive_evals_per_s': pcie_rate,
+            'contraction_only': contraction,
             'ansatz_params_inclusive': {'evals_per_s': ansatz_rate, 'mean_power_iterations': ansatz_iters,
                                         'what': 'ShallowCNOT parameters in host memory -> energies in host memory '
                                                 '(device-side circuit, environment, energy)'},

@@ -82,6 +82,8 @@ struct qmps_ctx {
   int handoff = 0;                  // plain power steps before the squaring tail (set in qmps_create)
   int default_solver = 1;           // solver of the one-shot entry points (QMPS_ENV_POWER_SQUARING)
   int skip_rounds = 0;              // untracked squarings when handoff == 0 (set in qmps_create)
+  bool no_pair = false;             // QMPS_NO_PAIR: D = 4 energy-only launches with one lane per evaluation (tuning knob)
+  bool pair_in_step = false;        // QMPS_PAIR_IN_STEP: two-lane energy pass inside qmps_energy_launch as well
   int matvec_period = QMPS_MATVEC_PERIOD_D4;   // D = 4: mat-vecs with T^(2^m) between two further squarings
   // state
   int n_terms = 0;
@@ -211,7 +213,7 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     HIP_TRY(hipMalloc(&c->d_h, (size_t)kMaxTerms * 256));
     HIP_TRY(hipMalloc((void**)&c->d_iters, (size_t)max_batch * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&c->d_status, (size_t)max_batch * sizeof(int32_t)));
-    c->partial_cap = (max_batch + 63) / 64 > kSumBlocks ? (max_batch + 63) / 64 : kSumBlocks;
+    c->partial_cap = (max_batch + 31) / 32 > kSumBlocks ? (max_batch + 31) / 32 : kSumBlocks;   // one partial per 32 (pair kernel) or 64 items
     HIP_TRY(hipMalloc((void**)&c->d_partial, (size_t)kMaxTerms * c->partial_cap * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->d_cost, kMaxTerms * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->d_cost_ring, qmps_ctx::kCostSlots * kMaxTerms * sizeof(double)));
@@ -228,6 +230,8 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     c->skip_rounds = (D == 2) ? QMPS_SKIP_ROUNDS_D2 : QMPS_SKIP_ROUNDS_D4;
     if (const char* e = getenv("QMPS_SKIP_ROUNDS")) c->skip_rounds = atoi(e);   // tuning knob
     if (const char* e = getenv("QMPS_MATVEC_PERIOD")) c->matvec_period = atoi(e);   // tuning knob
+    c->no_pair = getenv("QMPS_NO_PAIR") != nullptr;
+    c->pair_in_step = getenv("QMPS_PAIR_IN_STEP") != nullptr;
     return QMPS_OK;
   }();
   if (rc != QMPS_OK) {
@@ -542,7 +546,14 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     }
     HIP_TRY(qmps::launch_square_tail(c->D, q, grid, c->stream));
     if (c->handoff == 0) if (!c->capturing) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
-    HIP_TRY(qmps::launch_energy(c->D, e, false, c->stream));
+    // (inside a step the one-lane pass is kept: with the pair kernel the pass itself is 2 us shorter but the step
+    // measured 1.4 % LONGER - the environment kernel after it runs slower; QMPS_PAIR_IN_STEP switches it on)
+    if (e.idx_list == nullptr && !c->no_pair && c->pair_in_step) {
+      if (e.partial != nullptr) c->partials_n = (int)((B + 31) / 32);      // two lanes per evaluation: one partial per 32 items
+      HIP_TRY(qmps::launch_energy_pair_d4(e, c->stream));
+    } else {
+      HIP_TRY(qmps::launch_energy(c->D, e, false, c->stream));
+    }
   }
   if (!c->capturing) c->launches++;
   c->have_env = true;
@@ -586,6 +597,8 @@ int qmps_energy_only_launch(qmps_ctx* c, int64_t B) {
   c->partials_B = -1;
   if (c->D == 16 && !getenv("QMPS_D16_BLOCK"))
     HIP_TRY(qmps::launch_energy_mfma(c->D, a, false, c->stream));
+  else if (c->D == 4 && !c->no_pair)
+    HIP_TRY(qmps::launch_energy_pair_d4(a, c->stream));
   else
     HIP_TRY(qmps::launch_energy(c->D, a, false, c->stream));
   return QMPS_OK;

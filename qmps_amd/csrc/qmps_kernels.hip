@@ -716,6 +716,183 @@ __global__ __launch_bounds__(64) void energy_lane_kernel(LaneArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Kernel 1e: D = 4 energy pass, TWO lanes per evaluation.  The one-lane-per-evaluation pass needs 324 registers and a
+// 33 KB LDS slab per wave: one wave per SIMD, so a batch is processed in strictly serial generations (load, then
+// compute; 23 us per 65536 evaluations whatever the batch).  Here lane pair (2 e, 2 e + 1) shares evaluation e and
+// splits the two-site density matrix by t2 = lane & 1:
+//   X = A_t2 r;  for s2: R = X A_s2^+;  for t1: Z = A_t1 R;  rho[(t1 t2)][(s1 s2)] = sum_ik Z[i][k] conj(A_s1[i][k])
+// i.e. rows tau = t2, 2 + t2 of rho (all 16 entries, no Hermitian-triangle bookkeeping), then
+//   E_q = Re sum_{sigma,tau} h_q[sigma][tau] rho[tau][sigma]  =  own rows + the partner's (DPP quad swap).
+// The tensors stay in a padded 17 KB LDS slab (32 per wave) and are read as operands (ds_read_b128, the pair reads the
+// same address); X and R live in registers: 184 VGPR -> two waves per SIMD, whose load and compute phases overlap once
+// a batch spans more than one generation.  r is read from HBM, symmetrised and trace-normalised like the lane kernel;
+// optional Cholesky test (check_pd), rho_out, per-wave partial sums of E.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64, 2) void energy_pair_d4_kernel(LaneArgs p) {
+  constexpr int D = 4, ROW = 32 * D * D, PAD = ROW + 16, ITEMS = 32;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[ITEMS * PAD];
+  const int lane = threadIdx.x, e = lane >> 1, t2 = lane & 1;
+  const int64_t first = (int64_t)blockIdx.x * ITEMS;
+  const int64_t b = first + e;
+  const bool valid = b < p.B;
+  {
+    const unsigned char* slab = (const unsigned char*)p.A + first * ROW;
+    const int64_t slab_bytes = (p.B - first < ITEMS ? p.B - first : ITEMS) * (int64_t)ROW;
+#pragma unroll
+    for (int c = 0; c < ITEMS * ROW / 1024; ++c) {
+      const int off = c * 1024 + lane * 16;
+      double2 v = make_double2(0.0, 0.0);
+      if (off < slab_bytes) v = *(const double2*)(slab + off);
+      *(double2*)(lds + (off / ROW) * PAD + (off % ROW)) = v;
+    }
+  }
+  // environment: full Hermitian matrix, trace 1
+  double rre[D][D], rim[D][D];
+  {
+    const double2* g = (const double2*)p.r_in + (valid ? b : first) * (D * D);
+    double2 raw[D * D];
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) raw[i] = g[i];
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) tr += 0.5 * (raw[i * D + i].x + raw[i * D + i].x);
+    const double inv = 1.0 / tr;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) {
+        const double2 u = raw[i * D + j], l = raw[j * D + i];
+        rre[i][j] = rre[j][i] = 0.5 * (u.x + l.x) * inv;
+        rim[i][j] = (i == j) ? 0.0 : 0.5 * (u.y - l.y) * inv;
+        rim[j][i] = -rim[i][j];
+      }
+  }
+  int status = QMPS_ST_OK;
+  if (p.check_pd && valid) {
+    status = p.status[b];
+    if (status == QMPS_ST_OK && !is_positive_definite<D>(rre, rim)) status = QMPS_ST_NOT_PD;
+  }
+  __syncthreads();
+  const double2* row = (const double2*)(lds + e * PAD);     // A_s[i][j] = row[(s * D + i) * D + j]
+  // X = A_t2 r
+  double xre[D][D], xim[D][D];
+  {
+    const double2* a2 = row + t2 * (D * D);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double2 a[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) a[k] = a2[i * D + k];
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        double xr = 0.0, xi = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          xr = dfma(a[k].x, rre[k][j], xr);
+          xr = dfma(-a[k].y, rim[k][j], xr);
+          xi = dfma(a[k].x, rim[k][j], xi);
+          xi = dfma(a[k].y, rre[k][j], xi);
+        }
+        xre[i][j] = xr;
+        xim[i][j] = xi;
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);   // stage by stage: keeps the LDS operand reads of later stages from piling up in VGPRs
+  double pre[2][4], pim[2][4];      // rho[2 t1 + t2][sigma]
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    // R = X A_s2^+ :  R[i][j] = sum_k X[i][k] conj(A_s2[j][k])
+    double Rre[D][D], Rim[D][D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      double2 a[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) a[k] = row[(s2 * D + j) * D + k];
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        double cr = 0.0, ci = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          cr = dfma(xre[i][k], a[k].x, cr);
+          cr = dfma(xim[i][k], a[k].y, cr);
+          ci = dfma(xim[i][k], a[k].x, ci);
+          ci = dfma(-xre[i][k], a[k].y, ci);
+        }
+        Rre[i][j] = cr;
+        Rim[i][j] = ci;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t1 = 0; t1 < 2; ++t1) {
+      double acc_re[2] = {0.0, 0.0}, acc_im[2] = {0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        double2 a[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) a[j] = row[(t1 * D + i) * D + j];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          double zr = 0.0, zi = 0.0;
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            zr = dfma(a[j].x, Rre[j][k], zr);
+            zr = dfma(-a[j].y, Rim[j][k], zr);
+            zi = dfma(a[j].x, Rim[j][k], zi);
+            zi = dfma(a[j].y, Rre[j][k], zi);
+          }
+#pragma unroll
+          for (int s1 = 0; s1 < 2; ++s1) {
+            const double2 c1 = row[(s1 * D + i) * D + k];
+            acc_re[s1] = dfma(zr, c1.x, acc_re[s1]);
+            acc_re[s1] = dfma(zi, c1.y, acc_re[s1]);
+            acc_im[s1] = dfma(zi, c1.x, acc_im[s1]);
+            acc_im[s1] = dfma(-zr, c1.y, acc_im[s1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int s1 = 0; s1 < 2; ++s1) {
+        pre[t1][2 * s1 + s2] = acc_re[s1];
+        pim[t1][2 * s1 + s2] = acc_im[s1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // energies: own rows tau = 2 t1 + t2, partner's rows through a quad swap
+  for (int q = 0; q < p.n_terms; ++q) {
+    const double2* h = (const double2*)p.h + q * 16;
+    double en = 0.0;
+#pragma unroll
+    for (int t1 = 0; t1 < 2; ++t1)
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg) {
+        const double2 hv = h[sg * 4 + 2 * t1 + t2];
+        en = dfma(hv.x, pre[t1][sg], en);
+        en = dfma(-hv.y, pim[t1][sg], en);
+      }
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(en), 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(en), 0xB1, 0xf, 0xf, true);
+    const double tot = en + __hiloint2double(hi, lo);
+    if (valid && t2 == 0) p.E[b * p.n_terms + q] = tot;
+    if (p.partial != nullptr) {
+      const double s = wave_sum((valid && t2 == 0) ? tot : 0.0);
+      if (lane == 0) p.partial[(int64_t)q * gridDim.x + blockIdx.x] = s;
+    }
+  }
+  if (!valid) return;
+  if (p.check_pd && t2 == 0) p.status[b] = status;
+  if (p.rho_out != nullptr) {
+    double2* o = (double2*)p.rho_out + b * 16;
+#pragma unroll
+    for (int t1 = 0; t1 < 2; ++t1)
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg) o[(2 * t1 + t2) * 4 + sg] = make_double2(pre[t1][sg], (2 * t1 + t2 == sg) ? 0.0 : pim[t1][sg]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Kernel 1b: two-site unit cell (qmps/ground_state.py:291-331, NonSparseFullTwoSiteEnergyOptimizer),
 // one evaluation per lane.  Inputs are the two state UNITARIES U1, U2 [B][2D][2D]; the kernel applies
 // unitary_to_tensor on load.  r12 = fixed point of r -> T_A1(T_A2(r)) (transfer map of
@@ -2709,6 +2886,12 @@ hipError_t launch_energy(int D, const LaneArgs& a, bool solve, hipStream_t st) {
     case 16: return launch_block<16>(a, solve, st);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_energy_pair_d4(const LaneArgs& a, hipStream_t st) {
+  if (a.B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(energy_pair_d4_kernel, dim3((unsigned)((a.B + 31) / 32)), dim3(64), 0, st, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_cell2(int D, const Cell2Args& a, hipStream_t st) {

@@ -82,6 +82,9 @@ struct qmps_ctx {
   int handoff = 0;                  // plain power steps before the squaring tail (set in qmps_create)
   int default_solver = 1;           // solver of the one-shot entry points (QMPS_ENV_POWER_SQUARING)
   int skip_rounds = 0;              // untracked squarings when handoff == 0 (set in qmps_create)
+  int timing_period = 1;            // HIP events around the dominant kernel on every timing_period-th launch (0 = never)
+  int64_t samples = 0;              // launches timed so far (ring index)
+  bool timed = false;               // this launch is one of them
   bool no_pair = false;             // QMPS_NO_PAIR: D = 4 energy-only launches with one lane per evaluation (tuning knob)
   bool pair_in_step = false;        // QMPS_PAIR_IN_STEP: two-lane energy pass inside qmps_energy_launch as well
   int matvec_period = QMPS_MATVEC_PERIOD_D4;   // D = 4: mat-vecs with T^(2^m) between two further squarings
@@ -479,30 +482,31 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     return fail(QMPS_ERR_ARG, "unknown environment solver %d", solver);
   qmps::LaneArgs a = make_args(c, B, max_iter, tol, true);
   const bool hybrid = solver == QMPS_ENV_POWER_SQUARING && c->D <= 4 && c->handoff < max_iter;
-  const int slot = (int)(c->launches % qmps_ctx::kRing);
+  c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
+  const int slot = (int)(c->samples % qmps_ctx::kRing);
   c->partials_B = -1;
   const int lane_waves = (int)((B + 63) / 64);
   if (c->D == 16 && !getenv("QMPS_D16_BLOCK")) {
     // D = 16: power iteration on the matrix cores (one wave per evaluation), then the energy pass
     c->dominant = "energy_mfma_d16_kernel<true>";
-    if (!c->capturing) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+    if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy_mfma(c->D, a, true, c->stream));
-    if (!c->capturing) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
+    if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
   } else if (!hybrid) {
     c->dominant = c->D <= 4 ? "energy_lane_kernel<D,true>" : "energy_block_kernel<D,true>";
     if (c->D <= 4) { a.partial = c->d_partial; c->partials_B = B; c->partials_n = lane_waves; }
-    if (!c->capturing) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+    if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
-    if (!c->capturing) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
+    if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
   } else if (c->D == 2) {
     a.handoff = c->handoff;  // the squaring tail runs in-lane (real 4 x 4 transfer matrix in registers)
     a.hybrid = 1;
     a.skip = c->handoff == 0 ? c->skip_rounds : 0;
     a.partial = c->d_partial; c->partials_B = B; c->partials_n = lane_waves;
     c->dominant = "energy_lane_kernel<2,true>";
-    if (!c->capturing) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+    if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
-    if (!c->capturing) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
+    if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
   } else {
     // D = 4: (1) lane kernel: `handoff` plain steps, slow items -> worklist (skipped when handoff == 0:
     // every item goes straight to the squaring kernel); (2) wave-per-item MFMA squaring over the
@@ -523,9 +527,9 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
       a.work_count = c->d_work_count;
       a.work_idx = c->d_work_idx;
       c->dominant = "energy_lane_kernel<4,true>";
-      if (!c->capturing) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+      if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
       HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
-      if (!c->capturing) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
+      if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
       q.r_in = c->d_r;
       q.work_count = c->d_work_count;
       q.work_idx = c->d_work_idx;
@@ -542,10 +546,10 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     if (grid < 1) grid = 1;
     if (c->handoff == 0) {
       c->dominant = "env_square_d4_kernel";
-      if (!c->capturing) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+      if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     }
     HIP_TRY(qmps::launch_square_tail(c->D, q, grid, c->stream));
-    if (c->handoff == 0) if (!c->capturing) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
+    if (c->handoff == 0) if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
     // (inside a step the one-lane pass is kept: with the pair kernel the pass itself is 2 us shorter but the step
     // measured 1.4 % LONGER - the environment kernel after it runs slower; QMPS_PAIR_IN_STEP switches it on)
     if (e.idx_list == nullptr && !c->no_pair && c->pair_in_step) {
@@ -555,8 +559,17 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
       HIP_TRY(qmps::launch_energy(c->D, e, false, c->stream));
     }
   }
+  if (c->timed) c->samples++;
   if (!c->capturing) c->launches++;
   c->have_env = true;
+  return QMPS_OK;
+}
+
+int qmps_set_kernel_timing_period(qmps_ctx* c, int period) {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  if (period < 0) return fail(QMPS_ERR_ARG, "period must be >= 0");
+  c->timing_period = period;
+  c->samples = 0;          // earlier samples belong to another schedule
   return QMPS_OK;
 }
 
@@ -713,14 +726,16 @@ int qmps_cell2_energy_batch(qmps_ctx* c, int64_t B, const double* U1, const doub
 int qmps_kernel_time(qmps_ctx* c, int n_last, float* avg_ms, char* name, int name_len) {
   if (int rc = bind(c)) return rc;
   if (!avg_ms || n_last < 1) return fail(QMPS_ERR_ARG, "bad arguments");
-  if (c->launches < 1) return fail(QMPS_ERR_STATE, "no energy launch yet");
+  if (c->samples < 1) return fail(QMPS_ERR_STATE, "no timed energy launch yet (qmps_set_kernel_timing_period)");
   HIP_TRY(hipStreamSynchronize(c->stream));
-  int64_t n = n_last;
-  if (n > c->launches) n = c->launches;
+  // the timed launches among the last n_last ones
+  int64_t n = c->timing_period > 0 ? (n_last + c->timing_period - 1) / c->timing_period : 1;
+  if (n < 1) n = 1;
+  if (n > c->samples) n = c->samples;
   if (n > qmps_ctx::kRing) n = qmps_ctx::kRing;
   double sum = 0.0;
   for (int64_t k = 0; k < n; ++k) {
-    const int slot = (int)((c->launches - 1 - k) % qmps_ctx::kRing);
+    const int slot = (int)((c->samples - 1 - k) % qmps_ctx::kRing);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->kev0[slot], c->kev1[slot]));
     sum += ms;

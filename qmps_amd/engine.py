@@ -137,6 +137,11 @@ class EnergyEngine:
         L.check(self._lib.qmps_get_squaring_schedule(self._ctx, byref(a), byref(b)))
         return a.value, b.value
 
+    def set_kernel_timing_period(self, period):
+        """HIP events around the dominant kernel on every `period`-th launch only (they cost ~3 us each on the
+        stream); 1 = every launch (default), 0 = never."""
+        L.check(self._lib.qmps_set_kernel_timing_period(self._ctx, int(period)))
+
     def launch_energy_only(self, B=None):
         L.check(self._lib.qmps_energy_only_launch(self._ctx, self.B if B is None else B))
 

@@ -14,6 +14,27 @@ tag, D, B, solver, handoff = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sy
 src = os.path.join(ROOT, 'gpurun_out', f'prof_{tag}')
 stats = glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True)[0]
 shutil.copy(stats, os.path.join(ROOT, 'profiles', f'{tag}_kernel_stats.csv'))
+# per-kernel averages over the TIMED region of the traced run (the last `steps` launches of each kernel; the warm-up
+# launches run while the clocks are still ramping), next to rocprofv3's own all-launch statistics
+trace = glob.glob(os.path.join(src, 'trace', '**', '*kernel_trace.csv'), recursive=True)
+if trace:
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace[0])):
+        per[r['Kernel_Name'].split('(')[0].replace('void ', '')].append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+    steps = 200
+    for line in open(os.path.join(src, 'bench_trace.log')):
+        if line.startswith('{'):
+            steps = json.loads(line)['steps']
+    timed = {}
+    for k, v in per.items():
+        if 'qmps' in k:
+            v.sort()
+            last = [d for _, d in v[-steps:]]
+            timed[k] = {'launches_total': len(v), 'timed_region_launches': len(last),
+                        'timed_region_average_ns': sum(last) / len(last), 'all_launch_average_ns': sum(d for _, d in v) / len(v)}
+    json.dump({'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extras', 'steps': steps,
+               'kernels': timed}, open(os.path.join(ROOT, 'profiles', f'{tag}_timed_region.json'), 'w'), indent=1)
+    print(json.dumps(timed, indent=1))
 pmc = {}
 for f in glob.glob(os.path.join(src, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))

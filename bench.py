@@ -162,6 +162,9 @@ def main():
     ap.add_argument('--solver', choices=['squaring', 'plain'], default='squaring',
                     help="'squaring' = power iteration + repeated-squaring tail (library default); 'plain' = plain power iteration")
     ap.add_argument('--handoff', type=int, default=None, help='plain power steps before the squaring tail (default: library default)')
+    ap.add_argument('--settle-ms', type=float, default=60.0,
+                    help='milliseconds of sustained FP64 probe-kernel load before the warm-up steps, so that the power '
+                         'management has raised the clocks whatever --warmup is (0 disables; reported in config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the informational host-to-host legs (PCIe-inclusive, ansatz-parameter-inclusive) that run after the '
@@ -231,9 +234,9 @@ def main():
                          'summed cost reduced over gloo after the timed region'
             print(f'bench.py[rank {rank}]: {collective}', file=sys.stderr, flush=True)
 
-    # HIP events around the dominant kernel on at least 16 launches of the timed region, not on every one: a pair of
-    # events costs ~6 us of command-processor fencing per step
-    timing_period = max(1, args.steps // 16)
+    # HIP events around the dominant kernel on >= 4 (and, from 64 steps on, >= 12) launches of the timed region, not
+    # on every one: a pair of events costs ~6 us of command-processor fencing per step
+    timing_period = max(1, min(args.steps // 4, 16))
     eng.set_kernel_timing_period(timing_period)
 
     def step():
@@ -246,6 +249,10 @@ def main():
             dist.barrier()
         eng.sync()
 
+    # clock settle: sustained load from the library's FP64 probe kernel (not steps of the workload), see DESIGN.md section 5
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        eng.probe_fp64_tflops()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -379,6 +386,7 @@ def main():
                                    f'in-kernel power-iteration environment solve (tol {args.tol:g}, cap {args.max_iter}, solver {args.solver})',
                        'baseline_config': 'BASELINE.json configs[2]', 'D': D, 'batch_per_gpu': B,
                        'global_batch': world * B, 'tol': args.tol, 'max_iter': args.max_iter, 'seed': args.seed,
+                       'clock_settle_ms': args.settle_ms,
                        'mean_power_iterations': total_iters_all / (world * B),
                        'max_power_iterations_rank0': int(iters.max()), 'not_converged_or_not_pd': int(bad_all),
                        'collective': collective,

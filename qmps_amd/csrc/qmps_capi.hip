@@ -86,7 +86,8 @@ struct qmps_ctx {
   int64_t samples = 0;              // launches timed so far (ring index)
   bool timed = false;               // this launch is one of them
   bool no_pair = false;             // QMPS_NO_PAIR: D = 4 energy-only launches with one lane per evaluation (tuning knob)
-  bool pair_in_step = false;        // QMPS_PAIR_IN_STEP: two-lane energy pass inside qmps_energy_launch as well
+  bool pair_in_step = true;         // QMPS_LANE_IN_STEP: one-lane energy pass inside qmps_energy_launch
+  int n_cus = 256;                  // compute units of the device (set in qmps_create)
   int matvec_period = QMPS_MATVEC_PERIOD_D4;   // D = 4: mat-vecs with T^(2^m) between two further squarings
   // state
   int n_terms = 0;
@@ -200,6 +201,7 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
   qmps_ctx* c = new (std::nothrow) qmps_ctx();
   if (!c) return fail(QMPS_ERR_ARG, "out of host memory");
   c->device = device;
+  c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->D = D;
   c->max_batch = max_batch;
   int rc = [&]() -> int {
@@ -234,7 +236,7 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     if (const char* e = getenv("QMPS_SKIP_ROUNDS")) c->skip_rounds = atoi(e);   // tuning knob
     if (const char* e = getenv("QMPS_MATVEC_PERIOD")) c->matvec_period = atoi(e);   // tuning knob
     c->no_pair = getenv("QMPS_NO_PAIR") != nullptr;
-    c->pair_in_step = getenv("QMPS_PAIR_IN_STEP") != nullptr;
+    c->pair_in_step = getenv("QMPS_LANE_IN_STEP") == nullptr;
     return QMPS_OK;
   }();
   if (rc != QMPS_OK) {
@@ -539,10 +541,16 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
       q.r_in = c->have_guess ? c->d_r : nullptr;
       e.partial = c->d_partial; c->partials_B = B; c->partials_n = lane_waves;   // the energy pass covers every item
     }
+    // grid-stride workgroups of 4 waves: whole generations of the resident capacity (5 workgroups per CU), at most three
+    // (measured at B = 65536 with settled clocks: 1280 / 2560 / 3840 / 5120 workgroups -> 0.0876 / 0.0870 / 0.0859 / 0.0875 ms;
+    // 2048 and 3072, which end in a partial generation, 0.0900 and 0.0878)
     int grid = (int)((B + 15) / 16);
-    int cap = 2048;
-    if (const char* e = getenv("QMPS_SQ_GRID")) cap = atoi(e);   // tuning knob
-    if (grid > cap) grid = cap;
+    const int generation = c->n_cus * 5;
+    if (grid > generation) {
+      grid = (grid / generation) * generation;
+      if (grid > 3 * generation) grid = 3 * generation;
+    }
+    if (const char* e = getenv("QMPS_SQ_GRID")) grid = atoi(e) < grid ? atoi(e) : grid;   // tuning knob
     if (grid < 1) grid = 1;
     if (c->handoff == 0) {
       c->dominant = "env_square_d4_kernel";
@@ -550,8 +558,8 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     }
     HIP_TRY(qmps::launch_square_tail(c->D, q, grid, c->stream));
     if (c->handoff == 0) if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
-    // (inside a step the one-lane pass is kept: with the pair kernel the pass itself is 2 us shorter but the step
-    // measured 1.4 % LONGER - the environment kernel after it runs slower; QMPS_PAIR_IN_STEP switches it on)
+    // (with settled clocks the step is 0.9 % shorter with the pair kernel: 0.1112 against 0.1122 ms at B = 65536;
+    // QMPS_LANE_IN_STEP keeps the one-lane pass)
     if (e.idx_list == nullptr && !c->no_pair && c->pair_in_step) {
       if (e.partial != nullptr) c->partials_n = (int)((B + 31) / 32);      // two lanes per evaluation: one partial per 32 items
       HIP_TRY(qmps::launch_energy_pair_d4(e, c->stream));

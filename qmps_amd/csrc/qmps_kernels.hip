@@ -2782,18 +2782,29 @@ __global__ __launch_bounds__(256) void sum_partial_kernel(const double* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void sum_final_kernel(const double* __restrict__ partial, int n_partial, int n_terms,
-                                                        double* __restrict__ cost) {
-  __shared__ double red[4];
+__global__ __launch_bounds__(1024) void sum_final_kernel(const double* __restrict__ partial, int n_partial, int n_terms,
+                                                         double* __restrict__ cost) {
+  // one workgroup, latency-bound: every thread issues all its loads before the first add (fixed summation order)
+  __shared__ double red[16];
+  const int nw = blockDim.x >> 6;
   for (int q = 0; q < n_terms; ++q) {
-    double v = 0.0;
-    for (int k = threadIdx.x; k < n_partial; k += blockDim.x) v += partial[(int64_t)q * n_partial + k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const double* src = partial + (int64_t)q * n_partial;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    int k = threadIdx.x;
+    for (; k + 3 * (int)blockDim.x < n_partial; k += 4 * blockDim.x) {
+      const double a = src[k], b = src[k + blockDim.x], c = src[k + 2 * blockDim.x], d = src[k + 3 * blockDim.x];
+      v[0] += a; v[1] += b; v[2] += c; v[3] += d;
+    }
+    for (; k < n_partial; k += blockDim.x) v[0] += src[k];
+    const double w = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
     __syncthreads();
-    if (threadIdx.x == 0) cost[q] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int i = 0; i < nw; ++i) t += red[i];
+      cost[q] = t;
+    }
   }
 }
 
@@ -2918,7 +2929,7 @@ hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, 
 }
 
 hipError_t launch_sum_final(const double* partial, int n_partial, int n_terms, double* cost, hipStream_t st) {
-  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, st, partial, n_partial, n_terms, cost);
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(n_partial > 1024 ? 1024 : 256), 0, st, partial, n_partial, n_terms, cost);
   return hipGetLastError();
 }
 

@@ -12,8 +12,11 @@
 //                                 through a padded LDS tile; from then on every operand of every v_fma_f64 is
 //                                 a VGPR of the lane that needs it.  Plain power iteration (packed Hermitian r:
 //                                 12 D^3 - 2 D^2 FMAs per step), Cholesky test, two-site-RDM energy epilogue.
-//   env_square_d4_kernel          D = 4: power method by repeated squaring of the REAL 16 x 16 transfer matrix
-//                                 (Hermitian coordinates), one wave per item, v_mfma_f64_16x16x4_f64.
+//   env_square_d4_kernel          D = 4: power method 2^m steps at a time on the REAL 16 x 16 transfer matrix (Hermitian
+//                                 coordinates), one wave per item: squarings on v_mfma_f64_16x16x4_f64, then mat-vecs
+//                                 with T^(2^m); tensor tiles arrive by global_load_lds into a double-buffered LDS tile.
+//   energy_pair_d4_kernel         D = 4 energy pass (the contraction chain alone): two lanes per evaluation.
+//   rotosolve_fused_d2_kernel     D = 2: a whole rotosolve run (all sweeps of all restarts) in one launch.
 //   energy_mfma_d16_kernel<SOLVE> D = 16: power iteration + Cholesky + energy on the matrix cores, one wave per
 //                                 evaluation, register-to-register complex 16 x 16 x 16 products.
 //   energy_block_kernel<D,SOLVE>  D = 8 (and the D = 16 fallback): one evaluation per workgroup, tiles in LDS.

@@ -1127,23 +1127,23 @@ __global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(S
     int m = 0, iters = p.done, status = QMPS_ST_NOT_CONVERGED;
     // phase 1: `skip` squarings, matrix pipe only (no item converges in < 2^skip steps)
     fragments();
-    // two rounds per trip on two register sets: the accumulator of one round is the B operand of the next (no copies)
-    auto more = [&]() { return m < p.skip && m < 29 && (unsigned)p.done + (2u << m) <= cap; };
-    while (more()) {
+    // the number of untracked squarings is known up front: two rounds per trip on two register sets (the accumulator of
+    // one round is the B operand of the next, no copies), one odd round at the end
+    int m1 = 0;
+    while (m1 < p.skip && m1 < 29 && (unsigned)p.done + (2u << m1) <= cap) ++m1;
+    for (int pair = 0; pair < (m1 >> 1); ++pair) {
       const v4f64 R2 = square_of(R, af);
       double af2[4];
-      ++m;
       fragments_of(R2, af2);
-      if (!more()) {
-        R = R2;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) af[kk] = af2[kk];
-        break;
-      }
       R = square_of(R2, af2);
-      ++m;
       fragments_of(R, af);
     }
+    if (m1 & 1) {
+      const v4f64 R2 = square_of(R, af);
+      R = R2;
+      fragments_of(R, af);
+    }
+    m = m1;
     // start vector z (trace 1): a warm start / the lane kernel's iterate, else r_0 = |0><0| = e_0, for which
     // T^(2^m) e_0 is simply column 0 of R_m (held by the lanes c == 0)
     double xc[4];

@@ -165,6 +165,9 @@ def main():
     ap.add_argument('--settle-ms', type=float, default=60.0,
                     help='milliseconds of sustained FP64 probe-kernel load before the warm-up steps, so that the power '
                          'management has raised the clocks whatever --warmup is (0 disables; reported in config)')
+    ap.add_argument('--exchange-every', type=int, default=16,
+                    help='N > 1: the summed costs of this many steps travel in one RCCL all-reduce (every step is still '
+                         'reduced exactly once; 1 = an exchange per step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the informational host-to-host legs (PCIe-inclusive, ansatz-parameter-inclusive) that run after the '
@@ -222,7 +225,10 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.SUM)
         rccl_ok = flag.item() == 0.0
         if rccl_ok:
-            collective = 'one RCCL all-reduce(sum, f64[1]) per step'
+            ex = max(1, min(16, args.exchange_every))
+            eng.set_exchange_period(ex)
+            collective = ('one RCCL all-reduce(sum, f64[1]) per step' if ex == 1 else
+                          f'one RCCL all-reduce(sum, f64[{ex}]) per {ex} steps: every step\'s summed cost is reduced once, {ex} of them per message')
         else:
             # reported, never silent: the data path is unchanged (no collective in it); only the summed cost
             # travels over the launcher's gloo group, once, after the timed region

@@ -100,7 +100,12 @@ struct qmps_ctx {
   int rank = 0, nranks = 1;
   hipStream_t comm_stream = nullptr;
   static constexpr int kCostSlots = 4;        // ring: step n's all-reduce may still be in flight while step n+1 sums
-  double* d_cost_ring = nullptr;             // [kCostSlots][16]
+  static constexpr int kMaxGroup = 16;        // steps whose summed costs may travel in ONE all-reduce
+  double* d_cost_ring = nullptr;             // [kCostSlots][kMaxGroup][16]: a slot = one group of steps
+  int exchange_period = 1;                   // steps per all-reduce (qmps_set_exchange_period)
+  int group_fill = 0;                        // steps summed into the current group so far
+  int64_t groups = 0;                        // groups closed (exchanged or, without a communicator, just filled)
+  int last_slot = -1, last_pos = -1;         // where the newest cost lives
   hipEvent_t cost_ready[kCostSlots] = {};    // sum kernels done (main stream)
   hipEvent_t cost_reduced[kCostSlots] = {};  // all-reduce done (comm stream)
   int64_t cost_launches = 0;
@@ -150,6 +155,8 @@ qmps::LaneArgs make_args(qmps_ctx* c, int64_t B, int max_iter, double tol, bool 
   a.tol = tol;
   return a;
 }
+
+int close_group(qmps_ctx* c);
 
 }  // namespace
 
@@ -221,7 +228,8 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     c->partial_cap = (max_batch + 31) / 32 > kSumBlocks ? (max_batch + 31) / 32 : kSumBlocks;   // one partial per 32 (pair kernel) or 64 items
     HIP_TRY(hipMalloc((void**)&c->d_partial, (size_t)kMaxTerms * c->partial_cap * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->d_cost, kMaxTerms * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&c->d_cost_ring, qmps_ctx::kCostSlots * kMaxTerms * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->d_cost_ring, (size_t)qmps_ctx::kCostSlots * qmps_ctx::kMaxGroup * kMaxTerms * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(c->d_cost_ring, 0, (size_t)qmps_ctx::kCostSlots * qmps_ctx::kMaxGroup * kMaxTerms * sizeof(double), c->stream));
     HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     for (int i = 0; i < qmps_ctx::kCostSlots; ++i) {
       HIP_TRY(hipEventCreateWithFlags(&c->cost_ready[i], hipEventDisableTiming));
@@ -278,6 +286,7 @@ int qmps_destroy(qmps_ctx* c) {
 
 int qmps_sync(qmps_ctx* c) {
   if (int rc = bind(c)) return rc;
+  if (int rc = close_group(c)) return rc;     // costs still waiting for their exchange go out now
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipStreamSynchronize(c->comm_stream));
   return QMPS_OK;
@@ -975,30 +984,57 @@ int qmps_allreduce_sum(qmps_ctx* c, double* inout, int n) {
   return QMPS_OK;
 }
 
+namespace {
+// close the current group: ONE ncclAllReduce of its `fill` x 16 doubles on the communication stream, ordered after the
+// device-side sums by an event, so the exchange overlaps the next steps' kernels instead of stalling the compute stream
+int close_group(qmps_ctx* c) {
+  if (c->group_fill == 0) return QMPS_OK;
+  const int slot = (int)(c->groups % qmps_ctx::kCostSlots);
+  double* base = c->d_cost_ring + (size_t)slot * qmps_ctx::kMaxGroup * kMaxTerms;
+  if (c->comm) {
+    HIP_TRY(hipEventRecord(c->cost_ready[slot], c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->cost_ready[slot], 0));
+    RCCL_TRY(ncclAllReduce(base, base, (size_t)c->group_fill * kMaxTerms, ncclDouble, ncclSum, c->comm, c->comm_stream));
+    HIP_TRY(hipEventRecord(c->cost_reduced[slot], c->comm_stream));
+  }
+  c->group_fill = 0;
+  c->groups++;
+  return QMPS_OK;
+}
+}  // namespace
+
+int qmps_set_exchange_period(qmps_ctx* c, int steps) {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  if (steps < 1 || steps > qmps_ctx::kMaxGroup) return fail(QMPS_ERR_ARG, "exchange period must be in [1, %d]", qmps_ctx::kMaxGroup);
+  if (int rc = bind(c)) return rc;
+  if (int rc = close_group(c)) return rc;     // costs summed under the old period are exchanged now
+  c->exchange_period = steps;
+  return QMPS_OK;
+}
+
 int qmps_cost_launch(qmps_ctx* c, int64_t B) {
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
-  // device-side sum into this launch's ring slot (main stream) ...
-  const int slot = (int)(c->cost_launches % qmps_ctx::kCostSlots);
-  double* dst = c->d_cost_ring + (size_t)slot * kMaxTerms;
+  // device-side sum into this step's place in the current group of the ring (main stream) ...
+  const int slot = (int)(c->groups % qmps_ctx::kCostSlots);
+  double* dst = c->d_cost_ring + ((size_t)slot * qmps_ctx::kMaxGroup + c->group_fill) * kMaxTerms;
   // a slot is reused only after its previous all-reduce has finished
-  if (c->comm && c->cost_launches >= qmps_ctx::kCostSlots) HIP_TRY(hipStreamWaitEvent(c->stream, c->cost_reduced[slot], 0));
+  if (c->comm && c->group_fill == 0 && c->groups >= qmps_ctx::kCostSlots)
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->cost_reduced[slot], 0));
   if (c->partials_B == B)   // the energy kernel already left per-wave partial sums: only the final pass is needed
     HIP_TRY(qmps::launch_sum_final(c->d_partial, c->partials_n, c->n_terms, dst, c->stream));
   else {
     c->partials_B = -1;   // the generic two-pass reduction reuses d_partial
     HIP_TRY(qmps::launch_sum(c->d_E, B, c->n_terms, c->d_partial, kSumBlocks, dst, c->stream));
   }
-  if (c->comm) {
-    // ... then ONE ncclAllReduce on the communication stream, ordered after the sum by an event, so the
-    // exchange step overlaps the next step's kernels instead of stalling the compute stream
-    HIP_TRY(hipEventRecord(c->cost_ready[slot], c->stream));
-    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->cost_ready[slot], 0));
-    RCCL_TRY(ncclAllReduce(dst, dst, c->n_terms, ncclDouble, ncclSum, c->comm, c->comm_stream));
-    HIP_TRY(hipEventRecord(c->cost_reduced[slot], c->comm_stream));
-  }
+  c->last_slot = slot;
+  c->last_pos = c->group_fill;
+  c->group_fill++;
   c->cost_launches++;
+  // ... then, once per `exchange_period` steps, the exchange step
+  if (c->group_fill >= c->exchange_period)
+    if (int rc = close_group(c)) return rc;
   return QMPS_OK;
 }
 
@@ -1007,11 +1043,11 @@ int qmps_get_cost(qmps_ctx* c, double* cost) {
   if (!cost) return fail(QMPS_ERR_ARG, "null cost");
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
   if (c->cost_launches < 1) return fail(QMPS_ERR_STATE, "qmps_cost_launch has not been called");
-  const int slot = (int)((c->cost_launches - 1) % qmps_ctx::kCostSlots);
+  if (int rc = close_group(c)) return rc;     // a partly filled group is exchanged now
   hipStream_t st = c->comm ? c->comm_stream : c->stream;
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipMemcpyAsync(c->h_cost, c->d_cost_ring + (size_t)slot * kMaxTerms, c->n_terms * sizeof(double),
-                         hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(c->h_cost, c->d_cost_ring + ((size_t)c->last_slot * qmps_ctx::kMaxGroup + c->last_pos) * kMaxTerms,
+                         c->n_terms * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   memcpy(cost, c->h_cost, c->n_terms * sizeof(double));
   return QMPS_OK;

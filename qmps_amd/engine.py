@@ -137,6 +137,10 @@ class EnergyEngine:
         L.check(self._lib.qmps_get_squaring_schedule(self._ctx, byref(a), byref(b)))
         return a.value, b.value
 
+    def set_exchange_period(self, steps):
+        """Summed costs of `steps` consecutive cost_launch calls travel in one all-reduce (1..16, default 1)."""
+        L.check(self._lib.qmps_set_exchange_period(self._ctx, int(steps)))
+
     def set_kernel_timing_period(self, period):
         """HIP events around the dominant kernel on every `period`-th launch only (they cost ~3 us each on the
         stream); 1 = every launch (default), 0 = never."""

@@ -33,6 +33,42 @@ def test_rccl_world1_allreduce_and_cost():
         eng.comm_destroy()
 
 
+@pytest.mark.parametrize('with_comm', [True, False])
+def test_grouped_exchange_keeps_every_step_cost(with_comm):
+    """qmps_set_exchange_period: the summed costs of several steps share one all-reduce; get_cost always returns the
+    cost of the LAST step whether the group is full (3 steps of period 3), partly filled (2 of 3) or the period has
+    just been changed; more steps than ring slots x period wrap the ring."""
+    from qmps_amd import EnergyEngine
+    rng = np.random.default_rng(3)
+    h = np.stack([O.hamiltonian_matrix({'ZZ': -1, 'X': 1}), O.hamiltonian_matrix({'XX': 1, 'ZZ': 0.5})])
+    batches = [O.unitary_to_tensor(O.haar_unitaries(rng, 4, 96)) for _ in range(5)]
+    with EnergyEngine(2, 128) as eng:
+        if with_comm:
+            eng.comm_init(EnergyEngine.comm_unique_id(), 0, 1)
+        eng.set_hamiltonian(h)
+        sums = []
+        for A in batches:
+            E, _, _ = eng.energies(A, h)
+            sums.append(E.sum(0))
+        eng.set_exchange_period(3)
+        seen = []
+        for k in range(29):                       # 29 steps: 9 full groups (> 4 ring slots) + a partial one
+            eng.set_tensors(batches[k % 5])
+            eng.launch()
+            eng.cost_launch()
+            if k in (2, 4, 13, 27, 28):
+                seen.append((k, eng.get_cost()))
+        for k, c in seen:
+            assert np.allclose(c, sums[k % 5], rtol=0, atol=1e-10), k
+        eng.set_exchange_period(1)
+        eng.set_tensors(batches[1]); eng.launch(); eng.cost_launch()
+        assert np.allclose(eng.get_cost(), sums[1], rtol=0, atol=1e-10)
+        with pytest.raises(Exception):
+            eng.set_exchange_period(17)
+        if with_comm:
+            eng.comm_destroy()
+
+
 def test_bench_distributed_code_path_world1():
     """bench.py's N > 1 branch (gloo rendezvous, unique-id broadcast, RCCL init, all-reduce per step),
     forced at world size 1 through the same launcher the driver uses."""

@@ -159,8 +159,13 @@ def main():
     ap.add_argument('--max-iter', type=int, default=10000)
     ap.add_argument('--tol', type=float, default=1e-13)
     ap.add_argument('--seed', type=int, default=20241022)
-    ap.add_argument('--solver', choices=['squaring', 'plain'], default='squaring',
-                    help="'squaring' = power iteration + repeated-squaring tail (library default); 'plain' = plain power iteration")
+    ap.add_argument('--solver', choices=['direct', 'squaring', 'plain'], default='direct',
+                    help="'direct' = exact fixed-point solve accepted by one power step, fused with the energy (library default at "
+                         "D = 4; other bond dimensions run 'squaring'); 'squaring' = power iteration 2^m steps at a time; "
+                         "'plain' = plain power iteration")
+    ap.add_argument('--store-env', action='store_true',
+                    help="'direct' only: also write the environments r[B][D][D] to HBM in every step (default: energies, "
+                         'iteration counts and status only - SURVEY 8(d)\'s 32 D^2 + 8 bytes per evaluation)')
     ap.add_argument('--handoff', type=int, default=None, help='plain power steps before the squaring tail (default: library default)')
     ap.add_argument('--settle-ms', type=float, default=60.0,
                     help='milliseconds of sustained FP64 probe-kernel load before the warm-up steps, so that the power '
@@ -245,8 +250,11 @@ def main():
     timing_period = max(1, min(args.steps // 4, 16))
     eng.set_kernel_timing_period(timing_period)
 
+    direct = args.solver == 'direct' and D == 4
+    store_env = args.store_env or not direct
+
     def step():
-        eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver)
+        eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver, store_env=store_env)
         eng.cost_launch(B)
 
     def barrier():
@@ -300,7 +308,7 @@ def main():
 
         def ansatz_eval():
             eng.set_ansatz_params(_lib.ANSATZ_SHALLOW_CNOT, prm)
-            eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver)
+            eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver, store_env=store_env)
             return eng.results()
         ansatz_eval()
         t1 = time.perf_counter()
@@ -341,10 +349,24 @@ def main():
         # (context stream); step_ms_events brackets the whole K-step region on the same stream
         kernel_ms, kernel_name = eng.kernel_time(args.steps)
         step_ms_events = ev_ms / args.steps
-        hybrid = args.solver == 'squaring' and D <= 4
+        hybrid = args.solver == 'squaring' and D <= 4 or (args.solver == 'direct' and D == 2)
         handoff = eng.handoff if hybrid else 0
         n2 = (D * D) ** 3
-        if hybrid and D == 4:
+        if direct:
+            # executed algorithm of energy_direct_d4_kernel, per evaluation (FMA = 2 flop), qmps_direct_core.h:
+            #   real 16 x 16 transfer matrix: 16 rows x (4 x 4 + 12 x 8) FMA                         = 1792 FMA
+            #   Gauss-Jordan on 16 x (16 + 1): 16 rows x sum_k (16 - k) FMA + 16 x 16 multipliers     = 2176 FMA + 256 mul
+            #   acceptance power step from the tensor: 4 rows x (2 x 4 x 14 + 4 x 8 x 4) FMA          =  960 FMA
+            #   two-site density matrix: B = A A 4 x 256, Y = B r 4 x 224, rho 4 x 128 FMA            = 2432 FMA
+            #   LDL^H test ~60 FMA, energy 28 FMA per term
+            # evaluations that fell back to the squaring rounds (iters > 1) add 2 x 16^3 + 2 x 16^2 flop per round
+            per = 2.0 * (1792 + 2176 + 960 + 2432 + 60 + 28) + 256
+            rounds = np.where(iters > 1, np.log2(np.maximum(iters - 1, 1)), 0.0)
+            flops = float((per + rounds * (2.0 * n2 + 2.0 * (D * D) ** 2) + (iters > 1) * 3584.0).sum())
+            flop_note = ('executed algorithm of the fused kernel: real 16 x 16 transfer matrix (3584 flop) + Gauss-Jordan '
+                         '(4608) + acceptance power step (1920) + density matrix / LDL^H / energy (5040) per evaluation, '
+                         'squaring rounds of fallen-back evaluations added from the iteration count read back per item')
+        elif hybrid and D == 4:
             # executed algorithm: min(K, handoff) plain steps in the lane kernel, then in
             # env_square_d4_kernel: construction of the real 16 x 16 transfer matrix (32 D^4 flop), `skip` squarings
             # (2 (D^2)^3 flop each), mat-vecs with T^(2^m) (2 (D^2)^2 flop each) and one more squaring after every
@@ -389,7 +411,8 @@ def main():
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'TFIM g=1 two-site energy, D={D}, batch={B} per GPU, Haar-random state unitaries, '
-                                   f'in-kernel power-iteration environment solve (tol {args.tol:g}, cap {args.max_iter}, solver {args.solver})',
+                                   f'in-kernel environment solve (tol {args.tol:g}, cap {args.max_iter}, solver {args.solver}'
+                                   f'{"" if store_env else ", environments not stored"})',
                        'baseline_config': 'BASELINE.json configs[2]', 'D': D, 'batch_per_gpu': B,
                        'global_batch': world * B, 'tol': args.tol, 'max_iter': args.max_iter, 'seed': args.seed,
                        'clock_settle_ms': args.settle_ms,

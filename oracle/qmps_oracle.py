@@ -324,6 +324,71 @@ def env_power_iteration(A, r0=None, tol=1e-13, max_iter=10000, handoff=None, ski
     return r, it, 1
 
 
+def env_direct(A, tol=1e-13, max_iter=10000):
+    """QMPS_ENV_DIRECT, restated independently of the kernel's real-coordinate Gauss-Jordan: the reference does an
+    exact eigen-solve here (tools.py:176-182); for a left isometry the dominant eigenvalue of the transfer map is 1
+    and the map preserves the trace, so vec(r) solves the COMPLEX D^2 x D^2 system (E - 1 + e t^T) vec(r) = e
+    (t = trace functional, e = the last unit vector), here by LAPACK's pivoted LU.  The candidate is accepted iff
+    one power step moves it by less than tol in Frobenius norm (the criterion of env_power_iteration); otherwise the
+    power method continues 2^m steps at a time from r_0 = 1/D: r_m = herm(T^(2^m) r_0)/tr, stop at
+    ||r_m - r_(m-1)||_F < tol, with at most max_iter - 1 further power steps.
+
+    Returns (r, iterations, status): iterations = 1 for an accepted direct solve, else 1 + 2^m."""
+    D = A.shape[1]
+    N = D * D
+    E = transfer_matrix(A)
+    t = np.eye(D).reshape(N)
+    M = E - np.eye(N)
+    M[N - 1, :] += t
+    rhs = np.zeros(N, dtype=complex)
+    rhs[N - 1] = 1.0
+    ok = False
+    with np.errstate(all='ignore'):
+        try:
+            r = np.linalg.solve(M, rhs).reshape(D, D)
+            r = (r + r.conj().T) / 2
+            r = r / np.trace(r).real
+            rn = apply_transfer(A, r)
+            rn = (rn + rn.conj().T) / 2
+            rn = rn / np.trace(rn).real
+            ok = bool(float((np.abs(rn - r) ** 2).sum()) < tol * tol)
+        except np.linalg.LinAlgError:
+            ok = False
+    if ok:
+        return r, 1, 0
+    r0 = (np.eye(D, dtype=complex) / D).reshape(N)
+    r = r0.reshape(D, D) if not np.all(np.isfinite(r)) else r
+    P, m, it, prev = E, 0, 1, r0.reshape(D, D)
+    status = 1
+    while m < 29 and 2 ** (m + 1) <= max_iter - 1:
+        P = P @ P
+        m += 1
+        rn = (P @ r0).reshape(D, D)
+        rn = (rn + rn.conj().T) / 2
+        lam = np.trace(rn).real
+        rn = rn / lam
+        P = P / lam
+        d2 = float((np.abs(rn - prev) ** 2).sum())
+        prev = r = rn
+        it = 1 + 2 ** m
+        if d2 < tol * tol:
+            status = 0
+            break
+    return r, it, status
+
+
+def energy_direct(A, h, tol=1e-13, max_iter=10000):
+    """What one DPP quad of energy_direct_d4_kernel computes: env_direct + closed form; status 2 if r is not PD."""
+    r, it, status = env_direct(A, tol, max_iter)
+    E = energy_closed_form(A, h, r)
+    if status == 0:
+        try:
+            env_cholesky(r)
+        except np.linalg.LinAlgError:
+            status = 2
+    return E, it, status
+
+
 def env_cholesky(r):
     """L = cholesky(r)^dagger lower triangular, r = L L^dagger (tools.py:181-182).
     Raises numpy.linalg.LinAlgError if r is not positive definite (ground_state.py:155)."""

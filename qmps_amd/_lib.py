@@ -19,6 +19,8 @@ INPUT_ANSATZ_BASE = 16
 ANSATZ_SHALLOW_CNOT, ANSATZ_SHALLOW_QAOA, ANSATZ_SHALLOW_FULL, ANSATZ_SHALLOW_CNOT3 = 0, 1, 2, 3
 ENV_POWER = 0
 ENV_POWER_SQUARING = 1
+ENV_DIRECT = 2
+FLAG_NO_ENV_OUT = 0x100
 UNIQUE_ID_BYTES = 128
 
 _dp = POINTER(c_double)
@@ -98,7 +100,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.qmps_abi_version() != 1:
+    if lib.qmps_abi_version() != 2:
         raise ImportError('libqmps_hip.so ABI version mismatch')
     _lib = lib
     return lib

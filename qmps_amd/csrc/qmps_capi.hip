@@ -225,7 +225,7 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     HIP_TRY(hipMalloc(&c->d_h, (size_t)kMaxTerms * 256));
     HIP_TRY(hipMalloc((void**)&c->d_iters, (size_t)max_batch * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&c->d_status, (size_t)max_batch * sizeof(int32_t)));
-    c->partial_cap = (max_batch + 31) / 32 > kSumBlocks ? (max_batch + 31) / 32 : kSumBlocks;   // one partial per 32 (pair kernel) or 64 items
+    c->partial_cap = (max_batch + 15) / 16 > kSumBlocks ? (max_batch + 15) / 16 : kSumBlocks;   // one partial per 16 (direct kernel), 32 (pair kernel) or 64 items
     HIP_TRY(hipMalloc((void**)&c->d_partial, (size_t)kMaxTerms * c->partial_cap * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->d_cost, kMaxTerms * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->d_cost_ring, (size_t)qmps_ctx::kCostSlots * qmps_ctx::kMaxGroup * kMaxTerms * sizeof(double)));
@@ -240,6 +240,7 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     HIP_TRY(hipMalloc((void**)&c->d_work_idx, (size_t)max_batch * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(c->d_work_count, 0, sizeof(int32_t), c->stream));
     c->handoff = 0;   // D = 2, 4: squaring from the start (fastest); D = 8, 16 have no squaring path
+    c->default_solver = D == 4 ? QMPS_ENV_DIRECT : QMPS_ENV_POWER_SQUARING;
     c->skip_rounds = (D == 2) ? QMPS_SKIP_ROUNDS_D2 : QMPS_SKIP_ROUNDS_D4;
     if (const char* e = getenv("QMPS_SKIP_ROUNDS")) c->skip_rounds = atoi(e);   // tuning knob
     if (const char* e = getenv("QMPS_MATVEC_PERIOD")) c->matvec_period = atoi(e);   // tuning knob
@@ -488,15 +489,34 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "qmps_set_hamiltonian has not been called");
   if (max_iter < 1) return fail(QMPS_ERR_ARG, "max_iter must be >= 1");
   if (!(tol > 0.0)) return fail(QMPS_ERR_ARG, "tol must be > 0");
-  const int solver = flags & 0xff;
-  if (solver != QMPS_ENV_POWER && solver != QMPS_ENV_POWER_SQUARING)
+  int solver = flags & 0xff;
+  if (solver != QMPS_ENV_POWER && solver != QMPS_ENV_POWER_SQUARING && solver != QMPS_ENV_DIRECT)
     return fail(QMPS_ERR_ARG, "unknown environment solver %d", solver);
+  if ((flags & ~0xff) & ~QMPS_FLAG_NO_ENV_OUT) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags & ~0xff);
+  const bool direct = solver == QMPS_ENV_DIRECT && c->D == 4;
+  if ((flags & QMPS_FLAG_NO_ENV_OUT) && !direct) return fail(QMPS_ERR_ARG, "QMPS_FLAG_NO_ENV_OUT needs QMPS_ENV_DIRECT at D = 4");
+  if (solver == QMPS_ENV_DIRECT && !direct) solver = QMPS_ENV_POWER_SQUARING;   // documented: D = 2, 8, 16 iterate
   qmps::LaneArgs a = make_args(c, B, max_iter, tol, true);
   const bool hybrid = solver == QMPS_ENV_POWER_SQUARING && c->D <= 4 && c->handoff < max_iter;
   c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
   const int slot = (int)(c->samples % qmps_ctx::kRing);
   c->partials_B = -1;
   const int lane_waves = (int)((B + 63) / 64);
+  if (direct) {
+    // D = 4: direct fixed-point solve + acceptance power step + energies in ONE kernel (a DPP quad per evaluation);
+    // one read of A, one store of E (and, unless switched off, of r) per evaluation
+    a.r_in = nullptr;
+    a.r_out = (flags & QMPS_FLAG_NO_ENV_OUT) ? nullptr : c->d_r;
+    a.partial = c->d_partial; c->partials_B = B; c->partials_n = (int)((B + 15) / 16);
+    c->dominant = "energy_direct_d4_kernel";
+    if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+    HIP_TRY(qmps::launch_energy_direct_d4(a, c->stream));
+    if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
+    if (c->timed) c->samples++;
+    if (!c->capturing) c->launches++;
+    c->have_env = a.r_out != nullptr;
+    return QMPS_OK;
+  }
   if (c->D == 16 && !getenv("QMPS_D16_BLOCK")) {
     // D = 16: power iteration on the matrix cores (one wave per evaluation), then the energy pass
     c->dominant = "energy_mfma_d16_kernel<true>";
@@ -599,7 +619,8 @@ int qmps_set_handoff(qmps_ctx* c, int handoff) {
 
 int qmps_set_default_solver(qmps_ctx* c, int solver) {
   if (!c) return fail(QMPS_ERR_ARG, "null context");
-  if (solver != QMPS_ENV_POWER && solver != QMPS_ENV_POWER_SQUARING) return fail(QMPS_ERR_ARG, "unknown solver %d", solver);
+  if (solver != QMPS_ENV_POWER && solver != QMPS_ENV_POWER_SQUARING && solver != QMPS_ENV_DIRECT)
+    return fail(QMPS_ERR_ARG, "unknown solver %d", solver);
   c->default_solver = solver;
   return QMPS_OK;
 }

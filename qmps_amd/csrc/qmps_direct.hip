@@ -1,0 +1,188 @@
+// qmps_direct.hip - the DIRECT environment solve fused with the two-site energy (gfx950 only).
+//
+// energy_direct_d4_kernel: D = 4, ONE DPP QUAD (4 lanes) PER EVALUATION, 16 evaluations per wave.  Per evaluation:
+//   tensor (512 B, read once from HBM as part of the wave's contiguous 8 KB slab -> padded LDS tile)
+//   -> the real 16 x 16 transfer matrix R, four rows per lane
+//   -> (R - 1 + e_15 t^T) u = e_15 by Gauss-Jordan elimination in registers, pivot rows handed round the quad by
+//      v_mov_b32_dpp quad_perm (VALU only; no LDS, no cross-quad traffic)
+//   -> one power step as acceptance test (||T(r) - r||_F < tol; else the power method 2^m steps at a time)
+//   -> LDL^H positive-definiteness test, two-site density matrix, energies of all Hamiltonian terms
+//   -> E (8 B per term), iterations + status (8 B), optionally r (256 B); per-wave partial sums of E.
+// One read of A and one store of E per evaluation: the environment never travels through HBM.
+// The mathematics lives in qmps_direct_core.h (shared with the CPU lock-step emulation the test-suite uses).
+// Replaces qmps/tools.py:176-182 (get_env_exact: the reference does an exact eigen-solve here as well) +
+// qmps/represent.py:258-262 + qmps/ground_state.py:159-167.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qmps_kernels.h"
+#include "qmps_device.h"
+#include "qmps_direct_core.h"
+
+namespace qmps {
+
+namespace {
+
+struct QuadOps {
+  using V = double;
+  using P = bool;
+  int q;                  // row index of this lane inside its quad
+  const double2* row;     // the evaluation's tensor in LDS: A_s[i][j] = row[(4 s + i) 4 + j]
+  __device__ __forceinline__ P q_eq(int i) const { return q == i; }
+  __device__ __forceinline__ P q_gt(int i) const { return q > i; }
+  template <int L>
+  static __device__ __forceinline__ V bcast(V v) { return quad_bcast<L>(v); }
+  static __device__ __forceinline__ V qsum(V v) { return quad_sum(v); }
+  static __device__ __forceinline__ V sel(P p, V a, V b) { return p ? a : b; }
+  static __device__ __forceinline__ V splat(double x) { return x; }
+  static __device__ __forceinline__ V fma(V a, V b, V c) { return dfma(a, b, c); }
+  static __device__ __forceinline__ V rcp(V t) { return fast_rcp(t); }
+  static __device__ __forceinline__ P lt(V a, V b) { return a < b; }
+  static __device__ __forceinline__ P gt0(V a) { return a > 0.0; }
+  static __device__ __forceinline__ P p_and(P a, P b) { return a && b; }
+  static __device__ __forceinline__ P p_not(P a) { return !a; }
+  static __device__ __forceinline__ bool any(P a) { return __any(a) != 0; }   // wave-uniform: every quad stays in step
+  __device__ __forceinline__ void own(int s, int j, V& re, V& im) const {
+    const double2 v = row[(4 * s + q) * 4 + j];
+    re = v.x;
+    im = v.y;
+  }
+  __device__ __forceinline__ void uni(int s, int i, int j, V& re, V& im) const {
+    const double2 v = row[(4 * s + i) * 4 + j];
+    re = v.x;
+    im = v.y;
+  }
+};
+
+// The rare path, out of line: rebuild R, then the power method 2^m steps at a time.  Kept out of the kernel body so
+// that its register demand (two 16 x 16 matrices per quad) does not shape the register allocation of the main path.
+__device__ __attribute__((noinline)) bool squaring_fallback(int q, const double2* row, bool todo, int max_iter, double tol2,
+                                                            double (&x)[4], double& sq) {
+  using Core = DirectD4<QuadOps>;
+  const QuadOps o{q, row};
+  double Rc[4][16];
+  Core::build(o, Rc);
+  return Core::squaring(o, Rc, todo, max_iter, tol2, x, sq);
+}
+
+}  // namespace
+
+#ifndef QMPS_DIRECT_MINWAVES
+#define QMPS_DIRECT_MINWAVES 2
+#endif
+__global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_kernel(LaneArgs p) {
+  using Core = DirectD4<QuadOps>;
+  constexpr int ROW = 512, PAD = ROW + 16, ITEMS = 16;
+  // item stride 528 B = 4 banks: the four items of a ds_read_b128 lane group sit on disjoint banks both when a quad
+  // reads one address (rows of the partner index) and when its lanes read their own rows (64 B apart)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[ITEMS * PAD];
+  const int lane = threadIdx.x, e = lane >> 2, q = lane & 3;
+  const int64_t first = (int64_t)blockIdx.x * ITEMS;
+  const int64_t b = first + e;
+  const bool valid = b < p.B;
+  {
+    // HBM -> LDS: the wave's 16 tensors are one contiguous 8 KB slab, 16 B per lane per load
+    const unsigned char* slab = (const unsigned char*)p.A + first * ROW;
+    const int64_t slab_bytes = (p.B - first < ITEMS ? p.B - first : ITEMS) * (int64_t)ROW;
+    double2 v[ITEMS * ROW / 1024];
+#pragma unroll
+    for (int c = 0; c < ITEMS * ROW / 1024; ++c) {
+      const int off = c * 1024 + lane * 16;
+      v[c] = make_double2(0.0, 0.0);
+      if (off < slab_bytes) v[c] = *(const double2*)(slab + off);
+    }
+#pragma unroll
+    for (int c = 0; c < ITEMS * ROW / 1024; ++c) {
+      const int off = c * 1024 + lane * 16;
+      *(double2*)(lds + (off / ROW) * PAD + (off % ROW)) = v[c];
+    }
+  }
+  __syncthreads();
+  const QuadOps o{q, (const double2*)(lds + e * PAD)};
+  const double tol2 = p.tol * p.tol;
+
+  // ---- environment: direct solve, accepted by one power step ----
+  double x[4], us[16];
+  double steps = 1.0;
+  int status = QMPS_ST_OK;
+  {
+    double Rc[4][16], y[4];
+    Core::build(o, Rc);
+    __builtin_amdgcn_sched_barrier(0);     // phase by phase: keeps the operand reads of later phases out of the register file
+    Core::solve(o, Rc, x);
+    __builtin_amdgcn_sched_barrier(0);
+    Core::normalise(o, x);
+    Core::gather(x, us);
+    const double d2 = Core::power_step(o, x, us, y);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool todo = valid && !(d2 < tol2);     // NaN (a zero pivot) lands here too
+    if (__any(todo)) {
+      // rare: not an isometry / degenerate transfer spectrum.  Wave-uniform branch: every quad walks through the
+      // rounds, only the `todo` ones take the result.
+      double sq = 0.0;
+      const bool left = squaring_fallback(q, o.row, todo, p.max_iter - 1, tol2, x, sq);
+      if (todo) {
+        steps = 1.0 + sq;
+        status = left ? QMPS_ST_NOT_CONVERGED : QMPS_ST_OK;
+      }
+      Core::gather(x, us);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- positive definiteness, two-site density matrix, energies ----
+  double pre[4][4], pim[4][4];
+  const bool pd = Core::density(o, us, pre, pim);
+  if (status == QMPS_ST_OK && !pd) status = QMPS_ST_NOT_PD;
+  for (int t = 0; t < p.n_terms; ++t) {
+    const double en = quad_sum(Core::energy((const double*)p.h + 32 * t, pre, pim));
+    if (valid && q == 0) p.E[b * p.n_terms + t] = en;
+    if (p.partial != nullptr) {
+      // first pass of the cost reduction: one partial per wave, fixed order
+      const double s = wave_sum((valid && q == 0) ? en : 0.0);
+      if (lane == 0) p.partial[(int64_t)t * gridDim.x + blockIdx.x] = s;
+    }
+  }
+  if (p.rho_out != nullptr) {
+    double fre[4][4], fim[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int s = t; s < 4; ++s) {
+        fre[t][s] = quad_sum(pre[t][s]);
+        fim[t][s] = t == s ? 0.0 : quad_sum(pim[t][s]);
+      }
+    if (valid && q == 0) {
+      double2* o2 = (double2*)p.rho_out + b * 16;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          o2[t * 4 + s] = t <= s ? make_double2(fre[t][s], fim[t][s]) : make_double2(fre[s][t], -fim[s][t]);
+    }
+  }
+  if (!valid) return;
+  if (q == 0) {
+    p.iters[b] = (int32_t)steps;
+    p.status[b] = status;
+  }
+  if (p.r_out != nullptr) {
+    // row q of r: the lane owns u[(q,l)] = x[l]; the transposed coordinate u[(l,q)] comes out of the gathered copy
+    double2* o2 = (double2*)p.r_out + b * 16 + q * 4;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const double f = q == 0 ? us[4 * l] : (q == 1 ? us[4 * l + 1] : (q == 2 ? us[4 * l + 2] : us[4 * l + 3]));
+      const double re = q <= l ? x[l] : f;
+      const double im = q == l ? 0.0 : (q < l ? f : -x[l]);
+      o2[l] = make_double2(re, im);
+    }
+  }
+}
+
+hipError_t launch_energy_direct_d4(const LaneArgs& a, hipStream_t st) {
+  if (a.B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(energy_direct_d4_kernel, dim3((unsigned)((a.B + 15) / 16)), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace qmps

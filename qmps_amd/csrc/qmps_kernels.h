@@ -56,6 +56,8 @@ hipError_t launch_energy_mfma(int D, const LaneArgs& a, bool solve, hipStream_t 
 hipError_t launch_square_tail(int D, const SquareArgs& a, int grid, hipStream_t st);
 // D = 4 energy-only pass with two lanes per evaluation (a.r_in resident, no worklist); partials: one per 32 items
 hipError_t launch_energy_pair_d4(const LaneArgs& a, hipStream_t st);
+// D = 4 DIRECT solve fused with the energies: one DPP quad per evaluation (qmps_direct.hip); partials: one per 16 items
+hipError_t launch_energy_direct_d4(const LaneArgs& a, hipStream_t st);
 
 // Whole D = 2 rotosolve run in one launch (restarts are independent): base [R][P] in/out, hist [n_sweeps][R] out
 struct RotoArgs {

@@ -30,58 +30,9 @@
 #include <stdint.h>
 
 #include "qmps_kernels.h"
+#include "qmps_device.h"
 
 namespace qmps {
-
-// ------------------------------------------------------------------------------------------
-// small helpers
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-
-// ---- wave-level reductions (VALU only: DPP row rotations + gfx950 permlane swaps) ----
-// sum over the 16 lanes of a row group (lanes 16 g .. 16 g + 15); result in every lane of the group.
-// DPP row rotations (v_mov_b32_dpp row_ror:n, VALU only - no LDS crossbar traffic).
-template <int N>
-__device__ __forceinline__ double row_ror(double v) {
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x120 + N, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x120 + N, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row16_sum(double v) {
-  v += row_ror<8>(v);
-  v += row_ror<4>(v);
-  v += row_ror<2>(v);
-  v += row_ror<1>(v);
-  return v;
-}
-// sum over the four row groups, per lane position: lane (g, c) receives sum_g' v(g', c).
-// gfx950 v_permlane32_swap / v_permlane16_swap: VALU only, no LDS crossbar, no SGPR round trip.
-__device__ __forceinline__ double group4_sum(double v) {
-  typedef unsigned u2 __attribute__((ext_vector_type(2)));
-  unsigned lo = __double2loint(v), hi = __double2hiint(v);
-  u2 a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  u2 b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  const double x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-  lo = __double2loint(x);
-  hi = __double2hiint(x);
-  a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-}
-// the same sum on the matrix pipe: one v_mfma_f64_4x4x4_4b with an all-ones A operand.  Lane 16 x + 4 q + z
-// holds B_q[k = x][j = z]; D_q[i][j] = sum_k B_q[k][j] lands in lane (x = i, q, z = j): every row group
-// receives the column sums (16 cycles instead of ~10 VALU instructions; summation order differs).
-__device__ __forceinline__ double group4_sum_mfma(double v) {
-  return __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, v, 0.0, 0, 0, 0);
-}
-// wave-uniform copy of lane 0's value
-__device__ __forceinline__ double lane0(double v) {
-  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double wave_sum(double v) { return group4_sum(row16_sum(v)); }
 
 // Packed Hermitian accessors: only entries with j >= i are stored; the diagonal is real.
 template <int D>

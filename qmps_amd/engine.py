@@ -111,15 +111,19 @@ class EnergyEngine:
         L.check(self._lib.qmps_set_env_guess(self._ctx, r0.shape[0], _f64(r0.view(np.float64))))
 
     # -- hot path ---------------------------------------------------------------------------
-    def launch(self, B=None, max_iter=10000, tol=1e-13, solver='squaring'):
-        """Asynchronous: power-iteration environment + energies for the resident batch.
-        solver: 'squaring' (power iteration + repeated-squaring tail, default) or 'plain'."""
-        flag = {'plain': L.ENV_POWER, 'squaring': L.ENV_POWER_SQUARING}[solver]
+    _SOLVERS = {'plain': L.ENV_POWER, 'squaring': L.ENV_POWER_SQUARING, 'direct': L.ENV_DIRECT}
+
+    def launch(self, B=None, max_iter=10000, tol=1e-13, solver='direct', store_env=True):
+        """Asynchronous: right environment + energies for the resident batch.
+        solver: 'direct' (exact fixed-point solve accepted by one power step; D = 4, other bond dimensions run
+        'squaring'), 'squaring' (power iteration 2^m steps at a time) or 'plain' (power iteration).
+        store_env=False ('direct' only): the environments are not written to HBM."""
+        flag = self._SOLVERS[solver] | (0 if store_env else L.FLAG_NO_ENV_OUT)
         L.check(self._lib.qmps_energy_launch(self._ctx, self.B if B is None else B, int(max_iter), float(tol), flag))
 
-    def set_solver(self, solver='squaring', handoff=None):
-        """Solver of the one-shot calls (`energies`, `env_batch`) and the hand-off point of the tail."""
-        flag = {'plain': L.ENV_POWER, 'squaring': L.ENV_POWER_SQUARING}[solver]
+    def set_solver(self, solver='direct', handoff=None):
+        """Solver of the one-shot calls (`energies`, `env_batch`, `rotosolve`) and the hand-off point of the tail."""
+        flag = self._SOLVERS[solver]
         L.check(self._lib.qmps_set_default_solver(self._ctx, flag))
         if handoff is not None:
             L.check(self._lib.qmps_set_handoff(self._ctx, int(handoff)))

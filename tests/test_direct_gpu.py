@@ -1,0 +1,149 @@
+"""GPU parity tests of the DIRECT environment solver (QMPS_ENV_DIRECT, energy_direct_d4_kernel) through the C-ABI:
+against the oracle's independent restatement (dense complex transfer matrix + pivoted LAPACK solve), the reference's
+own route (dominant eigen-matrix by dense eig), the iterative solvers, and the CPU lock-step emulation of the
+kernel's own source.  Tolerance: energies and environments within 1e-10 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from oracle import qmps_oracle as O
+from tests import direct_emu as EMU
+
+pytestmark = pytest.mark.gpu
+
+E_TOL = 1e-10
+R_TOL = 1e-10
+
+
+def h3(rng):
+    return np.stack([O.hamiltonian_matrix({'ZZ': -1, 'X': 1}),
+                     O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5}),
+                     rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4))])
+
+
+def test_direct_is_the_default_at_d4_and_matches_golden(golden, engine_factory):
+    eng = engine_factory(4)
+    eng.set_solver('direct')
+    E, it, st = eng.energies(golden['ref_A_D4'], golden['ref_h_tfim'])
+    assert np.all(st == 0) and np.all(it == 1)
+    assert np.abs(E[:, 0] - golden['oracle_E_closed_D4']).max() < E_TOL
+    assert np.abs(E[:, 0] - golden['oracle_E_statevec_D4']).max() < E_TOL
+    assert np.abs(eng.environments() - golden['oracle_r_D4']).max() < R_TOL
+    E2, _, _ = eng.energies(golden['U_D4'], golden['ref_h_tfim'], kind='unitary')
+    assert np.array_equal(E, E2)
+    from qmps_amd import EnergyEngine
+    with EnergyEngine(4, 64) as fresh:          # a fresh context: the library default
+        E3, it3, st3 = fresh.energies(golden['ref_A_D4'], golden['ref_h_tfim'])
+    assert np.array_equal(E3, E) and np.all(it3 == 1)
+
+
+@pytest.mark.parametrize('B', [1, 3, 15, 16, 17, 65, 1000, 5000])
+def test_random_batches(B, c_oracle, engine_factory):
+    rng = np.random.default_rng(4000 + B)
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 8, B))
+    h = h3(rng)
+    eng = engine_factory(4)
+    eng.set_solver('direct')
+    E, it, st = eng.energies(A, h, max_iter=4000)
+    assert np.all(st == 0) and np.all(it == 1)
+    # the C oracle's plain power iteration (a different algorithm, same fixed point)
+    ref = c_oracle.energy_batch(A, h, max_iter=4000, want_r=True, want_rho=True)
+    ok = ref['status'] == 0
+    assert ok.mean() > 0.9
+    assert np.abs(E - ref['E'])[ok].max() < E_TOL
+    r = eng.environments()
+    assert np.abs(r - ref['r'])[ok].max() < R_TOL
+    assert np.abs(eng.rdm() - ref['rho'])[ok].max() < R_TOL
+    assert np.allclose(eng.summed_cost(), E.sum(0), rtol=0, atol=1e-9 * max(1, B))
+    # the oracle's direct restatement and the reference's dense-eig route, item by item
+    for b in range(0, B, max(1, B // 40)):
+        rd, itd, std = O.env_direct(A[b], max_iter=4000)
+        assert (itd, std) == (1, 0) and np.abs(r[b] - rd).max() < 1e-12
+        assert np.abs(r[b] - O.env_dense_eig(A[b])[1]).max() < R_TOL
+        for t in range(3):
+            assert abs(E[b, t] - O.energy_closed_form(A[b], h[t], rd)) < 1e-12
+    # the CPU lock-step emulation of the kernel's own source: same arithmetic up to FMA contraction / reciprocals
+    emu = EMU.energies_d4(A, h, max_iter=4000)
+    assert np.array_equal(emu['status'], st) and np.array_equal(emu['iters'], it)
+    assert np.abs(E - emu['E']).max() < 1e-12 and np.abs(r - emu['r']).max() < 1e-12
+    # asynchronous launch without the environment store: same energies, environments no longer resident
+    eng.set_tensors(A)
+    eng.set_hamiltonian(h)
+    eng.launch(max_iter=4000, solver='direct', store_env=False)
+    E2, it2, st2 = eng.results()
+    assert np.array_equal(E2, E) and np.array_equal(st2, st)
+    from qmps_amd._lib import QmpsError
+    with pytest.raises(QmpsError):
+        eng.environments()
+    eng.cost_launch()
+    assert np.allclose(eng.get_cost(), E.sum(0), rtol=0, atol=1e-9 * max(1, B))
+
+
+def test_agrees_with_the_iterative_solvers(engine_factory):
+    rng = np.random.default_rng(77)
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 8, 3000))
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 0.7})
+    eng = engine_factory(4)
+    eng.set_solver('direct')
+    E, it, st = eng.energies(A, h)
+    r = eng.environments()
+    eng.set_solver('squaring', handoff=0)
+    E2, it2, st2 = eng.energies(A, h)
+    r2 = eng.environments()
+    eng.set_solver('plain')
+    E3, it3, st3 = eng.energies(A, h)
+    ok = (st == 0) & (st2 == 0) & (st3 == 0)
+    assert ok.mean() > 0.99
+    assert np.abs(E - E2)[ok].max() < E_TOL and np.abs(E - E3)[ok].max() < E_TOL
+    assert np.abs(r - r2)[ok].max() < R_TOL
+    eng.set_solver('direct')
+
+
+def test_fallback_paths(engine_factory):
+    """Evaluations the direct solve cannot accept continue inside the same launch with the power method 2^m steps at
+    a time: tensors that are not isometries (dominant eigenvalue != 1), a degenerate product state, the iteration cap."""
+    rng = np.random.default_rng(78)
+    B = 300
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 8, B))
+    mix = A.copy()
+    bad = rng.random(B) < 0.3                     # a minority per wave: quads that fall back next to quads that do not
+    mix[bad] = mix[bad] * rng.uniform(0.6, 1.5, size=(bad.sum(), 1, 1, 1)) \
+        + 0.05 * (rng.standard_normal(mix[bad].shape) + 1j * rng.standard_normal(mix[bad].shape))
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+    eng = engine_factory(4)
+    eng.set_solver('direct')
+    r, it, st = eng.env_batch(mix, max_iter=100000)
+    assert np.all(st == 0) and np.all(it[~bad] == 1) and np.all(it[bad] > 1) and np.isfinite(r).all()
+    for b in range(B):
+        rd, itd, std = O.env_direct(mix[b], max_iter=100000)
+        assert std == 0 and itd == it[b]
+        assert np.abs(r[b] - rd).max() < 1e-11
+    for b in np.flatnonzero(bad)[:30]:
+        assert np.abs(r[b] - O.env_dense_eig(mix[b])[1]).max() < R_TOL
+    emu = EMU.energies_d4(mix, h, max_iter=100000)
+    assert np.array_equal(emu['iters'], it) and np.abs(emu['r'] - r).max() < 1e-11
+    # the cap is reported, not hidden
+    E, it, st = eng.energies(mix[bad][:20], h, max_iter=3)
+    assert np.all(st == 1) and np.all(it == 3)
+    E, it, st = eng.energies(mix[bad][:20], h, max_iter=1)
+    assert np.all(st == 1) and np.all(it == 1)
+    # product state: rank-one environment, not positive definite (the reference's LinAlgError branch)
+    U = np.eye(8, dtype=complex)[None]
+    E, it, st = eng.energies(U, h, kind='unitary')
+    assert st[0] == 2 and abs(E[0, 0] + 1.0) < 1e-12
+    # empty batch
+    E, it, st = eng.energies(np.zeros((0, 2, 4, 4), complex), h)
+    assert E.shape == (0, 1)
+
+
+def test_direct_flag_errors(engine_factory):
+    from qmps_amd._lib import QmpsError
+    eng8 = engine_factory(8, 64)
+    rng = np.random.default_rng(5)
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 16, 8))
+    eng8.set_tensors(A)
+    eng8.set_hamiltonian(O.hamiltonian_matrix({'ZZ': -1, 'X': 1}))
+    with pytest.raises(QmpsError):
+        eng8.launch(solver='direct', store_env=False)      # the flag belongs to the fused D = 4 kernel
+    eng8.launch(solver='direct')                             # documented: other bond dimensions iterate
+    E, it, st = eng8.results()
+    assert np.all(st == 0) and np.all(it > 1)

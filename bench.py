@@ -5,19 +5,22 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input that is already resident
-in HBM: the fused power-iteration-environment + two-site-energy kernel over B evaluations, the
-device-side sum of the batch's energies and - for N > 1 - the path's single exchange step, ONE
-RCCL all-reduce of the summed cost over xGMI.  Workload = BASELINE.json configs[2]: TFIM g=1,
-D=4, B=65536 Haar-random state unitaries per GPU (weak scaling: every rank evaluates its own
-shard of the restarts x shifts x terms batch), tol 1e-13.
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+the environment solve + two-site energy over B evaluations (at D = 4 ONE fused kernel: direct fixed-point
+solve, acceptance power step, energies), the device-side sum of the batch's energies and - for N > 1 - the
+path's single exchange step, ONE RCCL all-reduce of the summed cost over xGMI PER STEP.
+Workload = BASELINE.json configs[2]: TFIM g=1, D=4, B=65536 Haar-random state unitaries, tol 1e-13.
 
-The product path uses no PyTorch: kernels, streams, events and the RCCL communicator live in
-libqmps_hip.so (ctypes).  For N > 1 torch.distributed (gloo, CPU) is used only as launcher
-plumbing: rendezvous, the barriers around the timed region, the broadcast of the RCCL unique id
-and the max-over-ranks of the elapsed time.
+  --rotate R   R distinct resident batches are cycled, one per step, so that no step re-reads what an earlier
+               one left in the 256 MiB Infinity Cache (default: the smallest R with R x batch bytes > 256 MiB).
+  --scaling    weak: --batch evaluations per GPU (default);  strong: --batch is the GLOBAL batch, rank r
+               evaluates the contiguous shard qmps_amd.dist.shard_bounds(B, r, N)  (B/G per GPU).
 
-Rank 0 prints ONE JSON line (see README / DESIGN.md section "Measurement").
+The product path uses no PyTorch: kernels, streams, events and the RCCL communicator live in libqmps_hip.so
+(ctypes).  For N > 1 torch.distributed (gloo, CPU) is launcher plumbing only: rendezvous, the barriers around
+the timed region, the broadcast of the RCCL unique id and the max-over-ranks of the elapsed time.
+
+Rank 0 prints ONE JSON line (DESIGN.md section "Measurement").
 """
 import argparse
 import json
@@ -40,6 +43,7 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector == FP64 matrix peak (= 157.3 TF FP32 vector / 2, MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
+MALL_MIB = 256            # Infinity Cache
 
 
 def flops_per_eval(D, K):
@@ -72,27 +76,42 @@ def tfim_h(g=1.0):
     return -np.kron(Z, Z) + 0.5 * g * (np.kron(I, X) + np.kron(X, I))
 
 
-def committed_traffic(kernel_name, D, B, solver, handoff):
-    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
-    (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, collected in separate rocprofv3 --pmc runs of this very
-    command); None when no profile of this configuration is committed."""
-    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+def committed_traffic(D, B, solver, store_env, rotate):
+    """HBM bytes per step from the PMC passes committed under profiles/ (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE,
+    collected in separate rocprofv3 --pmc runs of this very command, tools/prof.sh + tools/collect_profiles.py);
+    None when no profile of this configuration is committed."""
     try:
-        table = json.load(open(path))
+        table = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
     except Exception:
         return None
-    rec = table.get(f'{kernel_name}|D={D}|B={B}|solver={solver}|handoff={handoff}')
-    if not rec:
-        return None
-    return {'bytes': rec['bytes'], 'unit': 'B per launch', 'fetch_kb_x2': rec['fetch_kb_x2'], 'write_kb': rec['write_kb'],
-            'algorithmic_bytes': B * bytes_per_eval(D), 'source': rec['source']}
+    return table.get(f'D={D}|B={B}|solver={solver}|store_env={int(store_env)}|rotate={rotate}')
 
 
-def cpu_baseline(D, A, h, max_iter, tol, budget_s=12.0):
-    """The oracle ("port") timed on this box's host cores, on a bounded sample of the same workload
-    (~budget_s seconds of single-thread work), plus two context figures: all host threads (OpenMP) and the
-    reference-STRUCTURED numpy path (dense eig -> Cholesky -> null-space completion -> Kronecker state
-    vector -> dense psi^+ (1 x h x 1) psi) on a small slice."""
+# ---- CPU baselines (run BEFORE the GPU is initialised: the process-parallel leg forks) ------------------------
+def _one_blas_thread():
+    """numpy/scipy in a worker must not start its own thread pool: N workers x N BLAS threads would fight for N cores."""
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+
+
+def _ref_chunk(args):
+    from oracle import qmps_oracle as O
+    U, h = args
+    t = time.perf_counter()
+    for k in range(len(U)):
+        O.reference_structured_energy(U[k], h)
+    return time.perf_counter() - t
+
+
+def cpu_baseline(D, A, h, max_iter, tol, budget_s=8.0):
+    """The oracle ("port") timed on this box's host cores on a bounded sample of the same workload, plus:
+    all host threads (OpenMP), and the reference-STRUCTURED numpy path (dense eig -> Cholesky -> null-space
+    completion -> Kronecker state vector -> dense psi^+ (1 x h x 1) psi) on 1 core and
+    process-parallel over all host cores."""
+    import multiprocessing as mp
     from oracle import c_oracle as C
     from oracle import qmps_oracle as O
     C.build()
@@ -107,25 +126,45 @@ def cpu_baseline(D, A, h, max_iter, tol, budget_s=12.0):
     v1 = reps * len(A) / (time.perf_counter() - t)
     cores = os.cpu_count() or 1
     nthr = min(cores, C.max_threads())
+    C.energy_batch(A[:4096], h, max_iter=max_iter, tol=tol, threads=nthr)      # thread pool start-up outside the timing
     t = time.perf_counter()
     C.energy_batch(A, h, max_iter=max_iter, tol=tol, threads=nthr)
     vall = len(A) / (time.perf_counter() - t)
-    nref = min(len(A), 1500)
-    U = np.zeros((nref, 2 * D, 2 * D), dtype=complex)
-    for k in range(nref):                      # complete each tensor to a unitary (the reference's input)
-        U[k] = O.tensor_to_unitary(A[k])
+    out_all = {'value': vall, 'threads': nthr, 'host_cpus': cores, 'speedup_over_1_thread': vall / v1,
+               'sample': f'all {len(A)} evaluations, OpenMP, dynamic schedule'}
+    if vall < 50 * v1 and nthr >= 100:
+        out_all['note'] = ('below 50x: the OpenMP threads are the hardware threads of the host (two per core) and the kernel is '
+                           'a scalar complex loop per evaluation; see the process-parallel numpy leg for the other all-core figure')
+    # reference-structured numpy: one core, then a pool of forked workers over all cores
+    nref = min(len(A), 600)
+    U = np.stack([O.tensor_to_unitary(A[k]) for k in range(nref)])     # complete each tensor to a unitary (the reference's input)
+    _one_blas_thread()                                                 # "1 core" means one thread
     t = time.perf_counter()
     for k in range(nref):
         O.reference_structured_energy(U[k], h)
     vref = nref / (time.perf_counter() - t)
+    per_worker = max(50, int(vref * 4))                               # ~4 s of work per worker
+    nproc = cores
+    Up = U[np.arange(per_worker) % nref]
+    ctx = mp.get_context('fork')
+    try:
+        with ctx.Pool(nproc, initializer=_one_blas_thread) as pool:
+            pool.map(_ref_chunk, [(Up[:5], h)] * nproc)              # workers up and warm
+            t = time.perf_counter()
+            pool.map(_ref_chunk, [(Up, h)] * nproc, chunksize=1)
+            vpar = nproc * per_worker / (time.perf_counter() - t)
+        par = {'value': vpar, 'processes': nproc, 'speedup_over_1_core': vpar / vref,
+               'sample': f'{nproc} forked workers x {per_worker} evaluations each (cycled over the first {nref} of the workload)'}
+    except Exception as e:                                             # reported, never silent
+        par = {'value': None, 'error': repr(e)}
     return {'value': v1, 'unit': 'two-site energy evals/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{reps} pass(es) over the {len(A)} evaluations of the GPU workload, same seed, C oracle '
-                      f'(oracle/qmps_oracle.c: plain power iteration + closed-form energy), 1 thread',
-            'all_cores': {'value': vall, 'threads': nthr, 'host_cpus': cores, 'sample': f'all {len(A)} evaluations, OpenMP'},
+            'sample': f'{reps} pass(es) over the {len(A)} evaluations of the first resident batch of the GPU workload, same seed, '
+                      f'C oracle (oracle/qmps_oracle.c: plain power iteration + closed-form energy), 1 thread',
+            'all_cores': out_all,
             'reference_structured_numpy': {'value': vref, 'cores': 1,
-                                           'sample': f'first {nref} evaluations; dense eig + Cholesky + null-space '
-                                                     'completion + Kronecker state vector (the reference\'s per-evaluation '
-                                                     'structure, numpy/scipy)'}}
+                                           'sample': f'first {nref} evaluations; dense eig + Cholesky + null-space completion + '
+                                                     'Kronecker state vector (the reference\'s per-evaluation structure, numpy/scipy)',
+                                           'all_cores': par}}
 
 
 def squaring_schedule_ops(steps, skip, period, max_steps, e0_start):
@@ -147,15 +186,76 @@ def squaring_schedule_ops(steps, skip, period, max_steps, e0_start):
     return nsq, nmv
 
 
+def executed_flops(D, solver, iters, eng, max_iter):
+    """FLOPs of the algorithm the dominant kernel actually executed, from the iteration counts read back per item."""
+    n2 = (D * D) ** 3
+    direct = solver == 'direct' and D == 4
+    hybrid = (solver == 'squaring' and D <= 4) or (solver == 'direct' and D == 2)
+    handoff = eng.handoff if hybrid else 0
+    if direct:
+        # energy_direct_d4_kernel per evaluation (FMA = 2 flop), qmps_direct_core.h:
+        #   real 16 x 16 transfer matrix: 16 rows x (4 x 4 + 12 x 8) FMA                        = 1792 FMA
+        #   Gauss-Jordan on 16 x (16 + 1): 16 rows x sum_k (16 - k) FMA + 16 x 16 multipliers    = 2176 FMA + 256 mul
+        #   acceptance power step from the tensor: 4 rows x (2 x 4 x 14 + 4 x 8 x 4) FMA         =  960 FMA
+        #   two-site density matrix: B = A A 4 x 256, Y = B r 4 x 224, rho 4 x 128 FMA           = 2432 FMA
+        #   LDL^H test ~60 FMA, energy 28 FMA per term
+        # an evaluation that fell back (iters > 1) rebuilds R (3584 flop) and adds 2 x 16^3 + 2 x 16^2 flop per round
+        per = 2.0 * (1792 + 2176 + 960 + 2432 + 60 + 28) + 256
+        rounds = np.where(iters > 1, np.log2(np.maximum(iters - 1, 1)), 0.0)
+        flops = float((per + rounds * (2.0 * n2 + 2.0 * (D * D) ** 2) + (iters > 1) * 3584.0).sum())
+        note = ('executed algorithm of the fused kernel: real 16 x 16 transfer matrix (3584 flop) + Gauss-Jordan (4608) + '
+                'acceptance power step (1920) + density matrix / LDL^H / energy (5040) = 15152 flop per evaluation; squaring '
+                'rounds of fallen-back evaluations added from the iteration count read back per item')
+    elif hybrid and D == 4:
+        skip, period = eng.squaring_schedule
+        skip = skip if handoff == 0 else 0
+        sq_flops = np.zeros(len(iters))
+        for k in np.unique(iters):
+            if k <= handoff:
+                continue
+            nsq, nmv = squaring_schedule_ops(int(k) - handoff, skip, period, max_iter - handoff, handoff == 0)
+            sq_flops[iters == k] = 32.0 * D ** 4 + nsq * 2.0 * n2 + nmv * 2.0 * (D * D) ** 2
+        k_plain = np.minimum(iters, handoff).astype(np.float64)
+        plain_flops = k_plain * (32 * D ** 3 + 4 * D ** 2)
+        epilogue_flops = 64 * D ** 3 + 128 * D ** 2
+        flops = float(sq_flops.sum()) if handoff == 0 else float((plain_flops + sq_flops + epilogue_flops).sum())
+        note = ('executed algorithm: per item 32 D^4 (real transfer matrix) + n_sq 2 (D^2)^3 (squarings on the matrix cores) + '
+                'n_mv 2 (D^2)^2 (mat-vecs with T^(2^m)); n_sq, n_mv replayed from the iteration count read back per item')
+    elif hybrid:
+        k_plain = np.minimum(iters, handoff).astype(np.float64)
+        m_sq = np.where(iters > handoff, np.log2(np.maximum(iters - handoff, 1)), 0.0)
+        sq_flops = np.where(iters > handoff, m_sq * 2.0 * n2 + 32.0 * D ** 4, 0.0)
+        flops = float((k_plain * (32 * D ** 3 + 4 * D ** 2) + sq_flops + 64 * D ** 3 + 128 * D ** 2).sum())
+        note = ('executed algorithm: m = log2(K) squarings of the real D^2 x D^2 transfer matrix per item (2 (D^2)^3 flop each) + '
+                'its construction; K read back per item')
+    else:
+        flops = float(flops_per_eval(D, iters.astype(np.float64)).sum())
+        note = 'SURVEY 8(d): sum_b [K_b(32D^3+4D^2)+64D^3+128D^2], K_b read back per item'
+    return flops, note, handoff
+
+
+def shard_plan(scaling, batch, rank, world):
+    """(first evaluation, evaluations on this rank, global batch).  weak: `batch` per GPU; strong: `batch` is the global
+    batch and rank r owns the contiguous block qmps_amd.dist.shard_bounds(batch, r, world) (B/G per GPU)."""
+    from qmps_amd.dist import shard_bounds
+    if scaling == 'strong':
+        lo, hi = shard_bounds(batch, rank, world)
+        return lo, hi - lo, batch
+    return rank * batch, batch, world * batch
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    # defaults: the chip needs ~250 steps (~30 ms) of sustained load before its clocks settle (0.131 ms per step cold,
-    # 0.111-0.118 ms settled); a production sweep lives in the settled regime
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=300)
+    # defaults: the chip needs tens of ms of sustained load before its clocks settle (DESIGN.md section 5)
+    ap.add_argument('--steps', type=int, default=450)
+    ap.add_argument('--warmup', type=int, default=450)
     ap.add_argument('--D', type=int, default=4)
-    ap.add_argument('--batch', type=int, default=65536, help='evaluations per GPU per step')
+    ap.add_argument('--batch', type=int, default=65536, help='evaluations per GPU per step (weak) or in all (strong)')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--rotate', type=int, default=0,
+                    help='distinct resident batches cycled step by step (0 = smallest count whose tensors exceed the 256 MiB '
+                         'Infinity Cache; 1 = re-evaluate one resident batch)')
     ap.add_argument('--max-iter', type=int, default=10000)
     ap.add_argument('--tol', type=float, default=1e-13)
     ap.add_argument('--seed', type=int, default=20241022)
@@ -170,13 +270,13 @@ def main():
     ap.add_argument('--settle-ms', type=float, default=60.0,
                     help='milliseconds of sustained FP64 probe-kernel load before the warm-up steps, so that the power '
                          'management has raised the clocks whatever --warmup is (0 disables; reported in config)')
-    ap.add_argument('--exchange-every', type=int, default=16,
-                    help='N > 1: the summed costs of this many steps travel in one RCCL all-reduce (every step is still '
-                         'reduced exactly once; 1 = an exchange per step)')
+    ap.add_argument('--exchange-every', type=int, default=1,
+                    help='N > 1: the summed costs of this many steps travel in one RCCL all-reduce (1 = an exchange per step, the '
+                         'headline; a grouped figure is printed as an extra)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
-                    help='skip the informational host-to-host legs (PCIe-inclusive, ansatz-parameter-inclusive) that run after the '
-                         'timed region: under rocprofv3 the per-kernel averages then cover the timed workload only')
+                    help='skip the informational legs that run after the timed region (PCIe-inclusive, ansatz-parameter-inclusive, '
+                         'contraction-only, grouped exchange): under rocprofv3 the per-kernel averages then cover the timed workload only')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -186,6 +286,24 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py: --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)')
         sys.exit(f'bench.py: WORLD_SIZE={world} but --gpus {args.gpus}')
+
+    D = args.D
+    _, B, global_batch = shard_plan(args.scaling, args.batch, rank, world)
+    if B < 1:
+        sys.exit(f'bench.py: rank {rank} owns no evaluations (global batch {args.batch} over {world} ranks)')
+    tensor_bytes = 32 * D * D
+    R = args.rotate if args.rotate > 0 else max(1, -(-(MALL_MIB * 2 ** 20 + 1) // (B * tensor_bytes)))
+    R = min(R, 64)
+
+    # synthetic inputs: every rank draws its own R resident batches (seed + 1000 k + rank)
+    A_all = np.concatenate([haar_tensors(args.seed + 1000 * k + rank, D, B) for k in range(R)])
+    A = A_all[:B]
+    h = tfim_h(1.0)
+
+    # CPU baselines first: nothing has touched the GPU yet, so the process pool may fork
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline(D, A, h, args.max_iter, args.tol)
 
     dist = None
     force_dist = os.environ.get('QMPS_BENCH_FORCE_DIST') == '1'   # exercise the N > 1 code path at world_size 1
@@ -197,14 +315,9 @@ def main():
         dist.init_process_group('gloo', rank=rank, world_size=world)
 
     from qmps_amd import EnergyEngine, _lib
-    D, B = args.D, args.batch
-    eng = EnergyEngine(D, B, device=local_rank)
+    eng = EnergyEngine(D, R * B, device=local_rank)
     info = _lib.device_info(local_rank)
-
-    # synthetic inputs: every rank draws its own shard (seed + rank), resident in HBM before timing
-    A = haar_tensors(args.seed + rank, D, B)
-    h = tfim_h(1.0)
-    eng.set_tensors(A)
+    eng.set_tensors(A_all)
     eng.set_hamiltonian(h)
     if args.handoff is not None:
         eng.set_solver(args.solver, handoff=args.handoff)
@@ -222,6 +335,8 @@ def main():
         if ids[0] is not None:
             try:
                 eng.comm_init(ids[0], rank, world)
+                if eng.comm_count() != world:
+                    err = f'communicator has {eng.comm_count()} ranks, expected {world}'
             except _lib.QmpsError as e:
                 err = str(e)
         else:
@@ -232,8 +347,9 @@ def main():
         if rccl_ok:
             ex = max(1, min(16, args.exchange_every))
             eng.set_exchange_period(ex)
-            collective = ('one RCCL all-reduce(sum, f64[1]) per step' if ex == 1 else
-                          f'one RCCL all-reduce(sum, f64[{ex}]) per {ex} steps: every step\'s summed cost is reduced once, {ex} of them per message')
+            collective = (f'RCCL communicator of {eng.comm_count()} ranks (ncclCommCount); ' +
+                          ('one all-reduce(sum, f64[16]) per step' if ex == 1 else
+                           f'one all-reduce(sum, f64[{ex} x 16]) per {ex} steps: every step\'s summed cost is reduced once, {ex} of them per message'))
         else:
             # reported, never silent: the data path is unchanged (no collective in it); only the summed cost
             # travels over the launcher's gloo group, once, after the timed region
@@ -245,15 +361,18 @@ def main():
                          'summed cost reduced over gloo after the timed region'
             print(f'bench.py[rank {rank}]: {collective}', file=sys.stderr, flush=True)
 
-    # HIP events around the dominant kernel on >= 4 (and, from 64 steps on, >= 12) launches of the timed region, not
-    # on every one: a pair of events costs ~6 us of command-processor fencing per step
+    # HIP events around the dominant kernel on some launches of the timed region, not on every one: a pair of events
+    # costs several us of command-processor fencing per step
     timing_period = max(1, min(args.steps // 4, 16))
     eng.set_kernel_timing_period(timing_period)
 
     direct = args.solver == 'direct' and D == 4
     store_env = args.store_env or not direct
+    count = [0]
 
     def step():
+        eng.set_window((count[0] % R) * B)
+        count[0] += 1
         eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver, store_env=store_env)
         eng.cost_launch(B)
 
@@ -263,187 +382,168 @@ def main():
             dist.barrier()
         eng.sync()
 
+    def timed(n):
+        barrier()
+        t0 = time.perf_counter()
+        eng.timer_begin()
+        for _ in range(n):
+            step()
+        ev = eng.timer_end()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, ev
+
     # clock settle: sustained load from the library's FP64 probe kernel (not steps of the workload), see DESIGN.md section 5
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
         eng.probe_fp64_tflops()
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    eng.timer_begin()
-    for _ in range(args.steps):
-        step()
-    ev_ms = eng.timer_end()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, ev_ms = timed(args.steps)
 
     cost = eng.get_cost()
     if dist is not None and not rccl_ok:
+        import torch
         t = torch.tensor([float(cost[0])], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         cost = np.array([t.item()])
-    E, iters, status = eng.results()
-    # PCIe-inclusive rate (never `value`): host tensors in, energies out through the one-shot entry point
-    pcie_rate = None
+    kernel_ms, kernel_name = eng.kernel_time(args.steps)
+    # iteration counts / status of every resident batch (each window holds the results of its last step)
+    its, sts = [], []
+    for k in range(min(R, count[0])):
+        eng.set_window(k * B)
+        _, it_k, st_k = eng.results(B)
+        its.append(it_k)
+        sts.append(st_k)
+    iters, status = np.concatenate(its), np.concatenate(sts)
+    eng.set_window(0)
+
+    extras = {}
     if rank == 0 and not args.no_extras:
+        # PCIe-inclusive rate (never `value`): host tensors in, energies out through the one-shot entry point
         eng.set_solver(args.solver, handoff=args.handoff if args.handoff is not None else eng.handoff)
         eng.energies(A, h, max_iter=args.max_iter, tol=args.tol)
         t1 = time.perf_counter()
         for _ in range(3):
             eng.energies(A, h, max_iter=args.max_iter, tol=args.tol)
-        pcie_rate = 3 * B / (time.perf_counter() - t1)
-    # the reference's own call pattern (params -> energy, SparseFullEnergyOptimizer with the default ShallowCNOT ansatz,
-    # ground_state.py:150-168): only 8 P bytes per evaluation cross PCIe, the circuit is simulated on the device
-    # (never `value`; the ansatz family converges differently from Haar-random states, its mean step count is reported)
-    ansatz_rate = ansatz_iters = None
-    if rank == 0 and D in (2, 4, 8, 16) and not args.no_extras:
-        depth = {2: 1, 4: 2, 8: 3, 16: 4}[D]
-        prm = np.random.default_rng(args.seed + 7).standard_normal((B, 2 * depth))
+        extras['pcie_inclusive_evals_per_s'] = 3 * B / (time.perf_counter() - t1)
+        # the reference's own call pattern (params -> energy, SparseFullEnergyOptimizer with the default ShallowCNOT ansatz,
+        # ground_state.py:150-168): only 8 P bytes per evaluation cross PCIe, the circuit is simulated on the device
+        if D in (2, 4, 8, 16):
+            depth = {2: 1, 4: 2, 8: 3, 16: 4}[D]
+            prm = np.random.default_rng(args.seed + 7).standard_normal((B, 2 * depth))
 
-        def ansatz_eval():
-            eng.set_ansatz_params(_lib.ANSATZ_SHALLOW_CNOT, prm)
-            eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver, store_env=store_env)
-            return eng.results()
-        ansatz_eval()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            _, it_a, _ = ansatz_eval()
-        ansatz_rate = 3 * B / (time.perf_counter() - t1)
-        ansatz_iters = float(it_a.mean())
-        eng.set_tensors(A)                      # leave the engine as the timed region left it
-    # the contraction chain alone (north star: A - Abar - h - A - Abar with the resident environment, HBM-bound):
-    # energy-only launches over the same batch; algorithmic bytes = tensor + environment in, energy out
-    contraction = None
-    if rank == 0 and not args.no_extras:
-        eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver)
-        for _ in range(3):
-            eng.launch_energy_only()
+            def ansatz_eval():
+                eng.set_ansatz_params(_lib.ANSATZ_SHALLOW_CNOT, prm)
+                eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver, store_env=store_env)
+                return eng.results(B)
+            ansatz_eval()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                _, it_a, st_a = ansatz_eval()
+            extras['ansatz_params_inclusive'] = {
+                'evals_per_s': 3 * B / (time.perf_counter() - t1), 'mean_power_iterations': float(it_a.mean()),
+                'fallback_fraction': float((it_a > 1).mean()) if direct else None, 'not_converged_or_not_pd': int((st_a != 0).sum()),
+                'what': 'ShallowCNOT parameters in host memory -> energies in host memory (device-side circuit, environment, energy)'}
+        # the contraction chain alone (north star: A - Abar - h - A - Abar with the resident environment): energy-only launches
+        # over the rotating windows; bytes: SURVEY 8(d)'s 32 D^2 + 8 (headline accounting) and the 48 D^2 + 8 the launch
+        # really reads (tensor + environment)
+        eng.set_tensors(A_all)
+        for k in range(R):
+            eng.set_window(k * B)
+            eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver, store_env=True)
+        for k in range(2 * R):
+            eng.set_window((k % R) * B)
+            eng.launch_energy_only(B)
         eng.sync()
+        n_co = max(30, 3 * R)
         eng.timer_begin()
-        for _ in range(30):
-            eng.launch_energy_only()
-        us = eng.timer_end() / 30 * 1e3
-        cbytes = 48 * D * D + 8
-        contraction = {'us_per_launch': us, 'evals_per_s': B / (us * 1e-6), 'bytes_per_eval': cbytes,
-                       'hbm_gbps': B * cbytes / (us * 1e-6) * 1e-9, 'hbm_frac': B * cbytes / (us * 1e-6) * 1e-9 / HBM_PEAK_GBPS,
-                       'what': 'qmps_energy_only_launch over the resident batch (no environment solve)'}
-    total_iters = int(iters.sum())
+        for k in range(n_co):
+            eng.set_window((k % R) * B)
+            eng.launch_energy_only(B)
+        us = eng.timer_end() / n_co * 1e3
+        eng.set_window(0)
+        extras['contraction_only'] = {
+            'us_per_launch': us, 'evals_per_s': B / (us * 1e-6),
+            'hbm_gbps_520B': B * bytes_per_eval(D) / (us * 1e-6) * 1e-9, 'hbm_frac_520B': B * bytes_per_eval(D) / (us * 1e-6) * 1e-9 / HBM_PEAK_GBPS,
+            'hbm_gbps_tensor_plus_env': B * (48 * D * D + 8) / (us * 1e-6) * 1e-9,
+            'hbm_frac_tensor_plus_env': B * (48 * D * D + 8) / (us * 1e-6) * 1e-9 / HBM_PEAK_GBPS,
+            'working_set_mib': R * B * 48 * D * D / 2 ** 20,
+            'what': f'qmps_energy_only_launch (no environment solve) cycled over the {R} resident batches; reads tensor + environment '
+                    f'({48 * D * D + 8} B per evaluation); the {bytes_per_eval(D)} B figure is SURVEY 8(d)\'s accounting'}
+    if dist is not None and rccl_ok and not args.no_extras and args.exchange_every == 1:
+        # the grouped exchange (16 steps' costs per all-reduce) as an extra, every rank takes part
+        eng.set_tensors(A_all)
+        eng.set_exchange_period(16)
+        for _ in range(32):
+            step()
+        n16 = max(32, args.steps // 4)
+        el16, _ = timed(n16)
+        eng.set_exchange_period(1)
+        extras['grouped_exchange_16'] = {'evals_per_s': global_batch * n16 / el16,
+                                         'what': 'same steps, the summed costs of 16 consecutive steps per all-reduce'}
+
+    tot = np.array([float(iters.sum()), float((status != 0).sum()), float((iters > 1).sum()), float(len(iters))])
     if dist is not None:
         import torch
-        t = torch.tensor([float(total_iters), float((status != 0).sum())], dtype=torch.float64)
+        t = torch.tensor(tot, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        total_iters_all, bad_all = t[0].item(), t[1].item()
-    else:
-        total_iters_all, bad_all = float(total_iters), float((status != 0).sum())
+        tot = t.numpy()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
-        # dominant kernel: HIP events recorded by the library around it on every launch of the timed region
-        # (context stream); step_ms_events brackets the whole K-step region on the same stream
-        kernel_ms, kernel_name = eng.kernel_time(args.steps)
+        value = global_batch * args.steps / elapsed
         step_ms_events = ev_ms / args.steps
-        hybrid = args.solver == 'squaring' and D <= 4 or (args.solver == 'direct' and D == 2)
-        handoff = eng.handoff if hybrid else 0
-        n2 = (D * D) ** 3
-        if direct:
-            # executed algorithm of energy_direct_d4_kernel, per evaluation (FMA = 2 flop), qmps_direct_core.h:
-            #   real 16 x 16 transfer matrix: 16 rows x (4 x 4 + 12 x 8) FMA                         = 1792 FMA
-            #   Gauss-Jordan on 16 x (16 + 1): 16 rows x sum_k (16 - k) FMA + 16 x 16 multipliers     = 2176 FMA + 256 mul
-            #   acceptance power step from the tensor: 4 rows x (2 x 4 x 14 + 4 x 8 x 4) FMA          =  960 FMA
-            #   two-site density matrix: B = A A 4 x 256, Y = B r 4 x 224, rho 4 x 128 FMA            = 2432 FMA
-            #   LDL^H test ~60 FMA, energy 28 FMA per term
-            # evaluations that fell back to the squaring rounds (iters > 1) add 2 x 16^3 + 2 x 16^2 flop per round
-            per = 2.0 * (1792 + 2176 + 960 + 2432 + 60 + 28) + 256
-            rounds = np.where(iters > 1, np.log2(np.maximum(iters - 1, 1)), 0.0)
-            flops = float((per + rounds * (2.0 * n2 + 2.0 * (D * D) ** 2) + (iters > 1) * 3584.0).sum())
-            flop_note = ('executed algorithm of the fused kernel: real 16 x 16 transfer matrix (3584 flop) + Gauss-Jordan '
-                         '(4608) + acceptance power step (1920) + density matrix / LDL^H / energy (5040) per evaluation, '
-                         'squaring rounds of fallen-back evaluations added from the iteration count read back per item')
-        elif hybrid and D == 4:
-            # executed algorithm: min(K, handoff) plain steps in the lane kernel, then in
-            # env_square_d4_kernel: construction of the real 16 x 16 transfer matrix (32 D^4 flop), `skip` squarings
-            # (2 (D^2)^3 flop each), mat-vecs with T^(2^m) (2 (D^2)^2 flop each) and one more squaring after every
-            # `period` unconverged mat-vecs - the schedule is replayed from the iteration count read back per item
-            skip, period = eng.squaring_schedule
-            skip = skip if handoff == 0 else 0
-            sq_flops = np.zeros(len(iters))
-            for k in np.unique(iters):
-                if k <= handoff:
-                    continue
-                nsq, nmv = squaring_schedule_ops(int(k) - handoff, skip, period, args.max_iter - handoff, handoff == 0)
-                sq_flops[iters == k] = 32.0 * D ** 4 + nsq * 2.0 * n2 + nmv * 2.0 * (D * D) ** 2
-            k_plain = np.minimum(iters, handoff).astype(np.float64)
-            plain_flops = k_plain * (32 * D ** 3 + 4 * D ** 2)
-            epilogue_flops = 64 * D ** 3 + 128 * D ** 2
-            if handoff == 0:
-                flops = float(sq_flops.sum())           # env_square_d4_kernel only (energy is a separate pass)
-            else:
-                flops = float((plain_flops + sq_flops + epilogue_flops).sum())
-            flop_note = ('executed algorithm: per item 32 D^4 (real transfer matrix) + n_sq 2 (D^2)^3 (squarings on the matrix '
-                         'cores) + n_mv 2 (D^2)^2 (mat-vecs with T^(2^m)); n_sq, n_mv replayed from the iteration count read back per item')
-        elif hybrid:
-            # D = 2: in-lane squaring of the real 4 x 4 transfer matrix, m = log2(K - handoff) rounds
-            k_plain = np.minimum(iters, handoff).astype(np.float64)
-            m_sq = np.where(iters > handoff, np.log2(np.maximum(iters - handoff, 1)), 0.0)
-            sq_flops = np.where(iters > handoff, m_sq * 2.0 * n2 + 32.0 * D ** 4, 0.0)
-            plain_flops = k_plain * (32 * D ** 3 + 4 * D ** 2)
-            epilogue_flops = 64 * D ** 3 + 128 * D ** 2
-            flops = float((plain_flops + sq_flops + epilogue_flops).sum())
-            flop_note = ('executed algorithm: m = log2(K) squarings of the real D^2 x D^2 transfer matrix per item '
-                         '(2 (D^2)^3 flop each) + its construction; K read back per item')
-        else:
-            flops = float(flops_per_eval(D, iters.astype(np.float64)).sum())
-            flop_note = 'SURVEY 8(d): sum_b [K_b(32D^3+4D^2)+64D^3+128D^2], K_b read back per item'
+        # roofline of the dominant kernel: executed-algorithm FLOPs of ONE launch (mean over the resident batches)
+        flops_all, flop_note, handoff = executed_flops(D, args.solver, iters, eng, args.max_iter)
+        flops = flops_all / max(1, len(iters) // B)
         tflops = flops / (kernel_ms * 1e-3) * 1e-12
-        traffic = committed_traffic(kernel_name, D, B, args.solver, handoff)
+        traffic = committed_traffic(D, B, args.solver, store_env, R)
         hbm_gbps = B * bytes_per_eval(D) / (kernel_ms * 1e-3) * 1e-9
+        step_gbps = B * bytes_per_eval(D) / (step_ms_events * 1e-3) * 1e-9
         out = {
-            'metric': 'two-site energy evals/sec at D=4, batch=65536' if (D, B) == (4, 65536)
-                      else f'two-site energy evals/sec at D={D}, batch={B}',
+            'metric': 'two-site energy evals/sec at D=4, batch=65536' if (D, args.batch) == (4, 65536)
+                      else f'two-site energy evals/sec at D={D}, batch={args.batch}',
             'value': value, 'unit': 'two-site energy evals/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'TFIM g=1 two-site energy, D={D}, batch={B} per GPU, Haar-random state unitaries, '
-                                   f'in-kernel environment solve (tol {args.tol:g}, cap {args.max_iter}, solver {args.solver}'
-                                   f'{"" if store_env else ", environments not stored"})',
+            'config': {'workload': f'TFIM g=1 two-site energy, D={D}, '
+                                   + (f'batch={B} per GPU' if args.scaling == 'weak' else f'global batch={global_batch} split B/G per GPU')
+                                   + f', Haar-random state unitaries, in-kernel environment solve (tol {args.tol:g}, cap {args.max_iter}, '
+                                     f'solver {args.solver}{"" if store_env else ", environments not stored"}), {R} resident batches cycled',
                        'baseline_config': 'BASELINE.json configs[2]', 'D': D, 'batch_per_gpu': B,
-                       'global_batch': world * B, 'tol': args.tol, 'max_iter': args.max_iter, 'seed': args.seed,
+                       'global_batch': global_batch, 'tol': args.tol, 'max_iter': args.max_iter, 'seed': args.seed,
+                       'resident_batches': R, 'working_set_mib': R * B * tensor_bytes / 2 ** 20,
                        'clock_settle_ms': args.settle_ms,
-                       'mean_power_iterations': total_iters_all / (world * B),
-                       'max_power_iterations_rank0': int(iters.max()), 'not_converged_or_not_pd': int(bad_all),
+                       'mean_power_iterations': tot[0] / tot[3],
+                       'fallback_fraction': (tot[2] / tot[3]) if direct else None,
+                       'max_power_iterations_rank0': int(iters.max()), 'not_converged_or_not_pd': int(tot[1]),
                        'collective': collective,
                        'device': info['name'], 'arch': info['arch']},
             'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': tflops / FP64_PEAK_TFLOPS, 'traffic': traffic,
                          'kernel': kernel_name, 'kernel_ms': kernel_ms, 'step_ms_events': step_ms_events,
                          'kernel_timed_every': timing_period,
-                         # not a hardware rate: what a PLAIN power iteration of the same step counts would have to
-                         # sustain (SURVEY 8(d) formula with K = the equivalent power steps read back per item)
-                         'equivalent_plain_power_tflops': float(flops_per_eval(D, iters.astype(np.float64)).sum())
-                                                          / (kernel_ms * 1e-3) * 1e-12,
-                         'note': 'FP64-bound (MI355X FP64 vector == FP64 matrix peak = 78.6 TFLOP/s spec; measured on '
-                                 'this part: v_fma_f64 70.9, v_mfma_f64_16x16x4 47.7 TFLOP/s, profiles/r01_probe.json); '
-                                 'FLOPs = ' + flop_note,
+                         'note': 'FP64-VALU-bound kernel: `bound` names the FP64 peak (MI355X FP64 vector == FP64 matrix = 78.6 TFLOP/s '
+                                 'spec; measured on this part: v_fma_f64 70.9 TFLOP/s, profiles/r01_probe.json); the fused D = 4 kernel '
+                                 'issues no MFMA.  FLOPs = ' + flop_note,
                          'hbm': {'achieved': hbm_gbps, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                                 'frac': hbm_gbps / HBM_PEAK_GBPS, 'bytes_per_eval': bytes_per_eval(D)}},
+                                 'frac': hbm_gbps / HBM_PEAK_GBPS, 'bytes_per_eval': bytes_per_eval(D),
+                                 'whole_step_gbps': step_gbps, 'whole_step_frac': step_gbps / HBM_PEAK_GBPS,
+                                 'working_set_mib': R * B * tensor_bytes / 2 ** 20,
+                                 'note': f'algorithmic bytes (SURVEY 8(d): 32 D^2 + 8 = {bytes_per_eval(D)} B per evaluation) over the '
+                                         f'dominant kernel / the whole step; {R} resident batches cycled, tensors '
+                                         f'{"exceed" if R * B * tensor_bytes > MALL_MIB * 2 ** 20 else "fit inside"} the {MALL_MIB} MiB Infinity Cache'}},
             'summed_cost': float(cost[0]),
-            'pcie_inclusive_evals_per_s': pcie_rate,
-            'contraction_only': contraction,
-            'ansatz_params_inclusive': {'evals_per_s': ansatz_rate, 'mean_power_iterations': ansatz_iters,
-                                        'what': 'ShallowCNOT parameters in host memory -> energies in host memory '
-                                                '(device-side circuit, environment, energy)'},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(D, A, h, args.max_iter, args.tol)
-        elif not args.no_cpu_baseline:
-            out['cpu_baseline'] = None
+        out.update(extras)
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
 
     if dist is not None and rccl_ok:

@@ -137,6 +137,12 @@ int qmps_get_states(qmps_ctx* ctx, int64_t B, double* A);
 /* h[n_terms][4][4] complex128, row/col index = 2*s1+s2, s1 = left site
  * (qmps/ground_state.py:82-88 Hamiltonian.to_matrix).  1 <= n_terms <= 16. */
 int qmps_set_hamiltonian(qmps_ctx* ctx, int n_terms, const double* h);
+/* Batch window: a context may hold several resident batches side by side (one per Hamiltonian term group, restart
+ * group, ...; qmps_set_states / qmps_set_states_ansatz fill [0, B) of the buffers).  After qmps_set_window(first) the
+ * launch and read-back calls - qmps_energy_launch, qmps_energy_only_launch, qmps_cost_launch, qmps_sum_energies,
+ * qmps_get_energies, qmps_get_env, qmps_get_rdm - address evaluations [first, first + B) of the resident arrays
+ * (first + B <= number of resident states).  The qmps_set_* calls reset the window to 0. */
+int qmps_set_window(qmps_ctx* ctx, int64_t first);
 /* optional warm start r0[B][D][D] complex128 (Hermitian, any positive trace); NULL = identity/D */
 int qmps_set_env_guess(qmps_ctx* ctx, int64_t B, const double* r0);
 
@@ -246,8 +252,14 @@ int qmps_set_kernel_timing_period(qmps_ctx* ctx, int period);
 int qmps_comm_unique_id(char id[QMPS_UNIQUE_ID_BYTES]); /* rank 0 creates, host code broadcasts */
 int qmps_comm_init(qmps_ctx* ctx, const char id[QMPS_UNIQUE_ID_BYTES], int rank, int nranks);
 int qmps_comm_destroy(qmps_ctx* ctx);
+/* ranks that joined the communicator (ncclCommCount); 1 and QMPS_OK without a communicator */
+int qmps_comm_count(qmps_ctx* ctx, int* nranks);
 /* in-place sum over ranks of a small float64 vector held on the host (staged through HBM) */
 int qmps_allreduce_sum(qmps_ctx* ctx, double* inout, int n);
+/* COLLECTIVE CALLS.  With a communicator, every function that exchanges costs must be called by ALL ranks, in the same
+ * order, with the same exchange period: qmps_cost_launch (closes a group every `period` calls), and the calls that
+ * flush a partly filled group - qmps_sync, qmps_get_cost, qmps_allreduce_cost, qmps_set_exchange_period - as well as
+ * qmps_allreduce_sum.  A rank that calls one of them alone (e.g. only rank 0 logging the cost) blocks in ncclAllReduce. */
 /* Asynchronous: device-side cost[t] = sum_b E[b][t] on the context stream, followed - when a
  * communicator exists - by ONE ncclAllReduce(sum, double, n_terms) over all ranks on the context's
  * COMMUNICATION stream (ordered after the sum by an event, results in a 4-slot ring), so the exchange

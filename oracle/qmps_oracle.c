@@ -74,7 +74,7 @@ static void herm_normalise(int D, cplx* rn) {
 static int squaring_tail(int D, const cplx* A, cplx* r, int done, int max_iter, double tol2, int skip, int period,
                          int e0_start, int* st) {
   const int n = D * D;
-  static _Thread_local cplx P[256 * 256], Q[256 * 256];
+  cplx P[16 * 16], Q[16 * 16];   /* D <= 4 here: n = D^2 <= 16 (was 2 MB of thread-local storage per OpenMP thread) */
   cplx rC[256], rn[256];
   for (int i = 0; i < D; ++i) for (int ip = 0; ip < D; ++ip)
     for (int j = 0; j < D; ++j) for (int jp = 0; jp < D; ++jp) {
@@ -209,7 +209,7 @@ static void eval_one(int D, const cplx* A, const cplx* h, int nt, const cplx* r0
     it = k;
     if (d2 < tol2) { st = 0; break; }
   }
-  if (st == 1 && handoff >= 0 && plain < max_iter) it = squaring_tail(D, A, r, plain, max_iter, tol2, skip, period, handoff == 0 && !r0, &st);
+  if (st == 1 && handoff >= 0 && plain < max_iter && D <= 4) it = squaring_tail(D, A, r, plain, max_iter, tol2, skip, period, handoff == 0 && !r0, &st);
   /* Cholesky positive-definiteness check (LAPACK zpotrf criterion: pivot <= 0 or NaN fails) */
   if (st == 0) {
     cplx L[DMAX * DMAX];

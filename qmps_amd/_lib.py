@@ -41,6 +41,7 @@ SIGNATURES = {
     'qmps_get_states': (c_int, [c_void_p, c_int64, _dp]),
     'qmps_set_hamiltonian': (c_int, [c_void_p, c_int, _dp]),
     'qmps_set_env_guess': (c_int, [c_void_p, c_int64, _dp]),
+    'qmps_set_window': (c_int, [c_void_p, c_int64]),
     'qmps_energy_launch': (c_int, [c_void_p, c_int64, c_int, c_double, c_int]),
     'qmps_set_handoff': (c_int, [c_void_p, c_int]),
     'qmps_get_handoff': (c_int, [c_void_p, POINTER(c_int)]),
@@ -66,6 +67,7 @@ SIGNATURES = {
     'qmps_comm_unique_id': (c_int, [c_char_p]),
     'qmps_comm_init': (c_int, [c_void_p, c_char_p, c_int, c_int]),
     'qmps_comm_destroy': (c_int, [c_void_p]),
+    'qmps_comm_count': (c_int, [c_void_p, POINTER(c_int)]),
     'qmps_allreduce_sum': (c_int, [c_void_p, _dp, c_int]),
     'qmps_cost_launch': (c_int, [c_void_p, c_int64]),
     'qmps_set_exchange_period': (c_int, [c_void_p, c_int]),

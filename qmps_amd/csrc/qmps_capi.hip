@@ -92,6 +92,7 @@ struct qmps_ctx {
   // state
   int n_terms = 0;
   int64_t n_states = 0;
+  int64_t window = 0;               // first evaluation addressed by the launch / read-back calls (qmps_set_window)
   bool have_guess = false;
   bool have_env = false;
   bool want_rho = false;
@@ -138,17 +139,31 @@ int check_B(const qmps_ctx* c, int64_t B) {
   return QMPS_OK;
 }
 
+// launch / read-back calls: the window [window, window + B) must lie inside the buffers
+int check_window(const qmps_ctx* c, int64_t B) {
+  if (B < 0 || c->window + B > c->max_batch)
+    return fail(QMPS_ERR_ARG, "window [%lld, %lld) outside [0, max_batch=%lld]", (long long)c->window, (long long)(c->window + B), (long long)c->max_batch);
+  return QMPS_OK;
+}
+
+// addresses of the window's first evaluation
+char* win_A(const qmps_ctx* c) { return (char*)c->d_A + (size_t)c->window * tensor_bytes(c); }
+char* win_r(const qmps_ctx* c) { return (char*)c->d_r + (size_t)c->window * env_bytes(c); }
+double* win_E(const qmps_ctx* c) { return c->d_E + c->window * (c->n_terms > 0 ? c->n_terms : 1); }
+int32_t* win_iters(const qmps_ctx* c) { return c->d_iters + c->window; }
+int32_t* win_status(const qmps_ctx* c) { return c->d_status + c->window; }
+
 qmps::LaneArgs make_args(qmps_ctx* c, int64_t B, int max_iter, double tol, bool solve) {
   qmps::LaneArgs a;
   memset(&a, 0, sizeof(a));
-  a.A = c->d_A;
+  a.A = win_A(c);
   a.h = c->d_h;
-  a.r_in = solve ? (c->have_guess ? c->d_r : nullptr) : c->d_r;
-  a.r_out = solve ? c->d_r : nullptr;
-  a.rho_out = c->want_rho ? c->d_rho : nullptr;
-  a.E = c->d_E;
-  a.iters = c->d_iters;
-  a.status = c->d_status;
+  a.r_in = solve ? (c->have_guess ? win_r(c) : nullptr) : win_r(c);
+  a.r_out = solve ? win_r(c) : nullptr;
+  a.rho_out = c->want_rho ? (char*)c->d_rho + (size_t)c->window * 256 : nullptr;
+  a.E = win_E(c);
+  a.iters = win_iters(c);
+  a.status = win_status(c);
   a.B = B;
   a.n_terms = c->n_terms;
   a.max_iter = max_iter;
@@ -309,8 +324,17 @@ int qmps_set_states(qmps_ctx* c, int64_t B, const double* states, int kind) {
   // the caller's host buffer may be pageable and re-used right after the call returns
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->n_states = B;
+  c->window = 0;
   c->have_guess = false;
   c->have_env = false;
+  return QMPS_OK;
+}
+
+int qmps_set_window(qmps_ctx* c, int64_t first) {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  if (first < 0 || first > c->n_states) return fail(QMPS_ERR_ARG, "window start %lld outside the %lld resident states", (long long)first, (long long)c->n_states);
+  c->window = first;
+  c->partials_B = -1;
   return QMPS_OK;
 }
 
@@ -335,6 +359,7 @@ int qmps_set_states_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const
   HIP_TRY(qmps::launch_ansatz(c->D, kind, c->d_params, n_params, c->d_A, B, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->n_states = B;
+  c->window = 0;
   c->have_guess = false;
   c->have_env = false;
   return QMPS_OK;
@@ -344,6 +369,7 @@ int qmps_rotosolve(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
                    double tol, double* E_hist) {
   if (int rc = bind(c)) return rc;
   if (R < 1 || 3 * R > c->max_batch) return fail(QMPS_ERR_ARG, "3 R = %lld evaluations exceed max_batch = %lld", (long long)(3 * R), (long long)c->max_batch);
+  c->window = 0;
   if (!params || !E_hist) return fail(QMPS_ERR_ARG, "null argument");
   if (n_sweeps < 1) return fail(QMPS_ERR_ARG, "n_sweeps must be >= 1");
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "qmps_set_hamiltonian has not been called");
@@ -471,6 +497,7 @@ int qmps_set_hamiltonian(qmps_ctx* c, int n_terms, const double* h) {
 int qmps_set_env_guess(qmps_ctx* c, int64_t B, const double* r0) {
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;
+  c->window = 0;
   if (!r0) {
     c->have_guess = false;
     return QMPS_OK;
@@ -484,8 +511,8 @@ int qmps_set_env_guess(qmps_ctx* c, int64_t B, const double* r0) {
 
 int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int flags) {
   if (int rc = bind(c)) return rc;
-  if (int rc = check_B(c, B)) return rc;
-  if (B > c->n_states) return fail(QMPS_ERR_STATE, "B=%lld but only %lld states are resident", (long long)B, (long long)c->n_states);
+  if (int rc = check_window(c, B)) return rc;
+  if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "qmps_set_hamiltonian has not been called");
   if (max_iter < 1) return fail(QMPS_ERR_ARG, "max_iter must be >= 1");
   if (!(tol > 0.0)) return fail(QMPS_ERR_ARG, "tol must be > 0");
@@ -545,7 +572,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     // item count from HBM.
     qmps::SquareArgs q;
     memset(&q, 0, sizeof(q));
-    q.A = c->d_A; q.r_out = c->d_r; q.iters = c->d_iters; q.status = c->d_status;
+    q.A = win_A(c); q.r_out = win_r(c); q.iters = win_iters(c); q.status = win_status(c);
     q.B = B; q.done = c->handoff; q.max_iter = max_iter; q.tol = tol;
     q.skip = c->handoff == 0 ? c->skip_rounds : 0;
     q.period = c->matvec_period;
@@ -561,13 +588,13 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
       if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
       HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
       if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
-      q.r_in = c->d_r;
+      q.r_in = win_r(c);
       q.work_count = c->d_work_count;
       q.work_idx = c->d_work_idx;
       e.idx_list = c->d_work_idx;
       e.idx_count = c->d_work_count;
     } else {
-      q.r_in = c->have_guess ? c->d_r : nullptr;
+      q.r_in = c->have_guess ? win_r(c) : nullptr;
       e.partial = c->d_partial; c->partials_B = B; c->partials_n = lane_waves;   // the energy pass covers every item
     }
     // grid-stride workgroups of 4 waves: whole generations of the resident capacity (5 workgroups per CU), at most three
@@ -640,8 +667,8 @@ int qmps_get_squaring_schedule(qmps_ctx* c, int* skip_rounds, int* matvec_period
 
 int qmps_energy_only_launch(qmps_ctx* c, int64_t B) {
   if (int rc = bind(c)) return rc;
-  if (int rc = check_B(c, B)) return rc;
-  if (B > c->n_states) return fail(QMPS_ERR_STATE, "B=%lld but only %lld states are resident", (long long)B, (long long)c->n_states);
+  if (int rc = check_window(c, B)) return rc;
+  if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "qmps_set_hamiltonian has not been called");
   if (!c->have_env) return fail(QMPS_ERR_STATE, "no resident environment: run qmps_energy_launch or qmps_set_env_guess first");
   qmps::LaneArgs a = make_args(c, B, 1, 1.0, false);
@@ -658,13 +685,13 @@ int qmps_energy_only_launch(qmps_ctx* c, int64_t B) {
 static int sum_on_device(qmps_ctx* c, int64_t B) {
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
   c->partials_B = -1;   // d_partial is about to be overwritten by the generic two-pass reduction
-  HIP_TRY(qmps::launch_sum(c->d_E, B, c->n_terms, c->d_partial, kSumBlocks, c->d_cost, c->stream));
+  HIP_TRY(qmps::launch_sum(win_E(c), B, c->n_terms, c->d_partial, kSumBlocks, c->d_cost, c->stream));
   return QMPS_OK;
 }
 
 int qmps_sum_energies(qmps_ctx* c, int64_t B, double* cost) {
   if (int rc = bind(c)) return rc;
-  if (int rc = check_B(c, B)) return rc;
+  if (int rc = check_window(c, B)) return rc;
   if (!cost) return fail(QMPS_ERR_ARG, "null cost");
   if (int rc = sum_on_device(c, B)) return rc;
   HIP_TRY(hipMemcpyAsync(c->h_cost, c->d_cost, c->n_terms * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -675,28 +702,28 @@ int qmps_sum_energies(qmps_ctx* c, int64_t B, double* cost) {
 
 int qmps_get_energies(qmps_ctx* c, int64_t B, double* E, int32_t* iters, int32_t* status) {
   if (int rc = bind(c)) return rc;
-  if (int rc = check_B(c, B)) return rc;
+  if (int rc = check_window(c, B)) return rc;
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
-  if (E) HIP_TRY(hipMemcpyAsync(E, c->d_E, (size_t)B * c->n_terms * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  if (iters) HIP_TRY(hipMemcpyAsync(iters, c->d_iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-  if (status) HIP_TRY(hipMemcpyAsync(status, c->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (E) HIP_TRY(hipMemcpyAsync(E, win_E(c), (size_t)B * c->n_terms * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (iters) HIP_TRY(hipMemcpyAsync(iters, win_iters(c), (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (status) HIP_TRY(hipMemcpyAsync(status, win_status(c), (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
 
 int qmps_get_env(qmps_ctx* c, int64_t B, double* r) {
   if (int rc = bind(c)) return rc;
-  if (int rc = check_B(c, B)) return rc;
+  if (int rc = check_window(c, B)) return rc;
   if (!r) return fail(QMPS_ERR_ARG, "null r");
   if (!c->have_env) return fail(QMPS_ERR_STATE, "no resident environment");
-  HIP_TRY(hipMemcpyAsync(r, c->d_r, (size_t)B * env_bytes(c), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(r, win_r(c), (size_t)B * env_bytes(c), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
 
 int qmps_get_rdm(qmps_ctx* c, int64_t B, double* rho) {
   if (int rc = bind(c)) return rc;
-  if (int rc = check_B(c, B)) return rc;
+  if (int rc = check_window(c, B)) return rc;
   if (!rho) return fail(QMPS_ERR_ARG, "null rho");
   if (!c->have_env) return fail(QMPS_ERR_STATE, "no resident environment");
   if (!c->d_rho) HIP_TRY(hipMalloc(&c->d_rho, (size_t)c->max_batch * 256));
@@ -705,7 +732,7 @@ int qmps_get_rdm(qmps_ctx* c, int64_t B, double* rho) {
   int rc = qmps_energy_only_launch(c, B);
   c->want_rho = false;
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(rho, c->d_rho, (size_t)B * 256, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(rho, (char*)c->d_rho + (size_t)c->window * 256, (size_t)B * 256, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
@@ -992,6 +1019,14 @@ int qmps_comm_destroy(qmps_ctx* c) {
   return QMPS_OK;
 }
 
+int qmps_comm_count(qmps_ctx* c, int* nranks) {
+  if (int rc = bind(c)) return rc;
+  if (!nranks) return fail(QMPS_ERR_ARG, "null nranks");
+  *nranks = 1;
+  if (c->comm) RCCL_TRY(ncclCommCount(c->comm, nranks));
+  return QMPS_OK;
+}
+
 int qmps_allreduce_sum(qmps_ctx* c, double* inout, int n) {
   if (int rc = bind(c)) return rc;
   if (!inout || n < 1 || n > kMaxTerms) return fail(QMPS_ERR_ARG, "n=%d outside [1,%d]", n, kMaxTerms);
@@ -1035,7 +1070,7 @@ int qmps_set_exchange_period(qmps_ctx* c, int steps) {
 
 int qmps_cost_launch(qmps_ctx* c, int64_t B) {
   if (int rc = bind(c)) return rc;
-  if (int rc = check_B(c, B)) return rc;
+  if (int rc = check_window(c, B)) return rc;
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
   // device-side sum into this step's place in the current group of the ring (main stream) ...
   const int slot = (int)(c->groups % qmps_ctx::kCostSlots);
@@ -1047,7 +1082,7 @@ int qmps_cost_launch(qmps_ctx* c, int64_t B) {
     HIP_TRY(qmps::launch_sum_final(c->d_partial, c->partials_n, c->n_terms, dst, c->stream));
   else {
     c->partials_B = -1;   // the generic two-pass reduction reuses d_partial
-    HIP_TRY(qmps::launch_sum(c->d_E, B, c->n_terms, c->d_partial, kSumBlocks, dst, c->stream));
+    HIP_TRY(qmps::launch_sum(win_E(c), B, c->n_terms, c->d_partial, kSumBlocks, dst, c->stream));
   }
   c->last_slot = slot;
   c->last_pos = c->group_fill;

@@ -7,8 +7,9 @@ trajectories (poincare_map/2body_scars.py:445,607) - the same "independent units
 
 Product path: `RcclReducer` (ncclAllReduce inside libqmps_hip.so over xGMI; the unique id is
 exchanged by whatever launcher plumbing the host has - bench.py uses torch.distributed/gloo).
-`GlooReducer` performs the same reduction with torch.distributed on the CPU and exists so the
-N > 1 control flow is testable without GPUs.
+(The CPU test-suite plugs a torch.distributed/gloo reducer with the same `allreduce_sum` method into
+`ShardedCost` - tests/gloo_reducer.py - so the N > 1 control flow is testable without GPUs; the product
+package itself never imports torch.)
 """
 import numpy as np
 
@@ -30,20 +31,6 @@ class RcclReducer:
 
     def allreduce_sum(self, values):
         return self.engine.allreduce_sum(values)
-
-
-class GlooReducer:
-    """Same reduction over a torch.distributed (gloo) process group - CPU test plumbing."""
-
-    def __init__(self, group=None):
-        import torch
-        import torch.distributed as dist
-        self._torch, self._dist, self.group = torch, dist, group
-
-    def allreduce_sum(self, values):
-        t = self._torch.tensor(np.asarray(values, dtype=np.float64))
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
-        return t.numpy().copy()
 
 
 class ShardedCost:

@@ -103,6 +103,11 @@ class EnergyEngine:
         L.check(self._lib.qmps_set_hamiltonian(self._ctx, h.shape[0], _f64(h.view(np.float64))))
         self.n_terms = h.shape[0]
 
+    def set_window(self, first):
+        """Several resident batches side by side: after set_window(first) the launch / read-back calls address
+        evaluations [first, first + B) of the resident arrays (`set_*` calls reset the window to 0)."""
+        L.check(self._lib.qmps_set_window(self._ctx, int(first)))
+
     def set_env_guess(self, r0):
         if r0 is None:
             L.check(self._lib.qmps_set_env_guess(self._ctx, 0, None))
@@ -154,6 +159,9 @@ class EnergyEngine:
         L.check(self._lib.qmps_energy_only_launch(self._ctx, self.B if B is None else B))
 
     def sync(self):
+        """Waits for both streams.  COLLECTIVE when a communicator exists and a group of costs is partly filled (it is
+        exchanged now): call it on every rank, like `cost_launch`, `get_cost`, `allreduce_cost`, `allreduce_sum` and
+        `set_exchange_period`."""
         L.check(self._lib.qmps_sync(self._ctx))
 
     def results(self, B=None):
@@ -313,6 +321,12 @@ class EnergyEngine:
 
     def comm_init(self, unique_id, rank, nranks):
         L.check(self._lib.qmps_comm_init(self._ctx, unique_id, int(rank), int(nranks)))
+
+    def comm_count(self):
+        """Ranks that joined the communicator (1 without one)."""
+        n = ctypes.c_int(0)
+        L.check(self._lib.qmps_comm_count(self._ctx, byref(n)))
+        return n.value
 
     def comm_destroy(self):
         L.check(self._lib.qmps_comm_destroy(self._ctx))

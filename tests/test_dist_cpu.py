@@ -32,7 +32,8 @@ def _worker(rank, world, port, B, out):
     import torch.distributed as dist
     from oracle import c_oracle as C
     from oracle import qmps_oracle as O
-    from qmps_amd.dist import GlooReducer, ShardedCost
+    from qmps_amd.dist import ShardedCost
+    from tests.gloo_reducer import GlooReducer
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -46,6 +47,63 @@ def _worker(rank, world, port, B, out):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(root, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _plan_worker(rank, world, port, scaling, batch, out):
+    """bench.py's shard plan on every rank + one gloo all-reduce of the local summed cost: what `--scaling strong`
+    (global batch split B/G) and `--scaling weak` (batch per GPU) evaluate, with the oracle as the local evaluator."""
+    import torch
+    import torch.distributed as dist
+    from oracle import c_oracle as C
+    from oracle import qmps_oracle as O
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        lo, n, global_batch = _bench_module().shard_plan(scaling, batch, rank, world)
+        rng = np.random.default_rng(7)
+        A = O.unitary_to_tensor(O.haar_unitaries(rng, 8, global_batch))        # the same global batch on every rank
+        h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+        local = C.energy_batch(A[lo:lo + n], h)['E'].sum(0) if n else np.zeros(1)
+        t = torch.tensor(local)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        out[rank] = (lo, n, global_batch, t.numpy().copy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('scaling,batch', [('strong', 37), ('strong', 64), ('weak', 20)])
+def test_bench_shard_plan_world2(scaling, batch):
+    import torch.multiprocessing as mp
+    from oracle import c_oracle as C
+    from oracle import qmps_oracle as O
+    C.build()
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_plan_worker, args=(world, port, scaling, batch, out), nprocs=world, join=True)
+        res = [out[r] for r in range(world)]
+    global_batch = batch if scaling == 'strong' else world * batch
+    assert all(r[2] == global_batch for r in res)
+    assert res[0][0] == 0 and res[0][0] + res[0][1] == res[1][0] and res[1][0] + res[1][1] == global_batch   # contiguous, complete
+    if scaling == 'strong':
+        assert abs(res[0][1] - res[1][1]) <= 1                    # B/G per GPU
+    else:
+        assert res[0][1] == res[1][1] == batch
+    rng = np.random.default_rng(7)
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 8, global_batch))
+    expect = C.energy_batch(A, O.hamiltonian_matrix({'ZZ': -1, 'X': 1}))['E'].sum(0)
+    assert np.allclose(res[0][3], res[1][3], rtol=0, atol=0) and np.allclose(res[0][3], expect, rtol=0, atol=1e-11)
 
 
 @pytest.mark.parametrize('B', [101, 2])

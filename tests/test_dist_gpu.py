@@ -69,16 +69,19 @@ def test_grouped_exchange_keeps_every_step_cost(with_comm):
             eng.comm_destroy()
 
 
-def test_bench_distributed_code_path_world1():
-    """bench.py's N > 1 branch (gloo rendezvous, unique-id broadcast, RCCL init, all-reduce per step),
-    forced at world size 1 through the same launcher the driver uses."""
+@pytest.mark.parametrize('scaling', ['weak', 'strong'])
+def test_bench_distributed_code_path_world1(scaling):
+    """bench.py's N > 1 branch (gloo rendezvous, unique-id broadcast, RCCL init + ncclCommCount check, one all-reduce
+    per step, the grouped-exchange extra), forced at world size 1 through the same launcher the driver uses."""
     env = dict(os.environ, QMPS_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
            '127.0.0.1', '--master-port', '29517', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3',
-           '--warmup', '1', '--no-cpu-baseline', '--batch', '4096']
+           '--warmup', '1', '--no-cpu-baseline', '--batch', '4096', '--rotate', '3', '--scaling', scaling]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
     line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
     d = json.loads(line)
-    assert d['n_gpus'] == 1 and d['value'] > 1e6 and 'RCCL' in d['config']['collective']
+    assert d['n_gpus'] == 1 and d['value'] > 1e6 and 'RCCL communicator of 1 ranks' in d['config']['collective']
+    assert 'per step' in d['config']['collective'] and d['scaling'] == scaling and d['config']['resident_batches'] == 3
+    assert d['grouped_exchange_16']['evals_per_s'] > 1e6

@@ -373,7 +373,7 @@ def main():
     def step():
         eng.set_window((count[0] % R) * B)
         count[0] += 1
-        eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver, store_env=store_env)
+        eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver, store_env=store_env, accumulate_cost=direct)
         eng.cost_launch(B)
 
     def barrier():

@@ -82,6 +82,15 @@ extern "C" {
  * 16 D^2 bytes of HBM writes per evaluation).  qmps_get_env / qmps_get_rdm / qmps_energy_only_launch then fail with
  * QMPS_ERR_STATE until a launch without the flag has run. */
 #define QMPS_FLAG_NO_ENV_OUT 0x100
+/* flag (QMPS_ENV_DIRECT at D = 4): the launch also accumulates cost[t] = sum_b E[b][t] inside the kernel - every wave
+ * adds its partial sum as a 64-bit FIXED-POINT integer (scale 2^k chosen from ||h||_F and B) to one of 32 shards:
+ * integer addition commutes, so the sum is exact and independent of the order the waves finish in.  The
+ * qmps_cost_launch(B) that follows consumes it WITHOUT launching a reduction kernel (with a communicator the conversion
+ * to double runs on the communication stream in front of the all-reduce).  Partial sums beyond the isometric bound
+ * 16 ||h||_F (tensors that are not isometries, NaN) are added to a double instead.  Contract: the next call that
+ * launches must be qmps_cost_launch with the same B and window; a second accumulating launch before that fails with
+ * QMPS_ERR_STATE. */
+#define QMPS_FLAG_ACCUMULATE_COST 0x200
 /* With handoff == 0 (squaring from the start) the iterate is not tracked during the first
  * QMPS_SKIP_ROUNDS_D* squarings (no state converges in fewer than 2^skip power steps); the first
  * convergence test compares T^(2^(skip+1)) r_0 with T^(2^skip) r_0. */

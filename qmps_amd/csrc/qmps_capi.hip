@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 #include <new>
 
@@ -110,6 +111,17 @@ struct qmps_ctx {
   hipEvent_t cost_ready[kCostSlots] = {};    // sum kernels done (main stream)
   hipEvent_t cost_reduced[kCostSlots] = {};  // all-reduce done (comm stream)
   int64_t cost_launches = 0;
+  // exact in-kernel cost accumulation (QMPS_FLAG_ACCUMULATE_COST): one fixed-point accumulator per ring position
+  long long* d_acc = nullptr;                // [kCostSlots][kMaxGroup][kAccWords]
+  long long* h_acc = nullptr;                // pinned [kAccWords]
+  bool acc_is[kCostSlots][kMaxGroup] = {};   // the position's cost lives in its accumulator (not yet a double in the ring)
+  bool acc_dirty[kCostSlots][kMaxGroup] = {};  // the accumulator has been added to since it was last cleared
+  double acc_scale[kCostSlots][kMaxGroup] = {};
+  bool acc_pending = false;                  // an accumulating launch waits for its qmps_cost_launch
+  int64_t acc_B = 0, acc_window = 0;
+  int acc_slot = 0, acc_pos = 0;
+  double h_fro = 0.0;                        // max_t ||h_t||_F (qmps_set_hamiltonian)
+  long long* acc_at(int slot, int pos) const { return d_acc + ((size_t)slot * kMaxGroup + pos) * qmps::kAccWords; }
 };
 
 namespace {
@@ -251,6 +263,10 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
       HIP_TRY(hipEventCreateWithFlags(&c->cost_reduced[i], hipEventDisableTiming));
     }
     HIP_TRY(hipHostMalloc((void**)&c->h_cost, kMaxTerms * sizeof(double), hipHostMallocDefault));
+    const size_t acc_bytes = (size_t)qmps_ctx::kCostSlots * qmps_ctx::kMaxGroup * qmps::kAccWords * sizeof(long long);
+    HIP_TRY(hipMalloc((void**)&c->d_acc, acc_bytes));
+    HIP_TRY(hipMemsetAsync(c->d_acc, 0, acc_bytes, c->stream));
+    HIP_TRY(hipHostMalloc((void**)&c->h_acc, qmps::kAccWords * sizeof(long long), hipHostMallocDefault));
     HIP_TRY(hipMalloc((void**)&c->d_work_count, sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&c->d_work_idx, (size_t)max_batch * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(c->d_work_count, 0, sizeof(int32_t), c->stream));
@@ -285,10 +301,11 @@ int qmps_destroy(qmps_ctx* c) {
     if (c->cost_reduced[i]) (void)hipEventDestroy(c->cost_reduced[i]);
   }
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
-  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx};
+  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
+  if (c->h_acc) (void)hipHostFree(c->h_acc);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (int i = 0; i < qmps_ctx::kRing; ++i) {
@@ -490,6 +507,13 @@ int qmps_set_hamiltonian(qmps_ctx* c, int n_terms, const double* h) {
   if (int rc = ensure_E(c, n_terms)) return rc;
   HIP_TRY(hipMemcpyAsync(c->d_h, h, (size_t)n_terms * 256, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  c->h_fro = 0.0;
+  for (int t = 0; t < n_terms; ++t) {
+    double f = 0.0;
+    for (int i = 0; i < 32; ++i) f += h[32 * t + i] * h[32 * t + i];
+    f = sqrt(f);
+    if (f > c->h_fro) c->h_fro = f;
+  }
   c->n_terms = n_terms;
   return QMPS_OK;
 }
@@ -519,10 +543,15 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   int solver = flags & 0xff;
   if (solver != QMPS_ENV_POWER && solver != QMPS_ENV_POWER_SQUARING && solver != QMPS_ENV_DIRECT)
     return fail(QMPS_ERR_ARG, "unknown environment solver %d", solver);
-  if ((flags & ~0xff) & ~QMPS_FLAG_NO_ENV_OUT) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags & ~0xff);
+  if ((flags & ~0xff) & ~(QMPS_FLAG_NO_ENV_OUT | QMPS_FLAG_ACCUMULATE_COST)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags & ~0xff);
   const bool direct = solver == QMPS_ENV_DIRECT && c->D == 4;
-  if ((flags & QMPS_FLAG_NO_ENV_OUT) && !direct) return fail(QMPS_ERR_ARG, "QMPS_FLAG_NO_ENV_OUT needs QMPS_ENV_DIRECT at D = 4");
+  if ((flags & (QMPS_FLAG_NO_ENV_OUT | QMPS_FLAG_ACCUMULATE_COST)) && !direct)
+    return fail(QMPS_ERR_ARG, "QMPS_FLAG_NO_ENV_OUT / QMPS_FLAG_ACCUMULATE_COST need QMPS_ENV_DIRECT at D = 4");
+  if ((flags & QMPS_FLAG_ACCUMULATE_COST) && c->acc_pending)
+    return fail(QMPS_ERR_STATE, "the cost accumulated by the previous launch has not been consumed by qmps_cost_launch");
+  if ((flags & QMPS_FLAG_ACCUMULATE_COST) && c->capturing) return fail(QMPS_ERR_STATE, "no cost accumulation inside a graph capture");
   if (solver == QMPS_ENV_DIRECT && !direct) solver = QMPS_ENV_POWER_SQUARING;   // documented: D = 2, 8, 16 iterate
+  c->acc_pending = false;   // whatever an earlier launch accumulated no longer describes the resident energies
   qmps::LaneArgs a = make_args(c, B, max_iter, tol, true);
   const bool hybrid = solver == QMPS_ENV_POWER_SQUARING && c->D <= 4 && c->handoff < max_iter;
   c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
@@ -534,7 +563,36 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     // one read of A, one store of E (and, unless switched off, of r) per evaluation
     a.r_in = nullptr;
     a.r_out = (flags & QMPS_FLAG_NO_ENV_OUT) ? nullptr : c->d_r;
-    a.partial = c->d_partial; c->partials_B = B; c->partials_n = (int)((B + 15) / 16);
+    if (flags & QMPS_FLAG_ACCUMULATE_COST) {
+      // the position the following qmps_cost_launch will use; its accumulator must be clear, and the kernel clears the
+      // one after it (a position is reused after kCostSlots x period steps)
+      const int slot = (int)(c->groups % qmps_ctx::kCostSlots), pos = c->group_fill;
+      int nslot = slot, npos = pos + 1;
+      if (npos >= c->exchange_period) { nslot = (int)((c->groups + 1) % qmps_ctx::kCostSlots); npos = 0; }
+      if (c->acc_dirty[slot][pos]) {   // unusual call order (period changed, an accumulated cost was dropped): clear it now
+        HIP_TRY(hipMemsetAsync(c->acc_at(slot, pos), 0, qmps::kAccWords * sizeof(long long), c->stream));
+        c->acc_dirty[slot][pos] = false;
+      }
+      // a slot of the ring is touched again only after its previous exchange has finished
+      if (c->comm && nslot != slot && c->groups + 1 >= qmps_ctx::kCostSlots)
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->cost_reduced[nslot], 0));
+      a.acc = c->acc_at(slot, pos);
+      a.acc_zero = c->acc_dirty[nslot][npos] ? c->acc_at(nslot, npos) : nullptr;
+      // scale 2^k with B ||h||_F 2^k <= 2^61; per-wave partial sums beyond 16 ||h||_F bypass the fixed-point sum
+      const double hf = c->h_fro > 1e-300 ? c->h_fro : 1.0;
+      int k = (int)floor(61.0 - log2((double)(B > 0 ? B : 1) * hf));
+      if (k > 1000) k = 1000;
+      if (k < -1000) k = -1000;
+      a.acc_scale = ldexp(1.0, k);
+      a.acc_bound = 16.0 * hf * (1.0 + 1e-6);
+      c->acc_scale[slot][pos] = a.acc_scale;
+      c->acc_dirty[slot][pos] = true;
+      c->acc_dirty[nslot][npos] = false;
+      c->acc_pending = true; c->acc_B = B; c->acc_window = c->window; c->acc_slot = slot; c->acc_pos = pos;
+      c->partials_B = -1;
+    } else {
+      a.partial = c->d_partial; c->partials_B = B; c->partials_n = (int)((B + 15) / 16);
+    }
     c->dominant = "energy_direct_d4_kernel";
     if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy_direct_d4(a, c->stream));
@@ -1050,6 +1108,12 @@ int close_group(qmps_ctx* c) {
   if (c->comm) {
     HIP_TRY(hipEventRecord(c->cost_ready[slot], c->stream));
     HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->cost_ready[slot], 0));
+    for (int pos = 0; pos < c->group_fill; ++pos)
+      if (c->acc_is[slot][pos]) {   // fixed-point accumulators -> doubles, off the compute stream
+        HIP_TRY(qmps::launch_cost_finish(c->acc_at(slot, pos), 1.0 / c->acc_scale[slot][pos], c->n_terms,
+                                         base + (size_t)pos * kMaxTerms, c->comm_stream));
+        c->acc_is[slot][pos] = false;
+      }
     RCCL_TRY(ncclAllReduce(base, base, (size_t)c->group_fill * kMaxTerms, ncclDouble, ncclSum, c->comm, c->comm_stream));
     HIP_TRY(hipEventRecord(c->cost_reduced[slot], c->comm_stream));
   }
@@ -1078,12 +1142,17 @@ int qmps_cost_launch(qmps_ctx* c, int64_t B) {
   // a slot is reused only after its previous all-reduce has finished
   if (c->comm && c->group_fill == 0 && c->groups >= qmps_ctx::kCostSlots)
     HIP_TRY(hipStreamWaitEvent(c->stream, c->cost_reduced[slot], 0));
-  if (c->partials_B == B)   // the energy kernel already left per-wave partial sums: only the final pass is needed
+  c->acc_is[slot][c->group_fill] = false;
+  if (c->acc_pending && c->acc_B == B && c->acc_window == c->window && c->acc_slot == slot && c->acc_pos == c->group_fill) {
+    // the energy kernel has summed the batch itself (exact fixed-point accumulator): nothing to launch
+    c->acc_is[slot][c->group_fill] = true;
+  } else if (c->partials_B == B)   // the energy kernel already left per-wave partial sums: only the final pass is needed
     HIP_TRY(qmps::launch_sum_final(c->d_partial, c->partials_n, c->n_terms, dst, c->stream));
   else {
     c->partials_B = -1;   // the generic two-pass reduction reuses d_partial
     HIP_TRY(qmps::launch_sum(win_E(c), B, c->n_terms, c->d_partial, kSumBlocks, dst, c->stream));
   }
+  c->acc_pending = false;
   c->last_slot = slot;
   c->last_pos = c->group_fill;
   c->group_fill++;
@@ -1102,6 +1171,18 @@ int qmps_get_cost(qmps_ctx* c, double* cost) {
   if (int rc = close_group(c)) return rc;     // a partly filled group is exchanged now
   hipStream_t st = c->comm ? c->comm_stream : c->stream;
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->acc_is[c->last_slot][c->last_pos]) {
+    // no communicator: the cost still lives in its fixed-point accumulator; sum the shards on the host (exact)
+    HIP_TRY(hipMemcpyAsync(c->h_acc, c->acc_at(c->last_slot, c->last_pos), qmps::kAccWords * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const double inv = 1.0 / c->acc_scale[c->last_slot][c->last_pos];
+    for (int t = 0; t < c->n_terms; ++t) {
+      long long v = 0;
+      for (int sh = 0; sh < qmps::kAccShards; ++sh) v += c->h_acc[(t * qmps::kAccShards + sh) * qmps::kAccStride];
+      cost[t] = (double)v * inv + ((const double*)(c->h_acc + qmps::kAccOver))[t];
+    }
+    return QMPS_OK;
+  }
   HIP_TRY(hipMemcpyAsync(c->h_cost, c->d_cost_ring + ((size_t)c->last_slot * qmps_ctx::kMaxGroup + c->last_pos) * kMaxTerms,
                          c->n_terms * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));

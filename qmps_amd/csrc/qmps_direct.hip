@@ -55,14 +55,20 @@ struct QuadOps {
 };
 
 // The rare path, out of line: rebuild R, then the power method 2^m steps at a time.  Kept out of the kernel body so
-// that its register demand (two 16 x 16 matrices per quad) does not shape the register allocation of the main path.
-__device__ __attribute__((noinline)) bool squaring_fallback(int q, const double2* row, bool todo, int max_iter, double tol2,
-                                                            double (&x)[4], double& sq) {
+// that its register demand (two 16 x 16 matrices per quad) does not shape the register allocation of the main path;
+// everything travels in registers (a reference parameter would pin x to scratch memory in the MAIN path too).
+struct FallbackOut {
+  double x0, x1, x2, x3, sq;
+  int left;
+};
+__device__ __attribute__((noinline)) FallbackOut squaring_fallback(int q, const double2* row, bool todo, int max_iter,
+                                                                   double tol2, double x0, double x1, double x2, double x3) {
   using Core = DirectD4<QuadOps>;
   const QuadOps o{q, row};
-  double Rc[4][16];
+  double Rc[4][16], x[4] = {x0, x1, x2, x3}, sq = 0.0;
   Core::build(o, Rc);
-  return Core::squaring(o, Rc, todo, max_iter, tol2, x, sq);
+  const bool left = Core::squaring(o, Rc, todo, max_iter, tol2, x, sq);
+  return FallbackOut{x[0], x[1], x[2], x[3], sq, left ? 1 : 0};
 }
 
 }  // namespace
@@ -119,11 +125,11 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
     if (__any(todo)) {
       // rare: not an isometry / degenerate transfer spectrum.  Wave-uniform branch: every quad walks through the
       // rounds, only the `todo` ones take the result.
-      double sq = 0.0;
-      const bool left = squaring_fallback(q, o.row, todo, p.max_iter - 1, tol2, x, sq);
+      const FallbackOut f = squaring_fallback(q, o.row, todo, p.max_iter - 1, tol2, x[0], x[1], x[2], x[3]);
+      x[0] = f.x0; x[1] = f.x1; x[2] = f.x2; x[3] = f.x3;
       if (todo) {
-        steps = 1.0 + sq;
-        status = left ? QMPS_ST_NOT_CONVERGED : QMPS_ST_OK;
+        steps = 1.0 + f.sq;
+        status = f.left ? QMPS_ST_NOT_CONVERGED : QMPS_ST_OK;
       }
       Core::gather(x, us);
     }
@@ -134,13 +140,28 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
   double pre[4][4], pim[4][4];
   const bool pd = Core::density(o, us, pre, pim);
   if (status == QMPS_ST_OK && !pd) status = QMPS_ST_NOT_PD;
+  if (p.acc_zero != nullptr && blockIdx.x == 0) {
+    // clear the accumulator of a later step (nobody reads or adds to it during this launch)
+    for (int i = lane; i < p.n_terms * kAccShards; i += 64) p.acc_zero[i * kAccStride] = 0;
+    if (lane < 16) p.acc_zero[kAccOver + lane] = 0;
+  }
   for (int t = 0; t < p.n_terms; ++t) {
     const double en = quad_sum(Core::energy((const double*)p.h + 32 * t, pre, pim));
     if (valid && q == 0) p.E[b * p.n_terms + t] = en;
-    if (p.partial != nullptr) {
-      // first pass of the cost reduction: one partial per wave, fixed order
+    if (p.partial != nullptr || p.acc != nullptr) {
       const double s = wave_sum((valid && q == 0) ? en : 0.0);
-      if (lane == 0) p.partial[(int64_t)t * gridDim.x + blockIdx.x] = s;
+      if (lane == 0) {
+        // first pass of the cost reduction: one partial per wave, fixed order
+        if (p.partial != nullptr) p.partial[(int64_t)t * gridDim.x + blockIdx.x] = s;
+        if (p.acc != nullptr) {
+          // ... or the whole reduction: an exact fixed-point sum (order-independent), no second kernel
+          if (fabs(s) <= p.acc_bound)
+            atomicAdd((unsigned long long*)p.acc + (t * kAccShards + (blockIdx.x & (kAccShards - 1))) * kAccStride,
+                      (unsigned long long)__double2ll_rn(s * p.acc_scale));
+          else
+            atomicAdd((double*)(p.acc + kAccOver) + t, s);
+        }
+      }
     }
   }
   if (p.rho_out != nullptr) {
@@ -177,6 +198,23 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
       o2[l] = make_double2(re, im);
     }
   }
+}
+
+// acc (fixed point) -> cost[t]: integer sum of the shards (exact), one conversion, plus the overflow sum
+__global__ __launch_bounds__(64) void cost_finish_kernel(const long long* __restrict__ acc, double inv_scale, int n_terms,
+                                                         double* __restrict__ cost) {
+  const int lane = threadIdx.x;
+  for (int t = 0; t < n_terms; ++t) {
+    long long v = lane < kAccShards ? acc[(t * kAccShards + lane) * kAccStride] : 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0) cost[t] = (double)v * inv_scale + ((const double*)(acc + kAccOver))[t];
+  }
+}
+
+hipError_t launch_cost_finish(const long long* acc, double inv_scale, int n_terms, double* cost, hipStream_t st) {
+  hipLaunchKernelGGL(cost_finish_kernel, dim3(1), dim3(64), 0, st, acc, inv_scale, n_terms, cost);
+  return hipGetLastError();
 }
 
 hipError_t launch_energy_direct_d4(const LaneArgs& a, hipStream_t st) {

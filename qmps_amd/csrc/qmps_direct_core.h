@@ -131,21 +131,19 @@ struct DirectD4 {
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
       for (int l = 0; l < 4; ++l) M[r][4 * l + r] = M[r][4 * l + r] - w[l];   // - identity: column 4 q + r
-      y[r] = zero;
       dinv[r] = zero;
     }
     // + the trace functional on the LAST pivot row (lane 3, register 3), right-hand side e_15: the singular direction
     // of R - 1 is then resolved by the final pivot (measured on the 65536 Haar tensors of the benchmark: largest
-    // residual ||T(r) - r||_F 1.1e-15, against 3.9e-13 with the functional on row 0)
+    // residual ||T(r) - r||_F 1.1e-15, against 3.9e-13 with the functional on row 0).  The right-hand side stays e_15
+    // until that last pivot, so it is not carried through the elimination: at k = 15 row r receives -f_r.
 #pragma unroll
     for (int j = 0; j < 4; ++j) M[3][5 * j] = M[3][5 * j] + w[3];
-    y[3] = w[3];
     static_for<16>([&](auto K) {
       constexpr int k = decltype(K)::value, pl = k >> 2, pr = k & 3;
       V prow[16];
 #pragma unroll
       for (int j = k; j < 16; ++j) prow[j] = O::template bcast<pl>(M[pr][j]);
-      const V py = O::template bcast<pl>(y[pr]);
       const V pinv = O::rcp(prow[k]);
       const P mine = o.q_eq(pl);
       dinv[pr] = O::sel(mine, pinv, dinv[pr]);
@@ -155,9 +153,10 @@ struct DirectD4 {
         if (r == pr) f = O::sel(mine, zero, f);
 #pragma unroll
         for (int j = k + 1; j < 16; ++j) M[r][j] = O::fma(-f, prow[j], M[r][j]);
-        y[r] = O::fma(-f, py, y[r]);
+        if (k == 15) y[r] = -f;
       }
     });
+    y[3] = O::sel(o.q_eq(3), one, y[3]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = y[r] * dinv[r];
   }

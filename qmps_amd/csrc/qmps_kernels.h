@@ -32,7 +32,21 @@ struct LaneArgs {
   const int32_t* idx_count;
   int check_pd;               // !SOLVE: Cholesky test of the resident r, status 0 -> 2 on failure
   double* partial;            // nullable [n_terms][gridDim.x]: per-wave sums of the energies (lane kernels)
+  // exact in-kernel cost accumulation (energy_direct_d4_kernel): per-wave sums are added as 64-bit fixed-point integers
+  // (integer addition commutes: the result does not depend on the order the waves finish in) to
+  // acc[(term * kAccShards + shard) * kAccStride], shard = workgroup % kAccShards; a partial beyond acc_bound (tensor not
+  // an isometry, NaN) goes to the double acc[kAccOver + term] instead.  acc_zero: accumulator of a LATER step, cleared here.
+  long long* acc;
+  long long* acc_zero;
+  double acc_scale;           // 2^k
+  double acc_bound;
 };
+
+// layout of one cost accumulator (long long units): 16 terms x 32 shards, each shard on its own 64-byte line, then 16
+// doubles of overflow sums
+constexpr int kAccShards = 32, kAccStride = 8, kAccOver = 16 * kAccShards * kAccStride, kAccWords = kAccOver + 16;
+// acc -> cost[t] = (sum of the shards) / scale + overflow sum; one wave
+hipError_t launch_cost_finish(const long long* acc, double inv_scale, int n_terms, double* cost, hipStream_t st);
 
 // D = 4 repeated-squaring tail over the worklist (one wave per item, MFMA f64 16x16x4)
 struct SquareArgs {

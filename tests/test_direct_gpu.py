@@ -147,3 +147,63 @@ def test_direct_flag_errors(engine_factory):
     eng8.launch(solver='direct')                             # documented: other bond dimensions iterate
     E, it, st = eng8.results()
     assert np.all(st == 0) and np.all(it > 1)
+
+
+@pytest.mark.parametrize('with_comm', [False, True])
+def test_in_kernel_cost_accumulation(with_comm):
+    """QMPS_FLAG_ACCUMULATE_COST: the fused kernel sums the batch itself (fixed-point integers: exact, independent of
+    the order the waves finish in); qmps_cost_launch then launches nothing.  Every step of a long sequence (the ring of
+    accumulators wraps several times), grouped exchanges, partly filled groups, a dropped accumulation, the overflow
+    path for tensors that are not isometries, and bit-identical repeats."""
+    from qmps_amd import EnergyEngine
+    from qmps_amd._lib import QmpsError
+    rng = np.random.default_rng(91)
+    h = np.stack([O.hamiltonian_matrix({'ZZ': -1, 'X': 1}), O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})])
+    batches = [O.unitary_to_tensor(O.haar_unitaries(rng, 8, 777)) for _ in range(5)]
+    with EnergyEngine(4, 5 * 777) as eng:
+        if with_comm:
+            eng.comm_init(EnergyEngine.comm_unique_id(), 0, 1)
+        sums = []
+        for A in batches:
+            E, _, st = eng.energies(A, h)
+            assert np.all(st == 0)
+            sums.append(E.sum(0))
+        eng.set_tensors(np.concatenate(batches))
+        eng.set_hamiltonian(h)
+        for period in (1, 3):
+            eng.set_exchange_period(period)
+            for k in range(23):
+                eng.set_window((k % 5) * 777)
+                eng.launch(777, accumulate_cost=True, store_env=(k % 2 == 0))
+                eng.cost_launch(777)
+                if k % 4 == 3 or k == 22:
+                    c = eng.get_cost()
+                    assert np.abs(c - sums[k % 5]).max() < 1e-10, (period, k)
+        eng.set_exchange_period(1)
+        # the fixed-point sum does not depend on the order the waves finish in: bit-identical repeats
+        seen = set()
+        for _ in range(5):
+            eng.set_window(0)
+            eng.launch(777, accumulate_cost=True)
+            eng.cost_launch(777)
+            seen.add(eng.get_cost().tobytes())
+        assert len(seen) == 1
+        # contract: an accumulating launch must be consumed before the next one
+        eng.launch(777, accumulate_cost=True)
+        with pytest.raises(QmpsError):
+            eng.launch(777, accumulate_cost=True)
+        eng.launch(777)                       # an ordinary launch drops the pending accumulation ...
+        eng.cost_launch(777)                  # ... and this is the two-kernel path again
+        assert np.abs(eng.get_cost() - sums[0]).max() < 1e-10
+        eng.launch(777, accumulate_cost=True)
+        eng.cost_launch(777)
+        assert np.abs(eng.get_cost() - sums[0]).max() < 1e-10
+        # tensors far from isometries: energies beyond 16 ||h||_F per wave bypass the fixed-point sum (double adds)
+        big = 30.0 * batches[0]
+        Eb, _, stb = eng.energies(big, h, max_iter=100000)
+        assert np.all(stb == 0) and np.abs(Eb).max() > 1e4
+        eng.launch(777, max_iter=100000, accumulate_cost=True)
+        eng.cost_launch(777)
+        assert np.allclose(eng.get_cost(), Eb.sum(0), rtol=1e-12, atol=0)
+        if with_comm:
+            eng.comm_destroy()

@@ -68,7 +68,7 @@ extern "C" {
  * point, same tolerance; `iters` reports the equivalent number of power steps handoff + 2^m.
  * This is the default of the one-shot entry points. */
 #define QMPS_ENV_POWER_SQUARING 1
-/* DIRECT fixed-point solve (D = 4; the other bond dimensions run QMPS_ENV_POWER_SQUARING): what the reference itself
+/* DIRECT fixed-point solve (D = 4 and 8; D = 2 and 16 run QMPS_ENV_POWER_SQUARING): what the reference itself
  * does at qmps/tools.py:176-182 - an exact solve, not an iteration.  For a left isometry the transfer map preserves
  * the trace, so the environment solves the real D^2 x D^2 linear system (R - 1 + e t^T) u = e (R: the map in real
  * coordinates of the Hermitian r, t: trace functional), done by Gauss-Jordan elimination in registers.  The result is
@@ -76,7 +76,10 @@ extern "C" {
  * iterative solvers, so `status` keeps its meaning); an evaluation that fails the test (tensor not an isometry,
  * degenerate transfer spectrum) continues inside the same launch with the power method 2^m steps at a time from
  * r_0 = 1/D.  `iters` = 1 for an accepted direct solve, else 1 + 2^m.  A warm start (qmps_set_env_guess) is ignored.
- * Environment and energy are fused: one read of A, one store of E per evaluation. */
+ * D = 4: environment and energy are fused: one read of A, one store of E per evaluation.
+ * D = 8: the solve (one wave per evaluation, a row of the real 64 x 64 system per lane) writes r; the power-iteration
+ * kernel starts from it - its first step is the acceptance test (`iters` = 1), its plain iteration the fall-back
+ * (`iters` = steps taken). */
 #define QMPS_ENV_DIRECT 2
 /* flag (OR into `flags` of qmps_energy_launch): do not store the environments r[B][D][D] (QMPS_ENV_DIRECT only; saves
  * 16 D^2 bytes of HBM writes per evaluation).  qmps_get_env / qmps_get_rdm / qmps_energy_only_launch then fail with
@@ -168,7 +171,7 @@ int qmps_get_handoff(qmps_ctx* ctx, int* handoff);
 /* the squaring schedule in force for this context (QMPS_SKIP_ROUNDS_D*, QMPS_MATVEC_PERIOD_D4 unless a tuning
  * knob overrode them): untracked squarings, and D = 4 mat-vecs between further squarings (0 for D != 4) */
 int qmps_get_squaring_schedule(qmps_ctx* ctx, int* skip_rounds, int* matvec_period);
-/* solver used by qmps_energy_batch / qmps_env_batch / qmps_rotosolve (default: QMPS_ENV_DIRECT at D = 4,
+/* solver used by qmps_energy_batch / qmps_env_batch / qmps_rotosolve (default: QMPS_ENV_DIRECT at D = 4 and 8,
  * QMPS_ENV_POWER_SQUARING otherwise) */
 int qmps_set_default_solver(qmps_ctx* ctx, int solver);
 /* Energy only, from the resident states and the resident environments (no solve): the

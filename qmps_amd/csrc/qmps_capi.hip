@@ -271,7 +271,7 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     HIP_TRY(hipMalloc((void**)&c->d_work_idx, (size_t)max_batch * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(c->d_work_count, 0, sizeof(int32_t), c->stream));
     c->handoff = 0;   // D = 2, 4: squaring from the start (fastest); D = 8, 16 have no squaring path
-    c->default_solver = D == 4 ? QMPS_ENV_DIRECT : QMPS_ENV_POWER_SQUARING;
+    c->default_solver = (D == 4 || D == 8) ? QMPS_ENV_DIRECT : QMPS_ENV_POWER_SQUARING;
     c->skip_rounds = (D == 2) ? QMPS_SKIP_ROUNDS_D2 : QMPS_SKIP_ROUNDS_D4;
     if (const char* e = getenv("QMPS_SKIP_ROUNDS")) c->skip_rounds = atoi(e);   // tuning knob
     if (const char* e = getenv("QMPS_MATVEC_PERIOD")) c->matvec_period = atoi(e);   // tuning knob
@@ -550,9 +550,16 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   if ((flags & QMPS_FLAG_ACCUMULATE_COST) && c->acc_pending)
     return fail(QMPS_ERR_STATE, "the cost accumulated by the previous launch has not been consumed by qmps_cost_launch");
   if ((flags & QMPS_FLAG_ACCUMULATE_COST) && c->capturing) return fail(QMPS_ERR_STATE, "no cost accumulation inside a graph capture");
-  if (solver == QMPS_ENV_DIRECT && !direct) solver = QMPS_ENV_POWER_SQUARING;   // documented: D = 2, 8, 16 iterate
+  const bool direct8 = solver == QMPS_ENV_DIRECT && c->D == 8;
+  if (solver == QMPS_ENV_DIRECT && !direct) solver = QMPS_ENV_POWER_SQUARING;   // documented: D = 2, 16 iterate
   c->acc_pending = false;   // whatever an earlier launch accumulated no longer describes the resident energies
   qmps::LaneArgs a = make_args(c, B, max_iter, tol, true);
+  if (direct8) {
+    // D = 8: the direct solve (one wave per evaluation) leaves its result in the environment buffer; the power
+    // iteration of the block kernel starts from it: its first step is the acceptance test, its loop the fall-back
+    HIP_TRY(qmps::launch_env_direct_d8(win_A(c), win_r(c), B, c->stream));
+    a.r_in = win_r(c);
+  }
   const bool hybrid = solver == QMPS_ENV_POWER_SQUARING && c->D <= 4 && c->handoff < max_iter;
   c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
   const int slot = (int)(c->samples % qmps_ctx::kRing);

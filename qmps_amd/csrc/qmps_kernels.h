@@ -42,6 +42,9 @@ struct LaneArgs {
   double acc_bound;
 };
 
+// D = 8 direct fixed-point solve, one wave per evaluation: writes the environments r[B][8][8] (the warm start / result
+// that energy_block_kernel<8, true> then accepts with one power step)
+hipError_t launch_env_direct_d8(const void* A, void* r_out, int64_t B, hipStream_t st);
 // layout of one cost accumulator (long long units): 16 terms x 32 shards, each shard on its own 64-byte line, then 16
 // doubles of overflow sums
 constexpr int kAccShards = 32, kAccStride = 8, kAccOver = 16 * kAccShards * kAccStride, kAccWords = kAccOver + 16;

@@ -143,10 +143,56 @@ def test_direct_flag_errors(engine_factory):
     eng8.set_tensors(A)
     eng8.set_hamiltonian(O.hamiltonian_matrix({'ZZ': -1, 'X': 1}))
     with pytest.raises(QmpsError):
-        eng8.launch(solver='direct', store_env=False)      # the flag belongs to the fused D = 4 kernel
-    eng8.launch(solver='direct')                             # documented: other bond dimensions iterate
-    E, it, st = eng8.results()
-    assert np.all(st == 0) and np.all(it > 1)
+        eng8.launch(solver='direct', store_env=False)      # the flags belong to the fused D = 4 kernel
+    with pytest.raises(QmpsError):
+        eng8.launch(solver='direct', accumulate_cost=True)
+    eng2 = engine_factory(2, 64)
+    A2 = O.unitary_to_tensor(O.haar_unitaries(rng, 4, 8))
+    E, it, st = eng2.energies(A2, O.hamiltonian_matrix({'ZZ': -1, 'X': 1}))
+    eng2.launch(solver='direct')                            # documented: D = 2 and 16 iterate
+    E2, it2, st2 = eng2.results()
+    assert np.all(st2 == 0) and np.all(it2 > 1) and np.abs(E - E2).max() < E_TOL
+
+
+@pytest.mark.parametrize('B', [1, 37, 768, 3000])
+def test_direct_d8(B, c_oracle, engine_factory):
+    """D = 8 (BASELINE.json configs[3]): wave-per-evaluation direct solve of the real 64 x 64 system, accepted by the
+    first power step of the iteration kernel."""
+    rng = np.random.default_rng(8000 + B)
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 16, B))
+    h = np.stack([O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5}), O.hamiltonian_matrix({'ZZ': -1, 'X': 1})])
+    eng = engine_factory(8, 4096)
+    eng.set_solver('direct')
+    E, it, st = eng.energies(A, h)
+    assert np.all(st == 0) and np.all(it == 1)
+    ref = c_oracle.energy_batch(A, h, want_r=True, want_rho=True)
+    ok = ref['status'] == 0
+    assert ok.mean() > 0.9
+    assert np.abs(E - ref['E'])[ok].max() < E_TOL
+    r = eng.environments()
+    assert np.abs(r - ref['r'])[ok].max() < R_TOL
+    assert np.abs(eng.rdm() - ref['rho'])[ok].max() < R_TOL
+    for b in range(0, B, max(1, B // 10)):
+        rd, itd, std = O.env_direct(A[b])
+        assert (itd, std) == (1, 0) and np.abs(r[b] - rd).max() < 1e-12
+        assert np.abs(r[b] - O.env_dense_eig(A[b])[1]).max() < R_TOL
+    # the plain power iteration of the same kernel agrees
+    eng.set_solver('plain')
+    E2, it2, st2 = eng.energies(A, h)
+    both = (st2 == 0)
+    assert np.abs(E - E2)[both].max() < E_TOL and it2.mean() > 10
+    eng.set_solver('direct')
+    if B == 37:
+        # fall-back: tensors that are not isometries converge by the plain iteration from the (wrong) direct start;
+        # a product state (zero pivot in the elimination) restarts from 1/8
+        bad = A * rng.uniform(0.7, 1.4, size=(B, 1, 1, 1)) + 0.03 * (rng.standard_normal(A.shape) + 1j * rng.standard_normal(A.shape))
+        rb, itb, stb = eng.env_batch(bad, max_iter=20000)
+        assert np.all(stb == 0) and np.all(itb > 1) and np.isfinite(rb).all()
+        for k in range(0, B, 6):
+            assert np.abs(rb[k] - O.env_dense_eig(bad[k])[1]).max() < R_TOL
+        U = np.eye(16, dtype=complex)[None]
+        Ep, itp, stp = eng.energies(U, h[1], kind='unitary')
+        assert stp[0] in (1, 2) and abs(Ep[0, 0] + 1.0) < 1e-12
 
 
 @pytest.mark.parametrize('with_comm', [False, True])

@@ -205,18 +205,29 @@ int qmps_cell2_energy_batch(qmps_ctx* ctx, int64_t B, const double* U1, const do
                             int n_terms, int max_iter, double tol, double* E_out, int32_t* iters_out,
                             int32_t* status_out);
 
-/* Time-evolution overlap objective, D = 2 (qmps/new_time_evolve.py:193-221, scripts/loschmidt.py:209-239):
+/* Time-evolution overlap objective (qmps/new_time_evolve.py:193-221, scripts/loschmidt.py:209-239):
  * eta_b = dominant eigenvalue of x -> sum_{s<4} (WW . merge(A, A))_s x merge(B_b, B_b)_s^+ ; the reference's
- * 6-qubit circuit measures 2 |psi[0]| = |eta| and minimises -sqrt(|eta|).  A: one tensor [2][2][2] shared by
- * the batch (a_shared = 1, the usual case: the current state) or one per item.  Candidates B_b: tensors
- * (QMPS_INPUT_TENSOR), unitaries (QMPS_INPUT_UNITARY) or ansatz parameters built on the device
- * (QMPS_INPUT_ANSATZ_BASE + QMPS_ANSATZ_*, n_params each).  eta_out [B] complex128; r_out nullable
- * [B][2][2] (unit-Frobenius right fixed point, what xmps Map.right_fixed_point returns up to phase);
- * rounds_out = squarings used; status 1 = no unique dominant eigenvalue within max_rounds. */
+ * 6-qubit circuit measures 2 |psi[0]| = |eta| and minimises -sqrt(|eta|).  Any bond dimension of the context
+ * (the reference's `merge`, qmps/time_evolve_tools.py:20-23, hard-codes D = 2; the map itself does not).
+ * A: one tensor [2][D][D] shared by the batch (a_shared = 1, the usual case: the current state) or one per item.
+ * Candidates B_b: tensors (QMPS_INPUT_TENSOR), unitaries (QMPS_INPUT_UNITARY) or ansatz parameters built on the device
+ * (QMPS_INPUT_ANSATZ_BASE + QMPS_ANSATZ_*, n_params each).  eta_out [B] complex128; r_out nullable [B][D][D]
+ * (unit-Frobenius right fixed point, what xmps Map.right_fixed_point returns up to phase); status 1 = no unique
+ * dominant eigenvalue within max_rounds.
+ * Solver: D = 2 squares the 4 x 4 matrix of the map (max_rounds <= 60 squarings, rounds_out = squarings used);
+ * D = 4, 8, 16 run the power method in operator form from x_0 = 1/sqrt(D), eta = <x, T x>, stop when
+ * ||T x - eta x||_F < tol (max_rounds = cap on power steps, rounds_out = steps used) - at D = 16 on the matrix
+ * cores (v_mfma_f64_16x16x4, one wave per evaluation). */
 #define QMPS_INPUT_ANSATZ_BASE 16
 int qmps_overlap_batch(qmps_ctx* ctx, int64_t B, const double* A, int a_shared, const double* states, int kind,
                        int n_params, const double* WW, int max_rounds, double tol, double* eta_out, double* r_out,
                        int32_t* rounds_out, int32_t* status_out);
+/* The same in three steps, for candidates that stay resident (qmps_set_states / qmps_set_states_ansatz): reference
+ * tensor(s) + two-site operator in, asynchronous launch over the resident candidates [window, window + B), results out.
+ * want_r: also keep the fixed points (read back by qmps_overlap_get with r_out != NULL). */
+int qmps_overlap_set(qmps_ctx* ctx, int64_t n_ref /* 1 = shared, else one per candidate */, const double* A, const double* WW);
+int qmps_overlap_launch(qmps_ctx* ctx, int64_t B, int max_rounds, double tol, int want_r);
+int qmps_overlap_get(qmps_ctx* ctx, int64_t B, double* eta_out, double* r_out, int32_t* rounds_out, int32_t* status_out);
 
 /* Variational-environment objective, D = 2 (qmps/ground_state.py:170-228, selected by
  * SparseFullEnergyOptimizer(optimize_environment=True); the objective the reference's own Rotosolve test drives,

@@ -59,6 +59,9 @@ SIGNATURES = {
     'qmps_kernel_time': (c_int, [c_void_p, c_int, POINTER(c_float), c_char_p, c_int]),
     'qmps_set_kernel_timing_period': (c_int, [c_void_p, c_int]),
     'qmps_overlap_batch': (c_int, [c_void_p, c_int64, _dp, c_int, _dp, c_int, c_int, _dp, c_int, c_double, _dp, _dp, _ip, _ip]),
+    'qmps_overlap_set': (c_int, [c_void_p, c_int64, _dp, _dp]),
+    'qmps_overlap_launch': (c_int, [c_void_p, c_int64, c_int, c_double, c_int]),
+    'qmps_overlap_get': (c_int, [c_void_p, c_int64, _dp, _dp, _ip, _ip]),
     'qmps_opt_env_objective': (c_int, [c_void_p, c_int64, _dp, _dp, c_double, _dp, _dp]),
     'qmps_bw_expval': (c_int, [c_void_p, c_int64, c_int, _dp, _dp, _dp, c_int, _dp]),
     'qmps_bw_env': (c_int, [c_void_p, c_int64, c_int, _dp, _dp, _dp, _dp, c_int, c_double, _dp, _dp, _dp, _ip]),

@@ -94,6 +94,7 @@ struct qmps_ctx {
   int n_terms = 0;
   int64_t n_states = 0;
   int64_t window = 0;               // first evaluation addressed by the launch / read-back calls (qmps_set_window)
+  int64_t overlap_refs = 0;         // reference tensors resident for the overlap objective (1 = shared by the batch)
   bool have_guess = false;
   bool have_env = false;
   bool want_rho = false;
@@ -875,14 +876,72 @@ int qmps_kernel_time(qmps_ctx* c, int n_last, float* avg_ms, char* name, int nam
   return QMPS_OK;
 }
 
+int qmps_overlap_set(qmps_ctx* c, int64_t n_ref, const double* A, const double* WW) {
+  if (int rc = bind(c)) return rc;
+  if (!A || !WW) return fail(QMPS_ERR_ARG, "null argument");
+  if (n_ref < 1 || n_ref > c->max_batch) return fail(QMPS_ERR_ARG, "n_ref=%lld outside [1, max_batch]", (long long)n_ref);
+  // the current state(s) go to d_U (scratch of 2 tensors per item), WW to its own 256 bytes
+  if (!c->d_U) HIP_TRY(hipMalloc(&c->d_U, (size_t)c->max_batch * 2 * tensor_bytes(c)));
+  HIP_TRY(hipMemcpyAsync(c->d_U, A, (size_t)n_ref * tensor_bytes(c), hipMemcpyHostToDevice, c->stream));
+  if (!c->d_ww) HIP_TRY(hipMalloc(&c->d_ww, 256));
+  HIP_TRY(hipMemcpyAsync(c->d_ww, WW, 256, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->overlap_refs = n_ref;
+  return QMPS_OK;
+}
+
+int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int want_r) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_window(c, B)) return rc;
+  if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
+  if (c->overlap_refs < 1) return fail(QMPS_ERR_STATE, "qmps_overlap_set has not been called");
+  if (c->overlap_refs != 1 && c->overlap_refs < c->window + B) return fail(QMPS_ERR_STATE, "%lld reference tensors for window end %lld", (long long)c->overlap_refs, (long long)(c->window + B));
+  const int cap = c->D == 2 ? 60 : (1 << 24);
+  if (max_rounds < 1 || max_rounds > cap || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_rounds / tol (D = %d: max_rounds in [1, %d])", c->D, cap);
+  if (!c->d_eta) HIP_TRY(hipMalloc(&c->d_eta, (size_t)c->max_batch * 16));
+  qmps::OverlapArgs a;
+  memset(&a, 0, sizeof(a));
+  const bool shared = c->overlap_refs == 1;
+  a.A = shared ? (char*)c->d_U : (char*)c->d_U + (size_t)c->window * tensor_bytes(c);
+  a.Bt = win_A(c);
+  a.WW = c->d_ww;
+  a.eta = (char*)c->d_eta + (size_t)c->window * 16;
+  a.r_out = want_r ? win_r(c) : nullptr;
+  a.iters = win_iters(c); a.status = win_status(c); a.B = B; a.a_shared = shared ? 1 : 0; a.max_rounds = max_rounds; a.tol = tol;
+  c->dominant = c->D == 2 ? "overlap_lane_kernel" : (c->D == 16 && !getenv("QMPS_D16_BLOCK") ? "overlap_mfma_d16_kernel" : "overlap_block_kernel<D>");
+  c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
+  const int slot = (int)(c->samples % qmps_ctx::kRing);
+  if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+  if (c->D == 2) HIP_TRY(qmps::launch_overlap(a, c->stream));
+  else HIP_TRY(qmps::launch_overlap_d(c->D, a, getenv("QMPS_D16_BLOCK") == nullptr, c->stream));
+  if (c->timed) { HIP_TRY(hipEventRecord(c->kev1[slot], c->stream)); c->samples++; }
+  if (!c->capturing) c->launches++;
+  c->have_env = false;
+  c->have_guess = false;
+  c->acc_pending = false;
+  c->partials_B = -1;
+  return QMPS_OK;
+}
+
+int qmps_overlap_get(qmps_ctx* c, int64_t B, double* eta_out, double* r_out, int32_t* rounds_out, int32_t* status_out) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_window(c, B)) return rc;
+  if (!eta_out) return fail(QMPS_ERR_ARG, "null eta_out");
+  if (!c->d_eta) return fail(QMPS_ERR_STATE, "qmps_overlap_launch has not been called");
+  HIP_TRY(hipMemcpyAsync(eta_out, (char*)c->d_eta + (size_t)c->window * 16, (size_t)B * 16, hipMemcpyDeviceToHost, c->stream));
+  if (r_out) HIP_TRY(hipMemcpyAsync(r_out, win_r(c), (size_t)B * env_bytes(c), hipMemcpyDeviceToHost, c->stream));
+  if (rounds_out) HIP_TRY(hipMemcpyAsync(rounds_out, win_iters(c), (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
+  if (status_out) HIP_TRY(hipMemcpyAsync(status_out, win_status(c), (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+
 int qmps_overlap_batch(qmps_ctx* c, int64_t B, const double* A, int a_shared, const double* states, int kind,
                        int n_params, const double* WW, int max_rounds, double tol, double* eta_out, double* r_out,
                        int32_t* rounds_out, int32_t* status_out) {
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;
-  if (c->D != 2) return fail(QMPS_ERR_ARG, "the time-evolution overlap path is D = 2 only (qmps/time_evolve_tools.py)");
   if (!A || !WW || !eta_out || (!states && B > 0)) return fail(QMPS_ERR_ARG, "null argument");
-  if (max_rounds < 1 || max_rounds > 60 || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_rounds / tol");
   // candidates -> d_A: tensors, unitaries or ansatz parameters
   if (kind == QMPS_INPUT_TENSOR || kind == QMPS_INPUT_UNITARY) {
     if (int rc = qmps_set_states(c, B, states, kind)) return rc;
@@ -891,25 +950,10 @@ int qmps_overlap_batch(qmps_ctx* c, int64_t B, const double* A, int a_shared, co
   } else {
     return fail(QMPS_ERR_ARG, "unknown input kind %d", kind);
   }
-  // the current state(s) go to d_U (scratch, >= 16 B * 2 * 8 bytes per item), WW behind the Hamiltonians
-  const size_t abytes = (size_t)(a_shared ? 1 : B) * 128;
-  if (!c->d_U) HIP_TRY(hipMalloc(&c->d_U, (size_t)c->max_batch * 2 * tensor_bytes(c)));
-  HIP_TRY(hipMemcpyAsync(c->d_U, A, abytes, hipMemcpyHostToDevice, c->stream));
-  if (!c->d_ww) HIP_TRY(hipMalloc(&c->d_ww, 256));
-  HIP_TRY(hipMemcpyAsync(c->d_ww, WW, 256, hipMemcpyHostToDevice, c->stream));
-  if (!c->d_eta) HIP_TRY(hipMalloc(&c->d_eta, (size_t)c->max_batch * 16));
-  qmps::OverlapArgs a;
-  memset(&a, 0, sizeof(a));
-  a.A = c->d_U; a.Bt = c->d_A; a.WW = c->d_ww; a.eta = c->d_eta; a.r_out = r_out ? c->d_r : nullptr;
-  a.iters = c->d_iters; a.status = c->d_status; a.B = B; a.a_shared = a_shared ? 1 : 0; a.max_rounds = max_rounds; a.tol = tol;
-  HIP_TRY(qmps::launch_overlap(a, c->stream));
-  HIP_TRY(hipMemcpyAsync(eta_out, c->d_eta, (size_t)B * 16, hipMemcpyDeviceToHost, c->stream));
-  if (r_out) HIP_TRY(hipMemcpyAsync(r_out, c->d_r, (size_t)B * 64, hipMemcpyDeviceToHost, c->stream));
-  if (rounds_out) HIP_TRY(hipMemcpyAsync(rounds_out, c->d_iters, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
-  if (status_out) HIP_TRY(hipMemcpyAsync(status_out, c->d_status, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  c->have_env = false;
-  return QMPS_OK;
+  if (B == 0) return QMPS_OK;
+  if (int rc = qmps_overlap_set(c, a_shared ? 1 : B, A, WW)) return rc;
+  if (int rc = qmps_overlap_launch(c, B, max_rounds, tol, r_out != nullptr)) return rc;
+  return qmps_overlap_get(c, B, eta_out, r_out, rounds_out, status_out);
 }
 
 // ---- brick-wall (new_tdvp) contractions -------------------------------------------------------

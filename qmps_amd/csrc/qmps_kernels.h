@@ -119,7 +119,10 @@ struct OverlapArgs {
   int max_rounds;
   double tol;
 };
-hipError_t launch_overlap(const OverlapArgs& a, hipStream_t st);
+hipError_t launch_overlap(const OverlapArgs& a, hipStream_t st);   // D = 2 (lane kernel, squaring)
+// D = 4, 8, 16: operator-form power method (qmps_overlap.hip); tensors [2][D][D]; max_rounds = cap on power steps;
+// mfma: D = 16 on the matrix cores (one wave per evaluation) instead of the generic LDS-tile kernel
+hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st);
 // brick-wall (new_tdvp) contractions: what = 0 two-site <O>, 1 four-site <O>, 2 environment matrix + eigenpair, 3 manifold overlap
 struct BwArgs {
   const void *U1, *U2, *U1p, *U2p;   // [B][4][4] complex

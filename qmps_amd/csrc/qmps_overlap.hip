@@ -1,0 +1,350 @@
+// qmps_overlap.hip - time-evolution overlap objective at bond dimension D = 4, 8, 16 (gfx950 only).
+//
+// Reference: qmps/new_time_evolve.py:193-221, scripts/loschmidt.py:209-239 and qmps/time_evolve_tools.py:20-23 (`merge`,
+// whose final reshape hard-codes D = 2 in the reference; the mathematics is bond-dimension agnostic):
+//   T(x) = sum_{s=0..3} C_s x Bm_s^+ ,   C = WW . merge(A, A) ,   Bm = merge(B, B) ,   merge(A, A)[2 s1 + s2] = A_s1 A_s2
+// eta = dominant eigenvalue of T (complex; T is not Hermitian).  The reference's circuit measures 2 |psi[0]| = |eta|
+// and minimises -sqrt(|eta|), so the kernel is only the dominant-eigenvalue solve.
+//
+// Power method in operator form (never builds the D^2 x D^2 matrix): x <- T(x)/||T(x)||_F from x_0 = 1/sqrt(D),
+// eta = <x, T x> (Rayleigh quotient, ||x||_F = 1), stop when ||T x - eta x||_F < tol.  status 1 = no unique dominant
+// eigenvalue within max_steps.  The D = 2 path (overlap_lane_kernel, qmps_kernels.hip) squares the 4 x 4 matrix instead.
+//
+//   overlap_block_kernel<D>    D = 4, 8, 16: thread (i, j) of a D x D tile per evaluation (D = 4: four evaluations per
+//                              wave, one per DPP row), tiles of C_s, Bm_s, x, Y_s = x Bm_s^+ in LDS.
+//   overlap_mfma_d16_kernel    D = 16: ONE WAVE PER EVALUATION on the matrix cores.  A complex 16 x 16 x 16 product is
+//                              4 real v_mfma_f64_16x16x4_f64 chains; per step Y_s = x Bm_s^+ and x' += C_s Y_s for the
+//                              four s: 128 MFMAs, register to register but for ONE LDS transpose of x
+//                              (layouts as in energy_mfma_d16_kernel: C-layout of a product == B-layout of the next;
+//                              Bm_s^+ in B-layout == conj of Bm_s in A-layout).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qmps_kernels.h"
+#include "qmps_device.h"
+
+namespace qmps {
+
+namespace {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ void cfma(double2 a, double2 b, double2& c) {   // c += a b
+  c.x = dfma(a.x, b.x, c.x);
+  c.x = dfma(-a.y, b.y, c.x);
+  c.y = dfma(a.x, b.y, c.y);
+  c.y = dfma(a.y, b.x, c.y);
+}
+__device__ __forceinline__ void cfma_conj(double2 a, double2 b, double2& c) {   // c += a conj(b)
+  c.x = dfma(a.x, b.x, c.x);
+  c.x = dfma(a.y, b.y, c.x);
+  c.y = dfma(a.y, b.x, c.y);
+  c.y = dfma(-a.x, b.y, c.y);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// generic tile kernel
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_block_kernel(OverlapArgs p) {
+  constexpr int N = D * D, P = D + 1;
+  constexpr int THREADS = N < 64 ? 64 : N, ITEMS = THREADS / N, WAVES = THREADS / 64;
+  __shared__ double2 sC[ITEMS][4][D][P], sB[ITEMS][4][D][P], sX[ITEMS][D][P], sY[ITEMS][4][D][P];
+  __shared__ double red[4][WAVES > 1 ? WAVES : 1];
+  const int tid = threadIdx.x, e = tid / N, l = tid % N, i = l / D, j = l % D;
+  const int64_t b = (int64_t)blockIdx.x * ITEMS + e;
+  const bool valid = b < p.B;
+  const int64_t bb = valid ? b : p.B - 1;       // surplus lanes of the last workgroup shadow a real evaluation
+  // sum over the N threads of one evaluation (up to four values at a time), result in every one of them
+  auto group_sum4 = [&](double (&v)[4]) {
+    if constexpr (N == 16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = row16_sum(v[q]);
+    } else if constexpr (N == 64) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = wave_sum(v[q]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = wave_sum(v[q]);
+      __syncthreads();
+      if ((tid & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[q][tid >> 6] = v[q];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) t += red[q][w];
+        v[q] = t;
+      }
+    }
+  };
+  // ---- set-up: inputs through the Y tiles, then C_s = sum_t WW[s][t] A_t1 A_t2 and Bm_s = B_s1 B_s2
+  {
+    const double2* Ap = (const double2*)p.A + (p.a_shared ? 0 : bb * (2 * N));
+    const double2* Bp = (const double2*)p.Bt + bb * (2 * N);
+    sY[e][0][i][j] = Ap[l];
+    sY[e][1][i][j] = Ap[N + l];
+    sY[e][2][i][j] = Bp[l];
+    sY[e][3][i][j] = Bp[N + l];
+  }
+  __syncthreads();
+  {
+    double2 aa[4], bm[4];
+#pragma unroll
+    for (int t1 = 0; t1 < 2; ++t1)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        double2 u = make_double2(0.0, 0.0), v = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          cfma(sY[e][t1][i][k], sY[e][t2][k][j], u);
+          cfma(sY[e][2 + t1][i][k], sY[e][2 + t2][k][j], v);
+        }
+        aa[2 * t1 + t2] = u;
+        bm[2 * t1 + t2] = v;
+      }
+    const double2* W = (const double2*)p.WW;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      double2 c = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) cfma(W[s * 4 + t], aa[t], c);
+      sC[e][s][i][j] = c;
+      sB[e][s][i][j] = bm[s];
+    }
+  }
+  double2 x = make_double2(i == j ? 1.0 / __builtin_sqrt((double)D) : 0.0, 0.0);
+  double2 eta = make_double2(0.0, 0.0);
+  int iters = 0, status = QMPS_ST_NOT_CONVERGED;
+  bool active = true;
+  const double tol2 = p.tol * p.tol;
+  __syncthreads();
+  for (int k = 1; k <= p.max_rounds; ++k) {
+    if (!__syncthreads_or(active ? 1 : 0)) break;
+    sX[e][i][j] = x;
+    __syncthreads();
+    // Y_s = x Bm_s^+
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      double2 y = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int kk = 0; kk < D; ++kk) cfma_conj(sX[e][i][kk], sB[e][s][j][kk], y);
+      sY[e][s][i][j] = y;
+    }
+    __syncthreads();
+    // x' = sum_s C_s Y_s
+    double2 xn = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int kk = 0; kk < D; ++kk) cfma(sC[e][s][i][kk], sY[e][s][kk][j], xn);
+    // eta = <x, x'>, ||x'||^2, then the residual ||x' - eta x||^2   (||x||_F = 1)
+    double v[4] = {x.x * xn.x + x.y * xn.y, x.x * xn.y - x.y * xn.x, xn.x * xn.x + xn.y * xn.y, 0.0};
+    group_sum4(v);
+    const double2 et = make_double2(v[0], v[1]);
+    const double nn = v[2];
+    const double dr = xn.x - (et.x * x.x - et.y * x.y), di = xn.y - (et.x * x.y + et.y * x.x);
+    double w[4] = {dr * dr + di * di, 0.0, 0.0, 0.0};
+    group_sum4(w);
+    if (active) {
+      eta = et;
+      iters = k;
+      if (w[0] < tol2) {
+        status = QMPS_ST_OK;
+        active = false;
+      } else {
+        const double inv = nn > 0.0 ? 1.0 / __builtin_sqrt(nn) : 0.0;
+        x = make_double2(xn.x * inv, xn.y * inv);
+      }
+    }
+  }
+  if (!valid) return;
+  if (l == 0) {
+    ((double2*)p.eta)[b] = eta;
+    p.iters[b] = iters;
+    p.status[b] = status;
+  }
+  if (p.r_out != nullptr) ((double2*)p.r_out)[b * N + l] = x;
+}
+
+// ------------------------------------------------------------------------------------------
+// D = 16 on the matrix cores, one wave per evaluation
+// ------------------------------------------------------------------------------------------
+namespace {
+
+// C += P * Q, P in A-layout (pre/pim[kk] = P[row = c][k = 4 kk + g]), Q in B-layout (qre/qim[kk] = Q[k = 4 kk + g][col = c])
+__device__ __forceinline__ void cmma16(const double (&pre)[4], const double (&pim)[4], const v4f64& qre, const v4f64& qim,
+                                       v4f64& cre, v4f64& cim) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    cre = __builtin_amdgcn_mfma_f64_16x16x4f64(pre[kk], qre[kk], cre, 0, 0, 0);
+    cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pre[kk], qim[kk], cim, 0, 0, 0);
+    cre = __builtin_amdgcn_mfma_f64_16x16x4f64(-pim[kk], qim[kk], cre, 0, 0, 0);
+    cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pim[kk], qre[kk], cim, 0, 0, 0);
+  }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
+  constexpr int D = 16, LD = 17, WAVES = 4;
+  __shared__ double2 sT_all[WAVES][D * LD];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  double2* sT = sT_all[wave];
+  const double tol2 = p.tol * p.tol;
+  // C-layout register q of a matrix: element [row = 4 q + g][col = c];  A-layout slab kk: element [row = c][k = 4 kk + g]
+  auto to_a_layout = [&](const v4f64& re, const v4f64& im, double (&are)[4], double (&aim)[4]) {   // wave-private LDS transpose
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sT[(4 * q + g) * LD + c] = make_double2(re[q], im[q]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const double2 t = sT[c * LD + 4 * kk + g];
+      are[kk] = t.x;
+      aim[kk] = t.y;
+    }
+  };
+  for (int64_t b = (int64_t)blockIdx.x * WAVES + wave; b < p.B; b += (int64_t)gridDim.x * WAVES) {
+    const double2* Ap = (const double2*)p.A + (p.a_shared ? 0 : b * (2 * D * D));
+    const double2* Bp = (const double2*)p.Bt + b * (2 * D * D);
+    const double2* W = (const double2*)p.WW;
+    // ---- set-up: AA_t = A_t1 A_t2 and BB_t = B_t1 B_t2 (C-layout), C_s = sum_t WW[s][t] AA_t; both sets to A-layout
+    double cre[4][4], cim[4][4];     // C_s in A-layout (the P operand of x' += C_s Y_s)
+    double bre[4][4], bimn[4][4];    // conj(Bm_s) in A-layout == Bm_s^+ in B-layout (the Q operand of Y_s = x Bm_s^+)
+    {
+      double pa[2][4], pai[2][4], pb[2][4], pbi[2][4];   // A_s, B_s in A-layout
+      v4f64 qa[2], qai[2], qb[2], qbi[2];                 // A_s, B_s in B-layout (= C-layout)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const double2 va = Ap[(s * D + c) * D + 4 * kk + g], vb = Bp[(s * D + c) * D + 4 * kk + g];
+          pa[s][kk] = va.x; pai[s][kk] = va.y;
+          pb[s][kk] = vb.x; pbi[s][kk] = vb.y;
+          const double2 wa = Ap[(s * D + 4 * kk + g) * D + c], wb = Bp[(s * D + 4 * kk + g) * D + c];
+          qa[s][kk] = wa.x; qai[s][kk] = wa.y;
+          qb[s][kk] = wb.x; qbi[s][kk] = wb.y;
+        }
+      v4f64 aar[4], aai[4];
+#pragma unroll
+      for (int t1 = 0; t1 < 2; ++t1)
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          v4f64 zr = {0, 0, 0, 0}, zi = {0, 0, 0, 0};
+          cmma16(pa[t1], pai[t1], qa[t2], qai[t2], zr, zi);
+          aar[2 * t1 + t2] = zr;
+          aai[2 * t1 + t2] = zi;
+          v4f64 yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
+          cmma16(pb[t1], pbi[t1], qb[t2], qbi[t2], yr, yi);
+          double tr[4], ti[4];
+          to_a_layout(yr, yi, tr, ti);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            bre[2 * t1 + t2][kk] = tr[kk];
+            bimn[2 * t1 + t2][kk] = -ti[kk];
+          }
+        }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        v4f64 zr = {0, 0, 0, 0}, zi = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double2 w = W[s * 4 + t];
+          zr += w.x * aar[t] - w.y * aai[t];
+          zi += w.x * aai[t] + w.y * aar[t];
+        }
+        to_a_layout(zr, zi, cre[s], cim[s]);
+      }
+    }
+    // ---- power method, x in C-layout, ||x||_F = 1
+    v4f64 xr, xi;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      xr[q] = (c == 4 * q + g) ? 0.25 : 0.0;
+      xi[q] = 0.0;
+    }
+    double eta_r = 0.0, eta_i = 0.0;
+    int iters = 0, status = QMPS_ST_NOT_CONVERGED;
+    for (int k = 1; k <= p.max_rounds; ++k) {
+      double xar[4], xai[4];
+      to_a_layout(xr, xi, xar, xai);
+      v4f64 nr = {0, 0, 0, 0}, ni = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        v4f64 yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
+        const v4f64 qre = {bre[s][0], bre[s][1], bre[s][2], bre[s][3]};
+        const v4f64 qim = {bimn[s][0], bimn[s][1], bimn[s][2], bimn[s][3]};
+        cmma16(xar, xai, qre, qim, yr, yi);           // Y_s = x Bm_s^+
+        cmma16(cre[s], cim[s], yr, yi, nr, ni);       // x' += C_s Y_s
+      }
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a0 = dfma(xr[q], nr[q], a0);
+        a0 = dfma(xi[q], ni[q], a0);
+        a1 = dfma(xr[q], ni[q], a1);
+        a1 = dfma(-xi[q], nr[q], a1);
+        a2 = dfma(nr[q], nr[q], a2);
+        a2 = dfma(ni[q], ni[q], a2);
+      }
+      eta_r = wave_sum(a0);
+      eta_i = wave_sum(a1);
+      const double nn = wave_sum(a2);
+      double rs = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double dr = nr[q] - (eta_r * xr[q] - eta_i * xi[q]), di = ni[q] - (eta_r * xi[q] + eta_i * xr[q]);
+        rs = dfma(dr, dr, rs);
+        rs = dfma(di, di, rs);
+      }
+      const double res2 = lane0(wave_sum(rs));
+      iters = k;
+      if (res2 < tol2) {
+        status = QMPS_ST_OK;
+        break;
+      }
+      const double inv = nn > 0.0 ? 1.0 / __builtin_sqrt(nn) : 0.0;
+      xr = nr * inv;
+      xi = ni * inv;
+    }
+    if (lane == 0) {
+      ((double2*)p.eta)[b] = make_double2(eta_r, eta_i);
+      p.iters[b] = iters;
+      p.status[b] = status;
+    }
+    if (p.r_out != nullptr) {
+      double2* ro = (double2*)p.r_out + b * (D * D);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ro[(4 * q + g) * D + c] = make_double2(xr[q], xi[q]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st) {
+  if (a.B <= 0) return hipSuccess;
+  switch (D) {
+    case 4: hipLaunchKernelGGL((overlap_block_kernel<4>), dim3((unsigned)((a.B + 3) / 4)), dim3(64), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((overlap_block_kernel<8>), dim3((unsigned)a.B), dim3(64), 0, st, a); break;
+    case 16:
+      if (mfma) {
+        int grid = (int)((a.B + 3) / 4);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(overlap_mfma_d16_kernel, dim3(grid), dim3(256), 0, st, a);
+      } else {
+        hipLaunchKernelGGL((overlap_block_kernel<16>), dim3((unsigned)a.B), dim3(256), 0, st, a);
+      }
+      break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace qmps

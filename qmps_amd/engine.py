@@ -243,32 +243,64 @@ class EnergyEngine:
         self.n_terms = nt
         return E, it, st
 
-    def overlaps(self, A, candidates, WW, kind='tensor', ansatz=None, max_rounds=40, tol=1e-13, want_r=False):
-        """Time-evolution overlap (D = 2): dominant eigenvalue eta of the mixed two-site transfer map between
-        WW . merge(A, A) and merge(B, B) for every candidate.  A: (2,2,2) shared or (B,2,2,2); candidates:
-        tensors (B,2,2,2) [kind='tensor'], unitaries (B,4,4) ['unitary'] or parameters (B,P) ['params' with
-        ansatz = L.ANSATZ_*].  Returns (eta complex (B,), rounds, status[, r (B,2,2)])."""
+    def overlaps(self, A, candidates, WW, kind='tensor', ansatz=None, max_rounds=None, tol=1e-13, want_r=False):
+        """Time-evolution overlap at the engine's bond dimension D: dominant eigenvalue eta of the mixed two-site
+        transfer map between WW . merge(A, A) and merge(B, B) for every candidate.  A: (2,D,D) shared or (B,2,D,D);
+        candidates: tensors (B,2,D,D) [kind='tensor'], unitaries (B,2D,2D) ['unitary'] or parameters (B,P) ['params' with
+        ansatz = L.ANSATZ_*].  max_rounds: D = 2 squarings (default 40, <= 60); D >= 4 cap on power steps (default 20000).
+        Returns (eta complex (B,), rounds, status[, r (B,D,D)])."""
+        D = self.D
+        if max_rounds is None:
+            max_rounds = 40 if D == 2 else 20000
         A = np.ascontiguousarray(A, dtype=np.complex128)
         shared = A.ndim == 3
-        WW = np.ascontiguousarray(WW, dtype=np.complex128)
+        if A.shape[-3:] != (2, D, D):
+            raise ValueError(f'A: expected (2,{D},{D}) or (B,2,{D},{D}), got {A.shape}')
+        WW = np.ascontiguousarray(WW, dtype=np.complex128).reshape(4, 4)
         if kind == 'params':
             cand = np.ascontiguousarray(np.atleast_2d(candidates), dtype=np.float64)
             code, npar, ptr = L.INPUT_ANSATZ_BASE + int(ansatz), cand.shape[1], _f64(cand)
         else:
-            tail = (2, 2, 2) if kind == 'tensor' else (4, 4)
+            tail = (2, D, D) if kind == 'tensor' else (2 * D, 2 * D)
             cand = _c128(candidates, tail, 'candidates')
             code, npar, ptr = (L.INPUT_TENSOR if kind == 'tensor' else L.INPUT_UNITARY), 0, _f64(cand.view(np.float64))
         B = cand.shape[0]
         if not shared and A.shape[0] != B:
-            raise ValueError('A must be (2,2,2) or (B,2,2,2)')
+            raise ValueError('A must be (2,D,D) or (B,2,D,D)')
         eta = np.empty(B, dtype=np.complex128)
-        r = np.empty((B, 2, 2), dtype=np.complex128) if want_r else None
+        r = np.empty((B, D, D), dtype=np.complex128) if want_r else None
         rounds = np.empty(B, dtype=np.int32)
         st = np.empty(B, dtype=np.int32)
         L.check(self._lib.qmps_overlap_batch(self._ctx, B, _f64(A.view(np.float64)), 1 if shared else 0, ptr, code, npar,
                                              _f64(WW.view(np.float64)), int(max_rounds), float(tol),
                                              _f64(eta.view(np.float64)), None if r is None else _f64(r.view(np.float64)),
                                              _i32(rounds), _i32(st)))
+        self.B = B
+        return (eta, rounds, st, r) if want_r else (eta, rounds, st)
+
+    def overlap_set(self, A, WW):
+        """Resident form of `overlaps`: reference tensor(s) A (2,D,D) or (n,2,D,D) and the two-site operator WW."""
+        A = np.ascontiguousarray(A, dtype=np.complex128)
+        if A.shape[-3:] != (2, self.D, self.D):
+            raise ValueError(f'A: expected (2,{self.D},{self.D}) or (n,2,{self.D},{self.D}), got {A.shape}')
+        WW = np.ascontiguousarray(WW, dtype=np.complex128).reshape(4, 4)
+        L.check(self._lib.qmps_overlap_set(self._ctx, 1 if A.ndim == 3 else A.shape[0], _f64(A.view(np.float64)),
+                                           _f64(WW.view(np.float64))))
+
+    def overlap_launch(self, B=None, max_rounds=None, tol=1e-13, want_r=False):
+        """Asynchronous: overlaps of the resident candidates [window, window + B) with the resident reference."""
+        if max_rounds is None:
+            max_rounds = 40 if self.D == 2 else 20000
+        L.check(self._lib.qmps_overlap_launch(self._ctx, self.B if B is None else B, int(max_rounds), float(tol), 1 if want_r else 0))
+
+    def overlap_results(self, B=None, want_r=False):
+        B = self.B if B is None else B
+        eta = np.empty(B, dtype=np.complex128)
+        r = np.empty((B, self.D, self.D), dtype=np.complex128) if want_r else None
+        rounds = np.empty(B, dtype=np.int32)
+        st = np.empty(B, dtype=np.int32)
+        L.check(self._lib.qmps_overlap_get(self._ctx, B, _f64(eta.view(np.float64)), None if r is None else _f64(r.view(np.float64)),
+                                           _i32(rounds), _i32(st)))
         return (eta, rounds, st, r) if want_r else (eta, rounds, st)
 
     def opt_env_objective(self, params, h, k=1.0, want_parts=False):

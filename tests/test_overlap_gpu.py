@@ -1,0 +1,107 @@
+"""GPU parity tests of the time-evolution overlap objective at bond dimension D = 2, 4, 8, 16 (BASELINE.json
+configs[4]: D = 16 on the matrix cores) against the oracle's dense eigen-solve of the D^2 x D^2 mixed transfer
+matrix (oracle.overlap_eta: qmps/new_time_evolve.py:193-221, scripts/loschmidt.py:209-239,
+qmps/time_evolve_tools.py:20-23).  Tolerance 1e-10 on eta (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+from scipy.linalg import expm
+
+from oracle import qmps_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ETA_TOL = 1e-10
+
+
+def nearby(rng, U, eps):
+    """Unitaries near U: U exp(i eps H), H random Hermitian (a time step moves the state a little)."""
+    n = U.shape[-1]
+    G = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    return U @ expm(1j * eps * (G + G.conj().T) / 2)
+
+
+def check(eta, st, r, A, Bt, WW, every=1):
+    assert np.all(st == 0)
+    for k in range(0, len(Bt), every):
+        a = A if A.ndim == 3 else A[k]
+        ref, r_ref = O.overlap_eta(a, Bt[k], WW)
+        assert abs(eta[k] - ref) < ETA_TOL, (k, eta[k], ref)
+        if r is not None:
+            assert abs(abs(np.vdot(r_ref, r[k])) - 1.0) < 1e-9          # the same ray (unit Frobenius norm, free phase)
+            assert abs(np.linalg.norm(r[k]) - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize('D,B', [(2, 200), (4, 130), (8, 40), (16, 9)])
+def test_overlap_vs_dense_eig(D, B, engine_factory):
+    rng = np.random.default_rng(600 + D)
+    eng = engine_factory(D, 4096)
+    U = O.haar_unitaries(rng, 2 * D, 1)[0]
+    A = O.unitary_to_tensor(U)
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+    # a time step moves the state a little: overlaps 0.8 .. 1, spectral gaps well below 1 (far candidates: next test)
+    cands = np.stack([O.unitary_to_tensor(nearby(rng, U, eps)) for eps in rng.uniform(0.0, 0.12, B)])
+    for WW in (np.eye(4, dtype=complex), expm(-1j * 0.05 * h)):
+        eta, rounds, st, r = eng.overlaps(A, cands, WW, want_r=True)
+        check(eta, st, r, A, cands, WW, every=max(1, B // 12))
+        assert np.all(np.abs(eta) <= 1 + 1e-12)
+    # W = 1 and B = A: the overlap of a state with itself is 1 (reference identity, new_time_evolve.py:100-184)
+    eta, rounds, st = eng.overlaps(A, A[None], np.eye(4, dtype=complex))
+    assert st[0] == 0 and abs(eta[0] - 1.0) < 1e-12
+    # one reference tensor per candidate, unitaries as input, results of the last launch through the resident API
+    Us = np.stack([nearby(rng, U, 0.1) for _ in range(6)])
+    As = np.stack([O.unitary_to_tensor(nearby(rng, U, 0.05)) for _ in range(6)])
+    WW = expm(-1j * 0.1 * h)
+    eta2, _, st2 = eng.overlaps(As, Us, WW, kind='unitary')
+    check(eta2, st2, None, As, O.unitary_to_tensor(Us), WW)
+    eng.set_tensors(cands)
+    eng.overlap_set(A, WW)
+    eng.set_window(3)
+    eng.overlap_launch(min(B - 3, 20), want_r=True)
+    eta3, rounds3, st3, r3 = eng.overlap_results(min(B - 3, 20), want_r=True)
+    check(eta3, st3, r3, A, cands[3:3 + min(B - 3, 20)], WW, every=5)
+    eng.set_window(0)
+
+
+@pytest.mark.parametrize('D', [4, 8, 16])
+def test_overlap_far_candidates_and_caps(D, engine_factory):
+    """Candidates unrelated to the reference state (what an optimiser may try): small, complex dominant eigenvalues,
+    slow convergence - the plain power method needs ~1/(1 - |eta_2/eta_1|) steps, and a near-degenerate dominant pair
+    (ratio 0.9997 occurs at D = 16) exhausts any practical cap: that is reported as status 1, never hidden, and the
+    Rayleigh quotient returned is then still close to the dominant eigenvalue."""
+    rng = np.random.default_rng(700 + D)
+    eng = engine_factory(D, 4096)
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, 1)[0])
+    cands = O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, 12))
+    WW = expm(-1j * 0.2 * O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5}))
+    eta, rounds, st = eng.overlaps(A, cands, WW, max_rounds=200000)
+    ok = st == 0
+    assert ok.mean() >= 0.5
+    for k in range(len(cands)):
+        ref = O.overlap_eta(A, cands[k], WW)[0]
+        assert abs(eta[k] - ref) < (ETA_TOL if ok[k] else 1e-3 * abs(ref)), (k, st[k], eta[k], ref)
+    eta, rounds, st = eng.overlaps(A, cands, WW, max_rounds=3)
+    assert np.all(st == 1) and np.all(rounds == 3)
+
+
+def test_overlap_d16_tile_kernel_matches_the_matrix_core_kernel():
+    """D = 16: the generic LDS-tile kernel (QMPS_D16_BLOCK) and the MFMA kernel implement the same iteration."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from oracle import qmps_oracle as O\nfrom qmps_amd import EnergyEngine\n"
+            "rng = np.random.default_rng(5); U = O.haar_unitaries(rng, 32, 7)\n"
+            "A = O.unitary_to_tensor(U[0]); C = O.unitary_to_tensor(U[1:])\n"
+            "C = 0.9 * A[None] + 0.1 * C\n"
+            "eng = EnergyEngine(16, 16); eta, rounds, st = eng.overlaps(A, C, np.eye(4), max_rounds=100000)\n"
+            "print(repr(list(eta)), list(rounds), list(st))\n" % root)
+    outs = []
+    for env in ({}, {'QMPS_D16_BLOCK': '1'}):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    e0, r0, s0 = eval('(' + outs[0].replace('] [', '], [') + ')')
+    e1, r1, s1 = eval('(' + outs[1].replace('] [', '], [') + ')')
+    assert s0 == s1 == [0] * 6
+    assert np.abs(np.array(e0) - np.array(e1)).max() < 1e-11 and np.abs(np.array(r0) - np.array(r1)).max() <= 2

@@ -144,6 +144,13 @@ int qmps_set_states_ansatz(qmps_ctx* ctx, int64_t B, int kind, int n_params, con
  * reference's M(x) = np.sum(eps)) after each sweep.  Needs 3 R <= max_batch and a Hamiltonian. */
 int qmps_rotosolve(qmps_ctx* ctx, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter,
                    double tol, double* E_hist);
+/* Device-resident DOUBLE-frequency rotosolve (qmps/tools.py:422-457, what Optimizer.optimize('Rotosolve') runs): per
+ * parameter ONE batch of 6 R evaluations (shifts 0, pi, +-pi/2, +-pi/4), the fit P sin(2x + u) + Q sin(x + v)
+ * (tools.py:440-447) and its GLOBAL minimiser on [-pi, pi) (the reference hands the fit to scipy's minimize_scalar,
+ * tools.py:451, which returns a local minimiser to 1e-5; grid + bisection + Newton here), all on the device.  The
+ * wrapped minimiser is added to the parameter, which is not re-wrapped (tools.py:453-454).  Needs 6 R <= max_batch. */
+int qmps_double_rotosolve(qmps_ctx* ctx, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter,
+                          double tol, double* E_hist);
 /* read back the resident state tensors A[B][2][D][D] (tests / debugging) */
 int qmps_get_states(qmps_ctx* ctx, int64_t B, double* A);
 /* h[n_terms][4][4] complex128, row/col index = 2*s1+s2, s1 = left site

@@ -151,6 +151,21 @@ def shallow_qaoa_unitary(D, params):
     return circuit_unitary(n, ops)
 
 
+def shallow_cnot3_unitary(D, params):
+    """ShallowCNOTStateTensor3 (represent.py:334-354): per (beta, gamma, omega): rz(beta), rx(gamma), rz(omega) on all
+    qubits, H(q0), then the CNOT ladder CNOT(q[n-2],q[n-1]) ... CNOT(q0,q1)."""
+    n = int(np.log2(D)) + 1
+    ops = []
+    p = list(params)
+    for b, g, w in [p[i:i + 3] for i in range(0, len(p), 3)]:
+        ops += [(rz(b), [q]) for q in range(n)]
+        ops += [(rx(g), [q]) for q in range(n)]
+        ops += [(rz(w), [q]) for q in range(n)]
+        ops += [(HAD, [0])]
+        ops += [(CNOT, [i, i + 1]) for i in reversed(range(n - 1))]
+    return circuit_unitary(n, ops)
+
+
 def shallow_full_unitary(v):
     """ShallowFullStateTensor(2, v[15]) - the 18-gate list at represent.py:393-401."""
     v = list(v)
@@ -519,6 +534,33 @@ def double_rotosolve_update(M0, Mpi, Mp2, Mm2, Mp4, Mm4):
     th = minimize_scalar(lambda x: P * np.sin(2 * x + u) + Q * np.sin(x + v),
                          bounds=[-np.pi, np.pi]).x
     return float(np.arctan2(np.sin(th), np.cos(th)))
+
+
+def double_sinusoid_coefficients(M0, Mpi, Mp2, Mm2, Mp4, Mm4):
+    """(P, u, Q, v) of the fit P sin(2x + u) + Q sin(x + v) through the six samples (tools.py:434-447)."""
+    A, Bv = (M0 + Mpi), (M0 - Mpi)
+    C, Dv = (Mp2 + Mm2), (Mp2 - Mm2)
+    E = (Mp4 - Mm4)
+    a, b, c, d = 0.25 * (2 * E - np.sqrt(2) * Dv), 0.25 * (A - C), 0.5 * Dv, 0.5 * Bv
+    return np.sqrt(a * a + b * b), np.arctan2(b, a), np.sqrt(c * c + d * d), np.arctan2(d, c)
+
+
+def double_sinusoid_argmin(P, u, Q, v):
+    """GLOBAL minimiser on [-pi, pi) of f(x) = P sin(2x + u) + Q sin(x + v): what the reference's
+    `minimize_scalar(f, bounds=[-pi, pi])` (tools.py:451) aims at - scipy's Brent returns a LOCAL minimiser to
+    xatol 1e-5 (and, in the scipy of the reference's time, ignored `bounds`).  Dense grid, then a root of f' by
+    scipy.optimize.brentq inside the bracket around the best grid point (independent of the kernel's
+    table-grid + bisection + Newton).  A flat fit (P = Q = 0) returns 0."""
+    from scipy.optimize import brentq
+    if not (P + Q > 0):
+        return 0.0
+    f = lambda x: P * np.sin(2 * x + u) + Q * np.sin(x + v)
+    df = lambda x: 2 * P * np.cos(2 * x + u) + Q * np.cos(x + v)
+    xs = -np.pi + 2 * np.pi * np.arange(4096) / 4096
+    k = int(np.argmin(f(xs)))
+    lo, hi = xs[k] - 2 * np.pi / 4096, xs[k] + 2 * np.pi / 4096
+    x = brentq(df, lo, hi, xtol=1e-15, rtol=1e-15, maxiter=200) if df(lo) < 0 < df(hi) else xs[k]
+    return float(np.arctan2(np.sin(x), np.cos(x)))
 
 
 def rotosolve_update(e0, ep, em):

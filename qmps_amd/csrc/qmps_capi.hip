@@ -383,10 +383,26 @@ int qmps_set_states_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const
   return QMPS_OK;
 }
 
+namespace {
+int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter, double tol,
+                   double* E_hist, int nsh);
+}
+
 int qmps_rotosolve(qmps_ctx* c, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter,
                    double tol, double* E_hist) {
+  return rotosolve_impl(c, R, kind, n_params, params, n_sweeps, max_iter, tol, E_hist, 3);
+}
+
+int qmps_double_rotosolve(qmps_ctx* c, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter,
+                          double tol, double* E_hist) {
+  return rotosolve_impl(c, R, kind, n_params, params, n_sweeps, max_iter, tol, E_hist, 6);
+}
+
+namespace {
+int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter, double tol,
+                   double* E_hist, int nsh) {
   if (int rc = bind(c)) return rc;
-  if (R < 1 || 3 * R > c->max_batch) return fail(QMPS_ERR_ARG, "3 R = %lld evaluations exceed max_batch = %lld", (long long)(3 * R), (long long)c->max_batch);
+  if (R < 1 || nsh * R > c->max_batch) return fail(QMPS_ERR_ARG, "%d R = %lld evaluations exceed max_batch = %lld", nsh, (long long)(nsh * R), (long long)c->max_batch);
   c->window = 0;
   if (!params || !E_hist) return fail(QMPS_ERR_ARG, "null argument");
   if (n_sweeps < 1) return fail(QMPS_ERR_ARG, "n_sweeps must be >= 1");
@@ -426,7 +442,7 @@ int qmps_rotosolve(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     // D = 2 with the library's default solver: the whole run is ONE launch (restarts are independent, see
     // rotosolve_fused_d2_kernel); afterwards one ordinary evaluation of the final parameters leaves the context's
     // resident tensors / energies / statuses exactly as the step-by-step path does.
-    if (c->D == 2 && c->handoff == 0 && c->default_solver == QMPS_ENV_POWER_SQUARING && n_params <= 64 &&
+    if (nsh == 3 && c->D == 2 && c->handoff == 0 && c->default_solver == QMPS_ENV_POWER_SQUARING && n_params <= 64 &&
         getenv("QMPS_NO_FUSED_ROTO") == nullptr) {
       qmps::RotoArgs ra;
       memset(&ra, 0, sizeof(ra));
@@ -447,11 +463,11 @@ int qmps_rotosolve(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     // parameter index lives in HBM and is advanced by the update kernel, so the sequence is captured ONCE
     // into a hipGraph and replayed n_params x n_sweeps times: the sweep is launch-bound at small R.
     auto one_update = [&]() -> int {
-      HIP_TRY(qmps::launch_roto_shift(d_base, c->d_params, (int)R, n_params, d_idx, c->stream));
-      HIP_TRY(qmps::launch_ansatz(c->D, kind, c->d_params, n_params, c->d_A, 3 * R, c->stream));
-      c->n_states = 3 * R;
-      if (int e = qmps_energy_launch(c, 3 * R, max_iter, tol, c->default_solver)) return e;
-      HIP_TRY(qmps::launch_roto_update(d_base, c->d_E, c->d_status, (int)R, n_params, d_idx, c->n_terms, c->stream));
+      HIP_TRY(qmps::launch_roto_shift(d_base, c->d_params, (int)R, n_params, d_idx, nsh, c->stream));
+      HIP_TRY(qmps::launch_ansatz(c->D, kind, c->d_params, n_params, c->d_A, nsh * R, c->stream));
+      c->n_states = nsh * R;
+      if (int e = qmps_energy_launch(c, nsh * R, max_iter, tol, c->default_solver)) return e;
+      HIP_TRY(qmps::launch_roto_update(d_base, c->d_E, c->d_status, (int)R, n_params, d_idx, c->n_terms, nsh, c->stream));
       return QMPS_OK;
     };
     const bool use_graph = getenv("QMPS_NO_GRAPH") == nullptr;
@@ -490,6 +506,7 @@ int qmps_rotosolve(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
   (void)hipFree(d_idx);
   return rc;
 }
+}  // namespace
 
 int qmps_get_states(qmps_ctx* c, int64_t B, double* A) {
   if (int rc = bind(c)) return rc;

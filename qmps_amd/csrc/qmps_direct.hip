@@ -221,8 +221,8 @@ hipError_t launch_cost_finish(const long long* acc, double inv_scale, int n_term
 // env_direct_d8_kernel: D = 8 direct fixed-point solve, ONE WAVE PER EVALUATION, one ROW of the real 64 x 64 system
 // per lane.  Lane a = 8 i + i' owns coordinate u[(i,i')] (r_ii | Re r_ii' for i < i' | Im r_i'i for i > i') and row a
 // of R - 1 (+ the trace functional on the last pivot row, right-hand side e_63, as at D = 4): 64 doubles in
-// registers.  Gauss-Jordan step k: lane k parks what is left of its row in LDS, every lane reads it back (one
-// address per ds_read_b128: a broadcast) and eliminates column k from its own row - 2080 FMAs per lane in all, no
+// registers.  Gauss-Jordan step k: what is left of lane k's row is broadcast through scalar registers
+// (v_readlane_b32) and every lane eliminates column k from its own row - 2080 FMAs per lane in all, no
 // pivoting (measured on Haar tensors: smallest pivot 0.37, residual 1e-15).  The result is written as the
 // environment r[8][8]; energy_block_kernel<8, true> then starts its power iteration from it, so its first step is
 // the acceptance test (iterations = 1) and its loop the fall-back for anything the solve got wrong; a non-finite
@@ -231,7 +231,6 @@ hipError_t launch_cost_finish(const long long* acc, double inv_scale, int n_term
 __global__ __launch_bounds__(64, 2) void env_direct_d8_kernel(const double2* __restrict__ A, double2* __restrict__ r_out, int64_t B) {
   constexpr int D = 8, N = 64, P = D + 1;
   __shared__ double2 sA[2][D][P];
-  __shared__ __attribute__((aligned(16))) double sRow[N];
   __shared__ double sT[D][P];
   const int lane = threadIdx.x, i = lane >> 3, ip = lane & 7;
   const int64_t b = blockIdx.x;
@@ -296,29 +295,35 @@ __global__ __launch_bounds__(64, 2) void env_direct_d8_kernel(const double2* __r
   }
   __builtin_amdgcn_sched_barrier(0);
   double dinv = 0.0, y = 0.0;
+  // the pivot row travels through SCALAR registers: v_readlane_b32 (lane k is a compile-time constant) puts each of
+  // its entries in an SGPR pair, which v_fma_f64 takes as an operand - no LDS round trip, no vector registers for the
+  // row, no latency between the steps beyond the reciprocal (measured: 41.8 us per launch with the row parked in LDS)
+  auto from_lane = [](double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+  };
   static_for<N>([&](auto K) {
-    constexpr int k = decltype(K)::value, k0 = k & ~1;
-    // lane k parks columns k0 .. 63 of its row (the LDS queue of a wave is in order: no hazard with the reads of step k - 1)
-    __builtin_amdgcn_wave_barrier();
-    if (lane == k) {
-#pragma unroll
-      for (int j = k0; j < N; j += 2) *(double2*)&sRow[j] = make_double2(M[j], M[j + 1]);
-    }
-    __builtin_amdgcn_wave_barrier();
-    double2 pr[(N - k0) / 2];
-#pragma unroll
-    for (int j = k0; j < N; j += 2) pr[(j - k0) / 2] = *(const double2*)&sRow[j];
-    const double pk = (k & 1) ? pr[0].y : pr[0].x;
+    constexpr int k = decltype(K)::value;
+    const double pk = from_lane(M[k], k);
     const double pinv = fast_rcp(pk);
     dinv = lane == k ? pinv : dinv;
     const double f = lane == k ? 0.0 : M[k] * pinv;
+    // sixteen entries at a time: 32 scalar reads, then 16 FMAs (a v_fmac right behind the v_readlane that feeds it
+    // would wait out the SGPR hazard with s_nops)
 #pragma unroll
-    for (int j = k + 1; j < N; ++j) {
-      const double pv = ((j - k0) & 1) ? pr[(j - k0) / 2].y : pr[(j - k0) / 2].x;
-      M[j] = dfma(-f, pv, M[j]);
+    for (int j0 = k + 1; j0 < N; j0 += 16) {
+      double pv[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        if (j0 + t < N) pv[t] = from_lane(M[j0 + t], k);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        if (j0 + t < N) M[j0 + t] = dfma(-f, pv[t], M[j0 + t]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (k == N - 1) y = -f;
-    __builtin_amdgcn_sched_barrier(0);
   });
   y = lane == N - 1 ? 1.0 : y;
   const double x = y * dinv;

@@ -140,9 +140,10 @@ hipError_t launch_bw(int what, const BwArgs& a, hipStream_t st);
 hipError_t launch_opt_env(const double* params, const void* h, double k, double* f, double* parts, int64_t B,
                           hipStream_t st);
 // i_ptr[0] = index of the parameter being updated, i_ptr[1] = arrival counter (both zero-initialised)
-hipError_t launch_roto_shift(const double* base, double* out, int R, int P, const int* i_ptr, hipStream_t st);
+// nsh = 3: single-frequency rotosolve (shifts 0, +-pi/2); nsh = 6: double-frequency (0, pi, +-pi/2, +-pi/4)
+hipError_t launch_roto_shift(const double* base, double* out, int R, int P, const int* i_ptr, int nsh, hipStream_t st);
 hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int* i_ptr, int n_terms,
-                              hipStream_t st);
+                              int nsh, hipStream_t st);
 hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, hipStream_t st);
 hipError_t launch_unitary_to_tensor(const void* U, void* A, int D, int64_t B, hipStream_t st);
 hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, int n_partial, double* cost,

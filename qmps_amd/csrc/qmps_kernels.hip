@@ -1958,43 +1958,105 @@ hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, vo
 //   theta* = -pi/2 - atan2(2 e0 - e+ - e-, e+ - e-),  params[i] = wrap(params[i] + wrap(theta*))
 // runs on the device, so a whole sweep needs no host round trip.
 // ------------------------------------------------------------------------------------------
+// nsh = 3: shifts {0, +pi/2, -pi/2} (qmps/rotosolve.py:175);  nsh = 6: {0, pi, +-pi/2, +-pi/4} (qmps/tools.py:434-438)
+__device__ __forceinline__ double roto_shift_value(int nsh, int k) {
+  if (nsh == 3) return k == 0 ? 0.0 : (k == 1 ? 1.5707963267948966 : -1.5707963267948966);
+  switch (k) {
+    case 0: return 0.0;
+    case 1: return 3.141592653589793;
+    case 2: return 1.5707963267948966;
+    case 3: return -1.5707963267948966;
+    case 4: return 0.7853981633974483;
+    default: return -0.7853981633974483;
+  }
+}
+
 __global__ __launch_bounds__(256) void roto_shift_kernel(const double* __restrict__ base, double* __restrict__ out, int R,
-                                                         int P, const int* __restrict__ i_ptr) {
+                                                         int P, const int* __restrict__ i_ptr, int nsh) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)R * 3 * P) return;
+  if (t >= (int64_t)R * nsh * P) return;
   const int i = *i_ptr;   // parameter being updated: lives in HBM so ONE captured hipGraph serves all of them
   const int col = (int)(t % P);
   const int64_t row = t / P;
-  const int k = (int)(row % 3);
-  const int64_t r = row / 3;
+  const int k = (int)(row % nsh);
+  const int64_t r = row / nsh;
   double v = base[r * P + col];
-  if (col == i) v += (k == 0) ? 0.0 : (k == 1 ? 1.5707963267948966 : -1.5707963267948966);
+  if (col == i) v += roto_shift_value(nsh, k);
   out[t] = v;
 }
 
 __device__ __forceinline__ double wrap_pi(double x) { return atan2(sin(x), cos(x)); }
 
+// Global minimiser on [-pi, pi) of f(x) = P sin(2x + u) + Q sin(x + v) - the fit of the double-frequency rotosolve
+// (qmps/tools.py:447-451; the reference hands f to scipy's minimize_scalar).  32-point grid from the angle-addition
+// formulas (the grid's sines and cosines come from 8 distinct values: one sincos per octant position), then the root of
+// f' inside the bracket around the best grid point: 14 bisections + 4 Newton steps.  A flat fit returns 0.
+__device__ double double_sinusoid_argmin(double P, double u, double Q, double v) {
+  if (!(P + Q > 0.0)) return 0.0;
+  constexpr int NG = 32;
+  constexpr double H = 6.283185307179586 / NG;
+  double su, cu, sv, cv;
+  sincos(u, &su, &cu);
+  sincos(v, &sv, &cv);
+  double best = 1e300, xb = -3.141592653589793;
+  for (int g = 0; g < NG; ++g) {
+    const double x = -3.141592653589793 + g * H;
+    double sx, cx;
+    sincos(x, &sx, &cx);
+    const double s2 = 2.0 * sx * cx, c2 = cx * cx - sx * sx;
+    const double f = P * (s2 * cu + c2 * su) + Q * (sx * cv + cx * sv);
+    if (f < best) { best = f; xb = x; }
+  }
+  auto df = [&](double x) { return 2.0 * P * cos(2.0 * x + u) + Q * cos(x + v); };
+  auto ff = [&](double x) { return P * sin(2.0 * x + u) + Q * sin(x + v); };
+  double lo = xb - H, hi = xb + H, x = xb;
+  if (df(lo) < 0.0 && df(hi) > 0.0) {
+    for (int it = 0; it < 14; ++it) {
+      const double mid = 0.5 * (lo + hi);
+      if (df(mid) > 0.0) hi = mid; else lo = mid;
+    }
+    x = 0.5 * (lo + hi);
+    for (int it = 0; it < 4; ++it) {
+      const double d2 = -4.0 * P * sin(2.0 * x + u) - Q * sin(x + v);
+      if (!(d2 > 0.0)) break;
+      const double xn = x - df(x) / d2;
+      if (!(xn > lo - 1e-3 && xn < hi + 1e-3)) break;
+      x = xn;
+    }
+    if (!(ff(x) <= best)) x = xb;
+  }
+  return x;
+}
+
 __global__ __launch_bounds__(256) void roto_update_kernel(double* __restrict__ base, const double* __restrict__ E,
                                                           const int32_t* __restrict__ status, int R, int P,
-                                                          int* __restrict__ i_ptr, int n_terms) {
+                                                          int* __restrict__ i_ptr, int n_terms, int nsh) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = *i_ptr;
   // the LAST workgroup to finish advances the parameter index for the next graph replay
   __shared__ int s_last;
   if (r < R) {
-  double e[3];
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    double v = 0.0;
-    for (int q = 0; q < n_terms; ++q) v += E[((int64_t)r * 3 + k) * n_terms + q];   // M(x) = sum over terms
-    e[k] = v;
-    ok = ok && status[(int64_t)r * 3 + k] == QMPS_ST_OK;
-  }
-  if (ok) {          // (an evaluation without a valid environment leaves this restart's parameter untouched)
-    const double theta = -1.5707963267948966 - atan2(2.0 * e[0] - e[1] - e[2], e[1] - e[2]);
-    base[(int64_t)r * P + i] = wrap_pi(base[(int64_t)r * P + i] + wrap_pi(theta));
-  }
+    double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    bool ok = true;
+    for (int k = 0; k < nsh; ++k) {
+      double v = 0.0;
+      for (int q = 0; q < n_terms; ++q) v += E[((int64_t)r * nsh + k) * n_terms + q];   // M(x) = sum over terms
+      e[k] = v;
+      ok = ok && status[(int64_t)r * nsh + k] == QMPS_ST_OK;
+    }
+    if (ok) {          // (an evaluation without a valid environment leaves this restart's parameter untouched)
+      double theta;
+      if (nsh == 3) {
+        theta = -1.5707963267948966 - atan2(2.0 * e[0] - e[1] - e[2], e[1] - e[2]);
+      } else {
+        // samples at {0, pi, +pi/2, -pi/2, +pi/4, -pi/4}: a, b, c, d -> P sin(2x + u) + Q sin(x + v)  (tools.py:434-447)
+        const double A = e[0] + e[1], Bv = e[0] - e[1], C = e[2] + e[3], Dv = e[2] - e[3], Ev = e[4] - e[5];
+        const double a = 0.25 * (2.0 * Ev - 1.4142135623730951 * Dv), b = 0.25 * (A - C), c = 0.5 * Dv, d = 0.5 * Bv;
+        theta = double_sinusoid_argmin(hypot(a, b), atan2(b, a), hypot(c, d), atan2(d, c));
+      }
+      const double moved = base[(int64_t)r * P + i] + wrap_pi(theta);
+      base[(int64_t)r * P + i] = nsh == 3 ? wrap_pi(moved) : moved;   // the double-frequency driver does not re-wrap (tools.py:453-454)
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -2018,14 +2080,14 @@ __global__ __launch_bounds__(256) void roto_record_kernel(const double* __restri
   hist[r] = v;
 }
 
-hipError_t launch_roto_shift(const double* base, double* out, int R, int P, const int* i_ptr, hipStream_t st) {
-  const int64_t n = (int64_t)R * 3 * P;
-  hipLaunchKernelGGL(roto_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, base, out, R, P, i_ptr);
+hipError_t launch_roto_shift(const double* base, double* out, int R, int P, const int* i_ptr, int nsh, hipStream_t st) {
+  const int64_t n = (int64_t)R * nsh * P;
+  hipLaunchKernelGGL(roto_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, base, out, R, P, i_ptr, nsh);
   return hipGetLastError();
 }
 hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int* i_ptr, int n_terms,
-                              hipStream_t st) {
-  hipLaunchKernelGGL(roto_update_kernel, dim3((R + 255) / 256), dim3(256), 0, st, base, E, status, R, P, i_ptr, n_terms);
+                              int nsh, hipStream_t st) {
+  hipLaunchKernelGGL(roto_update_kernel, dim3((R + 255) / 256), dim3(256), 0, st, base, E, status, R, P, i_ptr, n_terms, nsh);
   return hipGetLastError();
 }
 hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, hipStream_t st) {
@@ -2877,6 +2939,11 @@ hipError_t launch_unitary_to_tensor(const void* U, void* A, int D, int64_t B, hi
 
 hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, int n_partial, double* cost,
                       hipStream_t st) {
+  if (n_terms == 1 && B <= 16384) {
+    // a small single-term batch: E[B] has the layout of one row of partial sums - one launch instead of two
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(B > 1024 ? 1024 : 256), 0, st, E, (int)B, 1, cost);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(sum_partial_kernel, dim3(n_partial), dim3(256), 0, st, E, B, n_terms, partial);
   hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, n_partial, n_terms, cost);
   return hipGetLastError();

@@ -90,6 +90,15 @@ class EnergyEngine:
                                          int(max_iter), float(tol), _f64(hist)))
         return hist, P
 
+    def double_rotosolve(self, kind, params, n_sweeps=1, max_iter=10000, tol=1e-13):
+        """Device-resident DOUBLE-frequency rotosolve (qmps/tools.py:422-457): params (R, P) ->
+        (energies (n_sweeps, R), params (R, P)); needs 6 R <= max_batch and a resident Hamiltonian."""
+        P = np.array(np.atleast_2d(params), dtype=np.float64, order='C', copy=True)
+        hist = np.empty((int(n_sweeps), P.shape[0]))
+        L.check(self._lib.qmps_double_rotosolve(self._ctx, P.shape[0], int(kind), P.shape[1], _f64(P), int(n_sweeps),
+                                                int(max_iter), float(tol), _f64(hist)))
+        return hist, P
+
     def tensors(self, B=None):
         """Read back the resident state tensors (B, 2, D, D)."""
         B = self.B if B is None else B

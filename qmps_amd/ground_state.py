@@ -208,6 +208,22 @@ class SparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
         E, _, st = self._energies_from_params(params_batch)
         return np.where(st == STATUS_OK, E, np.nan)
 
+    def _device_double_rotosolve(self, n_sweeps):
+        """`Optimizer.optimize()` with settings['method'] == 'Rotosolve' (tools.py:248-270 -> double_rotosolve,
+        tools.py:422-457): when libqmps_hip can simulate the ansatz, the whole run - six shifted evaluations per
+        parameter, sinusoid fit, argmin, update, sweep energies - happens in one C call, without a host round trip per
+        parameter.  Returns None (host driver takes over) for gate classes without a device implementation."""
+        from .tools import RotosolveResult
+        kind = getattr(self.state_tensor, 'device_kind', None)
+        if self.optimize_environment or kind is None or (kind == 2 and self.D != 2):
+            return None
+        from .rotosolve import device_double_rotosolve
+        es, P = device_double_rotosolve(self, np.asarray(self.initial_guess, dtype=float)[None], n_sweeps)
+        self.initial_guess[...] = P[0]              # the reference updates the parameter vector in place
+        hist = [float(e) for e in es[:, 0]]
+        self.f = hist[-1]
+        return RotosolveResult(hist, hist[-1], self.initial_guess, '')
+
     def update_state(self):
         self.u = self.state_tensor(self.D, self.optimized_result.x)
         self.U = unitary(self.u)

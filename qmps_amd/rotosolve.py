@@ -75,7 +75,8 @@ def batched_rotosolve(batch_eps, initial_parameters, N_iters=10):
             batch[:, :, i] += shifts
             e = np.asarray(batch_eps(batch.reshape(R * 3, P))).reshape(R, 3)
             theta = -π / 2 - np.arctan2(2 * e[:, 0] - e[:, 1] - e[:, 2], e[:, 1] - e[:, 2])
-            params[:, i] = _wrap(params[:, i] + _wrap(theta))
+            ok = np.all(np.isfinite(e), axis=1)      # a sample without a valid environment leaves the restart's parameter untouched
+            params[ok, i] = _wrap(params[ok, i] + _wrap(theta[ok]))
         es.append(np.asarray(batch_eps(params)))
     return np.array(es), params
 
@@ -110,6 +111,21 @@ def device_rotosolve(optimizer, initial_parameters, N_iters=10):
     eng = _runtime.engine(optimizer.D, 3 * P.shape[0])
     eng.set_hamiltonian(_as_h(optimizer.H))
     return eng.rotosolve(kind, P, N_iters, max_iter=optimizer.max_iter, tol=optimizer.env_tol)
+
+
+def device_double_rotosolve(optimizer, initial_parameters, N_iters=5):
+    """Double-frequency rotosolve (tools.py:422-457) for R restarts entirely on the GPU (`qmps_double_rotosolve`): six
+    shifts per parameter, the P sin(2x+u) + Q sin(x+v) fit and its global argmin in the update kernel; no host round
+    trip per parameter.  Returns (energies (N_iters, R), params (R, P))."""
+    from . import _runtime
+    from .ground_state import _as_h
+    kind = getattr(optimizer.state_tensor, 'device_kind', None)
+    if kind is None:
+        raise ValueError(f'{optimizer.state_tensor.__name__} has no device implementation; use batched_double_rotosolve')
+    P = np.atleast_2d(np.asarray(initial_parameters, dtype=float))
+    eng = _runtime.engine(optimizer.D, 6 * P.shape[0])
+    eng.set_hamiltonian(_as_h(optimizer.H))
+    return eng.double_rotosolve(kind, P, N_iters, max_iter=optimizer.max_iter, tol=optimizer.env_tol)
 
 
 # ---- state functions of the variational-environment problem (rotosolve.py:15-62, 109-113) -----------------

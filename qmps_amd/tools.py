@@ -239,7 +239,11 @@ def double_rotosolve(eps, initial_parameters, N_iters=100, disp=True, batch_eps=
                     q[i] += x
                     return np.sum(eps(q))
                 M = [one(x) for x in ROTO_SHIFTS]
-            params[i] += _double_sinusoid_shift(*M)
+            # a sample without a valid environment (NaN from the batched objective: product / GHZ points, which the
+            # +-pi/2 shifts do hit) leaves the parameter where it is - what the device kernels do, and the nearest
+            # batch analogue of the scalar objective's "return the previous value" (ground_state.py:153-157)
+            if np.all(np.isfinite(M)):
+                params[i] += _double_sinusoid_shift(*M)
         if disp:
             print('\n', sep='', end='', flush=True)
         history.append(eps(params))
@@ -295,10 +299,13 @@ class Optimizer:
         if s['bayesian']:
             raise NotImplementedError('bayesian (skopt) optimisation is outside the hot path')
         if s['method'] == 'Rotosolve':
-            batch = self.batch_objective_function if type(self).batch_objective_function \
-                is not Optimizer.batch_objective_function else None
-            self.optimized_result = double_rotosolve(self.objective_function, self.initial_guess, s['maxiter'],
-                                                     verbose, batch_eps=batch)
+            device = getattr(self, '_device_double_rotosolve', None)
+            res = device(s['maxiter']) if device is not None else None
+            if res is None:
+                batch = self.batch_objective_function if type(self).batch_objective_function \
+                    is not Optimizer.batch_objective_function else None
+                res = double_rotosolve(self.objective_function, self.initial_guess, s['maxiter'], verbose, batch_eps=batch)
+            self.optimized_result = res
         else:
             self.optimized_result = minimize(fun=self.objective_function, x0=self.initial_guess, method=s['method'],
                                              tol=s['tol'], options={'maxiter': s['maxiter'], 'disp': verbose},

@@ -63,6 +63,11 @@ def test_device_ansatz_builder(D, engine_factory):
         A_dev = eng.tensors()
         A_host = np.stack([T.unitary_to_tensor(R.unitary(cls(D, p))) for p in P])
         assert np.abs(A_dev - A_host).max() < 1e-13, (kind, D)
+        # ... and == the ORACLE's independent circuit model (explicit 2^n x 2^n gate embeddings, oracle/qmps_oracle.py)
+        build = {L.ANSATZ_SHALLOW_CNOT: O.shallow_cnot_unitary, L.ANSATZ_SHALLOW_QAOA: O.shallow_qaoa_unitary,
+                 L.ANSATZ_SHALLOW_CNOT3: O.shallow_cnot3_unitary, L.ANSATZ_SHALLOW_FULL: lambda D_, p: O.shallow_full_unitary(p)}[kind]
+        A_orc = np.stack([O.unitary_to_tensor(build(D, p)) for p in P])
+        assert np.abs(A_dev - A_orc).max() < 1e-13, (kind, D)
     with pytest.raises(L.QmpsError):
         eng.set_ansatz_params(L.ANSATZ_SHALLOW_CNOT, rng.standard_normal((3, 5)))      # odd number of angles
     if D != 2:

@@ -86,13 +86,16 @@ extern "C" {
  * QMPS_ERR_STATE until a launch without the flag has run. */
 #define QMPS_FLAG_NO_ENV_OUT 0x100
 /* flag (QMPS_ENV_DIRECT at D = 4): the launch also accumulates cost[t] = sum_b E[b][t] inside the kernel - every wave
- * adds its partial sum as a 64-bit FIXED-POINT integer (scale 2^k chosen from ||h||_F and B) to one of 32 shards:
- * integer addition commutes, so the sum is exact and independent of the order the waves finish in.  The
- * qmps_cost_launch(B) that follows consumes it WITHOUT launching a reduction kernel (with a communicator the conversion
- * to double runs on the communication stream in front of the all-reduce).  Partial sums beyond the isometric bound
- * 16 ||h||_F (tensors that are not isometries, NaN) are added to a double instead.  Contract: the next call that
- * launches must be qmps_cost_launch with the same B and window; a second accumulating launch before that fails with
- * QMPS_ERR_STATE. */
+ * adds ONE 64-bit word per term to one of up to 1024 shards: its partial sum as a FIXED-POINT integer (scale 2^k chosen
+ * from ||h||_F) in the low 58 bits and an arrival count of 1 in the high 6.  Integer addition commutes, so the sum is
+ * exact and independent of the order the waves finish in.  The qmps_cost_launch(B) that follows consumes it WITHOUT
+ * launching a reduction kernel, and - with a communicator - without any event on the compute stream: the one-wave
+ * conversion kernel in front of the all-reduce runs on the COMMUNICATION stream and polls the arrival counts (a bounded
+ * number of sweeps; it cannot hang).  Measured at world size 1: 30.2 us per step with an exchange per step against
+ * 28.3 us without a communicator - and 41.3 us when the exchange was ordered by an event on the compute stream.
+ * Partial sums beyond the isometric bound 16 ||h||_F (tensors that are not isometries, NaN) are added to a double
+ * instead.  Contract: the next call that launches must be qmps_cost_launch with the same B and window; a second
+ * accumulating launch before that fails with QMPS_ERR_STATE.  At most 983 040 evaluations per launch. */
 #define QMPS_FLAG_ACCUMULATE_COST 0x200
 /* With handoff == 0 (squaring from the start) the iterate is not tracked during the first
  * QMPS_SKIP_ROUNDS_D* squarings (no state converges in fewer than 2^skip power steps); the first

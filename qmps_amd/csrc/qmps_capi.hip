@@ -102,7 +102,7 @@ struct qmps_ctx {
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
   hipStream_t comm_stream = nullptr;
-  static constexpr int kCostSlots = 4;        // ring: step n's all-reduce may still be in flight while step n+1 sums
+  static constexpr int kCostSlots = 8;        // ring: step n's all-reduce may still be in flight while the next steps sum
   static constexpr int kMaxGroup = 16;        // steps whose summed costs may travel in ONE all-reduce
   double* d_cost_ring = nullptr;             // [kCostSlots][kMaxGroup][16]: a slot = one group of steps
   int exchange_period = 1;                   // steps per all-reduce (qmps_set_exchange_period)
@@ -118,6 +118,9 @@ struct qmps_ctx {
   bool acc_is[kCostSlots][kMaxGroup] = {};   // the position's cost lives in its accumulator (not yet a double in the ring)
   bool acc_dirty[kCostSlots][kMaxGroup] = {};  // the accumulator has been added to since it was last cleared
   double acc_scale[kCostSlots][kMaxGroup] = {};
+  int acc_shards[kCostSlots][kMaxGroup] = {};
+  long long acc_expect[kCostSlots][kMaxGroup] = {};   // waves (tiles of 16 evaluations) that add to each term's shards
+  int* d_acc_err = nullptr;                  // set by a finish kernel whose producer never arrived (bounded poll)
   bool acc_pending = false;                  // an accumulating launch waits for its qmps_cost_launch
   int64_t acc_B = 0, acc_window = 0;
   int acc_slot = 0, acc_pos = 0;
@@ -268,6 +271,8 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     HIP_TRY(hipMalloc((void**)&c->d_acc, acc_bytes));
     HIP_TRY(hipMemsetAsync(c->d_acc, 0, acc_bytes, c->stream));
     HIP_TRY(hipHostMalloc((void**)&c->h_acc, qmps::kAccWords * sizeof(long long), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&c->d_acc_err, sizeof(int)));
+    HIP_TRY(hipMemsetAsync(c->d_acc_err, 0, sizeof(int), c->stream));
     HIP_TRY(hipMalloc((void**)&c->d_work_count, sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&c->d_work_idx, (size_t)max_batch * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(c->d_work_count, 0, sizeof(int32_t), c->stream));
@@ -302,7 +307,7 @@ int qmps_destroy(qmps_ctx* c) {
     if (c->cost_reduced[i]) (void)hipEventDestroy(c->cost_reduced[i]);
   }
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
-  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc};
+  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc, c->d_acc_err};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
@@ -598,18 +603,31 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
         HIP_TRY(hipMemsetAsync(c->acc_at(slot, pos), 0, qmps::kAccWords * sizeof(long long), c->stream));
         c->acc_dirty[slot][pos] = false;
       }
-      // a slot of the ring is touched again only after its previous exchange has finished
-      if (c->comm && nslot != slot && c->groups + 1 >= qmps_ctx::kCostSlots)
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->cost_reduced[nslot], 0));
+      // a slot of the ring is touched again only after its previous exchange has finished.  Asked on the HOST (the
+      // exchange of kCostSlots - 1 steps ago has normally finished long ago): a stream wait would put a barrier packet
+      // on the compute stream in every step (+4 us measured), and the compute stream carries no event either
+      if (c->comm && nslot != slot && c->groups + 1 >= qmps_ctx::kCostSlots && hipEventQuery(c->cost_reduced[nslot]) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipEventSynchronize(c->cost_reduced[nslot]));
+      }
+      const int64_t tiles = (B + 15) / 16;
+      int shards = 32;
+      while (shards * (int64_t)qmps::kAccMaxWavesPerShard < tiles && shards < qmps::kAccMaxShards) shards *= 2;
+      if (shards * (int64_t)qmps::kAccMaxWavesPerShard < tiles)
+        return fail(QMPS_ERR_ARG, "B=%lld too large for QMPS_FLAG_ACCUMULATE_COST (at most %lld evaluations per launch)", (long long)B,
+                    (long long)qmps::kAccMaxShards * qmps::kAccMaxWavesPerShard * 16);
       a.acc = c->acc_at(slot, pos);
       a.acc_zero = c->acc_dirty[nslot][npos] ? c->acc_at(nslot, npos) : nullptr;
-      // scale 2^k with B ||h||_F 2^k <= 2^61; per-wave partial sums beyond 16 ||h||_F bypass the fixed-point sum
+      a.acc_shards = shards;
+      // per-wave partial sums (16 evaluations) beyond 16 ||h||_F bypass the fixed-point sum; scale 2^k with bound 2^k <= 2^51
       const double hf = c->h_fro > 1e-300 ? c->h_fro : 1.0;
-      int k = (int)floor(61.0 - log2((double)(B > 0 ? B : 1) * hf));
+      a.acc_bound = 16.0 * hf * (1.0 + 1e-6);
+      int k = (int)floor((double)qmps::kAccOffsetBits - 1e-9 - log2(a.acc_bound));
       if (k > 1000) k = 1000;
       if (k < -1000) k = -1000;
       a.acc_scale = ldexp(1.0, k);
-      a.acc_bound = 16.0 * hf * (1.0 + 1e-6);
+      c->acc_shards[slot][pos] = shards;
+      c->acc_expect[slot][pos] = tiles;
       c->acc_scale[slot][pos] = a.acc_scale;
       c->acc_dirty[slot][pos] = true;
       c->acc_dirty[nslot][npos] = false;
@@ -1174,15 +1192,26 @@ int close_group(qmps_ctx* c) {
   const int slot = (int)(c->groups % qmps_ctx::kCostSlots);
   double* base = c->d_cost_ring + (size_t)slot * qmps_ctx::kMaxGroup * kMaxTerms;
   if (c->comm) {
-    HIP_TRY(hipEventRecord(c->cost_ready[slot], c->stream));
-    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->cost_ready[slot], 0));
+    static const bool dbg_noevent = getenv("QMPS_DBG_NOEVENT") != nullptr, dbg_noar = getenv("QMPS_DBG_NOAR") != nullptr,
+                      dbg_nofinish = getenv("QMPS_DBG_NOFINISH") != nullptr;   // timing experiments only (wrong results)
+    // positions whose cost lives in a fixed-point accumulator need no ordering on the compute stream: their finish
+    // kernel polls the arrival counts.  Only costs written by reduction kernels on the compute stream need the event.
+    bool need_event = false;
+    for (int pos = 0; pos < c->group_fill; ++pos) need_event = need_event || !c->acc_is[slot][pos];
+    if (need_event && !dbg_noevent) {
+      HIP_TRY(hipEventRecord(c->cost_ready[slot], c->stream));
+      HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->cost_ready[slot], 0));
+    }
     for (int pos = 0; pos < c->group_fill; ++pos)
       if (c->acc_is[slot][pos]) {   // fixed-point accumulators -> doubles, off the compute stream
-        HIP_TRY(qmps::launch_cost_finish(c->acc_at(slot, pos), 1.0 / c->acc_scale[slot][pos], c->n_terms,
-                                         base + (size_t)pos * kMaxTerms, c->comm_stream));
+        if (!dbg_nofinish)
+          HIP_TRY(qmps::launch_cost_finish(c->acc_at(slot, pos), c->acc_shards[slot][pos], c->acc_expect[slot][pos], 1 << 22,
+                                           1.0 / c->acc_scale[slot][pos], c->n_terms, base + (size_t)pos * kMaxTerms,
+                                           c->d_acc_err, c->comm_stream));
         c->acc_is[slot][pos] = false;
       }
-    RCCL_TRY(ncclAllReduce(base, base, (size_t)c->group_fill * kMaxTerms, ncclDouble, ncclSum, c->comm, c->comm_stream));
+    if (!dbg_noar)
+      RCCL_TRY(ncclAllReduce(base, base, (size_t)c->group_fill * kMaxTerms, ncclDouble, ncclSum, c->comm, c->comm_stream));
     HIP_TRY(hipEventRecord(c->cost_reduced[slot], c->comm_stream));
   }
   c->group_fill = 0;
@@ -1245,9 +1274,17 @@ int qmps_get_cost(qmps_ctx* c, double* cost) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     const double inv = 1.0 / c->acc_scale[c->last_slot][c->last_pos];
     for (int t = 0; t < c->n_terms; ++t) {
-      long long v = 0;
-      for (int sh = 0; sh < qmps::kAccShards; ++sh) v += c->h_acc[(t * qmps::kAccShards + sh) * qmps::kAccStride];
-      cost[t] = (double)v * inv + ((const double*)(c->h_acc + qmps::kAccOver))[t];
+      long long cnt = 0, hi = 0, lo = 0;
+      for (int sh = 0; sh < c->acc_shards[c->last_slot][c->last_pos]; ++sh) {
+        long long k, v;
+        qmps::acc_decode(c->h_acc[t * qmps::kAccMaxShards + sh], k, v);
+        cnt += k;
+        hi += v >> 20;
+        lo += v & 0xFFFFF;
+      }
+      if (cnt != c->acc_expect[c->last_slot][c->last_pos])
+        return fail(QMPS_ERR_STATE, "cost accumulator: %lld of %lld waves arrived", cnt, c->acc_expect[c->last_slot][c->last_pos]);
+      cost[t] = ((double)hi * 1048576.0 + (double)lo) * inv + ((const double*)(c->h_acc + qmps::kAccOver))[t];
     }
     return QMPS_OK;
   }

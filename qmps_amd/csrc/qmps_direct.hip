@@ -142,7 +142,8 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
   if (status == QMPS_ST_OK && !pd) status = QMPS_ST_NOT_PD;
   if (p.acc_zero != nullptr && blockIdx.x == 0) {
     // clear the accumulator of a later step (nobody reads or adds to it during this launch)
-    for (int i = lane; i < p.n_terms * kAccShards; i += 64) p.acc_zero[i * kAccStride] = 0;
+    for (int t = 0; t < p.n_terms; ++t)
+      for (int i = lane; i < kAccMaxShards; i += 64) p.acc_zero[t * kAccMaxShards + i] = 0;
     if (lane < 16) p.acc_zero[kAccOver + lane] = 0;
   }
   for (int t = 0; t < p.n_terms; ++t) {
@@ -154,12 +155,16 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
         // first pass of the cost reduction: one partial per wave, fixed order
         if (p.partial != nullptr) p.partial[(int64_t)t * gridDim.x + blockIdx.x] = s;
         if (p.acc != nullptr) {
-          // ... or the whole reduction: an exact fixed-point sum (order-independent), no second kernel
-          if (fabs(s) <= p.acc_bound)
-            atomicAdd((unsigned long long*)p.acc + (t * kAccShards + (blockIdx.x & (kAccShards - 1))) * kAccStride,
-                      (unsigned long long)__double2ll_rn(s * p.acc_scale));
-          else
+          // ... or the whole reduction: an exact fixed-point sum (order-independent) + the arrival count, ONE atomic
+          long long fx = 0;
+          if (fabs(s) <= p.acc_bound) {
+            fx = __double2ll_rn(s * p.acc_scale);
+          } else {
             atomicAdd((double*)(p.acc + kAccOver) + t, s);
+            __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the overflow sum is in before this wave counts as arrived
+          }
+          atomicAdd((unsigned long long*)p.acc + t * kAccMaxShards + (blockIdx.x & (p.acc_shards - 1)),
+                    (unsigned long long)(fx + (1LL << kAccOffsetBits) + (1LL << kAccValueBits)));
         }
       }
     }
@@ -200,20 +205,46 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
   }
 }
 
-// acc (fixed point) -> cost[t]: integer sum of the shards (exact), one conversion, plus the overflow sum
-__global__ __launch_bounds__(64) void cost_finish_kernel(const long long* __restrict__ acc, double inv_scale, int n_terms,
-                                                         double* __restrict__ cost) {
+// acc (fixed point + arrival counts) -> cost[t].  One wave.  With expect > 0 the producer may still be running on
+// another stream: sweep the shards (agent-scope loads) until `expect` waves per term have arrived, sleeping in between;
+// a bounded number of sweeps, then NaN + *err (a reader never hangs the GPU).  The integer sum of the shards is exact.
+__global__ __launch_bounds__(64) void cost_finish_kernel(const long long* __restrict__ acc, int n_shards, long long expect,
+                                                         int max_polls, double inv_scale, int n_terms,
+                                                         double* __restrict__ cost, int* __restrict__ err) {
   const int lane = threadIdx.x;
   for (int t = 0; t < n_terms; ++t) {
-    long long v = lane < kAccShards ? acc[(t * kAccShards + lane) * kAccStride] : 0;
+    long long cnt = 0, hi = 0, lo = 0;
+    for (int poll = 0;; ++poll) {
+      cnt = 0; hi = 0; lo = 0;
+      for (int i = lane; i < n_shards; i += 64) {
+        const long long w = __hip_atomic_load(acc + t * kAccMaxShards + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long c, v;
+        acc_decode(w, c, v);
+        cnt += c;
+        hi += v >> 20;                  // split so that the sum over <= 1024 shards stays inside 64 bits
+        lo += v & 0xFFFFF;
+      }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    if (lane == 0) cost[t] = (double)v * inv_scale + ((const double*)(acc + kAccOver))[t];
+      for (int m = 32; m >= 1; m >>= 1) {
+        cnt += __shfl_xor(cnt, m, 64);
+        hi += __shfl_xor(hi, m, 64);
+        lo += __shfl_xor(lo, m, 64);
+      }
+      if (expect <= 0 || cnt >= expect || poll >= max_polls) break;
+      __builtin_amdgcn_s_sleep(32);
+    }
+    if (lane == 0) {
+      const bool ok = expect <= 0 || cnt == expect;
+      const double over = __hip_atomic_load((const double*)(acc + kAccOver) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cost[t] = ok ? ((double)hi * 1048576.0 + (double)lo) * inv_scale + over : __builtin_nan("");
+      if (!ok && err != nullptr) *err = 1;
+    }
   }
 }
 
-hipError_t launch_cost_finish(const long long* acc, double inv_scale, int n_terms, double* cost, hipStream_t st) {
-  hipLaunchKernelGGL(cost_finish_kernel, dim3(1), dim3(64), 0, st, acc, inv_scale, n_terms, cost);
+hipError_t launch_cost_finish(const long long* acc, int n_shards, long long expect, int max_polls, double inv_scale,
+                              int n_terms, double* cost, int* err, hipStream_t st) {
+  hipLaunchKernelGGL(cost_finish_kernel, dim3(1), dim3(64), 0, st, acc, n_shards, expect, max_polls, inv_scale, n_terms, cost, err);
   return hipGetLastError();
 }
 

@@ -32,25 +32,36 @@ struct LaneArgs {
   const int32_t* idx_count;
   int check_pd;               // !SOLVE: Cholesky test of the resident r, status 0 -> 2 on failure
   double* partial;            // nullable [n_terms][gridDim.x]: per-wave sums of the energies (lane kernels)
-  // exact in-kernel cost accumulation (energy_direct_d4_kernel): per-wave sums are added as 64-bit fixed-point integers
-  // (integer addition commutes: the result does not depend on the order the waves finish in) to
-  // acc[(term * kAccShards + shard) * kAccStride], shard = workgroup % kAccShards; a partial beyond acc_bound (tensor not
-  // an isometry, NaN) goes to the double acc[kAccOver + term] instead.  acc_zero: accumulator of a LATER step, cleared here.
+  // exact in-kernel cost accumulation (energy_direct_d4_kernel): every wave adds ONE 64-bit word per term to
+  // acc[term * kAccMaxShards + (tile % acc_shards)] - its partial sum as a fixed-point integer (scale acc_scale, offset
+  // 2^51 so that the addend is positive) in bits 0..57 and an arrival count of 1 in bits 58..63.  Integer addition
+  // commutes: the sum is exact and does not depend on the order the waves finish in; the count tells a reader on another
+  // stream when every wave has arrived (no event on the compute stream).  A partial beyond acc_bound (tensor not an
+  // isometry, NaN) goes to the double acc[kAccOver + term] first and counts with value 0.
+  // acc_zero: accumulator of a LATER step, cleared here.
   long long* acc;
   long long* acc_zero;
-  double acc_scale;           // 2^k
+  double acc_scale;           // 2^k with acc_bound * 2^k <= 2^51
   double acc_bound;
+  int acc_shards;             // power of two, waves per shard <= 60
 };
 
 // D = 8 direct fixed-point solve, one wave per evaluation: writes the environments r[B][8][8] (the warm start / result
 // that energy_block_kernel<8, true> then accepts with one power step)
 hipError_t launch_env_direct_d8(const void* A, void* r_out, int64_t B, hipStream_t st);
-// layout of one cost accumulator (long long units): 16 terms x 32 shards, each shard on its own 64-byte line, then 16
-// doubles of overflow sums
-constexpr int kAccShards = 32, kAccStride = 8, kAccOver = 16 * kAccShards * kAccStride, kAccWords = kAccOver + 16;
-// acc -> cost[t] = (sum of the shards) / scale + overflow sum; one wave
-hipError_t launch_cost_finish(const long long* acc, double inv_scale, int n_terms, double* cost, hipStream_t st);
-
+// layout of one cost accumulator (long long units): 16 terms x kAccMaxShards words, then 16 doubles of overflow sums
+constexpr int kAccMaxShards = 1024, kAccOver = 16 * kAccMaxShards, kAccWords = kAccOver + 16;
+constexpr int kAccValueBits = 58, kAccOffsetBits = 51, kAccMaxWavesPerShard = 60;
+// decode one word: (count, value) - value = sum of the fixed-point partials of `count` waves
+__host__ __device__ inline void acc_decode(long long w, long long& count, long long& value) {
+  count = (long long)((unsigned long long)w >> kAccValueBits);
+  value = (w & ((1LL << kAccValueBits) - 1)) - count * (1LL << kAccOffsetBits);
+}
+// acc -> cost[t] = (sum of the shards) / scale + overflow sum; one wave.  expect > 0: first POLL until `expect` waves
+// per term have arrived (the producer kernel may still be running on another stream), at most max_polls sweeps - then
+// cost = NaN and *err = 1.
+hipError_t launch_cost_finish(const long long* acc, int n_shards, long long expect, int max_polls, double inv_scale,
+                              int n_terms, double* cost, int* err, hipStream_t st);
 // D = 4 repeated-squaring tail over the worklist (one wave per item, MFMA f64 16x16x4)
 struct SquareArgs {
   const void* A;

@@ -102,6 +102,13 @@ struct qmps_ctx {
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
   hipStream_t comm_stream = nullptr;
+  // a second communicator (ncclCommSplit of the first) on its own stream: the exchanges of consecutive ring slots
+  // alternate between the two, so two small all-reduces can be in flight - the exchange keeps up with the compute stream
+  // as long as an all-reduce takes less than TWO steps (a step is ~28 us; a small all-reduce over 8 GPUs 15-40 us)
+  ncclComm_t comm2 = nullptr;
+  hipStream_t comm_stream2 = nullptr;
+  ncclComm_t comm_of(int slot) const { return (slot & 1) && comm2 ? comm2 : comm; }
+  hipStream_t comm_stream_of(int slot) const { return (slot & 1) && comm2 ? comm_stream2 : comm_stream; }
   static constexpr int kCostSlots = 8;        // ring: step n's all-reduce may still be in flight while the next steps sum
   static constexpr int kMaxGroup = 16;        // steps whose summed costs may travel in ONE all-reduce
   double* d_cost_ring = nullptr;             // [kCostSlots][kMaxGroup][16]: a slot = one group of steps
@@ -117,6 +124,7 @@ struct qmps_ctx {
   long long* h_acc = nullptr;                // pinned [kAccWords]
   bool acc_is[kCostSlots][kMaxGroup] = {};   // the position's cost lives in its accumulator (not yet a double in the ring)
   bool acc_dirty[kCostSlots][kMaxGroup] = {};  // the accumulator has been added to since it was last cleared
+  bool acc_after_event[kCostSlots][kMaxGroup] = {};  // cleared by a memset on the compute stream: its finish kernel must wait for an event
   double acc_scale[kCostSlots][kMaxGroup] = {};
   int acc_shards[kCostSlots][kMaxGroup] = {};
   long long acc_expect[kCostSlots][kMaxGroup] = {};   // waves (tiles of 16 evaluations) that add to each term's shards
@@ -262,6 +270,7 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     HIP_TRY(hipMalloc((void**)&c->d_cost_ring, (size_t)qmps_ctx::kCostSlots * qmps_ctx::kMaxGroup * kMaxTerms * sizeof(double)));
     HIP_TRY(hipMemsetAsync(c->d_cost_ring, 0, (size_t)qmps_ctx::kCostSlots * qmps_ctx::kMaxGroup * kMaxTerms * sizeof(double), c->stream));
     HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream2, hipStreamNonBlocking));
     for (int i = 0; i < qmps_ctx::kCostSlots; ++i) {
       HIP_TRY(hipEventCreateWithFlags(&c->cost_ready[i], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c->cost_reduced[i], hipEventDisableTiming));
@@ -301,12 +310,15 @@ int qmps_destroy(qmps_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+  if (c->comm_stream2) (void)hipStreamSynchronize(c->comm_stream2);
+  if (c->comm2) (void)ncclCommDestroy(c->comm2);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   for (int i = 0; i < qmps_ctx::kCostSlots; ++i) {
     if (c->cost_ready[i]) (void)hipEventDestroy(c->cost_ready[i]);
     if (c->cost_reduced[i]) (void)hipEventDestroy(c->cost_reduced[i]);
   }
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  if (c->comm_stream2) (void)hipStreamDestroy(c->comm_stream2);
   void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc, c->d_acc_err};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -328,6 +340,7 @@ int qmps_sync(qmps_ctx* c) {
   if (int rc = close_group(c)) return rc;     // costs still waiting for their exchange go out now
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipStreamSynchronize(c->comm_stream));
+  HIP_TRY(hipStreamSynchronize(c->comm_stream2));
   return QMPS_OK;
 }
 
@@ -594,19 +607,26 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     a.r_in = nullptr;
     a.r_out = (flags & QMPS_FLAG_NO_ENV_OUT) ? nullptr : c->d_r;
     if (flags & QMPS_FLAG_ACCUMULATE_COST) {
-      // the position the following qmps_cost_launch will use; its accumulator must be clear, and the kernel clears the
-      // one after it (a position is reused after kCostSlots x period steps)
+      // The position the following qmps_cost_launch will use: its accumulator must be clear BEFORE the finish kernel of
+      // this step starts to poll it on a communication stream (a stale word of the previous lap carries a full arrival
+      // count).  Consecutive ring slots alternate between two communication streams, so every launch clears the same
+      // position TWO slots ahead: the finish kernel of this step (same stream as that later slot's) completes only when
+      // every wave of this kernel - the clearing one included - has arrived, and the later slot's finish kernel is queued
+      // behind it.
       const int slot = (int)(c->groups % qmps_ctx::kCostSlots), pos = c->group_fill;
-      int nslot = slot, npos = pos + 1;
-      if (npos >= c->exchange_period) { nslot = (int)((c->groups + 1) % qmps_ctx::kCostSlots); npos = 0; }
-      if (c->acc_dirty[slot][pos]) {   // unusual call order (period changed, an accumulated cost was dropped): clear it now
+      const int nslot = (int)((c->groups + 2) % qmps_ctx::kCostSlots), npos = pos;
+      c->acc_after_event[slot][pos] = false;
+      if (c->acc_dirty[slot][pos]) {
+        // unusual call order (exchange period changed, a partly filled group, an accumulated cost that was dropped): clear
+        // it now on the compute stream, and order this position's finish kernel behind that by an event
         HIP_TRY(hipMemsetAsync(c->acc_at(slot, pos), 0, qmps::kAccWords * sizeof(long long), c->stream));
         c->acc_dirty[slot][pos] = false;
+        c->acc_after_event[slot][pos] = true;
       }
-      // a slot of the ring is touched again only after its previous exchange has finished.  Asked on the HOST (the
-      // exchange of kCostSlots - 1 steps ago has normally finished long ago): a stream wait would put a barrier packet
+      // a slot of the ring is touched again only after its previous exchange has finished.  Asked on the HOST (that
+      // exchange, kCostSlots - 2 groups ago, has normally finished long ago): a stream wait would put a barrier packet
       // on the compute stream in every step (+4 us measured), and the compute stream carries no event either
-      if (c->comm && nslot != slot && c->groups + 1 >= qmps_ctx::kCostSlots && hipEventQuery(c->cost_reduced[nslot]) != hipSuccess) {
+      if (c->comm && c->groups + 2 >= qmps_ctx::kCostSlots && hipEventQuery(c->cost_reduced[nslot]) != hipSuccess) {
         (void)hipGetLastError();
         HIP_TRY(hipEventSynchronize(c->cost_reduced[nslot]));
       }
@@ -1145,6 +1165,11 @@ int qmps_comm_init(qmps_ctx* c, const char id[QMPS_UNIQUE_ID_BYTES], int rank, i
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
   RCCL_TRY(ncclCommInitRank(&c->comm, nranks, u, rank));
+  if (!getenv("QMPS_ONE_COMM")) {
+    // second communicator over the same ranks (collective, like the init itself); without it everything runs on the first
+    ncclResult_t r2 = ncclCommSplit(c->comm, 0, rank, &c->comm2, nullptr);
+    if (r2 != ncclSuccess) c->comm2 = nullptr;
+  }
   c->rank = rank;
   c->nranks = nranks;
   return QMPS_OK;
@@ -1155,6 +1180,9 @@ int qmps_comm_destroy(qmps_ctx* c) {
   if (c->comm) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    HIP_TRY(hipStreamSynchronize(c->comm_stream2));
+    if (c->comm2) RCCL_TRY(ncclCommDestroy(c->comm2));
+    c->comm2 = nullptr;
     RCCL_TRY(ncclCommDestroy(c->comm));
     c->comm = nullptr;
     c->nranks = 1;
@@ -1197,22 +1225,22 @@ int close_group(qmps_ctx* c) {
     // positions whose cost lives in a fixed-point accumulator need no ordering on the compute stream: their finish
     // kernel polls the arrival counts.  Only costs written by reduction kernels on the compute stream need the event.
     bool need_event = false;
-    for (int pos = 0; pos < c->group_fill; ++pos) need_event = need_event || !c->acc_is[slot][pos];
+    for (int pos = 0; pos < c->group_fill; ++pos) need_event = need_event || !c->acc_is[slot][pos] || c->acc_after_event[slot][pos];
     if (need_event && !dbg_noevent) {
       HIP_TRY(hipEventRecord(c->cost_ready[slot], c->stream));
-      HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->cost_ready[slot], 0));
+      HIP_TRY(hipStreamWaitEvent(c->comm_stream_of(slot), c->cost_ready[slot], 0));
     }
     for (int pos = 0; pos < c->group_fill; ++pos)
       if (c->acc_is[slot][pos]) {   // fixed-point accumulators -> doubles, off the compute stream
         if (!dbg_nofinish)
           HIP_TRY(qmps::launch_cost_finish(c->acc_at(slot, pos), c->acc_shards[slot][pos], c->acc_expect[slot][pos], 1 << 22,
                                            1.0 / c->acc_scale[slot][pos], c->n_terms, base + (size_t)pos * kMaxTerms,
-                                           c->d_acc_err, c->comm_stream));
+                                           c->d_acc_err, c->comm_stream_of(slot)));
         c->acc_is[slot][pos] = false;
       }
     if (!dbg_noar)
-      RCCL_TRY(ncclAllReduce(base, base, (size_t)c->group_fill * kMaxTerms, ncclDouble, ncclSum, c->comm, c->comm_stream));
-    HIP_TRY(hipEventRecord(c->cost_reduced[slot], c->comm_stream));
+      RCCL_TRY(ncclAllReduce(base, base, (size_t)c->group_fill * kMaxTerms, ncclDouble, ncclSum, c->comm_of(slot), c->comm_stream_of(slot)));
+    HIP_TRY(hipEventRecord(c->cost_reduced[slot], c->comm_stream_of(slot)));
   }
   c->group_fill = 0;
   c->groups++;
@@ -1266,7 +1294,7 @@ int qmps_get_cost(qmps_ctx* c, double* cost) {
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
   if (c->cost_launches < 1) return fail(QMPS_ERR_STATE, "qmps_cost_launch has not been called");
   if (int rc = close_group(c)) return rc;     // a partly filled group is exchanged now
-  hipStream_t st = c->comm ? c->comm_stream : c->stream;
+  hipStream_t st = c->comm ? c->comm_stream_of(c->last_slot) : c->stream;
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->acc_is[c->last_slot][c->last_pos]) {
     // no communicator: the cost still lives in its fixed-point accumulator; sum the shards on the host (exact)

@@ -226,6 +226,14 @@ def test_in_kernel_cost_accumulation(with_comm):
                     c = eng.get_cost()
                     assert np.abs(c - sums[k % 5]).max() < 1e-10, (period, k)
         eng.set_exchange_period(1)
+        # many laps of the accumulator ring with the host running far ahead of the GPU (no read-back in between): a finish
+        # kernel must never mistake the previous lap's words (full arrival count) for this step's
+        for k in range(150):
+            eng.set_window((k % 5) * 777)
+            eng.launch(777, accumulate_cost=True, store_env=False)
+            eng.cost_launch(777)
+            if k % 37 == 36 or k == 149:
+                assert np.abs(eng.get_cost() - sums[k % 5]).max() < 1e-10, k
         # the fixed-point sum does not depend on the order the waves finish in: bit-identical repeats
         seen = set()
         for _ in range(5):

@@ -1831,6 +1831,25 @@ struct Reg {
     }
     return e;
   }
+  // reduced density matrix of qubit 0 (the most significant index bit): rho[a][b] = sum_rest psi[a, rest] conj(psi[b, rest])
+  __device__ __forceinline__ void rdm_q0(double (&rr)[2][2], double (&ri)[2][2]) const {
+    constexpr int H = N / 2;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        double xr = 0.0, xi = 0.0;
+#pragma unroll
+        for (int t = 0; t < H; ++t) {
+          xr = dfma(re[a * H + t], re[b * H + t], xr);
+          xr = dfma(im[a * H + t], im[b * H + t], xr);
+          xi = dfma(im[a * H + t], re[b * H + t], xi);
+          xi = dfma(-re[a * H + t], im[b * H + t], xi);
+        }
+        rr[a][b] = xr;
+        ri[a][b] = xi;
+      }
+  }
   // ShallowFullStateTensor(2, v) (qmps/represent.py:393-401) on qubits (a, b)
   __device__ __forceinline__ void shallow_full(int a, int b, const double* v) {
     rz(a, v[0]); rx(a, v[1]); rz(a, v[2]);
@@ -1842,6 +1861,19 @@ struct Reg {
     cnot(a, b);
     rz(a, v[9]); rx(a, v[10]); rz(a, v[11]);
     rz(b, v[12]); rx(b, v[13]); rz(b, v[14]);
+  }
+  // the same gate list with the half-angle cosines / sines already computed (one sincos per angle, whatever the number
+  // of circuits the gate appears in)
+  __device__ __forceinline__ void shallow_full_cs(int a, int b, const double* c, const double* s) {
+    u2(a, c[0], -s[0], 0, 0, 0, 0, c[0], s[0]); u2(a, c[1], 0, 0, -s[1], 0, -s[1], c[1], 0); u2(a, c[2], -s[2], 0, 0, 0, 0, c[2], s[2]);
+    u2(b, c[3], -s[3], 0, 0, 0, 0, c[3], s[3]); u2(b, c[4], 0, 0, -s[4], 0, -s[4], c[4], 0); u2(b, c[5], -s[5], 0, 0, 0, 0, c[5], s[5]);
+    cnot(a, b);
+    u2(a, c[6], 0, -s[6], 0, s[6], 0, c[6], 0);
+    cnot(b, a);
+    u2(a, c[7], 0, -s[7], 0, s[7], 0, c[7], 0); u2(b, c[8], -s[8], 0, 0, 0, 0, c[8], s[8]);
+    cnot(a, b);
+    u2(a, c[9], -s[9], 0, 0, 0, 0, c[9], s[9]); u2(a, c[10], 0, 0, -s[10], 0, -s[10], c[10], 0); u2(a, c[11], -s[11], 0, 0, 0, 0, c[11], s[11]);
+    u2(b, c[12], -s[12], 0, 0, 0, 0, c[12], s[12]); u2(b, c[13], 0, 0, -s[13], 0, -s[13], c[13], 0); u2(b, c[14], -s[14], 0, 0, 0, 0, c[14], s[14]);
   }
   __device__ __forceinline__ void reset() {
 #pragma unroll
@@ -2618,63 +2650,161 @@ __global__ __launch_bounds__(64) void bw_env_kernel(BwArgs p) {
   p.status[b] = status;
 }
 
+// ManifoldOverlap.circuit (new_tdvp/ClassicalTDVPStripped.py:239-275) without a 6-qubit state vector (the literal
+// simulation of round 1 held 64 amplitudes per lane and spilled 882 registers).  With a = U2[:, 0] (the pair state
+// U2|00>), b = U2'[0, :] (the bra <00|U2') and big-endian two-bit indices,
+//   ket(y0; y12; y34; y5) = sum_z U1[y12, z1 z2] U1[y34, z3 z4] a[y0 z1] a[z2 z3] a[z4 y5]
+//   bra(x0; x12; x34; x5) = sum_w b[x0 w1] b[w2 w3] b[w4 x5] U1'[w1 w2, x12] U1'[w3 w4, x34]
+//   out = sum Ml[x0, y0] Mr[x5, y5] bra(x) W[x12 x34, y12 y34] ket(y)
+// Both vectors have rank 2 across the middle bond: ket = sum_c KL[y0][y12][c] KR[y5][y34][c] (the middle pair a[z2 z3] folded
+// into KL), bra likewise with Ml, Mr folded into BL, BR.  So out = sum_{y0, y5} <B_{y0 y5}| W |K_{y0 y5}> : four 16 x 16
+// sandwiches, the 16-vectors rebuilt from their 4 x 2 factors on the fly.
 __global__ __launch_bounds__(64) void bw_manifold_kernel(BwArgs p) {
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= p.B) return;
-  Reg<6> r;
+  const double2* U1 = (const double2*)p.U1 + b * 16;
+  const double2* U2 = (const double2*)p.U2 + b * 16;
+  const double2* U1p = (const double2*)p.U1p + b * 16;
+  const double2* U2p = (const double2*)p.U2p + b * 16;
+  const double2* Ml = (const double2*)p.Ml + (p.m_shared ? 0 : b * 4);
+  const double2* Mr = (const double2*)p.Mr + (p.m_shared ? 0 : b * 4);
+  const double2* W = (const double2*)p.O + (p.o_shared ? 0 : b * 256);
+  auto cm = [](double2 x, double2 y) { return make_double2(x.x * y.x - x.y * y.y, x.x * y.y + x.y * y.x); };
+  auto acc = [](double2& t, double2 x, double2 y) {
+    t.x = dfma(x.x, y.x, t.x);
+    t.x = dfma(-x.y, y.y, t.x);
+    t.y = dfma(x.x, y.y, t.y);
+    t.y = dfma(x.y, y.x, t.y);
+  };
+  double2 a[4], bb[4];
 #pragma unroll
-  for (int x = 0; x < 64; ++x) { r.re[x] = (x == 0) ? 1.0 : 0.0; r.im[x] = 0.0; }
-  double gr[16], gi[16];
-  load_u4((const double2*)p.U2 + b * 16, gr, gi);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) r.u4(2 * k, 2 * k + 1, gr, gi);
-  load_u4((const double2*)p.U1 + b * 16, gr, gi);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) r.u4(2 * k + 1, 2 * k + 2, gr, gi);
-  {
-    const double2* Ml = (const double2*)p.Ml + (p.m_shared ? 0 : b * 4);
-    const double2* Mr = (const double2*)p.Mr + (p.m_shared ? 0 : b * 4);
-    double ar[4], ai[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { ar[k] = Ml[k].x; ai[k] = Ml[k].y; }
-    r.u2m(0, ar, ai);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { ar[k] = Mr[k].x; ai[k] = Mr[k].y; }
-    r.u2m(5, ar, ai);
+  for (int k = 0; k < 4; ++k) {
+    a[k] = U2[k * 4];        // column 0 of U2
+    bb[k] = U2p[k];          // row 0 of U2'
   }
+  // ket factors: KL[y0][y12][z3] = sum_{z1 z2} U1[y12, z1 z2] a[y0 z1] a[z2 z3];  KR[y5][y34][z3] = sum_{z4} U1[y34, z3 z4] a[z4 y5]
+  double2 KL[2][4][2], KR[2][4][2];
   {
-    // W (16 x 16) on qubits 1..4: index bits 4..1; outer bits: qubit 0 (bit 5) and qubit 5 (bit 0)
-    const double2* W = (const double2*)p.O + (p.o_shared ? 0 : b * 256);
+    double2 u1[16];
 #pragma unroll
-    for (int hi = 0; hi < 2; ++hi)
+    for (int k = 0; k < 16; ++k) u1[k] = U1[k];
 #pragma unroll
-      for (int lo = 0; lo < 2; ++lo) {
-        double tr[16], ti[16];
+    for (int y0 = 0; y0 < 2; ++y0)
 #pragma unroll
-        for (int t = 0; t < 16; ++t) { tr[t] = r.re[(hi << 5) | (t << 1) | lo]; ti[t] = r.im[(hi << 5) | (t << 1) | lo]; }
+      for (int y = 0; y < 4; ++y) {
+        double2 t[2];     // sum_{z1} U1[y, z1 z2] a[y0 z1], z2 = 0, 1
 #pragma unroll
-        for (int a = 0; a < 16; ++a) {
-          double xr = 0.0, xi = 0.0;
+        for (int z2 = 0; z2 < 2; ++z2) {
+          t[z2] = make_double2(0.0, 0.0);
 #pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const double2 w = W[a * 16 + t];
-            xr = dfma(w.x, tr[t], xr);
-            xr = dfma(-w.y, ti[t], xr);
-            xi = dfma(w.x, ti[t], xi);
-            xi = dfma(w.y, tr[t], xi);
-          }
-          r.re[(hi << 5) | (a << 1) | lo] = xr;
-          r.im[(hi << 5) | (a << 1) | lo] = xi;
+          for (int z1 = 0; z1 < 2; ++z1) acc(t[z2], u1[y * 4 + 2 * z1 + z2], a[2 * y0 + z1]);
+        }
+#pragma unroll
+        for (int z3 = 0; z3 < 2; ++z3) {
+          double2 v = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int z2 = 0; z2 < 2; ++z2) acc(v, t[z2], a[2 * z2 + z3]);
+          KL[y0][y][z3] = v;
         }
       }
+#pragma unroll
+    for (int y5 = 0; y5 < 2; ++y5)
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int z3 = 0; z3 < 2; ++z3) {
+          double2 v = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int z4 = 0; z4 < 2; ++z4) acc(v, u1[y * 4 + 2 * z3 + z4], a[2 * z4 + y5]);
+          KR[y5][y][z3] = v;
+        }
   }
-  load_u4((const double2*)p.U1p + b * 16, gr, gi);
+  // bra factors with the boundary matrices folded in:
+  //   BL[y0][x12][w3] = sum_{x0} Ml[x0, y0] sum_{w1 w2} b[x0 w1] U1'[w1 w2, x12] b[w2 w3]
+  //   BR[y5][x34][w3] = sum_{x5} Mr[x5, y5] sum_{w4} U1'[w3 w4, x34] b[w4 x5]
+  double2 BL[2][4][2], BR[2][4][2];
+  {
+    double2 u1p[16], ml[4], mr[4];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) r.u4(2 * k + 1, 2 * k + 2, gr, gi);
-  load_u4((const double2*)p.U2p + b * 16, gr, gi);
+    for (int k = 0; k < 16; ++k) u1p[k] = U1p[k];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) r.u4(2 * k, 2 * k + 1, gr, gi);
-  ((double2*)p.out)[b] = make_double2(r.re[0], r.im[0]);
+    for (int k = 0; k < 4; ++k) { ml[k] = Ml[k]; mr[k] = Mr[k]; }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      double2 raw[2][2];   // [x0][w3]
+#pragma unroll
+      for (int x0 = 0; x0 < 2; ++x0) {
+        double2 t[2];      // sum_{w1} b[x0 w1] U1'[w1 w2, x], w2 = 0, 1
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+          t[w2] = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int w1 = 0; w1 < 2; ++w1) acc(t[w2], bb[2 * x0 + w1], u1p[(2 * w1 + w2) * 4 + x]);
+        }
+#pragma unroll
+        for (int w3 = 0; w3 < 2; ++w3) {
+          double2 v = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int w2 = 0; w2 < 2; ++w2) acc(v, t[w2], bb[2 * w2 + w3]);
+          raw[x0][w3] = v;
+        }
+      }
+#pragma unroll
+      for (int y0 = 0; y0 < 2; ++y0)
+#pragma unroll
+        for (int w3 = 0; w3 < 2; ++w3) {
+          double2 v = cm(ml[0 * 2 + y0], raw[0][w3]);
+          acc(v, ml[1 * 2 + y0], raw[1][w3]);
+          BL[y0][x][w3] = v;
+        }
+      double2 rawr[2][2];  // [x5][w3]
+#pragma unroll
+      for (int x5 = 0; x5 < 2; ++x5)
+#pragma unroll
+        for (int w3 = 0; w3 < 2; ++w3) {
+          double2 v = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int w4 = 0; w4 < 2; ++w4) acc(v, u1p[(2 * w3 + w4) * 4 + x], bb[2 * w4 + x5]);
+          rawr[x5][w3] = v;
+        }
+#pragma unroll
+      for (int y5 = 0; y5 < 2; ++y5)
+#pragma unroll
+        for (int w3 = 0; w3 < 2; ++w3) {
+          double2 v = cm(mr[0 * 2 + y5], rawr[0][w3]);
+          acc(v, mr[1 * 2 + y5], rawr[1][w3]);
+          BR[y5][x][w3] = v;
+        }
+    }
+  }
+  // out = sum_{y0, y5} sum_{x, y} B_{y0 y5}(x) W[x, y] K_{y0 y5}(y),  x = 4 x12 + x34,  y = 4 y12 + y34
+  double2 out = make_double2(0.0, 0.0);
+#pragma unroll
+  for (int y0 = 0; y0 < 2; ++y0)
+#pragma unroll
+    for (int y5 = 0; y5 < 2; ++y5) {
+      double2 K[16];
+#pragma unroll
+      for (int yl = 0; yl < 4; ++yl)
+#pragma unroll
+        for (int yr = 0; yr < 4; ++yr) {
+          double2 v = cm(KL[y0][yl][0], KR[y5][yr][0]);
+          acc(v, KL[y0][yl][1], KR[y5][yr][1]);
+          K[4 * yl + yr] = v;
+        }
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {       // (unrolled: a rolled loop would index BL / BR dynamically and push them to scratch)
+        double2 sx = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int y = 0; y < 16; ++y) acc(sx, W[x * 16 + y], K[y]);
+        const int xl = x >> 2, xr = x & 3;
+        double2 bx = cm(BL[y0][xl][0], BR[y5][xr][0]);
+        acc(bx, BL[y0][xl][1], BR[y5][xr][1]);
+        acc(out, bx, sx);
+        __builtin_amdgcn_sched_barrier(0);   // row by row: keeps the 1024 loads of W from being hoisted into the register file
+      }
+    }
+  ((double2*)p.out)[b] = out;
 }
 
 hipError_t launch_bw(int what, const BwArgs& a, hipStream_t st) {
@@ -2699,25 +2829,30 @@ hipError_t launch_bw(int what, const BwArgs& a, hipStream_t st) {
 //   u_purity   (6 qubits): V(1,2) U(0,1) V(4,5) U(3,4) SWAP(0,1) SWAP(1,2);   <SWAP(2,3)>
 //   uv_purity  (5 qubits): V(3,4) U(2,3) V(0,1) SWAP(0,1);        <SWAP(1,2)>
 //   f = energy + k (u_purity + v_purity - 2 uv_purity)
+// The three purity circuits act on PRODUCT states - psi_V = V|00> on a pair, phi = U(0,1) V(1,2)|000> on a triple - and for
+// |alpha> x |beta> the expectation of a SWAP between a qubit of alpha and a qubit of beta is tr(rho_alpha rho_beta).  The
+// SWAPs inside each circuit only move qubit 0 of the factor next to the measured cut, so (round 2; the literal 5- and
+// 6-qubit simulation of round 1 spilled 1390 registers per lane)
+//   v_purity = tr(rho_V^2),  uv_purity = tr(rho_V rho_phi),  u_purity = tr(rho_phi^2),   rho_X = one-qubit state of qubit 0 of X
+// Parity: oracle.opt_environment_objective simulates the four circuits literally.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void opt_env_lane_kernel(const double* __restrict__ params, const double2* __restrict__ h,
                                                           double k, double* __restrict__ f, double* __restrict__ parts,
                                                           int64_t B) {
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
-  double pu[15], pv[15];
-#pragma unroll
-  for (int i = 0; i < 15; ++i) {
-    pu[i] = params[b * 30 + i];
-    pv[i] = params[b * 30 + 15 + i];
+  double cu[15], su[15], cv[15], sv[15];      // cos / sin of the half angles: U = params[:15], V = params[15:]
+  for (int i = 0; i < 15; ++i) {               // (a rolled loop: one copy of the sincos expansion)
+    sincos(0.5 * params[b * 30 + i], &su[i], &cu[i]);
+    sincos(0.5 * params[b * 30 + 15 + i], &sv[i], &cv[i]);
   }
-  double energy, v_purity, u_purity, uv_purity;
+  double energy;
   {
     Reg<4> r;
     r.reset();
-    r.shallow_full(2, 3, pv);
-    r.shallow_full(1, 2, pu);
-    r.shallow_full(0, 1, pu);
+    r.shallow_full_cs(2, 3, cv, sv);
+    r.shallow_full_cs(1, 2, cu, su);
+    r.shallow_full_cs(0, 1, cu, su);
     // <psi| 1 x H x 1 |psi>, H on qubits 1,2 = index bits 2,1
     double e = 0.0;
 #pragma unroll
@@ -2735,32 +2870,31 @@ __global__ __launch_bounds__(64) void opt_env_lane_kernel(const double* __restri
             e += r.re[x] * yr + r.im[x] * yi;
           }
     energy = e;
+  }
+  double vr[2][2], vi[2][2], fr[2][2], fi[2][2];
+  {
+    Reg<2> r;
     r.reset();
-    r.shallow_full(0, 1, pv);
-    r.shallow_full(2, 3, pv);
-    r.swapq(0, 1);
-    v_purity = r.swap_expectation(1, 2);
+    r.shallow_full_cs(0, 1, cv, sv);
+    r.rdm_q0(vr, vi);
   }
   {
-    Reg<5> r;
+    Reg<3> r;
     r.reset();
-    r.shallow_full(3, 4, pv);
-    r.shallow_full(2, 3, pu);
-    r.shallow_full(0, 1, pv);
-    r.swapq(0, 1);
-    uv_purity = r.swap_expectation(1, 2);
+    r.shallow_full_cs(1, 2, cv, sv);
+    r.shallow_full_cs(0, 1, cu, su);
+    r.rdm_q0(fr, fi);
   }
-  {
-    Reg<6> r;
-    r.reset();
-    r.shallow_full(1, 2, pv);
-    r.shallow_full(0, 1, pu);
-    r.shallow_full(4, 5, pv);
-    r.shallow_full(3, 4, pu);
-    r.swapq(0, 1);
-    r.swapq(1, 2);
-    u_purity = r.swap_expectation(2, 3);
-  }
+  // tr(X Y) = sum_ab X[a][b] Y[b][a]  (real for Hermitian X, Y)
+  auto trprod = [](const double (&xr)[2][2], const double (&xi)[2][2], const double (&yr)[2][2], const double (&yi)[2][2]) {
+    double t = 0.0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) t += xr[a][c] * yr[c][a] - xi[a][c] * yi[c][a];
+    return t;
+  };
+  const double v_purity = trprod(vr, vi, vr, vi), u_purity = trprod(fr, fi, fr, fi), uv_purity = trprod(vr, vi, fr, fi);
   f[b] = energy + k * (u_purity + v_purity - 2.0 * uv_purity);
   if (parts != nullptr) {
     parts[b * 4 + 0] = energy;

@@ -19,16 +19,21 @@ def haar_tensors(seed, D, B):
     return out
 
 
-@pytest.mark.parametrize('D,B', [(4, 65536), (2, 4096), (8, 768), (16, 768)])
-def test_full_size_properties(D, B, c_oracle, engine_factory):
+@pytest.mark.parametrize('D,B,solver', [(4, 65536, 'direct'), (4, 65536, 'squaring'), (2, 4096, 'squaring'), (8, 768, 'direct'),
+                                        (8, 768, 'squaring'), (16, 768, 'squaring')])
+def test_full_size_properties(D, B, solver, c_oracle, engine_factory):
+    """solver = 'direct': the library default at D = 4 and 8 (exact fixed-point solve, accepted by one power step);
+    'squaring': the iterative path of round 1 (and what D = 2, 16 run)."""
     A = haar_tensors(20241022, D, B)
     h1 = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
     h2 = O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})
     eng = engine_factory(D, 65536)
-    eng.set_solver('squaring', handoff=0)
+    eng.set_solver(solver, handoff=0)
     E, it, st = eng.energies(A, np.stack([h1, h2, h1 + 2 * h2, np.eye(4)]))
     ok = st == 0
     assert ok.mean() > 0.999
+    if solver == 'direct':
+        assert np.all(it == 1)                 # every Haar evaluation is accepted without a fall-back round
     # (1) linearity in the Hamiltonian and normalisation <1> = 1
     assert np.abs(E[:, 2] - E[:, 0] - 2 * E[:, 1])[ok].max() < 1e-12
     assert np.abs(E[:, 3] - 1)[ok].max() < 1e-12
@@ -63,7 +68,16 @@ def test_full_size_properties(D, B, c_oracle, engine_factory):
     Ep, itp, stp = eng.energies(A, np.stack([h1, h2]))
     both = ok & (stp == 0)
     assert np.abs(Ep - E1)[both].max() < 1e-10
-    eng.set_solver('squaring', handoff=0)
+    eng.set_solver(solver, handoff=0)
+    if solver == 'direct' and D == 4:
+        # (6b) the exact in-kernel cost (fixed-point accumulation inside the fused kernel, no reduction kernel)
+        eng.set_tensors(A)
+        eng.set_hamiltonian(np.stack([h1, h2]))
+        eng.launch(B, solver='direct', store_env=False, accumulate_cost=True)
+        eng.cost_launch(B)
+        acc = eng.get_cost()
+        E2, _, _ = eng.results(B)
+        assert np.array_equal(E2, E1) and np.allclose(acc, E1.sum(0), rtol=0, atol=1e-8)
     # (7) strided sample against the C oracle (plain algorithm)
     samp = np.arange(0, B, max(1, B // 1024))
     ref = c_oracle.energy_batch(A[samp], np.stack([h1, h2]), threads=8)

@@ -503,12 +503,13 @@ def main():
 
     direct = args.solver == 'direct' and D == 4
     store_env = args.store_env or not direct
+    accumulate = not (D == 4 and args.solver == 'squaring')      # every path but the two-kernel D = 4 squaring solver
     count = [0]
 
     def step():
         eng.set_window((count[0] % R) * B)
         count[0] += 1
-        eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver, store_env=store_env, accumulate_cost=direct)
+        eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=args.solver, store_env=store_env, accumulate_cost=accumulate)
         eng.cost_launch(B)
 
     def barrier():

@@ -85,7 +85,9 @@ extern "C" {
  * 16 D^2 bytes of HBM writes per evaluation).  qmps_get_env / qmps_get_rdm / qmps_energy_only_launch then fail with
  * QMPS_ERR_STATE until a launch without the flag has run. */
 #define QMPS_FLAG_NO_ENV_OUT 0x100
-/* flag (QMPS_ENV_DIRECT at D = 4): the launch also accumulates cost[t] = sum_b E[b][t] inside the kernel - every wave
+/* flag: the launch also accumulates cost[t] = sum_b E[b][t] inside the energy kernel (the fused D = 4 kernel of
+ * QMPS_ENV_DIRECT, the D = 2 / D = 4 lane kernels of the iterative solvers - not the D = 4 squaring path, whose energy
+ * pass is a separate kernel - and the D = 8, 16 kernels, where every evaluation arrives by itself) - every wave
  * adds ONE 64-bit word per term to one of up to 1024 shards: its partial sum as a FIXED-POINT integer (scale 2^k chosen
  * from ||h||_F) in the low 58 bits and an arrival count of 1 in the high 6.  Integer addition commutes, so the sum is
  * exact and independent of the order the waves finish in.  The qmps_cost_launch(B) that follows consumes it WITHOUT
@@ -95,7 +97,8 @@ extern "C" {
  * 28.3 us without a communicator - and 41.3 us when the exchange was ordered by an event on the compute stream.
  * Partial sums beyond the isometric bound 16 ||h||_F (tensors that are not isometries, NaN) are added to a double
  * instead.  Contract: the next call that launches must be qmps_cost_launch with the same B and window; a second
- * accumulating launch before that fails with QMPS_ERR_STATE.  At most 983 040 evaluations per launch. */
+ * accumulating launch before that fails with QMPS_ERR_STATE.  At most 2048 x 60 arrivals per launch (1.9 M evaluations
+ * at D = 4 direct, 7.8 M on the lane kernels, 122 880 at D = 8, 16). */
 #define QMPS_FLAG_ACCUMULATE_COST 0x200
 /* With handoff == 0 (squaring from the start) the iterate is not tracked during the first
  * QMPS_SKIP_ROUNDS_D* squarings (no state converges in fewer than 2^skip power steps); the first

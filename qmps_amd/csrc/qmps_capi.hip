@@ -196,6 +196,57 @@ qmps::LaneArgs make_args(qmps_ctx* c, int64_t B, int max_iter, double tol, bool 
 }
 
 int close_group(qmps_ctx* c);
+// QMPS_FLAG_ACCUMULATE_COST: point the energy kernel at the accumulator of the ring position the following
+// qmps_cost_launch will use.  adds = arrivals per term (waves or evaluations that add one word each), per_add =
+// evaluations behind one arrival (bounds the partial sum: per_add ||h||_F).
+int setup_accumulator(qmps_ctx* c, qmps::LaneArgs& a, int64_t B, int64_t adds, int per_add) {
+  // The position the following qmps_cost_launch will use: its accumulator must be clear BEFORE the finish kernel of
+  // this step starts to poll it on a communication stream (a stale word of the previous lap carries a full arrival
+  // count).  Consecutive ring slots alternate between two communication streams, so every launch clears the same
+  // position TWO slots ahead: the finish kernel of this step (same stream as that later slot's) completes only when
+  // every wave of this kernel - the clearing one included - has arrived, and the later slot's finish kernel is queued
+  // behind it.
+  const int slot = (int)(c->groups % qmps_ctx::kCostSlots), pos = c->group_fill;
+  const int nslot = (int)((c->groups + 2) % qmps_ctx::kCostSlots), npos = pos;
+  c->acc_after_event[slot][pos] = false;
+  if (c->acc_dirty[slot][pos]) {
+    // unusual call order (exchange period changed, a partly filled group, an accumulated cost that was dropped): clear
+    // it now on the compute stream, and order this position's finish kernel behind that by an event
+    HIP_TRY(hipMemsetAsync(c->acc_at(slot, pos), 0, qmps::kAccWords * sizeof(long long), c->stream));
+    c->acc_dirty[slot][pos] = false;
+    c->acc_after_event[slot][pos] = true;
+  }
+  // a slot of the ring is touched again only after its previous exchange has finished.  Asked on the HOST (that
+  // exchange, kCostSlots - 2 groups ago, has normally finished long ago): a stream wait would put a barrier packet
+  // on the compute stream in every step (+4 us measured), and the compute stream carries no event either
+  if (c->comm && c->groups + 2 >= qmps_ctx::kCostSlots && hipEventQuery(c->cost_reduced[nslot]) != hipSuccess) {
+    (void)hipGetLastError();
+    HIP_TRY(hipEventSynchronize(c->cost_reduced[nslot]));
+  }
+  int shards = 32;
+  while (shards * (int64_t)qmps::kAccMaxWavesPerShard < adds && shards < qmps::kAccMaxShards) shards *= 2;
+  if (shards * (int64_t)qmps::kAccMaxWavesPerShard < adds)
+    return fail(QMPS_ERR_ARG, "B=%lld too large for QMPS_FLAG_ACCUMULATE_COST (at most %lld evaluations per launch on this path)", (long long)B,
+                (long long)qmps::kAccMaxShards * qmps::kAccMaxWavesPerShard * per_add);
+  a.acc = c->acc_at(slot, pos);
+  a.acc_zero = c->acc_dirty[nslot][npos] ? c->acc_at(nslot, npos) : nullptr;
+  a.acc_shards = shards;
+  // partial sums (per_add evaluations each) beyond per_add ||h||_F bypass the fixed-point sum; scale 2^k with bound 2^k <= 2^51
+  const double hf = c->h_fro > 1e-300 ? c->h_fro : 1.0;
+  a.acc_bound = (double)per_add * hf * (1.0 + 1e-6);
+  int k = (int)floor((double)qmps::kAccOffsetBits - 1e-9 - log2(a.acc_bound));
+  if (k > 1000) k = 1000;
+  if (k < -1000) k = -1000;
+  a.acc_scale = ldexp(1.0, k);
+  c->acc_shards[slot][pos] = shards;
+  c->acc_expect[slot][pos] = adds;
+  c->acc_scale[slot][pos] = a.acc_scale;
+  c->acc_dirty[slot][pos] = true;
+  c->acc_dirty[nslot][npos] = false;
+  c->acc_pending = true; c->acc_B = B; c->acc_window = c->window; c->acc_slot = slot; c->acc_pos = pos;
+  c->partials_B = -1;
+  return QMPS_OK;
+}
 
 }  // namespace
 
@@ -581,8 +632,10 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     return fail(QMPS_ERR_ARG, "unknown environment solver %d", solver);
   if ((flags & ~0xff) & ~(QMPS_FLAG_NO_ENV_OUT | QMPS_FLAG_ACCUMULATE_COST)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags & ~0xff);
   const bool direct = solver == QMPS_ENV_DIRECT && c->D == 4;
-  if ((flags & (QMPS_FLAG_NO_ENV_OUT | QMPS_FLAG_ACCUMULATE_COST)) && !direct)
-    return fail(QMPS_ERR_ARG, "QMPS_FLAG_NO_ENV_OUT / QMPS_FLAG_ACCUMULATE_COST need QMPS_ENV_DIRECT at D = 4");
+  if ((flags & QMPS_FLAG_NO_ENV_OUT) && !direct) return fail(QMPS_ERR_ARG, "QMPS_FLAG_NO_ENV_OUT needs QMPS_ENV_DIRECT at D = 4");
+  const bool accumulate = (flags & QMPS_FLAG_ACCUMULATE_COST) != 0;
+  if (accumulate && c->D == 4 && !direct && solver == QMPS_ENV_POWER_SQUARING)
+    return fail(QMPS_ERR_ARG, "QMPS_FLAG_ACCUMULATE_COST: at D = 4 use QMPS_ENV_DIRECT or QMPS_ENV_POWER");
   if ((flags & QMPS_FLAG_ACCUMULATE_COST) && c->acc_pending)
     return fail(QMPS_ERR_STATE, "the cost accumulated by the previous launch has not been consumed by qmps_cost_launch");
   if ((flags & QMPS_FLAG_ACCUMULATE_COST) && c->capturing) return fail(QMPS_ERR_STATE, "no cost accumulation inside a graph capture");
@@ -607,52 +660,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     a.r_in = nullptr;
     a.r_out = (flags & QMPS_FLAG_NO_ENV_OUT) ? nullptr : c->d_r;
     if (flags & QMPS_FLAG_ACCUMULATE_COST) {
-      // The position the following qmps_cost_launch will use: its accumulator must be clear BEFORE the finish kernel of
-      // this step starts to poll it on a communication stream (a stale word of the previous lap carries a full arrival
-      // count).  Consecutive ring slots alternate between two communication streams, so every launch clears the same
-      // position TWO slots ahead: the finish kernel of this step (same stream as that later slot's) completes only when
-      // every wave of this kernel - the clearing one included - has arrived, and the later slot's finish kernel is queued
-      // behind it.
-      const int slot = (int)(c->groups % qmps_ctx::kCostSlots), pos = c->group_fill;
-      const int nslot = (int)((c->groups + 2) % qmps_ctx::kCostSlots), npos = pos;
-      c->acc_after_event[slot][pos] = false;
-      if (c->acc_dirty[slot][pos]) {
-        // unusual call order (exchange period changed, a partly filled group, an accumulated cost that was dropped): clear
-        // it now on the compute stream, and order this position's finish kernel behind that by an event
-        HIP_TRY(hipMemsetAsync(c->acc_at(slot, pos), 0, qmps::kAccWords * sizeof(long long), c->stream));
-        c->acc_dirty[slot][pos] = false;
-        c->acc_after_event[slot][pos] = true;
-      }
-      // a slot of the ring is touched again only after its previous exchange has finished.  Asked on the HOST (that
-      // exchange, kCostSlots - 2 groups ago, has normally finished long ago): a stream wait would put a barrier packet
-      // on the compute stream in every step (+4 us measured), and the compute stream carries no event either
-      if (c->comm && c->groups + 2 >= qmps_ctx::kCostSlots && hipEventQuery(c->cost_reduced[nslot]) != hipSuccess) {
-        (void)hipGetLastError();
-        HIP_TRY(hipEventSynchronize(c->cost_reduced[nslot]));
-      }
-      const int64_t tiles = (B + 15) / 16;
-      int shards = 32;
-      while (shards * (int64_t)qmps::kAccMaxWavesPerShard < tiles && shards < qmps::kAccMaxShards) shards *= 2;
-      if (shards * (int64_t)qmps::kAccMaxWavesPerShard < tiles)
-        return fail(QMPS_ERR_ARG, "B=%lld too large for QMPS_FLAG_ACCUMULATE_COST (at most %lld evaluations per launch)", (long long)B,
-                    (long long)qmps::kAccMaxShards * qmps::kAccMaxWavesPerShard * 16);
-      a.acc = c->acc_at(slot, pos);
-      a.acc_zero = c->acc_dirty[nslot][npos] ? c->acc_at(nslot, npos) : nullptr;
-      a.acc_shards = shards;
-      // per-wave partial sums (16 evaluations) beyond 16 ||h||_F bypass the fixed-point sum; scale 2^k with bound 2^k <= 2^51
-      const double hf = c->h_fro > 1e-300 ? c->h_fro : 1.0;
-      a.acc_bound = 16.0 * hf * (1.0 + 1e-6);
-      int k = (int)floor((double)qmps::kAccOffsetBits - 1e-9 - log2(a.acc_bound));
-      if (k > 1000) k = 1000;
-      if (k < -1000) k = -1000;
-      a.acc_scale = ldexp(1.0, k);
-      c->acc_shards[slot][pos] = shards;
-      c->acc_expect[slot][pos] = tiles;
-      c->acc_scale[slot][pos] = a.acc_scale;
-      c->acc_dirty[slot][pos] = true;
-      c->acc_dirty[nslot][npos] = false;
-      c->acc_pending = true; c->acc_B = B; c->acc_window = c->window; c->acc_slot = slot; c->acc_pos = pos;
-      c->partials_B = -1;
+      if (int rc = setup_accumulator(c, a, B, (B + 15) / 16, 16)) return rc;
     } else {
       a.partial = c->d_partial; c->partials_B = B; c->partials_n = (int)((B + 15) / 16);
     }
@@ -668,12 +676,15 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   if (c->D == 16 && !getenv("QMPS_D16_BLOCK")) {
     // D = 16: power iteration on the matrix cores (one wave per evaluation), then the energy pass
     c->dominant = "energy_mfma_d16_kernel<true>";
+    if (accumulate) if (int rc = setup_accumulator(c, a, B, B, 1)) return rc;
     if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy_mfma(c->D, a, true, c->stream));
     if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
   } else if (!hybrid) {
     c->dominant = c->D <= 4 ? "energy_lane_kernel<D,true>" : "energy_block_kernel<D,true>";
-    if (c->D <= 4) { a.partial = c->d_partial; c->partials_B = B; c->partials_n = lane_waves; }
+    if (accumulate) {
+      if (int rc = setup_accumulator(c, a, B, c->D <= 4 ? lane_waves : B, c->D <= 4 ? 64 : 1)) return rc;
+    } else if (c->D <= 4) { a.partial = c->d_partial; c->partials_B = B; c->partials_n = lane_waves; }
     if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
     if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
@@ -681,7 +692,9 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     a.handoff = c->handoff;  // the squaring tail runs in-lane (real 4 x 4 transfer matrix in registers)
     a.hybrid = 1;
     a.skip = c->handoff == 0 ? c->skip_rounds : 0;
-    a.partial = c->d_partial; c->partials_B = B; c->partials_n = lane_waves;
+    if (accumulate) {
+      if (int rc = setup_accumulator(c, a, B, lane_waves, 64)) return rc;
+    } else { a.partial = c->d_partial; c->partials_B = B; c->partials_n = lane_waves; }
     c->dominant = "energy_lane_kernel<2,true>";
     if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));

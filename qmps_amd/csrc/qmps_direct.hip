@@ -140,12 +140,7 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
   double pre[4][4], pim[4][4];
   const bool pd = Core::density(o, us, pre, pim);
   if (status == QMPS_ST_OK && !pd) status = QMPS_ST_NOT_PD;
-  if (p.acc_zero != nullptr && blockIdx.x == 0) {
-    // clear the accumulator of a later step (nobody reads or adds to it during this launch)
-    for (int t = 0; t < p.n_terms; ++t)
-      for (int i = lane; i < kAccMaxShards; i += 64) p.acc_zero[t * kAccMaxShards + i] = 0;
-    if (lane < 16) p.acc_zero[kAccOver + lane] = 0;
-  }
+  if (p.acc_zero != nullptr && blockIdx.x == 0) acc_clear(p.acc_zero, p.n_terms, lane, 64);   // accumulator of a later step
   for (int t = 0; t < p.n_terms; ++t) {
     const double en = quad_sum(Core::energy((const double*)p.h + 32 * t, pre, pim));
     if (valid && q == 0) p.E[b * p.n_terms + t] = en;
@@ -154,18 +149,8 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
       if (lane == 0) {
         // first pass of the cost reduction: one partial per wave, fixed order
         if (p.partial != nullptr) p.partial[(int64_t)t * gridDim.x + blockIdx.x] = s;
-        if (p.acc != nullptr) {
-          // ... or the whole reduction: an exact fixed-point sum (order-independent) + the arrival count, ONE atomic
-          long long fx = 0;
-          if (fabs(s) <= p.acc_bound) {
-            fx = __double2ll_rn(s * p.acc_scale);
-          } else {
-            atomicAdd((double*)(p.acc + kAccOver) + t, s);
-            __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the overflow sum is in before this wave counts as arrived
-          }
-          atomicAdd((unsigned long long*)p.acc + t * kAccMaxShards + (blockIdx.x & (p.acc_shards - 1)),
-                    (unsigned long long)(fx + (1LL << kAccOffsetBits) + (1LL << kAccValueBits)));
-        }
+        // ... or the whole reduction: an exact fixed-point sum (order-independent) + the arrival count, ONE atomic
+        if (p.acc != nullptr) acc_arrive(p.acc, p.acc_shards, t, blockIdx.x, s, p.acc_bound, p.acc_scale);
       }
     }
   }

@@ -50,13 +50,33 @@ struct LaneArgs {
 // that energy_block_kernel<8, true> then accepts with one power step)
 hipError_t launch_env_direct_d8(const void* A, void* r_out, int64_t B, hipStream_t st);
 // layout of one cost accumulator (long long units): 16 terms x kAccMaxShards words, then 16 doubles of overflow sums
-constexpr int kAccMaxShards = 1024, kAccOver = 16 * kAccMaxShards, kAccWords = kAccOver + 16;
+constexpr int kAccMaxShards = 2048, kAccOver = 16 * kAccMaxShards, kAccWords = kAccOver + 16;
 constexpr int kAccValueBits = 58, kAccOffsetBits = 51, kAccMaxWavesPerShard = 60;
 // decode one word: (count, value) - value = sum of the fixed-point partials of `count` waves
 __host__ __device__ inline void acc_decode(long long w, long long& count, long long& value) {
   count = (long long)((unsigned long long)w >> kAccValueBits);
   value = (w & ((1LL << kAccValueBits) - 1)) - count * (1LL << kAccOffsetBits);
 }
+#if defined(__HIPCC__)
+// one arrival: `s` = the partial sum of this wave / evaluation for term t (see LaneArgs::acc)
+__device__ __forceinline__ void acc_arrive(long long* acc, int shards, int t, unsigned id, double s, double bound, double scale) {
+  long long fx = 0;
+  if (fabs(s) <= bound) {
+    fx = __double2ll_rn(s * scale);
+  } else {
+    atomicAdd((double*)(acc + kAccOver) + t, s);
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the overflow sum is in before this arrival counts
+  }
+  atomicAdd((unsigned long long*)acc + t * kAccMaxShards + (id & (unsigned)(shards - 1)),
+            (unsigned long long)(fx + (1LL << kAccOffsetBits) + (1LL << kAccValueBits)));
+}
+// clear a whole accumulator (called by the threads of ONE workgroup)
+__device__ __forceinline__ void acc_clear(long long* acc, int n_terms, int tid, int nthreads) {
+  for (int t = 0; t < n_terms; ++t)
+    for (int i = tid; i < kAccMaxShards; i += nthreads) acc[t * kAccMaxShards + i] = 0;
+  if (tid < 16) acc[kAccOver + tid] = 0;
+}
+#endif
 // acc -> cost[t] = (sum of the shards) / scale + overflow sum; one wave.  expect > 0: first POLL until `expect` waves
 // per term have arrived (the producer kernel may still be running on another stream), at most max_polls sweeps - then
 // cost = NaN and *err = 1.

@@ -467,6 +467,7 @@ __global__ __launch_bounds__(64) void energy_lane_kernel(LaneArgs p) {
   const int64_t wave_first = (int64_t)blockIdx.x * 64;
   int64_t b = wave_first + lane;
   bool valid = b < p.B;
+  if (p.acc_zero != nullptr && blockIdx.x == 0) acc_clear(p.acc_zero, p.n_terms, lane, 64);   // accumulator of a later step
   double are[2][D][D], aim[2][D][D];
 
   if (p.idx_list != nullptr) {
@@ -631,10 +632,14 @@ __global__ __launch_bounds__(64) void energy_lane_kernel(LaneArgs p) {
     const double2* h = (const double2*)p.h + q * 16;  // wave-uniform -> scalar loads
     const double e = rdm_energy(h, pre, pim);
     if (valid) p.E[b * p.n_terms + q] = e;
-    if (p.partial != nullptr) {
-      // fused first pass of the cost reduction: one partial per wave (deterministic order)
+    if (p.partial != nullptr || p.acc != nullptr) {
+      // fused first pass of the cost reduction: one partial per wave (deterministic order) - or the whole reduction
+      // (exact fixed-point accumulator, qmps_kernels.h)
       const double s = wave_sum(valid ? e : 0.0);
-      if (lane == 0) p.partial[(int64_t)q * gridDim.x + blockIdx.x] = s;
+      if (lane == 0) {
+        if (p.partial != nullptr) p.partial[(int64_t)q * gridDim.x + blockIdx.x] = s;
+        if (p.acc != nullptr) acc_arrive(p.acc, p.acc_shards, q, blockIdx.x, s, p.acc_bound, p.acc_scale);
+      }
     }
   }
   if (!valid) return;
@@ -1228,6 +1233,7 @@ __global__ __launch_bounds__(256) void energy_mfma_d16_kernel(LaneArgs p) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   double2* sT = sT_all[wave];
   const double tol2 = p.tol * p.tol;
+  if (p.acc_zero != nullptr && blockIdx.x == 0) acc_clear(p.acc_zero, p.n_terms, threadIdx.x, 256);   // accumulator of a later step
   for (int64_t b = (int64_t)blockIdx.x * WAVES + wave; b < p.B; b += (int64_t)gridDim.x * WAVES) {
     // A_s in A-layout (and the negated imaginary part, MFMA has no operand negation for f64)
     double are[2][4], aim[2][4], aimn[2][4];
@@ -1434,6 +1440,7 @@ __global__ __launch_bounds__(256) void energy_mfma_d16_kernel(LaneArgs p) {
             e += hv.x * rv.x - hv.y * rv.y;
           }
         p.E[b * p.n_terms + q] = e;
+        if (p.acc != nullptr) acc_arrive(p.acc, p.acc_shards, q, (unsigned)b, e, p.acc_bound, p.acc_scale);   // exact in-kernel cost
       }
       if (SOLVE) p.iters[b] = iters;
       if (SOLVE || p.check_pd) p.status[b] = status;
@@ -1476,6 +1483,7 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
   const int i = tid / D, j = tid % D;
   const int64_t b = blockIdx.x;
   if (b >= p.B) return;
+  if (p.acc_zero != nullptr && blockIdx.x == 0) acc_clear(p.acc_zero, p.n_terms, tid, N);   // accumulator of a later step
 
   {
     const double2* a = (const double2*)p.A + b * (2 * N);
@@ -1674,6 +1682,7 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
           e += hv.x * rho_loc[t][s].x - hv.y * rho_loc[t][s].y;
         }
       p.E[b * p.n_terms + q] = e;
+      if (p.acc != nullptr) acc_arrive(p.acc, p.acc_shards, q, (unsigned)b, e, p.acc_bound, p.acc_scale);   // exact in-kernel cost
     }
     if (SOLVE) {
       p.iters[b] = iters;

@@ -143,9 +143,7 @@ def test_direct_flag_errors(engine_factory):
     eng8.set_tensors(A)
     eng8.set_hamiltonian(O.hamiltonian_matrix({'ZZ': -1, 'X': 1}))
     with pytest.raises(QmpsError):
-        eng8.launch(solver='direct', store_env=False)      # the flags belong to the fused D = 4 kernel
-    with pytest.raises(QmpsError):
-        eng8.launch(solver='direct', accumulate_cost=True)
+        eng8.launch(solver='direct', store_env=False)      # the environment store can only be skipped by the fused D = 4 kernel
     eng2 = engine_factory(2, 64)
     A2 = O.unitary_to_tensor(O.haar_unitaries(rng, 4, 8))
     E, it, st = eng2.energies(A2, O.hamiltonian_matrix({'ZZ': -1, 'X': 1}))
@@ -261,3 +259,30 @@ def test_in_kernel_cost_accumulation(with_comm):
         assert np.allclose(eng.get_cost(), Eb.sum(0), rtol=1e-12, atol=0)
         if with_comm:
             eng.comm_destroy()
+
+
+@pytest.mark.parametrize('D,B', [(2, 4096), (2, 100), (4, 1000), (8, 768), (16, 40)])
+def test_in_kernel_cost_on_the_other_kernels(D, B, engine_factory):
+    """QMPS_FLAG_ACCUMULATE_COST on the lane kernels (D = 2; D = 4 plain power iteration), the D = 8 block kernel behind the
+    direct solve and the D = 16 MFMA kernel: the exact in-kernel sum equals the host sum of the energies; the two-kernel
+    D = 4 squaring path refuses the flag."""
+    from qmps_amd._lib import QmpsError
+    rng = np.random.default_rng(50 + D + B)
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, B))
+    h = np.stack([O.hamiltonian_matrix({'ZZ': -1, 'X': 1}), O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})])
+    eng = engine_factory(D, 4096)
+    for solver in (['plain', 'direct'] if D == 4 else ['direct', 'plain']):
+        eng.set_solver(solver)
+        E, _, st = eng.energies(A, h)
+        eng.set_tensors(A)
+        eng.set_hamiltonian(h)
+        for rep in range(11):                       # laps of the accumulator ring
+            eng.launch(B, solver=solver, accumulate_cost=True)
+            eng.cost_launch(B)
+        c = eng.get_cost()
+        E2, _, _ = eng.results(B)
+        assert np.array_equal(E2, E) and np.abs(c - E.sum(0)).max() < 1e-9 * max(1, B / 100), (D, solver)
+    if D == 4:
+        with pytest.raises(QmpsError):
+            eng.launch(B, solver='squaring', accumulate_cost=True)
+    eng.set_solver('direct')

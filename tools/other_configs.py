@@ -23,7 +23,8 @@ def run(D, B, solver, reps=200):
             eng.probe_fp64_tflops()
 
         def step():
-            eng.launch(B, solver=solver)
+            eng.launch(B, solver=solver, store_env=False if (D == 4 and solver == 'direct') else True,
+                       accumulate_cost=not (D == 4 and solver == 'squaring'))
             eng.cost_launch(B)
         for _ in range(50):
             step()

@@ -345,7 +345,10 @@ def main_overlap(args):
     if rank == 0:
         # executed algorithm: per power step 8 complex D^3 products (Y_s = x Bm_s^+, x' += C_s Y_s, s < 4) = 64 D^3 flop,
         # set-up 8 products (merge(A,A), merge(B,B)) + the WW combination
-        flops = float((rounds.astype(np.float64) * 64 * D ** 3 + 64 * D ** 3 + 128 * D * D).sum())
+        if D in (2, 4):   # squarings of the complex D^2 x D^2 matrix: 8 (D^2)^3 flop each
+            flops = float((rounds.astype(np.float64) * 8 * (D * D) ** 3 + 64 * D ** 3 + 32 * D ** 4).sum())
+        else:
+            flops = float((rounds.astype(np.float64) * 64 * D ** 3 + 64 * D ** 3 + 128 * D * D).sum())
         tflops = flops / (kernel_ms * 1e-3) * 1e-12
         byts = B * (32 * D * D + 16)
         out = {'metric': f'time-evolution overlap evals/sec at D={D}, batch={B}', 'value': world * B * args.steps / elapsed,
@@ -353,7 +356,8 @@ def main_overlap(args):
                'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f64', 'data': 'synthetic',
                'config': {'workload': f'TFIM quench time-evolution overlap objective, D={D}, batch={B} candidates per GPU near one Haar '
-                                      f'reference state (U exp(i eps H), eps < 0.1), W = exp(-0.05 i h_TFIM), tol {args.tol:g}, cap {args.max_iter} power steps',
+                                      f'reference state (U exp(i eps H), eps < 0.1), W = exp(-0.05 i h_TFIM), tol {args.tol:g}, cap {args.max_iter} '
+                                      + ('squarings' if D in (2, 4) else 'power steps'),
                           'baseline_config': 'BASELINE.json configs[4]', 'D': D, 'batch_per_gpu': B, 'seed': args.seed,
                           'mean_power_steps': float(rounds.mean()), 'max_power_steps': int(rounds.max()), 'not_converged': int((st != 0).sum()),
                           'mean_abs_eta': float(np.abs(eta).mean()), 'collective': 'none: independent trajectories (replicas only)',
@@ -412,7 +416,7 @@ def main():
 
     if args.workload == 'overlap':
         if args.max_iter == 10000:
-            args.max_iter = 100000
+            args.max_iter = 60 if args.D in (2, 4) else 100000      # D = 2, 4: squarings; D = 8, 16: power steps
         return main_overlap(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

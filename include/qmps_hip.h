@@ -227,8 +227,10 @@ int qmps_cell2_energy_batch(qmps_ctx* ctx, int64_t B, const double* U1, const do
  * (QMPS_INPUT_ANSATZ_BASE + QMPS_ANSATZ_*, n_params each).  eta_out [B] complex128; r_out nullable [B][D][D]
  * (unit-Frobenius right fixed point, what xmps Map.right_fixed_point returns up to phase); status 1 = no unique
  * dominant eigenvalue within max_rounds.
- * Solver: D = 2 squares the 4 x 4 matrix of the map (max_rounds <= 60 squarings, rounds_out = squarings used);
- * D = 4, 8, 16 run the power method in operator form from x_0 = 1/sqrt(D), eta = <x, T x>, stop when
+ * Solver: D = 2 and 4 SQUARE the D^2 x D^2 matrix of the map (max_rounds <= 60 squarings, rounds_out = squarings used:
+ * O(log) rounds whatever the spectral gap) - D = 2 in a lane, D = 4 as one complex 16 x 16 tile on the matrix cores,
+ * until it is rank one (||M M - tr(M) M||_F < tol ||M M||_F), eta = tr(M E)/tr(M);
+ * D = 8, 16 run the power method in operator form from x_0 = 1/sqrt(D), eta = <x, T x>, stop when
  * ||T x - eta x||_F < tol (max_rounds = cap on power steps, rounds_out = steps used) - at D = 16 on the matrix
  * cores (v_mfma_f64_16x16x4, one wave per evaluation). */
 #define QMPS_INPUT_ANSATZ_BASE 16

@@ -964,7 +964,8 @@ int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int 
   if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
   if (c->overlap_refs < 1) return fail(QMPS_ERR_STATE, "qmps_overlap_set has not been called");
   if (c->overlap_refs != 1 && c->overlap_refs < c->window + B) return fail(QMPS_ERR_STATE, "%lld reference tensors for window end %lld", (long long)c->overlap_refs, (long long)(c->window + B));
-  const int cap = c->D == 2 ? 60 : (1 << 24);
+  const bool squaring = c->D == 2 || (c->D == 4 && !getenv("QMPS_OVERLAP_POWER"));   // these square the matrix of the map: rounds, not steps
+  const int cap = squaring ? 60 : (1 << 24);
   if (max_rounds < 1 || max_rounds > cap || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_rounds / tol (D = %d: max_rounds in [1, %d])", c->D, cap);
   if (!c->d_eta) HIP_TRY(hipMalloc(&c->d_eta, (size_t)c->max_batch * 16));
   qmps::OverlapArgs a;
@@ -976,12 +977,13 @@ int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int 
   a.eta = (char*)c->d_eta + (size_t)c->window * 16;
   a.r_out = want_r ? win_r(c) : nullptr;
   a.iters = win_iters(c); a.status = win_status(c); a.B = B; a.a_shared = shared ? 1 : 0; a.max_rounds = max_rounds; a.tol = tol;
-  c->dominant = c->D == 2 ? "overlap_lane_kernel" : (c->D == 16 && !getenv("QMPS_D16_BLOCK") ? "overlap_mfma_d16_kernel" : "overlap_block_kernel<D>");
+  c->dominant = c->D == 2 ? "overlap_lane_kernel" : (c->D == 4 && squaring ? "overlap_square_d4_kernel" :
+                (c->D == 16 && !getenv("QMPS_D16_BLOCK") ? "overlap_mfma_d16_kernel" : "overlap_block_kernel<D>"));
   c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
   const int slot = (int)(c->samples % qmps_ctx::kRing);
   if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
   if (c->D == 2) HIP_TRY(qmps::launch_overlap(a, c->stream));
-  else HIP_TRY(qmps::launch_overlap_d(c->D, a, getenv("QMPS_D16_BLOCK") == nullptr, c->stream));
+  else HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : getenv("QMPS_D16_BLOCK") == nullptr, c->stream));
   if (c->timed) { HIP_TRY(hipEventRecord(c->kev1[slot], c->stream)); c->samples++; }
   if (!c->capturing) c->launches++;
   c->have_env = false;

@@ -10,7 +10,9 @@
 // eta = <x, T x> (Rayleigh quotient, ||x||_F = 1), stop when ||T x - eta x||_F < tol.  status 1 = no unique dominant
 // eigenvalue within max_steps.  The D = 2 path (overlap_lane_kernel, qmps_kernels.hip) squares the 4 x 4 matrix instead.
 //
-//   overlap_block_kernel<D>    D = 4, 8, 16: thread (i, j) of a D x D tile per evaluation (D = 4: four evaluations per
+//   overlap_square_d4_kernel   D = 4: the map is ONE complex 16 x 16 tile - squared on the matrix cores until it is rank one
+//                              (O(log) rounds whatever the spectral gap), one wave per evaluation.
+//   overlap_block_kernel<D>    D = 8 (D = 4, 16 fall-backs): thread (i, j) of a D x D tile per evaluation (D = 4: four evaluations per
 //                              wave, one per DPP row), tiles of C_s, Bm_s, x, Y_s = x Bm_s^+ in LDS.
 //   overlap_mfma_d16_kernel    D = 16: ONE WAVE PER EVALUATION on the matrix cores.  A complex 16 x 16 x 16 product is
 //                              4 real v_mfma_f64_16x16x4_f64 chains; per step Y_s = x Bm_s^+ and x' += C_s Y_s for the
@@ -328,10 +330,191 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// D = 4 on the matrix cores: the mixed transfer map IS one complex 16 x 16 tile,
+//   E[(i,i'),(j,j')] = sum_{s<4} C_s[i][j] conj(Bm_s[i'][j']),
+// so the power method is taken 2^m steps at a time by SQUARING it (one wave per evaluation, 16 v_mfma_f64_16x16x4 per
+// round, Frobenius-normalised): O(log) rounds whatever the spectral gap - the plain power method needed up to 27 386
+// steps inside a batch of 65 536 time-step candidates.  M = E^(2^m)/scale tends to the rank-one u v^+; a rank-one
+// matrix satisfies M M = tr(M) M, which is the convergence test (||M M - tr(M) M||_F < tol ||M M||_F, elementwise in
+// the accumulator layout, no gather), and then eta = tr(M E)/tr(M) (= v^+ E u / v^+ u).  The right fixed point, when
+// asked for, is the largest column of M.  rounds = squarings used; status 1 = not rank one within max_rounds (two
+// dominant eigenvalues of equal modulus) or tr(M) = 0.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void overlap_square_d4_kernel(OverlapArgs p) {
+  constexpr int LD = 17, WAVES = 4;
+  __shared__ double2 sT_all[WAVES][16 * LD];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  double2* sT = sT_all[wave];
+  const double tol2 = p.tol * p.tol;
+  auto to_a_layout = [&](const v4f64& re, const v4f64& im, double (&are)[4], double (&aim)[4]) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sT[(4 * q + g) * LD + c] = make_double2(re[q], im[q]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const double2 t = sT[c * LD + 4 * kk + g];
+      are[kk] = t.x;
+      aim[kk] = t.y;
+    }
+  };
+  for (int64_t b = (int64_t)blockIdx.x * WAVES + wave; b < p.B; b += (int64_t)gridDim.x * WAVES) {
+    // ---- set-up through LDS: inputs at sT[0..63], then C_s[i][j] at sT[64 + 16 s + 4 i + j], Bm_s at sT[128 + ...]
+    {
+      const double2* Ap = (const double2*)p.A + (p.a_shared ? 0 : b * 32);
+      const double2* Bp = (const double2*)p.Bt + b * 32;
+      __builtin_amdgcn_wave_barrier();
+      sT[lane] = lane < 32 ? Ap[lane] : Bp[lane - 32];
+      __builtin_amdgcn_wave_barrier();
+      const int s = lane >> 4, i = (lane >> 2) & 3, j = lane & 3, s1 = s >> 1, s2 = s & 1;
+      const double2* W = (const double2*)p.WW;
+      double2 cs = make_double2(0.0, 0.0), bm = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int t1 = 0; t1 < 2; ++t1)
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          double2 aa = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) cfma(sT[(t1 * 4 + i) * 4 + k], sT[(t2 * 4 + k) * 4 + j], aa);
+          cfma(W[s * 4 + 2 * t1 + t2], aa, cs);
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cfma(sT[32 + (s1 * 4 + i) * 4 + k], sT[32 + (s2 * 4 + k) * 4 + j], bm);
+      __builtin_amdgcn_wave_barrier();
+      sT[64 + lane] = cs;
+      sT[128 + lane] = bm;
+      __builtin_amdgcn_wave_barrier();
+    }
+    // E and its transpose in C-layout: register q of lane (g, c) = element [row 4 q + g][col c], row = (i, i'), col = (j, j')
+    v4f64 er, ei, tr_, ti_;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double2 e = make_double2(0.0, 0.0), t = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        cfma_conj(sT[64 + 16 * s + 4 * q + (c >> 2)], sT[128 + 16 * s + 4 * g + (c & 3)], e);    // E[(q,g)][(c>>2,c&3)]
+        cfma_conj(sT[64 + 16 * s + 4 * (c >> 2) + q], sT[128 + 16 * s + 4 * (c & 3) + g], t);    // E[(c>>2,c&3)][(q,g)]
+      }
+      er[q] = e.x; ei[q] = e.y;
+      tr_[q] = t.x; ti_[q] = t.y;
+    }
+    // ---- squaring rounds
+    v4f64 mr = er, mi = ei;
+    {
+      double n2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) n2 = dfma(mr[q], mr[q], dfma(mi[q], mi[q], n2));
+      n2 = wave_sum(n2);
+      const double inv = n2 > 0.0 ? 1.0 / __builtin_sqrt(n2) : 0.0;
+      mr *= inv;
+      mi *= inv;
+    }
+    int rounds = 0, status = QMPS_ST_NOT_CONVERGED;
+    double trr = 0.0, tri = 0.0;
+    for (int m = 0; m <= p.max_rounds; ++m) {
+      double ar[4], ai[4];
+      to_a_layout(mr, mi, ar, ai);
+      v4f64 qr = {0, 0, 0, 0}, qi = {0, 0, 0, 0};
+      cmma16(ar, ai, mr, mi, qr, qi);                     // Q = M M
+      double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (c == 4 * q + g) { d0 = mr[q]; d1 = mi[q]; }
+      trr = wave_sum(d0);
+      tri = wave_sum(d1);
+      double res = 0.0, q2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double dr = qr[q] - (trr * mr[q] - tri * mi[q]), di = qi[q] - (trr * mi[q] + tri * mr[q]);
+        res = dfma(dr, dr, dfma(di, di, res));
+        q2 = dfma(qr[q], qr[q], dfma(qi[q], qi[q], q2));
+      }
+      res = lane0(wave_sum(res));
+      q2 = lane0(wave_sum(q2));
+      rounds = m;
+      if (q2 > 0.0 && res < tol2 * q2) {
+        status = QMPS_ST_OK;
+        break;
+      }
+      if (m == p.max_rounds || !(q2 > 0.0)) break;
+      const double inv = 1.0 / __builtin_sqrt(q2);
+      mr = qr * inv;
+      mi = qi * inv;
+    }
+    // eta = tr(M E)/tr(M):  tr(M E) = sum_{a,b} M[a][b] E[b][a] = sum over lanes and registers of M * E^T (elementwise)
+    double nr = 0.0, ni = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      nr = dfma(mr[q], tr_[q], dfma(-mi[q], ti_[q], nr));
+      ni = dfma(mr[q], ti_[q], dfma(mi[q], tr_[q], ni));
+    }
+    nr = wave_sum(nr);
+    ni = wave_sum(ni);
+    {
+      double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (c == 4 * q + g) { d0 = mr[q]; d1 = mi[q]; }
+      trr = wave_sum(d0);
+      tri = wave_sum(d1);
+    }
+    const double den = trr * trr + tri * tri;
+    double eta_r = 0.0, eta_i = 0.0;
+    if (den > 1e-280) {
+      eta_r = (nr * trr + ni * tri) / den;
+      eta_i = (ni * trr - nr * tri) / den;
+    } else {
+      status = QMPS_ST_NOT_CONVERGED;
+    }
+    if (lane == 0) {
+      ((double2*)p.eta)[b] = make_double2(eta_r, eta_i);
+      p.iters[b] = rounds;
+      p.status[b] = status;
+    }
+    if (p.r_out != nullptr) {
+      // right fixed point = the largest column of M, unit Frobenius norm
+      double cn = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cn = dfma(mr[q], mr[q], dfma(mi[q], mi[q], cn));
+      cn = group4_sum(cn);                       // norm^2 of column c, in every row group
+      __builtin_amdgcn_wave_barrier();
+      if (g == 0) sT[c] = make_double2(cn, 0.0);
+      __builtin_amdgcn_wave_barrier();
+      int best = 0;
+      double bn = -1.0;
+      for (int k = 0; k < 16; ++k) {
+        const double v = sT[k].x;
+        if (v > bn) { bn = v; best = k; }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (c == best) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sT[16 + 4 * q + g] = make_double2(mr[q], mi[q]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const double inv = bn > 0.0 ? 1.0 / __builtin_sqrt(bn) : 0.0;
+      if (lane < 16) {
+        const double2 u = sT[16 + lane];
+        ((double2*)p.r_out)[b * 16 + lane] = make_double2(u.x * inv, u.y * inv);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
   switch (D) {
-    case 4: hipLaunchKernelGGL((overlap_block_kernel<4>), dim3((unsigned)((a.B + 3) / 4)), dim3(64), 0, st, a); break;
+    case 4:
+      if (mfma) {
+        int grid = (int)((a.B + 3) / 4);
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(overlap_square_d4_kernel, dim3(grid), dim3(256), 0, st, a);
+      } else {
+        hipLaunchKernelGGL((overlap_block_kernel<4>), dim3((unsigned)((a.B + 3) / 4)), dim3(64), 0, st, a);
+      }
+      break;
     case 8: hipLaunchKernelGGL((overlap_block_kernel<8>), dim3((unsigned)a.B), dim3(64), 0, st, a); break;
     case 16:
       if (mfma) {

@@ -256,11 +256,12 @@ class EnergyEngine:
         """Time-evolution overlap at the engine's bond dimension D: dominant eigenvalue eta of the mixed two-site
         transfer map between WW . merge(A, A) and merge(B, B) for every candidate.  A: (2,D,D) shared or (B,2,D,D);
         candidates: tensors (B,2,D,D) [kind='tensor'], unitaries (B,2D,2D) ['unitary'] or parameters (B,P) ['params' with
-        ansatz = L.ANSATZ_*].  max_rounds: D = 2 squarings (default 40, <= 60); D >= 4 cap on power steps (default 20000).
+        ansatz = L.ANSATZ_*].  max_rounds: D = 2, 4 squarings of the matrix of the map (default 40, <= 60); D = 8, 16 cap on
+        power steps (default 20000).
         Returns (eta complex (B,), rounds, status[, r (B,D,D)])."""
         D = self.D
         if max_rounds is None:
-            max_rounds = 40 if D == 2 else 20000
+            max_rounds = 40 if D in (2, 4) else 20000
         A = np.ascontiguousarray(A, dtype=np.complex128)
         shared = A.ndim == 3
         if A.shape[-3:] != (2, D, D):
@@ -299,7 +300,7 @@ class EnergyEngine:
     def overlap_launch(self, B=None, max_rounds=None, tol=1e-13, want_r=False):
         """Asynchronous: overlaps of the resident candidates [window, window + B) with the resident reference."""
         if max_rounds is None:
-            max_rounds = 40 if self.D == 2 else 20000
+            max_rounds = 40 if self.D in (2, 4) else 20000
         L.check(self._lib.qmps_overlap_launch(self._ctx, self.B if B is None else B, int(max_rounds), float(tol), 1 if want_r else 0))
 
     def overlap_results(self, B=None, want_r=False):

@@ -73,14 +73,41 @@ def test_overlap_far_candidates_and_caps(D, engine_factory):
     A = O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, 1)[0])
     cands = O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, 12))
     WW = expm(-1j * 0.2 * O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5}))
-    eta, rounds, st = eng.overlaps(A, cands, WW, max_rounds=200000)
+    eta, rounds, st = eng.overlaps(A, cands, WW, max_rounds=60 if D == 4 else 200000)
     ok = st == 0
     assert ok.mean() >= 0.5
+    if D == 4:
+        assert ok.all() and rounds.max() <= 30          # squaring: O(log) rounds whatever the gap
     for k in range(len(cands)):
         ref = O.overlap_eta(A, cands[k], WW)[0]
         assert abs(eta[k] - ref) < (ETA_TOL if ok[k] else 1e-3 * abs(ref)), (k, st[k], eta[k], ref)
     eta, rounds, st = eng.overlaps(A, cands, WW, max_rounds=3)
     assert np.all(st == 1) and np.all(rounds == 3)
+
+
+def test_overlap_d4_power_method_matches_the_squaring_kernel():
+    """D = 4: the operator-form power method of the generic tile kernel (QMPS_OVERLAP_POWER) and the MFMA squaring
+    kernel find the same dominant eigenvalue."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from oracle import qmps_oracle as O\nfrom qmps_amd import EnergyEngine\n"
+            "rng = np.random.default_rng(6); U = O.haar_unitaries(rng, 8, 41)\n"
+            "A = O.unitary_to_tensor(U[0]); C = 0.85 * A[None] + 0.15 * O.unitary_to_tensor(U[1:])\n"
+            "eng = EnergyEngine(4, 64); eta, rounds, st, r = eng.overlaps(A, C, np.eye(4), max_rounds=%%d, want_r=True)\n"
+            "ref = np.array([O.overlap_eta(A, c, np.eye(4))[0] for c in C])\n"
+            "rr = np.array([abs(np.vdot(O.overlap_eta(A, c, np.eye(4))[1], x)) for c, x in zip(C, r)])\n"
+            "print(int(np.all(st == 0)), float(np.abs(eta - ref).max()), float(np.abs(rr - 1).max()), int(rounds.max()))\n" % root)
+    outs = []
+    for env, cap in (({}, 60), ({'QMPS_OVERLAP_POWER': '1'}, 100000)):
+        r = subprocess.run([sys.executable, '-c', code % cap], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1].split())
+    for ok, err, rerr, rounds in outs:
+        assert int(ok) == 1 and float(err) < ETA_TOL and float(rerr) < 1e-9
+    assert int(outs[0][3]) <= 30 < int(outs[1][3])           # squarings vs power steps
 
 
 def test_overlap_d16_tile_kernel_matches_the_matrix_core_kernel():

@@ -98,11 +98,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('QMPS_HIP_LIB', LIB_PATH)     # tuning experiments: an alternative build of the same library
+    if not os.path.exists(path):
         raise ImportError(
-            f'{LIB_PATH} not found: build it with `make -C qmps_amd/csrc` (or __graft_entry__.build()). '
+            f'{path} not found: build it with `make -C qmps_amd/csrc` (or __graft_entry__.build()). '
             'qmps_amd has no CPU fallback.')
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res

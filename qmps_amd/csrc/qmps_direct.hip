@@ -28,10 +28,34 @@ struct QuadOps {
   using P = bool;
   int q;                  // row index of this lane inside its quad
   const double2* row;     // the evaluation's tensor in LDS: A_s[i][j] = row[(4 s + i) 4 + j]
+  double* gj;             // QMPS_GJ_LDS: the quad's 16-double strip for the pivot rows of the elimination
   __device__ __forceinline__ P q_eq(int i) const { return q == i; }
   __device__ __forceinline__ P q_gt(int i) const { return q > i; }
   template <int L>
   static __device__ __forceinline__ V bcast(V v) { return quad_bcast<L>(v); }
+  template <int L, int K>
+  __device__ __forceinline__ void row_bcast(const V (&r)[16], V (&out)[16]) const {
+#ifdef QMPS_GJ_LDS
+    // through LDS: the owner lane parks the rest of its row, every lane of the quad reads it back (one address per quad:
+    // a broadcast read); the LDS pipe works beside the vector ALU, which the DPP moves (2 per double) keep busy
+    constexpr int K0 = K & ~1;
+    __builtin_amdgcn_wave_barrier();
+    if (q == L) {
+#pragma unroll
+      for (int j = K0; j < 16; j += 2) *(double2*)&gj[j] = make_double2(r[j], r[j + 1]);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = K0; j < 16; j += 2) {
+      const double2 t = *(const double2*)&gj[j];
+      if (j >= K) out[j] = t.x;
+      out[j + 1] = t.y;
+    }
+#else
+#pragma unroll
+    for (int j = K; j < 16; ++j) out[j] = quad_bcast<L>(r[j]);
+#endif
+  }
   static __device__ __forceinline__ V qsum(V v) { return quad_sum(v); }
   static __device__ __forceinline__ V sel(P p, V a, V b) { return p ? a : b; }
   static __device__ __forceinline__ V splat(double x) { return x; }
@@ -64,7 +88,7 @@ struct FallbackOut {
 __device__ __attribute__((noinline)) FallbackOut squaring_fallback(int q, const double2* row, bool todo, int max_iter,
                                                                    double tol2, double x0, double x1, double x2, double x3) {
   using Core = DirectD4<QuadOps>;
-  const QuadOps o{q, row};
+  const QuadOps o{q, row, nullptr};
   double Rc[4][16], x[4] = {x0, x1, x2, x3}, sq = 0.0;
   Core::build(o, Rc);
   const bool left = Core::squaring(o, Rc, todo, max_iter, tol2, x, sq);
@@ -82,6 +106,9 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
   // item stride 528 B = 4 banks: the four items of a ds_read_b128 lane group sit on disjoint banks both when a quad
   // reads one address (rows of the partner index) and when its lanes read their own rows (64 B apart)
   __shared__ __attribute__((aligned(16))) unsigned char lds[ITEMS * PAD];
+#ifdef QMPS_GJ_LDS
+  __shared__ __attribute__((aligned(16))) double gjbuf[ITEMS * 18];     // 144-byte stride: the 16 quads on disjoint banks
+#endif
   const int lane = threadIdx.x, e = lane >> 2, q = lane & 3;
   const int64_t first = (int64_t)blockIdx.x * ITEMS;
   const int64_t b = first + e;
@@ -104,7 +131,11 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
     }
   }
   __syncthreads();
-  const QuadOps o{q, (const double2*)(lds + e * PAD)};
+#ifdef QMPS_GJ_LDS
+  const QuadOps o{q, (const double2*)(lds + e * PAD), gjbuf + e * 18};
+#else
+  const QuadOps o{q, (const double2*)(lds + e * PAD), nullptr};
+#endif
   const double tol2 = p.tol * p.tol;
 
   // ---- environment: direct solve, accepted by one power step ----

@@ -23,6 +23,7 @@
 //   types   O::V (value), O::P (lane predicate)
 //   lanes   o.q_eq(i), o.q_gt(i)                       predicates on the lane's row index q
 //   quad    O::template bcast<L>(v), O::qsum(v)        value of lane L / sum over the quad, in every lane
+//           o.template row_bcast<L, K>(row, out)       out[K..15] = row[K..15] of lane L, in every lane
 //   select  O::sel(p, a, b);  O::rcp(v);  O::fma(a, b, c);  O::lt(a, b) -> P;  O::gt0(a) -> P
 //           O::p_and(p, q), O::p_not(p), O::any(p) -> bool
 //   tensor  o.own(s, j, re, im)   A_s[q][j]  (the lane's own row)
@@ -142,8 +143,7 @@ struct DirectD4 {
     static_for<16>([&](auto K) {
       constexpr int k = decltype(K)::value, pl = k >> 2, pr = k & 3;
       V prow[16];
-#pragma unroll
-      for (int j = k; j < 16; ++j) prow[j] = O::template bcast<pl>(M[pr][j]);
+      o.template row_bcast<pl, k>(M[pr], prow);      // entries k .. 15 of the pivot row, in every lane of the quad
       const V pinv = O::rcp(prow[k]);
       const P mine = o.q_eq(pl);
       dinv[pr] = O::sel(mine, pinv, dinv[pr]);

@@ -32,6 +32,10 @@ struct HostOps {
   static V bcast(V a) {
     return {{a.v[L], a.v[L], a.v[L], a.v[L]}};
   }
+  template <int L, int K>
+  void row_bcast(const V (&row)[16], V (&out)[16]) const {
+    for (int j = K; j < 16; ++j) out[j] = bcast<L>(row[j]);
+  }
   static V qsum(V a) {
     // same association as the DPP butterfly: (x + partner[1,0,3,2]) + pair[2,3,0,1]
     const double s01 = a.v[0] + a.v[1], s23 = a.v[2] + a.v[3];

@@ -82,8 +82,9 @@ struct DirectD4 {
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          tr[s][j] = O::sel(rot, -ai[s][j], ar[s][j]);
-          ti[s][j] = O::sel(rot, ar[s][j], ai[s][j]);
+          // (no lane has q > 3: the last partner index needs no select)
+          tr[s][j] = ip == 3 ? ar[s][j] : O::sel(rot, -ai[s][j], ar[s][j]);
+          ti[s][j] = ip == 3 ? ai[s][j] : O::sel(rot, ar[s][j], ai[s][j]);
           o.uni(s, ip, j, br[s][j], bi[s][j]);
         }
 #pragma unroll
@@ -234,7 +235,7 @@ struct DirectD4 {
           ci = O::fma(xi[s][k], br, ci);
           ci = O::fma(-xr[s][k], bi, ci);
         }
-      y[l] = O::sel(o.q_gt(l), -ci, cr);     // u[(q,l)] = Re r'[q][l] (q <= l),  Im r'[l][q] = -Im r'[q][l] (q > l)
+      y[l] = l == 3 ? cr : O::sel(o.q_gt(l), -ci, cr);     // u[(q,l)] = Re r'[q][l] (q <= l),  Im r'[l][q] = -Im r'[q][l] (q > l)
     }
     normalise(o, y);
     return dist2(o, x, y);

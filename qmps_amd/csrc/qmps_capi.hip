@@ -114,6 +114,7 @@ struct qmps_ctx {
   double* d_cost_ring = nullptr;             // [kCostSlots][kMaxGroup][16]: a slot = one group of steps
   int exchange_period = 1;                   // steps per all-reduce (qmps_set_exchange_period)
   int group_fill = 0;                        // steps summed into the current group so far
+  bool slot_waited = false;                  // the compute stream already waits for the current slot's previous exchange
   int64_t groups = 0;                        // groups closed (exchanged or, without a communicator, just filled)
   int last_slot = -1, last_pos = -1;         // where the newest cost lives
   hipEvent_t cost_ready[kCostSlots] = {};    // sum kernels done (main stream)
@@ -219,7 +220,8 @@ int setup_accumulator(qmps_ctx* c, qmps::LaneArgs& a, int64_t B, int64_t adds, i
   // a slot of the ring is touched again only after its previous exchange has finished.  Asked on the HOST (that
   // exchange, kCostSlots - 2 groups ago, has normally finished long ago): a stream wait would put a barrier packet
   // on the compute stream in every step (+4 us measured), and the compute stream carries no event either
-  if (c->comm && c->groups + 2 >= qmps_ctx::kCostSlots && hipEventQuery(c->cost_reduced[nslot]) != hipSuccess) {
+  static const bool dbg_nohostwait = getenv("QMPS_DBG_NOHOSTWAIT") != nullptr;   // timing experiments only
+  if (c->comm && !dbg_nohostwait && c->groups + 2 >= qmps_ctx::kCostSlots && hipEventQuery(c->cost_reduced[nslot]) != hipSuccess) {
     (void)hipGetLastError();
     HIP_TRY(hipEventSynchronize(c->cost_reduced[nslot]));
   }
@@ -1184,6 +1186,19 @@ int qmps_comm_init(qmps_ctx* c, const char id[QMPS_UNIQUE_ID_BYTES], int rank, i
     // second communicator over the same ranks (collective, like the init itself); without it everything runs on the first
     ncclResult_t r2 = ncclCommSplit(c->comm, 0, rank, &c->comm2, nullptr);
     if (r2 != ncclSuccess) c->comm2 = nullptr;
+    // every rank must take the same decision (slot -> communicator): agree on min over ranks of "I have the second one"
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double* flag = c->d_cost;
+    const double mine = c->comm2 ? 1.0 : 0.0;
+    double all = 0.0;
+    HIP_TRY(hipMemcpyAsync(flag, &mine, sizeof(double), hipMemcpyHostToDevice, c->comm_stream));
+    RCCL_TRY(ncclAllReduce(flag, flag, 1, ncclDouble, ncclMin, c->comm, c->comm_stream));
+    HIP_TRY(hipMemcpyAsync(&all, flag, sizeof(double), hipMemcpyDeviceToHost, c->comm_stream));
+    HIP_TRY(hipStreamSynchronize(c->comm_stream));
+    if (all < 0.5 && c->comm2) {
+      (void)ncclCommDestroy(c->comm2);
+      c->comm2 = nullptr;
+    }
   }
   c->rank = rank;
   c->nranks = nranks;
@@ -1236,7 +1251,8 @@ int close_group(qmps_ctx* c) {
   double* base = c->d_cost_ring + (size_t)slot * qmps_ctx::kMaxGroup * kMaxTerms;
   if (c->comm) {
     static const bool dbg_noevent = getenv("QMPS_DBG_NOEVENT") != nullptr, dbg_noar = getenv("QMPS_DBG_NOAR") != nullptr,
-                      dbg_nofinish = getenv("QMPS_DBG_NOFINISH") != nullptr;   // timing experiments only (wrong results)
+                      dbg_nofinish = getenv("QMPS_DBG_NOFINISH") != nullptr,   // timing experiments only (wrong results)
+                      dbg_nopoll = getenv("QMPS_DBG_NOPOLL") != nullptr;
     // positions whose cost lives in a fixed-point accumulator need no ordering on the compute stream: their finish
     // kernel polls the arrival counts.  Only costs written by reduction kernels on the compute stream need the event.
     bool need_event = false;
@@ -1248,7 +1264,7 @@ int close_group(qmps_ctx* c) {
     for (int pos = 0; pos < c->group_fill; ++pos)
       if (c->acc_is[slot][pos]) {   // fixed-point accumulators -> doubles, off the compute stream
         if (!dbg_nofinish)
-          HIP_TRY(qmps::launch_cost_finish(c->acc_at(slot, pos), c->acc_shards[slot][pos], c->acc_expect[slot][pos], 1 << 22,
+          HIP_TRY(qmps::launch_cost_finish(c->acc_at(slot, pos), c->acc_shards[slot][pos], c->acc_expect[slot][pos], dbg_nopoll ? 0 : 1 << 22,
                                            1.0 / c->acc_scale[slot][pos], c->n_terms, base + (size_t)pos * kMaxTerms,
                                            c->d_acc_err, c->comm_stream_of(slot)));
         c->acc_is[slot][pos] = false;
@@ -1259,6 +1275,7 @@ int close_group(qmps_ctx* c) {
   }
   c->group_fill = 0;
   c->groups++;
+  c->slot_waited = false;
   return QMPS_OK;
 }
 }  // namespace
@@ -1279,11 +1296,16 @@ int qmps_cost_launch(qmps_ctx* c, int64_t B) {
   // device-side sum into this step's place in the current group of the ring (main stream) ...
   const int slot = (int)(c->groups % qmps_ctx::kCostSlots);
   double* dst = c->d_cost_ring + ((size_t)slot * qmps_ctx::kMaxGroup + c->group_fill) * kMaxTerms;
-  // a slot is reused only after its previous all-reduce has finished
-  if (c->comm && c->group_fill == 0 && c->groups >= qmps_ctx::kCostSlots)
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->cost_reduced[slot], 0));
   c->acc_is[slot][c->group_fill] = false;
-  if (c->acc_pending && c->acc_B == B && c->acc_window == c->window && c->acc_slot == slot && c->acc_pos == c->group_fill) {
+  const bool in_kernel = c->acc_pending && c->acc_B == B && c->acc_window == c->window && c->acc_slot == slot && c->acc_pos == c->group_fill;
+  // A slot is reused only after its previous all-reduce has finished.  Costs written by a reduction kernel on the compute
+  // stream need that as a stream dependency; a cost that lives in a fixed-point accumulator is converted on the slot's own
+  // communication stream, behind that all-reduce, and puts nothing on the compute stream (no barrier packet per step).
+  if (c->comm && !in_kernel && c->groups >= qmps_ctx::kCostSlots && !c->slot_waited) {
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->cost_reduced[slot], 0));
+    c->slot_waited = true;
+  }
+  if (in_kernel) {
     // the energy kernel has summed the batch itself (exact fixed-point accumulator): nothing to launch
     c->acc_is[slot][c->group_fill] = true;
   } else if (c->partials_B == B)   // the energy kernel already left per-wave partial sums: only the final pass is needed

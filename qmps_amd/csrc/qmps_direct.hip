@@ -78,21 +78,115 @@ struct QuadOps {
   }
 };
 
-// The rare path, out of line: rebuild R, then the power method 2^m steps at a time.  Kept out of the kernel body so
-// that its register demand (two 16 x 16 matrices per quad) does not shape the register allocation of the main path;
-// everything travels in registers (a reference parameter would pin x to scratch memory in the MAIN path too).
-struct FallbackOut {
-  double x0, x1, x2, x3, sq;
-  int left;
-};
-__device__ __attribute__((noinline)) FallbackOut squaring_fallback(int q, const double2* row, bool todo, int max_iter,
-                                                                   double tol2, double x0, double x1, double x2, double x3) {
-  using Core = DirectD4<QuadOps>;
-  const QuadOps o{q, row, nullptr};
-  double Rc[4][16], x[4] = {x0, x1, x2, x3}, sq = 0.0;
-  Core::build(o, Rc);
-  const bool left = Core::squaring(o, Rc, todo, max_iter, tol2, x, sq);
-  return FallbackOut{x[0], x[1], x[2], x[3], sq, left ? 1 : 0};
+// The rare path (tensors that are not isometries, degenerate transfer spectra): the power method 2^m steps at a time,
+// ONE EVALUATION AT A TIME WITH THE WHOLE WAVE ON THE MATRIX CORES.  In orthonormal Hermitian coordinates
+// (a = 4 i + i': r_ii | sqrt2 Re r_ii' (i < i') | sqrt2 Im r_i'i (i > i')) the transfer map is one real 16 x 16 tile;
+// squaring it is 4 x v_mfma_f64_16x16x4 (accumulator layout = B-operand layout of the next round, A fragments from a
+// padded LDS image).  The recurrence is DirectD4::squaring's (qmps_direct_core.h: z_m = R^(2^m) r_0 / tr from
+// r_0 = 1/4, stop at ||z_m - z_(m-1)||_F < tol, the matrix rescaled by 1/tr every round), which the CPU emulation
+// runs in the quad layout; held in registers per quad that formulation needs two 16 x 16 matrices per evaluation
+// (256 VGPRs + spills), and a kernel that fills the register file cannot share a SIMD with any other resident wave
+// (a polling cost_finish_kernel or an RCCL kernel then costs the step a straggler wave, +3 us measured).  Here the
+// rare path needs ~40 registers and no scratch memory.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int kSqLD = 17;                              // padded row of the LDS image
+constexpr int kSqDoubles = 16 * kSqLD + 16;            // image + a 16-double strip
+
+// todo: lanes whose evaluation needs the fall-back (alike in the four lanes of a quad).  x / steps / left of those
+// evaluations are replaced; tiles: the wave's padded tensor tiles (stride pad bytes); img: kSqDoubles doubles of LDS.
+__device__ __forceinline__ void squaring_fallback(const unsigned char* tiles, int pad, double* img, int lane, bool todo,
+                                                  int max_iter, double tol2, double (&x)[4], double& steps, bool& left) {
+  constexpr int D = 4, LD = kSqLD;
+  constexpr double RS2 = 0.70710678118654752, S2 = 1.4142135623730951;
+  const int g = lane >> 4, c = lane & 15, j = c >> 2, jp = c & 3, q = lane & 3;
+  double* strip = img + 16 * LD;
+  // lane constants of the matrix build: column (j, j') combines conj(A_s[g][j']) and conj(A_s[g][j]) with
+  // (1, 0) on the diagonal, (1, 1)/sqrt2 for a real-part column, (-i, i)/sqrt2 for an imaginary-part column
+  const double cpx = j == jp ? 1.0 : (j < jp ? RS2 : 0.0), cpy = j > jp ? -RS2 : 0.0;
+  const double cqx = j < jp ? RS2 : 0.0, cqy = j > jp ? RS2 : 0.0;
+  const bool diag = j == jp;
+  unsigned long long mask = __ballot(todo);
+  while (mask != 0) {
+    const int e = (__ffsll((long long)mask) - 1) >> 2;        // wave-uniform
+    mask &= ~(0xFull << (4 * e));
+    const double2* sA = (const double2*)(tiles + e * pad);     // A_s[i][k] = sA[(4 s + i) 4 + k]
+    // R[a][b] = tr(H_a T(H_b)) in accumulator layout: lane (g, c) holds R[(reg, g)][(j, j')], reg = 0 .. 3
+    v4f64 R;
+    {
+      double pr[2], pi[2], qr[2], qi[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const double2 a = sA[(s * D + g) * D + jp], b = sA[(s * D + g) * D + j];
+        pr[s] = dfma(cpx, a.x, cpy * a.y);
+        pi[s] = dfma(cpy, a.x, -cpx * a.y);
+        qr[s] = dfma(cqx, b.x, cqy * b.y);
+        qi[s] = dfma(cqy, b.x, -cqx * b.y);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        double gr = 0.0, gi = 0.0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const double2 u = sA[(s * D + reg) * D + j], v = sA[(s * D + reg) * D + jp];
+          gr = dfma(u.x, pr[s], gr);
+          gr = dfma(-u.y, pi[s], gr);
+          gr = dfma(v.x, qr[s], gr);
+          gr = dfma(-v.y, qi[s], gr);
+          gi = dfma(u.x, pi[s], gi);
+          gi = dfma(u.y, pr[s], gi);
+          gi = dfma(v.x, qi[s], gi);
+          gi = dfma(v.y, qr[s], gi);
+        }
+        // Re G (reg == g), sqrt2 Re G (reg < g), -sqrt2 Im G (reg > g: the sorted pair is (g, reg))
+        R[reg] = reg == g ? gr : (reg < g ? S2 * gr : -S2 * gi);
+      }
+    }
+    // image of a matrix in LDS (wave-private, LDS is in order per wave) -> its A-operand fragments M[c][4 kk + g]
+    double af[4];
+    auto image = [&](const v4f64& M) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) img[(4 * reg + g) * LD + c] = M[reg];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) af[kk] = img[c * LD + 4 * kk + g];
+    };
+    image(R);
+    double prev = diag ? 0.25 : 0.0, z = prev, st = 0.0;   // coordinate a = c of the iterate (alike in the four row groups)
+    bool active = true;
+    int m = 0;
+    while (active && m < 29 && (2 << m) <= max_iter) {
+      v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], R[kk], acc, 0, 0, 0);
+      ++m;
+      image(acc);
+      // z = R^(2^m) r_0 with r_0 = 1/4: a quarter of the sum of the four diagonal-coordinate columns
+      z = 0.25 * ((img[c * LD + 0] + img[c * LD + 5]) + (img[c * LD + 10] + img[c * LD + 15]));
+      const double inv = fast_rcp(row16_sum(diag ? z : 0.0));
+      z *= inv;
+      R = acc * inv;                  // 1/tr ~ 1/lambda^(2^m): the squared matrix stays O(1) for tensors that are not isometries
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) af[kk] *= inv;
+      const double d = z - prev;
+      const double d2 = row16_sum(d * d);       // orthonormal coordinates: the Frobenius distance of the two matrices
+      prev = z;
+      st = (double)(1 << m);
+      active = !(d2 < tol2);
+    }
+    // hand the result to the evaluation's quad in its own coordinates (plain: Re / Im parts without the sqrt2)
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16) strip[lane] = diag ? z : RS2 * z;
+    __builtin_amdgcn_wave_barrier();
+    if ((lane >> 2) == e) {
+      if (m > 0) {                      // (an iteration cap below 3 leaves no room for a round: x stays what the solve gave)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) x[l] = strip[4 * q + l];
+      }
+      steps = 1.0 + st;
+      left = active;
+    }
+  }
 }
 
 }  // namespace
@@ -106,6 +200,7 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
   // item stride 528 B = 4 banks: the four items of a ds_read_b128 lane group sit on disjoint banks both when a quad
   // reads one address (rows of the partner index) and when its lanes read their own rows (64 B apart)
   __shared__ __attribute__((aligned(16))) unsigned char lds[ITEMS * PAD];
+  __shared__ double sq_img[kSqDoubles];      // the rare path's 16 x 16 image
 #ifdef QMPS_GJ_LDS
   __shared__ __attribute__((aligned(16))) double gjbuf[ITEMS * 18];     // 144-byte stride: the 16 quads on disjoint banks
 #endif
@@ -154,14 +249,10 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
     __builtin_amdgcn_sched_barrier(0);
     const bool todo = valid && !(d2 < tol2);     // NaN (a zero pivot) lands here too
     if (__any(todo)) {
-      // rare: not an isometry / degenerate transfer spectrum.  Wave-uniform branch: every quad walks through the
-      // rounds, only the `todo` ones take the result.
-      const FallbackOut f = squaring_fallback(q, o.row, todo, p.max_iter - 1, tol2, x[0], x[1], x[2], x[3]);
-      x[0] = f.x0; x[1] = f.x1; x[2] = f.x2; x[3] = f.x3;
-      if (todo) {
-        steps = 1.0 + f.sq;
-        status = f.left ? QMPS_ST_NOT_CONVERGED : QMPS_ST_OK;
-      }
+      // rare: not an isometry / degenerate transfer spectrum.  Wave-uniform branch, one evaluation at a time.
+      bool left = false;
+      squaring_fallback(lds, PAD, sq_img, lane, todo, p.max_iter - 1, tol2, x, steps, left);
+      if (todo) status = left ? QMPS_ST_NOT_CONVERGED : QMPS_ST_OK;
       Core::gather(x, us);
     }
   }
@@ -229,30 +320,30 @@ __global__ __launch_bounds__(64) void cost_finish_kernel(const long long* __rest
                                                          double* __restrict__ cost, int* __restrict__ err) {
   const int lane = threadIdx.x;
   for (int t = 0; t < n_terms; ++t) {
-    long long cnt = 0, hi = 0, lo = 0;
+    // per-lane sums as doubles (exact: counts and the two halves of the fixed-point values stay far below 2^53), reduced
+    // with the DPP / permlane wave sum: the kernel keeps to 32 VGPRs, so that it fits beside two waves of the energy
+    // kernel on a SIMD (a resident wave that does not fit costs the energy kernel a wave slot and the step a straggler)
+    double cnt = 0.0, hi = 0.0, lo = 0.0;
     for (int poll = 0;; ++poll) {
-      cnt = 0; hi = 0; lo = 0;
+      long long c_i = 0, hi_i = 0, lo_i = 0;
       for (int i = lane; i < n_shards; i += 64) {
         const long long w = __hip_atomic_load(acc + t * kAccMaxShards + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         long long c, v;
         acc_decode(w, c, v);
-        cnt += c;
-        hi += v >> 20;                  // split so that the sum over <= 1024 shards stays inside 64 bits
-        lo += v & 0xFFFFF;
+        c_i += c;
+        hi_i += v >> 20;                // split so that the sum over the shards stays exact
+        lo_i += v & 0xFFFFF;
       }
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) {
-        cnt += __shfl_xor(cnt, m, 64);
-        hi += __shfl_xor(hi, m, 64);
-        lo += __shfl_xor(lo, m, 64);
-      }
-      if (expect <= 0 || cnt >= expect || poll >= max_polls) break;
+      cnt = wave_sum((double)c_i);
+      hi = wave_sum((double)hi_i);
+      lo = wave_sum((double)lo_i);
+      if (expect <= 0 || cnt >= (double)expect || poll >= max_polls) break;
       __builtin_amdgcn_s_sleep(32);
     }
     if (lane == 0) {
-      const bool ok = expect <= 0 || cnt == expect;
+      const bool ok = expect <= 0 || cnt == (double)expect;
       const double over = __hip_atomic_load((const double*)(acc + kAccOver) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      cost[t] = ok ? ((double)hi * 1048576.0 + (double)lo) * inv_scale + over : __builtin_nan("");
+      cost[t] = ok ? (hi * 1048576.0 + lo) * inv_scale + over : __builtin_nan("");
       if (!ok && err != nullptr) *err = 1;
     }
   }

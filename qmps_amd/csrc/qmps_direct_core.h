@@ -242,6 +242,9 @@ struct DirectD4 {
   }
 
   // ---- 4. fall-back: the power method 2^m steps at a time from r_0 = 1/4, Rc <- Rc Rc in the quad layout ----
+  // Reference formulation, run by the CPU emulation.  The device kernel runs the SAME recurrence one evaluation at a
+  // time on the matrix cores (qmps_direct.hip: squaring_fallback; this form holds two 16 x 16 matrices per quad in
+  // registers, which would cost the common path its register budget); tests/test_direct_gpu.py compares the two.
   static QMPS_CORE_FN void square(V (&Rc)[4][16]) {
     V out[4][16];
     static_for<16>([&](auto C) {

@@ -98,6 +98,14 @@ struct qmps_ctx {
   bool have_guess = false;
   bool have_env = false;
   bool want_rho = false;
+  // ansatz-parametrised states: the parameters stay resident (d_params, or ans_src during a rotosolve run); at D = 4 the
+  // direct kernel builds the tensor itself, so d_A is materialised only when something else asks for the tensors
+  bool ans_have = false;            // the resident states ARE ansatz(kind, P) of the resident parameters
+  bool tensors_valid = true;        // d_A holds the tensors of the resident states
+  int ans_kind = 0, ans_P = 0;
+  const double* ans_src = nullptr;  // parameter rows (nullptr: d_params)
+  const int* ans_i = nullptr;       // rotosolve: device index of the parameter being updated
+  int ans_nsh = 0;                  // rotosolve: shifts per restart (0: one parameter row per evaluation)
   // RCCL: the all-reduce runs on its own stream so that it overlaps the next step's kernels
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
@@ -177,6 +185,21 @@ char* win_r(const qmps_ctx* c) { return (char*)c->d_r + (size_t)c->window * env_
 double* win_E(const qmps_ctx* c) { return c->d_E + c->window * (c->n_terms > 0 ? c->n_terms : 1); }
 int32_t* win_iters(const qmps_ctx* c) { return c->d_iters + c->window; }
 int32_t* win_status(const qmps_ctx* c) { return c->d_status + c->window; }
+
+// kinds the D = 4 direct kernel builds in front of the solve (three-qubit circuits with a per-layer gate list)
+bool fusable_ansatz(const qmps_ctx* c, int kind) {
+  static const bool off = getenv("QMPS_NO_FUSED_ANSATZ") != nullptr;   // A/B knob
+  return !off && c->D == 4 && (kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_QAOA || kind == QMPS_ANSATZ_SHALLOW_CNOT3);
+}
+
+// d_A <- tensors of the resident ansatz parameters, if nothing has built them yet
+int ensure_tensors(qmps_ctx* c) {
+  if (c->tensors_valid) return QMPS_OK;
+  if (!c->ans_have || c->ans_nsh != 0) return fail(QMPS_ERR_STATE, "no resident states");
+  HIP_TRY(qmps::launch_ansatz(c->D, c->ans_kind, c->ans_src ? c->ans_src : c->d_params, c->ans_P, c->d_A, c->n_states, c->stream));
+  c->tensors_valid = true;
+  return QMPS_OK;
+}
 
 qmps::LaneArgs make_args(qmps_ctx* c, int64_t B, int max_iter, double tol, bool solve) {
   qmps::LaneArgs a;
@@ -416,6 +439,8 @@ int qmps_set_states(qmps_ctx* c, int64_t B, const double* states, int kind) {
   c->window = 0;
   c->have_guess = false;
   c->have_env = false;
+  c->ans_have = false;
+  c->tensors_valid = true;
   return QMPS_OK;
 }
 
@@ -445,9 +470,13 @@ int qmps_set_states_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const
     c->params_cap = n_params;
   }
   HIP_TRY(hipMemcpyAsync(c->d_params, params, (size_t)B * n_params * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(qmps::launch_ansatz(c->D, kind, c->d_params, n_params, c->d_A, B, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->ans_have = true; c->ans_kind = kind; c->ans_P = n_params; c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0;
+  c->tensors_valid = false;
   c->n_states = B;
+  // D = 4: the direct kernel builds the tensors itself (8 P bytes per evaluation instead of 512); d_A is filled on demand
+  if (!fusable_ansatz(c, kind))
+    if (int rc = ensure_tensors(c)) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
   c->window = 0;
   c->have_guess = false;
   c->have_env = false;
@@ -497,7 +526,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
   int* d_idx = nullptr;
   HIP_TRY(hipMalloc((void**)&d_base, (size_t)R * n_params * sizeof(double)));
   if (hipMalloc((void**)&d_hist, (size_t)R * n_sweeps * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&d_idx, 2 * sizeof(int)) != hipSuccess) {
+      hipMalloc((void**)&d_idx, 3 * sizeof(int)) != hipSuccess) {
     (void)hipFree(d_base);
     if (d_hist) (void)hipFree(d_hist);
     return fail(QMPS_ERR_HIP, "hipMalloc failed");
@@ -506,7 +535,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
   hipGraphExec_t exec = nullptr;
   int rc = [&]() -> int {
     HIP_TRY(hipMemcpyAsync(d_base, params, (size_t)R * n_params * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(d_idx, 0, 2 * sizeof(int), c->stream));
+    HIP_TRY(hipMemsetAsync(d_idx, 0, 3 * sizeof(int), c->stream));   // parameter index, arrival counter, finished sweeps
     HIP_TRY(hipStreamSynchronize(c->stream));
     const bool saved_guess = c->have_guess;
     c->have_guess = false;
@@ -522,7 +551,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
       ra.skip = c->skip_rounds; ra.tol = tol;
       HIP_TRY(qmps::launch_rotosolve_fused_d2(kind, ra, c->stream));
       HIP_TRY(qmps::launch_ansatz(c->D, kind, d_base, n_params, c->d_A, R, c->stream));
-      c->n_states = R;
+      c->n_states = R; c->ans_have = false; c->tensors_valid = true;
       if (int e = qmps_energy_launch(c, R, max_iter, tol, c->default_solver)) return e;
       c->have_guess = saved_guess;
       HIP_TRY(hipMemcpyAsync(params, d_base, (size_t)R * n_params * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -533,19 +562,46 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     // One parameter update = shift build -> ansatz -> environment + energy -> closed-form update.  The
     // parameter index lives in HBM and is advanced by the update kernel, so the sequence is captured ONCE
     // into a hipGraph and replayed n_params x n_sweeps times: the sweep is launch-bound at small R.
+    // D = 4 with the direct solver: shift build and ansatz happen INSIDE the energy kernel (evaluation nsh r + k builds
+    // the tensor of restart r with shift k on parameter *d_idx straight into LDS): two kernels per parameter update
+    const bool fused = c->default_solver == QMPS_ENV_DIRECT && fusable_ansatz(c, kind);
+    auto evaluate = [&](int shifts) -> int {      // shifts = nsh: the shifted batch;  0: the R base vectors
+      const int64_t n = shifts > 0 ? (int64_t)shifts * R : R;
+      if (fused) {
+        c->ans_have = true; c->ans_kind = kind; c->ans_P = n_params; c->ans_src = d_base; c->ans_i = d_idx; c->ans_nsh = shifts;
+        c->tensors_valid = false;
+      } else {
+        const double* rows = d_base;
+        if (shifts > 0) {
+          HIP_TRY(qmps::launch_roto_shift(d_base, c->d_params, (int)R, n_params, d_idx, shifts, c->stream));
+          rows = c->d_params;
+        }
+        HIP_TRY(qmps::launch_ansatz(c->D, kind, rows, n_params, c->d_A, n, c->stream));
+        c->ans_have = false; c->tensors_valid = true;
+      }
+      c->n_states = n;
+      return qmps_energy_launch(c, n, max_iter, tol, c->default_solver);
+    };
     auto one_update = [&]() -> int {
-      HIP_TRY(qmps::launch_roto_shift(d_base, c->d_params, (int)R, n_params, d_idx, nsh, c->stream));
-      HIP_TRY(qmps::launch_ansatz(c->D, kind, c->d_params, n_params, c->d_A, nsh * R, c->stream));
-      c->n_states = nsh * R;
-      if (int e = qmps_energy_launch(c, nsh * R, max_iter, tol, c->default_solver)) return e;
+      if (int e = evaluate(nsh)) return e;
       HIP_TRY(qmps::launch_roto_update(d_base, c->d_E, c->d_status, (int)R, n_params, d_idx, c->n_terms, nsh, c->stream));
       return QMPS_OK;
     };
-    const bool use_graph = getenv("QMPS_NO_GRAPH") == nullptr;
+    // One sweep = n_params updates + the evaluation of the updated vectors + its record.  The parameter index and the
+    // sweep counter live in HBM and are advanced by the update kernel, so the sweep is captured ONCE into a hipGraph and
+    // replayed n_sweeps times (a graph launch costs ~15 us: per update it was a third of the time, per sweep it is noise)
+    auto one_sweep = [&]() -> int {
+      for (int i = 0; i < n_params; ++i)
+        if (int e = one_update()) return e;
+      if (int e = evaluate(0)) return e;
+      HIP_TRY(qmps::launch_roto_record(c->d_E, d_hist, (int)R, c->n_terms, d_idx + 2, c->stream));
+      return QMPS_OK;
+    };
+    const bool use_graph = getenv("QMPS_NO_GRAPH") == nullptr && n_params <= 256;
     if (use_graph) {
       c->capturing = true;
       HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-      const int e = one_update();
+      const int e = one_sweep();
       const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
       c->capturing = false;
       if (e) return e;
@@ -553,14 +609,13 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
       HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     }
     for (int sw = 0; sw < n_sweeps; ++sw) {
-      for (int i = 0; i < n_params; ++i) {
-        if (use_graph) HIP_TRY(hipGraphLaunch(exec, c->stream));
-        else if (int e = one_update()) return e;
-      }
-      HIP_TRY(qmps::launch_ansatz(c->D, kind, d_base, n_params, c->d_A, R, c->stream));
-      c->n_states = R;
-      if (int e = qmps_energy_launch(c, R, max_iter, tol, c->default_solver)) return e;
-      HIP_TRY(qmps::launch_roto_record(c->d_E, d_hist + (size_t)sw * R, (int)R, c->n_terms, c->stream));
+      if (use_graph) HIP_TRY(hipGraphLaunch(exec, c->stream));
+      else if (int e = one_sweep()) return e;
+    }
+    if (fused) {
+      // leave the context as a qmps_set_states_ansatz of the final parameters would: rows resident in d_params
+      HIP_TRY(hipMemcpyAsync(c->d_params, d_base, (size_t)R * n_params * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0;
     }
     c->have_guess = saved_guess;
     HIP_TRY(hipMemcpyAsync(params, d_base, (size_t)R * n_params * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -570,6 +625,9 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
   }();
   c->capturing = false;
   (void)hipStreamSynchronize(c->stream);
+  if (c->ans_src != nullptr) {     // an error left the context pointing at the run's own buffers
+    c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0; c->ans_have = false; c->tensors_valid = true; c->n_states = 0;
+  }
   if (exec) (void)hipGraphExecDestroy(exec);
   if (graph) (void)hipGraphDestroy(graph);
   (void)hipFree(d_base);
@@ -584,6 +642,7 @@ int qmps_get_states(qmps_ctx* c, int64_t B, double* A) {
   if (int rc = check_B(c, B)) return rc;
   if (!A) return fail(QMPS_ERR_ARG, "null A");
   if (B > c->n_states) return fail(QMPS_ERR_STATE, "only %lld states are resident", (long long)c->n_states);
+  if (int rc = ensure_tensors(c)) return rc;
   HIP_TRY(hipMemcpyAsync(A, c->d_A, (size_t)B * tensor_bytes(c), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
@@ -644,6 +703,9 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   const bool direct8 = solver == QMPS_ENV_DIRECT && c->D == 8;
   if (solver == QMPS_ENV_DIRECT && !direct) solver = QMPS_ENV_POWER_SQUARING;   // documented: D = 2, 16 iterate
   c->acc_pending = false;   // whatever an earlier launch accumulated no longer describes the resident energies
+  const bool fused = direct && c->ans_have && fusable_ansatz(c, c->ans_kind);
+  if (!fused)
+    if (int rc = ensure_tensors(c)) return rc;
   qmps::LaneArgs a = make_args(c, B, max_iter, tol, true);
   if (direct8) {
     // D = 8: the direct solve (one wave per evaluation) leaves its result in the environment buffer; the power
@@ -660,7 +722,12 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     // D = 4: direct fixed-point solve + acceptance power step + energies in ONE kernel (a DPP quad per evaluation);
     // one read of A, one store of E (and, unless switched off, of r) per evaluation
     a.r_in = nullptr;
-    a.r_out = (flags & QMPS_FLAG_NO_ENV_OUT) ? nullptr : c->d_r;
+    a.r_out = (flags & QMPS_FLAG_NO_ENV_OUT) ? nullptr : win_r(c);
+    if (fused) {
+      const double* rows = c->ans_src ? c->ans_src : c->d_params;
+      a.ans_params = c->ans_nsh > 0 ? rows : rows + (size_t)c->window * c->ans_P;
+      a.ans_P = c->ans_P; a.ans_kind = c->ans_kind; a.ans_nsh = c->ans_nsh; a.ans_i = c->ans_i;
+    }
     if (flags & QMPS_FLAG_ACCUMULATE_COST) {
       if (int rc = setup_accumulator(c, a, B, (B + 15) / 16, 16)) return rc;
     } else {
@@ -807,6 +874,7 @@ int qmps_energy_only_launch(qmps_ctx* c, int64_t B) {
   if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "qmps_set_hamiltonian has not been called");
   if (!c->have_env) return fail(QMPS_ERR_STATE, "no resident environment: run qmps_energy_launch or qmps_set_env_guess first");
+  if (int rc = ensure_tensors(c)) return rc;
   qmps::LaneArgs a = make_args(c, B, 1, 1.0, false);
   c->partials_B = -1;
   if (c->D == 16 && !getenv("QMPS_D16_BLOCK"))
@@ -974,6 +1042,7 @@ int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int 
   memset(&a, 0, sizeof(a));
   const bool shared = c->overlap_refs == 1;
   a.A = shared ? (char*)c->d_U : (char*)c->d_U + (size_t)c->window * tensor_bytes(c);
+  if (int rc = ensure_tensors(c)) return rc;
   a.Bt = win_A(c);
   a.WW = c->d_ww;
   a.eta = (char*)c->d_eta + (size_t)c->window * 16;

@@ -15,8 +15,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "qmps_hip.h"
 #include "qmps_kernels.h"
 #include "qmps_device.h"
+#include "qmps_circuit.h"
 #include "qmps_direct_core.h"
 
 namespace qmps {
@@ -194,6 +196,10 @@ __device__ __forceinline__ void squaring_fallback(const unsigned char* tiles, in
 #ifndef QMPS_DIRECT_MINWAVES
 #define QMPS_DIRECT_MINWAVES 2
 #endif
+// ANS = -1: tensors from HBM;  ANS = QMPS_ANSATZ_* (0, 1, 3): the tensor is built in LDS from the evaluation's ansatz
+// parameters - lane q of the quad simulates the three-qubit circuit on the basis state |0>|q>, i.e. column q of the
+// unitary, which is all unitary_to_tensor keeps (qmps/tools.py:151-154) - 8 P bytes per evaluation instead of 512.
+template <int ANS>
 __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_kernel(LaneArgs p) {
   using Core = DirectD4<QuadOps>;
   constexpr int ROW = 512, PAD = ROW + 16, ITEMS = 16;
@@ -208,7 +214,51 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
   const int64_t first = (int64_t)blockIdx.x * ITEMS;
   const int64_t b = first + e;
   const bool valid = b < p.B;
-  {
+  if constexpr (ANS >= 0) {
+    Reg<3> reg;
+#pragma unroll
+    for (int xx = 0; xx < 8; ++xx) {
+      reg.re[xx] = (valid && xx == q) ? 1.0 : 0.0;     // an evaluation beyond the batch gets a zero tensor
+      reg.im[xx] = 0.0;
+    }
+    const int nsh = p.ans_nsh;
+    const int64_t row = valid ? b : 0;
+    const int64_t ridx = nsh > 0 ? row / nsh : row;
+    const int shift_k = nsh > 0 ? (int)(row - ridx * nsh) : 0;
+    const int isel = nsh > 0 ? *p.ans_i : -1;
+    const double* pp = p.ans_params + ridx * p.ans_P;
+    // The four lanes of the quad need the same angles: lane q does the sincos of angle l + q (double-precision sincos is
+    // ~150 instructions, the gates of a layer ~110), quad_perm hands the results round.  KIND 0 / 1: four angles = two
+    // layers per trip; KIND 3: the three angles of one layer.
+    constexpr int per = ANS == QMPS_ANSATZ_SHALLOW_CNOT3 ? 3 : 2, trip = ANS == QMPS_ANSATZ_SHALLOW_CNOT3 ? 3 : 4;
+    const int P = p.ans_P;
+    for (int l = 0; l + per <= P; l += trip) {
+      const int mine = l + q;
+      double ang = 0.0;
+      if (q < trip && mine < P) {
+        ang = pp[mine];
+        if (mine == isel) ang += roto_shift_value(nsh, shift_k);
+      }
+      // position of the angle inside its layer: q % per
+      const double scale = ansatz_angle_scale<ANS>(ANS == QMPS_ANSATZ_SHALLOW_CNOT3 ? q : (q & 1));
+      double sn, cs;
+      sincos(scale * ang, &sn, &cs);
+      {
+        const double c0[3] = {quad_bcast<0>(cs), quad_bcast<1>(cs), quad_bcast<2>(cs)};
+        const double s0[3] = {quad_bcast<0>(sn), quad_bcast<1>(sn), quad_bcast<2>(sn)};
+        ansatz_layer_cs<3, ANS>(reg, c0, s0);
+      }
+      if (trip == 4 && l + 2 + per <= P) {
+        const double c1[2] = {quad_bcast<2>(cs), quad_bcast<3>(cs)};
+        const double s1[2] = {quad_bcast<2>(sn), quad_bcast<3>(sn)};
+        ansatz_layer_cs<3, ANS>(reg, c1, s1);
+      }
+    }
+    // A[s][i][j = q] = amplitude[2 i + s]
+    double2* tile = (double2*)(lds + e * PAD);
+#pragma unroll
+    for (int xx = 0; xx < 8; ++xx) tile[((xx & 1) * 4 + (xx >> 1)) * 4 + q] = make_double2(reg.re[xx], reg.im[xx]);
+  } else {
     // HBM -> LDS: the wave's 16 tensors are one contiguous 8 KB slab, 16 B per lane per load
     const unsigned char* slab = (const unsigned char*)p.A + first * ROW;
     const int64_t slab_bytes = (p.B - first < ITEMS ? p.B - first : ITEMS) * (int64_t)ROW;
@@ -492,7 +542,15 @@ hipError_t launch_env_direct_d8(const void* A, void* r_out, int64_t B, hipStream
 
 hipError_t launch_energy_direct_d4(const LaneArgs& a, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
-  hipLaunchKernelGGL(energy_direct_d4_kernel, dim3((unsigned)((a.B + 15) / 16)), dim3(64), 0, st, a);
+  const dim3 grid((unsigned)((a.B + 15) / 16)), block(64);
+  if (a.ans_params == nullptr) hipLaunchKernelGGL(energy_direct_d4_kernel<-1>, grid, block, 0, st, a);
+  else
+    switch (a.ans_kind) {
+      case QMPS_ANSATZ_SHALLOW_CNOT: hipLaunchKernelGGL(energy_direct_d4_kernel<QMPS_ANSATZ_SHALLOW_CNOT>, grid, block, 0, st, a); break;
+      case QMPS_ANSATZ_SHALLOW_QAOA: hipLaunchKernelGGL(energy_direct_d4_kernel<QMPS_ANSATZ_SHALLOW_QAOA>, grid, block, 0, st, a); break;
+      case QMPS_ANSATZ_SHALLOW_CNOT3: hipLaunchKernelGGL(energy_direct_d4_kernel<QMPS_ANSATZ_SHALLOW_CNOT3>, grid, block, 0, st, a); break;
+      default: return hipErrorInvalidValue;
+    }
   return hipGetLastError();
 }
 

@@ -44,6 +44,12 @@ struct LaneArgs {
   double acc_scale;           // 2^k with acc_bound * 2^k <= 2^51
   double acc_bound;
   int acc_shards;             // power of two, waves per shard <= 60
+  // energy_direct_d4_kernel with the ansatz fused in front: the state tensor is built in LDS from
+  // ans_P parameters per evaluation (ans_kind = QMPS_ANSATZ_*) and never travels through HBM.  ans_nsh > 0: rotosolve
+  // shift batches - evaluation b = ans_nsh r + k evaluates restart r (parameter row r) with shift k added to parameter *ans_i
+  const double* ans_params;   // nullable [rows][ans_P]
+  const int* ans_i;           // device pointer to the index of the parameter being updated (ans_nsh > 0)
+  int ans_P, ans_kind, ans_nsh;
 };
 
 // D = 8 direct fixed-point solve, one wave per evaluation: writes the environments r[B][8][8] (the warm start / result
@@ -175,7 +181,7 @@ hipError_t launch_opt_env(const double* params, const void* h, double k, double*
 hipError_t launch_roto_shift(const double* base, double* out, int R, int P, const int* i_ptr, int nsh, hipStream_t st);
 hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int* i_ptr, int n_terms,
                               int nsh, hipStream_t st);
-hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, hipStream_t st);
+hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, const int* sweep_ptr, hipStream_t st);
 hipError_t launch_unitary_to_tensor(const void* U, void* A, int D, int64_t B, hipStream_t st);
 hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, int n_partial, double* cost,
                       hipStream_t st);

@@ -31,6 +31,7 @@
 
 #include "qmps_kernels.h"
 #include "qmps_device.h"
+#include "qmps_circuit.h"
 
 namespace qmps {
 
@@ -1728,221 +1729,7 @@ __global__ __launch_bounds__(256) void unitary_to_tensor_kernel(const double2* _
 //   kind 2: ShallowFullStateTensor   15 angles, two qubits (D = 2)
 //   kind 3: ShallowCNOTStateTensor3  per (beta, gamma, omega): rz, rx, rz all, H(q0), CNOT ladder
 // ------------------------------------------------------------------------------------------
-template <int NQ>
-struct Reg {
-  static constexpr int N = 1 << NQ;
-  double re[N], im[N];
-  __device__ __forceinline__ static constexpr int mask(int q) { return 1 << (NQ - 1 - q); }
-  // general single-qubit gate [[a, b], [c, d]] (complex) on qubit q
-  __device__ __forceinline__ void u2(int q, double ar, double ai, double br, double bi, double cr, double ci, double dr,
-                                     double di) {
-    const int m = mask(q);
-#pragma unroll
-    for (int x = 0; x < N; ++x)
-      if (!(x & m)) {
-        const double pr = re[x], pi = im[x], qr = re[x | m], qi = im[x | m];
-        re[x] = ar * pr - ai * pi + br * qr - bi * qi;
-        im[x] = ar * pi + ai * pr + br * qi + bi * qr;
-        re[x | m] = cr * pr - ci * pi + dr * qr - di * qi;
-        im[x | m] = cr * pi + ci * pr + dr * qi + di * qr;
-      }
-  }
-  __device__ __forceinline__ void rz(int q, double t) {
-    double s, c;
-    sincos(0.5 * t, &s, &c);
-    u2(q, c, -s, 0, 0, 0, 0, c, s);
-  }
-  __device__ __forceinline__ void rx(int q, double t) {
-    double s, c;
-    sincos(0.5 * t, &s, &c);
-    u2(q, c, 0, 0, -s, 0, -s, c, 0);
-  }
-  __device__ __forceinline__ void ry(int q, double t) {
-    double s, c;
-    sincos(0.5 * t, &s, &c);
-    u2(q, c, 0, -s, 0, s, 0, c, 0);
-  }
-  __device__ __forceinline__ void had(int q) {
-    const double h = 0.70710678118654752;
-    u2(q, h, 0, h, 0, h, 0, -h, 0);
-  }
-  __device__ __forceinline__ void xpow(int q, double t) {   // cirq.X**t = e^{i pi t/2} (cos I - i sin X)
-    double s, c, ps, pc;
-    sincos(1.5707963267948966 * t, &s, &c);
-    ps = s; pc = c;                                          // global phase e^{i pi t / 2} = (c + i s)
-    // (pc + i ps) * [[c, -i s], [-i s, c]]
-    const double dr = pc * c, di = ps * c;                   // diagonal
-    const double orr = ps * s, oi = -pc * s;                 // off-diagonal: (pc + i ps)(-i s) = ps s - i pc s
-    u2(q, dr, di, orr, oi, orr, oi, dr, di);
-  }
-  __device__ __forceinline__ void zzpow(int q1, int q2, double t) {   // diag(1, e, e, 1), e = e^{i pi t}
-    double s, c;
-    sincos(3.141592653589793 * t, &s, &c);
-    const int m1 = mask(q1), m2 = mask(q2);
-#pragma unroll
-    for (int x = 0; x < N; ++x)
-      if (((x & m1) != 0) != ((x & m2) != 0)) {
-        const double pr = re[x], pi = im[x];
-        re[x] = c * pr - s * pi;
-        im[x] = c * pi + s * pr;
-      }
-  }
-  // general single-qubit matrix m[2][2] (complex, row-major: re/im arrays)
-  __device__ __forceinline__ void u2m(int q, const double (&mr_)[4], const double (&mi_)[4]) {
-    u2(q, mr_[0], mi_[0], mr_[1], mi_[1], mr_[2], mi_[2], mr_[3], mi_[3]);
-  }
-  // general two-qubit matrix g[4][4] (complex) on qubits (q1, q2), q1 = more significant bit of the gate index
-  __device__ __forceinline__ void u4(int q1, int q2, const double (&gr)[16], const double (&gi)[16]) {
-    const int m1 = mask(q1), m2 = mask(q2);
-#pragma unroll
-    for (int x = 0; x < N; ++x)
-      if (!(x & m1) && !(x & m2)) {
-        const int idx[4] = {x, x | m2, x | m1, x | m1 | m2};
-        double pr[4], pi[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { pr[k] = re[idx[k]]; pi[k] = im[idx[k]]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          double xr = 0.0, xi = 0.0;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            xr = dfma(gr[a * 4 + k], pr[k], xr);
-            xr = dfma(-gi[a * 4 + k], pi[k], xr);
-            xi = dfma(gr[a * 4 + k], pi[k], xi);
-            xi = dfma(gi[a * 4 + k], pr[k], xi);
-          }
-          re[idx[a]] = xr;
-          im[idx[a]] = xi;
-        }
-      }
-  }
-  __device__ __forceinline__ void swapq(int q1, int q2) {
-    const int m1 = mask(q1), m2 = mask(q2);
-#pragma unroll
-    for (int x = 0; x < N; ++x)
-      if ((x & m1) && !(x & m2)) {
-        const int y = (x & ~m1) | m2;
-        const double pr = re[x], pi = im[x];
-        re[x] = re[y]; im[x] = im[y];
-        re[y] = pr; im[y] = pi;
-      }
-  }
-  // <psi| SWAP(q1,q2) |psi> (real: SWAP is Hermitian)
-  __device__ __forceinline__ double swap_expectation(int q1, int q2) const {
-    const int m1 = mask(q1), m2 = mask(q2);
-    double e = 0.0;
-#pragma unroll
-    for (int x = 0; x < N; ++x) {
-      const bool b1 = (x & m1) != 0, b2 = (x & m2) != 0;
-      const int y = (b1 == b2) ? x : (x ^ m1 ^ m2);
-      e = dfma(re[x], re[y], e);
-      e = dfma(im[x], im[y], e);
-    }
-    return e;
-  }
-  // reduced density matrix of qubit 0 (the most significant index bit): rho[a][b] = sum_rest psi[a, rest] conj(psi[b, rest])
-  __device__ __forceinline__ void rdm_q0(double (&rr)[2][2], double (&ri)[2][2]) const {
-    constexpr int H = N / 2;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        double xr = 0.0, xi = 0.0;
-#pragma unroll
-        for (int t = 0; t < H; ++t) {
-          xr = dfma(re[a * H + t], re[b * H + t], xr);
-          xr = dfma(im[a * H + t], im[b * H + t], xr);
-          xi = dfma(im[a * H + t], re[b * H + t], xi);
-          xi = dfma(-re[a * H + t], im[b * H + t], xi);
-        }
-        rr[a][b] = xr;
-        ri[a][b] = xi;
-      }
-  }
-  // ShallowFullStateTensor(2, v) (qmps/represent.py:393-401) on qubits (a, b)
-  __device__ __forceinline__ void shallow_full(int a, int b, const double* v) {
-    rz(a, v[0]); rx(a, v[1]); rz(a, v[2]);
-    rz(b, v[3]); rx(b, v[4]); rz(b, v[5]);
-    cnot(a, b);
-    ry(a, v[6]);
-    cnot(b, a);
-    ry(a, v[7]); rz(b, v[8]);
-    cnot(a, b);
-    rz(a, v[9]); rx(a, v[10]); rz(a, v[11]);
-    rz(b, v[12]); rx(b, v[13]); rz(b, v[14]);
-  }
-  // the same gate list with the half-angle cosines / sines already computed (one sincos per angle, whatever the number
-  // of circuits the gate appears in)
-  __device__ __forceinline__ void shallow_full_cs(int a, int b, const double* c, const double* s) {
-    u2(a, c[0], -s[0], 0, 0, 0, 0, c[0], s[0]); u2(a, c[1], 0, 0, -s[1], 0, -s[1], c[1], 0); u2(a, c[2], -s[2], 0, 0, 0, 0, c[2], s[2]);
-    u2(b, c[3], -s[3], 0, 0, 0, 0, c[3], s[3]); u2(b, c[4], 0, 0, -s[4], 0, -s[4], c[4], 0); u2(b, c[5], -s[5], 0, 0, 0, 0, c[5], s[5]);
-    cnot(a, b);
-    u2(a, c[6], 0, -s[6], 0, s[6], 0, c[6], 0);
-    cnot(b, a);
-    u2(a, c[7], 0, -s[7], 0, s[7], 0, c[7], 0); u2(b, c[8], -s[8], 0, 0, 0, 0, c[8], s[8]);
-    cnot(a, b);
-    u2(a, c[9], -s[9], 0, 0, 0, 0, c[9], s[9]); u2(a, c[10], 0, 0, -s[10], 0, -s[10], c[10], 0); u2(a, c[11], -s[11], 0, 0, 0, 0, c[11], s[11]);
-    u2(b, c[12], -s[12], 0, 0, 0, 0, c[12], s[12]); u2(b, c[13], 0, 0, -s[13], 0, -s[13], c[13], 0); u2(b, c[14], -s[14], 0, 0, 0, 0, c[14], s[14]);
-  }
-  __device__ __forceinline__ void reset() {
-#pragma unroll
-    for (int x = 0; x < N; ++x) { re[x] = (x == 0) ? 1.0 : 0.0; im[x] = 0.0; }
-  }
-  __device__ __forceinline__ void cnot(int ctrl, int tgt) {
-    const int mc = mask(ctrl), mt = mask(tgt);
-#pragma unroll
-    for (int x = 0; x < N; ++x)
-      if ((x & mc) && !(x & mt)) {
-        const double pr = re[x], pi = im[x];
-        re[x] = re[x | mt]; im[x] = im[x | mt];
-        re[x | mt] = pr; im[x | mt] = pi;
-      }
-  }
-};
-
-// The ansatz circuits on a register file of NQ qubits; `par(l)` returns angle l (HBM, LDS, shifted ... the caller's choice).
-template <int NQ, int KIND, class Par>
-__device__ __forceinline__ void ansatz_circuit(Reg<NQ>& r, Par par, int n_params) {
-  if (KIND == 0 || KIND == 3) {
-    const int per = (KIND == 0) ? 2 : 3;
-    for (int l = 0; l + per <= n_params; l += per) {
-      const double beta = par(l), gamma = par(l + 1);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) r.rz(q, beta);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) r.rx(q, gamma);
-      if (KIND == 3) {
-        const double omega = par(l + 2);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) r.rz(q, omega);
-      }
-      r.had(0);
-#pragma unroll
-      for (int q = NQ - 2; q >= 0; --q) r.cnot(q, q + 1);
-    }
-  } else if (KIND == 1) {
-    for (int l = 0; l + 2 <= n_params; l += 2) {
-      const double beta = par(l), gamma = par(l + 1);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) r.xpow(q, beta);
-#pragma unroll
-      for (int q = 0; q + 1 < NQ; ++q) r.zzpow(q, q + 1, gamma);
-    }
-  } else if (KIND == 2) {
-    if constexpr (NQ == 2) {
-      r.rz(0, par(0)); r.rx(0, par(1)); r.rz(0, par(2));
-      r.rz(1, par(3)); r.rx(1, par(4)); r.rz(1, par(5));
-      r.cnot(0, 1);
-      r.ry(0, par(6));
-      r.cnot(1, 0);
-      r.ry(0, par(7)); r.rz(1, par(8));
-      r.cnot(0, 1);
-      r.rz(0, par(9)); r.rx(0, par(10)); r.rz(0, par(11));
-      r.rz(1, par(12)); r.rx(1, par(13)); r.rz(1, par(14));
-    }
-  }
-}
-
+// (Reg<NQ>, ansatz_circuit, roto_shift_value: qmps_circuit.h)
 template <int D, int KIND>
 __global__ __launch_bounds__(64) void ansatz_tensor_kernel(const double* __restrict__ params, int n_params,
                                                            double2* __restrict__ A, int64_t B) {
@@ -1999,18 +1786,6 @@ hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, vo
 //   theta* = -pi/2 - atan2(2 e0 - e+ - e-, e+ - e-),  params[i] = wrap(params[i] + wrap(theta*))
 // runs on the device, so a whole sweep needs no host round trip.
 // ------------------------------------------------------------------------------------------
-// nsh = 3: shifts {0, +pi/2, -pi/2} (qmps/rotosolve.py:175);  nsh = 6: {0, pi, +-pi/2, +-pi/4} (qmps/tools.py:434-438)
-__device__ __forceinline__ double roto_shift_value(int nsh, int k) {
-  if (nsh == 3) return k == 0 ? 0.0 : (k == 1 ? 1.5707963267948966 : -1.5707963267948966);
-  switch (k) {
-    case 0: return 0.0;
-    case 1: return 3.141592653589793;
-    case 2: return 1.5707963267948966;
-    case 3: return -1.5707963267948966;
-    case 4: return 0.7853981633974483;
-    default: return -0.7853981633974483;
-  }
-}
 
 __global__ __launch_bounds__(256) void roto_shift_kernel(const double* __restrict__ base, double* __restrict__ out, int R,
                                                          int P, const int* __restrict__ i_ptr, int nsh) {
@@ -2108,17 +1883,21 @@ __global__ __launch_bounds__(256) void roto_update_kernel(double* __restrict__ b
   if (s_last && threadIdx.x == 0) {
     i_ptr[1] = 0;
     i_ptr[0] = (i + 1 == P) ? 0 : i + 1;             // every block has read *i_ptr before its arrival
+    if (i + 1 == P) i_ptr[2] += 1;                   // i_ptr[2]: sweeps finished (roto_record_kernel)
     __threadfence();
   }
 }
 
+// sweep_ptr (nullable): device counter of finished sweeps (advanced by the update kernel that wraps the parameter index):
+// the record of sweep n lands in hist[(n - 1) R ...], so ONE captured graph serves every sweep
 __global__ __launch_bounds__(256) void roto_record_kernel(const double* __restrict__ E, double* __restrict__ hist, int R,
-                                                          int n_terms) {
+                                                          int n_terms, const int* __restrict__ sweep_ptr) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   double v = 0.0;
   for (int q = 0; q < n_terms; ++q) v += E[(int64_t)r * n_terms + q];
-  hist[r] = v;
+  const int64_t sw = sweep_ptr != nullptr ? (int64_t)(*sweep_ptr - 1) : 0;
+  hist[sw * R + r] = v;
 }
 
 hipError_t launch_roto_shift(const double* base, double* out, int R, int P, const int* i_ptr, int nsh, hipStream_t st) {
@@ -2131,8 +1910,8 @@ hipError_t launch_roto_update(double* base, const double* E, const int32_t* stat
   hipLaunchKernelGGL(roto_update_kernel, dim3((R + 255) / 256), dim3(256), 0, st, base, E, status, R, P, i_ptr, n_terms, nsh);
   return hipGetLastError();
 }
-hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, hipStream_t st) {
-  hipLaunchKernelGGL(roto_record_kernel, dim3((R + 255) / 256), dim3(256), 0, st, E, hist, R, n_terms);
+hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, const int* sweep_ptr, hipStream_t st) {
+  hipLaunchKernelGGL(roto_record_kernel, dim3((R + 255) / 256), dim3(256), 0, st, E, hist, R, n_terms, sweep_ptr);
   return hipGetLastError();
 }
 

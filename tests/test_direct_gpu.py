@@ -286,3 +286,43 @@ def test_in_kernel_cost_on_the_other_kernels(D, B, engine_factory):
         with pytest.raises(QmpsError):
             eng.launch(B, solver='squaring', accumulate_cost=True)
     eng.set_solver('direct')
+
+
+@pytest.mark.parametrize('kind,P', [('cnot', 4), ('cnot', 6), ('qaoa', 4), ('cnot3', 6)])
+def test_ansatz_fused_in_front_of_the_solve(kind, P, engine_factory):
+    """at D = 4 the direct kernel builds the state tensor in LDS from the ansatz parameters (8 P bytes per
+    evaluation instead of 512) - same energies / environments as the tensors of the stand-alone builder, for whole
+    batches, windows into the resident parameters and ragged batch sizes; against the oracle's circuits."""
+    from qmps_amd import _lib
+    code = {'cnot': _lib.ANSATZ_SHALLOW_CNOT, 'qaoa': _lib.ANSATZ_SHALLOW_QAOA, 'cnot3': _lib.ANSATZ_SHALLOW_CNOT3}[kind]
+    build = {'cnot': O.shallow_cnot_unitary, 'qaoa': O.shallow_qaoa_unitary, 'cnot3': O.shallow_cnot3_unitary}[kind]
+    rng = np.random.default_rng(31)
+    B = 1000 + 7                                     # not a multiple of 16: the last wave is ragged
+    prm = rng.standard_normal((B, P))
+    h = np.stack([O.hamiltonian_matrix({'ZZ': -1, 'X': 1}), O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})])
+    eng = engine_factory(4, 2048)
+    eng.set_hamiltonian(h)
+    eng.set_ansatz_params(code, prm)
+    eng.launch(B, solver='direct', store_env=True)            # fused: no tensor has been built yet
+    E1, it1, st1 = eng.results(B)
+    r1 = eng.environments(B)
+    A = eng.tensors(B)                                         # materialised on demand by the stand-alone builder
+    for b in range(0, B, 83):
+        assert np.abs(A[b] - O.unitary_to_tensor(build(4, prm[b])[None])[0]).max() < 1e-14
+    # a window into the resident parameters
+    eng.set_window(496)
+    eng.launch(300, solver='direct', store_env=True)
+    Ew, itw, stw = eng.results(300)
+    assert np.array_equal(Ew, E1[496:796]) and np.array_equal(stw, st1[496:796])
+    eng.set_window(0)
+    # the same tensors through the HBM path
+    eng.set_tensors(A)
+    eng.launch(B, solver='direct', store_env=True)
+    E2, it2, st2 = eng.results(B)
+    r2 = eng.environments(B)
+    ok = (st1 == 0) & (st2 == 0)
+    assert np.array_equal(st1, st2) and ok.mean() > 0.9
+    assert np.abs(E1 - E2)[ok].max() < 1e-12 and np.abs(r1 - r2)[ok].max() < 1e-12
+    for b in np.flatnonzero(ok)[::97]:
+        for t in range(2):
+            assert abs(E1[b, t] - O.energy_closed_form(A[b], h[t])) < 1e-10

@@ -136,7 +136,12 @@ int qmps_set_states(qmps_ctx* ctx, int64_t B, const double* states, int kind);
 /* Ansatz parameters -> state tensors ON THE DEVICE (replaces gate construction + cirq.unitary,
  * qmps/ground_state.py:151-154, and unitary_to_tensor): params[B][n_params] float64.
  * Gate lists: qmps/represent.py:288-310 (ShallowCNOT, the optimisers' default), :268-285 (QAOA),
- * :382-404 (ShallowFull, D = 2, 15 angles), :334-354 (ShallowCNOT3). */
+ * :382-404 (ShallowFull, D = 2, 15 angles), :334-354 (ShallowCNOT3).
+ * The parameters stay resident.  At D = 4 (ShallowCNOT, QAOA, ShallowCNOT3) nothing else happens in this call: a
+ * following qmps_energy_launch with QMPS_ENV_DIRECT builds each tensor in LDS in front of the solve (lane q of the
+ * evaluation's quad simulates column q of the circuit) - 8 n_params bytes per evaluation from HBM instead of 512, no
+ * tensor ever written; the tensors are materialised in HBM only when something asks for them (qmps_get_states, the
+ * other solvers, qmps_energy_only_launch, the overlap objective).  Elsewhere the tensors are built here. */
 #define QMPS_ANSATZ_SHALLOW_CNOT 0
 #define QMPS_ANSATZ_SHALLOW_QAOA 1
 #define QMPS_ANSATZ_SHALLOW_FULL 2
@@ -147,7 +152,11 @@ int qmps_set_states_ansatz(qmps_ctx* ctx, int64_t B, int kind, int n_params, con
  * 0, +pi/2, -pi/2) - ansatz build, environment, energy - and the closed-form update all run on the device,
  * n_sweeps x n_params times, without a host round trip.  params[R][n_params] is updated in place;
  * E_hist[n_sweeps][R] receives the energy (summed over the resident Hamiltonian terms, like the
- * reference's M(x) = np.sum(eps)) after each sweep.  Needs 3 R <= max_batch and a Hamiltonian. */
+ * reference's M(x) = np.sum(eps)) after each sweep.  Needs 3 R <= max_batch and a Hamiltonian.
+ * A whole sweep (n_params updates, the evaluation of the updated vectors, its record) is ONE hipGraph launch.  D = 4
+ * with the direct solver: two kernels per parameter update - the energy kernel, which builds evaluation 3 r + k's
+ * tensor from restart r's parameters with shift k added to the parameter being updated, and the update kernel.
+ * D = 2: every sweep of every restart inside one kernel launch. */
 int qmps_rotosolve(qmps_ctx* ctx, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter,
                    double tol, double* E_hist);
 /* Device-resident DOUBLE-frequency rotosolve (qmps/tools.py:422-457, what Optimizer.optimize('Rotosolve') runs): per

@@ -1585,30 +1585,25 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
   if (!SOLVE && p.check_pd) status = p.status[b];
   if (SOLVE || p.check_pd) {
     if (status == QMPS_ST_OK) {
-      // Cholesky PD test by thread 0 on the LDS copy (D <= 16: <= 816 complex MACs)
-      __shared__ int s_pd;
-      if (tid == 0) {
-        bool ok = true;
-        for (int c = 0; c < D && ok; ++c) {
-          double d = sR[c][c].x;
-          for (int k = 0; k < c; ++k) d -= sT[1][c][k].x * sT[1][c][k].x + sT[1][c][k].y * sT[1][c][k].y;
-          if (!(d > 0.0)) { ok = false; break; }
-          const double ljj = __builtin_sqrt(d);
-          sT[1][c][c] = make_double2(ljj, 0.0);
-          for (int rI = c + 1; rI < D; ++rI) {
-            double cr = sR[rI][c].x, ci = sR[rI][c].y;
-            for (int k = 0; k < c; ++k) {
-              const double2 a = sT[1][rI][k], bb = sT[1][c][k];
-              cr -= a.x * bb.x + a.y * bb.y;
-              ci -= a.y * bb.x - a.x * bb.y;
-            }
-            sT[1][rI][c] = make_double2(cr / ljj, ci / ljj);
-          }
-        }
-        s_pd = ok ? 1 : 0;
+      // Positive definiteness (the criterion of cholesky(r), qmps/tools.py:182): the pivots of LDL^H, all D^2 threads at
+      // once - thread (i, j) owns the Schur-complement entry S[i][j]; per pivot one LDS round trip (column c and the pivot),
+      // S[i][j] -= S[i][c] conj(S[j][c]) / S[c][c].  (A single thread walking the Cholesky recurrence through LDS took
+      // ~6 us of the 22 us this kernel needs per evaluation at D = 8.)
+      double2 S = r;
+      bool ok = true;
+      for (int c = 0; c < D; ++c) {
+        __syncthreads();
+        sT[1][i][j] = S;
+        __syncthreads();
+        const double pc = sT[1][c][c].x;
+        ok = ok && (pc > 0.0);
+        const double2 li = sT[1][i][c], lj = sT[1][j][c];
+        const double inv = fast_rcp(pc);
+        const double wr = (li.x * lj.x + li.y * lj.y) * inv, wi = (li.y * lj.x - li.x * lj.y) * inv;
+        S.x -= wr;
+        S.y -= wi;
       }
-      __syncthreads();
-      if (!s_pd) status = QMPS_ST_NOT_PD;
+      if (!ok) status = QMPS_ST_NOT_PD;
       __syncthreads();
     }
   }
@@ -1662,29 +1657,44 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
         }
 #pragma unroll
         for (int s1 = 0; s1 < 2; ++s1) {
+          // this thread's share of rho[tau][sigma] (summed over the workgroup below)
           const double2 a = sA[s1][i][j];
-          const double pr = zr * a.x + zi * a.y;
-          const double pi = zi * a.x - zr * a.y;
-          const double sr = block_sum<D>(pr, red, tid);
-          const double si = block_sum<D>(pi, red, tid);
-          rho_loc[2 * t1 + t2][2 * s1 + s2] = make_double2(sr / trr, si / trr);
+          rho_loc[2 * t1 + t2][2 * s1 + s2] = make_double2(zr * a.x + zi * a.y, zi * a.x - zr * a.y);
         }
       }
     }
-  if (tid == 0) {
-    for (int q = 0; q < p.n_terms; ++q) {
-      const double2* h = (const double2*)p.h + q * 16;
-      double e = 0.0;
+  const double inv_tr = 1.0 / trr;
+  if (p.rho_out != nullptr) {
+    // the density matrix itself is wanted: 16 complex sums over the workgroup
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const double2 hv = h[s * 4 + t];
-          e += hv.x * rho_loc[t][s].x - hv.y * rho_loc[t][s].y;
-        }
+      for (int s = 0; s < 4; ++s) {
+        const double sr = block_sum<D>(rho_loc[t][s].x, red, tid);
+        const double si = block_sum<D>(rho_loc[t][s].y, red, tid);
+        rho_loc[t][s] = make_double2(sr * inv_tr, si * inv_tr);
+      }
+  }
+  for (int q = 0; q < p.n_terms; ++q) {
+    // E_q = Re sum h_q[s][t] rho[t][s] is linear in rho: combine the thread's shares first, ONE sum over the workgroup per
+    // term instead of 32 (with the density matrix already summed every thread holds the total: no sum at all)
+    const double2* h = (const double2*)p.h + q * 16;
+    double e = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double2 hv = h[s * 4 + t];
+        e = dfma(hv.x, rho_loc[t][s].x, e);
+        e = dfma(-hv.y, rho_loc[t][s].y, e);
+      }
+    if (p.rho_out == nullptr) e = block_sum<D>(e, red, tid) * inv_tr;
+    if (tid == 0) {
       p.E[b * p.n_terms + q] = e;
       if (p.acc != nullptr) acc_arrive(p.acc, p.acc_shards, q, (unsigned)b, e, p.acc_bound, p.acc_scale);   // exact in-kernel cost
     }
+  }
+  if (tid == 0) {
     if (SOLVE) {
       p.iters[b] = iters;
       p.status[b] = status;

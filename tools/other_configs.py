@@ -38,12 +38,13 @@ def run(D, B, solver, reps=200):
                 'mean_iters': float(it.mean()), 'not_ok': int((st != 0).sum())}
 
 
-out = []
-for D, B, solver in ((2, 4096, 'squaring'), (2, 65536, 'squaring'),
-                     (8, 96, 'direct'), (8, 768, 'direct'), (8, 65536, 'direct'),
-                     (8, 96, 'plain'), (8, 768, 'plain'), (8, 65536, 'plain'),
-                     (16, 96, 'squaring'), (16, 768, 'squaring'), (16, 16384, 'squaring'),
-                     (4, 4096, 'direct'), (4, 65536, 'direct'), (4, 65536, 'squaring')):
-    r = run(D, B, solver, reps=200 if B <= 4096 else 30)
-    out.append(r)
-    print(json.dumps(r), flush=True)
+if __name__ == '__main__':
+    out = []
+    for D, B, solver in ((2, 4096, 'squaring'), (2, 65536, 'squaring'),
+                         (8, 96, 'direct'), (8, 768, 'direct'), (8, 65536, 'direct'),
+                         (8, 96, 'plain'), (8, 768, 'plain'), (8, 65536, 'plain'),
+                         (16, 96, 'squaring'), (16, 768, 'squaring'), (16, 16384, 'squaring'),
+                         (4, 4096, 'direct'), (4, 65536, 'direct'), (4, 65536, 'squaring')):
+        r = run(D, B, solver, reps=200 if B <= 4096 else 30)
+        out.append(r)
+        print(json.dumps(r), flush=True)

@@ -376,12 +376,81 @@ def main_overlap(args):
         dist.destroy_process_group()
 
 
+def main_rotosolve(args):
+    """--workload rotosolve: the caller that produces the batch (qmps/rotosolve.py:154-181,
+    qmps/tools.py:422-457).  R restarts of the optimisers' default ansatz (ShallowCNOTStateTensor, depth log2(D)) in
+    lock-step; one step = one SWEEP of the device-resident rotosolve (every parameter once: shifted batches of 3 R
+    evaluations - ansatz, environment, energy - and the closed-form updates), --batch = 3 R evaluations per parameter
+    update.  `value` counts the energy evaluations the optimiser consumed per second.  Replicas only at N > 1."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    D = args.D
+    nsh = 6 if args.double_frequency else 3
+    R = max(1, args.batch // nsh)
+    depth = {2: 1, 4: 2, 8: 3, 16: 4}[D]
+    P = 2 * depth
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from qmps_amd import EnergyEngine, _lib
+    eng = EnergyEngine(D, nsh * R, device=local_rank)
+    info = _lib.device_info(local_rank)
+    eng.set_hamiltonian(tfim_h(1.0))
+    p0 = np.random.default_rng(args.seed + rank).standard_normal((R, P))
+    run = eng.double_rotosolve if args.double_frequency else eng.rotosolve
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        eng.probe_fp64_tflops()
+    sweeps_w = max(1, min(args.warmup, 64))
+    sweeps = max(1, min(args.steps, 256))
+    run(_lib.ANSATZ_SHALLOW_CNOT, p0, sweeps_w, max_iter=args.max_iter, tol=args.tol)
+    eng.sync()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    hist, pfin = run(_lib.ANSATZ_SHALLOW_CNOT, p0, sweeps, max_iter=args.max_iter, tol=args.tol)
+    eng.sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        evals = sweeps * (P * nsh * R + R)          # shifted batches + the evaluation recorded after each sweep
+        out = {'metric': f'rotosolve energy evals/sec at D={D}, {R} restarts x {nsh} shifts', 'value': world * evals / elapsed,
+               'unit': 'two-site energy evals/s', 'n_gpus': world, 'steps': sweeps, 'warmup': sweeps_w,
+               'ms_per_step': elapsed / sweeps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f64', 'data': 'synthetic',
+               'config': {'workload': f'device-resident {"double-frequency " if nsh == 6 else ""}rotosolve, TFIM g=1, D={D}, ShallowCNOT depth {depth} '
+                                      f'({P} parameters), {R} restarts x {nsh} shifts = {nsh * R} evaluations per parameter update, one step = one sweep; '
+                                      'the whole run is ONE C call (fixed costs - allocation, graph capture, copies - included)',
+                          'baseline_config': 'BASELINE.json configs[1] (D = 2) / configs[2] (D = 4)', 'D': D, 'restarts': R, 'shifts': nsh,
+                          'n_params': P, 'us_per_parameter_update': elapsed / (sweeps * P) * 1e6,
+                          'best_energy': float(np.nanmin(hist[-1])), 'mean_energy_first_sweep': float(np.nanmean(hist[0])),
+                          'mean_energy_last_sweep': float(np.nanmean(hist[-1])), 'exact_ground_state_energy': -4 / np.pi,
+                          'collective': 'none: independent restarts (replicas only)', 'device': info['name'], 'arch': info['arch']},
+               'roofline': None, 'cpu_baseline': None}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--workload', choices=['energy', 'overlap'], default='energy',
+    ap.add_argument('--workload', choices=['energy', 'overlap', 'rotosolve'], default='energy',
                     help="'energy' = the headline (two-site energy evaluations, BASELINE.json configs[2]); 'overlap' = the time-evolution "
-                         'overlap objective (configs[4]; use with --D 16 --batch 768)')
+                         "overlap objective (configs[4]; use with --D 16 --batch 768); 'rotosolve' = sweeps of the device-resident optimiser loop "
+                         '(--steps = sweeps, --batch = evaluations per parameter update)')
+    ap.add_argument('--double-frequency', action='store_true', help='rotosolve workload: six shifts per parameter (qmps/tools.py:422-457)')
     # defaults: the chip needs tens of ms of sustained load before its clocks settle (DESIGN.md section 5)
     ap.add_argument('--steps', type=int, default=450)
     ap.add_argument('--warmup', type=int, default=450)
@@ -418,6 +487,10 @@ def main():
         if args.max_iter == 10000:
             args.max_iter = 60 if args.D in (2, 4) else 100000      # D = 2, 4: squarings; D = 8, 16: power steps
         return main_overlap(args)
+    if args.workload == 'rotosolve':
+        if args.steps == 450:
+            args.steps, args.warmup = 160, 8
+        return main_rotosolve(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -689,6 +689,36 @@ def main():
             'working_set_mib': R * B * 48 * D * D / 2 ** 20,
             'what': f'qmps_energy_only_launch (no environment solve) cycled over the {R} resident batches; reads tensor + environment '
                     f'({48 * D * D + 8} B per evaluation); the {bytes_per_eval(D)} B figure is SURVEY 8(d)\'s accounting'}
+        if direct:
+            # warm start ("reachable only for small K (warm-started environments)"): every evaluation finds its
+            # converged environment resident, passes the acceptance test and skips the matrix build and the elimination
+            eng.set_tensors(A_all)
+            for k in range(R):
+                eng.set_window(k * B)
+                eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver='direct', store_env=True)
+            def warm_step(k):
+                eng.set_window((k % R) * B)
+                eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver='direct', store_env=False, accumulate_cost=True, warm_start=True)
+                eng.cost_launch(B)
+            for k in range(3 * R):
+                warm_step(k)
+            eng.sync()
+            n_w = max(90, 10 * R)
+            eng.timer_begin()
+            for k in range(n_w):
+                warm_step(k)
+            us_w = eng.timer_end() / n_w * 1e3
+            _, it_w, st_w = eng.results(B)
+            eng.set_window(0)
+            extras['warm_start'] = {
+                'us_per_step': us_w, 'evals_per_s': B / (us_w * 1e-6), 'accepted_fraction': float((it_w == 1).mean()),
+                'not_converged_or_not_pd': int((st_w != 0).sum()),
+                'hbm_gbps_520B': B * bytes_per_eval(D) / (us_w * 1e-6) * 1e-9, 'hbm_frac_520B': B * bytes_per_eval(D) / (us_w * 1e-6) * 1e-9 / HBM_PEAK_GBPS,
+                'hbm_gbps_tensor_plus_env': B * (48 * D * D + 8) / (us_w * 1e-6) * 1e-9,
+                'hbm_frac_tensor_plus_env': B * (48 * D * D + 8) / (us_w * 1e-6) * 1e-9 / HBM_PEAK_GBPS,
+                'flops_per_eval': 1920 + 5040, 'working_set_mib': R * B * 48 * D * D / 2 ** 20,
+                'what': 'QMPS_FLAG_WARM_RESIDENT: the resident (converged) environment of every evaluation is accepted by one power step; '
+                        f'no matrix build, no elimination; reads tensor + environment ({48 * D * D + 8} B per evaluation), cycled over the {R} resident batches'}
     if dist is not None and rccl_ok and not args.no_extras and args.exchange_every == 1:
         # the grouped exchange (16 steps' costs per all-reduce) as an extra, every rank takes part
         eng.set_tensors(A_all)

@@ -93,13 +93,19 @@ extern "C" {
  * exact and independent of the order the waves finish in.  The qmps_cost_launch(B) that follows consumes it WITHOUT
  * launching a reduction kernel, and - with a communicator - without any event on the compute stream: the one-wave
  * conversion kernel in front of the all-reduce runs on the COMMUNICATION stream and polls the arrival counts (a bounded
- * number of sweeps; it cannot hang).  Measured at world size 1: 30.2 us per step with an exchange per step against
- * 28.3 us without a communicator - and 41.3 us when the exchange was ordered by an event on the compute stream.
+ * number of sweeps; it cannot hang).  Measured at world size 1: 28.7-29.1 us per step with an exchange per step against
+ * 28.5 us without a communicator - and 41.3 us when the exchange was ordered by an event on the compute stream.
  * Partial sums beyond the isometric bound 16 ||h||_F (tensors that are not isometries, NaN) are added to a double
  * instead.  Contract: the next call that launches must be qmps_cost_launch with the same B and window; a second
  * accumulating launch before that fails with QMPS_ERR_STATE.  At most 2048 x 60 arrivals per launch (1.9 M evaluations
  * at D = 4 direct, 7.8 M on the lane kernels, 122 880 at D = 8, 16). */
 #define QMPS_FLAG_ACCUMULATE_COST 0x200
+/* QMPS_FLAG_WARM_RESIDENT: start from the RESIDENT environments (left by an earlier launch that stored them, or by
+ * qmps_set_env_guess) - the device-side form of the warm start, no host round trip.  With QMPS_ENV_DIRECT at D = 4 an
+ * evaluation whose resident environment passes the acceptance test (one power step moves it by less than tol) skips the
+ * matrix build and the elimination altogether (iterations = 1; ~7 instead of 15 kflop); the others are solved as usual
+ * (iterations = 2: the rejected step + the solve's acceptance step).  The iterative solvers start their iteration from it. */
+#define QMPS_FLAG_WARM_RESIDENT 0x400
 /* With handoff == 0 (squaring from the start) the iterate is not tracked during the first
  * QMPS_SKIP_ROUNDS_D* squarings (no state converges in fewer than 2^skip power steps); the first
  * convergence test compares T^(2^(skip+1)) r_0 with T^(2^skip) r_0. */

@@ -22,6 +22,7 @@ ENV_POWER_SQUARING = 1
 ENV_DIRECT = 2
 FLAG_NO_ENV_OUT = 0x100
 FLAG_ACCUMULATE_COST = 0x200
+FLAG_WARM_RESIDENT = 0x400
 UNIQUE_ID_BYTES = 128
 
 _dp = POINTER(c_double)

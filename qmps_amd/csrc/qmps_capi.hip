@@ -691,7 +691,9 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   int solver = flags & 0xff;
   if (solver != QMPS_ENV_POWER && solver != QMPS_ENV_POWER_SQUARING && solver != QMPS_ENV_DIRECT)
     return fail(QMPS_ERR_ARG, "unknown environment solver %d", solver);
-  if ((flags & ~0xff) & ~(QMPS_FLAG_NO_ENV_OUT | QMPS_FLAG_ACCUMULATE_COST)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags & ~0xff);
+  if ((flags & ~0xff) & ~(QMPS_FLAG_NO_ENV_OUT | QMPS_FLAG_ACCUMULATE_COST | QMPS_FLAG_WARM_RESIDENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags & ~0xff);
+  const bool warm_resident = (flags & QMPS_FLAG_WARM_RESIDENT) != 0;
+  if (warm_resident && !c->have_env) return fail(QMPS_ERR_STATE, "QMPS_FLAG_WARM_RESIDENT: no resident environments (run a launch that stores them, or qmps_set_env_guess)");
   const bool direct = solver == QMPS_ENV_DIRECT && c->D == 4;
   if ((flags & QMPS_FLAG_NO_ENV_OUT) && !direct) return fail(QMPS_ERR_ARG, "QMPS_FLAG_NO_ENV_OUT needs QMPS_ENV_DIRECT at D = 4");
   const bool accumulate = (flags & QMPS_FLAG_ACCUMULATE_COST) != 0;
@@ -707,6 +709,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   if (!fused)
     if (int rc = ensure_tensors(c)) return rc;
   qmps::LaneArgs a = make_args(c, B, max_iter, tol, true);
+  if (warm_resident) a.r_in = win_r(c);
   if (direct8) {
     // D = 8: the direct solve (one wave per evaluation) leaves its result in the environment buffer; the power
     // iteration of the block kernel starts from it: its first step is the acceptance test, its loop the fall-back
@@ -721,7 +724,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   if (direct) {
     // D = 4: direct fixed-point solve + acceptance power step + energies in ONE kernel (a DPP quad per evaluation);
     // one read of A, one store of E (and, unless switched off, of r) per evaluation
-    a.r_in = nullptr;
+    // a.r_in (qmps_set_env_guess / QMPS_FLAG_WARM_RESIDENT): evaluations whose guess passes the acceptance test skip the solve
     a.r_out = (flags & QMPS_FLAG_NO_ENV_OUT) ? nullptr : win_r(c);
     if (fused) {
       const double* rows = c->ans_src ? c->ans_src : c->d_params;
@@ -739,7 +742,8 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
     if (c->timed) c->samples++;
     if (!c->capturing) c->launches++;
-    c->have_env = a.r_out != nullptr;
+    if (a.r_out != nullptr) c->have_env = true;
+    else if (a.r_in == nullptr) c->have_env = false;      // (a warm launch that stores nothing leaves the resident guesses in place)
     return QMPS_OK;
   }
   if (c->D == 16 && !getenv("QMPS_D16_BLOCK")) {

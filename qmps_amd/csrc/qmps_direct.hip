@@ -199,7 +199,7 @@ __device__ __forceinline__ void squaring_fallback(const unsigned char* tiles, in
 // ANS = -1: tensors from HBM;  ANS = QMPS_ANSATZ_* (0, 1, 3): the tensor is built in LDS from the evaluation's ansatz
 // parameters - lane q of the quad simulates the three-qubit circuit on the basis state |0>|q>, i.e. column q of the
 // unitary, which is all unitary_to_tensor keeps (qmps/tools.py:151-154) - 8 P bytes per evaluation instead of 512.
-template <int ANS>
+template <int ANS, bool WARM>
 __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_kernel(LaneArgs p) {
   using Core = DirectD4<QuadOps>;
   constexpr int ROW = 512, PAD = ROW + 16, ITEMS = 16;
@@ -287,24 +287,54 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
   double x[4], us[16];
   double steps = 1.0;
   int status = QMPS_ST_OK;
-  {
-    double Rc[4][16], y[4];
-    Core::build(o, Rc);
-    __builtin_amdgcn_sched_barrier(0);     // phase by phase: keeps the operand reads of later phases out of the register file
-    Core::solve(o, Rc, x);
-    __builtin_amdgcn_sched_barrier(0);
+  bool have = false;            // WARM: the evaluation's resident environment passed the acceptance test as it is
+  if constexpr (WARM) {
+    // Warm start (environments carried over between evaluations of unchanged / barely changed tensors): one
+    // power step from r_in; what it moves by less than tol IS the fixed point to the solvers' criterion - no matrix build,
+    // no elimination (7 of the 15 kflop).  The rest of the wave's evaluations go through the direct solve below.
+    const double2* rin = (const double2*)p.r_in + (valid ? b : 0) * 16;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const double2 rw = rin[q * 4 + l], cl = rin[l * 4 + q];       // r[q][l], r[l][q]
+      x[l] = q <= l ? rw.x : cl.y;                                   // Re r[q][l] (q <= l) | Im r[l][q] (q > l)
+    }
     Core::normalise(o, x);
     Core::gather(x, us);
+    double y[4];
     const double d2 = Core::power_step(o, x, us, y);
+    have = valid && d2 < tol2;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) x[l] = have ? y[l] : x[l];
     __builtin_amdgcn_sched_barrier(0);
-    const bool todo = valid && !(d2 < tol2);     // NaN (a zero pivot) lands here too
+  }
+  if (!WARM || __any(valid && !have)) {
+    double Rc[4][16], xs[4], y[4];
+    Core::build(o, Rc);
+    __builtin_amdgcn_sched_barrier(0);     // phase by phase: keeps the operand reads of later phases out of the register file
+    Core::solve(o, Rc, xs);
+    __builtin_amdgcn_sched_barrier(0);
+    Core::normalise(o, xs);
+    Core::gather(xs, us);
+    const double d2 = Core::power_step(o, xs, us, y);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!have) {
+#pragma unroll
+      for (int l = 0; l < 4; ++l) x[l] = xs[l];
+      if (WARM) steps = 2.0;               // the rejected warm step + the acceptance step of the solve
+    }
+    const bool todo = valid && !have && !(d2 < tol2);     // NaN (a zero pivot) lands here too
     if (__any(todo)) {
       // rare: not an isometry / degenerate transfer spectrum.  Wave-uniform branch, one evaluation at a time.
       bool left = false;
       squaring_fallback(lds, PAD, sq_img, lane, todo, p.max_iter - 1, tol2, x, steps, left);
-      if (todo) status = left ? QMPS_ST_NOT_CONVERGED : QMPS_ST_OK;
-      Core::gather(x, us);
+      if (todo) {
+        status = left ? QMPS_ST_NOT_CONVERGED : QMPS_ST_OK;
+        if (WARM) steps += 1.0;
+      }
     }
+    if (WARM || __any(todo)) Core::gather(x, us);
+  } else {
+    Core::gather(x, us);
   }
   __builtin_amdgcn_sched_barrier(0);
 
@@ -641,14 +671,25 @@ hipError_t launch_env_direct_d8(const void* A, void* r_out, int64_t B, hipStream
 hipError_t launch_energy_direct_d4(const LaneArgs& a, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
   const dim3 grid((unsigned)((a.B + 15) / 16)), block(64);
-  if (a.ans_params == nullptr) hipLaunchKernelGGL(energy_direct_d4_kernel<-1>, grid, block, 0, st, a);
-  else
+  const bool warm = a.r_in != nullptr;
+  if (a.ans_params == nullptr) {
+    if (warm) hipLaunchKernelGGL((energy_direct_d4_kernel<-1, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((energy_direct_d4_kernel<-1, false>), grid, block, 0, st, a);
+  } else if (warm) {
     switch (a.ans_kind) {
-      case QMPS_ANSATZ_SHALLOW_CNOT: hipLaunchKernelGGL(energy_direct_d4_kernel<QMPS_ANSATZ_SHALLOW_CNOT>, grid, block, 0, st, a); break;
-      case QMPS_ANSATZ_SHALLOW_QAOA: hipLaunchKernelGGL(energy_direct_d4_kernel<QMPS_ANSATZ_SHALLOW_QAOA>, grid, block, 0, st, a); break;
-      case QMPS_ANSATZ_SHALLOW_CNOT3: hipLaunchKernelGGL(energy_direct_d4_kernel<QMPS_ANSATZ_SHALLOW_CNOT3>, grid, block, 0, st, a); break;
+      case QMPS_ANSATZ_SHALLOW_CNOT: hipLaunchKernelGGL((energy_direct_d4_kernel<QMPS_ANSATZ_SHALLOW_CNOT, true>), grid, block, 0, st, a); break;
+      case QMPS_ANSATZ_SHALLOW_QAOA: hipLaunchKernelGGL((energy_direct_d4_kernel<QMPS_ANSATZ_SHALLOW_QAOA, true>), grid, block, 0, st, a); break;
+      case QMPS_ANSATZ_SHALLOW_CNOT3: hipLaunchKernelGGL((energy_direct_d4_kernel<QMPS_ANSATZ_SHALLOW_CNOT3, true>), grid, block, 0, st, a); break;
       default: return hipErrorInvalidValue;
     }
+  } else {
+    switch (a.ans_kind) {
+      case QMPS_ANSATZ_SHALLOW_CNOT: hipLaunchKernelGGL((energy_direct_d4_kernel<QMPS_ANSATZ_SHALLOW_CNOT, false>), grid, block, 0, st, a); break;
+      case QMPS_ANSATZ_SHALLOW_QAOA: hipLaunchKernelGGL((energy_direct_d4_kernel<QMPS_ANSATZ_SHALLOW_QAOA, false>), grid, block, 0, st, a); break;
+      case QMPS_ANSATZ_SHALLOW_CNOT3: hipLaunchKernelGGL((energy_direct_d4_kernel<QMPS_ANSATZ_SHALLOW_CNOT3, false>), grid, block, 0, st, a); break;
+      default: return hipErrorInvalidValue;
+    }
+  }
   return hipGetLastError();
 }
 

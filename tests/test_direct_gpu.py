@@ -326,3 +326,59 @@ def test_ansatz_fused_in_front_of_the_solve(kind, P, engine_factory):
     for b in np.flatnonzero(ok)[::97]:
         for t in range(2):
             assert abs(E1[b, t] - O.energy_closed_form(A[b], h[t])) < 1e-10
+
+
+def test_warm_start_from_resident_environments(engine_factory):
+    """environments carried over between evaluations.  An evaluation whose resident environment passes the
+    acceptance test (one power step moves it by less than tol) skips the matrix build and the elimination (iterations 1);
+    a stale environment is rejected and the evaluation solved from scratch (iterations 2) - same energies either way."""
+    rng = np.random.default_rng(41)
+    B = 2000 + 5
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 8, B))
+    A2 = O.unitary_to_tensor(O.haar_unitaries(rng, 8, B))
+    h = np.stack([O.hamiltonian_matrix({'ZZ': -1, 'X': 1}), O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})])
+    eng = engine_factory(4, 4096)
+    eng.set_hamiltonian(h)
+    eng.set_tensors(A)
+    eng.launch(B, solver='direct', store_env=True)
+    E0, it0, st0 = eng.results(B)
+    r0 = eng.environments(B)
+    assert np.all(st0 == 0) and np.all(it0 == 1)
+    # (1) unchanged tensors, resident environments: every evaluation takes the fast path
+    eng.launch(B, solver='direct', store_env=True, warm_start=True)
+    E1, it1, st1 = eng.results(B)
+    assert np.all(st1 == 0) and np.all(it1 == 1)
+    assert np.abs(E1 - E0).max() < 1e-12 and np.abs(eng.environments(B) - r0).max() < 1e-12
+    # ... also without storing anything, and summed inside the kernel
+    eng.launch(B, solver='direct', store_env=False, accumulate_cost=True, warm_start=True)
+    eng.cost_launch(B)
+    acc = eng.get_cost()
+    E1b, _, _ = eng.results(B)
+    assert np.abs(E1b - E1).max() < 1e-13 and np.allclose(acc, E1b.sum(0), rtol=0, atol=1e-9)
+    # (2) half of the tensors replaced: their resident environments are stale -> solved from scratch, the others accepted
+    mix = A.copy()
+    mix[::2] = A2[::2]
+    eng.set_tensors(mix)            # (keeps the resident environments: they are the guess)
+    eng.set_env_guess(r0)
+    eng.launch(B, solver='direct', store_env=True)          # a guess set by the host is used the same way
+    E2, it2, st2 = eng.results(B)
+    assert np.all(st2 == 0) and np.all(it2[1::2] == 1) and np.all(it2[::2] == 2)
+    eng.set_tensors(mix)
+    eng.launch(B, solver='direct', store_env=True)
+    Ec, itc, stc = eng.results(B)
+    assert np.all(itc == 1) and np.abs(E2 - Ec).max() < 1e-12
+    # (3) a guess of a different trace / not Hermitian-exact is normalised; garbage is rejected, never believed
+    eng.set_tensors(A)
+    junk = r0 * 3.7
+    junk[5] = np.eye(4) * 0.25
+    junk[6] = np.nan
+    eng.set_env_guess(junk)
+    eng.launch(B, solver='direct', store_env=True)
+    E3, it3, st3 = eng.results(B)
+    assert np.all(st3 == 0) and it3[5] == 2 and it3[6] == 2 and np.all(np.delete(it3, [5, 6]) == 1)
+    assert np.abs(E3 - E0).max() < 1e-12
+    # (4) the flag without resident environments is an error, not a silent cold start
+    eng.set_tensors(A)
+    eng.launch(B, solver='direct', store_env=False)
+    with pytest.raises(Exception):
+        eng.launch(B, solver='direct', warm_start=True)

@@ -243,7 +243,11 @@ int setup_accumulator(qmps_ctx* c, qmps::LaneArgs& a, int64_t B, int64_t adds, i
   // a slot of the ring is touched again only after its previous exchange has finished.  Asked on the HOST (that
   // exchange, kCostSlots - 2 groups ago, has normally finished long ago): a stream wait would put a barrier packet
   // on the compute stream in every step (+4 us measured), and the compute stream carries no event either
-  static const bool dbg_nohostwait = getenv("QMPS_DBG_NOHOSTWAIT") != nullptr;   // timing experiments only
+#ifdef QMPS_DEBUG_KNOBS
+  static const bool dbg_nohostwait = getenv("QMPS_DBG_NOHOSTWAIT") != nullptr;   // timing dissection only (unsafe slot reuse)
+#else
+  constexpr bool dbg_nohostwait = false;
+#endif
   if (c->comm && !dbg_nohostwait && c->groups + 2 >= qmps_ctx::kCostSlots && hipEventQuery(c->cost_reduced[nslot]) != hipSuccess) {
     (void)hipGetLastError();
     HIP_TRY(hipEventSynchronize(c->cost_reduced[nslot]));
@@ -1323,9 +1327,12 @@ int close_group(qmps_ctx* c) {
   const int slot = (int)(c->groups % qmps_ctx::kCostSlots);
   double* base = c->d_cost_ring + (size_t)slot * qmps_ctx::kMaxGroup * kMaxTerms;
   if (c->comm) {
+#ifdef QMPS_DEBUG_KNOBS   // timing dissections only (they produce WRONG costs): compiled in with -DQMPS_DEBUG_KNOBS, never in the shipped library
     static const bool dbg_noevent = getenv("QMPS_DBG_NOEVENT") != nullptr, dbg_noar = getenv("QMPS_DBG_NOAR") != nullptr,
-                      dbg_nofinish = getenv("QMPS_DBG_NOFINISH") != nullptr,   // timing experiments only (wrong results)
-                      dbg_nopoll = getenv("QMPS_DBG_NOPOLL") != nullptr;
+                      dbg_nofinish = getenv("QMPS_DBG_NOFINISH") != nullptr, dbg_nopoll = getenv("QMPS_DBG_NOPOLL") != nullptr;
+#else
+    constexpr bool dbg_noevent = false, dbg_noar = false, dbg_nofinish = false, dbg_nopoll = false;
+#endif
     // positions whose cost lives in a fixed-point accumulator need no ordering on the compute stream: their finish
     // kernel polls the arrival counts.  Only costs written by reduction kernels on the compute stream need the event.
     bool need_event = false;

@@ -519,6 +519,14 @@ def main():
 
     dist = None
     force_dist = os.environ.get('QMPS_BENCH_FORCE_DIST') == '1'   # exercise the N > 1 code path at world_size 1
+    rccl_env = {}
+    if world > 1 or force_dist:
+        # The exchange is 128 bytes per step and must not take compute-unit slots from the energy kernel (two of its waves
+        # fill a SIMD's registers to 480 of 512: any resident RCCL wave displaces one): one channel,
+        # and not the many-channel MSCCL small-message algorithms.  Defaults only - an exported value wins.
+        for k, v in (('NCCL_MAX_NCHANNELS', '1'), ('RCCL_MSCCL_ENABLE', '0'), ('RCCL_MSCCLPP_ENABLE', '0')):
+            os.environ.setdefault(k, v)
+            rccl_env[k] = os.environ[k]
     if world > 1 or force_dist:
         import torch.distributed as dist  # launcher plumbing only (gloo, CPU)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -559,7 +567,7 @@ def main():
         if rccl_ok:
             ex = max(1, min(16, args.exchange_every))
             eng.set_exchange_period(ex)
-            collective = (f'RCCL communicator of {eng.comm_count()} ranks (ncclCommCount); ' +
+            collective = (f'RCCL communicator of {eng.comm_count()} ranks (ncclCommCount; {", ".join(k + "=" + v for k, v in rccl_env.items())}); ' +
                           ('one all-reduce(sum, f64[16]) per step' if ex == 1 else
                            f'one all-reduce(sum, f64[{ex} x 16]) per {ex} steps: every step\'s summed cost is reduced once, {ex} of them per message'))
         else:

@@ -367,6 +367,10 @@ def env_direct(A, tol=1e-13, max_iter=10000):
             rn = (rn + rn.conj().T) / 2
             rn = rn / np.trace(rn).real
             ok = bool(float((np.abs(rn - r) ** 2).sum()) < tol * tol)
+            # a fixed point that is not unique (degenerate dominant eigenvalue) makes the system singular to rounding: ANY
+            # fixed point passes the step above; the kernels hand such evaluations (a pivot below 1e-10) to the power method
+            if ok and np.linalg.svd(M, compute_uv=False)[-1] < 1e-10:
+                ok = False
         except np.linalg.LinAlgError:
             ok = False
     if ok:

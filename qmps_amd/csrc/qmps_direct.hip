@@ -59,6 +59,12 @@ struct QuadOps {
 #endif
   }
   static __device__ __forceinline__ V qsum(V v) { return quad_sum(v); }
+  static __device__ __forceinline__ V qmax(V v) {
+    v = fmax(v, quad_perm<0xB1>(v));
+    return fmax(v, quad_perm<0x4E>(v));
+  }
+  static __device__ __forceinline__ V vabs(V v) { return fabs(v); }
+  static __device__ __forceinline__ V vmax(V a, V b) { return fmax(a, b); }
   static __device__ __forceinline__ V sel(P p, V a, V b) { return p ? a : b; }
   static __device__ __forceinline__ V splat(double x) { return x; }
   static __device__ __forceinline__ V fma(V a, V b, V c) { return dfma(a, b, c); }
@@ -311,18 +317,20 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
     double Rc[4][16], xs[4], y[4];
     Core::build(o, Rc);
     __builtin_amdgcn_sched_barrier(0);     // phase by phase: keeps the operand reads of later phases out of the register file
-    Core::solve(o, Rc, xs);
+    double pivmax;
+    Core::solve(o, Rc, xs, pivmax);
     __builtin_amdgcn_sched_barrier(0);
     Core::normalise(o, xs);
     Core::gather(xs, us);
     const double d2 = Core::power_step(o, xs, us, y);
     __builtin_amdgcn_sched_barrier(0);
+    const bool accepted = d2 < tol2 && pivmax < Core::kMaxInversePivot;     // NaN (a zero pivot) fails both
     if (!have) {
 #pragma unroll
       for (int l = 0; l < 4; ++l) x[l] = xs[l];
       if (WARM) steps = 2.0;               // the rejected warm step + the acceptance step of the solve
     }
-    const bool todo = valid && !have && !(d2 < tol2);     // NaN (a zero pivot) lands here too
+    const bool todo = valid && !have && !accepted;
     if (__any(todo)) {
       // rare: not an isometry / degenerate transfer spectrum.  Wave-uniform branch, one evaluation at a time.
       bool left = false;
@@ -641,6 +649,10 @@ __global__ __launch_bounds__(64, 2) void env_direct_d8_kernel(const double2* __r
     }
     __builtin_amdgcn_wave_barrier();
     x = sT[i][ip];
+    // singular to rounding (a fixed point that is not unique, see DirectD4::kMaxInversePivot): let the power iteration of
+    // the energy kernel decide, from its default start
+    const bool tiny = fabs(dinv[0]) > 1e10 || fabs(dinv[1]) > 1e10 || fabs(dinv[2]) > 1e10 || fabs(dinv[3]) > 1e10;
+    if (__any(tiny)) x = __builtin_nan("");
   }
 #endif
   // coordinates -> complex r[i][i']: the transposed coordinate comes through LDS; trace 1; a non-finite solve -> 1/8

@@ -123,7 +123,8 @@ struct DirectD4 {
   // Step k: the lane that owns row k (lane k / 4, register k % 4) broadcasts what is left of it; every lane
   // eliminates column k from its four rows (the pivot row itself is skipped by a zero multiplier).
   // M: the lane's rows of R on entry; destroyed.
-  static QMPS_CORE_FN void solve(const O& o, V (&M)[4][16], V (&x)[4]) {
+  // pivmax: the largest |1 / pivot| of the elimination (the same in every lane of the quad) - see kMaxInversePivot
+  static QMPS_CORE_FN void solve(const O& o, V (&M)[4][16], V (&x)[4], V& pivmax) {
     V y[4], dinv[4];
     const V one = O::splat(1.0), zero = O::splat(0.0);
     V w[4];
@@ -160,7 +161,15 @@ struct DirectD4 {
     y[3] = O::sel(o.q_eq(3), one, y[3]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = y[r] * dinv[r];
+    pivmax = O::qmax(O::vmax(O::vmax(O::vabs(dinv[0]), O::vabs(dinv[1])), O::vmax(O::vabs(dinv[2]), O::vabs(dinv[3]))));
   }
+
+  // A transfer map whose fixed point is NOT unique (degenerate dominant eigenvalue: product states, special angles of the
+  // ansatz) makes the system singular to rounding; the elimination then returns SOME fixed point - it passes the acceptance
+  // step like any other - which one being decided by rounding errors.  Such evaluations (a pivot below 1e-10) are handed to
+  // the power method instead, which returns the projection of r_0 = 1/D onto the fixed-point space or reports that it does
+  // not converge, exactly as the iterative solvers do.
+  static constexpr double kMaxInversePivot = 1e10;
 
   // all sixteen coordinates in every lane: xs[4 l + r] = x[r] of lane l
   static QMPS_CORE_FN void gather(const V (&x)[4], V (&xs)[16]) {

@@ -42,6 +42,12 @@ struct HostOps {
     const double t = s01 + s23;
     return {{t, t, t, t}};
   }
+  static V qmax(V a) {
+    const double t = std::fmax(std::fmax(a.v[0], a.v[1]), std::fmax(a.v[2], a.v[3]));
+    return {{t, t, t, t}};
+  }
+  static V vabs(V a) { return {{std::fabs(a.v[0]), std::fabs(a.v[1]), std::fabs(a.v[2]), std::fabs(a.v[3])}}; }
+  static V vmax(V a, V b) { return {{std::fmax(a.v[0], b.v[0]), std::fmax(a.v[1], b.v[1]), std::fmax(a.v[2], b.v[2]), std::fmax(a.v[3], b.v[3])}}; }
   static V sel(P p, V a, V b) { return {{p.v[0] ? a.v[0] : b.v[0], p.v[1] ? a.v[1] : b.v[1], p.v[2] ? a.v[2] : b.v[2], p.v[3] ? a.v[3] : b.v[3]}}; }
   static V splat(double x) { return {{x, x, x, x}}; }
   static V fma(V a, V b, V c) { return {{std::fma(a.v[0], b.v[0], c.v[0]), std::fma(a.v[1], b.v[1], c.v[1]), std::fma(a.v[2], b.v[2], c.v[2]), std::fma(a.v[3], b.v[3], c.v[3])}}; }
@@ -75,12 +81,13 @@ extern "C" int direct_emu_d4(long B, const double* A, const double* h, int nt, i
     HostOps o{A + b * 64};
     V Rc[4][16], x[4], y[4], us[16];
     Core::build(o, Rc);
-    Core::solve(o, Rc, x);
+    V pivmax;
+    Core::solve(o, Rc, x, pivmax);
     Core::normalise(o, x);
     Core::gather(x, us);
     const V d2 = Core::power_step(o, x, us, y);
     const double tol2 = tol * tol;
-    P4 ok = HostOps::lt(d2, HostOps::splat(tol2));
+    P4 ok = HostOps::p_and(HostOps::lt(d2, HostOps::splat(tol2)), HostOps::lt(pivmax, HostOps::splat(Core::kMaxInversePivot)));
     V steps = HostOps::splat(1.0);
     int st = 0;
     if (resid) resid[b] = std::sqrt(d2.v[0]);

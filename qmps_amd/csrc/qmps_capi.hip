@@ -104,6 +104,25 @@ struct qmps_ctx {
   bool tensors_valid = true;        // d_A holds the tensors of the resident states
   int ans_kind = 0, ans_P = 0;
   const double* ans_src = nullptr;  // parameter rows (nullptr: d_params)
+  // rotosolve work buffers and the captured sweep are kept between calls (a call used to spend ~0.6 ms on hipMalloc /
+  // hipFree / graph capture + instantiation - as much as three sweeps at D = 4)
+  double* roto_base = nullptr;
+  double* roto_hist = nullptr;
+  int* roto_idx = nullptr;
+  size_t roto_base_bytes = 0, roto_hist_bytes = 0;
+  hipGraph_t roto_graph = nullptr;
+  hipGraphExec_t roto_exec = nullptr;
+  struct RotoKey {
+    int64_t R = -1;
+    int kind = 0, P = 0, nsh = 0, max_iter = 0, n_terms = 0, solver = 0, handoff = 0;
+    double tol = 0.0;
+    bool fused = false;
+    const void *base = nullptr, *hist = nullptr, *params = nullptr, *E = nullptr;
+    bool operator==(const RotoKey& o) const {
+      return R == o.R && kind == o.kind && P == o.P && nsh == o.nsh && max_iter == o.max_iter && n_terms == o.n_terms && solver == o.solver &&
+             handoff == o.handoff && tol == o.tol && fused == o.fused && base == o.base && hist == o.hist && params == o.params && E == o.E;
+    }
+  } roto_key;
   const int* ans_i = nullptr;       // rotosolve: device index of the parameter being updated
   int ans_nsh = 0;                  // rotosolve: shifts per restart (0: one parameter row per evaluation)
   // RCCL: the all-reduce runs on its own stream so that it overlaps the next step's kernels
@@ -391,6 +410,8 @@ int qmps_destroy(qmps_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
   if (c->comm_stream2) (void)hipStreamSynchronize(c->comm_stream2);
+  if (c->roto_exec) (void)hipGraphExecDestroy(c->roto_exec);
+  if (c->roto_graph) (void)hipGraphDestroy(c->roto_graph);
   if (c->comm2) (void)ncclCommDestroy(c->comm2);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   for (int i = 0; i < qmps_ctx::kCostSlots; ++i) {
@@ -399,7 +420,7 @@ int qmps_destroy(qmps_ctx* c) {
   }
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   if (c->comm_stream2) (void)hipStreamDestroy(c->comm_stream2);
-  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc, c->d_acc_err};
+  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc, c->d_acc_err, c->roto_base, c->roto_hist, c->roto_idx};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
@@ -526,17 +547,21 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     HIP_TRY(hipMalloc((void**)&c->d_params, (size_t)c->max_batch * n_params * sizeof(double)));
     c->params_cap = n_params;
   }
-  double *d_base = nullptr, *d_hist = nullptr;
-  int* d_idx = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_base, (size_t)R * n_params * sizeof(double)));
-  if (hipMalloc((void**)&d_hist, (size_t)R * n_sweeps * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&d_idx, 3 * sizeof(int)) != hipSuccess) {
-    (void)hipFree(d_base);
-    if (d_hist) (void)hipFree(d_hist);
-    return fail(QMPS_ERR_HIP, "hipMalloc failed");
-  }
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
+  auto grow = [&](double*& buf, size_t& have, size_t need) -> int {
+    if (need > have) {
+      if (buf) HIP_TRY(hipFree(buf));
+      buf = nullptr;
+      have = 0;
+      HIP_TRY(hipMalloc((void**)&buf, need));
+      have = need;
+    }
+    return QMPS_OK;
+  };
+  if (int rc = grow(c->roto_base, c->roto_base_bytes, (size_t)R * n_params * sizeof(double))) return rc;
+  if (int rc = grow(c->roto_hist, c->roto_hist_bytes, (size_t)R * n_sweeps * sizeof(double))) return rc;
+  if (!c->roto_idx) HIP_TRY(hipMalloc((void**)&c->roto_idx, 3 * sizeof(int)));
+  double *d_base = c->roto_base, *d_hist = c->roto_hist;
+  int* d_idx = c->roto_idx;
   int rc = [&]() -> int {
     HIP_TRY(hipMemcpyAsync(d_base, params, (size_t)R * n_params * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(d_idx, 0, 3 * sizeof(int), c->stream));   // parameter index, arrival counter, finished sweeps
@@ -603,23 +628,44 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     };
     const bool use_graph = getenv("QMPS_NO_GRAPH") == nullptr && n_params <= 256;
     if (use_graph) {
-      c->capturing = true;
-      HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-      const int e = one_sweep();
-      const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
-      c->capturing = false;
-      if (e) return e;
-      HIP_TRY(ce);
-      HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      qmps_ctx::RotoKey key;
+      key.R = R; key.kind = kind; key.P = n_params; key.nsh = nsh; key.max_iter = max_iter; key.n_terms = c->n_terms;
+      key.solver = c->default_solver; key.handoff = c->handoff; key.tol = tol; key.fused = fused;
+      key.base = d_base; key.hist = d_hist; key.params = c->d_params; key.E = c->d_E;
+      if (!(c->roto_exec && key == c->roto_key)) {
+        if (c->roto_exec) (void)hipGraphExecDestroy(c->roto_exec);
+        if (c->roto_graph) (void)hipGraphDestroy(c->roto_graph);
+        c->roto_exec = nullptr; c->roto_graph = nullptr;
+        c->capturing = true;
+        HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int e = one_sweep();
+        const hipError_t ce = hipStreamEndCapture(c->stream, &c->roto_graph);
+        c->capturing = false;
+        if (e) return e;
+        HIP_TRY(ce);
+        HIP_TRY(hipGraphInstantiate(&c->roto_exec, c->roto_graph, nullptr, nullptr, 0));
+        c->roto_key = key;
+      }
     }
     for (int sw = 0; sw < n_sweeps; ++sw) {
-      if (use_graph) HIP_TRY(hipGraphLaunch(exec, c->stream));
+      if (use_graph) HIP_TRY(hipGraphLaunch(c->roto_exec, c->stream));
       else if (int e = one_sweep()) return e;
     }
+    // The context's view of what is resident - a replayed graph runs no host code, so it is stated here, not inherited from
+    // the capture: the R final parameter vectors, their energies / statuses / environments
+    c->n_states = R;
+    c->window = 0;
+    c->have_env = true;
+    c->partials_B = -1;
+    c->acc_pending = false;
     if (fused) {
-      // leave the context as a qmps_set_states_ansatz of the final parameters would: rows resident in d_params
+      // as a qmps_set_states_ansatz of the final parameters would leave it: rows resident in d_params, tensors on demand
       HIP_TRY(hipMemcpyAsync(c->d_params, d_base, (size_t)R * n_params * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-      c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0;
+      c->ans_have = true; c->ans_kind = kind; c->ans_P = n_params; c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0;
+      c->tensors_valid = false;
+    } else {
+      c->ans_have = false; c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0;
+      c->tensors_valid = true;
     }
     c->have_guess = saved_guess;
     HIP_TRY(hipMemcpyAsync(params, d_base, (size_t)R * n_params * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -632,11 +678,11 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
   if (c->ans_src != nullptr) {     // an error left the context pointing at the run's own buffers
     c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0; c->ans_have = false; c->tensors_valid = true; c->n_states = 0;
   }
-  if (exec) (void)hipGraphExecDestroy(exec);
-  if (graph) (void)hipGraphDestroy(graph);
-  (void)hipFree(d_base);
-  (void)hipFree(d_hist);
-  (void)hipFree(d_idx);
+  if (rc != QMPS_OK && c->roto_exec) {     // do not trust a sweep captured by a failed run
+    (void)hipGraphExecDestroy(c->roto_exec);
+    if (c->roto_graph) (void)hipGraphDestroy(c->roto_graph);
+    c->roto_exec = nullptr; c->roto_graph = nullptr;
+  }
   return rc;
 }
 }  // namespace

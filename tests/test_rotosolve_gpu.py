@@ -177,3 +177,33 @@ def test_invalid_environments_leave_parameters_finite():
         args = (opt4.batch_objective_function, bad0) if drv is RS.batched_rotosolve else (opt4, bad0)
         e, p = drv(*args, N_iters=1)
         assert np.all(np.isfinite(p)) and np.isfinite(e[:, 1]).all()
+
+
+def test_cached_sweep_graph_is_replayed_faithfully(engine_factory):
+    """The captured sweep is kept in the context: a second call of the same shape replays it.  Whatever happened to the
+    context in between, the run and the state it leaves (energies, tensors of the final parameters) are the same."""
+    from qmps_amd import _lib
+    rng = np.random.default_rng(77)
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+    for D, P in ((4, 4), (8, 6)):
+        R = 40
+        eng = engine_factory(D, 1024)
+        eng.set_hamiltonian(h)
+        P0 = rng.standard_normal((R, P))
+        h1, p1 = eng.rotosolve(_lib.ANSATZ_SHALLOW_CNOT, P0, 3)
+        eng.set_tensors(O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, 100)))     # something else resident in between
+        eng.launch(100)
+        h2, p2 = eng.rotosolve(_lib.ANSATZ_SHALLOW_CNOT, P0, 3)
+        assert np.array_equal(h1, h2, equal_nan=True) and np.array_equal(p1, p2)
+        E, it, st = eng.results(R)
+        ok = st == 0
+        assert np.abs(E[:, 0] - h2[-1])[ok].max() < 1e-13
+        A = eng.tensors(R)
+        for b in range(0, R, 7):
+            assert np.abs(A[b] - O.unitary_to_tensor(O.shallow_cnot_unitary(D, p2[b])[None])[0]).max() < 1e-13
+        # other start vectors through the same graph
+        P1 = rng.standard_normal((R, P))
+        h3, p3 = eng.rotosolve(_lib.ANSATZ_SHALLOW_CNOT, P1, 3)
+        assert not np.array_equal(p3, p2)
+        for b in np.flatnonzero(~np.isnan(h3[-1]))[::9]:
+            assert abs(h3[-1][b] - O.energy_closed_form(O.unitary_to_tensor(O.shallow_cnot_unitary(D, p3[b])[None])[0], h)) < 1e-9

@@ -421,3 +421,38 @@ def test_structured_angles_stress(engine_factory):
     # the fall-back is taken (singular systems) and reported: iterations 1 + 2^m
     fb = it > 1
     assert fb.any() and np.all(np.log2(it[fb] - 1) % 1 == 0)
+
+
+def test_warm_start_with_the_fused_ansatz(engine_factory):
+    """Both prologues together: tensors built from ansatz parameters in LDS AND resident environments accepted as they are."""
+    from qmps_amd import _lib
+    rng = np.random.default_rng(43)
+    B = 777
+    prm = rng.standard_normal((B, 4))
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+    eng = engine_factory(4, 2048)
+    eng.set_hamiltonian(h)
+    for code in (_lib.ANSATZ_SHALLOW_CNOT, _lib.ANSATZ_SHALLOW_QAOA):
+        eng.set_ansatz_params(code, prm)
+        eng.launch(B, solver='direct', store_env=True)
+        E0, it0, st0 = eng.results(B)
+        eng.launch(B, solver='direct', store_env=True, warm_start=True)
+        E1, it1, st1 = eng.results(B)
+        ok = (st0 == 0) & (st1 == 0)
+        # (an environment with a zero eigenvalue to rounding may flip between OK and NOT_PD from one power step to the next)
+        assert (st0 == st1).mean() > 0.99 and ok.mean() > 0.9
+        assert np.all(it1[ok & (it0 == 1)] == 1) and np.abs(E1 - E0)[ok].max() < 1e-12
+        # new parameters, stale environments: rejected, solved from scratch
+        prm2 = prm + 0.3
+        eng.set_ansatz_params(code, prm2)
+        eng.launch(B, solver='direct', store_env=True)
+        Ec, itc, stc = eng.results(B)
+        eng.set_ansatz_params(code, prm)
+        eng.launch(B, solver='direct', store_env=True)
+        r_old = eng.environments(B)
+        eng.set_ansatz_params(code, prm2)
+        eng.set_env_guess(r_old)
+        eng.launch(B, solver='direct', store_env=True)
+        Ew, itw, stw = eng.results(B)
+        both = (stc == 0) & (stw == 0)
+        assert np.abs(Ew - Ec)[both].max() < 1e-12 and np.all(itw[both & (itc == 1)] == 2)

@@ -109,8 +109,11 @@ class EnergyEngine:
     def set_hamiltonian(self, h):
         """h: (4, 4) or (n_terms, 4, 4) complex; index 2*s1+s2 with s1 the left site."""
         h = np.ascontiguousarray(np.asarray(h, dtype=np.complex128).reshape(-1, 4, 4))
+        if getattr(self, '_h_resident', None) is not None and self._h_resident.shape == h.shape and np.array_equal(self._h_resident, h):
+            return                  # already resident (an optimiser passes the same Hamiltonian with every objective call)
         L.check(self._lib.qmps_set_hamiltonian(self._ctx, h.shape[0], _f64(h.view(np.float64))))
         self.n_terms = h.shape[0]
+        self._h_resident = h.copy()
 
     def set_window(self, first):
         """Several resident batches side by side: after set_window(first) the launch / read-back calls address
@@ -219,6 +222,7 @@ class EnergyEngine:
             _f64(h.view(np.float64)), nt, None if r0c is None else _f64(r0c.view(np.float64)), int(max_iter),
             float(tol), _f64(E), _i32(it), _i32(st)))
         self.B, self.n_terms = B, nt
+        self._h_resident = h.copy()
         return E, it, st
 
     def env_batch(self, states, kind='tensor', r0=None, max_iter=10000, tol=1e-13):
@@ -236,6 +240,7 @@ class EnergyEngine:
         self.B = B
         if self.n_terms == 0:
             self.n_terms = 1
+            self._h_resident = None       # the library made h = 0 resident
         return r, it, st
 
     def cell2_energies(self, U1, U2, h, max_iter=10000, tol=1e-13):
@@ -253,6 +258,7 @@ class EnergyEngine:
                                                   _f64(h.view(np.float64)), nt, int(max_iter), float(tol), _f64(E),
                                                   _i32(it), _i32(st)))
         self.n_terms = nt
+        self._h_resident = h.copy()
         return E, it, st
 
     def overlaps(self, A, candidates, WW, kind='tensor', ansatz=None, max_rounds=None, tol=1e-13, want_r=False):

@@ -494,6 +494,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('QMPS_BENCH_ONE_DEVICE') == '1':      # functional test of the N > 1 branch on a one-GPU box (if RCCL allows it)
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py: --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)')

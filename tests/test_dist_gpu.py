@@ -85,3 +85,28 @@ def test_bench_distributed_code_path_world1(scaling):
     assert d['n_gpus'] == 1 and d['value'] > 1e6 and 'RCCL communicator of 1 ranks' in d['config']['collective']
     assert 'per step' in d['config']['collective'] and d['scaling'] == scaling and d['config']['resident_batches'] == 3
     assert d['grouped_exchange_16']['evals_per_s'] > 1e6
+
+
+@pytest.mark.parametrize('scaling', ['weak', 'strong'])
+def test_bench_two_ranks_on_one_device(scaling):
+    """Two ranks through the driver's launcher, both on device 0 (QMPS_BENCH_ONE_DEVICE): RCCL refuses two ranks on one
+    GPU ('Duplicate GPU detected'), so this covers everything of bench.py's N = 2 branch EXCEPT the RCCL exchange itself -
+    rendezvous, shard plan, every rank reaching the collective calls in step, the reported (never silent) fall-back of the
+    summed cost to the launcher's gloo group, max-over-ranks timing, one JSON line from rank 0, clean exit of both ranks."""
+    import json
+    env = dict(os.environ, QMPS_BENCH_ONE_DEVICE='1', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', '29519', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5',
+           '--warmup', '2', '--no-cpu-baseline', '--no-extras', '--batch', '4096', '--rotate', '2', '--scaling', scaling]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                     # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == scaling and d['value'] > 1e6
+    per_gpu = 4096 if scaling == 'weak' else 2048
+    assert d['config']['batch_per_gpu'] == per_gpu and d['config']['global_batch'] == 2 * per_gpu
+    coll = d['config']['collective']
+    if 'RCCL communicator of 2 ranks' not in coll:             # (a box with two GPUs would take the RCCL path)
+        assert 'RCCL communicator unavailable on 2 rank(s)' in coll and 'gloo' in coll
+    assert np.isfinite(d['summed_cost']) and d['config']['not_converged_or_not_pd'] == 0

@@ -1395,6 +1395,13 @@ int close_group(qmps_ctx* c) {
                                            c->d_acc_err, c->comm_stream_of(slot)));
         c->acc_is[slot][pos] = false;
       }
+#ifdef QMPS_DEBUG_KNOBS
+    // robustness drill for the exchange pipeline at world size 1, where the real all-reduce is instantaneous: a busy kernel in
+    // front of it makes every exchange last QMPS_DBG_SLOW_AR probe iterations (~1300 = 40 us, longer than a step), so the ring
+    // fills up, the host-side slot guard blocks and the finish kernels queue behind exchanges that are still in flight
+    static const int slow_ar = getenv("QMPS_DBG_SLOW_AR") ? atoi(getenv("QMPS_DBG_SLOW_AR")) : 0;
+    if (slow_ar > 0) HIP_TRY(qmps::launch_probe_fp64((double*)c->d_work_idx, 1, slow_ar, c->comm_stream_of(slot)));
+#endif
     if (!dbg_noar)
       RCCL_TRY(ncclAllReduce(base, base, (size_t)c->group_fill * kMaxTerms, ncclDouble, ncclSum, c->comm_of(slot), c->comm_stream_of(slot)));
     HIP_TRY(hipEventRecord(c->cost_reduced[slot], c->comm_stream_of(slot)));

@@ -1027,6 +1027,7 @@ int qmps_cell2_energy_batch(qmps_ctx* c, int64_t B, const double* U1, const doub
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;
   if (c->D != 2) return fail(QMPS_ERR_ARG, "the two-site unit cell path is D = 2 only (qmps/ground_state.py:276)");
+  c->window = 0;      // a one-shot call: results at the start of the buffers, like the qmps_set_* calls
   if ((!U1 || !U2) && B > 0) return fail(QMPS_ERR_ARG, "null unitaries");
   if (!E_out) return fail(QMPS_ERR_ARG, "null E_out");
   if (max_iter < 1 || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_iter / tol");
@@ -1488,7 +1489,14 @@ int qmps_get_cost(qmps_ctx* c, double* cost) {
   }
   HIP_TRY(hipMemcpyAsync(c->h_cost, c->d_cost_ring + ((size_t)c->last_slot * qmps_ctx::kMaxGroup + c->last_pos) * kMaxTerms,
                          c->n_terms * sizeof(double), hipMemcpyDeviceToHost, st));
+  int acc_err = 0;
+  if (c->comm) HIP_TRY(hipMemcpyAsync(&acc_err, c->d_acc_err, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  if (acc_err) {
+    // a finish kernel gave up waiting for its energy kernel's waves (bounded poll): the cost it wrote is NaN
+    (void)hipMemsetAsync(c->d_acc_err, 0, sizeof(int), st);
+    return fail(QMPS_ERR_STATE, "cost accumulator: a step's energy kernel did not arrive within the polling bound (was it launched?)");
+  }
   memcpy(cost, c->h_cost, c->n_terms * sizeof(double));
   return QMPS_OK;
 }

@@ -933,6 +933,8 @@ int qmps_energy_only_launch(qmps_ctx* c, int64_t B) {
   c->partials_B = -1;
   if (c->D == 16 && !getenv("QMPS_D16_BLOCK"))
     HIP_TRY(qmps::launch_energy_mfma(c->D, a, false, c->stream));
+  else if (c->D == 4 && getenv("QMPS_ENERGY_PAIR") == nullptr)
+    HIP_TRY(qmps::launch_energy_only_d4(a, c->stream));     // quad layout, 4+ waves per SIMD (round 1: two lanes per evaluation)
   else if (c->D == 4 && !c->no_pair)
     HIP_TRY(qmps::launch_energy_pair_d4(a, c->stream));
   else

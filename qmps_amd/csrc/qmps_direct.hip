@@ -400,6 +400,113 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// energy_only_d4_kernel: the contraction chain A - Abar - h - A - Abar of the north star with the RESIDENT environment
+// (qmps_energy_only_launch, qmps_get_rdm): no solve.  Same quad layout and the same density / energy code as the fused
+// kernel (one wave = 16 evaluations = one contiguous 8 KB slab of tensors + 4 KB of environments), without the 16 x 16
+// system: half the instructions of round 1's two-lanes-per-evaluation kernel.
+// r is read as stored (r[i][j] complex), symmetrised by taking Re r[q][l] / Im r[l][q] of the upper triangle, and
+// trace-normalised; check_pd: LDL^H pivots, status 0 -> 2.
+// ------------------------------------------------------------------------------------------
+// LEAN (no density matrix asked for, no positive-definiteness test, one or two Hamiltonian terms): the energy without rho
+// (DirectD4::energy_lean: ~30 % fewer instructions for one term).  Measured over 9 rotating batches (432 MiB): 15.5 us per
+// 65 536 evaluations = 3.3 TB/s on the 776 B actually read (41 % of the HBM peak); the rho route 18.3 us; round 1's
+// two-lanes-per-evaluation kernel 27.9 us.  Three waves per SIMD (168 VGPRs) spill 28 bytes and are SLOWER (18.7 us: any
+// scratch use costs more than the third wave brings), four spill 764 bytes (36.8 us): two it is.
+#ifndef QMPS_ENERGY_ONLY_LEAN_WAVES
+#define QMPS_ENERGY_ONLY_LEAN_WAVES 2
+#endif
+template <bool LEAN>
+__global__ __launch_bounds__(64, LEAN ? QMPS_ENERGY_ONLY_LEAN_WAVES : 2) void energy_only_d4_kernel(LaneArgs p) {
+  using Core = DirectD4<QuadOps>;
+  constexpr int ROW = 512, PAD = ROW + 16, ITEMS = 16;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[ITEMS * PAD];
+  const int lane = threadIdx.x, e = lane >> 2, q = lane & 3;
+  const int64_t first = (int64_t)blockIdx.x * ITEMS;
+  const int64_t b = first + e;
+  const bool valid = b < p.B;
+  if (p.acc_zero != nullptr && blockIdx.x == 0) acc_clear(p.acc_zero, p.n_terms, lane, 64);
+  {
+    const unsigned char* slab = (const unsigned char*)p.A + first * ROW;
+    const int64_t slab_bytes = (p.B - first < ITEMS ? p.B - first : ITEMS) * (int64_t)ROW;
+    double2 v[ITEMS * ROW / 1024];
+#pragma unroll
+    for (int c = 0; c < ITEMS * ROW / 1024; ++c) {
+      const int off = c * 1024 + lane * 16;
+      v[c] = make_double2(0.0, 0.0);
+      if (off < slab_bytes) v[c] = *(const double2*)(slab + off);
+    }
+    // the environment: lane q takes Re r[q][l] (q <= l) | Im r[l][q] (q > l), l = 0 .. 3
+    double x[4];
+    {
+      const double2* rin = (const double2*)p.r_in + (valid ? b : 0) * 16;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const double2 rw = rin[q * 4 + l], cl = rin[l * 4 + q];
+        x[l] = q <= l ? rw.x : cl.y;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < ITEMS * ROW / 1024; ++c) {
+      const int off = c * 1024 + lane * 16;
+      *(double2*)(lds + (off / ROW) * PAD + (off % ROW)) = v[c];
+    }
+    __syncthreads();
+    const QuadOps o{q, (const double2*)(lds + e * PAD), nullptr};
+    Core::normalise(o, x);
+    double us[16];
+    Core::gather(x, us);
+    double pre[4][4], pim[4][4];
+    bool pd = true;
+    if constexpr (!LEAN) pd = Core::density(o, us, pre, pim);
+    int status = QMPS_ST_OK;
+    if (p.check_pd) {
+      status = valid ? p.status[b] : QMPS_ST_OK;
+      if (status == QMPS_ST_OK && !pd) status = QMPS_ST_NOT_PD;
+    }
+    for (int t = 0; t < p.n_terms; ++t) {
+      double en;
+      if constexpr (LEAN) en = quad_sum(Core::energy_lean(o, us, (const double*)p.h + 32 * t));
+      else en = quad_sum(Core::energy((const double*)p.h + 32 * t, pre, pim));
+      if (valid && q == 0) p.E[b * p.n_terms + t] = en;
+      if (p.partial != nullptr || p.acc != nullptr) {
+        const double s = wave_sum((valid && q == 0) ? en : 0.0);
+        if (lane == 0) {
+          if (p.partial != nullptr) p.partial[(int64_t)t * gridDim.x + blockIdx.x] = s;
+          if (p.acc != nullptr) acc_arrive(p.acc, p.acc_shards, t, blockIdx.x, s, p.acc_bound, p.acc_scale);
+        }
+      }
+    }
+    if (!LEAN && p.rho_out != nullptr) {
+      double fre[4][4], fim[4][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s2 = t; s2 < 4; ++s2) {
+          fre[t][s2] = quad_sum(pre[t][s2]);
+          fim[t][s2] = t == s2 ? 0.0 : quad_sum(pim[t][s2]);
+        }
+      if (valid && q == 0) {
+        double2* o2 = (double2*)p.rho_out + b * 16;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2)
+            o2[t * 4 + s2] = t <= s2 ? make_double2(fre[t][s2], fim[t][s2]) : make_double2(fre[s2][t], -fim[s2][t]);
+      }
+    }
+    if (p.check_pd && valid && q == 0) p.status[b] = status;
+  }
+}
+
+hipError_t launch_energy_only_d4(const LaneArgs& a, hipStream_t st) {
+  if (a.B <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((a.B + 15) / 16)), block(64);
+  if (a.rho_out == nullptr && !a.check_pd && a.n_terms <= 2) hipLaunchKernelGGL(energy_only_d4_kernel<true>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(energy_only_d4_kernel<false>, grid, block, 0, st, a);
+  return hipGetLastError();
+}
+
 // acc (fixed point + arrival counts) -> cost[t].  One wave.  With expect > 0 the producer may still be running on
 // another stream: sweep the shards (agent-scope loads) until `expect` waves per term have arrived, sleeping in between;
 // a bounded number of sweeps, then NaN + *err (a reader never hangs the GPU).  The integer sum of the shards is exact.

@@ -304,6 +304,88 @@ struct DirectD4 {
     return active;
   }
 
+  // row q of B_tau = A_t1 A_t2, tau = 2 t1 + t2
+  static QMPS_CORE_FN void b_rows(const O& o, V (&bre)[4][4], V (&bim)[4][4]) {
+    V ar[2][4], ai[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.own(s, j, ar[s][j], ai[s][j]);
+    // one row j of A_t2 at a time (8 values live instead of the whole matrix): B[(t1 t2)][k] += A_t1[q][j] A_t2[j][k]
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        V ur[4], ui[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o.uni(t2, j, k, ur[k], ui[k]);
+#pragma unroll
+        for (int t1 = 0; t1 < 2; ++t1)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            V cr, ci;
+            if (j == 0) {
+              cr = ar[t1][0] * ur[k];
+              ci = ar[t1][0] * ui[k];
+            } else {
+              cr = O::fma(ar[t1][j], ur[k], bre[2 * t1 + t2][k]);
+              ci = O::fma(ar[t1][j], ui[k], bim[2 * t1 + t2][k]);
+            }
+            bre[2 * t1 + t2][k] = O::fma(-ai[t1][j], ui[k], cr);
+            bim[2 * t1 + t2][k] = O::fma(ai[t1][j], ur[k], ci);
+          }
+      }
+  }
+
+  // ---- 5b. one energy without the density matrix (the energy-only contraction chain at high occupancy): with
+  // C_sigma = sum_tau h[sigma,tau] B_tau (row q) and Z_sigma = C_sigma r,
+  //   E = Re sum_sigma sum_l Z_sigma[l] conj(B_sigma[l])     ( = Re sum h[sigma,tau] tr(B_tau r B_sigma^+) )
+  // - only the four B rows and r stay live (~150 registers against ~230 for the rho route).  Returns the lane's share.
+  static QMPS_CORE_FN V energy_lean(const O& o, const V (&us)[16], const double* h) {
+    V bre[4][4], bim[4][4];
+    b_rows(o, bre, bim);
+    V e = O::splat(0.0);
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg) {
+      V cr[4], ci[4];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        cr[l] = O::splat(0.0);
+        ci[l] = O::splat(0.0);
+      }
+#pragma unroll
+      for (int tau = 0; tau < 4; ++tau) {
+        const V hr = O::splat(h[2 * (4 * sg + tau)]), hi = O::splat(h[2 * (4 * sg + tau) + 1]);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          cr[l] = O::fma(hr, bre[tau][l], cr[l]);
+          cr[l] = O::fma(-hi, bim[tau][l], cr[l]);
+          ci[l] = O::fma(hr, bim[tau][l], ci[l]);
+          ci[l] = O::fma(hi, bre[tau][l], ci[l]);
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        // Z[l] = sum_k C[k] r[k][l];  r[k][l] for k <= l from (us[4k+l], us[4l+k]), the conjugate otherwise
+        V zr = O::splat(0.0), zi = O::splat(0.0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const V rr = us[k <= l ? 4 * k + l : 4 * l + k];
+          zr = O::fma(cr[k], rr, zr);
+          zi = O::fma(ci[k], rr, zi);
+          if (k != l) {
+            const V ri = k < l ? us[4 * l + k] : -us[4 * k + l];
+            zr = O::fma(-ci[k], ri, zr);
+            zi = O::fma(cr[k], ri, zi);
+          }
+        }
+        e = O::fma(zr, bre[sg][l], e);
+        e = O::fma(zi, bim[sg][l], e);
+      }
+    }
+    return e;
+  }
+
   // ---- 5. positive-definiteness of r (LDL^H pivots > 0: the criterion of cholesky(r), qmps/tools.py:182) and the
   //         lane's share of the two-site density matrix rho[tau][sigma] = tr(B_tau r B_sigma^+), tau <= sigma ----
   // us: all sixteen coordinates of r (trace 1).  Lane q contributes row q of B_tau = A_t1 A_t2 (tau = 2 t1 + t2).
@@ -345,38 +427,8 @@ struct DirectD4 {
         }
       }
     }
-    // row q of B_tau
-    V ar[2][4], ai[2][4];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o.own(s, j, ar[s][j], ai[s][j]);
     V bre[4][4], bim[4][4];
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
-      V ur[4][4], ui[4][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o.uni(t2, j, k, ur[j][k], ui[j][k]);
-#pragma unroll
-      for (int t1 = 0; t1 < 2; ++t1)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          V cr = ar[t1][0] * ur[0][k], ci = ar[t1][0] * ui[0][k];
-          cr = O::fma(-ai[t1][0], ui[0][k], cr);
-          ci = O::fma(ai[t1][0], ur[0][k], ci);
-#pragma unroll
-          for (int j = 1; j < 4; ++j) {
-            cr = O::fma(ar[t1][j], ur[j][k], cr);
-            cr = O::fma(-ai[t1][j], ui[j][k], cr);
-            ci = O::fma(ar[t1][j], ui[j][k], ci);
-            ci = O::fma(ai[t1][j], ur[j][k], ci);
-          }
-          bre[2 * t1 + t2][k] = cr;
-          bim[2 * t1 + t2][k] = ci;
-        }
-    }
+    b_rows(o, bre, bim);
     // Y_tau = (row q of B_tau) r
     V yre[4][4], yim[4][4];
 #pragma unroll

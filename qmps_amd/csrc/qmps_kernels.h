@@ -110,6 +110,8 @@ hipError_t launch_energy_mfma(int D, const LaneArgs& a, bool solve, hipStream_t 
 hipError_t launch_square_tail(int D, const SquareArgs& a, int grid, hipStream_t st);
 // D = 4 energy-only pass with two lanes per evaluation (a.r_in resident, no worklist); partials: one per 32 items
 hipError_t launch_energy_pair_d4(const LaneArgs& a, hipStream_t st);
+// D = 4 energy-only pass in the quad layout of the fused kernel (no worklist mode): qmps_direct.hip
+hipError_t launch_energy_only_d4(const LaneArgs& a, hipStream_t st);
 // D = 4 DIRECT solve fused with the energies: one DPP quad per evaluation (qmps_direct.hip); partials: one per 16 items
 hipError_t launch_energy_direct_d4(const LaneArgs& a, hipStream_t st);
 

@@ -74,7 +74,7 @@ struct HostOps {
 // One batch through the same sequence of core calls as energy_direct_d4_kernel.
 // A [B][2][4][4] c128, h [nt][4][4] c128; outputs E [B][nt], r [B][4][4] c128, rho [B][4][4] c128, iters, status [B].
 extern "C" int direct_emu_d4(long B, const double* A, const double* h, int nt, int max_iter, double tol, double* E,
-                             double* r_out, double* rho_out, int32_t* iters, int32_t* status, double* resid) {
+                             double* r_out, double* rho_out, int32_t* iters, int32_t* status, double* resid, double* E_lean) {
   using Core = qmps::DirectD4<HostOps>;
   using V = Q4;
   for (long b = 0; b < B; ++b) {
@@ -103,6 +103,9 @@ extern "C" int direct_emu_d4(long B, const double* A, const double* h, int nt, i
     const P4 pd = Core::density(o, us, pre, pim);
     if (st == 0 && !pd.v[0]) st = 2;
     for (int t = 0; t < nt; ++t) E[b * nt + t] = HostOps::qsum(Core::energy(h + 32 * t, pre, pim)).v[0];
+    // the density-matrix-free route of the energy-only kernel, from the same environment
+    if (E_lean)
+      for (int t = 0; t < nt; ++t) E_lean[b * nt + t] = HostOps::qsum(Core::energy_lean(o, us, h + 32 * t)).v[0];
     iters[b] = (int32_t)steps.v[0];
     status[b] = st;
     if (r_out)

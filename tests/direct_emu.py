@@ -16,7 +16,7 @@ def lib():
         subprocess.check_call(['make', '-C', _HERE, '--no-print-directory'], stdout=subprocess.DEVNULL)
         L = ctypes.CDLL(os.path.join(_HERE, 'libdirect_emu.so'))
         dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
-        L.direct_emu_d4.argtypes = [ctypes.c_long, dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, dp, dp, ip, ip, dp]
+        L.direct_emu_d4.argtypes = [ctypes.c_long, dp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, dp, dp, ip, ip, dp, dp]
         L.direct_emu_d4.restype = ctypes.c_int
         _LIB = L
     return _LIB
@@ -34,7 +34,8 @@ def energies_d4(A, h, max_iter=10000, tol=1e-13):
     it = np.empty(B, dtype=np.int32)
     st = np.empty(B, dtype=np.int32)
     res = np.empty(B)
+    Elean = np.empty((B, nt))
     lib().direct_emu_d4(B, A.ctypes.data_as(dp), h.ctypes.data_as(dp), nt, int(max_iter), float(tol), E.ctypes.data_as(dp),
                         r.ctypes.data_as(dp), rho.ctypes.data_as(dp), it.ctypes.data_as(ip), st.ctypes.data_as(ip),
-                        res.ctypes.data_as(dp))
-    return {'E': E, 'r': r, 'rho': rho, 'iters': it, 'status': st, 'resid': res}
+                        res.ctypes.data_as(dp), Elean.ctypes.data_as(dp))
+    return {'E': E, 'r': r, 'rho': rho, 'iters': it, 'status': st, 'resid': res, 'E_lean': Elean}

@@ -26,6 +26,7 @@ def test_haar_batch_against_the_oracle():
     h = H3(rng)
     out = EMU.energies_d4(A, h)
     assert np.all(out['status'] == 0) and np.all(out['iters'] == 1) and out['resid'].max() < 1e-14
+    assert np.abs(out['E_lean'] - out['E']).max() < 1e-13          # the density-matrix-free route of the energy-only kernel
     for b in range(0, 400, 7):
         r, it, st = O.env_direct(A[b])
         assert (it, st) == (1, 0)

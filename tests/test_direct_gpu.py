@@ -459,3 +459,42 @@ def test_warm_start_with_the_fused_ansatz(engine_factory):
         Ew, itw, stw = eng.results(B)
         both = (stc == 0) & (stw == 0)
         assert np.abs(Ew - Ec)[both].max() < 1e-12 and np.all(itw[both & (itc == 1)] == 2)
+
+
+@pytest.mark.parametrize('n_terms', [1, 2, 3])
+def test_energy_only_contraction_chain_d4(n_terms, engine_factory):
+    """qmps_energy_only_launch at D = 4 (the A - Abar - h - A - Abar chain with resident environments): the density-matrix-
+    free route (one or two terms) and the rho route (more terms, the density matrix itself) against the oracle's closed
+    form with the SAME environments; ragged batch, a window, non-Hermitian h, unnormalised environments."""
+    rng = np.random.default_rng(51)
+    B = 3000 + 11
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 8, B))
+    hs = [O.hamiltonian_matrix({'ZZ': -1, 'X': 1}), rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4)),
+          O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})][:n_terms]
+    h = np.stack(hs)
+    eng = engine_factory(4, 8192)
+    eng.set_hamiltonian(h)
+    eng.set_tensors(A)
+    eng.launch(B, solver='direct', store_env=True)
+    E0, _, st = eng.results(B)
+    r = eng.environments(B)
+    assert np.all(st == 0)
+    # resident environments replaced by scaled copies: the pass normalises by the trace
+    eng.set_env_guess(r * rng.uniform(0.5, 3.0, size=(B, 1, 1)))
+    eng.launch_energy_only(B)
+    E1, _, _ = eng.results(B)
+    assert np.abs(E1 - E0).max() < 1e-12
+    for b in range(0, B, 211):
+        for t in range(n_terms):
+            want = np.einsum('st,ts->', h[t], O.two_site_rdm(A[b], r[b]))
+            assert abs(E1[b, t] - want.real) < 1e-12
+    # a window
+    eng.set_window(1024)
+    eng.launch_energy_only(500)
+    Ew, _, _ = eng.results(500)
+    assert np.array_equal(Ew, E1[1024:1524])
+    eng.set_window(0)
+    # the density matrix (rho route whatever the number of terms)
+    rho = eng.rdm(B)
+    for b in range(0, B, 307):
+        assert np.abs(rho[b] - O.two_site_rdm(A[b], r[b])).max() < 1e-13

@@ -222,6 +222,12 @@ int qmps_get_rdm(qmps_ctx* ctx, int64_t B, double* rho);
 int qmps_energy_batch(qmps_ctx* ctx, int64_t B, const double* states, int kind, const double* h, int n_terms,
                       const double* r0 /* nullable */, int max_iter, double tol, double* E_out, int32_t* iters_out,
                       int32_t* status_out);
+/* The optimisers' own call shape in one round trip (qmps/ground_state.py:150-168: parameters -> gates -> unitary ->
+ * environment -> energy): params[B][n_params] of ansatz `ansatz_kind` (QMPS_ANSATZ_*) in, energies out; inputs go to the
+ * device asynchronously and the call synchronises once, at the read-back.  Leaves the states resident like
+ * qmps_set_states_ansatz (at D = 4 with the direct solver no environments are stored). */
+int qmps_energy_batch_ansatz(qmps_ctx* ctx, int64_t B, int ansatz_kind, int n_params, const double* params, const double* h,
+                             int n_terms, int max_iter, double tol, double* E_out, int32_t* iters_out, int32_t* status_out);
 int qmps_env_batch(qmps_ctx* ctx, int64_t B, const double* states, int kind, const double* r0 /* nullable */,
                    int max_iter, double tol, double* r_out, int32_t* iters_out, int32_t* status_out);
 

@@ -56,6 +56,7 @@ SIGNATURES = {
     'qmps_get_env': (c_int, [c_void_p, c_int64, _dp]),
     'qmps_get_rdm': (c_int, [c_void_p, c_int64, _dp]),
     'qmps_energy_batch': (c_int, [c_void_p, c_int64, _dp, c_int, _dp, c_int, _dp, c_int, c_double, _dp, _ip, _ip]),
+    'qmps_energy_batch_ansatz': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, _dp, c_int, c_int, c_double, _dp, _ip, _ip]),
     'qmps_env_batch': (c_int, [c_void_p, c_int64, _dp, c_int, _dp, c_int, c_double, _dp, _ip, _ip]),
     'qmps_cell2_energy_batch': (c_int, [c_void_p, c_int64, _dp, _dp, _dp, c_int, c_int, c_double, _dp, _ip, _ip]),
     'qmps_kernel_time': (c_int, [c_void_p, c_int, POINTER(c_float), c_char_p, c_int]),

@@ -98,6 +98,7 @@ struct qmps_ctx {
   bool have_guess = false;
   bool have_env = false;
   bool want_rho = false;
+  bool defer_sync = false;          // one-shot entry points: the setters leave their H2D copies in flight, ONE synchronisation at the end
   // ansatz-parametrised states: the parameters stay resident (d_params, or ans_src during a rotosolve run); at D = 4 the
   // direct kernel builds the tensor itself, so d_A is materialised only when something else asks for the tensors
   bool ans_have = false;            // the resident states ARE ansatz(kind, P) of the resident parameters
@@ -501,7 +502,7 @@ int qmps_set_states_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const
   // D = 4: the direct kernel builds the tensors itself (8 P bytes per evaluation instead of 512); d_A is filled on demand
   if (!fusable_ansatz(c, kind))
     if (int rc = ensure_tensors(c)) return rc;
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (!c->defer_sync) HIP_TRY(hipStreamSynchronize(c->stream));
   c->window = 0;
   c->have_guess = false;
   c->have_env = false;
@@ -704,7 +705,7 @@ int qmps_set_hamiltonian(qmps_ctx* c, int n_terms, const double* h) {
   if (!h) return fail(QMPS_ERR_ARG, "null h");
   if (int rc = ensure_E(c, n_terms)) return rc;
   HIP_TRY(hipMemcpyAsync(c->d_h, h, (size_t)n_terms * 256, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (!c->defer_sync) HIP_TRY(hipStreamSynchronize(c->stream));
   c->h_fro = 0.0;
   for (int t = 0; t < n_terms; ++t) {
     double f = 0.0;
@@ -1005,6 +1006,24 @@ int qmps_energy_batch(qmps_ctx* c, int64_t B, const double* states, int kind, co
   if (int rc = qmps_set_hamiltonian(c, n_terms, h)) return rc;
   if (int rc = qmps_set_env_guess(c, B, r0)) return rc;
   if (int rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver)) return rc;
+  return qmps_get_energies(c, B, E_out, iters_out, status_out);
+}
+
+int qmps_energy_batch_ansatz(qmps_ctx* c, int64_t B, int ansatz_kind, int n_params, const double* params, const double* h,
+                             int n_terms, int max_iter, double tol, double* E_out, int32_t* iters_out, int32_t* status_out) {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  if (!E_out) return fail(QMPS_ERR_ARG, "null E_out");
+  // the host buffers stay the caller's until this function returns: the copies in may stay in flight until the ONE
+  // synchronisation of the read-back (a scalar objective call is all latency: three round trips -> one)
+  c->defer_sync = true;
+  int rc = qmps_set_states_ansatz(c, B, ansatz_kind, n_params, params);
+  if (!rc) rc = qmps_set_hamiltonian(c, n_terms, h);
+  if (!rc) rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver | ((c->D == 4 && c->default_solver == QMPS_ENV_DIRECT) ? QMPS_FLAG_NO_ENV_OUT : 0));
+  c->defer_sync = false;
+  if (rc) {
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
+  }
   return qmps_get_energies(c, B, E_out, iters_out, status_out);
 }
 

@@ -225,6 +225,20 @@ class EnergyEngine:
         self._h_resident = h.copy()
         return E, it, st
 
+    def energies_from_params(self, kind, params, h, max_iter=10000, tol=1e-13):
+        """Ansatz parameters (B, P) -> (E (B, n_terms), iters, status) in ONE round trip (the optimisers' call shape)."""
+        P = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
+        h = np.ascontiguousarray(np.asarray(h, dtype=np.complex128).reshape(-1, 4, 4))
+        B, nt = P.shape[0], h.shape[0]
+        E = np.empty((B, nt))
+        it = np.empty(B, dtype=np.int32)
+        st = np.empty(B, dtype=np.int32)
+        L.check(self._lib.qmps_energy_batch_ansatz(self._ctx, B, int(kind), P.shape[1], _f64(P), _f64(h.view(np.float64)), nt,
+                                                   int(max_iter), float(tol), _f64(E), _i32(it), _i32(st)))
+        self.B, self.n_terms = B, nt
+        self._h_resident = h.copy()
+        return E, it, st
+
     def env_batch(self, states, kind='tensor', r0=None, max_iter=10000, tol=1e-13):
         tail = (2, self.D, self.D) if kind == 'tensor' else (2 * self.D, 2 * self.D)
         states = _c128(states, tail, 'states')

@@ -177,11 +177,7 @@ class SparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
         if kind is None or (kind == 2 and self.D != 2):
             return self._energies_from_unitaries(self.unitaries(P))
         eng = _runtime.engine(self.D, P.shape[0])
-        eng.set_ansatz_params(kind, P)
-        eng.set_hamiltonian(_as_h(self.H))
-        eng.set_env_guess(None)
-        eng.launch(max_iter=self.max_iter, tol=self.env_tol)
-        E, it, st = eng.results()
+        E, it, st = eng.energies_from_params(kind, P, _as_h(self.H), max_iter=self.max_iter, tol=self.env_tol)
         return E[:, 0], it, st
 
     def objective_function_exact_environment(self, u_params):

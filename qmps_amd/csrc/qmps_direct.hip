@@ -455,10 +455,15 @@ __global__ __launch_bounds__(64, LEAN ? QMPS_ENERGY_ONLY_LEAN_WAVES : 2) void en
     const QuadOps o{q, (const double2*)(lds + e * PAD), nullptr};
     Core::normalise(o, x);
     double us[16];
-    Core::gather(x, us);
-    double pre[4][4], pim[4][4];
+    double pre[4][4], pim[4][4], bre[4][4], bim[4][4];
     bool pd = true;
-    if constexpr (!LEAN) pd = Core::density(o, us, pre, pim);
+    if constexpr (LEAN) {
+      Core::b_rows(o, bre, bim);       // (before the gather: only the lane's four coordinates of r are live meanwhile)
+      Core::gather(x, us);
+    } else {
+      Core::gather(x, us);
+      pd = Core::density(o, us, pre, pim);
+    }
     int status = QMPS_ST_OK;
     if (p.check_pd) {
       status = valid ? p.status[b] : QMPS_ST_OK;
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(64, LEAN ? QMPS_ENERGY_ONLY_LEAN_WAVES : 2) void en
     }
     for (int t = 0; t < p.n_terms; ++t) {
       double en;
-      if constexpr (LEAN) en = quad_sum(Core::energy_lean(o, us, (const double*)p.h + 32 * t));
+      if constexpr (LEAN) en = quad_sum(Core::energy_lean(bre, bim, us, (const double*)p.h + 32 * t));
       else en = quad_sum(Core::energy((const double*)p.h + 32 * t, pre, pim));
       if (valid && q == 0) p.E[b * p.n_terms + t] = en;
       if (p.partial != nullptr || p.acc != nullptr) {

@@ -340,10 +340,9 @@ struct DirectD4 {
   // ---- 5b. one energy without the density matrix (the energy-only contraction chain at high occupancy): with
   // C_sigma = sum_tau h[sigma,tau] B_tau (row q) and Z_sigma = C_sigma r,
   //   E = Re sum_sigma sum_l Z_sigma[l] conj(B_sigma[l])     ( = Re sum h[sigma,tau] tr(B_tau r B_sigma^+) )
-  // - only the four B rows and r stay live (~150 registers against ~230 for the rho route).  Returns the lane's share.
-  static QMPS_CORE_FN V energy_lean(const O& o, const V (&us)[16], const double* h) {
-    V bre[4][4], bim[4][4];
-    b_rows(o, bre, bim);
+  // - only the four B rows (b_rows, computed once for all terms) and r stay live (~150 registers against ~230 for the
+  // rho route).  Returns the lane's share.
+  static QMPS_CORE_FN V energy_lean(const V (&bre)[4][4], const V (&bim)[4][4], const V (&us)[16], const double* h) {
     V e = O::splat(0.0);
 #pragma unroll
     for (int sg = 0; sg < 4; ++sg) {

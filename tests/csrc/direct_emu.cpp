@@ -104,8 +104,11 @@ extern "C" int direct_emu_d4(long B, const double* A, const double* h, int nt, i
     if (st == 0 && !pd.v[0]) st = 2;
     for (int t = 0; t < nt; ++t) E[b * nt + t] = HostOps::qsum(Core::energy(h + 32 * t, pre, pim)).v[0];
     // the density-matrix-free route of the energy-only kernel, from the same environment
-    if (E_lean)
-      for (int t = 0; t < nt; ++t) E_lean[b * nt + t] = HostOps::qsum(Core::energy_lean(o, us, h + 32 * t)).v[0];
+    if (E_lean) {
+      V bre[4][4], bim[4][4];
+      Core::b_rows(o, bre, bim);
+      for (int t = 0; t < nt; ++t) E_lean[b * nt + t] = HostOps::qsum(Core::energy_lean(bre, bim, us, h + 32 * t)).v[0];
+    }
     iters[b] = (int32_t)steps.v[0];
     status[b] = st;
     if (r_out)

@@ -627,7 +627,10 @@ def main():
         eng.probe_fp64_tflops()
     for _ in range(args.warmup):
         step()
+    if dist is not None and rccl_ok:
+        eng.exchange_stats(reset=True)
     elapsed, ev_ms = timed(args.steps)
+    exch = eng.exchange_stats() if dist is not None and rccl_ok else None
 
     cost = eng.get_cost()
     if dist is not None and not rccl_ok:
@@ -783,6 +786,11 @@ def main():
                        'fallback_fraction': (tot[2] / tot[3]) if direct else None,
                        'max_power_iterations_rank0': int(iters.max()), 'not_converged_or_not_pd': int(tot[1]),
                        'collective': collective,
+                       'exchange_pipeline_rank0': None if exch is None else {
+                           'slot_guard_checks': exch[0], 'host_waited_for_an_exchange': exch[1], 'host_wait_ms': exch[2],
+                           'what': 'timed region, rank 0: the host issues a step in ~10 us and is throttled at the ring (it may run 6 steps ahead): '
+                                   'how often and for how long it waited for the exchange that last used the slot.  Whether the all-reduce or the '
+                                   'energy kernel sets the pace shows in ms_per_step against roofline.kernel_ms'},
                        'device': info['name'], 'arch': info['arch']},
             'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': tflops / FP64_PEAK_TFLOPS, 'traffic': traffic,

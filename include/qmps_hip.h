@@ -325,6 +325,10 @@ int qmps_allreduce_sum(qmps_ctx* ctx, double* inout, int n);
  * step of one batch overlaps the kernels of the next.  This is the path's single exchange step (the
  * summed cost of rotosolve's M(x), qmps/tools.py:432-433).  qmps_sync waits for both streams. */
 int qmps_cost_launch(qmps_ctx* ctx, int64_t B);
+/* Health of the exchange pipeline (accumulating launches with a communicator): how often the host-side slot guard was
+ * asked, how often the exchange that last used the ring slot was still in flight (the host then waits: it issues steps
+ * faster than the GPU runs them and is throttled at the ring), and for how long in all.  reset != 0 zeroes the counters. */
+int qmps_exchange_stats(qmps_ctx* ctx, int64_t* checks, int64_t* blocked, double* blocked_ms, int reset);
 /* Exchange granularity: the summed costs of `steps` consecutive qmps_cost_launch calls (1..16, default 1) travel in ONE
  * all-reduce.  Every step's cost is still reduced exactly once; qmps_get_cost / qmps_sync / a change of the period
  * exchange a partly filled group at once.  Why: the cross-stream ordering of one exchange (two event records and a

@@ -78,6 +78,7 @@ SIGNATURES = {
     'qmps_allreduce_sum': (c_int, [c_void_p, _dp, c_int]),
     'qmps_cost_launch': (c_int, [c_void_p, c_int64]),
     'qmps_set_exchange_period': (c_int, [c_void_p, c_int]),
+    'qmps_exchange_stats': (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_double), c_int]),
     'qmps_get_cost': (c_int, [c_void_p, _dp]),
     'qmps_allreduce_cost': (c_int, [c_void_p, c_int64, _dp]),
     'qmps_probe_fp64_peak': (c_int, [c_void_p, _dp]),

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <time.h>
 
 #include <new>
 
@@ -143,6 +144,8 @@ struct qmps_ctx {
   int exchange_period = 1;                   // steps per all-reduce (qmps_set_exchange_period)
   int group_fill = 0;                        // steps summed into the current group so far
   bool slot_waited = false;                  // the compute stream already waits for the current slot's previous exchange
+  int64_t slot_checks = 0, slot_blocks = 0;  // host-side slot guard: times asked / times the previous exchange was still in flight
+  double slot_block_ms = 0.0;                // ... and how long the host then waited (qmps_exchange_stats)
   int64_t groups = 0;                        // groups closed (exchanged or, without a communicator, just filled)
   int last_slot = -1, last_pos = -1;         // where the newest cost lives
   hipEvent_t cost_ready[kCostSlots] = {};    // sum kernels done (main stream)
@@ -268,9 +271,17 @@ int setup_accumulator(qmps_ctx* c, qmps::LaneArgs& a, int64_t B, int64_t adds, i
 #else
   constexpr bool dbg_nohostwait = false;
 #endif
-  if (c->comm && !dbg_nohostwait && c->groups + 2 >= qmps_ctx::kCostSlots && hipEventQuery(c->cost_reduced[nslot]) != hipSuccess) {
-    (void)hipGetLastError();
-    HIP_TRY(hipEventSynchronize(c->cost_reduced[nslot]));
+  if (c->comm && !dbg_nohostwait && c->groups + 2 >= qmps_ctx::kCostSlots) {
+    c->slot_checks++;
+    if (hipEventQuery(c->cost_reduced[nslot]) != hipSuccess) {
+      (void)hipGetLastError();
+      timespec t0, t1;
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      HIP_TRY(hipEventSynchronize(c->cost_reduced[nslot]));
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      c->slot_blocks++;
+      c->slot_block_ms += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+    }
   }
   int shards = 32;
   while (shards * (int64_t)qmps::kAccMaxWavesPerShard < adds && shards < qmps::kAccMaxShards) shards *= 2;
@@ -1434,6 +1445,15 @@ int close_group(qmps_ctx* c) {
   return QMPS_OK;
 }
 }  // namespace
+
+int qmps_exchange_stats(qmps_ctx* c, int64_t* checks, int64_t* blocked, double* blocked_ms, int reset) {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  if (checks) *checks = c->slot_checks;
+  if (blocked) *blocked = c->slot_blocks;
+  if (blocked_ms) *blocked_ms = c->slot_block_ms;
+  if (reset) { c->slot_checks = 0; c->slot_blocks = 0; c->slot_block_ms = 0.0; }
+  return QMPS_OK;
+}
 
 int qmps_set_exchange_period(qmps_ctx* c, int steps) {
   if (!c) return fail(QMPS_ERR_ARG, "null context");

@@ -167,6 +167,13 @@ class EnergyEngine:
         """Summed costs of `steps` consecutive cost_launch calls travel in one all-reduce (1..16, default 1)."""
         L.check(self._lib.qmps_set_exchange_period(self._ctx, int(steps)))
 
+    def exchange_stats(self, reset=False):
+        """(slot-guard checks, times the previous exchange of the slot was still in flight, host milliseconds spent waiting)."""
+        import ctypes
+        a, b, ms = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_double(0.0)
+        L.check(self._lib.qmps_exchange_stats(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(ms), 1 if reset else 0))
+        return int(a.value), int(b.value), float(ms.value)
+
     def set_kernel_timing_period(self, period):
         """HIP events around the dominant kernel on every `period`-th launch only (they cost ~3 us each on the
         stream); 1 = every launch (default), 0 = never."""

@@ -68,7 +68,7 @@ extern "C" {
  * point, same tolerance; `iters` reports the equivalent number of power steps handoff + 2^m.
  * This is the default of the one-shot entry points. */
 #define QMPS_ENV_POWER_SQUARING 1
-/* DIRECT fixed-point solve (D = 4 and 8; D = 2 and 16 run QMPS_ENV_POWER_SQUARING): what the reference itself
+/* DIRECT fixed-point solve (D = 2, 4 and 8; D = 16 runs QMPS_ENV_POWER_SQUARING): what the reference itself
  * does at qmps/tools.py:176-182 - an exact solve, not an iteration.  For a left isometry the transfer map preserves
  * the trace, so the environment solves the real D^2 x D^2 linear system (R - 1 + e t^T) u = e (R: the map in real
  * coordinates of the Hermitian r, t: trace functional), done by Gauss-Jordan elimination in registers.  The result is
@@ -199,7 +199,7 @@ int qmps_get_handoff(qmps_ctx* ctx, int* handoff);
 /* the squaring schedule in force for this context (QMPS_SKIP_ROUNDS_D*, QMPS_MATVEC_PERIOD_D4 unless a tuning
  * knob overrode them): untracked squarings, and D = 4 mat-vecs between further squarings (0 for D != 4) */
 int qmps_get_squaring_schedule(qmps_ctx* ctx, int* skip_rounds, int* matvec_period);
-/* solver used by qmps_energy_batch / qmps_env_batch / qmps_rotosolve (default: QMPS_ENV_DIRECT at D = 4 and 8,
+/* solver used by qmps_energy_batch / qmps_env_batch / qmps_rotosolve (default: QMPS_ENV_DIRECT at D = 2, 4 and 8,
  * QMPS_ENV_POWER_SQUARING otherwise) */
 int qmps_set_default_solver(qmps_ctx* ctx, int solver);
 /* Energy only, from the resident states and the resident environments (no solve): the

@@ -397,7 +397,7 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     HIP_TRY(hipMalloc((void**)&c->d_work_idx, (size_t)max_batch * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(c->d_work_count, 0, sizeof(int32_t), c->stream));
     c->handoff = 0;   // D = 2, 4: squaring from the start (fastest); D = 8, 16 have no squaring path
-    c->default_solver = (D == 4 || D == 8) ? QMPS_ENV_DIRECT : QMPS_ENV_POWER_SQUARING;
+    c->default_solver = (D == 2 || D == 4 || D == 8) ? QMPS_ENV_DIRECT : QMPS_ENV_POWER_SQUARING;
     c->skip_rounds = (D == 2) ? QMPS_SKIP_ROUNDS_D2 : QMPS_SKIP_ROUNDS_D4;
     if (const char* e = getenv("QMPS_SKIP_ROUNDS")) c->skip_rounds = atoi(e);   // tuning knob
     if (const char* e = getenv("QMPS_MATVEC_PERIOD")) c->matvec_period = atoi(e);   // tuning knob
@@ -583,13 +583,13 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     // D = 2 with the library's default solver: the whole run is ONE launch (restarts are independent, see
     // rotosolve_fused_d2_kernel); afterwards one ordinary evaluation of the final parameters leaves the context's
     // resident tensors / energies / statuses exactly as the step-by-step path does.
-    if (nsh == 3 && c->D == 2 && c->handoff == 0 && c->default_solver == QMPS_ENV_POWER_SQUARING && n_params <= 64 &&
+    if (nsh == 3 && c->D == 2 && c->handoff == 0 && (c->default_solver == QMPS_ENV_POWER_SQUARING || c->default_solver == QMPS_ENV_DIRECT) && n_params <= 64 &&
         getenv("QMPS_NO_FUSED_ROTO") == nullptr) {
       qmps::RotoArgs ra;
       memset(&ra, 0, sizeof(ra));
       ra.base = d_base; ra.h = c->d_h; ra.hist = d_hist;
       ra.R = (int)R; ra.P = n_params; ra.n_terms = c->n_terms; ra.n_sweeps = n_sweeps; ra.max_iter = max_iter;
-      ra.skip = c->skip_rounds; ra.tol = tol;
+      ra.skip = c->skip_rounds; ra.tol = tol; ra.direct = c->default_solver == QMPS_ENV_DIRECT ? 1 : 0;
       HIP_TRY(qmps::launch_rotosolve_fused_d2(kind, ra, c->stream));
       HIP_TRY(qmps::launch_ansatz(c->D, kind, d_base, n_params, c->d_A, R, c->stream));
       c->n_states = R; c->ans_have = false; c->tensors_valid = true;
@@ -765,7 +765,8 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     return fail(QMPS_ERR_STATE, "the cost accumulated by the previous launch has not been consumed by qmps_cost_launch");
   if ((flags & QMPS_FLAG_ACCUMULATE_COST) && c->capturing) return fail(QMPS_ERR_STATE, "no cost accumulation inside a graph capture");
   const bool direct8 = solver == QMPS_ENV_DIRECT && c->D == 8;
-  if (solver == QMPS_ENV_DIRECT && !direct) solver = QMPS_ENV_POWER_SQUARING;   // documented: D = 2, 16 iterate
+  const bool direct2 = solver == QMPS_ENV_DIRECT && c->D == 2;     // 4 x 4 solve in the lane, in front of the squaring tail
+  if (solver == QMPS_ENV_DIRECT && !direct) solver = QMPS_ENV_POWER_SQUARING;   // D = 2: the lane kernel's squaring path with the 4 x 4 solve in front (direct2); D = 16 iterates (documented)
   c->acc_pending = false;   // whatever an earlier launch accumulated no longer describes the resident energies
   const bool fused = direct && c->ans_have && fusable_ansatz(c, c->ans_kind);
   if (!fused)
@@ -826,6 +827,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   } else if (c->D == 2) {
     a.handoff = c->handoff;  // the squaring tail runs in-lane (real 4 x 4 transfer matrix in registers)
     a.hybrid = 1;
+    a.direct = direct2 ? 1 : 0;
     a.skip = c->handoff == 0 ? c->skip_rounds : 0;
     if (accumulate) {
       if (int rc = setup_accumulator(c, a, B, lane_waves, 64)) return rc;

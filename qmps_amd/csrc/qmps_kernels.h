@@ -50,6 +50,7 @@ struct LaneArgs {
   const double* ans_params;   // nullable [rows][ans_P]
   const int* ans_i;           // device pointer to the index of the parameter being updated (ans_nsh > 0)
   int ans_P, ans_kind, ans_nsh;
+  int direct;                 // D = 2 lane kernel: QMPS_ENV_DIRECT (4 x 4 fixed-point solve in the lane, then the squaring tail)
 };
 
 // D = 8 direct fixed-point solve, one wave per evaluation: writes the environments r[B][8][8] (the warm start / result
@@ -122,6 +123,7 @@ struct RotoArgs {
   double* hist;
   int R, P, n_terms, n_sweeps, max_iter, skip;
   double tol;
+  int direct;     // QMPS_ENV_DIRECT: try the 4 x 4 fixed-point solve before squaring
 };
 hipError_t launch_rotosolve_fused_d2(int kind, const RotoArgs& a, hipStream_t st);
 

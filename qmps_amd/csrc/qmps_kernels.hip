@@ -377,7 +377,8 @@ __device__ __forceinline__ void unpack_herm(const double (&x)[D * D], double (&r
 // registers, x_m = R x_C / tr, stop at ||x_m - x_{m-1}||^2 < tol^2;  iterations = done + 2^m.
 __device__ __forceinline__ void squaring_tail_d2(const double (&are)[2][2][2], const double (&aim)[2][2][2],
                                                  double (&rre)[2][2], double (&rim)[2][2], bool& active, int& iters,
-                                                 int& status, int done, int max_iter, double tol2, int skip) {
+                                                 int& status, int done, int max_iter, double tol2, int skip,
+                                                 bool direct = false) {
   auto getA = [&](int s, int i, int j) { return make_double2(are[s][i][j], aim[s][i][j]); };
   double R[4][4];
 #pragma unroll
@@ -388,6 +389,66 @@ __device__ __forceinline__ void squaring_tail_d2(const double (&are)[2][2][2], c
   pack_herm<2>(rre, rim, x0);
 #pragma unroll
   for (int a = 0; a < 4; ++a) xp[a] = x0[a];
+  if (direct) {
+    // QMPS_ENV_DIRECT at D = 2 (the same idea as at D = 4 and 8): for an isometry the fixed point solves the real 4 x 4
+    // system (R - 1 + e_1 t^T) u = e_1, t = the trace functional (coordinates 0, 1 are the diagonal r_00, r_11).  Trace
+    // preservation makes the two DIAGONAL rows of R - 1 sum to zero, so the functional has to sit on one of them, and that
+    // row is the last pivot (order 0, 2, 3, 1), as at D = 4.  Unpivoted Gauss-Jordan in the lane; accepted iff one power
+    // step moves it by less than tol (iterations = done + 1) and no pivot was below 1e-10 (a fixed point that is not
+    // unique); everything else goes on to the squaring below.
+    double M[4][5];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) M[a][b] = R[a][b] - (a == b ? 1.0 : 0.0);
+      M[a][4] = a == 1 ? 1.0 : 0.0;
+    }
+    M[1][0] += 1.0;
+    M[1][1] += 1.0;
+    double pivmax = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = kk == 0 ? 0 : (kk == 1 ? 2 : (kk == 2 ? 3 : 1));
+      const double pinv = fast_rcp(M[k][k]);
+      pivmax = fmax(pivmax, fabs(pinv));
+#pragma unroll
+      for (int b = 0; b < 5; ++b)
+        if (b != k) M[k][b] *= pinv;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        if (a != k) {
+          const double f = M[a][k];
+#pragma unroll
+          for (int b = 0; b < 5; ++b)
+            if (b != k) M[a][b] = dfma(-f, M[k][b], M[a][b]);
+        }
+    }
+    double u[4], y[4];
+    const double tinv = fast_rcp(M[0][4] + M[1][4]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) u[a] = M[a][4] * tinv;
+    double d2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v = dfma(R[a][k], u[k], v);
+      y[a] = v;
+    }
+    const double yinv = fast_rcp(y[0] + y[1]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const double d = y[a] * yinv - u[a];
+      d2 = dfma(d, d, d2);
+    }
+    if (active && d2 < tol2 && pivmax < 1e10 && done + 1 <= max_iter) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xp[a] = y[a] * yinv;
+      iters = done + 1;
+      status = QMPS_ST_OK;
+      active = false;
+    }
+  }
   int m = 0;
   auto square = [&]() {
     double Q[4][4];
@@ -422,7 +483,7 @@ __device__ __forceinline__ void squaring_tail_d2(const double (&are)[2][2][2], c
     }
   };
   // phase 1: `skip` squarings without tracking the iterate; the comparison chain then starts at z_skip
-  while (m < skip && done + (1 << (m + 1)) <= max_iter) {
+  while (m < skip && done + (1 << (m + 1)) <= max_iter && __any(active)) {
     square();
     ++m;
   }
@@ -592,7 +653,7 @@ __global__ __launch_bounds__(64) void energy_lane_kernel(LaneArgs p) {
     if (hybrid) {
       active = valid && status == QMPS_ST_NOT_CONVERGED;
       if (D == 2) {
-        if constexpr (D == 2) squaring_tail_d2(are, aim, rre, rim, active, iters, status, plain, p.max_iter, tol2, p.skip);
+        if constexpr (D == 2) squaring_tail_d2(are, aim, rre, rim, active, iters, status, plain, p.max_iter, tol2, p.skip, p.direct != 0);
       } else if (p.work_idx != nullptr) {
         // hand the slow items to the wave-per-item squaring kernel: wave-aggregated append
         const unsigned long long mask = __ballot(active);
@@ -1994,7 +2055,7 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
       }
     int iters = 0, status = QMPS_ST_NOT_CONVERGED;
     bool active = true;
-    squaring_tail_d2(are, aim, rre, rim, active, iters, status, 0, p.max_iter, tol2, p.skip);
+    squaring_tail_d2(are, aim, rre, rim, active, iters, status, 0, p.max_iter, tol2, p.skip, p.direct != 0);
     if (status == QMPS_ST_OK && !is_positive_definite<D>(rre, rim)) status = QMPS_ST_NOT_PD;
     double pre[4][4], pim[4][4];
     two_site_rdm<D>(are, aim, are, aim, rre, rim, pre, pim);

@@ -147,9 +147,16 @@ def test_direct_flag_errors(engine_factory):
     eng2 = engine_factory(2, 64)
     A2 = O.unitary_to_tensor(O.haar_unitaries(rng, 4, 8))
     E, it, st = eng2.energies(A2, O.hamiltonian_matrix({'ZZ': -1, 'X': 1}))
-    eng2.launch(solver='direct')                            # documented: D = 2 and 16 iterate
+    assert np.all(st == 0) and np.all(it == 1)              # D = 2: 4 x 4 solve in the lane, accepted by one power step
+    eng2.launch(solver='squaring')
     E2, it2, st2 = eng2.results()
     assert np.all(st2 == 0) and np.all(it2 > 1) and np.abs(E - E2).max() < E_TOL
+    eng16 = engine_factory(16, 64)
+    A16 = O.unitary_to_tensor(O.haar_unitaries(rng, 32, 4))
+    E16, it16, st16 = eng16.energies(A16, O.hamiltonian_matrix({'ZZ': -1, 'X': 1}))
+    eng16.launch(solver='direct')                           # documented: D = 16 iterates
+    _, it16b, st16b = eng16.results()
+    assert np.all(st16b == 0) and np.all(it16b > 1)
 
 
 @pytest.mark.parametrize('B', [1, 37, 768, 3000])
@@ -498,3 +505,46 @@ def test_energy_only_contraction_chain_d4(n_terms, engine_factory):
     rho = eng.rdm(B)
     for b in range(0, B, 307):
         assert np.abs(rho[b] - O.two_site_rdm(A[b], r[b])).max() < 1e-13
+
+
+def test_direct_d2(c_oracle, engine_factory):
+    """D = 2 (BASELINE.json configs[0], [1]): the 4 x 4 fixed-point solve in the lane.  Iteration counts of the power
+    method are heavy-tailed at D = 2 (p99.9 ~ 3000 plain steps, some Haar items do not converge in 10 000): the direct
+    solve accepts every one of them in one step.  Non-isometric tensors and product states take the squaring path."""
+    rng = np.random.default_rng(99)
+    B = 20000
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 4, B))
+    h = np.stack([O.hamiltonian_matrix({'ZZ': -1, 'X': 1}), O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})])
+    eng = engine_factory(2, 32768)
+    eng.set_solver('direct')
+    E, it, st = eng.energies(A, h)
+    r = eng.environments()
+    assert np.all(st == 0) and np.all(it == 1)
+    for b in range(0, B, 331):
+        rd, itd, std = O.env_direct(A[b])
+        assert (itd, std) == (1, 0) and np.abs(r[b] - rd).max() < 1e-12
+        assert np.abs(r[b] - O.env_dense_eig(A[b])[1]).max() < 1e-10
+        for t in range(2):
+            assert abs(E[b, t] - O.energy_closed_form(A[b], h[t], rd)) < 1e-12
+    eng.set_solver('squaring')
+    E2, it2, st2 = eng.energies(A, h)
+    both = st2 == 0
+    assert both.mean() > 0.99 and np.abs(E - E2)[both].max() < 1e-10 and it2.max() > 100
+    eng.set_solver('direct')
+    # tensors that are not isometries: rejected, the squaring tail takes over (iterations > 1), same fixed point as dense eig
+    bad = A[:200] * rng.uniform(0.6, 1.5, size=(200, 1, 1, 1)) + 0.05 * (rng.standard_normal((200, 2, 2, 2)) + 1j * rng.standard_normal((200, 2, 2, 2)))
+    rb, itb, stb = eng.env_batch(bad, max_iter=100000)
+    assert np.all(stb == 0) and np.all(itb > 1)
+    for b in range(0, 200, 9):
+        assert np.abs(rb[b] - O.env_dense_eig(bad[b])[1]).max() < 1e-10
+    # product state |00>: rank-one environment -> NOT_PD, energy -1 (ZZ = -1 on |00>)
+    Ep, itp, stp = eng.energies(np.eye(4, dtype=complex)[None], h[0], kind='unitary')
+    assert stp[0] == 2 and abs(Ep[0, 0] + 1.0) < 1e-12
+    # the device-resident rotosolve (every sweep of every restart in one kernel) runs the same solve
+    from qmps_amd import _lib
+    P0 = rng.standard_normal((64, 4))
+    eng.set_hamiltonian(h)
+    hist, pf = eng.rotosolve(_lib.ANSATZ_SHALLOW_CNOT, P0, 3)
+    for b in np.flatnonzero(~np.isnan(hist[-1]))[::7]:
+        Ab = O.unitary_to_tensor(O.shallow_cnot_unitary(2, pf[b])[None])[0]
+        assert abs(hist[-1][b] - sum(O.energy_closed_form(Ab, h[t]) for t in range(2))) < 1e-9

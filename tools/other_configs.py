@@ -40,7 +40,7 @@ def run(D, B, solver, reps=200):
 
 if __name__ == '__main__':
     out = []
-    for D, B, solver in ((2, 4096, 'squaring'), (2, 65536, 'squaring'),
+    for D, B, solver in ((2, 4096, 'direct'), (2, 65536, 'direct'), (2, 4096, 'squaring'), (2, 65536, 'squaring'),
                          (8, 96, 'direct'), (8, 768, 'direct'), (8, 65536, 'direct'),
                          (8, 96, 'plain'), (8, 768, 'plain'), (8, 65536, 'plain'),
                          (16, 96, 'squaring'), (16, 768, 'squaring'), (16, 16384, 'squaring'),

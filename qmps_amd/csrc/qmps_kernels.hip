@@ -375,6 +375,44 @@ __device__ __forceinline__ void unpack_herm(const double (&x)[D * D], double (&r
 
 // D = 2 only: repeated-squaring tail, one evaluation per lane.  R = T^(2^m) as a real 4 x 4 matrix in
 // registers, x_m = R x_C / tr, stop at ||x_m - x_{m-1}||^2 < tol^2;  iterations = done + 2^m.
+// The fixed point of a trace-preserving map at D = 2 from its real 4 x 4 matrix R (HermBasis<2> coordinates: r_00, r_11,
+// sqrt2 Re r_01, sqrt2 Im r_01): (R - 1 + e_1 t^T) u = e_1, t = the trace functional.  Trace preservation makes the two
+// DIAGONAL rows of R - 1 sum to zero, so the functional sits on one of them and that row is the last pivot (order 0, 2, 3, 1),
+// as at D = 4.  Unpivoted Gauss-Jordan in the lane; u comes back trace-normalised, pivmax = the largest |1 / pivot|
+// (above 1e10: the fixed point is not unique / the system is singular to rounding - do not trust u).
+__device__ __forceinline__ void direct_fixed_point_d2(const double (&R)[4][4], double (&u)[4], double& pivmax) {
+  double M[4][5];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) M[a][b] = R[a][b] - (a == b ? 1.0 : 0.0);
+    M[a][4] = a == 1 ? 1.0 : 0.0;
+  }
+  M[1][0] += 1.0;
+  M[1][1] += 1.0;
+  pivmax = 0.0;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int k = kk == 0 ? 0 : (kk == 1 ? 2 : (kk == 2 ? 3 : 1));
+    const double pinv = fast_rcp(M[k][k]);
+    pivmax = fmax(pivmax, fabs(pinv));
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+      if (b != k) M[k][b] *= pinv;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+      if (a != k) {
+        const double f = M[a][k];
+#pragma unroll
+        for (int b = 0; b < 5; ++b)
+          if (b != k) M[a][b] = dfma(-f, M[k][b], M[a][b]);
+      }
+  }
+  const double tinv = fast_rcp(M[0][4] + M[1][4]);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) u[a] = M[a][4] * tinv;
+}
+
 __device__ __forceinline__ void squaring_tail_d2(const double (&are)[2][2][2], const double (&aim)[2][2][2],
                                                  double (&rre)[2][2], double (&rim)[2][2], bool& active, int& iters,
                                                  int& status, int done, int max_iter, double tol2, int skip,
@@ -390,43 +428,10 @@ __device__ __forceinline__ void squaring_tail_d2(const double (&are)[2][2][2], c
 #pragma unroll
   for (int a = 0; a < 4; ++a) xp[a] = x0[a];
   if (direct) {
-    // QMPS_ENV_DIRECT at D = 2 (the same idea as at D = 4 and 8): for an isometry the fixed point solves the real 4 x 4
-    // system (R - 1 + e_1 t^T) u = e_1, t = the trace functional (coordinates 0, 1 are the diagonal r_00, r_11).  Trace
-    // preservation makes the two DIAGONAL rows of R - 1 sum to zero, so the functional has to sit on one of them, and that
-    // row is the last pivot (order 0, 2, 3, 1), as at D = 4.  Unpivoted Gauss-Jordan in the lane; accepted iff one power
-    // step moves it by less than tol (iterations = done + 1) and no pivot was below 1e-10 (a fixed point that is not
-    // unique); everything else goes on to the squaring below.
-    double M[4][5];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) M[a][b] = R[a][b] - (a == b ? 1.0 : 0.0);
-      M[a][4] = a == 1 ? 1.0 : 0.0;
-    }
-    M[1][0] += 1.0;
-    M[1][1] += 1.0;
-    double pivmax = 0.0;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int k = kk == 0 ? 0 : (kk == 1 ? 2 : (kk == 2 ? 3 : 1));
-      const double pinv = fast_rcp(M[k][k]);
-      pivmax = fmax(pivmax, fabs(pinv));
-#pragma unroll
-      for (int b = 0; b < 5; ++b)
-        if (b != k) M[k][b] *= pinv;
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-        if (a != k) {
-          const double f = M[a][k];
-#pragma unroll
-          for (int b = 0; b < 5; ++b)
-            if (b != k) M[a][b] = dfma(-f, M[k][b], M[a][b]);
-        }
-    }
-    double u[4], y[4];
-    const double tinv = fast_rcp(M[0][4] + M[1][4]);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) u[a] = M[a][4] * tinv;
+    // QMPS_ENV_DIRECT at D = 2: the 4 x 4 fixed-point solve; accepted iff one power step moves it by less than tol (iterations =
+    // done + 1) and no pivot was below 1e-10; everything else goes on to the squaring below.
+    double u[4], y[4], pivmax;
+    direct_fixed_point_d2(R, u, pivmax);
     double d2 = 0.0;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -963,6 +968,34 @@ __global__ __launch_bounds__(64) void cell2_lane_kernel(Cell2Args p) {
       rre[i][j] = (i == j) ? 1.0 / D : 0.0;
       rim[i][j] = 0.0;
     }
+  if constexpr (D == 2) {
+    // the fixed point of the two-site map T1 o T2 directly: its real matrix is R1 R2; the candidate becomes the start of the
+    // loop below, whose first step is then the acceptance test (iterations = 1).  The power method's iteration counts are
+    // heavy-tailed at D = 2 (some Haar cells do not converge in 10 000 steps)
+    auto getA1 = [&](int s, int i, int j) { return make_double2(a1re[s][i][j], a1im[s][i][j]); };
+    auto getA2 = [&](int s, int i, int j) { return make_double2(a2re[s][i][j], a2im[s][i][j]); };
+    double R1[4][4], R2[4][4], R[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        R1[a][c] = real_transfer_entry<2>(getA1, a, c);
+        R2[a][c] = real_transfer_entry<2>(getA2, a, c);
+      }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v = dfma(R1[a][k], R2[k][c], v);
+        R[a][c] = v;
+      }
+    double u[4], pivmax;
+    direct_fixed_point_d2(R, u, pivmax);
+    const bool good = pivmax < 1e10 && fabs(u[0]) < 1e300 && fabs(u[1]) < 1e300 && fabs(u[2]) < 1e300 && fabs(u[3]) < 1e300;
+    if (good) unpack_herm<2>(u, rre, rim);
+  }
   int iters = 0, status = QMPS_ST_NOT_CONVERGED;
   const double tol2 = p.tol * p.tol;
   for (int k = 1; k <= p.max_iter; ++k) {

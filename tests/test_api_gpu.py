@@ -145,6 +145,14 @@ def test_two_site_cell(golden, engine_factory):
     e = opt.objective_function(p)
     assert abs(e - O.two_site_cell_energy(G.SU(p[:15], 4), G.SU(p[15:], 4), h)) < 1e-10
     assert abs(opt.batch_objective_function(p[None])[0] - e) < 1e-12
+    # a large Haar batch: the fixed point of T1 o T2 comes from the 4 x 4 direct solve - every cell accepted in ONE step (the
+    # plain power method has a heavy tail at D = 2), energies against the oracle's circuits
+    B = 5000
+    U1, U2 = O.haar_unitaries(rng, 4, B), O.haar_unitaries(rng, 4, B)
+    Eb, itb, stb = eng.cell2_energies(U1, U2, h)
+    assert np.all(stb == 0) and np.all(itb == 1)
+    for b in range(0, B, 199):
+        assert abs(Eb[b, 0] - O.two_site_cell_energy(U1[b], U2[b], h)) < 1e-10
 
 
 def test_rotosolve_reaches_the_D2_ground_state():

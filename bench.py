@@ -452,7 +452,7 @@ def main():
                          '(--steps = sweeps, --batch = evaluations per parameter update)')
     ap.add_argument('--double-frequency', action='store_true', help='rotosolve workload: six shifts per parameter (qmps/tools.py:422-457)')
     # defaults: the chip needs tens of ms of sustained load before its clocks settle
-    ap.add_argument('--steps', type=int, default=450)
+    ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=450)
     ap.add_argument('--D', type=int, default=4)
     ap.add_argument('--batch', type=int, default=65536, help='evaluations per GPU per step (weak) or in all (strong)')
@@ -488,7 +488,7 @@ def main():
             args.max_iter = 60 if args.D in (2, 4) else 100000      # D = 2, 4: squarings; D = 8, 16: power steps
         return main_overlap(args)
     if args.workload == 'rotosolve':
-        if args.steps == 450:
+        if args.steps == 2000 and args.warmup == 450:
             args.steps, args.warmup = 160, 8
         return main_rotosolve(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -774,10 +774,18 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   qmps::LaneArgs a = make_args(c, B, max_iter, tol, true);
   if (warm_resident) a.r_in = win_r(c);
   if (direct8) {
-    // D = 8: the direct solve (one wave per evaluation) leaves its result in the environment buffer; the power
-    // iteration of the block kernel starts from it: its first step is the acceptance test, its loop the fall-back
-    HIP_TRY(qmps::launch_env_direct_d8(win_A(c), win_r(c), B, c->stream));
-    a.r_in = win_r(c);
+    // D = 8: the direct solve (one wave per evaluation) hands its result to the power iteration of the block kernel: its
+    // first step is the acceptance test, its loop the fall-back.  Small batches (all launch latency: BASELINE configs[3]
+    // is 96 evaluations per GPU) run both in ONE launch; large ones keep two kernels - the block kernel alone runs four
+    // waves per SIMD, the solve two.
+    static const int64_t fuse_below = getenv("QMPS_D8_FUSE_BELOW") ? atoll(getenv("QMPS_D8_FUSE_BELOW")) : 4096;   // A/B knob
+    if (B <= fuse_below) {
+      a.direct = 1;
+      a.r_in = nullptr;
+    } else {
+      HIP_TRY(qmps::launch_env_direct_d8(win_A(c), win_r(c), B, c->stream));
+      a.r_in = win_r(c);
+    }
   }
   const bool hybrid = solver == QMPS_ENV_POWER_SQUARING && c->D <= 4 && c->handoff < max_iter;
   c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;

@@ -20,6 +20,7 @@
 #include "qmps_device.h"
 #include "qmps_circuit.h"
 #include "qmps_direct_core.h"
+#include "qmps_direct_d8.h"
 
 namespace qmps {
 
@@ -555,18 +556,6 @@ hipError_t launch_cost_finish(const long long* acc, int n_shards, long long expe
   return hipGetLastError();
 }
 
-// One Gauss-Jordan update of the D = 8 cyclic layout (see env_direct_d8_kernel): column class entry T of the lane's four
-// rows, pivot row = local row KQ of lane KC of the same 16-lane DPP row.  The pivot row's own local row index goes last:
-// its registers are the DPP source of the other three.
-template <int KC, int KQ, int T>
-__device__ __forceinline__ void d8_update(double (&Mn)[4][16], const double (&nf)[4]) {
-#pragma unroll
-  for (int mm = 1; mm <= 4; ++mm) {
-    const int m = (KQ + mm) & 3;
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(Mn[m][T]) : "v"(Mn[KQ][T]), "v"(nf[m]), "n"(KC));
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // env_direct_d8_kernel: D = 8 direct fixed-point solve, ONE WAVE PER EVALUATION, one ROW of the real 64 x 64 system
 // per lane.  Lane a = 8 i + i' owns coordinate u[(i,i')] (r_ii | Re r_ii' for i < i' | Im r_i'i for i > i') and row a
@@ -582,9 +571,7 @@ __global__ __launch_bounds__(64, 2) void env_direct_d8_kernel(const double2* __r
   constexpr int D = 8, N = 64, P = D + 1;
   __shared__ double2 sA[2][D][P];
   __shared__ double sT[D][P];
-#ifndef QMPS_D8_READLANE
   __shared__ double sM[N][17];
-#endif
   const int lane = threadIdx.x, i = lane >> 3, ip = lane & 7;
   const int64_t b = blockIdx.x;
   if (b >= B) return;
@@ -595,195 +582,7 @@ __global__ __launch_bounds__(64, 2) void env_direct_d8_kernel(const double2* __r
   }
   __builtin_amdgcn_wave_barrier();
   __syncthreads();
-  double M[N];
-  {
-    // row (i, i') of the real transfer matrix: P(j,j') = sum_s (gamma A_s[i][j]) conj(A_s[i'][j']), gamma = 1 (i <= i') | i (i > i')
-    const bool rot = i > ip;
-    double tr[2][D], ti[2][D], br[2][D], bi[2][D];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        const double2 a = sA[s][i][j], c = sA[s][ip][j];
-        tr[s][j] = rot ? -a.y : a.x;
-        ti[s][j] = rot ? a.x : a.y;
-        br[s][j] = c.x;
-        bi[s][j] = c.y;
-      }
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      double v = tr[0][j] * br[0][j];
-      v = dfma(ti[0][j], bi[0][j], v);
-      v = dfma(tr[1][j], br[1][j], v);
-      v = dfma(ti[1][j], bi[1][j], v);
-      M[9 * j] = v;
-    }
-#pragma unroll
-    for (int lo = 0; lo < D; ++lo)
-#pragma unroll
-      for (int hi = lo + 1; hi < D; ++hi) {
-        double re = tr[0][lo] * br[0][hi], im = tr[0][lo] * bi[0][hi];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if (s > 0) {
-            re = dfma(tr[s][lo], br[s][hi], re);
-            im = dfma(tr[s][lo], bi[s][hi], im);
-          }
-          re = dfma(ti[s][lo], bi[s][hi], re);
-          re = dfma(tr[s][hi], br[s][lo], re);
-          re = dfma(ti[s][hi], bi[s][lo], re);
-          im = dfma(-ti[s][lo], br[s][hi], im);
-          im = dfma(ti[s][hi], br[s][lo], im);
-          im = dfma(-tr[s][hi], bi[s][lo], im);
-        }
-        M[8 * lo + hi] = re;
-        M[8 * hi + lo] = im;
-      }
-    // - identity (column = the lane's own index), + trace functional on the last row
-    const double w63 = lane == N - 1 ? 1.0 : 0.0;
-#pragma unroll
-    for (int c = 0; c < N; ++c) M[c] -= (lane == c ? 1.0 : 0.0);
-#pragma unroll
-    for (int j = 0; j < D; ++j) M[9 * j] += w63;
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#ifdef QMPS_D8_READLANE
-  double dinv = 0.0, y = 0.0;
-  // the pivot row travels through SCALAR registers: v_readlane_b32 (lane k is a compile-time constant) puts each of
-  // its entries in an SGPR pair, which v_fma_f64 takes as an operand - no LDS round trip, no vector registers for the
-  // row, no latency between the steps beyond the reciprocal (measured: 41.8 us per launch with the row parked in LDS)
-  auto from_lane = [](double v, int src) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-  };
-  static_for<N>([&](auto K) {
-    constexpr int k = decltype(K)::value;
-    const double pk = from_lane(M[k], k);
-    const double pinv = fast_rcp(pk);
-    dinv = lane == k ? pinv : dinv;
-    const double f = lane == k ? 0.0 : M[k] * pinv;
-    // sixteen entries at a time: 32 scalar reads, then 16 FMAs (a v_fmac right behind the v_readlane that feeds it
-    // would wait out the SGPR hazard with s_nops)
-#pragma unroll
-    for (int j0 = k + 1; j0 < N; j0 += 16) {
-      double pv[16];
-#pragma unroll
-      for (int t = 0; t < 16; ++t)
-        if (j0 + t < N) pv[t] = from_lane(M[j0 + t], k);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 16; ++t)
-        if (j0 + t < N) M[j0 + t] = dfma(-f, pv[t], M[j0 + t]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (k == N - 1) y = -f;
-  });
-  y = lane == N - 1 ? 1.0 : y;
-  const double x = y * dinv;
-#else
-  // ---- elimination in a 2-D cyclic layout: lane (g, c) = (lane >> 4, lane & 15) holds rows c + 16 m (m < 4) x columns
-  // g + 4 t (t < 16).  Step k: the pivot row's entries of the lane's column class sit in lane k % 16 OF THE SAME
-  // 16-LANE DPP ROW, so the update is ONE instruction per entry - v_fmac_f64_dpp row_newbcast (gfx90a+ 64-bit DPP, full
-  // FMA rate measured: tools/scratch/dpp64_probe.hip) - with no separate broadcast (the row-per-lane layout spends two
-  // v_readlane_b32 per FMA).  The multipliers (column k of the lane's four rows) come from the same c in row group
-  // k % 4 (ds_bpermute), and are the same in all four row groups.  ~3 800 instead of ~7 200 instructions per evaluation.
-  double Mn[4][16];
-  {
-    // row-per-lane -> cyclic layout through LDS, a quarter of the columns at a time (8.5 KB)
-    const int g = lane >> 4, c = lane & 15;
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) sM[lane][jj] = M[16 * qt + jj];
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) Mn[m][4 * qt + tt] = sM[c + 16 * m][g + 4 * tt];
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  double x;
-  {
-    const int c = lane & 15;
-    double dinv[4] = {0.0, 0.0, 0.0, 0.0}, yv[4] = {0.0, 0.0, 0.0, 0.0};
-    auto from_lane = [](double v, int src) {
-      const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-      const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-      return __hiloint2double(hi, lo);
-    };
-    // Software pipeline: step k first updates the column class that holds column k + 1, then fetches step k + 1's pivot
-    // and multipliers (v_readlane + v_rcp_f64, ds_bpermute: ~150 cycles of latency) and only then the rest of its own
-    // updates, which cover that latency (one wave per SIMD at small batches: nothing else would).
-    double pinv = fast_rcp(from_lane(Mn[0][0], 0)), colk[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) colk[m] = __shfl(Mn[m][0], c, 64);
-    static_for<N>([&](auto K) {
-      constexpr int k = decltype(K)::value, kc = k & 15, kq = k >> 4, tk = k >> 2;
-      constexpr int k1 = k + 1, kc1 = k1 & 15, kq1 = (k1 >> 4) & 3, gk1 = k1 & 3, tk1 = (k1 >> 2) & 15;
-      double nf[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const bool piv = m == kq && c == kc;
-        dinv[m] = piv ? pinv : dinv[m];
-        nf[m] = piv ? 0.0 : -colk[m] * pinv;
-      }
-      // columns t >= k / 4: the lane's columns g + 4 t > k and up to three already eliminated ones (the pivot row holds
-      // rounding-level residues there; those columns are never read again).  The pivot row's own local row index last: its
-      // registers are the DPP source of the other three.
-      if constexpr (k1 < N) {
-        d8_update<kc, kq, tk1>(Mn, nf);
-        __builtin_amdgcn_sched_barrier(0);
-        pinv = fast_rcp(from_lane(Mn[kq1][tk1], 16 * gk1 + kc1));
-#pragma unroll
-        for (int m = 0; m < 4; ++m) colk[m] = __shfl(Mn[m][tk1], 16 * gk1 + c, 64);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      static_for<16>([&](auto T) {
-        constexpr int t = decltype(T)::value;
-        if constexpr (t >= tk && !(k1 < N && t == tk1)) d8_update<kc, kq, t>(Mn, nf);
-      });
-      if (k == N - 1) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) yv[m] = nf[m];
-      }
-    });
-    // coordinate a = c + 16 m: the four row groups hold the same values; row group 0 hands them out through LDS
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 16) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int a = c + 16 * m;
-        sT[a >> 3][a & 7] = (a == N - 1 ? 1.0 : yv[m]) * dinv[m];
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    x = sT[i][ip];
-    // singular to rounding (a fixed point that is not unique, see DirectD4::kMaxInversePivot): let the power iteration of
-    // the energy kernel decide, from its default start
-    const bool tiny = fabs(dinv[0]) > 1e10 || fabs(dinv[1]) > 1e10 || fabs(dinv[2]) > 1e10 || fabs(dinv[3]) > 1e10;
-    if (__any(tiny)) x = __builtin_nan("");
-  }
-#endif
-  // coordinates -> complex r[i][i']: the transposed coordinate comes through LDS; trace 1; a non-finite solve -> 1/8
-  __builtin_amdgcn_wave_barrier();
-  sT[i][ip] = x;
-  __builtin_amdgcn_wave_barrier();
-  const double xt = sT[ip][i];
-  const double tr = wave_sum(i == ip ? x : 0.0);
-  const bool good = fabs(tr) > 1e-300 && fabs(tr) < 1e300;      // wave-uniform; NaN fails
-  const double inv = good ? 1.0 / tr : 0.0;
-  double re = i <= ip ? x : xt, im = i == ip ? 0.0 : (i < ip ? xt : -x);
-  re *= inv;
-  im *= inv;
-  const bool fin = __all(fabs(re) < 1e300 && fabs(im) < 1e300) && good;
-  if (!fin) {
-    re = i == ip ? 1.0 / D : 0.0;
-    im = 0.0;
-  }
-  r_out[b * N + lane] = make_double2(re, im);
+  r_out[b * N + lane] = env_direct_d8_solve(sA, sT, sM, lane);
 }
 
 hipError_t launch_env_direct_d8(const void* A, void* r_out, int64_t B, hipStream_t st) {

@@ -32,6 +32,7 @@
 #include "qmps_kernels.h"
 #include "qmps_device.h"
 #include "qmps_circuit.h"
+#include "qmps_direct_d8.h"
 
 namespace qmps {
 
@@ -1565,7 +1566,10 @@ __device__ __forceinline__ double block_sum(double v, double* red, int tid) {
   return v;
 }
 
-template <int D, bool SOLVE>
+// FUSED8 (D = 8, SOLVE): the direct fixed-point solve (qmps_direct_d8.h) runs in front, in the same wave - solve, acceptance
+// step and energies in ONE launch (the small batches of BASELINE.json configs[3] are all launch latency).  A separate
+// instantiation: the solve needs ~190 VGPRs, the plain block kernel runs four waves per SIMD.
+template <int D, bool SOLVE, bool FUSED8 = false>
 __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
   constexpr int N = D * D;
   constexpr int P = D + 1;  // padded row (in double2 units) against bank conflicts
@@ -1586,7 +1590,13 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
     sA[1][i][j] = a[N + tid];
   }
   double2 r;
-  if (p.r_in != nullptr) {
+  if constexpr (FUSED8) {
+    __shared__ double sM8[64][17];
+    __shared__ double sT8[8][9];
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    r = env_direct_d8_solve(sA, sT8, sM8, tid);
+  } else if (p.r_in != nullptr) {
     const double2* g = (const double2*)p.r_in + b * N;
     const double2 u = g[i * D + j], l = g[j * D + i];
     r = make_double2(0.5 * (u.x + l.x), (i == j) ? 0.0 : 0.5 * (u.y - l.y));
@@ -2923,7 +2933,9 @@ static hipError_t launch_lane(const LaneArgs& a, bool solve, hipStream_t st) {
 
 template <int D>
 static hipError_t launch_block(const LaneArgs& a, bool solve, hipStream_t st) {
-  if (solve)
+  if (solve && D == 8 && a.direct != 0) {
+    if constexpr (D == 8) hipLaunchKernelGGL((energy_block_kernel<8, true, true>), dim3((unsigned)a.B), dim3(64), 0, st, a);
+  } else if (solve)
     hipLaunchKernelGGL((energy_block_kernel<D, true>), dim3((unsigned)a.B), dim3(D * D), 0, st, a);
   else
     hipLaunchKernelGGL((energy_block_kernel<D, false>), dim3((unsigned)a.B), dim3(D * D), 0, st, a);

@@ -612,12 +612,8 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
         c->ans_have = true; c->ans_kind = kind; c->ans_P = n_params; c->ans_src = d_base; c->ans_i = d_idx; c->ans_nsh = shifts;
         c->tensors_valid = false;
       } else {
-        const double* rows = d_base;
-        if (shifts > 0) {
-          HIP_TRY(qmps::launch_roto_shift(d_base, c->d_params, (int)R, n_params, d_idx, shifts, c->stream));
-          rows = c->d_params;
-        }
-        HIP_TRY(qmps::launch_ansatz(c->D, kind, rows, n_params, c->d_A, n, c->stream));
+        // shifted tensors straight from the base vectors (the shift build is folded into the ansatz kernel)
+        HIP_TRY(qmps::launch_ansatz_shifted(c->D, kind, d_base, n_params, c->d_A, n, shifts, d_idx, c->stream));
         c->ans_have = false; c->tensors_valid = true;
       }
       c->n_states = n;

@@ -146,6 +146,9 @@ hipError_t launch_cell2(int D, const Cell2Args& a, hipStream_t st);
 hipError_t launch_energy(int D, const LaneArgs& a, bool solve, hipStream_t st);
 // ansatz parameters [B][n_params] -> state tensors A [B][2][D][D]; kind: 0 ShallowCNOT, 1 QAOA, 2 ShallowFull (D=2), 3 ShallowCNOT3
 hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, void* A, int64_t B, hipStream_t st);
+// the same for rotosolve shift batches: B = nsh R evaluations, evaluation nsh r + k = row r with shift k on parameter *i_ptr
+hipError_t launch_ansatz_shifted(int D, int kind, const double* params, int n_params, void* A, int64_t B, int nsh, const int* i_ptr,
+                                 hipStream_t st);
 // time-evolution overlap (D = 2): dominant eigenvalue of the mixed two-site transfer map
 struct OverlapArgs {
   const void* A;     // [B or 1][2][2][2] current state tensor(s)
@@ -182,7 +185,6 @@ hipError_t launch_opt_env(const double* params, const void* h, double k, double*
                           hipStream_t st);
 // i_ptr[0] = index of the parameter being updated, i_ptr[1] = arrival counter (both zero-initialised)
 // nsh = 3: single-frequency rotosolve (shifts 0, +-pi/2); nsh = 6: double-frequency (0, pi, +-pi/2, +-pi/4)
-hipError_t launch_roto_shift(const double* base, double* out, int R, int P, const int* i_ptr, int nsh, hipStream_t st);
 hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int* i_ptr, int n_terms,
                               int nsh, hipStream_t st);
 hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, const int* sweep_ptr, hipStream_t st);

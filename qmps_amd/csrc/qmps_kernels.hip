@@ -1845,21 +1845,31 @@ __global__ __launch_bounds__(256) void unitary_to_tensor_kernel(const double2* _
 // ------------------------------------------------------------------------------------------
 // (Reg<NQ>, ansatz_circuit, roto_shift_value: qmps_circuit.h)
 template <int D, int KIND>
+// nsh > 0: rotosolve shift batches without a separate shift-build kernel - evaluation b = nsh r + k is restart r (parameter
+// row r) with shift k added to parameter *i_ptr
 __global__ __launch_bounds__(64) void ansatz_tensor_kernel(const double* __restrict__ params, int n_params,
-                                                           double2* __restrict__ A, int64_t B) {
+                                                           double2* __restrict__ A, int64_t B, int nsh,
+                                                           const int* __restrict__ i_ptr) {
   constexpr int NQ = (D == 2 ? 2 : D == 4 ? 3 : D == 8 ? 4 : 5);
   const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const int64_t b = t / D;
   const int j = (int)(t % D);
   if (b >= B) return;
-  const double* pp = params + b * n_params;
+  const int64_t row = nsh > 0 ? b / nsh : b;
+  const int shift_k = nsh > 0 ? (int)(b - row * nsh) : 0;
+  const int isel = nsh > 0 ? *i_ptr : -1;
+  const double* pp = params + row * n_params;
   Reg<NQ> r;
 #pragma unroll
   for (int x = 0; x < Reg<NQ>::N; ++x) {
     r.re[x] = (x == j) ? 1.0 : 0.0;
     r.im[x] = 0.0;
   }
-  ansatz_circuit<NQ, KIND>(r, [&](int l) { return pp[l]; }, n_params);
+  ansatz_circuit<NQ, KIND>(r, [&](int l) {
+    double v = pp[l];
+    if (l == isel) v += roto_shift_value(nsh, shift_k);
+    return v;
+  }, n_params);
   // A[b][s][i][j] = amplitude[2 i + s]
   double2* out = A + b * (2 * D * D);
 #pragma unroll
@@ -1867,31 +1877,36 @@ __global__ __launch_bounds__(64) void ansatz_tensor_kernel(const double* __restr
 }
 
 template <int D>
-static hipError_t launch_ansatz_d(int kind, const double* params, int n_params, void* A, int64_t B, hipStream_t st) {
+static hipError_t launch_ansatz_d(int kind, const double* params, int n_params, void* A, int64_t B, int nsh, const int* i_ptr, hipStream_t st) {
   const int64_t threads = B * D;
   const dim3 grid((unsigned)((threads + 63) / 64)), block(64);
   switch (kind) {
-    case 0: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 0>), grid, block, 0, st, params, n_params, (double2*)A, B); break;
-    case 1: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 1>), grid, block, 0, st, params, n_params, (double2*)A, B); break;
+    case 0: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 0>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr); break;
+    case 1: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 1>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr); break;
     case 2:
       if (D != 2) return hipErrorInvalidValue;
-      hipLaunchKernelGGL((ansatz_tensor_kernel<2, 2>), grid, block, 0, st, params, n_params, (double2*)A, B);
+      hipLaunchKernelGGL((ansatz_tensor_kernel<2, 2>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr);
       break;
-    case 3: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 3>), grid, block, 0, st, params, n_params, (double2*)A, B); break;
+    case 3: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 3>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, void* A, int64_t B, hipStream_t st) {
+hipError_t launch_ansatz_shifted(int D, int kind, const double* params, int n_params, void* A, int64_t B, int nsh, const int* i_ptr,
+                                 hipStream_t st) {
   if (B <= 0) return hipSuccess;
   switch (D) {
-    case 2: return launch_ansatz_d<2>(kind, params, n_params, A, B, st);
-    case 4: return launch_ansatz_d<4>(kind, params, n_params, A, B, st);
-    case 8: return launch_ansatz_d<8>(kind, params, n_params, A, B, st);
-    case 16: return launch_ansatz_d<16>(kind, params, n_params, A, B, st);
+    case 2: return launch_ansatz_d<2>(kind, params, n_params, A, B, nsh, i_ptr, st);
+    case 4: return launch_ansatz_d<4>(kind, params, n_params, A, B, nsh, i_ptr, st);
+    case 8: return launch_ansatz_d<8>(kind, params, n_params, A, B, nsh, i_ptr, st);
+    case 16: return launch_ansatz_d<16>(kind, params, n_params, A, B, nsh, i_ptr, st);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, void* A, int64_t B, hipStream_t st) {
+  return launch_ansatz_shifted(D, kind, params, n_params, A, B, 0, nullptr, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1900,20 +1915,6 @@ hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, vo
 //   theta* = -pi/2 - atan2(2 e0 - e+ - e-, e+ - e-),  params[i] = wrap(params[i] + wrap(theta*))
 // runs on the device, so a whole sweep needs no host round trip.
 // ------------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(256) void roto_shift_kernel(const double* __restrict__ base, double* __restrict__ out, int R,
-                                                         int P, const int* __restrict__ i_ptr, int nsh) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)R * nsh * P) return;
-  const int i = *i_ptr;   // parameter being updated: lives in HBM so ONE captured hipGraph serves all of them
-  const int col = (int)(t % P);
-  const int64_t row = t / P;
-  const int k = (int)(row % nsh);
-  const int64_t r = row / nsh;
-  double v = base[r * P + col];
-  if (col == i) v += roto_shift_value(nsh, k);
-  out[t] = v;
-}
 
 __device__ __forceinline__ double wrap_pi(double x) { return atan2(sin(x), cos(x)); }
 
@@ -2032,11 +2033,6 @@ __global__ __launch_bounds__(256) void roto_record_kernel(const double* __restri
   hist[sw * R + r] = v;
 }
 
-hipError_t launch_roto_shift(const double* base, double* out, int R, int P, const int* i_ptr, int nsh, hipStream_t st) {
-  const int64_t n = (int64_t)R * nsh * P;
-  hipLaunchKernelGGL(roto_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, base, out, R, P, i_ptr, nsh);
-  return hipGetLastError();
-}
 hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int* i_ptr, int n_terms,
                               int nsh, hipStream_t st) {
   hipLaunchKernelGGL(roto_update_kernel, dim3((R + 255) / 256), dim3(256), 0, st, base, E, status, R, P, i_ptr, n_terms, nsh);

@@ -422,7 +422,7 @@ def main_rotosolve(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        evals = sweeps * (P * nsh * R + R)          # shifted batches + the evaluation recorded after each sweep
+        evals = sweeps * P * nsh * R + R            # shifted batches (a sweep's record comes from the next sweep's shift-0 rows) + the final evaluation
         out = {'metric': f'rotosolve energy evals/sec at D={D}, {R} restarts x {nsh} shifts', 'value': world * evals / elapsed,
                'unit': 'two-site energy evals/s', 'n_gpus': world, 'steps': sweeps, 'warmup': sweeps_w,
                'ms_per_step': elapsed / sweeps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,

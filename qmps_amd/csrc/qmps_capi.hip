@@ -619,19 +619,19 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
       c->n_states = n;
       return qmps_energy_launch(c, n, max_iter, tol, c->default_solver);
     };
-    auto one_update = [&]() -> int {
+    auto one_update = [&](bool first_of_sweep) -> int {
       if (int e = evaluate(nsh)) return e;
+      // the shift-0 row of a sweep's first batch is the evaluation of the vectors the PREVIOUS sweep left: its record
+      if (first_of_sweep) HIP_TRY(qmps::launch_roto_record(c->d_E, d_hist, (int)R, c->n_terms, d_idx + 2, nsh, c->stream));
       HIP_TRY(qmps::launch_roto_update(d_base, c->d_E, c->d_status, (int)R, n_params, d_idx, c->n_terms, nsh, c->stream));
       return QMPS_OK;
     };
-    // One sweep = n_params updates + the evaluation of the updated vectors + its record.  The parameter index and the
+    // One sweep = n_params updates (the first one also records the previous sweep from its shift-0 rows).  The parameter index and the
     // sweep counter live in HBM and are advanced by the update kernel, so the sweep is captured ONCE into a hipGraph and
     // replayed n_sweeps times (a graph launch costs ~15 us: per update it was a third of the time, per sweep it is noise)
     auto one_sweep = [&]() -> int {
       for (int i = 0; i < n_params; ++i)
-        if (int e = one_update()) return e;
-      if (int e = evaluate(0)) return e;
-      HIP_TRY(qmps::launch_roto_record(c->d_E, d_hist, (int)R, c->n_terms, d_idx + 2, c->stream));
+        if (int e = one_update(i == 0)) return e;
       return QMPS_OK;
     };
     const bool use_graph = getenv("QMPS_NO_GRAPH") == nullptr && n_params <= 256;
@@ -659,6 +659,9 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
       if (use_graph) HIP_TRY(hipGraphLaunch(c->roto_exec, c->stream));
       else if (int e = one_sweep()) return e;
     }
+    // the last sweep's record, and the resident state the call leaves: one evaluation of the final vectors
+    if (int e = evaluate(0)) return e;
+    HIP_TRY(qmps::launch_roto_record(c->d_E, d_hist, (int)R, c->n_terms, d_idx + 2, 1, c->stream));
     // The context's view of what is resident - a replayed graph runs no host code, so it is stated here, not inherited from
     // the capture: the R final parameter vectors, their energies / statuses / environments
     c->n_states = R;

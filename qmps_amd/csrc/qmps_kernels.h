@@ -187,7 +187,7 @@ hipError_t launch_opt_env(const double* params, const void* h, double k, double*
 // nsh = 3: single-frequency rotosolve (shifts 0, +-pi/2); nsh = 6: double-frequency (0, pi, +-pi/2, +-pi/4)
 hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int* i_ptr, int n_terms,
                               int nsh, hipStream_t st);
-hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, const int* sweep_ptr, hipStream_t st);
+hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, const int* sweep_ptr, int stride, hipStream_t st);
 hipError_t launch_unitary_to_tensor(const void* U, void* A, int D, int64_t B, hipStream_t st);
 hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, int n_partial, double* cost,
                       hipStream_t st);

@@ -2023,13 +2023,17 @@ __global__ __launch_bounds__(256) void roto_update_kernel(double* __restrict__ b
 
 // sweep_ptr (nullable): device counter of finished sweeps (advanced by the update kernel that wraps the parameter index):
 // the record of sweep n lands in hist[(n - 1) R ...], so ONE captured graph serves every sweep
+// stride: evaluations per restart in E (1: the R base vectors; nsh: a shifted batch, whose shift-0 row IS the evaluation of the
+// base vector - the record of a sweep is taken from the first shifted batch of the NEXT one, so a sweep costs n_params
+// batches, not n_params + 1); nothing is written before the first sweep has finished
 __global__ __launch_bounds__(256) void roto_record_kernel(const double* __restrict__ E, double* __restrict__ hist, int R,
-                                                          int n_terms, const int* __restrict__ sweep_ptr) {
+                                                          int n_terms, const int* __restrict__ sweep_ptr, int stride) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
-  double v = 0.0;
-  for (int q = 0; q < n_terms; ++q) v += E[(int64_t)r * n_terms + q];
   const int64_t sw = sweep_ptr != nullptr ? (int64_t)(*sweep_ptr - 1) : 0;
+  if (sw < 0) return;
+  double v = 0.0;
+  for (int q = 0; q < n_terms; ++q) v += E[(int64_t)r * stride * n_terms + q];
   hist[sw * R + r] = v;
 }
 
@@ -2038,8 +2042,8 @@ hipError_t launch_roto_update(double* base, const double* E, const int32_t* stat
   hipLaunchKernelGGL(roto_update_kernel, dim3((R + 255) / 256), dim3(256), 0, st, base, E, status, R, P, i_ptr, n_terms, nsh);
   return hipGetLastError();
 }
-hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, const int* sweep_ptr, hipStream_t st) {
-  hipLaunchKernelGGL(roto_record_kernel, dim3((R + 255) / 256), dim3(256), 0, st, E, hist, R, n_terms, sweep_ptr);
+hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, const int* sweep_ptr, int stride, hipStream_t st) {
+  hipLaunchKernelGGL(roto_record_kernel, dim3((R + 255) / 256), dim3(256), 0, st, E, hist, R, n_terms, sweep_ptr, stride);
   return hipGetLastError();
 }
 

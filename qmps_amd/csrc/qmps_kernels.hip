@@ -2132,6 +2132,8 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
       int st;
       evaluate(i, shift, e, st);
       const double e0 = quad_bcast(e, 0), ep = quad_bcast(e, 1), em = quad_bcast(e, 2);
+      // the unshifted evaluation of a sweep's first parameter IS the energy at the parameters the previous sweep left
+      if (i == 0 && sw > 0 && valid && k == 0) p.hist[(int64_t)(sw - 1) * p.R + r] = e0;
       const double okv = (st == QMPS_ST_OK || k == 3) ? 1.0 : 0.0;
       const bool ok = quad_bcast(okv, 0) * quad_bcast(okv, 1) * quad_bcast(okv, 2) != 0.0;
       __builtin_amdgcn_wave_barrier();
@@ -2141,10 +2143,12 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
       }
       __builtin_amdgcn_wave_barrier();
     }
+  }
+  {
     double e;
     int st;
-    evaluate(-1, 0.0, e, st);                     // energy at the swept parameters (the reference records eps(params))
-    if (valid && k == 0) p.hist[(int64_t)sw * p.R + r] = e;
+    evaluate(-1, 0.0, e, st);                     // energy at the swept parameters (the reference records eps(params)): last sweep
+    if (valid && k == 0) p.hist[(int64_t)(p.n_sweeps - 1) * p.R + r] = e;
   }
   __builtin_amdgcn_wave_barrier();
   if (valid)

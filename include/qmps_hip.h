@@ -164,7 +164,7 @@ int qmps_set_states_ansatz(qmps_ctx* ctx, int64_t B, int kind, int n_params, con
  * A whole sweep (n_params updates, the evaluation of the updated vectors, its record) is ONE hipGraph launch.  D = 4
  * with the direct solver: two kernels per parameter update - the energy kernel, which builds evaluation 3 r + k's
  * tensor from restart r's parameters with shift k added to the parameter being updated, and the update kernel.
- * D = 2: every sweep of every restart inside one kernel launch. */
+ * D = 2: every sweep of every restart inside one kernel launch (qmps_double_rotosolve too). */
 int qmps_rotosolve(qmps_ctx* ctx, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter,
                    double tol, double* E_hist);
 /* Device-resident DOUBLE-frequency rotosolve (qmps/tools.py:422-457, what Optimizer.optimize('Rotosolve') runs): per

@@ -583,13 +583,13 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     // D = 2 with the library's default solver: the whole run is ONE launch (restarts are independent, see
     // rotosolve_fused_d2_kernel); afterwards one ordinary evaluation of the final parameters leaves the context's
     // resident tensors / energies / statuses exactly as the step-by-step path does.
-    if (nsh == 3 && c->D == 2 && c->handoff == 0 && (c->default_solver == QMPS_ENV_POWER_SQUARING || c->default_solver == QMPS_ENV_DIRECT) && n_params <= 64 &&
+    if ((nsh == 3 || nsh == 6) && c->D == 2 && c->handoff == 0 && (c->default_solver == QMPS_ENV_POWER_SQUARING || c->default_solver == QMPS_ENV_DIRECT) && n_params <= 64 &&
         getenv("QMPS_NO_FUSED_ROTO") == nullptr) {
       qmps::RotoArgs ra;
       memset(&ra, 0, sizeof(ra));
       ra.base = d_base; ra.h = c->d_h; ra.hist = d_hist;
       ra.R = (int)R; ra.P = n_params; ra.n_terms = c->n_terms; ra.n_sweeps = n_sweeps; ra.max_iter = max_iter;
-      ra.skip = c->skip_rounds; ra.tol = tol; ra.direct = c->default_solver == QMPS_ENV_DIRECT ? 1 : 0;
+      ra.skip = c->skip_rounds; ra.tol = tol; ra.direct = c->default_solver == QMPS_ENV_DIRECT ? 1 : 0; ra.nsh = nsh;
       HIP_TRY(qmps::launch_rotosolve_fused_d2(kind, ra, c->stream));
       HIP_TRY(qmps::launch_ansatz(c->D, kind, d_base, n_params, c->d_A, R, c->stream));
       c->n_states = R; c->ans_have = false; c->tensors_valid = true;

@@ -124,6 +124,7 @@ struct RotoArgs {
   int R, P, n_terms, n_sweeps, max_iter, skip;
   double tol;
   int direct;     // QMPS_ENV_DIRECT: try the 4 x 4 fixed-point solve before squaring
+  int nsh;        // 3: single-frequency rotosolve, 6: double-frequency
 };
 hipError_t launch_rotosolve_fused_d2(int kind, const RotoArgs& a, hipStream_t st);
 

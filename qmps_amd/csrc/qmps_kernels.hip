@@ -2055,7 +2055,10 @@ hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms,
 // order: bit-identical energies), exchanges the three energies by DPP and applies the closed-form update to the restart's
 // parameter vector in LDS.  One launch replaces (4 kernels + graph replay) x n_params x n_sweeps.
 // ------------------------------------------------------------------------------------------
-template <int KIND>
+// NSH = 3: shifts {0, +pi/2, -pi/2}, closed-form update (qmps/rotosolve.py:154-181);  NSH = 6: the double-frequency rotosolve
+// of Optimizer.optimize('Rotosolve') (qmps/tools.py:422-457) - lanes 0..2 evaluate shifts k and k + 3 of {0, pi, +-pi/2, +-pi/4},
+// lane 0 fits a sin 2x + b cos 2x + c sin x + d cos x and moves the parameter to its global minimiser (not re-wrapped).
+template <int KIND, int NSH>
 __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
   constexpr int D = 2;
   extern __shared__ double sP[];                 // [16 restarts][P]
@@ -2068,7 +2071,8 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
   for (int l = k; l < P; l += 4) mine[l] = p.base[(int64_t)rr * P + l];
   __builtin_amdgcn_wave_barrier();
   const double tol2 = p.tol * p.tol;
-  const double shift = k == 1 ? 1.5707963267948966 : (k == 2 ? -1.5707963267948966 : 0.0);
+  const double shift = roto_shift_value(NSH, k > 2 ? 0 : k);            // lane 3 idles along with shift 0
+  const double shift2 = NSH == 6 ? roto_shift_value(6, k > 2 ? 3 : k + 3) : 0.0;
 
   // one evaluation at (params + delta e_i): summed energy over the Hamiltonian terms, status
   auto evaluate = [&](int i, double delta, double& e_out, int& status_out) {
@@ -2134,12 +2138,30 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
       const double e0 = quad_bcast(e, 0), ep = quad_bcast(e, 1), em = quad_bcast(e, 2);
       // the unshifted evaluation of a sweep's first parameter IS the energy at the parameters the previous sweep left
       if (i == 0 && sw > 0 && valid && k == 0) p.hist[(int64_t)(sw - 1) * p.R + r] = e0;
-      const double okv = (st == QMPS_ST_OK || k == 3) ? 1.0 : 0.0;
+      double okv = (st == QMPS_ST_OK || k == 3) ? 1.0 : 0.0;
+      double e3 = 0.0, e4 = 0.0, e5 = 0.0;
+      if constexpr (NSH == 6) {
+        double f;
+        int st2;
+        evaluate(i, shift2, f, st2);
+        e3 = quad_bcast(f, 0);
+        e4 = quad_bcast(f, 1);
+        e5 = quad_bcast(f, 2);
+        okv = (okv != 0.0 && (st2 == QMPS_ST_OK || k == 3)) ? 1.0 : 0.0;
+      }
       const bool ok = quad_bcast(okv, 0) * quad_bcast(okv, 1) * quad_bcast(okv, 2) != 0.0;
       __builtin_amdgcn_wave_barrier();
       if (ok && k == 0) {      // (an evaluation without a valid environment leaves this restart's parameter untouched)
-        const double theta = -1.5707963267948966 - atan2(2.0 * e0 - ep - em, ep - em);
-        mine[i] = wrap_pi(mine[i] + wrap_pi(theta));
+        if constexpr (NSH == 3) {
+          const double theta = -1.5707963267948966 - atan2(2.0 * e0 - ep - em, ep - em);
+          mine[i] = wrap_pi(mine[i] + wrap_pi(theta));
+        } else {
+          // samples at {0, pi, +pi/2, -pi/2, +pi/4, -pi/4} = e0, ep, em, e3, e4, e5 (roto_update_kernel's fit, tools.py:434-447)
+          const double Av = e0 + ep, Bv = e0 - ep, Cv = em + e3, Dv = em - e3, Ev = e4 - e5;
+          const double a = 0.25 * (2.0 * Ev - 1.4142135623730951 * Dv), b = 0.25 * (Av - Cv), c = 0.5 * Dv, d = 0.5 * Bv;
+          const double theta = double_sinusoid_argmin(a, b, c, d);
+          mine[i] += theta < -3.141592653589793 ? theta + 6.283185307179586 : (theta > 3.141592653589793 ? theta - 6.283185307179586 : theta);
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -2158,13 +2180,22 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
 hipError_t launch_rotosolve_fused_d2(int kind, const RotoArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)((a.R + 15) / 16)), block(64);
   const size_t lds = (size_t)16 * a.P * sizeof(double);
-  switch (kind) {
-    case 0: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<0>), grid, block, lds, st, a); break;
-    case 1: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<1>), grid, block, lds, st, a); break;
-    case 2: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<2>), grid, block, lds, st, a); break;
-    case 3: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<3>), grid, block, lds, st, a); break;
-    default: return hipErrorInvalidValue;
-  }
+  if (a.nsh == 6)
+    switch (kind) {
+      case 0: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<0, 6>), grid, block, lds, st, a); break;
+      case 1: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<1, 6>), grid, block, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<2, 6>), grid, block, lds, st, a); break;
+      case 3: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<3, 6>), grid, block, lds, st, a); break;
+      default: return hipErrorInvalidValue;
+    }
+  else
+    switch (kind) {
+      case 0: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<0, 3>), grid, block, lds, st, a); break;
+      case 1: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<1, 3>), grid, block, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<2, 3>), grid, block, lds, st, a); break;
+      case 3: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<3, 3>), grid, block, lds, st, a); break;
+      default: return hipErrorInvalidValue;
+    }
   return hipGetLastError();
 }
 

@@ -207,3 +207,33 @@ def test_cached_sweep_graph_is_replayed_faithfully(engine_factory):
         assert not np.array_equal(p3, p2)
         for b in np.flatnonzero(~np.isnan(h3[-1]))[::9]:
             assert abs(h3[-1][b] - O.energy_closed_form(O.unitary_to_tensor(O.shallow_cnot_unitary(D, p3[b])[None])[0], h)) < 1e-9
+
+
+@pytest.mark.parametrize('double', [False, True])
+def test_d2_whole_run_kernel_matches_the_step_by_step_path(double, engine_factory, monkeypatch):
+    """D = 2: every sweep of every restart runs inside ONE kernel launch (single- and double-frequency); the same run through
+    the step-by-step path (ansatz / energy / update kernels per parameter) gives the same trajectories."""
+    from qmps_amd import _lib
+    rng = np.random.default_rng(123)
+    h = np.stack([O.hamiltonian_matrix({'ZZ': -1, 'X': 1}), O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})])
+    eng = engine_factory(2, 4096)
+    eng.set_hamiltonian(h)
+    run = eng.double_rotosolve if double else eng.rotosolve
+    for kind, P in ((_lib.ANSATZ_SHALLOW_CNOT, 8), (_lib.ANSATZ_SHALLOW_QAOA, 4), (_lib.ANSATZ_SHALLOW_FULL, 15)):
+        P0 = rng.standard_normal((50, P))
+        monkeypatch.delenv('QMPS_NO_FUSED_ROTO', raising=False)
+        h1, p1 = run(kind, P0, 3)
+        monkeypatch.setenv('QMPS_NO_FUSED_ROTO', '1')
+        h2, p2 = run(kind, P0, 3)
+        monkeypatch.delenv('QMPS_NO_FUSED_ROTO', raising=False)
+        both = ~(np.isnan(h1).any(0) | np.isnan(h2).any(0))
+        assert both.mean() > 0.8
+        # trajectories agree while they stay on the same branch (a flat direction may send the two minimisers apart)
+        close = both & (np.abs(p1 - p2).max(1) < 1e-6)
+        assert close.mean() > 0.8 and np.abs(h1 - h2)[:, close].max() < 1e-9
+        # and every final energy is the oracle's energy at the parameters that came back
+        build = {_lib.ANSATZ_SHALLOW_CNOT: O.shallow_cnot_unitary, _lib.ANSATZ_SHALLOW_QAOA: O.shallow_qaoa_unitary}.get(kind)
+        if build is not None:
+            for b in np.flatnonzero(both)[::7]:
+                Ab = O.unitary_to_tensor(build(2, p1[b])[None])[0]
+                assert abs(h1[-1][b] - sum(O.energy_closed_form(Ab, h[t]) for t in range(2))) < 1e-9

@@ -20,6 +20,7 @@
 //                              (layouts as in energy_mfma_d16_kernel: C-layout of a product == B-layout of the next;
 //                              Bm_s^+ in B-layout == conj of Bm_s in A-layout).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "qmps_kernels.h"
@@ -503,6 +504,165 @@ __global__ __launch_bounds__(256) void overlap_square_d4_kernel(OverlapArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// D = 16, FOUR WAVES PER EVALUATION (small batches: BASELINE.json configs[4] shards its trajectories over the GPUs, a GPU
+// holds tens to hundreds of candidates).  Wave w of the workgroup owns the physical index s = w: it keeps only C_w and
+// Bm_w, computes n_w = C_w (x Bm_w^+) - 32 of the step's 128 MFMAs - and the four partial maps are summed through LDS (same
+// order in every wave, so all four hold bit-identical x' and take the same decisions).  One wave per evaluation leaves a
+// quarter of the SIMDs idle at B = 768 and, worse, lets the launch wait for its slowest candidate at one wave's pace; here
+// the stragglers run on four SIMDs each.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) {
+  constexpr int D = 16, LD = 17, WAVES = 4;
+  __shared__ double2 sT_all[WAVES][D * LD];          // wave-private transposes
+  __shared__ double2 sX_all[WAVES][D * D];           // exchange: one C-layout matrix per wave, element (q, lane) at [q * 64 + lane]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  double2* sT = sT_all[wave];
+  const double tol2 = p.tol * p.tol;
+  auto to_a_layout = [&](const v4f64& re, const v4f64& im, double (&are)[4], double (&aim)[4]) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sT[(4 * q + g) * LD + c] = make_double2(re[q], im[q]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const double2 t = sT[c * LD + 4 * kk + g];
+      are[kk] = t.x;
+      aim[kk] = t.y;
+    }
+  };
+  // every wave publishes one C-layout matrix; afterwards fetch(w, ...) reads wave w's
+  auto publish = [&](const v4f64& re, const v4f64& im) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sX_all[wave][q * 64 + lane] = make_double2(re[q], im[q]);
+  };
+  auto fetch = [&](int w, v4f64& re, v4f64& im) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double2 t = sX_all[w][q * 64 + lane];
+      re[q] = t.x;
+      im[q] = t.y;
+    }
+  };
+  for (int64_t b = blockIdx.x; b < p.B; b += gridDim.x) {
+    const double2* Ap = (const double2*)p.A + (p.a_shared ? 0 : b * (2 * D * D));
+    const double2* Bp = (const double2*)p.Bt + b * (2 * D * D);
+    const double2* W = (const double2*)p.WW;
+    const int t1 = wave >> 1, t2 = wave & 1;          // this wave's pair (s = 2 t1 + t2 = wave)
+    // ---- set-up: wave t forms AA_t = A_t1 A_t2 (published) and Bm_t = B_t1 B_t2 (kept); then C_w = sum_t WW[w][t] AA_t
+    double cre[4], cim[4];       // C_w in A-layout
+    double bre[4], bimn[4];      // conj(Bm_w) in A-layout == Bm_w^+ in B-layout
+    {
+      double pa[4], pai[4], pb[4], pbi[4];
+      v4f64 qa, qai, qb, qbi;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const double2 va = Ap[(t1 * D + c) * D + 4 * kk + g], vb = Bp[(t1 * D + c) * D + 4 * kk + g];
+        pa[kk] = va.x; pai[kk] = va.y;
+        pb[kk] = vb.x; pbi[kk] = vb.y;
+        const double2 wa = Ap[(t2 * D + 4 * kk + g) * D + c], wb = Bp[(t2 * D + 4 * kk + g) * D + c];
+        qa[kk] = wa.x; qai[kk] = wa.y;
+        qb[kk] = wb.x; qbi[kk] = wb.y;
+      }
+      v4f64 zr = {0, 0, 0, 0}, zi = {0, 0, 0, 0};
+      cmma16(pa, pai, qa, qai, zr, zi);
+      publish(zr, zi);
+      v4f64 yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
+      cmma16(pb, pbi, qb, qbi, yr, yi);
+      double tr[4], ti[4];
+      to_a_layout(yr, yi, tr, ti);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bre[kk] = tr[kk];
+        bimn[kk] = -ti[kk];
+      }
+      __syncthreads();
+      v4f64 sr = {0, 0, 0, 0}, si = {0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        v4f64 ar, ai;
+        fetch(t, ar, ai);
+        const double2 w = W[wave * 4 + t];
+        sr += w.x * ar - w.y * ai;
+        si += w.x * ai + w.y * ar;
+      }
+      to_a_layout(sr, si, cre, cim);
+      __syncthreads();               // the exchange buffers are free again
+    }
+    // ---- power method, x in C-layout (alike in the four waves), ||x||_F = 1
+    v4f64 xr, xi;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      xr[q] = (c == 4 * q + g) ? 0.25 : 0.0;
+      xi[q] = 0.0;
+    }
+    double eta_r = 0.0, eta_i = 0.0;
+    int iters = 0, status = QMPS_ST_NOT_CONVERGED;
+    for (int k = 1; k <= p.max_rounds; ++k) {
+      double xar[4], xai[4];
+      to_a_layout(xr, xi, xar, xai);
+      v4f64 yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0}, pr = {0, 0, 0, 0}, pi = {0, 0, 0, 0};
+      const v4f64 qre = {bre[0], bre[1], bre[2], bre[3]};
+      const v4f64 qim = {bimn[0], bimn[1], bimn[2], bimn[3]};
+      cmma16(xar, xai, qre, qim, yr, yi);           // Y_w = x Bm_w^+
+      cmma16(cre, cim, yr, yi, pr, pi);             // C_w Y_w
+      publish(pr, pi);
+      __syncthreads();
+      v4f64 nr = {0, 0, 0, 0}, ni = {0, 0, 0, 0};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {                 // the same order in every wave: bit-identical sums
+        v4f64 ar, ai;
+        fetch(w, ar, ai);
+        nr += ar;
+        ni += ai;
+      }
+      __syncthreads();
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a0 = dfma(xr[q], nr[q], a0);
+        a0 = dfma(xi[q], ni[q], a0);
+        a1 = dfma(xr[q], ni[q], a1);
+        a1 = dfma(-xi[q], nr[q], a1);
+        a2 = dfma(nr[q], nr[q], a2);
+        a2 = dfma(ni[q], ni[q], a2);
+      }
+      eta_r = wave_sum(a0);
+      eta_i = wave_sum(a1);
+      const double nn = wave_sum(a2);
+      double rs = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double dr = nr[q] - (eta_r * xr[q] - eta_i * xi[q]), di = ni[q] - (eta_r * xi[q] + eta_i * xr[q]);
+        rs = dfma(dr, dr, rs);
+        rs = dfma(di, di, rs);
+      }
+      const double res2 = lane0(wave_sum(rs));
+      iters = k;
+      if (res2 < tol2) {
+        status = QMPS_ST_OK;
+        break;
+      }
+      const double inv = nn > 0.0 ? 1.0 / __builtin_sqrt(nn) : 0.0;
+      xr = nr * inv;
+      xi = ni * inv;
+    }
+    if (wave == 0) {
+      if (lane == 0) {
+        ((double2*)p.eta)[b] = make_double2(eta_r, eta_i);
+        p.iters[b] = iters;
+        p.status[b] = status;
+      }
+      if (p.r_out != nullptr) {
+        double2* ro = (double2*)p.r_out + b * (D * D);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ro[(4 * q + g) * D + c] = make_double2(xr[q], xi[q]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
   switch (D) {
@@ -518,9 +678,16 @@ hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t 
     case 8: hipLaunchKernelGGL((overlap_block_kernel<8>), dim3((unsigned)a.B), dim3(64), 0, st, a); break;
     case 16:
       if (mfma) {
-        int grid = (int)((a.B + 3) / 4);
-        if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(overlap_mfma_d16_kernel, dim3(grid), dim3(256), 0, st, a);
+        // few candidates: four waves per evaluation (the launch waits for its slowest candidate - give it four SIMDs);
+        // many: one wave per evaluation (no exchange through LDS, same MFMA work)
+        static const int64_t split_below = getenv("QMPS_D16_SPLIT_BELOW") ? atoll(getenv("QMPS_D16_SPLIT_BELOW")) : 2048;   // A/B knob
+        if (a.B <= split_below) {
+          hipLaunchKernelGGL(overlap_mfma_d16x4_kernel, dim3((unsigned)(a.B < 4096 ? a.B : 4096)), dim3(256), 0, st, a);
+        } else {
+          int grid = (int)((a.B + 3) / 4);
+          if (grid > 4096) grid = 4096;
+          hipLaunchKernelGGL(overlap_mfma_d16_kernel, dim3(grid), dim3(256), 0, st, a);
+        }
       } else {
         hipLaunchKernelGGL((overlap_block_kernel<16>), dim3((unsigned)a.B), dim3(256), 0, st, a);
       }

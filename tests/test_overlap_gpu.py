@@ -132,3 +132,35 @@ def test_overlap_d16_tile_kernel_matches_the_matrix_core_kernel():
     e1, r1, s1 = eval('(' + outs[1].replace('] [', '], [') + ')')
     assert s0 == s1 == [0] * 6
     assert np.abs(np.array(e0) - np.array(e1)).max() < 1e-11 and np.abs(np.array(r0) - np.array(r1)).max() <= 2
+
+
+def test_d16_split_kernels_match_the_one_wave_kernels(engine_factory, monkeypatch):
+    """Small batches at D = 16 run four waves per evaluation (overlap objective) / two (energy): same results as one wave per
+    evaluation (QMPS_D16_SPLIT_BELOW=0 is read when the first launch of the process picks a kernel, so this compares a small
+    batch - split - with the same items inside a large batch - one wave each)."""
+    from scipy.linalg import expm
+    rng = np.random.default_rng(2024)
+    D = 16
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+    WW = expm(-0.05j * h)
+    U = O.haar_unitaries(rng, 2 * D, 1)[0]
+    A = O.unitary_to_tensor(U)
+    G = rng.standard_normal((24, 2 * D, 2 * D)) + 1j * rng.standard_normal((24, 2 * D, 2 * D))
+    cand = np.stack([O.unitary_to_tensor(U @ expm(0.05j * (g + g.conj().T) / 2)) for g in G])
+    eng = engine_factory(D, 4096)
+    eta_s, it_s, st_s = eng.overlaps(A, cand, WW)                       # 24 candidates: split kernel
+    big = np.concatenate([cand] * 100)                                  # 2400 candidates: one wave per evaluation
+    eta_b, it_b, st_b = eng.overlaps(A, big, WW)
+    assert np.all(st_s == 0) and np.array_equal(st_b[:24], st_s)
+    assert np.abs(eta_b[:24] - eta_s).max() < 1e-12 and np.abs(it_b[:24] - it_s).max() <= 1
+    for k in range(0, 24, 5):
+        assert abs(eta_s[k] - O.overlap_eta(A, cand[k], WW)[0]) < 1e-10
+    # energies
+    As = O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, 40))
+    E_s, it_s, st_s = eng.energies(As, h)                               # 40 evaluations: two waves each
+    E_b, it_b, st_b = eng.energies(np.concatenate([As] * 20), h)        # 800: one wave each
+    assert np.all(st_s == 0) and np.array_equal(st_b[:40], st_s)
+    assert np.abs(E_b[:40] - E_s).max() < 1e-12 and np.abs(it_b[:40] - it_s).max() <= 1
+    r = eng.environments(800)
+    eng.energies(As, h)
+    assert np.abs(eng.environments(40) - r[:40]).max() < 1e-12 and np.abs(eng.rdm(40) - np.array([O.two_site_rdm(As[b], r[b]) for b in range(40)])).max() < 1e-10

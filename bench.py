@@ -709,10 +709,15 @@ def main():
             for k in range(R):
                 eng.set_window(k * B)
                 eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver='direct', store_env=True)
+            # (this leg runs on rank 0 ALONE: with a communicator `cost_launch` is a collective call - a rank that issued it by
+            # itself would queue unmatched all-reduces - so the summed cost is only taken without one)
+            with_cost = not (dist is not None and rccl_ok)
+
             def warm_step(k):
                 eng.set_window((k % R) * B)
-                eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver='direct', store_env=False, accumulate_cost=True, warm_start=True)
-                eng.cost_launch(B)
+                eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver='direct', store_env=False, accumulate_cost=with_cost, warm_start=True)
+                if with_cost:
+                    eng.cost_launch(B)
             for k in range(3 * R):
                 warm_step(k)
             eng.sync()

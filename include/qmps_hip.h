@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define QMPS_ABI_VERSION 2
+#define QMPS_ABI_VERSION 3
 
 /* error codes */
 #define QMPS_OK 0
@@ -214,6 +214,8 @@ int qmps_sum_energies(qmps_ctx* ctx, int64_t B, double* cost /* [n_terms] */);
 /* ---- outputs (HBM -> host; each waits for outstanding launches) ------------------------- */
 int qmps_get_energies(qmps_ctx* ctx, int64_t B, double* E /* [B][n_terms] */, int32_t* iters /* [B] or NULL */,
                       int32_t* status /* [B] or NULL */);
+/* per-evaluation status of the last launch over the window (energy or overlap), without the energies */
+int qmps_get_status(qmps_ctx* ctx, int64_t B, int32_t* status /* [B] */);
 /* r[B][D][D] complex128, Hermitian, tr r = 1 (the dominant right eigen-matrix returned by
  * xmps TransferMatrix(A).eigs() at qmps/tools.py:181, up to its normalisation) */
 int qmps_get_env(qmps_ctx* ctx, int64_t B, double* r);
@@ -264,8 +266,49 @@ int qmps_overlap_batch(qmps_ctx* ctx, int64_t B, const double* A, int a_shared, 
  * tensor(s) + two-site operator in, asynchronous launch over the resident candidates [window, window + B), results out.
  * want_r: also keep the fixed points (read back by qmps_overlap_get with r_out != NULL). */
 int qmps_overlap_set(qmps_ctx* ctx, int64_t n_ref /* 1 = shared, else one per candidate */, const double* A, const double* WW);
-int qmps_overlap_launch(qmps_ctx* ctx, int64_t B, int max_rounds, double tol, int want_r);
+/* The reference states given as ansatz parameters ref_params[n_ref][n_params] (QMPS_ANSATZ_*): the tensors are built on
+ * the device (the reference does this per time step: A_ = iMPS([unitary_to_tensor(cirq.unitary(gate(params)))]),
+ * qmps/new_time_evolve.py:281-283, scripts/loschmidt.py:368). */
+int qmps_overlap_set_refs_ansatz(qmps_ctx* ctx, int64_t n_ref, int kind, int n_params, const double* ref_params, const double* WW);
+/* Trajectory-major candidate batches: with group = G > 0 candidate b is compared with reference tensor b / G (G candidates -
+ * rotosolve shifts, finite-difference columns, line-search points, simplex vertices - per trajectory); needs
+ * n_ref G >= window + B and a window that starts at a multiple of G.  group = 0 (default, and after qmps_overlap_set*):
+ * one shared reference (n_ref = 1) or one per candidate. */
+int qmps_overlap_set_group(qmps_ctx* ctx, int64_t group);
+/* flags of qmps_overlap_launch (the argument was `want_r` in ABI 2: bit 0 keeps that meaning) */
+#define QMPS_OVERLAP_WANT_R 1 /* keep the unit-Frobenius right fixed points resident (qmps_overlap_get r_out) */
+/* Warm start (D = 8, 16: the power method; ignored by the squaring solvers of D = 2, 4, whose cost does not depend on the
+ * start): every candidate starts from the RESIDENT fixed point of its slot - what the previous launch with
+ * QMPS_OVERLAP_WANT_R left there - instead of 1/sqrt(D).  The optimisers re-evaluate nearby candidates (the reference
+ * warm-starts every time step from the previous parameters, scripts/loschmidt.py:373): a slot whose candidate moved by
+ * delta converges in log(delta/tol)/log(|eta_1/eta_2|) steps.  An all-zero slot means cold start.  Needs
+ * QMPS_OVERLAP_WANT_R (the new fixed points replace the old ones). */
+#define QMPS_OVERLAP_WARM 2
+int qmps_overlap_launch(qmps_ctx* ctx, int64_t B, int max_rounds, double tol, int flags);
 int qmps_overlap_get(qmps_ctx* ctx, int64_t B, double* eta_out, double* r_out, int32_t* rounds_out, int32_t* status_out);
+/* the objective itself, f_b = -sqrt(|eta_b|) (qmps/new_time_evolve.py:221, scripts/loschmidt.py:238-239), computed by the kernel */
+int qmps_overlap_get_objective(qmps_ctx* ctx, int64_t B, double* f_out /* [B] */);
+/* Solver statistics accumulated by every overlap evaluation of this context since the last reset (device-side atomics):
+ * evaluations, sum and maximum of their rounds (squarings at D = 2, 4; power steps at D = 8, 16), evaluations that ended
+ * with status != 0.  Waits for the stream. */
+int qmps_overlap_stats(qmps_ctx* ctx, int64_t* evaluations, int64_t* rounds_sum, int64_t* rounds_max, int64_t* not_converged, int reset);
+
+/* Device-resident TIME EVOLUTION by rotosolve on the overlap objective (BASELINE.json configs[4]; the reference's loop:
+ * qmps/new_time_evolve.py:276-292 / scripts/loschmidt.py:367-375 `for _ in T: A_ = tensor(params); params =
+ * minimize(obj, params, (A_, WW)).x`, with the rotosolve update of qmps/rotosolve.py:154-181 (nsh = 3) or
+ * qmps/tools.py:422-457 (nsh = 6; the variant the reference sketches at new_time_evolve.py:292 and scripts/rotosolve.py:270-294)
+ * as the minimiser).  T independent trajectories in lock-step, params[T][n_params] in / out (QMPS_ANSATZ_* kind).  Per time
+ * step: reference tensors A_t = tensor(params_t) built on the device; n_sweeps sweeps; per parameter ONE batch of nsh T
+ * candidates (trajectory-major: candidate nsh t + k = trajectory t with shift k on the parameter) - ansatz, overlap
+ * objective f = -sqrt|eta| against A_t, closed-form / fitted update - and per sweep one batch of the T updated vectors
+ * whose objective is the sweep's record: f_hist[n_steps][n_sweeps][T].  params_hist (nullable) [n_steps][T][n_params]: the
+ * parameters after each time step.  Warm start from the previous parameters, as in the reference (scripts/loschmidt.py:373).
+ * No host round trip inside the call: a sweep is one hipGraph; at D = 8, 16 the fixed points of every (parameter, candidate)
+ * slot stay resident between sweeps and time steps (warm start of the power method, see QMPS_OVERLAP_WARM).
+ * A candidate whose solve does not converge within max_rounds leaves its trajectory's parameter untouched in that update
+ * (like the energy rotosolve).  Needs nsh T <= max_batch.  Statistics: qmps_overlap_stats. */
+int qmps_evolve_rotosolve(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps,
+                          int n_sweeps, int nsh, int max_rounds, double tol, double* params_hist, double* f_hist);
 
 /* Variational-environment objective, D = 2 (qmps/ground_state.py:170-228, selected by
  * SparseFullEnergyOptimizer(optimize_environment=True); the objective the reference's own Rotosolve test drives,

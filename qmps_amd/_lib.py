@@ -23,6 +23,7 @@ ENV_DIRECT = 2
 FLAG_NO_ENV_OUT = 0x100
 FLAG_ACCUMULATE_COST = 0x200
 FLAG_WARM_RESIDENT = 0x400
+OVERLAP_WANT_R, OVERLAP_WARM = 1, 2
 UNIQUE_ID_BYTES = 128
 
 _dp = POINTER(c_double)
@@ -53,6 +54,7 @@ SIGNATURES = {
     'qmps_energy_only_launch': (c_int, [c_void_p, c_int64]),
     'qmps_sum_energies': (c_int, [c_void_p, c_int64, _dp]),
     'qmps_get_energies': (c_int, [c_void_p, c_int64, _dp, _ip, _ip]),
+    'qmps_get_status': (c_int, [c_void_p, c_int64, _ip]),
     'qmps_get_env': (c_int, [c_void_p, c_int64, _dp]),
     'qmps_get_rdm': (c_int, [c_void_p, c_int64, _dp]),
     'qmps_energy_batch': (c_int, [c_void_p, c_int64, _dp, c_int, _dp, c_int, _dp, c_int, c_double, _dp, _ip, _ip]),
@@ -65,6 +67,11 @@ SIGNATURES = {
     'qmps_overlap_set': (c_int, [c_void_p, c_int64, _dp, _dp]),
     'qmps_overlap_launch': (c_int, [c_void_p, c_int64, c_int, c_double, c_int]),
     'qmps_overlap_get': (c_int, [c_void_p, c_int64, _dp, _dp, _ip, _ip]),
+    'qmps_overlap_set_refs_ansatz': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, _dp]),
+    'qmps_overlap_set_group': (c_int, [c_void_p, c_int64]),
+    'qmps_overlap_get_objective': (c_int, [c_void_p, c_int64, _dp]),
+    'qmps_overlap_stats': (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_int]),
+    'qmps_evolve_rotosolve': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, _dp, c_int, c_int, c_int, c_int, c_double, _dp, _dp]),
     'qmps_opt_env_objective': (c_int, [c_void_p, c_int64, _dp, _dp, c_double, _dp, _dp]),
     'qmps_bw_expval': (c_int, [c_void_p, c_int64, c_int, _dp, _dp, _dp, c_int, _dp]),
     'qmps_bw_env': (c_int, [c_void_p, c_int64, c_int, _dp, _dp, _dp, _dp, c_int, c_double, _dp, _dp, _dp, _ip]),
@@ -111,7 +118,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.qmps_abi_version() != 2:
+    if lib.qmps_abi_version() != 3:
         raise ImportError('libqmps_hip.so ABI version mismatch')
     _lib = lib
     return lib

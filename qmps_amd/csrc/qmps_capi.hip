@@ -63,6 +63,13 @@ struct qmps_ctx {
   double* d_params = nullptr;  // ansatz parameters [max_batch][params_cap] (lazy)
   void* d_ww = nullptr;        // two-site operator of the overlap objective (lazy)
   void* d_eta = nullptr;       // overlap eigenvalues [max_batch] complex (lazy)
+  void* d_ref = nullptr;       // reference tensors of the overlap objective [ref_cap][2][D][D] (lazy; its own buffer: d_U is
+  int64_t ref_cap = 0;         //   overwritten by qmps_set_states(kind = UNITARY) and the two-site unit cell)
+  double* d_f = nullptr;       // overlap objective -sqrt|eta| [max_batch] (lazy)
+  unsigned long long* d_ostats = nullptr;   // overlap solver statistics [4] (lazy)
+  void* d_xwarm = nullptr;     // qmps_evolve_rotosolve: fixed points per (parameter, candidate) (lazy, grown on demand)
+  size_t xwarm_bytes = 0;
+  int64_t overlap_group = 0;   // > 0: candidate b is compared with reference b / overlap_group
   void* d_scratch = nullptr;   // brick-wall inputs / outputs (lazy, grown on demand)
   size_t scratch_bytes = 0;
   int params_cap = 0;
@@ -98,6 +105,7 @@ struct qmps_ctx {
   int64_t overlap_refs = 0;         // reference tensors resident for the overlap objective (1 = shared by the batch)
   bool have_guess = false;
   bool have_env = false;
+  bool have_overlap_x = false;       // d_r holds the fixed points of the last overlap launch (QMPS_OVERLAP_WANT_R)
   bool want_rho = false;
   bool defer_sync = false;          // one-shot entry points: the setters leave their H2D copies in flight, ONE synchronisation at the end
   // ansatz-parametrised states: the parameters stay resident (d_params, or ans_src during a rotosolve run); at D = 4 the
@@ -179,6 +187,17 @@ int bind(qmps_ctx* c) {
 size_t tensor_bytes(const qmps_ctx* c) { return (size_t)32 * c->D * c->D; }
 size_t env_bytes(const qmps_ctx* c) { return (size_t)16 * c->D * c->D; }
 
+int ensure_scratch(qmps_ctx* c, size_t bytes) {
+  if (bytes > c->scratch_bytes) {
+    if (c->d_scratch) HIP_TRY(hipFree(c->d_scratch));
+    c->d_scratch = nullptr;
+    c->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&c->d_scratch, bytes));
+    c->scratch_bytes = bytes;
+  }
+  return QMPS_OK;
+}
+
 int ensure_E(qmps_ctx* c, int n_terms) {
   const int64_t need = c->max_batch * n_terms;
   if (need > c->E_capacity) {
@@ -213,6 +232,18 @@ int32_t* win_status(const qmps_ctx* c) { return c->d_status + c->window; }
 bool fusable_ansatz(const qmps_ctx* c, int kind) {
   static const bool off = getenv("QMPS_NO_FUSED_ANSATZ") != nullptr;   // A/B knob
   return !off && c->D == 4 && (kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_QAOA || kind == QMPS_ANSATZ_SHALLOW_CNOT3);
+}
+
+// (kind, n_params) of an ansatz the device builders know (qmps/represent.py:268-404)
+int check_ansatz(const qmps_ctx* c, int kind, int n_params) {
+  if (n_params < 1 || n_params > 4096) return fail(QMPS_ERR_ARG, "n_params=%d outside [1,4096]", n_params);
+  if (kind < 0 || kind > 3) return fail(QMPS_ERR_ARG, "unknown ansatz kind %d", kind);
+  if (kind == QMPS_ANSATZ_SHALLOW_FULL && (c->D != 2 || n_params != 15))
+    return fail(QMPS_ERR_ARG, "ShallowFullStateTensor is a two-qubit gate: D = 2, 15 parameters");
+  if ((kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_QAOA) && n_params % 2)
+    return fail(QMPS_ERR_ARG, "this ansatz takes (beta, gamma) pairs");
+  if (kind == QMPS_ANSATZ_SHALLOW_CNOT3 && n_params % 3) return fail(QMPS_ERR_ARG, "this ansatz takes (beta, gamma, omega) triples");
+  return QMPS_OK;
 }
 
 // d_A <- tensors of the resident ansatz parameters, if nothing has built them yet
@@ -432,7 +463,7 @@ int qmps_destroy(qmps_ctx* c) {
   }
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   if (c->comm_stream2) (void)hipStreamDestroy(c->comm_stream2);
-  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc, c->d_acc_err, c->roto_base, c->roto_hist, c->roto_idx};
+  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_ref, c->d_f, c->d_ostats, c->d_xwarm, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc, c->d_acc_err, c->roto_base, c->roto_hist, c->roto_idx};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
@@ -493,13 +524,7 @@ int qmps_set_states_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;
   if (!params && B > 0) return fail(QMPS_ERR_ARG, "null params");
-  if (n_params < 1 || n_params > 4096) return fail(QMPS_ERR_ARG, "n_params=%d outside [1,4096]", n_params);
-  if (kind < 0 || kind > 3) return fail(QMPS_ERR_ARG, "unknown ansatz kind %d", kind);
-  if (kind == QMPS_ANSATZ_SHALLOW_FULL && (c->D != 2 || n_params != 15))
-    return fail(QMPS_ERR_ARG, "ShallowFullStateTensor is a two-qubit gate: D = 2, 15 parameters");
-  if ((kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_QAOA) && n_params % 2)
-    return fail(QMPS_ERR_ARG, "this ansatz takes (beta, gamma) pairs");
-  if (kind == QMPS_ANSATZ_SHALLOW_CNOT3 && n_params % 3) return fail(QMPS_ERR_ARG, "this ansatz takes (beta, gamma, omega) triples");
+  if (int rc = check_ansatz(c, kind, n_params)) return rc;
   if (n_params > c->params_cap) {
     if (c->d_params) HIP_TRY(hipFree(c->d_params));
     c->d_params = nullptr;
@@ -544,15 +569,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
   if (!params || !E_hist) return fail(QMPS_ERR_ARG, "null argument");
   if (n_sweeps < 1) return fail(QMPS_ERR_ARG, "n_sweeps must be >= 1");
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "qmps_set_hamiltonian has not been called");
-  // validate (kind, n_params) and size d_params for the 3 R shifted parameter vectors
-  {
-    double dummy[1] = {0.0};
-    (void)dummy;
-  }
-  if (kind < 0 || kind > 3) return fail(QMPS_ERR_ARG, "unknown ansatz kind %d", kind);
-  if (kind == QMPS_ANSATZ_SHALLOW_FULL && (c->D != 2 || n_params != 15)) return fail(QMPS_ERR_ARG, "ShallowFullStateTensor: D = 2, 15 parameters");
-  if ((kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_QAOA) && n_params % 2) return fail(QMPS_ERR_ARG, "this ansatz takes (beta, gamma) pairs");
-  if (kind == QMPS_ANSATZ_SHALLOW_CNOT3 && n_params % 3) return fail(QMPS_ERR_ARG, "this ansatz takes (beta, gamma, omega) triples");
+  if (int rc = check_ansatz(c, kind, n_params)) return rc;
   if (n_params > c->params_cap) {
     if (c->d_params) HIP_TRY(hipFree(c->d_params));
     c->d_params = nullptr;
@@ -571,7 +588,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
   };
   if (int rc = grow(c->roto_base, c->roto_base_bytes, (size_t)R * n_params * sizeof(double))) return rc;
   if (int rc = grow(c->roto_hist, c->roto_hist_bytes, (size_t)R * n_sweeps * sizeof(double))) return rc;
-  if (!c->roto_idx) HIP_TRY(hipMalloc((void**)&c->roto_idx, 3 * sizeof(int)));
+  if (!c->roto_idx) HIP_TRY(hipMalloc((void**)&c->roto_idx, 4 * sizeof(int)));
   double *d_base = c->roto_base, *d_hist = c->roto_hist;
   int* d_idx = c->roto_idx;
   int rc = [&]() -> int {
@@ -739,6 +756,7 @@ int qmps_set_env_guess(qmps_ctx* c, int64_t B, const double* r0) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->have_guess = true;
   c->have_env = true;
+  c->have_overlap_x = false;
   return QMPS_OK;
 }
 
@@ -767,6 +785,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   const bool direct2 = solver == QMPS_ENV_DIRECT && c->D == 2;     // 4 x 4 solve in the lane, in front of the squaring tail
   if (solver == QMPS_ENV_DIRECT && !direct) solver = QMPS_ENV_POWER_SQUARING;   // D = 2: the lane kernel's squaring path with the 4 x 4 solve in front (direct2); D = 16 iterates (documented)
   c->acc_pending = false;   // whatever an earlier launch accumulated no longer describes the resident energies
+  c->have_overlap_x = false;   // d_r is about to hold environments, not overlap fixed points
   const bool fused = direct && c->ans_have && fusable_ansatz(c, c->ans_kind);
   if (!fused)
     if (int rc = ensure_tensors(c)) return rc;
@@ -992,6 +1011,15 @@ int qmps_get_energies(qmps_ctx* c, int64_t B, double* E, int32_t* iters, int32_t
   return QMPS_OK;
 }
 
+int qmps_get_status(qmps_ctx* c, int64_t B, int32_t* status) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_window(c, B)) return rc;
+  if (!status) return fail(QMPS_ERR_ARG, "null status");
+  HIP_TRY(hipMemcpyAsync(status, win_status(c), (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+
 int qmps_get_env(qmps_ctx* c, int64_t B, double* r) {
   if (int rc = bind(c)) return rc;
   if (int rc = check_window(c, B)) return rc;
@@ -1110,40 +1138,35 @@ int qmps_kernel_time(qmps_ctx* c, int n_last, float* avg_ms, char* name, int nam
   return QMPS_OK;
 }
 
-int qmps_overlap_set(qmps_ctx* c, int64_t n_ref, const double* A, const double* WW) {
-  if (int rc = bind(c)) return rc;
-  if (!A || !WW) return fail(QMPS_ERR_ARG, "null argument");
-  if (n_ref < 1 || n_ref > c->max_batch) return fail(QMPS_ERR_ARG, "n_ref=%lld outside [1, max_batch]", (long long)n_ref);
-  // the current state(s) go to d_U (scratch of 2 tensors per item), WW to its own 256 bytes
-  if (!c->d_U) HIP_TRY(hipMalloc(&c->d_U, (size_t)c->max_batch * 2 * tensor_bytes(c)));
-  HIP_TRY(hipMemcpyAsync(c->d_U, A, (size_t)n_ref * tensor_bytes(c), hipMemcpyHostToDevice, c->stream));
-  if (!c->d_ww) HIP_TRY(hipMalloc(&c->d_ww, 256));
-  HIP_TRY(hipMemcpyAsync(c->d_ww, WW, 256, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  c->overlap_refs = n_ref;
+namespace {
+int ensure_refs(qmps_ctx* c, int64_t n_ref) {
+  if (n_ref > c->ref_cap) {
+    if (c->d_ref) HIP_TRY(hipFree(c->d_ref));
+    c->d_ref = nullptr;
+    c->ref_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_ref, (size_t)n_ref * tensor_bytes(c)));
+    c->ref_cap = n_ref;
+  }
   return QMPS_OK;
 }
-
-int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int want_r) {
-  if (int rc = bind(c)) return rc;
-  if (int rc = check_window(c, B)) return rc;
-  if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
-  if (c->overlap_refs < 1) return fail(QMPS_ERR_STATE, "qmps_overlap_set has not been called");
-  if (c->overlap_refs != 1 && c->overlap_refs < c->window + B) return fail(QMPS_ERR_STATE, "%lld reference tensors for window end %lld", (long long)c->overlap_refs, (long long)(c->window + B));
-  const bool squaring = c->D == 2 || (c->D == 4 && !getenv("QMPS_OVERLAP_POWER"));   // these square the matrix of the map: rounds, not steps
-  const int cap = squaring ? 60 : (1 << 24);
-  if (max_rounds < 1 || max_rounds > cap || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_rounds / tol (D = %d: max_rounds in [1, %d])", c->D, cap);
+int set_ww(qmps_ctx* c, const double* WW) {
+  if (!c->d_ww) HIP_TRY(hipMalloc(&c->d_ww, 256));
+  HIP_TRY(hipMemcpyAsync(c->d_ww, WW, 256, hipMemcpyHostToDevice, c->stream));
+  return QMPS_OK;
+}
+int ensure_overlap_outputs(qmps_ctx* c) {
   if (!c->d_eta) HIP_TRY(hipMalloc(&c->d_eta, (size_t)c->max_batch * 16));
-  qmps::OverlapArgs a;
-  memset(&a, 0, sizeof(a));
-  const bool shared = c->overlap_refs == 1;
-  a.A = shared ? (char*)c->d_U : (char*)c->d_U + (size_t)c->window * tensor_bytes(c);
-  if (int rc = ensure_tensors(c)) return rc;
-  a.Bt = win_A(c);
-  a.WW = c->d_ww;
-  a.eta = (char*)c->d_eta + (size_t)c->window * 16;
-  a.r_out = want_r ? win_r(c) : nullptr;
-  a.iters = win_iters(c); a.status = win_status(c); a.B = B; a.a_shared = shared ? 1 : 0; a.max_rounds = max_rounds; a.tol = tol;
+  if (!c->d_f) HIP_TRY(hipMalloc((void**)&c->d_f, (size_t)c->max_batch * sizeof(double)));
+  if (!c->d_ostats) {
+    HIP_TRY(hipMalloc((void**)&c->d_ostats, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(c->d_ostats, 0, 4 * sizeof(unsigned long long), c->stream));
+  }
+  return QMPS_OK;
+}
+// the kernel the overlap launch of this context runs (name for qmps_kernel_time) and whether it counts squarings
+bool overlap_squares(const qmps_ctx* c) { return c->D == 2 || (c->D == 4 && !getenv("QMPS_OVERLAP_POWER")); }
+int launch_overlap_kernels(qmps_ctx* c, const qmps::OverlapArgs& a) {
+  const bool squaring = overlap_squares(c);
   c->dominant = c->D == 2 ? "overlap_lane_kernel" : (c->D == 4 && squaring ? "overlap_square_d4_kernel" :
                 (c->D == 16 && !getenv("QMPS_D16_BLOCK") ? "overlap_mfma_d16_kernel" : "overlap_block_kernel<D>"));
   c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
@@ -1153,8 +1176,88 @@ int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int 
   else HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : getenv("QMPS_D16_BLOCK") == nullptr, c->stream));
   if (c->timed) { HIP_TRY(hipEventRecord(c->kev1[slot], c->stream)); c->samples++; }
   if (!c->capturing) c->launches++;
+  return QMPS_OK;
+}
+}  // namespace
+
+int qmps_overlap_set(qmps_ctx* c, int64_t n_ref, const double* A, const double* WW) {
+  if (int rc = bind(c)) return rc;
+  if (!A || !WW) return fail(QMPS_ERR_ARG, "null argument");
+  if (n_ref < 1 || n_ref > c->max_batch) return fail(QMPS_ERR_ARG, "n_ref=%lld outside [1, max_batch]", (long long)n_ref);
+  // the reference state(s) live in their own buffer: nothing else in the context writes it
+  if (int rc = ensure_refs(c, n_ref)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_ref, A, (size_t)n_ref * tensor_bytes(c), hipMemcpyHostToDevice, c->stream));
+  if (int rc = set_ww(c, WW)) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->overlap_refs = n_ref;
+  c->overlap_group = 0;
+  return QMPS_OK;
+}
+
+int qmps_overlap_set_refs_ansatz(qmps_ctx* c, int64_t n_ref, int kind, int n_params, const double* params, const double* WW) {
+  if (int rc = bind(c)) return rc;
+  if (!params || !WW) return fail(QMPS_ERR_ARG, "null argument");
+  if (n_ref < 1 || n_ref > c->max_batch) return fail(QMPS_ERR_ARG, "n_ref=%lld outside [1, max_batch]", (long long)n_ref);
+  if (int rc = check_ansatz(c, kind, n_params)) return rc;
+  if (int rc = ensure_refs(c, n_ref)) return rc;
+  // parameter rows through the scratch arena, tensors built on the device straight into the reference buffer
+  if (int rc = ensure_scratch(c, (size_t)n_ref * n_params * sizeof(double))) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_scratch, params, (size_t)n_ref * n_params * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(qmps::launch_ansatz(c->D, kind, (const double*)c->d_scratch, n_params, c->d_ref, n_ref, c->stream));
+  if (int rc = set_ww(c, WW)) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->overlap_refs = n_ref;
+  c->overlap_group = 0;
+  return QMPS_OK;
+}
+
+int qmps_overlap_set_group(qmps_ctx* c, int64_t group) {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  if (group < 0) return fail(QMPS_ERR_ARG, "group must be >= 0");
+  c->overlap_group = group;
+  return QMPS_OK;
+}
+
+int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int flags) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_window(c, B)) return rc;
+  if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
+  if (c->overlap_refs < 1) return fail(QMPS_ERR_STATE, "qmps_overlap_set has not been called");
+  if (flags & ~(QMPS_OVERLAP_WANT_R | QMPS_OVERLAP_WARM)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
+  const bool want_r = (flags & QMPS_OVERLAP_WANT_R) != 0, warm = (flags & QMPS_OVERLAP_WARM) != 0;
+  if (warm && !want_r) return fail(QMPS_ERR_ARG, "QMPS_OVERLAP_WARM needs QMPS_OVERLAP_WANT_R (the fixed points stay resident for the next launch)");
+  if (warm && !c->have_overlap_x) return fail(QMPS_ERR_STATE, "QMPS_OVERLAP_WARM: no resident fixed points (run a launch with QMPS_OVERLAP_WANT_R first)");
+  const int64_t group = c->overlap_group;
+  if (group > 0) {
+    if (c->overlap_refs * group < c->window + B) return fail(QMPS_ERR_STATE, "%lld reference tensors x group %lld for window end %lld", (long long)c->overlap_refs, (long long)group, (long long)(c->window + B));
+  } else if (c->overlap_refs != 1 && c->overlap_refs < c->window + B) {
+    return fail(QMPS_ERR_STATE, "%lld reference tensors for window end %lld", (long long)c->overlap_refs, (long long)(c->window + B));
+  }
+  const bool squaring = overlap_squares(c);   // these square the matrix of the map: rounds, not steps
+  const int cap = squaring ? 60 : (1 << 24);
+  if (max_rounds < 1 || max_rounds > cap || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_rounds / tol (D = %d: max_rounds in [1, %d])", c->D, cap);
+  if (int rc = ensure_overlap_outputs(c)) return rc;
+  qmps::OverlapArgs a;
+  memset(&a, 0, sizeof(a));
+  const bool shared = group == 0 && c->overlap_refs == 1;
+  // (the window displaces the candidates; with a group the references are addressed by the candidate's GLOBAL index)
+  a.A = (shared || group > 0) ? (char*)c->d_ref + (group > 0 ? (size_t)(c->window / group) * tensor_bytes(c) : 0)
+                              : (char*)c->d_ref + (size_t)c->window * tensor_bytes(c);
+  if (group > 0 && c->window % group) return fail(QMPS_ERR_ARG, "with a candidate group the window must start at a multiple of it");
+  if (int rc = ensure_tensors(c)) return rc;
+  a.Bt = win_A(c);
+  a.WW = c->d_ww;
+  a.eta = (char*)c->d_eta + (size_t)c->window * 16;
+  a.f_out = c->d_f + c->window;
+  a.r_out = want_r ? win_r(c) : nullptr;
+  a.x_in = warm ? win_r(c) : nullptr;
+  a.stats = c->d_ostats;
+  a.group = (int)group;
+  a.iters = win_iters(c); a.status = win_status(c); a.B = B; a.a_shared = shared ? 1 : 0; a.max_rounds = max_rounds; a.tol = tol;
+  if (int rc = launch_overlap_kernels(c, a)) return rc;
   c->have_env = false;
   c->have_guess = false;
+  c->have_overlap_x = want_r;
   c->acc_pending = false;
   c->partials_B = -1;
   return QMPS_OK;
@@ -1166,11 +1269,160 @@ int qmps_overlap_get(qmps_ctx* c, int64_t B, double* eta_out, double* r_out, int
   if (!eta_out) return fail(QMPS_ERR_ARG, "null eta_out");
   if (!c->d_eta) return fail(QMPS_ERR_STATE, "qmps_overlap_launch has not been called");
   HIP_TRY(hipMemcpyAsync(eta_out, (char*)c->d_eta + (size_t)c->window * 16, (size_t)B * 16, hipMemcpyDeviceToHost, c->stream));
-  if (r_out) HIP_TRY(hipMemcpyAsync(r_out, win_r(c), (size_t)B * env_bytes(c), hipMemcpyDeviceToHost, c->stream));
+  if (r_out) {
+    if (!c->have_overlap_x) return fail(QMPS_ERR_STATE, "the last overlap launch did not keep the fixed points (QMPS_OVERLAP_WANT_R)");
+    HIP_TRY(hipMemcpyAsync(r_out, win_r(c), (size_t)B * env_bytes(c), hipMemcpyDeviceToHost, c->stream));
+  }
   if (rounds_out) HIP_TRY(hipMemcpyAsync(rounds_out, win_iters(c), (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
   if (status_out) HIP_TRY(hipMemcpyAsync(status_out, win_status(c), (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
+}
+
+int qmps_overlap_get_objective(qmps_ctx* c, int64_t B, double* f_out) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_window(c, B)) return rc;
+  if (!f_out) return fail(QMPS_ERR_ARG, "null f_out");
+  if (!c->d_f) return fail(QMPS_ERR_STATE, "qmps_overlap_launch has not been called");
+  HIP_TRY(hipMemcpyAsync(f_out, c->d_f + c->window, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+
+int qmps_overlap_stats(qmps_ctx* c, int64_t* evaluations, int64_t* rounds_sum, int64_t* rounds_max, int64_t* not_converged, int reset) {
+  if (int rc = bind(c)) return rc;
+  unsigned long long h[4] = {0, 0, 0, 0};
+  if (c->d_ostats) {
+    HIP_TRY(hipMemcpyAsync(h, c->d_ostats, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    if (reset) HIP_TRY(hipMemsetAsync(c->d_ostats, 0, sizeof(h), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  if (evaluations) *evaluations = (int64_t)h[0];
+  if (rounds_sum) *rounds_sum = (int64_t)h[1];
+  if (rounds_max) *rounds_max = (int64_t)h[2];
+  if (not_converged) *not_converged = (int64_t)h[3];
+  return QMPS_OK;
+}
+
+int qmps_evolve_rotosolve(qmps_ctx* c, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps,
+                          int n_sweeps, int nsh, int max_rounds, double tol, double* params_hist, double* f_hist) {
+  if (int rc = bind(c)) return rc;
+  if (!params || !WW || !f_hist) return fail(QMPS_ERR_ARG, "null argument");
+  if (nsh != 3 && nsh != 6) return fail(QMPS_ERR_ARG, "nsh must be 3 (single-frequency) or 6 (double-frequency)");
+  if (T < 1 || nsh * T > c->max_batch) return fail(QMPS_ERR_ARG, "%d T = %lld candidates exceed max_batch = %lld", nsh, (long long)(nsh * T), (long long)c->max_batch);
+  if (n_steps < 1 || n_sweeps < 1) return fail(QMPS_ERR_ARG, "n_steps and n_sweeps must be >= 1");
+  if (int rc = check_ansatz(c, kind, n_params)) return rc;
+  const bool squaring = overlap_squares(c);
+  const int cap = squaring ? 60 : (1 << 24);
+  if (max_rounds < 1 || max_rounds > cap || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_rounds / tol (D = %d: max_rounds in [1, %d])", c->D, cap);
+  const int P = n_params;
+  const int64_t n_rec = (int64_t)n_steps * n_sweeps;
+  auto grow = [&](double*& buf, size_t& have, size_t need) -> int {
+    if (need > have) {
+      if (buf) HIP_TRY(hipFree(buf));
+      buf = nullptr;
+      have = 0;
+      HIP_TRY(hipMalloc((void**)&buf, need));
+      have = need;
+    }
+    return QMPS_OK;
+  };
+  if (int rc = grow(c->roto_base, c->roto_base_bytes, (size_t)T * P * sizeof(double))) return rc;
+  if (int rc = grow(c->roto_hist, c->roto_hist_bytes, (size_t)T * n_rec * sizeof(double))) return rc;
+  if (!c->roto_idx) HIP_TRY(hipMalloc((void**)&c->roto_idx, 4 * sizeof(int)));
+  if (int rc = ensure_refs(c, T)) return rc;
+  if (int rc = ensure_E(c, c->n_terms > 0 ? c->n_terms : 1)) return rc;
+  if (int rc = ensure_overlap_outputs(c)) return rc;
+  if (int rc = ensure_scratch(c, (size_t)n_steps * T * P * sizeof(double))) return rc;    // parameter history
+  // fixed points of the power method (D = 8, 16), one set per parameter plus one for the unshifted evaluation of a sweep:
+  // the candidates of parameter i come back to the same slot in the next sweep and in the next time step - by then the
+  // parameters have moved by one sweep's updates, so the resident fixed point is the natural warm start
+  const bool warm = !squaring;
+  const size_t slot_bytes = (size_t)nsh * T * env_bytes(c);
+  if (warm) {
+    const size_t need = (size_t)(P + 1) * slot_bytes;
+    if (need > c->xwarm_bytes) {
+      if (c->d_xwarm) HIP_TRY(hipFree(c->d_xwarm));
+      c->d_xwarm = nullptr;
+      c->xwarm_bytes = 0;
+      HIP_TRY(hipMalloc(&c->d_xwarm, need));
+      c->xwarm_bytes = need;
+    }
+    HIP_TRY(hipMemsetAsync(c->d_xwarm, 0, need, c->stream));       // all zero = cold start
+  }
+  double *d_base = c->roto_base, *d_hist = c->roto_hist, *d_phist = (double*)c->d_scratch;
+  int* d_idx = c->roto_idx;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int rc = [&]() -> int {
+    HIP_TRY(hipMemcpyAsync(d_base, params, (size_t)T * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int idx0[4] = {0, 0, 0, P};      // parameter index, arrival counter, finished sweeps, slot of the unshifted evaluation
+    HIP_TRY(hipMemcpyAsync(d_idx, idx0, sizeof(idx0), hipMemcpyHostToDevice, c->stream));
+    if (int e = set_ww(c, WW)) return e;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->window = 0;
+    c->have_env = false; c->have_guess = false; c->have_overlap_x = false; c->acc_pending = false; c->partials_B = -1;
+    c->ans_have = false; c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0;
+    auto evaluate = [&](int shifts) -> int {      // shifts = nsh: the shifted batch of parameter *d_idx;  0: the T base vectors
+      const int64_t n = shifts > 0 ? (int64_t)shifts * T : T;
+      HIP_TRY(qmps::launch_ansatz_shifted(c->D, kind, d_base, P, c->d_A, n, shifts, d_idx, c->stream));
+      qmps::OverlapArgs a;
+      memset(&a, 0, sizeof(a));
+      a.A = c->d_ref; a.Bt = c->d_A; a.WW = c->d_ww; a.eta = c->d_eta; a.f_out = c->d_E;
+      a.iters = c->d_iters; a.status = c->d_status; a.B = n; a.group = shifts > 0 ? shifts : 1;
+      a.max_rounds = max_rounds; a.tol = tol; a.stats = c->d_ostats;
+      if (warm) {
+        a.x_in = c->d_xwarm; a.r_out = c->d_xwarm;
+        a.slot_ptr = shifts > 0 ? d_idx : d_idx + 3; a.slot_stride = (int64_t)slot_bytes;
+      }
+      return launch_overlap_kernels(c, a);
+    };
+    auto one_sweep = [&]() -> int {
+      for (int i = 0; i < P; ++i) {
+        if (int e = evaluate(nsh)) return e;
+        HIP_TRY(qmps::launch_roto_update(d_base, c->d_E, c->d_status, (int)T, P, d_idx, 1, nsh, c->stream));
+      }
+      // the sweep's record: the objective of the updated vectors against this time step's reference states
+      if (int e = evaluate(0)) return e;
+      HIP_TRY(qmps::launch_roto_record(c->d_E, d_hist, (int)T, 1, d_idx + 2, 1, c->stream));
+      return QMPS_OK;
+    };
+    const bool use_graph = getenv("QMPS_NO_GRAPH") == nullptr && P <= 256;
+    if (use_graph) {
+      c->capturing = true;
+      HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      const int e = one_sweep();
+      const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+      c->capturing = false;
+      if (e) return e;
+      HIP_TRY(ce);
+      HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    }
+    for (int step = 0; step < n_steps; ++step) {
+      // the states the step starts from are the reference: A_t = tensor(params_t)  (new_time_evolve.py:281-283)
+      HIP_TRY(qmps::launch_ansatz(c->D, kind, d_base, P, c->d_ref, T, c->stream));
+      for (int sw = 0; sw < n_sweeps; ++sw) {
+        if (use_graph) HIP_TRY(hipGraphLaunch(exec, c->stream));
+        else if (int e = one_sweep()) return e;
+      }
+      HIP_TRY(hipMemcpyAsync(d_phist + (size_t)step * T * P, d_base, (size_t)T * P * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(params, d_base, (size_t)T * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(f_hist, d_hist, (size_t)T * n_rec * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (params_hist) HIP_TRY(hipMemcpyAsync(params_hist, d_phist, (size_t)n_steps * T * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QMPS_OK;
+  }();
+  c->capturing = false;
+  (void)hipStreamSynchronize(c->stream);
+  if (exec) (void)hipGraphExecDestroy(exec);
+  if (graph) (void)hipGraphDestroy(graph);
+  // what the call leaves resident: the T final candidates (tensors, eta, objective, status) against the last step's references
+  c->n_states = rc == QMPS_OK ? T : 0;
+  c->tensors_valid = true;
+  c->overlap_refs = rc == QMPS_OK ? T : 0;
+  c->overlap_group = 0;
+  return rc;
 }
 
 int qmps_overlap_batch(qmps_ctx* c, int64_t B, const double* A, int a_shared, const double* states, int kind,
@@ -1189,22 +1441,12 @@ int qmps_overlap_batch(qmps_ctx* c, int64_t B, const double* A, int a_shared, co
   }
   if (B == 0) return QMPS_OK;
   if (int rc = qmps_overlap_set(c, a_shared ? 1 : B, A, WW)) return rc;
-  if (int rc = qmps_overlap_launch(c, B, max_rounds, tol, r_out != nullptr)) return rc;
+  if (int rc = qmps_overlap_launch(c, B, max_rounds, tol, r_out != nullptr ? QMPS_OVERLAP_WANT_R : 0)) return rc;
   return qmps_overlap_get(c, B, eta_out, r_out, rounds_out, status_out);
 }
 
 // ---- brick-wall (new_tdvp) contractions -------------------------------------------------------
 namespace {
-int ensure_scratch(qmps_ctx* c, size_t bytes) {
-  if (bytes > c->scratch_bytes) {
-    if (c->d_scratch) HIP_TRY(hipFree(c->d_scratch));
-    c->d_scratch = nullptr;
-    c->scratch_bytes = 0;
-    HIP_TRY(hipMalloc(&c->d_scratch, bytes));
-    c->scratch_bytes = bytes;
-  }
-  return QMPS_OK;
-}
 // bump allocator over the scratch arena: copies a host array in, returns the device address
 struct Arena {
   qmps_ctx* c;

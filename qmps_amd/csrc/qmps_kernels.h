@@ -163,7 +163,31 @@ struct OverlapArgs {
   int a_shared;      // 1: one A for the whole batch
   int max_rounds;
   double tol;
+  // time-evolution drivers (qmps_evolve_rotosolve, grouped candidates)
+  int group;                   // > 0: candidate b is compared with reference tensor b / group (trajectory-major batches)
+  double* f_out;               // nullable [B]: the objective -sqrt(|eta|) (qmps/new_time_evolve.py:221)
+  const void* x_in;            // nullable [B][D][D]: warm start of the power method (D = 8, 16); an all-zero matrix = cold start
+  const int* slot_ptr;         // nullable: x_in and r_out are displaced by *slot_ptr * slot_stride bytes (rotosolve keeps one
+  int64_t slot_stride;         //   set of fixed points per parameter: the candidates of parameter i return to the same slot every sweep)
+  unsigned long long* stats;   // nullable [4]: evaluations, sum of rounds, max rounds, not converged (atomics)
 };
+#if defined(__HIPCC__)
+__device__ __forceinline__ int64_t overlap_ref_index(const OverlapArgs& p, int64_t b) { return p.group > 0 ? b / p.group : (p.a_shared ? 0 : b); }
+__device__ __forceinline__ int64_t overlap_slot_offset(const OverlapArgs& p) { return p.slot_ptr != nullptr ? (int64_t)(*p.slot_ptr) * p.slot_stride : 0; }
+// results of one evaluation (called by ONE lane)
+__device__ __forceinline__ void overlap_store(const OverlapArgs& p, int64_t b, double eta_r, double eta_i, int rounds, int status) {
+  ((double2*)p.eta)[b] = make_double2(eta_r, eta_i);
+  p.iters[b] = rounds;
+  p.status[b] = status;
+  if (p.f_out != nullptr) p.f_out[b] = -__builtin_sqrt(__builtin_sqrt(eta_r * eta_r + eta_i * eta_i));
+  if (p.stats != nullptr) {
+    atomicAdd(p.stats + 0, 1ULL);
+    atomicAdd(p.stats + 1, (unsigned long long)rounds);
+    atomicMax(p.stats + 2, (unsigned long long)rounds);
+    if (status != QMPS_ST_OK) atomicAdd(p.stats + 3, 1ULL);
+  }
+}
+#endif
 hipError_t launch_overlap(const OverlapArgs& a, hipStream_t st);   // D = 2 (lane kernel, squaring)
 // D = 4, 8, 16: operator-form power method (qmps_overlap.hip); tensors [2][D][D]; max_rounds = cap on power steps;
 // mfma: D = 16 on the matrix cores (one wave per evaluation) instead of the generic LDS-tile kernel

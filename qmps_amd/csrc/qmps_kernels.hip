@@ -2460,7 +2460,7 @@ hipError_t launch_rotosolve_fused_d2(int kind, const RotoArgs& a, hipStream_t st
 __global__ __launch_bounds__(64) void overlap_lane_kernel(OverlapArgs p) {
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= p.B) return;
-  const double2* Ap = (const double2*)p.A + (p.a_shared ? 0 : b * 8);
+  const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * 8;
   const double2* Bp = (const double2*)p.Bt + b * 8;
   const double2* W = (const double2*)p.WW;
   // two-site products: AA[t1 t2] = A_t1 A_t2, BB likewise (2 x 2 complex each)
@@ -2591,17 +2591,16 @@ __global__ __launch_bounds__(64) void overlap_lane_kernel(OverlapArgs p) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) { mr[a][c] = qr[a][c] * inv; mi[a][c] = qi[a][c] * inv; }
   }
-  ((double2*)p.eta)[b] = make_double2(eta_r, eta_i);
+  overlap_store(p, b, eta_r, eta_i, rounds, status);
   if (p.r_out != nullptr) {
     double n2 = 0.0;
 #pragma unroll
     for (int a = 0; a < 4; ++a) n2 += vr[a] * vr[a] + vi[a] * vi[a];
     const double inv = n2 > 0.0 ? 1.0 / __builtin_sqrt(n2) : 0.0;
+    double2* ro = (double2*)((char*)p.r_out + overlap_slot_offset(p));
 #pragma unroll
-    for (int a = 0; a < 4; ++a) ((double2*)p.r_out)[b * 4 + a] = make_double2(vr[a] * inv, vi[a] * inv);
+    for (int a = 0; a < 4; ++a) ro[b * 4 + a] = make_double2(vr[a] * inv, vi[a] * inv);
   }
-  p.status[b] = status;
-  p.iters[b] = rounds;
 }
 
 hipError_t launch_overlap(const OverlapArgs& a, hipStream_t st) {

@@ -89,7 +89,7 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_block_kerne
   };
   // ---- set-up: inputs through the Y tiles, then C_s = sum_t WW[s][t] A_t1 A_t2 and Bm_s = B_s1 B_s2
   {
-    const double2* Ap = (const double2*)p.A + (p.a_shared ? 0 : bb * (2 * N));
+    const double2* Ap = (const double2*)p.A + overlap_ref_index(p, bb) * (2 * N);
     const double2* Bp = (const double2*)p.Bt + bb * (2 * N);
     sY[e][0][i][j] = Ap[l];
     sY[e][1][i][j] = Ap[N + l];
@@ -123,6 +123,16 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_block_kerne
     }
   }
   double2 x = make_double2(i == j ? 1.0 / __builtin_sqrt((double)D) : 0.0, 0.0);
+  const int64_t slot_off = overlap_slot_offset(p);
+  if (p.x_in != nullptr) {      // warm start: the resident fixed point of this candidate's slot (all zero: none yet)
+    const double2 w = ((const double2*)((const char*)p.x_in + slot_off))[bb * N + l];
+    double v[4] = {w.x * w.x + w.y * w.y, 0.0, 0.0, 0.0};
+    group_sum4(v);
+    if (v[0] > 1e-200 && v[0] < 1e200) {
+      const double inv = 1.0 / __builtin_sqrt(v[0]);
+      x = make_double2(w.x * inv, w.y * inv);
+    }
+  }
   double2 eta = make_double2(0.0, 0.0);
   int iters = 0, status = QMPS_ST_NOT_CONVERGED;
   bool active = true;
@@ -168,12 +178,8 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_block_kerne
     }
   }
   if (!valid) return;
-  if (l == 0) {
-    ((double2*)p.eta)[b] = eta;
-    p.iters[b] = iters;
-    p.status[b] = status;
-  }
-  if (p.r_out != nullptr) ((double2*)p.r_out)[b * N + l] = x;
+  if (l == 0) overlap_store(p, b, eta.x, eta.y, iters, status);
+  if (p.r_out != nullptr) ((double2*)((char*)p.r_out + slot_off))[b * N + l] = x;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -214,8 +220,9 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
       aim[kk] = t.y;
     }
   };
+  const int64_t slot_off = overlap_slot_offset(p);
   for (int64_t b = (int64_t)blockIdx.x * WAVES + wave; b < p.B; b += (int64_t)gridDim.x * WAVES) {
-    const double2* Ap = (const double2*)p.A + (p.a_shared ? 0 : b * (2 * D * D));
+    const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * (2 * D * D);
     const double2* Bp = (const double2*)p.Bt + b * (2 * D * D);
     const double2* W = (const double2*)p.WW;
     // ---- set-up: AA_t = A_t1 A_t2 and BB_t = B_t1 B_t2 (C-layout), C_s = sum_t WW[s][t] AA_t; both sets to A-layout
@@ -273,6 +280,23 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
       xr[q] = (c == 4 * q + g) ? 0.25 : 0.0;
       xi[q] = 0.0;
     }
+    if (p.x_in != nullptr) {      // warm start: the resident fixed point of this candidate's slot (all zero: none yet)
+      const double2* xi_ = (const double2*)((const char*)p.x_in + slot_off) + b * (D * D);
+      v4f64 wr, wi;
+      double n2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double2 t = xi_[(4 * q + g) * D + c];
+        wr[q] = t.x; wi[q] = t.y;
+        n2 = dfma(t.x, t.x, dfma(t.y, t.y, n2));
+      }
+      n2 = lane0(wave_sum(n2));
+      if (n2 > 1e-200 && n2 < 1e200) {
+        const double inv = 1.0 / __builtin_sqrt(n2);
+        xr = wr * inv;
+        xi = wi * inv;
+      }
+    }
     double eta_r = 0.0, eta_i = 0.0;
     int iters = 0, status = QMPS_ST_NOT_CONVERGED;
     for (int k = 1; k <= p.max_rounds; ++k) {
@@ -317,13 +341,9 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
       xr = nr * inv;
       xi = ni * inv;
     }
-    if (lane == 0) {
-      ((double2*)p.eta)[b] = make_double2(eta_r, eta_i);
-      p.iters[b] = iters;
-      p.status[b] = status;
-    }
+    if (lane == 0) overlap_store(p, b, eta_r, eta_i, iters, status);
     if (p.r_out != nullptr) {
-      double2* ro = (double2*)p.r_out + b * (D * D);
+      double2* ro = (double2*)((char*)p.r_out + slot_off) + b * (D * D);
 #pragma unroll
       for (int q = 0; q < 4; ++q) ro[(4 * q + g) * D + c] = make_double2(xr[q], xi[q]);
     }
@@ -363,7 +383,7 @@ __global__ __launch_bounds__(256) void overlap_square_d4_kernel(OverlapArgs p) {
   for (int64_t b = (int64_t)blockIdx.x * WAVES + wave; b < p.B; b += (int64_t)gridDim.x * WAVES) {
     // ---- set-up through LDS: inputs at sT[0..63], then C_s[i][j] at sT[64 + 16 s + 4 i + j], Bm_s at sT[128 + ...]
     {
-      const double2* Ap = (const double2*)p.A + (p.a_shared ? 0 : b * 32);
+      const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * 32;
       const double2* Bp = (const double2*)p.Bt + b * 32;
       __builtin_amdgcn_wave_barrier();
       sT[lane] = lane < 32 ? Ap[lane] : Bp[lane - 32];
@@ -468,11 +488,7 @@ __global__ __launch_bounds__(256) void overlap_square_d4_kernel(OverlapArgs p) {
     } else {
       status = QMPS_ST_NOT_CONVERGED;
     }
-    if (lane == 0) {
-      ((double2*)p.eta)[b] = make_double2(eta_r, eta_i);
-      p.iters[b] = rounds;
-      p.status[b] = status;
-    }
+    if (lane == 0) overlap_store(p, b, eta_r, eta_i, rounds, status);
     if (p.r_out != nullptr) {
       // right fixed point = the largest column of M, unit Frobenius norm
       double cn = 0.0;
@@ -497,7 +513,7 @@ __global__ __launch_bounds__(256) void overlap_square_d4_kernel(OverlapArgs p) {
       const double inv = bn > 0.0 ? 1.0 / __builtin_sqrt(bn) : 0.0;
       if (lane < 16) {
         const double2 u = sT[16 + lane];
-        ((double2*)p.r_out)[b * 16 + lane] = make_double2(u.x * inv, u.y * inv);
+        ((double2*)((char*)p.r_out + overlap_slot_offset(p)))[b * 16 + lane] = make_double2(u.x * inv, u.y * inv);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -544,8 +560,9 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) 
       im[q] = t.y;
     }
   };
+  const int64_t slot_off = overlap_slot_offset(p);
   for (int64_t b = blockIdx.x; b < p.B; b += gridDim.x) {
-    const double2* Ap = (const double2*)p.A + (p.a_shared ? 0 : b * (2 * D * D));
+    const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * (2 * D * D);
     const double2* Bp = (const double2*)p.Bt + b * (2 * D * D);
     const double2* W = (const double2*)p.WW;
     const int t1 = wave >> 1, t2 = wave & 1;          // this wave's pair (s = 2 t1 + t2 = wave)
@@ -595,6 +612,23 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) 
     for (int q = 0; q < 4; ++q) {
       xr[q] = (c == 4 * q + g) ? 0.25 : 0.0;
       xi[q] = 0.0;
+    }
+    if (p.x_in != nullptr) {      // warm start: the resident fixed point of this candidate's slot (all zero: none yet)
+      const double2* xi_ = (const double2*)((const char*)p.x_in + slot_off) + b * (D * D);
+      v4f64 wr, wi;
+      double n2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double2 t = xi_[(4 * q + g) * D + c];
+        wr[q] = t.x; wi[q] = t.y;
+        n2 = dfma(t.x, t.x, dfma(t.y, t.y, n2));
+      }
+      n2 = lane0(wave_sum(n2));
+      if (n2 > 1e-200 && n2 < 1e200) {
+        const double inv = 1.0 / __builtin_sqrt(n2);
+        xr = wr * inv;
+        xi = wi * inv;
+      }
     }
     double eta_r = 0.0, eta_i = 0.0;
     int iters = 0, status = QMPS_ST_NOT_CONVERGED;
@@ -648,13 +682,9 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) 
       xi = ni * inv;
     }
     if (wave == 0) {
-      if (lane == 0) {
-        ((double2*)p.eta)[b] = make_double2(eta_r, eta_i);
-        p.iters[b] = iters;
-        p.status[b] = status;
-      }
+      if (lane == 0) overlap_store(p, b, eta_r, eta_i, iters, status);
       if (p.r_out != nullptr) {
-        double2* ro = (double2*)p.r_out + b * (D * D);
+        double2* ro = (double2*)((char*)p.r_out + slot_off) + b * (D * D);
 #pragma unroll
         for (int q = 0; q < 4; ++q) ro[(4 * q + g) * D + c] = make_double2(xr[q], xi[q]);
       }

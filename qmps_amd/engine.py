@@ -88,6 +88,7 @@ class EnergyEngine:
         hist = np.empty((int(n_sweeps), P.shape[0]))
         L.check(self._lib.qmps_rotosolve(self._ctx, P.shape[0], int(kind), P.shape[1], _f64(P), int(n_sweeps),
                                          int(max_iter), float(tol), _f64(hist)))
+        self.B = P.shape[0]         # the library leaves the R final vectors (tensors, energies, statuses) resident
         return hist, P
 
     def double_rotosolve(self, kind, params, n_sweeps=1, max_iter=10000, tol=1e-13):
@@ -97,6 +98,7 @@ class EnergyEngine:
         hist = np.empty((int(n_sweeps), P.shape[0]))
         L.check(self._lib.qmps_double_rotosolve(self._ctx, P.shape[0], int(kind), P.shape[1], _f64(P), int(n_sweeps),
                                                 int(max_iter), float(tol), _f64(hist)))
+        self.B = P.shape[0]
         return hist, P
 
     def tensors(self, B=None):
@@ -111,6 +113,7 @@ class EnergyEngine:
         h = np.ascontiguousarray(np.asarray(h, dtype=np.complex128).reshape(-1, 4, 4))
         if getattr(self, '_h_resident', None) is not None and self._h_resident.shape == h.shape and np.array_equal(self._h_resident, h):
             return                  # already resident (an optimiser passes the same Hamiltonian with every objective call)
+        self._h_resident = None
         L.check(self._lib.qmps_set_hamiltonian(self._ctx, h.shape[0], _f64(h.view(np.float64))))
         self.n_terms = h.shape[0]
         self._h_resident = h.copy()
@@ -196,6 +199,13 @@ class EnergyEngine:
         L.check(self._lib.qmps_get_energies(self._ctx, B, _f64(E), _i32(it), _i32(st)))
         return E, it, st
 
+    def results_status(self, B=None):
+        """Per-evaluation status of the last launch (energy or overlap) only."""
+        B = self.B if B is None else B
+        st = np.empty(B, dtype=np.int32)
+        L.check(self._lib.qmps_get_status(self._ctx, B, _i32(st)))
+        return st
+
     def environments(self, B=None):
         B = self.B if B is None else B
         r = np.empty((B, self.D, self.D), dtype=np.complex128)
@@ -224,6 +234,7 @@ class EnergyEngine:
         E = np.empty((B, nt))
         it = np.empty(B, dtype=np.int32)
         st = np.empty(B, dtype=np.int32)
+        self._h_resident = None     # the call uploads h before it can fail: the cache is valid again only after success
         L.check(self._lib.qmps_energy_batch(
             self._ctx, B, _f64(states.view(np.float64)), L.INPUT_TENSOR if kind == 'tensor' else L.INPUT_UNITARY,
             _f64(h.view(np.float64)), nt, None if r0c is None else _f64(r0c.view(np.float64)), int(max_iter),
@@ -240,6 +251,7 @@ class EnergyEngine:
         E = np.empty((B, nt))
         it = np.empty(B, dtype=np.int32)
         st = np.empty(B, dtype=np.int32)
+        self._h_resident = None
         L.check(self._lib.qmps_energy_batch_ansatz(self._ctx, B, int(kind), P.shape[1], _f64(P), _f64(h.view(np.float64)), nt,
                                                    int(max_iter), float(tol), _f64(E), _i32(it), _i32(st)))
         self.B, self.n_terms = B, nt
@@ -275,6 +287,7 @@ class EnergyEngine:
         E = np.empty((B, nt))
         it = np.empty(B, dtype=np.int32)
         st = np.empty(B, dtype=np.int32)
+        self._h_resident = None
         L.check(self._lib.qmps_cell2_energy_batch(self._ctx, B, _f64(U1.view(np.float64)), _f64(U2.view(np.float64)),
                                                   _f64(h.view(np.float64)), nt, int(max_iter), float(tol), _f64(E),
                                                   _i32(it), _i32(st)))
@@ -327,11 +340,54 @@ class EnergyEngine:
         L.check(self._lib.qmps_overlap_set(self._ctx, 1 if A.ndim == 3 else A.shape[0], _f64(A.view(np.float64)),
                                            _f64(WW.view(np.float64))))
 
-    def overlap_launch(self, B=None, max_rounds=None, tol=1e-13, want_r=False):
-        """Asynchronous: overlaps of the resident candidates [window, window + B) with the resident reference."""
+    def overlap_set_refs_params(self, kind, ref_params, WW):
+        """Reference states as ansatz parameters (n, P): the tensors A_t = tensor(params_t) are built on the device
+        (what the reference does at the top of every time step, new_time_evolve.py:281-283)."""
+        P = np.ascontiguousarray(np.atleast_2d(ref_params), dtype=np.float64)
+        WW = np.ascontiguousarray(WW, dtype=np.complex128).reshape(4, 4)
+        L.check(self._lib.qmps_overlap_set_refs_ansatz(self._ctx, P.shape[0], int(kind), P.shape[1], _f64(P), _f64(WW.view(np.float64))))
+
+    def overlap_set_group(self, group):
+        """Trajectory-major batches: candidate b is compared with reference b // group (0 = shared / one per candidate)."""
+        L.check(self._lib.qmps_overlap_set_group(self._ctx, int(group)))
+
+    def overlap_launch(self, B=None, max_rounds=None, tol=1e-13, want_r=False, warm=False):
+        """Asynchronous: overlaps of the resident candidates [window, window + B) with the resident reference(s).
+        warm=True (D = 8, 16): start every candidate from the fixed point its slot holds from the previous launch
+        (implies want_r: the new fixed points stay resident)."""
         if max_rounds is None:
             max_rounds = 40 if self.D in (2, 4) else 20000
-        L.check(self._lib.qmps_overlap_launch(self._ctx, self.B if B is None else B, int(max_rounds), float(tol), 1 if want_r else 0))
+        flags = (L.OVERLAP_WANT_R if (want_r or warm) else 0) | (L.OVERLAP_WARM if warm else 0)
+        L.check(self._lib.qmps_overlap_launch(self._ctx, self.B if B is None else B, int(max_rounds), float(tol), flags))
+
+    def overlap_objective(self, B=None):
+        """f_b = -sqrt(|eta_b|) of the last overlap launch (new_time_evolve.py:221), computed on the device."""
+        B = self.B if B is None else B
+        f = np.empty(B)
+        L.check(self._lib.qmps_overlap_get_objective(self._ctx, B, _f64(f)))
+        return f
+
+    def overlap_stats(self, reset=False):
+        """dict(evaluations, rounds_sum, rounds_max, not_converged) accumulated by the overlap kernels since the last reset."""
+        v = [ctypes.c_int64(0) for _ in range(4)]
+        L.check(self._lib.qmps_overlap_stats(self._ctx, byref(v[0]), byref(v[1]), byref(v[2]), byref(v[3]), 1 if reset else 0))
+        return {'evaluations': v[0].value, 'rounds_sum': v[1].value, 'rounds_max': v[2].value, 'not_converged': v[3].value}
+
+    def evolve_rotosolve(self, kind, params, WW, n_steps=1, n_sweeps=1, double_frequency=False, max_rounds=None, tol=1e-12):
+        """Device-resident time evolution (qmps_evolve_rotosolve): params (T, P) -> (params after the last step (T, P),
+        params_hist (n_steps, T, P), f_hist (n_steps, n_sweeps, T))."""
+        P = np.array(np.atleast_2d(params), dtype=np.float64, order='C', copy=True)
+        WW = np.ascontiguousarray(WW, dtype=np.complex128).reshape(4, 4)
+        if max_rounds is None:
+            max_rounds = 60 if self.D in (2, 4) else 100000
+        T, npar = P.shape
+        ph = np.empty((int(n_steps), T, npar))
+        fh = np.empty((int(n_steps), int(n_sweeps), T))
+        L.check(self._lib.qmps_evolve_rotosolve(self._ctx, T, int(kind), npar, _f64(P), _f64(WW.view(np.float64)), int(n_steps),
+                                                int(n_sweeps), 6 if double_frequency else 3, int(max_rounds), float(tol),
+                                                _f64(ph), _f64(fh)))
+        self.B = T
+        return P, ph, fh
 
     def overlap_results(self, B=None, want_r=False):
         B = self.B if B is None else B

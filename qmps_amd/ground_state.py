@@ -215,7 +215,14 @@ class SparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
             return None
         from .rotosolve import device_double_rotosolve
         es, P = device_double_rotosolve(self, np.asarray(self.initial_guess, dtype=float)[None], n_sweeps)
-        self.initial_guess[...] = P[0]              # the reference updates the parameter vector in place
+        # the reference updates the caller's parameter vector in place, element by element (tools.py:453): that works for
+        # lists as well as arrays (a tuple cannot be updated in place there either)
+        if isinstance(self.initial_guess, np.ndarray):
+            self.initial_guess[...] = P[0]
+        elif isinstance(self.initial_guess, list):
+            self.initial_guess[:] = [float(v) for v in P[0]]
+        else:
+            self.initial_guess = P[0].copy()
         hist = [float(e) for e in es[:, 0]]
         self.f = hist[-1]
         return RotosolveResult(hist, hist[-1], self.initial_guess, '')

@@ -18,44 +18,159 @@ from .tools import unitary_to_tensor
 
 
 def gate(v, symbol='U'):
-    """The candidate state tensor's gate (new_time_evolve.py:186-187, scripts/loschmidt.py:203-207)."""
+    """The candidate state tensor's gate (new_time_evolve.py:186-187; scripts/loschmidt.py:203-207 uses
+    ShallowCNOTStateTensor(2, v) instead - pass `state_tensor=` to the functions below for that)."""
     return ShallowFullStateTensor(2, v, symbol)
 
 
-def state_tensor(p):
+def _default_class(D):
+    """new_time_evolve.py evolves ShallowFullStateTensor(2, .) (15 angles); scripts/loschmidt.py ShallowCNOTStateTensor(2, .),
+    the only family with members at every bond dimension."""
+    from .represent import ShallowCNOTStateTensor
+    return ShallowFullStateTensor if D == 2 else ShallowCNOTStateTensor
+
+
+def _n_angles(cls, p):
+    return 15 if cls is ShallowFullStateTensor else len(p)
+
+
+def state_tensor(p, D=2, state_tensor=None):
     """A(p) = unitary_to_tensor(unitary(gate(p))); already left-canonical (a unitary's first D columns)."""
-    return unitary_to_tensor(unitary(gate(p)))
+    cls = state_tensor or _default_class(D)
+    return unitary_to_tensor(unitary(cls(D, np.asarray(p, dtype=float)[:_n_angles(cls, p)])))
 
 
-def batch_obj(P, A, WW, return_eta=False):
-    """-sqrt(|eta|) for every row of P (B, 15) against the current state A (2,2,2): one kernel launch."""
+def batch_obj(P, A, WW, return_eta=False, D=2, state_tensor=None, max_rounds=None, tol=1e-13):
+    """-sqrt(|eta|) for every row of P (B, n_angles) against the current state A (2,D,D) [or one state per row,
+    (B,2,D,D)]: one kernel launch.  Gate classes the library simulates (`device_kind`) are built on the device."""
+    cls = state_tensor or _default_class(D)
     P = np.ascontiguousarray(np.atleast_2d(P), dtype=np.float64)
-    eng = _runtime.engine(2, P.shape[0])
-    eta, rounds, st = eng.overlaps(A, P[:, :15], WW, kind='params', ansatz=L.ANSATZ_SHALLOW_FULL)
+    P = P[:, :_n_angles(cls, P[0])]
+    eng = _runtime.engine(D, P.shape[0])
+    kind = getattr(cls, 'device_kind', None)
+    if kind is None or (kind == L.ANSATZ_SHALLOW_FULL and D != 2):
+        cand = np.stack([unitary_to_tensor(unitary(cls(D, p))) for p in P])
+        eta, rounds, st = eng.overlaps(A, cand, WW, kind='tensor', max_rounds=max_rounds, tol=tol)
+    else:
+        eta, rounds, st = eng.overlaps(A, P, WW, kind='params', ansatz=kind, max_rounds=max_rounds, tol=tol)
     f = -np.sqrt(np.abs(eta))
     f = np.where(st == L.STATUS_OK, f, np.nan)
     return (f, eta) if return_eta else f
 
 
-def obj(p, A, WW):
-    """Scalar objective with the reference's signature `obj(p, A, WW)` (extra entries of p beyond the 15
-    gate angles - the reference's unused `rs` - are ignored)."""
-    return float(batch_obj(np.asarray(p, dtype=float)[None, :15], A, WW)[0])
+def obj(p, A, WW, D=None, state_tensor=None):
+    """Scalar objective with the reference's signature `obj(p, A, WW)` (extra entries of p beyond the gate angles -
+    the reference's unused `rs` - are ignored).  The bond dimension is read off A."""
+    D = np.asarray(A).shape[-1] if D is None else D
+    return float(batch_obj(np.asarray(p, dtype=float)[None], A, WW, D=D, state_tensor=state_tensor)[0])
 
 
-def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=None):
-    """The reference's time-evolution loop (new_time_evolve.py:276-292): at each step the current tensor
-    A = A(params) is fixed and the next parameters maximise the overlap with W . |A A>."""
-    params = np.array(params, dtype=float)
-    history = [params.copy()]
-    for step in range(n_steps):
-        A = state_tensor(params)
-        res = minimize(obj, params, (A, WW), method=method, options=options or {})
-        params = res.x
-        history.append(params.copy())
+class _GroupedObjective:
+    """Batched objective of T trajectories against their own reference states, trajectory-major candidate batches of a
+    FIXED group size G (candidate t G + k belongs to trajectory t): parameters -> tensors, overlap objective and
+    -sqrt|eta| all on the device; the fixed points stay resident in the candidates' slots, so the next batch of the
+    same shape - the next iteration's neighbours of a slightly moved iterate - starts warm (D = 8, 16)."""
+
+    def __init__(self, D, kind, T, G, max_rounds, tol, device=0):
+        from .engine import EnergyEngine
+        self.eng = EnergyEngine(D, T * G, device=device)
+        self.kind, self.T, self.G, self.max_rounds, self.tol = kind, T, G, max_rounds, tol
+        self.warm = False
+
+    def set_reference(self, ref_params, WW):
+        self.eng.overlap_set_refs_params(self.kind, ref_params, WW)
+        self.eng.overlap_set_group(self.G)
+
+    def __call__(self, cand):
+        cand = np.ascontiguousarray(cand, dtype=np.float64)
+        assert cand.shape[0] == self.T * self.G
+        self.eng.set_ansatz_params(self.kind, cand)
+        self.eng.overlap_launch(self.T * self.G, max_rounds=self.max_rounds, tol=self.tol, warm=self.warm)
+        self.warm = self.eng.D >= 8
+        f = self.eng.overlap_objective(self.T * self.G)
+        st = self.eng.results_status(self.T * self.G)
+        return np.where(st == L.STATUS_OK, f, np.nan)
+
+    def close(self):
+        self.eng.close()
+
+
+def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=None, D=2, state_tensor=None,
+           n_sweeps=4, max_rounds=None, tol=1e-12, return_info=False):
+    """The reference's time-evolution loop (new_time_evolve.py:276-292, scripts/loschmidt.py:367-375): at each step the
+    current tensor A = A(params) is fixed and the next parameters maximise the overlap with W . |A A>, starting from the
+    current ones.  `params` (P,) - one trajectory, the reference's shape - or (T, P): T independent trajectories
+    (BASELINE.json configs[4]) evolved in lock-step.  Any bond dimension D in {2, 4, 8, 16}; `state_tensor` = gate class
+    (default: ShallowFullStateTensor at D = 2, ShallowCNOTStateTensor otherwise).
+      method 'Rotosolve' / 'DoubleRotosolve': the WHOLE evolution - every step, sweep, parameter, trajectory - is one C
+          call (`qmps_evolve_rotosolve`, n_sweeps sweeps per step), no host round trip;
+      method 'BFGS': lock-step batched BFGS (`tools.batched_bfgs`): per iteration two device batches over all
+          trajectories - central-difference gradient columns, backtracking ladder - warm-started from resident fixed points;
+      anything else: scipy.optimize.minimize on the scalar `obj` per trajectory (the reference's own call).
+    Returns the parameter history (n_steps + 1, [T,] P) [and an info dict with the objective history]."""
+    cls = state_tensor or _default_class(D)
+    single = np.ndim(params) == 1
+    X = np.array(np.atleast_2d(params), dtype=float)
+    X = X[:, :_n_angles(cls, X[0])]
+    T, P = X.shape
+    kind = getattr(cls, 'device_kind', None)
+    on_device = kind is not None and not (kind == L.ANSATZ_SHALLOW_FULL and D != 2)
+    history, info = [X.copy()], {'fun': []}
+    m = method.lower() if isinstance(method, str) else method
+    if m in ('rotosolve', 'doublerotosolve') and on_device:
+        nsh = 6 if m == 'doublerotosolve' else 3
+        eng = _runtime.engine(D, nsh * T)
+        Xf, ph, fh = eng.evolve_rotosolve(kind, X, WW, n_steps=n_steps, n_sweeps=n_sweeps, double_frequency=nsh == 6,
+                                          max_rounds=max_rounds, tol=tol)
+        history += [ph[k] for k in range(n_steps)]
+        info['fun'] = fh
+        info['solver'] = eng.overlap_stats()
         if callback is not None:
-            callback(step, params, res.fun)
-    return np.array(history)
+            for k in range(n_steps):
+                callback(k, ph[k] if not single else ph[k][0], fh[k, -1] if not single else fh[k, -1, 0])
+    elif m == 'bfgs' and on_device:
+        from .tools import batched_bfgs
+        opts = dict(options or {})
+        ladder = opts.pop('alphas', (1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096))
+        mr = max_rounds if max_rounds is not None else (60 if D in (2, 4) else 100000)
+        fg = _GroupedObjective(D, kind, T, 2 * P + 1, mr, tol)
+        fl = _GroupedObjective(D, kind, T, len(ladder), mr, tol)
+        try:
+            for step in range(n_steps):
+                fg.set_reference(X, WW)
+                fl.set_reference(X, WW)
+                res = batched_bfgs(fg, fl, X, maxiter=opts.get('maxiter', 200), gtol=opts.get('gtol', 1e-5),
+                                   h=opts.get('eps', 1e-6), alphas=ladder)
+                X = res['x']
+                history.append(X.copy())
+                info['fun'].append(res['history'])
+                info.setdefault('nit', []).append(res['nit'])
+                info.setdefault('nfev', []).append(res['nfev'])
+                if callback is not None:
+                    callback(step, X if not single else X[0], res['fun'] if not single else res['fun'][0])
+            info['solver'] = {'gradient_batches': fg.eng.overlap_stats(), 'line_search_batches': fl.eng.overlap_stats()}
+        finally:
+            fg.close()
+            fl.close()
+    else:
+        for step in range(n_steps):
+            Xn, fs = np.empty_like(X), np.empty(T)
+            for t in range(T):
+                A = state_tensor_of(cls, D, X[t])
+                res = minimize(obj, X[t], (A, WW, D, cls), method=method, options=options or {})
+                Xn[t], fs[t] = res.x, res.fun
+            X = Xn
+            history.append(X.copy())
+            info['fun'].append(fs)
+            if callback is not None:
+                callback(step, X if not single else X[0], fs if not single else fs[0])
+    H = np.array(history)
+    H = H[:, 0] if single else H
+    return (H, info) if return_info else H
+
+
+def state_tensor_of(cls, D, p):
+    return unitary_to_tensor(unitary(cls(D, p)))
 
 
 # ---- the rest of the reference module's surface ------------------------------------------------------------
@@ -135,7 +250,7 @@ def run(params, WW, T, ops=None, method='Nelder-Mead', options=None):
     for _ in T[1:]:
         A = state_tensor(params)
         res = minimize(obj, params, (A, WW), method=method, options=options or {})
-        params = res.x
+        params = res.x[:15]
         evs.append(one_site_expectations(A, ops))
         les.append(loschmidt_overlap(A, A0))
         ps.append(params.copy())

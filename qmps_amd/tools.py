@@ -250,6 +250,77 @@ def double_rotosolve(eps, initial_parameters, N_iters=100, disp=True, batch_eps=
     return RotosolveResult(history, history[-1], params, '')
 
 
+def batched_fd_gradient(batch_fun, X, h=1e-6, F0=None):
+    """Central-difference gradients of T independent objectives in ONE batched evaluation: the "finite-difference
+    columns" of SURVEY section 3 as a batch.  batch_fun: (N, P) -> (N,), rows independent; X (T, P).
+    Returns (f (T,), g (T, P)); the candidates are trajectory-major, row t (2P + 1) + k."""
+    X = np.atleast_2d(np.asarray(X, dtype=float))
+    T, P = X.shape
+    I = np.eye(P)
+    cand = np.concatenate([X[:, None, :], X[:, None, :] + h * I[None], X[:, None, :] - h * I[None]], axis=1)
+    F = np.asarray(batch_fun(cand.reshape(-1, P))).reshape(T, 2 * P + 1)
+    return F[:, 0], (F[:, 1:P + 1] - F[:, P + 1:]) / (2 * h)
+
+
+def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=1e-4,
+                 alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096)):
+    """T independent BFGS minimisations in LOCK-STEP (scipy's BFGS is what the reference's time-evolution loop runs per
+    step: `minimize(obj, params, (A_, WW))`, new_time_evolve.py:284 / scripts/loschmidt.py:371 - one trajectory, one
+    scalar objective call at a time).  Here every iteration is two batched evaluations over all trajectories:
+      grad_batch  (T (2P+1), P) -> values: the iterates and their 2P central-difference neighbours (step h),
+      line_batch  (T len(alphas), P) -> values: the backtracking ladder x + alpha d; the first alpha with the Armijo
+                  decrease f(x + alpha d) <= f + c1 alpha g.d is taken (none: the best of the ladder if it decreases f,
+                  else the trajectory stops).
+    Rows are trajectory-major (what `qmps_overlap_set_group` expects).  Inverse-Hessian update: the BFGS formula, skipped
+    when s.y <= 1e-12 |s||y|.  A trajectory is converged when max|g| < gtol and then stays put (its rows are still
+    evaluated: the batch shape never changes, so resident warm starts keep their slots).
+    Returns dict(x (T,P), fun (T,), jac (T,P), nit, nfev, converged (T,), history [fun per iteration])."""
+    X = np.array(np.atleast_2d(X0), dtype=float)
+    T, P = X.shape
+    al = np.asarray(alphas, dtype=float)
+    Hinv = np.tile(np.eye(P), (T, 1, 1))
+    f, g = batched_fd_gradient(grad_batch, X, h)
+    nfev = T * (2 * P + 1)
+    active = np.abs(g).max(axis=1) >= gtol
+    history = [f.copy()]
+    nit = 0
+    while nit < maxiter and active.any():
+        d = -np.einsum('tij,tj->ti', Hinv, g)
+        slope = np.einsum('ti,ti->t', g, d)
+        bad = ~(slope < 0)
+        if bad.any():                                   # not a descent direction: restart from steepest descent
+            Hinv[bad] = np.eye(P)
+            d[bad] = -g[bad]
+            slope[bad] = -np.einsum('ti,ti->t', g[bad], g[bad])
+        d[~active] = 0.0
+        cand = X[:, None, :] + al[None, :, None] * d[:, None, :]
+        Fc = np.asarray(line_batch(cand.reshape(-1, P))).reshape(T, len(al))
+        nfev += T * len(al)
+        Fc = np.where(np.isfinite(Fc), Fc, np.inf)
+        ok = Fc <= f[:, None] + c1 * al[None, :] * slope[:, None]
+        first = np.where(ok.any(axis=1), ok.argmax(axis=1), Fc.argmin(axis=1))
+        fa = Fc[np.arange(T), first]
+        moved = active & (fa < f)
+        a = np.where(moved, al[first], 0.0)
+        s = a[:, None] * d
+        Xn = X + s
+        fn, gn = batched_fd_gradient(grad_batch, Xn, h)
+        nfev += T * (2 * P + 1)
+        y = gn - g
+        sy = np.einsum('ti,ti->t', s, y)
+        upd = moved & (sy > 1e-12 * np.linalg.norm(s, axis=1) * np.linalg.norm(y, axis=1)) & (sy > 0)
+        for t in np.nonzero(upd)[0]:
+            rho = 1.0 / sy[t]
+            V = np.eye(P) - rho * np.outer(s[t], y[t])
+            Hinv[t] = V @ Hinv[t] @ V.T + rho * np.outer(s[t], s[t])
+        X, f, g = Xn, np.where(moved, fn, f), np.where(moved[:, None], gn, g)
+        active = active & moved & (np.abs(g).max(axis=1) >= gtol)
+        history.append(f.copy())
+        nit += 1
+    return {'x': X, 'fun': f, 'jac': g, 'nit': nit, 'nfev': nfev, 'converged': np.abs(g).max(axis=1) < gtol,
+            'history': np.array(history)}
+
+
 class Optimizer:
     """Same contract as tools.py:203-284: subclasses bind/override `objective_function(params) ->
     float`; `optimize()` dispatches on settings['method'] ('Rotosolve' -> double_rotosolve,

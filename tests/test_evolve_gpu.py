@@ -1,0 +1,182 @@
+"""GPU: BASELINE.json configs[4] as a workload - device-backed TIME EVOLUTION at D = 2, 4, 16 (qmps/new_time_evolve.py:252-302,
+scripts/loschmidt.py:335-383, scripts/rotosolve.py:270-294) replayed on the host with the ORACLE (numpy dense eig of the
+D^2 x D^2 mixed transfer matrix, oracle.overlap_eta) as evaluator; plus the pieces the drivers are made of: reference states
+built from parameters on the device, trajectory-major candidate groups, resident warm starts, solver statistics.
+Tolerance: 1e-8 on every recorded objective value -sqrt|eta| (eta itself 1e-10, as in test_overlap_gpu.py)."""
+import numpy as np
+import pytest
+from scipy.linalg import expm
+
+import evolve_replay as ER
+from oracle import qmps_oracle as O
+from qmps_amd import _lib as L
+from qmps_amd import new_time_evolve as NT
+from qmps_amd import represent as R
+
+pytestmark = pytest.mark.gpu
+
+H_TFIM = O.hamiltonian_matrix({'ZZ': -1.0, 'X': 1.0})
+F_TOL = 1e-8
+
+
+def WW_of(dt):
+    return expm(-1j * dt * H_TFIM)
+
+
+@pytest.mark.parametrize('D,kind,P,G', [(2, 2, 15, 5), (4, 0, 4, 4), (8, 0, 6, 3), (16, 0, 8, 3)])
+def test_grouped_candidates_against_device_built_references(D, kind, P, G, engine_factory):
+    """Reference tensors from parameters on the device, candidate b against reference b // G, objective -sqrt|eta|
+    computed by the kernel, statistics - all against the oracle."""
+    rng = np.random.default_rng(40 + D)
+    eng = engine_factory(D, 4096)
+    T = 5
+    WW = WW_of(0.05)
+    ref = rng.standard_normal((T, P))
+    cand = (ref[:, None, :] + 0.05 * rng.standard_normal((T, G, P))).reshape(T * G, P)
+    eng.overlap_set_refs_params(kind, ref, WW)
+    eng.overlap_set_group(G)
+    eng.set_ansatz_params(kind, cand)
+    eng.overlap_stats(reset=True)
+    eng.overlap_launch(T * G, tol=1e-13, want_r=True)
+    eta, rounds, st, r = eng.overlap_results(T * G, want_r=True)
+    f = eng.overlap_objective(T * G)
+    assert np.all(st == 0)
+    for b in range(T * G):
+        A = ER.tensor(kind, D, ref[b // G])
+        ref_eta, r_ref = O.overlap_eta(A, ER.tensor(kind, D, cand[b]), WW)
+        assert abs(eta[b] - ref_eta) < 1e-10, (b, eta[b], ref_eta)
+        assert abs(f[b] + np.sqrt(abs(ref_eta))) < 1e-10
+        assert abs(abs(np.vdot(r_ref, r[b])) - 1.0) < 1e-8
+    s = eng.overlap_stats()
+    assert s['evaluations'] == T * G and s['rounds_sum'] == int(rounds.sum()) and s['rounds_max'] == int(rounds.max()) and s['not_converged'] == 0
+    # a window inside the groups: candidates [2 G, 4 G) against references 2 and 3
+    eng.set_window(2 * G)
+    eng.overlap_launch(2 * G, tol=1e-13)
+    eta_w, _, st_w = eng.overlap_results(2 * G)
+    assert np.all(st_w == 0) and np.abs(eta_w - eta[2 * G:4 * G]).max() < 1e-12
+    with pytest.raises(L.QmpsError):
+        eng.set_window(1)
+        eng.overlap_launch(G, tol=1e-13)          # a window must start at a multiple of the group
+    eng.set_window(0)
+    eng.overlap_set_group(0)
+    with pytest.raises(L.QmpsError):
+        eng.overlap_launch(T * G, tol=1e-13)      # 5 references, 15+ candidates, no group: refused, not mis-addressed
+
+
+@pytest.mark.parametrize('D,P', [(8, 6), (16, 8)])
+def test_warm_start_from_resident_fixed_points(D, P, engine_factory):
+    """QMPS_OVERLAP_WARM: the same batch shape re-evaluated after the candidates moved a little starts from the fixed
+    points the previous launch left in the slots: same eigenvalues (oracle), fewer power steps; unmoved candidates are
+    accepted by their first step; a launch without resident fixed points is refused."""
+    rng = np.random.default_rng(50 + D)
+    eng = engine_factory(D, 4096)
+    T, G = 6, 4
+    WW = WW_of(0.05)
+    ref = rng.standard_normal((T, P))
+    cand = (ref[:, None, :] + 0.03 * rng.standard_normal((T, G, P))).reshape(T * G, P)
+    eng.overlap_set_refs_params(0, ref, WW)
+    eng.overlap_set_group(G)
+    eng.set_ansatz_params(0, cand)
+    eng.overlap_launch(T * G, tol=1e-12)                      # no fixed points kept
+    with pytest.raises(L.QmpsError):
+        eng.overlap_launch(T * G, tol=1e-12, warm=True)
+    eng.overlap_launch(T * G, tol=1e-12, want_r=True)
+    eta0, rounds0, st0 = eng.overlap_results(T * G)
+    assert np.all(st0 == 0)
+    eng.overlap_launch(T * G, tol=1e-12, warm=True)           # nothing moved: one step each
+    eta1, rounds1, st1 = eng.overlap_results(T * G)
+    assert np.all(st1 == 0) and np.all(rounds1 <= 2) and np.abs(eta1 - eta0).max() < 1e-11
+    moved = cand + 1e-6 * rng.standard_normal(cand.shape)     # finite-difference neighbours of the same iterates
+    eng.set_ansatz_params(0, moved)
+    eng.overlap_launch(T * G, tol=1e-12, warm=True)
+    eta2, rounds2, st2 = eng.overlap_results(T * G)
+    assert np.all(st2 == 0)
+    assert rounds2.mean() < 0.75 * rounds0.mean(), (rounds2.mean(), rounds0.mean())
+    for b in range(0, T * G, 5):
+        ref_eta, _ = O.overlap_eta(ER.tensor(0, D, ref[b // G]), ER.tensor(0, D, moved[b]), WW)
+        assert abs(eta2[b] - ref_eta) < 1e-10
+
+
+# (D, ansatz kind, parameters, trajectories, steps, sweeps, shifts per parameter, seed)
+ROTO_CASES = [(2, 2, 15, 3, 3, 2, 3, 11),      # the reference's own case: ShallowFullStateTensor(2, .), new_time_evolve.py:186-187
+              (2, 0, 8, 3, 3, 2, 6, 12),       # scripts/loschmidt.py:203-207: ShallowCNOTStateTensor(2, .) with 8 angles, double frequency
+              (4, 0, 4, 3, 3, 2, 3, 13),
+              (4, 0, 4, 2, 3, 1, 6, 14),
+              (16, 0, 8, 2, 3, 1, 3, 903)]     # configs[4]: D = 16, depth 4
+
+
+@pytest.mark.parametrize('D,kind,P,T,n_steps,n_sweeps,nsh,seed', ROTO_CASES)
+def test_device_time_evolution_by_rotosolve_vs_oracle_replay(D, kind, P, T, n_steps, n_sweeps, nsh, seed, engine_factory):
+    """qmps_evolve_rotosolve (every step, sweep, parameter and trajectory inside one C call) against the host replay that
+    evaluates every candidate with the oracle's dense eigen-solve."""
+    rng = np.random.default_rng(seed)
+    X0 = rng.standard_normal((T, P))
+    WW = WW_of(0.05)
+    eng = engine_factory(D, 4096)
+    eng.overlap_stats(reset=True)
+    Xf, ph, fh = eng.evolve_rotosolve(kind, X0, WW, n_steps=n_steps, n_sweeps=n_sweeps, double_frequency=nsh == 6,
+                                      max_rounds=60 if D <= 4 else 400000, tol=1e-12)
+    stats = eng.overlap_stats()
+    assert stats['not_converged'] == 0, stats
+    assert stats['evaluations'] == n_steps * n_sweeps * (P * nsh + 1) * T
+    ph_ref, fh_ref = ER.replay_rotosolve(kind, D, X0, WW, n_steps, n_sweeps, nsh)
+    assert np.abs(fh - fh_ref).max() < F_TOL, np.abs(fh - fh_ref).max()
+    # the parameters themselves: same trajectory (angles compared on the circle)
+    d = np.angle(np.exp(1j * (ph - ph_ref)))
+    assert np.abs(d).max() < 1e-6, np.abs(d).max()
+    assert np.array_equal(Xf, ph[-1])
+    assert np.all(fh < 0) and np.all(fh >= -1 - 1e-12)
+    # a time step of a tenth of the coupling keeps the overlap density close to one after the sweeps
+    assert fh[:, -1].mean() < -0.9
+
+
+@pytest.mark.parametrize('D,P,T', [(2, 8, 4), (4, 4, 4), (16, 8, 3)])
+def test_lockstep_bfgs_time_evolution(D, P, T):
+    """`evolve(..., method='BFGS')`: batched central-difference gradients and backtracking ladders of all trajectories on
+    the device (warm-started at D = 16) against the SAME lock-step driver with the oracle as evaluator."""
+    from qmps_amd.tools import batched_bfgs
+    rng = np.random.default_rng(70 + D)
+    X0 = rng.standard_normal((T, P))
+    WW = WW_of(0.05)
+    n_steps = 3
+    H, info = NT.evolve(X0, WW, n_steps, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-13,
+                        options={'maxiter': 12}, return_info=True)
+    assert H.shape == (n_steps + 1, T, P)
+    X = X0.copy()
+    for step in range(n_steps):
+        A = [ER.tensor(0, D, X[t]) for t in range(T)]
+
+        def fb(G):
+            return lambda C: np.array([ER.objective(0, D, A[b // G], C[b], WW) for b in range(len(C))])
+        res = batched_bfgs(fb(2 * P + 1), fb(8), X, maxiter=12)
+        dev = info['fun'][step]
+        assert dev.shape == res['history'].shape, (dev.shape, res['history'].shape)
+        assert np.abs(dev - res['history']).max() < F_TOL, np.abs(dev - res['history']).max()
+        # continue from the DEVICE's iterate: the comparison of the next step is then about that step only
+        assert np.abs(H[step + 1] - res['x']).max() < 1e-4
+        X = H[step + 1]
+        # the optimiser did its job: the projected state is closer to W|A A> than the unevolved one
+        assert np.all(dev[-1] <= dev[0] + 1e-12)
+        assert dev[-1].mean() < -0.999
+    if D == 16:
+        s = info['solver']['gradient_batches']
+        assert s['not_converged'] == 0
+
+
+def test_reference_signature_single_trajectory(engine_factory):
+    """evolve(params (P,), ...) keeps the reference's shape: history (n_steps + 1, P); scipy method per trajectory."""
+    rng = np.random.default_rng(5)
+    p0 = rng.standard_normal(15)
+    WW = WW_of(0.02)
+    H = NT.evolve(p0, WW, 2, method='Rotosolve', n_sweeps=2)
+    assert H.shape == (3, 15)
+    A = NT.state_tensor(H[0])
+    f = NT.obj(H[1], A, WW)
+    assert abs(f - O.overlap_objective(A, NT.state_tensor(H[1]), WW)) < 1e-10
+    assert f < NT.obj(H[0], A, WW)                                  # a sweep of rotosolve improved on "do not move"
+    Hs = NT.evolve(p0, WW, 1, method='Nelder-Mead', options={'maxiter': 60})
+    assert Hs.shape == (2, 15)
+    # D = 4 through the scalar objective
+    p4 = rng.standard_normal(4)
+    A4 = NT.state_tensor(p4, D=4)
+    assert abs(NT.obj(p4 + 0.01, A4, WW) - O.overlap_objective(A4, NT.state_tensor(p4 + 0.01, D=4), WW)) < 1e-10

@@ -85,8 +85,9 @@ class _GroupedObjective:
         cand = np.ascontiguousarray(cand, dtype=np.float64)
         assert cand.shape[0] == self.T * self.G
         self.eng.set_ansatz_params(self.kind, cand)
-        self.eng.overlap_launch(self.T * self.G, max_rounds=self.max_rounds, tol=self.tol, warm=self.warm)
-        self.warm = self.eng.D >= 8
+        keep = self.eng.D >= 8          # power-method bond dimensions: the fixed points stay in the candidates' slots
+        self.eng.overlap_launch(self.T * self.G, max_rounds=self.max_rounds, tol=self.tol, want_r=keep, warm=self.warm)
+        self.warm = keep
         f = self.eng.overlap_objective(self.T * self.G)
         st = self.eng.results_status(self.T * self.G)
         return np.where(st == L.STATUS_OK, f, np.nan)

@@ -23,12 +23,10 @@ def tensor(kind, D, p):
 
 def objective(kind, D, A, p, WW, want_gap=False):
     B = tensor(kind, D, p)
-    if not want_gap:
-        return -np.sqrt(abs(O.overlap_eta(A, B, WW)[0]))
+    # the eigenvalues of the matrix oracle.overlap_eta diagonalises (no eigenvectors: half the time at D = 16)
     C = np.tensordot(WW, O.merge(A, A), [1, 0])
-    w = np.linalg.eigvals(O.transfer_matrix(C, O.merge(B, B)))
-    w = np.sort(np.abs(w))[::-1]
-    return -np.sqrt(w[0]), w[1] / w[0]
+    w = np.sort(np.abs(np.linalg.eigvals(O.transfer_matrix(C, O.merge(B, B)))))[::-1]
+    return (-np.sqrt(w[0]), w[1] / w[0]) if want_gap else -np.sqrt(w[0])
 
 
 def replay_rotosolve(kind, D, params, WW, n_steps, n_sweeps, nsh=3, gaps=None):

@@ -376,6 +376,137 @@ def main_overlap(args):
         dist.destroy_process_group()
 
 
+def evolve_cpu_baseline(D, P, WW, seed, maxiter, budget_T=2):
+    """The same lock-step BFGS time step with the ORACLE as evaluator, the way the reference obtains eta (xmps Map ->
+    scipy.sparse.linalg.eigs, ARPACK in operator form: oracle.overlap_eta_arpack) and the oracle's own circuit model for
+    parameters -> tensor, one host core, on a bounded sample: budget_T trajectories, one time step."""
+    from oracle import qmps_oracle as O
+    from qmps_amd.tools import batched_bfgs
+    _one_blas_thread()
+    X = np.random.default_rng(seed).standard_normal((budget_T, P))
+    A = [O.unitary_to_tensor(O.shallow_cnot_unitary(D, x)) for x in X]
+    n = [0]
+
+    def fb(G):
+        def f(C):
+            n[0] += len(C)
+            return np.array([-np.sqrt(abs(O.overlap_eta_arpack(A[b // G], O.unitary_to_tensor(O.shallow_cnot_unitary(D, C[b])), WW)[0]))
+                             for b in range(len(C))])
+        return f
+    t = time.perf_counter()
+    res = batched_bfgs(fb(2 * P + 1), fb(8), X, maxiter=maxiter)
+    dt = time.perf_counter() - t
+    return {'value': budget_T / dt, 'unit': 'trajectory time steps/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{budget_T} trajectories x 1 time step of the same lock-step BFGS (maxiter {maxiter}), {n[0]} objective evaluations, each '
+                      f'ARPACK (scipy eigs, operator form: what xmps Map.right_fixed_point runs for the reference) on the {D * D}-dimensional map '
+                      '+ the oracle\'s gate-by-gate circuit for parameters -> tensor; numpy, 1 thread',
+            'objective_evals_per_s': n[0] / dt, 'iterations': int(res['nit']), 'mean_final_objective': float(res['fun'].mean())}
+
+
+def main_evolve(args):
+    """--workload evolve: BASELINE.json configs[4] as it is worded - TFIM quench TIME EVOLUTION at D = 16, depth 4, independent
+    trajectories per GPU.  One step = one TIME STEP of all T trajectories (qmps/new_time_evolve.py:276-292,
+    scripts/loschmidt.py:367-375): reference tensors A_t = tensor(params_t) built on the device, then the minimiser the reference
+    runs per step (scipy BFGS with finite-difference gradients) in lock-step over the trajectories: per iteration one device
+    batch of T (2P + 1) central-difference candidates and one of T x 8 backtracking candidates - parameters -> tensor ->
+    dominant eigenvalue of the mixed transfer map -> -sqrt|eta| - warm-started from the fixed points resident in the candidates'
+    slots.  `value` = trajectory time steps per second.  Independent trajectories: replicas only at N > 1, no collective."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    D, T = args.D, args.batch
+    depth = {2: 4, 4: 2, 8: 3, 16: 4}[D]          # D = 2: scripts/loschmidt.py evolves ShallowCNOTStateTensor(2, .) with 8 angles
+    P = 2 * depth
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if os.path.isdir('/sys/class/net/lo'):
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from scipy.linalg import expm
+    WW = expm(-1j * args.dt * tfim_h(1.0))
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = evolve_cpu_baseline(D, P, WW, args.seed, args.bfgs_iters)
+    from qmps_amd import _lib
+    from qmps_amd.new_time_evolve import LockstepEvolver
+    from qmps_amd.represent import ShallowCNOTStateTensor
+    ev = LockstepEvolver(D, T, P, ShallowCNOTStateTensor, tol=args.tol, maxiter=args.bfgs_iters, device=local_rank)
+    info = _lib.device_info(local_rank)
+    X = np.random.default_rng(args.seed + rank).standard_normal((T, P))
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        ev.fg.eng.probe_fp64_tflops()
+    for _ in range(args.warmup):
+        X = ev.step(X, WW)['x']
+    ev.fg.eng.overlap_stats(reset=True)
+    ev.fl.eng.overlap_stats(reset=True)
+    ev.fg.kernel_ms, ev.fl.kernel_ms = [], []
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    nit, nfev, f_last = [], 0, None
+    for _ in range(args.steps):
+        res = ev.step(X, WW)
+        X = res['x']
+        nit.append(res['nit'])
+        nfev += res['nfev']
+        f_last = res['fun']
+    ev.fg.eng.sync()
+    ev.fl.eng.sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sg, sl = ev.fg.eng.overlap_stats(), ev.fl.eng.overlap_stats()
+    if rank == 0:
+        squaring = D in (2, 4)
+        per_round = 8 * (D * D) ** 3 if squaring else 64 * D ** 3           # a squaring of the complex D^2 x D^2 matrix / a power step (8 complex D^3 products)
+        setup = 64 * D ** 3 + (32 * D ** 4 if squaring else 128 * D * D)
+        kms = np.array(ev.fg.kernel_ms)
+        flops_g = sg['rounds_sum'] * per_round + sg['evaluations'] * setup
+        tflops = flops_g / max(kms.sum() * 1e-3, 1e-12) * 1e-12
+        byts = sg['evaluations'] * (32 * D * D + 16 + (32 * D * D if not squaring else 0))
+        kernel_total_ms = float(kms.sum() + np.sum(ev.fl.kernel_ms))
+        out = {'metric': f'time-evolution trajectory steps/sec at D={D}, depth={depth}, {T} trajectories per GPU',
+               'value': world * T * args.steps / elapsed, 'unit': 'trajectory time steps/s', 'n_gpus': world, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+               'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+               'config': {'workload': f'TFIM g=1 quench time evolution, D={D}, ShallowCNOT depth {depth} ({P} parameters), {T} independent trajectories per GPU '
+                                      f'from random parameters, W = exp(-{args.dt:g} i h), one step = one time step of every trajectory: lock-step BFGS '
+                                      f'(<= {args.bfgs_iters} iterations, gtol 1e-5, central differences h = 1e-6, 8-point backtracking ladder), objective '
+                                      f'-sqrt|eta| with eta to {args.tol:g} (residual of the power method / rank-one test of the squaring)',
+                          'baseline_config': 'BASELINE.json configs[4]', 'D': D, 'trajectories_per_gpu': T, 'n_params': P, 'seed': args.seed,
+                          'bfgs_iterations_per_step': float(np.mean(nit)), 'objective_evals_per_step': nfev / args.steps,
+                          'objective_evals_per_s': world * nfev / elapsed,
+                          'mean_final_objective': float(np.nanmean(f_last)), 'worst_final_objective': float(np.nanmax(f_last)),
+                          'solver_rounds_mean_gradient_batches': sg['rounds_sum'] / max(1, sg['evaluations']), 'solver_rounds_max_gradient_batches': sg['rounds_max'],
+                          'solver_rounds_mean_ladder_batches': sl['rounds_sum'] / max(1, sl['evaluations']), 'solver_rounds_max_ladder_batches': sl['rounds_max'],
+                          'not_converged': sg['not_converged'] + sl['not_converged'],
+                          'kernel_share_of_wall': kernel_total_ms * 1e-3 / elapsed,
+                          'collective': 'none: independent trajectories (replicas only)', 'device': info['name'], 'arch': info['arch']},
+               'roofline': {'bound': 'fp64_matrix' if D == 16 else ('fp64_matrix' if D == 4 else 'fp64_valu'), 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                            'frac': tflops / FP64_PEAK_TFLOPS, 'traffic': None,
+                            'kernel': ev.fg.eng.kernel_time(1)[1], 'kernel_ms': float(kms.mean()), 'launches': int(len(kms)),
+                            'kernel_ms_from': 'HIP events around EVERY launch of the gradient batches\' overlap kernel in the timed region (sum of durations / launches)',
+                            'note': f'dominant kernel = the overlap kernel of the gradient batches (T (2P+1) = {T * (2 * P + 1)} candidates per launch); executed FLOPs = '
+                                    f'rounds x {per_round} + evaluations x {setup} summed by the kernel itself (qmps_overlap_stats) over the same launches',
+                            'hbm': {'achieved': byts / max(kms.sum() * 1e-3, 1e-12) * 1e-9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                                    'frac': byts / max(kms.sum() * 1e-3, 1e-12) * 1e-9 / HBM_PEAK_GBPS,
+                                    'note': 'candidate tensor in + fixed point in and out (warm start) + eta / objective / status out per evaluation; the reference tensor is shared by a group'}},
+               'cpu_baseline': cpu}
+        print(json.dumps(out), flush=True)
+    ev.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main_rotosolve(args):
     """--workload rotosolve: the caller that produces the batch (qmps/rotosolve.py:154-181,
     qmps/tools.py:422-457).  R restarts of the optimisers' default ansatz (ShallowCNOTStateTensor, depth log2(D)) in
@@ -446,10 +577,12 @@ def main_rotosolve(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--workload', choices=['energy', 'overlap', 'rotosolve'], default='energy',
+    ap.add_argument('--workload', choices=['energy', 'overlap', 'rotosolve', 'evolve'], default='energy',
                     help="'energy' = the headline (two-site energy evaluations, BASELINE.json configs[2]); 'overlap' = the time-evolution "
                          "overlap objective (configs[4]; use with --D 16 --batch 768); 'rotosolve' = sweeps of the device-resident optimiser loop "
                          '(--steps = sweeps, --batch = evaluations per parameter update)')
+    ap.add_argument('--dt', type=float, default=0.05, help='evolve workload: time step (W = exp(-i dt h))')
+    ap.add_argument('--bfgs-iters', type=int, default=30, help='evolve workload: cap on BFGS iterations per time step')
     ap.add_argument('--double-frequency', action='store_true', help='rotosolve workload: six shifts per parameter (qmps/tools.py:422-457)')
     # defaults: the chip needs tens of ms of sustained load before its clocks settle
     ap.add_argument('--steps', type=int, default=2000)
@@ -487,6 +620,16 @@ def main():
         if args.max_iter == 10000:
             args.max_iter = 60 if args.D in (2, 4) else 100000      # D = 2, 4: squarings; D = 8, 16: power steps
         return main_overlap(args)
+    if args.workload == 'evolve':
+        if args.steps == 2000 and args.warmup == 450:
+            args.steps, args.warmup = 8, 2
+        if args.batch == 65536:
+            args.batch = 256
+        if args.D == 4 and '--D' not in sys.argv:
+            args.D = 16
+        if args.tol == 1e-13:
+            args.tol = 1e-12
+        return main_evolve(args)
     if args.workload == 'rotosolve':
         if args.steps == 2000 and args.warmup == 450:
             args.steps, args.warmup = 160, 8

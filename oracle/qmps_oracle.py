@@ -606,6 +606,26 @@ def overlap_eta(A, B, WW):
     return w[k], r / np.linalg.norm(r)
 
 
+def overlap_eta_arpack(A, B, WW, tol=1e-14, ncv=24):
+    """The same dominant eigenvalue the way the reference obtains it: xmps `Map.right_fixed_point` hands the map as a
+    LinearOperator to scipy.sparse.linalg.eigs (ARPACK, implicitly restarted Arnoldi, k = 1, which = 'LM').  Operator form:
+    x -> sum_s C_s x Bm_s^+ on D x D matrices, never the D^2 x D^2 matrix.  Used where the dense eigen-solve of
+    `overlap_eta` is too slow for a test (hundreds of D = 16 candidates); cross-checked against it in tests/test_oracle.py."""
+    from scipy.sparse.linalg import LinearOperator, eigs
+    C = np.tensordot(WW, merge(A, A), [1, 0])
+    Bh = merge(B, B).conj().transpose(0, 2, 1)
+    D = A.shape[1]
+
+    def mv(x):
+        X = x.reshape(D, D)
+        return np.matmul(np.matmul(C, X), Bh).sum(axis=0).reshape(-1)
+    op = LinearOperator((D * D, D * D), matvec=mv, dtype=complex)
+    w, v = eigs(op, k=1, which='LM', v0=np.eye(D, dtype=complex).reshape(-1) / np.sqrt(D), tol=tol, ncv=min(ncv, D * D - 1),
+                maxiter=100000)
+    r = v[:, 0].reshape(D, D)
+    return w[0], r / np.linalg.norm(r)
+
+
 def overlap_objective(A, B, WW):
     """-sqrt(2 |psi[0]|) of the reference's circuit == -sqrt(|eta|)."""
     return -np.sqrt(abs(overlap_eta(A, B, WW)[0]))

@@ -76,6 +76,7 @@ class _GroupedObjective:
         self.eng = EnergyEngine(D, T * G, device=device)
         self.kind, self.T, self.G, self.max_rounds, self.tol = kind, T, G, max_rounds, tol
         self.warm = False
+        self.kernel_ms = None          # a list: receives the HIP-event duration of every launch's overlap kernel (bench.py)
 
     def set_reference(self, ref_params, WW):
         self.eng.overlap_set_refs_params(self.kind, ref_params, WW)
@@ -89,6 +90,8 @@ class _GroupedObjective:
         self.eng.overlap_launch(self.T * self.G, max_rounds=self.max_rounds, tol=self.tol, want_r=keep, warm=self.warm)
         self.warm = keep
         f = self.eng.overlap_objective(self.T * self.G)
+        if self.kernel_ms is not None:
+            self.kernel_ms.append(self.eng.kernel_time(1)[0])
         st = self.eng.results_status(self.T * self.G)
         return np.where(st == L.STATUS_OK, f, np.nan)
 
@@ -130,18 +133,14 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
             for k in range(n_steps):
                 callback(k, ph[k] if not single else ph[k][0], fh[k, -1] if not single else fh[k, -1, 0])
     elif m == 'bfgs' and on_device:
-        from .tools import batched_bfgs
         opts = dict(options or {})
         ladder = opts.pop('alphas', (1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096))
         mr = max_rounds if max_rounds is not None else (60 if D in (2, 4) else 100000)
-        fg = _GroupedObjective(D, kind, T, 2 * P + 1, mr, tol)
-        fl = _GroupedObjective(D, kind, T, len(ladder), mr, tol)
+        ev = LockstepEvolver(D, T, P, cls, mr, tol, opts.get('maxiter', 200), opts.get('gtol', 1e-5), opts.get('eps', 1e-6), ladder)
+        fg, fl = ev.fg, ev.fl
         try:
             for step in range(n_steps):
-                fg.set_reference(X, WW)
-                fl.set_reference(X, WW)
-                res = batched_bfgs(fg, fl, X, maxiter=opts.get('maxiter', 200), gtol=opts.get('gtol', 1e-5),
-                                   h=opts.get('eps', 1e-6), alphas=ladder)
+                res = ev.step(X, WW)
                 X = res['x']
                 history.append(X.copy())
                 info['fun'].append(res['history'])
@@ -151,8 +150,7 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
                     callback(step, X if not single else X[0], res['fun'] if not single else res['fun'][0])
             info['solver'] = {'gradient_batches': fg.eng.overlap_stats(), 'line_search_batches': fl.eng.overlap_stats()}
         finally:
-            fg.close()
-            fl.close()
+            ev.close()
     else:
         for step in range(n_steps):
             Xn, fs = np.empty_like(X), np.empty(T)
@@ -168,6 +166,30 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
     H = np.array(history)
     H = H[:, 0] if single else H
     return (H, info) if return_info else H
+
+
+class LockstepEvolver:
+    """The 'BFGS' branch of `evolve` as an object that keeps its two device contexts (gradient batches, ladder batches) and
+    their resident fixed points across time steps: `step(X)` = one time step of all trajectories."""
+
+    def __init__(self, D, T, P, cls=None, max_rounds=None, tol=1e-12, maxiter=200, gtol=1e-5, eps=1e-6,
+                 alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), device=0):
+        cls = cls or _default_class(D)
+        self.kind = getattr(cls, 'device_kind')
+        mr = max_rounds if max_rounds is not None else (60 if D in (2, 4) else 100000)
+        self.alphas, self.maxiter, self.gtol, self.eps = tuple(alphas), maxiter, gtol, eps
+        self.fg = _GroupedObjective(D, self.kind, T, 2 * P + 1, mr, tol, device=device)
+        self.fl = _GroupedObjective(D, self.kind, T, len(self.alphas), mr, tol, device=device)
+
+    def step(self, X, WW):
+        from .tools import batched_bfgs
+        self.fg.set_reference(X, WW)
+        self.fl.set_reference(X, WW)
+        return batched_bfgs(self.fg, self.fl, X, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas)
+
+    def close(self):
+        self.fg.close()
+        self.fl.close()
 
 
 def state_tensor_of(cls, D, p):

@@ -140,7 +140,7 @@ def test_device_time_evolution_by_rotosolve_vs_oracle_replay(D, kind, P, T, n_st
     # so this driver is checked for what it computes; the optimiser that does the physics is method='BFGS' below)
 
 
-@pytest.mark.parametrize('D,P,T,iters', [(2, 8, 4, 12), (4, 4, 4, 12), (16, 8, 2, 5)])
+@pytest.mark.parametrize('D,P,T,iters', [(2, 8, 4, 12), (4, 4, 4, 12), (16, 8, 3, 8)])
 def test_lockstep_bfgs_time_evolution(D, P, T, iters):
     """`evolve(..., method='BFGS')`: batched central-difference gradients and backtracking ladders of all trajectories on
     the device (warm-started at D = 16) against the SAME lock-step driver with the oracle as evaluator."""
@@ -157,7 +157,15 @@ def test_lockstep_bfgs_time_evolution(D, P, T, iters):
         A = [ER.tensor(0, D, X[t]) for t in range(T)]
 
         def fb(G):
-            return lambda C: np.array([ER.objective(0, D, A[b // G], C[b], WW) for b in range(len(C))])
+            # D = 16: ARPACK in operator form, the reference's own route (xmps Map -> scipy eigs) - the dense eigen-solve of
+            # hundreds of 256 x 256 matrices takes minutes; every 7th candidate is cross-checked against it
+            def f(C):
+                v = np.array([ER.objective(0, D, A[b // G], C[b], WW, arpack=D >= 16) for b in range(len(C))])
+                if D >= 16:
+                    for b in range(0, len(C), 7):
+                        assert abs(v[b] - ER.objective(0, D, A[b // G], C[b], WW)) < 1e-10
+                return v
+            return f
         res = batched_bfgs(fb(2 * P + 1), fb(8), X, maxiter=iters)
         dev = info['fun'][step]
         assert dev.shape == res['history'].shape, (dev.shape, res['history'].shape)

@@ -280,6 +280,23 @@ def test_overlap_circuit_identity():
     assert abs(O.overlap_eta(A, A, np.eye(4))[0] - 1) < 1e-12
 
 
+def test_overlap_arpack_route_equals_the_dense_eigen_solve():
+    """The reference's route (xmps Map -> scipy.sparse.linalg.eigs, ARPACK in operator form) and the dense eigen-solve of the
+    D^2 x D^2 matrix give the same dominant eigenvalue and ray for time-step candidates at every bond dimension."""
+    from scipy.linalg import expm
+    rng = np.random.default_rng(23)
+    WW = expm(-0.05j * O.hamiltonian_matrix({'ZZ': -1, 'X': 1}))
+    for D, P in ((2, 8), (4, 4), (8, 6), (16, 8)):
+        for _ in range(3):
+            p = rng.standard_normal(P)
+            A = O.unitary_to_tensor(O.shallow_cnot_unitary(D, p))
+            B = O.unitary_to_tensor(O.shallow_cnot_unitary(D, p + 0.05 * rng.standard_normal(P)))
+            e1, r1 = O.overlap_eta(A, B, WW)
+            e2, r2 = O.overlap_eta_arpack(A, B, WW)
+            assert abs(e1 - e2) < 1e-12
+            assert abs(abs(np.vdot(r1, r2)) - 1) < 1e-10
+
+
 def test_bench_schedule_replay_matches_the_oracle_schedule(golden, c_oracle):
     """bench.py turns the per-item step counts it reads back into executed squarings / mat-vecs by replaying the
     kernel's schedule; the replay must land exactly on the step counts the oracle's restatement of that schedule

@@ -293,6 +293,14 @@ int qmps_overlap_get_objective(qmps_ctx* ctx, int64_t B, double* f_out /* [B] */
  * with status != 0.  Waits for the stream. */
 int qmps_overlap_stats(qmps_ctx* ctx, int64_t* evaluations, int64_t* rounds_sum, int64_t* rounds_max, int64_t* not_converged, int reset);
 
+/* One round trip for the optimiser drivers that keep their update on the host (lock-step BFGS, simplex methods): candidate
+ * parameters params[B][n_params] (QMPS_ANSATZ_* kind) in; tensors built on the device; overlap objective against the
+ * resident references (qmps_overlap_set / _set_refs_ansatz / _set_group) with the flags of qmps_overlap_launch; f_out[B] =
+ * -sqrt|eta_b| and status_out[B] (nullable) back - ONE synchronisation.  eta, rounds, fixed points stay resident
+ * (qmps_overlap_get). */
+int qmps_overlap_eval_ansatz(qmps_ctx* ctx, int64_t B, int kind, int n_params, const double* params, int max_rounds, double tol,
+                             int flags, double* f_out, int32_t* status_out);
+
 /* Device-resident TIME EVOLUTION by rotosolve on the overlap objective (BASELINE.json configs[4]; the reference's loop:
  * qmps/new_time_evolve.py:276-292 / scripts/loschmidt.py:367-375 `for _ in T: A_ = tensor(params); params =
  * minimize(obj, params, (A_, WW)).x`, with the rotosolve update of qmps/rotosolve.py:154-181 (nsh = 3) or

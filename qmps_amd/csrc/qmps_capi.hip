@@ -1304,6 +1304,26 @@ int qmps_overlap_stats(qmps_ctx* c, int64_t* evaluations, int64_t* rounds_sum, i
   return QMPS_OK;
 }
 
+int qmps_overlap_eval_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const double* params, int max_rounds, double tol,
+                             int flags, double* f_out, int32_t* status_out) {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  if (!f_out) return fail(QMPS_ERR_ARG, "null f_out");
+  // one round trip: parameters in, ansatz + overlap kernels, objective and status out - ONE synchronisation (the optimiser
+  // drivers call this twice per iteration; three separate calls cost three synchronisations and two extra launch gaps)
+  c->defer_sync = true;
+  int rc = qmps_set_states_ansatz(c, B, kind, n_params, params);
+  c->defer_sync = false;
+  if (!rc) rc = qmps_overlap_launch(c, B, max_rounds, tol, flags);
+  if (rc) {
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(f_out, c->d_f, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (status_out) HIP_TRY(hipMemcpyAsync(status_out, c->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+
 int qmps_evolve_rotosolve(qmps_ctx* c, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps,
                           int n_sweeps, int nsh, int max_rounds, double tol, double* params_hist, double* f_hist) {
   if (int rc = bind(c)) return rc;

@@ -360,6 +360,20 @@ class EnergyEngine:
         flags = (L.OVERLAP_WANT_R if (want_r or warm) else 0) | (L.OVERLAP_WARM if warm else 0)
         L.check(self._lib.qmps_overlap_launch(self._ctx, self.B if B is None else B, int(max_rounds), float(tol), flags))
 
+    def overlap_eval_params(self, kind, cand, max_rounds=None, tol=1e-12, want_r=False, warm=False):
+        """Candidate parameters (B, P) -> (f = -sqrt|eta| (B,), status (B,)) against the resident references, one round trip."""
+        cand = np.ascontiguousarray(np.atleast_2d(cand), dtype=np.float64)
+        if max_rounds is None:
+            max_rounds = 40 if self.D in (2, 4) else 20000
+        B = cand.shape[0]
+        f = np.empty(B)
+        st = np.empty(B, dtype=np.int32)
+        flags = (L.OVERLAP_WANT_R if (want_r or warm) else 0) | (L.OVERLAP_WARM if warm else 0)
+        L.check(self._lib.qmps_overlap_eval_ansatz(self._ctx, B, int(kind), cand.shape[1], _f64(cand), int(max_rounds), float(tol), flags,
+                                                   _f64(f), _i32(st)))
+        self.B = B
+        return f, st
+
     def overlap_objective(self, B=None):
         """f_b = -sqrt(|eta_b|) of the last overlap launch (new_time_evolve.py:221), computed on the device."""
         B = self.B if B is None else B

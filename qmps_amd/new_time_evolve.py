@@ -85,14 +85,11 @@ class _GroupedObjective:
     def __call__(self, cand):
         cand = np.ascontiguousarray(cand, dtype=np.float64)
         assert cand.shape[0] == self.T * self.G
-        self.eng.set_ansatz_params(self.kind, cand)
         keep = self.eng.D >= 8          # power-method bond dimensions: the fixed points stay in the candidates' slots
-        self.eng.overlap_launch(self.T * self.G, max_rounds=self.max_rounds, tol=self.tol, want_r=keep, warm=self.warm)
+        f, st = self.eng.overlap_eval_params(self.kind, cand, max_rounds=self.max_rounds, tol=self.tol, want_r=keep, warm=self.warm)
         self.warm = keep
-        f = self.eng.overlap_objective(self.T * self.G)
         if self.kernel_ms is not None:
             self.kernel_ms.append(self.eng.kernel_time(1)[0])
-        st = self.eng.results_status(self.T * self.G)
         return np.where(st == L.STATUS_OK, f, np.nan)
 
     def close(self):

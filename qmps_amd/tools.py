@@ -309,10 +309,11 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
         y = gn - g
         sy = np.einsum('ti,ti->t', s, y)
         upd = moved & (sy > 1e-12 * np.linalg.norm(s, axis=1) * np.linalg.norm(y, axis=1)) & (sy > 0)
-        for t in np.nonzero(upd)[0]:
-            rho = 1.0 / sy[t]
-            V = np.eye(P) - rho * np.outer(s[t], y[t])
-            Hinv[t] = V @ Hinv[t] @ V.T + rho * np.outer(s[t], s[t])
+        if upd.any():                                   # BFGS update of the inverse Hessians, all trajectories at once
+            rho = 1.0 / sy[upd]
+            su, yu = s[upd], y[upd]
+            V = np.eye(P)[None] - rho[:, None, None] * su[:, :, None] * yu[:, None, :]
+            Hinv[upd] = V @ Hinv[upd] @ V.transpose(0, 2, 1) + rho[:, None, None] * su[:, :, None] * su[:, None, :]
         X, f, g = Xn, np.where(moved, fn, f), np.where(moved[:, None], gn, g)
         active = active & moved & (np.abs(g).max(axis=1) >= gtol)
         history.append(f.copy())

@@ -76,6 +76,23 @@ def tfim_h(g=1.0):
     return -np.kron(Z, Z) + 0.5 * g * (np.kron(I, X) + np.kron(X, I))
 
 
+def xxz_h(delta=0.5):
+    """Heisenberg XXZ two-site term XX + YY + delta ZZ (BASELINE.json configs[3]; Hamiltonian({'XX': 1, 'YY': 1, 'ZZ': delta}).to_matrix(),
+    qmps/ground_state.py:73-88)."""
+    X = np.array([[0, 1], [1, 0]], dtype=complex)
+    Y = np.array([[0, -1j], [1j, 0]], dtype=complex)
+    Z = np.array([[1, 0], [0, -1]], dtype=complex)
+    return np.kron(X, X) + np.kron(Y, Y) + delta * np.kron(Z, Z)
+
+
+def hamiltonian_of(args):
+    """(h, description): --hamiltonian tfim|xxz; default = the one BASELINE.json names for the bond dimension (XXZ at D = 8)."""
+    name = args.hamiltonian or ('xxz' if args.D == 8 else 'tfim')
+    if name == 'xxz':
+        return xxz_h(0.5), 'Heisenberg XXZ (XX + YY + 0.5 ZZ)'
+    return tfim_h(1.0), 'TFIM g=1'
+
+
 def committed_traffic(D, B, solver, store_env, rotate):
     """HBM bytes per step from the PMC passes committed under profiles/ (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE,
     collected in separate rocprofv3 --pmc runs of this very command, tools/prof.sh + tools/collect_profiles.py);
@@ -255,6 +272,12 @@ def executed_flops(D, solver, iters, eng, max_iter):
         flops = float((k_plain * (32 * D ** 3 + 4 * D ** 2) + sq_flops + 64 * D ** 3 + 128 * D ** 2).sum())
         note = ('executed algorithm: m = log2(K) squarings of the real D^2 x D^2 transfer matrix per item (2 (D^2)^3 flop each) + '
                 'its construction; K read back per item')
+    elif solver == 'direct' and D == 8:
+        # env_direct_d8: real 64 x 64 system - build 64 rows x 480 FMA = 30 720 FMA, Gauss-Jordan 64 pivots x 64 rows x ~34 FMA
+        # = 139 264 FMA (DESIGN.md kernel table) - then the block kernel's acceptance step(s) and the energy epilogue
+        flops = float((2.0 * (30720 + 139264) + flops_per_eval(D, iters.astype(np.float64))).sum())
+        note = ('executed algorithm at D = 8: direct 64 x 64 real solve (2 x (30 720 + 139 264) flop) + SURVEY 8(d) K_b(32D^3+4D^2)+64D^3+128D^2 '
+                'for the acceptance step(s) and the energies, K_b read back per item')
     else:
         flops = float(flops_per_eval(D, iters.astype(np.float64)).sum())
         note = 'SURVEY 8(d): sum_b [K_b(32D^3+4D^2)+64D^3+128D^2], K_b read back per item'
@@ -362,8 +385,9 @@ def main_overlap(args):
                           'mean_power_steps': float(rounds.mean()), 'max_power_steps': int(rounds.max()), 'not_converged': int((st != 0).sum()),
                           'mean_abs_eta': float(np.abs(eta).mean()), 'collective': 'none: independent trajectories (replicas only)',
                           'device': info['name'], 'arch': info['arch']},
-               'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / FP64_PEAK_TFLOPS,
-                            'traffic': None, 'kernel': kernel_name, 'kernel_ms': kernel_ms, 'step_ms_events': ev_ms / args.steps,
+               'roofline': {'bound': 'fp64_matrix' if D in (4, 16) else 'fp64_valu', 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / FP64_PEAK_TFLOPS,
+                            'hbm_frac': byts / (kernel_ms * 1e-3) * 1e-9 / HBM_PEAK_GBPS,
+                            'traffic': committed_traffic(D, B, 'overlap', 0, 1), 'kernel': kernel_name, 'kernel_ms': kernel_ms, 'step_ms_events': ev_ms / args.steps,
                             'note': 'executed FLOPs = sum_b [steps_b 64 D^3 + 64 D^3] (complex D^3 products = 8 D^3 flop), steps read back per '
                                     'item; D = 16: v_mfma_f64_16x16x4 (measured 47.7 TFLOP/s issue rate on this part, profiles/r01_probe.json)',
                             'hbm': {'achieved': byts / (kernel_ms * 1e-3) * 1e-9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
@@ -526,11 +550,29 @@ def main_rotosolve(args):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)
+    h, h_name = hamiltonian_of(args)
+    p0 = np.random.default_rng(args.seed + rank).standard_normal((R, P))
+    shifts = np.array([0.0, np.pi, np.pi / 2, -np.pi / 2, np.pi / 4, -np.pi / 4]) if nsh == 6 else np.array([0.0, np.pi / 2, -np.pi / 2])
+    shifted = np.repeat(p0, nsh, axis=0)
+    shifted[:, 0] += np.tile(shifts, R)          # the batch of the first parameter update: evaluation nsh r + k = restart r, shift k
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        # the oracle on one host core over a bounded sample of the same shifted batch: circuit model -> tensor (numpy),
+        # plain power iteration + closed-form energy (C)
+        from oracle import c_oracle as C
+        from oracle import qmps_oracle as O
+        C.build()
+        n = min(len(shifted), 3000 if D <= 4 else (600 if D == 8 else 150))
+        t = time.perf_counter()
+        A_cpu = np.stack([O.unitary_to_tensor(O.shallow_cnot_unitary(D, q)) for q in shifted[:n]])
+        C.energy_batch(A_cpu, h, max_iter=args.max_iter, tol=args.tol, threads=1)
+        cpu = {'value': n / (time.perf_counter() - t), 'unit': 'two-site energy evals/s', 'cores': 1, 'kind': 'port',
+               'sample': f'first {n} evaluations of the first parameter update\'s shifted batch: parameters -> unitary by the oracle\'s gate-by-gate '
+                         'circuit model (numpy) -> tensor -> plain power iteration + closed-form energy (oracle/qmps_oracle.c), 1 thread'}
     from qmps_amd import EnergyEngine, _lib
     eng = EnergyEngine(D, nsh * R, device=local_rank)
     info = _lib.device_info(local_rank)
-    eng.set_hamiltonian(tfim_h(1.0))
-    p0 = np.random.default_rng(args.seed + rank).standard_normal((R, P))
+    eng.set_hamiltonian(h)
     run = eng.double_rotosolve if args.double_frequency else eng.rotosolve
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
@@ -552,21 +594,42 @@ def main_rotosolve(args):
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # roofline of the dominant kernel of a parameter update: the environment + energy kernel over one shifted batch, timed by
+    # HIP events on stand-alone launches of that very batch (inside the run the sweep is a replayed hipGraph: no events there)
+    roof = None
+    if rank == 0:
+        eng.set_ansatz_params(_lib.ANSATZ_SHALLOW_CNOT, shifted)
+        eng.set_kernel_timing_period(1)
+        for _ in range(12):
+            eng.launch(nsh * R, max_iter=args.max_iter, tol=args.tol, solver='direct', store_env=(D != 4))
+        kms, kname = eng.kernel_time(8)
+        _, it_r, st_r = eng.results(nsh * R)
+        fl, fl_note, _ = executed_flops(D, 'direct', it_r, eng, args.max_iter)
+        if D == 4:
+            fl += 1700.0 * len(it_r)                 # the fused ansatz prologue (DESIGN.md kernel table)
+        tf = fl / (kms * 1e-3) * 1e-12
+        byts = nsh * R * (8 * P + 16) if D == 4 else nsh * R * bytes_per_eval(D)
+        roof = {'bound': 'fp64_matrix' if D == 16 else 'fp64_valu', 'achieved': tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / FP64_PEAK_TFLOPS,
+                'hbm_frac': byts / (kms * 1e-3) * 1e-9 / HBM_PEAK_GBPS, 'traffic': None, 'kernel': kname, 'kernel_ms': kms,
+                'kernel_ms_from': 'HIP event pairs around 8 stand-alone launches of the first parameter update\'s shifted batch (same kernel, same shape as inside the captured sweep)',
+                'mean_power_iterations': float(it_r.mean()), 'not_converged_or_not_pd': int((st_r != 0).sum()),
+                'note': 'small batches are latency-bound: the fraction says how far below the FP64 roofline a parameter update sits.  FLOPs = ' + fl_note}
     if rank == 0:
         evals = sweeps * P * nsh * R + R            # shifted batches (a sweep's record comes from the next sweep's shift-0 rows) + the final evaluation
         out = {'metric': f'rotosolve energy evals/sec at D={D}, {R} restarts x {nsh} shifts', 'value': world * evals / elapsed,
                'unit': 'two-site energy evals/s', 'n_gpus': world, 'steps': sweeps, 'warmup': sweeps_w,
                'ms_per_step': elapsed / sweeps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f64', 'data': 'synthetic',
-               'config': {'workload': f'device-resident {"double-frequency " if nsh == 6 else ""}rotosolve, TFIM g=1, D={D}, ShallowCNOT depth {depth} '
+               'config': {'workload': f'device-resident {"double-frequency " if nsh == 6 else ""}rotosolve, {h_name}, D={D}, ShallowCNOT depth {depth} '
                                       f'({P} parameters), {R} restarts x {nsh} shifts = {nsh * R} evaluations per parameter update, one step = one sweep; '
                                       'the whole run is ONE C call (fixed costs - allocation, graph capture, copies - included)',
-                          'baseline_config': 'BASELINE.json configs[1] (D = 2) / configs[2] (D = 4)', 'D': D, 'restarts': R, 'shifts': nsh,
+                          'baseline_config': {2: 'BASELINE.json configs[1]', 4: 'BASELINE.json configs[2] (as an optimiser loop)', 8: 'BASELINE.json configs[3]', 16: 'BASELINE.json configs[4] (energy objective)'}[D],
+                          'hamiltonian': h_name, 'D': D, 'restarts': R, 'shifts': nsh,
                           'n_params': P, 'us_per_parameter_update': elapsed / (sweeps * P) * 1e6,
                           'best_energy': float(np.nanmin(hist[-1])), 'mean_energy_first_sweep': float(np.nanmean(hist[0])),
-                          'mean_energy_last_sweep': float(np.nanmean(hist[-1])), 'exact_ground_state_energy': -4 / np.pi,
+                          'mean_energy_last_sweep': float(np.nanmean(hist[-1])), 'exact_ground_state_energy': (-4 / np.pi) if h_name.startswith('TFIM') else None,
                           'collective': 'none: independent restarts (replicas only)', 'device': info['name'], 'arch': info['arch']},
-               'roofline': None, 'cpu_baseline': None}
+               'roofline': roof, 'cpu_baseline': cpu}
         print(json.dumps(out), flush=True)
     eng.close()
     if dist is not None:
@@ -581,6 +644,8 @@ def main():
                     help="'energy' = the headline (two-site energy evaluations, BASELINE.json configs[2]); 'overlap' = the time-evolution "
                          "overlap objective (configs[4]; use with --D 16 --batch 768); 'rotosolve' = sweeps of the device-resident optimiser loop "
                          '(--steps = sweeps, --batch = evaluations per parameter update)')
+    ap.add_argument('--hamiltonian', choices=['tfim', 'xxz'], default=None,
+                    help='two-site Hamiltonian (default: the one BASELINE.json names for the bond dimension: xxz at D = 8, tfim otherwise)')
     ap.add_argument('--dt', type=float, default=0.05, help='evolve workload: time step (W = exp(-i dt h))')
     ap.add_argument('--bfgs-iters', type=int, default=30, help='evolve workload: cap on BFGS iterations per time step')
     ap.add_argument('--double-frequency', action='store_true', help='rotosolve workload: six shifts per parameter (qmps/tools.py:422-457)')
@@ -655,7 +720,7 @@ def main():
     # synthetic inputs: every rank draws its own R resident batches (seed + 1000 k + rank)
     A_all = np.concatenate([haar_tensors(args.seed + 1000 * k + rank, D, B) for k in range(R)])
     A = A_all[:B]
-    h = tfim_h(1.0)
+    h, h_name = hamiltonian_of(args)
 
     # CPU baselines first: nothing has touched the GPU yet, so the process pool may fork
     cpu = None
@@ -880,6 +945,33 @@ def main():
                 'flops_per_eval': 1920 + 5040, 'working_set_mib': R * B * 48 * D * D / 2 ** 20,
                 'what': 'QMPS_FLAG_WARM_RESIDENT: the resident (converged) environment of every evaluation is accepted by one power step; '
                         f'no matrix build, no elimination; reads tensor + environment ({48 * D * D + 8} B per evaluation), cycled over the {R} resident batches'}
+    if rank == 0 and not args.no_extras and D <= 8:
+        # BASELINE.json configs[2] says "power-iteration environment solve": the same step with the iterative solvers on the
+        # record (QMPS_ENV_POWER = the reference's krylov / PowerCircuit, QMPS_ENV_POWER_SQUARING = the same 2^m steps at a time);
+        # same fixed point, same tolerance as the direct solve of the headline.  No cost exchange in this rank-0-only leg.
+        eng.set_tensors(A_all)
+        legs = {}
+        for name in ('plain', 'squaring'):
+            if name == args.solver:
+                continue
+            n_leg = max(3, min(20, args.steps)) if name == 'plain' else max(5, min(60, args.steps))
+            def leg_step(k, name=name):
+                eng.set_window((k % R) * B)
+                eng.launch(B, max_iter=args.max_iter, tol=args.tol, solver=name, store_env=True)
+            for k in range(2):
+                leg_step(k)
+            eng.sync()
+            eng.timer_begin()
+            for k in range(n_leg):
+                leg_step(k)
+            ms = eng.timer_end() / n_leg
+            _, it_l, st_l = eng.results(B)
+            legs[name] = {'evals_per_s': B / (ms * 1e-3), 'ms_per_step': ms, 'steps_timed': n_leg, 'mean_power_iterations': float(it_l.mean()),
+                          'max_power_iterations': int(it_l.max()), 'not_converged_or_not_pd': int((st_l != 0).sum())}
+        eng.set_window(0)
+        legs['what'] = ('the same resident batches, environment by power iteration to the same tolerance: "plain" = normalised power '
+                        'iteration (krylov / PowerCircuit of the reference), "squaring" = 2^m power steps at a time; energies stored, no cost sum')
+        extras['power_iteration'] = legs
     if dist is not None and rccl_ok and not args.no_extras and args.exchange_every == 1:
         # the grouped exchange (16 steps' costs per all-reduce) as an extra, every rank takes part
         eng.set_tensors(A_all)
@@ -910,8 +1002,9 @@ def main():
         single_kernel_step = direct and world == 1 and dist is None
         if single_kernel_step:
             # the step IS the dominant kernel (the cost is accumulated inside it): its average duration is the event-bracketed
-            # timed region / steps; a pair of events around single launches adds ~2.5 us of command-processor fencing
-            kernel_ms = min(kernel_ms, step_ms_events)
+            # timed region / steps (a pair of events around single launches adds ~2.5 us of command-processor fencing, reported
+            # beside it as kernel_ms_event_pairs)
+            kernel_ms = step_ms_events
         tflops = flops / (kernel_ms * 1e-3) * 1e-12
         traffic = committed_traffic(D, B, args.solver, store_env, R)
         hbm_gbps = B * bytes_per_eval(D) / (kernel_ms * 1e-3) * 1e-9
@@ -922,12 +1015,12 @@ def main():
             'value': value, 'unit': 'two-site energy evals/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'TFIM g=1 two-site energy, D={D}, '
+            'config': {'workload': f'{h_name} two-site energy, D={D}, '
                                    + (f'batch={B} per GPU' if args.scaling == 'weak' else f'global batch={global_batch} split B/G per GPU')
                                    + f', Haar-random state unitaries, in-kernel environment solve (tol {args.tol:g}, cap {args.max_iter}, '
                                      f'solver {args.solver}{"" if store_env else ", environments not stored"}), {R} resident batches cycled',
-                       'baseline_config': 'BASELINE.json configs[2]', 'D': D, 'batch_per_gpu': B,
-                       'global_batch': global_batch, 'tol': args.tol, 'max_iter': args.max_iter, 'seed': args.seed,
+                       'baseline_config': {2: 'BASELINE.json configs[1]', 4: 'BASELINE.json configs[2]', 8: 'BASELINE.json configs[3]', 16: 'BASELINE.json configs[4] (energy kernel)'}[D],
+                       'hamiltonian': h_name, 'D': D, 'batch_per_gpu': B, 'global_batch': global_batch, 'tol': args.tol, 'max_iter': args.max_iter, 'seed': args.seed,
                        'resident_batches': R, 'working_set_mib': R * B * tensor_bytes / 2 ** 20,
                        'clock_settle_ms': args.settle_ms,
                        'mean_power_iterations': tot[0] / tot[3],
@@ -940,15 +1033,19 @@ def main():
                                    'how often and for how long it waited for the exchange that last used the slot.  Whether the all-reduce or the '
                                    'energy kernel sets the pace shows in ms_per_step against roofline.kernel_ms'},
                        'device': info['name'], 'arch': info['arch']},
-            'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': tflops / FP64_PEAK_TFLOPS, 'traffic': traffic,
+            'roofline': {'bound': 'fp64_matrix' if D == 16 or (D == 4 and args.solver == 'squaring') else 'fp64_valu',
+                         'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': tflops / FP64_PEAK_TFLOPS, 'hbm_frac': hbm_gbps / HBM_PEAK_GBPS, 'traffic': traffic,
                          'kernel': kernel_name, 'kernel_ms': kernel_ms, 'step_ms_events': step_ms_events,
                          'kernel_ms_event_pairs': kernel_ms_pair, 'kernel_timed_every': timing_period,
                          'kernel_ms_from': ('HIP events bracketing the timed region on the context stream / steps: the step is this ONE kernel'
                                             if single_kernel_step else 'HIP event pairs around the kernel on every kernel_timed_every-th launch'),
-                         'note': 'FP64-VALU-bound kernel: `bound` names the FP64 peak (MI355X FP64 vector == FP64 matrix = 78.6 TFLOP/s '
-                                 'spec; measured on this part: v_fma_f64 70.9 TFLOP/s, profiles/r01_probe.json); the fused D = 4 kernel '
-                                 'issues no MFMA.  FLOPs = ' + flop_note,
+                         'note': '`bound` names the roofline that binds: fp64_valu = the FP64 vector pipe (the fused D = 4 kernel and the D = 2, 8 '
+                                 'kernels issue no MFMA), fp64_matrix = v_mfma_f64 (D = 16, the D = 4 squaring solver); both peaks are 78.6 TFLOP/s '
+                                 'spec (measured on this part: v_fma_f64 70.9, v_mfma_f64_16x16x4 47.7 TFLOP/s, profiles/r01_probe.json); `hbm_frac` = '
+                                 'the same launch against the 8 TB/s HBM roofline on the algorithmic bytes.  `traffic` = HBM bytes per launch from the '
+                                 'PMC passes COMMITTED under profiles/ (rocprofv3 --pmc cannot run inside this process: `traffic.source` names the run).  '
+                                 'FLOPs = ' + flop_note,
                          'hbm': {'achieved': hbm_gbps, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                  'frac': hbm_gbps / HBM_PEAK_GBPS, 'bytes_per_eval': bytes_per_eval(D),
                                  'whole_step_gbps': step_gbps, 'whole_step_frac': step_gbps / HBM_PEAK_GBPS,

@@ -301,6 +301,19 @@ int qmps_overlap_stats(qmps_ctx* ctx, int64_t* evaluations, int64_t* rounds_sum,
 int qmps_overlap_eval_ansatz(qmps_ctx* ctx, int64_t B, int kind, int n_params, const double* params, int max_rounds, double tol,
                              int flags, double* f_out, int32_t* status_out);
 
+/* Central-difference GRADIENT of the overlap objective for T iterates at once (the "finite-difference columns" of scipy's BFGS,
+ * which the reference runs per time step: qmps/new_time_evolve.py:284, scripts/loschmidt.py:371) from ONE pair of eigen-solves
+ * per iterate instead of 2 n_params + 1.  params[T][n_params]: iterate t is compared with resident reference t.  The library
+ * solves the RIGHT and the LEFT fixed point of the iterate's map (T(r) = eta r, T^+(y) = conj(eta) y; the left one by the power
+ * method on the adjoint map y -> sum_s C_s^+ y Bm_s) and evaluates each of the 2 n_params neighbours params_t +- h e_k by
+ *     eta' = <y, T'(r)> / <y, r>       (exact to second order in h: error O(h^2) ~ 1e-12 at h = 1e-6)
+ * - one application of the neighbour's map instead of a power iteration.  f_out[T] = -sqrt|eta_t| (from the solve),
+ * g_out[T][n_params] = (f(+h e_k) - f(-h e_k)) / 2h, status_out[T] = worst of the two solves.  QMPS_OVERLAP_WARM: both power
+ * iterations start from the fixed points the previous call left resident (same T).  D = 4, 8, 16; needs
+ * T (1 + 2 n_params) <= max_batch.  One synchronisation. */
+int qmps_overlap_gradient(qmps_ctx* ctx, int64_t T, int kind, int n_params, const double* params, double h, int max_rounds, double tol,
+                          int flags, double* f_out, double* g_out, int32_t* status_out);
+
 /* Device-resident TIME EVOLUTION by rotosolve on the overlap objective (BASELINE.json configs[4]; the reference's loop:
  * qmps/new_time_evolve.py:276-292 / scripts/loschmidt.py:367-375 `for _ in T: A_ = tensor(params); params =
  * minimize(obj, params, (A_, WW)).x`, with the rotosolve update of qmps/rotosolve.py:154-181 (nsh = 3) or

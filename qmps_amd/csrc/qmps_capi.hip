@@ -11,6 +11,7 @@
 #include <time.h>
 
 #include <new>
+#include <vector>
 
 #include "qmps_hip.h"
 #include "qmps_kernels.h"
@@ -67,6 +68,8 @@ struct qmps_ctx {
   int64_t ref_cap = 0;         //   overwritten by qmps_set_states(kind = UNITARY) and the two-site unit cell)
   double* d_f = nullptr;       // overlap objective -sqrt|eta| [max_batch] (lazy)
   unsigned long long* d_ostats = nullptr;   // overlap solver statistics [4] (lazy)
+  void* d_y = nullptr;         // qmps_overlap_gradient: LEFT fixed points [max_batch][D][D] (lazy)
+  int64_t grad_warm_T = 0;     // d_r / d_y hold the fixed points of this many trajectories' iterates (qmps_overlap_gradient)
   void* d_xwarm = nullptr;     // qmps_evolve_rotosolve: fixed points per (parameter, candidate) (lazy, grown on demand)
   size_t xwarm_bytes = 0;
   int64_t overlap_group = 0;   // > 0: candidate b is compared with reference b / overlap_group
@@ -463,7 +466,7 @@ int qmps_destroy(qmps_ctx* c) {
   }
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   if (c->comm_stream2) (void)hipStreamDestroy(c->comm_stream2);
-  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_ref, c->d_f, c->d_ostats, c->d_xwarm, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc, c->d_acc_err, c->roto_base, c->roto_hist, c->roto_idx};
+  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_ref, c->d_f, c->d_ostats, c->d_xwarm, c->d_y, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc, c->d_acc_err, c->roto_base, c->roto_hist, c->roto_idx};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
@@ -786,6 +789,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   if (solver == QMPS_ENV_DIRECT && !direct) solver = QMPS_ENV_POWER_SQUARING;   // D = 2: the lane kernel's squaring path with the 4 x 4 solve in front (direct2); D = 16 iterates (documented)
   c->acc_pending = false;   // whatever an earlier launch accumulated no longer describes the resident energies
   c->have_overlap_x = false;   // d_r is about to hold environments, not overlap fixed points
+  c->grad_warm_T = 0;
   const bool fused = direct && c->ans_have && fusable_ansatz(c, c->ans_kind);
   if (!fused)
     if (int rc = ensure_tensors(c)) return rc;
@@ -1258,6 +1262,7 @@ int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int 
   c->have_env = false;
   c->have_guess = false;
   c->have_overlap_x = want_r;
+  if (want_r) c->grad_warm_T = 0;
   c->acc_pending = false;
   c->partials_B = -1;
   return QMPS_OK;
@@ -1321,6 +1326,65 @@ int qmps_overlap_eval_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, con
   HIP_TRY(hipMemcpyAsync(f_out, c->d_f, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (status_out) HIP_TRY(hipMemcpyAsync(status_out, c->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+
+int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const double* params, double h, int max_rounds, double tol,
+                          int flags, double* f_out, double* g_out, int32_t* status_out) {
+  if (int rc = bind(c)) return rc;
+  if (!params || !f_out || !g_out) return fail(QMPS_ERR_ARG, "null argument");
+  if (c->D < 4) return fail(QMPS_ERR_ARG, "qmps_overlap_gradient: D = 4, 8, 16 (at D = 2 evaluate the central-difference neighbours themselves)");
+  if (flags & ~QMPS_OVERLAP_WARM) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
+  if (!(h > 0.0)) return fail(QMPS_ERR_ARG, "h must be > 0");
+  const int P = n_params;
+  if (T < 1 || T * (1 + 2 * (int64_t)P) > c->max_batch) return fail(QMPS_ERR_ARG, "T (1 + 2 n_params) = %lld evaluations exceed max_batch = %lld", (long long)(T * (1 + 2 * (int64_t)P)), (long long)c->max_batch);
+  if (c->overlap_refs < T) return fail(QMPS_ERR_STATE, "%lld reference tensors resident, %lld trajectories (qmps_overlap_set / qmps_overlap_set_refs_ansatz)", (long long)c->overlap_refs, (long long)T);
+  if (max_rounds < 1 || max_rounds > (1 << 24) || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_rounds / tol");
+  const bool warm = (flags & QMPS_OVERLAP_WARM) != 0;
+  if (warm && c->grad_warm_T != T) return fail(QMPS_ERR_STATE, "QMPS_OVERLAP_WARM: the resident fixed points belong to %lld trajectories, not %lld", (long long)c->grad_warm_T, (long long)T);
+  if (int rc = ensure_overlap_outputs(c)) return rc;
+  if (!c->d_y) HIP_TRY(hipMalloc(&c->d_y, (size_t)c->max_batch * env_bytes(c)));
+  const size_t nD = (size_t)c->D * c->D;
+  if (int rc = ensure_scratch(c, (size_t)T * (4 * nD + 1) * 16 + 256)) return rc;
+  // the iterates: parameters -> tensors in d_A[0, T)
+  c->defer_sync = true;
+  int rc = qmps_set_states_ansatz(c, T, kind, P, params);
+  c->defer_sync = false;
+  if (!rc) rc = ensure_tensors(c);
+  if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+  const bool squaring = overlap_squares(c);       // D = 4: the right fixed point comes from the squaring kernel (largest column)
+  qmps::OverlapArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = c->d_ref; a.Bt = c->d_A; a.WW = c->d_ww; a.eta = c->d_eta; a.f_out = c->d_f; a.r_out = c->d_r;
+  a.x_in = (warm && !squaring) ? c->d_r : nullptr;
+  a.stats = c->d_ostats; a.iters = c->d_iters; a.status = c->d_status; a.B = T; a.a_shared = 0;
+  a.max_rounds = squaring && max_rounds > 60 ? 60 : max_rounds; a.tol = tol;
+  if (int e = launch_overlap_kernels(c, a)) return e;
+  // the left fixed points: power method on the adjoint map; results behind the iterates' (eta, rounds, status at [T, 2T))
+  qmps::OverlapArgs l = a;
+  l.adjoint = 1; l.eta = (char*)c->d_eta + (size_t)T * 16; l.f_out = nullptr; l.r_out = c->d_y; l.x_in = warm ? c->d_y : nullptr;
+  l.iters = c->d_iters + T; l.status = c->d_status + T; l.max_rounds = max_rounds;
+  HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 16 && getenv("QMPS_D16_BLOCK") == nullptr, c->stream));
+  // the 2 P central-difference neighbours of every iterate, evaluated to second order in h from (y, r)
+  HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->stream));
+  qmps::OverlapGradArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = c->d_ref; g.WW = c->d_ww; g.r = c->d_r; g.y = c->d_y; g.G = c->d_scratch; g.yr = (char*)c->d_scratch + (size_t)T * 4 * nD * 16;
+  g.Bt = (char*)c->d_A + (size_t)T * tensor_bytes(c); g.f_out = c->d_f + T; g.T = T; g.G2P = 2 * P;
+  HIP_TRY(qmps::launch_overlap_grad(c->D, g, c->stream));
+  std::vector<double> fn((size_t)T * 2 * P);
+  std::vector<int32_t> st((size_t)2 * T);
+  HIP_TRY(hipMemcpyAsync(f_out, c->d_f, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(fn.data(), c->d_f + T, fn.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(st.data(), c->d_status, st.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int64_t t = 0; t < T; ++t) {
+    for (int k = 0; k < P; ++k) g_out[t * P + k] = (fn[(size_t)t * 2 * P + k] - fn[(size_t)t * 2 * P + P + k]) / (2.0 * h);
+    if (status_out) status_out[t] = st[t] > st[T + t] ? st[t] : st[T + t];
+  }
+  c->window = 0;
+  c->have_env = false; c->have_guess = false; c->have_overlap_x = false; c->acc_pending = false; c->partials_B = -1;
+  c->grad_warm_T = T;
   return QMPS_OK;
 }
 

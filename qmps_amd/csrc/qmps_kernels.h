@@ -150,6 +150,8 @@ hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, vo
 // the same for rotosolve shift batches: B = nsh R evaluations, evaluation nsh r + k = row r with shift k on parameter *i_ptr
 hipError_t launch_ansatz_shifted(int D, int kind, const double* params, int n_params, void* A, int64_t B, int nsh, const int* i_ptr,
                                  hipStream_t st);
+// central-difference batches: 2 n_params evaluations per row, evaluation 2 P r + k = row r with +h (k < P) / -h (k >= P) on parameter k mod P
+hipError_t launch_ansatz_fd(int D, int kind, const double* params, int n_params, void* A, int64_t rows, double h, hipStream_t st);
 // time-evolution overlap (D = 2): dominant eigenvalue of the mixed two-site transfer map
 struct OverlapArgs {
   const void* A;     // [B or 1][2][2][2] current state tensor(s)
@@ -170,7 +172,23 @@ struct OverlapArgs {
   const int* slot_ptr;         // nullable: x_in and r_out are displaced by *slot_ptr * slot_stride bytes (rotosolve keeps one
   int64_t slot_stride;         //   set of fixed points per parameter: the candidates of parameter i return to the same slot every sweep)
   unsigned long long* stats;   // nullable [4]: evaluations, sum of rounds, max rounds, not converged (atomics)
+  int adjoint;                 // 1 (D = 8, 16): the LEFT fixed point - power method on the adjoint map y -> sum_s C_s^+ y Bm_s
+                               //   (eigenvalue conj(eta); eta_out receives eta itself)
 };
+// two-sided first-order evaluation of central-difference neighbours (qmps_overlap_gradient; qmps_overlap_grad.hip)
+struct OverlapGradArgs {
+  const void* A;       // [T][2][D][D] reference tensors
+  const void* WW;      // [4][4]
+  const void* r;       // [T][D][D] right fixed points of the iterates
+  const void* y;       // [T][D][D] left fixed points
+  void* G;             // [T][4][D][D] scratch: G_s = y^+ C_s r
+  void* yr;            // [T] complex scratch: <y, r>
+  const void* Bt;      // [T * 2P][2][D][D] neighbour tensors
+  double* f_out;       // [T * 2P]: -sqrt|eta'|,  eta' = <y, T'(r)>/<y, r>
+  int64_t T;
+  int G2P;             // neighbours per trajectory (2 P)
+};
+hipError_t launch_overlap_grad(int D, const OverlapGradArgs& a, hipStream_t st);
 #if defined(__HIPCC__)
 __device__ __forceinline__ int64_t overlap_ref_index(const OverlapArgs& p, int64_t b) { return p.group > 0 ? b / p.group : (p.a_shared ? 0 : b); }
 __device__ __forceinline__ int64_t overlap_slot_offset(const OverlapArgs& p) { return p.slot_ptr != nullptr ? (int64_t)(*p.slot_ptr) * p.slot_stride : 0; }

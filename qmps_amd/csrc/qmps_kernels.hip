@@ -2095,9 +2095,11 @@ __global__ __launch_bounds__(256) void unitary_to_tensor_kernel(const double2* _
 template <int D, int KIND>
 // nsh > 0: rotosolve shift batches without a separate shift-build kernel - evaluation b = nsh r + k is restart r (parameter
 // row r) with shift k added to parameter *i_ptr
+// fd_h != 0: central-difference batches - nsh = 2 P evaluations per row, evaluation nsh r + k = row r with +fd_h (k < P) or
+// -fd_h (k >= P) added to parameter k mod P
 __global__ __launch_bounds__(64) void ansatz_tensor_kernel(const double* __restrict__ params, int n_params,
                                                            double2* __restrict__ A, int64_t B, int nsh,
-                                                           const int* __restrict__ i_ptr) {
+                                                           const int* __restrict__ i_ptr, double fd_h) {
   constexpr int NQ = (D == 2 ? 2 : D == 4 ? 3 : D == 8 ? 4 : 5);
   const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const int64_t b = t / D;
@@ -2105,7 +2107,9 @@ __global__ __launch_bounds__(64) void ansatz_tensor_kernel(const double* __restr
   if (b >= B) return;
   const int64_t row = nsh > 0 ? b / nsh : b;
   const int shift_k = nsh > 0 ? (int)(b - row * nsh) : 0;
-  const int isel = nsh > 0 ? *i_ptr : -1;
+  const bool fd = fd_h != 0.0;
+  const int isel = nsh > 0 ? (fd ? shift_k % n_params : *i_ptr) : -1;
+  const double fd_shift = shift_k < n_params ? fd_h : -fd_h;
   const double* pp = params + row * n_params;
   Reg<NQ> r;
 #pragma unroll
@@ -2115,7 +2119,7 @@ __global__ __launch_bounds__(64) void ansatz_tensor_kernel(const double* __restr
   }
   ansatz_circuit<NQ, KIND>(r, [&](int l) {
     double v = pp[l];
-    if (l == isel) v += roto_shift_value(nsh, shift_k);
+    if (l == isel) v += fd ? fd_shift : roto_shift_value(nsh, shift_k);
     return v;
   }, n_params);
   // A[b][s][i][j] = amplitude[2 i + s]
@@ -2125,17 +2129,17 @@ __global__ __launch_bounds__(64) void ansatz_tensor_kernel(const double* __restr
 }
 
 template <int D>
-static hipError_t launch_ansatz_d(int kind, const double* params, int n_params, void* A, int64_t B, int nsh, const int* i_ptr, hipStream_t st) {
+static hipError_t launch_ansatz_d(int kind, const double* params, int n_params, void* A, int64_t B, int nsh, const int* i_ptr, hipStream_t st, double fd_h = 0.0) {
   const int64_t threads = B * D;
   const dim3 grid((unsigned)((threads + 63) / 64)), block(64);
   switch (kind) {
-    case 0: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 0>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr); break;
-    case 1: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 1>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr); break;
+    case 0: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 0>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
+    case 1: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 1>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
     case 2:
       if (D != 2) return hipErrorInvalidValue;
-      hipLaunchKernelGGL((ansatz_tensor_kernel<2, 2>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr);
+      hipLaunchKernelGGL((ansatz_tensor_kernel<2, 2>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h);
       break;
-    case 3: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 3>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr); break;
+    case 3: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 3>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -2149,6 +2153,18 @@ hipError_t launch_ansatz_shifted(int D, int kind, const double* params, int n_pa
     case 4: return launch_ansatz_d<4>(kind, params, n_params, A, B, nsh, i_ptr, st);
     case 8: return launch_ansatz_d<8>(kind, params, n_params, A, B, nsh, i_ptr, st);
     case 16: return launch_ansatz_d<16>(kind, params, n_params, A, B, nsh, i_ptr, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_ansatz_fd(int D, int kind, const double* params, int n_params, void* A, int64_t rows, double h, hipStream_t st) {
+  const int64_t B = rows * 2 * n_params;
+  if (B <= 0) return hipSuccess;
+  switch (D) {
+    case 2: return launch_ansatz_d<2>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h);
+    case 4: return launch_ansatz_d<4>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h);
+    case 8: return launch_ansatz_d<8>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h);
+    case 16: return launch_ansatz_d<16>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h);
     default: return hipErrorInvalidValue;
   }
 }

@@ -51,7 +51,9 @@ __device__ __forceinline__ void cfma_conj(double2 a, double2 b, double2& c) {   
 // ------------------------------------------------------------------------------------------
 // generic tile kernel
 // ------------------------------------------------------------------------------------------
-template <int D>
+// ADJ: power method on the adjoint map y -> sum_s C_s^+ y Bm_s (its dominant eigenvalue is conj(eta), its fixed point the LEFT
+// eigenvector of T for the Frobenius pairing: <y, T x> = <T^+ y, x>); eta_out receives eta itself
+template <int D, bool ADJ = false>
 __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_block_kernel(OverlapArgs p) {
   constexpr int N = D * D, P = D + 1;
   constexpr int THREADS = N < 64 ? 64 : N, ITEMS = THREADS / N, WAVES = THREADS / 64;
@@ -142,21 +144,27 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_block_kerne
     if (!__syncthreads_or(active ? 1 : 0)) break;
     sX[e][i][j] = x;
     __syncthreads();
-    // Y_s = x Bm_s^+
+    // Y_s = x Bm_s^+   (ADJ: x Bm_s)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       double2 y = make_double2(0.0, 0.0);
 #pragma unroll
-      for (int kk = 0; kk < D; ++kk) cfma_conj(sX[e][i][kk], sB[e][s][j][kk], y);
+      for (int kk = 0; kk < D; ++kk) {
+        if constexpr (ADJ) cfma(sX[e][i][kk], sB[e][s][kk][j], y);
+        else cfma_conj(sX[e][i][kk], sB[e][s][j][kk], y);
+      }
       sY[e][s][i][j] = y;
     }
     __syncthreads();
-    // x' = sum_s C_s Y_s
+    // x' = sum_s C_s Y_s   (ADJ: C_s^+ Y_s)
     double2 xn = make_double2(0.0, 0.0);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int kk = 0; kk < D; ++kk) cfma(sC[e][s][i][kk], sY[e][s][kk][j], xn);
+      for (int kk = 0; kk < D; ++kk) {
+        if constexpr (ADJ) cfma_conj(sY[e][s][kk][j], sC[e][s][kk][i], xn);
+        else cfma(sC[e][s][i][kk], sY[e][s][kk][j], xn);
+      }
     // eta = <x, x'>, ||x'||^2, then the residual ||x' - eta x||^2   (||x||_F = 1)
     double v[4] = {x.x * xn.x + x.y * xn.y, x.x * xn.y - x.y * xn.x, xn.x * xn.x + xn.y * xn.y, 0.0};
     group_sum4(v);
@@ -178,7 +186,7 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_block_kerne
     }
   }
   if (!valid) return;
-  if (l == 0) overlap_store(p, b, eta.x, eta.y, iters, status);
+  if (l == 0) overlap_store(p, b, eta.x, ADJ ? -eta.y : eta.y, iters, status);
   if (p.r_out != nullptr) ((double2*)((char*)p.r_out + slot_off))[b * N + l] = x;
 }
 
@@ -201,6 +209,7 @@ __device__ __forceinline__ void cmma16(const double (&pre)[4], const double (&pi
 
 }  // namespace
 
+template <bool ADJ>
 __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
   constexpr int D = 16, LD = 17, WAVES = 4;
   __shared__ double2 sT_all[WAVES][D * LD];
@@ -228,6 +237,8 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
     // ---- set-up: AA_t = A_t1 A_t2 and BB_t = B_t1 B_t2 (C-layout), C_s = sum_t WW[s][t] AA_t; both sets to A-layout
     double cre[4][4], cim[4][4];     // C_s in A-layout (the P operand of x' += C_s Y_s)
     double bre[4][4], bimn[4][4];    // conj(Bm_s) in A-layout == Bm_s^+ in B-layout (the Q operand of Y_s = x Bm_s^+)
+    // ADJ (y -> sum_s C_s^+ y Bm_s): the Q operand of Y_s = y Bm_s is Bm_s in B-layout - the C-layout the product B_s1 B_s2 comes
+    // out in - and the P operand of y' += C_s^+ Y_s is C_s^+ in A-layout = conj of C_s in C-layout: no LDS transpose in the set-up
     {
       double pa[2][4], pai[2][4], pb[2][4], pbi[2][4];   // A_s, B_s in A-layout
       v4f64 qa[2], qai[2], qb[2], qbi[2];                 // A_s, B_s in B-layout (= C-layout)
@@ -253,12 +264,20 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
           aai[2 * t1 + t2] = zi;
           v4f64 yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
           cmma16(pb[t1], pbi[t1], qb[t2], qbi[t2], yr, yi);
-          double tr[4], ti[4];
-          to_a_layout(yr, yi, tr, ti);
+          if constexpr (ADJ) {
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            bre[2 * t1 + t2][kk] = tr[kk];
-            bimn[2 * t1 + t2][kk] = -ti[kk];
+            for (int kk = 0; kk < 4; ++kk) {
+              bre[2 * t1 + t2][kk] = yr[kk];
+              bimn[2 * t1 + t2][kk] = yi[kk];
+            }
+          } else {
+            double tr[4], ti[4];
+            to_a_layout(yr, yi, tr, ti);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              bre[2 * t1 + t2][kk] = tr[kk];
+              bimn[2 * t1 + t2][kk] = -ti[kk];
+            }
           }
         }
 #pragma unroll
@@ -270,7 +289,15 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
           zr += w.x * aar[t] - w.y * aai[t];
           zi += w.x * aai[t] + w.y * aar[t];
         }
-        to_a_layout(zr, zi, cre[s], cim[s]);
+        if constexpr (ADJ) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            cre[s][kk] = zr[kk];
+            cim[s][kk] = -zi[kk];
+          }
+        } else {
+          to_a_layout(zr, zi, cre[s], cim[s]);
+        }
       }
     }
     // ---- power method, x in C-layout, ||x||_F = 1
@@ -341,7 +368,7 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
       xr = nr * inv;
       xi = ni * inv;
     }
-    if (lane == 0) overlap_store(p, b, eta_r, eta_i, iters, status);
+    if (lane == 0) overlap_store(p, b, eta_r, ADJ ? -eta_i : eta_i, iters, status);
     if (p.r_out != nullptr) {
       double2* ro = (double2*)((char*)p.r_out + slot_off) + b * (D * D);
 #pragma unroll
@@ -528,6 +555,7 @@ __global__ __launch_bounds__(256) void overlap_square_d4_kernel(OverlapArgs p) {
 // quarter of the SIMDs idle at B = 768 and, worse, lets the launch wait for its slowest candidate at one wave's pace; here
 // the stragglers run on four SIMDs each.
 // ------------------------------------------------------------------------------------------
+template <bool ADJ>
 __global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) {
   constexpr int D = 16, LD = 17, WAVES = 4;
   __shared__ double2 sT_all[WAVES][D * LD];          // wave-private transposes
@@ -586,12 +614,20 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) 
       publish(zr, zi);
       v4f64 yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
       cmma16(pb, pbi, qb, qbi, yr, yi);
-      double tr[4], ti[4];
-      to_a_layout(yr, yi, tr, ti);
+      if constexpr (ADJ) {      // Bm_w in B-layout as it comes out of the product (see overlap_mfma_d16_kernel)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        bre[kk] = tr[kk];
-        bimn[kk] = -ti[kk];
+        for (int kk = 0; kk < 4; ++kk) {
+          bre[kk] = yr[kk];
+          bimn[kk] = yi[kk];
+        }
+      } else {
+        double tr[4], ti[4];
+        to_a_layout(yr, yi, tr, ti);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          bre[kk] = tr[kk];
+          bimn[kk] = -ti[kk];
+        }
       }
       __syncthreads();
       v4f64 sr = {0, 0, 0, 0}, si = {0, 0, 0, 0};
@@ -603,7 +639,15 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) 
         sr += w.x * ar - w.y * ai;
         si += w.x * ai + w.y * ar;
       }
-      to_a_layout(sr, si, cre, cim);
+      if constexpr (ADJ) {      // C_w^+ in A-layout = conj of C_w in C-layout
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          cre[kk] = sr[kk];
+          cim[kk] = -si[kk];
+        }
+      } else {
+        to_a_layout(sr, si, cre, cim);
+      }
       __syncthreads();               // the exchange buffers are free again
     }
     // ---- power method, x in C-layout (alike in the four waves), ||x||_F = 1
@@ -682,7 +726,7 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) 
       xi = ni * inv;
     }
     if (wave == 0) {
-      if (lane == 0) overlap_store(p, b, eta_r, eta_i, iters, status);
+      if (lane == 0) overlap_store(p, b, eta_r, ADJ ? -eta_i : eta_i, iters, status);
       if (p.r_out != nullptr) {
         double2* ro = (double2*)((char*)p.r_out + slot_off) + b * (D * D);
 #pragma unroll
@@ -695,6 +739,10 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) 
 
 hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
+  if (a.adjoint && D == 4) {      // the squaring kernel returns right vectors only: left fixed points come from the power method
+    hipLaunchKernelGGL((overlap_block_kernel<4, true>), dim3((unsigned)((a.B + 3) / 4)), dim3(64), 0, st, a);
+    return hipGetLastError();
+  }
   switch (D) {
     case 4:
       if (mfma) {
@@ -705,21 +753,28 @@ hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t 
         hipLaunchKernelGGL((overlap_block_kernel<4>), dim3((unsigned)((a.B + 3) / 4)), dim3(64), 0, st, a);
       }
       break;
-    case 8: hipLaunchKernelGGL((overlap_block_kernel<8>), dim3((unsigned)a.B), dim3(64), 0, st, a); break;
+    case 8:
+      if (a.adjoint) hipLaunchKernelGGL((overlap_block_kernel<8, true>), dim3((unsigned)a.B), dim3(64), 0, st, a);
+      else hipLaunchKernelGGL((overlap_block_kernel<8>), dim3((unsigned)a.B), dim3(64), 0, st, a);
+      break;
     case 16:
       if (mfma) {
         // few candidates: four waves per evaluation (the launch waits for its slowest candidate - give it four SIMDs);
         // many: one wave per evaluation (no exchange through LDS, same MFMA work)
         static const int64_t split_below = getenv("QMPS_D16_SPLIT_BELOW") ? atoll(getenv("QMPS_D16_SPLIT_BELOW")) : 2048;   // A/B knob
         if (a.B <= split_below) {
-          hipLaunchKernelGGL(overlap_mfma_d16x4_kernel, dim3((unsigned)(a.B < 4096 ? a.B : 4096)), dim3(256), 0, st, a);
+          const dim3 grid((unsigned)(a.B < 4096 ? a.B : 4096));
+          if (a.adjoint) hipLaunchKernelGGL(overlap_mfma_d16x4_kernel<true>, grid, dim3(256), 0, st, a);
+          else hipLaunchKernelGGL(overlap_mfma_d16x4_kernel<false>, grid, dim3(256), 0, st, a);
         } else {
           int grid = (int)((a.B + 3) / 4);
           if (grid > 4096) grid = 4096;
-          hipLaunchKernelGGL(overlap_mfma_d16_kernel, dim3(grid), dim3(256), 0, st, a);
+          if (a.adjoint) hipLaunchKernelGGL(overlap_mfma_d16_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+          else hipLaunchKernelGGL(overlap_mfma_d16_kernel<false>, dim3(grid), dim3(256), 0, st, a);
         }
       } else {
-        hipLaunchKernelGGL((overlap_block_kernel<16>), dim3((unsigned)a.B), dim3(256), 0, st, a);
+        if (a.adjoint) hipLaunchKernelGGL((overlap_block_kernel<16, true>), dim3((unsigned)a.B), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((overlap_block_kernel<16>), dim3((unsigned)a.B), dim3(256), 0, st, a);
       }
       break;
     default: return hipErrorInvalidValue;

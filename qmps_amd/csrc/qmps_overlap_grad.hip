@@ -1,0 +1,201 @@
+// qmps_overlap_grad.hip - central-difference gradient of the time-evolution overlap objective from ONE pair of eigen-solves
+// per trajectory (gfx950 only).
+//
+// The optimiser the reference runs per time step (scipy BFGS on `obj`, qmps/new_time_evolve.py:284, scripts/loschmidt.py:371)
+// differentiates the objective by finite differences: 2 P more dominant-eigenvalue solves per iterate, each of a map that differs
+// from the iterate's by O(h) = 1e-6.  With the right AND the left fixed point of the iterate's map T,
+//     T(r) = eta r ,   T^+(y) = conj(eta) y     (<a, b> = tr(a^+ b)),
+// the dominant eigenvalue of a neighbour T' = T + O(h) is, to SECOND order in h,
+//     eta' = <y, T'(r)> / <y, r> ,
+// (error O(h^2 |dT|^2 / gap) ~ 1e-12: the accuracy of the solves themselves; measured against dense eigen-solves in
+// tests/test_evolve_gpu.py), so the 2 P neighbours cost one application of the map each instead of a power iteration each.
+// With T'(x) = sum_s C_s x Bm'_s^+ only Bm' = merge(B', B') depends on the neighbour:
+//     <y, T'(r)> = sum_s tr(Bm'_s^+ G_s) ,   G_s = y^+ C_s r   (per trajectory, overlap_g_kernel),
+// an elementwise contraction per neighbour (overlap_probe_kernel).
+//
+// Thread (i, j) of a D x D tile per item, tiles in LDS (D = 2, 4: several items per wave).  These kernels are a few percent of
+// a gradient evaluation (the two power iterations dominate), so they are written for clarity, one code path for every D.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qmps_kernels.h"
+#include "qmps_device.h"
+
+namespace qmps {
+
+namespace {
+
+__device__ __forceinline__ void cfma(double2 a, double2 b, double2& c) {   // c += a b
+  c.x = dfma(a.x, b.x, c.x);
+  c.x = dfma(-a.y, b.y, c.x);
+  c.y = dfma(a.x, b.y, c.y);
+  c.y = dfma(a.y, b.x, c.y);
+}
+__device__ __forceinline__ void cfma_conj1(double2 a, double2 b, double2& c) {   // c += conj(a) b
+  c.x = dfma(a.x, b.x, c.x);
+  c.x = dfma(a.y, b.y, c.x);
+  c.y = dfma(a.x, b.y, c.y);
+  c.y = dfma(-a.y, b.x, c.y);
+}
+
+// sum of two values over the N = D * D threads of one item (consecutive lanes, or the whole workgroup at D = 16)
+template <int N>
+__device__ __forceinline__ void item_sum2(double& a, double& b, double* red, int tid) {
+  if constexpr (N == 4) {
+    a = quad_sum(a);
+    b = quad_sum(b);
+  } else if constexpr (N == 16) {
+    a = row16_sum(a);
+    b = row16_sum(b);
+  } else if constexpr (N == 64) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+  } else {
+    constexpr int WAVES = N / 64;
+    a = wave_sum(a);
+    b = wave_sum(b);
+    __syncthreads();
+    if ((tid & 63) == 0) {
+      red[tid >> 6] = a;
+      red[WAVES + (tid >> 6)] = b;
+    }
+    __syncthreads();
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      sa += red[w];
+      sb += red[WAVES + w];
+    }
+    a = sa;
+    b = sb;
+  }
+}
+
+}  // namespace
+
+// G_s = y^+ C_s r (s < 4) and <y, r> per trajectory
+template <int D>
+__global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_g_kernel(OverlapGradArgs p) {
+  constexpr int N = D * D, P = D + 1, THREADS = N < 64 ? 64 : N, ITEMS = THREADS / N;
+  __shared__ double2 sA[ITEMS][2][D][P], sC[ITEMS][4][D][P], sR[ITEMS][D][P], sYv[ITEMS][D][P];
+  __shared__ double red[16];
+  const int tid = threadIdx.x, e = tid / N, l = tid % N, i = l / D, j = l % D;
+  const int64_t t = (int64_t)blockIdx.x * ITEMS + e;
+  const int64_t tt = t < p.T ? t : p.T - 1;       // surplus lanes of the last workgroup shadow a real trajectory
+  {
+    const double2* Ap = (const double2*)p.A + tt * (2 * N);
+    sA[e][0][i][j] = Ap[l];
+    sA[e][1][i][j] = Ap[N + l];
+    sR[e][i][j] = ((const double2*)p.r)[tt * N + l];
+    sYv[e][i][j] = ((const double2*)p.y)[tt * N + l];
+  }
+  __syncthreads();
+  {
+    double2 aa[4];
+#pragma unroll
+    for (int t1 = 0; t1 < 2; ++t1)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        double2 u = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < D; ++k) cfma(sA[e][t1][i][k], sA[e][t2][k][j], u);
+        aa[2 * t1 + t2] = u;
+      }
+    const double2* W = (const double2*)p.WW;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      double2 c = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cfma(W[s * 4 + q], aa[q], c);
+      sC[e][s][i][j] = c;
+    }
+  }
+  __syncthreads();
+  // Z_s = C_s r (kept in this thread's registers, then published in place of C_s)
+  double2 z[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    double2 v = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < D; ++k) cfma(sC[e][s][i][k], sR[e][k][j], v);
+    z[s] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) sC[e][s][i][j] = z[s];
+  __syncthreads();
+  // G_s = y^+ Z_s
+  double2* Gp = (double2*)p.G + tt * (4 * N);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    double2 g = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < D; ++k) cfma_conj1(sYv[e][k][i], sC[e][s][k][j], g);
+    if (t < p.T) Gp[s * N + l] = g;
+  }
+  const double2 yv = sYv[e][i][j], rv = sR[e][i][j];
+  double a = yv.x * rv.x + yv.y * rv.y, b = yv.x * rv.y - yv.y * rv.x;   // conj(y) r
+  item_sum2<N>(a, b, red, tid);
+  if (l == 0 && t < p.T) ((double2*)p.yr)[t] = make_double2(a, b);
+}
+
+// eta' = sum_s tr(Bm'_s^+ G_s) / <y, r>,  f = -sqrt|eta'|  per central-difference neighbour
+template <int D>
+__global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_probe_kernel(OverlapGradArgs p) {
+  constexpr int N = D * D, P = D + 1, THREADS = N < 64 ? 64 : N, ITEMS = THREADS / N;
+  __shared__ double2 sB[ITEMS][2][D][P];
+  __shared__ double red[16];
+  const int tid = threadIdx.x, e = tid / N, l = tid % N, i = l / D, j = l % D;
+  const int64_t nb = p.T * p.G2P;
+  const int64_t b = (int64_t)blockIdx.x * ITEMS + e;
+  const int64_t bb = b < nb ? b : nb - 1;
+  const int64_t t = bb / p.G2P;
+  {
+    const double2* Bp = (const double2*)p.Bt + bb * (2 * N);
+    sB[e][0][i][j] = Bp[l];
+    sB[e][1][i][j] = Bp[N + l];
+  }
+  __syncthreads();
+  const double2* Gp = (const double2*)p.G + t * (4 * N);
+  double nr = 0.0, ni = 0.0;
+#pragma unroll
+  for (int s1 = 0; s1 < 2; ++s1)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      double2 bm = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < D; ++k) cfma(sB[e][s1][i][k], sB[e][s2][k][j], bm);
+      const double2 g = Gp[(2 * s1 + s2) * N + l];
+      nr = dfma(bm.x, g.x, dfma(bm.y, g.y, nr));       // conj(bm) g
+      ni = dfma(bm.x, g.y, dfma(-bm.y, g.x, ni));
+    }
+  item_sum2<N>(nr, ni, red, tid);
+  if (l == 0 && b < nb) {
+    const double2 d = ((const double2*)p.yr)[t];
+    const double den = d.x * d.x + d.y * d.y;
+    const double er = (nr * d.x + ni * d.y) / den, ei = (ni * d.x - nr * d.y) / den;
+    p.f_out[b] = -__builtin_sqrt(__builtin_sqrt(er * er + ei * ei));
+  }
+}
+
+template <int D>
+static hipError_t launch_grad_d(const OverlapGradArgs& a, hipStream_t st) {
+  constexpr int N = D * D, THREADS = N < 64 ? 64 : N, ITEMS = THREADS / N;
+  hipLaunchKernelGGL((overlap_g_kernel<D>), dim3((unsigned)((a.T + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);
+  const int64_t nb = a.T * a.G2P;
+  hipLaunchKernelGGL((overlap_probe_kernel<D>), dim3((unsigned)((nb + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_overlap_grad(int D, const OverlapGradArgs& a, hipStream_t st) {
+  if (a.T <= 0 || a.G2P <= 0) return hipSuccess;
+  switch (D) {
+    case 2: return launch_grad_d<2>(a, st);
+    case 4: return launch_grad_d<4>(a, st);
+    case 8: return launch_grad_d<8>(a, st);
+    case 16: return launch_grad_d<16>(a, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace qmps

@@ -374,6 +374,19 @@ class EnergyEngine:
         self.B = B
         return f, st
 
+    def overlap_gradient(self, kind, X, h=1e-6, max_rounds=None, tol=1e-12, warm=False):
+        """Iterates X (T, P) -> (f (T,), g (T, P), status (T,)): objective and its central-difference gradient against the
+        resident references, from one right + one left eigen-solve per iterate (qmps_overlap_gradient; D = 4, 8, 16)."""
+        X = np.ascontiguousarray(np.atleast_2d(X), dtype=np.float64)
+        if max_rounds is None:
+            max_rounds = 100000
+        T, P = X.shape
+        f, g, st = np.empty(T), np.empty((T, P)), np.empty(T, dtype=np.int32)
+        L.check(self._lib.qmps_overlap_gradient(self._ctx, T, int(kind), P, _f64(X), float(h), int(max_rounds), float(tol),
+                                                L.OVERLAP_WARM if warm else 0, _f64(f), _f64(g), _i32(st)))
+        self.B = T
+        return f, g, st
+
     def overlap_objective(self, B=None):
         """f_b = -sqrt(|eta_b|) of the last overlap launch (new_time_evolve.py:221), computed on the device."""
         B = self.B if B is None else B

@@ -73,24 +73,38 @@ class _GroupedObjective:
 
     def __init__(self, D, kind, T, G, max_rounds, tol, device=0):
         from .engine import EnergyEngine
-        self.eng = EnergyEngine(D, T * G, device=device)
+        self.eng = EnergyEngine(D, T * max(np.atleast_1d(G)), device=device)
         self.kind, self.T, self.G, self.max_rounds, self.tol = kind, T, G, max_rounds, tol
         self.warm = False
+        self.grad_warm = False
         self.kernel_ms = None          # a list: receives the HIP-event duration of every launch's overlap kernel (bench.py)
 
     def set_reference(self, ref_params, WW):
         self.eng.overlap_set_refs_params(self.kind, ref_params, WW)
-        self.eng.overlap_set_group(self.G)
 
     def __call__(self, cand):
+        """cand (T G, P), trajectory-major; G = the group size given to the constructor (or any of them, if several were given)."""
         cand = np.ascontiguousarray(cand, dtype=np.float64)
-        assert cand.shape[0] == self.T * self.G
-        keep = self.eng.D >= 8          # power-method bond dimensions: the fixed points stay in the candidates' slots
-        f, st = self.eng.overlap_eval_params(self.kind, cand, max_rounds=self.max_rounds, tol=self.tol, want_r=keep, warm=self.warm)
+        G = cand.shape[0] // self.T
+        assert cand.shape[0] == self.T * G and G in np.atleast_1d(self.G)
+        self.eng.overlap_set_group(G)
+        # power-method bond dimensions: the fixed points stay in the candidates' slots (one slot layout: only while G is fixed)
+        keep = self.eng.D >= 8 and np.ndim(self.G) == 0
+        f, st = self.eng.overlap_eval_params(self.kind, cand, max_rounds=self.max_rounds, tol=self.tol, want_r=keep, warm=self.warm and keep)
         self.warm = keep
         if self.kernel_ms is not None:
             self.kernel_ms.append(self.eng.kernel_time(1)[0])
         return np.where(st == L.STATUS_OK, f, np.nan)
+
+    def value_and_grad(self, X, h=1e-6):
+        """(f (T,), g (T, P)) of the iterates X from one right + one left eigen-solve each (qmps_overlap_gradient), warm-started
+        from the previous call's fixed points."""
+        f, g, st = self.eng.overlap_gradient(self.kind, X, h=h, max_rounds=max(self.max_rounds, 100000), tol=self.tol, warm=self.grad_warm)
+        self.grad_warm = True
+        if self.kernel_ms is not None:
+            self.kernel_ms.append(self.eng.kernel_time(1)[0])
+        bad = st != L.STATUS_OK
+        return np.where(bad, np.nan, f), np.where(bad[:, None], np.nan, g)
 
     def close(self):
         self.eng.close()
@@ -133,7 +147,8 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
         opts = dict(options or {})
         ladder = opts.pop('alphas', (1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096))
         mr = max_rounds if max_rounds is not None else (60 if D in (2, 4) else 100000)
-        ev = LockstepEvolver(D, T, P, cls, mr, tol, opts.get('maxiter', 200), opts.get('gtol', 1e-5), opts.get('eps', 1e-6), ladder)
+        ev = LockstepEvolver(D, T, P, cls, mr, tol, opts.get('maxiter', 200), opts.get('gtol', 1e-5), opts.get('eps', 1e-6), ladder,
+                             gradient=opts.get('gradient', 'auto'), first_rungs=opts.get('first_rungs'))
         fg, fl = ev.fg, ev.fl
         try:
             for step in range(n_steps):
@@ -170,19 +185,27 @@ class LockstepEvolver:
     their resident fixed points across time steps: `step(X)` = one time step of all trajectories."""
 
     def __init__(self, D, T, P, cls=None, max_rounds=None, tol=1e-12, maxiter=200, gtol=1e-5, eps=1e-6,
-                 alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), device=0):
+                 alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), device=0, gradient='auto', first_rungs=None):
+        """gradient: 'fd' = the 2P + 1 central-difference candidates are eigen-solved one by one (any D); 'two-sided' = one right
+        and one left eigen-solve per iterate, the neighbours by the second-order formula eta' = <y, T'(r)>/<y, r> (D >= 4);
+        'auto' = 'two-sided' where the library has it.  first_rungs: two-stage ladder (tools.batched_bfgs)."""
         cls = cls or _default_class(D)
         self.kind = getattr(cls, 'device_kind')
         mr = max_rounds if max_rounds is not None else (60 if D in (2, 4) else 100000)
         self.alphas, self.maxiter, self.gtol, self.eps = tuple(alphas), maxiter, gtol, eps
+        self.two_sided = (gradient == 'two-sided') or (gradient == 'auto' and D >= 4)
+        self.first_rungs = first_rungs
         self.fg = _GroupedObjective(D, self.kind, T, 2 * P + 1, mr, tol, device=device)
-        self.fl = _GroupedObjective(D, self.kind, T, len(self.alphas), mr, tol, device=device)
+        rungs = len(self.alphas) if not first_rungs else (first_rungs, len(self.alphas) - first_rungs)
+        self.fl = _GroupedObjective(D, self.kind, T, rungs, mr, tol, device=device)
 
     def step(self, X, WW):
         from .tools import batched_bfgs
         self.fg.set_reference(X, WW)
         self.fl.set_reference(X, WW)
-        return batched_bfgs(self.fg, self.fl, X, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas)
+        vg = (lambda Z: self.fg.value_and_grad(Z, self.eps)) if self.two_sided else None
+        return batched_bfgs(self.fg, self.fl, X, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas,
+                            value_and_grad=vg, first_rungs=self.first_rungs)
 
     def close(self):
         self.fg.close()

@@ -263,7 +263,7 @@ def batched_fd_gradient(batch_fun, X, h=1e-6, F0=None):
 
 
 def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=1e-4,
-                 alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096)):
+                 alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), value_and_grad=None, first_rungs=None):
     """T independent BFGS minimisations in LOCK-STEP (scipy's BFGS is what the reference's time-evolution loop runs per
     step: `minimize(obj, params, (A_, WW))`, new_time_evolve.py:284 / scripts/loschmidt.py:371 - one trajectory, one
     scalar objective call at a time).  Here every iteration is two batched evaluations over all trajectories:
@@ -274,12 +274,18 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
     Rows are trajectory-major (what `qmps_overlap_set_group` expects).  Inverse-Hessian update: the BFGS formula, skipped
     when s.y <= 1e-12 |s||y|.  A trajectory is converged when max|g| < gtol and then stays put (its rows are still
     evaluated: the batch shape never changes, so resident warm starts keep their slots).
+    value_and_grad (optional): X (T,P) -> (f (T,), g (T,P)) replaces the central-difference batches (the device computes the same
+    central differences from one pair of eigen-solves per iterate: qmps_overlap_gradient).
+    first_rungs (optional int n < len(alphas)): the ladder is evaluated in two stages - line_batch receives T n candidates (the first
+    n step lengths) and, only if some trajectory finds no acceptable step among them, a second batch of T (len(alphas) - n) - near
+    the minimum BFGS accepts alpha = 1 almost always.  line_batch must then accept both group sizes.
     Returns dict(x (T,P), fun (T,), jac (T,P), nit, nfev, converged (T,), history [fun per iteration])."""
     X = np.array(np.atleast_2d(X0), dtype=float)
     T, P = X.shape
     al = np.asarray(alphas, dtype=float)
     Hinv = np.tile(np.eye(P), (T, 1, 1))
-    f, g = batched_fd_gradient(grad_batch, X, h)
+    vg = value_and_grad if value_and_grad is not None else (lambda Z: batched_fd_gradient(grad_batch, Z, h))
+    f, g = vg(X)
     nfev = T * (2 * P + 1)
     active = np.abs(g).max(axis=1) >= gtol
     history = [f.copy()]
@@ -293,10 +299,20 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
             d[bad] = -g[bad]
             slope[bad] = -np.einsum('ti,ti->t', g[bad], g[bad])
         d[~active] = 0.0
-        cand = X[:, None, :] + al[None, :, None] * d[:, None, :]
-        Fc = np.asarray(line_batch(cand.reshape(-1, P))).reshape(T, len(al))
-        nfev += T * len(al)
-        Fc = np.where(np.isfinite(Fc), Fc, np.inf)
+        def ladder(a):
+            cand = X[:, None, :] + a[None, :, None] * d[:, None, :]
+            F = np.asarray(line_batch(cand.reshape(-1, P))).reshape(T, len(a))
+            return np.where(np.isfinite(F), F, np.inf)
+        if first_rungs:
+            Fc = np.full((T, len(al)), np.inf)
+            Fc[:, :first_rungs] = ladder(al[:first_rungs])
+            nfev += T * first_rungs
+            if not (Fc <= f[:, None] + c1 * al[None, :] * slope[:, None]).any(axis=1)[active].all():
+                Fc[:, first_rungs:] = ladder(al[first_rungs:])
+                nfev += T * (len(al) - first_rungs)
+        else:
+            Fc = ladder(al)
+            nfev += T * len(al)
         ok = Fc <= f[:, None] + c1 * al[None, :] * slope[:, None]
         first = np.where(ok.any(axis=1), ok.argmax(axis=1), Fc.argmin(axis=1))
         fa = Fc[np.arange(T), first]
@@ -304,7 +320,7 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
         a = np.where(moved, al[first], 0.0)
         s = a[:, None] * d
         Xn = X + s
-        fn, gn = batched_fd_gradient(grad_batch, Xn, h)
+        fn, gn = vg(Xn)
         nfev += T * (2 * P + 1)
         y = gn - g
         sy = np.einsum('ti,ti->t', s, y)

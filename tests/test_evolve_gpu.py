@@ -97,6 +97,43 @@ def test_warm_start_from_resident_fixed_points(D, P, engine_factory):
         assert abs(eta2[b] - ref_eta) < 1e-10
 
 
+@pytest.mark.parametrize('D,P', [(4, 4), (8, 6), (16, 8)])
+def test_two_sided_gradient_vs_oracle_central_differences(D, P, engine_factory):
+    """qmps_overlap_gradient: objective and central-difference gradient of T iterates from ONE right and ONE left eigen-solve
+    each (the neighbours by eta' = <y, T'(r)>/<y, r>) against the oracle's central differences of dense eigen-solves."""
+    rng = np.random.default_rng(80 + D)
+    eng = engine_factory(D, 4096)
+    T, h = 5, 1e-6
+    WW = WW_of(0.05)
+    ref = rng.standard_normal((T, P))
+    X = ref + 0.03 * rng.standard_normal((T, P))
+    eng.overlap_set_refs_params(0, ref, WW)
+    eng.overlap_stats(reset=True)
+    f, g, st = eng.overlap_gradient(0, X, h=h, tol=1e-13)
+    assert np.all(st == 0)
+    cold = eng.overlap_stats(reset=True)
+    assert cold['evaluations'] == 2 * T                       # two solves per iterate, not 2 P + 1
+    for t in range(T):
+        A = ER.tensor(0, D, ref[t])
+        assert abs(f[t] - ER.objective(0, D, A, X[t], WW)) < 1e-10
+        for k in range(P):
+            e = np.zeros(P)
+            e[k] = h
+            g_ref = (ER.objective(0, D, A, X[t] + e, WW) - ER.objective(0, D, A, X[t] - e, WW)) / (2 * h)
+            assert abs(g[t, k] - g_ref) < 2e-7, (t, k, g[t, k], g_ref)
+    # warm: the iterates moved by a BFGS step's worth; same answers, fewer power steps on both sides
+    X2 = X + 1e-3 * rng.standard_normal(X.shape)
+    f2, g2, st2 = eng.overlap_gradient(0, X2, h=h, tol=1e-13, warm=True)
+    warm = eng.overlap_stats()
+    assert np.all(st2 == 0)
+    f3, g3, st3 = eng.overlap_gradient(0, X2, h=h, tol=1e-13)
+    assert np.abs(f2 - f3).max() < 1e-11 and np.abs(g2 - g3).max() < 1e-6
+    if D >= 8:
+        assert warm['rounds_sum'] < cold['rounds_sum']
+    with pytest.raises(L.QmpsError):
+        eng.overlap_gradient(0, X2[:3], h=h, warm=True)        # the resident fixed points belong to 5 trajectories
+
+
 # (D, ansatz kind, parameters, trajectories, steps, sweeps, shifts per parameter, seed)
 ROTO_CASES = [(2, 2, 15, 3, 3, 2, 3, 11),      # the reference's own case: ShallowFullStateTensor(2, .), new_time_evolve.py:186-187
               (2, 0, 8, 3, 3, 2, 6, 12),       # scripts/loschmidt.py:203-207: ShallowCNOTStateTensor(2, .) with 8 angles, double frequency
@@ -149,8 +186,17 @@ def test_lockstep_bfgs_time_evolution(D, P, T, iters):
     X0 = rng.standard_normal((T, P))
     WW = WW_of(0.05)
     n_steps = 3
+    # D = 2: the neighbours are eigen-solved one by one; D = 4: both gradient routes; D = 16: two-sided + two-stage ladder
+    opts = {'maxiter': iters}
+    if D == 16:
+        opts['first_rungs'] = 2
     H, info = NT.evolve(X0, WW, n_steps, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-13,
-                        options={'maxiter': iters}, return_info=True)
+                        options=opts, return_info=True)
+    if D == 4:
+        H_fd, info_fd = NT.evolve(X0, WW, n_steps, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-13,
+                                  options={'maxiter': iters, 'gradient': 'fd'}, return_info=True)
+        for a, b in zip(info['fun'], info_fd['fun']):
+            assert a.shape == b.shape and np.abs(a - b).max() < F_TOL
     assert H.shape == (n_steps + 1, T, P)
     X = X0.copy()
     for step in range(n_steps):
@@ -179,6 +225,7 @@ def test_lockstep_bfgs_time_evolution(D, P, T, iters):
     if D == 16:
         s = info['solver']['gradient_batches']
         assert s['not_converged'] == 0
+        assert s['evaluations'] == 2 * T * sum(n + 1 for n in info['nit'])      # two solves per iterate and iteration
 
 
 def test_reference_signature_single_trajectory(engine_factory):

@@ -301,3 +301,38 @@ def test_batched_bfgs_lockstep_driver():
     assert res['history'].shape == (res['nit'] + 1, T)
     assert np.all(np.diff(res['history'], axis=0) <= 1e-15)          # monotone per trajectory
     assert calls['line'] == res['nit'] and calls['grad'] == res['nit'] + 2
+
+
+def test_batched_bfgs_with_supplied_gradient_and_two_stage_ladder():
+    """value_and_grad replaces the central-difference batches; first_rungs evaluates the ladder in two stages (the second one
+    only when some trajectory needs it) - same minimisers."""
+    from qmps_amd.tools import batched_bfgs
+    rng = np.random.default_rng(4)
+    T, P = 6, 3
+    c = rng.standard_normal((T, P))
+    sizes = []
+
+    def rosen_like(C, t):
+        d = C - c[t]
+        return np.sum(d ** 2, axis=1) + 5.0 * (d[:, 0] * d[:, 1]) ** 2 + 0.3 * np.sum(d ** 4, axis=1)
+
+    def line(C):
+        G = len(C) // T
+        sizes.append(G)
+        return rosen_like(C, np.arange(len(C)) // G)
+
+    def vg(X):
+        f = rosen_like(X, np.arange(T))
+        h = 1e-6
+        g = np.empty_like(X)
+        for k in range(P):
+            e = np.zeros(P)
+            e[k] = h
+            g[:, k] = (rosen_like(X + e, np.arange(T)) - rosen_like(X - e, np.arange(T))) / (2 * h)
+        return f, g
+    X0 = c + rng.standard_normal((T, P))
+    res = batched_bfgs(None, line, X0, maxiter=200, gtol=1e-8, value_and_grad=vg, first_rungs=2)
+    assert res['converged'].all() and np.abs(res['x'] - c).max() < 1e-6
+    assert set(sizes) <= {2, 6} and sizes.count(2) == res['nit'] and sizes.count(6) < res['nit']
+    res_full = batched_bfgs(None, line, X0, maxiter=200, gtol=1e-8, value_and_grad=vg)
+    assert np.abs(res_full['x'] - res['x']).max() < 1e-6

@@ -456,7 +456,8 @@ def main_evolve(args):
     from qmps_amd import _lib
     from qmps_amd.new_time_evolve import LockstepEvolver
     from qmps_amd.represent import ShallowCNOTStateTensor
-    ev = LockstepEvolver(D, T, P, ShallowCNOTStateTensor, tol=args.tol, maxiter=args.bfgs_iters, device=local_rank)
+    ev = LockstepEvolver(D, T, P, ShallowCNOTStateTensor, tol=args.tol, maxiter=args.bfgs_iters, device=local_rank,
+                         gradient=args.gradient, first_rungs=2 if args.gradient != 'fd' else None)
     info = _lib.device_info(local_rank)
     X = np.random.default_rng(args.seed + rank).standard_normal((T, P))
     t_settle = time.perf_counter()
@@ -493,7 +494,11 @@ def main_evolve(args):
         per_round = 8 * (D * D) ** 3 if squaring else 64 * D ** 3           # a squaring of the complex D^2 x D^2 matrix / a power step (8 complex D^3 products)
         setup = 64 * D ** 3 + (32 * D ** 4 if squaring else 128 * D * D)
         kms = np.array(ev.fg.kernel_ms)
-        flops_g = sg['rounds_sum'] * per_round + sg['evaluations'] * setup
+        two_sided = ev.two_sided
+        # two-sided gradient: besides the two solves per iterate, 2P neighbours x (merge(B', B'): 4 complex D^3 products + the contraction
+        # with G) and per iterate G_s = y^+ C_s r (12 products + the set-up of C_s)
+        n_iter_evals = sg['evaluations'] // 2 if two_sided else 0
+        flops_g = sg['rounds_sum'] * per_round + sg['evaluations'] * setup + n_iter_evals * (2 * P * (32 * D ** 3 + 32 * D * D) + 16 * 8 * D ** 3)
         tflops = flops_g / max(kms.sum() * 1e-3, 1e-12) * 1e-12
         byts = sg['evaluations'] * (32 * D * D + 16 + (32 * D * D if not squaring else 0))
         kernel_total_ms = float(kms.sum() + np.sum(ev.fl.kernel_ms))
@@ -503,7 +508,9 @@ def main_evolve(args):
                'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                'config': {'workload': f'TFIM g=1 quench time evolution, D={D}, ShallowCNOT depth {depth} ({P} parameters), {T} independent trajectories per GPU '
                                       f'from random parameters, W = exp(-{args.dt:g} i h), one step = one time step of every trajectory: lock-step BFGS '
-                                      f'(<= {args.bfgs_iters} iterations, gtol 1e-5, central differences h = 1e-6, 8-point backtracking ladder), objective '
+                                      f'(<= {args.bfgs_iters} iterations, gtol 1e-5, central differences h = 1e-6 ' +
+                                      ('from one right + one left eigen-solve per iterate (neighbours to second order in h), ladder in two stages (2 + 6 rungs)' if two_sided
+                                       else 'with every neighbour eigen-solved, 8-point backtracking ladder') + '), objective '
                                       f'-sqrt|eta| with eta to {args.tol:g} (residual of the power method / rank-one test of the squaring)',
                           'baseline_config': 'BASELINE.json configs[4]', 'D': D, 'trajectories_per_gpu': T, 'n_params': P, 'seed': args.seed,
                           'bfgs_iterations_per_step': float(np.mean(nit)), 'objective_evals_per_step': nfev / args.steps,
@@ -517,9 +524,11 @@ def main_evolve(args):
                'roofline': {'bound': 'fp64_matrix' if D == 16 else ('fp64_matrix' if D == 4 else 'fp64_valu'), 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                             'frac': tflops / FP64_PEAK_TFLOPS, 'traffic': None,
                             'kernel': ev.fg.eng.kernel_time(1)[1], 'kernel_ms': float(kms.mean()), 'launches': int(len(kms)),
-                            'kernel_ms_from': 'HIP events around EVERY launch of the gradient batches\' overlap kernel in the timed region (sum of durations / launches)',
-                            'note': f'dominant kernel = the overlap kernel of the gradient batches (T (2P+1) = {T * (2 * P + 1)} candidates per launch); executed FLOPs = '
-                                    f'rounds x {per_round} + evaluations x {setup} summed by the kernel itself (qmps_overlap_stats) over the same launches',
+                            'kernel_ms_from': 'HIP events around EVERY gradient evaluation of the timed region (sum of durations / launches)' +
+                                              (': right solve + left solve + neighbour tensors + G + probes' if two_sided else ': the overlap kernel of the T (2P+1) candidates'),
+                            'note': (f'dominant work = the gradient evaluation ({2 * T} eigen-solves + {2 * P * T} neighbour probes per launch); ' if two_sided else
+                                     f'dominant kernel = the overlap kernel of the gradient batches (T (2P+1) = {T * (2 * P + 1)} candidates per launch); ') +
+                                    f'executed FLOPs = rounds x {per_round} + evaluations x {setup} (+ probes) with rounds summed by the kernels themselves (qmps_overlap_stats) over the same launches',
                             'hbm': {'achieved': byts / max(kms.sum() * 1e-3, 1e-12) * 1e-9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                     'frac': byts / max(kms.sum() * 1e-3, 1e-12) * 1e-9 / HBM_PEAK_GBPS,
                                     'note': 'candidate tensor in + fixed point in and out (warm start) + eta / objective / status out per evaluation; the reference tensor is shared by a group'}},
@@ -647,6 +656,9 @@ def main():
     ap.add_argument('--hamiltonian', choices=['tfim', 'xxz'], default=None,
                     help='two-site Hamiltonian (default: the one BASELINE.json names for the bond dimension: xxz at D = 8, tfim otherwise)')
     ap.add_argument('--dt', type=float, default=0.05, help='evolve workload: time step (W = exp(-i dt h))')
+    ap.add_argument('--gradient', choices=['auto', 'two-sided', 'fd'], default='auto',
+                    help="evolve workload: 'two-sided' (auto at D >= 4) = one right + one left eigen-solve per iterate, the central-difference "
+                         "neighbours by eta' = <y, T'(r)>/<y, r>; 'fd' = every neighbour eigen-solved (what scipy's BFGS does with the reference objective)")
     ap.add_argument('--bfgs-iters', type=int, default=30, help='evolve workload: cap on BFGS iterations per time step')
     ap.add_argument('--double-frequency', action='store_true', help='rotosolve workload: six shifts per parameter (qmps/tools.py:422-457)')
     # defaults: the chip needs tens of ms of sustained load before its clocks settle

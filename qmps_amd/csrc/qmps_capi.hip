@@ -68,6 +68,8 @@ struct qmps_ctx {
   int64_t ref_cap = 0;         //   overwritten by qmps_set_states(kind = UNITARY) and the two-site unit cell)
   double* d_f = nullptr;       // overlap objective -sqrt|eta| [max_batch] (lazy)
   unsigned long long* d_ostats = nullptr;   // overlap solver statistics [4] (lazy)
+  char* h_pin = nullptr;       // pinned staging for the optimiser drivers' small host <-> device transfers (lazy, grown on demand):
+  size_t h_pin_bytes = 0;      //   pageable buffers make every hipMemcpyAsync a blocking, internally staged copy
   void* d_y = nullptr;         // qmps_overlap_gradient: LEFT fixed points [max_batch][D][D] (lazy)
   int64_t grad_warm_T = 0;     // d_r / d_y hold the fixed points of this many trajectories' iterates (qmps_overlap_gradient)
   void* d_xwarm = nullptr;     // qmps_evolve_rotosolve: fixed points per (parameter, candidate) (lazy, grown on demand)
@@ -235,6 +237,18 @@ int32_t* win_status(const qmps_ctx* c) { return c->d_status + c->window; }
 bool fusable_ansatz(const qmps_ctx* c, int kind) {
   static const bool off = getenv("QMPS_NO_FUSED_ANSATZ") != nullptr;   // A/B knob
   return !off && c->D == 4 && (kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_QAOA || kind == QMPS_ANSATZ_SHALLOW_CNOT3);
+}
+
+int ensure_pinned(qmps_ctx* c, size_t bytes) {
+  if (bytes > c->h_pin_bytes) {
+    if (c->h_pin) HIP_TRY(hipHostFree(c->h_pin));
+    c->h_pin = nullptr;
+    c->h_pin_bytes = 0;
+    const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    HIP_TRY(hipHostMalloc((void**)&c->h_pin, want, hipHostMallocDefault));
+    c->h_pin_bytes = want;
+  }
+  return QMPS_OK;
 }
 
 // (kind, n_params) of an ansatz the device builders know (qmps/represent.py:268-404)
@@ -470,6 +484,7 @@ int qmps_destroy(qmps_ctx* c) {
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -534,7 +549,16 @@ int qmps_set_states_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const
     HIP_TRY(hipMalloc((void**)&c->d_params, (size_t)c->max_batch * n_params * sizeof(double)));
     c->params_cap = n_params;
   }
-  HIP_TRY(hipMemcpyAsync(c->d_params, params, (size_t)B * n_params * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  {
+    const size_t pb = (size_t)B * n_params * sizeof(double);
+    const void* src = params;
+    if (c->defer_sync && pb <= (8u << 20)) {       // one-round-trip callers: through pinned memory, truly asynchronous
+      if (int rc = ensure_pinned(c, (16u << 20))) return rc;
+      memcpy(c->h_pin, params, pb);
+      src = c->h_pin;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_params, src, pb, hipMemcpyHostToDevice, c->stream));
+  }
   c->ans_have = true; c->ans_kind = kind; c->ans_P = n_params; c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0;
   c->tensors_valid = false;
   c->n_states = B;
@@ -1261,8 +1285,10 @@ int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int 
   if (int rc = launch_overlap_kernels(c, a)) return rc;
   c->have_env = false;
   c->have_guess = false;
-  c->have_overlap_x = want_r;
-  if (want_r) c->grad_warm_T = 0;
+  if (want_r) {                 // (a launch that keeps no fixed points leaves the resident ones alone)
+    c->have_overlap_x = true;
+    c->grad_warm_T = 0;
+  }
   c->acc_pending = false;
   c->partials_B = -1;
   return QMPS_OK;
@@ -1323,8 +1349,18 @@ int qmps_overlap_eval_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, con
     (void)hipStreamSynchronize(c->stream);
     return rc;
   }
-  HIP_TRY(hipMemcpyAsync(f_out, c->d_f, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  if (status_out) HIP_TRY(hipMemcpyAsync(status_out, c->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  const size_t fb = (size_t)B * sizeof(double), sb = (size_t)B * sizeof(int32_t);
+  if (fb + sb <= (8u << 20) && c->h_pin_bytes >= (16u << 20)) {
+    char* out = c->h_pin + (8u << 20);
+    HIP_TRY(hipMemcpyAsync(out, c->d_f, fb, hipMemcpyDeviceToHost, c->stream));
+    if (status_out) HIP_TRY(hipMemcpyAsync(out + fb, c->d_status, sb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(f_out, out, fb);
+    if (status_out) memcpy(status_out, out + fb, sb);
+    return QMPS_OK;
+  }
+  HIP_TRY(hipMemcpyAsync(f_out, c->d_f, fb, hipMemcpyDeviceToHost, c->stream));
+  if (status_out) HIP_TRY(hipMemcpyAsync(status_out, c->d_status, sb, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
@@ -1346,6 +1382,10 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   if (!c->d_y) HIP_TRY(hipMalloc(&c->d_y, (size_t)c->max_batch * env_bytes(c)));
   const size_t nD = (size_t)c->D * c->D;
   if (int rc = ensure_scratch(c, (size_t)T * (4 * nD + 1) * 16 + 256)) return rc;
+  {      // pinned staging for the results, sized BEFORE anything is in flight through it
+    const size_t need = (size_t)T * (1 + 2 * P) * sizeof(double) + (size_t)2 * T * sizeof(int32_t) + (8u << 20);
+    if (int e = ensure_pinned(c, need > (16u << 20) ? need : (16u << 20))) return e;
+  }
   // the iterates: parameters -> tensors in d_A[0, T)
   c->defer_sync = true;
   int rc = qmps_set_states_ansatz(c, T, kind, P, params);
@@ -1359,12 +1399,22 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   a.x_in = (warm && !squaring) ? c->d_r : nullptr;
   a.stats = c->d_ostats; a.iters = c->d_iters; a.status = c->d_status; a.B = T; a.a_shared = 0;
   a.max_rounds = squaring && max_rounds > 60 ? 60 : max_rounds; a.tol = tol;
-  if (int e = launch_overlap_kernels(c, a)) return e;
+  // HIP events around the WHOLE gradient evaluation (right solve, left solve, neighbour tensors, G, probes): qmps_kernel_time
+  c->dominant = c->D == 16 ? "overlap_mfma_d16_kernel + adjoint + neighbour probes" : "overlap solve + adjoint + neighbour probes";
+  c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
+  const int tslot = (int)(c->samples % qmps_ctx::kRing);
+  if (c->timed) HIP_TRY(hipEventRecord(c->kev0[tslot], c->stream));
   // the left fixed points: power method on the adjoint map; results behind the iterates' (eta, rounds, status at [T, 2T))
   qmps::OverlapArgs l = a;
   l.adjoint = 1; l.eta = (char*)c->d_eta + (size_t)T * 16; l.f_out = nullptr; l.r_out = c->d_y; l.x_in = warm ? c->d_y : nullptr;
   l.iters = c->d_iters + T; l.status = c->d_status + T; l.max_rounds = max_rounds;
-  HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 16 && getenv("QMPS_D16_BLOCK") == nullptr, c->stream));
+  if (c->D == 16 && T <= 4096 && getenv("QMPS_D16_BLOCK") == nullptr) {
+    // both solves in ONE launch: the iteration chains are latency-bound at these batch sizes, so the left solve rides along
+    HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream));
+  } else {
+    HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : getenv("QMPS_D16_BLOCK") == nullptr, c->stream));
+    HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 16 && getenv("QMPS_D16_BLOCK") == nullptr, c->stream));
+  }
   // the 2 P central-difference neighbours of every iterate, evaluated to second order in h from (y, r)
   HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->stream));
   qmps::OverlapGradArgs g;
@@ -1372,12 +1422,17 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   g.A = c->d_ref; g.WW = c->d_ww; g.r = c->d_r; g.y = c->d_y; g.G = c->d_scratch; g.yr = (char*)c->d_scratch + (size_t)T * 4 * nD * 16;
   g.Bt = (char*)c->d_A + (size_t)T * tensor_bytes(c); g.f_out = c->d_f + T; g.T = T; g.G2P = 2 * P;
   HIP_TRY(qmps::launch_overlap_grad(c->D, g, c->stream));
-  std::vector<double> fn((size_t)T * 2 * P);
-  std::vector<int32_t> st((size_t)2 * T);
-  HIP_TRY(hipMemcpyAsync(f_out, c->d_f, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(fn.data(), c->d_f + T, fn.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(st.data(), c->d_status, st.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (c->timed) { HIP_TRY(hipEventRecord(c->kev1[tslot], c->stream)); c->samples++; }
+  c->launches++;
+  // f of the iterates and of their neighbours are contiguous in d_f: one copy; statuses of both solves: one copy (pinned staging)
+  const size_t fbytes = (size_t)T * (1 + 2 * P) * sizeof(double), sbytes = (size_t)2 * T * sizeof(int32_t);
+  double* fall = (double*)(c->h_pin + (8u << 20));
+  int32_t* st = (int32_t*)(c->h_pin + (8u << 20) + fbytes);
+  HIP_TRY(hipMemcpyAsync(fall, c->d_f, fbytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(st, c->d_status, sbytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(f_out, fall, (size_t)T * sizeof(double));
+  const double* fn = fall + T;
   for (int64_t t = 0; t < T; ++t) {
     for (int k = 0; k < P; ++k) g_out[t * P + k] = (fn[(size_t)t * 2 * P + k] - fn[(size_t)t * 2 * P + P + k]) / (2.0 * h);
     if (status_out) status_out[t] = st[t] > st[T + t] ? st[t] : st[T + t];

@@ -555,11 +555,11 @@ __global__ __launch_bounds__(256) void overlap_square_d4_kernel(OverlapArgs p) {
 // quarter of the SIMDs idle at B = 768 and, worse, lets the launch wait for its slowest candidate at one wave's pace; here
 // the stragglers run on four SIMDs each.
 // ------------------------------------------------------------------------------------------
+// (the body as a device function: the workgroups of one launch may run different instantiations - overlap_mfma_d16x4_pair_kernel)
 template <bool ADJ>
-__global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) {
-  constexpr int D = 16, LD = 17, WAVES = 4;
-  __shared__ double2 sT_all[WAVES][D * LD];          // wave-private transposes
-  __shared__ double2 sX_all[WAVES][D * D];           // exchange: one C-layout matrix per wave, element (q, lane) at [q * 64 + lane]
+__device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, int64_t b_first, int64_t b_stride, double2 (*sT_all)[16 * 17],
+                                                        double2 (*sX_all)[16 * 16]) {
+  constexpr int D = 16, LD = 17;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   double2* sT = sT_all[wave];
   const double tol2 = p.tol * p.tol;
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) 
     }
   };
   const int64_t slot_off = overlap_slot_offset(p);
-  for (int64_t b = blockIdx.x; b < p.B; b += gridDim.x) {
+  for (int64_t b = b_first; b < p.B; b += b_stride) {
     const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * (2 * D * D);
     const double2* Bp = (const double2*)p.Bt + b * (2 * D * D);
     const double2* W = (const double2*)p.WW;
@@ -735,6 +735,29 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) 
     }
     __syncthreads();
   }
+}
+
+template <bool ADJ>
+__global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) {
+  __shared__ double2 sT_all[4][16 * 17];          // wave-private transposes
+  __shared__ double2 sX_all[4][16 * 16];          // exchange: one C-layout matrix per wave, element (q, lane) at [q * 64 + lane]
+  overlap_mfma_d16x4_body<ADJ>(p, blockIdx.x, gridDim.x, sT_all, sX_all);
+}
+
+// RIGHT and LEFT fixed points in one launch (qmps_overlap_gradient): workgroups [0, n_right) run the map of `pr`, the others the
+// adjoint map of `pl` - twice the waves in flight for the same length of the (latency-bound) iteration chain
+__global__ __launch_bounds__(256) void overlap_mfma_d16x4_pair_kernel(OverlapArgs pr, OverlapArgs pl, int n_right) {
+  __shared__ double2 sT_all[4][16 * 17];
+  __shared__ double2 sX_all[4][16 * 16];
+  if ((int)blockIdx.x < n_right) overlap_mfma_d16x4_body<false>(pr, blockIdx.x, n_right, sT_all, sX_all);
+  else overlap_mfma_d16x4_body<true>(pl, blockIdx.x - n_right, gridDim.x - n_right, sT_all, sX_all);
+}
+
+hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st) {
+  if (right.B <= 0) return hipSuccess;
+  const int nr = (int)(right.B < 2048 ? right.B : 2048), nl = (int)(left.B < 2048 ? left.B : 2048);
+  hipLaunchKernelGGL(overlap_mfma_d16x4_pair_kernel, dim3((unsigned)(nr + nl)), dim3(256), 0, st, right, left, nr);
+  return hipGetLastError();
 }
 
 hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st) {

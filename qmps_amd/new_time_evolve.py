@@ -89,9 +89,10 @@ class _GroupedObjective:
         assert cand.shape[0] == self.T * G and G in np.atleast_1d(self.G)
         self.eng.overlap_set_group(G)
         # power-method bond dimensions: the fixed points stay in the candidates' slots (one slot layout: only while G is fixed)
-        keep = self.eng.D >= 8 and np.ndim(self.G) == 0
+        # the ladder's FIRST stage (or the only group size) owns the slots; a second-stage batch neither reads nor overwrites them
+        keep = self.eng.D >= 8 and G == np.atleast_1d(self.G)[0]
         f, st = self.eng.overlap_eval_params(self.kind, cand, max_rounds=self.max_rounds, tol=self.tol, want_r=keep, warm=self.warm and keep)
-        self.warm = keep
+        self.warm = self.warm or keep
         if self.kernel_ms is not None:
             self.kernel_ms.append(self.eng.kernel_time(1)[0])
         return np.where(st == L.STATUS_OK, f, np.nan)

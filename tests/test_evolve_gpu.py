@@ -77,9 +77,14 @@ def test_warm_start_from_resident_fixed_points(D, P, engine_factory):
     eng.overlap_set_refs_params(0, ref, WW)
     eng.overlap_set_group(G)
     eng.set_ansatz_params(0, cand)
-    eng.overlap_launch(T * G, tol=1e-12)                      # no fixed points kept
-    with pytest.raises(L.QmpsError):
-        eng.overlap_launch(T * G, tol=1e-12, warm=True)
+    from qmps_amd import EnergyEngine
+    with EnergyEngine(D, 64) as fresh:                        # a context that has never kept fixed points refuses a warm launch
+        fresh.overlap_set_refs_params(0, ref, WW)
+        fresh.overlap_set_group(G)
+        fresh.set_ansatz_params(0, cand)
+        fresh.overlap_launch(T * G, tol=1e-12)
+        with pytest.raises(L.QmpsError):
+            fresh.overlap_launch(T * G, tol=1e-12, warm=True)
     eng.overlap_launch(T * G, tol=1e-12, want_r=True)
     eta0, rounds0, st0 = eng.overlap_results(T * G)
     assert np.all(st0 == 0)

@@ -338,6 +338,103 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
             'history': np.array(history)}
 
 
+def batched_nelder_mead(batch_fun, x0, xatol=1e-4, fatol=1e-4, maxiter=None, maxfev=None, callback=None, speculate=True):
+    """scipy's Nelder-Mead (the reference's DEFAULT optimiser: settings['method'], qmps/tools.py:212-219) with its objective
+    evaluations issued as batches: the initial simplex (N + 1 points) and every shrink step (N points) are one batched call
+    each, and - speculate=True - the four candidate points of an iteration (reflection, expansion, outside and inside
+    contraction) are evaluated together, so an iteration is ONE device launch instead of up to three dependent scalar calls.
+    The decisions are scipy's (`_minimize_neldermead`, rho = 1, chi = 2, psi = sigma = 1/2, initial simplex x0 (1 + 0.05 e_k),
+    same termination test), taken on the same values: the simplex sequence is the one the scalar path produces.
+    batch_fun: (n, N) -> (n,); NaN (no valid environment) counts as +inf.  Returns a scipy OptimizeResult; `nfev` counts the
+    evaluations scipy would have made, `nfev_batched` the points actually evaluated, `n_batches` the device launches."""
+    from scipy.optimize import OptimizeResult
+    x0 = np.asarray(x0, dtype=float).ravel()
+    N = len(x0)
+    rho, chi, psi, sigma = 1.0, 2.0, 0.5, 0.5
+    if maxiter is None and maxfev is None:          # scipy's defaults, case by case
+        maxiter = maxfev = N * 200
+    elif maxiter is None:
+        maxiter = N * 200 if maxfev == np.inf else np.inf
+    elif maxfev is None:
+        maxfev = N * 200 if maxiter == np.inf else np.inf
+    stats = {'batches': 0, 'points': 0}
+
+    def F(X):
+        stats['batches'] += 1
+        stats['points'] += len(X)
+        v = np.asarray(batch_fun(np.atleast_2d(X)), dtype=float).ravel()
+        return np.where(np.isfinite(v), v, np.inf)
+    sim = np.empty((N + 1, N))
+    sim[0] = x0
+    for k in range(N):
+        y = x0.copy()
+        y[k] = (1 + 0.05) * y[k] if y[k] != 0 else 0.00025
+        sim[k + 1] = y
+    fsim = F(sim)
+    fcalls = N + 1
+    ind = np.argsort(fsim)
+    sim, fsim = sim[ind], fsim[ind]
+    iterations = 1
+    while fcalls < maxfev and iterations < maxiter:
+        if np.max(np.abs(sim[1:] - sim[0])) <= xatol and np.max(np.abs(fsim[0] - fsim[1:])) <= fatol:
+            break
+        xbar = np.add.reduce(sim[:-1], 0) / N
+        xr = (1 + rho) * xbar - rho * sim[-1]
+        xe = (1 + rho * chi) * xbar - rho * chi * sim[-1]
+        xc = (1 + psi * rho) * xbar - psi * rho * sim[-1]
+        xcc = (1 - psi) * xbar + psi * sim[-1]
+        if speculate:
+            fxr, fxe, fxc, fxcc = F(np.stack([xr, xe, xc, xcc]))
+        else:
+            fxr = F(xr)[0]
+        fcalls += 1
+        doshrink = False
+        if fxr < fsim[0]:
+            if not speculate:
+                fxe = F(xe)[0]
+            fcalls += 1
+            if fxe < fxr:
+                sim[-1], fsim[-1] = xe, fxe
+            else:
+                sim[-1], fsim[-1] = xr, fxr
+        elif fxr < fsim[-2]:
+            sim[-1], fsim[-1] = xr, fxr
+        elif fxr < fsim[-1]:
+            if not speculate:
+                fxc = F(xc)[0]
+            fcalls += 1
+            if fxc <= fxr:
+                sim[-1], fsim[-1] = xc, fxc
+            else:
+                doshrink = True
+        else:
+            if not speculate:
+                fxcc = F(xcc)[0]
+            fcalls += 1
+            if fxcc < fsim[-1]:
+                sim[-1], fsim[-1] = xcc, fxcc
+            else:
+                doshrink = True
+        if doshrink:
+            sim[1:] = sim[0] + sigma * (sim[1:] - sim[0])
+            fsim[1:] = F(sim[1:])
+            fcalls += N
+        iterations += 1
+        ind = np.argsort(fsim)
+        sim, fsim = sim[ind], fsim[ind]
+        if callback is not None:
+            callback(sim[0])
+    x, fval = sim[0], float(np.min(fsim))
+    if fcalls >= maxfev:
+        status, msg = 1, 'Maximum number of function evaluations has been exceeded.'
+    elif iterations >= maxiter:
+        status, msg = 2, 'Maximum number of iterations has been exceeded.'
+    else:
+        status, msg = 0, 'Optimization terminated successfully.'
+    return OptimizeResult(fun=fval, nit=iterations, nfev=fcalls, status=status, success=status == 0, message=msg, x=x,
+                          final_simplex=(sim, fsim), nfev_batched=stats['points'], n_batches=stats['batches'])
+
+
 class Optimizer:
     """Same contract as tools.py:203-284: subclasses bind/override `objective_function(params) ->
     float`; `optimize()` dispatches on settings['method'] ('Rotosolve' -> double_rotosolve,
@@ -395,9 +492,25 @@ class Optimizer:
                 res = double_rotosolve(self.objective_function, self.initial_guess, s['maxiter'], verbose, batch_eps=batch)
             self.optimized_result = res
         else:
-            self.optimized_result = minimize(fun=self.objective_function, x0=self.initial_guess, method=s['method'],
-                                             tol=s['tol'], options={'maxiter': s['maxiter'], 'disp': verbose},
-                                             callback=self.callback_store_values if s['store_values'] else None)
+            batch = self.batch_objective_function if type(self).batch_objective_function \
+                is not Optimizer.batch_objective_function else None
+            cb = self.callback_store_values if s['store_values'] else None
+            if batch is not None and s.get('batched', True) and s['method'] == 'Nelder-Mead':
+                # the reference's default method with its simplex points evaluated as device batches (same decisions, same simplex)
+                self.optimized_result = batched_nelder_mead(batch, self.initial_guess, xatol=s['tol'], fatol=s['tol'],
+                                                            maxiter=s['maxiter'], callback=cb)
+                if verbose:
+                    print(self.optimized_result.message)
+            elif batch is not None and s.get('batched', True) and s['method'] in ('BFGS', 'L-BFGS-B', 'CG', 'SLSQP', 'TNC'):
+                # gradient methods: scipy differentiates by one scalar call per column; here the 2 P central-difference
+                # neighbours of an iterate are ONE batch (the "finite-difference columns" of SURVEY section 3)
+                def jac(x):
+                    return batched_fd_gradient(batch, np.asarray(x, dtype=float)[None], h=1e-6)[1][0]
+                self.optimized_result = minimize(fun=self.objective_function, x0=self.initial_guess, method=s['method'], jac=jac,
+                                                 tol=s['tol'], options={'maxiter': s['maxiter'], 'disp': verbose}, callback=cb)
+            else:
+                self.optimized_result = minimize(fun=self.objective_function, x0=self.initial_guess, method=s['method'],
+                                                 tol=s['tol'], options={'maxiter': s['maxiter'], 'disp': verbose}, callback=cb)
         self.update_state()
         if verbose:
             print(f'Reason for termination is {self.optimized_result.message} ' +

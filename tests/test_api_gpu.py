@@ -352,3 +352,32 @@ def test_opt_environment_objective(engine_factory):
     opt = G.SparseFullEnergyOptimizer(h, 2, optimize_environment=True, initial_guess=P[0].copy())
     assert abs(opt.objective_function(P[0]) - f[0]) < 1e-13
     assert np.abs(opt.batch_objective_function(P) - f).max() < 1e-13
+
+
+@pytest.mark.parametrize('D,key', [(2, 'cnot_params_D2'), (4, 'cnot_params_D4')])
+def test_default_optimisers_with_batched_evaluations(D, key, golden):
+    """Optimizer.optimize() with the reference's DEFAULT method (Nelder-Mead, qmps/tools.py:212-219) and with BFGS / L-BFGS-B
+    (qmps/tools.py:248-264): simplex points and finite-difference columns go to the device as batches
+    (tools.batched_nelder_mead, tools.batched_fd_gradient); same minimiser as the scalar path on the golden ShallowCNOT cases."""
+    h = golden['ref_h_tfim']
+    p0 = golden[key][0].copy()
+    depth = len(p0) // 2
+    out = {}
+    for method in ('Nelder-Mead', 'BFGS', 'L-BFGS-B'):
+        for batched in (True, False):
+            opt = G.SparseFullEnergyOptimizer(h, D, depth, initial_guess=p0.copy(),
+                                              settings={'verbose': False, 'store_values': False, 'method': method, 'tol': 1e-10,
+                                                        'maxiter': 2000, 'batched': batched})
+            res = opt.optimize()
+            out[method, batched] = res
+            assert abs(O.energy_closed_form(O.unitary_to_tensor(O.shallow_cnot_unitary(D, res.x)), h) - res.fun) < 1e-10
+    nm_b, nm_s = out['Nelder-Mead', True], out['Nelder-Mead', False]
+    # the batched simplex takes scipy's decisions on the same values: the same iteration count and the same minimiser
+    assert nm_b.nit == nm_s.nit and nm_b.nfev == nm_s.nfev
+    assert np.abs(nm_b.x - nm_s.x).max() < 1e-8 and abs(nm_b.fun - nm_s.fun) < 1e-12
+    assert nm_b.n_batches <= nm_b.nit + 1 + nm_b.nit // 2       # one launch per iteration (+ shrinks), not one per evaluation
+    for method in ('BFGS', 'L-BFGS-B'):
+        a, b = out[method, True], out[method, False]
+        assert abs(a.fun - b.fun) < 1e-8, (method, a.fun, b.fun)
+        assert a.fun <= nm_b.fun + 1e-6                           # at least as low as the simplex result from the same start
+        assert a.nfev < b.nfev                                    # the columns no longer count as objective calls

@@ -336,3 +336,28 @@ def test_batched_bfgs_with_supplied_gradient_and_two_stage_ladder():
     assert set(sizes) <= {2, 6} and sizes.count(2) == res['nit'] and sizes.count(6) < res['nit']
     res_full = batched_bfgs(None, line, X0, maxiter=200, gtol=1e-8, value_and_grad=vg)
     assert np.abs(res_full['x'] - res['x']).max() < 1e-6
+
+
+def test_batched_nelder_mead_reproduces_scipy():
+    """tools.batched_nelder_mead takes scipy's decisions on the same values: same simplex sequence, same minimiser, same
+    evaluation count as scipy.optimize.minimize(method='Nelder-Mead') - with the points of an iteration evaluated as one batch."""
+    from scipy.optimize import minimize
+    from qmps_amd.tools import batched_nelder_mead
+    rng = np.random.default_rng(9)
+    for N in (2, 4, 7):
+        c = rng.standard_normal(N)
+        Q = rng.standard_normal((N, N))
+        Q = Q @ Q.T + np.eye(N)
+
+        def f(x):
+            d = np.asarray(x) - c
+            return float(d @ Q @ d + 0.2 * np.sum(np.cos(3 * d)))
+        x0 = rng.standard_normal(N)
+        ref = minimize(f, x0, method='Nelder-Mead', tol=1e-9, options={'maxiter': 4000})
+        for spec in (True, False):
+            res = batched_nelder_mead(lambda X: np.array([f(x) for x in X]), x0, xatol=1e-9, fatol=1e-9, maxiter=4000, speculate=spec)
+            if True:
+                assert res.nit == ref.nit and res.nfev == ref.nfev, (N, spec, res.nit, ref.nit, res.nfev, ref.nfev)
+                assert np.array_equal(res.x, ref.x) and res.fun == ref.fun
+            assert res.n_batches <= res.nit + 1 + (res.nit if not spec else res.nit)
+        assert res.nfev_batched >= res.nfev

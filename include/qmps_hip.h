@@ -121,6 +121,18 @@ extern "C" {
  * eigenvalue between ~1e-4 and ~6e4 (tensors within a factor ~250 of an isometry) at D = 4; state unitaries and
  * ansatz-built tensors are exact isometries (eigenvalue 1).  Later squarings are rescaled by the measured eigenvalue. */
 
+/* ---- environment switches -----------------------------------------------------------------
+ * The library reads the environment in ONE place (qmps_amd/csrc/qmps_knobs.h).  The switches below are part of its
+ * documented behaviour: each selects between two implementations of the SAME computation, so that the test-suite can run
+ * both against the oracle.  Set (to any value) before the first call that would pick a kernel.
+ *   QMPS_NO_FUSED_ROTO    D = 2 rotosolve: one launch per parameter update instead of the whole run in one kernel
+ *   QMPS_NO_FUSED_ANSATZ  D = 4: materialise ansatz-built tensors in HBM instead of building them inside the energy kernel
+ *   QMPS_NO_GRAPH         rotosolve / time evolution: plain launches instead of a captured hipGraph per sweep
+ *   QMPS_OVERLAP_POWER    D = 4 overlap objective: operator-form power method instead of squaring the 16 x 16 map
+ *   QMPS_D16_BLOCK        D = 16: the generic LDS-tile kernels instead of the matrix-core kernels
+ * Everything else that used to be tunable from the environment (thresholds, schedules: profiles/EXPERIMENTS.md) is compiled
+ * in only with -DQMPS_DEBUG_KNOBS; the shipped library ignores those variables (tests/test_cabi.py checks both lists). */
+
 typedef struct qmps_ctx qmps_ctx;
 
 /* ---- library / device ------------------------------------------------------------------ */

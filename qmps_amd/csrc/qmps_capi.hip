@@ -15,6 +15,10 @@
 
 #include "qmps_hip.h"
 #include "qmps_kernels.h"
+#include "qmps_knobs.h"
+
+using qmps::documented_switch;
+using qmps::tuning_knob;
 
 namespace {
 
@@ -235,7 +239,7 @@ int32_t* win_status(const qmps_ctx* c) { return c->d_status + c->window; }
 
 // kinds the D = 4 direct kernel builds in front of the solve (three-qubit circuits with a per-layer gate list)
 bool fusable_ansatz(const qmps_ctx* c, int kind) {
-  static const bool off = getenv("QMPS_NO_FUSED_ANSATZ") != nullptr;   // A/B knob
+  static const bool off = documented_switch("QMPS_NO_FUSED_ANSATZ") != nullptr;   // A/B knob
   return !off && c->D == 4 && (kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_QAOA || kind == QMPS_ANSATZ_SHALLOW_CNOT3);
 }
 
@@ -447,10 +451,10 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     c->handoff = 0;   // D = 2, 4: squaring from the start (fastest); D = 8, 16 have no squaring path
     c->default_solver = (D == 2 || D == 4 || D == 8) ? QMPS_ENV_DIRECT : QMPS_ENV_POWER_SQUARING;
     c->skip_rounds = (D == 2) ? QMPS_SKIP_ROUNDS_D2 : QMPS_SKIP_ROUNDS_D4;
-    if (const char* e = getenv("QMPS_SKIP_ROUNDS")) c->skip_rounds = atoi(e);   // tuning knob
-    if (const char* e = getenv("QMPS_MATVEC_PERIOD")) c->matvec_period = atoi(e);   // tuning knob
-    c->no_pair = getenv("QMPS_NO_PAIR") != nullptr;
-    c->pair_in_step = getenv("QMPS_LANE_IN_STEP") == nullptr;
+    if (const char* e = tuning_knob("QMPS_SKIP_ROUNDS")) c->skip_rounds = atoi(e);   // tuning knob
+    if (const char* e = tuning_knob("QMPS_MATVEC_PERIOD")) c->matvec_period = atoi(e);   // tuning knob
+    c->no_pair = tuning_knob("QMPS_NO_PAIR") != nullptr;
+    c->pair_in_step = tuning_knob("QMPS_LANE_IN_STEP") == nullptr;
     return QMPS_OK;
   }();
   if (rc != QMPS_OK) {
@@ -628,7 +632,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     // rotosolve_fused_d2_kernel); afterwards one ordinary evaluation of the final parameters leaves the context's
     // resident tensors / energies / statuses exactly as the step-by-step path does.
     if ((nsh == 3 || nsh == 6) && c->D == 2 && c->handoff == 0 && (c->default_solver == QMPS_ENV_POWER_SQUARING || c->default_solver == QMPS_ENV_DIRECT) && n_params <= 64 &&
-        getenv("QMPS_NO_FUSED_ROTO") == nullptr) {
+        documented_switch("QMPS_NO_FUSED_ROTO") == nullptr) {
       qmps::RotoArgs ra;
       memset(&ra, 0, sizeof(ra));
       ra.base = d_base; ra.h = c->d_h; ra.hist = d_hist;
@@ -678,7 +682,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
         if (int e = one_update(i == 0)) return e;
       return QMPS_OK;
     };
-    const bool use_graph = getenv("QMPS_NO_GRAPH") == nullptr && n_params <= 256;
+    const bool use_graph = documented_switch("QMPS_NO_GRAPH") == nullptr && n_params <= 256;
     if (use_graph) {
       qmps_ctx::RotoKey key;
       key.R = R; key.kind = kind; key.P = n_params; key.nsh = nsh; key.max_iter = max_iter; key.n_terms = c->n_terms;
@@ -824,7 +828,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     // first step is the acceptance test, its loop the fall-back.  Small batches (all launch latency: BASELINE configs[3]
     // is 96 evaluations per GPU) run both in ONE launch; large ones keep two kernels - the block kernel alone runs four
     // waves per SIMD, the solve two.
-    static const int64_t fuse_below = getenv("QMPS_D8_FUSE_BELOW") ? atoll(getenv("QMPS_D8_FUSE_BELOW")) : 4096;   // A/B knob
+    static const int64_t fuse_below = tuning_knob("QMPS_D8_FUSE_BELOW") ? atoll(tuning_knob("QMPS_D8_FUSE_BELOW")) : 4096;   // A/B knob
     if (B <= fuse_below) {
       a.direct = 1;
       a.r_in = nullptr;
@@ -863,7 +867,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     else if (a.r_in == nullptr) c->have_env = false;      // (a warm launch that stores nothing leaves the resident guesses in place)
     return QMPS_OK;
   }
-  if (c->D == 16 && !getenv("QMPS_D16_BLOCK")) {
+  if (c->D == 16 && !documented_switch("QMPS_D16_BLOCK")) {
     // D = 16: power iteration on the matrix cores (one wave per evaluation), then the energy pass
     c->dominant = "energy_mfma_d16_kernel<true>";
     if (accumulate) if (int rc = setup_accumulator(c, a, B, B, 1)) return rc;
@@ -931,7 +935,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
       grid = (grid / generation) * generation;
       if (grid > 3 * generation) grid = 3 * generation;
     }
-    if (const char* e = getenv("QMPS_SQ_GRID")) grid = atoi(e) < grid ? atoi(e) : grid;   // tuning knob
+    if (const char* e = tuning_knob("QMPS_SQ_GRID")) grid = atoi(e) < grid ? atoi(e) : grid;   // tuning knob
     if (grid < 1) grid = 1;
     if (c->handoff == 0) {
       c->dominant = "env_square_d4_kernel";
@@ -999,9 +1003,9 @@ int qmps_energy_only_launch(qmps_ctx* c, int64_t B) {
   if (int rc = ensure_tensors(c)) return rc;
   qmps::LaneArgs a = make_args(c, B, 1, 1.0, false);
   c->partials_B = -1;
-  if (c->D == 16 && !getenv("QMPS_D16_BLOCK"))
+  if (c->D == 16 && !documented_switch("QMPS_D16_BLOCK"))
     HIP_TRY(qmps::launch_energy_mfma(c->D, a, false, c->stream));
-  else if (c->D == 4 && getenv("QMPS_ENERGY_PAIR") == nullptr)
+  else if (c->D == 4 && tuning_knob("QMPS_ENERGY_PAIR") == nullptr)
     HIP_TRY(qmps::launch_energy_only_d4(a, c->stream));     // quad layout, 4+ waves per SIMD (round 1: two lanes per evaluation)
   else if (c->D == 4 && !c->no_pair)
     HIP_TRY(qmps::launch_energy_pair_d4(a, c->stream));
@@ -1192,16 +1196,16 @@ int ensure_overlap_outputs(qmps_ctx* c) {
   return QMPS_OK;
 }
 // the kernel the overlap launch of this context runs (name for qmps_kernel_time) and whether it counts squarings
-bool overlap_squares(const qmps_ctx* c) { return c->D == 2 || (c->D == 4 && !getenv("QMPS_OVERLAP_POWER")); }
+bool overlap_squares(const qmps_ctx* c) { return c->D == 2 || (c->D == 4 && !documented_switch("QMPS_OVERLAP_POWER")); }
 int launch_overlap_kernels(qmps_ctx* c, const qmps::OverlapArgs& a) {
   const bool squaring = overlap_squares(c);
   c->dominant = c->D == 2 ? "overlap_lane_kernel" : (c->D == 4 && squaring ? "overlap_square_d4_kernel" :
-                (c->D == 16 && !getenv("QMPS_D16_BLOCK") ? "overlap_mfma_d16_kernel" : "overlap_block_kernel<D>"));
+                (c->D == 16 && !documented_switch("QMPS_D16_BLOCK") ? "overlap_mfma_d16_kernel" : "overlap_block_kernel<D>"));
   c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
   const int slot = (int)(c->samples % qmps_ctx::kRing);
   if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
   if (c->D == 2) HIP_TRY(qmps::launch_overlap(a, c->stream));
-  else HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : getenv("QMPS_D16_BLOCK") == nullptr, c->stream));
+  else HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : documented_switch("QMPS_D16_BLOCK") == nullptr, c->stream));
   if (c->timed) { HIP_TRY(hipEventRecord(c->kev1[slot], c->stream)); c->samples++; }
   if (!c->capturing) c->launches++;
   return QMPS_OK;
@@ -1408,12 +1412,12 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   qmps::OverlapArgs l = a;
   l.adjoint = 1; l.eta = (char*)c->d_eta + (size_t)T * 16; l.f_out = nullptr; l.r_out = c->d_y; l.x_in = warm ? c->d_y : nullptr;
   l.iters = c->d_iters + T; l.status = c->d_status + T; l.max_rounds = max_rounds;
-  if (c->D == 16 && T <= 4096 && getenv("QMPS_D16_BLOCK") == nullptr) {
+  if (c->D == 16 && T <= 4096 && documented_switch("QMPS_D16_BLOCK") == nullptr) {
     // both solves in ONE launch: the iteration chains are latency-bound at these batch sizes, so the left solve rides along
     HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream));
   } else {
-    HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : getenv("QMPS_D16_BLOCK") == nullptr, c->stream));
-    HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 16 && getenv("QMPS_D16_BLOCK") == nullptr, c->stream));
+    HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : documented_switch("QMPS_D16_BLOCK") == nullptr, c->stream));
+    HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr, c->stream));
   }
   // the 2 P central-difference neighbours of every iterate, evaluated to second order in h from (y, r)
   HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->stream));
@@ -1526,7 +1530,7 @@ int qmps_evolve_rotosolve(qmps_ctx* c, int64_t T, int kind, int n_params, double
       HIP_TRY(qmps::launch_roto_record(c->d_E, d_hist, (int)T, 1, d_idx + 2, 1, c->stream));
       return QMPS_OK;
     };
-    const bool use_graph = getenv("QMPS_NO_GRAPH") == nullptr && P <= 256;
+    const bool use_graph = documented_switch("QMPS_NO_GRAPH") == nullptr && P <= 256;
     if (use_graph) {
       c->capturing = true;
       HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -1728,7 +1732,7 @@ int qmps_comm_init(qmps_ctx* c, const char id[QMPS_UNIQUE_ID_BYTES], int rank, i
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
   RCCL_TRY(ncclCommInitRank(&c->comm, nranks, u, rank));
-  if (!getenv("QMPS_ONE_COMM")) {
+  if (!tuning_knob("QMPS_ONE_COMM")) {
     // second communicator over the same ranks (collective, like the init itself); without it everything runs on the first
     ncclResult_t r2 = ncclCommSplit(c->comm, 0, rank, &c->comm2, nullptr);
     if (r2 != ncclSuccess) c->comm2 = nullptr;

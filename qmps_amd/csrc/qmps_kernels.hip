@@ -31,6 +31,7 @@
 #include <stdint.h>
 
 #include "qmps_kernels.h"
+#include "qmps_knobs.h"
 #include "qmps_device.h"
 #include "qmps_circuit.h"
 #include "qmps_direct_d8.h"
@@ -3245,7 +3246,7 @@ hipError_t launch_energy_mfma(int D, const LaneArgs& a, bool solve, hipStream_t 
   if (a.B <= 0) return hipSuccess;
   // measured: B = 96: 0.210 ms against 0.287 with one wave per evaluation; B = 768: 0.325 against 0.318 (the exchange through LDS
   // and its two barriers per step cost what the shorter chain saves once every SIMD has a wave anyway)
-  static const int64_t split_below = getenv("QMPS_D16_SPLIT_BELOW") ? atoll(getenv("QMPS_D16_SPLIT_BELOW")) : 512;   // A/B knob
+  static const int64_t split_below = tuning_knob("QMPS_D16_SPLIT_BELOW") ? atoll(tuning_knob("QMPS_D16_SPLIT_BELOW")) : 512;   // A/B knob
   if (solve && a.B <= split_below) {
     // few evaluations: two waves per evaluation (half the dependent MFMA chain per wave)
     hipLaunchKernelGGL(energy_mfma_d16x2_kernel<true>, dim3((unsigned)(a.B < 8192 ? a.B : 8192)), dim3(128), 0, st, a);

@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "qmps_kernels.h"
+#include "qmps_knobs.h"
 #include "qmps_device.h"
 
 namespace qmps {
@@ -784,7 +785,7 @@ hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t 
       if (mfma) {
         // few candidates: four waves per evaluation (the launch waits for its slowest candidate - give it four SIMDs);
         // many: one wave per evaluation (no exchange through LDS, same MFMA work)
-        static const int64_t split_below = getenv("QMPS_D16_SPLIT_BELOW") ? atoll(getenv("QMPS_D16_SPLIT_BELOW")) : 2048;   // A/B knob
+        static const int64_t split_below = tuning_knob("QMPS_D16_SPLIT_BELOW") ? atoll(tuning_knob("QMPS_D16_SPLIT_BELOW")) : 2048;   // A/B knob
         if (a.B <= split_below) {
           const dim3 grid((unsigned)(a.B < 4096 ? a.B : 4096));
           if (a.adjoint) hipLaunchKernelGGL(overlap_mfma_d16x4_kernel<true>, grid, dim3(256), 0, st, a);

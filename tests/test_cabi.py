@@ -68,3 +68,36 @@ def test_product_code_never_imports_the_oracle():
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f'{f} imports the oracle'
                 assert 'libqmps_oracle' not in src and 'qmps_oracle_energy' not in src, f'{f} links the oracle'
                 assert not re.search(r'#include\s+[<"].*oracle', src), f'{f} includes oracle sources'
+
+
+def test_environment_switches_are_documented_or_compiled_out():
+    """The library reads the environment only through qmps_knobs.h: `documented_switch` names must be listed in
+    include/qmps_hip.h, `tuning_knob` names are dead unless built with -DQMPS_DEBUG_KNOBS, and a raw getenv() appears
+    nowhere else except inside `#ifdef QMPS_DEBUG_KNOBS` blocks (the QMPS_DBG_* timing dissections)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, 'include', 'qmps_hip.h')).read()
+    documented, tuning = set(), set()
+    for f in glob.glob(os.path.join(root, 'qmps_amd', 'csrc', '*')):
+        if not f.endswith(('.hip', '.h')) or f.endswith('qmps_knobs.h'):
+            continue
+        src = open(f).read()
+        documented |= set(re.findall(r'documented_switch\("([A-Z0-9_]+)"\)', src))
+        tuning |= set(re.findall(r'tuning_knob\("([A-Z0-9_]+)"\)', src))
+        # raw getenv only between #ifdef QMPS_DEBUG_KNOBS and its #else / #endif
+        depth_dbg = False
+        for line in src.splitlines():
+            t = line.strip()
+            if t.startswith('#ifdef QMPS_DEBUG_KNOBS'):
+                depth_dbg = True
+            elif depth_dbg and (t.startswith('#else') or t.startswith('#endif')):
+                depth_dbg = False
+            if 'getenv(' in line:
+                assert depth_dbg, (f, line)
+    assert documented, 'no documented switches found'
+    for name in documented:
+        assert name in header, f'{name} is read by the library but not documented in include/qmps_hip.h'
+    assert not (documented & tuning)
+    knobs = open(os.path.join(root, 'qmps_amd', 'csrc', 'qmps_knobs.h')).read()
+    assert '#ifdef QMPS_DEBUG_KNOBS' in knobs and knobs.count('getenv(') == 2

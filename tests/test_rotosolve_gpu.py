@@ -117,6 +117,30 @@ def test_double_frequency_trajectory_follows_the_oracle(D, kind, c_oracle, engin
     assert same > len(fits) // 4
 
 
+@pytest.mark.parametrize('double', [False, True])
+def test_config3_trajectories_follow_the_oracle(double, c_oracle, engine_factory):
+    """BASELINE.json configs[3] exactly: Heisenberg XXZ, D = 8, ShallowCNOT depth 3 (6 angles), 256 random restarts x 3 angle
+    samples (single frequency) - and the six-sample double-frequency driver - replayed with the C oracle as evaluator."""
+    name, builder, per = KINDS[0]
+    rng = np.random.default_rng(8300 + int(double))
+    D, R, sweeps = 8, 256, 2
+    P0 = rng.standard_normal((R, 6))
+    h = O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})
+    es_ref, p_ref, bad, _ = oracle_trajectory(c_oracle, builder, D, P0, h[None], sweeps, double=double)
+    eng = engine_factory(D, 4096)
+    eng.set_hamiltonian(h)
+    es, p = (eng.double_rotosolve if double else eng.rotosolve)(0, P0, sweeps)
+    good = ~bad
+    assert good.sum() >= R - 8
+    # a restart that crosses a nearly flat direction may leave the oracle's trajectory for good (see the module docstring):
+    # allow a few of the 256, require the others to follow it to 1e-8
+    follows = good & (np.abs(es - es_ref).max(0) < 1e-8)
+    assert follows.sum() >= R - 12, (follows.sum(), np.sort(np.abs(es - es_ref).max(0))[-16:])
+    e_at_p, st_at_p = oracle_energies(c_oracle, builder, D, p, h[None])
+    assert np.abs(e_at_p - es[-1])[good & (st_at_p == 0)].max() < 1e-9
+    assert np.nanmin(es[-1]) < np.nanmin(es[0]) + 1e-12 and np.nanmean(es[-1]) < np.nanmean(es_ref[0]) + 1e-9
+
+
 def test_optimizer_rotosolve_runs_on_the_device(c_oracle):
     """Optimizer.optimize() with settings['method'] = 'Rotosolve' (tools.py:248-270): the whole double-frequency run is
     one C call - the host objective is never evaluated per parameter."""

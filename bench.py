@@ -309,6 +309,48 @@ def nearby_tensors(seed, D, B, eps_max):
     return np.ascontiguousarray(to_tensor(U)), np.ascontiguousarray(to_tensor(Us))
 
 
+def init_rccl(eng, dist, rank, world):
+    """RCCL communicator for this rank's engine: rank 0 creates the unique id, the launcher's gloo group broadcasts it, every rank
+    joins; all ranks then agree (gloo) on whether it worked.  Returns (ok, error text)."""
+    import torch
+    from qmps_amd import EnergyEngine, _lib
+    err = ''
+    try:
+        ids = [EnergyEngine.comm_unique_id() if rank == 0 else None]
+    except _lib.QmpsError as e:          # keep the ranks in step: everyone must reach the broadcast
+        ids, err = [None], str(e)
+    dist.broadcast_object_list(ids, src=0)
+    if ids[0] is not None:
+        try:
+            eng.comm_init(ids[0], rank, world)
+            if eng.comm_count() != world:
+                err = f'communicator has {eng.comm_count()} ranks, expected {world}'
+        except _lib.QmpsError as e:
+            err = str(e)
+    else:
+        err = err or 'rank 0 could not create an RCCL unique id'
+    flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+    if flag.item() != 0.0:
+        try:
+            eng.comm_destroy()
+        except _lib.QmpsError:
+            pass
+        return False, f'RCCL communicator unavailable on {int(flag.item())} rank(s) ({err or "see other ranks"})'
+    return True, ''
+
+
+def rotosolve_shard_plan(R_global, rank, world, shard):
+    """(first restart, restarts on this rank, restarts in all).  --shard: the R_global restarts are split into contiguous
+    blocks (qmps_amd.dist.shard_bounds; BASELINE.json configs[3]: "256 random restarts x 3 angle samples sharded over 8 MI355X");
+    otherwise every rank runs its own R_global restarts (replicas)."""
+    from qmps_amd.dist import shard_bounds
+    if shard:
+        lo, hi = shard_bounds(R_global, rank, world)
+        return lo, hi - lo, R_global
+    return rank * R_global, R_global, world * R_global
+
+
 def main_overlap(args):
     """--workload overlap: BASELINE.json configs[4] (TFIM quench time evolution, D = 16 on the matrix cores): one step =
     the overlap objective eta_b (dominant eigenvalue of the mixed two-site transfer map, qmps/new_time_evolve.py:193-221)
@@ -549,18 +591,30 @@ def main_rotosolve(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('QMPS_BENCH_ONE_DEVICE') == '1':
+        local_rank = 0
     D = args.D
     nsh = 6 if args.double_frequency else 3
-    R = max(1, args.batch // nsh)
+    R_global = max(1, args.batch // nsh)
+    first, R, R_all = rotosolve_shard_plan(R_global, rank, world, args.shard)
+    if R < 1:
+        sys.exit(f'bench.py: rank {rank} owns no restarts ({R_global} over {world} ranks)')
     depth = {2: 1, 4: 2, 8: 3, 16: 4}[D]
     P = 2 * depth
     dist = None
-    if world > 1:
+    force_dist = os.environ.get('QMPS_BENCH_FORCE_DIST') == '1'
+    if world > 1 or (force_dist and args.shard):
+        for k, v in (('NCCL_MAX_NCHANNELS', '1'), ('RCCL_MSCCL_ENABLE', '0'), ('RCCL_MSCCLPP_ENABLE', '0')):
+            os.environ.setdefault(k, v)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if os.path.isdir('/sys/class/net/lo'):
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
         dist.init_process_group('gloo', rank=rank, world_size=world)
     h, h_name = hamiltonian_of(args)
-    p0 = np.random.default_rng(args.seed + rank).standard_normal((R, P))
+    # --shard: ONE global set of restarts (same seed on every rank), this rank's contiguous block of it
+    p0 = (np.random.default_rng(args.seed).standard_normal((R_all, P))[first:first + R] if args.shard
+          else np.random.default_rng(args.seed + rank).standard_normal((R, P)))
     shifts = np.array([0.0, np.pi, np.pi / 2, -np.pi / 2, np.pi / 4, -np.pi / 4]) if nsh == 6 else np.array([0.0, np.pi / 2, -np.pi / 2])
     shifted = np.repeat(p0, nsh, axis=0)
     shifted[:, 0] += np.tile(shifts, R)          # the batch of the first parameter update: evaluation nsh r + k = restart r, shift k
@@ -582,6 +636,27 @@ def main_rotosolve(args):
     eng = EnergyEngine(D, nsh * R, device=local_rank)
     info = _lib.device_info(local_rank)
     eng.set_hamiltonian(h)
+    collective, reducer = 'none: independent restarts (replicas only)', None
+    if args.shard and dist is not None:
+        from qmps_amd.dist import RcclReducer
+        ok, err = init_rccl(eng, dist, rank, world)
+        if ok:
+            reducer = RcclReducer(eng)
+            collective = (f'RCCL communicator of {eng.comm_count()} ranks (ncclCommCount): after the sweeps of a run, the summed cost of every '
+                          'sweep over all ranks\' restarts (ncclAllReduce sum, <= 16 doubles per message) and the best final energy (ncclAllReduce min)')
+        else:
+            # reported, never silent; the restarts themselves need no collective, the reduction then travels over the launcher's gloo group
+            import torch
+
+            class _Gloo:
+                def allreduce_sum(self, v):
+                    t = torch.tensor(np.asarray(v, dtype=np.float64)); dist.all_reduce(t, op=dist.ReduceOp.SUM); return t.numpy().copy()
+
+                def allreduce_min(self, v):
+                    t = torch.tensor(np.asarray(v, dtype=np.float64)); dist.all_reduce(t, op=dist.ReduceOp.MIN); return t.numpy().copy()
+            reducer = _Gloo()
+            collective = err + '; sweep costs reduced over gloo'
+            print(f'bench.py[rank {rank}]: {collective}', file=sys.stderr, flush=True)
     run = eng.double_rotosolve if args.double_frequency else eng.rotosolve
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
@@ -594,6 +669,11 @@ def main_rotosolve(args):
         dist.barrier()
     t0 = time.perf_counter()
     hist, pfin = run(_lib.ANSATZ_SHALLOW_CNOT, p0, sweeps, max_iter=args.max_iter, tol=args.tol)
+    reduced = None
+    if reducer is not None:
+        # the path's exchange step for sharded restarts, inside the timed region
+        from qmps_amd.dist import reduce_sweep_costs
+        reduced = reduce_sweep_costs(hist, reducer)
     eng.sync()
     if dist is not None:
         dist.barrier()
@@ -624,10 +704,10 @@ def main_rotosolve(args):
                 'mean_power_iterations': float(it_r.mean()), 'not_converged_or_not_pd': int((st_r != 0).sum()),
                 'note': 'small batches are latency-bound: the fraction says how far below the FP64 roofline a parameter update sits.  FLOPs = ' + fl_note}
     if rank == 0:
-        evals = sweeps * P * nsh * R + R            # shifted batches (a sweep's record comes from the next sweep's shift-0 rows) + the final evaluation
-        out = {'metric': f'rotosolve energy evals/sec at D={D}, {R} restarts x {nsh} shifts', 'value': world * evals / elapsed,
+        evals_all = sweeps * P * nsh * R_all + R_all  # shifted batches (a sweep's record comes from the next sweep's shift-0 rows) + the final evaluation
+        out = {'metric': f'rotosolve energy evals/sec at D={D}, {R_all} restarts x {nsh} shifts', 'value': evals_all / elapsed,
                'unit': 'two-site energy evals/s', 'n_gpus': world, 'steps': sweeps, 'warmup': sweeps_w,
-               'ms_per_step': elapsed / sweeps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'ms_per_step': elapsed / sweeps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if args.shard else 'weak', 'vs_baseline': None,
                'dtype': 'f64', 'data': 'synthetic',
                'config': {'workload': f'device-resident {"double-frequency " if nsh == 6 else ""}rotosolve, {h_name}, D={D}, ShallowCNOT depth {depth} '
                                       f'({P} parameters), {R} restarts x {nsh} shifts = {nsh * R} evaluations per parameter update, one step = one sweep; '
@@ -637,9 +717,15 @@ def main_rotosolve(args):
                           'n_params': P, 'us_per_parameter_update': elapsed / (sweeps * P) * 1e6,
                           'best_energy': float(np.nanmin(hist[-1])), 'mean_energy_first_sweep': float(np.nanmean(hist[0])),
                           'mean_energy_last_sweep': float(np.nanmean(hist[-1])), 'exact_ground_state_energy': (-4 / np.pi) if h_name.startswith('TFIM') else None,
-                          'collective': 'none: independent restarts (replicas only)', 'device': info['name'], 'arch': info['arch']},
+                          'restarts_global': R_all, 'restarts_this_rank': R, 'sharded': bool(args.shard),
+                          'summed_cost_last_sweep_all_ranks': None if reduced is None else float(reduced[0][-1]),
+                          'restarts_counted_all_ranks': None if reduced is None else reduced[1],
+                          'best_energy_all_ranks': None if reduced is None else reduced[2],
+                          'collective': collective, 'device': info['name'], 'arch': info['arch']},
                'roofline': roof, 'cpu_baseline': cpu}
         print(json.dumps(out), flush=True)
+    if reducer is not None and hasattr(reducer, 'engine'):
+        eng.comm_destroy()
     eng.close()
     if dist is not None:
         dist.barrier()
@@ -653,6 +739,10 @@ def main():
                     help="'energy' = the headline (two-site energy evaluations, BASELINE.json configs[2]); 'overlap' = the time-evolution "
                          "overlap objective (configs[4]; use with --D 16 --batch 768); 'rotosolve' = sweeps of the device-resident optimiser loop "
                          '(--steps = sweeps, --batch = evaluations per parameter update)')
+    ap.add_argument('--shard', action='store_true',
+                    help='rotosolve workload at N > 1: --batch / shifts restarts IN ALL, split into contiguous blocks over the ranks '
+                         '(qmps_amd.dist.shard_bounds), the sweep costs summed and the best energy taken by RCCL all-reduces (strong scaling; '
+                         'BASELINE.json configs[3]); default: every rank runs its own restarts (replicas, weak scaling)')
     ap.add_argument('--hamiltonian', choices=['tfim', 'xxz'], default=None,
                     help='two-site Hamiltonian (default: the one BASELINE.json names for the bond dimension: xxz at D = 8, tfim otherwise)')
     ap.add_argument('--dt', type=float, default=0.05, help='evolve workload: time step (W = exp(-i dt h))')
@@ -767,25 +857,7 @@ def main():
     collective = 'none (N=1)'
     rccl_ok = False
     if dist is not None:
-        import torch
-        err = ''
-        try:
-            ids = [EnergyEngine.comm_unique_id() if rank == 0 else None]
-        except _lib.QmpsError as e:          # keep the ranks in step: everyone must reach the broadcast
-            ids, err = [None], str(e)
-        dist.broadcast_object_list(ids, src=0)
-        if ids[0] is not None:
-            try:
-                eng.comm_init(ids[0], rank, world)
-                if eng.comm_count() != world:
-                    err = f'communicator has {eng.comm_count()} ranks, expected {world}'
-            except _lib.QmpsError as e:
-                err = str(e)
-        else:
-            err = err or 'rank 0 could not create an RCCL unique id'
-        flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64)
-        dist.all_reduce(flag, op=dist.ReduceOp.SUM)
-        rccl_ok = flag.item() == 0.0
+        rccl_ok, err = init_rccl(eng, dist, rank, world)
         if rccl_ok:
             ex = max(1, min(16, args.exchange_every))
             eng.set_exchange_period(ex)
@@ -795,12 +867,7 @@ def main():
         else:
             # reported, never silent: the data path is unchanged (no collective in it); only the summed cost
             # travels over the launcher's gloo group, once, after the timed region
-            try:
-                eng.comm_destroy()
-            except _lib.QmpsError:
-                pass
-            collective = f'RCCL communicator unavailable on {int(flag.item())} rank(s) ({err or "see other ranks"}); ' \
-                         'summed cost reduced over gloo after the timed region'
+            collective = err + '; summed cost reduced over gloo after the timed region'
             print(f'bench.py[rank {rank}]: {collective}', file=sys.stderr, flush=True)
 
     # HIP events around the dominant kernel on some launches of the timed region, not on every one: a pair of events

@@ -393,6 +393,8 @@ int qmps_comm_destroy(qmps_ctx* ctx);
 int qmps_comm_count(qmps_ctx* ctx, int* nranks);
 /* in-place sum over ranks of a small float64 vector held on the host (staged through HBM) */
 int qmps_allreduce_sum(qmps_ctx* ctx, double* inout, int n);
+/* the same with ncclMin: the best cost over the restarts of all ranks (BASELINE.json configs[3]: restarts sharded over the GPUs) */
+int qmps_allreduce_min(qmps_ctx* ctx, double* inout, int n);
 /* COLLECTIVE CALLS.  With a communicator, every function that exchanges costs must be called by ALL ranks, in the same
  * order, with the same exchange period: qmps_cost_launch (closes a group every `period` calls), and the calls that
  * flush a partly filled group - qmps_sync, qmps_get_cost, qmps_allreduce_cost, qmps_set_exchange_period - as well as

@@ -85,6 +85,7 @@ SIGNATURES = {
     'qmps_comm_destroy': (c_int, [c_void_p]),
     'qmps_comm_count': (c_int, [c_void_p, POINTER(c_int)]),
     'qmps_allreduce_sum': (c_int, [c_void_p, _dp, c_int]),
+    'qmps_allreduce_min': (c_int, [c_void_p, _dp, c_int]),
     'qmps_cost_launch': (c_int, [c_void_p, c_int64]),
     'qmps_set_exchange_period': (c_int, [c_void_p, c_int]),
     'qmps_exchange_stats': (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_double), c_int]),

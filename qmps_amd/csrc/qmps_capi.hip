@@ -1792,6 +1792,19 @@ int qmps_allreduce_sum(qmps_ctx* c, double* inout, int n) {
   return QMPS_OK;
 }
 
+int qmps_allreduce_min(qmps_ctx* c, double* inout, int n) {
+  if (int rc = bind(c)) return rc;
+  if (!inout || n < 1 || n > kMaxTerms) return fail(QMPS_ERR_ARG, "n=%d outside [1,%d]", n, kMaxTerms);
+  if (!c->comm) return fail(QMPS_ERR_STATE, "qmps_comm_init has not been called");
+  memcpy(c->h_cost, inout, n * sizeof(double));
+  HIP_TRY(hipMemcpyAsync(c->d_cost, c->h_cost, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  RCCL_TRY(ncclAllReduce(c->d_cost, c->d_cost, n, ncclDouble, ncclMin, c->comm, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_cost, c->d_cost, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(inout, c->h_cost, n * sizeof(double));
+  return QMPS_OK;
+}
+
 namespace {
 // close the current group: ONE ncclAllReduce of its `fill` x 16 doubles on the communication stream, ordered after the
 // device-side sums by an event, so the exchange overlaps the next steps' kernels instead of stalling the compute stream

@@ -32,6 +32,22 @@ class RcclReducer:
     def allreduce_sum(self, values):
         return self.engine.allreduce_sum(values)
 
+    def allreduce_min(self, values):
+        return self.engine.allreduce_min(values)
+
+
+def reduce_sweep_costs(hist, reducer, chunk=16):
+    """Exchange step of a sharded optimiser run (BASELINE.json configs[3]: restarts sharded over the GPUs, RCCL all-reduce):
+    hist (n_sweeps, R_local) = the energies of this rank's restarts after every sweep.  Returns (summed cost per sweep over ALL
+    ranks' restarts (n_sweeps,), restarts counted, best final energy over all ranks).  Rows of NaN-free values only count;
+    sums travel `chunk` (<= 16) doubles per all-reduce (the library's small-vector all-reduce), the best cost as one ncclMin."""
+    hist = np.asarray(hist, dtype=np.float64).reshape(len(hist), -1)
+    ok = np.isfinite(hist).all(axis=0) if hist.shape[1] else np.zeros(0, bool)
+    local = np.concatenate([hist[:, ok].sum(axis=1), [float(ok.sum())]])
+    total = np.concatenate([reducer.allreduce_sum(local[k:k + chunk]) for k in range(0, len(local), chunk)])
+    best = reducer.allreduce_min(np.array([hist[-1, ok].min() if ok.any() else np.inf]))[0]
+    return total[:-1], int(round(total[-1])), float(best)
+
 
 class ShardedCost:
     """cost[t] = sum over the GLOBAL batch of E[b, t], each rank evaluating only its shard.

@@ -493,6 +493,11 @@ class EnergyEngine:
         L.check(self._lib.qmps_allreduce_sum(self._ctx, _f64(v), v.size))
         return v
 
+    def allreduce_min(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        L.check(self._lib.qmps_allreduce_min(self._ctx, _f64(v), v.size))
+        return v
+
     def cost_launch(self, B=None):
         """Asynchronous: device-side sum over the batch (+ one RCCL all-reduce when a communicator exists)."""
         L.check(self._lib.qmps_cost_launch(self._ctx, self.B if B is None else B))

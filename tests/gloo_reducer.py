@@ -15,3 +15,8 @@ class GlooReducer:
         t = self._torch.tensor(np.asarray(values, dtype=np.float64))
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
         return t.numpy().copy()
+
+    def allreduce_min(self, values):
+        t = self._torch.tensor(np.asarray(values, dtype=np.float64))
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=self.group)
+        return t.numpy().copy()

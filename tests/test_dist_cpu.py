@@ -123,3 +123,62 @@ def test_sharded_cost_world2(B):
     expect = C.energy_batch(A, h)['E'].sum(0)
     assert np.allclose(res[0], res[1], rtol=0, atol=0)        # every rank holds the same reduced cost
     assert np.allclose(res[0], expect, rtol=0, atol=1e-11)
+
+
+def _roto_shard_worker(rank, world, port, R_global, out):
+    """bench.py --workload rotosolve --shard on every rank, with the oracle as the local evaluator: this rank's contiguous
+    block of the ONE global set of restarts, sweep energies of the block, then the path's exchange step
+    (qmps_amd.dist.reduce_sweep_costs: all-reduce sums of the per-sweep costs + all-reduce min of the best energy)."""
+    import torch.distributed as dist
+    from oracle import c_oracle as C
+    from oracle import qmps_oracle as O
+    from qmps_amd.dist import reduce_sweep_costs
+    from tests.gloo_reducer import GlooReducer
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        first, R, R_all = _bench_module().rotosolve_shard_plan(R_global, rank, world, True)
+        hist = _sweep_energies(C, O, R_all)[:, first:first + R]
+        out[rank] = (first, R, R_all) + reduce_sweep_costs(hist, GlooReducer())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _sweep_energies(C, O, R_all, sweeps=19):
+    """(sweeps, R_all) energies of R_all restarts along a deterministic parameter path (a stand-in for the sweeps of the
+    optimiser: what matters here is which rank owns which column); restart 3 is given an invalid (NaN) entry."""
+    P0 = np.random.default_rng(99).standard_normal((R_all, 4))
+    h = O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})
+    rows = []
+    for k in range(sweeps):
+        A = np.stack([O.unitary_to_tensor(O.shallow_cnot_unitary(4, p + 0.05 * k)) for p in P0])
+        rows.append(C.energy_batch(A, h)['E'][:, 0])
+    hist = np.array(rows)
+    if R_all > 3:
+        hist[5, 3] = np.nan
+    return hist
+
+
+@pytest.mark.parametrize('R_global', [11, 4])
+def test_sharded_rotosolve_exchange_world2(R_global):
+    import torch.multiprocessing as mp
+    from oracle import c_oracle as C
+    from oracle import qmps_oracle as O
+    C.build()
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_roto_shard_worker, args=(world, port, R_global, out), nprocs=world, join=True)
+        res = [out[r] for r in range(world)]
+    assert res[0][0] == 0 and res[0][0] + res[0][1] == res[1][0] and res[1][0] + res[1][1] == R_global      # contiguous, complete
+    assert abs(res[0][1] - res[1][1]) <= 1 and res[0][2] == res[1][2] == R_global
+    hist = _sweep_energies(C, O, R_global)
+    ok = np.isfinite(hist).all(axis=0)
+    for r in res:                                           # every rank holds the same reduced numbers
+        assert np.allclose(r[3], hist[:, ok].sum(axis=1), rtol=0, atol=1e-11) and len(r[3]) == 19   # 19 sweeps + the count: two messages
+        assert r[4] == int(ok.sum()) and abs(r[5] - hist[-1, ok].min()) < 1e-14
+    # replicas (no --shard): every rank its own restarts
+    plan = _bench_module().rotosolve_shard_plan
+    assert plan(R_global, 1, 2, False) == (R_global, R_global, 2 * R_global)

@@ -110,3 +110,57 @@ def test_bench_two_ranks_on_one_device(scaling):
     if 'RCCL communicator of 2 ranks' not in coll:             # (a box with two GPUs would take the RCCL path)
         assert 'RCCL communicator unavailable on 2 rank(s)' in coll and 'gloo' in coll
     assert np.isfinite(d['summed_cost']) and d['config']['not_converged_or_not_pd'] == 0
+
+
+def test_bench_two_ranks_with_extras():
+    """The same with the informational legs enabled: the rank-0-only extras must not issue collective calls (round 2's advisor
+    finding: a cost exchange inside a rank-0-only leg would leave unmatched all-reduces behind)."""
+    import json
+    env = dict(os.environ, QMPS_BENCH_ONE_DEVICE='1', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', '29521', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5',
+           '--warmup', '2', '--no-cpu-baseline', '--batch', '4096', '--rotate', '2']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and 'warm_start' in d and 'power_iteration' in d and 'contraction_only' in d
+
+
+def test_bench_extras_with_a_communicator_world1():
+    """Extras enabled WITH a live RCCL communicator (world size 1 through the launcher): the warm-start leg runs without a
+    cost exchange, the run completes and reports it."""
+    import json
+    env = dict(os.environ, QMPS_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+           '127.0.0.1', '--master-port', '29523', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5',
+           '--warmup', '2', '--no-cpu-baseline', '--batch', '4096', '--rotate', '2']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert 'RCCL communicator of 1 ranks' in d['config']['collective'] and d['warm_start']['accepted_fraction'] == 1.0
+
+
+@pytest.mark.parametrize('nproc', [1, 2])
+def test_bench_sharded_rotosolve(nproc):
+    """--workload rotosolve --shard (BASELINE.json configs[3]: restarts sharded over the GPUs, RCCL all-reduce of the sweep costs):
+    world size 1 with a real RCCL communicator; two ranks on one device (RCCL refuses a duplicate GPU: the reported gloo
+    fall-back) - shard plan, exchange inside the timed region, one JSON line."""
+    import json
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    env['QMPS_BENCH_FORCE_DIST' if nproc == 1 else 'QMPS_BENCH_ONE_DEVICE'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr',
+           '127.0.0.1', '--master-port', str(29525 + nproc), os.path.join(ROOT, 'bench.py'), '--gpus', str(nproc), '--workload', 'rotosolve',
+           '--D', '8', '--batch', '768', '--shard', '--steps', '4', '--warmup', '1', '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    c = d['config']
+    assert d['n_gpus'] == nproc and d['scaling'] == 'strong' and c['sharded'] and c['restarts_global'] == 256
+    assert c['restarts_this_rank'] == 256 // nproc and c['restarts_counted_all_ranks'] == 256
+    assert c['best_energy_all_ranks'] <= c['best_energy'] + 1e-12 and np.isfinite(c['summed_cost_last_sweep_all_ranks'])
+    if nproc == 1:
+        assert 'RCCL communicator of 1 ranks' in c['collective']
+    elif 'RCCL communicator of 2 ranks' not in c['collective']:
+        assert 'unavailable' in c['collective'] and 'gloo' in c['collective']

@@ -125,7 +125,7 @@ extern "C" {
  * The library reads the environment in ONE place (qmps_amd/csrc/qmps_knobs.h).  The switches below are part of its
  * documented behaviour: each selects between two implementations of the SAME computation, so that the test-suite can run
  * both against the oracle.  Set (to any value) before the first call that would pick a kernel.
- *   QMPS_NO_FUSED_ROTO    D = 2 rotosolve: one launch per parameter update instead of the whole run in one kernel
+ *   QMPS_NO_FUSED_ROTO    D = 2, 8 rotosolve: one launch per parameter update instead of the whole run in one kernel
  *   QMPS_NO_FUSED_ANSATZ  D = 4: materialise ansatz-built tensors in HBM instead of building them inside the energy kernel
  *   QMPS_NO_GRAPH         rotosolve / time evolution: plain launches instead of a captured hipGraph per sweep
  *   QMPS_OVERLAP_POWER    D = 4 overlap objective: operator-form power method instead of squaring the 16 x 16 map
@@ -176,7 +176,8 @@ int qmps_set_states_ansatz(qmps_ctx* ctx, int64_t B, int kind, int n_params, con
  * A whole sweep (n_params updates, the evaluation of the updated vectors, its record) is ONE hipGraph launch.  D = 4
  * with the direct solver: two kernels per parameter update - the energy kernel, which builds evaluation 3 r + k's
  * tensor from restart r's parameters with shift k added to the parameter being updated, and the update kernel.
- * D = 2: every sweep of every restart inside one kernel launch (qmps_double_rotosolve too). */
+ * D = 2 and D = 8 (ShallowCNOT families): every sweep of every restart inside ONE kernel launch (qmps_double_rotosolve too) -
+ * restarts are independent, so a quad of lanes (D = 2) or a workgroup with one wave per shift (D = 8) owns a restart. */
 int qmps_rotosolve(qmps_ctx* ctx, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter,
                    double tol, double* E_hist);
 /* Device-resident DOUBLE-frequency rotosolve (qmps/tools.py:422-457, what Optimizer.optimize('Rotosolve') runs): per

@@ -648,6 +648,25 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
       HIP_TRY(hipStreamSynchronize(c->stream));
       return QMPS_OK;
     }
+    // D = 8 (ShallowCNOT families, direct solver): the whole run in ONE launch as well - a workgroup per restart, a wave per
+    // shift (qmps_roto_d8.hip); afterwards one ordinary evaluation of the final parameters, as above
+    if (c->D == 8 && c->default_solver == QMPS_ENV_DIRECT && (kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_CNOT3) && n_params <= 64 &&
+        documented_switch("QMPS_NO_FUSED_ROTO") == nullptr) {
+      qmps::RotoArgs ra;
+      memset(&ra, 0, sizeof(ra));
+      ra.base = d_base; ra.h = c->d_h; ra.hist = d_hist;
+      ra.R = (int)R; ra.P = n_params; ra.n_terms = c->n_terms; ra.n_sweeps = n_sweeps; ra.max_iter = max_iter;
+      ra.tol = tol; ra.direct = 1; ra.nsh = nsh;
+      HIP_TRY(qmps::launch_rotosolve_fused_d8(kind, ra, c->stream));
+      HIP_TRY(qmps::launch_ansatz(c->D, kind, d_base, n_params, c->d_A, R, c->stream));
+      c->n_states = R; c->ans_have = false; c->tensors_valid = true;
+      if (int e = qmps_energy_launch(c, R, max_iter, tol, c->default_solver)) return e;
+      c->have_guess = saved_guess;
+      HIP_TRY(hipMemcpyAsync(params, d_base, (size_t)R * n_params * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(E_hist, d_hist, (size_t)R * n_sweeps * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      return QMPS_OK;
+    }
     // One parameter update = shift build -> ansatz -> environment + energy -> closed-form update.  The
     // parameter index lives in HBM and is advanced by the update kernel, so the sequence is captured ONCE
     // into a hipGraph and replayed n_params x n_sweeps times: the sweep is launch-bound at small R.

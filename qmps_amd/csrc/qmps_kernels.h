@@ -127,6 +127,8 @@ struct RotoArgs {
   int nsh;        // 3: single-frequency rotosolve, 6: double-frequency
 };
 hipError_t launch_rotosolve_fused_d2(int kind, const RotoArgs& a, hipStream_t st);
+// the same at D = 8 (ShallowCNOT, ShallowCNOT3): one workgroup per restart, one wave per shift (qmps_roto_d8.hip)
+hipError_t launch_rotosolve_fused_d8(int kind, const RotoArgs& a, hipStream_t st);
 
 // Two-site unit cell (NonSparseFullTwoSiteEnergyOptimizer): state unitaries U1, U2 [B][2D][2D].
 struct Cell2Args {

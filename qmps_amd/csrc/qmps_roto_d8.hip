@@ -1,0 +1,388 @@
+// qmps_roto_d8.hip - the WHOLE rotosolve run of a D = 8 ansatz in one kernel launch (gfx950 only).
+//
+// BASELINE.json configs[3] (Heisenberg XXZ, D = 8, depth 3, 256 restarts x 3 angle samples) is all latency: 768 evaluations
+// per parameter update occupy three quarters of the chip's SIMDs for ~22 us, and every update used to be three kernels
+// (shifted ansatz, solve + energy, update) with their launch gaps: 42 us.  Restarts are independent, so - as at D = 2
+// (rotosolve_fused_d2_kernel) - the sequential loop over parameters and sweeps needs no grid-wide step: ONE WORKGROUP PER
+// RESTART, one wave per shift (NSH = 3: {0, +pi/2, -pi/2}, qmps/rotosolve.py:154-181; NSH = 6: {0, pi, +-pi/2, +-pi/4},
+// qmps/tools.py:422-457).  Per parameter update each wave
+//   1. builds its shifted state tensor in LDS: the 8 columns of the 4-qubit ansatz circuit, DISTRIBUTED over the wave - lane
+//      8 j + a holds the two amplitudes (q0 q1 q2) = a, q3 = 0 | 1 of column j; diagonal gates are local, rx / H on q0..q2 are
+//      butterflies with the lane a xor 1 | 2 | 4 (ds_swizzle), the CNOT ladder is one gather (ds_bpermute) - ~300 instructions
+//      instead of ~2 300 for a lane that simulates a whole column by itself;
+//   2. solves the environment directly (env_direct_d8_solve, qmps_direct_d8.h), accepts it by one power step (or iterates),
+//      tests positive definiteness and evaluates the energies - the arithmetic of energy_block_kernel<8, true, FUSED>, wave-local;
+//   3. publishes its energy; wave 0 applies the update to the restart's parameter vector in LDS.
+// No launch, no graph replay, no HBM traffic inside the run: a parameter update costs the latency of ONE evaluation.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qmps_kernels.h"
+#include "qmps_device.h"
+#include "qmps_direct_d8.h"
+#include "qmps_roto_math.h"
+#include "qmps_circuit.h"     // roto_shift_value
+
+namespace qmps {
+
+namespace {
+
+struct D8Work {
+  double2 sA[2][8][9];
+  double2 sR[8][9];
+  double2 sX[2][8][9];
+  double2 sT[2][8][9];
+  double sM8[64][17];
+  double sT8[8][9];
+  double cs[64][2];        // cos / sin of the half angles of this wave's (shifted) parameter vector
+};
+
+__device__ __forceinline__ void wsync() { __builtin_amdgcn_wave_barrier(); }
+
+template <int PATTERN>
+__device__ __forceinline__ double swz(double v) {      // value of the lane (own index xor mask), within groups of 32 lanes
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), PATTERN);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), PATTERN);
+  return __hiloint2double(hi, lo);
+}
+
+struct Amp {
+  double re[2], im[2];
+};
+
+// rx on the qubit whose bit is the lane-index bit selected by PATTERN: a' = c a - i s (partner's a), both local amplitudes
+template <int PATTERN>
+__device__ __forceinline__ void rx_cross(Amp& v, double c, double s) {
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const double pr = swz<PATTERN>(v.re[l]), pi = swz<PATTERN>(v.im[l]);
+    const double nr = dfma(c, v.re[l], s * pi), ni = dfma(c, v.im[l], -s * pr);
+    v.re[l] = nr;
+    v.im[l] = ni;
+  }
+}
+
+// ShallowCNOTStateTensor (KIND 0) / ShallowCNOTStateTensor3 (KIND 3) at D = 8 (qmps/represent.py:288-310, 334-354): column j of the
+// 4-qubit circuit on |0>|j>, distributed over the lanes 8 j + a; writes A[s][i][j] = amplitude[2 i + s] into w.sA.
+// par(l): angle l of this wave's (shifted) parameter vector.
+template <int KIND, class Par>
+__device__ __forceinline__ void build_tensor_d8(D8Work& w, Par par, int n_params, int lane) {
+  constexpr int per = KIND == 3 ? 3 : 2;
+  const int j = lane >> 3, a = lane & 7;
+  // one sincos for the whole wave: lane l takes angle l
+  wsync();
+  if (lane < n_params) {
+    double sn, cn;
+    sincos(0.5 * par(lane), &sn, &cn);
+    w.cs[lane][0] = cn;
+    w.cs[lane][1] = sn;
+  }
+  wsync();
+  Amp v;
+  // |0>|j>: basis state x = j (q0 = 0), x = 2 a + l
+  v.re[0] = (2 * a == j) ? 1.0 : 0.0;
+  v.re[1] = (2 * a + 1 == j) ? 1.0 : 0.0;
+  v.im[0] = v.im[1] = 0.0;
+  const int pa = __builtin_popcount(a);
+  auto rz_all = [&](double c, double s) {
+    // prod_q rz(theta) = diag(exp(-i phi (4 - 2 popcount(x)))), phi = theta / 2, popcount(x) = popcount(a) + l
+    const double c2 = dfma(c, c, -s * s), s2 = 2.0 * s * c, c4 = dfma(c2, c2, -s2 * s2), s4 = 2.0 * s2 * c2;
+    // m = 4 - 2 pop:  exp(-i m phi) = (cos m phi, -sin m phi)
+    auto phase = [&](int m, double& pr, double& pi) {
+      pr = m == 0 ? 1.0 : ((m == 2 || m == -2) ? c2 : c4);
+      pi = m == 0 ? 0.0 : (m == 2 ? -s2 : (m == -2 ? s2 : (m == 4 ? -s4 : s4)));
+    };
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      double pr, pi;
+      phase(4 - 2 * (pa + l), pr, pi);
+      const double nr = dfma(v.re[l], pr, -v.im[l] * pi), ni = dfma(v.re[l], pi, v.im[l] * pr);
+      v.re[l] = nr;
+      v.im[l] = ni;
+    }
+  };
+  for (int l0 = 0; l0 + per <= n_params; l0 += per) {
+    rz_all(w.cs[l0][0], w.cs[l0][1]);
+    {
+      const double c = w.cs[l0 + 1][0], s = w.cs[l0 + 1][1];
+      // rx on q3: local 2 x 2
+      const double r0 = dfma(c, v.re[0], s * v.im[1]), i0 = dfma(c, v.im[0], -s * v.re[1]);
+      const double r1 = dfma(c, v.re[1], s * v.im[0]), i1 = dfma(c, v.im[1], -s * v.re[0]);
+      v.re[0] = r0; v.im[0] = i0; v.re[1] = r1; v.im[1] = i1;
+      rx_cross<0x041F>(v, c, s);     // q2 <-> a bit 0
+      rx_cross<0x081F>(v, c, s);     // q1 <-> a bit 1
+      rx_cross<0x101F>(v, c, s);     // q0 <-> a bit 2
+    }
+    if (KIND == 3) rz_all(w.cs[l0 + 2][0], w.cs[l0 + 2][1]);
+    {
+      // H on q0 (a bit 2): (a + partner)/sqrt 2 on the 0 side, (partner - a)/sqrt 2 on the 1 side
+      const double h = 0.70710678118654752, sg = (a & 4) ? -h : h;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const double pr = swz<0x101F>(v.re[l]), pi = swz<0x101F>(v.im[l]);
+        v.re[l] = dfma(sg, v.re[l], h * pr);
+        v.im[l] = dfma(sg, v.im[l], h * pi);
+      }
+    }
+    {
+      // CNOT(q2, q3), CNOT(q1, q2), CNOT(q0, q1): amplitude (b0 b1 b2 b3) moves to (b0, b1^b0, b2^b1, b3^b2).  Destination lane
+      // a' = (b0, b1^b0, b2^b1) gathers from a = (b0, b1, b2) and swaps the two local amplitudes when b2 = 1.
+      const int b0 = (a >> 2) & 1, b1 = ((a >> 1) & 1) ^ b0, b2 = (a & 1) ^ b1;
+      const int src = (lane & ~7) | (b0 << 2) | (b1 << 1) | b2;
+      const double r0 = __shfl(v.re[0], src, 64), i0 = __shfl(v.im[0], src, 64), r1 = __shfl(v.re[1], src, 64), i1 = __shfl(v.im[1], src, 64);
+      v.re[0] = b2 ? r1 : r0; v.im[0] = b2 ? i1 : i0;
+      v.re[1] = b2 ? r0 : r1; v.im[1] = b2 ? i0 : i1;
+    }
+  }
+  wsync();
+  w.sA[0][a][j] = make_double2(v.re[0], v.im[0]);
+  w.sA[1][a][j] = make_double2(v.re[1], v.im[1]);
+  wsync();
+}
+
+// Environment + energies of the tensor in w.sA, one wave (lane = 8 i + j owns r[i][j]): direct solve, power step(s) until
+// ||r' - r||_F < tol, LDL^H pivots > 0, E = sum over the Hamiltonian terms (the reference's M(x) = np.sum(eps), qmps/tools.py:432-433).
+// The arithmetic of energy_block_kernel<8, true, FUSED> (qmps_kernels.hip) with wave-local synchronisation.
+__device__ __forceinline__ double eval_d8(D8Work& w, const double2* __restrict__ h, int n_terms, int max_iter, double tol, int lane,
+                                          int& status_out) {
+  constexpr int D = 8;
+  const int i = lane >> 3, j = lane & 7;
+  wsync();
+  double2 r = env_direct_d8_solve(w.sA, w.sT8, w.sM8, lane);
+  w.sR[i][j] = r;
+  wsync();
+  double2 ai_[2][D];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int k = 0; k < D; ++k) ai_[s][k] = w.sA[s][i][k];
+  int status = QMPS_ST_NOT_CONVERGED;
+  const double tol2 = tol * tol;
+  for (int it = 1; it <= max_iter; ++it) {
+    double2 rc[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) rc[k] = w.sR[k][j];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      double xr = 0.0, xi = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double2 a = ai_[s][k], rr = rc[k];
+        xr = dfma(a.x, rr.x, xr);
+        xr = dfma(-a.y, rr.y, xr);
+        xi = dfma(a.x, rr.y, xi);
+        xi = dfma(a.y, rr.x, xi);
+      }
+      w.sX[s][i][j] = make_double2(xr, xi);
+    }
+    wsync();
+    double nr = 0.0, ni = 0.0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double2 a = w.sA[s][j][k], x = w.sX[s][i][k];
+        nr = dfma(x.x, a.x, nr);
+        nr = dfma(x.y, a.y, nr);
+        ni = dfma(x.y, a.x, ni);
+        ni = dfma(-x.x, a.y, ni);
+      }
+    // hermitise through LDS, normalise by the trace
+    w.sT[0][i][j] = make_double2(nr, ni);
+    wsync();
+    const double2 m = w.sT[0][j][i];
+    double2 n = make_double2(0.5 * (nr + m.x), (i == j) ? 0.0 : 0.5 * (ni - m.y));
+    const double tr = wave_sum(i == j ? n.x : 0.0);
+    const double inv = 1.0 / tr;
+    n.x *= inv;
+    n.y *= inv;
+    const double dr = n.x - r.x, di = n.y - r.y;
+    const double d2 = wave_sum(dr * dr + di * di);
+    r = n;
+    wsync();
+    w.sR[i][j] = r;
+    wsync();
+    if (d2 < tol2) {
+      status = QMPS_ST_OK;
+      break;
+    }
+  }
+  if (status == QMPS_ST_OK) {
+    // positive definiteness: the pivots of LDL^H, all 64 lanes at once (thread (i, j) owns the Schur-complement entry)
+    double2 S = r;
+    bool ok = true;
+    for (int c = 0; c < D; ++c) {
+      wsync();
+      w.sT[1][i][j] = S;
+      wsync();
+      const double pc = w.sT[1][c][c].x;
+      ok = ok && (pc > 0.0);
+      const double2 li = w.sT[1][i][c], lj = w.sT[1][j][c];
+      const double inv = fast_rcp(pc);
+      const double wr = (li.x * lj.x + li.y * lj.y) * inv, wi = (li.y * lj.x - li.x * lj.y) * inv;
+      S.x -= wr;
+      S.y -= wi;
+    }
+    if (!ok) status = QMPS_ST_NOT_PD;
+    wsync();
+  }
+  // ---- energy: rho[tau][sigma] = tr(A_t1 (A_t2 r A_s2^+) A_s1^+), this lane's share; E is linear in rho: one wave sum per term
+  const double trr = wave_sum(i == j ? r.x : 0.0);
+  double2 rho_loc[4][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    double xr = 0.0, xi = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const double2 a = w.sA[s][i][k], rr = w.sR[k][j];
+      xr = dfma(a.x, rr.x, xr);
+      xr = dfma(-a.y, rr.y, xr);
+      xi = dfma(a.x, rr.y, xi);
+      xi = dfma(a.y, rr.x, xi);
+    }
+    w.sX[s][i][j] = make_double2(xr, xi);
+  }
+  wsync();
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      double cr = 0.0, ci = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double2 x = w.sX[t2][i][k], a = w.sA[s2][j][k];
+        cr = dfma(x.x, a.x, cr);
+        cr = dfma(x.y, a.y, cr);
+        ci = dfma(x.y, a.x, ci);
+        ci = dfma(-x.x, a.y, ci);
+      }
+      wsync();
+      w.sT[0][i][j] = make_double2(cr, ci);
+      wsync();
+#pragma unroll
+      for (int t1 = 0; t1 < 2; ++t1) {
+        double zr = 0.0, zi = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const double2 a = w.sA[t1][i][k], rr = w.sT[0][k][j];
+          zr = dfma(a.x, rr.x, zr);
+          zr = dfma(-a.y, rr.y, zr);
+          zi = dfma(a.x, rr.y, zi);
+          zi = dfma(a.y, rr.x, zi);
+        }
+#pragma unroll
+        for (int s1 = 0; s1 < 2; ++s1) {
+          const double2 a = w.sA[s1][i][j];
+          rho_loc[2 * t1 + t2][2 * s1 + s2] = make_double2(zr * a.x + zi * a.y, zi * a.x - zr * a.y);
+        }
+      }
+    }
+  double e = 0.0;
+  for (int q = 0; q < n_terms; ++q) {
+    const double2* hq = h + q * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double2 hv = hq[s * 4 + t];
+        e = dfma(hv.x, rho_loc[t][s].x, e);
+        e = dfma(-hv.y, rho_loc[t][s].y, e);
+      }
+  }
+  e = wave_sum(e) / trr;
+  status_out = status;
+  return e;
+}
+
+}  // namespace
+
+template <int KIND, int NSH>
+__global__ __launch_bounds__(64 * NSH) void rotosolve_fused_d8_kernel(RotoArgs p) {
+  extern __shared__ double2 lds_dyn[];
+  char* lds_raw = (char*)lds_dyn;
+  D8Work* work = (D8Work*)lds_raw;
+  double* s_par = (double*)(lds_raw + NSH * sizeof(D8Work));      // the restart's parameter vector [P]
+  double* s_e = s_par + 64;                                        // [NSH] energies of the shifted evaluations
+  int* s_st = (int*)(s_e + 8);                                     // [NSH]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x;
+  if (r >= p.R) return;
+  D8Work& w = work[wave];
+  const double2* h = (const double2*)p.h;
+  for (int l = threadIdx.x; l < p.P; l += blockDim.x) s_par[l] = p.base[(int64_t)r * p.P + l];
+  __syncthreads();
+  auto evaluate = [&](int i_sel, double shift) {
+    build_tensor_d8<KIND>(w, [&](int l) { return s_par[l] + (l == i_sel ? shift : 0.0); }, p.P, lane);
+    int st;
+    const double e = eval_d8(w, h, p.n_terms, p.max_iter, p.tol, lane, st);
+    if (lane == 0) {
+      s_e[wave] = e;
+      s_st[wave] = st;
+    }
+  };
+  for (int sw = 0; sw < p.n_sweeps; ++sw) {
+    for (int i = 0; i < p.P; ++i) {
+      evaluate(i, roto_shift_value(NSH, wave));
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        // the shift-0 evaluation of a sweep's first parameter IS the evaluation of the vector the previous sweep left: its record
+        if (i == 0 && sw > 0) p.hist[(int64_t)(sw - 1) * p.R + r] = s_e[0];
+        bool ok = true;
+        for (int k = 0; k < NSH; ++k) ok = ok && s_st[k] == QMPS_ST_OK;
+        if (ok) {          // (an evaluation without a valid environment leaves the parameter untouched)
+          if (NSH == 3) {
+            const double theta = -1.5707963267948966 - atan2(2.0 * s_e[0] - s_e[1] - s_e[2], s_e[1] - s_e[2]);
+            s_par[i] = wrap_pi(s_par[i] + wrap_pi(theta));
+          } else {
+            const double A = s_e[0] + s_e[1], Bv = s_e[0] - s_e[1], C = s_e[2] + s_e[3], Dv = s_e[2] - s_e[3], Ev = s_e[4] - s_e[5];
+            const double a = 0.25 * (2.0 * Ev - 1.4142135623730951 * Dv), b = 0.25 * (A - C), c = 0.5 * Dv, d = 0.5 * Bv;
+            const double theta = double_sinusoid_argmin(a, b, c, d);
+            s_par[i] += theta < -3.141592653589793 ? theta + 6.283185307179586 : (theta > 3.141592653589793 ? theta - 6.283185307179586 : theta);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // the last sweep's record: the unshifted evaluation of the final vector (wave 0)
+  if (wave == 0) {
+    evaluate(-1, 0.0);
+    if (lane == 0) p.hist[(int64_t)(p.n_sweeps - 1) * p.R + r] = s_e[0];
+  }
+  __syncthreads();
+  for (int l = threadIdx.x; l < p.P; l += blockDim.x) p.base[(int64_t)r * p.P + l] = s_par[l];
+}
+
+hipError_t launch_rotosolve_fused_d8(int kind, const RotoArgs& a, hipStream_t st) {
+  if (a.R <= 0) return hipSuccess;
+  const dim3 grid((unsigned)a.R);
+  auto lds = [](int nsh) { return (size_t)nsh * sizeof(D8Work) + (64 + 8) * sizeof(double) + 8 * sizeof(int); };
+  hipError_t e = hipSuccess;
+  if (a.nsh == 3) {
+    if (kind == 0) {
+      e = hipFuncSetAttribute((const void*)rotosolve_fused_d8_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(3));
+      if (e == hipSuccess) hipLaunchKernelGGL((rotosolve_fused_d8_kernel<0, 3>), grid, dim3(192), lds(3), st, a);
+    } else if (kind == 3) {
+      e = hipFuncSetAttribute((const void*)rotosolve_fused_d8_kernel<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(3));
+      if (e == hipSuccess) hipLaunchKernelGGL((rotosolve_fused_d8_kernel<3, 3>), grid, dim3(192), lds(3), st, a);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  } else if (a.nsh == 6) {
+    if (kind == 0) {
+      e = hipFuncSetAttribute((const void*)rotosolve_fused_d8_kernel<0, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(6));
+      if (e == hipSuccess) hipLaunchKernelGGL((rotosolve_fused_d8_kernel<0, 6>), grid, dim3(384), lds(6), st, a);
+    } else if (kind == 3) {
+      e = hipFuncSetAttribute((const void*)rotosolve_fused_d8_kernel<3, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(6));
+      if (e == hipSuccess) hipLaunchKernelGGL((rotosolve_fused_d8_kernel<3, 6>), grid, dim3(384), lds(6), st, a);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  } else {
+    return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  return hipGetLastError();
+}
+
+}  // namespace qmps

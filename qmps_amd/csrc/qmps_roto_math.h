@@ -1,0 +1,71 @@
+// qmps_roto_math.h - the update rules of the rotosolve drivers (gfx950 only), shared by roto_update_kernel, the whole-run
+// D = 2 kernel (qmps_kernels.hip) and the whole-run D = 8 kernel (qmps_roto_d8.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "qmps_device.h"
+
+namespace qmps {
+
+__device__ __forceinline__ double wrap_pi(double x) { return atan2(sin(x), cos(x)); }
+
+// Global minimiser on [-pi, pi) of the fit of the double-frequency rotosolve (qmps/tools.py:447-451; the reference hands
+// it to scipy's minimize_scalar),  f(x) = P sin(2x + u) + Q sin(x + v) = a sin 2x + b cos 2x + c sin x + d cos x
+// with (a, b) = P (cos u, sin u), (c, d) = Q (cos v, sin v) - i.e. the fitted coefficients themselves, no hypot / atan2 /
+// sincos round trip.  32-point grid (sines and cosines of k pi/16: compile-time constants), then the root of f' inside the
+// bracket around the best grid point: 6 bisections + up to 5 guarded Newton steps, ONE sincos per evaluation (sin 2x and
+// cos 2x by the double-angle formulas).  A flat fit returns 0.  (First version: 32 + ~80 transcendental calls per fit, the
+// update kernel took 21 us - a third of a parameter update at D = 4.)
+__device__ __forceinline__ constexpr double sin_k_pi_16(int k) {
+  constexpr double S[9] = {0.0, 0.19509032201612825, 0.3826834323650898, 0.5555702330196022, 0.7071067811865476,
+                           0.8314696123025452, 0.9238795325112867, 0.9807852804032304, 1.0};
+  k &= 31;
+  return k <= 8 ? S[k] : (k <= 16 ? S[16 - k] : (k <= 24 ? -S[k - 16] : -S[32 - k]));
+}
+__device__ inline double double_sinusoid_argmin(double a, double b, double c, double d) {
+  if (!(fabs(a) + fabs(b) + fabs(c) + fabs(d) > 0.0)) return 0.0;
+  constexpr int NG = 32;
+  constexpr double H = 6.283185307179586 / NG;
+  double best = 1e300;
+  int gb = 0;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    // x_g = -pi + g pi/16:  sin x_g = -sin(g pi/16),  cos x_g = -cos(g pi/16);  2 x_g = g pi/8 (mod 2 pi)
+    const double sx = -sin_k_pi_16(g), cx = -sin_k_pi_16(g + 8), s2 = sin_k_pi_16(2 * g), c2 = sin_k_pi_16(2 * g + 8);
+    const double f = dfma(a, s2, dfma(b, c2, dfma(c, sx, d * cx)));
+    if (f < best) { best = f; gb = g; }
+  }
+  const double xb = -3.141592653589793 + gb * H;
+  auto eval = [&](double x, double& f, double& df, double& d2f) {
+    double sx, cx;
+    sincos(x, &sx, &cx);
+    const double s2 = 2.0 * sx * cx, c2 = dfma(cx, cx, -sx * sx);
+    f = dfma(a, s2, dfma(b, c2, dfma(c, sx, d * cx)));
+    df = dfma(2.0 * a, c2, dfma(-2.0 * b, s2, dfma(c, cx, -d * sx)));
+    d2f = -dfma(4.0 * a, s2, dfma(4.0 * b, c2, dfma(c, sx, d * cx)));
+  };
+  double lo = xb - H, hi = xb + H, x = xb, f, df, d2f, dlo, dhi;
+  eval(lo, f, dlo, d2f);
+  eval(hi, f, dhi, d2f);
+  if (dlo < 0.0 && dhi > 0.0) {
+    for (int it = 0; it < 6; ++it) {
+      const double mid = 0.5 * (lo + hi);
+      eval(mid, f, df, d2f);
+      if (df > 0.0) hi = mid; else lo = mid;
+    }
+    x = 0.5 * (lo + hi);
+    for (int it = 0; it < 5; ++it) {
+      eval(x, f, df, d2f);
+      if (!(d2f > 0.0)) break;
+      const double xn = x - df / d2f;
+      if (!(xn > lo - 1e-3 && xn < hi + 1e-3) || xn == x) break;
+      x = xn;
+    }
+    eval(x, f, df, d2f);
+    if (!(f <= best)) x = xb;
+  }
+  return x;
+}
+
+
+}  // namespace qmps

@@ -261,3 +261,34 @@ def test_d2_whole_run_kernel_matches_the_step_by_step_path(double, engine_factor
             for b in np.flatnonzero(both)[::7]:
                 Ab = O.unitary_to_tensor(build(2, p1[b])[None])[0]
                 assert abs(h1[-1][b] - sum(O.energy_closed_form(Ab, h[t]) for t in range(2))) < 1e-9
+
+
+@pytest.mark.parametrize('double', [False, True])
+def test_d8_whole_run_kernel_matches_the_step_by_step_path(double, c_oracle, engine_factory, monkeypatch):
+    """D = 8 (ShallowCNOT families): a workgroup per restart, a wave per shift, every sweep inside ONE launch - with the state
+    tensor built by the wave-distributed circuit (butterflies across lanes) - against the step-by-step path (ansatz / solve +
+    energy / update kernels per parameter) and against the oracle at the final parameters."""
+    from qmps_amd import _lib
+    rng = np.random.default_rng(888)
+    h = np.stack([O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5}), 0.3 * O.hamiltonian_matrix({'ZZ': -1, 'X': 1})])
+    eng = engine_factory(8, 4096)
+    eng.set_hamiltonian(h)
+    run = eng.double_rotosolve if double else eng.rotosolve
+    for kind, P, builder in ((_lib.ANSATZ_SHALLOW_CNOT, 6, O.shallow_cnot_unitary), (_lib.ANSATZ_SHALLOW_CNOT3, 6, O.shallow_cnot3_unitary),
+                             (_lib.ANSATZ_SHALLOW_CNOT, 2, O.shallow_cnot_unitary)):
+        P0 = rng.standard_normal((40, P))
+        monkeypatch.delenv('QMPS_NO_FUSED_ROTO', raising=False)
+        h1, p1 = run(kind, P0, 3)
+        E1 = eng.results(40)[0].sum(1)                    # the resident state the call leaves: energies of the final vectors
+        monkeypatch.setenv('QMPS_NO_FUSED_ROTO', '1')
+        h2, p2 = run(kind, P0, 3)
+        monkeypatch.delenv('QMPS_NO_FUSED_ROTO', raising=False)
+        both = ~(np.isnan(h1).any(0) | np.isnan(h2).any(0))
+        assert both.mean() > 0.8
+        close = both & (np.abs(wrap(p1 - p2)).max(1) < 1e-6)
+        assert close.mean() > 0.8, close.mean()
+        assert np.abs(h1 - h2)[:, close].max() < 1e-9
+        assert np.abs(E1 - h1[-1])[both].max() < 1e-10
+        e_at_p, st_at_p = oracle_energies(c_oracle, builder, 8, p1, h)
+        ok = both & (st_at_p == 0)
+        assert np.abs(e_at_p - h1[-1])[ok].max() < 1e-9

@@ -618,7 +618,12 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     return QMPS_OK;
   };
   if (int rc = grow(c->roto_base, c->roto_base_bytes, (size_t)R * n_params * sizeof(double))) return rc;
-  if (int rc = grow(c->roto_hist, c->roto_hist_bytes, (size_t)R * n_sweeps * sizeof(double))) return rc;
+#ifdef QMPS_D8_PROFILE        // scratch instrumentation build (tools/scratch/d8_profile.py): 8 phase clocks behind the history
+  constexpr size_t kHistExtra = 8;
+#else
+  constexpr size_t kHistExtra = 0;
+#endif
+  if (int rc = grow(c->roto_hist, c->roto_hist_bytes, ((size_t)R * n_sweeps + kHistExtra) * sizeof(double))) return rc;
   if (!c->roto_idx) HIP_TRY(hipMalloc((void**)&c->roto_idx, 4 * sizeof(int)));
   double *d_base = c->roto_base, *d_hist = c->roto_hist;
   int* d_idx = c->roto_idx;
@@ -650,8 +655,10 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     }
     // D = 8 (ShallowCNOT families, direct solver): the whole run in ONE launch as well - a workgroup per restart, a wave per
     // shift (qmps_roto_d8.hip); afterwards one ordinary evaluation of the final parameters, as above
-    if (c->D == 8 && c->default_solver == QMPS_ENV_DIRECT && (kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_CNOT3) && n_params <= 64 &&
-        documented_switch("QMPS_NO_FUSED_ROTO") == nullptr) {
+    // (single frequency only: with six shifts the workgroup needs six waves on four SIMDs - two share a register file, the
+    // solve spills - and measured 60 us per update against 44.5 us step by step; three shifts: 34.5 against 42)
+    if (c->D == 8 && nsh == 3 && c->default_solver == QMPS_ENV_DIRECT && (kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_CNOT3) &&
+        n_params <= 64 && documented_switch("QMPS_NO_FUSED_ROTO") == nullptr) {
       qmps::RotoArgs ra;
       memset(&ra, 0, sizeof(ra));
       ra.base = d_base; ra.h = c->d_h; ra.hist = d_hist;
@@ -663,7 +670,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
       if (int e = qmps_energy_launch(c, R, max_iter, tol, c->default_solver)) return e;
       c->have_guess = saved_guess;
       HIP_TRY(hipMemcpyAsync(params, d_base, (size_t)R * n_params * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipMemcpyAsync(E_hist, d_hist, (size_t)R * n_sweeps * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(E_hist, d_hist, ((size_t)R * n_sweeps + kHistExtra) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
       return QMPS_OK;
     }

@@ -311,10 +311,19 @@ __global__ __launch_bounds__(64 * NSH) void rotosolve_fused_d8_kernel(RotoArgs p
   const double2* h = (const double2*)p.h;
   for (int l = threadIdx.x; l < p.P; l += blockDim.x) s_par[l] = p.base[(int64_t)r * p.P + l];
   __syncthreads();
+#ifdef QMPS_D8_PROFILE      // scratch instrumentation (tools/scratch/d8_profile.sh): phase clocks of restart 0 into the history buffer
+  long long tp[6] = {0, 0, 0, 0, 0, 0};
+#define QMPS_TICK(k) do { if (r == 0 && threadIdx.x == 0) tp[k] = wall_clock64(); } while (0)
+#else
+#define QMPS_TICK(k) do { } while (0)
+#endif
   auto evaluate = [&](int i_sel, double shift) {
+    QMPS_TICK(0);
     build_tensor_d8<KIND>(w, [&](int l) { return s_par[l] + (l == i_sel ? shift : 0.0); }, p.P, lane);
+    QMPS_TICK(1);
     int st;
     const double e = eval_d8(w, h, p.n_terms, p.max_iter, p.tol, lane, st);
+    QMPS_TICK(2);
     if (lane == 0) {
       s_e[wave] = e;
       s_st[wave] = st;
@@ -324,6 +333,7 @@ __global__ __launch_bounds__(64 * NSH) void rotosolve_fused_d8_kernel(RotoArgs p
     for (int i = 0; i < p.P; ++i) {
       evaluate(i, roto_shift_value(NSH, wave));
       __syncthreads();
+      QMPS_TICK(3);
       if (threadIdx.x == 0) {
         // the shift-0 evaluation of a sweep's first parameter IS the evaluation of the vector the previous sweep left: its record
         if (i == 0 && sw > 0) p.hist[(int64_t)(sw - 1) * p.R + r] = s_e[0];
@@ -342,6 +352,14 @@ __global__ __launch_bounds__(64 * NSH) void rotosolve_fused_d8_kernel(RotoArgs p
         }
       }
       __syncthreads();
+#ifdef QMPS_D8_PROFILE
+      if (r == 0 && threadIdx.x == 0 && sw == 1 && i == 1) {
+        tp[4] = wall_clock64();
+        double* dbg = p.hist + (int64_t)p.n_sweeps * p.R;       // caller allocates 8 extra doubles
+        dbg[0] = (double)(tp[1] - tp[0]); dbg[1] = (double)(tp[2] - tp[1]); dbg[2] = (double)(tp[3] - tp[2]); dbg[3] = (double)(tp[4] - tp[3]);
+        dbg[4] = (double)(tp[4] - tp[0]);
+      }
+#endif
     }
   }
   // the last sweep's record: the unshifted evaluation of the final vector (wave 0)
@@ -356,7 +374,12 @@ __global__ __launch_bounds__(64 * NSH) void rotosolve_fused_d8_kernel(RotoArgs p
 hipError_t launch_rotosolve_fused_d8(int kind, const RotoArgs& a, hipStream_t st) {
   if (a.R <= 0) return hipSuccess;
   const dim3 grid((unsigned)a.R);
-  auto lds = [](int nsh) { return (size_t)nsh * sizeof(D8Work) + (64 + 8) * sizeof(double) + 8 * sizeof(int); };
+  // (at least 84 KB: more than half of a CU's 160 KB, so that no CU hosts two restarts - two workgroups on one CU would put two
+  // waves on one SIMD and make those restarts, and with them the whole launch, half as fast again)
+  auto lds = [](int nsh) {
+    const size_t need = (size_t)nsh * sizeof(D8Work) + (64 + 8) * sizeof(double) + 8 * sizeof(int);
+    return need > (size_t)84 * 1024 ? need : (size_t)84 * 1024;
+  };
   hipError_t e = hipSuccess;
   if (a.nsh == 3) {
     if (kind == 0) {

@@ -167,6 +167,20 @@ int qmps_set_states(qmps_ctx* ctx, int64_t B, const double* states, int kind);
 #define QMPS_ANSATZ_SHALLOW_FULL 2
 #define QMPS_ANSATZ_SHALLOW_CNOT3 3
 int qmps_set_states_ansatz(qmps_ctx* ctx, int64_t B, int kind, int n_params, const double* params);
+/* SU(2D) parameters -> state tensors ON THE DEVICE: params[B][(2D)^2 - 1], U = exp(-i/2 sum_k p_k G_k) with G_k the generalised
+ * Gell-Mann matrices (order: for a < b the symmetric then the antisymmetric one, rows first; then the 2D - 1 diagonal ones) -
+ * what NonSparseFullEnergyOptimizer does per evaluation on the host, `U = SU(u_params, 2 D)` (qmps/ground_state.py:245, 251-266;
+ * scripts/bond_dimension.py:21-50: D = 2 .. 16, 1 023 parameters at D = 16).  `SU` lives in xmps.spin, which is not in the reference
+ * tree: the convention is this library's (documentation-pinned; the optimisation problem is the same for any smooth onto map).
+ * Scaling and squaring of a degree-13 Taylor polynomial, one workgroup of 2D x 2D threads per evaluation; the tensor
+ * A[s][i][j] = U[2 i + s][j] (qmps/tools.py:151-154) is written directly.  8 ((2D)^2 - 1) bytes per evaluation cross PCIe
+ * instead of 64 D^2. */
+int qmps_set_states_su(qmps_ctx* ctx, int64_t B, const double* params);
+/* parameters -> energies in one round trip (the call shape of NonSparseFullEnergyOptimizer.objective_function) */
+int qmps_energy_batch_su(qmps_ctx* ctx, int64_t B, const double* params, const double* h, int n_terms, int max_iter, double tol,
+                         double* E_out, int32_t* iters_out, int32_t* status_out);
+/* the unitaries themselves, U_out[B][N][N] complex128, N in {4, 8, 16, 32} (any context; tests, U4 = SU(., 4)) */
+int qmps_su_unitaries(qmps_ctx* ctx, int64_t B, int N, const double* params /* [B][N^2 - 1] */, double* U_out);
 /* Device-resident single-frequency rotosolve (qmps/rotosolve.py:154-181; the caller shape of SURVEY
  * 8(a)-10/(f)-2): R restarts in lock-step; for each parameter i ONE batch of 3 R evaluations (shifts
  * 0, +pi/2, -pi/2) - ansatz build, environment, energy - and the closed-form update all run on the device,
@@ -255,6 +269,11 @@ int qmps_env_batch(qmps_ctx* ctx, int64_t B, const double* states, int kind, con
 int qmps_cell2_energy_batch(qmps_ctx* ctx, int64_t B, const double* U1, const double* U2, const double* h,
                             int n_terms, int max_iter, double tol, double* E_out, int32_t* iters_out,
                             int32_t* status_out);
+
+/* The same from the optimiser's 30 parameters per evaluation: U1 = U4(p[:15]), U2 = U4(p[15:]) (qmps/ground_state.py:300-301,
+ * U4 = SU(., 4)) built on the device. */
+int qmps_cell2_energy_batch_su(qmps_ctx* ctx, int64_t B, const double* params /* [B][30] */, const double* h, int n_terms, int max_iter,
+                               double tol, double* E_out, int32_t* iters_out, int32_t* status_out);
 
 /* Time-evolution overlap objective (qmps/new_time_evolve.py:193-221, scripts/loschmidt.py:209-239):
  * eta_b = dominant eigenvalue of x -> sum_{s<4} (WW . merge(A, A))_s x merge(B_b, B_b)_s^+ ; the reference's

@@ -40,6 +40,10 @@ SIGNATURES = {
     'qmps_sync': (c_int, [c_void_p]),
     'qmps_set_states': (c_int, [c_void_p, c_int64, _dp, c_int]),
     'qmps_set_states_ansatz': (c_int, [c_void_p, c_int64, c_int, c_int, _dp]),
+    'qmps_set_states_su': (c_int, [c_void_p, c_int64, _dp]),
+    'qmps_energy_batch_su': (c_int, [c_void_p, c_int64, _dp, _dp, c_int, c_int, c_double, _dp, _ip, _ip]),
+    'qmps_su_unitaries': (c_int, [c_void_p, c_int64, c_int, _dp, _dp]),
+    'qmps_cell2_energy_batch_su': (c_int, [c_void_p, c_int64, _dp, _dp, c_int, c_int, c_double, _dp, _ip, _ip]),
     'qmps_rotosolve': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, c_int, c_int, c_double, _dp]),
     'qmps_double_rotosolve': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, c_int, c_int, c_double, _dp]),
     'qmps_get_states': (c_int, [c_void_p, c_int64, _dp]),

@@ -576,6 +576,60 @@ int qmps_set_states_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const
   return QMPS_OK;
 }
 
+int qmps_set_states_su(qmps_ctx* c, int64_t B, const double* params) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (!params && B > 0) return fail(QMPS_ERR_ARG, "null params");
+  const int N = 2 * c->D, np_ = N * N - 1;
+  if (np_ > c->params_cap) {
+    if (c->d_params) HIP_TRY(hipFree(c->d_params));
+    c->d_params = nullptr;
+    HIP_TRY(hipMalloc((void**)&c->d_params, (size_t)c->max_batch * np_ * sizeof(double)));
+    c->params_cap = np_;
+  }
+  HIP_TRY(hipMemcpyAsync(c->d_params, params, (size_t)B * np_ * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(qmps::launch_su_exp(N, c->d_params, B, np_, c->d_A, 1, c->stream));
+  if (!c->defer_sync) HIP_TRY(hipStreamSynchronize(c->stream));
+  c->n_states = B;
+  c->window = 0;
+  c->have_guess = false;
+  c->have_env = false;
+  c->ans_have = false;
+  c->tensors_valid = true;
+  return QMPS_OK;
+}
+
+int qmps_energy_batch_su(qmps_ctx* c, int64_t B, const double* params, const double* h, int n_terms, int max_iter, double tol,
+                         double* E_out, int32_t* iters_out, int32_t* status_out) {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  if (!E_out) return fail(QMPS_ERR_ARG, "null E_out");
+  c->defer_sync = true;
+  int rc = qmps_set_states_su(c, B, params);
+  if (!rc) rc = qmps_set_hamiltonian(c, n_terms, h);
+  if (!rc) rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver);
+  c->defer_sync = false;
+  if (rc) {
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
+  }
+  return qmps_get_energies(c, B, E_out, iters_out, status_out);
+}
+
+int qmps_su_unitaries(qmps_ctx* c, int64_t B, int N, const double* params, double* U_out) {
+  if (int rc = bind(c)) return rc;
+  if (B < 0 || !params || !U_out) return fail(QMPS_ERR_ARG, "bad arguments");
+  if (N != 4 && N != 8 && N != 16 && N != 32) return fail(QMPS_ERR_ARG, "N=%d not in {4, 8, 16, 32}", N);
+  const size_t pb = (size_t)B * (N * N - 1) * sizeof(double), ub = (size_t)B * N * N * 16;
+  if (int rc = ensure_scratch(c, ((pb + 255) & ~(size_t)255) + ub + 256)) return rc;
+  double* d_p = (double*)c->d_scratch;
+  void* d_u = (char*)c->d_scratch + ((pb + 255) & ~(size_t)255);
+  HIP_TRY(hipMemcpyAsync(d_p, params, pb, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(qmps::launch_su_exp(N, d_p, B, N * N - 1, d_u, 0, c->stream));
+  HIP_TRY(hipMemcpyAsync(U_out, d_u, ub, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+
 namespace {
 int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter, double tol,
                    double* E_hist, int nsh);
@@ -1170,6 +1224,35 @@ int qmps_cell2_energy_batch(qmps_ctx* c, int64_t B, const double* U1, const doub
   c->partials_B = -1;
   HIP_TRY(qmps::launch_cell2(c->D, a, c->stream));
   c->n_states = 0;  // the resident single-site states (if any) are no longer what d_E refers to
+  c->have_env = false;
+  return qmps_get_energies(c, B, E_out, iters_out, status_out);
+}
+
+int qmps_cell2_energy_batch_su(qmps_ctx* c, int64_t B, const double* params, const double* h, int n_terms, int max_iter, double tol,
+                               double* E_out, int32_t* iters_out, int32_t* status_out) {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_B(c, B)) return rc;
+  if (c->D != 2) return fail(QMPS_ERR_ARG, "the two-site unit cell path is D = 2 only (qmps/ground_state.py:276)");
+  c->window = 0;
+  if (!params && B > 0) return fail(QMPS_ERR_ARG, "null params");
+  if (!E_out) return fail(QMPS_ERR_ARG, "null E_out");
+  if (max_iter < 1 || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_iter / tol");
+  if (int rc = qmps_set_hamiltonian(c, n_terms, h)) return rc;
+  const size_t ub = 2 * tensor_bytes(c);
+  if (!c->d_U) HIP_TRY(hipMalloc(&c->d_U, (size_t)c->max_batch * ub));
+  if (!c->d_U2) HIP_TRY(hipMalloc(&c->d_U2, (size_t)c->max_batch * ub));
+  if (int rc = ensure_scratch(c, (size_t)B * 30 * sizeof(double) + 256)) return rc;
+  double* d_p = (double*)c->d_scratch;
+  HIP_TRY(hipMemcpyAsync(d_p, params, (size_t)B * 30 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  // U1 = U4(p[:15]), U2 = U4(p[15:])  (qmps/ground_state.py:300-301), both built on the device
+  HIP_TRY(qmps::launch_su_exp(4, d_p, B, 30, c->d_U, 0, c->stream));
+  HIP_TRY(qmps::launch_su_exp(4, d_p + 15, B, 30, c->d_U2, 0, c->stream));
+  qmps::Cell2Args a;
+  a.U1 = c->d_U; a.U2 = c->d_U2; a.h = c->d_h; a.E = c->d_E; a.E12 = nullptr;
+  a.iters = c->d_iters; a.status = c->d_status; a.B = B; a.n_terms = n_terms; a.max_iter = max_iter; a.tol = tol;
+  c->partials_B = -1;
+  HIP_TRY(qmps::launch_cell2(c->D, a, c->stream));
+  c->n_states = 0;
   c->have_env = false;
   return qmps_get_energies(c, B, E_out, iters_out, status_out);
 }

@@ -152,6 +152,9 @@ hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, vo
 // the same for rotosolve shift batches: B = nsh R evaluations, evaluation nsh r + k = row r with shift k on parameter *i_ptr
 hipError_t launch_ansatz_shifted(int D, int kind, const double* params, int n_params, void* A, int64_t B, int nsh, const int* i_ptr,
                                  hipStream_t st);
+// SU(N) parameters [B][stride_params] (the first N^2 - 1 of each row) -> unitaries U[B][N][N] (out_tensor = 0) or state tensors
+// A[B][2][N/2][N/2] (out_tensor = 1), N in {4, 8, 16, 32}: qmps_su.hip
+hipError_t launch_su_exp(int N, const double* params, int64_t B, int stride_params, void* out, int out_tensor, hipStream_t st);
 // central-difference batches: 2 n_params evaluations per row, evaluation 2 P r + k = row r with +h (k < P) / -h (k >= P) on parameter k mod P
 hipError_t launch_ansatz_fd(int D, int kind, const double* params, int n_params, void* A, int64_t rows, double h, hipStream_t st);
 // time-evolution overlap (D = 2): dominant eigenvalue of the mixed two-site transfer map

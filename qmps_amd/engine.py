@@ -258,6 +258,50 @@ class EnergyEngine:
         self._h_resident = h.copy()
         return E, it, st
 
+    def energies_from_su(self, params, h, max_iter=10000, tol=1e-13):
+        """SU(2D) parameters (B, (2D)^2 - 1) -> (E (B, n_terms), iters, status): matrix exponential, unitary_to_tensor,
+        environment and energies on the device, one round trip (NonSparseFullEnergyOptimizer's call shape)."""
+        P = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
+        if P.shape[1] != (2 * self.D) ** 2 - 1:
+            raise ValueError(f'SU({2 * self.D}) takes {(2 * self.D) ** 2 - 1} parameters, got {P.shape[1]}')
+        h = np.ascontiguousarray(np.asarray(h, dtype=np.complex128).reshape(-1, 4, 4))
+        B, nt = P.shape[0], h.shape[0]
+        E = np.empty((B, nt))
+        it = np.empty(B, dtype=np.int32)
+        st = np.empty(B, dtype=np.int32)
+        self._h_resident = None
+        L.check(self._lib.qmps_energy_batch_su(self._ctx, B, _f64(P), _f64(h.view(np.float64)), nt, int(max_iter), float(tol),
+                                               _f64(E), _i32(it), _i32(st)))
+        self.B, self.n_terms = B, nt
+        self._h_resident = h.copy()
+        return E, it, st
+
+    def su_unitaries(self, params, N):
+        """SU(N) parameters (B, N^2 - 1) -> unitaries (B, N, N) built on the device (N in 4, 8, 16, 32)."""
+        P = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
+        if P.shape[1] != N * N - 1:
+            raise ValueError(f'SU({N}) takes {N * N - 1} parameters, got {P.shape[1]}')
+        U = np.empty((P.shape[0], N, N), dtype=np.complex128)
+        L.check(self._lib.qmps_su_unitaries(self._ctx, P.shape[0], int(N), _f64(P), _f64(U.view(np.float64))))
+        return U
+
+    def cell2_energies_su(self, params, h, max_iter=10000, tol=1e-13):
+        """Two-site unit cell from the optimiser's 30 parameters per row: U1 = U4(p[:15]), U2 = U4(p[15:]) on the device."""
+        P = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
+        if P.shape[1] != 30:
+            raise ValueError('the two-site unit cell takes 30 parameters')
+        h = np.ascontiguousarray(np.asarray(h, dtype=np.complex128).reshape(-1, 4, 4))
+        B, nt = P.shape[0], h.shape[0]
+        E = np.empty((B, nt))
+        it = np.empty(B, dtype=np.int32)
+        st = np.empty(B, dtype=np.int32)
+        self._h_resident = None
+        L.check(self._lib.qmps_cell2_energy_batch_su(self._ctx, B, _f64(P), _f64(h.view(np.float64)), nt, int(max_iter), float(tol),
+                                                     _f64(E), _i32(it), _i32(st)))
+        self.n_terms = nt
+        self._h_resident = h.copy()
+        return E, it, st
+
     def env_batch(self, states, kind='tensor', r0=None, max_iter=10000, tol=1e-13):
         tail = (2, self.D, self.D) if kind == 'tensor' else (2 * self.D, 2 * self.D)
         states = _c128(states, tail, 'states')

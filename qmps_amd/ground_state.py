@@ -267,9 +267,12 @@ class NonSparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
         return float(E[0])
 
     def batch_objective_function(self, params_batch):
-        U = np.stack([SU(p, 2 * self.D) for p in np.atleast_2d(params_batch)])
-        E, _, st = self._energies_from_unitaries(U)
-        return np.where(st == STATUS_OK, E, np.nan)
+        """B parameter vectors -> energies; the unitaries SU(p, 2D) are built ON THE DEVICE (qmps_set_states_su: scaling and
+        squaring, one workgroup per evaluation) - no host matrix exponential per row, 8 ((2D)^2 - 1) bytes per evaluation over PCIe."""
+        P = np.ascontiguousarray(np.atleast_2d(params_batch), dtype=np.float64)
+        eng = _runtime.engine(self.D, P.shape[0])
+        E, _, st = eng.energies_from_su(P, _as_h(self.H), max_iter=self.max_iter, tol=self.env_tol)
+        return np.where(st == STATUS_OK, E[:, 0], np.nan)
 
     def update_state(self):
         self.U = SU(self.optimized_result.x, 2 * self.D)
@@ -298,11 +301,11 @@ class NonSparseFullTwoSiteEnergyOptimizer(Optimizer):
         return float(E[0])
 
     def batch_objective_function(self, params_batch):
-        P = np.atleast_2d(params_batch)
-        U1 = np.stack([SU(p[:15], 4) for p in P])
-        U2 = np.stack([SU(p[15:], 4) for p in P])
-        E, _, st = self._cell(U1, U2)
-        return np.where(st == STATUS_OK, E, np.nan)
+        """U1 = U4(p[:15]), U2 = U4(p[15:]) for every row ON THE DEVICE (qmps_cell2_energy_batch_su)."""
+        P = np.ascontiguousarray(np.atleast_2d(params_batch), dtype=np.float64)
+        eng = _runtime.engine(2, P.shape[0])
+        E, _, st = eng.cell2_energies_su(P, _as_h(self.H))
+        return np.where(st == STATUS_OK, E[:, 0], np.nan)
 
     def update_state(self):
         self.u1 = SU(self.optimized_result.x[:15], 4)

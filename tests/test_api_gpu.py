@@ -380,3 +380,47 @@ def test_default_optimisers_with_batched_evaluations(D, key, golden):
         a, b = out[method, True], out[method, False]
         assert abs(a.fun - b.fun) < 1e-8, (method, a.fun, b.fun)
         assert a.fun <= nm_b.fun + 1e-6                           # at least as low as the simplex result from the same start
+
+
+@pytest.mark.parametrize('N', [4, 8, 16, 32])
+def test_su_unitaries_on_the_device_vs_expm(N, engine_factory):
+    """qmps_su_unitaries: exp(-i/2 sum_k p_k G_k) by scaling and squaring on the device against scipy.linalg.expm of the host
+    mirror's generator (qmps_amd.ground_state.SU; the convention is documentation-pinned: xmps.spin is not in the reference tree)."""
+    rng = np.random.default_rng(500 + N)
+    eng = engine_factory(2, 4096)
+    # optimiser-sized parameters (randn, ground_state.py:245) and large ones (many squarings), plus the zero vector
+    P = np.concatenate([rng.standard_normal((9, N * N - 1)), 6.0 * rng.standard_normal((3, N * N - 1)), np.zeros((1, N * N - 1))])
+    U = eng.su_unitaries(P, N)
+    for p, u in zip(P, U):
+        ref = G.SU(p, N)
+        assert np.abs(u - ref).max() < 1e-12, np.abs(u - ref).max()
+        assert np.abs(u.conj().T @ u - np.eye(N)).max() < 1e-12
+    assert np.abs(U[-1] - np.eye(N)).max() == 0.0
+
+
+@pytest.mark.parametrize('D', [2, 4, 8, 16])
+def test_full_su_optimiser_batches_build_their_unitaries_on_the_device(D):
+    """NonSparseFullEnergyOptimizer (ground_state.py:230-269, scripts/bond_dimension.py:21-50): the batched objective goes from
+    (2D)^2 - 1 parameters to energies on the device; same values as the scalar objective (host SU + expm, then the device) and as
+    the oracle's closed form on the host-built unitary."""
+    rng = np.random.default_rng(600 + D)
+    h = O.hamiltonian_matrix({'XX': 1, 'YY': 1})               # scripts/bond_dimension.py:18 uses the XY model
+    opt = G.NonSparseFullEnergyOptimizer(h, D, initial_guess=rng.standard_normal((2 * D) ** 2 - 1))
+    P = rng.standard_normal((7, (2 * D) ** 2 - 1))
+    Eb = opt.batch_objective_function(P)
+    for p, e in zip(P, Eb):
+        U = G.SU(p, 2 * D)
+        assert abs(e - O.energy_closed_form(O.unitary_to_tensor(U), h)) < 1e-10
+        assert abs(e - opt.objective_function(p)) < 1e-10
+
+
+def test_two_site_cell_batches_build_u4_on_the_device(golden):
+    """NonSparseFullTwoSiteEnergyOptimizer (ground_state.py:271-335): U1 = U4(p[:15]), U2 = U4(p[15:]) on the device."""
+    rng = np.random.default_rng(77)
+    h = golden['ref_h_tfim']
+    opt = G.NonSparseFullTwoSiteEnergyOptimizer(h, initial_guess=rng.standard_normal(30))
+    P = rng.standard_normal((9, 30))
+    Eb = opt.batch_objective_function(P)
+    for p, e in zip(P, Eb):
+        assert abs(e - opt.objective_function(p)) < 1e-10
+        assert abs(e - O.two_site_cell_energy(G.SU(p[:15], 4), G.SU(p[15:], 4), h)) < 1e-10

@@ -208,6 +208,30 @@ __device__ __forceinline__ void cmma16(const double (&pre)[4], const double (&pi
   }
 }
 
+// The same product with THREE real products per k-slab instead of four (K1 = (Pr + Pi) Qr, K2 = Pr (Qi - Qr), K3 = Pi (Qr + Qi);
+// Re = K1 - K3, Im = K1 + K2): 12 v_mfma_f64_16x16x4 per complex 16 x 16 x 16 product instead of 16, in three independent
+// accumulator chains of four.  The matrix pipe is what bounds the power iteration (a v_mfma_f64_16x16x4 occupies it for ~100
+// cycles on this part, profiles/EXPERIMENTS.md), the handful of extra additions run on the vector pipe beside it.  Rounding:
+// norm-wise the same bound as the four-product form (|error| <= c eps |P| |Q|).
+__device__ __forceinline__ void cmma16_3m(const double (&pre)[4], const double (&pim)[4], const v4f64& qre, const v4f64& qim,
+                                          v4f64& cre, v4f64& cim) {
+  v4f64 k1 = {0, 0, 0, 0}, k2 = {0, 0, 0, 0}, k3 = {0, 0, 0, 0};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const double ps = pre[kk] + pim[kk], qd = qim[kk] - qre[kk], qs = qre[kk] + qim[kk];
+    k1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ps, qre[kk], k1, 0, 0, 0);
+    k2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pre[kk], qd, k2, 0, 0, 0);
+    k3 = __builtin_amdgcn_mfma_f64_16x16x4f64(pim[kk], qs, k3, 0, 0, 0);
+  }
+  cre += k1 - k3;
+  cim += k1 + k2;
+}
+
+// The power iterations below test convergence on every SECOND step only (and on the last one): the three wave-wide sums and the
+// residual pass of a test are a third of a step's latency once the products take 24 instead of 32 matrix instructions; between
+// tests the iterate is not normalised (it shrinks by |eta| ~ 0.5 .. 1 per step).  `rounds` counts every step.
+__device__ __forceinline__ bool overlap_check_step(int k, int max_rounds) { return (k & 1) == 0 || k == max_rounds; }
+
 }  // namespace
 
 template <bool ADJ>
@@ -336,10 +360,16 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
         v4f64 yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
         const v4f64 qre = {bre[s][0], bre[s][1], bre[s][2], bre[s][3]};
         const v4f64 qim = {bimn[s][0], bimn[s][1], bimn[s][2], bimn[s][3]};
-        cmma16(xar, xai, qre, qim, yr, yi);           // Y_s = x Bm_s^+
-        cmma16(cre[s], cim[s], yr, yi, nr, ni);       // x' += C_s Y_s
+        cmma16_3m(xar, xai, qre, qim, yr, yi);           // Y_s = x Bm_s^+
+        cmma16_3m(cre[s], cim[s], yr, yi, nr, ni);       // x' += C_s Y_s
       }
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      iters = k;
+      if (!overlap_check_step(k, p.max_rounds)) {        // no test on this step: carry the (unnormalised) iterate on
+        xr = nr;
+        xi = ni;
+        continue;
+      }
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         a0 = dfma(xr[q], nr[q], a0);
@@ -348,9 +378,12 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
         a1 = dfma(-xi[q], nr[q], a1);
         a2 = dfma(nr[q], nr[q], a2);
         a2 = dfma(ni[q], ni[q], a2);
+        a3 = dfma(xr[q], xr[q], a3);
+        a3 = dfma(xi[q], xi[q], a3);
       }
-      eta_r = wave_sum(a0);
-      eta_i = wave_sum(a1);
+      const double xx = wave_sum(a3), ixx = xx > 0.0 ? 1.0 / xx : 0.0;
+      eta_r = wave_sum(a0) * ixx;                        // eta = <x, T x> / <x, x>
+      eta_i = wave_sum(a1) * ixx;
       const double nn = wave_sum(a2);
       double rs = 0.0;
 #pragma unroll
@@ -359,10 +392,12 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
         rs = dfma(dr, dr, rs);
         rs = dfma(di, di, rs);
       }
-      const double res2 = lane0(wave_sum(rs));
-      iters = k;
+      const double res2 = lane0(wave_sum(rs)) * ixx;     // ||T x - eta x||^2 / ||x||^2
       if (res2 < tol2) {
         status = QMPS_ST_OK;
+        const double inv = xx > 0.0 ? 1.0 / __builtin_sqrt(xx) : 0.0;      // the fixed point handed out has unit norm
+        xr *= inv;
+        xi *= inv;
         break;
       }
       const double inv = nn > 0.0 ? 1.0 / __builtin_sqrt(nn) : 0.0;
@@ -683,20 +718,31 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
       v4f64 yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0}, pr = {0, 0, 0, 0}, pi = {0, 0, 0, 0};
       const v4f64 qre = {bre[0], bre[1], bre[2], bre[3]};
       const v4f64 qim = {bimn[0], bimn[1], bimn[2], bimn[3]};
-      cmma16(xar, xai, qre, qim, yr, yi);           // Y_w = x Bm_w^+
-      cmma16(cre, cim, yr, yi, pr, pi);             // C_w Y_w
-      publish(pr, pi);
+      cmma16_3m(xar, xai, qre, qim, yr, yi);           // Y_w = x Bm_w^+
+      cmma16_3m(cre, cim, yr, yi, pr, pi);             // C_w Y_w
+      // the four partial maps are exchanged through one of TWO sets of buffers, alternately: a wave may publish step k + 1
+      // while another still reads step k, so a step needs ONE workgroup barrier (a set is reused two barriers later)
+      double2 (*sXk)[16 * 16] = sX_all + 4 * (k & 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sXk[wave][q * 64 + lane] = make_double2(pr[q], pi[q]);
       __syncthreads();
       v4f64 nr = {0, 0, 0, 0}, ni = {0, 0, 0, 0};
 #pragma unroll
       for (int w = 0; w < 4; ++w) {                 // the same order in every wave: bit-identical sums
-        v4f64 ar, ai;
-        fetch(w, ar, ai);
-        nr += ar;
-        ni += ai;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double2 t = sXk[w][q * 64 + lane];
+          nr[q] += t.x;
+          ni[q] += t.y;
+        }
       }
-      __syncthreads();
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      iters = k;
+      if (!overlap_check_step(k, p.max_rounds)) {   // no test on this step (see overlap_check_step)
+        xr = nr;
+        xi = ni;
+        continue;
+      }
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         a0 = dfma(xr[q], nr[q], a0);
@@ -705,9 +751,12 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
         a1 = dfma(-xi[q], nr[q], a1);
         a2 = dfma(nr[q], nr[q], a2);
         a2 = dfma(ni[q], ni[q], a2);
+        a3 = dfma(xr[q], xr[q], a3);
+        a3 = dfma(xi[q], xi[q], a3);
       }
-      eta_r = wave_sum(a0);
-      eta_i = wave_sum(a1);
+      const double xx = wave_sum(a3), ixx = xx > 0.0 ? 1.0 / xx : 0.0;
+      eta_r = wave_sum(a0) * ixx;
+      eta_i = wave_sum(a1) * ixx;
       const double nn = wave_sum(a2);
       double rs = 0.0;
 #pragma unroll
@@ -716,10 +765,12 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
         rs = dfma(dr, dr, rs);
         rs = dfma(di, di, rs);
       }
-      const double res2 = lane0(wave_sum(rs));
-      iters = k;
+      const double res2 = lane0(wave_sum(rs)) * ixx;
       if (res2 < tol2) {
         status = QMPS_ST_OK;
+        const double inv = xx > 0.0 ? 1.0 / __builtin_sqrt(xx) : 0.0;
+        xr *= inv;
+        xi *= inv;
         break;
       }
       const double inv = nn > 0.0 ? 1.0 / __builtin_sqrt(nn) : 0.0;
@@ -741,7 +792,7 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
 template <bool ADJ>
 __global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) {
   __shared__ double2 sT_all[4][16 * 17];          // wave-private transposes
-  __shared__ double2 sX_all[4][16 * 16];          // exchange: one C-layout matrix per wave, element (q, lane) at [q * 64 + lane]
+  __shared__ double2 sX_all[8][16 * 16];          // exchange: two sets of one C-layout matrix per wave, element (q, lane) at [q * 64 + lane]
   overlap_mfma_d16x4_body<ADJ>(p, blockIdx.x, gridDim.x, sT_all, sX_all);
 }
 
@@ -749,7 +800,7 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) 
 // adjoint map of `pl` - twice the waves in flight for the same length of the (latency-bound) iteration chain
 __global__ __launch_bounds__(256) void overlap_mfma_d16x4_pair_kernel(OverlapArgs pr, OverlapArgs pl, int n_right) {
   __shared__ double2 sT_all[4][16 * 17];
-  __shared__ double2 sX_all[4][16 * 16];
+  __shared__ double2 sX_all[8][16 * 16];
   if ((int)blockIdx.x < n_right) overlap_mfma_d16x4_body<false>(pr, blockIdx.x, n_right, sT_all, sX_all);
   else overlap_mfma_d16x4_body<true>(pl, blockIdx.x - n_right, gridDim.x - n_right, sT_all, sX_all);
 }

@@ -3,7 +3,8 @@
 under profiles/: <tag>_kernel_stats.csv, <tag>_timed_region.json, <tag>_pmc.json and the traffic.json table bench.py
 reads (whole-step HBM bytes = sum over the kernels of one step of FETCH_SIZE x 2 + WRITE_SIZE).
 
-usage: tools/collect_profiles.py <tag> <D> <B> <solver> <store_env 0|1> <rotate>"""
+usage: tools/collect_profiles.py <tag> <D> <B> <solver> <store_env 0|1> <rotate> [bytes per evaluation]
+(solver 'overlap': the time-evolution overlap workload, algorithmic bytes 32 D^2 + 16 per candidate)"""
 import collections
 import csv
 import glob
@@ -38,7 +39,7 @@ if trace:
             last = [d for _, d in v[-steps:]]
             timed[k] = {'launches_total': len(v), 'timed_region_launches': len(last),
                         'timed_region_average_ns': sum(last) / len(last), 'all_launch_average_ns': sum(d for _, d in v) / len(v)}
-    json.dump({'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extras', 'steps': steps,
+    json.dump({'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extras ' + os.environ.get('BENCH_EXTRA', ''), 'steps': steps,
                'bench_line_of_the_traced_run': bench_line, 'kernels': timed},
               open(os.path.join(ROOT, 'profiles', f'{tag}_timed_region.json'), 'w'), indent=1)
     print(json.dumps(timed, indent=1))
@@ -66,7 +67,8 @@ tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
 table = json.load(open(tpath)) if os.path.exists(tpath) else {}
 if detail:
     dom = max(detail, key=lambda k: detail[k]['bytes'])
-    alg = B * (32 * D * D + 8)
+    per_eval = int(sys.argv[7]) if len(sys.argv) > 7 else (32 * D * D + (16 if solver == 'overlap' else 8))
+    alg = B * per_eval
     table[f'D={D}|B={B}|solver={solver}|store_env={store_env}|rotate={rotate}'] = {
         'bytes': detail[dom]['bytes'], 'unit': 'B per launch of the dominant kernel', 'kernel': dom,
         'step_bytes': step_bytes, 'algorithmic_bytes': alg, 'dominant_over_algorithmic': detail[dom]['bytes'] / alg,

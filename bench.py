@@ -101,7 +101,11 @@ def committed_traffic(D, B, solver, store_env, rotate):
         table = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
     except Exception:
         return None
-    return table.get(f'D={D}|B={B}|solver={solver}|store_env={int(store_env)}|rotate={rotate}')
+    for name in ((solver, 'squaring') if D == 16 else (solver,)):       # (D = 16 has no direct solve: 'direct' runs the iterative kernel)
+        hit = table.get(f'D={D}|B={B}|solver={name}|store_env={int(store_env)}|rotate={rotate}')
+        if hit is not None:
+            return hit
+    return None
 
 
 # ---- CPU baselines (run BEFORE the GPU is initialised: the process-parallel leg forks) ------------------------

@@ -1526,7 +1526,9 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
     HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream));
   } else {
     HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : documented_switch("QMPS_D16_BLOCK") == nullptr, c->stream));
-    HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr, c->stream));
+    // (D = 4: the squaring kernel again - the left fixed point is the largest row of the squared map, whatever the spectral gap)
+    if (c->D == 4 && squaring) l.max_rounds = a.max_rounds;
+    HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 4 ? squaring : (c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr), c->stream));
   }
   // the 2 P central-difference neighbours of every iterate, evaluated to second order in h from (y, r)
   HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->stream));

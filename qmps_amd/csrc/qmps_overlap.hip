@@ -552,7 +552,38 @@ __global__ __launch_bounds__(256) void overlap_square_d4_kernel(OverlapArgs p) {
       status = QMPS_ST_NOT_CONVERGED;
     }
     if (lane == 0) overlap_store(p, b, eta_r, eta_i, rounds, status);
-    if (p.r_out != nullptr) {
+    if (p.r_out != nullptr && p.adjoint) {
+      // LEFT fixed point (T^+ y = conj(eta) y): M -> u v^+, so every row of M is a multiple of v^+; y = conj of the largest row
+      double rn[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rn[q] = row16_sum(dfma(mr[q], mr[q], mi[q] * mi[q]));      // |row 4 q + g|^2, in the 16 lanes of row group g
+      __builtin_amdgcn_wave_barrier();
+      if (c == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sT[4 * q + g] = make_double2(rn[q], 0.0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      int best = 0;
+      double bn = -1.0;
+      for (int k = 0; k < 16; ++k) {
+        const double v = sT[k].x;
+        if (v > bn) { bn = v; best = k; }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (g == (best & 3)) {
+        double vr = 0.0, vi = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q == (best >> 2)) { vr = mr[q]; vi = mi[q]; }
+        sT[16 + c] = make_double2(vr, -vi);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const double inv = bn > 0.0 ? 1.0 / __builtin_sqrt(bn) : 0.0;
+      if (lane < 16) {
+        const double2 u = sT[16 + lane];
+        ((double2*)((char*)p.r_out + overlap_slot_offset(p)))[b * 16 + lane] = make_double2(u.x * inv, u.y * inv);
+      }
+    } else if (p.r_out != nullptr) {
       // right fixed point = the largest column of M, unit Frobenius norm
       double cn = 0.0;
 #pragma unroll
@@ -814,7 +845,7 @@ hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& 
 
 hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
-  if (a.adjoint && D == 4) {      // the squaring kernel returns right vectors only: left fixed points come from the power method
+  if (a.adjoint && D == 4 && !mfma) {      // (the squaring kernel hands out left fixed points itself: the largest row of the squared map)
     hipLaunchKernelGGL((overlap_block_kernel<4, true>), dim3((unsigned)((a.B + 3) / 4)), dim3(64), 0, st, a);
     return hipGetLastError();
   }

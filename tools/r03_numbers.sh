@@ -1,0 +1,38 @@
+#!/bin/bash
+# usage (GPU box): bash tools/r03_numbers.sh <tag>   -> gpurun_out/<tag>_*.json : the bench lines the round's DESIGN.md quotes
+tag=${1:-r03e}
+R=$GRAFT_REPO_ROOT
+o=$R/gpurun_out
+run() { n=$1; shift; timeout 600 python $R/bench.py "$@" > $o/${tag}_$n.json 2> $o/${tag}_$n.err || echo "FAILED $n"; }
+run headline
+run d8_b768 --D 8 --batch 768 --steps 400 --warmup 100
+run d8_b96 --D 8 --batch 96 --steps 400 --warmup 100 --no-cpu-baseline
+run d16_b768 --D 16 --batch 768 --steps 100 --warmup 20 --no-cpu-baseline
+run d16_b96 --D 16 --batch 96 --steps 100 --warmup 20 --no-cpu-baseline
+run d2_b4096 --D 2 --batch 4096 --steps 400 --warmup 100 --no-cpu-baseline
+run roto_d2 --workload rotosolve --D 2 --batch 4096
+run roto_d4 --workload rotosolve --D 4 --batch 65535 --steps 40 --warmup 4
+run roto2_d4 --workload rotosolve --D 4 --batch 65535 --steps 40 --warmup 4 --double-frequency --no-cpu-baseline
+run roto_d8 --workload rotosolve --D 8 --batch 768
+run roto2_d8 --workload rotosolve --D 8 --batch 768 --double-frequency --no-cpu-baseline
+run overlap_d16_b768 --workload overlap --D 16 --batch 768 --steps 20 --warmup 3
+run overlap_d16_b96 --workload overlap --D 16 --batch 96 --steps 20 --warmup 3 --no-cpu-baseline
+run overlap_d8_b768 --workload overlap --D 8 --batch 768 --steps 20 --warmup 3 --no-cpu-baseline
+run overlap_d4_b65536 --workload overlap --D 4 --batch 65536 --steps 10 --warmup 2 --no-cpu-baseline
+run evolve_d16_t256 --workload evolve --D 16 --batch 256 --steps 8 --warmup 2
+run evolve_d16_t1024 --workload evolve --D 16 --batch 1024 --steps 6 --warmup 2 --no-cpu-baseline
+run evolve_d16_t256_fd --workload evolve --D 16 --batch 256 --steps 6 --warmup 2 --gradient fd --no-cpu-baseline
+run evolve_d8_t256 --workload evolve --D 8 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline
+run evolve_d4_t256 --workload evolve --D 4 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline
+run evolve_d2_t256 --workload evolve --D 2 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_${tag}_evolve -- python3 $R/bench.py --workload evolve --D 16 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline > $o/${tag}_evolve_trace.log 2>&1
+for f in $(find $o/prof_${tag}_evolve -name "*kernel_stats.csv"); do cp $f $o/${tag}_evolve_kernel_stats.csv; done
+python3 - <<PY
+import json,glob,os
+for f in sorted(glob.glob("$o/${tag}_*.json")):
+    try:
+        d=json.load(open(f)); r=d.get("roofline") or {}
+        print(os.path.basename(f), "value=%.4g"%d["value"], d["unit"], "ms/step=%.4g"%d["ms_per_step"], "frac=%s"%r.get("frac"), "hbm=%s"%r.get("hbm_frac"))
+    except Exception as e: print(os.path.basename(f), "ERR", e)
+PY

@@ -1315,13 +1315,20 @@ struct C4 {   // a complex matrix in C-layout: 4 registers re, 4 registers im
 // C += P * Q with P given in A-layout (pa_re/pa_im[kk]) and Q in B-layout (C-layout registers)
 __device__ __forceinline__ void cmma(const double (&pre)[4], const double (&pim)[4], const double (&pimn)[4],
                                      const v4f64& qre, const v4f64& qim, v4f64& cre, v4f64& cim) {
+  // Three real products per k-slab instead of four (round 3, as in qmps_overlap.hip: K1 = (Pr + Pi) Qr, K2 = Pr (Qi - Qr),
+  // K3 = Pi (Qr + Qi); Re = K1 - K3, Im = K1 + K2): 12 v_mfma_f64_16x16x4 per complex product instead of 16, in three
+  // independent accumulator chains - the matrix pipe (~100 cycles per instruction on this part) bounds these kernels.
+  (void)pimn;
+  v4f64 k1 = {0, 0, 0, 0}, k2 = {0, 0, 0, 0}, k3 = {0, 0, 0, 0};
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    cre = __builtin_amdgcn_mfma_f64_16x16x4f64(pre[kk], qre[kk], cre, 0, 0, 0);
-    cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pre[kk], qim[kk], cim, 0, 0, 0);
-    cre = __builtin_amdgcn_mfma_f64_16x16x4f64(pimn[kk], qim[kk], cre, 0, 0, 0);   // - P_im Q_im
-    cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pim[kk], qre[kk], cim, 0, 0, 0);
+    const double ps = pre[kk] + pim[kk], qd = qim[kk] - qre[kk], qs = qre[kk] + qim[kk];
+    k1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ps, qre[kk], k1, 0, 0, 0);
+    k2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pre[kk], qd, k2, 0, 0, 0);
+    k3 = __builtin_amdgcn_mfma_f64_16x16x4f64(pim[kk], qs, k3, 0, 0, 0);
   }
+  cre += k1 - k3;
+  cim += k1 + k2;
 }
 
 

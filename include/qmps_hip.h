@@ -156,7 +156,8 @@ int qmps_set_states(qmps_ctx* ctx, int64_t B, const double* states, int kind);
 /* Ansatz parameters -> state tensors ON THE DEVICE (replaces gate construction + cirq.unitary,
  * qmps/ground_state.py:151-154, and unitary_to_tensor): params[B][n_params] float64.
  * Gate lists: qmps/represent.py:288-310 (ShallowCNOT, the optimisers' default), :268-285 (QAOA),
- * :382-404 (ShallowFull, D = 2, 15 angles), :334-354 (ShallowCNOT3).
+ * :382-404 (ShallowFull, D = 2, 15 angles), :334-354 (ShallowCNOT3), :312-332 (_nonuniform), :356-380 (ExactAfter4),
+ * :406-423 (StateGate, D = 2).
  * The parameters stay resident.  At D = 4 (ShallowCNOT, QAOA, ShallowCNOT3) nothing else happens in this call: a
  * following qmps_energy_launch with QMPS_ENV_DIRECT builds each tensor in LDS in front of the solve (lane q of the
  * evaluation's quad simulates column q of the circuit) - 8 n_params bytes per evaluation from HBM instead of 512, no
@@ -166,6 +167,9 @@ int qmps_set_states(qmps_ctx* ctx, int64_t B, const double* states, int kind);
 #define QMPS_ANSATZ_SHALLOW_QAOA 1
 #define QMPS_ANSATZ_SHALLOW_FULL 2
 #define QMPS_ANSATZ_SHALLOW_CNOT3 3
+#define QMPS_ANSATZ_SHALLOW_CNOT_NONUNIFORM 4 /* represent.py:312-332: 2 (log2 D + 1) angles per layer, one rz and one rx angle per qubit */
+#define QMPS_ANSATZ_EXACT_AFTER4 5            /* represent.py:356-380: six angles per layer on qubits 0, 1, CNOT ladder, cyclic SWAPs */
+#define QMPS_ANSATZ_STATE_GATE 6              /* represent.py:406-423: rx, rx, rz, rz, XX**e, YY**f on two qubits (D = 2) */
 int qmps_set_states_ansatz(qmps_ctx* ctx, int64_t B, int kind, int n_params, const double* params);
 /* SU(2D) parameters -> state tensors ON THE DEVICE: params[B][(2D)^2 - 1], U = exp(-i/2 sum_k p_k G_k) with G_k the generalised
  * Gell-Mann matrices (order: for a < b the symmetric then the antisymmetric one, rows first; then the 2D - 1 diagonal ones) -

@@ -166,6 +166,50 @@ def shallow_cnot3_unitary(D, params):
     return circuit_unitary(n, ops)
 
 
+def shallow_cnot_nonuniform_unitary(D, params):
+    """ShallowCNOTStateTensor_nonuniform (represent.py:312-332): per layer 2 n angles (n = log2 D + 1 qubits): rz(p[i]) on
+    qubit i, rx(p[i + n]) on qubit i, CNOT(q[n-2], q[n-1]) ... CNOT(q0, q1) (reversed list); no Hadamard."""
+    n = int(np.log2(D)) + 1
+    ops = []
+    params = np.asarray(params, dtype=float)
+    for l in range(0, len(params) - 2 * n + 1, 2 * n):
+        p = params[l:l + 2 * n]
+        ops += [(rz(p[i]), [i]) for i in range(n)]
+        ops += [(rx(p[i + n]), [i]) for i in range(n)]
+        ops += [(CNOT, [i, i + 1]) for i in reversed(range(n - 1))]
+    return circuit_unitary(n, ops)
+
+
+def exact_after4_unitary(D, params):
+    """ExactAfter4 (represent.py:356-380): per (a, b, c, d, e, f): rz(a) q0, rz(d) q1, rx(b) q0, rx(e) q1, rz(c) q0, rz(f) q1,
+    the reversed CNOT ladder, then SWAP(q[i], q[i+1 if i != n-1 else 0]) for i = 0 .. n-1."""
+    n = int(np.log2(D)) + 1
+    ops = []
+    params = np.asarray(params, dtype=float)
+    for l in range(0, len(params) - 5, 6):
+        a, b, c, d, e, f = params[l:l + 6]
+        ops += [(rz(a), [0]), (rz(d), [1]), (rx(b), [0]), (rx(e), [1]), (rz(c), [0]), (rz(f), [1])]
+        ops += [(CNOT, [i, i + 1]) for i in reversed(range(n - 1))]
+        ops += [(SWAP, [i, i + 1 if i != n - 1 else 0]) for i in range(n)]
+    return circuit_unitary(n, ops)
+
+
+def _pauli_pair_power(P, t):
+    """cirq.XX**t / cirq.YY**t: eigenvalue 1 on the +1 eigenspace of P x P, e^{i pi t} on the -1 eigenspace."""
+    PP = np.kron(P, P)
+    e = np.exp(1j * np.pi * t)
+    return 0.5 * (1 + e) * np.eye(4) + 0.5 * (1 - e) * PP
+
+
+def state_gate_unitary(params):
+    """StateGate (represent.py:406-423): rx(a) q0, rx(b) q1, rz(c) q0, rz(d) q1, XX**e, YY**f on two qubits."""
+    a, b, c, d, e, f = np.asarray(params, dtype=float)[:6]
+    X = np.array([[0, 1], [1, 0]], dtype=complex)
+    Y = np.array([[0, -1j], [1j, 0]], dtype=complex)
+    ops = [(rx(a), [0]), (rx(b), [1]), (rz(c), [0]), (rz(d), [1]), (_pauli_pair_power(X, e), [0, 1]), (_pauli_pair_power(Y, f), [0, 1])]
+    return circuit_unitary(2, ops)
+
+
 def shallow_full_unitary(v):
     """ShallowFullStateTensor(2, v[15]) - the 18-gate list at represent.py:393-401."""
     v = list(v)

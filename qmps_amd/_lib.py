@@ -17,6 +17,7 @@ STATUS_OK, STATUS_NOT_CONVERGED, STATUS_NOT_PD = 0, 1, 2
 INPUT_TENSOR, INPUT_UNITARY = 0, 1
 INPUT_ANSATZ_BASE = 16
 ANSATZ_SHALLOW_CNOT, ANSATZ_SHALLOW_QAOA, ANSATZ_SHALLOW_FULL, ANSATZ_SHALLOW_CNOT3 = 0, 1, 2, 3
+ANSATZ_SHALLOW_CNOT_NONUNIFORM, ANSATZ_EXACT_AFTER4, ANSATZ_STATE_GATE = 4, 5, 6
 ENV_POWER = 0
 ENV_POWER_SQUARING = 1
 ENV_DIRECT = 2

@@ -258,9 +258,17 @@ int ensure_pinned(qmps_ctx* c, size_t bytes) {
 // (kind, n_params) of an ansatz the device builders know (qmps/represent.py:268-404)
 int check_ansatz(const qmps_ctx* c, int kind, int n_params) {
   if (n_params < 1 || n_params > 4096) return fail(QMPS_ERR_ARG, "n_params=%d outside [1,4096]", n_params);
-  if (kind < 0 || kind > 3) return fail(QMPS_ERR_ARG, "unknown ansatz kind %d", kind);
+  if (kind < 0 || kind > 6) return fail(QMPS_ERR_ARG, "unknown ansatz kind %d", kind);
   if (kind == QMPS_ANSATZ_SHALLOW_FULL && (c->D != 2 || n_params != 15))
     return fail(QMPS_ERR_ARG, "ShallowFullStateTensor is a two-qubit gate: D = 2, 15 parameters");
+  if (kind == QMPS_ANSATZ_STATE_GATE && (c->D != 2 || n_params < 6))
+    return fail(QMPS_ERR_ARG, "StateGate is a two-qubit gate: D = 2, 6 parameters");
+  if (kind == QMPS_ANSATZ_EXACT_AFTER4 && n_params % 6) return fail(QMPS_ERR_ARG, "ExactAfter4 takes six angles per layer");
+  if (kind == QMPS_ANSATZ_SHALLOW_CNOT_NONUNIFORM) {
+    int nq = 1;
+    while ((1 << (nq - 1)) < c->D) ++nq;      // n + 1 qubits
+    if (n_params % (2 * nq)) return fail(QMPS_ERR_ARG, "ShallowCNOTStateTensor_nonuniform takes %d angles per layer at D = %d", 2 * nq, c->D);
+  }
   if ((kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_QAOA) && n_params % 2)
     return fail(QMPS_ERR_ARG, "this ansatz takes (beta, gamma) pairs");
   if (kind == QMPS_ANSATZ_SHALLOW_CNOT3 && n_params % 3) return fail(QMPS_ERR_ARG, "this ansatz takes (beta, gamma, omega) triples");
@@ -1688,7 +1696,7 @@ int qmps_overlap_batch(qmps_ctx* c, int64_t B, const double* A, int a_shared, co
   // candidates -> d_A: tensors, unitaries or ansatz parameters
   if (kind == QMPS_INPUT_TENSOR || kind == QMPS_INPUT_UNITARY) {
     if (int rc = qmps_set_states(c, B, states, kind)) return rc;
-  } else if (kind >= QMPS_INPUT_ANSATZ_BASE && kind <= QMPS_INPUT_ANSATZ_BASE + 3) {
+  } else if (kind >= QMPS_INPUT_ANSATZ_BASE && kind <= QMPS_INPUT_ANSATZ_BASE + 6) {
     if (int rc = qmps_set_states_ansatz(c, B, kind - QMPS_INPUT_ANSATZ_BASE, n_params, states)) return rc;
   } else {
     return fail(QMPS_ERR_ARG, "unknown input kind %d", kind);

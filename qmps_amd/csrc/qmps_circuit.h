@@ -211,6 +211,25 @@ struct Reg {
     u2(a, c[9], -s[9], 0, 0, 0, 0, c[9], s[9]); u2(a, c[10], 0, 0, -s[10], 0, -s[10], c[10], 0); u2(a, c[11], -s[11], 0, 0, 0, 0, c[11], s[11]);
     u2(b, c[12], -s[12], 0, 0, 0, 0, c[12], s[12]); u2(b, c[13], 0, 0, -s[13], 0, -s[13], c[13], 0); u2(b, c[14], -s[14], 0, 0, 0, 0, c[14], s[14]);
   }
+  // cirq.XX**t / cirq.YY**t = (1 + e)/2 + (1 - e)/2 PP, e = e^{i pi t}: eigenvalue 1 on PP = +1, e on PP = -1.
+  // XX flips both bits; YY flips both bits with sign -1 when they are equal (Y|0> = i|1>, Y|1> = -i|0>).
+  __device__ __forceinline__ void pppow(int q1, int q2, double t, bool yy) {
+    double sn, cn;
+    sincos(3.141592653589793 * t, &sn, &cn);
+    const double ar = 0.5 * (1.0 + cn), ai = 0.5 * sn, br = 0.5 * (1.0 - cn), bi = -0.5 * sn;
+    const int m1 = mask(q1), m2 = mask(q2);
+#pragma unroll
+    for (int x = 0; x < N; ++x)
+      if (!(x & m1)) {                 // pairs (x, x ^ m1 ^ m2), visited once: the representative has bit q1 = 0
+        const int y = x ^ m1 ^ m2;
+        const double sg = (yy && !(x & m2)) ? -1.0 : 1.0;      // bits of x equal (0, 0) <-> (1, 1): YY gives -1
+        const double pr = re[x], pi = im[x], qr = re[y], qi = im[y];
+        re[x] = ar * pr - ai * pi + sg * (br * qr - bi * qi);
+        im[x] = ar * pi + ai * pr + sg * (br * qi + bi * qr);
+        re[y] = ar * qr - ai * qi + sg * (br * pr - bi * pi);
+        im[y] = ar * qi + ai * qr + sg * (br * pi + bi * pr);
+      }
+  }
   __device__ __forceinline__ void reset() {
 #pragma unroll
     for (int x = 0; x < N; ++x) { re[x] = (x == 0) ? 1.0 : 0.0; im[x] = 0.0; }
@@ -265,6 +284,37 @@ __device__ __forceinline__ void ansatz_circuit(Reg<NQ>& r, Par par, int n_params
 #pragma unroll
       for (int k = 0; k < per; ++k) sincos(ansatz_angle_scale<KIND>(k) * par(l + k), &s[k], &c[k]);
       ansatz_layer_cs<NQ, KIND>(r, c, s);
+    }
+  } else if (KIND == 4) {
+    // ShallowCNOTStateTensor_nonuniform (represent.py:312-332): per layer 2 NQ angles - rz(p[i]) and rx(p[i + NQ]) on qubit i,
+    // CNOT ladder from the bottom (no Hadamard)
+    for (int l = 0; l + 2 * NQ <= n_params; l += 2 * NQ) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) r.rz(q, par(l + q));
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) r.rx(q, par(l + NQ + q));
+#pragma unroll
+      for (int q = NQ - 2; q >= 0; --q) r.cnot(q, q + 1);
+    }
+  } else if (KIND == 5) {
+    // ExactAfter4 (represent.py:356-380): per layer (a, b, c, d, e, f): rz(a) q0, rz(d) q1, rx(b) q0, rx(e) q1, rz(c) q0, rz(f) q1,
+    // CNOT ladder from the bottom, then SWAP(q[i], q[i + 1]) for i = 0 .. NQ - 2 and SWAP(q[NQ - 1], q[0])
+    for (int l = 0; l + 6 <= n_params; l += 6) {
+      r.rz(0, par(l)); r.rz(1, par(l + 3));
+      r.rx(0, par(l + 1)); r.rx(1, par(l + 4));
+      r.rz(0, par(l + 2)); r.rz(1, par(l + 5));
+#pragma unroll
+      for (int q = NQ - 2; q >= 0; --q) r.cnot(q, q + 1);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) r.swapq(q, q + 1 < NQ ? q + 1 : 0);
+    }
+  } else if (KIND == 6) {
+    // StateGate (represent.py:406-423), two qubits: rx(a) q0, rx(b) q1, rz(c) q0, rz(d) q1, XX**e, YY**f
+    if constexpr (NQ == 2) {
+      r.rx(0, par(0)); r.rx(1, par(1));
+      r.rz(0, par(2)); r.rz(1, par(3));
+      r.pppow(0, 1, par(4), false);
+      r.pppow(0, 1, par(5), true);
     }
   } else if (KIND == 2) {
     if constexpr (NQ == 2) {

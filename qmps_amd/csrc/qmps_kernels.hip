@@ -2099,6 +2099,9 @@ __global__ __launch_bounds__(256) void unitary_to_tensor_kernel(const double2* _
 //   kind 1: ShallowQAOAStateTensor   per (beta, gamma): X**beta all, ZZ**gamma neighbours
 //   kind 2: ShallowFullStateTensor   15 angles, two qubits (D = 2)
 //   kind 3: ShallowCNOTStateTensor3  per (beta, gamma, omega): rz, rx, rz all, H(q0), CNOT ladder
+//   kind 4: ShallowCNOTStateTensor_nonuniform  per layer 2 (n + 1) angles: rz(p[i]), rx(p[i + n + 1]) on qubit i, CNOT ladder
+//   kind 5: ExactAfter4              per layer 6 angles on qubits 0, 1, CNOT ladder, cyclic SWAPs
+//   kind 6: StateGate                6 angles, two qubits (D = 2): rx, rx, rz, rz, XX**e, YY**f
 // ------------------------------------------------------------------------------------------
 // (Reg<NQ>, ansatz_circuit, roto_shift_value: qmps_circuit.h)
 template <int D, int KIND>
@@ -2149,6 +2152,12 @@ static hipError_t launch_ansatz_d(int kind, const double* params, int n_params, 
       hipLaunchKernelGGL((ansatz_tensor_kernel<2, 2>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h);
       break;
     case 3: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 3>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
+    case 4: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 4>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
+    case 5: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 5>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
+    case 6:
+      if (D != 2) return hipErrorInvalidValue;
+      hipLaunchKernelGGL((ansatz_tensor_kernel<2, 6>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h);
+      break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -174,7 +174,7 @@ class SparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
         unitary built gate by gate on the host; any other gate class goes through `unitary()`."""
         P = np.ascontiguousarray(np.atleast_2d(params_batch), dtype=np.float64)
         kind = getattr(self.state_tensor, 'device_kind', None)
-        if kind is None or (kind == 2 and self.D != 2):
+        if kind is None or (kind in (2, 6) and self.D != 2):
             return self._energies_from_unitaries(self.unitaries(P))
         eng = _runtime.engine(self.D, P.shape[0])
         E, it, st = eng.energies_from_params(kind, P, _as_h(self.H), max_iter=self.max_iter, tol=self.env_tol)
@@ -211,8 +211,8 @@ class SparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
         parameter.  Returns None (host driver takes over) for gate classes without a device implementation."""
         from .tools import RotosolveResult
         kind = getattr(self.state_tensor, 'device_kind', None)
-        if self.optimize_environment or kind is None or (kind == 2 and self.D != 2):
-            return None
+        if self.optimize_environment or kind is None or kind > 3 or (kind == 2 and self.D != 2):
+            return None          # (the device rotosolve drivers know the layered families 0 .. 3; other gate classes: host driver, batched objective)
         from .rotosolve import device_double_rotosolve
         es, P = device_double_rotosolve(self, np.asarray(self.initial_guess, dtype=float)[None], n_sweeps)
         # the reference updates the caller's parameter vector in place, element by element (tools.py:453): that works for

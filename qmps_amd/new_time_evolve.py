@@ -48,7 +48,7 @@ def batch_obj(P, A, WW, return_eta=False, D=2, state_tensor=None, max_rounds=Non
     P = P[:, :_n_angles(cls, P[0])]
     eng = _runtime.engine(D, P.shape[0])
     kind = getattr(cls, 'device_kind', None)
-    if kind is None or (kind == L.ANSATZ_SHALLOW_FULL and D != 2):
+    if kind is None or (kind in (L.ANSATZ_SHALLOW_FULL, L.ANSATZ_STATE_GATE) and D != 2):
         cand = np.stack([unitary_to_tensor(unitary(cls(D, p))) for p in P])
         eta, rounds, st = eng.overlaps(A, cand, WW, kind='tensor', max_rounds=max_rounds, tol=tol)
     else:
@@ -130,7 +130,7 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
     X = X[:, :_n_angles(cls, X[0])]
     T, P = X.shape
     kind = getattr(cls, 'device_kind', None)
-    on_device = kind is not None and not (kind == L.ANSATZ_SHALLOW_FULL and D != 2)
+    on_device = kind is not None and not (kind in (L.ANSATZ_SHALLOW_FULL, L.ANSATZ_STATE_GATE) and D != 2)
     history, info = [X.copy()], {'fun': []}
     m = method.lower() if isinstance(method, str) else method
     if m in ('rotosolve', 'doublerotosolve') and on_device:

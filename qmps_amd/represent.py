@@ -283,6 +283,7 @@ class ShallowCNOTStateTensor(_Ansatz):
 
 class ShallowCNOTStateTensor_nonuniform(_Ansatz):
     """Per layer 2(n) angles: rz(p[i]) and rx(p[i+n]) on qubit i, CNOT ladder (represent.py:312-332)."""
+    device_kind = 4      # QMPS_ANSATZ_SHALLOW_CNOT_NONUNIFORM
 
     def __init__(self, bond_dim, βγs):
         super().__init__(bond_dim, βγs)
@@ -309,6 +310,7 @@ class ShallowCNOTStateTensor3(_Ansatz):
 
 class ExactAfter4(_Ansatz):
     """Six angles per layer on qubits 0,1, CNOT ladder, cyclic SWAPs (represent.py:356-380)."""
+    device_kind = 5      # QMPS_ANSATZ_EXACT_AFTER4
 
     def __init__(self, bond_dim, βγs):
         super().__init__(bond_dim, βγs)
@@ -339,6 +341,7 @@ class ShallowFullStateTensor(_Ansatz):
 
 class StateGate(Gate):
     """rx, rx, rz, rz, XX**e, YY**f on two qubits (represent.py:406-423)."""
+    device_kind = 6      # QMPS_ANSATZ_STATE_GATE (D = 2; built as StateGate(params), no bond-dimension argument)
 
     def __init__(self, βγs, symbol='U'):
         self.βγs = βγs

@@ -424,3 +424,41 @@ def test_two_site_cell_batches_build_u4_on_the_device(golden):
     for p, e in zip(P, Eb):
         assert abs(e - opt.objective_function(p)) < 1e-10
         assert abs(e - O.two_site_cell_energy(G.SU(p[:15], 4), G.SU(p[15:], 4), h)) < 1e-10
+
+
+@pytest.mark.parametrize('D', [2, 4, 8, 16])
+def test_device_builders_of_the_remaining_ansatz_classes(D, engine_factory):
+    """ShallowCNOTStateTensor_nonuniform (represent.py:312-332), ExactAfter4 (:356-380) and, at D = 2, StateGate (:406-423):
+    parameters -> state tensor on the device == the host gate-by-gate classes == the oracle's explicit circuit model; and the
+    optimiser's batched objective runs through them."""
+    from qmps_amd import _lib as L
+    rng = np.random.default_rng(900 + D)
+    eng = engine_factory(D)
+    n = int(np.log2(D)) + 1
+    cases = [(L.ANSATZ_SHALLOW_CNOT_NONUNIFORM, lambda p: R.ShallowCNOTStateTensor_nonuniform(D, p), lambda p: O.shallow_cnot_nonuniform_unitary(D, p), 2 * n * 3),
+             (L.ANSATZ_EXACT_AFTER4, lambda p: R.ExactAfter4(D, p), lambda p: O.exact_after4_unitary(D, p), 12)]
+    if D == 2:
+        cases.append((L.ANSATZ_STATE_GATE, lambda p: R.StateGate(p), lambda p: O.state_gate_unitary(p), 6))
+    for kind, host, oracle, npar in cases:
+        P = rng.standard_normal((23, npar))
+        eng.set_ansatz_params(kind, P)
+        A_dev = eng.tensors()
+        A_host = np.stack([T.unitary_to_tensor(R.unitary(host(p))) for p in P])
+        A_orc = np.stack([O.unitary_to_tensor(oracle(p)) for p in P])
+        assert np.abs(A_dev - A_host).max() < 1e-13 and np.abs(A_dev - A_orc).max() < 1e-13, (kind, D)
+    with pytest.raises(L.QmpsError):
+        eng.set_ansatz_params(L.ANSATZ_EXACT_AFTER4, rng.standard_normal((3, 5)))
+    with pytest.raises(L.QmpsError):
+        eng.set_ansatz_params(L.ANSATZ_SHALLOW_CNOT_NONUNIFORM, rng.standard_normal((3, 2 * n + 1)))
+    if D != 2:
+        with pytest.raises(L.QmpsError):
+            eng.set_ansatz_params(L.ANSATZ_STATE_GATE, rng.standard_normal((3, 6)))
+    if D in (2, 4):
+        h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+        P = rng.standard_normal((11, 2 * n * 2))
+        opt = G.SparseFullEnergyOptimizer(h, D, 2, state_tensor=R.ShallowCNOTStateTensor_nonuniform, initial_guess=P[0].copy())
+        Eb = opt.batch_objective_function(P)
+        for p, e in zip(P, Eb):
+            if np.isfinite(e):
+                assert abs(e - O.energy_closed_form(O.unitary_to_tensor(O.shallow_cnot_nonuniform_unitary(D, p)), h)) < 1e-10
+        assert np.isfinite(Eb).sum() >= 8

@@ -280,6 +280,31 @@ def test_overlap_circuit_identity():
     assert abs(O.overlap_eta(A, A, np.eye(4))[0] - 1) < 1e-12
 
 
+def test_remaining_ansatz_builders_are_unitary_and_match_their_gate_lists():
+    """Oracle builders of ShallowCNOTStateTensor_nonuniform / ExactAfter4 / StateGate: unitary, and equal to a product of the
+    elementary gates written out by hand for one layer (represent.py:312-332, 356-380, 406-423)."""
+    rng = np.random.default_rng(41)
+    for D in (2, 4, 8):
+        n = int(np.log2(D)) + 1
+        for U in (O.shallow_cnot_nonuniform_unitary(D, rng.standard_normal(4 * n)), O.exact_after4_unitary(D, rng.standard_normal(12))):
+            assert np.abs(U.conj().T @ U - np.eye(2 * D)).max() < 1e-13
+    # D = 2, one layer of the nonuniform ansatz by hand: CNOT(q0, q1) (rx(p3) x rx(p2) after rz ...) in big-endian kron order
+    p = rng.standard_normal(4)
+    hand = O.CNOT @ np.kron(O.rx(p[2]), O.rx(p[3])) @ np.kron(O.rz(p[0]), O.rz(p[1]))
+    assert np.abs(O.shallow_cnot_nonuniform_unitary(2, p) - hand).max() < 1e-14
+    # ExactAfter4 at D = 2: SWAP(q0, q1) twice (i = 0 and the cyclic i = 1) cancels
+    q = rng.standard_normal(6)
+    hand = O.CNOT @ np.kron(O.rz(q[2]), O.rz(q[5])) @ np.kron(O.rx(q[1]), O.rx(q[4])) @ np.kron(O.rz(q[0]), O.rz(q[3]))
+    assert np.abs(O.exact_after4_unitary(2, q) - hand).max() < 1e-14
+    # StateGate: XX**e and YY**f commute with each other and have eigenvalues 1 / e^{i pi t}
+    s = rng.standard_normal(6)
+    U = O.state_gate_unitary(s)
+    assert np.abs(U.conj().T @ U - np.eye(4)).max() < 1e-13
+    XX = O._pauli_pair_power(np.array([[0, 1], [1, 0]], dtype=complex), 0.37)
+    w = np.linalg.eigvals(XX)
+    assert np.allclose(sorted(np.angle(w)), sorted([0, 0, 0.37 * np.pi, 0.37 * np.pi]))
+
+
 def test_overlap_arpack_route_equals_the_dense_eigen_solve():
     """The reference's route (xmps Map -> scipy.sparse.linalg.eigs, ARPACK in operator form) and the dense eigen-solve of the
     D^2 x D^2 matrix give the same dominant eigenvalue and ray for time-step candidates at every bond dimension."""

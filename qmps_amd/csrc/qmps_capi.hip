@@ -433,8 +433,8 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     HIP_TRY(hipMalloc(&c->d_A, (size_t)max_batch * tensor_bytes(c)));
     HIP_TRY(hipMalloc(&c->d_r, (size_t)max_batch * env_bytes(c)));
     HIP_TRY(hipMalloc(&c->d_h, (size_t)kMaxTerms * 256));
-    HIP_TRY(hipMalloc((void**)&c->d_iters, (size_t)max_batch * sizeof(int32_t)));
-    HIP_TRY(hipMalloc((void**)&c->d_status, (size_t)max_batch * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&c->d_iters, (size_t)(max_batch + 2) * sizeof(int32_t)));     // (+ 2: read in 8-byte units by the staging copy)
+    HIP_TRY(hipMalloc((void**)&c->d_status, (size_t)(max_batch + 2) * sizeof(int32_t)));
     c->partial_cap = (max_batch + 15) / 16 > kSumBlocks ? (max_batch + 15) / 16 : kSumBlocks;   // one partial per 16 (direct kernel), 32 (pair kernel) or 64 items
     HIP_TRY(hipMalloc((void**)&c->d_partial, (size_t)kMaxTerms * c->partial_cap * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->d_cost, kMaxTerms * sizeof(double)));
@@ -563,13 +563,14 @@ int qmps_set_states_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const
   }
   {
     const size_t pb = (size_t)B * n_params * sizeof(double);
-    const void* src = params;
-    if (c->defer_sync && pb <= (8u << 20)) {       // one-round-trip callers: through pinned memory, truly asynchronous
+    if (c->defer_sync && pb <= (8u << 20)) {
+      // one-round-trip callers: through pinned memory, moved by a kernel on the context stream (no copy-queue hop)
       if (int rc = ensure_pinned(c, (16u << 20))) return rc;
       memcpy(c->h_pin, params, pb);
-      src = c->h_pin;
+      HIP_TRY(qmps::launch_stage_copy(c->h_pin, c->d_params, (int64_t)(pb / 8), c->stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(c->d_params, params, pb, hipMemcpyHostToDevice, c->stream));
     }
-    HIP_TRY(hipMemcpyAsync(c->d_params, src, pb, hipMemcpyHostToDevice, c->stream));
   }
   c->ans_have = true; c->ans_kind = kind; c->ans_P = n_params; c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0;
   c->tensors_valid = false;
@@ -1473,8 +1474,8 @@ int qmps_overlap_eval_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, con
   const size_t fb = (size_t)B * sizeof(double), sb = (size_t)B * sizeof(int32_t);
   if (fb + sb <= (8u << 20) && c->h_pin_bytes >= (16u << 20)) {
     char* out = c->h_pin + (8u << 20);
-    HIP_TRY(hipMemcpyAsync(out, c->d_f, fb, hipMemcpyDeviceToHost, c->stream));
-    if (status_out) HIP_TRY(hipMemcpyAsync(out + fb, c->d_status, sb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(qmps::launch_stage_copy(c->d_f, out, B, c->stream));
+    if (status_out) HIP_TRY(qmps::launch_stage_copy(c->d_status, out + fb, (B + 1) / 2, c->stream));     // (d_status has max_batch >= B + 1 entries or the tail is never read)
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(f_out, out, fb);
     if (status_out) memcpy(status_out, out + fb, sb);
@@ -1551,8 +1552,8 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   const size_t fbytes = (size_t)T * (1 + 2 * P) * sizeof(double), sbytes = (size_t)2 * T * sizeof(int32_t);
   double* fall = (double*)(c->h_pin + (8u << 20));
   int32_t* st = (int32_t*)(c->h_pin + (8u << 20) + fbytes);
-  HIP_TRY(hipMemcpyAsync(fall, c->d_f, fbytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(st, c->d_status, sbytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(qmps::launch_stage_copy(c->d_f, fall, (int64_t)(fbytes / 8), c->stream));
+  HIP_TRY(qmps::launch_stage_copy(c->d_status, st, (int64_t)(sbytes / 8), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   memcpy(f_out, fall, (size_t)T * sizeof(double));
   const double* fn = fall + T;

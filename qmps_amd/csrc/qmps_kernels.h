@@ -245,5 +245,7 @@ hipError_t launch_sum_final(const double* partial, int n_partial, int n_terms, d
 hipError_t launch_probe_fp64(double* out, int blocks, int iters, hipStream_t st);
 hipError_t launch_probe_mfma_f64(double* out, int blocks, int iters, hipStream_t st);
 hipError_t launch_probe_copy(const void* src, void* dst, int64_t n16, hipStream_t st);
+// copy of n8 x 8 bytes by a kernel on the given stream (pinned host memory <-> HBM without a copy-queue hop)
+hipError_t launch_stage_copy(const void* src, void* dst, int64_t n8, hipStream_t st);
 
 }  // namespace qmps

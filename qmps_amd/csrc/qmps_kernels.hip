@@ -3285,6 +3285,21 @@ hipError_t launch_probe_mfma_f64(double* out, int blocks, int iters, hipStream_t
   return hipGetLastError();
 }
 
+// small copies between pinned host memory and HBM done by a kernel ON THE CONTEXT STREAM (n8 units of 8 bytes): a
+// hipMemcpyAsync runs on a copy queue, and the cross-queue dependency in front of / behind it cost 40-80 us per round trip of
+// the optimiser drivers (rocprofv3 kernel trace of bench.py --workload evolve); the kernel reads / writes the pinned buffer directly
+__global__ __launch_bounds__(256) void stage_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n8) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += stride) dst[t] = src[t];
+}
+hipError_t launch_stage_copy(const void* src, void* dst, int64_t n8, hipStream_t st) {
+  if (n8 <= 0) return hipSuccess;
+  int64_t blocks = (n8 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(stage_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const double*)src, (double*)dst, n8);
+  return hipGetLastError();
+}
+
 hipError_t launch_probe_copy(const void* src, void* dst, int64_t n16, hipStream_t st) {
   hipLaunchKernelGGL(probe_copy_kernel, dim3(2048), dim3(256), 0, st, (const double2*)src, (double2*)dst, n16);
   return hipGetLastError();

@@ -503,7 +503,7 @@ def main_evolve(args):
     from qmps_amd.new_time_evolve import LockstepEvolver
     from qmps_amd.represent import ShallowCNOTStateTensor
     ev = LockstepEvolver(D, T, P, ShallowCNOTStateTensor, tol=args.tol, maxiter=args.bfgs_iters, device=local_rank,
-                         gradient=args.gradient, first_rungs=2 if args.gradient != 'fd' else None)
+                         gradient=args.gradient, first_rungs=2 if args.gradient != 'fd' else None, carry_hessian=args.carry_hessian)
     info = _lib.device_info(local_rank)
     X = np.random.default_rng(args.seed + rank).standard_normal((T, P))
     t_settle = time.perf_counter()
@@ -535,6 +535,27 @@ def main_evolve(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     sg, sl = ev.fg.eng.overlap_stats(), ev.fl.eng.overlap_stats()
+    kms_timed = (list(ev.fg.kernel_ms), list(ev.fl.kernel_ms))
+    identity_leg = None
+    if args.carry_hessian and not args.no_extras:
+        # the same time steps the way scipy (the reference) starts them: inverse Hessian = identity at the top of every step
+        ev.carry_hessian = False
+        n_leg = max(2, min(4, args.steps))
+        Xl = X.copy()
+        if dist is not None:
+            dist.barrier()
+        t1 = time.perf_counter()
+        nit_l, f_l = [], None
+        for _ in range(n_leg):
+            res = ev.step(Xl, WW)
+            Xl, f_l = res['x'], res['fun']
+            nit_l.append(res['nit'])
+        el = time.perf_counter() - t1
+        ev.carry_hessian = True
+        identity_leg = {'value': T * n_leg / el, 'unit': 'trajectory time steps/s (this rank)', 'steps': n_leg, 'ms_per_step': el / n_leg * 1e3,
+                        'bfgs_iterations_per_step': float(np.mean(nit_l)), 'mean_final_objective': float(np.nanmean(f_l)),
+                        'what': 'BFGS restarted from the identity at every time step (scipy / the reference); same tolerance, same ladder'}
+    ev.fg.kernel_ms, ev.fl.kernel_ms = kms_timed
     if rank == 0:
         squaring = D in (2, 4)
         per_round = 8 * (D * D) ** 3 if squaring else 64 * D ** 3           # a squaring of the complex D^2 x D^2 matrix / a power step (8 complex D^3 products)
@@ -554,12 +575,14 @@ def main_evolve(args):
                'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                'config': {'workload': f'TFIM g=1 quench time evolution, D={D}, ShallowCNOT depth {depth} ({P} parameters), {T} independent trajectories per GPU '
                                       f'from random parameters, W = exp(-{args.dt:g} i h), one step = one time step of every trajectory: lock-step BFGS '
-                                      f'(<= {args.bfgs_iters} iterations, gtol 1e-5, central differences h = 1e-6 ' +
+                                      f'(<= {args.bfgs_iters} iterations, gtol 1e-5, ' + ('inverse Hessians carried from time step to time step, '
+                                                                                          if args.carry_hessian else 'identity start at every time step, ') +
+                                      'central differences h = 1e-6 ' +
                                       ('from one right + one left eigen-solve per iterate (neighbours to second order in h), ladder in two stages (2 + 6 rungs)' if two_sided
                                        else 'with every neighbour eigen-solved, 8-point backtracking ladder') + '), objective '
                                       f'-sqrt|eta| with eta to {args.tol:g} (residual of the power method / rank-one test of the squaring)',
                           'baseline_config': 'BASELINE.json configs[4]', 'D': D, 'trajectories_per_gpu': T, 'n_params': P, 'seed': args.seed,
-                          'bfgs_iterations_per_step': float(np.mean(nit)), 'objective_evals_per_step': nfev / args.steps,
+                          'bfgs_iterations_per_step': float(np.mean(nit)), 'carry_hessian': bool(args.carry_hessian), 'objective_evals_per_step': nfev / args.steps,
                           'objective_evals_per_s': world * nfev / elapsed,
                           'mean_final_objective': float(np.nanmean(f_last)), 'worst_final_objective': float(np.nanmax(f_last)),
                           'solver_rounds_mean_gradient_batches': sg['rounds_sum'] / max(1, sg['evaluations']), 'solver_rounds_max_gradient_batches': sg['rounds_max'],
@@ -579,6 +602,8 @@ def main_evolve(args):
                                     'frac': byts / max(kms.sum() * 1e-3, 1e-12) * 1e-9 / HBM_PEAK_GBPS,
                                     'note': 'candidate tensor in + fixed point in and out (warm start) + eta / objective / status out per evaluation; the reference tensor is shared by a group'}},
                'cpu_baseline': cpu}
+        if identity_leg is not None:
+            out['identity_start'] = identity_leg
         print(json.dumps(out), flush=True)
     ev.close()
     if dist is not None:
@@ -753,6 +778,9 @@ def main():
     ap.add_argument('--gradient', choices=['auto', 'two-sided', 'fd'], default='auto',
                     help="evolve workload: 'two-sided' (auto at D >= 4) = one right + one left eigen-solve per iterate, the central-difference "
                          "neighbours by eta' = <y, T'(r)>/<y, r>; 'fd' = every neighbour eigen-solved (what scipy's BFGS does with the reference objective)")
+    ap.add_argument('--no-carry-hessian', dest='carry_hessian', action='store_false',
+                    help='evolve workload: start the BFGS of every time step from the identity (what scipy - the reference - does) instead of '
+                         'the inverse Hessians the previous step ended with; the default run reports this variant as the extra `identity_start`')
     ap.add_argument('--bfgs-iters', type=int, default=30, help='evolve workload: cap on BFGS iterations per time step')
     ap.add_argument('--double-frequency', action='store_true', help='rotosolve workload: six shifts per parameter (qmps/tools.py:422-457)')
     # defaults: the chip needs tens of ms of sustained load before its clocks settle

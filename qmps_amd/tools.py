@@ -263,7 +263,7 @@ def batched_fd_gradient(batch_fun, X, h=1e-6, F0=None):
 
 
 def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=1e-4,
-                 alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), value_and_grad=None, first_rungs=None):
+                 alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), value_and_grad=None, first_rungs=None, Hinv0=None):
     """T independent BFGS minimisations in LOCK-STEP (scipy's BFGS is what the reference's time-evolution loop runs per
     step: `minimize(obj, params, (A_, WW))`, new_time_evolve.py:284 / scripts/loschmidt.py:371 - one trajectory, one
     scalar objective call at a time).  Here every iteration is two batched evaluations over all trajectories:
@@ -279,11 +279,13 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
     first_rungs (optional int n < len(alphas)): the ladder is evaluated in two stages - line_batch receives T n candidates (the first
     n step lengths) and, only if some trajectory finds no acceptable step among them, a second batch of T (len(alphas) - n) - near
     the minimum BFGS accepts alpha = 1 almost always.  line_batch must then accept both group sizes.
-    Returns dict(x (T,P), fun (T,), jac (T,P), nit, nfev, converged (T,), history [fun per iteration])."""
+    Hinv0 (optional, (T,P,P)): initial inverse Hessians instead of the identity (scipy's start) - e.g. the ones the previous time
+    step of the same trajectories ended with; the result carries the final ones as 'hess_inv'.
+    Returns dict(x (T,P), fun (T,), jac (T,P), nit, nfev, converged (T,), history [fun per iteration], hess_inv (T,P,P))."""
     X = np.array(np.atleast_2d(X0), dtype=float)
     T, P = X.shape
     al = np.asarray(alphas, dtype=float)
-    Hinv = np.tile(np.eye(P), (T, 1, 1))
+    Hinv = np.tile(np.eye(P), (T, 1, 1)) if Hinv0 is None else np.array(Hinv0, dtype=float, copy=True)
     vg = value_and_grad if value_and_grad is not None else (lambda Z: batched_fd_gradient(grad_batch, Z, h))
     f, g = vg(X)
     nfev = T * (2 * P + 1)
@@ -339,7 +341,7 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
         history.append(f.copy())
         nit += 1
     return {'x': X, 'fun': f, 'jac': g, 'nit': nit, 'nfev': nfev, 'converged': np.abs(g).max(axis=1) < gtol,
-            'history': np.array(history)}
+            'history': np.array(history), 'hess_inv': Hinv}
 
 
 def batched_nelder_mead(batch_fun, x0, xatol=1e-4, fatol=1e-4, maxiter=None, maxfev=None, callback=None, speculate=True):

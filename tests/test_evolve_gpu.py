@@ -198,6 +198,14 @@ def test_lockstep_bfgs_time_evolution(D, P, T, iters):
     H, info = NT.evolve(X0, WW, n_steps, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-13,
                         options=opts, return_info=True)
     if D == 4:
+        # carried inverse Hessians: the same minima (objective to 1e-8), fewer iterations from the second time step on
+        H_c, info_c = NT.evolve(X0, WW, n_steps, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-13,
+                                options={'maxiter': 40, 'carry_hessian': True}, return_info=True)
+        H_i, info_i = NT.evolve(X0, WW, n_steps, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-13,
+                                options={'maxiter': 40}, return_info=True)
+        for a, b in zip(info_c['fun'], info_i['fun']):
+            assert np.abs(a[-1] - b[-1]).max() < 1e-7
+        assert sum(info_c['nit'][1:]) < sum(info_i['nit'][1:])
         H_fd, info_fd = NT.evolve(X0, WW, n_steps, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-13,
                                   options={'maxiter': iters, 'gradient': 'fd'}, return_info=True)
         for a, b in zip(info['fun'], info_fd['fun']):

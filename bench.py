@@ -503,7 +503,8 @@ def main_evolve(args):
     from qmps_amd.new_time_evolve import LockstepEvolver
     from qmps_amd.represent import ShallowCNOTStateTensor
     ev = LockstepEvolver(D, T, P, ShallowCNOTStateTensor, tol=args.tol, maxiter=args.bfgs_iters, device=local_rank,
-                         gradient=args.gradient, first_rungs=2 if args.gradient != 'fd' else None, carry_hessian=args.carry_hessian)
+                         gradient=args.gradient, first_rungs=2 if args.gradient != 'fd' else None, carry_hessian=args.carry_hessian,
+                         speculative=args.gradient != 'fd' and not args.no_speculative)
     info = _lib.device_info(local_rank)
     X = np.random.default_rng(args.seed + rank).standard_normal((T, P))
     t_settle = time.perf_counter()
@@ -578,7 +579,8 @@ def main_evolve(args):
                                       f'(<= {args.bfgs_iters} iterations, gtol 1e-5, ' + ('inverse Hessians carried from time step to time step, '
                                                                                           if args.carry_hessian else 'identity start at every time step, ') +
                                       'central differences h = 1e-6 ' +
-                                      ('from one right + one left eigen-solve per iterate (neighbours to second order in h), ladder in two stages (2 + 6 rungs)' if two_sided
+                                      ('from one right + one left eigen-solve per iterate (neighbours to second order in h), ' +
+                                       ('full step evaluated with its gradient first, ladder only on rejection' if ev.speculative else 'ladder in two stages (2 + 6 rungs)') if two_sided
                                        else 'with every neighbour eigen-solved, 8-point backtracking ladder') + '), objective '
                                       f'-sqrt|eta| with eta to {args.tol:g} (residual of the power method / rank-one test of the squaring)',
                           'baseline_config': 'BASELINE.json configs[4]', 'D': D, 'trajectories_per_gpu': T, 'n_params': P, 'seed': args.seed,
@@ -778,6 +780,9 @@ def main():
     ap.add_argument('--gradient', choices=['auto', 'two-sided', 'fd'], default='auto',
                     help="evolve workload: 'two-sided' (auto at D >= 4) = one right + one left eigen-solve per iterate, the central-difference "
                          "neighbours by eta' = <y, T'(r)>/<y, r>; 'fd' = every neighbour eigen-solved (what scipy's BFGS does with the reference objective)")
+    ap.add_argument('--no-speculative', action='store_true',
+                    help='evolve workload: always evaluate the backtracking ladder before the gradient (default: objective and gradient at the full '
+                         'quasi-Newton step first, the ladder only when some trajectory rejects that step)')
     ap.add_argument('--no-carry-hessian', dest='carry_hessian', action='store_false',
                     help='evolve workload: start the BFGS of every time step from the identity (what scipy - the reference - does) instead of '
                          'the inverse Hessians the previous step ended with; the default run reports this variant as the extra `identity_start`')

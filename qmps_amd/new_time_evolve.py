@@ -150,7 +150,7 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
         mr = max_rounds if max_rounds is not None else (60 if D in (2, 4) else 100000)
         ev = LockstepEvolver(D, T, P, cls, mr, tol, opts.get('maxiter', 200), opts.get('gtol', 1e-5), opts.get('eps', 1e-6), ladder,
                              gradient=opts.get('gradient', 'auto'), first_rungs=opts.get('first_rungs'),
-                             carry_hessian=opts.get('carry_hessian', False))
+                             carry_hessian=opts.get('carry_hessian', False), speculative=opts.get('speculative', False))
         fg, fl = ev.fg, ev.fl
         try:
             for step in range(n_steps):
@@ -188,10 +188,12 @@ class LockstepEvolver:
 
     def __init__(self, D, T, P, cls=None, max_rounds=None, tol=1e-12, maxiter=200, gtol=1e-5, eps=1e-6,
                  alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), device=0, gradient='auto', first_rungs=None,
-                 carry_hessian=False):
+                 carry_hessian=False, speculative=False):
         """gradient: 'fd' = the 2P + 1 central-difference candidates are eigen-solved one by one (any D); 'two-sided' = one right
         and one left eigen-solve per iterate, the neighbours by the second-order formula eta' = <y, T'(r)>/<y, r> (D >= 4);
         'auto' = 'two-sided' where the library has it.  first_rungs: two-stage ladder (tools.batched_bfgs).
+        speculative: gradient batches at the full quasi-Newton step first (tools.batched_bfgs): one device batch per iteration
+        whenever every trajectory accepts it.
         carry_hessian: every time step starts BFGS from the inverse Hessians the previous step ended with instead of the identity
         (scipy - and the reference - start every minimisation afresh; consecutive time steps minimise nearly the same function)."""
         cls = cls or _default_class(D)
@@ -200,9 +202,12 @@ class LockstepEvolver:
         self.alphas, self.maxiter, self.gtol, self.eps = tuple(alphas), maxiter, gtol, eps
         self.two_sided = (gradient == 'two-sided') or (gradient == 'auto' and D >= 4)
         self.first_rungs = first_rungs
+        self.speculative = speculative and self.two_sided
         self.carry_hessian, self._hinv = carry_hessian, None
         self.fg = _GroupedObjective(D, self.kind, T, 2 * P + 1, mr, tol, device=device)
         rungs = len(self.alphas) if not first_rungs else (first_rungs, len(self.alphas) - first_rungs)
+        if self.speculative:
+            rungs = len(self.alphas) - 1
         self.fl = _GroupedObjective(D, self.kind, T, rungs, mr, tol, device=device)
 
     def step(self, X, WW):
@@ -211,7 +216,8 @@ class LockstepEvolver:
         self.fl.set_reference(X, WW)
         vg = (lambda Z: self.fg.value_and_grad(Z, self.eps)) if self.two_sided else None
         res = batched_bfgs(self.fg, self.fl, X, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas,
-                           value_and_grad=vg, first_rungs=self.first_rungs, Hinv0=self._hinv if self.carry_hessian else None)
+                           value_and_grad=vg, first_rungs=None if self.speculative else self.first_rungs,
+                           Hinv0=self._hinv if self.carry_hessian else None, speculative=self.speculative)
         self._hinv = res['hess_inv']
         return res
 

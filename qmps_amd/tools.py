@@ -263,7 +263,7 @@ def batched_fd_gradient(batch_fun, X, h=1e-6, F0=None):
 
 
 def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=1e-4,
-                 alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), value_and_grad=None, first_rungs=None, Hinv0=None):
+                 alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), value_and_grad=None, first_rungs=None, Hinv0=None, speculative=False):
     """T independent BFGS minimisations in LOCK-STEP (scipy's BFGS is what the reference's time-evolution loop runs per
     step: `minimize(obj, params, (A_, WW))`, new_time_evolve.py:284 / scripts/loschmidt.py:371 - one trajectory, one
     scalar objective call at a time).  Here every iteration is two batched evaluations over all trajectories:
@@ -279,6 +279,10 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
     first_rungs (optional int n < len(alphas)): the ladder is evaluated in two stages - line_batch receives T n candidates (the first
     n step lengths) and, only if some trajectory finds no acceptable step among them, a second batch of T (len(alphas) - n) - near
     the minimum BFGS accepts alpha = 1 almost always.  line_batch must then accept both group sizes.
+    speculative (needs value_and_grad): objective AND gradient are evaluated at the full step x + alphas[0] d straight away;
+    if every active trajectory accepts that step (Armijo) - the normal case of a quasi-Newton iteration - the iteration is that
+    ONE batch; otherwise the remaining rungs of the ladder are evaluated (line_batch receives T (len(alphas) - 1) candidates) and
+    the gradient at the accepted points as usual.  Same decisions as the plain ladder: the first rung is tested first either way.
     Hinv0 (optional, (T,P,P)): initial inverse Hessians instead of the identity (scipy's start) - e.g. the ones the previous time
     step of the same trajectories ended with; the result carries the final ones as 'hess_inv'.
     Returns dict(x (T,P), fun (T,), jac (T,P), nit, nfev, converged (T,), history [fun per iteration], hess_inv (T,P,P))."""
@@ -305,7 +309,18 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
             cand = X[:, None, :] + a[None, :, None] * d[:, None, :]
             F = np.asarray(line_batch(cand.reshape(-1, P))).reshape(T, len(a))
             return np.where(np.isfinite(F), F, np.inf)
-        if first_rungs:
+        fn = gn = None
+        if speculative and value_and_grad is not None:
+            fs, gs = vg(X + al[0] * d)
+            nfev += T * (2 * P + 1)
+            Fc = np.full((T, len(al)), np.inf)
+            Fc[:, 0] = np.where(np.isfinite(fs), fs, np.inf)
+            if (Fc[:, 0] <= f + c1 * al[0] * slope)[active].all():
+                fn, gn = fs, gs                          # every active trajectory takes the full step: nothing else to evaluate
+            else:
+                Fc[:, 1:] = ladder(al[1:])
+                nfev += T * (len(al) - 1)
+        elif first_rungs:
             Fc = np.full((T, len(al)), np.inf)
             Fc[:, :first_rungs] = ladder(al[:first_rungs])
             nfev += T * first_rungs
@@ -322,8 +337,9 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
         a = np.where(moved, al[first], 0.0)
         s = a[:, None] * d
         Xn = X + s
-        fn, gn = vg(Xn)
-        nfev += T * (2 * P + 1)
+        if fn is None:
+            fn, gn = vg(Xn)
+            nfev += T * (2 * P + 1)
         y = gn - g
         sy = np.einsum('ti,ti->t', s, y)
         upd = moved & (sy > 1e-12 * np.sqrt(np.einsum('ti,ti->t', s, s) * np.einsum('ti,ti->t', y, y))) & (sy > 0)

@@ -194,7 +194,7 @@ def test_lockstep_bfgs_time_evolution(D, P, T, iters):
     # D = 2: the neighbours are eigen-solved one by one; D = 4: both gradient routes; D = 16: two-sided + two-stage ladder
     opts = {'maxiter': iters}
     if D == 16:
-        opts['first_rungs'] = 2
+        opts['speculative'] = True                    # objective + gradient at the full step first, ladder on rejection
     H, info = NT.evolve(X0, WW, n_steps, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-13,
                         options=opts, return_info=True)
     if D == 4:
@@ -225,7 +225,16 @@ def test_lockstep_bfgs_time_evolution(D, P, T, iters):
                         assert abs(v[b] - ER.objective(0, D, A[b // G], C[b], WW)) < 1e-10
                 return v
             return f
-        res = batched_bfgs(fb(2 * P + 1), fb(8), X, maxiter=iters)
+        if D == 16:                                   # the same driver options on the host side
+            G = 2 * P + 1
+            fd = fb(G)
+
+            def vg_host(Z, fd=fd, G=G):
+                from qmps_amd.tools import batched_fd_gradient
+                return batched_fd_gradient(fd, Z, 1e-6)
+            res = batched_bfgs(None, fb(7), X, maxiter=iters, value_and_grad=vg_host, speculative=True)
+        else:
+            res = batched_bfgs(fb(2 * P + 1), fb(8), X, maxiter=iters)
         dev = info['fun'][step]
         assert dev.shape == res['history'].shape, (dev.shape, res['history'].shape)
         assert np.abs(dev - res['history']).max() < F_TOL, np.abs(dev - res['history']).max()
@@ -238,7 +247,7 @@ def test_lockstep_bfgs_time_evolution(D, P, T, iters):
     if D == 16:
         s = info['solver']['gradient_batches']
         assert s['not_converged'] == 0
-        assert s['evaluations'] == 2 * T * sum(n + 1 for n in info['nit'])      # two solves per iterate and iteration
+        assert s['evaluations'] >= 2 * T * sum(n + 1 for n in info['nit'])      # two solves per iterate and iteration (+ re-evaluations after a rejected full step)
 
 
 def test_reference_signature_single_trajectory(engine_factory):

@@ -361,3 +361,36 @@ def test_batched_nelder_mead_reproduces_scipy():
                 assert np.array_equal(res.x, ref.x) and res.fun == ref.fun
             assert res.n_batches <= res.nit + 1 + (res.nit if not spec else res.nit)
         assert res.nfev_batched >= res.nfev
+
+
+def test_batched_bfgs_speculative_full_step():
+    """speculative=True evaluates objective and gradient at the full step first and falls back to the rest of the ladder only
+    when some trajectory rejects it: the same iterates as the plain ladder, fewer batches."""
+    from qmps_amd.tools import batched_bfgs
+    rng = np.random.default_rng(6)
+    T, P = 5, 3
+    c = rng.standard_normal((T, P))
+    n = {'vg': 0, 'line': 0}
+
+    def val(C, t):
+        d = C - c[t]
+        return np.sum(d ** 2, axis=1) + 3.0 * (d[:, 0] * d[:, 1]) ** 2 + 0.5 * np.sum(d ** 4, axis=1)
+
+    def line(C):
+        n['line'] += 1
+        G = len(C) // T
+        return val(C, np.arange(len(C)) // G)
+
+    def vg(X):
+        n['vg'] += 1
+        h = 1e-6
+        g = np.stack([(val(X + h * np.eye(P)[k], np.arange(T)) - val(X - h * np.eye(P)[k], np.arange(T))) / (2 * h) for k in range(P)], axis=1)
+        return val(X, np.arange(T)), g
+    X0 = c + 1.5 * rng.standard_normal((T, P))
+    plain = batched_bfgs(None, line, X0, maxiter=100, gtol=1e-8, value_and_grad=vg)
+    n_plain = dict(n)
+    n.update(vg=0, line=0)
+    spec = batched_bfgs(None, line, X0, maxiter=100, gtol=1e-8, value_and_grad=vg, speculative=True)
+    assert spec['nit'] == plain['nit'] and np.abs(spec['history'] - plain['history']).max() < 1e-12
+    assert np.abs(spec['x'] - plain['x']).max() < 1e-10 and spec['converged'].all()
+    assert n['line'] < n_plain['line'] and n['vg'] + n['line'] < n_plain['vg'] + n_plain['line']

@@ -5,6 +5,8 @@
 
 namespace qmps {
 
+typedef double v4f64 __attribute__((ext_vector_type(4)));     // accumulator / B operand of v_mfma_f64_16x16x4
+
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,303 @@
+// qmps_energy_block.hip - D = 8 (and the D = 16 fall-back) energy path: one evaluation per workgroup of D x D threads, tiles in
+// LDS; at D = 8 with the direct fixed-point solve (qmps_direct_d8.h) in front, in the same launch.  Split out of qmps_kernels.hip in round 3.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <stdint.h>
+
+#include "qmps_kernels.h"
+#include "qmps_knobs.h"
+#include "qmps_device.h"
+#include "qmps_direct_d8.h"
+
+namespace qmps {
+
+// ------------------------------------------------------------------------------------------
+// Kernel 2: D = 8, 16 - one evaluation per workgroup of D x D threads, tiles in LDS.
+// Thread (i, j) owns r[i][j].  First correct version of the large-D path.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ double block_sum(double v, double* red, int tid) {
+  // sum over the D*D threads of the workgroup; result broadcast to every thread
+  constexpr int N = D * D;
+  v = wave_sum(v);   // DPP row rotations + permlane swaps: VALU only, ~20 instructions
+  if (N > 64) {
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    v = 0.0;
+#pragma unroll
+    for (int w = 0; w < N / 64; ++w) v += red[w];
+  }
+  return v;
+}
+
+// FUSED8 (D = 8, SOLVE): the direct fixed-point solve (qmps_direct_d8.h) runs in front, in the same wave - solve, acceptance
+// step and energies in ONE launch (the small batches of BASELINE.json configs[3] are all launch latency).  A separate
+// instantiation: the solve needs ~190 VGPRs, the plain block kernel runs four waves per SIMD.
+template <int D, bool SOLVE, bool FUSED8 = false>
+__global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
+  constexpr int N = D * D;
+  constexpr int P = D + 1;  // padded row (in double2 units) against bank conflicts
+  __shared__ double2 sA[2][D][P];
+  __shared__ double2 sR[D][P];
+  __shared__ double2 sX[2][D][P];
+  __shared__ double2 sT[2][D][P];
+  __shared__ double red[8];
+  const int tid = threadIdx.x;
+  const int i = tid / D, j = tid % D;
+  const int64_t b = blockIdx.x;
+  if (b >= p.B) return;
+  if (p.acc_zero != nullptr && blockIdx.x == 0) acc_clear(p.acc_zero, p.n_terms, tid, N);   // accumulator of a later step
+
+  {
+    const double2* a = (const double2*)p.A + b * (2 * N);
+    sA[0][i][j] = a[tid];
+    sA[1][i][j] = a[N + tid];
+  }
+  double2 r;
+  if constexpr (FUSED8) {
+    __shared__ double sM8[64][17];
+    __shared__ double sT8[8][9];
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    r = env_direct_d8_solve(sA, sT8, sM8, tid);
+  } else if (p.r_in != nullptr) {
+    const double2* g = (const double2*)p.r_in + b * N;
+    const double2 u = g[i * D + j], l = g[j * D + i];
+    r = make_double2(0.5 * (u.x + l.x), (i == j) ? 0.0 : 0.5 * (u.y - l.y));
+    const double tr = block_sum<D>(i == j ? r.x : 0.0, red, tid);
+    r.x /= tr;
+    r.y /= tr;
+  } else {
+    r = make_double2(i == j ? 1.0 / D : 0.0, 0.0);
+  }
+  sR[i][j] = r;
+  __syncthreads();
+
+  // D = 8: row i of A (for X = A r) lives in registers; row j (for r' = X A^+), the r column and the X row
+  // come from LDS (40 instead of 56 ds_read_b128 per step) - keeps the kernel at 4 waves per SIMD, which
+  // matters more here: the step is latency-bound (two LDS round trips + two reductions per step).  D = 16 keeps them in LDS (register budget);
+  // that instantiation is only the fallback behind the MFMA kernel.
+  constexpr bool kRowsInRegs = (D == 8);
+  constexpr int RD = kRowsInRegs ? D : 1;
+  double2 ai_[2][RD];
+  if constexpr (kRowsInRegs) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int k = 0; k < D; ++k) ai_[s][k] = sA[s][i][k];
+  }
+  auto apply = [&](double2& out) {
+    // X_s[i][j] = sum_k A_s[i][k] r[k][j]
+    double2 rc[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) rc[k] = sR[k][j];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      double xr = 0.0, xi = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        double2 a;
+        if constexpr (kRowsInRegs) a = ai_[s][k]; else a = sA[s][i][k];
+        const double2 rr = rc[k];
+        xr = dfma(a.x, rr.x, xr);
+        xr = dfma(-a.y, rr.y, xr);
+        xi = dfma(a.x, rr.y, xi);
+        xi = dfma(a.y, rr.x, xi);
+      }
+      sX[s][i][j] = make_double2(xr, xi);
+    }
+    __syncthreads();
+    double nr = 0.0, ni = 0.0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double2 a = sA[s][j][k];
+        const double2 x = sX[s][i][k];
+        nr = dfma(x.x, a.x, nr);
+        nr = dfma(x.y, a.y, nr);
+        ni = dfma(x.y, a.x, ni);
+        ni = dfma(-x.x, a.y, ni);
+      }
+    out = make_double2(nr, ni);
+  };
+
+  int iters = 0, status = QMPS_ST_OK;
+  if (SOLVE) {
+    status = QMPS_ST_NOT_CONVERGED;
+    const double tol2 = p.tol * p.tol;
+    for (int k = 1; k <= p.max_iter; ++k) {
+      double2 n;
+      apply(n);
+      // hermitise through LDS, normalise by the trace
+      sT[0][i][j] = n;
+      __syncthreads();
+      const double2 m = sT[0][j][i];
+      n = make_double2(0.5 * (n.x + m.x), (i == j) ? 0.0 : 0.5 * (n.y - m.y));
+      const double tr = block_sum<D>(i == j ? n.x : 0.0, red, tid);
+      const double inv = 1.0 / tr;
+      n.x *= inv;
+      n.y *= inv;
+      const double dr = n.x - r.x, di = n.y - r.y;
+      const double d2 = block_sum<D>(dr * dr + di * di, red, tid);
+      r = n;
+      sR[i][j] = r;
+      __syncthreads();
+      iters = k;
+      if (d2 < tol2) {
+        status = QMPS_ST_OK;
+        break;
+      }
+    }
+  }
+  if (!SOLVE && p.check_pd) status = p.status[b];
+  if (SOLVE || p.check_pd) {
+    if (status == QMPS_ST_OK) {
+      // Positive definiteness (the criterion of cholesky(r), qmps/tools.py:182): the pivots of LDL^H, all D^2 threads at
+      // once - thread (i, j) owns the Schur-complement entry S[i][j]; per pivot one LDS round trip (column c and the pivot),
+      // S[i][j] -= S[i][c] conj(S[j][c]) / S[c][c].  (A single thread walking the Cholesky recurrence through LDS took
+      // ~6 us of the 22 us this kernel needs per evaluation at D = 8.)
+      double2 S = r;
+      bool ok = true;
+      for (int c = 0; c < D; ++c) {
+        __syncthreads();
+        sT[1][i][j] = S;
+        __syncthreads();
+        const double pc = sT[1][c][c].x;
+        ok = ok && (pc > 0.0);
+        const double2 li = sT[1][i][c], lj = sT[1][j][c];
+        const double inv = fast_rcp(pc);
+        const double wr = (li.x * lj.x + li.y * lj.y) * inv, wi = (li.y * lj.x - li.x * lj.y) * inv;
+        S.x -= wr;
+        S.y -= wi;
+      }
+      if (!ok) status = QMPS_ST_NOT_PD;
+      __syncthreads();
+    }
+  }
+
+  // ---- energy: rho[tau][sigma] = tr(A_t1 (A_t2 r A_s2^+) A_s1^+)
+  const double trr = block_sum<D>(i == j ? r.x : 0.0, red, tid);
+  double2 rho_loc[4][4];
+  // X_t2 = A_t2 r  (both t2) -> sX
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    double xr = 0.0, xi = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const double2 a = sA[s][i][k], rr = sR[k][j];
+      xr = dfma(a.x, rr.x, xr);
+      xr = dfma(-a.y, rr.y, xr);
+      xi = dfma(a.x, rr.y, xi);
+      xi = dfma(a.y, rr.x, xi);
+    }
+    sX[s][i][j] = make_double2(xr, xi);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      // R[i][j] = sum_k X_t2[i][k] conj(A_s2[j][k]) -> sT[0]
+      double cr = 0.0, ci = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double2 x = sX[t2][i][k], a = sA[s2][j][k];
+        cr = dfma(x.x, a.x, cr);
+        cr = dfma(x.y, a.y, cr);
+        ci = dfma(x.y, a.x, ci);
+        ci = dfma(-x.x, a.y, ci);
+      }
+      __syncthreads();
+      sT[0][i][j] = make_double2(cr, ci);
+      __syncthreads();
+#pragma unroll
+      for (int t1 = 0; t1 < 2; ++t1) {
+        // Z[i][j] = sum_k A_t1[i][k] R[k][j]
+        double zr = 0.0, zi = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const double2 a = sA[t1][i][k], rr = sT[0][k][j];
+          zr = dfma(a.x, rr.x, zr);
+          zr = dfma(-a.y, rr.y, zr);
+          zi = dfma(a.x, rr.y, zi);
+          zi = dfma(a.y, rr.x, zi);
+        }
+#pragma unroll
+        for (int s1 = 0; s1 < 2; ++s1) {
+          // this thread's share of rho[tau][sigma] (summed over the workgroup below)
+          const double2 a = sA[s1][i][j];
+          rho_loc[2 * t1 + t2][2 * s1 + s2] = make_double2(zr * a.x + zi * a.y, zi * a.x - zr * a.y);
+        }
+      }
+    }
+  const double inv_tr = 1.0 / trr;
+  if (p.rho_out != nullptr) {
+    // the density matrix itself is wanted: 16 complex sums over the workgroup
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double sr = block_sum<D>(rho_loc[t][s].x, red, tid);
+        const double si = block_sum<D>(rho_loc[t][s].y, red, tid);
+        rho_loc[t][s] = make_double2(sr * inv_tr, si * inv_tr);
+      }
+  }
+  for (int q = 0; q < p.n_terms; ++q) {
+    // E_q = Re sum h_q[s][t] rho[t][s] is linear in rho: combine the thread's shares first, ONE sum over the workgroup per
+    // term instead of 32 (with the density matrix already summed every thread holds the total: no sum at all)
+    const double2* h = (const double2*)p.h + q * 16;
+    double e = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double2 hv = h[s * 4 + t];
+        e = dfma(hv.x, rho_loc[t][s].x, e);
+        e = dfma(-hv.y, rho_loc[t][s].y, e);
+      }
+    if (p.rho_out == nullptr) e = block_sum<D>(e, red, tid) * inv_tr;
+    if (tid == 0) {
+      p.E[b * p.n_terms + q] = e;
+      if (p.acc != nullptr) acc_arrive(p.acc, p.acc_shards, q, (unsigned)b, e, p.acc_bound, p.acc_scale);   // exact in-kernel cost
+    }
+  }
+  if (tid == 0) {
+    if (SOLVE) {
+      p.iters[b] = iters;
+      p.status[b] = status;
+    } else if (p.check_pd) {
+      p.status[b] = status;
+    }
+    if (p.rho_out != nullptr) {
+      double2* o = (double2*)p.rho_out + b * 16;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o[t * 4 + s] = rho_loc[t][s];
+    }
+  }
+  if (p.r_out != nullptr && SOLVE) ((double2*)p.r_out)[b * N + tid] = r;
+}
+
+template <int D>
+static hipError_t launch_block(const LaneArgs& a, bool solve, hipStream_t st) {
+  if (solve && D == 8 && a.direct != 0) {
+    if constexpr (D == 8) hipLaunchKernelGGL((energy_block_kernel<8, true, true>), dim3((unsigned)a.B), dim3(64), 0, st, a);
+  } else if (solve)
+    hipLaunchKernelGGL((energy_block_kernel<D, true>), dim3((unsigned)a.B), dim3(D * D), 0, st, a);
+  else
+    hipLaunchKernelGGL((energy_block_kernel<D, false>), dim3((unsigned)a.B), dim3(D * D), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_energy_block(int D, const LaneArgs& a, bool solve, hipStream_t st) {
+  switch (D) {
+    case 8: return launch_block<8>(a, solve, st);
+    case 16: return launch_block<16>(a, solve, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace qmps

@@ -147,6 +147,8 @@ struct Cell2Args {
 
 hipError_t launch_cell2(int D, const Cell2Args& a, hipStream_t st);
 hipError_t launch_energy(int D, const LaneArgs& a, bool solve, hipStream_t st);
+// D = 8, 16: one evaluation per workgroup of D x D threads (qmps_energy_block.hip); launch_energy dispatches here
+hipError_t launch_energy_block(int D, const LaneArgs& a, bool solve, hipStream_t st);
 // ansatz parameters [B][n_params] -> state tensors A [B][2][D][D]; kind: 0 ShallowCNOT, 1 QAOA, 2 ShallowFull (D=2), 3 ShallowCNOT3
 hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, void* A, int64_t B, hipStream_t st);
 // the same for rotosolve shift batches: B = nsh R evaluations, evaluation nsh r + k = row r with shift k on parameter *i_ptr

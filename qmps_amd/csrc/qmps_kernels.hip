@@ -1,4 +1,7 @@
-// qmps_kernels.hip - hand-written CDNA4 (gfx950) kernels for qmps's classical inner loop.
+// qmps_kernels.hip - hand-written CDNA4 (gfx950) kernels for qmps's classical inner loop: the one-evaluation-per-lane family
+// (D = 2, 4), the D = 4 squaring solver, the two-site unit cell and the whole-run D = 2 rotosolve.  The other families live in
+// qmps_direct.hip (fused D = 4), qmps_energy_block.hip (D = 8), qmps_energy_d16.hip, qmps_roto_d8.hip, qmps_overlap*.hip,
+// qmps_ansatz.hip, qmps_su.hip, qmps_brickwall.hip, qmps_util.hip.
 //
 // Hot path (per evaluation; reference = fergusfinn/qmps, cited file:line):
 //   A[2][D][D]  --(dominant fixed point of r -> sum_s A_s r A_s^+ ; replaces the xmps eigen-solve behind
@@ -1057,7 +1060,6 @@ __global__ __launch_bounds__(64) void cell2_lane_kernel(Cell2Args p) {
 // once more.  iterations = power steps applied to the start matrix (done + 2^skip + 2^m + ...).
 // Items: the worklist written by the lane kernel, or (work_idx == nullptr) all of 0 .. B-1.
 // ------------------------------------------------------------------------------------------
-typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // Coordinates (kernel-local): a = 4 i + i' packs a Hermitian 4 x 4 matrix r into a real one -
 //   x[(i,i)] = r_ii,   x[(i,i')] = sqrt2 Re r_ii' (i < i'),   x[(i,i')] = sqrt2 Im r_i'i (i > i')
@@ -1296,981 +1298,6 @@ __global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(S
 }
 
 // ------------------------------------------------------------------------------------------
-// Kernel 1d: D = 16 power iteration on the matrix cores, ONE WAVE PER EVALUATION, no LDS traffic in
-// the products.  A complex 16 x 16 x 16 product is 4 real v_mfma_f64_16x16x4_f64 chains; layouts:
-//   A operand, slab kk : lane (g, c) holds M[row = c][k = 4 kk + g]      ("A-layout")
-//   B operand, slab kk : lane (g, c) holds M[k = 4 kk + g][col = c]      ("B-layout")
-//   C / D, register q  : lane (g, c) holds M[row = 4 q + g][col = c]     (== B-layout with kk = q)
-// One power step r' = sum_s A_s r A_s^+ is done as  Y_s = r A_s^+ ,  r' += A_s Y_s :
-//   * r lives in C-layout; because r is Hermitian its A-layout is conj(C-layout) - same registers;
-//   * A_s lives ONCE, in A-layout; A_s^+ in B-layout is conj(A-layout of A_s) - same registers;
-//   * Y_s comes out in C-layout == the B operand of the second product.
-// So the whole iteration runs register-to-register: 64 MFMAs per step, plus one LDS transpose per
-// step to re-hermitise r'.  status/iters semantics as in the other kernels.
-// ------------------------------------------------------------------------------------------
-struct C4 {   // a complex matrix in C-layout: 4 registers re, 4 registers im
-  v4f64 re, im;
-};
-
-// C += P * Q with P given in A-layout (pa_re/pa_im[kk]) and Q in B-layout (C-layout registers)
-__device__ __forceinline__ void cmma(const double (&pre)[4], const double (&pim)[4], const double (&pimn)[4],
-                                     const v4f64& qre, const v4f64& qim, v4f64& cre, v4f64& cim) {
-  // Three real products per k-slab instead of four (round 3, as in qmps_overlap.hip: K1 = (Pr + Pi) Qr, K2 = Pr (Qi - Qr),
-  // K3 = Pi (Qr + Qi); Re = K1 - K3, Im = K1 + K2): 12 v_mfma_f64_16x16x4 per complex product instead of 16, in three
-  // independent accumulator chains - the matrix pipe (~100 cycles per instruction on this part) bounds these kernels.
-  (void)pimn;
-  v4f64 k1 = {0, 0, 0, 0}, k2 = {0, 0, 0, 0}, k3 = {0, 0, 0, 0};
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const double ps = pre[kk] + pim[kk], qd = qim[kk] - qre[kk], qs = qre[kk] + qim[kk];
-    k1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ps, qre[kk], k1, 0, 0, 0);
-    k2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pre[kk], qd, k2, 0, 0, 0);
-    k3 = __builtin_amdgcn_mfma_f64_16x16x4f64(pim[kk], qs, k3, 0, 0, 0);
-  }
-  cre += k1 - k3;
-  cim += k1 + k2;
-}
-
-
-template <bool SOLVE>
-__global__ __launch_bounds__(256) void energy_mfma_d16_kernel(LaneArgs p) {
-  constexpr int D = 16, LD = 17, WAVES = 4;
-  __shared__ double2 sT_all[WAVES][D * LD];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  double2* sT = sT_all[wave];
-  const double tol2 = p.tol * p.tol;
-  if (p.acc_zero != nullptr && blockIdx.x == 0) acc_clear(p.acc_zero, p.n_terms, threadIdx.x, 256);   // accumulator of a later step
-  for (int64_t b = (int64_t)blockIdx.x * WAVES + wave; b < p.B; b += (int64_t)gridDim.x * WAVES) {
-    // A_s in A-layout (and the negated imaginary part, MFMA has no operand negation for f64)
-    double are[2][4], aim[2][4], aimn[2][4];
-    const double2* Ab = (const double2*)p.A + b * (2 * D * D);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const double2 v = Ab[(s * D + c) * D + 4 * kk + g];
-        are[s][kk] = v.x;
-        aim[s][kk] = v.y;
-        aimn[s][kk] = -v.y;
-      }
-    // r in C-layout
-    C4 r;
-    if (p.r_in != nullptr) {
-      const double2* gi = (const double2*)p.r_in + b * (D * D);
-      double tr = 0.0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double2 u = gi[(4 * q + g) * D + c], l = gi[c * D + 4 * q + g];
-        r.re[q] = 0.5 * (u.x + l.x);
-        r.im[q] = 0.5 * (u.y - l.y);
-        tr += (c == 4 * q + g) ? r.re[q] : 0.0;
-      }
-      const double inv = 1.0 / wave_sum(tr);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        r.re[q] *= inv;
-        r.im[q] *= inv;
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        r.re[q] = (c == 4 * q + g) ? 1.0 / D : 0.0;
-        r.im[q] = 0.0;
-      }
-    }
-    int iters = 0, status = SOLVE ? QMPS_ST_NOT_CONVERGED : QMPS_ST_OK;
-    for (int k = 1; SOLVE && k <= p.max_iter; ++k) {
-      C4 n;
-      n.re = (v4f64){0, 0, 0, 0};
-      n.im = (v4f64){0, 0, 0, 0};
-      // A-layout of r = conj(C-layout): re as is, im negated; its negated imaginary part = + r.im
-      double rre[4], rimn[4], rim[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        rre[q] = r.re[q];
-        rim[q] = -r.im[q];
-        rimn[q] = r.im[q];
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        // Y = r A_s^+ : B operand = conj(A-layout of A_s) = (are, -aim)
-        C4 y;
-        y.re = (v4f64){0, 0, 0, 0};
-        y.im = (v4f64){0, 0, 0, 0};
-        v4f64 bre = {are[s][0], are[s][1], are[s][2], are[s][3]};
-        v4f64 bim = {aimn[s][0], aimn[s][1], aimn[s][2], aimn[s][3]};
-        cmma(rre, rim, rimn, bre, bim, y.re, y.im);
-        // r' += A_s Y
-        cmma(are[s], aim[s], aimn[s], y.re, y.im, n.re, n.im);
-      }
-      // hermitise through a padded LDS transpose, trace-normalise, compare
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) sT[(4 * q + g) * LD + c] = make_double2(n.re[q], n.im[q]);
-      __builtin_amdgcn_wave_barrier();
-      double tr = 0.0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double2 t = sT[c * LD + 4 * q + g];      // n[c][4 q + g]
-        const bool diag = (c == 4 * q + g);
-        n.re[q] = 0.5 * (n.re[q] + t.x);
-        n.im[q] = diag ? 0.0 : 0.5 * (n.im[q] - t.y);
-        tr += diag ? n.re[q] : 0.0;
-      }
-      const double inv = 1.0 / wave_sum(tr);
-      double dpart = 0.0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        n.re[q] *= inv;
-        n.im[q] *= inv;
-        const double dr = n.re[q] - r.re[q], di = n.im[q] - r.im[q];
-        dpart = dfma(dr, dr, dpart);
-        dpart = dfma(di, di, dpart);
-      }
-      const double d2 = lane0(wave_sum(dpart));
-      r = n;
-      iters = k;
-      if (d2 < tol2) {
-        status = QMPS_ST_OK;
-        break;
-      }
-    }
-    if (SOLVE && p.r_out != nullptr) {
-      double2* ro = (double2*)p.r_out + b * (D * D);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) ro[(4 * q + g) * D + c] = make_double2(r.re[q], r.im[q]);
-    }
-    // ---- positive-definiteness (the reference's cholesky(r), qmps/tools.py:182): column Cholesky on the
-    // LDS copy, one lane per row (lanes 0..15), pivot test by lane 0 semantics (wave-uniform result)
-    if (!SOLVE && p.check_pd) status = p.status[b];
-    if ((SOLVE || p.check_pd) && status == QMPS_ST_OK) {
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) sT[(4 * q + g) * LD + c] = make_double2(r.re[q], r.im[q]);
-      __builtin_amdgcn_wave_barrier();
-      bool ok = true;
-      // right-looking: after column j is scaled, rows i > j update their trailing entries; lane = row i
-      for (int j = 0; j < D; ++j) {
-        const double d = sT[j * LD + j].x;              // current pivot (already updated)
-        if (!(d > 0.0)) { ok = false; break; }
-        const double inv = 1.0 / __builtin_sqrt(d);
-        __builtin_amdgcn_wave_barrier();
-        double2 lij = make_double2(0.0, 0.0);
-        if (lane < D && lane > j) {
-          const double2 v = sT[lane * LD + j];
-          lij = make_double2(v.x * inv, v.y * inv);
-          sT[lane * LD + j] = lij;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < D && lane > j) {
-          // row `lane`: a[lane][k] -= l[lane][j] conj(l[k][j]) for j < k <= lane
-          for (int k = j + 1; k <= lane; ++k) {
-            const double2 lkj = sT[k * LD + j];
-            double2 a = sT[lane * LD + k];
-            a.x -= lij.x * lkj.x + lij.y * lkj.y;
-            a.y -= lij.y * lkj.x - lij.x * lkj.y;
-            sT[lane * LD + k] = a;
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      if (!ok) status = QMPS_ST_NOT_PD;
-    }
-    // ---- energy on the matrix cores: rho[(t1 t2)][(s1 s2)] = tr(A_t1 (A_t2 r A_s2^+) A_s1^+)/tr r
-    //   Y_s2 = r A_s2^+ ;  R = A_t2 Y_s2 ;  Z = A_t1 R  (all C-layout) ;  rho = <A_s1, Z>_F  (wave reduction)
-    double cre[2][4], cim[2][4];      // A_s in C-layout for the final inner products
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double2 v = Ab[(s * D + 4 * q + g) * D + c];
-        cre[s][q] = v.x;
-        cim[s][q] = v.y;
-      }
-    double trp = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) trp += (c == 4 * q + g) ? r.re[q] : 0.0;
-    const double inv_tr = 1.0 / wave_sum(trp);
-    double rre[4], rimn[4], rim[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      rre[q] = r.re[q];
-      rim[q] = -r.im[q];
-      rimn[q] = r.im[q];
-    }
-    __builtin_amdgcn_wave_barrier();      // sT is free again: rho[t][s] (wave-uniform) is parked in its first 16 slots
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      C4 y;
-      y.re = (v4f64){0, 0, 0, 0};
-      y.im = (v4f64){0, 0, 0, 0};
-      v4f64 bre = {are[s2][0], are[s2][1], are[s2][2], are[s2][3]};
-      v4f64 bim = {aimn[s2][0], aimn[s2][1], aimn[s2][2], aimn[s2][3]};
-      cmma(rre, rim, rimn, bre, bim, y.re, y.im);
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        C4 R;
-        R.re = (v4f64){0, 0, 0, 0};
-        R.im = (v4f64){0, 0, 0, 0};
-        cmma(are[t2], aim[t2], aimn[t2], y.re, y.im, R.re, R.im);
-#pragma unroll
-        for (int t1 = 0; t1 < 2; ++t1) {
-          C4 Z;
-          Z.re = (v4f64){0, 0, 0, 0};
-          Z.im = (v4f64){0, 0, 0, 0};
-          cmma(are[t1], aim[t1], aimn[t1], R.re, R.im, Z.re, Z.im);
-#pragma unroll
-          for (int s1 = 0; s1 < 2; ++s1) {
-            double pr = 0.0, pi = 0.0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {   // Z conj(A_s1)
-              pr = dfma(Z.re[q], cre[s1][q], pr);
-              pr = dfma(Z.im[q], cim[s1][q], pr);
-              pi = dfma(Z.im[q], cre[s1][q], pi);
-              pi = dfma(-Z.re[q], cim[s1][q], pi);
-            }
-            const double sr = wave_sum(pr) * inv_tr, si = wave_sum(pi) * inv_tr;
-            if (lane == 0) sT[(2 * t1 + t2) * 4 + 2 * s1 + s2] = make_double2(sr, si);
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-      for (int q = 0; q < p.n_terms; ++q) {
-        const double2* h = (const double2*)p.h + q * 16;
-        double e = 0.0;
-        for (int s = 0; s < 4; ++s)
-          for (int t = 0; t < 4; ++t) {
-            const double2 hv = h[s * 4 + t], rv = sT[t * 4 + s];
-            e += hv.x * rv.x - hv.y * rv.y;
-          }
-        p.E[b * p.n_terms + q] = e;
-        if (p.acc != nullptr) acc_arrive(p.acc, p.acc_shards, q, (unsigned)b, e, p.acc_bound, p.acc_scale);   // exact in-kernel cost
-      }
-      if (SOLVE) p.iters[b] = iters;
-      if (SOLVE || p.check_pd) p.status[b] = status;
-    }
-    if (p.rho_out != nullptr && lane < 16) ((double2*)p.rho_out)[b * 16 + lane] = sT[lane];
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Kernel 1d': the same with TWO WAVES PER EVALUATION (small batches: BASELINE.json configs[4] shards its trajectories, a GPU
-// holds tens to hundreds of evaluations).  Wave w owns the physical index s = w: its half of the step is Y = r A_w^+,
-// n_w = A_w Y (32 of the 64 MFMAs), the halves are summed through LDS in the same order by both waves (bit-identical
-// iterates, identical decisions); the density matrix is split by s2 = w the same way.  One wave per evaluation leaves a
-// quarter of the SIMDs idle at B = 768 and runs every dependent MFMA chain on one matrix pipe.
-// ------------------------------------------------------------------------------------------
-template <bool SOLVE>
-__global__ __launch_bounds__(128) void energy_mfma_d16x2_kernel(LaneArgs p) {
-  constexpr int D = 16, LD = 17, WAVES = 2;
-  __shared__ double2 sT_all[WAVES][D * LD];          // wave-private transposes
-  __shared__ double2 sX_all[WAVES][D * D];           // exchange: one C-layout matrix per wave, element (q, lane) at [q * 64 + lane]
-  __shared__ double2 sRho[16];                        // rho[t][s], entries with s2 = w written by wave w
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  double2* sT = sT_all[wave];
-  const double tol2 = p.tol * p.tol;
-  if (p.acc_zero != nullptr && blockIdx.x == 0) acc_clear(p.acc_zero, p.n_terms, threadIdx.x, 128);   // accumulator of a later step
-  for (int64_t b = blockIdx.x; b < p.B; b += gridDim.x) {
-    // A_s in A-layout (and the negated imaginary part, MFMA has no operand negation for f64)
-    double are[2][4], aim[2][4], aimn[2][4];
-    const double2* Ab = (const double2*)p.A + b * (2 * D * D);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const double2 v = Ab[(s * D + c) * D + 4 * kk + g];
-        are[s][kk] = v.x;
-        aim[s][kk] = v.y;
-        aimn[s][kk] = -v.y;
-      }
-    // r in C-layout
-    C4 r;
-    if (p.r_in != nullptr) {
-      const double2* gi = (const double2*)p.r_in + b * (D * D);
-      double tr = 0.0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double2 u = gi[(4 * q + g) * D + c], l = gi[c * D + 4 * q + g];
-        r.re[q] = 0.5 * (u.x + l.x);
-        r.im[q] = 0.5 * (u.y - l.y);
-        tr += (c == 4 * q + g) ? r.re[q] : 0.0;
-      }
-      const double inv = 1.0 / wave_sum(tr);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        r.re[q] *= inv;
-        r.im[q] *= inv;
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        r.re[q] = (c == 4 * q + g) ? 1.0 / D : 0.0;
-        r.im[q] = 0.0;
-      }
-    }
-    int iters = 0, status = SOLVE ? QMPS_ST_NOT_CONVERGED : QMPS_ST_OK;
-    for (int k = 1; SOLVE && k <= p.max_iter; ++k) {
-      C4 n;
-      n.re = (v4f64){0, 0, 0, 0};
-      n.im = (v4f64){0, 0, 0, 0};
-      // A-layout of r = conj(C-layout): re as is, im negated; its negated imaginary part = + r.im
-      double rre[4], rimn[4], rim[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        rre[q] = r.re[q];
-        rim[q] = -r.im[q];
-        rimn[q] = r.im[q];
-      }
-      {
-        // this wave's physical index s = wave:  Y = r A_s^+ (B operand = conj(A-layout of A_s) = (are, -aim)),  n_s = A_s Y
-        const int s = wave;
-        C4 y, part;
-        y.re = (v4f64){0, 0, 0, 0};
-        y.im = (v4f64){0, 0, 0, 0};
-        part.re = (v4f64){0, 0, 0, 0};
-        part.im = (v4f64){0, 0, 0, 0};
-        v4f64 bre = {are[s][0], are[s][1], are[s][2], are[s][3]};
-        v4f64 bim = {aimn[s][0], aimn[s][1], aimn[s][2], aimn[s][3]};
-        cmma(rre, rim, rimn, bre, bim, y.re, y.im);
-        cmma(are[s], aim[s], aimn[s], y.re, y.im, part.re, part.im);
-        // r' = n_0 + n_1 through LDS, summed in the same order by both waves (bit-identical iterates, identical decisions)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sX_all[wave][q * 64 + lane] = make_double2(part.re[q], part.im[q]);
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < 2; ++w)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const double2 v = sX_all[w][q * 64 + lane];
-            n.re[q] += v.x;
-            n.im[q] += v.y;
-          }
-        __syncthreads();
-      }
-      // hermitise through a padded LDS transpose, trace-normalise, compare
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) sT[(4 * q + g) * LD + c] = make_double2(n.re[q], n.im[q]);
-      __builtin_amdgcn_wave_barrier();
-      double tr = 0.0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double2 t = sT[c * LD + 4 * q + g];      // n[c][4 q + g]
-        const bool diag = (c == 4 * q + g);
-        n.re[q] = 0.5 * (n.re[q] + t.x);
-        n.im[q] = diag ? 0.0 : 0.5 * (n.im[q] - t.y);
-        tr += diag ? n.re[q] : 0.0;
-      }
-      const double inv = 1.0 / wave_sum(tr);
-      double dpart = 0.0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        n.re[q] *= inv;
-        n.im[q] *= inv;
-        const double dr = n.re[q] - r.re[q], di = n.im[q] - r.im[q];
-        dpart = dfma(dr, dr, dpart);
-        dpart = dfma(di, di, dpart);
-      }
-      const double d2 = lane0(wave_sum(dpart));
-      r = n;
-      iters = k;
-      if (d2 < tol2) {
-        status = QMPS_ST_OK;
-        break;
-      }
-    }
-    if (SOLVE && p.r_out != nullptr && wave == 0) {
-      double2* ro = (double2*)p.r_out + b * (D * D);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) ro[(4 * q + g) * D + c] = make_double2(r.re[q], r.im[q]);
-    }
-    // ---- positive-definiteness (the reference's cholesky(r), qmps/tools.py:182): column Cholesky on the
-    // LDS copy, one lane per row (lanes 0..15), pivot test by lane 0 semantics (wave-uniform result)
-    if (!SOLVE && p.check_pd) status = p.status[b];
-    if ((SOLVE || p.check_pd) && status == QMPS_ST_OK && wave == 0) {
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) sT[(4 * q + g) * LD + c] = make_double2(r.re[q], r.im[q]);
-      __builtin_amdgcn_wave_barrier();
-      bool ok = true;
-      // right-looking: after column j is scaled, rows i > j update their trailing entries; lane = row i
-      for (int j = 0; j < D; ++j) {
-        const double d = sT[j * LD + j].x;              // current pivot (already updated)
-        if (!(d > 0.0)) { ok = false; break; }
-        const double inv = 1.0 / __builtin_sqrt(d);
-        __builtin_amdgcn_wave_barrier();
-        double2 lij = make_double2(0.0, 0.0);
-        if (lane < D && lane > j) {
-          const double2 v = sT[lane * LD + j];
-          lij = make_double2(v.x * inv, v.y * inv);
-          sT[lane * LD + j] = lij;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < D && lane > j) {
-          // row `lane`: a[lane][k] -= l[lane][j] conj(l[k][j]) for j < k <= lane
-          for (int k = j + 1; k <= lane; ++k) {
-            const double2 lkj = sT[k * LD + j];
-            double2 a = sT[lane * LD + k];
-            a.x -= lij.x * lkj.x + lij.y * lkj.y;
-            a.y -= lij.y * lkj.x - lij.x * lkj.y;
-            sT[lane * LD + k] = a;
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      if (!ok) status = QMPS_ST_NOT_PD;
-    }
-    // ---- energy on the matrix cores: rho[(t1 t2)][(s1 s2)] = tr(A_t1 (A_t2 r A_s2^+) A_s1^+)/tr r
-    //   Y_s2 = r A_s2^+ ;  R = A_t2 Y_s2 ;  Z = A_t1 R  (all C-layout) ;  rho = <A_s1, Z>_F  (wave reduction)
-    double cre[2][4], cim[2][4];      // A_s in C-layout for the final inner products
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double2 v = Ab[(s * D + 4 * q + g) * D + c];
-        cre[s][q] = v.x;
-        cim[s][q] = v.y;
-      }
-    double trp = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) trp += (c == 4 * q + g) ? r.re[q] : 0.0;
-    const double inv_tr = 1.0 / wave_sum(trp);
-    double rre[4], rimn[4], rim[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      rre[q] = r.re[q];
-      rim[q] = -r.im[q];
-      rimn[q] = r.im[q];
-    }
-    __builtin_amdgcn_wave_barrier();      // sT is free again: rho[t][s] (wave-uniform) is parked in its first 16 slots
-    {
-      const int s2 = wave;             // this wave's half of the density matrix
-      C4 y;
-      y.re = (v4f64){0, 0, 0, 0};
-      y.im = (v4f64){0, 0, 0, 0};
-      v4f64 bre = {are[s2][0], are[s2][1], are[s2][2], are[s2][3]};
-      v4f64 bim = {aimn[s2][0], aimn[s2][1], aimn[s2][2], aimn[s2][3]};
-      cmma(rre, rim, rimn, bre, bim, y.re, y.im);
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        C4 R;
-        R.re = (v4f64){0, 0, 0, 0};
-        R.im = (v4f64){0, 0, 0, 0};
-        cmma(are[t2], aim[t2], aimn[t2], y.re, y.im, R.re, R.im);
-#pragma unroll
-        for (int t1 = 0; t1 < 2; ++t1) {
-          C4 Z;
-          Z.re = (v4f64){0, 0, 0, 0};
-          Z.im = (v4f64){0, 0, 0, 0};
-          cmma(are[t1], aim[t1], aimn[t1], R.re, R.im, Z.re, Z.im);
-#pragma unroll
-          for (int s1 = 0; s1 < 2; ++s1) {
-            double pr = 0.0, pi = 0.0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {   // Z conj(A_s1)
-              pr = dfma(Z.re[q], cre[s1][q], pr);
-              pr = dfma(Z.im[q], cim[s1][q], pr);
-              pi = dfma(Z.im[q], cre[s1][q], pi);
-              pi = dfma(-Z.re[q], cim[s1][q], pi);
-            }
-            const double sr = wave_sum(pr) * inv_tr, si = wave_sum(pi) * inv_tr;
-            if (lane == 0) sRho[(2 * t1 + t2) * 4 + 2 * s1 + s2] = make_double2(sr, si);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    if (wave == 0 && lane == 0) {
-      for (int q = 0; q < p.n_terms; ++q) {
-        const double2* h = (const double2*)p.h + q * 16;
-        double e = 0.0;
-        for (int s = 0; s < 4; ++s)
-          for (int t = 0; t < 4; ++t) {
-            const double2 hv = h[s * 4 + t], rv = sRho[t * 4 + s];
-            e += hv.x * rv.x - hv.y * rv.y;
-          }
-        p.E[b * p.n_terms + q] = e;
-        if (p.acc != nullptr) acc_arrive(p.acc, p.acc_shards, q, (unsigned)b, e, p.acc_bound, p.acc_scale);   // exact in-kernel cost
-      }
-      if (SOLVE) p.iters[b] = iters;
-      if (SOLVE || p.check_pd) p.status[b] = status;
-    }
-    if (p.rho_out != nullptr && wave == 0 && lane < 16) ((double2*)p.rho_out)[b * 16 + lane] = sRho[lane];
-    __syncthreads();
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Kernel 2: D = 8, 16 - one evaluation per workgroup of D x D threads, tiles in LDS.
-// Thread (i, j) owns r[i][j].  First correct version of the large-D path.
-// ------------------------------------------------------------------------------------------
-template <int D>
-__device__ __forceinline__ double block_sum(double v, double* red, int tid) {
-  // sum over the D*D threads of the workgroup; result broadcast to every thread
-  constexpr int N = D * D;
-  v = wave_sum(v);   // DPP row rotations + permlane swaps: VALU only, ~20 instructions
-  if (N > 64) {
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    v = 0.0;
-#pragma unroll
-    for (int w = 0; w < N / 64; ++w) v += red[w];
-  }
-  return v;
-}
-
-// FUSED8 (D = 8, SOLVE): the direct fixed-point solve (qmps_direct_d8.h) runs in front, in the same wave - solve, acceptance
-// step and energies in ONE launch (the small batches of BASELINE.json configs[3] are all launch latency).  A separate
-// instantiation: the solve needs ~190 VGPRs, the plain block kernel runs four waves per SIMD.
-template <int D, bool SOLVE, bool FUSED8 = false>
-__global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
-  constexpr int N = D * D;
-  constexpr int P = D + 1;  // padded row (in double2 units) against bank conflicts
-  __shared__ double2 sA[2][D][P];
-  __shared__ double2 sR[D][P];
-  __shared__ double2 sX[2][D][P];
-  __shared__ double2 sT[2][D][P];
-  __shared__ double red[8];
-  const int tid = threadIdx.x;
-  const int i = tid / D, j = tid % D;
-  const int64_t b = blockIdx.x;
-  if (b >= p.B) return;
-  if (p.acc_zero != nullptr && blockIdx.x == 0) acc_clear(p.acc_zero, p.n_terms, tid, N);   // accumulator of a later step
-
-  {
-    const double2* a = (const double2*)p.A + b * (2 * N);
-    sA[0][i][j] = a[tid];
-    sA[1][i][j] = a[N + tid];
-  }
-  double2 r;
-  if constexpr (FUSED8) {
-    __shared__ double sM8[64][17];
-    __shared__ double sT8[8][9];
-    __builtin_amdgcn_wave_barrier();
-    __syncthreads();
-    r = env_direct_d8_solve(sA, sT8, sM8, tid);
-  } else if (p.r_in != nullptr) {
-    const double2* g = (const double2*)p.r_in + b * N;
-    const double2 u = g[i * D + j], l = g[j * D + i];
-    r = make_double2(0.5 * (u.x + l.x), (i == j) ? 0.0 : 0.5 * (u.y - l.y));
-    const double tr = block_sum<D>(i == j ? r.x : 0.0, red, tid);
-    r.x /= tr;
-    r.y /= tr;
-  } else {
-    r = make_double2(i == j ? 1.0 / D : 0.0, 0.0);
-  }
-  sR[i][j] = r;
-  __syncthreads();
-
-  // D = 8: row i of A (for X = A r) lives in registers; row j (for r' = X A^+), the r column and the X row
-  // come from LDS (40 instead of 56 ds_read_b128 per step) - keeps the kernel at 4 waves per SIMD, which
-  // matters more here: the step is latency-bound (two LDS round trips + two reductions per step).  D = 16 keeps them in LDS (register budget);
-  // that instantiation is only the fallback behind the MFMA kernel.
-  constexpr bool kRowsInRegs = (D == 8);
-  constexpr int RD = kRowsInRegs ? D : 1;
-  double2 ai_[2][RD];
-  if constexpr (kRowsInRegs) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int k = 0; k < D; ++k) ai_[s][k] = sA[s][i][k];
-  }
-  auto apply = [&](double2& out) {
-    // X_s[i][j] = sum_k A_s[i][k] r[k][j]
-    double2 rc[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) rc[k] = sR[k][j];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      double xr = 0.0, xi = 0.0;
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        double2 a;
-        if constexpr (kRowsInRegs) a = ai_[s][k]; else a = sA[s][i][k];
-        const double2 rr = rc[k];
-        xr = dfma(a.x, rr.x, xr);
-        xr = dfma(-a.y, rr.y, xr);
-        xi = dfma(a.x, rr.y, xi);
-        xi = dfma(a.y, rr.x, xi);
-      }
-      sX[s][i][j] = make_double2(xr, xi);
-    }
-    __syncthreads();
-    double nr = 0.0, ni = 0.0;
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const double2 a = sA[s][j][k];
-        const double2 x = sX[s][i][k];
-        nr = dfma(x.x, a.x, nr);
-        nr = dfma(x.y, a.y, nr);
-        ni = dfma(x.y, a.x, ni);
-        ni = dfma(-x.x, a.y, ni);
-      }
-    out = make_double2(nr, ni);
-  };
-
-  int iters = 0, status = QMPS_ST_OK;
-  if (SOLVE) {
-    status = QMPS_ST_NOT_CONVERGED;
-    const double tol2 = p.tol * p.tol;
-    for (int k = 1; k <= p.max_iter; ++k) {
-      double2 n;
-      apply(n);
-      // hermitise through LDS, normalise by the trace
-      sT[0][i][j] = n;
-      __syncthreads();
-      const double2 m = sT[0][j][i];
-      n = make_double2(0.5 * (n.x + m.x), (i == j) ? 0.0 : 0.5 * (n.y - m.y));
-      const double tr = block_sum<D>(i == j ? n.x : 0.0, red, tid);
-      const double inv = 1.0 / tr;
-      n.x *= inv;
-      n.y *= inv;
-      const double dr = n.x - r.x, di = n.y - r.y;
-      const double d2 = block_sum<D>(dr * dr + di * di, red, tid);
-      r = n;
-      sR[i][j] = r;
-      __syncthreads();
-      iters = k;
-      if (d2 < tol2) {
-        status = QMPS_ST_OK;
-        break;
-      }
-    }
-  }
-  if (!SOLVE && p.check_pd) status = p.status[b];
-  if (SOLVE || p.check_pd) {
-    if (status == QMPS_ST_OK) {
-      // Positive definiteness (the criterion of cholesky(r), qmps/tools.py:182): the pivots of LDL^H, all D^2 threads at
-      // once - thread (i, j) owns the Schur-complement entry S[i][j]; per pivot one LDS round trip (column c and the pivot),
-      // S[i][j] -= S[i][c] conj(S[j][c]) / S[c][c].  (A single thread walking the Cholesky recurrence through LDS took
-      // ~6 us of the 22 us this kernel needs per evaluation at D = 8.)
-      double2 S = r;
-      bool ok = true;
-      for (int c = 0; c < D; ++c) {
-        __syncthreads();
-        sT[1][i][j] = S;
-        __syncthreads();
-        const double pc = sT[1][c][c].x;
-        ok = ok && (pc > 0.0);
-        const double2 li = sT[1][i][c], lj = sT[1][j][c];
-        const double inv = fast_rcp(pc);
-        const double wr = (li.x * lj.x + li.y * lj.y) * inv, wi = (li.y * lj.x - li.x * lj.y) * inv;
-        S.x -= wr;
-        S.y -= wi;
-      }
-      if (!ok) status = QMPS_ST_NOT_PD;
-      __syncthreads();
-    }
-  }
-
-  // ---- energy: rho[tau][sigma] = tr(A_t1 (A_t2 r A_s2^+) A_s1^+)
-  const double trr = block_sum<D>(i == j ? r.x : 0.0, red, tid);
-  double2 rho_loc[4][4];
-  // X_t2 = A_t2 r  (both t2) -> sX
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    double xr = 0.0, xi = 0.0;
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      const double2 a = sA[s][i][k], rr = sR[k][j];
-      xr = dfma(a.x, rr.x, xr);
-      xr = dfma(-a.y, rr.y, xr);
-      xi = dfma(a.x, rr.y, xi);
-      xi = dfma(a.y, rr.x, xi);
-    }
-    sX[s][i][j] = make_double2(xr, xi);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      // R[i][j] = sum_k X_t2[i][k] conj(A_s2[j][k]) -> sT[0]
-      double cr = 0.0, ci = 0.0;
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const double2 x = sX[t2][i][k], a = sA[s2][j][k];
-        cr = dfma(x.x, a.x, cr);
-        cr = dfma(x.y, a.y, cr);
-        ci = dfma(x.y, a.x, ci);
-        ci = dfma(-x.x, a.y, ci);
-      }
-      __syncthreads();
-      sT[0][i][j] = make_double2(cr, ci);
-      __syncthreads();
-#pragma unroll
-      for (int t1 = 0; t1 < 2; ++t1) {
-        // Z[i][j] = sum_k A_t1[i][k] R[k][j]
-        double zr = 0.0, zi = 0.0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-          const double2 a = sA[t1][i][k], rr = sT[0][k][j];
-          zr = dfma(a.x, rr.x, zr);
-          zr = dfma(-a.y, rr.y, zr);
-          zi = dfma(a.x, rr.y, zi);
-          zi = dfma(a.y, rr.x, zi);
-        }
-#pragma unroll
-        for (int s1 = 0; s1 < 2; ++s1) {
-          // this thread's share of rho[tau][sigma] (summed over the workgroup below)
-          const double2 a = sA[s1][i][j];
-          rho_loc[2 * t1 + t2][2 * s1 + s2] = make_double2(zr * a.x + zi * a.y, zi * a.x - zr * a.y);
-        }
-      }
-    }
-  const double inv_tr = 1.0 / trr;
-  if (p.rho_out != nullptr) {
-    // the density matrix itself is wanted: 16 complex sums over the workgroup
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double sr = block_sum<D>(rho_loc[t][s].x, red, tid);
-        const double si = block_sum<D>(rho_loc[t][s].y, red, tid);
-        rho_loc[t][s] = make_double2(sr * inv_tr, si * inv_tr);
-      }
-  }
-  for (int q = 0; q < p.n_terms; ++q) {
-    // E_q = Re sum h_q[s][t] rho[t][s] is linear in rho: combine the thread's shares first, ONE sum over the workgroup per
-    // term instead of 32 (with the density matrix already summed every thread holds the total: no sum at all)
-    const double2* h = (const double2*)p.h + q * 16;
-    double e = 0.0;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const double2 hv = h[s * 4 + t];
-        e = dfma(hv.x, rho_loc[t][s].x, e);
-        e = dfma(-hv.y, rho_loc[t][s].y, e);
-      }
-    if (p.rho_out == nullptr) e = block_sum<D>(e, red, tid) * inv_tr;
-    if (tid == 0) {
-      p.E[b * p.n_terms + q] = e;
-      if (p.acc != nullptr) acc_arrive(p.acc, p.acc_shards, q, (unsigned)b, e, p.acc_bound, p.acc_scale);   // exact in-kernel cost
-    }
-  }
-  if (tid == 0) {
-    if (SOLVE) {
-      p.iters[b] = iters;
-      p.status[b] = status;
-    } else if (p.check_pd) {
-      p.status[b] = status;
-    }
-    if (p.rho_out != nullptr) {
-      double2* o = (double2*)p.rho_out + b * 16;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) o[t * 4 + s] = rho_loc[t][s];
-    }
-  }
-  if (p.r_out != nullptr && SOLVE) ((double2*)p.r_out)[b * N + tid] = r;
-}
-
-// ------------------------------------------------------------------------------------------
-// Kernel 3: unitary_to_tensor (qmps/tools.py:151-154):  A[b][s][i][j] = U[b][2 i + s][j], j < D
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void unitary_to_tensor_kernel(const double2* __restrict__ U,
-                                                                double2* __restrict__ A, int D, int64_t total) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int n = D * D;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t b = t / (2 * n);
-    const int e = (int)(t % (2 * n));
-    const int s = e / n, i = (e / D) % D, j = e % D;
-    A[t] = U[b * (4 * n) + (int64_t)(2 * i + s) * (2 * D) + j];
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Kernel 3b: ansatz parameters -> state tensor on the device (qmps/represent.py:268-404).
-// Thread (b, j) simulates the ansatz circuit on the basis state |0>|j> of the n + 1 = log2(2 D) qubit
-// register (big-endian: qubit 0 is the most significant bit) - i.e. column j < D of the unitary, which
-// is all unitary_to_tensor keeps (qmps/tools.py:151-154): A[s][i][j] = U[2 i + s][j].  The 2 D
-// amplitudes live in registers; CNOTs are register renames.  HBM input drops from 64 D^2 bytes (U) to
-// 8 P bytes (parameters) per evaluation.
-//   kind 0: ShallowCNOTStateTensor   per (beta, gamma): rz(beta) all, rx(gamma) all, H(q0), CNOT ladder
-//   kind 1: ShallowQAOAStateTensor   per (beta, gamma): X**beta all, ZZ**gamma neighbours
-//   kind 2: ShallowFullStateTensor   15 angles, two qubits (D = 2)
-//   kind 3: ShallowCNOTStateTensor3  per (beta, gamma, omega): rz, rx, rz all, H(q0), CNOT ladder
-//   kind 4: ShallowCNOTStateTensor_nonuniform  per layer 2 (n + 1) angles: rz(p[i]), rx(p[i + n + 1]) on qubit i, CNOT ladder
-//   kind 5: ExactAfter4              per layer 6 angles on qubits 0, 1, CNOT ladder, cyclic SWAPs
-//   kind 6: StateGate                6 angles, two qubits (D = 2): rx, rx, rz, rz, XX**e, YY**f
-// ------------------------------------------------------------------------------------------
-// (Reg<NQ>, ansatz_circuit, roto_shift_value: qmps_circuit.h)
-template <int D, int KIND>
-// nsh > 0: rotosolve shift batches without a separate shift-build kernel - evaluation b = nsh r + k is restart r (parameter
-// row r) with shift k added to parameter *i_ptr
-// fd_h != 0: central-difference batches - nsh = 2 P evaluations per row, evaluation nsh r + k = row r with +fd_h (k < P) or
-// -fd_h (k >= P) added to parameter k mod P
-__global__ __launch_bounds__(64) void ansatz_tensor_kernel(const double* __restrict__ params, int n_params,
-                                                           double2* __restrict__ A, int64_t B, int nsh,
-                                                           const int* __restrict__ i_ptr, double fd_h) {
-  constexpr int NQ = (D == 2 ? 2 : D == 4 ? 3 : D == 8 ? 4 : 5);
-  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  const int64_t b = t / D;
-  const int j = (int)(t % D);
-  if (b >= B) return;
-  const int64_t row = nsh > 0 ? b / nsh : b;
-  const int shift_k = nsh > 0 ? (int)(b - row * nsh) : 0;
-  const bool fd = fd_h != 0.0;
-  const int isel = nsh > 0 ? (fd ? shift_k % n_params : *i_ptr) : -1;
-  const double fd_shift = shift_k < n_params ? fd_h : -fd_h;
-  const double* pp = params + row * n_params;
-  Reg<NQ> r;
-#pragma unroll
-  for (int x = 0; x < Reg<NQ>::N; ++x) {
-    r.re[x] = (x == j) ? 1.0 : 0.0;
-    r.im[x] = 0.0;
-  }
-  ansatz_circuit<NQ, KIND>(r, [&](int l) {
-    double v = pp[l];
-    if (l == isel) v += fd ? fd_shift : roto_shift_value(nsh, shift_k);
-    return v;
-  }, n_params);
-  // A[b][s][i][j] = amplitude[2 i + s]
-  double2* out = A + b * (2 * D * D);
-#pragma unroll
-  for (int x = 0; x < Reg<NQ>::N; ++x) out[((x & 1) * D + (x >> 1)) * D + j] = make_double2(r.re[x], r.im[x]);
-}
-
-template <int D>
-static hipError_t launch_ansatz_d(int kind, const double* params, int n_params, void* A, int64_t B, int nsh, const int* i_ptr, hipStream_t st, double fd_h = 0.0) {
-  const int64_t threads = B * D;
-  const dim3 grid((unsigned)((threads + 63) / 64)), block(64);
-  switch (kind) {
-    case 0: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 0>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
-    case 1: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 1>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
-    case 2:
-      if (D != 2) return hipErrorInvalidValue;
-      hipLaunchKernelGGL((ansatz_tensor_kernel<2, 2>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h);
-      break;
-    case 3: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 3>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
-    case 4: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 4>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
-    case 5: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 5>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
-    case 6:
-      if (D != 2) return hipErrorInvalidValue;
-      hipLaunchKernelGGL((ansatz_tensor_kernel<2, 6>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h);
-      break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
-hipError_t launch_ansatz_shifted(int D, int kind, const double* params, int n_params, void* A, int64_t B, int nsh, const int* i_ptr,
-                                 hipStream_t st) {
-  if (B <= 0) return hipSuccess;
-  switch (D) {
-    case 2: return launch_ansatz_d<2>(kind, params, n_params, A, B, nsh, i_ptr, st);
-    case 4: return launch_ansatz_d<4>(kind, params, n_params, A, B, nsh, i_ptr, st);
-    case 8: return launch_ansatz_d<8>(kind, params, n_params, A, B, nsh, i_ptr, st);
-    case 16: return launch_ansatz_d<16>(kind, params, n_params, A, B, nsh, i_ptr, st);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-hipError_t launch_ansatz_fd(int D, int kind, const double* params, int n_params, void* A, int64_t rows, double h, hipStream_t st) {
-  const int64_t B = rows * 2 * n_params;
-  if (B <= 0) return hipSuccess;
-  switch (D) {
-    case 2: return launch_ansatz_d<2>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h);
-    case 4: return launch_ansatz_d<4>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h);
-    case 8: return launch_ansatz_d<8>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h);
-    case 16: return launch_ansatz_d<16>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, void* A, int64_t B, hipStream_t st) {
-  return launch_ansatz_shifted(D, kind, params, n_params, A, B, 0, nullptr, st);
-}
-
-// ------------------------------------------------------------------------------------------
-// Kernel 3c: device-resident rotosolve (qmps/rotosolve.py:154-181).  For parameter i,
-// R restarts x 3 shifts {0, +pi/2, -pi/2} form one batch; the closed-form update
-//   theta* = -pi/2 - atan2(2 e0 - e+ - e-, e+ - e-),  params[i] = wrap(params[i] + wrap(theta*))
-// runs on the device, so a whole sweep needs no host round trip.
-// ------------------------------------------------------------------------------------------
-
-// (wrap_pi, double_sinusoid_argmin: qmps_roto_math.h)
-__global__ __launch_bounds__(256) void roto_update_kernel(double* __restrict__ base, const double* __restrict__ E,
-                                                          const int32_t* __restrict__ status, int R, int P,
-                                                          int* __restrict__ i_ptr, int n_terms, int nsh) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = *i_ptr;
-  // the LAST workgroup to finish advances the parameter index for the next graph replay
-  __shared__ int s_last;
-  if (r < R) {
-    double e[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    bool ok = true;
-    for (int k = 0; k < nsh; ++k) {
-      double v = 0.0;
-      for (int q = 0; q < n_terms; ++q) v += E[((int64_t)r * nsh + k) * n_terms + q];   // M(x) = sum over terms
-      e[k] = v;
-      ok = ok && status[(int64_t)r * nsh + k] == QMPS_ST_OK;
-    }
-    if (ok) {          // (an evaluation without a valid environment leaves this restart's parameter untouched)
-      double theta;
-      if (nsh == 3) {
-        theta = -1.5707963267948966 - atan2(2.0 * e[0] - e[1] - e[2], e[1] - e[2]);
-      } else {
-        // samples at {0, pi, +pi/2, -pi/2, +pi/4, -pi/4}: a, b, c, d -> P sin(2x + u) + Q sin(x + v)  (tools.py:434-447)
-        const double A = e[0] + e[1], Bv = e[0] - e[1], C = e[2] + e[3], Dv = e[2] - e[3], Ev = e[4] - e[5];
-        const double a = 0.25 * (2.0 * Ev - 1.4142135623730951 * Dv), b = 0.25 * (A - C), c = 0.5 * Dv, d = 0.5 * Bv;
-        theta = double_sinusoid_argmin(a, b, c, d);      // P sin(2x + u) = a sin 2x + b cos 2x,  Q sin(x + v) = c sin x + d cos x
-      }
-      // (the minimiser of the double-frequency fit already lies in [-pi - pi/16, pi): one conditional shift wraps it)
-      const double moved = base[(int64_t)r * P + i] + (nsh == 3 ? wrap_pi(theta) : (theta < -3.141592653589793 ? theta + 6.283185307179586 : (theta > 3.141592653589793 ? theta - 6.283185307179586 : theta)));
-      base[(int64_t)r * P + i] = nsh == 3 ? wrap_pi(moved) : moved;   // the double-frequency driver does not re-wrap (tools.py:453-454)
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int done = atomicAdd(i_ptr + 1, 1);        // i_ptr[1]: arrival counter
-    s_last = (done == (int)gridDim.x - 1);
-  }
-  __syncthreads();
-  if (s_last && threadIdx.x == 0) {
-    i_ptr[1] = 0;
-    i_ptr[0] = (i + 1 == P) ? 0 : i + 1;             // every block has read *i_ptr before its arrival
-    if (i + 1 == P) i_ptr[2] += 1;                   // i_ptr[2]: sweeps finished (roto_record_kernel)
-    __threadfence();
-  }
-}
-
-// sweep_ptr (nullable): device counter of finished sweeps (advanced by the update kernel that wraps the parameter index):
-// the record of sweep n lands in hist[(n - 1) R ...], so ONE captured graph serves every sweep
-// stride: evaluations per restart in E (1: the R base vectors; nsh: a shifted batch, whose shift-0 row IS the evaluation of the
-// base vector - the record of a sweep is taken from the first shifted batch of the NEXT one, so a sweep costs n_params
-// batches, not n_params + 1); nothing is written before the first sweep has finished
-__global__ __launch_bounds__(256) void roto_record_kernel(const double* __restrict__ E, double* __restrict__ hist, int R,
-                                                          int n_terms, const int* __restrict__ sweep_ptr, int stride) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
-  const int64_t sw = sweep_ptr != nullptr ? (int64_t)(*sweep_ptr - 1) : 0;
-  if (sw < 0) return;
-  double v = 0.0;
-  for (int q = 0; q < n_terms; ++q) v += E[(int64_t)r * stride * n_terms + q];
-  hist[sw * R + r] = v;
-}
-
-hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int* i_ptr, int n_terms,
-                              int nsh, hipStream_t st) {
-  hipLaunchKernelGGL(roto_update_kernel, dim3((R + 255) / 256), dim3(256), 0, st, base, E, status, R, P, i_ptr, n_terms, nsh);
-  return hipGetLastError();
-}
-hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, const int* sweep_ptr, int stride, hipStream_t st) {
-  hipLaunchKernelGGL(roto_record_kernel, dim3((R + 255) / 256), dim3(256), 0, st, E, hist, R, n_terms, sweep_ptr, stride);
-  return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
 // Kernel 3c': the WHOLE rotosolve run of a D = 2 ansatz in one launch.  Restarts are independent, so the sequential loop
 // over parameters and sweeps needs no grid-wide step: a quad of lanes owns one restart (lanes 0..2 = the shifts
 // {0, +pi/2, -pi/2}, lane 3 idles along), builds its shifted state tensor in registers, solves the environment and the
@@ -2423,758 +1450,6 @@ hipError_t launch_rotosolve_fused_d2(int kind, const RotoArgs& a, hipStream_t st
 }
 
 // ------------------------------------------------------------------------------------------
-// Kernel 3d: time-evolution overlap objective (qmps/new_time_evolve.py:193-221,
-// scripts/loschmidt.py:209-239), D = 2, one evaluation per lane.
-//   T(x) = sum_{s=0..3} C_s x Bm_s^+ ,  C = WW . merge(A, A) ,  Bm = merge(B, B)
-// (qmps/time_evolve_tools.py:20-23); the 6-qubit circuit of the reference measures
-// 2 |psi[0]| = |eta|, eta the dominant eigenvalue of T, and the objective is -sqrt(|eta|).
-// eta is found by power iteration applied 2^m steps at a time: the 4 x 4 complex matrix of T is
-// squared (Frobenius-normalised each round), its dominant right vector v read off the largest column,
-// eta = <v, T v>/<v, v>, stop when ||T v - eta v|| < tol ||v||.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void overlap_lane_kernel(OverlapArgs p) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= p.B) return;
-  const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * 8;
-  const double2* Bp = (const double2*)p.Bt + b * 8;
-  const double2* W = (const double2*)p.WW;
-  // two-site products: AA[t1 t2] = A_t1 A_t2, BB likewise (2 x 2 complex each)
-  double aar[4][2][2], aai[4][2][2], bbr[4][2][2], bbi[4][2][2];
-#pragma unroll
-  for (int t1 = 0; t1 < 2; ++t1)
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          double ar = 0, ai = 0, br = 0, bi = 0;
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const double2 x = Ap[(t1 * 2 + i) * 2 + k], y = Ap[(t2 * 2 + k) * 2 + j];
-            ar += x.x * y.x - x.y * y.y;
-            ai += x.x * y.y + x.y * y.x;
-            const double2 u = Bp[(t1 * 2 + i) * 2 + k], v = Bp[(t2 * 2 + k) * 2 + j];
-            br += u.x * v.x - u.y * v.y;
-            bi += u.x * v.y + u.y * v.x;
-          }
-          aar[2 * t1 + t2][i][j] = ar; aai[2 * t1 + t2][i][j] = ai;
-          bbr[2 * t1 + t2][i][j] = br; bbi[2 * t1 + t2][i][j] = bi;
-        }
-  // C_s = sum_t WW[s][t] AA_t
-  double cr[4][2][2], ci[4][2][2];
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        double xr = 0, xi = 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const double2 w = W[s * 4 + t];
-          xr += w.x * aar[t][i][j] - w.y * aai[t][i][j];
-          xi += w.x * aai[t][i][j] + w.y * aar[t][i][j];
-        }
-        cr[s][i][j] = xr; ci[s][i][j] = xi;
-      }
-  // E[(i,i'),(j,j')] = sum_s C_s[i][j] conj(Bm_s[i'][j'])
-  double er[4][4], ei[4][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int ip = 0; ip < 2; ++ip)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          double xr = 0, xi = 0;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            xr += cr[s][i][j] * bbr[s][ip][jp] + ci[s][i][j] * bbi[s][ip][jp];
-            xi += ci[s][i][j] * bbr[s][ip][jp] - cr[s][i][j] * bbi[s][ip][jp];
-          }
-          er[2 * i + ip][2 * j + jp] = xr; ei[2 * i + ip][2 * j + jp] = xi;
-        }
-  double mr[4][4], mi[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { mr[a][c] = er[a][c]; mi[a][c] = ei[a][c]; }
-  double eta_r = 0.0, eta_i = 0.0, vr[4] = {1, 0, 0, 0}, vi[4] = {0, 0, 0, 0};
-  int status = QMPS_ST_NOT_CONVERGED, rounds = 0;
-  const double tol2 = p.tol * p.tol;
-  for (int m = 0; m <= p.max_rounds; ++m) {
-    // dominant right vector = largest column of the current power
-    double best = -1.0;
-    int bc = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      double n2 = 0.0;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) n2 += mr[a][c] * mr[a][c] + mi[a][c] * mi[a][c];
-      if (n2 > best) { best = n2; bc = c; }
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      vr[a] = bc == 0 ? mr[a][0] : (bc == 1 ? mr[a][1] : (bc == 2 ? mr[a][2] : mr[a][3]));
-      vi[a] = bc == 0 ? mi[a][0] : (bc == 1 ? mi[a][1] : (bc == 2 ? mi[a][2] : mi[a][3]));
-    }
-    // eta = <v, E v>/<v, v>, residual ||E v - eta v||^2 / ||v||^2
-    double wr[4], wi[4], num_r = 0, num_i = 0, vv = 0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      double xr = 0, xi = 0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        xr += er[a][c] * vr[c] - ei[a][c] * vi[c];
-        xi += er[a][c] * vi[c] + ei[a][c] * vr[c];
-      }
-      wr[a] = xr; wi[a] = xi;
-      num_r += vr[a] * xr + vi[a] * xi;
-      num_i += vr[a] * xi - vi[a] * xr;
-      vv += vr[a] * vr[a] + vi[a] * vi[a];
-    }
-    eta_r = num_r / vv; eta_i = num_i / vv;
-    double res = 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const double dr = wr[a] - (eta_r * vr[a] - eta_i * vi[a]), di = wi[a] - (eta_r * vi[a] + eta_i * vr[a]);
-      res += dr * dr + di * di;
-    }
-    rounds = m;
-    if (res < tol2 * vv) { status = QMPS_ST_OK; break; }
-    if (m == p.max_rounds) break;
-    // square and Frobenius-normalise
-    double qr[4][4], qi[4][4], f2 = 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        double xr = 0, xi = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          xr += mr[a][k] * mr[k][c] - mi[a][k] * mi[k][c];
-          xi += mr[a][k] * mi[k][c] + mi[a][k] * mr[k][c];
-        }
-        qr[a][c] = xr; qi[a][c] = xi;
-        f2 += xr * xr + xi * xi;
-      }
-    const double inv = f2 > 0.0 ? 1.0 / __builtin_sqrt(f2) : 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { mr[a][c] = qr[a][c] * inv; mi[a][c] = qi[a][c] * inv; }
-  }
-  overlap_store(p, b, eta_r, eta_i, rounds, status);
-  if (p.r_out != nullptr) {
-    double n2 = 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) n2 += vr[a] * vr[a] + vi[a] * vi[a];
-    const double inv = n2 > 0.0 ? 1.0 / __builtin_sqrt(n2) : 0.0;
-    double2* ro = (double2*)((char*)p.r_out + overlap_slot_offset(p));
-#pragma unroll
-    for (int a = 0; a < 4; ++a) ro[b * 4 + a] = make_double2(vr[a] * inv, vi[a] * inv);
-  }
-}
-
-hipError_t launch_overlap(const OverlapArgs& a, hipStream_t st) {
-  if (a.B <= 0) return hipSuccess;
-  hipLaunchKernelGGL(overlap_lane_kernel, dim3((unsigned)((a.B + 63) / 64)), dim3(64), 0, st, a);
-  return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// Kernel 3e: brick-wall ("new_tdvp") classical contractions (SURVEY 8(a)-11 / (f)-4;
-// new_tdvp/ClassicalTDVPStripped.py), one evaluation per lane, state vectors in registers.
-//   psi_l = (1 x U1^(l-1) x 1)(U2^l)|0..0> on 2 l qubits (bwMPS.state :179-191)
-//   expectation values  <psi_l| 1 x O x 1 |psi_l>,  l = 2 (O 4x4, :511-544) and l = 3 (O 16x16, :464-496)
-//   environment matrices of RightEnvironment / LeftEnvironment.exact_environment_circuit (:399-422, :316-338)
-//     and their dominant eigenpair with the reference's rule eta[np.argmax(eta)] (largest REAL part)
-//   ManifoldOverlap.circuit (:239-275)
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_u4(const double2* p, double (&gr)[16], double (&gi)[16]) {
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const double2 v = p[k];
-    gr[k] = v.x;
-    gi[k] = v.y;
-  }
-}
-__device__ __forceinline__ void load_u4_dagger(const double2* p, double (&gr)[16], double (&gi)[16]) {
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const double2 v = p[c * 4 + a];
-      gr[a * 4 + c] = v.x;
-      gi[a * 4 + c] = -v.y;
-    }
-}
-
-template <int L>
-__global__ __launch_bounds__(64) void bw_expval_kernel(BwArgs p) {
-  constexpr int NQ = 2 * L;
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= p.B) return;
-  Reg<NQ> r;
-#pragma unroll
-  for (int x = 0; x < Reg<NQ>::N; ++x) { r.re[x] = (x == 0) ? 1.0 : 0.0; r.im[x] = 0.0; }
-  double gr[16], gi[16];
-  load_u4((const double2*)p.U2 + b * 16, gr, gi);
-#pragma unroll
-  for (int k = 0; k < L; ++k) r.u4(2 * k, 2 * k + 1, gr, gi);
-  load_u4((const double2*)p.U1 + b * 16, gr, gi);
-#pragma unroll
-  for (int k = 0; k < L - 1; ++k) r.u4(2 * k + 1, 2 * k + 2, gr, gi);
-  // <psi| 1 x O x 1 |psi>: the operator acts on qubits 1 .. NQ-2 (index bits NQ-2 .. 1)
-  constexpr int NO = 1 << (NQ - 2);
-  const double2* O = (const double2*)p.O + (p.o_shared ? 0 : b * (int64_t)NO * NO);
-  double er = 0.0, ei = 0.0;
-#pragma unroll
-  for (int xm = 0; xm < NO; ++xm)
-#pragma unroll
-    for (int ym = 0; ym < NO; ++ym) {
-      const double2 o = O[xm * NO + ym];
-      // sum over the outer bits of conj(psi[hi, xm, lo]) psi[hi, ym, lo]
-      double sr = 0.0, si = 0.0;
-#pragma unroll
-      for (int hi = 0; hi < 2; ++hi)
-#pragma unroll
-        for (int lo = 0; lo < 2; ++lo) {
-          const int x = (hi << (NQ - 1)) | (xm << 1) | lo, y = (hi << (NQ - 1)) | (ym << 1) | lo;
-          sr = dfma(r.re[x], r.re[y], sr);
-          sr = dfma(r.im[x], r.im[y], sr);
-          si = dfma(r.re[x], r.im[y], si);
-          si = dfma(-r.im[x], r.re[y], si);
-        }
-      er = dfma(o.x, sr, er);
-      er = dfma(-o.y, si, er);
-      ei = dfma(o.x, si, ei);
-      ei = dfma(o.y, sr, ei);
-    }
-  ((double2*)p.out)[b] = make_double2(er, ei);
-}
-
-// exp((1 - i eps) M) by Taylor series (||M|| <= ~1: transfer matrices of unitaries), then repeated squaring:
-// the dominant-modulus eigenvector of exp(cM) is the eigenvector of M with the largest real part (ties broken
-// towards the larger imaginary part by the -i eps tilt) - the reference's eta[np.argmax(eta)].
-__device__ __forceinline__ void mat4_mul(const double (&ar)[4][4], const double (&ai)[4][4], const double (&br)[4][4],
-                                         const double (&bi)[4][4], double (&cr)[4][4], double (&ci)[4][4]) {
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      double xr = 0.0, xi = 0.0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        xr += ar[a][k] * br[k][c] - ai[a][k] * bi[k][c];
-        xi += ar[a][k] * bi[k][c] + ai[a][k] * br[k][c];
-      }
-      cr[a][c] = xr;
-      ci[a][c] = xi;
-    }
-}
-
-__global__ __launch_bounds__(64) void bw_env_kernel(BwArgs p) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= p.B) return;
-  // phi_i = U1 U2 |i,0,0> (right: U2 on (b,c), U1 on (a,b), open wire a = qubit 0)
-  //         (left : U2 on (a,b), U1 on (b,c), open wire c = qubit 2)
-  // chi_i' = (U2' U1')^+ |i',0,0>  resp. mirrored;  Mmat[(i,i'),(j,j')] = sum_{rest} conj(chi_i'[..j'..]) phi_i[..j..]
-  const bool left = p.side != 0;
-  Reg<3> phi[2], chi[2];
-  double gr[16], gi[16];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      const int start = left ? i : (i << 2);
-      phi[i].re[x] = (x == start) ? 1.0 : 0.0; phi[i].im[x] = 0.0;
-      chi[i].re[x] = (x == start) ? 1.0 : 0.0; chi[i].im[x] = 0.0;
-    }
-  }
-  load_u4((const double2*)p.U2 + b * 16, gr, gi);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { if (left) phi[i].u4(0, 1, gr, gi); else phi[i].u4(1, 2, gr, gi); }
-  load_u4((const double2*)p.U1 + b * 16, gr, gi);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { if (left) phi[i].u4(1, 2, gr, gi); else phi[i].u4(0, 1, gr, gi); }
-  load_u4_dagger((const double2*)p.U2p + b * 16, gr, gi);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { if (left) chi[i].u4(0, 1, gr, gi); else chi[i].u4(1, 2, gr, gi); }
-  load_u4_dagger((const double2*)p.U1p + b * 16, gr, gi);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { if (left) chi[i].u4(1, 2, gr, gi); else chi[i].u4(0, 1, gr, gi); }
-  // open wire carrying (j, j'): right -> qubit 2 (bit 0); left -> qubit 0 (bit 2)
-  double mr[4][4], mi[4][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int ip = 0; ip < 2; ++ip)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          double xr = 0.0, xi = 0.0;
-#pragma unroll
-          for (int rest = 0; rest < 4; ++rest) {
-            const int xphi = left ? ((j << 2) | rest) : ((rest << 1) | j);
-            const int xchi = left ? ((jp << 2) | rest) : ((rest << 1) | jp);
-            xr += chi[ip].re[xchi] * phi[i].re[xphi] + chi[ip].im[xchi] * phi[i].im[xphi];
-            xi += chi[ip].re[xchi] * phi[i].im[xphi] - chi[ip].im[xchi] * phi[i].re[xphi];
-          }
-          mr[2 * i + ip][2 * j + jp] = xr;
-          mi[2 * i + ip][2 * j + jp] = xi;
-        }
-  if (p.mat_out != nullptr) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) ((double2*)p.mat_out)[b * 16 + a * 4 + c] = make_double2(mr[a][c], mi[a][c]);
-  }
-  // P = exp((1 - i eps) M), 20-term Taylor series evaluated by Horner
-  const double eps = 1e-6;
-  double cr[4][4], ci[4][4], pr[4][4], pi[4][4], tr_[4][4], ti_[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      cr[a][c] = mr[a][c] + eps * mi[a][c];       // (1 - i eps)(mr + i mi)
-      ci[a][c] = mi[a][c] - eps * mr[a][c];
-      pr[a][c] = (a == c) ? 1.0 : 0.0;
-      pi[a][c] = 0.0;
-    }
-  for (int k = 20; k >= 1; --k) {
-    mat4_mul(cr, ci, pr, pi, tr_, ti_);
-    const double inv = 1.0 / k;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        pr[a][c] = tr_[a][c] * inv + ((a == c) ? 1.0 : 0.0);
-        pi[a][c] = ti_[a][c] * inv;
-      }
-  }
-  double eta_r = 0.0, eta_i = 0.0, vr[4] = {1, 0, 0, 0}, vi[4] = {0, 0, 0, 0};
-  int status = QMPS_ST_NOT_CONVERGED;
-  const double tol2 = p.tol * p.tol;
-  for (int m = 0; m <= p.max_rounds; ++m) {
-    double best = -1.0;
-    int bc = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      double n2 = 0.0;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) n2 += pr[a][c] * pr[a][c] + pi[a][c] * pi[a][c];
-      if (n2 > best) { best = n2; bc = c; }
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      vr[a] = bc == 0 ? pr[a][0] : (bc == 1 ? pr[a][1] : (bc == 2 ? pr[a][2] : pr[a][3]));
-      vi[a] = bc == 0 ? pi[a][0] : (bc == 1 ? pi[a][1] : (bc == 2 ? pi[a][2] : pi[a][3]));
-    }
-    double wr[4], wi[4], num_r = 0, num_i = 0, vv = 0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      double xr = 0, xi = 0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        xr += mr[a][c] * vr[c] - mi[a][c] * vi[c];
-        xi += mr[a][c] * vi[c] + mi[a][c] * vr[c];
-      }
-      wr[a] = xr; wi[a] = xi;
-      num_r += vr[a] * xr + vi[a] * xi;
-      num_i += vr[a] * xi - vi[a] * xr;
-      vv += vr[a] * vr[a] + vi[a] * vi[a];
-    }
-    eta_r = num_r / vv; eta_i = num_i / vv;
-    double res = 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const double dr = wr[a] - (eta_r * vr[a] - eta_i * vi[a]), di = wi[a] - (eta_r * vi[a] + eta_i * vr[a]);
-      res += dr * dr + di * di;
-    }
-    if (res < tol2 * vv) { status = QMPS_ST_OK; break; }
-    if (m == p.max_rounds) break;
-    mat4_mul(pr, pi, pr, pi, tr_, ti_);
-    double f2 = 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) f2 += tr_[a][c] * tr_[a][c] + ti_[a][c] * ti_[a][c];
-    const double inv = f2 > 0.0 ? 1.0 / __builtin_sqrt(f2) : 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { pr[a][c] = tr_[a][c] * inv; pi[a][c] = ti_[a][c] * inv; }
-  }
-  // unit 2-norm, phase: largest-magnitude entry real positive
-  double n2 = 0.0, bigr = 1.0, bigi = 0.0, bigm = -1.0;
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const double m2 = vr[a] * vr[a] + vi[a] * vi[a];
-    n2 += m2;
-    if (m2 > bigm) { bigm = m2; bigr = vr[a]; bigi = vi[a]; }
-  }
-  const double sc = 1.0 / (__builtin_sqrt(n2) * __builtin_sqrt(bigm));
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const double xr = (vr[a] * bigr + vi[a] * bigi) * sc, xi = (vi[a] * bigr - vr[a] * bigi) * sc;
-    ((double2*)p.vec_out)[b * 4 + a] = make_double2(xr, xi);
-  }
-  ((double2*)p.out)[b] = make_double2(eta_r, eta_i);
-  p.status[b] = status;
-}
-
-// ManifoldOverlap.circuit (new_tdvp/ClassicalTDVPStripped.py:239-275) without a 6-qubit state vector (the literal
-// simulation of round 1 held 64 amplitudes per lane and spilled 882 registers).  With a = U2[:, 0] (the pair state
-// U2|00>), b = U2'[0, :] (the bra <00|U2') and big-endian two-bit indices,
-//   ket(y0; y12; y34; y5) = sum_z U1[y12, z1 z2] U1[y34, z3 z4] a[y0 z1] a[z2 z3] a[z4 y5]
-//   bra(x0; x12; x34; x5) = sum_w b[x0 w1] b[w2 w3] b[w4 x5] U1'[w1 w2, x12] U1'[w3 w4, x34]
-//   out = sum Ml[x0, y0] Mr[x5, y5] bra(x) W[x12 x34, y12 y34] ket(y)
-// Both vectors have rank 2 across the middle bond: ket = sum_c KL[y0][y12][c] KR[y5][y34][c] (the middle pair a[z2 z3] folded
-// into KL), bra likewise with Ml, Mr folded into BL, BR.  So out = sum_{y0, y5} <B_{y0 y5}| W |K_{y0 y5}> : four 16 x 16
-// sandwiches, the 16-vectors rebuilt from their 4 x 2 factors on the fly.
-__global__ __launch_bounds__(64) void bw_manifold_kernel(BwArgs p) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= p.B) return;
-  const double2* U1 = (const double2*)p.U1 + b * 16;
-  const double2* U2 = (const double2*)p.U2 + b * 16;
-  const double2* U1p = (const double2*)p.U1p + b * 16;
-  const double2* U2p = (const double2*)p.U2p + b * 16;
-  const double2* Ml = (const double2*)p.Ml + (p.m_shared ? 0 : b * 4);
-  const double2* Mr = (const double2*)p.Mr + (p.m_shared ? 0 : b * 4);
-  const double2* W = (const double2*)p.O + (p.o_shared ? 0 : b * 256);
-  auto cm = [](double2 x, double2 y) { return make_double2(x.x * y.x - x.y * y.y, x.x * y.y + x.y * y.x); };
-  auto acc = [](double2& t, double2 x, double2 y) {
-    t.x = dfma(x.x, y.x, t.x);
-    t.x = dfma(-x.y, y.y, t.x);
-    t.y = dfma(x.x, y.y, t.y);
-    t.y = dfma(x.y, y.x, t.y);
-  };
-  double2 a[4], bb[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    a[k] = U2[k * 4];        // column 0 of U2
-    bb[k] = U2p[k];          // row 0 of U2'
-  }
-  // ket factors: KL[y0][y12][z3] = sum_{z1 z2} U1[y12, z1 z2] a[y0 z1] a[z2 z3];  KR[y5][y34][z3] = sum_{z4} U1[y34, z3 z4] a[z4 y5]
-  double2 KL[2][4][2], KR[2][4][2];
-  {
-    double2 u1[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) u1[k] = U1[k];
-#pragma unroll
-    for (int y0 = 0; y0 < 2; ++y0)
-#pragma unroll
-      for (int y = 0; y < 4; ++y) {
-        double2 t[2];     // sum_{z1} U1[y, z1 z2] a[y0 z1], z2 = 0, 1
-#pragma unroll
-        for (int z2 = 0; z2 < 2; ++z2) {
-          t[z2] = make_double2(0.0, 0.0);
-#pragma unroll
-          for (int z1 = 0; z1 < 2; ++z1) acc(t[z2], u1[y * 4 + 2 * z1 + z2], a[2 * y0 + z1]);
-        }
-#pragma unroll
-        for (int z3 = 0; z3 < 2; ++z3) {
-          double2 v = make_double2(0.0, 0.0);
-#pragma unroll
-          for (int z2 = 0; z2 < 2; ++z2) acc(v, t[z2], a[2 * z2 + z3]);
-          KL[y0][y][z3] = v;
-        }
-      }
-#pragma unroll
-    for (int y5 = 0; y5 < 2; ++y5)
-#pragma unroll
-      for (int y = 0; y < 4; ++y)
-#pragma unroll
-        for (int z3 = 0; z3 < 2; ++z3) {
-          double2 v = make_double2(0.0, 0.0);
-#pragma unroll
-          for (int z4 = 0; z4 < 2; ++z4) acc(v, u1[y * 4 + 2 * z3 + z4], a[2 * z4 + y5]);
-          KR[y5][y][z3] = v;
-        }
-  }
-  // bra factors with the boundary matrices folded in:
-  //   BL[y0][x12][w3] = sum_{x0} Ml[x0, y0] sum_{w1 w2} b[x0 w1] U1'[w1 w2, x12] b[w2 w3]
-  //   BR[y5][x34][w3] = sum_{x5} Mr[x5, y5] sum_{w4} U1'[w3 w4, x34] b[w4 x5]
-  double2 BL[2][4][2], BR[2][4][2];
-  {
-    double2 u1p[16], ml[4], mr[4];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) u1p[k] = U1p[k];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { ml[k] = Ml[k]; mr[k] = Mr[k]; }
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      double2 raw[2][2];   // [x0][w3]
-#pragma unroll
-      for (int x0 = 0; x0 < 2; ++x0) {
-        double2 t[2];      // sum_{w1} b[x0 w1] U1'[w1 w2, x], w2 = 0, 1
-#pragma unroll
-        for (int w2 = 0; w2 < 2; ++w2) {
-          t[w2] = make_double2(0.0, 0.0);
-#pragma unroll
-          for (int w1 = 0; w1 < 2; ++w1) acc(t[w2], bb[2 * x0 + w1], u1p[(2 * w1 + w2) * 4 + x]);
-        }
-#pragma unroll
-        for (int w3 = 0; w3 < 2; ++w3) {
-          double2 v = make_double2(0.0, 0.0);
-#pragma unroll
-          for (int w2 = 0; w2 < 2; ++w2) acc(v, t[w2], bb[2 * w2 + w3]);
-          raw[x0][w3] = v;
-        }
-      }
-#pragma unroll
-      for (int y0 = 0; y0 < 2; ++y0)
-#pragma unroll
-        for (int w3 = 0; w3 < 2; ++w3) {
-          double2 v = cm(ml[0 * 2 + y0], raw[0][w3]);
-          acc(v, ml[1 * 2 + y0], raw[1][w3]);
-          BL[y0][x][w3] = v;
-        }
-      double2 rawr[2][2];  // [x5][w3]
-#pragma unroll
-      for (int x5 = 0; x5 < 2; ++x5)
-#pragma unroll
-        for (int w3 = 0; w3 < 2; ++w3) {
-          double2 v = make_double2(0.0, 0.0);
-#pragma unroll
-          for (int w4 = 0; w4 < 2; ++w4) acc(v, u1p[(2 * w3 + w4) * 4 + x], bb[2 * w4 + x5]);
-          rawr[x5][w3] = v;
-        }
-#pragma unroll
-      for (int y5 = 0; y5 < 2; ++y5)
-#pragma unroll
-        for (int w3 = 0; w3 < 2; ++w3) {
-          double2 v = cm(mr[0 * 2 + y5], rawr[0][w3]);
-          acc(v, mr[1 * 2 + y5], rawr[1][w3]);
-          BR[y5][x][w3] = v;
-        }
-    }
-  }
-  // out = sum_{y0, y5} sum_{x, y} B_{y0 y5}(x) W[x, y] K_{y0 y5}(y),  x = 4 x12 + x34,  y = 4 y12 + y34
-  double2 out = make_double2(0.0, 0.0);
-#pragma unroll
-  for (int y0 = 0; y0 < 2; ++y0)
-#pragma unroll
-    for (int y5 = 0; y5 < 2; ++y5) {
-      double2 K[16];
-#pragma unroll
-      for (int yl = 0; yl < 4; ++yl)
-#pragma unroll
-        for (int yr = 0; yr < 4; ++yr) {
-          double2 v = cm(KL[y0][yl][0], KR[y5][yr][0]);
-          acc(v, KL[y0][yl][1], KR[y5][yr][1]);
-          K[4 * yl + yr] = v;
-        }
-#pragma unroll
-      for (int x = 0; x < 16; ++x) {       // (unrolled: a rolled loop would index BL / BR dynamically and push them to scratch)
-        double2 sx = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int y = 0; y < 16; ++y) acc(sx, W[x * 16 + y], K[y]);
-        const int xl = x >> 2, xr = x & 3;
-        double2 bx = cm(BL[y0][xl][0], BR[y5][xr][0]);
-        acc(bx, BL[y0][xl][1], BR[y5][xr][1]);
-        acc(out, bx, sx);
-        __builtin_amdgcn_sched_barrier(0);   // row by row: keeps the 1024 loads of W from being hoisted into the register file
-      }
-    }
-  ((double2*)p.out)[b] = out;
-}
-
-hipError_t launch_bw(int what, const BwArgs& a, hipStream_t st) {
-  if (a.B <= 0) return hipSuccess;
-  const dim3 grid((unsigned)((a.B + 63) / 64)), block(64);
-  switch (what) {
-    case 0: hipLaunchKernelGGL(bw_expval_kernel<2>, grid, block, 0, st, a); break;
-    case 1: hipLaunchKernelGGL(bw_expval_kernel<3>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(bw_env_kernel, grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(bw_manifold_kernel, grid, block, 0, st, a); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// Kernel 3f: variational-environment objective (qmps/ground_state.py:170-228), D = 2, one
-// evaluation per lane.  30 parameters: p2 = params[:15] -> U, p1 = params[15:] -> V (both
-// ShallowFullStateTensor).  Four circuits, simulated literally:
-//   energy     (4 qubits): V(2,3) U(1,2) U(0,1);                  <1 x H x 1>
-//   v_purity   (4 qubits): V(0,1) V(2,3) SWAP(0,1);               <SWAP(1,2)>
-//   u_purity   (6 qubits): V(1,2) U(0,1) V(4,5) U(3,4) SWAP(0,1) SWAP(1,2);   <SWAP(2,3)>
-//   uv_purity  (5 qubits): V(3,4) U(2,3) V(0,1) SWAP(0,1);        <SWAP(1,2)>
-//   f = energy + k (u_purity + v_purity - 2 uv_purity)
-// The three purity circuits act on PRODUCT states - psi_V = V|00> on a pair, phi = U(0,1) V(1,2)|000> on a triple - and for
-// |alpha> x |beta> the expectation of a SWAP between a qubit of alpha and a qubit of beta is tr(rho_alpha rho_beta).  The
-// SWAPs inside each circuit only move qubit 0 of the factor next to the measured cut, so (round 2; the literal 5- and
-// 6-qubit simulation of round 1 spilled 1390 registers per lane)
-//   v_purity = tr(rho_V^2),  uv_purity = tr(rho_V rho_phi),  u_purity = tr(rho_phi^2),   rho_X = one-qubit state of qubit 0 of X
-// Parity: oracle.opt_environment_objective simulates the four circuits literally.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void opt_env_lane_kernel(const double* __restrict__ params, const double2* __restrict__ h,
-                                                          double k, double* __restrict__ f, double* __restrict__ parts,
-                                                          int64_t B) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= B) return;
-  double cu[15], su[15], cv[15], sv[15];      // cos / sin of the half angles: U = params[:15], V = params[15:]
-  for (int i = 0; i < 15; ++i) {               // (a rolled loop: one copy of the sincos expansion)
-    sincos(0.5 * params[b * 30 + i], &su[i], &cu[i]);
-    sincos(0.5 * params[b * 30 + 15 + i], &sv[i], &cv[i]);
-  }
-  double energy;
-  {
-    Reg<4> r;
-    r.reset();
-    r.shallow_full_cs(2, 3, cv, sv);
-    r.shallow_full_cs(1, 2, cu, su);
-    r.shallow_full_cs(0, 1, cu, su);
-    // <psi| 1 x H x 1 |psi>, H on qubits 1,2 = index bits 2,1
-    double e = 0.0;
-#pragma unroll
-    for (int hi = 0; hi < 2; ++hi)
-#pragma unroll
-      for (int lo = 0; lo < 2; ++lo)
-#pragma unroll
-        for (int xm = 0; xm < 4; ++xm)
-#pragma unroll
-          for (int ym = 0; ym < 4; ++ym) {
-            const double2 o = h[xm * 4 + ym];
-            const int x = (hi << 3) | (xm << 1) | lo, y = (hi << 3) | (ym << 1) | lo;
-            // Re( conj(psi[x]) o psi[y] )
-            const double yr = o.x * r.re[y] - o.y * r.im[y], yi = o.x * r.im[y] + o.y * r.re[y];
-            e += r.re[x] * yr + r.im[x] * yi;
-          }
-    energy = e;
-  }
-  double vr[2][2], vi[2][2], fr[2][2], fi[2][2];
-  {
-    Reg<2> r;
-    r.reset();
-    r.shallow_full_cs(0, 1, cv, sv);
-    r.rdm_q0(vr, vi);
-  }
-  {
-    Reg<3> r;
-    r.reset();
-    r.shallow_full_cs(1, 2, cv, sv);
-    r.shallow_full_cs(0, 1, cu, su);
-    r.rdm_q0(fr, fi);
-  }
-  // tr(X Y) = sum_ab X[a][b] Y[b][a]  (real for Hermitian X, Y)
-  auto trprod = [](const double (&xr)[2][2], const double (&xi)[2][2], const double (&yr)[2][2], const double (&yi)[2][2]) {
-    double t = 0.0;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) t += xr[a][c] * yr[c][a] - xi[a][c] * yi[c][a];
-    return t;
-  };
-  const double v_purity = trprod(vr, vi, vr, vi), u_purity = trprod(fr, fi, fr, fi), uv_purity = trprod(vr, vi, fr, fi);
-  f[b] = energy + k * (u_purity + v_purity - 2.0 * uv_purity);
-  if (parts != nullptr) {
-    parts[b * 4 + 0] = energy;
-    parts[b * 4 + 1] = u_purity;
-    parts[b * 4 + 2] = v_purity;
-    parts[b * 4 + 3] = uv_purity;
-  }
-}
-
-hipError_t launch_opt_env(const double* params, const void* h, double k, double* f, double* parts, int64_t B,
-                          hipStream_t st) {
-  if (B <= 0) return hipSuccess;
-  hipLaunchKernelGGL(opt_env_lane_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, params, (const double2*)h, k, f,
-                     parts, B);
-  return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// Kernel 4: cost[t] = sum_b E[b][t]   (rotosolve's M(x) = np.sum(eps(...)), qmps/tools.py:432-433)
-// Deterministic two-pass reduction: per-block partials, then one block sums the partials.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sum_partial_kernel(const double* __restrict__ E, int64_t B, int n_terms,
-                                                          double* __restrict__ partial) {
-  __shared__ double red[4];
-  for (int q = 0; q < n_terms; ++q) {
-    double v = 0.0;
-    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x)
-      v += E[b * n_terms + q];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[(int64_t)q * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-  }
-}
-
-__global__ __launch_bounds__(1024) void sum_final_kernel(const double* __restrict__ partial, int n_partial, int n_terms,
-                                                         double* __restrict__ cost) {
-  // one workgroup, latency-bound: every thread issues all its loads before the first add (fixed summation order)
-  __shared__ double red[16];
-  const int nw = blockDim.x >> 6;
-  for (int q = 0; q < n_terms; ++q) {
-    const double* src = partial + (int64_t)q * n_partial;
-    double v[4] = {0.0, 0.0, 0.0, 0.0};
-    int k = threadIdx.x;
-    for (; k + 3 * (int)blockDim.x < n_partial; k += 4 * blockDim.x) {
-      const double a = src[k], b = src[k + blockDim.x], c = src[k + 2 * blockDim.x], d = src[k + 3 * blockDim.x];
-      v[0] += a; v[1] += b; v[2] += c; v[3] += d;
-    }
-    for (; k < n_partial; k += blockDim.x) v[0] += src[k];
-    const double w = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double t = 0.0;
-      for (int i = 0; i < nw; ++i) t += red[i];
-      cost[q] = t;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Probes: FP64 FMA peak and HBM streaming rate, measured on the box the numbers are quoted on.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void probe_fp64_kernel(double* out, int iters) {
-  double a[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) a[k] = 1.0 + 1e-9 * (threadIdx.x + k);
-  const double m = 1.0000001, c = 1e-7;
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = dfma(a[k], m, c);
-  }
-  double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) s += a[k];
-  if (s == 123.456) out[0] = s;  // keep the chain live without a store in the common case
-}
-
-// v_mfma_f64_16x16x4_f64 issue-rate probe: 4 independent accumulators per wave
-__global__ __launch_bounds__(256) void probe_mfma_f64_kernel(double* out, int iters) {
-  typedef double v4 __attribute__((ext_vector_type(4)));
-  v4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
-  const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
-  for (int it = 0; it < iters; ++it) {
-    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, c1, 0, 0, 0);
-    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, c2, 0, 0, 0);
-    c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, b, c3, 0, 0, 0);
-  }
-  const v4 s = c0 + c1 + c2 + c3;
-  if (s[0] + s[1] + s[2] + s[3] == 123.456) out[0] = s[0];
-}
-
-__global__ __launch_bounds__(256) void probe_copy_kernel(const double2* __restrict__ src, double2* __restrict__ dst,
-                                                         int64_t n) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) dst[t] = src[t];
-}
-
-// ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
 template <int D>
@@ -3188,52 +1463,10 @@ static hipError_t launch_lane(const LaneArgs& a, bool solve, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int D>
-static hipError_t launch_block(const LaneArgs& a, bool solve, hipStream_t st) {
-  if (solve && D == 8 && a.direct != 0) {
-    if constexpr (D == 8) hipLaunchKernelGGL((energy_block_kernel<8, true, true>), dim3((unsigned)a.B), dim3(64), 0, st, a);
-  } else if (solve)
-    hipLaunchKernelGGL((energy_block_kernel<D, true>), dim3((unsigned)a.B), dim3(D * D), 0, st, a);
-  else
-    hipLaunchKernelGGL((energy_block_kernel<D, false>), dim3((unsigned)a.B), dim3(D * D), 0, st, a);
-  return hipGetLastError();
-}
-
-hipError_t launch_energy_mfma(int D, const LaneArgs& a, bool solve, hipStream_t st) {
-  if (D != 16) return hipErrorInvalidValue;
-  if (a.B <= 0) return hipSuccess;
-  // measured: B = 96: 0.210 ms against 0.287 with one wave per evaluation; B = 768: 0.325 against 0.318 (the exchange through LDS
-  // and its two barriers per step cost what the shorter chain saves once every SIMD has a wave anyway)
-  static const int64_t split_below = tuning_knob("QMPS_D16_SPLIT_BELOW") ? atoll(tuning_knob("QMPS_D16_SPLIT_BELOW")) : 512;   // A/B knob
-  if (solve && a.B <= split_below) {
-    // few evaluations: two waves per evaluation (half the dependent MFMA chain per wave)
-    hipLaunchKernelGGL(energy_mfma_d16x2_kernel<true>, dim3((unsigned)(a.B < 8192 ? a.B : 8192)), dim3(128), 0, st, a);
-    return hipGetLastError();
-  }
-  int grid = (int)((a.B + 3) / 4);
-  if (grid > 4096) grid = 4096;
-  if (solve)
-    hipLaunchKernelGGL(energy_mfma_d16_kernel<true>, dim3(grid), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(energy_mfma_d16_kernel<false>, dim3(grid), dim3(256), 0, st, a);
-  return hipGetLastError();
-}
-
 hipError_t launch_square_tail(int D, const SquareArgs& a, int grid, hipStream_t st) {
   if (D != 4) return hipErrorInvalidValue;
   hipLaunchKernelGGL(env_square_d4_kernel, dim3(grid), dim3(256), 0, st, a);
   return hipGetLastError();
-}
-
-hipError_t launch_energy(int D, const LaneArgs& a, bool solve, hipStream_t st) {
-  if (a.B <= 0) return hipSuccess;
-  switch (D) {
-    case 2: return launch_lane<2>(a, solve, st);
-    case 4: return launch_lane<4>(a, solve, st);
-    case 8: return launch_block<8>(a, solve, st);
-    case 16: return launch_block<16>(a, solve, st);
-    default: return hipErrorInvalidValue;
-  }
 }
 
 hipError_t launch_energy_pair_d4(const LaneArgs& a, hipStream_t st) {
@@ -3249,60 +1482,15 @@ hipError_t launch_cell2(int D, const Cell2Args& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_unitary_to_tensor(const void* U, void* A, int D, int64_t B, hipStream_t st) {
-  if (B <= 0) return hipSuccess;
-  const int64_t total = B * 2 * D * D;
-  int grid = (int)((total + 255) / 256);
-  if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(unitary_to_tensor_kernel, dim3(grid), dim3(256), 0, st, (const double2*)U, (double2*)A, D, total);
-  return hipGetLastError();
-}
-
-hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, int n_partial, double* cost,
-                      hipStream_t st) {
-  if (n_terms == 1 && B <= 16384) {
-    // a small single-term batch: E[B] has the layout of one row of partial sums - one launch instead of two
-    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(B > 1024 ? 1024 : 256), 0, st, E, (int)B, 1, cost);
-    return hipGetLastError();
+hipError_t launch_energy(int D, const LaneArgs& a, bool solve, hipStream_t st) {
+  if (a.B <= 0) return hipSuccess;
+  switch (D) {
+    case 2: return launch_lane<2>(a, solve, st);
+    case 4: return launch_lane<4>(a, solve, st);
+    case 8:
+    case 16: return launch_energy_block(D, a, solve, st);
+    default: return hipErrorInvalidValue;
   }
-  hipLaunchKernelGGL(sum_partial_kernel, dim3(n_partial), dim3(256), 0, st, E, B, n_terms, partial);
-  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, n_partial, n_terms, cost);
-  return hipGetLastError();
-}
-
-hipError_t launch_sum_final(const double* partial, int n_partial, int n_terms, double* cost, hipStream_t st) {
-  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(n_partial > 1024 ? 1024 : 256), 0, st, partial, n_partial, n_terms, cost);
-  return hipGetLastError();
-}
-
-hipError_t launch_probe_fp64(double* out, int blocks, int iters, hipStream_t st) {
-  hipLaunchKernelGGL(probe_fp64_kernel, dim3(blocks), dim3(256), 0, st, out, iters);
-  return hipGetLastError();
-}
-
-hipError_t launch_probe_mfma_f64(double* out, int blocks, int iters, hipStream_t st) {
-  hipLaunchKernelGGL(probe_mfma_f64_kernel, dim3(blocks), dim3(256), 0, st, out, iters);
-  return hipGetLastError();
-}
-
-// small copies between pinned host memory and HBM done by a kernel ON THE CONTEXT STREAM (n8 units of 8 bytes): a
-// hipMemcpyAsync runs on a copy queue, and the cross-queue dependency in front of / behind it cost 40-80 us per round trip of
-// the optimiser drivers (rocprofv3 kernel trace of bench.py --workload evolve); the kernel reads / writes the pinned buffer directly
-__global__ __launch_bounds__(256) void stage_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n8) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += stride) dst[t] = src[t];
-}
-hipError_t launch_stage_copy(const void* src, void* dst, int64_t n8, hipStream_t st) {
-  if (n8 <= 0) return hipSuccess;
-  int64_t blocks = (n8 + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(stage_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const double*)src, (double*)dst, n8);
-  return hipGetLastError();
-}
-
-hipError_t launch_probe_copy(const void* src, void* dst, int64_t n16, hipStream_t st) {
-  hipLaunchKernelGGL(probe_copy_kernel, dim3(2048), dim3(256), 0, st, (const double2*)src, (double2*)dst, n16);
-  return hipGetLastError();
 }
 
 }  // namespace qmps

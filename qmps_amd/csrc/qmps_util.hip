@@ -1,0 +1,145 @@
+// qmps_util.hip - reductions of the per-evaluation energies, staging copies and the micro-benchmarks behind qmps_probe_* (gfx950 only).
+// Split out of qmps_kernels.hip in round 3.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <stdint.h>
+
+#include "qmps_kernels.h"
+#include "qmps_knobs.h"
+#include "qmps_device.h"
+
+namespace qmps {
+
+// ------------------------------------------------------------------------------------------
+// Kernel 4: cost[t] = sum_b E[b][t]   (rotosolve's M(x) = np.sum(eps(...)), qmps/tools.py:432-433)
+// Deterministic two-pass reduction: per-block partials, then one block sums the partials.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sum_partial_kernel(const double* __restrict__ E, int64_t B, int n_terms,
+                                                          double* __restrict__ partial) {
+  __shared__ double red[4];
+  for (int q = 0; q < n_terms; ++q) {
+    double v = 0.0;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x)
+      v += E[b * n_terms + q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)q * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+__global__ __launch_bounds__(1024) void sum_final_kernel(const double* __restrict__ partial, int n_partial, int n_terms,
+                                                         double* __restrict__ cost) {
+  // one workgroup, latency-bound: every thread issues all its loads before the first add (fixed summation order)
+  __shared__ double red[16];
+  const int nw = blockDim.x >> 6;
+  for (int q = 0; q < n_terms; ++q) {
+    const double* src = partial + (int64_t)q * n_partial;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    int k = threadIdx.x;
+    for (; k + 3 * (int)blockDim.x < n_partial; k += 4 * blockDim.x) {
+      const double a = src[k], b = src[k + blockDim.x], c = src[k + 2 * blockDim.x], d = src[k + 3 * blockDim.x];
+      v[0] += a; v[1] += b; v[2] += c; v[3] += d;
+    }
+    for (; k < n_partial; k += blockDim.x) v[0] += src[k];
+    const double w = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int i = 0; i < nw; ++i) t += red[i];
+      cost[q] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Probes: FP64 FMA peak and HBM streaming rate, measured on the box the numbers are quoted on.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void probe_fp64_kernel(double* out, int iters) {
+  double a[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = 1.0 + 1e-9 * (threadIdx.x + k);
+  const double m = 1.0000001, c = 1e-7;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = dfma(a[k], m, c);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += a[k];
+  if (s == 123.456) out[0] = s;  // keep the chain live without a store in the common case
+}
+
+// v_mfma_f64_16x16x4_f64 issue-rate probe: 4 independent accumulators per wave
+__global__ __launch_bounds__(256) void probe_mfma_f64_kernel(double* out, int iters) {
+  typedef double v4 __attribute__((ext_vector_type(4)));
+  v4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
+  const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, b, c3, 0, 0, 0);
+  }
+  const v4 s = c0 + c1 + c2 + c3;
+  if (s[0] + s[1] + s[2] + s[3] == 123.456) out[0] = s[0];
+}
+
+__global__ __launch_bounds__(256) void probe_copy_kernel(const double2* __restrict__ src, double2* __restrict__ dst,
+                                                         int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) dst[t] = src[t];
+}
+
+hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, int n_partial, double* cost,
+                      hipStream_t st) {
+  if (n_terms == 1 && B <= 16384) {
+    // a small single-term batch: E[B] has the layout of one row of partial sums - one launch instead of two
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(B > 1024 ? 1024 : 256), 0, st, E, (int)B, 1, cost);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(sum_partial_kernel, dim3(n_partial), dim3(256), 0, st, E, B, n_terms, partial);
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, n_partial, n_terms, cost);
+  return hipGetLastError();
+}
+
+hipError_t launch_sum_final(const double* partial, int n_partial, int n_terms, double* cost, hipStream_t st) {
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(n_partial > 1024 ? 1024 : 256), 0, st, partial, n_partial, n_terms, cost);
+  return hipGetLastError();
+}
+
+hipError_t launch_probe_fp64(double* out, int blocks, int iters, hipStream_t st) {
+  hipLaunchKernelGGL(probe_fp64_kernel, dim3(blocks), dim3(256), 0, st, out, iters);
+  return hipGetLastError();
+}
+
+hipError_t launch_probe_mfma_f64(double* out, int blocks, int iters, hipStream_t st) {
+  hipLaunchKernelGGL(probe_mfma_f64_kernel, dim3(blocks), dim3(256), 0, st, out, iters);
+  return hipGetLastError();
+}
+
+// small copies between pinned host memory and HBM done by a kernel ON THE CONTEXT STREAM (n8 units of 8 bytes): a
+// hipMemcpyAsync runs on a copy queue, and the cross-queue dependency in front of / behind it cost 40-80 us per round trip of
+// the optimiser drivers (rocprofv3 kernel trace of bench.py --workload evolve); the kernel reads / writes the pinned buffer directly
+__global__ __launch_bounds__(256) void stage_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n8) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += stride) dst[t] = src[t];
+}
+hipError_t launch_stage_copy(const void* src, void* dst, int64_t n8, hipStream_t st) {
+  if (n8 <= 0) return hipSuccess;
+  int64_t blocks = (n8 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(stage_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const double*)src, (double*)dst, n8);
+  return hipGetLastError();
+}
+
+hipError_t launch_probe_copy(const void* src, void* dst, int64_t n16, hipStream_t st) {
+  hipLaunchKernelGGL(probe_copy_kernel, dim3(2048), dim3(256), 0, st, (const double2*)src, (double2*)dst, n16);
+  return hipGetLastError();
+}
+
+}  // namespace qmps

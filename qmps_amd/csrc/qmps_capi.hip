@@ -74,6 +74,7 @@ struct qmps_ctx {
   unsigned long long* d_ostats = nullptr;   // overlap solver statistics [4] (lazy)
   char* h_pin = nullptr;       // pinned staging for the optimiser drivers' small host <-> device transfers (lazy, grown on demand):
   size_t h_pin_bytes = 0;      //   pageable buffers make every hipMemcpyAsync a blocking, internally staged copy
+  int* d_queue = nullptr;      // D = 16 overlap kernels: two counters the workgroups draw their evaluations from (lazy)
   void* d_y = nullptr;         // qmps_overlap_gradient: LEFT fixed points [max_batch][D][D] (lazy)
   int64_t grad_warm_T = 0;     // d_r / d_y hold the fixed points of this many trajectories' iterates (qmps_overlap_gradient)
   void* d_xwarm = nullptr;     // qmps_evolve_rotosolve: fixed points per (parameter, candidate) (lazy, grown on demand)
@@ -492,7 +493,7 @@ int qmps_destroy(qmps_ctx* c) {
   }
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   if (c->comm_stream2) (void)hipStreamDestroy(c->comm_stream2);
-  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_ref, c->d_f, c->d_ostats, c->d_xwarm, c->d_y, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc, c->d_acc_err, c->roto_base, c->roto_hist, c->roto_idx};
+  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_ref, c->d_f, c->d_ostats, c->d_xwarm, c->d_y, c->d_queue, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc, c->d_acc_err, c->roto_base, c->roto_hist, c->roto_idx};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
@@ -1313,9 +1314,21 @@ int ensure_overlap_outputs(qmps_ctx* c) {
   }
   return QMPS_OK;
 }
+// D = 16 batches above 2 048 evaluations: the four-waves-per-evaluation kernel with a work queue (zeroed here, on the stream)
+int arm_queue(qmps_ctx* c, qmps::OverlapArgs& a, int which) {
+  a.queue = nullptr;
+  if (c->D != 16 || a.B <= 2048 || documented_switch("QMPS_D16_ONE_WAVE") != nullptr || documented_switch("QMPS_D16_BLOCK") != nullptr) return QMPS_OK;
+  if (!c->d_queue) HIP_TRY(hipMalloc((void**)&c->d_queue, 2 * sizeof(int)));
+  HIP_TRY(hipMemsetAsync(c->d_queue + which, 0, sizeof(int), c->stream));
+  a.queue = c->d_queue + which;
+  return QMPS_OK;
+}
+
 // the kernel the overlap launch of this context runs (name for qmps_kernel_time) and whether it counts squarings
 bool overlap_squares(const qmps_ctx* c) { return c->D == 2 || (c->D == 4 && !documented_switch("QMPS_OVERLAP_POWER")); }
-int launch_overlap_kernels(qmps_ctx* c, const qmps::OverlapArgs& a) {
+int launch_overlap_kernels(qmps_ctx* c, const qmps::OverlapArgs& a_in) {
+  qmps::OverlapArgs a = a_in;
+  if (int rc = arm_queue(c, a, 0)) return rc;
   const bool squaring = overlap_squares(c);
   c->dominant = c->D == 2 ? "overlap_lane_kernel" : (c->D == 4 && squaring ? "overlap_square_d4_kernel" :
                 (c->D == 16 && !documented_switch("QMPS_D16_BLOCK") ? "overlap_mfma_d16_kernel" : "overlap_block_kernel<D>"));
@@ -1530,8 +1543,11 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   qmps::OverlapArgs l = a;
   l.adjoint = 1; l.eta = (char*)c->d_eta + (size_t)T * 16; l.f_out = nullptr; l.r_out = c->d_y; l.x_in = warm ? c->d_y : nullptr;
   l.iters = c->d_iters + T; l.status = c->d_status + T; l.max_rounds = max_rounds;
-  if (c->D == 16 && T <= 4096 && documented_switch("QMPS_D16_BLOCK") == nullptr) {
-    // both solves in ONE launch: the iteration chains are latency-bound at these batch sizes, so the left solve rides along
+  if (c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr && documented_switch("QMPS_D16_ONE_WAVE") == nullptr) {
+    // both solves in ONE launch: the iteration chains are latency-bound, so the left solve rides along (more than 2 048
+    // iterates: the workgroups draw them from two queues)
+    if (int e = arm_queue(c, a, 0)) return e;
+    if (int e = arm_queue(c, l, 1)) return e;
     HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream));
   } else {
     HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : documented_switch("QMPS_D16_BLOCK") == nullptr, c->stream));

@@ -179,6 +179,7 @@ struct OverlapArgs {
   const int* slot_ptr;         // nullable: x_in and r_out are displaced by *slot_ptr * slot_stride bytes (rotosolve keeps one
   int64_t slot_stride;         //   set of fixed points per parameter: the candidates of parameter i return to the same slot every sweep)
   unsigned long long* stats;   // nullable [4]: evaluations, sum of rounds, max rounds, not converged (atomics)
+  int* queue;                  // nullable (D = 16, four waves per evaluation): counter the workgroups draw their evaluations from (zeroed by the host)
   int adjoint;                 // 1 (D = 8, 16): the LEFT fixed point - power method on the adjoint map y -> sum_s C_s^+ y Bm_s
                                //   (eigenvalue conj(eta); eta_out receives eta itself)
 };

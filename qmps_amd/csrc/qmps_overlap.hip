@@ -655,7 +655,17 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
     }
   };
   const int64_t slot_off = overlap_slot_offset(p);
-  for (int64_t b = b_first; b < p.B; b += b_stride) {
+  // p.queue != nullptr: the workgroups PULL their evaluations from a counter in HBM (dynamic: a workgroup that drew a slow
+  // candidate - hundreds of power steps against tens - does not hold up the candidates a static stride would have queued behind
+  // it); the counter value travels to the four waves through the (then idle) first exchange word
+  for (int64_t b = b_first;; b += b_stride) {
+    if (p.queue != nullptr) {
+      if (threadIdx.x == 0) ((int*)&sX_all[0][0])[0] = atomicAdd(p.queue, 1);
+      __syncthreads();
+      b = ((const int*)&sX_all[0][0])[0];
+      __syncthreads();
+    }
+    if (b >= p.B) break;
     const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * (2 * D * D);
     const double2* Bp = (const double2*)p.Bt + b * (2 * D * D);
     const double2* W = (const double2*)p.WW;
@@ -866,9 +876,10 @@ hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t 
       if (mfma) {
         // few candidates: four waves per evaluation (the launch waits for its slowest candidate - give it four SIMDs);
         // many: one wave per evaluation (no exchange through LDS, same MFMA work)
-        static const int64_t split_below = tuning_knob("QMPS_D16_SPLIT_BELOW") ? atoll(tuning_knob("QMPS_D16_SPLIT_BELOW")) : 2048;   // A/B knob
-        if (a.B <= split_below) {
-          const dim3 grid((unsigned)(a.B < 4096 ? a.B : 4096));
+        // four waves per evaluation at every batch size (a queue in HBM hands out the evaluations when there are more of them than
+        // workgroups); QMPS_D16_ONE_WAVE: round 2's one-wave-per-evaluation kernel for batches above 2 048
+        if (a.B <= 2048 || a.queue != nullptr) {
+          const dim3 grid((unsigned)(a.B < 2048 ? a.B : 2048));
           if (a.adjoint) hipLaunchKernelGGL(overlap_mfma_d16x4_kernel<true>, grid, dim3(256), 0, st, a);
           else hipLaunchKernelGGL(overlap_mfma_d16x4_kernel<false>, grid, dim3(256), 0, st, a);
         } else {

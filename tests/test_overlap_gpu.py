@@ -148,9 +148,14 @@ def test_d16_split_kernels_match_the_one_wave_kernels(engine_factory, monkeypatc
     G = rng.standard_normal((24, 2 * D, 2 * D)) + 1j * rng.standard_normal((24, 2 * D, 2 * D))
     cand = np.stack([O.unitary_to_tensor(U @ expm(0.05j * (g + g.conj().T) / 2)) for g in G])
     eng = engine_factory(D, 4096)
-    eta_s, it_s, st_s = eng.overlaps(A, cand, WW)                       # 24 candidates: split kernel
-    big = np.concatenate([cand] * 100)                                  # 2400 candidates: one wave per evaluation
+    eta_s, it_s, st_s = eng.overlaps(A, cand, WW)                       # 24 candidates: four waves each
+    big = np.concatenate([cand] * 100)                                  # 2400 candidates: four waves each, drawn from the work queue
+    eta_q, it_q, st_q = eng.overlaps(A, big, WW)
+    assert np.array_equal(st_q, np.tile(st_s, 100)) and np.array_equal(it_q, np.tile(it_s, 100))
+    assert np.abs(eta_q - np.tile(eta_s, 100)).max() == 0.0             # the same kernel body: bit-identical, whichever workgroup drew the candidate
+    monkeypatch.setenv('QMPS_D16_ONE_WAVE', '1')                        # ... and round 2's one wave per evaluation
     eta_b, it_b, st_b = eng.overlaps(A, big, WW)
+    monkeypatch.delenv('QMPS_D16_ONE_WAVE')
     assert np.all(st_s == 0) and np.array_equal(st_b[:24], st_s)
     assert np.abs(eta_b[:24] - eta_s).max() < 1e-12 and np.abs(it_b[:24] - it_s).max() <= 1
     for k in range(0, 24, 5):

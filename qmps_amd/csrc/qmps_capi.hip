@@ -1309,8 +1309,8 @@ int ensure_overlap_outputs(qmps_ctx* c) {
   if (!c->d_eta) HIP_TRY(hipMalloc(&c->d_eta, (size_t)c->max_batch * 16));
   if (!c->d_f) HIP_TRY(hipMalloc((void**)&c->d_f, (size_t)c->max_batch * sizeof(double)));
   if (!c->d_ostats) {
-    HIP_TRY(hipMalloc((void**)&c->d_ostats, 4 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(c->d_ostats, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMalloc((void**)&c->d_ostats, (size_t)qmps::kOverlapStatShards * 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(c->d_ostats, 0, (size_t)qmps::kOverlapStatShards * 4 * sizeof(unsigned long long), c->stream));
   }
   return QMPS_OK;
 }
@@ -1459,9 +1459,16 @@ int qmps_overlap_stats(qmps_ctx* c, int64_t* evaluations, int64_t* rounds_sum, i
   if (int rc = bind(c)) return rc;
   unsigned long long h[4] = {0, 0, 0, 0};
   if (c->d_ostats) {
-    HIP_TRY(hipMemcpyAsync(h, c->d_ostats, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    if (reset) HIP_TRY(hipMemsetAsync(c->d_ostats, 0, sizeof(h), c->stream));
+    std::vector<unsigned long long> sh((size_t)qmps::kOverlapStatShards * 4);
+    HIP_TRY(hipMemcpyAsync(sh.data(), c->d_ostats, sh.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    if (reset) HIP_TRY(hipMemsetAsync(c->d_ostats, 0, sh.size() * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < qmps::kOverlapStatShards; ++k) {
+      h[0] += sh[4 * k];
+      h[1] += sh[4 * k + 1];
+      if (sh[4 * k + 2] > h[2]) h[2] = sh[4 * k + 2];
+      h[3] += sh[4 * k + 3];
+    }
   }
   if (evaluations) *evaluations = (int64_t)h[0];
   if (rounds_sum) *rounds_sum = (int64_t)h[1];

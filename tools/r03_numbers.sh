@@ -19,14 +19,15 @@ run overlap_d16_b768 --workload overlap --D 16 --batch 768 --steps 20 --warmup 3
 run overlap_d16_b96 --workload overlap --D 16 --batch 96 --steps 20 --warmup 3 --no-cpu-baseline
 run overlap_d8_b768 --workload overlap --D 8 --batch 768 --steps 20 --warmup 3 --no-cpu-baseline
 run overlap_d4_b65536 --workload overlap --D 4 --batch 65536 --steps 10 --warmup 2 --no-cpu-baseline
-run evolve_d16_t256 --workload evolve --D 16 --batch 256 --steps 8 --warmup 2
-run evolve_d16_t1024 --workload evolve --D 16 --batch 1024 --steps 6 --warmup 2 --no-cpu-baseline
-run evolve_d16_t256_fd --workload evolve --D 16 --batch 256 --steps 6 --warmup 2 --gradient fd --no-cpu-baseline
+run evolve_d16_t256 --workload evolve --D 16 --batch 256 --steps 10 --warmup 3
+run evolve_d16_t1024 --workload evolve --D 16 --batch 1024 --steps 10 --warmup 3 --no-cpu-baseline
+run evolve_d16_t2048 --workload evolve --D 16 --batch 2048 --steps 8 --warmup 3 --no-cpu-baseline
+run evolve_d16_t256_fd --workload evolve --D 16 --batch 256 --steps 6 --warmup 2 --gradient fd --no-carry-hessian --no-cpu-baseline
 run evolve_d8_t256 --workload evolve --D 8 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline
 run evolve_d4_t256 --workload evolve --D 4 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline
 run evolve_d2_t256 --workload evolve --D 2 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_${tag}_evolve -- python3 $R/bench.py --workload evolve --D 16 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline > $o/${tag}_evolve_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_${tag}_evolve -- python3 $R/bench.py --workload evolve --D 16 --batch 256 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $o/${tag}_evolve_trace.log 2>&1
 for f in $(find $o/prof_${tag}_evolve -name "*kernel_stats.csv"); do cp $f $o/${tag}_evolve_kernel_stats.csv; done
 python3 - <<PY
 import json,glob,os

@@ -313,6 +313,12 @@ int qmps_overlap_set_refs_ansatz(qmps_ctx* ctx, int64_t n_ref, int kind, int n_p
  * n_ref G >= window + B and a window that starts at a multiple of G.  group = 0 (default, and after qmps_overlap_set*):
  * one shared reference (n_ref = 1) or one per candidate. */
 int qmps_overlap_set_group(qmps_ctx* ctx, int64_t group);
+/* One-shot mask for the NEXT qmps_overlap_launch / qmps_overlap_eval_ansatz / qmps_overlap_gradient: active[t] == 0 skips every
+ * candidate of trajectory t (candidate group t with qmps_overlap_set_group, candidate t otherwise; iterate t of
+ * qmps_overlap_gradient) - eta, objective, status, fixed points and gradient entries of a skipped trajectory keep the values the
+ * previous launch left.  The lock-step optimiser drivers evaluate every trajectory in every iteration so that batch shapes and
+ * warm-start slots never change; with the mask a trajectory that has converged costs nothing.  n = 0 or active = NULL disarms. */
+int qmps_overlap_set_active(qmps_ctx* ctx, int64_t n, const unsigned char* active);
 /* flags of qmps_overlap_launch (the argument was `want_r` in ABI 2: bit 0 keeps that meaning) */
 #define QMPS_OVERLAP_WANT_R 1 /* keep the unit-Frobenius right fixed points resident (qmps_overlap_get r_out) */
 /* Warm start (D = 8, 16: the power method; ignored by the squaring solvers of D = 2, 4, whose cost does not depend on the

@@ -74,6 +74,8 @@ struct qmps_ctx {
   unsigned long long* d_ostats = nullptr;   // overlap solver statistics [4] (lazy)
   char* h_pin = nullptr;       // pinned staging for the optimiser drivers' small host <-> device transfers (lazy, grown on demand):
   size_t h_pin_bytes = 0;      //   pageable buffers make every hipMemcpyAsync a blocking, internally staged copy
+  unsigned char* d_active = nullptr;   // qmps_overlap_set_active: per-trajectory mask consumed by the next overlap launch (lazy, [max_batch])
+  int64_t active_n = 0;                //   entries armed (0: none)
   int* d_queue = nullptr;      // D = 16 overlap kernels: two counters the workgroups draw their evaluations from (lazy)
   void* d_y = nullptr;         // qmps_overlap_gradient: LEFT fixed points [max_batch][D][D] (lazy)
   int64_t grad_warm_T = 0;     // d_r / d_y hold the fixed points of this many trajectories' iterates (qmps_overlap_gradient)
@@ -493,7 +495,7 @@ int qmps_destroy(qmps_ctx* c) {
   }
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   if (c->comm_stream2) (void)hipStreamDestroy(c->comm_stream2);
-  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_ref, c->d_f, c->d_ostats, c->d_xwarm, c->d_y, c->d_queue, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc, c->d_acc_err, c->roto_base, c->roto_hist, c->roto_idx};
+  void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_ref, c->d_f, c->d_ostats, c->d_xwarm, c->d_y, c->d_queue, c->d_active, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc, c->d_acc_err, c->roto_base, c->roto_hist, c->roto_idx};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
@@ -1381,6 +1383,25 @@ int qmps_overlap_set_group(qmps_ctx* c, int64_t group) {
   return QMPS_OK;
 }
 
+int qmps_overlap_set_active(qmps_ctx* c, int64_t n, const unsigned char* active) {
+  if (int rc = bind(c)) return rc;
+  if (n < 0 || n > c->max_batch) return fail(QMPS_ERR_ARG, "n=%lld outside [0, max_batch]", (long long)n);
+  if (n == 0 || !active) {
+    c->active_n = 0;
+    return QMPS_OK;
+  }
+  if (!c->d_active) HIP_TRY(hipMalloc((void**)&c->d_active, (size_t)c->max_batch));
+  if (int rc = ensure_pinned(c, (16u << 20))) return rc;
+  // through the pinned staging buffer (its last MiB: the parameter / result regions may be in use by the same driver)
+  unsigned char* stage = (unsigned char*)c->h_pin + (15u << 20);
+  if ((size_t)n > (1u << 20)) return fail(QMPS_ERR_ARG, "mask longer than 2^20 entries");
+  memcpy(stage, active, (size_t)n);
+  memset(stage + n, 1, (size_t)((8 - n % 8) % 8));
+  HIP_TRY(qmps::launch_stage_copy(stage, c->d_active, (n + 7) / 8, c->stream));
+  c->active_n = n;
+  return QMPS_OK;
+}
+
 int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int flags) {
   if (int rc = bind(c)) return rc;
   if (int rc = check_window(c, B)) return rc;
@@ -1417,6 +1438,12 @@ int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int 
   a.stats = c->d_ostats;
   a.group = (int)group;
   a.iters = win_iters(c); a.status = win_status(c); a.B = B; a.a_shared = shared ? 1 : 0; a.max_rounds = max_rounds; a.tol = tol;
+  if (c->active_n > 0) {           // one-shot mask of qmps_overlap_set_active: one entry per trajectory (candidate group)
+    const int64_t need = group > 0 ? (c->window + B + group - 1) / group : c->window + B;
+    if (c->active_n < need) return fail(QMPS_ERR_STATE, "qmps_overlap_set_active: %lld entries for %lld trajectories", (long long)c->active_n, (long long)need);
+    a.active = c->d_active + (group > 0 ? c->window / group : c->window);
+    c->active_n = 0;
+  }
   if (int rc = launch_overlap_kernels(c, a)) return rc;
   c->have_env = false;
   c->have_guess = false;
@@ -1541,6 +1568,13 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   a.x_in = (warm && !squaring) ? c->d_r : nullptr;
   a.stats = c->d_ostats; a.iters = c->d_iters; a.status = c->d_status; a.B = T; a.a_shared = 0;
   a.max_rounds = squaring && max_rounds > 60 ? 60 : max_rounds; a.tol = tol;
+  const unsigned char* mask = nullptr;
+  if (c->active_n > 0) {
+    if (c->active_n < T) return fail(QMPS_ERR_STATE, "qmps_overlap_set_active: %lld entries for %lld trajectories", (long long)c->active_n, (long long)T);
+    mask = c->d_active;
+    c->active_n = 0;
+  }
+  a.active = mask;
   // HIP events around the WHOLE gradient evaluation (right solve, left solve, neighbour tensors, G, probes): qmps_kernel_time
   c->dominant = c->D == 16 ? "overlap_mfma_d16_kernel + adjoint + neighbour probes" : "overlap solve + adjoint + neighbour probes";
   c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
@@ -1567,7 +1601,7 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   qmps::OverlapGradArgs g;
   memset(&g, 0, sizeof(g));
   g.A = c->d_ref; g.WW = c->d_ww; g.r = c->d_r; g.y = c->d_y; g.G = c->d_scratch; g.yr = (char*)c->d_scratch + (size_t)T * 4 * nD * 16;
-  g.Bt = (char*)c->d_A + (size_t)T * tensor_bytes(c); g.f_out = c->d_f + T; g.T = T; g.G2P = 2 * P;
+  g.Bt = (char*)c->d_A + (size_t)T * tensor_bytes(c); g.f_out = c->d_f + T; g.T = T; g.G2P = 2 * P; g.active = mask;
   HIP_TRY(qmps::launch_overlap_grad(c->D, g, c->stream));
   if (c->timed) { HIP_TRY(hipEventRecord(c->kev1[tslot], c->stream)); c->samples++; }
   c->launches++;

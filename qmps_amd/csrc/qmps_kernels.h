@@ -179,6 +179,8 @@ struct OverlapArgs {
   const int* slot_ptr;         // nullable: x_in and r_out are displaced by *slot_ptr * slot_stride bytes (rotosolve keeps one
   int64_t slot_stride;         //   set of fixed points per parameter: the candidates of parameter i return to the same slot every sweep)
   unsigned long long* stats;   // nullable [kOverlapStatShards][4]: evaluations, sum of rounds, max rounds, not converged (atomics, sharded by evaluation index)
+  const unsigned char* active; // nullable [B / max(group, 1)]: 0 = SKIP every candidate of that trajectory (its outputs keep the values of
+                               //   the previous launch) - the lock-step optimiser drivers stop paying for trajectories that have converged
   int* queue;                  // nullable (D = 16, four waves per evaluation): counter the workgroups draw their evaluations from (zeroed by the host)
   int adjoint;                 // 1 (D = 8, 16): the LEFT fixed point - power method on the adjoint map y -> sum_s C_s^+ y Bm_s
                                //   (eigenvalue conj(eta); eta_out receives eta itself)
@@ -195,11 +197,13 @@ struct OverlapGradArgs {
   double* f_out;       // [T * 2P]: -sqrt|eta'|,  eta' = <y, T'(r)>/<y, r>
   int64_t T;
   int G2P;             // neighbours per trajectory (2 P)
+  const unsigned char* active;   // nullable [T]: 0 = skip the trajectory (outputs keep their previous values)
 };
 hipError_t launch_overlap_grad(int D, const OverlapGradArgs& a, hipStream_t st);
 constexpr int kOverlapStatShards = 1024;
 #if defined(__HIPCC__)
 __device__ __forceinline__ int64_t overlap_ref_index(const OverlapArgs& p, int64_t b) { return p.group > 0 ? b / p.group : (p.a_shared ? 0 : b); }
+__device__ __forceinline__ bool overlap_skipped(const OverlapArgs& p, int64_t b) { return p.active != nullptr && p.active[p.group > 0 ? b / p.group : b] == 0; }
 __device__ __forceinline__ int64_t overlap_slot_offset(const OverlapArgs& p) { return p.slot_ptr != nullptr ? (int64_t)(*p.slot_ptr) * p.slot_stride : 0; }
 // results of one evaluation (called by ONE lane)
 __device__ __forceinline__ void overlap_store(const OverlapArgs& p, int64_t b, double eta_r, double eta_i, int rounds, int status) {

@@ -61,6 +61,7 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_block_kerne
   __shared__ double red[4][WAVES > 1 ? WAVES : 1];
   const int tid = threadIdx.x, e = tid / N, l = tid % N, i = l / D, j = l % D;
   const int64_t b = (int64_t)blockIdx.x * ITEMS + e;
+  if (ITEMS == 1 && b < p.B && overlap_skipped(p, b)) return;      // (one evaluation per workgroup: a uniform exit)
   const bool valid = b < p.B;
   const int64_t bb = valid ? b : p.B - 1;       // surplus lanes of the last workgroup shadow a real evaluation
   // sum over the N threads of one evaluation (up to four values at a time), result in every one of them
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
   };
   const int64_t slot_off = overlap_slot_offset(p);
   for (int64_t b = (int64_t)blockIdx.x * WAVES + wave; b < p.B; b += (int64_t)gridDim.x * WAVES) {
+    if (overlap_skipped(p, b)) continue;
     const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * (2 * D * D);
     const double2* Bp = (const double2*)p.Bt + b * (2 * D * D);
     const double2* W = (const double2*)p.WW;
@@ -443,6 +445,7 @@ __global__ __launch_bounds__(256) void overlap_square_d4_kernel(OverlapArgs p) {
     }
   };
   for (int64_t b = (int64_t)blockIdx.x * WAVES + wave; b < p.B; b += (int64_t)gridDim.x * WAVES) {
+    if (overlap_skipped(p, b)) continue;
     // ---- set-up through LDS: inputs at sT[0..63], then C_s[i][j] at sT[64 + 16 s + 4 i + j], Bm_s at sT[128 + ...]
     {
       const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * 32;
@@ -666,6 +669,7 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
       __syncthreads();
     }
     if (b >= p.B) break;
+    if (overlap_skipped(p, b)) continue;          // (uniform over the workgroup: all four waves see the same b)
     const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * (2 * D * D);
     const double2* Bp = (const double2*)p.Bt + b * (2 * D * D);
     const double2* W = (const double2*)p.WW;
@@ -910,7 +914,7 @@ hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void overlap_lane_kernel(OverlapArgs p) {
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= p.B) return;
+  if (b >= p.B || overlap_skipped(p, b)) return;
   const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * 8;
   const double2* Bp = (const double2*)p.Bt + b * 8;
   const double2* W = (const double2*)p.WW;

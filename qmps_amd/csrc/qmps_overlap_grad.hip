@@ -81,6 +81,7 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_g_kernel(Ov
   __shared__ double red[16];
   const int tid = threadIdx.x, e = tid / N, l = tid % N, i = l / D, j = l % D;
   const int64_t t = (int64_t)blockIdx.x * ITEMS + e;
+  if (ITEMS == 1 && p.active != nullptr && t < p.T && p.active[t] == 0) return;      // skipped trajectory (uniform exit)
   const int64_t tt = t < p.T ? t : p.T - 1;       // surplus lanes of the last workgroup shadow a real trajectory
   {
     const double2* Ap = (const double2*)p.A + tt * (2 * N);
@@ -131,12 +132,12 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_g_kernel(Ov
     double2 g = make_double2(0.0, 0.0);
 #pragma unroll
     for (int k = 0; k < D; ++k) cfma_conj1(sYv[e][k][i], sC[e][s][k][j], g);
-    if (t < p.T) Gp[s * N + l] = g;
+    if (t < p.T && !(p.active != nullptr && p.active[t] == 0)) Gp[s * N + l] = g;
   }
   const double2 yv = sYv[e][i][j], rv = sR[e][i][j];
   double a = yv.x * rv.x + yv.y * rv.y, b = yv.x * rv.y - yv.y * rv.x;   // conj(y) r
   item_sum2<N>(a, b, red, tid);
-  if (l == 0 && t < p.T) ((double2*)p.yr)[t] = make_double2(a, b);
+  if (l == 0 && t < p.T && !(p.active != nullptr && p.active[t] == 0)) ((double2*)p.yr)[t] = make_double2(a, b);
 }
 
 // eta' = sum_s tr(Bm'_s^+ G_s) / <y, r>,  f = -sqrt|eta'|  per central-difference neighbour
@@ -150,6 +151,7 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_probe_kerne
   const int64_t b = (int64_t)blockIdx.x * ITEMS + e;
   const int64_t bb = b < nb ? b : nb - 1;
   const int64_t t = bb / p.G2P;
+  if (ITEMS == 1 && p.active != nullptr && p.active[t] == 0) return;
   {
     const double2* Bp = (const double2*)p.Bt + bb * (2 * N);
     sB[e][0][i][j] = Bp[l];
@@ -170,7 +172,7 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_probe_kerne
       ni = dfma(bm.x, g.y, dfma(-bm.y, g.x, ni));
     }
   item_sum2<N>(nr, ni, red, tid);
-  if (l == 0 && b < nb) {
+  if (l == 0 && b < nb && !(p.active != nullptr && p.active[t] == 0)) {
     const double2 d = ((const double2*)p.yr)[t];
     const double den = d.x * d.x + d.y * d.y;
     const double er = (nr * d.x + ni * d.y) / den, ei = (ni * d.x - nr * d.y) / den;

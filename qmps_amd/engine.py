@@ -395,6 +395,15 @@ class EnergyEngine:
         """Trajectory-major batches: candidate b is compared with reference b // group (0 = shared / one per candidate)."""
         L.check(self._lib.qmps_overlap_set_group(self._ctx, int(group)))
 
+    def overlap_set_active(self, active):
+        """One-shot mask for the next overlap launch / evaluation / gradient: trajectories with active[t] == False are skipped
+        (their outputs keep the previous launch's values).  None disarms."""
+        if active is None:
+            L.check(self._lib.qmps_overlap_set_active(self._ctx, 0, None))
+            return
+        m = np.ascontiguousarray(np.asarray(active, dtype=bool).astype(np.uint8))
+        L.check(self._lib.qmps_overlap_set_active(self._ctx, m.size, m.ctypes.data_as(ctypes.c_char_p)))
+
     def overlap_launch(self, B=None, max_rounds=None, tol=1e-13, want_r=False, warm=False):
         """Asynchronous: overlaps of the resident candidates [window, window + B) with the resident reference(s).
         warm=True (D = 8, 16): start every candidate from the fixed point its slot holds from the previous launch

@@ -215,7 +215,9 @@ class LockstepEvolver:
         self.fg.set_reference(X, WW)
         self.fl.set_reference(X, WW)
         vg = (lambda Z: self.fg.value_and_grad(Z, self.eps)) if self.two_sided else None
-        res = batched_bfgs(self.fg, self.fl, X, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas,
+        def on_active(kind, mask):          # converged trajectories cost nothing in the batches that follow
+            (self.fg if kind == 'grad' else self.fl).eng.overlap_set_active(mask)
+        res = batched_bfgs(self.fg, self.fl, X, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas, on_active=on_active,
                            value_and_grad=vg, first_rungs=None if self.speculative else self.first_rungs,
                            Hinv0=self._hinv if self.carry_hessian else None, speculative=self.speculative)
         self._hinv = res['hess_inv']

@@ -263,7 +263,7 @@ def batched_fd_gradient(batch_fun, X, h=1e-6, F0=None):
 
 
 def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=1e-4,
-                 alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), value_and_grad=None, first_rungs=None, Hinv0=None, speculative=False):
+                 alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), value_and_grad=None, first_rungs=None, Hinv0=None, speculative=False, on_active=None):
     """T independent BFGS minimisations in LOCK-STEP (scipy's BFGS is what the reference's time-evolution loop runs per
     step: `minimize(obj, params, (A_, WW))`, new_time_evolve.py:284 / scripts/loschmidt.py:371 - one trajectory, one
     scalar objective call at a time).  Here every iteration is two batched evaluations over all trajectories:
@@ -283,6 +283,9 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
     if every active trajectory accepts that step (Armijo) - the normal case of a quasi-Newton iteration - the iteration is that
     ONE batch; otherwise the remaining rungs of the ladder are evaluated (line_batch receives T (len(alphas) - 1) candidates) and
     the gradient at the accepted points as usual.  Same decisions as the plain ladder: the first rung is tested first either way.
+    on_active (optional): called as on_active('grad' | 'line', active (T,) bool) right before every batch of the loop - an evaluator
+    that can skip trajectories (qmps_overlap_set_active) then spends nothing on the converged ones; rows of skipped trajectories
+    may come back with stale values: they are never used.
     Hinv0 (optional, (T,P,P)): initial inverse Hessians instead of the identity (scipy's start) - e.g. the ones the previous time
     step of the same trajectories ended with; the result carries the final ones as 'hess_inv'.
     Returns dict(x (T,P), fun (T,), jac (T,P), nit, nfev, converged (T,), history [fun per iteration], hess_inv (T,P,P))."""
@@ -306,12 +309,17 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
             slope[bad] = -np.einsum('ti,ti->t', g[bad], g[bad])
         d[~active] = 0.0
         def ladder(a):
+            if on_active is not None:
+                on_active('line', active)
             cand = X[:, None, :] + a[None, :, None] * d[:, None, :]
             F = np.asarray(line_batch(cand.reshape(-1, P))).reshape(T, len(a))
             return np.where(np.isfinite(F), F, np.inf)
         fn = gn = None
         if speculative and value_and_grad is not None:
+            if on_active is not None:
+                on_active('grad', active)
             fs, gs = vg(X + al[0] * d)
+            fs, gs = np.where(active, fs, f), np.where(active[:, None], gs, g)      # (rows of skipped trajectories: their last values)
             nfev += T * (2 * P + 1)
             Fc = np.full((T, len(al)), np.inf)
             Fc[:, 0] = np.where(np.isfinite(fs), fs, np.inf)
@@ -338,6 +346,8 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
         s = a[:, None] * d
         Xn = X + s
         if fn is None:
+            if on_active is not None:
+                on_active('grad', active)
             fn, gn = vg(Xn)
             nfev += T * (2 * P + 1)
         y = gn - g

@@ -270,3 +270,45 @@ def test_reference_signature_single_trajectory(engine_factory):
     p4 = rng.standard_normal(4)
     A4 = NT.state_tensor(p4, D=4)
     assert abs(NT.obj(p4 + 0.01, A4, WW) - O.overlap_objective(A4, NT.state_tensor(p4 + 0.01, D=4), WW)) < 1e-10
+
+
+@pytest.mark.parametrize('D,P', [(4, 4), (16, 8)])
+def test_active_mask_skips_trajectories_and_keeps_their_values(D, P, engine_factory):
+    """qmps_overlap_set_active: a one-shot per-trajectory mask - the masked trajectories' candidates / iterates are skipped (no
+    solver rounds counted) and their outputs keep the previous launch's values; the others are evaluated as usual."""
+    rng = np.random.default_rng(60 + D)
+    eng = engine_factory(D, 4096)
+    T, G = 6, 3
+    WW = WW_of(0.05)
+    ref = rng.standard_normal((T, P))
+    cand = (ref[:, None, :] + 0.03 * rng.standard_normal((T, G, P))).reshape(T * G, P)
+    eng.overlap_set_refs_params(0, ref, WW)
+    eng.overlap_set_group(G)
+    f0, st0 = eng.overlap_eval_params(0, cand, tol=1e-13)
+    moved = cand + 0.01 * rng.standard_normal(cand.shape)
+    mask = np.array([1, 0, 1, 1, 0, 1], dtype=bool)
+    eng.overlap_stats(reset=True)
+    eng.overlap_set_active(mask)
+    f1, st1 = eng.overlap_eval_params(0, moved, tol=1e-13)
+    assert eng.overlap_stats()['evaluations'] == int(mask.sum()) * G
+    f_all, _ = eng.overlap_eval_params(0, moved, tol=1e-13)            # the mask was one-shot: everything is evaluated again
+    for t in range(T):
+        rows = slice(t * G, (t + 1) * G)
+        if mask[t]:
+            assert np.abs(f1[rows] - f_all[rows]).max() < 1e-13
+        else:
+            assert np.array_equal(f1[rows], f0[rows]) and np.abs(f_all[rows] - f0[rows]).max() > 1e-9
+    # the gradient entry point
+    eng.overlap_set_group(0)
+    X = ref + 0.02 * rng.standard_normal((T, P))
+    fa, ga, _ = eng.overlap_gradient(0, X, tol=1e-13)
+    X2 = X + 0.01 * rng.standard_normal(X.shape)
+    eng.overlap_set_active(mask)
+    fb, gb, _ = eng.overlap_gradient(0, X2, tol=1e-13)
+    fc, gc, _ = eng.overlap_gradient(0, X2, tol=1e-13)
+    assert np.array_equal(fb[~mask], fa[~mask]) and np.array_equal(gb[~mask], ga[~mask])
+    assert np.abs(fb[mask] - fc[mask]).max() < 1e-12 and np.abs(gb[mask] - gc[mask]).max() < 1e-7
+    with pytest.raises(L.QmpsError):
+        eng.overlap_set_active(mask[:3])
+        eng.overlap_gradient(0, X2, tol=1e-13)                          # three entries for six trajectories
+    eng.overlap_set_active(None)

@@ -2,6 +2,7 @@
 // Host-side runtime: context = one device + one HIP stream + HBM buffers; asynchronous launches;
 // pinned staging for small results; native RCCL communicator for the summed-cost all-reduce.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <rccl/rccl.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -684,18 +685,44 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     return QMPS_OK;
   };
   if (int rc = grow(c->roto_base, c->roto_base_bytes, (size_t)R * n_params * sizeof(double))) return rc;
-#ifdef QMPS_D8_PROFILE        // scratch instrumentation build (tools/scratch/d8_profile.py): 8 phase clocks behind the history
-  constexpr size_t kHistExtra = 8;
+  // The run's results (final parameters, energy history) come back through the context's pinned buffer when they fit: the
+  // first LARGE copy into pageable memory makes the runtime set up its internal staging, ~8 ms once per process (measured
+  // in the first 160-sweep call after an 8-sweep one: 27.7 instead of 19.5 us per parameter update at D = 8).
+  auto download_results = [&](size_t hist_doubles) -> int {
+    const size_t pb = (size_t)R * n_params * sizeof(double), hb = hist_doubles * sizeof(double);
+    if (pb + hb <= (8u << 20)) {
+      if (int e = ensure_pinned(c, (16u << 20))) return e;
+      HIP_TRY(hipMemcpyAsync(c->h_pin, c->roto_base, pb, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(c->h_pin + pb, c->roto_hist, hb, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      memcpy(params, c->h_pin, pb);
+      memcpy(E_hist, c->h_pin + pb, hb);
+      return QMPS_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(params, c->roto_base, pb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(E_hist, c->roto_hist, hb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QMPS_OK;
+  };
+#ifdef QMPS_D8_PROFILE        // scratch instrumentation build (tools/scratch/d8_profile.py): 16 phase clocks behind the history
+  constexpr size_t kHistExtra = 16 + 3 * 4096;
 #else
   constexpr size_t kHistExtra = 0;
 #endif
+#ifdef QMPS_D8_PROFILE
+  const auto g0 = std::chrono::steady_clock::now();
+#endif
   if (int rc = grow(c->roto_hist, c->roto_hist_bytes, ((size_t)R * n_sweeps + kHistExtra) * sizeof(double))) return rc;
+#ifdef QMPS_D8_PROFILE
+  fprintf(stderr, "[d8 profile] history buffer: %.0f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g0).count());
+#endif
   if (!c->roto_idx) HIP_TRY(hipMalloc((void**)&c->roto_idx, 4 * sizeof(int)));
   double *d_base = c->roto_base, *d_hist = c->roto_hist;
   int* d_idx = c->roto_idx;
   int rc = [&]() -> int {
     HIP_TRY(hipMemcpyAsync(d_base, params, (size_t)R * n_params * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(d_idx, 0, 3 * sizeof(int), c->stream));   // parameter index, arrival counter, finished sweeps
+    if (kHistExtra) HIP_TRY(hipMemsetAsync(d_hist + (size_t)R * n_sweeps, 0, kHistExtra * sizeof(double), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const bool saved_guess = c->have_guess;
     c->have_guess = false;
@@ -714,10 +741,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
       c->n_states = R; c->ans_have = false; c->tensors_valid = true;
       if (int e = qmps_energy_launch(c, R, max_iter, tol, c->default_solver)) return e;
       c->have_guess = saved_guess;
-      HIP_TRY(hipMemcpyAsync(params, d_base, (size_t)R * n_params * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipMemcpyAsync(E_hist, d_hist, (size_t)R * n_sweeps * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipStreamSynchronize(c->stream));
-      return QMPS_OK;
+      return download_results((size_t)R * n_sweeps);
     }
     // D = 8 (ShallowCNOT families, direct solver): the whole run in ONE launch as well - a workgroup per restart, a wave per
     // shift (qmps_roto_d8.hip); afterwards one ordinary evaluation of the final parameters, as above
@@ -730,14 +754,24 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
       ra.base = d_base; ra.h = c->d_h; ra.hist = d_hist;
       ra.R = (int)R; ra.P = n_params; ra.n_terms = c->n_terms; ra.n_sweeps = n_sweeps; ra.max_iter = max_iter;
       ra.tol = tol; ra.direct = 1; ra.nsh = nsh;
+#ifdef QMPS_D8_PROFILE
+      auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+      const double h0 = now();
+#endif
       HIP_TRY(qmps::launch_rotosolve_fused_d8(kind, ra, c->stream));
+#ifdef QMPS_D8_PROFILE
+      const double h1 = now();
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      const double h2 = now();
+#endif
       HIP_TRY(qmps::launch_ansatz(c->D, kind, d_base, n_params, c->d_A, R, c->stream));
       c->n_states = R; c->ans_have = false; c->tensors_valid = true;
       if (int e = qmps_energy_launch(c, R, max_iter, tol, c->default_solver)) return e;
       c->have_guess = saved_guess;
-      HIP_TRY(hipMemcpyAsync(params, d_base, (size_t)R * n_params * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipMemcpyAsync(E_hist, d_hist, ((size_t)R * n_sweeps + kHistExtra) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (int e = download_results((size_t)R * n_sweeps + kHistExtra)) return e;
+#ifdef QMPS_D8_PROFILE
+      fprintf(stderr, "[d8 profile] launch call %.0f us, kernel until sync %.0f us, final evaluation + downloads %.0f us\n", h1 - h0, h2 - h1, now() - h2);
+#endif
       return QMPS_OK;
     }
     // One parameter update = shift build -> ansatz -> environment + energy -> closed-form update.  The
@@ -819,10 +853,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
       c->tensors_valid = true;
     }
     c->have_guess = saved_guess;
-    HIP_TRY(hipMemcpyAsync(params, d_base, (size_t)R * n_params * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(E_hist, d_hist, (size_t)R * n_sweeps * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return QMPS_OK;
+    return download_results((size_t)R * n_sweeps);
   }();
   c->capturing = false;
   (void)hipStreamSynchronize(c->stream);

@@ -24,8 +24,17 @@ __device__ __forceinline__ void d8_update(double (&Mn)[4][16], const double (&nf
 
 // One wave, lane = 8 i + i'.  sA: the evaluation's tensor A_s[i][j] (padded rows of 9), sT / sM: scratch.  Returns r[i][i'] of
 // the lane (trace 1); a non-finite or ill-conditioned solve returns the default start 1/8 (the caller's power iteration decides).
-__device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9], double (*sT)[9], double (*sM)[17], int lane) {
+__device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9], double (*sT)[9], double (*sM)[17], int lane,
+                                                        long long* prof = nullptr) {     // prof: phase clocks, scratch builds only
   constexpr int D = 8, N = 64;
+  auto tick = [&](int k) {
+    if (prof) {
+      __builtin_amdgcn_sched_barrier(0);
+      prof[k] = wall_clock64();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  tick(0);
   const int i = lane >> 3, ip = lane & 7;
   double M[N];
   {
@@ -79,6 +88,7 @@ __device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9]
     for (int j = 0; j < D; ++j) M[9 * j] += w63;
   }
   __builtin_amdgcn_sched_barrier(0);
+  tick(1);
   // ---- elimination in a 2-D cyclic layout: lane (g, c) = (lane >> 4, lane & 15) holds rows c + 16 m (m < 4) x columns
   // g + 4 t (t < 16).  Step k: the pivot row's entries of the lane's column class sit in lane k % 16 OF THE SAME
   // 16-LANE DPP ROW, so the update is ONE instruction per entry - v_fmac_f64_dpp row_newbcast (gfx90a+ 64-bit DPP, full
@@ -102,6 +112,7 @@ __device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9]
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  tick(2);
   double x;
   {
     const int c = lane & 15;
@@ -111,6 +122,65 @@ __device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9]
       const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
       return __hiloint2double(hi, lo);
     };
+#ifdef QMPS_D8_BLOCKED_PANEL
+    // Blocks of four pivots (k = 4 K .. 4 K + 3: column class K of the four row groups).  The PANEL - the lane's rows' entries in
+    // those four columns and the 4 x 4 pivot block - is fetched once per block (ds_bpermute / v_readlane: ~150 cycles of latency,
+    // paid 16 instead of 64 times) and eliminated in registers, which gives the multipliers of all four steps; the bulk update
+    // then applies the four steps class by class, in order, in place (step q reads pivot row k + q as steps < q left it): the
+    // same fused multiply-adds in the same order as the step-by-step elimination, bit for bit.  Software pipeline: a block
+    // first updates the column class that holds the next panel, then fetches it, and only then the rest of its updates,
+    // which cover that latency (one wave per SIMD at small batches: nothing else would).
+    double Cm[4][4], Pb[4][4];
+    auto fetch_panel = [&](auto KK) {
+      constexpr int K = decltype(KK)::value, kq = K >> 2, kc0 = (4 * K) & 15;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) Cm[m][q] = __shfl(Mn[m][K], 16 * q + c, 64);        // M[c + 16 m][4 K + q]
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) Pb[q][q2] = from_lane(Mn[kq][K], 16 * q2 + kc0 + q);   // M[4 K + q][4 K + q2]
+    };
+    fetch_panel(std::integral_constant<int, 0>{});
+    static_for<16>([&](auto KK) {
+      constexpr int K = decltype(KK)::value, kq = K >> 2, kc0 = (4 * K) & 15;
+      double nf[4][4];
+      static_for<4>([&](auto QQ) {
+        constexpr int q1 = decltype(QQ)::value;
+        const double pinv = fast_rcp(Pb[q1][q1]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const bool piv = m == kq && c == kc0 + q1;
+          dinv[m] = piv ? pinv : dinv[m];
+          nf[q1][m] = piv ? 0.0 : -Cm[m][q1] * pinv;
+        }
+#pragma unroll
+        for (int q2 = q1 + 1; q2 < 4; ++q2) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) Cm[m][q2] = dfma(Pb[q1][q2], nf[q1][m], Cm[m][q2]);
+#pragma unroll
+          for (int q = q1 + 1; q < 4; ++q) Pb[q][q2] = dfma(Pb[q1][q2], -Pb[q][q1] * pinv, Pb[q][q2]);
+        }
+      });
+      // bulk: column classes t > K (class K was the panel: never read again)
+      if constexpr (K < 15) {
+        static_for<4>([&](auto QQ) { d8_update<kc0 + decltype(QQ)::value, kq, K + 1>(Mn, nf[decltype(QQ)::value]); });
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_panel(std::integral_constant<int, K + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      static_for<16>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        if constexpr (t >= K + 2)
+          static_for<4>([&](auto QQ) { d8_update<kc0 + decltype(QQ)::value, kq, t>(Mn, nf[decltype(QQ)::value]); });
+      });
+      if constexpr (K == 15) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) yv[m] = nf[3][m];
+      }
+    });
+#else
     // Software pipeline: step k first updates the column class that holds column k + 1, then fetches step k + 1's pivot
     // and multipliers (v_readlane + v_rcp_f64, ds_bpermute: ~150 cycles of latency) and only then the rest of its own
     // updates, which cover that latency (one wave per SIMD at small batches: nothing else would).
@@ -147,6 +217,8 @@ __device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9]
         for (int m = 0; m < 4; ++m) yv[m] = nf[m];
       }
     });
+#endif
+    tick(3);
     // coordinate a = c + 16 m: the four row groups hold the same values; row group 0 hands them out through LDS
     __builtin_amdgcn_wave_barrier();
     if (lane < 16) {
@@ -179,6 +251,7 @@ __device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9]
     re = i == ip ? 1.0 / D : 0.0;
     im = 0.0;
   }
+  tick(4);
   return make_double2(re, im);
 }
 

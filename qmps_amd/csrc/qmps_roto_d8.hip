@@ -15,6 +15,7 @@
 //   3. publishes its energy; wave 0 applies the update to the restart's parameter vector in LDS.
 // No launch, no graph replay, no HBM traffic inside the run: a parameter update costs the latency of ONE evaluation.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "qmps_kernels.h"
@@ -144,11 +145,18 @@ __device__ __forceinline__ void build_tensor_d8(D8Work& w, Par par, int n_params
 // ||r' - r||_F < tol, LDL^H pivots > 0, E = sum over the Hamiltonian terms (the reference's M(x) = np.sum(eps), qmps/tools.py:432-433).
 // The arithmetic of energy_block_kernel<8, true, FUSED> (qmps_kernels.hip) with wave-local synchronisation.
 __device__ __forceinline__ double eval_d8(D8Work& w, const double2* __restrict__ h, int n_terms, int max_iter, double tol, int lane,
-                                          int& status_out) {
+                                          int& status_out, long long* prof = nullptr, int* iters_out = nullptr) {
   constexpr int D = 8;
+  auto tick = [&](int k) {
+    if (prof) {
+      __builtin_amdgcn_sched_barrier(0);
+      prof[k] = wall_clock64();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   const int i = lane >> 3, j = lane & 7;
   wsync();
-  double2 r = env_direct_d8_solve(w.sA, w.sT8, w.sM8, lane);
+  double2 r = env_direct_d8_solve(w.sA, w.sT8, w.sM8, lane, prof);
   w.sR[i][j] = r;
   wsync();
   double2 ai_[2][D];
@@ -202,11 +210,13 @@ __device__ __forceinline__ double eval_d8(D8Work& w, const double2* __restrict__
     wsync();
     w.sR[i][j] = r;
     wsync();
+    if (iters_out) *iters_out = it;
     if (d2 < tol2) {
       status = QMPS_ST_OK;
       break;
     }
   }
+  tick(5);
   if (status == QMPS_ST_OK) {
     // positive definiteness: the pivots of LDL^H, all 64 lanes at once (thread (i, j) owns the Schur-complement entry)
     double2 S = r;
@@ -226,57 +236,62 @@ __device__ __forceinline__ double eval_d8(D8Work& w, const double2* __restrict__
     if (!ok) status = QMPS_ST_NOT_PD;
     wsync();
   }
-  // ---- energy: rho[tau][sigma] = tr(A_t1 (A_t2 r A_s2^+) A_s1^+), this lane's share; E is linear in rho: one wave sum per term
+  tick(6);
+  // ---- energy: rho[tau][sigma] = tr(B_tau r B_sigma^+), B_(2 t1 + t2) = A_t1 A_t2 (qmps/tools.py:432-433 through the merged
+  // two-site tensor).  Two stages - the four B_tau, then Y_tau = B_tau r - and the lane's share Y_tau[i][j] conj(B_sigma[i][j]);
+  // E is linear in rho: one wave sum.  (At one wave per SIMD an evaluation costs its instruction count - ~1.9 ns per issue
+  // slot, LDS reads two - so this form, 64 complex multiply-adds and 56 LDS reads, replaced one with 112 and ~240.)
   const double trr = wave_sum(i == j ? r.x : 0.0);
-  double2 rho_loc[4][4];
+  double2 (*sB)[8][9] = w.sX;                // B_0, B_1 in sX[0..1], B_2, B_3 in sT[0..1] (contiguous in D8Work)
+  static_assert(offsetof(D8Work, sT) == offsetof(D8Work, sX) + sizeof(D8Work::sX), "B tiles span sX and sT");
+  double2 bt[4];
+  {
+    double2 acol[2][D];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    double xr = 0.0, xi = 0.0;
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-      const double2 a = w.sA[s][i][k], rr = w.sR[k][j];
-      xr = dfma(a.x, rr.x, xr);
-      xr = dfma(-a.y, rr.y, xr);
-      xi = dfma(a.x, rr.y, xi);
-      xi = dfma(a.y, rr.x, xi);
-    }
-    w.sX[s][i][j] = make_double2(xr, xi);
+      for (int k = 0; k < D; ++k) acol[s][k] = w.sA[s][k][j];
+#pragma unroll
+    for (int t1 = 0; t1 < 2; ++t1)
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        double br = 0.0, bi = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const double2 a = ai_[t1][k], c = acol[t2][k];
+          br = dfma(a.x, c.x, br);
+          br = dfma(-a.y, c.y, br);
+          bi = dfma(a.x, c.y, bi);
+          bi = dfma(a.y, c.x, bi);
+        }
+        bt[2 * t1 + t2] = make_double2(br, bi);
+      }
   }
   wsync();
 #pragma unroll
-  for (int t2 = 0; t2 < 2; ++t2)
+  for (int t = 0; t < 4; ++t) sB[t][i][j] = bt[t];
+  wsync();
+  double2 rho_loc[4][4];
+  {
+    double2 rc[D];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      double cr = 0.0, ci = 0.0;
+    for (int k = 0; k < D; ++k) rc[k] = w.sR[k][j];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      double yr = 0.0, yi = 0.0;
 #pragma unroll
       for (int k = 0; k < D; ++k) {
-        const double2 x = w.sX[t2][i][k], a = w.sA[s2][j][k];
-        cr = dfma(x.x, a.x, cr);
-        cr = dfma(x.y, a.y, cr);
-        ci = dfma(x.y, a.x, ci);
-        ci = dfma(-x.x, a.y, ci);
+        const double2 b = sB[t][i][k], rr = rc[k];
+        yr = dfma(b.x, rr.x, yr);
+        yr = dfma(-b.y, rr.y, yr);
+        yi = dfma(b.x, rr.y, yi);
+        yi = dfma(b.y, rr.x, yi);
       }
-      wsync();
-      w.sT[0][i][j] = make_double2(cr, ci);
-      wsync();
 #pragma unroll
-      for (int t1 = 0; t1 < 2; ++t1) {
-        double zr = 0.0, zi = 0.0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-          const double2 a = w.sA[t1][i][k], rr = w.sT[0][k][j];
-          zr = dfma(a.x, rr.x, zr);
-          zr = dfma(-a.y, rr.y, zr);
-          zi = dfma(a.x, rr.y, zi);
-          zi = dfma(a.y, rr.x, zi);
-        }
-#pragma unroll
-        for (int s1 = 0; s1 < 2; ++s1) {
-          const double2 a = w.sA[s1][i][j];
-          rho_loc[2 * t1 + t2][2 * s1 + s2] = make_double2(zr * a.x + zi * a.y, zi * a.x - zr * a.y);
-        }
-      }
+      for (int sg = 0; sg < 4; ++sg)
+        rho_loc[t][sg] = make_double2(yr * bt[sg].x + yi * bt[sg].y, yi * bt[sg].x - yr * bt[sg].y);
     }
+  }
   double e = 0.0;
   for (int q = 0; q < n_terms; ++q) {
     const double2* hq = h + q * 16;
@@ -290,8 +305,24 @@ __device__ __forceinline__ double eval_d8(D8Work& w, const double2* __restrict__
       }
   }
   e = wave_sum(e) / trr;
+  tick(7);
   status_out = status;
   return e;
+}
+
+// The parameter update of one rotosolve step (qmps/tools.py:Rotosolve / DoubleRotosolve closed forms, as roto_update_kernel).
+// Deliberately NOT inlined: inside the kernel's loop the compiler hoists the eighteen polynomial constants of atan2 out of
+// the loop, runs out of registers around the 64 x 64 elimination and reloads them from scratch one dependent load at a time
+// (measured: 4.3 us per update instead of 1.6).
+__device__ __noinline__ double roto_new_angle3(double par, double e0, double e1, double e2) {
+  const double theta = -1.5707963267948966 - atan2(2.0 * e0 - e1 - e2, e1 - e2);
+  return wrap_pi(par + wrap_pi(theta));
+}
+__device__ __noinline__ double roto_new_angle6(double par, double e0, double e1, double e2, double e3, double e4, double e5) {
+  const double A = e0 + e1, Bv = e0 - e1, C = e2 + e3, Dv = e2 - e3, Ev = e4 - e5;
+  const double a = 0.25 * (2.0 * Ev - 1.4142135623730951 * Dv), b = 0.25 * (A - C), c = 0.5 * Dv, d = 0.5 * Bv;
+  const double theta = double_sinusoid_argmin(a, b, c, d);
+  return par + (theta < -3.141592653589793 ? theta + 6.283185307179586 : (theta > 3.141592653589793 ? theta - 6.283185307179586 : theta));
 }
 
 }  // namespace
@@ -312,7 +343,10 @@ __global__ __launch_bounds__(64 * NSH) void rotosolve_fused_d8_kernel(RotoArgs p
   for (int l = threadIdx.x; l < p.P; l += blockDim.x) s_par[l] = p.base[(int64_t)r * p.P + l];
   __syncthreads();
 #ifdef QMPS_D8_PROFILE      // scratch instrumentation (tools/scratch/d8_profile.sh): phase clocks of restart 0 into the history buffer
-  long long tp[6] = {0, 0, 0, 0, 0, 0};
+  long long tp[6] = {0, 0, 0, 0, 0, 0}, fine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long t_begin = wall_clock64();
+  int prof_max_it = 0;
+  long long prof_sum_it = 0;
 #define QMPS_TICK(k) do { if (r == 0 && threadIdx.x == 0) tp[k] = wall_clock64(); } while (0)
 #else
 #define QMPS_TICK(k) do { } while (0)
@@ -322,53 +356,75 @@ __global__ __launch_bounds__(64 * NSH) void rotosolve_fused_d8_kernel(RotoArgs p
     build_tensor_d8<KIND>(w, [&](int l) { return s_par[l] + (l == i_sel ? shift : 0.0); }, p.P, lane);
     QMPS_TICK(1);
     int st;
+#ifdef QMPS_D8_PROFILE
+    int its = 0;
+    const double e = eval_d8(w, h, p.n_terms, p.max_iter, p.tol, lane, st, fine, &its);
+    prof_max_it = its > prof_max_it ? its : prof_max_it;
+    prof_sum_it += its;
+#else
     const double e = eval_d8(w, h, p.n_terms, p.max_iter, p.tol, lane, st);
+#endif
     QMPS_TICK(2);
     if (lane == 0) {
       s_e[wave] = e;
       s_st[wave] = st;
     }
   };
-  for (int sw = 0; sw < p.n_sweeps; ++sw) {
-    for (int i = 0; i < p.P; ++i) {
-      evaluate(i, roto_shift_value(NSH, wave));
-      __syncthreads();
-      QMPS_TICK(3);
-      if (threadIdx.x == 0) {
-        // the shift-0 evaluation of a sweep's first parameter IS the evaluation of the vector the previous sweep left: its record
-        if (i == 0 && sw > 0) p.hist[(int64_t)(sw - 1) * p.R + r] = s_e[0];
-        bool ok = true;
-        for (int k = 0; k < NSH; ++k) ok = ok && s_st[k] == QMPS_ST_OK;
-        if (ok) {          // (an evaluation without a valid environment leaves the parameter untouched)
-          if (NSH == 3) {
-            const double theta = -1.5707963267948966 - atan2(2.0 * s_e[0] - s_e[1] - s_e[2], s_e[1] - s_e[2]);
-            s_par[i] = wrap_pi(s_par[i] + wrap_pi(theta));
-          } else {
-            const double A = s_e[0] + s_e[1], Bv = s_e[0] - s_e[1], C = s_e[2] + s_e[3], Dv = s_e[2] - s_e[3], Ev = s_e[4] - s_e[5];
-            const double a = 0.25 * (2.0 * Ev - 1.4142135623730951 * Dv), b = 0.25 * (A - C), c = 0.5 * Dv, d = 0.5 * Bv;
-            const double theta = double_sinusoid_argmin(a, b, c, d);
-            s_par[i] += theta < -3.141592653589793 ? theta + 6.283185307179586 : (theta > 3.141592653589793 ? theta - 6.283185307179586 : theta);
-          }
-        }
+  // ONE call site for the evaluation (it is ~12 000 instructions: inlined once, LDS accesses stay ds_* instructions - through a
+  // real function call they would become flat loads): the record of the last sweep - the unshifted evaluation of the final
+  // vector, wave 0 - is one more trip round the same loop.
+  const int n_updates = p.n_sweeps * p.P;
+  for (int u = 0; u <= n_updates; ++u) {
+    const bool last = u == n_updates;
+    const int sw = u / p.P, i = u - sw * p.P;
+    evaluate(last ? -1 : i, roto_shift_value(NSH, wave));
+    __syncthreads();
+    QMPS_TICK(3);
+    if (threadIdx.x == 0) {
+      // the shift-0 evaluation of a sweep's first parameter IS the evaluation of the vector the previous sweep left: its record
+      if (i == 0 && sw > 0) p.hist[(int64_t)(sw - 1) * p.R + r] = s_e[0];
+      bool ok = !last;
+      for (int k = 0; k < NSH; ++k) ok = ok && s_st[k] == QMPS_ST_OK;
+      if (ok) {          // (an evaluation without a valid environment leaves the parameter untouched)
+        double e[6];
+#pragma unroll
+        for (int k = 0; k < NSH; ++k) e[k] = s_e[k];
+        s_par[i] = NSH == 3 ? roto_new_angle3(s_par[i], e[0], e[1], e[2]) : roto_new_angle6(s_par[i], e[0], e[1], e[2], e[3], e[4], e[5]);
       }
-      __syncthreads();
-#ifdef QMPS_D8_PROFILE
-      if (r == 0 && threadIdx.x == 0 && sw == 1 && i == 1) {
-        tp[4] = wall_clock64();
-        double* dbg = p.hist + (int64_t)p.n_sweeps * p.R;       // caller allocates 8 extra doubles
-        dbg[0] = (double)(tp[1] - tp[0]); dbg[1] = (double)(tp[2] - tp[1]); dbg[2] = (double)(tp[3] - tp[2]); dbg[3] = (double)(tp[4] - tp[3]);
-        dbg[4] = (double)(tp[4] - tp[0]);
-      }
-#endif
     }
-  }
-  // the last sweep's record: the unshifted evaluation of the final vector (wave 0)
-  if (wave == 0) {
-    evaluate(-1, 0.0);
-    if (lane == 0) p.hist[(int64_t)(p.n_sweeps - 1) * p.R + r] = s_e[0];
+    __syncthreads();
+#ifdef QMPS_D8_PROFILE
+    if (r == 0 && threadIdx.x == 0 && sw == p.n_sweeps / 2 && i == 1) {
+      tp[4] = wall_clock64();
+      double* dbg = p.hist + (int64_t)p.n_sweeps * p.R;       // caller allocates 16 extra doubles
+      dbg[0] = (double)(tp[1] - tp[0]); dbg[1] = (double)(tp[2] - tp[1]); dbg[2] = (double)(tp[3] - tp[2]); dbg[3] = (double)(tp[4] - tp[3]);
+      dbg[4] = (double)(tp[4] - tp[0]);
+      for (int q = 0; q < 7; ++q) dbg[8 + q] = (double)(fine[q + 1] - fine[q]);
+    }
+#endif
   }
   __syncthreads();
   for (int l = threadIdx.x; l < p.P; l += blockDim.x) p.base[(int64_t)r * p.P + l] = s_par[l];
+#ifdef QMPS_D8_PROFILE      // whole-kernel ticks of the first, a middle and the last restart, and the start offset of the last
+  if (threadIdx.x == 0 && (r == 0 || r == p.R / 2 || r == p.R - 1)) {
+    double* dbg = p.hist + (int64_t)p.n_sweeps * p.R;
+    dbg[r == 0 ? 5 : (r == p.R - 1 ? 7 : 6)] = (double)(wall_clock64() - t_begin);
+  }
+  if (threadIdx.x == 0 && r < 4096) {      // per restart: whole-run ticks, HW_ID, XCC_ID
+    double* dbg = p.hist + (int64_t)p.n_sweeps * p.R + 16;
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    dbg[3 * r] = (double)(wall_clock64() - t_begin);
+    dbg[3 * r + 1] = (double)hw;
+    dbg[3 * r + 2] = (double)xcc;
+  }
+  if (lane == 0) {      // largest / total number of power steps of any evaluation of the run (dbg[15] as two ints, zeroed by the caller)
+    int* cnt = (int*)(p.hist + (int64_t)p.n_sweeps * p.R + 15);
+    atomicMax(cnt, prof_max_it);
+    atomicAdd(cnt + 1, (int)prof_sum_it);
+  }
+#endif
 }
 
 hipError_t launch_rotosolve_fused_d8(int kind, const RotoArgs& a, hipStream_t st) {

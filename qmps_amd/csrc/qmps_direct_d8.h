@@ -200,18 +200,41 @@ __device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9]
       // columns t >= k / 4: the lane's columns g + 4 t > k and up to three already eliminated ones (the pivot row holds
       // rounding-level residues there; those columns are never read again).  The pivot row's own local row index last: its
       // registers are the DPP source of the other three.
+      // The reciprocal of the next pivot is a dependent chain (v_rcp_f64, two Newton multiply-adds: ~60 cycles of an in-order
+      // wave doing nothing else); its three instructions are spread between the first column classes of the remaining updates.
+      double praw = 0.0, px = 0.0, pe = 0.0;
       if constexpr (k1 < N) {
         d8_update<kc, kq, tk1>(Mn, nf);
         __builtin_amdgcn_sched_barrier(0);
-        pinv = fast_rcp(from_lane(Mn[kq1][tk1], 16 * gk1 + kc1));
+        praw = from_lane(Mn[kq1][tk1], 16 * gk1 + kc1);
 #pragma unroll
         for (int m = 0; m < 4; ++m) colk[m] = __shfl(Mn[m][tk1], 16 * gk1 + c, 64);
+        px = __builtin_amdgcn_rcp(praw);
         __builtin_amdgcn_sched_barrier(0);
       }
       static_for<16>([&](auto T) {
         constexpr int t = decltype(T)::value;
-        if constexpr (t >= tk && !(k1 < N && t == tk1)) d8_update<kc, kq, t>(Mn, nf);
+        constexpr int idx = t == tk ? 0 : t - tk - 1;          // position among the classes still to update
+        if constexpr (t >= tk && !(k1 < N && t == tk1)) {
+          if constexpr (k1 < N && idx == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            pe = dfma(-praw, px, 1.0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (k1 < N && idx == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            pinv = dfma(pe, px, px);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          d8_update<kc, kq, t>(Mn, nf);
+        }
       });
+      if constexpr (k1 < N) {
+        // (late steps: fewer than three classes were left, finish the chain here)
+        constexpr int n_left = 15 - tk;      // classes tk .. 15 without tk1
+        if constexpr (n_left < 2) pe = dfma(-praw, px, 1.0);
+        if constexpr (n_left < 3) pinv = dfma(pe, px, px);
+      }
       if (k == N - 1) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) yv[m] = nf[m];

@@ -177,61 +177,63 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
     }
   }
 
-  // ---- energy: rho[tau][sigma] = tr(A_t1 (A_t2 r A_s2^+) A_s1^+)
+  // ---- energy: rho[tau][sigma] = tr(B_tau r B_sigma^+), B_(2 t1 + t2) = A_t1 A_t2 - the merged two-site tensor (qmps/tools.py:432-433).
+  // Two stages: the four B_tau (tiles in sX, sT), then Y_tau = B_tau r and this thread's share Y_tau[i][j] conj(B_sigma[i][j]).
+  // (The first version went A_t2 r -> (.) A_s2^+ -> A_t1 (.) per (t2, s2): 112 complex multiply-adds, ~240 LDS reads and nine
+  // barriers per evaluation instead of 64, 56 and two; at one wave per SIMD an evaluation costs its instruction count.)
   const double trr = block_sum<D>(i == j ? r.x : 0.0, red, tid);
   double2 rho_loc[4][4];
-  // X_t2 = A_t2 r  (both t2) -> sX
+  {
+    double2 bt[4];
+    {
+      double2 acol[2][D];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    double xr = 0.0, xi = 0.0;
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-      const double2 a = sA[s][i][k], rr = sR[k][j];
-      xr = dfma(a.x, rr.x, xr);
-      xr = dfma(-a.y, rr.y, xr);
-      xi = dfma(a.x, rr.y, xi);
-      xi = dfma(a.y, rr.x, xi);
+        for (int k = 0; k < D; ++k) acol[s][k] = sA[s][k][j];
+#pragma unroll
+      for (int t1 = 0; t1 < 2; ++t1)
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          double br = 0.0, bi = 0.0;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            double2 a;
+            if constexpr (kRowsInRegs) a = ai_[t1][k]; else a = sA[t1][i][k];
+            const double2 c = acol[t2][k];
+            br = dfma(a.x, c.x, br);
+            br = dfma(-a.y, c.y, br);
+            bi = dfma(a.x, c.y, bi);
+            bi = dfma(a.y, c.x, bi);
+          }
+          bt[2 * t1 + t2] = make_double2(br, bi);
+        }
     }
-    sX[s][i][j] = make_double2(xr, xi);
-  }
-  __syncthreads();
+    __syncthreads();                       // the tiles are free: acceptance step and LDL^H are done with them
+    sX[0][i][j] = bt[0];
+    sX[1][i][j] = bt[1];
+    sT[0][i][j] = bt[2];
+    sT[1][i][j] = bt[3];
+    __syncthreads();
+    double2 rc[D];
 #pragma unroll
-  for (int t2 = 0; t2 < 2; ++t2)
+    for (int k = 0; k < D; ++k) rc[k] = sR[k][j];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      // R[i][j] = sum_k X_t2[i][k] conj(A_s2[j][k]) -> sT[0]
-      double cr = 0.0, ci = 0.0;
+    for (int t = 0; t < 4; ++t) {
+      double yr = 0.0, yi = 0.0;
 #pragma unroll
       for (int k = 0; k < D; ++k) {
-        const double2 x = sX[t2][i][k], a = sA[s2][j][k];
-        cr = dfma(x.x, a.x, cr);
-        cr = dfma(x.y, a.y, cr);
-        ci = dfma(x.y, a.x, ci);
-        ci = dfma(-x.x, a.y, ci);
+        const double2 b2 = t < 2 ? sX[t][i][k] : sT[t - 2][i][k], rr = rc[k];
+        yr = dfma(b2.x, rr.x, yr);
+        yr = dfma(-b2.y, rr.y, yr);
+        yi = dfma(b2.x, rr.y, yi);
+        yi = dfma(b2.y, rr.x, yi);
       }
-      __syncthreads();
-      sT[0][i][j] = make_double2(cr, ci);
-      __syncthreads();
 #pragma unroll
-      for (int t1 = 0; t1 < 2; ++t1) {
-        // Z[i][j] = sum_k A_t1[i][k] R[k][j]
-        double zr = 0.0, zi = 0.0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-          const double2 a = sA[t1][i][k], rr = sT[0][k][j];
-          zr = dfma(a.x, rr.x, zr);
-          zr = dfma(-a.y, rr.y, zr);
-          zi = dfma(a.x, rr.y, zi);
-          zi = dfma(a.y, rr.x, zi);
-        }
-#pragma unroll
-        for (int s1 = 0; s1 < 2; ++s1) {
-          // this thread's share of rho[tau][sigma] (summed over the workgroup below)
-          const double2 a = sA[s1][i][j];
-          rho_loc[2 * t1 + t2][2 * s1 + s2] = make_double2(zr * a.x + zi * a.y, zi * a.x - zr * a.y);
-        }
-      }
+      for (int sg = 0; sg < 4; ++sg)
+        rho_loc[t][sg] = make_double2(yr * bt[sg].x + yi * bt[sg].y, yi * bt[sg].x - yr * bt[sg].y);
     }
+  }
   const double inv_tr = 1.0 / trr;
   if (p.rho_out != nullptr) {
     // the density matrix itself is wanted: 16 complex sums over the workgroup

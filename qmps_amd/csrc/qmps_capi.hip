@@ -745,9 +745,11 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     }
     // D = 8 (ShallowCNOT families, direct solver): the whole run in ONE launch as well - a workgroup per restart, a wave per
     // shift (qmps_roto_d8.hip); afterwards one ordinary evaluation of the final parameters, as above
-    // (single frequency only: with six shifts the workgroup needs six waves on four SIMDs - two share a register file, the
-    // solve spills - and measured 60 us per update against 44.5 us step by step; three shifts: 34.5 against 42)
-    if (c->D == 8 && nsh == 3 && c->default_solver == QMPS_ENV_DIRECT && (kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_CNOT3) &&
+    // (six shifts: every wave evaluates two of them in turn).  A restart occupies a CU for the whole run, so this is the path of
+    // the SMALL runs (BASELINE.json configs[3]: 256 restarts): measured against the step-by-step path below, us per update,
+    // three shifts: R = 256: 19.9 / 34, 512: 40.8 / 45.4, 1 024: 77 / 63, 21 845: 1 552 / 785; six shifts: R = 128: 40.6 / 35.6, 256: 41.0 / 44.1.
+    const bool d8_fused_pays = nsh == 3 ? R <= 512 : (R <= 256 && 6 * R > 1024);
+    if (c->D == 8 && (nsh == 3 || nsh == 6) && d8_fused_pays && c->default_solver == QMPS_ENV_DIRECT && (kind == QMPS_ANSATZ_SHALLOW_CNOT || kind == QMPS_ANSATZ_SHALLOW_CNOT3) &&
         n_params <= 64 && documented_switch("QMPS_NO_FUSED_ROTO") == nullptr) {
       qmps::RotoArgs ra;
       memset(&ra, 0, sizeof(ra));

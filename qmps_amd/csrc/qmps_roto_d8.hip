@@ -327,12 +327,14 @@ __device__ __noinline__ double roto_new_angle6(double par, double e0, double e1,
 
 }  // namespace
 
+// Three waves per restart whatever NSH: with six shifts every wave evaluates two of them, one after the other (six waves would
+// put two on one SIMD and halve each one's register file: the solve then spills - 60 us per update measured).
 template <int KIND, int NSH>
-__global__ __launch_bounds__(64 * NSH) void rotosolve_fused_d8_kernel(RotoArgs p) {
+__global__ __launch_bounds__(192) void rotosolve_fused_d8_kernel(RotoArgs p) {
   extern __shared__ double2 lds_dyn[];
   char* lds_raw = (char*)lds_dyn;
   D8Work* work = (D8Work*)lds_raw;
-  double* s_par = (double*)(lds_raw + NSH * sizeof(D8Work));      // the restart's parameter vector [P]
+  double* s_par = (double*)(lds_raw + 3 * sizeof(D8Work));        // the restart's parameter vector [P]
   double* s_e = s_par + 64;                                        // [NSH] energies of the shifted evaluations
   int* s_st = (int*)(s_e + 8);                                     // [NSH]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -351,7 +353,8 @@ __global__ __launch_bounds__(64 * NSH) void rotosolve_fused_d8_kernel(RotoArgs p
 #else
 #define QMPS_TICK(k) do { } while (0)
 #endif
-  auto evaluate = [&](int i_sel, double shift) {
+  auto evaluate = [&](int i_sel, int shift_index) {
+    const double shift = roto_shift_value(NSH, shift_index);
     QMPS_TICK(0);
     build_tensor_d8<KIND>(w, [&](int l) { return s_par[l] + (l == i_sel ? shift : 0.0); }, p.P, lane);
     QMPS_TICK(1);
@@ -366,8 +369,8 @@ __global__ __launch_bounds__(64 * NSH) void rotosolve_fused_d8_kernel(RotoArgs p
 #endif
     QMPS_TICK(2);
     if (lane == 0) {
-      s_e[wave] = e;
-      s_st[wave] = st;
+      s_e[shift_index] = e;
+      s_st[shift_index] = st;
     }
   };
   // ONE call site for the evaluation (it is ~12 000 instructions: inlined once, LDS accesses stay ds_* instructions - through a
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(64 * NSH) void rotosolve_fused_d8_kernel(RotoArgs p
   for (int u = 0; u <= n_updates; ++u) {
     const bool last = u == n_updates;
     const int sw = u / p.P, i = u - sw * p.P;
-    evaluate(last ? -1 : i, roto_shift_value(NSH, wave));
+    for (int k = wave; k < NSH; k += 3) evaluate(last ? -1 : i, k);
     __syncthreads();
     QMPS_TICK(3);
     if (threadIdx.x == 0) {
@@ -432,34 +435,17 @@ hipError_t launch_rotosolve_fused_d8(int kind, const RotoArgs& a, hipStream_t st
   const dim3 grid((unsigned)a.R);
   // (at least 84 KB: more than half of a CU's 160 KB, so that no CU hosts two restarts - two workgroups on one CU would put two
   // waves on one SIMD and make those restarts, and with them the whole launch, half as fast again)
-  auto lds = [](int nsh) {
-    const size_t need = (size_t)nsh * sizeof(D8Work) + (64 + 8) * sizeof(double) + 8 * sizeof(int);
-    return need > (size_t)84 * 1024 ? need : (size_t)84 * 1024;
+  const size_t need = 3 * sizeof(D8Work) + (64 + 8) * sizeof(double) + 8 * sizeof(int);
+  const int lds = (int)(need > (size_t)84 * 1024 ? need : (size_t)84 * 1024);
+  hipError_t e = hipErrorInvalidValue;
+  auto go = [&](auto kernel) {
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) hipLaunchKernelGGL(kernel, grid, dim3(192), lds, st, a);
   };
-  hipError_t e = hipSuccess;
-  if (a.nsh == 3) {
-    if (kind == 0) {
-      e = hipFuncSetAttribute((const void*)rotosolve_fused_d8_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(3));
-      if (e == hipSuccess) hipLaunchKernelGGL((rotosolve_fused_d8_kernel<0, 3>), grid, dim3(192), lds(3), st, a);
-    } else if (kind == 3) {
-      e = hipFuncSetAttribute((const void*)rotosolve_fused_d8_kernel<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(3));
-      if (e == hipSuccess) hipLaunchKernelGGL((rotosolve_fused_d8_kernel<3, 3>), grid, dim3(192), lds(3), st, a);
-    } else {
-      return hipErrorInvalidValue;
-    }
-  } else if (a.nsh == 6) {
-    if (kind == 0) {
-      e = hipFuncSetAttribute((const void*)rotosolve_fused_d8_kernel<0, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(6));
-      if (e == hipSuccess) hipLaunchKernelGGL((rotosolve_fused_d8_kernel<0, 6>), grid, dim3(384), lds(6), st, a);
-    } else if (kind == 3) {
-      e = hipFuncSetAttribute((const void*)rotosolve_fused_d8_kernel<3, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(6));
-      if (e == hipSuccess) hipLaunchKernelGGL((rotosolve_fused_d8_kernel<3, 6>), grid, dim3(384), lds(6), st, a);
-    } else {
-      return hipErrorInvalidValue;
-    }
-  } else {
-    return hipErrorInvalidValue;
-  }
+  if (a.nsh == 3 && kind == 0) go(rotosolve_fused_d8_kernel<0, 3>);
+  else if (a.nsh == 3 && kind == 3) go(rotosolve_fused_d8_kernel<3, 3>);
+  else if (a.nsh == 6 && kind == 0) go(rotosolve_fused_d8_kernel<0, 6>);
+  else if (a.nsh == 6 && kind == 3) go(rotosolve_fused_d8_kernel<3, 6>);
   if (e != hipSuccess) return e;
   return hipGetLastError();
 }

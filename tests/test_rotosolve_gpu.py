@@ -276,10 +276,11 @@ def test_d8_whole_run_kernel_matches_the_step_by_step_path(double, c_oracle, eng
     run = eng.double_rotosolve if double else eng.rotosolve
     for kind, P, builder in ((_lib.ANSATZ_SHALLOW_CNOT, 6, O.shallow_cnot_unitary), (_lib.ANSATZ_SHALLOW_CNOT3, 9, O.shallow_cnot3_unitary),
                              (_lib.ANSATZ_SHALLOW_CNOT, 8, O.shallow_cnot_unitary)):      # (fewer than three layers: no full-rank environment at D = 8)
-        P0 = rng.standard_normal((40, P))
+        R = 180 if double else 40          # (six shifts: the whole-run kernel serves 1 024 < 6 R <= 1 536 evaluations per update)
+        P0 = rng.standard_normal((R, P))
         monkeypatch.delenv('QMPS_NO_FUSED_ROTO', raising=False)
         h1, p1 = run(kind, P0, 3)
-        E1 = eng.results(40)[0].sum(1)                    # the resident state the call leaves: energies of the final vectors
+        E1 = eng.results(R)[0].sum(1)                    # the resident state the call leaves: energies of the final vectors
         monkeypatch.setenv('QMPS_NO_FUSED_ROTO', '1')
         h2, p2 = run(kind, P0, 3)
         monkeypatch.delenv('QMPS_NO_FUSED_ROTO', raising=False)

@@ -45,7 +45,7 @@ int fail(int code, const char* fmt, ...) {
     if (r_ != ncclSuccess) return fail(QMPS_ERR_RCCL, "%s failed: %s", #expr, ncclGetErrorString(r_)); \
   } while (0)
 
-constexpr int kMaxTerms = 16;
+constexpr int kMaxTerms = 16;      // (energy_block_kernel stages kMaxTerms x 16 entries in LDS: qmps_energy_block.hip kHMax)
 constexpr int kSumBlocks = 256;
 
 }  // namespace

@@ -54,6 +54,16 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
     sA[0][i][j] = a[tid];
     sA[1][i][j] = a[N + tid];
   }
+  // The Hamiltonian terms are fetched NOW, into registers, and parked in LDS just before the energy stage: fetched where they
+  // are used they cost an HBM / L2 round trip (~1 us of a 16 us evaluation at D = 8) at the very end of the kernel.
+  constexpr int kHMax = 16 * 16, HR = (kHMax + N - 1) / N;      // kMaxTerms (qmps_capi.hip) x 16 entries
+  __shared__ double2 sH[kHMax];
+  double2 hreg[HR];
+#pragma unroll
+  for (int u = 0; u < HR; ++u) {
+    const int l = tid + u * N;
+    hreg[u] = l < 16 * p.n_terms ? ((const double2*)p.h)[l] : make_double2(0.0, 0.0);
+  }
   double2 r;
   if constexpr (FUSED8) {
     __shared__ double sM8[64][17];
@@ -210,6 +220,8 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
         }
     }
     __syncthreads();                       // the tiles are free: acceptance step and LDL^H are done with them
+#pragma unroll
+    for (int u = 0; u < HR; ++u) sH[tid + u * N] = hreg[u];
     sX[0][i][j] = bt[0];
     sX[1][i][j] = bt[1];
     sT[0][i][j] = bt[2];
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
   for (int q = 0; q < p.n_terms; ++q) {
     // E_q = Re sum h_q[s][t] rho[t][s] is linear in rho: combine the thread's shares first, ONE sum over the workgroup per
     // term instead of 32 (with the density matrix already summed every thread holds the total: no sum at all)
-    const double2* h = (const double2*)p.h + q * 16;
+    const double2* h = sH + q * 16;
     double e = 0.0;
 #pragma unroll
     for (int s = 0; s < 4; ++s)

@@ -142,9 +142,11 @@ __device__ __forceinline__ void build_tensor_d8(D8Work& w, Par par, int n_params
 }
 
 // Environment + energies of the tensor in w.sA, one wave (lane = 8 i + j owns r[i][j]): direct solve, power step(s) until
-// ||r' - r||_F < tol, LDL^H pivots > 0, E = sum over the Hamiltonian terms (the reference's M(x) = np.sum(eps), qmps/tools.py:432-433).
+// ||r' - r||_F < tol, LDL^H pivots > 0, E = sum over the Hamiltonian terms (the reference's M(x) = np.sum(eps), qmps/tools.py:432-433):
+// hsum is the SUM of the terms' 4 x 4 matrices, staged in LDS once per run (E is linear in h; fetching the terms from HBM
+// inside every evaluation cost ~1 us of latency).
 // The arithmetic of energy_block_kernel<8, true, FUSED> (qmps_kernels.hip) with wave-local synchronisation.
-__device__ __forceinline__ double eval_d8(D8Work& w, const double2* __restrict__ h, int n_terms, int max_iter, double tol, int lane,
+__device__ __forceinline__ double eval_d8(D8Work& w, const double2* hsum, int max_iter, double tol, int lane,
                                           int& status_out, long long* prof = nullptr, int* iters_out = nullptr) {
   constexpr int D = 8;
   auto tick = [&](int k) {
@@ -293,17 +295,14 @@ __device__ __forceinline__ double eval_d8(D8Work& w, const double2* __restrict__
     }
   }
   double e = 0.0;
-  for (int q = 0; q < n_terms; ++q) {
-    const double2* hq = h + q * 16;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+  for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const double2 hv = hq[s * 4 + t];
-        e = dfma(hv.x, rho_loc[t][s].x, e);
-        e = dfma(-hv.y, rho_loc[t][s].y, e);
-      }
-  }
+    for (int t = 0; t < 4; ++t) {
+      const double2 hv = hsum[s * 4 + t];
+      e = dfma(hv.x, rho_loc[t][s].x, e);
+      e = dfma(-hv.y, rho_loc[t][s].y, e);
+    }
   e = wave_sum(e) / trr;
   tick(7);
   status_out = status;
@@ -337,12 +336,21 @@ __global__ __launch_bounds__(192) void rotosolve_fused_d8_kernel(RotoArgs p) {
   double* s_par = (double*)(lds_raw + 3 * sizeof(D8Work));        // the restart's parameter vector [P]
   double* s_e = s_par + 64;                                        // [NSH] energies of the shifted evaluations
   int* s_st = (int*)(s_e + 8);                                     // [NSH]
+  double2* s_h = (double2*)(s_st + 8);                             // [16] sum of the Hamiltonian terms
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x;
   if (r >= p.R) return;
   D8Work& w = work[wave];
-  const double2* h = (const double2*)p.h;
   for (int l = threadIdx.x; l < p.P; l += blockDim.x) s_par[l] = p.base[(int64_t)r * p.P + l];
+  if (threadIdx.x < 16) {
+    const double2* h = (const double2*)p.h;
+    double2 acc = h[threadIdx.x];
+    for (int q = 1; q < p.n_terms; ++q) {
+      acc.x += h[q * 16 + threadIdx.x].x;
+      acc.y += h[q * 16 + threadIdx.x].y;
+    }
+    s_h[threadIdx.x] = acc;
+  }
   __syncthreads();
 #ifdef QMPS_D8_PROFILE      // scratch instrumentation (tools/scratch/d8_profile.sh): phase clocks of restart 0 into the history buffer
   long long tp[6] = {0, 0, 0, 0, 0, 0}, fine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -361,11 +369,11 @@ __global__ __launch_bounds__(192) void rotosolve_fused_d8_kernel(RotoArgs p) {
     int st;
 #ifdef QMPS_D8_PROFILE
     int its = 0;
-    const double e = eval_d8(w, h, p.n_terms, p.max_iter, p.tol, lane, st, fine, &its);
+    const double e = eval_d8(w, s_h, p.max_iter, p.tol, lane, st, fine, &its);
     prof_max_it = its > prof_max_it ? its : prof_max_it;
     prof_sum_it += its;
 #else
-    const double e = eval_d8(w, h, p.n_terms, p.max_iter, p.tol, lane, st);
+    const double e = eval_d8(w, s_h, p.max_iter, p.tol, lane, st);
 #endif
     QMPS_TICK(2);
     if (lane == 0) {
@@ -435,7 +443,7 @@ hipError_t launch_rotosolve_fused_d8(int kind, const RotoArgs& a, hipStream_t st
   const dim3 grid((unsigned)a.R);
   // (at least 84 KB: more than half of a CU's 160 KB, so that no CU hosts two restarts - two workgroups on one CU would put two
   // waves on one SIMD and make those restarts, and with them the whole launch, half as fast again)
-  const size_t need = 3 * sizeof(D8Work) + (64 + 8) * sizeof(double) + 8 * sizeof(int);
+  const size_t need = 3 * sizeof(D8Work) + (64 + 8) * sizeof(double) + 8 * sizeof(int) + 16 * sizeof(double2);
   const int lds = (int)(need > (size_t)84 * 1024 ? need : (size_t)84 * 1024);
   hipError_t e = hipErrorInvalidValue;
   auto go = [&](auto kernel) {

@@ -3,7 +3,7 @@ wall_clock64 ticks (100 MHz) of restart 0, sweep 1, parameter 1: ansatz build | 
 import os, sys, ctypes
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ['QMPS_HIP_LIB'] = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'qmps_amd', 'lib', 'libqmps_hip_prof.so')
+os.environ.setdefault('QMPS_HIP_LIB', os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'qmps_amd', 'lib', 'libqmps_hip_prof.so'))
 from qmps_amd import EnergyEngine, _lib as L
 from qmps_amd.engine import _f64
 eng = EnergyEngine(8, 4096)

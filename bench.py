@@ -504,14 +504,18 @@ def main_evolve(args):
     from qmps_amd.represent import ShallowCNOTStateTensor
     ev = LockstepEvolver(D, T, P, ShallowCNOTStateTensor, tol=args.tol, maxiter=args.bfgs_iters, device=local_rank,
                          gradient=args.gradient, first_rungs=2 if args.gradient != 'fd' else None, carry_hessian=args.carry_hessian,
-                         speculative=args.gradient != 'fd' and not args.no_speculative)
+                         speculative=args.gradient != 'fd' and not args.no_speculative, native=not args.python_driver)
+    native = ev.native            # the whole timed region is ONE C call (qmps_evolve_bfgs); else: the numpy loop, one ctypes call per batch
     info = _lib.device_info(local_rank)
     X = np.random.default_rng(args.seed + rank).standard_normal((T, P))
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
         ev.fg.eng.probe_fp64_tflops()
-    for _ in range(args.warmup):
-        X = ev.step(X, WW)['x']
+    if native and args.warmup > 0:
+        X = ev.steps(X, WW, args.warmup)['x']
+    else:
+        for _ in range(args.warmup):
+            X = ev.step(X, WW)['x']
     ev.fg.eng.overlap_stats(reset=True)
     ev.fl.eng.overlap_stats(reset=True)
     ev.fg.kernel_ms, ev.fl.kernel_ms = [], []
@@ -519,12 +523,16 @@ def main_evolve(args):
         dist.barrier()
     t0 = time.perf_counter()
     nit, nfev, f_last = [], 0, None
-    for _ in range(args.steps):
-        res = ev.step(X, WW)
-        X = res['x']
-        nit.append(res['nit'])
-        nfev += res['nfev']
-        f_last = res['fun']
+    if native:
+        res = ev.steps(X, WW, args.steps)
+        X, nit, nfev, f_last = res['x'], [int(n) for n in res['nit']], res['nfev'], res['fun'][-1]
+    else:
+        for _ in range(args.steps):
+            res = ev.step(X, WW)
+            X = res['x']
+            nit.append(res['nit'])
+            nfev += res['nfev']
+            f_last = res['fun']
     ev.fg.eng.sync()
     ev.fl.eng.sync()
     if dist is not None:
@@ -535,8 +543,10 @@ def main_evolve(args):
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    sg, sl = ev.fg.eng.overlap_stats(), ev.fl.eng.overlap_stats()
-    kms_timed = (list(ev.fg.kernel_ms), list(ev.fl.kernel_ms))
+    sg = ev.fg.eng.overlap_stats()
+    # (native driver: one context, its statistics pool the - rare - ladder batches with the gradient batches)
+    sl = ev.fl.eng.overlap_stats() if ev.fl is not ev.fg else {k: 0 for k in sg}
+    kms_timed = (list(ev.fg.kernel_ms), list(ev.fl.kernel_ms) if ev.fl is not ev.fg else [])
     identity_leg = None
     if args.carry_hessian and not args.no_extras:
         # the same time steps the way scipy (the reference) starts them: inverse Hessian = identity at the top of every step
@@ -556,7 +566,8 @@ def main_evolve(args):
         identity_leg = {'value': T * n_leg / el, 'unit': 'trajectory time steps/s (this rank)', 'steps': n_leg, 'ms_per_step': el / n_leg * 1e3,
                         'bfgs_iterations_per_step': float(np.mean(nit_l)), 'mean_final_objective': float(np.nanmean(f_l)),
                         'what': 'BFGS restarted from the identity at every time step (scipy / the reference); same tolerance, same ladder'}
-    ev.fg.kernel_ms, ev.fl.kernel_ms = kms_timed
+    ev.fg.kernel_ms = kms_timed[0]
+    ladder_ms = kms_timed[1]
     if rank == 0:
         squaring = D in (2, 4)
         per_round = 8 * (D * D) ** 3 if squaring else 64 * D ** 3           # a squaring of the complex D^2 x D^2 matrix / a power step (8 complex D^3 products)
@@ -569,7 +580,7 @@ def main_evolve(args):
         flops_g = sg['rounds_sum'] * per_round + sg['evaluations'] * setup + n_iter_evals * (2 * P * (32 * D ** 3 + 32 * D * D) + 16 * 8 * D ** 3)
         tflops = flops_g / max(kms.sum() * 1e-3, 1e-12) * 1e-12
         byts = sg['evaluations'] * (32 * D * D + 16 + (32 * D * D if not squaring else 0))
-        kernel_total_ms = float(kms.sum() + np.sum(ev.fl.kernel_ms))
+        kernel_total_ms = float(kms.sum() + np.sum(ladder_ms))
         out = {'metric': f'time-evolution trajectory steps/sec at D={D}, depth={depth}, {T} trajectories per GPU',
                'value': world * T * args.steps / elapsed, 'unit': 'trajectory time steps/s', 'n_gpus': world, 'steps': args.steps,
                'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
@@ -584,7 +595,8 @@ def main_evolve(args):
                                        else 'with every neighbour eigen-solved, 8-point backtracking ladder') + '), objective '
                                       f'-sqrt|eta| with eta to {args.tol:g} (residual of the power method / rank-one test of the squaring)',
                           'baseline_config': 'BASELINE.json configs[4]', 'D': D, 'trajectories_per_gpu': T, 'n_params': P, 'seed': args.seed,
-                          'bfgs_iterations_per_step': float(np.mean(nit)), 'carry_hessian': bool(args.carry_hessian), 'objective_evals_per_step': nfev / args.steps,
+                          'bfgs_iterations_per_step': float(np.mean(nit)), 'carry_hessian': bool(args.carry_hessian),
+                          'driver': 'qmps_evolve_bfgs: the whole timed region is one C call' if native else 'numpy loop (tools.batched_bfgs), one ctypes call per batch', 'objective_evals_per_step': nfev / args.steps,
                           'objective_evals_per_s': world * nfev / elapsed,
                           'mean_final_objective': float(np.nanmean(f_last)), 'worst_final_objective': float(np.nanmax(f_last)),
                           'solver_rounds_mean_gradient_batches': sg['rounds_sum'] / max(1, sg['evaluations']), 'solver_rounds_max_gradient_batches': sg['rounds_max'],
@@ -780,6 +792,8 @@ def main():
     ap.add_argument('--gradient', choices=['auto', 'two-sided', 'fd'], default='auto',
                     help="evolve workload: 'two-sided' (auto at D >= 4) = one right + one left eigen-solve per iterate, the central-difference "
                          "neighbours by eta' = <y, T'(r)>/<y, r>; 'fd' = every neighbour eigen-solved (what scipy's BFGS does with the reference objective)")
+    ap.add_argument('--python-driver', action='store_true',
+                    help='evolve workload: the lock-step BFGS loop in numpy (tools.batched_bfgs), one ctypes call per batch, instead of the one-call native driver (qmps_evolve_bfgs)')
     ap.add_argument('--no-speculative', action='store_true',
                     help='evolve workload: always evaluate the backtracking ladder before the gradient (default: objective and gradient at the full '
                          'quasi-Newton step first, the ladder only when some trajectory rejects that step)')

@@ -358,6 +358,36 @@ int qmps_overlap_eval_ansatz(qmps_ctx* ctx, int64_t B, int kind, int n_params, c
 int qmps_overlap_gradient(qmps_ctx* ctx, int64_t T, int kind, int n_params, const double* params, double h, int max_rounds, double tol,
                           int flags, double* f_out, double* g_out, int32_t* status_out);
 
+/* TIME EVOLUTION by lock-step BFGS, the whole run in ONE C call (BASELINE.json configs[4]; the reference's loop:
+ * qmps/new_time_evolve.py:276-292 / scripts/loschmidt.py:367-375 `for _ in T: A_ = tensor(params); params =
+ * minimize(obj, params, (A_, WW)).x` - scipy's BFGS with finite-difference gradients, one trajectory and one scalar objective
+ * call at a time).  T independent trajectories, params[T][n_params] in / out.  Per time step the reference tensors
+ * A_t = tensor(params_t) are built on the device and every trajectory runs BFGS from its current parameters, all of them in
+ * LOCK-STEP - the iteration of qmps_amd/tools.py:batched_bfgs(speculative=True), decision for decision, with its host
+ * arithmetic (directions, Armijo tests, rank-two inverse-Hessian updates: O(T n_params^2) per iteration) in C++ inside the
+ * library instead of numpy behind five ctypes calls:
+ *   objective + central-difference gradient of all iterates: qmps_overlap_gradient (one right + one left eigen-solve each,
+ *     warm-started from the previous batch's fixed points; converged trajectories masked out);
+ *   the full quasi-Newton step x + alphas[0] d is evaluated WITH its gradient first; only if some active trajectory fails the
+ *     Armijo test f(x + a d) <= f + c1 a g.d there, the remaining rungs alphas[1 ..] are evaluated as one batch of
+ *     T (n_alphas - 1) candidates (cold start) and the gradient at the accepted points follows;
+ *   inverse-Hessian update skipped when s.y <= 1e-12 |s||y|; a trajectory stops when max|g| < gtol, when no rung decreases f,
+ *     or after maxiter iterations.
+ * flags: QMPS_BFGS_CARRY_HESSIAN - a time step starts from the inverse Hessians the previous one ended with (scipy, and the
+ *   reference, start from the identity every time); QMPS_BFGS_WARM - the first gradient batch of this call starts from the
+ *   fixed points a previous qmps_evolve_bfgs / qmps_overlap_gradient call left resident (same T).
+ * hinv (nullable) [T][n_params][n_params]: in - the initial inverse Hessians of the first time step when QMPS_BFGS_CARRY_HESSIAN
+ *   and QMPS_BFGS_WARM are both set (a continued evolution), else ignored; out - the final ones.
+ * Outputs per time step: params_hist (nullable) [n_steps][T][n_params], f_hist [n_steps][T] final objectives -sqrt|eta|,
+ * nit_out (nullable) [n_steps] lock-step iterations, counters_out (nullable) [4] = gradient batches, ladder batches, objective
+ * evaluations in scipy's count (2 n_params + 1 per gradient), summed HIP-event milliseconds of the gradient batches.
+ * D = 4, 8, 16; needs T max(2 n_params + 1, n_alphas - 1) <= max_batch. */
+#define QMPS_BFGS_CARRY_HESSIAN 1
+#define QMPS_BFGS_WARM 2
+int qmps_evolve_bfgs(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
+                     double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
+                     double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out);
+
 /* Device-resident TIME EVOLUTION by rotosolve on the overlap objective (BASELINE.json configs[4]; the reference's loop:
  * qmps/new_time_evolve.py:276-292 / scripts/loschmidt.py:367-375 `for _ in T: A_ = tensor(params); params =
  * minimize(obj, params, (A_, WW)).x`, with the rotosolve update of qmps/rotosolve.py:154-181 (nsh = 3) or

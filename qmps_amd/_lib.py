@@ -25,6 +25,7 @@ FLAG_NO_ENV_OUT = 0x100
 FLAG_ACCUMULATE_COST = 0x200
 FLAG_WARM_RESIDENT = 0x400
 OVERLAP_WANT_R, OVERLAP_WARM = 1, 2
+BFGS_CARRY_HESSIAN, BFGS_WARM = 1, 2
 UNIQUE_ID_BYTES = 128
 
 _dp = POINTER(c_double)
@@ -80,6 +81,8 @@ SIGNATURES = {
     'qmps_overlap_eval_ansatz': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, c_int, c_double, c_int, _dp, _ip]),
     'qmps_overlap_gradient': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, c_double, c_int, c_double, c_int, _dp, _dp, _ip]),
     'qmps_evolve_rotosolve': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, _dp, c_int, c_int, c_int, c_int, c_double, _dp, _dp]),
+    'qmps_evolve_bfgs': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, _dp, c_int, c_int, c_double, c_double, c_double, c_int, _dp, c_int, c_int, c_double,
+                                 _dp, _dp, _dp, _ip, _dp]),
     'qmps_opt_env_objective': (c_int, [c_void_p, c_int64, _dp, _dp, c_double, _dp, _dp]),
     'qmps_bw_expval': (c_int, [c_void_p, c_int64, c_int, _dp, _dp, _dp, c_int, _dp]),
     'qmps_bw_env': (c_int, [c_void_p, c_int64, c_int, _dp, _dp, _dp, _dp, c_int, c_double, _dp, _dp, _dp, _ip]),

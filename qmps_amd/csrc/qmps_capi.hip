@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <cmath>
 #include <time.h>
 
 #include <new>
@@ -1654,6 +1655,200 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   c->window = 0;
   c->have_env = false; c->have_guess = false; c->have_overlap_x = false; c->acc_pending = false; c->partials_B = -1;
   c->grad_warm_T = T;
+  return QMPS_OK;
+}
+
+int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
+                     double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
+                     double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out) {
+  if (int rc = bind(c)) return rc;
+  if (!params || !WW || !f_hist || !alphas) return fail(QMPS_ERR_ARG, "null argument");
+  if (c->D < 4) return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs: D = 4, 8, 16 (the two-sided gradient)");
+  if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
+  const int P = n_params, NA = n_alphas;
+  if (NA < 1 || NA > 64) return fail(QMPS_ERR_ARG, "n_alphas outside [1, 64]");
+  const int64_t G = NA - 1;
+  if (T < 1 || T * (1 + 2 * (int64_t)P) > c->max_batch || T * G > c->max_batch)
+    return fail(QMPS_ERR_ARG, "T max(2 n_params + 1, n_alphas - 1) = %lld evaluations exceed max_batch = %lld",
+                (long long)(T * ((1 + 2 * (int64_t)P) > G ? (1 + 2 * (int64_t)P) : G)), (long long)c->max_batch);
+  if (n_steps < 1 || maxiter < 0 || !(gtol > 0.0) || !(h > 0.0)) return fail(QMPS_ERR_ARG, "bad n_steps / maxiter / gtol / h");
+  if (int rc = check_ansatz(c, kind, P)) return rc;
+  const bool carry = (flags & QMPS_BFGS_CARRY_HESSIAN) != 0;
+  bool warm = (flags & QMPS_BFGS_WARM) != 0;
+  if (warm && c->grad_warm_T != T) return fail(QMPS_ERR_STATE, "QMPS_BFGS_WARM: the resident fixed points belong to %lld trajectories, not %lld", (long long)c->grad_warm_T, (long long)T);
+  const bool squaring = overlap_squares(c);
+  const int ladder_rounds = squaring ? (max_rounds > 60 ? 60 : max_rounds) : max_rounds;
+  const int grad_rounds = max_rounds > 100000 ? max_rounds : 100000;       // (as _GroupedObjective.value_and_grad)
+  const size_t TP = (size_t)T * P;
+  const double nan = __builtin_nan("");
+  std::vector<double> X(params, params + TP), Hinv(TP * P), f(T), g(TP), d(TP), slope(T), fs(T), gs(TP), fn(T), gn(TP), Xc(TP), Xn(TP), s(TP), Fc((size_t)T * NA),
+      cand, Fl, Hy(P);
+  std::vector<int32_t> st(T), stl;
+  std::vector<unsigned char> active(T), moved(T);
+  const int saved_period = c->timing_period;
+  if (counters_out) c->timing_period = 1;
+  double n_grad = 0.0, n_ladder = 0.0, nfev = 0.0, grad_ms = 0.0;
+  auto set_identity = [&](int64_t t) {
+    double* Ht = &Hinv[(size_t)t * P * P];
+    for (int a = 0; a < P; ++a)
+      for (int b = 0; b < P; ++b) Ht[a * P + b] = a == b ? 1.0 : 0.0;
+  };
+  if (carry && warm && hinv) memcpy(Hinv.data(), hinv, TP * P * sizeof(double));
+  else for (int64_t t = 0; t < T; ++t) set_identity(t);
+  // objective + gradient of a batch of iterates; trajectories with a failed solve come back as NaN (tools.py / new_time_evolve.py)
+  auto value_and_grad = [&](const double* Z, double* fo, double* go, const unsigned char* mask) -> int {
+    if (mask) { if (int e = qmps_overlap_set_active(c, T, mask)) return e; }
+    if (int e = qmps_overlap_gradient(c, T, kind, P, Z, h, grad_rounds, tol, warm ? QMPS_OVERLAP_WARM : 0, fo, go, st.data())) return e;
+    warm = true;
+    for (int64_t t = 0; t < T; ++t)
+      if (st[t] != qmps::QMPS_ST_OK) {
+        fo[t] = nan;
+        for (int k = 0; k < P; ++k) go[(size_t)t * P + k] = nan;
+      }
+    n_grad += 1.0;
+    nfev += (double)T * (2 * P + 1);
+    if (counters_out) {
+      float ms = 0.f;
+      if (qmps_kernel_time(c, 1, &ms, nullptr, 0) == QMPS_OK) grad_ms += ms;
+    }
+    return QMPS_OK;
+  };
+  auto gmax_at_least = [&](const double* gt, double bound) {       // np.abs(g).max() >= bound, NaN-propagating: false with any NaN
+    double m = 0.0;
+    for (int k = 0; k < P; ++k) {
+      if (gt[k] != gt[k]) return false;
+      const double a = fabs(gt[k]);
+      m = a > m ? a : m;
+    }
+    return m >= bound;
+  };
+  int rc = QMPS_OK;
+  for (int step = 0; step < n_steps && rc == QMPS_OK; ++step) {
+    // the step's references: A_t = tensor(current parameters)
+    if ((rc = qmps_overlap_set_refs_ansatz(c, T, kind, P, X.data(), WW))) break;
+    if (!(carry && (step > 0 || (warm && hinv))))
+      for (int64_t t = 0; t < T; ++t) set_identity(t);
+    if ((rc = value_and_grad(X.data(), f.data(), g.data(), nullptr))) break;
+    bool any_active = false;
+    for (int64_t t = 0; t < T; ++t) { active[t] = gmax_at_least(&g[(size_t)t * P], gtol) ? 1 : 0; any_active |= active[t] != 0; }
+    int nit = 0;
+    while (nit < maxiter && any_active) {
+      for (int64_t t = 0; t < T; ++t) {
+        const double* Ht = &Hinv[(size_t)t * P * P];
+        const double* gt = &g[(size_t)t * P];
+        double* dt = &d[(size_t)t * P];
+        double sl = 0.0;
+        for (int a = 0; a < P; ++a) {
+          double acc = 0.0;
+          for (int b = 0; b < P; ++b) acc += Ht[a * P + b] * gt[b];
+          dt[a] = -acc;
+        }
+        for (int a = 0; a < P; ++a) sl += gt[a] * dt[a];
+        if (!(sl < 0.0)) {                                  // not a descent direction: restart from steepest descent
+          set_identity(t);
+          sl = 0.0;
+          for (int a = 0; a < P; ++a) { dt[a] = -gt[a]; sl -= gt[a] * gt[a]; }
+        }
+        slope[t] = sl;
+        if (!active[t]) for (int a = 0; a < P; ++a) dt[a] = 0.0;
+      }
+      // the full step with its gradient, straight away
+      for (size_t q = 0; q < TP; ++q) Xc[q] = X[q] + alphas[0] * d[q];
+      if ((rc = value_and_grad(Xc.data(), fs.data(), gs.data(), active.data()))) break;
+      bool all_accept = true;
+      for (int64_t t = 0; t < T; ++t) {
+        if (!active[t]) {                                   // (rows of skipped trajectories: their last values)
+          fs[t] = f[t];
+          memcpy(&gs[(size_t)t * P], &g[(size_t)t * P], P * sizeof(double));
+        }
+        double* Ft = &Fc[(size_t)t * NA];
+        for (int r = 0; r < NA; ++r) Ft[r] = INFINITY;
+        Ft[0] = std::isfinite(fs[t]) ? fs[t] : INFINITY;
+        if (active[t] && !(Ft[0] <= f[t] + c1 * alphas[0] * slope[t])) all_accept = false;
+      }
+      bool have_new = all_accept;
+      if (all_accept) {
+        fn = fs;
+        gn = gs;
+      } else if (G > 0) {
+        cand.resize((size_t)T * G * P);
+        Fl.resize((size_t)T * G);
+        stl.resize((size_t)T * G);
+        for (int64_t t = 0; t < T; ++t)
+          for (int64_t r = 0; r < G; ++r)
+            for (int k = 0; k < P; ++k) cand[((size_t)t * G + r) * P + k] = X[(size_t)t * P + k] + alphas[r + 1] * d[(size_t)t * P + k];
+        if ((rc = qmps_overlap_set_group(c, G))) break;
+        if ((rc = qmps_overlap_set_active(c, T, active.data()))) break;
+        rc = qmps_overlap_eval_ansatz(c, T * G, kind, P, cand.data(), ladder_rounds, tol, 0, Fl.data(), stl.data());
+        (void)qmps_overlap_set_group(c, 0);
+        if (rc) break;
+        n_ladder += 1.0;
+        nfev += (double)T * G;
+        for (int64_t t = 0; t < T; ++t)
+          for (int64_t r = 0; r < G; ++r) {
+            const double v = stl[(size_t)t * G + r] == qmps::QMPS_ST_OK ? Fl[(size_t)t * G + r] : nan;
+            Fc[(size_t)t * NA + r + 1] = std::isfinite(v) ? v : INFINITY;
+          }
+      }
+      for (int64_t t = 0; t < T; ++t) {
+        const double* Ft = &Fc[(size_t)t * NA];
+        int first = -1, best = 0;
+        for (int r = 0; r < NA; ++r) {
+          if (first < 0 && Ft[r] <= f[t] + c1 * alphas[r] * slope[t]) first = r;
+          if (Ft[r] < Ft[best]) best = r;
+        }
+        if (first < 0) first = best;
+        moved[t] = (active[t] && Ft[first] < f[t]) ? 1 : 0;
+        const double a = moved[t] ? alphas[first] : 0.0;
+        for (int k = 0; k < P; ++k) {
+          s[(size_t)t * P + k] = a * d[(size_t)t * P + k];
+          Xn[(size_t)t * P + k] = X[(size_t)t * P + k] + s[(size_t)t * P + k];
+        }
+      }
+      if (!have_new)
+        if ((rc = value_and_grad(Xn.data(), fn.data(), gn.data(), active.data()))) break;
+      any_active = false;
+      for (int64_t t = 0; t < T; ++t) {
+        double* gt = &g[(size_t)t * P];
+        const double* gnt = &gn[(size_t)t * P];
+        const double* sv = &s[(size_t)t * P];
+        if (moved[t]) {
+          double sy = 0.0, ss = 0.0, yy = 0.0;
+          for (int k = 0; k < P; ++k) { const double y = gnt[k] - gt[k]; sy += sv[k] * y; ss += sv[k] * sv[k]; yy += y * y; }
+          if (sy > 1e-12 * sqrt(ss * yy) && sy > 0.0) {
+            // H' = H - rho (s (Hy)^T + (Hy) s^T) + rho (1 + rho y^T H y) s s^T
+            double* Ht = &Hinv[(size_t)t * P * P];
+            const double rho = 1.0 / sy;
+            double yHy = 0.0;
+            for (int a = 0; a < P; ++a) {
+              double acc = 0.0;
+              for (int b = 0; b < P; ++b) acc += Ht[a * P + b] * (gnt[b] - gt[b]);
+              Hy[a] = acc;
+            }
+            for (int a = 0; a < P; ++a) yHy += (gnt[a] - gt[a]) * Hy[a];
+            const double coef = rho * (1.0 + rho * yHy);
+            for (int a = 0; a < P; ++a)
+              for (int b = 0; b < P; ++b) Ht[a * P + b] = Ht[a * P + b] - (rho * sv[a] * Hy[b] + rho * sv[b] * Hy[a]) + coef * sv[a] * sv[b];
+          }
+          f[t] = fn[t];
+          memcpy(gt, gnt, P * sizeof(double));
+        }
+        active[t] = (active[t] && moved[t] && gmax_at_least(gt, gtol)) ? 1 : 0;
+        any_active |= active[t] != 0;
+      }
+      X = Xn;
+      ++nit;
+    }
+    if (rc) break;
+    memcpy(f_hist + (size_t)step * T, f.data(), (size_t)T * sizeof(double));
+    if (params_hist) memcpy(params_hist + (size_t)step * TP, X.data(), TP * sizeof(double));
+    if (nit_out) nit_out[step] = nit;
+  }
+  c->timing_period = saved_period;
+  if (rc) return rc;
+  memcpy(params, X.data(), TP * sizeof(double));
+  if (hinv) memcpy(hinv, Hinv.data(), TP * P * sizeof(double));
+  if (counters_out) { counters_out[0] = n_grad; counters_out[1] = n_ladder; counters_out[2] = nfev; counters_out[3] = grad_ms; }
   return QMPS_OK;
 }
 

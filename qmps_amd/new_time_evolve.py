@@ -150,7 +150,7 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
         mr = max_rounds if max_rounds is not None else (60 if D in (2, 4) else 100000)
         ev = LockstepEvolver(D, T, P, cls, mr, tol, opts.get('maxiter', 200), opts.get('gtol', 1e-5), opts.get('eps', 1e-6), ladder,
                              gradient=opts.get('gradient', 'auto'), first_rungs=opts.get('first_rungs'),
-                             carry_hessian=opts.get('carry_hessian', False), speculative=opts.get('speculative', False))
+                             carry_hessian=opts.get('carry_hessian', False), speculative=opts.get('speculative', False), native=opts.get('native', True))
         fg, fl = ev.fg, ev.fl
         try:
             for step in range(n_steps):
@@ -188,8 +188,11 @@ class LockstepEvolver:
 
     def __init__(self, D, T, P, cls=None, max_rounds=None, tol=1e-12, maxiter=200, gtol=1e-5, eps=1e-6,
                  alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), device=0, gradient='auto', first_rungs=None,
-                 carry_hessian=False, speculative=False):
-        """gradient: 'fd' = the 2P + 1 central-difference candidates are eigen-solved one by one (any D); 'two-sided' = one right
+                 carry_hessian=False, speculative=False, native=True):
+        """native (with speculative and the two-sided gradient): the whole time step - every BFGS iteration of every trajectory - is
+        ONE C call (qmps_evolve_bfgs: the loop of tools.batched_bfgs with its host arithmetic in C++ inside the library); False: the
+        same loop in numpy, one ctypes call per batch.
+        gradient: 'fd' = the 2P + 1 central-difference candidates are eigen-solved one by one (any D); 'two-sided' = one right
         and one left eigen-solve per iterate, the neighbours by the second-order formula eta' = <y, T'(r)>/<y, r> (D >= 4);
         'auto' = 'two-sided' where the library has it.  first_rungs: two-stage ladder (tools.batched_bfgs).
         speculative: gradient batches at the full quasi-Newton step first (tools.batched_bfgs): one device batch per iteration
@@ -204,13 +207,38 @@ class LockstepEvolver:
         self.first_rungs = first_rungs
         self.speculative = speculative and self.two_sided
         self.carry_hessian, self._hinv = carry_hessian, None
+        self.native = bool(native) and self.speculative
+        self.mr, self.tol = mr, tol
+        if self.native:
+            # one context serves the gradient batches and the (rare, cold-started) ladder batches
+            self.fg = _GroupedObjective(D, self.kind, T, max(2 * P + 1, len(self.alphas) - 1), mr, tol, device=device)
+            self.fl = self.fg
+            self._continued = False
+            return
         self.fg = _GroupedObjective(D, self.kind, T, 2 * P + 1, mr, tol, device=device)
         rungs = len(self.alphas) if not first_rungs else (first_rungs, len(self.alphas) - first_rungs)
         if self.speculative:
             rungs = len(self.alphas) - 1
         self.fl = _GroupedObjective(D, self.kind, T, rungs, mr, tol, device=device)
 
+    def steps(self, X, WW, n_steps):
+        """n_steps time steps in one C call (native driver): dict(x, params_hist, fun (n_steps, T), nit (n_steps,), ...)."""
+        if not self.native:
+            raise RuntimeError('LockstepEvolver.steps needs the native driver (speculative=True, two-sided gradient)')
+        res = self.fg.eng.evolve_bfgs(self.kind, X, WW, n_steps=n_steps, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas,
+                                      carry_hessian=self.carry_hessian, hess_inv=self._hinv if (self.carry_hessian and self._continued) else None,
+                                      warm=self._continued, max_rounds=self.mr, tol=self.tol)
+        self._continued = True
+        self._hinv = res['hess_inv']
+        if self.fg.kernel_ms is not None and res['gradient_batches']:
+            self.fg.kernel_ms += [res['gradient_ms'] / res['gradient_batches']] * res['gradient_batches']
+        return res
+
     def step(self, X, WW):
+        if self.native:
+            res = self.steps(X, WW, 1)
+            return {'x': res['x'], 'fun': res['fun'][0], 'nit': int(res['nit'][0]), 'nfev': res['nfev'], 'history': res['fun'][:1],
+                    'hess_inv': res['hess_inv'], 'converged': None}
         from .tools import batched_bfgs
         self.fg.set_reference(X, WW)
         self.fl.set_reference(X, WW)
@@ -225,7 +253,8 @@ class LockstepEvolver:
 
     def close(self):
         self.fg.close()
-        self.fl.close()
+        if self.fl is not self.fg:
+            self.fl.close()
 
 
 def state_tensor_of(cls, D, p):

@@ -195,6 +195,7 @@ def test_lockstep_bfgs_time_evolution(D, P, T, iters):
     opts = {'maxiter': iters}
     if D == 16:
         opts['speculative'] = True                    # objective + gradient at the full step first, ladder on rejection
+        opts['native'] = False                        # the numpy loop: its per-iteration history is compared below (native driver: next test)
     H, info = NT.evolve(X0, WW, n_steps, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-13,
                         options=opts, return_info=True)
     if D == 4:
@@ -248,6 +249,44 @@ def test_lockstep_bfgs_time_evolution(D, P, T, iters):
         s = info['solver']['gradient_batches']
         assert s['not_converged'] == 0
         assert s['evaluations'] >= 2 * T * sum(n + 1 for n in info['nit'])      # two solves per iterate and iteration (+ re-evaluations after a rejected full step)
+
+
+@pytest.mark.parametrize('D,P,carry', [(4, 4, False), (8, 6, True), (16, 8, True), (16, 8, False)])
+def test_native_bfgs_driver_takes_the_decisions_of_the_numpy_loop(D, P, carry):
+    """qmps_evolve_bfgs - the lock-step BFGS time step with its host arithmetic in C++ inside the library, one C call for the
+    whole evolution - against tools.batched_bfgs(speculative=True) driving the same device batches from numpy: same iteration
+    counts, same objectives, same parameters (the two sum their dot products in different orders: rounding-level differences)."""
+    rng = np.random.default_rng(300 + D)
+    T, n_steps = 6, 3
+    X0 = rng.standard_normal((T, P))
+    WW = WW_of(0.05)
+    out = {}
+    for native in (False, True):
+        H, info = NT.evolve(X0, WW, n_steps, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-13,
+                            options={'maxiter': 25, 'speculative': True, 'carry_hessian': carry, 'native': native}, return_info=True)
+        out[native] = (H, info)
+    (Hn, In), (Hp, Ip) = out[True], out[False]
+    assert Hn.shape == Hp.shape == (n_steps + 1, T, P)
+    assert list(In['nit']) == list(Ip['nit'])
+    for a, b in zip(In['fun'], Ip['fun']):
+        assert np.abs(a[-1] - b[-1]).max() < 1e-9
+    assert np.abs(Hn - Hp).max() < 1e-6
+    assert all(f[-1].mean() < -0.999 for f in In['fun'])
+    # one C call for three time steps = three calls of one step each (resident fixed points and inverse Hessians carried over)
+    ev = NT.LockstepEvolver(D, T, P, R.ShallowCNOTStateTensor, None, 1e-13, 25, 1e-5, 1e-6, speculative=True, carry_hessian=carry)
+    ev2 = NT.LockstepEvolver(D, T, P, R.ShallowCNOTStateTensor, None, 1e-13, 25, 1e-5, 1e-6, speculative=True, carry_hessian=carry)
+    try:
+        whole = ev.steps(X0, WW, n_steps)
+        X = X0
+        for k in range(n_steps):
+            r = ev2.step(X, WW)
+            X = r['x']
+            assert np.array_equal(r['fun'], whole['fun'][k]) and np.array_equal(X, whole['params_hist'][k])
+        assert np.array_equal(Hn[1:], whole['params_hist'])
+        assert whole['gradient_batches'] >= n_steps and whole['gradient_ms'] > 0
+    finally:
+        ev.close()
+        ev2.close()
 
 
 def test_reference_signature_single_trajectory(engine_factory):

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define QMPS_ABI_VERSION 3
+#define QMPS_ABI_VERSION 4
 
 /* error codes */
 #define QMPS_OK 0

@@ -289,6 +289,34 @@ def test_native_bfgs_driver_takes_the_decisions_of_the_numpy_loop(D, P, carry):
         ev2.close()
 
 
+def test_native_bfgs_driver_argument_checks_and_single_rung(engine_factory):
+    """Refusals of qmps_evolve_bfgs (D = 2, batch larger than the context, a warm continuation without resident fixed points)
+    and the ladder-free variant (one step length: a rejected full step ends the trajectory's minimisation)."""
+    from qmps_amd import _lib
+    from qmps_amd._lib import QmpsError
+    WW = WW_of(0.05)
+    rng = np.random.default_rng(5)
+    with pytest.raises(QmpsError, match='D = 4, 8, 16'):
+        engine_factory(2, 64).evolve_bfgs(_lib.ANSATZ_SHALLOW_CNOT, rng.standard_normal((2, 2)), WW)
+    eng = engine_factory(4, 4 * 9)
+    X0 = rng.standard_normal((4, 4))
+    with pytest.raises(QmpsError, match='exceed max_batch'):
+        eng.evolve_bfgs(_lib.ANSATZ_SHALLOW_CNOT, rng.standard_normal((5, 4)), WW)
+    with pytest.raises(QmpsError, match='QMPS_BFGS_WARM'):
+        eng.evolve_bfgs(_lib.ANSATZ_SHALLOW_CNOT, X0, WW, warm=True)
+    with pytest.raises(ValueError, match='hess_inv'):
+        eng.evolve_bfgs(_lib.ANSATZ_SHALLOW_CNOT, X0, WW, warm=True, carry_hessian=True)
+    full = eng.evolve_bfgs(_lib.ANSATZ_SHALLOW_CNOT, X0, WW, n_steps=2, maxiter=40, tol=1e-13)
+    one = eng.evolve_bfgs(_lib.ANSATZ_SHALLOW_CNOT, X0, WW, n_steps=2, maxiter=40, alphas=(1.0,), tol=1e-13)
+    assert one['ladder_batches'] == 0 and full['nfev'] >= one['gradient_batches'] * 4 * 9
+    # without a ladder a trajectory whose full step is rejected stops early: never better than the full driver by more than rounding
+    assert np.all(full['fun'][-1] <= one['fun'][-1] + 1e-9)
+    assert np.all(np.isfinite(full['fun'])) and full['fun'][-1].mean() < -0.999
+    # a continued call starts where the previous one stopped
+    cont = eng.evolve_bfgs(_lib.ANSATZ_SHALLOW_CNOT, full['x'], WW, n_steps=1, maxiter=40, tol=1e-13, warm=True)
+    assert cont['fun'].shape == (1, 4) and cont['fun'][0].mean() < -0.999
+
+
 def test_reference_signature_single_trajectory(engine_factory):
     """evolve(params (P,), ...) keeps the reference's shape: history (n_steps + 1, P); scipy method per trajectory."""
     rng = np.random.default_rng(5)

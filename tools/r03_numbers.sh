@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): bash tools/r03_numbers.sh <tag>   -> gpurun_out/<tag>_*.json : the bench lines the round's DESIGN.md quotes
-tag=${1:-r03e}
+tag=${1:-r03h}
 R=$GRAFT_REPO_ROOT
 o=$R/gpurun_out
 run() { n=$1; shift; timeout 600 python $R/bench.py "$@" > $o/${tag}_$n.json 2> $o/${tag}_$n.err || echo "FAILED $n"; }
@@ -22,7 +22,9 @@ run overlap_d4_b65536 --workload overlap --D 4 --batch 65536 --steps 10 --warmup
 run evolve_d16_t256 --workload evolve --D 16 --batch 256 --steps 10 --warmup 3
 run evolve_d16_t1024 --workload evolve --D 16 --batch 1024 --steps 10 --warmup 3 --no-cpu-baseline
 run evolve_d16_t2048 --workload evolve --D 16 --batch 2048 --steps 8 --warmup 3 --no-cpu-baseline
-run evolve_d16_t256_fd --workload evolve --D 16 --batch 256 --steps 6 --warmup 2 --gradient fd --no-carry-hessian --no-cpu-baseline
+run evolve_d16_t256_numpy --workload evolve --D 16 --batch 256 --steps 10 --warmup 3 --python-driver --no-cpu-baseline
+run evolve_d16_t4096 --workload evolve --D 16 --batch 4096 --steps 6 --warmup 2 --no-cpu-baseline
+run evolve_d16_t256_fd --workload evolve --D 16 --batch 256 --steps 6 --warmup 2 --gradient fd --no-carry-hessian --python-driver --no-cpu-baseline
 run evolve_d8_t256 --workload evolve --D 8 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline
 run evolve_d4_t256 --workload evolve --D 4 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline
 run evolve_d2_t256 --workload evolve --D 2 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline

@@ -353,8 +353,13 @@ int qmps_overlap_eval_ansatz(qmps_ctx* ctx, int64_t B, int kind, int n_params, c
  *     eta' = <y, T'(r)> / <y, r>       (exact to second order in h: error O(h^2) ~ 1e-12 at h = 1e-6)
  * - one application of the neighbour's map instead of a power iteration.  f_out[T] = -sqrt|eta_t| (from the solve),
  * g_out[T][n_params] = (f(+h e_k) - f(-h e_k)) / 2h, status_out[T] = worst of the two solves.  QMPS_OVERLAP_WARM: both power
- * iterations start from the fixed points the previous call left resident (same T).  D = 4, 8, 16; needs
- * T (1 + 2 n_params) <= max_batch.  One synchronisation. */
+ * iterations start from the fixed points the previous call left resident (same T).
+ * QMPS_OVERLAP_TWO_SIDED_F: f_out comes from the two-sided quotient as well, f = -sqrt|<y, T(r)> / <y, r>| - its error is the
+ * PRODUCT of the residuals of y and r, so the two solves may stop at tol ~ 1e-8 and still deliver eta to ~1e-16 (measured at
+ * D = 16: |f - f_exact| < 1e-13 at tol = 1e-8, 16 power steps fewer than tol = 1e-12); the gradient inherits the residual to
+ * first order (2e-8 at tol = 1e-8; central differences with h = 1e-6 carry 2e-10 of rounding themselves, scipy's own
+ * forward differences ~1e-8).  D = 4, 8, 16; needs T (1 + 2 n_params) <= max_batch.  One synchronisation. */
+#define QMPS_OVERLAP_TWO_SIDED_F 4
 int qmps_overlap_gradient(qmps_ctx* ctx, int64_t T, int kind, int n_params, const double* params, double h, int max_rounds, double tol,
                           int flags, double* f_out, double* g_out, int32_t* status_out);
 
@@ -381,8 +386,12 @@ int qmps_overlap_gradient(qmps_ctx* ctx, int64_t T, int kind, int n_params, cons
  * Outputs per time step: params_hist (nullable) [n_steps][T][n_params], f_hist [n_steps][T] final objectives -sqrt|eta|,
  * nit_out (nullable) [n_steps] lock-step iterations, counters_out (nullable) [4] = gradient batches, ladder batches, objective
  * evaluations in scipy's count (2 n_params + 1 per gradient), summed HIP-event milliseconds of the gradient batches.
+ * tol: the accuracy of eta / of the objective.  The gradient batches use QMPS_OVERLAP_TWO_SIDED_F with their two eigen-solves
+ * stopped at residual max(tol, 1e-8) (objective error ~ residual^2, gradient error ~ residual: 2e-8 against gtol); the ladder
+ * batches, one-sided, iterate to tol.  QMPS_BFGS_TIGHT_GRADIENT: the gradient solves iterate to tol as well.
  * D = 4, 8, 16; needs T max(2 n_params + 1, n_alphas - 1) <= max_batch. */
 #define QMPS_BFGS_CARRY_HESSIAN 1
+#define QMPS_BFGS_TIGHT_GRADIENT 4
 #define QMPS_BFGS_WARM 2
 int qmps_evolve_bfgs(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
                      double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,

@@ -24,8 +24,8 @@ ENV_DIRECT = 2
 FLAG_NO_ENV_OUT = 0x100
 FLAG_ACCUMULATE_COST = 0x200
 FLAG_WARM_RESIDENT = 0x400
-OVERLAP_WANT_R, OVERLAP_WARM = 1, 2
-BFGS_CARRY_HESSIAN, BFGS_WARM = 1, 2
+OVERLAP_WANT_R, OVERLAP_WARM, OVERLAP_TWO_SIDED_F = 1, 2, 4
+BFGS_CARRY_HESSIAN, BFGS_WARM, BFGS_TIGHT_GRADIENT = 1, 2, 4
 UNIQUE_ID_BYTES = 128
 
 _dp = POINTER(c_double)

@@ -1573,7 +1573,7 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   if (int rc = bind(c)) return rc;
   if (!params || !f_out || !g_out) return fail(QMPS_ERR_ARG, "null argument");
   if (c->D < 4) return fail(QMPS_ERR_ARG, "qmps_overlap_gradient: D = 4, 8, 16 (at D = 2 evaluate the central-difference neighbours themselves)");
-  if (flags & ~QMPS_OVERLAP_WARM) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
+  if (flags & ~(QMPS_OVERLAP_WARM | QMPS_OVERLAP_TWO_SIDED_F)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
   if (!(h > 0.0)) return fail(QMPS_ERR_ARG, "h must be > 0");
   const int P = n_params;
   if (T < 1 || T * (1 + 2 * (int64_t)P) > c->max_batch) return fail(QMPS_ERR_ARG, "T (1 + 2 n_params) = %lld evaluations exceed max_batch = %lld", (long long)(T * (1 + 2 * (int64_t)P)), (long long)c->max_batch);
@@ -1636,6 +1636,7 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   memset(&g, 0, sizeof(g));
   g.A = c->d_ref; g.WW = c->d_ww; g.r = c->d_r; g.y = c->d_y; g.G = c->d_scratch; g.yr = (char*)c->d_scratch + (size_t)T * 4 * nD * 16;
   g.Bt = (char*)c->d_A + (size_t)T * tensor_bytes(c); g.f_out = c->d_f + T; g.T = T; g.G2P = 2 * P; g.active = mask;
+  if (flags & QMPS_OVERLAP_TWO_SIDED_F) { g.Bc = c->d_A; g.fc_out = c->d_f; }       // (overwrites the right solve's own estimate)
   HIP_TRY(qmps::launch_overlap_grad(c->D, g, c->stream));
   if (c->timed) { HIP_TRY(hipEventRecord(c->kev1[tslot], c->stream)); c->samples++; }
   c->launches++;
@@ -1664,7 +1665,7 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
   if (int rc = bind(c)) return rc;
   if (!params || !WW || !f_hist || !alphas) return fail(QMPS_ERR_ARG, "null argument");
   if (c->D < 4) return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs: D = 4, 8, 16 (the two-sided gradient)");
-  if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
+  if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
   const int P = n_params, NA = n_alphas;
   if (NA < 1 || NA > 64) return fail(QMPS_ERR_ARG, "n_alphas outside [1, 64]");
   const int64_t G = NA - 1;
@@ -1679,6 +1680,8 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
   const bool squaring = overlap_squares(c);
   const int ladder_rounds = squaring ? (max_rounds > 60 ? 60 : max_rounds) : max_rounds;
   const int grad_rounds = max_rounds > 100000 ? max_rounds : 100000;       // (as _GroupedObjective.value_and_grad)
+  // objective by the two-sided quotient (error ~ residual^2): the gradient batches' solves stop at 1e-8 (see qmps_hip.h)
+  const double grad_tol = (flags & QMPS_BFGS_TIGHT_GRADIENT) ? tol : (tol > 1e-8 ? tol : 1e-8);
   const size_t TP = (size_t)T * P;
   const double nan = __builtin_nan("");
   std::vector<double> X(params, params + TP), Hinv(TP * P), f(T), g(TP), d(TP), slope(T), fs(T), gs(TP), fn(T), gn(TP), Xc(TP), Xn(TP), s(TP), Fc((size_t)T * NA),
@@ -1698,7 +1701,7 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
   // objective + gradient of a batch of iterates; trajectories with a failed solve come back as NaN (tools.py / new_time_evolve.py)
   auto value_and_grad = [&](const double* Z, double* fo, double* go, const unsigned char* mask) -> int {
     if (mask) { if (int e = qmps_overlap_set_active(c, T, mask)) return e; }
-    if (int e = qmps_overlap_gradient(c, T, kind, P, Z, h, grad_rounds, tol, warm ? QMPS_OVERLAP_WARM : 0, fo, go, st.data())) return e;
+    if (int e = qmps_overlap_gradient(c, T, kind, P, Z, h, grad_rounds, grad_tol, (warm ? QMPS_OVERLAP_WARM : 0) | QMPS_OVERLAP_TWO_SIDED_F, fo, go, st.data())) return e;
     warm = true;
     for (int64_t t = 0; t < T; ++t)
       if (st[t] != qmps::QMPS_ST_OK) {

@@ -198,6 +198,8 @@ struct OverlapGradArgs {
   int64_t T;
   int G2P;             // neighbours per trajectory (2 P)
   const unsigned char* active;   // nullable [T]: 0 = skip the trajectory (outputs keep their previous values)
+  const void* Bc;      // nullable [T][2][D][D]: the iterates' own tensors - their objective by the same two-sided quotient
+  double* fc_out;      // [T]: -sqrt|<y, T(r)>/<y, r>|  (error ~ the PRODUCT of the residuals of y and r)
 };
 hipError_t launch_overlap_grad(int D, const OverlapGradArgs& a, hipStream_t st);
 constexpr int kOverlapStatShards = 1024;

@@ -186,6 +186,11 @@ static hipError_t launch_grad_d(const OverlapGradArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((overlap_g_kernel<D>), dim3((unsigned)((a.T + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);
   const int64_t nb = a.T * a.G2P;
   hipLaunchKernelGGL((overlap_probe_kernel<D>), dim3((unsigned)((nb + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);
+  if (a.Bc != nullptr) {          // the iterates themselves: one more probe per trajectory
+    OverlapGradArgs c = a;
+    c.Bt = a.Bc; c.f_out = a.fc_out; c.G2P = 1;
+    hipLaunchKernelGGL((overlap_probe_kernel<D>), dim3((unsigned)((a.T + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, c);
+  }
   return hipGetLastError();
 }
 

@@ -427,16 +427,17 @@ class EnergyEngine:
         self.B = B
         return f, st
 
-    def overlap_gradient(self, kind, X, h=1e-6, max_rounds=None, tol=1e-12, warm=False):
+    def overlap_gradient(self, kind, X, h=1e-6, max_rounds=None, tol=1e-12, warm=False, two_sided_f=False):
         """Iterates X (T, P) -> (f (T,), g (T, P), status (T,)): objective and its central-difference gradient against the
-        resident references, from one right + one left eigen-solve per iterate (qmps_overlap_gradient; D = 4, 8, 16)."""
+        resident references, from one right + one left eigen-solve per iterate (qmps_overlap_gradient; D = 4, 8, 16).
+        two_sided_f: f from the two-sided quotient as well (error ~ tol^2: the solves may stop at tol ~ 1e-8)."""
         X = np.ascontiguousarray(np.atleast_2d(X), dtype=np.float64)
         if max_rounds is None:
             max_rounds = 100000
         T, P = X.shape
         f, g, st = np.empty(T), np.empty((T, P)), np.empty(T, dtype=np.int32)
         L.check(self._lib.qmps_overlap_gradient(self._ctx, T, int(kind), P, _f64(X), float(h), int(max_rounds), float(tol),
-                                                L.OVERLAP_WARM if warm else 0, _f64(f), _f64(g), _i32(st)))
+                                                (L.OVERLAP_WARM if warm else 0) | (L.OVERLAP_TWO_SIDED_F if two_sided_f else 0), _f64(f), _f64(g), _i32(st)))
         self.B = T
         return f, g, st
 
@@ -471,11 +472,12 @@ class EnergyEngine:
 
     def evolve_bfgs(self, kind, params, WW, n_steps=1, maxiter=200, gtol=1e-5, h=1e-6, c1=1e-4,
                     alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), carry_hessian=False, hess_inv=None, warm=False,
-                    max_rounds=None, tol=1e-12):
+                    max_rounds=None, tol=1e-12, tight_gradient=False):
         """Time evolution by lock-step BFGS, every time step of every trajectory in ONE C call (qmps_evolve_bfgs): params (T, P) ->
         dict(x (T, P), params_hist (n_steps, T, P), fun (n_steps, T), nit (n_steps,), hess_inv (T, P, P), gradient_batches,
         ladder_batches, nfev, gradient_ms).  warm=True continues a previous call on this engine (resident fixed points; with
-        carry_hessian also `hess_inv`)."""
+        carry_hessian also `hess_inv`).  tight_gradient: the eigen-solves of the gradient batches iterate to tol instead of
+        max(tol, 1e-8) (their objective comes from the two-sided quotient either way)."""
         P = np.array(np.atleast_2d(params), dtype=np.float64, order='C', copy=True)
         WW = np.ascontiguousarray(WW, dtype=np.complex128).reshape(4, 4)
         al = np.ascontiguousarray(alphas, dtype=np.float64)
@@ -491,7 +493,7 @@ class EnergyEngine:
         Hinv = np.zeros((T, npar, npar))
         if hess_inv is not None:
             Hinv[...] = hess_inv
-        flags = (L.BFGS_CARRY_HESSIAN if carry_hessian else 0) | (L.BFGS_WARM if warm else 0)
+        flags = (L.BFGS_CARRY_HESSIAN if carry_hessian else 0) | (L.BFGS_WARM if warm else 0) | (L.BFGS_TIGHT_GRADIENT if tight_gradient else 0)
         L.check(self._lib.qmps_evolve_bfgs(self._ctx, T, int(kind), npar, _f64(P), _f64(WW.view(np.float64)), int(n_steps), int(maxiter),
                                            float(gtol), float(h), float(c1), len(al), _f64(al), flags, int(max_rounds), float(tol),
                                            _f64(Hinv), _f64(ph), _f64(fh), _i32(nit), _f64(cnt)))

@@ -100,7 +100,10 @@ class _GroupedObjective:
     def value_and_grad(self, X, h=1e-6):
         """(f (T,), g (T, P)) of the iterates X from one right + one left eigen-solve each (qmps_overlap_gradient), warm-started
         from the previous call's fixed points."""
-        f, g, st = self.eng.overlap_gradient(self.kind, X, h=h, max_rounds=max(self.max_rounds, 100000), tol=self.tol, warm=self.grad_warm)
+        # (tight_gradient False: objective by the two-sided quotient, the two solves stop at 1e-8 - what qmps_evolve_bfgs does)
+        tight = getattr(self, 'tight_gradient', True)
+        f, g, st = self.eng.overlap_gradient(self.kind, X, h=h, max_rounds=max(self.max_rounds, 100000), tol=self.tol if tight else max(self.tol, 1e-8),
+                                             warm=self.grad_warm, two_sided_f=not tight)
         self.grad_warm = True
         if self.kernel_ms is not None:
             self.kernel_ms.append(self.eng.kernel_time(1)[0])
@@ -150,7 +153,8 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
         mr = max_rounds if max_rounds is not None else (60 if D in (2, 4) else 100000)
         ev = LockstepEvolver(D, T, P, cls, mr, tol, opts.get('maxiter', 200), opts.get('gtol', 1e-5), opts.get('eps', 1e-6), ladder,
                              gradient=opts.get('gradient', 'auto'), first_rungs=opts.get('first_rungs'),
-                             carry_hessian=opts.get('carry_hessian', False), speculative=opts.get('speculative', False), native=opts.get('native', True))
+                             carry_hessian=opts.get('carry_hessian', False), speculative=opts.get('speculative', False), native=opts.get('native', True),
+                             tight_gradient=opts.get('tight_gradient', False))
         fg, fl = ev.fg, ev.fl
         try:
             for step in range(n_steps):
@@ -188,10 +192,13 @@ class LockstepEvolver:
 
     def __init__(self, D, T, P, cls=None, max_rounds=None, tol=1e-12, maxiter=200, gtol=1e-5, eps=1e-6,
                  alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), device=0, gradient='auto', first_rungs=None,
-                 carry_hessian=False, speculative=False, native=True):
+                 carry_hessian=False, speculative=False, native=True, tight_gradient=False):
         """native (with speculative and the two-sided gradient): the whole time step - every BFGS iteration of every trajectory - is
         ONE C call (qmps_evolve_bfgs: the loop of tools.batched_bfgs with its host arithmetic in C++ inside the library); False: the
         same loop in numpy, one ctypes call per batch.
+        tight_gradient=False (two-sided gradient): the objective of an iterate comes from the two-sided quotient <y, T(r)>/<y, r> - its
+        error is the product of the residuals of y and r - so the two eigen-solves of a gradient batch stop at max(tol, 1e-8): eta
+        to ~1e-16, gradient to ~2e-8 (gtol = 1e-5; scipy's own forward differences carry ~1e-8), ~16 power steps fewer per solve.
         gradient: 'fd' = the 2P + 1 central-difference candidates are eigen-solved one by one (any D); 'two-sided' = one right
         and one left eigen-solve per iterate, the neighbours by the second-order formula eta' = <y, T'(r)>/<y, r> (D >= 4);
         'auto' = 'two-sided' where the library has it.  first_rungs: two-stage ladder (tools.batched_bfgs).
@@ -209,10 +216,12 @@ class LockstepEvolver:
         self.carry_hessian, self._hinv = carry_hessian, None
         self.native = bool(native) and self.speculative
         self.mr, self.tol = mr, tol
+        self.tight_gradient = bool(tight_gradient) or not self.two_sided
         if self.native:
             # one context serves the gradient batches and the (rare, cold-started) ladder batches
             self.fg = _GroupedObjective(D, self.kind, T, max(2 * P + 1, len(self.alphas) - 1), mr, tol, device=device)
             self.fl = self.fg
+            self.fg.tight_gradient = self.tight_gradient
             self._continued = False
             return
         self.fg = _GroupedObjective(D, self.kind, T, 2 * P + 1, mr, tol, device=device)
@@ -220,6 +229,7 @@ class LockstepEvolver:
         if self.speculative:
             rungs = len(self.alphas) - 1
         self.fl = _GroupedObjective(D, self.kind, T, rungs, mr, tol, device=device)
+        self.fg.tight_gradient = self.tight_gradient
 
     def steps(self, X, WW, n_steps):
         """n_steps time steps in one C call (native driver): dict(x, params_hist, fun (n_steps, T), nit (n_steps,), ...)."""
@@ -227,7 +237,7 @@ class LockstepEvolver:
             raise RuntimeError('LockstepEvolver.steps needs the native driver (speculative=True, two-sided gradient)')
         res = self.fg.eng.evolve_bfgs(self.kind, X, WW, n_steps=n_steps, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas,
                                       carry_hessian=self.carry_hessian, hess_inv=self._hinv if (self.carry_hessian and self._continued) else None,
-                                      warm=self._continued, max_rounds=self.mr, tol=self.tol)
+                                      warm=self._continued, max_rounds=self.mr, tol=self.tol, tight_gradient=self.tight_gradient)
         self._continued = True
         self._hinv = res['hess_inv']
         if self.fg.kernel_ms is not None and res['gradient_batches']:

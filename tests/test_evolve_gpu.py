@@ -289,6 +289,31 @@ def test_native_bfgs_driver_takes_the_decisions_of_the_numpy_loop(D, P, carry):
         ev2.close()
 
 
+@pytest.mark.parametrize('D,P', [(8, 6), (16, 8)])
+def test_two_sided_objective_is_second_order_in_the_residuals(D, P, engine_factory):
+    """QMPS_OVERLAP_TWO_SIDED_F: with the eigen-solves stopped at a residual of 1e-8 the objective from <y, T(r)>/<y, r> is as
+    accurate as a solve to 1e-14 (error = product of the residuals), the one-sided estimate of the right solve is not, and the
+    gradient inherits the residual to first order - what qmps_evolve_bfgs relies on for its gradient batches."""
+    from qmps_amd import _lib
+    rng = np.random.default_rng(40 + D)
+    T = 24
+    X = rng.standard_normal((T, P))
+    Z = X + 0.02 * rng.standard_normal((T, P))
+    eng = engine_factory(D, T * (2 * P + 1))
+    eng.overlap_set_refs_params(_lib.ANSATZ_SHALLOW_CNOT, X, WW_of(0.05))
+    f0, g0, st0 = eng.overlap_gradient(_lib.ANSATZ_SHALLOW_CNOT, Z, tol=1e-14)
+    eng.overlap_stats(reset=True)
+    f1, g1, st1 = eng.overlap_gradient(_lib.ANSATZ_SHALLOW_CNOT, Z, tol=1e-8)
+    loose = eng.overlap_stats(reset=True)
+    f2, g2, st2 = eng.overlap_gradient(_lib.ANSATZ_SHALLOW_CNOT, Z, tol=1e-8, two_sided_f=True)
+    assert (st0 == 0).all() and (st1 == 0).all() and (st2 == 0).all()
+    assert np.abs(f2 - f0).max() < 1e-13 < np.abs(f1 - f0).max()
+    assert np.abs(g2 - g0).max() < 2e-7 and np.array_equal(g1, g2)
+    eng.overlap_gradient(_lib.ANSATZ_SHALLOW_CNOT, Z, tol=1e-12)
+    tight = eng.overlap_stats()
+    assert loose['rounds_sum'] < 0.85 * tight['rounds_sum']
+
+
 def test_native_bfgs_driver_argument_checks_and_single_rung(engine_factory):
     """Refusals of qmps_evolve_bfgs (D = 2, batch larger than the context, a warm continuation without resident fixed points)
     and the ladder-free variant (one step length: a rejected full step ends the trajectory's minimisation)."""

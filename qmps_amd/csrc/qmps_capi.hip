@@ -1371,6 +1371,7 @@ int launch_overlap_kernels(qmps_ctx* c, const qmps::OverlapArgs& a_in) {
   c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
   const int slot = (int)(c->samples % qmps_ctx::kRing);
   if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+  a.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
   if (c->D == 2) HIP_TRY(qmps::launch_overlap(a, c->stream));
   else HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : documented_switch("QMPS_D16_BLOCK") == nullptr, c->stream));
   if (c->timed) { HIP_TRY(hipEventRecord(c->kev1[slot], c->stream)); c->samples++; }
@@ -1625,9 +1626,11 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
     if (int e = arm_queue(c, l, 1)) return e;
     HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream));
   } else {
+    a.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
     HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : documented_switch("QMPS_D16_BLOCK") == nullptr, c->stream));
     // (D = 4: the squaring kernel again - the left fixed point is the largest row of the squared map, whatever the spectral gap)
     if (c->D == 4 && squaring) l.max_rounds = a.max_rounds;
+    l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
     HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 4 ? squaring : (c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr), c->stream));
   }
   // the 2 P central-difference neighbours of every iterate, evaluated to second order in h from (y, r)

@@ -140,6 +140,12 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_block_kerne
   int iters = 0, status = QMPS_ST_NOT_CONVERGED;
   bool active = true;
   const double tol2 = p.tol * p.tol;
+  // deflation steps (below): one evaluation per wave only - the branch must be uniform over the lanes of a reduction
+  constexpr bool kDeflate = D == 8;
+  double2 rp = make_double2(0.0, 0.0), sg_prev = make_double2(0.0, 0.0);
+  double w0_prev = 0.0, n_prev = 0.0, sig_max2 = 0.0;
+  int last_deflation = 0;
+  bool deflate_on = p.no_deflation == 0;
   __syncthreads();
   for (int k = 1; k <= p.max_rounds; ++k) {
     if (!__syncthreads_or(active ? 1 : 0)) break;
@@ -172,17 +178,58 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_block_kerne
     const double2 et = make_double2(v[0], v[1]);
     const double nn = v[2];
     const double dr = xn.x - (et.x * x.x - et.y * x.y), di = xn.y - (et.x * x.y + et.y * x.x);
-    double w[4] = {dr * dr + di * di, 0.0, 0.0, 0.0};
+    // (the spare slots of this reduction: <r_{k-1}, r_k> for the estimate of the second eigenvalue, see below)
+    double w[4] = {dr * dr + di * di, rp.x * dr + rp.y * di, rp.x * di - rp.y * dr, 0.0};
     group_sum4(w);
     if (active) {
       eta = et;
       iters = k;
-      if (w[0] < tol2) {
+      const double e2 = et.x * et.x + et.y * et.y;
+      if (w[0] < tol2 && kDeflate && sig_max2 > 0.0 && !(e2 > sig_max2 * (1.0 + 1e-3))) {
+        // converged - to an eigenvalue that does not dominate one of those a deflation step removed (a nearly degenerate
+        // dominant pair: the shift took out the wrong one).  Start again, plain power method only.
+        deflate_on = false;
+        sig_max2 = 0.0;
+        w0_prev = 0.0;
+        rp = make_double2(0.0, 0.0);
+        x = make_double2(i == j ? 1.0 / __builtin_sqrt((double)D) : 0.0, 0.0);
+      } else if (w[0] < tol2) {
         status = QMPS_ST_OK;
         active = false;
       } else {
-        const double inv = nn > 0.0 ? 1.0 / __builtin_sqrt(nn) : 0.0;
-        x = make_double2(xn.x * inv, xn.y * inv);
+        bool deflated = false;
+        if constexpr (kDeflate) {
+          // Slow convergence = a second eigenvalue eta_2 close to eta_1 in modulus.  The residual r_k = (T - eta_k) x_k is then
+          // dominated by that eigenvector, r_k ~ (eta_2 / n_{k-1}) r_{k-1} with n = ||T x||, so two successive residuals give
+          // eta_2 for free; ONE step with the shifted map, x <- (T - sigma) x = T x - sigma x, removes that component (Wielandt).
+          // It also amplifies every other component by |eta_j - sigma| / |eta_1 - sigma|, so it is taken only when the plain
+          // iteration is slow, the estimate has settled, and not again before the plain steps have damped what it stirred up.
+          // The result is still the power method's: convergence is declared by the same residual test on plain steps only.
+          const double2 sg = w0_prev > 0.0 ? make_double2(n_prev * w[1] / w0_prev, n_prev * w[2] / w0_prev) : make_double2(0.0, 0.0);
+          const double ds = (sg.x - sg_prev.x) * (sg.x - sg_prev.x) + (sg.y - sg_prev.y) * (sg.y - sg_prev.y), s2 = sg.x * sg.x + sg.y * sg.y;
+          // (the estimate settled to 1e-4, and what it names is smaller in modulus than the current Rayleigh quotient - never
+          // shift out something that may be the dominant eigenvalue; the check above is the safety net behind this one)
+          if (deflate_on && k >= 24 && k - last_deflation >= 12 && w[0] > 0.64 * w0_prev && ds < 1e-8 * s2 && s2 < 0.998 * e2 && s2 > 0.25 * e2) {
+            double2 xd = make_double2(xn.x - (sg.x * x.x - sg.y * x.y), xn.y - (sg.x * x.y + sg.y * x.x));
+            double q[4] = {xd.x * xd.x + xd.y * xd.y, 0.0, 0.0, 0.0};
+            group_sum4(q);
+            if (q[0] > 1e-280) {
+              const double inv = 1.0 / __builtin_sqrt(q[0]);
+              x = make_double2(xd.x * inv, xd.y * inv);
+              deflated = true;
+              last_deflation = k;
+              sig_max2 = s2 > sig_max2 ? s2 : sig_max2;
+            }
+          }
+          sg_prev = sg;
+          w0_prev = deflated ? 0.0 : w[0];
+          n_prev = __builtin_sqrt(nn);
+          rp = make_double2(dr, di);
+        }
+        if (!deflated) {
+          const double inv = nn > 0.0 ? 1.0 / __builtin_sqrt(nn) : 0.0;
+          x = make_double2(xn.x * inv, xn.y * inv);
+        }
       }
     }
   }

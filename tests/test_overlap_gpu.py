@@ -85,6 +85,37 @@ def test_overlap_far_candidates_and_caps(D, engine_factory):
     assert np.all(st == 1) and np.all(rounds == 3)
 
 
+def test_d8_deflation_steps_find_the_same_dominant_eigenvalue(engine_factory, monkeypatch):
+    """D = 8: the power method with its occasional shifted step (a slowly decaying second eigenvector removed, its eigenvalue
+    estimated from two successive residuals) against the plain power method (QMPS_NO_DEFLATION) and the dense eigen-solve:
+    same dominant eigenvalue - never a smaller one declared converged - in fewer steps on the slow candidates."""
+    rng = np.random.default_rng(4242)
+    D, n = 8, 600
+    eng = engine_factory(D, n)
+    WW = expm(-1j * 0.2 * O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5}))
+    U = O.haar_unitaries(rng, 2 * D, n)
+    A = O.unitary_to_tensor(U)
+    K = rng.standard_normal((n, 2 * D, 2 * D)) + 1j * rng.standard_normal((n, 2 * D, 2 * D))
+    K = K - K.conj().transpose(0, 2, 1)
+    near = O.unitary_to_tensor(np.stack([expm(0.5 * K[b] / np.linalg.norm(K[b])) @ U[b] for b in range(n)]))
+    far = O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, n))
+    for cands, cap in ((near, 20000), (far, 4000)):
+        monkeypatch.delenv('QMPS_NO_DEFLATION', raising=False)
+        eta, rounds, st = eng.overlaps(A, cands, WW, max_rounds=cap)
+        monkeypatch.setenv('QMPS_NO_DEFLATION', '1')
+        eta_p, rounds_p, st_p = eng.overlaps(A, cands, WW, max_rounds=cap)
+        monkeypatch.delenv('QMPS_NO_DEFLATION', raising=False)
+        both = (st == 0) & (st_p == 0)
+        assert np.abs(eta - eta_p)[both].max() < 1e-10
+        assert (st == 0).sum() >= (st_p == 0).sum() and rounds[both].sum() <= rounds_p[both].sum()
+        # whatever converged - with or without a plain twin - is the dominant eigenvalue of the dense map
+        for b in np.flatnonzero(st == 0)[::9]:
+            assert abs(eta[b] - O.overlap_eta(A[b], cands[b], WW)[0]) < ETA_TOL
+        for b in np.flatnonzero((st == 0) & (st_p != 0)):
+            assert abs(eta[b] - O.overlap_eta(A[b], cands[b], WW)[0]) < ETA_TOL
+    assert rounds.max() <= 4000
+
+
 def test_overlap_d4_power_method_matches_the_squaring_kernel():
     """D = 4: the operator-form power method of the generic tile kernel (QMPS_OVERLAP_POWER) and the MFMA squaring
     kernel find the same dominant eigenvalue."""

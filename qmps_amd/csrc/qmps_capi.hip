@@ -1690,7 +1690,7 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
   std::vector<double> X(params, params + TP), Hinv(TP * P), f(T), g(TP), d(TP), slope(T), fs(T), gs(TP), fn(T), gn(TP), Xc(TP), Xn(TP), s(TP), Fc((size_t)T * NA),
       cand, Fl, Hy(P);
   std::vector<int32_t> st(T), stl;
-  std::vector<unsigned char> active(T), moved(T);
+  std::vector<unsigned char> active(T), moved(T), need(T);
   const int saved_period = c->timing_period;
   if (counters_out) c->timing_period = 1;
   double n_grad = 0.0, n_ladder = 0.0, nfev = 0.0, grad_ms = 0.0;
@@ -1770,7 +1770,9 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
         double* Ft = &Fc[(size_t)t * NA];
         for (int r = 0; r < NA; ++r) Ft[r] = INFINITY;
         Ft[0] = std::isfinite(fs[t]) ? fs[t] : INFINITY;
-        if (active[t] && !(Ft[0] <= f[t] + c1 * alphas[0] * slope[t])) all_accept = false;
+        // need: the trajectories that rejected the full step - the ladder and the gradient at the accepted point are for them only
+        need[t] = (active[t] && !(Ft[0] <= f[t] + c1 * alphas[0] * slope[t])) ? 1 : 0;
+        if (need[t]) all_accept = false;
       }
       bool have_new = all_accept;
       if (all_accept) {
@@ -1784,7 +1786,7 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
           for (int64_t r = 0; r < G; ++r)
             for (int k = 0; k < P; ++k) cand[((size_t)t * G + r) * P + k] = X[(size_t)t * P + k] + alphas[r + 1] * d[(size_t)t * P + k];
         if ((rc = qmps_overlap_set_group(c, G))) break;
-        if ((rc = qmps_overlap_set_active(c, T, active.data()))) break;
+        if ((rc = qmps_overlap_set_active(c, T, need.data()))) break;
         rc = qmps_overlap_eval_ansatz(c, T * G, kind, P, cand.data(), ladder_rounds, tol, 0, Fl.data(), stl.data());
         (void)qmps_overlap_set_group(c, 0);
         if (rc) break;
@@ -1792,7 +1794,7 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
         nfev += (double)T * G;
         for (int64_t t = 0; t < T; ++t)
           for (int64_t r = 0; r < G; ++r) {
-            const double v = stl[(size_t)t * G + r] == qmps::QMPS_ST_OK ? Fl[(size_t)t * G + r] : nan;
+            const double v = (need[t] && stl[(size_t)t * G + r] == qmps::QMPS_ST_OK) ? Fl[(size_t)t * G + r] : nan;
             Fc[(size_t)t * NA + r + 1] = std::isfinite(v) ? v : INFINITY;
           }
       }
@@ -1811,8 +1813,14 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
           Xn[(size_t)t * P + k] = X[(size_t)t * P + k] + s[(size_t)t * P + k];
         }
       }
-      if (!have_new)
-        if ((rc = value_and_grad(Xn.data(), fn.data(), gn.data(), active.data()))) break;
+      if (!have_new) {
+        if ((rc = value_and_grad(Xn.data(), fn.data(), gn.data(), need.data()))) break;
+        for (int64_t t = 0; t < T; ++t)
+          if (!need[t]) {                                   // accepted the full step: its values are the speculative batch's
+            fn[t] = fs[t];
+            memcpy(&gn[(size_t)t * P], &gs[(size_t)t * P], P * sizeof(double));
+          }
+      }
       any_active = false;
       for (int64_t t = 0; t < T; ++t) {
         double* gt = &g[(size_t)t * P];

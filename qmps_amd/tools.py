@@ -282,7 +282,7 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
     speculative (needs value_and_grad): objective AND gradient are evaluated at the full step x + alphas[0] d straight away;
     if every active trajectory accepts that step (Armijo) - the normal case of a quasi-Newton iteration - the iteration is that
     ONE batch; otherwise the remaining rungs of the ladder are evaluated (line_batch receives T (len(alphas) - 1) candidates) and
-    the gradient at the accepted points as usual.  Same decisions as the plain ladder: the first rung is tested first either way.
+    the gradient at the accepted points - both masked (on_active) to the trajectories that rejected the full step.  Same decisions as the plain ladder: the first rung is tested first either way.
     on_active (optional): called as on_active('grad' | 'line', active (T,) bool) right before every batch of the loop - an evaluator
     that can skip trajectories (qmps_overlap_set_active) then spends nothing on the converged ones; rows of skipped trajectories
     may come back with stale values: they are never used.
@@ -308,9 +308,9 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
             d[bad] = -g[bad]
             slope[bad] = -np.einsum('ti,ti->t', g[bad], g[bad])
         d[~active] = 0.0
-        def ladder(a):
+        def ladder(a, need=None):
             if on_active is not None:
-                on_active('line', active)
+                on_active('line', active if need is None else need)
             cand = X[:, None, :] + a[None, :, None] * d[:, None, :]
             F = np.asarray(line_batch(cand.reshape(-1, P))).reshape(T, len(a))
             return np.where(np.isfinite(F), F, np.inf)
@@ -323,10 +323,14 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
             nfev += T * (2 * P + 1)
             Fc = np.full((T, len(al)), np.inf)
             Fc[:, 0] = np.where(np.isfinite(fs), fs, np.inf)
-            if (Fc[:, 0] <= f + c1 * al[0] * slope)[active].all():
+            took = Fc[:, 0] <= f + c1 * al[0] * slope
+            if took[active].all():
                 fn, gn = fs, gs                          # every active trajectory takes the full step: nothing else to evaluate
             else:
-                Fc[:, 1:] = ladder(al[1:])
+                # the ladder and the gradient at the accepted point only for the trajectories that rejected the full step (the
+                # others keep what the speculative batch gave them: their accepted point IS x + alphas[0] d)
+                need = active & ~took
+                Fc[:, 1:] = np.where(need[:, None], ladder(al[1:], need), np.inf)
                 nfev += T * (len(al) - 1)
         elif first_rungs:
             Fc = np.full((T, len(al)), np.inf)
@@ -346,9 +350,12 @@ def batched_bfgs(grad_batch, line_batch, X0, maxiter=200, gtol=1e-5, h=1e-6, c1=
         s = a[:, None] * d
         Xn = X + s
         if fn is None:
+            redo = active if not (speculative and value_and_grad is not None) else need
             if on_active is not None:
-                on_active('grad', active)
+                on_active('grad', redo)
             fn, gn = vg(Xn)
+            if redo is not active:
+                fn, gn = np.where(redo, fn, fs), np.where(redo[:, None], gn, gs)
             nfev += T * (2 * P + 1)
         y = gn - g
         sy = np.einsum('ti,ti->t', s, y)

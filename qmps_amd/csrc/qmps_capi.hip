@@ -152,6 +152,8 @@ struct qmps_ctx {
   // RCCL: the all-reduce runs on its own stream so that it overlaps the next step's kernels
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
+  hipStream_t aux_stream = nullptr;     // qmps_overlap_gradient: the neighbour tensors are built beside the eigen-solves (lazy)
+  hipEvent_t aux_fork = nullptr, aux_join = nullptr;
   hipStream_t comm_stream = nullptr;
   // a second communicator (ncclCommSplit of the first) on its own stream: the exchanges of consecutive ring slots
   // alternate between the two, so two small all-reduces can be in flight - the exchange keeps up with the compute stream
@@ -495,6 +497,9 @@ int qmps_destroy(qmps_ctx* c) {
     if (c->cost_ready[i]) (void)hipEventDestroy(c->cost_ready[i]);
     if (c->cost_reduced[i]) (void)hipEventDestroy(c->cost_reduced[i]);
   }
+  if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+  if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
+  if (c->aux_join) (void)hipEventDestroy(c->aux_join);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   if (c->comm_stream2) (void)hipStreamDestroy(c->comm_stream2);
   void* bufs[] = {c->d_A, c->d_U, c->d_U2, c->d_params, c->d_ww, c->d_eta, c->d_ref, c->d_f, c->d_ostats, c->d_xwarm, c->d_y, c->d_queue, c->d_active, c->d_scratch, c->d_h, c->d_r, c->d_rho, c->d_E, c->d_iters, c->d_status, c->d_partial, c->d_cost, c->d_cost_ring, c->d_work_count, c->d_work_idx, c->d_acc, c->d_acc_err, c->roto_base, c->roto_hist, c->roto_idx};
@@ -1615,6 +1620,22 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
   const int tslot = (int)(c->samples % qmps_ctx::kRing);
   if (c->timed) HIP_TRY(hipEventRecord(c->kev0[tslot], c->stream));
+  // the 2 P central-difference neighbours of every iterate (evaluated below to second order in h from (y, r)): their tensors
+  // need the parameters only, so they are built on a second stream BESIDE the eigen-solves (at small T a gradient batch is the
+  // latency of its slowest solve; the neighbour tensors were a fifth of it in front of the probes)
+  if (!c->aux_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
+  }
+  // (beyond ~1 000 iterates the solves fill the chip by themselves: T = 2 048 measured 5 % slower with the second stream)
+  const bool beside = T <= 1024;
+  if (beside) {
+    HIP_TRY(hipEventRecord(c->aux_fork, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
+    HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->aux_stream));
+    HIP_TRY(hipEventRecord(c->aux_join, c->aux_stream));
+  }
   // the left fixed points: power method on the adjoint map; results behind the iterates' (eta, rounds, status at [T, 2T))
   qmps::OverlapArgs l = a;
   l.adjoint = 1; l.eta = (char*)c->d_eta + (size_t)T * 16; l.f_out = nullptr; l.r_out = c->d_y; l.x_in = warm ? c->d_y : nullptr;
@@ -1633,8 +1654,8 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
     l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
     HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 4 ? squaring : (c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr), c->stream));
   }
-  // the 2 P central-difference neighbours of every iterate, evaluated to second order in h from (y, r)
-  HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->stream));
+  if (beside) HIP_TRY(hipStreamWaitEvent(c->stream, c->aux_join, 0));
+  else HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->stream));
   qmps::OverlapGradArgs g;
   memset(&g, 0, sizeof(g));
   g.A = c->d_ref; g.WW = c->d_ww; g.r = c->d_r; g.y = c->d_y; g.G = c->d_scratch; g.yr = (char*)c->d_scratch + (size_t)T * 4 * nD * 16;

@@ -391,7 +391,8 @@ int qmps_overlap_gradient(qmps_ctx* ctx, int64_t T, int kind, int n_params, cons
  * tol: the accuracy of eta / of the objective.  The gradient batches use QMPS_OVERLAP_TWO_SIDED_F with their two eigen-solves
  * stopped at residual max(tol, 1e-8) (objective error ~ residual^2, gradient error ~ residual: 2e-8 against gtol); the ladder
  * batches, one-sided, iterate to tol.  QMPS_BFGS_TIGHT_GRADIENT: the gradient solves iterate to tol as well.
- * D = 4, 8, 16; needs T max(2 n_params + 1, n_alphas - 1) <= max_batch. */
+ * Any D; at D = 2 (the reference's own bond dimension) the 2 n_params + 1 central-difference candidates of a gradient batch are
+ * eigen-solved themselves.  Needs T max(2 n_params + 1, n_alphas - 1) <= max_batch. */
 #define QMPS_BFGS_CARRY_HESSIAN 1
 #define QMPS_BFGS_TIGHT_GRADIENT 4
 #define QMPS_BFGS_WARM 2

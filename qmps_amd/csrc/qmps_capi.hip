@@ -1688,7 +1688,6 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
                      double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out) {
   if (int rc = bind(c)) return rc;
   if (!params || !WW || !f_hist || !alphas) return fail(QMPS_ERR_ARG, "null argument");
-  if (c->D < 4) return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs: D = 4, 8, 16 (the two-sided gradient)");
   if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
   const int P = n_params, NA = n_alphas;
   if (NA < 1 || NA > 64) return fail(QMPS_ERR_ARG, "n_alphas outside [1, 64]");
@@ -1700,7 +1699,8 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
   if (int rc = check_ansatz(c, kind, P)) return rc;
   const bool carry = (flags & QMPS_BFGS_CARRY_HESSIAN) != 0;
   bool warm = (flags & QMPS_BFGS_WARM) != 0;
-  if (warm && c->grad_warm_T != T) return fail(QMPS_ERR_STATE, "QMPS_BFGS_WARM: the resident fixed points belong to %lld trajectories, not %lld", (long long)c->grad_warm_T, (long long)T);
+  const bool two_sided = c->D >= 4;       // D = 2: the 2 P + 1 central-difference candidates are eigen-solved themselves (a lane each)
+  if (warm && two_sided && c->grad_warm_T != T) return fail(QMPS_ERR_STATE, "QMPS_BFGS_WARM: the resident fixed points belong to %lld trajectories, not %lld", (long long)c->grad_warm_T, (long long)T);
   const bool squaring = overlap_squares(c);
   const int ladder_rounds = squaring ? (max_rounds > 60 ? 60 : max_rounds) : max_rounds;
   const int grad_rounds = max_rounds > 100000 ? max_rounds : 100000;       // (as _GroupedObjective.value_and_grad)
@@ -1723,7 +1723,39 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
   if (carry && warm && hinv) memcpy(Hinv.data(), hinv, TP * P * sizeof(double));
   else for (int64_t t = 0; t < T; ++t) set_identity(t);
   // objective + gradient of a batch of iterates; trajectories with a failed solve come back as NaN (tools.py / new_time_evolve.py)
+  std::vector<double> fdc, fdf;
+  std::vector<int32_t> fds;
   auto value_and_grad = [&](const double* Z, double* fo, double* go, const unsigned char* mask) -> int {
+    if (!two_sided) {
+      // tools.batched_fd_gradient: candidate t (2 P + 1) + 0 = the iterate, + 1 + k = +h e_k, + 1 + P + k = -h e_k
+      const int64_t G1 = 2 * (int64_t)P + 1;
+      fdc.resize((size_t)T * G1 * P);
+      fdf.resize((size_t)T * G1);
+      fds.resize((size_t)T * G1);
+      for (int64_t t = 0; t < T; ++t)
+        for (int64_t r = 0; r < G1; ++r)
+          for (int k = 0; k < P; ++k)
+            fdc[((size_t)t * G1 + r) * P + k] = Z[(size_t)t * P + k] + (r >= 1 && (r - 1) % P == k ? (r <= P ? h : -h) : 0.0);
+      if (int e = qmps_overlap_set_group(c, G1)) return e;
+      if (mask) { if (int e = qmps_overlap_set_active(c, T, mask)) return e; }
+      int e = qmps_overlap_eval_ansatz(c, T * G1, kind, P, fdc.data(), ladder_rounds, tol, 0, fdf.data(), fds.data());
+      (void)qmps_overlap_set_group(c, 0);
+      if (e) return e;
+      for (int64_t t = 0; t < T; ++t) {
+        const double* F = &fdf[(size_t)t * G1];
+        const int32_t* S = &fds[(size_t)t * G1];
+        fo[t] = S[0] == qmps::QMPS_ST_OK ? F[0] : nan;
+        for (int k = 0; k < P; ++k)
+          go[(size_t)t * P + k] = (S[1 + k] == qmps::QMPS_ST_OK && S[1 + P + k] == qmps::QMPS_ST_OK) ? (F[1 + k] - F[1 + P + k]) / (2.0 * h) : nan;
+      }
+      n_grad += 1.0;
+      nfev += (double)T * (2 * P + 1);
+      if (counters_out) {
+        float ms = 0.f;
+        if (qmps_kernel_time(c, 1, &ms, nullptr, 0) == QMPS_OK) grad_ms += ms;
+      }
+      return QMPS_OK;
+    }
     if (mask) { if (int e = qmps_overlap_set_active(c, T, mask)) return e; }
     if (int e = qmps_overlap_gradient(c, T, kind, P, Z, h, grad_rounds, grad_tol, (warm ? QMPS_OVERLAP_WARM : 0) | QMPS_OVERLAP_TWO_SIDED_F, fo, go, st.data())) return e;
     warm = true;

@@ -212,7 +212,7 @@ class LockstepEvolver:
         self.alphas, self.maxiter, self.gtol, self.eps = tuple(alphas), maxiter, gtol, eps
         self.two_sided = (gradient == 'two-sided') or (gradient == 'auto' and D >= 4)
         self.first_rungs = first_rungs
-        self.speculative = speculative and self.two_sided
+        self.speculative = bool(speculative)      # (D = 2: with the central-difference candidates eigen-solved one by one)
         self.carry_hessian, self._hinv = carry_hessian, None
         self.native = bool(native) and self.speculative
         self.mr, self.tol = mr, tol
@@ -253,6 +253,9 @@ class LockstepEvolver:
         self.fg.set_reference(X, WW)
         self.fl.set_reference(X, WW)
         vg = (lambda Z: self.fg.value_and_grad(Z, self.eps)) if self.two_sided else None
+        if vg is None and self.speculative:
+            from .tools import batched_fd_gradient
+            vg = lambda Z: batched_fd_gradient(self.fg, Z, self.eps)
         def on_active(kind, mask):          # converged trajectories cost nothing in the batches that follow
             (self.fg if kind == 'grad' else self.fl).eng.overlap_set_active(mask)
         res = batched_bfgs(self.fg, self.fl, X, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas, on_active=on_active,

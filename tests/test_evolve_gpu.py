@@ -251,7 +251,7 @@ def test_lockstep_bfgs_time_evolution(D, P, T, iters):
         assert s['evaluations'] >= 2 * T * sum(n + 1 for n in info['nit'])      # two solves per iterate and iteration (+ re-evaluations after a rejected full step)
 
 
-@pytest.mark.parametrize('D,P,carry', [(4, 4, False), (8, 6, True), (16, 8, True), (16, 8, False)])
+@pytest.mark.parametrize('D,P,carry', [(2, 8, True), (4, 4, False), (8, 6, True), (16, 8, True), (16, 8, False)])
 def test_native_bfgs_driver_takes_the_decisions_of_the_numpy_loop(D, P, carry):
     """qmps_evolve_bfgs - the lock-step BFGS time step with its host arithmetic in C++ inside the library, one C call for the
     whole evolution - against tools.batched_bfgs(speculative=True) driving the same device batches from numpy: same iteration
@@ -270,7 +270,9 @@ def test_native_bfgs_driver_takes_the_decisions_of_the_numpy_loop(D, P, carry):
     assert list(In['nit']) == list(Ip['nit'])
     for a, b in zip(In['fun'], Ip['fun']):
         assert np.abs(a[-1] - b[-1]).max() < 1e-9
-    assert np.abs(Hn - Hp).max() < 1e-6
+    # (D = 2, depth 4: eight angles on two qubits - flat directions along which rounding-level differences of the two drivers'
+    # dot products travel freely; the objectives above agree to 1e-9)
+    assert np.abs(Hn - Hp).max() < (1e-6 if D >= 4 else 2e-3)
     assert all(f[-1].mean() < -0.999 for f in In['fun'])
     # one C call for three time steps = three calls of one step each (resident fixed points and inverse Hessians carried over)
     ev = NT.LockstepEvolver(D, T, P, R.ShallowCNOTStateTensor, None, 1e-13, 25, 1e-5, 1e-6, speculative=True, carry_hessian=carry)
@@ -315,14 +317,12 @@ def test_two_sided_objective_is_second_order_in_the_residuals(D, P, engine_facto
 
 
 def test_native_bfgs_driver_argument_checks_and_single_rung(engine_factory):
-    """Refusals of qmps_evolve_bfgs (D = 2, batch larger than the context, a warm continuation without resident fixed points)
+    """Refusals of qmps_evolve_bfgs (batch larger than the context, a warm continuation without resident fixed points)
     and the ladder-free variant (one step length: a rejected full step ends the trajectory's minimisation)."""
     from qmps_amd import _lib
     from qmps_amd._lib import QmpsError
     WW = WW_of(0.05)
     rng = np.random.default_rng(5)
-    with pytest.raises(QmpsError, match='D = 4, 8, 16'):
-        engine_factory(2, 64).evolve_bfgs(_lib.ANSATZ_SHALLOW_CNOT, rng.standard_normal((2, 2)), WW)
     eng = engine_factory(4, 4 * 9)
     X0 = rng.standard_normal((4, 4))
     with pytest.raises(QmpsError, match='exceed max_batch'):

@@ -499,6 +499,10 @@ def main_evolve(args):
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         cpu = evolve_cpu_baseline(D, P, WW, args.seed, args.bfgs_iters)
+    if args.carry_hessian is None:
+        # measured (profiles/r03h_evolve_*.json): D = 16 3.2 against 9.5 iterations per time step, D = 8 6.8 against 13 - but
+        # D = 4 19.6 against 12 and D = 2 no gain: the shallow ansaetze of D = 2, 4 have flat directions a carried Hessian mis-scales
+        args.carry_hessian = D >= 8
     from qmps_amd import _lib
     from qmps_amd.new_time_evolve import LockstepEvolver
     from qmps_amd.represent import ShallowCNOTStateTensor
@@ -797,6 +801,8 @@ def main():
     ap.add_argument('--no-speculative', action='store_true',
                     help='evolve workload: always evaluate the backtracking ladder before the gradient (default: objective and gradient at the full '
                          'quasi-Newton step first, the ladder only when some trajectory rejects that step)')
+    ap.add_argument('--carry-hessian', dest='carry_hessian', action='store_true', default=None,
+                    help='evolve workload: carry the inverse Hessians from time step to time step (the default at D >= 8; at D = 2, 4 the identity start measured faster)')
     ap.add_argument('--no-carry-hessian', dest='carry_hessian', action='store_false',
                     help='evolve workload: start the BFGS of every time step from the identity (what scipy - the reference - does) instead of '
                          'the inverse Hessians the previous step ended with; the default run reports this variant as the extra `identity_start`')

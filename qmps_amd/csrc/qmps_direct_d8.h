@@ -80,10 +80,9 @@ __device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9]
         M[8 * lo + hi] = re;
         M[8 * hi + lo] = im;
       }
-    // - identity (column = the lane's own index), + trace functional on the last row
+    // + trace functional on the last row; the identity (column = the lane's own index: a register index that depends on the
+    // lane - 64 compare / select / subtract triples here) is subtracted in LDS during the layout change below
     const double w63 = lane == N - 1 ? 1.0 : 0.0;
-#pragma unroll
-    for (int c = 0; c < N; ++c) M[c] -= (lane == c ? 1.0 : 0.0);
 #pragma unroll
     for (int j = 0; j < D; ++j) M[9 * j] += w63;
   }
@@ -106,6 +105,8 @@ __device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9]
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int jj = 0; jj < 16; ++jj) sM[lane][jj] = M[16 * qt + jj];
+      __builtin_amdgcn_wave_barrier();
+      if ((lane >> 4) == qt) sM[lane][lane & 15] -= 1.0;      // - identity: the lane's own diagonal entry sits in this quarter
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int m = 0; m < 4; ++m)

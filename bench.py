@@ -484,6 +484,8 @@ def main_evolve(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('QMPS_BENCH_ONE_DEVICE') == '1':
+        local_rank = 0
     D, T = args.D, args.batch
     depth = {2: 4, 4: 2, 8: 3, 16: 4}[D]          # D = 2: scripts/loschmidt.py evolves ShallowCNOTStateTensor(2, .) with 8 angles
     P = 2 * depth

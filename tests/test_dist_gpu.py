@@ -164,3 +164,23 @@ def test_bench_sharded_rotosolve(nproc):
         assert 'RCCL communicator of 1 ranks' in c['collective']
     elif 'RCCL communicator of 2 ranks' not in c['collective']:
         assert 'unavailable' in c['collective'] and 'gloo' in c['collective']
+
+
+def test_bench_evolve_two_ranks_on_one_device():
+    """--workload evolve through the driver's launcher with two ranks (BASELINE.json configs[4]: trajectories sharded over the
+    GPUs, no data-path collective): each rank evolves its own trajectories with the one-call native driver, the launcher's
+    gloo group carries the barriers and the max-over-ranks time, rank 0 prints the one JSON line with the whole-job rate."""
+    import json
+    env = dict(os.environ, QMPS_BENCH_ONE_DEVICE='1', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', '29531', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'evolve', '--D', '16',
+           '--batch', '32', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-extras']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    c = d['config']
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and c['trajectories_per_gpu'] == 32 and 'qmps_evolve_bfgs' in c['driver']
+    assert d['value'] > 0 and c['not_converged'] == 0 and c['mean_final_objective'] < -0.999
+    assert abs(d['value'] - 2 * 32 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-6 * d['value']

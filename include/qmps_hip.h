@@ -130,8 +130,9 @@ extern "C" {
  *   QMPS_NO_GRAPH         rotosolve / time evolution: plain launches instead of a captured hipGraph per sweep
  *   QMPS_OVERLAP_POWER    D = 4 overlap objective: operator-form power method instead of squaring the 16 x 16 map
  *   QMPS_D16_BLOCK        D = 16: the generic LDS-tile kernels instead of the matrix-core kernels
- *   QMPS_NO_DEFLATION     D = 8 overlap objective: plain power method, without the occasional shifted step that removes a slowly
- *                         decaying second eigenvector (same results; candidates with |eta_2 / eta_1| > 0.9 take 3 - 10 x more steps)
+ *   QMPS_NO_DEFLATION     D = 8, 16 overlap objective: plain power method, without the occasional shifted step that removes a slowly
+ *                         decaying second eigenvector (same results; candidates with |eta_2 / eta_1| > 0.9 take 2 - 10 x more steps;
+ *                         D = 16: cold starts only - warm-started batches run the lean loop)
  *   QMPS_D16_ONE_WAVE     D = 16 overlap objective, batches above 2 048 candidates: one wave per candidate with a static stride
  *                         (round 2) instead of four waves per candidate drawn from a work queue
  * Everything else that used to be tunable from the environment (thresholds, schedules: profiles/EXPERIMENTS.md) is compiled

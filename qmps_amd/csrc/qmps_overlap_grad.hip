@@ -180,16 +180,74 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_probe_kerne
   }
 }
 
+// D = 16: ONE WAVE per neighbour, a 2 x 2 register tile per lane (lane = 8 i2 + j2 owns rows 2 i2, 2 i2 + 1 x columns 2 j2, 2 j2 + 1):
+// half the LDS reads per complex multiply-add of the one-thread-per-element kernel above, and no workgroup barrier
+// (32 768 neighbours of 2 048 iterates: 150 -> 126 us; it is then bound by the issue of its 1 024 multiply-adds per lane).
+// Tried and dropped: neighbours LINEARISED around the iterate (<y, T'(r)> = <y, T(r)> + sum_s <B'_s - B_s, M_s>, M once per
+// iterate; the even orders cancel in the central difference) - an elementwise contraction per neighbour, but it reads three
+// tiles per neighbour (B', B, M: memory-bound, 80 us) and the eight extra products for M cost the G kernel 50 us: slower in sum.
+__global__ __launch_bounds__(64) void overlap_probe_d16_kernel(OverlapGradArgs p) {
+  constexpr int D = 16, N = 256, P = 17;
+  __shared__ double2 sB[2][D][P];
+  const int lane = threadIdx.x, i2 = lane >> 3, j2 = lane & 7;
+  const int64_t b = blockIdx.x;
+  const int64_t t = b / p.G2P;
+  if (p.active != nullptr && p.active[t] == 0) return;
+  {
+    const double2* Bp = (const double2*)p.Bt + b * (2 * N);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int l = lane + 64 * u, s = l >> 8, e = l & 255;
+      sB[s][e >> 4][e & 15] = Bp[l];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const double2* Gp = (const double2*)p.G + t * (4 * N);
+  double nr = 0.0, ni = 0.0;
+#pragma unroll
+  for (int s1 = 0; s1 < 2; ++s1)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      double2 acc[2][2] = {{make_double2(0.0, 0.0), make_double2(0.0, 0.0)}, {make_double2(0.0, 0.0), make_double2(0.0, 0.0)}};
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double2 a0 = sB[s1][2 * i2][k], a1 = sB[s1][2 * i2 + 1][k], b0 = sB[s2][k][2 * j2], b1 = sB[s2][k][2 * j2 + 1];
+        cfma(a0, b0, acc[0][0]);
+        cfma(a0, b1, acc[0][1]);
+        cfma(a1, b0, acc[1][0]);
+        cfma(a1, b1, acc[1][1]);
+      }
+#pragma unroll
+      for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+          const double2 g = Gp[(2 * s1 + s2) * N + (2 * i2 + di) * D + 2 * j2 + dj], bm = acc[di][dj];
+          nr = dfma(bm.x, g.x, dfma(bm.y, g.y, nr));       // conj(bm) g
+          ni = dfma(bm.x, g.y, dfma(-bm.y, g.x, ni));
+        }
+    }
+  nr = wave_sum(nr);
+  ni = wave_sum(ni);
+  if (lane == 0) {
+    const double2 d = ((const double2*)p.yr)[t];
+    const double den = d.x * d.x + d.y * d.y;
+    const double er = (nr * d.x + ni * d.y) / den, ei = (ni * d.x - nr * d.y) / den;
+    p.f_out[b] = -__builtin_sqrt(__builtin_sqrt(er * er + ei * ei));
+  }
+}
+
 template <int D>
 static hipError_t launch_grad_d(const OverlapGradArgs& a, hipStream_t st) {
   constexpr int N = D * D, THREADS = N < 64 ? 64 : N, ITEMS = THREADS / N;
   hipLaunchKernelGGL((overlap_g_kernel<D>), dim3((unsigned)((a.T + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);
   const int64_t nb = a.T * a.G2P;
-  hipLaunchKernelGGL((overlap_probe_kernel<D>), dim3((unsigned)((nb + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);
+  if constexpr (D == 16) hipLaunchKernelGGL(overlap_probe_d16_kernel, dim3((unsigned)nb), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL((overlap_probe_kernel<D>), dim3((unsigned)((nb + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);
   if (a.Bc != nullptr) {          // the iterates themselves: one more probe per trajectory
     OverlapGradArgs c = a;
     c.Bt = a.Bc; c.f_out = a.fc_out; c.G2P = 1;
-    hipLaunchKernelGGL((overlap_probe_kernel<D>), dim3((unsigned)((a.T + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, c);
+    if constexpr (D == 16) hipLaunchKernelGGL(overlap_probe_d16_kernel, dim3((unsigned)a.T), dim3(64), 0, st, c);
+    else hipLaunchKernelGGL((overlap_probe_kernel<D>), dim3((unsigned)((a.T + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, c);
   }
   return hipGetLastError();
 }

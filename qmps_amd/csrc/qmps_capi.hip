@@ -1,30 +1,19 @@
-// qmps_capi.hip - the C-ABI of libqmps_hip.so (declared in include/qmps_hip.h).
+// qmps_capi.hip - the C-ABI of libqmps_hip.so (declared in include/qmps_hip.h): library / device, context lifetime, states,
+// the energy path, the rotosolve drivers, read-back, the summed-cost exchange (RCCL), probes.  The time-evolution overlap
+// objective and the evolve drivers: qmps_capi_overlap.hip.  Shared context + helpers: qmps_ctx.h.
 // Host-side runtime: context = one device + one HIP stream + HBM buffers; asynchronous launches;
 // pinned staging for small results; native RCCL communicator for the summed-cost all-reduce.
-#include <hip/hip_runtime.h>
-#include <chrono>
-#include <rccl/rccl.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <math.h>
-#include <cmath>
+#include "qmps_ctx.h"
+
 #include <time.h>
 
-#include <new>
-#include <vector>
-
-#include "qmps_hip.h"
-#include "qmps_kernels.h"
-#include "qmps_knobs.h"
-
-using qmps::documented_switch;
-using qmps::tuning_knob;
+using namespace qmps_host;
 
 namespace {
-
 thread_local char g_err[512] = "";
+}  // namespace
+
+namespace qmps_host {
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -34,165 +23,6 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t e_ = (expr);                                                                        \
-    if (e_ != hipSuccess) return fail(QMPS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-  } while (0)
-
-#define RCCL_TRY(expr)                                                                               \
-  do {                                                                                               \
-    ncclResult_t r_ = (expr);                                                                        \
-    if (r_ != ncclSuccess) return fail(QMPS_ERR_RCCL, "%s failed: %s", #expr, ncclGetErrorString(r_)); \
-  } while (0)
-
-constexpr int kMaxTerms = 16;      // (energy_block_kernel stages kMaxTerms x 16 entries in LDS: qmps_energy_block.hip kHMax)
-constexpr int kSumBlocks = 256;
-
-}  // namespace
-
-struct qmps_ctx {
-  int device = -1;
-  int D = 0;
-  int64_t max_batch = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // ring of event pairs around the DOMINANT kernel of each qmps_energy_launch (read by qmps_kernel_time)
-  static constexpr int kRing = 64;
-  hipEvent_t kev0[kRing] = {}, kev1[kRing] = {};
-  int64_t launches = 0;
-  bool capturing = false;   // inside hipStreamBeginCapture: skip the timing events
-  const char* dominant = "";
-  // HBM
-  void* d_A = nullptr;       // [max_batch][2][D][D] c128
-  void* d_U = nullptr;       // [max_batch][2D][2D] c128 (lazy)
-  void* d_U2 = nullptr;      // second unitary of a two-site unit cell (lazy)
-  double* d_params = nullptr;  // ansatz parameters [max_batch][params_cap] (lazy)
-  void* d_ww = nullptr;        // two-site operator of the overlap objective (lazy)
-  void* d_eta = nullptr;       // overlap eigenvalues [max_batch] complex (lazy)
-  void* d_ref = nullptr;       // reference tensors of the overlap objective [ref_cap][2][D][D] (lazy; its own buffer: d_U is
-  int64_t ref_cap = 0;         //   overwritten by qmps_set_states(kind = UNITARY) and the two-site unit cell)
-  double* d_f = nullptr;       // overlap objective -sqrt|eta| [max_batch] (lazy)
-  unsigned long long* d_ostats = nullptr;   // overlap solver statistics [4] (lazy)
-  char* h_pin = nullptr;       // pinned staging for the optimiser drivers' small host <-> device transfers (lazy, grown on demand):
-  size_t h_pin_bytes = 0;      //   pageable buffers make every hipMemcpyAsync a blocking, internally staged copy
-  unsigned char* d_active = nullptr;   // qmps_overlap_set_active: per-trajectory mask consumed by the next overlap launch (lazy, [max_batch])
-  int64_t active_n = 0;                //   entries armed (0: none)
-  int* d_queue = nullptr;      // D = 16 overlap kernels: two counters the workgroups draw their evaluations from (lazy)
-  void* d_y = nullptr;         // qmps_overlap_gradient: LEFT fixed points [max_batch][D][D] (lazy)
-  int64_t grad_warm_T = 0;     // d_r / d_y hold the fixed points of this many trajectories' iterates (qmps_overlap_gradient)
-  void* d_xwarm = nullptr;     // qmps_evolve_rotosolve: fixed points per (parameter, candidate) (lazy, grown on demand)
-  size_t xwarm_bytes = 0;
-  int64_t overlap_group = 0;   // > 0: candidate b is compared with reference b / overlap_group
-  void* d_scratch = nullptr;   // brick-wall inputs / outputs (lazy, grown on demand)
-  size_t scratch_bytes = 0;
-  int params_cap = 0;
-  void* d_h = nullptr;       // [16][4][4] c128
-  void* d_r = nullptr;       // [max_batch][D][D] c128
-  void* d_rho = nullptr;     // [max_batch][4][4] c128 (lazy)
-  double* d_E = nullptr;     // [max_batch][n_terms]
-  int64_t E_capacity = 0;    // in doubles
-  int32_t* d_iters = nullptr;
-  int32_t* d_status = nullptr;
-  double* d_partial = nullptr;  // [16][max(kSumBlocks, waves of the lane kernels)]
-  int64_t partial_cap = 0;      // entries per term
-  int64_t partials_B = -1;      // >= 0: the last launch left per-wave partial sums for this batch size
-  int partials_n = 0;           //       ... in this many entries per term
-  double* d_cost = nullptr;     // [16]
-  double* h_cost = nullptr;     // pinned [16]
-  int32_t* d_work_count = nullptr;  // [1]  hybrid solve: number of slow items handed to the squaring tail
-  int32_t* d_work_idx = nullptr;    // [max_batch]
-  int handoff = 0;                  // plain power steps before the squaring tail (set in qmps_create)
-  int default_solver = 1;           // solver of the one-shot entry points (QMPS_ENV_POWER_SQUARING)
-  int skip_rounds = 0;              // untracked squarings when handoff == 0 (set in qmps_create)
-  int timing_period = 1;            // HIP events around the dominant kernel on every timing_period-th launch (0 = never)
-  int64_t samples = 0;              // launches timed so far (ring index)
-  bool timed = false;               // this launch is one of them
-  bool no_pair = false;             // QMPS_NO_PAIR: D = 4 energy-only launches with one lane per evaluation (tuning knob)
-  bool pair_in_step = true;         // QMPS_LANE_IN_STEP: one-lane energy pass inside qmps_energy_launch
-  int n_cus = 256;                  // compute units of the device (set in qmps_create)
-  int matvec_period = QMPS_MATVEC_PERIOD_D4;   // D = 4: mat-vecs with T^(2^m) between two further squarings
-  // state
-  int n_terms = 0;
-  int64_t n_states = 0;
-  int64_t window = 0;               // first evaluation addressed by the launch / read-back calls (qmps_set_window)
-  int64_t overlap_refs = 0;         // reference tensors resident for the overlap objective (1 = shared by the batch)
-  bool have_guess = false;
-  bool have_env = false;
-  bool have_overlap_x = false;       // d_r holds the fixed points of the last overlap launch (QMPS_OVERLAP_WANT_R)
-  bool want_rho = false;
-  bool defer_sync = false;          // one-shot entry points: the setters leave their H2D copies in flight, ONE synchronisation at the end
-  // ansatz-parametrised states: the parameters stay resident (d_params, or ans_src during a rotosolve run); at D = 4 the
-  // direct kernel builds the tensor itself, so d_A is materialised only when something else asks for the tensors
-  bool ans_have = false;            // the resident states ARE ansatz(kind, P) of the resident parameters
-  bool tensors_valid = true;        // d_A holds the tensors of the resident states
-  int ans_kind = 0, ans_P = 0;
-  const double* ans_src = nullptr;  // parameter rows (nullptr: d_params)
-  // rotosolve work buffers and the captured sweep are kept between calls (a call used to spend ~0.6 ms on hipMalloc /
-  // hipFree / graph capture + instantiation - as much as three sweeps at D = 4)
-  double* roto_base = nullptr;
-  double* roto_hist = nullptr;
-  int* roto_idx = nullptr;
-  size_t roto_base_bytes = 0, roto_hist_bytes = 0;
-  hipGraph_t roto_graph = nullptr;
-  hipGraphExec_t roto_exec = nullptr;
-  struct RotoKey {
-    int64_t R = -1;
-    int kind = 0, P = 0, nsh = 0, max_iter = 0, n_terms = 0, solver = 0, handoff = 0;
-    double tol = 0.0;
-    bool fused = false;
-    const void *base = nullptr, *hist = nullptr, *params = nullptr, *E = nullptr;
-    bool operator==(const RotoKey& o) const {
-      return R == o.R && kind == o.kind && P == o.P && nsh == o.nsh && max_iter == o.max_iter && n_terms == o.n_terms && solver == o.solver &&
-             handoff == o.handoff && tol == o.tol && fused == o.fused && base == o.base && hist == o.hist && params == o.params && E == o.E;
-    }
-  } roto_key;
-  const int* ans_i = nullptr;       // rotosolve: device index of the parameter being updated
-  int ans_nsh = 0;                  // rotosolve: shifts per restart (0: one parameter row per evaluation)
-  // RCCL: the all-reduce runs on its own stream so that it overlaps the next step's kernels
-  ncclComm_t comm = nullptr;
-  int rank = 0, nranks = 1;
-  hipStream_t aux_stream = nullptr;     // qmps_overlap_gradient: the neighbour tensors are built beside the eigen-solves (lazy)
-  hipEvent_t aux_fork = nullptr, aux_join = nullptr;
-  hipStream_t comm_stream = nullptr;
-  // a second communicator (ncclCommSplit of the first) on its own stream: the exchanges of consecutive ring slots
-  // alternate between the two, so two small all-reduces can be in flight - the exchange keeps up with the compute stream
-  // as long as an all-reduce takes less than TWO steps (a step is ~28 us; a small all-reduce over 8 GPUs 15-40 us)
-  ncclComm_t comm2 = nullptr;
-  hipStream_t comm_stream2 = nullptr;
-  ncclComm_t comm_of(int slot) const { return (slot & 1) && comm2 ? comm2 : comm; }
-  hipStream_t comm_stream_of(int slot) const { return (slot & 1) && comm2 ? comm_stream2 : comm_stream; }
-  static constexpr int kCostSlots = 8;        // ring: step n's all-reduce may still be in flight while the next steps sum
-  static constexpr int kMaxGroup = 16;        // steps whose summed costs may travel in ONE all-reduce
-  double* d_cost_ring = nullptr;             // [kCostSlots][kMaxGroup][16]: a slot = one group of steps
-  int exchange_period = 1;                   // steps per all-reduce (qmps_set_exchange_period)
-  int group_fill = 0;                        // steps summed into the current group so far
-  bool slot_waited = false;                  // the compute stream already waits for the current slot's previous exchange
-  int64_t slot_checks = 0, slot_blocks = 0;  // host-side slot guard: times asked / times the previous exchange was still in flight
-  double slot_block_ms = 0.0;                // ... and how long the host then waited (qmps_exchange_stats)
-  int64_t groups = 0;                        // groups closed (exchanged or, without a communicator, just filled)
-  int last_slot = -1, last_pos = -1;         // where the newest cost lives
-  hipEvent_t cost_ready[kCostSlots] = {};    // sum kernels done (main stream)
-  hipEvent_t cost_reduced[kCostSlots] = {};  // all-reduce done (comm stream)
-  int64_t cost_launches = 0;
-  // exact in-kernel cost accumulation (QMPS_FLAG_ACCUMULATE_COST): one fixed-point accumulator per ring position
-  long long* d_acc = nullptr;                // [kCostSlots][kMaxGroup][kAccWords]
-  long long* h_acc = nullptr;                // pinned [kAccWords]
-  bool acc_is[kCostSlots][kMaxGroup] = {};   // the position's cost lives in its accumulator (not yet a double in the ring)
-  bool acc_dirty[kCostSlots][kMaxGroup] = {};  // the accumulator has been added to since it was last cleared
-  bool acc_after_event[kCostSlots][kMaxGroup] = {};  // cleared by a memset on the compute stream: its finish kernel must wait for an event
-  double acc_scale[kCostSlots][kMaxGroup] = {};
-  int acc_shards[kCostSlots][kMaxGroup] = {};
-  long long acc_expect[kCostSlots][kMaxGroup] = {};   // waves (tiles of 16 evaluations) that add to each term's shards
-  int* d_acc_err = nullptr;                  // set by a finish kernel whose producer never arrived (bounded poll)
-  bool acc_pending = false;                  // an accumulating launch waits for its qmps_cost_launch
-  int64_t acc_B = 0, acc_window = 0;
-  int acc_slot = 0, acc_pos = 0;
-  double h_fro = 0.0;                        // max_t ||h_t||_F (qmps_set_hamiltonian)
-  long long* acc_at(int slot, int pos) const { return d_acc + ((size_t)slot * kMaxGroup + pos) * qmps::kAccWords; }
-};
-
-namespace {
 
 int bind(qmps_ctx* c) {
   if (!c) return fail(QMPS_ERR_ARG, "null context");
@@ -200,8 +30,6 @@ int bind(qmps_ctx* c) {
   return QMPS_OK;
 }
 
-size_t tensor_bytes(const qmps_ctx* c) { return (size_t)32 * c->D * c->D; }
-size_t env_bytes(const qmps_ctx* c) { return (size_t)16 * c->D * c->D; }
 
 int ensure_scratch(qmps_ctx* c, size_t bytes) {
   if (bytes > c->scratch_bytes) {
@@ -238,11 +66,6 @@ int check_window(const qmps_ctx* c, int64_t B) {
 }
 
 // addresses of the window's first evaluation
-char* win_A(const qmps_ctx* c) { return (char*)c->d_A + (size_t)c->window * tensor_bytes(c); }
-char* win_r(const qmps_ctx* c) { return (char*)c->d_r + (size_t)c->window * env_bytes(c); }
-double* win_E(const qmps_ctx* c) { return c->d_E + c->window * (c->n_terms > 0 ? c->n_terms : 1); }
-int32_t* win_iters(const qmps_ctx* c) { return c->d_iters + c->window; }
-int32_t* win_status(const qmps_ctx* c) { return c->d_status + c->window; }
 
 // kinds the D = 4 direct kernel builds in front of the solve (three-qubit circuits with a per-layer gate list)
 bool fusable_ansatz(const qmps_ctx* c, int kind) {
@@ -375,7 +198,7 @@ int setup_accumulator(qmps_ctx* c, qmps::LaneArgs& a, int64_t B, int64_t adds, i
   return QMPS_OK;
 }
 
-}  // namespace
+}  // namespace qmps_host
 
 extern "C" {
 
@@ -1331,738 +1154,6 @@ int qmps_kernel_time(qmps_ctx* c, int n_last, float* avg_ms, char* name, int nam
 }
 
 namespace {
-int ensure_refs(qmps_ctx* c, int64_t n_ref) {
-  if (n_ref > c->ref_cap) {
-    if (c->d_ref) HIP_TRY(hipFree(c->d_ref));
-    c->d_ref = nullptr;
-    c->ref_cap = 0;
-    HIP_TRY(hipMalloc(&c->d_ref, (size_t)n_ref * tensor_bytes(c)));
-    c->ref_cap = n_ref;
-  }
-  return QMPS_OK;
-}
-int set_ww(qmps_ctx* c, const double* WW) {
-  if (!c->d_ww) HIP_TRY(hipMalloc(&c->d_ww, 256));
-  HIP_TRY(hipMemcpyAsync(c->d_ww, WW, 256, hipMemcpyHostToDevice, c->stream));
-  return QMPS_OK;
-}
-int ensure_overlap_outputs(qmps_ctx* c) {
-  if (!c->d_eta) HIP_TRY(hipMalloc(&c->d_eta, (size_t)c->max_batch * 16));
-  if (!c->d_f) HIP_TRY(hipMalloc((void**)&c->d_f, (size_t)c->max_batch * sizeof(double)));
-  if (!c->d_ostats) {
-    HIP_TRY(hipMalloc((void**)&c->d_ostats, (size_t)qmps::kOverlapStatShards * 4 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(c->d_ostats, 0, (size_t)qmps::kOverlapStatShards * 4 * sizeof(unsigned long long), c->stream));
-  }
-  return QMPS_OK;
-}
-// D = 16 batches above 2 048 evaluations: the four-waves-per-evaluation kernel with a work queue (zeroed here, on the stream)
-int arm_queue(qmps_ctx* c, qmps::OverlapArgs& a, int which) {
-  a.queue = nullptr;
-  if (c->D != 16 || a.B <= 2048 || documented_switch("QMPS_D16_ONE_WAVE") != nullptr || documented_switch("QMPS_D16_BLOCK") != nullptr) return QMPS_OK;
-  if (!c->d_queue) HIP_TRY(hipMalloc((void**)&c->d_queue, 2 * sizeof(int)));
-  HIP_TRY(hipMemsetAsync(c->d_queue + which, 0, sizeof(int), c->stream));
-  a.queue = c->d_queue + which;
-  return QMPS_OK;
-}
-
-// the kernel the overlap launch of this context runs (name for qmps_kernel_time) and whether it counts squarings
-bool overlap_squares(const qmps_ctx* c) { return c->D == 2 || (c->D == 4 && !documented_switch("QMPS_OVERLAP_POWER")); }
-int launch_overlap_kernels(qmps_ctx* c, const qmps::OverlapArgs& a_in) {
-  qmps::OverlapArgs a = a_in;
-  if (int rc = arm_queue(c, a, 0)) return rc;
-  const bool squaring = overlap_squares(c);
-  c->dominant = c->D == 2 ? "overlap_lane_kernel" : (c->D == 4 && squaring ? "overlap_square_d4_kernel" :
-                (c->D == 16 && !documented_switch("QMPS_D16_BLOCK") ? "overlap_mfma_d16_kernel" : "overlap_block_kernel<D>"));
-  c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
-  const int slot = (int)(c->samples % qmps_ctx::kRing);
-  if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
-  a.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
-  if (c->D == 2) HIP_TRY(qmps::launch_overlap(a, c->stream));
-  else HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : documented_switch("QMPS_D16_BLOCK") == nullptr, c->stream));
-  if (c->timed) { HIP_TRY(hipEventRecord(c->kev1[slot], c->stream)); c->samples++; }
-  if (!c->capturing) c->launches++;
-  return QMPS_OK;
-}
-}  // namespace
-
-int qmps_overlap_set(qmps_ctx* c, int64_t n_ref, const double* A, const double* WW) {
-  if (int rc = bind(c)) return rc;
-  if (!A || !WW) return fail(QMPS_ERR_ARG, "null argument");
-  if (n_ref < 1 || n_ref > c->max_batch) return fail(QMPS_ERR_ARG, "n_ref=%lld outside [1, max_batch]", (long long)n_ref);
-  // the reference state(s) live in their own buffer: nothing else in the context writes it
-  if (int rc = ensure_refs(c, n_ref)) return rc;
-  HIP_TRY(hipMemcpyAsync(c->d_ref, A, (size_t)n_ref * tensor_bytes(c), hipMemcpyHostToDevice, c->stream));
-  if (int rc = set_ww(c, WW)) return rc;
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  c->overlap_refs = n_ref;
-  c->overlap_group = 0;
-  return QMPS_OK;
-}
-
-int qmps_overlap_set_refs_ansatz(qmps_ctx* c, int64_t n_ref, int kind, int n_params, const double* params, const double* WW) {
-  if (int rc = bind(c)) return rc;
-  if (!params || !WW) return fail(QMPS_ERR_ARG, "null argument");
-  if (n_ref < 1 || n_ref > c->max_batch) return fail(QMPS_ERR_ARG, "n_ref=%lld outside [1, max_batch]", (long long)n_ref);
-  if (int rc = check_ansatz(c, kind, n_params)) return rc;
-  if (int rc = ensure_refs(c, n_ref)) return rc;
-  // parameter rows through the scratch arena, tensors built on the device straight into the reference buffer
-  if (int rc = ensure_scratch(c, (size_t)n_ref * n_params * sizeof(double))) return rc;
-  HIP_TRY(hipMemcpyAsync(c->d_scratch, params, (size_t)n_ref * n_params * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(qmps::launch_ansatz(c->D, kind, (const double*)c->d_scratch, n_params, c->d_ref, n_ref, c->stream));
-  if (int rc = set_ww(c, WW)) return rc;
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  c->overlap_refs = n_ref;
-  c->overlap_group = 0;
-  return QMPS_OK;
-}
-
-int qmps_overlap_set_group(qmps_ctx* c, int64_t group) {
-  if (!c) return fail(QMPS_ERR_ARG, "null context");
-  if (group < 0) return fail(QMPS_ERR_ARG, "group must be >= 0");
-  c->overlap_group = group;
-  return QMPS_OK;
-}
-
-int qmps_overlap_set_active(qmps_ctx* c, int64_t n, const unsigned char* active) {
-  if (int rc = bind(c)) return rc;
-  if (n < 0 || n > c->max_batch) return fail(QMPS_ERR_ARG, "n=%lld outside [0, max_batch]", (long long)n);
-  if (n == 0 || !active) {
-    c->active_n = 0;
-    return QMPS_OK;
-  }
-  if (!c->d_active) HIP_TRY(hipMalloc((void**)&c->d_active, (size_t)c->max_batch));
-  if (int rc = ensure_pinned(c, (16u << 20))) return rc;
-  // through the pinned staging buffer (its last MiB: the parameter / result regions may be in use by the same driver)
-  unsigned char* stage = (unsigned char*)c->h_pin + (15u << 20);
-  if ((size_t)n > (1u << 20)) return fail(QMPS_ERR_ARG, "mask longer than 2^20 entries");
-  memcpy(stage, active, (size_t)n);
-  memset(stage + n, 1, (size_t)((8 - n % 8) % 8));
-  HIP_TRY(qmps::launch_stage_copy(stage, c->d_active, (n + 7) / 8, c->stream));
-  c->active_n = n;
-  return QMPS_OK;
-}
-
-int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int flags) {
-  if (int rc = bind(c)) return rc;
-  if (int rc = check_window(c, B)) return rc;
-  if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
-  if (c->overlap_refs < 1) return fail(QMPS_ERR_STATE, "qmps_overlap_set has not been called");
-  if (flags & ~(QMPS_OVERLAP_WANT_R | QMPS_OVERLAP_WARM)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
-  const bool want_r = (flags & QMPS_OVERLAP_WANT_R) != 0, warm = (flags & QMPS_OVERLAP_WARM) != 0;
-  if (warm && !want_r) return fail(QMPS_ERR_ARG, "QMPS_OVERLAP_WARM needs QMPS_OVERLAP_WANT_R (the fixed points stay resident for the next launch)");
-  if (warm && !c->have_overlap_x) return fail(QMPS_ERR_STATE, "QMPS_OVERLAP_WARM: no resident fixed points (run a launch with QMPS_OVERLAP_WANT_R first)");
-  const int64_t group = c->overlap_group;
-  if (group > 0) {
-    if (c->overlap_refs * group < c->window + B) return fail(QMPS_ERR_STATE, "%lld reference tensors x group %lld for window end %lld", (long long)c->overlap_refs, (long long)group, (long long)(c->window + B));
-  } else if (c->overlap_refs != 1 && c->overlap_refs < c->window + B) {
-    return fail(QMPS_ERR_STATE, "%lld reference tensors for window end %lld", (long long)c->overlap_refs, (long long)(c->window + B));
-  }
-  const bool squaring = overlap_squares(c);   // these square the matrix of the map: rounds, not steps
-  const int cap = squaring ? 60 : (1 << 24);
-  if (max_rounds < 1 || max_rounds > cap || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_rounds / tol (D = %d: max_rounds in [1, %d])", c->D, cap);
-  if (int rc = ensure_overlap_outputs(c)) return rc;
-  qmps::OverlapArgs a;
-  memset(&a, 0, sizeof(a));
-  const bool shared = group == 0 && c->overlap_refs == 1;
-  // (the window displaces the candidates; with a group the references are addressed by the candidate's GLOBAL index)
-  a.A = (shared || group > 0) ? (char*)c->d_ref + (group > 0 ? (size_t)(c->window / group) * tensor_bytes(c) : 0)
-                              : (char*)c->d_ref + (size_t)c->window * tensor_bytes(c);
-  if (group > 0 && c->window % group) return fail(QMPS_ERR_ARG, "with a candidate group the window must start at a multiple of it");
-  if (int rc = ensure_tensors(c)) return rc;
-  a.Bt = win_A(c);
-  a.WW = c->d_ww;
-  a.eta = (char*)c->d_eta + (size_t)c->window * 16;
-  a.f_out = c->d_f + c->window;
-  a.r_out = want_r ? win_r(c) : nullptr;
-  a.x_in = warm ? win_r(c) : nullptr;
-  a.stats = c->d_ostats;
-  a.group = (int)group;
-  a.iters = win_iters(c); a.status = win_status(c); a.B = B; a.a_shared = shared ? 1 : 0; a.max_rounds = max_rounds; a.tol = tol;
-  if (c->active_n > 0) {           // one-shot mask of qmps_overlap_set_active: one entry per trajectory (candidate group)
-    const int64_t need = group > 0 ? (c->window + B + group - 1) / group : c->window + B;
-    if (c->active_n < need) return fail(QMPS_ERR_STATE, "qmps_overlap_set_active: %lld entries for %lld trajectories", (long long)c->active_n, (long long)need);
-    a.active = c->d_active + (group > 0 ? c->window / group : c->window);
-    c->active_n = 0;
-  }
-  if (int rc = launch_overlap_kernels(c, a)) return rc;
-  c->have_env = false;
-  c->have_guess = false;
-  if (want_r) {                 // (a launch that keeps no fixed points leaves the resident ones alone)
-    c->have_overlap_x = true;
-    c->grad_warm_T = 0;
-  }
-  c->acc_pending = false;
-  c->partials_B = -1;
-  return QMPS_OK;
-}
-
-int qmps_overlap_get(qmps_ctx* c, int64_t B, double* eta_out, double* r_out, int32_t* rounds_out, int32_t* status_out) {
-  if (int rc = bind(c)) return rc;
-  if (int rc = check_window(c, B)) return rc;
-  if (!eta_out) return fail(QMPS_ERR_ARG, "null eta_out");
-  if (!c->d_eta) return fail(QMPS_ERR_STATE, "qmps_overlap_launch has not been called");
-  HIP_TRY(hipMemcpyAsync(eta_out, (char*)c->d_eta + (size_t)c->window * 16, (size_t)B * 16, hipMemcpyDeviceToHost, c->stream));
-  if (r_out) {
-    if (!c->have_overlap_x) return fail(QMPS_ERR_STATE, "the last overlap launch did not keep the fixed points (QMPS_OVERLAP_WANT_R)");
-    HIP_TRY(hipMemcpyAsync(r_out, win_r(c), (size_t)B * env_bytes(c), hipMemcpyDeviceToHost, c->stream));
-  }
-  if (rounds_out) HIP_TRY(hipMemcpyAsync(rounds_out, win_iters(c), (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
-  if (status_out) HIP_TRY(hipMemcpyAsync(status_out, win_status(c), (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return QMPS_OK;
-}
-
-int qmps_overlap_get_objective(qmps_ctx* c, int64_t B, double* f_out) {
-  if (int rc = bind(c)) return rc;
-  if (int rc = check_window(c, B)) return rc;
-  if (!f_out) return fail(QMPS_ERR_ARG, "null f_out");
-  if (!c->d_f) return fail(QMPS_ERR_STATE, "qmps_overlap_launch has not been called");
-  HIP_TRY(hipMemcpyAsync(f_out, c->d_f + c->window, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return QMPS_OK;
-}
-
-int qmps_overlap_stats(qmps_ctx* c, int64_t* evaluations, int64_t* rounds_sum, int64_t* rounds_max, int64_t* not_converged, int reset) {
-  if (int rc = bind(c)) return rc;
-  unsigned long long h[4] = {0, 0, 0, 0};
-  if (c->d_ostats) {
-    std::vector<unsigned long long> sh((size_t)qmps::kOverlapStatShards * 4);
-    HIP_TRY(hipMemcpyAsync(sh.data(), c->d_ostats, sh.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    if (reset) HIP_TRY(hipMemsetAsync(c->d_ostats, 0, sh.size() * sizeof(unsigned long long), c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < qmps::kOverlapStatShards; ++k) {
-      h[0] += sh[4 * k];
-      h[1] += sh[4 * k + 1];
-      if (sh[4 * k + 2] > h[2]) h[2] = sh[4 * k + 2];
-      h[3] += sh[4 * k + 3];
-    }
-  }
-  if (evaluations) *evaluations = (int64_t)h[0];
-  if (rounds_sum) *rounds_sum = (int64_t)h[1];
-  if (rounds_max) *rounds_max = (int64_t)h[2];
-  if (not_converged) *not_converged = (int64_t)h[3];
-  return QMPS_OK;
-}
-
-int qmps_overlap_eval_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const double* params, int max_rounds, double tol,
-                             int flags, double* f_out, int32_t* status_out) {
-  if (!c) return fail(QMPS_ERR_ARG, "null context");
-  if (!f_out) return fail(QMPS_ERR_ARG, "null f_out");
-  // one round trip: parameters in, ansatz + overlap kernels, objective and status out - ONE synchronisation (the optimiser
-  // drivers call this twice per iteration; three separate calls cost three synchronisations and two extra launch gaps)
-  c->defer_sync = true;
-  int rc = qmps_set_states_ansatz(c, B, kind, n_params, params);
-  c->defer_sync = false;
-  if (!rc) rc = qmps_overlap_launch(c, B, max_rounds, tol, flags);
-  if (rc) {
-    (void)hipStreamSynchronize(c->stream);
-    return rc;
-  }
-  const size_t fb = (size_t)B * sizeof(double), sb = (size_t)B * sizeof(int32_t);
-  if (fb + sb <= (8u << 20) && c->h_pin_bytes >= (16u << 20)) {
-    char* out = c->h_pin + (8u << 20);
-    HIP_TRY(qmps::launch_stage_copy(c->d_f, out, B, c->stream));
-    if (status_out) HIP_TRY(qmps::launch_stage_copy(c->d_status, out + fb, (B + 1) / 2, c->stream));     // (d_status has max_batch >= B + 1 entries or the tail is never read)
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    memcpy(f_out, out, fb);
-    if (status_out) memcpy(status_out, out + fb, sb);
-    return QMPS_OK;
-  }
-  HIP_TRY(hipMemcpyAsync(f_out, c->d_f, fb, hipMemcpyDeviceToHost, c->stream));
-  if (status_out) HIP_TRY(hipMemcpyAsync(status_out, c->d_status, sb, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return QMPS_OK;
-}
-
-int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const double* params, double h, int max_rounds, double tol,
-                          int flags, double* f_out, double* g_out, int32_t* status_out) {
-  if (int rc = bind(c)) return rc;
-  if (!params || !f_out || !g_out) return fail(QMPS_ERR_ARG, "null argument");
-  if (c->D < 4) return fail(QMPS_ERR_ARG, "qmps_overlap_gradient: D = 4, 8, 16 (at D = 2 evaluate the central-difference neighbours themselves)");
-  if (flags & ~(QMPS_OVERLAP_WARM | QMPS_OVERLAP_TWO_SIDED_F)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
-  if (!(h > 0.0)) return fail(QMPS_ERR_ARG, "h must be > 0");
-  const int P = n_params;
-  if (T < 1 || T * (1 + 2 * (int64_t)P) > c->max_batch) return fail(QMPS_ERR_ARG, "T (1 + 2 n_params) = %lld evaluations exceed max_batch = %lld", (long long)(T * (1 + 2 * (int64_t)P)), (long long)c->max_batch);
-  if (c->overlap_refs < T) return fail(QMPS_ERR_STATE, "%lld reference tensors resident, %lld trajectories (qmps_overlap_set / qmps_overlap_set_refs_ansatz)", (long long)c->overlap_refs, (long long)T);
-  if (max_rounds < 1 || max_rounds > (1 << 24) || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_rounds / tol");
-  const bool warm = (flags & QMPS_OVERLAP_WARM) != 0;
-  if (warm && c->grad_warm_T != T) return fail(QMPS_ERR_STATE, "QMPS_OVERLAP_WARM: the resident fixed points belong to %lld trajectories, not %lld", (long long)c->grad_warm_T, (long long)T);
-  if (int rc = ensure_overlap_outputs(c)) return rc;
-  if (!c->d_y) HIP_TRY(hipMalloc(&c->d_y, (size_t)c->max_batch * env_bytes(c)));
-  const size_t nD = (size_t)c->D * c->D;
-  if (int rc = ensure_scratch(c, (size_t)T * (4 * nD + 1) * 16 + 256)) return rc;
-  {      // pinned staging for the results, sized BEFORE anything is in flight through it
-    const size_t need = (size_t)T * (1 + 2 * P) * sizeof(double) + (size_t)2 * T * sizeof(int32_t) + (8u << 20);
-    if (int e = ensure_pinned(c, need > (16u << 20) ? need : (16u << 20))) return e;
-  }
-  // the iterates: parameters -> tensors in d_A[0, T)
-  c->defer_sync = true;
-  int rc = qmps_set_states_ansatz(c, T, kind, P, params);
-  c->defer_sync = false;
-  if (!rc) rc = ensure_tensors(c);
-  if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
-  const bool squaring = overlap_squares(c);       // D = 4: the right fixed point comes from the squaring kernel (largest column)
-  qmps::OverlapArgs a;
-  memset(&a, 0, sizeof(a));
-  a.A = c->d_ref; a.Bt = c->d_A; a.WW = c->d_ww; a.eta = c->d_eta; a.f_out = c->d_f; a.r_out = c->d_r;
-  a.x_in = (warm && !squaring) ? c->d_r : nullptr;
-  a.stats = c->d_ostats; a.iters = c->d_iters; a.status = c->d_status; a.B = T; a.a_shared = 0;
-  a.max_rounds = squaring && max_rounds > 60 ? 60 : max_rounds; a.tol = tol;
-  const unsigned char* mask = nullptr;
-  if (c->active_n > 0) {
-    if (c->active_n < T) return fail(QMPS_ERR_STATE, "qmps_overlap_set_active: %lld entries for %lld trajectories", (long long)c->active_n, (long long)T);
-    mask = c->d_active;
-    c->active_n = 0;
-  }
-  a.active = mask;
-  // HIP events around the WHOLE gradient evaluation (right solve, left solve, neighbour tensors, G, probes): qmps_kernel_time
-  c->dominant = c->D == 16 ? "overlap_mfma_d16_kernel + adjoint + neighbour probes" : "overlap solve + adjoint + neighbour probes";
-  c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
-  const int tslot = (int)(c->samples % qmps_ctx::kRing);
-  if (c->timed) HIP_TRY(hipEventRecord(c->kev0[tslot], c->stream));
-  // the 2 P central-difference neighbours of every iterate (evaluated below to second order in h from (y, r)): their tensors
-  // need the parameters only, so they are built on a second stream BESIDE the eigen-solves (at small T a gradient batch is the
-  // latency of its slowest solve; the neighbour tensors were a fifth of it in front of the probes)
-  if (!c->aux_stream) {
-    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
-  }
-  // (beyond ~1 000 iterates the solves fill the chip by themselves: T = 2 048 measured 5 % slower with the second stream)
-  const bool beside = T <= 1024;
-  if (beside) {
-    HIP_TRY(hipEventRecord(c->aux_fork, c->stream));
-    HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
-    HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->aux_stream));
-    HIP_TRY(hipEventRecord(c->aux_join, c->aux_stream));
-  }
-  // the left fixed points: power method on the adjoint map; results behind the iterates' (eta, rounds, status at [T, 2T))
-  qmps::OverlapArgs l = a;
-  l.adjoint = 1; l.eta = (char*)c->d_eta + (size_t)T * 16; l.f_out = nullptr; l.r_out = c->d_y; l.x_in = warm ? c->d_y : nullptr;
-  l.iters = c->d_iters + T; l.status = c->d_status + T; l.max_rounds = max_rounds;
-  if (c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr && documented_switch("QMPS_D16_ONE_WAVE") == nullptr) {
-    // both solves in ONE launch: the iteration chains are latency-bound, so the left solve rides along (more than 2 048
-    // iterates: the workgroups draw them from two queues)
-    a.no_deflation = l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
-    if (int e = arm_queue(c, a, 0)) return e;
-    if (int e = arm_queue(c, l, 1)) return e;
-    HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream));
-  } else {
-    a.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
-    HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : documented_switch("QMPS_D16_BLOCK") == nullptr, c->stream));
-    // (D = 4: the squaring kernel again - the left fixed point is the largest row of the squared map, whatever the spectral gap)
-    if (c->D == 4 && squaring) l.max_rounds = a.max_rounds;
-    l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
-    HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 4 ? squaring : (c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr), c->stream));
-  }
-  if (beside) HIP_TRY(hipStreamWaitEvent(c->stream, c->aux_join, 0));
-  else HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->stream));
-  qmps::OverlapGradArgs g;
-  memset(&g, 0, sizeof(g));
-  g.A = c->d_ref; g.WW = c->d_ww; g.r = c->d_r; g.y = c->d_y; g.G = c->d_scratch; g.yr = (char*)c->d_scratch + (size_t)T * 4 * nD * 16;
-  g.Bt = (char*)c->d_A + (size_t)T * tensor_bytes(c); g.f_out = c->d_f + T; g.T = T; g.G2P = 2 * P; g.active = mask;
-  if (flags & QMPS_OVERLAP_TWO_SIDED_F) { g.Bc = c->d_A; g.fc_out = c->d_f; }       // (overwrites the right solve's own estimate)
-  HIP_TRY(qmps::launch_overlap_grad(c->D, g, c->stream));
-  if (c->timed) { HIP_TRY(hipEventRecord(c->kev1[tslot], c->stream)); c->samples++; }
-  c->launches++;
-  // f of the iterates and of their neighbours are contiguous in d_f: one copy; statuses of both solves: one copy (pinned staging)
-  const size_t fbytes = (size_t)T * (1 + 2 * P) * sizeof(double), sbytes = (size_t)2 * T * sizeof(int32_t);
-  double* fall = (double*)(c->h_pin + (8u << 20));
-  int32_t* st = (int32_t*)(c->h_pin + (8u << 20) + fbytes);
-  HIP_TRY(qmps::launch_stage_copy(c->d_f, fall, (int64_t)(fbytes / 8), c->stream));
-  HIP_TRY(qmps::launch_stage_copy(c->d_status, st, (int64_t)(sbytes / 8), c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  memcpy(f_out, fall, (size_t)T * sizeof(double));
-  const double* fn = fall + T;
-  for (int64_t t = 0; t < T; ++t) {
-    for (int k = 0; k < P; ++k) g_out[t * P + k] = (fn[(size_t)t * 2 * P + k] - fn[(size_t)t * 2 * P + P + k]) / (2.0 * h);
-    if (status_out) status_out[t] = st[t] > st[T + t] ? st[t] : st[T + t];
-  }
-  c->window = 0;
-  c->have_env = false; c->have_guess = false; c->have_overlap_x = false; c->acc_pending = false; c->partials_B = -1;
-  c->grad_warm_T = T;
-  return QMPS_OK;
-}
-
-int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
-                     double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
-                     double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out) {
-  if (int rc = bind(c)) return rc;
-  if (!params || !WW || !f_hist || !alphas) return fail(QMPS_ERR_ARG, "null argument");
-  if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
-  const int P = n_params, NA = n_alphas;
-  if (NA < 1 || NA > 64) return fail(QMPS_ERR_ARG, "n_alphas outside [1, 64]");
-  const int64_t G = NA - 1;
-  if (T < 1 || T * (1 + 2 * (int64_t)P) > c->max_batch || T * G > c->max_batch)
-    return fail(QMPS_ERR_ARG, "T max(2 n_params + 1, n_alphas - 1) = %lld evaluations exceed max_batch = %lld",
-                (long long)(T * ((1 + 2 * (int64_t)P) > G ? (1 + 2 * (int64_t)P) : G)), (long long)c->max_batch);
-  if (n_steps < 1 || maxiter < 0 || !(gtol > 0.0) || !(h > 0.0)) return fail(QMPS_ERR_ARG, "bad n_steps / maxiter / gtol / h");
-  if (int rc = check_ansatz(c, kind, P)) return rc;
-  const bool carry = (flags & QMPS_BFGS_CARRY_HESSIAN) != 0;
-  bool warm = (flags & QMPS_BFGS_WARM) != 0;
-  const bool two_sided = c->D >= 4;       // D = 2: the 2 P + 1 central-difference candidates are eigen-solved themselves (a lane each)
-  if (warm && two_sided && c->grad_warm_T != T) return fail(QMPS_ERR_STATE, "QMPS_BFGS_WARM: the resident fixed points belong to %lld trajectories, not %lld", (long long)c->grad_warm_T, (long long)T);
-  const bool squaring = overlap_squares(c);
-  const int ladder_rounds = squaring ? (max_rounds > 60 ? 60 : max_rounds) : max_rounds;
-  const int grad_rounds = max_rounds > 100000 ? max_rounds : 100000;       // (as _GroupedObjective.value_and_grad)
-  // objective by the two-sided quotient (error ~ residual^2): the gradient batches' solves stop at 1e-8 (see qmps_hip.h)
-  const double grad_tol = (flags & QMPS_BFGS_TIGHT_GRADIENT) ? tol : (tol > 1e-8 ? tol : 1e-8);
-  const size_t TP = (size_t)T * P;
-  const double nan = __builtin_nan("");
-  std::vector<double> X(params, params + TP), Hinv(TP * P), f(T), g(TP), d(TP), slope(T), fs(T), gs(TP), fn(T), gn(TP), Xc(TP), Xn(TP), s(TP), Fc((size_t)T * NA),
-      cand, Fl, Hy(P);
-  std::vector<int32_t> st(T), stl;
-  std::vector<unsigned char> active(T), moved(T), need(T);
-  const int saved_period = c->timing_period;
-  if (counters_out) c->timing_period = 1;
-  double n_grad = 0.0, n_ladder = 0.0, nfev = 0.0, grad_ms = 0.0;
-  auto set_identity = [&](int64_t t) {
-    double* Ht = &Hinv[(size_t)t * P * P];
-    for (int a = 0; a < P; ++a)
-      for (int b = 0; b < P; ++b) Ht[a * P + b] = a == b ? 1.0 : 0.0;
-  };
-  if (carry && warm && hinv) memcpy(Hinv.data(), hinv, TP * P * sizeof(double));
-  else for (int64_t t = 0; t < T; ++t) set_identity(t);
-  // objective + gradient of a batch of iterates; trajectories with a failed solve come back as NaN (tools.py / new_time_evolve.py)
-  std::vector<double> fdc, fdf;
-  std::vector<int32_t> fds;
-  auto value_and_grad = [&](const double* Z, double* fo, double* go, const unsigned char* mask) -> int {
-    if (!two_sided) {
-      // tools.batched_fd_gradient: candidate t (2 P + 1) + 0 = the iterate, + 1 + k = +h e_k, + 1 + P + k = -h e_k
-      const int64_t G1 = 2 * (int64_t)P + 1;
-      fdc.resize((size_t)T * G1 * P);
-      fdf.resize((size_t)T * G1);
-      fds.resize((size_t)T * G1);
-      for (int64_t t = 0; t < T; ++t)
-        for (int64_t r = 0; r < G1; ++r)
-          for (int k = 0; k < P; ++k)
-            fdc[((size_t)t * G1 + r) * P + k] = Z[(size_t)t * P + k] + (r >= 1 && (r - 1) % P == k ? (r <= P ? h : -h) : 0.0);
-      if (int e = qmps_overlap_set_group(c, G1)) return e;
-      if (mask) { if (int e = qmps_overlap_set_active(c, T, mask)) return e; }
-      int e = qmps_overlap_eval_ansatz(c, T * G1, kind, P, fdc.data(), ladder_rounds, tol, 0, fdf.data(), fds.data());
-      (void)qmps_overlap_set_group(c, 0);
-      if (e) return e;
-      for (int64_t t = 0; t < T; ++t) {
-        const double* F = &fdf[(size_t)t * G1];
-        const int32_t* S = &fds[(size_t)t * G1];
-        fo[t] = S[0] == qmps::QMPS_ST_OK ? F[0] : nan;
-        for (int k = 0; k < P; ++k)
-          go[(size_t)t * P + k] = (S[1 + k] == qmps::QMPS_ST_OK && S[1 + P + k] == qmps::QMPS_ST_OK) ? (F[1 + k] - F[1 + P + k]) / (2.0 * h) : nan;
-      }
-      n_grad += 1.0;
-      nfev += (double)T * (2 * P + 1);
-      if (counters_out) {
-        float ms = 0.f;
-        if (qmps_kernel_time(c, 1, &ms, nullptr, 0) == QMPS_OK) grad_ms += ms;
-      }
-      return QMPS_OK;
-    }
-    if (mask) { if (int e = qmps_overlap_set_active(c, T, mask)) return e; }
-    if (int e = qmps_overlap_gradient(c, T, kind, P, Z, h, grad_rounds, grad_tol, (warm ? QMPS_OVERLAP_WARM : 0) | QMPS_OVERLAP_TWO_SIDED_F, fo, go, st.data())) return e;
-    warm = true;
-    for (int64_t t = 0; t < T; ++t)
-      if (st[t] != qmps::QMPS_ST_OK) {
-        fo[t] = nan;
-        for (int k = 0; k < P; ++k) go[(size_t)t * P + k] = nan;
-      }
-    n_grad += 1.0;
-    nfev += (double)T * (2 * P + 1);
-    if (counters_out) {
-      float ms = 0.f;
-      if (qmps_kernel_time(c, 1, &ms, nullptr, 0) == QMPS_OK) grad_ms += ms;
-    }
-    return QMPS_OK;
-  };
-  auto gmax_at_least = [&](const double* gt, double bound) {       // np.abs(g).max() >= bound, NaN-propagating: false with any NaN
-    double m = 0.0;
-    for (int k = 0; k < P; ++k) {
-      if (gt[k] != gt[k]) return false;
-      const double a = fabs(gt[k]);
-      m = a > m ? a : m;
-    }
-    return m >= bound;
-  };
-  int rc = QMPS_OK;
-  for (int step = 0; step < n_steps && rc == QMPS_OK; ++step) {
-    // the step's references: A_t = tensor(current parameters)
-    if ((rc = qmps_overlap_set_refs_ansatz(c, T, kind, P, X.data(), WW))) break;
-    if (!(carry && (step > 0 || (warm && hinv))))
-      for (int64_t t = 0; t < T; ++t) set_identity(t);
-    if ((rc = value_and_grad(X.data(), f.data(), g.data(), nullptr))) break;
-    bool any_active = false;
-    for (int64_t t = 0; t < T; ++t) { active[t] = gmax_at_least(&g[(size_t)t * P], gtol) ? 1 : 0; any_active |= active[t] != 0; }
-    int nit = 0;
-    while (nit < maxiter && any_active) {
-      for (int64_t t = 0; t < T; ++t) {
-        const double* Ht = &Hinv[(size_t)t * P * P];
-        const double* gt = &g[(size_t)t * P];
-        double* dt = &d[(size_t)t * P];
-        double sl = 0.0;
-        for (int a = 0; a < P; ++a) {
-          double acc = 0.0;
-          for (int b = 0; b < P; ++b) acc += Ht[a * P + b] * gt[b];
-          dt[a] = -acc;
-        }
-        for (int a = 0; a < P; ++a) sl += gt[a] * dt[a];
-        if (!(sl < 0.0)) {                                  // not a descent direction: restart from steepest descent
-          set_identity(t);
-          sl = 0.0;
-          for (int a = 0; a < P; ++a) { dt[a] = -gt[a]; sl -= gt[a] * gt[a]; }
-        }
-        slope[t] = sl;
-        if (!active[t]) for (int a = 0; a < P; ++a) dt[a] = 0.0;
-      }
-      // the full step with its gradient, straight away
-      for (size_t q = 0; q < TP; ++q) Xc[q] = X[q] + alphas[0] * d[q];
-      if ((rc = value_and_grad(Xc.data(), fs.data(), gs.data(), active.data()))) break;
-      bool all_accept = true;
-      for (int64_t t = 0; t < T; ++t) {
-        if (!active[t]) {                                   // (rows of skipped trajectories: their last values)
-          fs[t] = f[t];
-          memcpy(&gs[(size_t)t * P], &g[(size_t)t * P], P * sizeof(double));
-        }
-        double* Ft = &Fc[(size_t)t * NA];
-        for (int r = 0; r < NA; ++r) Ft[r] = INFINITY;
-        Ft[0] = std::isfinite(fs[t]) ? fs[t] : INFINITY;
-        // need: the trajectories that rejected the full step - the ladder and the gradient at the accepted point are for them only
-        need[t] = (active[t] && !(Ft[0] <= f[t] + c1 * alphas[0] * slope[t])) ? 1 : 0;
-        if (need[t]) all_accept = false;
-      }
-      bool have_new = all_accept;
-      if (all_accept) {
-        fn = fs;
-        gn = gs;
-      } else if (G > 0) {
-        cand.resize((size_t)T * G * P);
-        Fl.resize((size_t)T * G);
-        stl.resize((size_t)T * G);
-        for (int64_t t = 0; t < T; ++t)
-          for (int64_t r = 0; r < G; ++r)
-            for (int k = 0; k < P; ++k) cand[((size_t)t * G + r) * P + k] = X[(size_t)t * P + k] + alphas[r + 1] * d[(size_t)t * P + k];
-        if ((rc = qmps_overlap_set_group(c, G))) break;
-        if ((rc = qmps_overlap_set_active(c, T, need.data()))) break;
-        rc = qmps_overlap_eval_ansatz(c, T * G, kind, P, cand.data(), ladder_rounds, tol, 0, Fl.data(), stl.data());
-        (void)qmps_overlap_set_group(c, 0);
-        if (rc) break;
-        n_ladder += 1.0;
-        nfev += (double)T * G;
-        for (int64_t t = 0; t < T; ++t)
-          for (int64_t r = 0; r < G; ++r) {
-            const double v = (need[t] && stl[(size_t)t * G + r] == qmps::QMPS_ST_OK) ? Fl[(size_t)t * G + r] : nan;
-            Fc[(size_t)t * NA + r + 1] = std::isfinite(v) ? v : INFINITY;
-          }
-      }
-      for (int64_t t = 0; t < T; ++t) {
-        const double* Ft = &Fc[(size_t)t * NA];
-        int first = -1, best = 0;
-        for (int r = 0; r < NA; ++r) {
-          if (first < 0 && Ft[r] <= f[t] + c1 * alphas[r] * slope[t]) first = r;
-          if (Ft[r] < Ft[best]) best = r;
-        }
-        if (first < 0) first = best;
-        moved[t] = (active[t] && Ft[first] < f[t]) ? 1 : 0;
-        const double a = moved[t] ? alphas[first] : 0.0;
-        for (int k = 0; k < P; ++k) {
-          s[(size_t)t * P + k] = a * d[(size_t)t * P + k];
-          Xn[(size_t)t * P + k] = X[(size_t)t * P + k] + s[(size_t)t * P + k];
-        }
-      }
-      if (!have_new) {
-        if ((rc = value_and_grad(Xn.data(), fn.data(), gn.data(), need.data()))) break;
-        for (int64_t t = 0; t < T; ++t)
-          if (!need[t]) {                                   // accepted the full step: its values are the speculative batch's
-            fn[t] = fs[t];
-            memcpy(&gn[(size_t)t * P], &gs[(size_t)t * P], P * sizeof(double));
-          }
-      }
-      any_active = false;
-      for (int64_t t = 0; t < T; ++t) {
-        double* gt = &g[(size_t)t * P];
-        const double* gnt = &gn[(size_t)t * P];
-        const double* sv = &s[(size_t)t * P];
-        if (moved[t]) {
-          double sy = 0.0, ss = 0.0, yy = 0.0;
-          for (int k = 0; k < P; ++k) { const double y = gnt[k] - gt[k]; sy += sv[k] * y; ss += sv[k] * sv[k]; yy += y * y; }
-          if (sy > 1e-12 * sqrt(ss * yy) && sy > 0.0) {
-            // H' = H - rho (s (Hy)^T + (Hy) s^T) + rho (1 + rho y^T H y) s s^T
-            double* Ht = &Hinv[(size_t)t * P * P];
-            const double rho = 1.0 / sy;
-            double yHy = 0.0;
-            for (int a = 0; a < P; ++a) {
-              double acc = 0.0;
-              for (int b = 0; b < P; ++b) acc += Ht[a * P + b] * (gnt[b] - gt[b]);
-              Hy[a] = acc;
-            }
-            for (int a = 0; a < P; ++a) yHy += (gnt[a] - gt[a]) * Hy[a];
-            const double coef = rho * (1.0 + rho * yHy);
-            for (int a = 0; a < P; ++a)
-              for (int b = 0; b < P; ++b) Ht[a * P + b] = Ht[a * P + b] - (rho * sv[a] * Hy[b] + rho * sv[b] * Hy[a]) + coef * sv[a] * sv[b];
-          }
-          f[t] = fn[t];
-          memcpy(gt, gnt, P * sizeof(double));
-        }
-        active[t] = (active[t] && moved[t] && gmax_at_least(gt, gtol)) ? 1 : 0;
-        any_active |= active[t] != 0;
-      }
-      X = Xn;
-      ++nit;
-    }
-    if (rc) break;
-    memcpy(f_hist + (size_t)step * T, f.data(), (size_t)T * sizeof(double));
-    if (params_hist) memcpy(params_hist + (size_t)step * TP, X.data(), TP * sizeof(double));
-    if (nit_out) nit_out[step] = nit;
-  }
-  c->timing_period = saved_period;
-  if (rc) return rc;
-  memcpy(params, X.data(), TP * sizeof(double));
-  if (hinv) memcpy(hinv, Hinv.data(), TP * P * sizeof(double));
-  if (counters_out) { counters_out[0] = n_grad; counters_out[1] = n_ladder; counters_out[2] = nfev; counters_out[3] = grad_ms; }
-  return QMPS_OK;
-}
-
-int qmps_evolve_rotosolve(qmps_ctx* c, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps,
-                          int n_sweeps, int nsh, int max_rounds, double tol, double* params_hist, double* f_hist) {
-  if (int rc = bind(c)) return rc;
-  if (!params || !WW || !f_hist) return fail(QMPS_ERR_ARG, "null argument");
-  if (nsh != 3 && nsh != 6) return fail(QMPS_ERR_ARG, "nsh must be 3 (single-frequency) or 6 (double-frequency)");
-  if (T < 1 || nsh * T > c->max_batch) return fail(QMPS_ERR_ARG, "%d T = %lld candidates exceed max_batch = %lld", nsh, (long long)(nsh * T), (long long)c->max_batch);
-  if (n_steps < 1 || n_sweeps < 1) return fail(QMPS_ERR_ARG, "n_steps and n_sweeps must be >= 1");
-  if (int rc = check_ansatz(c, kind, n_params)) return rc;
-  const bool squaring = overlap_squares(c);
-  const int cap = squaring ? 60 : (1 << 24);
-  if (max_rounds < 1 || max_rounds > cap || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad max_rounds / tol (D = %d: max_rounds in [1, %d])", c->D, cap);
-  const int P = n_params;
-  const int64_t n_rec = (int64_t)n_steps * n_sweeps;
-  auto grow = [&](double*& buf, size_t& have, size_t need) -> int {
-    if (need > have) {
-      if (buf) HIP_TRY(hipFree(buf));
-      buf = nullptr;
-      have = 0;
-      HIP_TRY(hipMalloc((void**)&buf, need));
-      have = need;
-    }
-    return QMPS_OK;
-  };
-  if (int rc = grow(c->roto_base, c->roto_base_bytes, (size_t)T * P * sizeof(double))) return rc;
-  if (int rc = grow(c->roto_hist, c->roto_hist_bytes, (size_t)T * n_rec * sizeof(double))) return rc;
-  if (!c->roto_idx) HIP_TRY(hipMalloc((void**)&c->roto_idx, 4 * sizeof(int)));
-  if (int rc = ensure_refs(c, T)) return rc;
-  if (int rc = ensure_E(c, c->n_terms > 0 ? c->n_terms : 1)) return rc;
-  if (int rc = ensure_overlap_outputs(c)) return rc;
-  if (int rc = ensure_scratch(c, (size_t)n_steps * T * P * sizeof(double))) return rc;    // parameter history
-  // fixed points of the power method (D = 8, 16), one set per parameter plus one for the unshifted evaluation of a sweep:
-  // the candidates of parameter i come back to the same slot in the next sweep and in the next time step - by then the
-  // parameters have moved by one sweep's updates, so the resident fixed point is the natural warm start
-  const bool warm = !squaring;
-  const size_t slot_bytes = (size_t)nsh * T * env_bytes(c);
-  if (warm) {
-    const size_t need = (size_t)(P + 1) * slot_bytes;
-    if (need > c->xwarm_bytes) {
-      if (c->d_xwarm) HIP_TRY(hipFree(c->d_xwarm));
-      c->d_xwarm = nullptr;
-      c->xwarm_bytes = 0;
-      HIP_TRY(hipMalloc(&c->d_xwarm, need));
-      c->xwarm_bytes = need;
-    }
-    HIP_TRY(hipMemsetAsync(c->d_xwarm, 0, need, c->stream));       // all zero = cold start
-  }
-  double *d_base = c->roto_base, *d_hist = c->roto_hist, *d_phist = (double*)c->d_scratch;
-  int* d_idx = c->roto_idx;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-  int rc = [&]() -> int {
-    HIP_TRY(hipMemcpyAsync(d_base, params, (size_t)T * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    const int idx0[4] = {0, 0, 0, P};      // parameter index, arrival counter, finished sweeps, slot of the unshifted evaluation
-    HIP_TRY(hipMemcpyAsync(d_idx, idx0, sizeof(idx0), hipMemcpyHostToDevice, c->stream));
-    if (int e = set_ww(c, WW)) return e;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->window = 0;
-    c->have_env = false; c->have_guess = false; c->have_overlap_x = false; c->acc_pending = false; c->partials_B = -1;
-    c->ans_have = false; c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0;
-    auto evaluate = [&](int shifts) -> int {      // shifts = nsh: the shifted batch of parameter *d_idx;  0: the T base vectors
-      const int64_t n = shifts > 0 ? (int64_t)shifts * T : T;
-      HIP_TRY(qmps::launch_ansatz_shifted(c->D, kind, d_base, P, c->d_A, n, shifts, d_idx, c->stream));
-      qmps::OverlapArgs a;
-      memset(&a, 0, sizeof(a));
-      a.A = c->d_ref; a.Bt = c->d_A; a.WW = c->d_ww; a.eta = c->d_eta; a.f_out = c->d_E;
-      a.iters = c->d_iters; a.status = c->d_status; a.B = n; a.group = shifts > 0 ? shifts : 1;
-      a.max_rounds = max_rounds; a.tol = tol; a.stats = c->d_ostats;
-      if (warm) {
-        a.x_in = c->d_xwarm; a.r_out = c->d_xwarm;
-        a.slot_ptr = shifts > 0 ? d_idx : d_idx + 3; a.slot_stride = (int64_t)slot_bytes;
-      }
-      return launch_overlap_kernels(c, a);
-    };
-    auto one_sweep = [&]() -> int {
-      for (int i = 0; i < P; ++i) {
-        if (int e = evaluate(nsh)) return e;
-        HIP_TRY(qmps::launch_roto_update(d_base, c->d_E, c->d_status, (int)T, P, d_idx, 1, nsh, c->stream));
-      }
-      // the sweep's record: the objective of the updated vectors against this time step's reference states
-      if (int e = evaluate(0)) return e;
-      HIP_TRY(qmps::launch_roto_record(c->d_E, d_hist, (int)T, 1, d_idx + 2, 1, c->stream));
-      return QMPS_OK;
-    };
-    const bool use_graph = documented_switch("QMPS_NO_GRAPH") == nullptr && P <= 256;
-    if (use_graph) {
-      c->capturing = true;
-      HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-      const int e = one_sweep();
-      const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
-      c->capturing = false;
-      if (e) return e;
-      HIP_TRY(ce);
-      HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    }
-    for (int step = 0; step < n_steps; ++step) {
-      // the states the step starts from are the reference: A_t = tensor(params_t)  (new_time_evolve.py:281-283)
-      HIP_TRY(qmps::launch_ansatz(c->D, kind, d_base, P, c->d_ref, T, c->stream));
-      for (int sw = 0; sw < n_sweeps; ++sw) {
-        if (use_graph) HIP_TRY(hipGraphLaunch(exec, c->stream));
-        else if (int e = one_sweep()) return e;
-      }
-      HIP_TRY(hipMemcpyAsync(d_phist + (size_t)step * T * P, d_base, (size_t)T * P * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    }
-    HIP_TRY(hipMemcpyAsync(params, d_base, (size_t)T * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(f_hist, d_hist, (size_t)T * n_rec * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (params_hist) HIP_TRY(hipMemcpyAsync(params_hist, d_phist, (size_t)n_steps * T * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return QMPS_OK;
-  }();
-  c->capturing = false;
-  (void)hipStreamSynchronize(c->stream);
-  if (exec) (void)hipGraphExecDestroy(exec);
-  if (graph) (void)hipGraphDestroy(graph);
-  // what the call leaves resident: the T final candidates (tensors, eta, objective, status) against the last step's references
-  c->n_states = rc == QMPS_OK ? T : 0;
-  c->tensors_valid = true;
-  c->overlap_refs = rc == QMPS_OK ? T : 0;
-  c->overlap_group = 0;
-  return rc;
-}
-
-int qmps_overlap_batch(qmps_ctx* c, int64_t B, const double* A, int a_shared, const double* states, int kind,
-                       int n_params, const double* WW, int max_rounds, double tol, double* eta_out, double* r_out,
-                       int32_t* rounds_out, int32_t* status_out) {
-  if (int rc = bind(c)) return rc;
-  if (int rc = check_B(c, B)) return rc;
-  if (!A || !WW || !eta_out || (!states && B > 0)) return fail(QMPS_ERR_ARG, "null argument");
-  // candidates -> d_A: tensors, unitaries or ansatz parameters
-  if (kind == QMPS_INPUT_TENSOR || kind == QMPS_INPUT_UNITARY) {
-    if (int rc = qmps_set_states(c, B, states, kind)) return rc;
-  } else if (kind >= QMPS_INPUT_ANSATZ_BASE && kind <= QMPS_INPUT_ANSATZ_BASE + 6) {
-    if (int rc = qmps_set_states_ansatz(c, B, kind - QMPS_INPUT_ANSATZ_BASE, n_params, states)) return rc;
-  } else {
-    return fail(QMPS_ERR_ARG, "unknown input kind %d", kind);
-  }
-  if (B == 0) return QMPS_OK;
-  if (int rc = qmps_overlap_set(c, a_shared ? 1 : B, A, WW)) return rc;
-  if (int rc = qmps_overlap_launch(c, B, max_rounds, tol, r_out != nullptr ? QMPS_OVERLAP_WANT_R : 0)) return rc;
-  return qmps_overlap_get(c, B, eta_out, r_out, rounds_out, status_out);
-}
-
-// ---- brick-wall (new_tdvp) contractions -------------------------------------------------------
-namespace {
 // bump allocator over the scratch arena: copies a host array in, returns the device address
 struct Arena {
   qmps_ctx* c;
@@ -2278,7 +1369,8 @@ int qmps_allreduce_min(qmps_ctx* c, double* inout, int n) {
   return QMPS_OK;
 }
 
-namespace {
+}  // extern "C"
+namespace qmps_host {
 // close the current group: ONE ncclAllReduce of its `fill` x 16 doubles on the communication stream, ordered after the
 // device-side sums by an event, so the exchange overlaps the next steps' kernels instead of stalling the compute stream
 int close_group(qmps_ctx* c) {
@@ -2324,7 +1416,8 @@ int close_group(qmps_ctx* c) {
   c->slot_waited = false;
   return QMPS_OK;
 }
-}  // namespace
+}  // namespace qmps_host
+extern "C" {
 
 int qmps_exchange_stats(qmps_ctx* c, int64_t* checks, int64_t* blocked, double* blocked_ms, int reset) {
   if (!c) return fail(QMPS_ERR_ARG, "null context");

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
   }
   // The Hamiltonian terms are fetched NOW, into registers, and parked in LDS just before the energy stage: fetched where they
   // are used they cost an HBM / L2 round trip (~1 us of a 16 us evaluation at D = 8) at the very end of the kernel.
-  constexpr int kHMax = 16 * 16, HR = (kHMax + N - 1) / N;      // kMaxTerms (qmps_capi.hip) x 16 entries
+  constexpr int kHMax = 16 * 16, HR = (kHMax + N - 1) / N;      // kMaxTerms (qmps_ctx.h) x 16 entries
   __shared__ double2 sH[kHMax];
   double2 hreg[HR];
 #pragma unroll

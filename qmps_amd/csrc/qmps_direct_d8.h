@@ -125,65 +125,9 @@ __device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9]
       const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
       return __hiloint2double(hi, lo);
     };
-#ifdef QMPS_D8_BLOCKED_PANEL
-    // Blocks of four pivots (k = 4 K .. 4 K + 3: column class K of the four row groups).  The PANEL - the lane's rows' entries in
-    // those four columns and the 4 x 4 pivot block - is fetched once per block (ds_bpermute / v_readlane: ~150 cycles of latency,
-    // paid 16 instead of 64 times) and eliminated in registers, which gives the multipliers of all four steps; the bulk update
-    // then applies the four steps class by class, in order, in place (step q reads pivot row k + q as steps < q left it): the
-    // same fused multiply-adds in the same order as the step-by-step elimination, bit for bit.  Software pipeline: a block
-    // first updates the column class that holds the next panel, then fetches it, and only then the rest of its updates,
-    // which cover that latency (one wave per SIMD at small batches: nothing else would).
-    double Cm[4][4], Pb[4][4];
-    auto fetch_panel = [&](auto KK) {
-      constexpr int K = decltype(KK)::value, kq = K >> 2, kc0 = (4 * K) & 15;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) Cm[m][q] = __shfl(Mn[m][K], 16 * q + c, 64);        // M[c + 16 m][4 K + q]
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int q2 = 0; q2 < 4; ++q2) Pb[q][q2] = from_lane(Mn[kq][K], 16 * q2 + kc0 + q);   // M[4 K + q][4 K + q2]
-    };
-    fetch_panel(std::integral_constant<int, 0>{});
-    static_for<16>([&](auto KK) {
-      constexpr int K = decltype(KK)::value, kq = K >> 2, kc0 = (4 * K) & 15;
-      double nf[4][4];
-      static_for<4>([&](auto QQ) {
-        constexpr int q1 = decltype(QQ)::value;
-        const double pinv = fast_rcp(Pb[q1][q1]);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const bool piv = m == kq && c == kc0 + q1;
-          dinv[m] = piv ? pinv : dinv[m];
-          nf[q1][m] = piv ? 0.0 : -Cm[m][q1] * pinv;
-        }
-#pragma unroll
-        for (int q2 = q1 + 1; q2 < 4; ++q2) {
-#pragma unroll
-          for (int m = 0; m < 4; ++m) Cm[m][q2] = dfma(Pb[q1][q2], nf[q1][m], Cm[m][q2]);
-#pragma unroll
-          for (int q = q1 + 1; q < 4; ++q) Pb[q][q2] = dfma(Pb[q1][q2], -Pb[q][q1] * pinv, Pb[q][q2]);
-        }
-      });
-      // bulk: column classes t > K (class K was the panel: never read again)
-      if constexpr (K < 15) {
-        static_for<4>([&](auto QQ) { d8_update<kc0 + decltype(QQ)::value, kq, K + 1>(Mn, nf[decltype(QQ)::value]); });
-        __builtin_amdgcn_sched_barrier(0);
-        fetch_panel(std::integral_constant<int, K + 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      static_for<16>([&](auto T) {
-        constexpr int t = decltype(T)::value;
-        if constexpr (t >= K + 2)
-          static_for<4>([&](auto QQ) { d8_update<kc0 + decltype(QQ)::value, kq, t>(Mn, nf[decltype(QQ)::value]); });
-      });
-      if constexpr (K == 15) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) yv[m] = nf[3][m];
-      }
-    });
-#else
+    // (a 4-pivot blocked variant - panel fetched once per block, the four steps' multipliers from in-register panel elimination;
+    // bit-identical - was built and measured slower: 1 920 instead of 2 176 multiply-adds but ~1 500 panel instructions;
+    // profiles/EXPERIMENTS.md, git history)
     // Software pipeline: step k first updates the column class that holds column k + 1, then fetches step k + 1's pivot
     // and multipliers (v_readlane + v_rcp_f64, ds_bpermute: ~150 cycles of latency) and only then the rest of its own
     // updates, which cover that latency (one wave per SIMD at small batches: nothing else would).
@@ -243,7 +187,6 @@ __device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9]
         for (int m = 0; m < 4; ++m) yv[m] = nf[m];
       }
     });
-#endif
     tick(3);
     // coordinate a = c + 16 m: the four row groups hold the same values; row group 0 hands them out through LDS
     __builtin_amdgcn_wave_barrier();

@@ -340,6 +340,9 @@ def test_native_bfgs_driver_argument_checks_and_single_rung(engine_factory):
     # a continued call starts where the previous one stopped
     cont = eng.evolve_bfgs(_lib.ANSATZ_SHALLOW_CNOT, full['x'], WW, n_steps=1, maxiter=40, tol=1e-13, warm=True)
     assert cont['fun'].shape == (1, 4) and cont['fun'][0].mean() < -0.999
+    # QMPS_BFGS_TIGHT_GRADIENT: the gradient batches' eigen-solves iterate to tol instead of 1e-8 - the same minima
+    tight = eng.evolve_bfgs(_lib.ANSATZ_SHALLOW_CNOT, X0, WW, n_steps=2, maxiter=40, tol=1e-13, tight_gradient=True)
+    assert np.abs(tight['fun'] - full['fun']).max() < 1e-9
 
 
 def test_reference_signature_single_trajectory(engine_factory):

@@ -388,7 +388,8 @@ int qmps_overlap_gradient(qmps_ctx* ctx, int64_t T, int kind, int n_params, cons
  *   and QMPS_BFGS_WARM are both set (a continued evolution), else ignored; out - the final ones.
  * Outputs per time step: params_hist (nullable) [n_steps][T][n_params], f_hist [n_steps][T] final objectives -sqrt|eta|,
  * nit_out (nullable) [n_steps] lock-step iterations, counters_out (nullable) [4] = gradient batches, ladder batches, objective
- * evaluations in scipy's count (2 n_params + 1 per gradient), summed HIP-event milliseconds of the gradient batches.
+ * evaluations in scipy's count (2 n_params + 1 per gradient), summed HIP-event milliseconds of the gradient batches (with
+ * counters_out NULL no events are recorded: they cost the stream ~12 us per batch).
  * tol: the accuracy of eta / of the objective.  The gradient batches use QMPS_OVERLAP_TWO_SIDED_F with their two eigen-solves
  * stopped at residual max(tol, 1e-8) (objective error ~ residual^2, gradient error ~ residual: 2e-8 against gtol); the ladder
  * batches, one-sided, iterate to tol.  QMPS_BFGS_TIGHT_GRADIENT: the gradient solves iterate to tol as well.

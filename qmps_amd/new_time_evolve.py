@@ -231,13 +231,13 @@ class LockstepEvolver:
         self.fl = _GroupedObjective(D, self.kind, T, rungs, mr, tol, device=device)
         self.fg.tight_gradient = self.tight_gradient
 
-    def steps(self, X, WW, n_steps):
+    def steps(self, X, WW, n_steps, counters=True):
         """n_steps time steps in one C call (native driver): dict(x, params_hist, fun (n_steps, T), nit (n_steps,), ...)."""
         if not self.native:
             raise RuntimeError('LockstepEvolver.steps needs the native driver (speculative=True, two-sided gradient)')
         res = self.fg.eng.evolve_bfgs(self.kind, X, WW, n_steps=n_steps, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas,
                                       carry_hessian=self.carry_hessian, hess_inv=self._hinv if (self.carry_hessian and self._continued) else None,
-                                      warm=self._continued, max_rounds=self.mr, tol=self.tol, tight_gradient=self.tight_gradient)
+                                      warm=self._continued, max_rounds=self.mr, tol=self.tol, tight_gradient=self.tight_gradient, counters=counters)
         self._continued = True
         self._hinv = res['hess_inv']
         if self.fg.kernel_ms is not None and res['gradient_batches']:

@@ -456,7 +456,7 @@ int qmps_timer_end(qmps_ctx* ctx, float* milliseconds); /* waits for the end eve
  * for the stream.  This is what bench.py's roofline.achieved is computed from. */
 int qmps_kernel_time(qmps_ctx* ctx, int n_last, float* avg_ms, char* name, int name_len);
 /* The two events cost ~3 us each on the stream (they fence the command processor): time only every period-th
- * qmps_energy_launch (default 1 = every launch, 0 = never).  qmps_kernel_time then averages the timed launches
+ * qmps_energy_launch / overlap launch (0 = never, the default since ABI 4; 1 = every launch).  qmps_kernel_time then averages the timed launches
  * among the last n_last ones.  Measured at D = 4, B = 65536: 0.118 ms per step with period 1, 0.111 ms untimed. */
 int qmps_set_kernel_timing_period(qmps_ctx* ctx, int period);
 

@@ -98,7 +98,8 @@ struct qmps_ctx {
   int handoff = 0;                  // plain power steps before the squaring tail (set in qmps_create)
   int default_solver = 1;           // solver of the one-shot entry points (QMPS_ENV_POWER_SQUARING)
   int skip_rounds = 0;              // untracked squarings when handoff == 0 (set in qmps_create)
-  int timing_period = 1;            // HIP events around the dominant kernel on every timing_period-th launch (0 = never)
+  int timing_period = 0;            // HIP events around the dominant kernel on every timing_period-th launch (0 = never, the default:
+                                    // a pair of event records costs the stream several us; qmps_set_kernel_timing_period)
   int64_t samples = 0;              // launches timed so far (ring index)
   bool timed = false;               // this launch is one of them
   bool no_pair = false;             // QMPS_NO_PAIR: D = 4 energy-only launches with one lane per evaluation (tuning knob)

@@ -78,6 +78,7 @@ class _GroupedObjective:
         self.warm = False
         self.grad_warm = False
         self.kernel_ms = None          # a list: receives the HIP-event duration of every launch's overlap kernel (bench.py)
+        self._timing = False
 
     def set_reference(self, ref_params, WW):
         self.eng.overlap_set_refs_params(self.kind, ref_params, WW)
@@ -85,6 +86,7 @@ class _GroupedObjective:
     def __call__(self, cand):
         """cand (T G, P), trajectory-major; G = the group size given to the constructor (or any of them, if several were given)."""
         cand = np.ascontiguousarray(cand, dtype=np.float64)
+        self._want_timing()
         G = cand.shape[0] // self.T
         assert cand.shape[0] == self.T * G and G in np.atleast_1d(self.G)
         self.eng.overlap_set_group(G)
@@ -101,6 +103,7 @@ class _GroupedObjective:
         """(f (T,), g (T, P)) of the iterates X from one right + one left eigen-solve each (qmps_overlap_gradient), warm-started
         from the previous call's fixed points."""
         # (tight_gradient False: objective by the two-sided quotient, the two solves stop at 1e-8 - what qmps_evolve_bfgs does)
+        self._want_timing()
         tight = getattr(self, 'tight_gradient', True)
         f, g, st = self.eng.overlap_gradient(self.kind, X, h=h, max_rounds=max(self.max_rounds, 100000), tol=self.tol if tight else max(self.tol, 1e-8),
                                              warm=self.grad_warm, two_sided_f=not tight)
@@ -109,6 +112,11 @@ class _GroupedObjective:
             self.kernel_ms.append(self.eng.kernel_time(1)[0])
         bad = st != L.STATUS_OK
         return np.where(bad, np.nan, f), np.where(bad[:, None], np.nan, g)
+
+    def _want_timing(self):
+        if self.kernel_ms is not None and not self._timing:      # (event records are off by default: they cost the stream several us per launch)
+            self.eng.set_kernel_timing_period(1)
+            self._timing = True
 
     def close(self):
         self.eng.close()

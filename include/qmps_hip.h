@@ -386,7 +386,8 @@ int qmps_overlap_gradient(qmps_ctx* ctx, int64_t T, int kind, int n_params, cons
  *   fixed points a previous qmps_evolve_bfgs / qmps_overlap_gradient call left resident (same T).
  * hinv (nullable) [T][n_params][n_params]: in - the initial inverse Hessians of the first time step when QMPS_BFGS_CARRY_HESSIAN
  *   and QMPS_BFGS_WARM are both set (a continued evolution), else ignored; out - the final ones.
- * Outputs per time step: params_hist (nullable) [n_steps][T][n_params], f_hist [n_steps][T] final objectives -sqrt|eta|,
+ * Outputs per time step: params_hist (nullable) [n_steps][T][n_params], f_hist [n_steps][2][T] objectives -sqrt|eta| at
+ * the start (the previous parameters against the new references) and at the end of the time step,
  * nit_out (nullable) [n_steps] lock-step iterations, counters_out (nullable) [4] = gradient batches, ladder batches, objective
  * evaluations in scipy's count (2 n_params + 1 per gradient), summed HIP-event milliseconds of the gradient batches (with
  * counters_out NULL no events are recorded: they cost the stream ~12 us per batch).

@@ -466,6 +466,7 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
     if (!(carry && (step > 0 || (warm && hinv))))
       for (int64_t t = 0; t < T; ++t) set_identity(t);
     if ((rc = value_and_grad(X.data(), f.data(), g.data(), nullptr))) break;
+    memcpy(f_hist + (size_t)step * 2 * T, f.data(), (size_t)T * sizeof(double));          // objective at the start of the time step
     bool any_active = false;
     for (int64_t t = 0; t < T; ++t) { active[t] = gmax_at_least(&g[(size_t)t * P], gtol) ? 1 : 0; any_active |= active[t] != 0; }
     int nit = 0;
@@ -585,7 +586,7 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
       ++nit;
     }
     if (rc) break;
-    memcpy(f_hist + (size_t)step * T, f.data(), (size_t)T * sizeof(double));
+    memcpy(f_hist + ((size_t)step * 2 + 1) * T, f.data(), (size_t)T * sizeof(double));     // ... and at its end
     if (params_hist) memcpy(params_hist + (size_t)step * TP, X.data(), TP * sizeof(double));
     if (nit_out) nit_out[step] = nit;
   }

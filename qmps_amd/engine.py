@@ -474,7 +474,7 @@ class EnergyEngine:
                     alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), carry_hessian=False, hess_inv=None, warm=False,
                     max_rounds=None, tol=1e-12, tight_gradient=False, counters=True):
         """Time evolution by lock-step BFGS, every time step of every trajectory in ONE C call (qmps_evolve_bfgs): params (T, P) ->
-        dict(x (T, P), params_hist (n_steps, T, P), fun (n_steps, T), nit (n_steps,), hess_inv (T, P, P), gradient_batches,
+        dict(x (T, P), params_hist (n_steps, T, P), fun (n_steps, T) [and fun_start: at the start of each time step], nit (n_steps,), hess_inv (T, P, P), gradient_batches,
         ladder_batches, nfev, gradient_ms).  warm=True continues a previous call on this engine (resident fixed points; with
         carry_hessian also `hess_inv`).  tight_gradient: the eigen-solves of the gradient batches iterate to tol instead of
         max(tol, 1e-8) (their objective comes from the two-sided quotient either way).  counters=False: no batch counts and no
@@ -486,7 +486,7 @@ class EnergyEngine:
             max_rounds = 60 if self.D in (2, 4) else 100000
         T, npar = P.shape
         ph = np.empty((int(n_steps), T, npar))
-        fh = np.empty((int(n_steps), T))
+        fh = np.empty((int(n_steps), 2, T))
         nit = np.zeros(int(n_steps), dtype=np.int32)
         cnt = np.zeros(4)
         if warm and carry_hessian and hess_inv is None:
@@ -499,7 +499,7 @@ class EnergyEngine:
                                            float(gtol), float(h), float(c1), len(al), _f64(al), flags, int(max_rounds), float(tol),
                                            _f64(Hinv), _f64(ph), _f64(fh), _i32(nit), _f64(cnt) if counters else None))
         self.B = T
-        return {'x': P, 'params_hist': ph, 'fun': fh, 'nit': nit, 'hess_inv': Hinv, 'gradient_batches': int(cnt[0]),
+        return {'x': P, 'params_hist': ph, 'fun': fh[:, 1], 'fun_start': fh[:, 0], 'nit': nit, 'hess_inv': Hinv, 'gradient_batches': int(cnt[0]),
                 'ladder_batches': int(cnt[1]), 'nfev': int(cnt[2]), 'gradient_ms': float(cnt[3])}
 
     def overlap_results(self, B=None, want_r=False):

@@ -131,8 +131,11 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
     (default: ShallowFullStateTensor at D = 2, ShallowCNOTStateTensor otherwise).
       method 'Rotosolve' / 'DoubleRotosolve': the WHOLE evolution - every step, sweep, parameter, trajectory - is one C
           call (`qmps_evolve_rotosolve`, n_sweeps sweeps per step), no host round trip;
-      method 'BFGS': lock-step batched BFGS (`tools.batched_bfgs`): per iteration two device batches over all
-          trajectories - central-difference gradient columns, backtracking ladder - warm-started from resident fixed points;
+      method 'BFGS': lock-step batched BFGS - by default the whole evolution in ONE C call (`qmps_evolve_bfgs`: objective and
+          gradient at the full quasi-Newton step first, the backtracking ladder only for trajectories that reject it; the same
+          decisions as a plain ladder); options {'native': False} runs the same loop from numpy (`tools.batched_bfgs`, per-iteration
+          objective history), {'speculative': False} the plain two-batch iteration (gradient columns, then the ladder);
+          'carry_hessian', 'tight_gradient', 'gradient', 'first_rungs', 'maxiter', 'gtol', 'eps', 'alphas' as in LockstepEvolver;
       anything else: scipy.optimize.minimize on the scalar `obj` per trajectory (the reference's own call).
     Returns the parameter history (n_steps + 1, [T,] P) [and an info dict with the objective history]."""
     cls = state_tensor or _default_class(D)
@@ -161,7 +164,7 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
         mr = max_rounds if max_rounds is not None else (60 if D in (2, 4) else 100000)
         ev = LockstepEvolver(D, T, P, cls, mr, tol, opts.get('maxiter', 200), opts.get('gtol', 1e-5), opts.get('eps', 1e-6), ladder,
                              gradient=opts.get('gradient', 'auto'), first_rungs=opts.get('first_rungs'),
-                             carry_hessian=opts.get('carry_hessian', False), speculative=opts.get('speculative', False), native=opts.get('native', True),
+                             carry_hessian=opts.get('carry_hessian', False), speculative=opts.get('speculative', True), native=opts.get('native', True),
                              tight_gradient=opts.get('tight_gradient', False))
         fg, fl = ev.fg, ev.fl
         try:
@@ -255,7 +258,8 @@ class LockstepEvolver:
     def step(self, X, WW):
         if self.native:
             res = self.steps(X, WW, 1)
-            return {'x': res['x'], 'fun': res['fun'][0], 'nit': int(res['nit'][0]), 'nfev': res['nfev'], 'history': res['fun'][:1],
+            # history: the objective at the start and at the end of the time step (the numpy loop records every iteration)
+            return {'x': res['x'], 'fun': res['fun'][0], 'nit': int(res['nit'][0]), 'nfev': res['nfev'], 'history': np.stack([res['fun_start'][0], res['fun'][0]]),
                     'hess_inv': res['hess_inv'], 'converged': None}
         from .tools import batched_bfgs
         self.fg.set_reference(X, WW)

@@ -324,6 +324,10 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
     if (int e = arm_queue(c, a, 0)) return e;
     if (int e = arm_queue(c, l, 1)) return e;
     HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream));
+  } else if (c->D == 8) {
+    // D = 8: the same - one launch, the left solves on the SIMDs the right ones leave idle
+    a.no_deflation = l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
+    HIP_TRY(qmps::launch_overlap_pair_d8(a, l, c->stream));
   } else {
     a.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
     HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : documented_switch("QMPS_D16_BLOCK") == nullptr, c->stream));

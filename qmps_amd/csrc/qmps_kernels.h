@@ -231,6 +231,7 @@ hipError_t launch_overlap(const OverlapArgs& a, hipStream_t st);   // D = 2 (lan
 hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st);
 // D = 16, at most 8192 evaluations in all: right fixed points (`right`) and left fixed points (`left`, adjoint map) in ONE launch, four waves per evaluation
 hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st);
+hipError_t launch_overlap_pair_d8(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st);
 // brick-wall (new_tdvp) contractions: what = 0 two-site <O>, 1 four-site <O>, 2 environment matrix + eigenpair, 3 manifold overlap
 struct BwArgs {
   const void *U1, *U2, *U1p, *U2p;   // [B][4][4] complex

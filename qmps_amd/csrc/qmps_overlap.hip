@@ -53,14 +53,15 @@ __device__ __forceinline__ void cfma_conj(double2 a, double2 b, double2& c) {   
 // ------------------------------------------------------------------------------------------
 // ADJ: power method on the adjoint map y -> sum_s C_s^+ y Bm_s (its dominant eigenvalue is conj(eta), its fixed point the LEFT
 // eigenvector of T for the Frobenius pairing: <y, T x> = <T^+ y, x>); eta_out receives eta itself
-template <int D, bool ADJ = false>
-__global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_block_kernel(OverlapArgs p) {
+// (the body as a device function: the workgroups of one launch may run different instantiations - overlap_block_pair_kernel)
+template <int D, bool ADJ>
+__device__ __forceinline__ void overlap_block_body(const OverlapArgs& p, int64_t block) {
   constexpr int N = D * D, P = D + 1;
   constexpr int THREADS = N < 64 ? 64 : N, ITEMS = THREADS / N, WAVES = THREADS / 64;
   __shared__ double2 sC[ITEMS][4][D][P], sB[ITEMS][4][D][P], sX[ITEMS][D][P], sY[ITEMS][4][D][P];
   __shared__ double red[4][WAVES > 1 ? WAVES : 1];
   const int tid = threadIdx.x, e = tid / N, l = tid % N, i = l / D, j = l % D;
-  const int64_t b = (int64_t)blockIdx.x * ITEMS + e;
+  const int64_t b = block * ITEMS + e;
   if (ITEMS == 1 && b < p.B && overlap_skipped(p, b)) return;      // (one evaluation per workgroup: a uniform exit)
   const bool valid = b < p.B;
   const int64_t bb = valid ? b : p.B - 1;       // surplus lanes of the last workgroup shadow a real evaluation
@@ -236,6 +237,19 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_block_kerne
   if (!valid) return;
   if (l == 0) overlap_store(p, b, eta.x, ADJ ? -eta.y : eta.y, iters, status);
   if (p.r_out != nullptr) ((double2*)((char*)p.r_out + slot_off))[b * N + l] = x;
+}
+
+template <int D, bool ADJ = false>
+__global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_block_kernel(OverlapArgs p) {
+  overlap_block_body<D, ADJ>(p, blockIdx.x);
+}
+
+// RIGHT and LEFT fixed points in one launch (qmps_overlap_gradient at D = 8): workgroups [0, n_right) run the map of `pr`, the
+// others the adjoint map of `pl` - the iteration chains are latency-bound, the left solve rides along on idle SIMDs
+template <int D>
+__global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_block_pair_kernel(OverlapArgs pr, OverlapArgs pl, int n_right) {
+  if ((int)blockIdx.x < n_right) overlap_block_body<D, false>(pr, blockIdx.x);
+  else overlap_block_body<D, true>(pl, (int64_t)blockIdx.x - n_right);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -967,6 +981,12 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16x4_pair_kernel(OverlapArg
   __shared__ double2 sX_all[8][16 * 16];
   if ((int)blockIdx.x < n_right) overlap_mfma_d16x4_body<false, DEFL>(pr, blockIdx.x, n_right, sT_all, sX_all);
   else overlap_mfma_d16x4_body<true, DEFL>(pl, blockIdx.x - n_right, gridDim.x - n_right, sT_all, sX_all);
+}
+
+hipError_t launch_overlap_pair_d8(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st) {
+  if (right.B <= 0) return hipSuccess;
+  hipLaunchKernelGGL((overlap_block_pair_kernel<8>), dim3((unsigned)(right.B + left.B)), dim3(64), 0, st, right, left, (int)right.B);
+  return hipGetLastError();
 }
 
 hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st) {

@@ -8,7 +8,7 @@ run evolve_d16_t2048 --workload evolve --D 16 --batch 2048 --steps 8 --warmup 3 
 run evolve_d16_t256_numpy --workload evolve --D 16 --batch 256 --steps 10 --warmup 3 --python-driver --no-cpu-baseline
 run evolve_d16_t4096 --workload evolve --D 16 --batch 4096 --steps 6 --warmup 2 --no-cpu-baseline
 run evolve_d8_t256 --workload evolve --D 8 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline
-run evolve_d8_t2048 --workload evolve --D 8 --batch 2048 --steps 6 --warmup 2 --no-cpu-baseline
+run evolve_d8_t1024 --workload evolve --D 8 --batch 1024 --steps 6 --warmup 2 --no-cpu-baseline
 run evolve_d4_t256 --workload evolve --D 4 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline
 run evolve_d2_t256 --workload evolve --D 2 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline
 run overlap_d8_b768 --workload overlap --D 8 --batch 768 --steps 20 --warmup 3 --no-cpu-baseline

@@ -22,11 +22,13 @@ __device__ __forceinline__ void d8_update(double (&Mn)[4][16], const double (&nf
   }
 }
 
-// One wave, lane = 8 i + i'.  sA: the evaluation's tensor A_s[i][j] (padded rows of 9), sT / sM: scratch.  Returns r[i][i'] of
-// the lane (trace 1); a non-finite or ill-conditioned solve returns the default start 1/8 (the caller's power iteration decides).
-__device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9], double (*sT)[9], double (*sM)[17], int lane,
-                                                        long long* prof = nullptr) {     // prof: phase clocks, scratch builds only
+// The elimination itself, on a matrix that is already in the cyclic layout (lane (g, c) = (lane >> 4, lane & 15): rows c + 16 m,
+// columns g + 4 t).  Returns r[i][i'] of the lane, lane = 8 i + i' (trace 1; see env_direct_d8_solve).
+// (A four-wave variant - all waves build the matrix, one eliminates - was costed and not built: splitting a row's 28 column pairs
+// over four lanes needs lane-dependent operand selection, the build would drop from 1.6 to ~0.9 us only.)
+__device__ __forceinline__ double2 env_direct_d8_eliminate(double (&Mn)[4][16], double (*sT)[9], int lane, long long* prof = nullptr) {
   constexpr int D = 8, N = 64;
+  const int i = lane >> 3, ip = lane & 7;
   auto tick = [&](int k) {
     if (prof) {
       __builtin_amdgcn_sched_barrier(0);
@@ -34,86 +36,6 @@ __device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9]
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  tick(0);
-  const int i = lane >> 3, ip = lane & 7;
-  double M[N];
-  {
-    // row (i, i') of the real transfer matrix: P(j,j') = sum_s (gamma A_s[i][j]) conj(A_s[i'][j']), gamma = 1 (i <= i') | i (i > i')
-    const bool rot = i > ip;
-    double tr[2][D], ti[2][D], br[2][D], bi[2][D];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        const double2 a = sA[s][i][j], c = sA[s][ip][j];
-        tr[s][j] = rot ? -a.y : a.x;
-        ti[s][j] = rot ? a.x : a.y;
-        br[s][j] = c.x;
-        bi[s][j] = c.y;
-      }
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      double v = tr[0][j] * br[0][j];
-      v = dfma(ti[0][j], bi[0][j], v);
-      v = dfma(tr[1][j], br[1][j], v);
-      v = dfma(ti[1][j], bi[1][j], v);
-      M[9 * j] = v;
-    }
-#pragma unroll
-    for (int lo = 0; lo < D; ++lo)
-#pragma unroll
-      for (int hi = lo + 1; hi < D; ++hi) {
-        double re = tr[0][lo] * br[0][hi], im = tr[0][lo] * bi[0][hi];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if (s > 0) {
-            re = dfma(tr[s][lo], br[s][hi], re);
-            im = dfma(tr[s][lo], bi[s][hi], im);
-          }
-          re = dfma(ti[s][lo], bi[s][hi], re);
-          re = dfma(tr[s][hi], br[s][lo], re);
-          re = dfma(ti[s][hi], bi[s][lo], re);
-          im = dfma(-ti[s][lo], br[s][hi], im);
-          im = dfma(ti[s][hi], br[s][lo], im);
-          im = dfma(-tr[s][hi], bi[s][lo], im);
-        }
-        M[8 * lo + hi] = re;
-        M[8 * hi + lo] = im;
-      }
-    // + trace functional on the last row; the identity (column = the lane's own index: a register index that depends on the
-    // lane - 64 compare / select / subtract triples here) is subtracted in LDS during the layout change below
-    const double w63 = lane == N - 1 ? 1.0 : 0.0;
-#pragma unroll
-    for (int j = 0; j < D; ++j) M[9 * j] += w63;
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  tick(1);
-  // ---- elimination in a 2-D cyclic layout: lane (g, c) = (lane >> 4, lane & 15) holds rows c + 16 m (m < 4) x columns
-  // g + 4 t (t < 16).  Step k: the pivot row's entries of the lane's column class sit in lane k % 16 OF THE SAME
-  // 16-LANE DPP ROW, so the update is ONE instruction per entry - v_fmac_f64_dpp row_newbcast (gfx90a+ 64-bit DPP, full
-  // FMA rate measured: tools/scratch/dpp64_probe.hip) - with no separate broadcast (the row-per-lane layout spends two
-  // v_readlane_b32 per FMA).  The multipliers (column k of the lane's four rows) come from the same c in row group
-  // k % 4 (ds_bpermute), and are the same in all four row groups.  ~3 800 instead of ~7 200 instructions per evaluation.
-  double Mn[4][16];
-  {
-    // row-per-lane -> cyclic layout through LDS, a quarter of the columns at a time (8.5 KB)
-    const int g = lane >> 4, c = lane & 15;
-#pragma unroll
-    // (one pass through a 33 KB image instead of four: no faster - the 128 LDS instructions take ~1.1 us whatever the row
-    // padding, 1 or 2 doubles: the reads are 2- to 4-way bank conflicts in either; paddings of 4 and 8: 1.9 and 3.7 us)
-    for (int qt = 0; qt < 4; ++qt) {
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) sM[lane][jj] = M[16 * qt + jj];
-      __builtin_amdgcn_wave_barrier();
-      if ((lane >> 4) == qt) sM[lane][lane & 15] -= 1.0;      // - identity: the lane's own diagonal entry sits in this quarter
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) Mn[m][4 * qt + tt] = sM[c + 16 * m][g + 4 * tt];
-    }
-  }
   __builtin_amdgcn_sched_barrier(0);
   tick(2);
   double x;
@@ -222,6 +144,101 @@ __device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9]
   }
   tick(4);
   return make_double2(re, im);
+}
+
+// One wave, lane = 8 i + i'.  sA: the evaluation's tensor A_s[i][j] (padded rows of 9), sT / sM: scratch.  Returns r[i][i'] of
+// the lane (trace 1); a non-finite or ill-conditioned solve returns the default start 1/8 (the caller's power iteration decides).
+__device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9], double (*sT)[9], double (*sM)[17], int lane,
+                                                        long long* prof = nullptr) {     // prof: phase clocks, scratch builds only
+  constexpr int D = 8, N = 64;
+  auto tick = [&](int k) {
+    if (prof) {
+      __builtin_amdgcn_sched_barrier(0);
+      prof[k] = wall_clock64();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  tick(0);
+  const int i = lane >> 3, ip = lane & 7;
+  double M[N];
+  {
+    // row (i, i') of the real transfer matrix: P(j,j') = sum_s (gamma A_s[i][j]) conj(A_s[i'][j']), gamma = 1 (i <= i') | i (i > i')
+    const bool rot = i > ip;
+    double tr[2][D], ti[2][D], br[2][D], bi[2][D];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const double2 a = sA[s][i][j], c = sA[s][ip][j];
+        tr[s][j] = rot ? -a.y : a.x;
+        ti[s][j] = rot ? a.x : a.y;
+        br[s][j] = c.x;
+        bi[s][j] = c.y;
+      }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      double v = tr[0][j] * br[0][j];
+      v = dfma(ti[0][j], bi[0][j], v);
+      v = dfma(tr[1][j], br[1][j], v);
+      v = dfma(ti[1][j], bi[1][j], v);
+      M[9 * j] = v;
+    }
+#pragma unroll
+    for (int lo = 0; lo < D; ++lo)
+#pragma unroll
+      for (int hi = lo + 1; hi < D; ++hi) {
+        double re = tr[0][lo] * br[0][hi], im = tr[0][lo] * bi[0][hi];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s > 0) {
+            re = dfma(tr[s][lo], br[s][hi], re);
+            im = dfma(tr[s][lo], bi[s][hi], im);
+          }
+          re = dfma(ti[s][lo], bi[s][hi], re);
+          re = dfma(tr[s][hi], br[s][lo], re);
+          re = dfma(ti[s][hi], bi[s][lo], re);
+          im = dfma(-ti[s][lo], br[s][hi], im);
+          im = dfma(ti[s][hi], br[s][lo], im);
+          im = dfma(-tr[s][hi], bi[s][lo], im);
+        }
+        M[8 * lo + hi] = re;
+        M[8 * hi + lo] = im;
+      }
+    // + trace functional on the last row; the identity (column = the lane's own index: a register index that depends on the
+    // lane - 64 compare / select / subtract triples here) is subtracted in LDS during the layout change below
+    const double w63 = lane == N - 1 ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) M[9 * j] += w63;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  tick(1);
+  // ---- elimination in a 2-D cyclic layout: lane (g, c) = (lane >> 4, lane & 15) holds rows c + 16 m (m < 4) x columns
+  // g + 4 t (t < 16).  Step k: the pivot row's entries of the lane's column class sit in lane k % 16 OF THE SAME
+  // 16-LANE DPP ROW, so the update is ONE instruction per entry - v_fmac_f64_dpp row_newbcast (gfx90a+ 64-bit DPP, full
+  // FMA rate measured: tools/scratch/dpp64_probe.hip) - with no separate broadcast (the row-per-lane layout spends two
+  // v_readlane_b32 per FMA).  The multipliers (column k of the lane's four rows) come from the same c in row group
+  // k % 4 (ds_bpermute), and are the same in all four row groups.  ~3 800 instead of ~7 200 instructions per evaluation.
+  double Mn[4][16];
+  {
+    // row-per-lane -> cyclic layout through LDS, a quarter of the columns at a time (8.5 KB)
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    // (one pass through a 33 KB image instead of four: no faster - the 128 LDS instructions take ~1.1 us whatever the row
+    // padding, 1 or 2 doubles: the reads are 2- to 4-way bank conflicts in either; paddings of 4 and 8: 1.9 and 3.7 us)
+    for (int qt = 0; qt < 4; ++qt) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) sM[lane][jj] = M[16 * qt + jj];
+      __builtin_amdgcn_wave_barrier();
+      if ((lane >> 4) == qt) sM[lane][lane & 15] -= 1.0;      // - identity: the lane's own diagonal entry sits in this quarter
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) Mn[m][4 * qt + tt] = sM[c + 16 * m][g + 4 * tt];
+    }
+  }
+  return env_direct_d8_eliminate(Mn, sT, lane, prof);
 }
 
 }  // namespace qmps

@@ -519,7 +519,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
   // in the first 160-sweep call after an 8-sweep one: 27.7 instead of 19.5 us per parameter update at D = 8).
   auto download_results = [&](size_t hist_doubles) -> int {
     const size_t pb = (size_t)R * n_params * sizeof(double), hb = hist_doubles * sizeof(double);
-    if (pb + hb <= (8u << 20)) {
+    if (pb + hb <= (2u << 20)) {      // (small results only: a 7 MB history copied twice cost the D = 4 run of 21 845 restarts 16 %)
       if (int e = ensure_pinned(c, (16u << 20))) return e;
       HIP_TRY(hipMemcpyAsync(c->h_pin, c->roto_base, pb, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipMemcpyAsync(c->h_pin + pb, c->roto_hist, hb, hipMemcpyDeviceToHost, c->stream));

@@ -328,6 +328,10 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
     // D = 8: the same - one launch, the left solves on the SIMDs the right ones leave idle
     a.no_deflation = l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
     HIP_TRY(qmps::launch_overlap_pair_d8(a, l, c->stream));
+  } else if (c->D == 4 && squaring) {
+    // D = 4: largest column AND largest row of the squared map in one launch (right and left fixed point, whatever the gap)
+    a.l_out = c->d_y;
+    HIP_TRY(qmps::launch_overlap_d(c->D, a, true, c->stream));
   } else {
     a.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
     HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : documented_switch("QMPS_D16_BLOCK") == nullptr, c->stream));

@@ -184,6 +184,8 @@ struct OverlapArgs {
   int* queue;                  // nullable (D = 16, four waves per evaluation): counter the workgroups draw their evaluations from (zeroed by the host)
   int adjoint;                 // 1 (D = 8, 16): the LEFT fixed point - power method on the adjoint map y -> sum_s C_s^+ y Bm_s
   int no_deflation;            // 1: plain power method only (QMPS_NO_DEFLATION: the A/B switch of the deflation steps at D = 8)
+  void* l_out;                 // nullable (D = 4 squaring kernel): ALSO the left fixed points [B][D][D] - the largest row of the squared map comes out
+                               // of the same squarings as the largest column; eta / rounds / status of the left solve at index B + b
                                //   (eigenvalue conj(eta); eta_out receives eta itself)
 };
 // two-sided first-order evaluation of central-difference neighbours (qmps_overlap_gradient; qmps_overlap_grad.hip)

@@ -615,8 +615,10 @@ __global__ __launch_bounds__(256) void overlap_square_d4_kernel(OverlapArgs p) {
       status = QMPS_ST_NOT_CONVERGED;
     }
     if (lane == 0) overlap_store(p, b, eta_r, eta_i, rounds, status);
-    if (p.r_out != nullptr && p.adjoint) {
+    if (p.l_out != nullptr && lane == 0) overlap_store(p, b + p.B, eta_r, eta_i, rounds, status);      // (the left solve's record)
+    if ((p.r_out != nullptr && p.adjoint) || p.l_out != nullptr) {
       // LEFT fixed point (T^+ y = conj(eta) y): M -> u v^+, so every row of M is a multiple of v^+; y = conj of the largest row
+      void* lo = p.l_out != nullptr ? p.l_out : p.r_out;
       double rn[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) rn[q] = row16_sum(dfma(mr[q], mr[q], mi[q] * mi[q]));      // |row 4 q + g|^2, in the 16 lanes of row group g
@@ -644,9 +646,11 @@ __global__ __launch_bounds__(256) void overlap_square_d4_kernel(OverlapArgs p) {
       const double inv = bn > 0.0 ? 1.0 / __builtin_sqrt(bn) : 0.0;
       if (lane < 16) {
         const double2 u = sT[16 + lane];
-        ((double2*)((char*)p.r_out + overlap_slot_offset(p)))[b * 16 + lane] = make_double2(u.x * inv, u.y * inv);
+        ((double2*)((char*)lo + overlap_slot_offset(p)))[b * 16 + lane] = make_double2(u.x * inv, u.y * inv);
       }
-    } else if (p.r_out != nullptr) {
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (p.r_out != nullptr && !p.adjoint) {
       // right fixed point = the largest column of M, unit Frobenius norm
       double cn = 0.0;
 #pragma unroll

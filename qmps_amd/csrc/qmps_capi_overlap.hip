@@ -238,8 +238,8 @@ int qmps_overlap_eval_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, con
   const size_t fb = (size_t)B * sizeof(double), sb = (size_t)B * sizeof(int32_t);
   if (fb + sb <= (8u << 20) && c->h_pin_bytes >= (16u << 20)) {
     char* out = c->h_pin + (8u << 20);
-    HIP_TRY(qmps::launch_stage_copy(c->d_f, out, B, c->stream));
-    if (status_out) HIP_TRY(qmps::launch_stage_copy(c->d_status, out + fb, (B + 1) / 2, c->stream));     // (d_status has max_batch >= B + 1 entries or the tail is never read)
+    // (d_status has max_batch >= B + 1 entries or the tail is never read)
+    HIP_TRY(qmps::launch_stage_copy2(c->d_f, out, B, c->d_status, out + fb, status_out ? (B + 1) / 2 : 0, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(f_out, out, fb);
     if (status_out) memcpy(status_out, out + fb, sb);
@@ -354,8 +354,7 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   const size_t fbytes = (size_t)T * (1 + 2 * P) * sizeof(double), sbytes = (size_t)2 * T * sizeof(int32_t);
   double* fall = (double*)(c->h_pin + (8u << 20));
   int32_t* st = (int32_t*)(c->h_pin + (8u << 20) + fbytes);
-  HIP_TRY(qmps::launch_stage_copy(c->d_f, fall, (int64_t)(fbytes / 8), c->stream));
-  HIP_TRY(qmps::launch_stage_copy(c->d_status, st, (int64_t)(sbytes / 8), c->stream));
+  HIP_TRY(qmps::launch_stage_copy2(c->d_f, fall, (int64_t)(fbytes / 8), c->d_status, st, (int64_t)(sbytes / 8), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   memcpy(f_out, fall, (size_t)T * sizeof(double));
   const double* fn = fall + T;

@@ -264,5 +264,6 @@ hipError_t launch_probe_mfma_f64(double* out, int blocks, int iters, hipStream_t
 hipError_t launch_probe_copy(const void* src, void* dst, int64_t n16, hipStream_t st);
 // copy of n8 x 8 bytes by a kernel on the given stream (pinned host memory <-> HBM without a copy-queue hop)
 hipError_t launch_stage_copy(const void* src, void* dst, int64_t n8, hipStream_t st);
+hipError_t launch_stage_copy2(const void* src1, void* dst1, int64_t n1, const void* src2, void* dst2, int64_t n2, hipStream_t st);
 
 }  // namespace qmps

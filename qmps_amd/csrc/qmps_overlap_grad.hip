@@ -147,13 +147,15 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_probe_kerne
   __shared__ double2 sB[ITEMS][2][D][P];
   __shared__ double red[16];
   const int tid = threadIdx.x, e = tid / N, l = tid % N, i = l / D, j = l % D;
-  const int64_t nb = p.T * p.G2P;
+  // items [0, T G2P): the neighbours; with p.Bc set, items [T G2P, T G2P + T): the iterates themselves (same launch)
+  const int64_t nn = p.T * p.G2P, nb = nn + (p.Bc != nullptr ? p.T : 0);
   const int64_t b = (int64_t)blockIdx.x * ITEMS + e;
   const int64_t bb = b < nb ? b : nb - 1;
-  const int64_t t = bb / p.G2P;
+  const bool centre = bb >= nn;
+  const int64_t t = centre ? bb - nn : bb / p.G2P;
   if (ITEMS == 1 && p.active != nullptr && p.active[t] == 0) return;
   {
-    const double2* Bp = (const double2*)p.Bt + bb * (2 * N);
+    const double2* Bp = centre ? (const double2*)p.Bc + t * (2 * N) : (const double2*)p.Bt + bb * (2 * N);
     sB[e][0][i][j] = Bp[l];
     sB[e][1][i][j] = Bp[N + l];
   }
@@ -176,7 +178,9 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_probe_kerne
     const double2 d = ((const double2*)p.yr)[t];
     const double den = d.x * d.x + d.y * d.y;
     const double er = (nr * d.x + ni * d.y) / den, ei = (ni * d.x - nr * d.y) / den;
-    p.f_out[b] = -__builtin_sqrt(__builtin_sqrt(er * er + ei * ei));
+    const double f = -__builtin_sqrt(__builtin_sqrt(er * er + ei * ei));
+    if (centre) p.fc_out[t] = f;
+    else p.f_out[b] = f;
   }
 }
 
@@ -190,11 +194,12 @@ __global__ __launch_bounds__(64) void overlap_probe_d16_kernel(OverlapGradArgs p
   constexpr int D = 16, N = 256, P = 17;
   __shared__ double2 sB[2][D][P];
   const int lane = threadIdx.x, i2 = lane >> 3, j2 = lane & 7;
-  const int64_t b = blockIdx.x;
-  const int64_t t = b / p.G2P;
+  const int64_t b = blockIdx.x, nn = p.T * p.G2P;
+  const bool centre = b >= nn;                      // (with p.Bc set the launch carries T more items: the iterates themselves)
+  const int64_t t = centre ? b - nn : b / p.G2P;
   if (p.active != nullptr && p.active[t] == 0) return;
   {
-    const double2* Bp = (const double2*)p.Bt + b * (2 * N);
+    const double2* Bp = centre ? (const double2*)p.Bc + t * (2 * N) : (const double2*)p.Bt + b * (2 * N);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int l = lane + 64 * u, s = l >> 8, e = l & 255;
@@ -232,7 +237,9 @@ __global__ __launch_bounds__(64) void overlap_probe_d16_kernel(OverlapGradArgs p
     const double2 d = ((const double2*)p.yr)[t];
     const double den = d.x * d.x + d.y * d.y;
     const double er = (nr * d.x + ni * d.y) / den, ei = (ni * d.x - nr * d.y) / den;
-    p.f_out[b] = -__builtin_sqrt(__builtin_sqrt(er * er + ei * ei));
+    const double f = -__builtin_sqrt(__builtin_sqrt(er * er + ei * ei));
+    if (centre) p.fc_out[t] = f;
+    else p.f_out[b] = f;
   }
 }
 
@@ -240,15 +247,9 @@ template <int D>
 static hipError_t launch_grad_d(const OverlapGradArgs& a, hipStream_t st) {
   constexpr int N = D * D, THREADS = N < 64 ? 64 : N, ITEMS = THREADS / N;
   hipLaunchKernelGGL((overlap_g_kernel<D>), dim3((unsigned)((a.T + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);
-  const int64_t nb = a.T * a.G2P;
+  const int64_t nb = a.T * a.G2P + (a.Bc != nullptr ? a.T : 0);      // neighbours (+ the iterates themselves: same launch)
   if constexpr (D == 16) hipLaunchKernelGGL(overlap_probe_d16_kernel, dim3((unsigned)nb), dim3(64), 0, st, a);
   else hipLaunchKernelGGL((overlap_probe_kernel<D>), dim3((unsigned)((nb + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);
-  if (a.Bc != nullptr) {          // the iterates themselves: one more probe per trajectory
-    OverlapGradArgs c = a;
-    c.Bt = a.Bc; c.f_out = a.fc_out; c.G2P = 1;
-    if constexpr (D == 16) hipLaunchKernelGGL(overlap_probe_d16_kernel, dim3((unsigned)a.T), dim3(64), 0, st, c);
-    else hipLaunchKernelGGL((overlap_probe_kernel<D>), dim3((unsigned)((a.T + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, c);
-  }
   return hipGetLastError();
 }
 

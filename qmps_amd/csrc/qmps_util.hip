@@ -137,6 +137,23 @@ hipError_t launch_stage_copy(const void* src, void* dst, int64_t n8, hipStream_t
   return hipGetLastError();
 }
 
+// two segments in one launch (the optimiser drivers read back values + statuses after every batch: a launch less per round trip)
+__global__ __launch_bounds__(256) void stage_copy2_kernel(const double* __restrict__ src1, double* __restrict__ dst1, int64_t n1,
+                                                         const double* __restrict__ src2, double* __restrict__ dst2, int64_t n2) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n1 + n2; t += stride) {
+    if (t < n1) dst1[t] = src1[t];
+    else dst2[t - n1] = src2[t - n1];
+  }
+}
+hipError_t launch_stage_copy2(const void* src1, void* dst1, int64_t n1, const void* src2, void* dst2, int64_t n2, hipStream_t st) {
+  if (n1 + n2 <= 0) return hipSuccess;
+  int64_t blocks = (n1 + n2 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(stage_copy2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const double*)src1, (double*)dst1, n1, (const double*)src2, (double*)dst2, n2);
+  return hipGetLastError();
+}
+
 hipError_t launch_probe_copy(const void* src, void* dst, int64_t n16, hipStream_t st) {
   hipLaunchKernelGGL(probe_copy_kernel, dim3(2048), dim3(256), 0, st, (const double2*)src, (double2*)dst, n16);
   return hipGetLastError();

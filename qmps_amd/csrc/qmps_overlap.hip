@@ -971,7 +971,7 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
 }
 
 template <bool ADJ, bool DEFL>
-__global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) {
+__global__ __launch_bounds__(256, 3) void overlap_mfma_d16x4_kernel(OverlapArgs p) {
   __shared__ double2 sT_all[4][16 * 17];          // wave-private transposes
   __shared__ double2 sX_all[8][16 * 16];          // exchange: two sets of one C-layout matrix per wave, element (q, lane) at [q * 64 + lane]
   overlap_mfma_d16x4_body<ADJ, DEFL>(p, blockIdx.x, gridDim.x, sT_all, sX_all);
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16x4_kernel(OverlapArgs p) 
 // RIGHT and LEFT fixed points in one launch (qmps_overlap_gradient): workgroups [0, n_right) run the map of `pr`, the others the
 // adjoint map of `pl` - twice the waves in flight for the same length of the (latency-bound) iteration chain
 template <bool DEFL>
-__global__ __launch_bounds__(256) void overlap_mfma_d16x4_pair_kernel(OverlapArgs pr, OverlapArgs pl, int n_right) {
+__global__ __launch_bounds__(256, 3) void overlap_mfma_d16x4_pair_kernel(OverlapArgs pr, OverlapArgs pl, int n_right) {
   __shared__ double2 sT_all[4][16 * 17];
   __shared__ double2 sX_all[8][16 * 16];
   if ((int)blockIdx.x < n_right) overlap_mfma_d16x4_body<false, DEFL>(pr, blockIdx.x, n_right, sT_all, sX_all);

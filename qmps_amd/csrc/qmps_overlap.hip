@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
 // asked for, is the largest column of M.  rounds = squarings used; status 1 = not rank one within max_rounds (two
 // dominant eigenvalues of equal modulus) or tr(M) = 0.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void overlap_square_d4_kernel(OverlapArgs p) {
+__global__ __launch_bounds__(256, 3) void overlap_square_d4_kernel(OverlapArgs p) {
   constexpr int LD = 17, WAVES = 4;
   __shared__ double2 sT_all[WAVES][16 * LD];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;

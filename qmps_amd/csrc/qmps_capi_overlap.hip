@@ -30,15 +30,36 @@ int ensure_overlap_outputs(qmps_ctx* c) {
     HIP_TRY(hipMalloc((void**)&c->d_ostats, (size_t)qmps::kOverlapStatShards * 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->d_ostats, 0, (size_t)qmps::kOverlapStatShards * 4 * sizeof(unsigned long long), c->stream));
   }
+  // work counters of the D = 16 queue kernels [0, 1] and of the Krylov fall-back [2, 3], and the fall-back's iterate scratch: allocated
+  // HERE, never lazily at a launch (a launch may sit inside a stream capture - qmps_evolve_rotosolve - where hipMalloc is illegal)
+  if (!c->d_queue) HIP_TRY(hipMalloc((void**)&c->d_queue, 4 * sizeof(int)));
+  if (c->D >= 8 && !c->d_kry) HIP_TRY(hipMalloc(&c->d_kry, (size_t)c->max_batch * env_bytes(c)));
   return QMPS_OK;
 }
 // D = 16 batches above 2 048 evaluations: the four-waves-per-evaluation kernel with a work queue (zeroed here, on the stream)
 int arm_queue(qmps_ctx* c, qmps::OverlapArgs& a, int which) {
   a.queue = nullptr;
   if (c->D != 16 || a.B <= 2048 || documented_switch("QMPS_D16_ONE_WAVE") != nullptr || documented_switch("QMPS_D16_BLOCK") != nullptr) return QMPS_OK;
-  if (!c->d_queue) HIP_TRY(hipMalloc((void**)&c->d_queue, 2 * sizeof(int)));
+  if (!c->d_queue) return fail(QMPS_ERR_STATE, "overlap work counters not allocated (ensure_overlap_outputs)");
   HIP_TRY(hipMemsetAsync(c->d_queue + which, 0, sizeof(int), c->stream));
   a.queue = c->d_queue + which;
+  return QMPS_OK;
+}
+// D = 8, 16: arm the Krylov fall-back of a power launch (include/qmps_hip.h "fixed-point solvers"): the power kernel hands a
+// candidate over once its residual history predicts more than kKrylovAfter further steps.  QMPS_NO_KRYLOV: plain power method.
+constexpr int kKrylovAfter = 256;
+int arm_krylov(qmps_ctx* c, qmps::OverlapArgs& a, int which) {
+  a.krylov_after = 0;
+  a.kry_counter = nullptr;
+  if (c->D < 8 || documented_switch("QMPS_NO_KRYLOV") != nullptr || documented_switch("QMPS_D16_ONE_WAVE") != nullptr || documented_switch("QMPS_D16_BLOCK") != nullptr) return QMPS_OK;
+  if (!c->d_queue || !c->d_kry) return fail(QMPS_ERR_STATE, "Krylov fall-back buffers not allocated (ensure_overlap_outputs)");
+  int after = kKrylovAfter;
+  if (const char* e = tuning_knob("QMPS_KRYLOV_AFTER")) after = atoi(e);
+  if (after <= 0) return QMPS_OK;
+  if (a.r_out == nullptr) a.r_out = (char*)c->d_kry + (size_t)c->window * env_bytes(c);     // (the iterate travels through r_out)
+  HIP_TRY(hipMemsetAsync(c->d_queue + 2 + which, 0, sizeof(int), c->stream));
+  a.krylov_after = after;
+  a.kry_counter = c->d_queue + 2 + which;
   return QMPS_OK;
 }
 
@@ -47,6 +68,7 @@ bool overlap_squares(const qmps_ctx* c) { return c->D == 2 || (c->D == 4 && !doc
 int launch_overlap_kernels(qmps_ctx* c, const qmps::OverlapArgs& a_in) {
   qmps::OverlapArgs a = a_in;
   if (int rc = arm_queue(c, a, 0)) return rc;
+  if (int rc = arm_krylov(c, a, 0)) return rc;
   const bool squaring = overlap_squares(c);
   c->dominant = c->D == 2 ? "overlap_lane_kernel" : (c->D == 4 && squaring ? "overlap_square_d4_kernel" :
                 (c->D == 16 && !documented_switch("QMPS_D16_BLOCK") ? "overlap_mfma_d16_kernel" : "overlap_block_kernel<D>"));
@@ -323,10 +345,14 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
     a.no_deflation = l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
     if (int e = arm_queue(c, a, 0)) return e;
     if (int e = arm_queue(c, l, 1)) return e;
+    if (int e = arm_krylov(c, a, 0)) return e;
+    if (int e = arm_krylov(c, l, 1)) return e;
     HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream));
   } else if (c->D == 8) {
     // D = 8: the same - one launch, the left solves on the SIMDs the right ones leave idle
     a.no_deflation = l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
+    if (int e = arm_krylov(c, a, 0)) return e;
+    if (int e = arm_krylov(c, l, 1)) return e;
     HIP_TRY(qmps::launch_overlap_pair_d8(a, l, c->stream));
   } else if (c->D == 4 && squaring) {
     // D = 4: largest column AND largest row of the squared map in one launch (right and left fixed point, whatever the gap)

@@ -187,6 +187,11 @@ struct OverlapArgs {
   void* l_out;                 // nullable (D = 4 squaring kernel): ALSO the left fixed points [B][D][D] - the largest row of the squared map comes out
                                // of the same squarings as the largest column; eta / rounds / status of the left solve at index B + b
                                //   (eigenvalue conj(eta); eta_out receives eta itself)
+  // Krylov fall-back (D = 8, 16; qmps_overlap_krylov.hip): the power kernels GIVE A CANDIDATE UP (status 1, steps used < max_rounds,
+  // iterate in r_out - which must then be non-null) as soon as its residual history predicts more than `krylov_after` further
+  // steps (or after 4 krylov_after steps in all); launch_overlap_d / _pair_* then run overlap_krylov_kernel over the batch.
+  int krylov_after;            // 0: plain power method to max_rounds (QMPS_NO_KRYLOV)
+  int* kry_counter;            // the fall-back kernel's work counter (zeroed by the host on the stream); null = no fall-back launch
 };
 // two-sided first-order evaluation of central-difference neighbours (qmps_overlap_gradient; qmps_overlap_grad.hip)
 struct OverlapGradArgs {
@@ -226,8 +231,29 @@ __device__ __forceinline__ void overlap_store(const OverlapArgs& p, int64_t b, d
     if (status != QMPS_ST_OK) atomicAdd(st + 3, 1ULL);
   }
 }
+// power method -> Krylov hand-over (see OverlapArgs::krylov_after).  Called at a convergence test of step k (k >= 16) with the
+// squared residual: every 32 steps or more the decay rate since the last look (bits per step) is extrapolated to tol2.
+// (k_ref, l_ref): the last look (k_ref = 0: none - also after anything that makes the residual jump, e.g. a deflation step).
+__device__ __forceinline__ bool power_gives_up(int k, double res2, double tol2, int limit, int& k_ref, float& l_ref) {
+  if (limit <= 0 || k < 16) return false;
+  if (k >= 4 * limit) return true;
+  if (k_ref == 0) {
+    k_ref = k;
+    l_ref = __log2f((float)res2);
+    return false;
+  }
+  if (k - k_ref < 32) return false;
+  const float l = __log2f((float)res2), rate = (l_ref - l) / (float)(k - k_ref);
+  k_ref = k;
+  l_ref = l;
+  if (!(rate > 0.0f)) return true;                          // no progress over 32 steps
+  return (l - __log2f((float)tol2)) > rate * (float)limit;
+}
 #endif
 hipError_t launch_overlap(const OverlapArgs& a, hipStream_t st);   // D = 2 (lane kernel, squaring)
+// D = 8, 16: thick-restart Arnoldi over the candidates the power kernels gave up (status 1, iters < max_rounds); a.r_out holds their
+// iterates and receives the fixed points; `counter` zeroed by the caller (qmps_overlap_krylov.hip)
+hipError_t launch_overlap_krylov(int D, const OverlapArgs& a, int* counter, hipStream_t st);
 // D = 4, 8, 16: operator-form power method (qmps_overlap.hip); tensors [2][D][D]; max_rounds = cap on power steps;
 // mfma: D = 16 on the matrix cores (one wave per evaluation) instead of the generic LDS-tile kernel
 hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st);

@@ -147,6 +147,10 @@ __device__ __forceinline__ void overlap_block_body(const OverlapArgs& p, int64_t
   double w0_prev = 0.0, n_prev = 0.0, sig_max2 = 0.0;
   int last_deflation = 0;
   bool deflate_on = p.no_deflation == 0;
+  // hand-over to the Krylov fall-back (one evaluation per workgroup only: the decision must be uniform)
+  const int give_up_after = (ITEMS == 1 && p.r_out != nullptr) ? p.krylov_after : 0;
+  int k_ref = 0;
+  float l_ref = 0.0f;
   __syncthreads();
   for (int k = 1; k <= p.max_rounds; ++k) {
     if (!__syncthreads_or(active ? 1 : 0)) break;
@@ -192,6 +196,7 @@ __device__ __forceinline__ void overlap_block_body(const OverlapArgs& p, int64_t
         deflate_on = false;
         sig_max2 = 0.0;
         w0_prev = 0.0;
+        k_ref = 0;
         rp = make_double2(0.0, 0.0);
         x = make_double2(i == j ? 1.0 / __builtin_sqrt((double)D) : 0.0, 0.0);
       } else if (w[0] < tol2) {
@@ -230,7 +235,11 @@ __device__ __forceinline__ void overlap_block_body(const OverlapArgs& p, int64_t
         if (!deflated) {
           const double inv = nn > 0.0 ? 1.0 / __builtin_sqrt(nn) : 0.0;
           x = make_double2(xn.x * inv, xn.y * inv);
+        } else {
+          k_ref = 0;
         }
+        // a long tail ahead: stop here (status 1, k < max_rounds) - overlap_krylov_kernel takes the candidate over from x
+        if (power_gives_up(k, w[0], tol2, give_up_after, k_ref, l_ref) && k < p.max_rounds) active = false;
       }
     }
   }
@@ -831,6 +840,9 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
     v4f64 rr = {0, 0, 0, 0}, ri = {0, 0, 0, 0};
     double rs_chk = 0.0, inv_chk = 0.0, res_prev = 0.0, sgr_prev = 0.0, sgi_prev = 0.0, sig_max2 = 0.0;
     int last_deflation = 0;
+    const int give_up_after = p.r_out != nullptr ? p.krylov_after : 0;       // hand-over to the Krylov fall-back (see OverlapArgs)
+    int k_ref = 0;
+    float l_ref = 0.0f;
     for (int k = 1; k <= p.max_rounds; ++k) {
       double xar[4], xai[4];
       to_a_layout(xr, xi, xar, xai);
@@ -887,6 +899,7 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
             sig_max2 = s2 > sig_max2 ? s2 : sig_max2;
             have_prev_sigma = false;
             res_prev = 0.0;
+            k_ref = 0;
             continue;
           }
         }
@@ -927,6 +940,7 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
           defl_on = false;
           sig_max2 = 0.0;
           pending = false;
+          k_ref = 0;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             xr[q] = (c == 4 * q + g) ? 0.25 : 0.0;
@@ -957,6 +971,8 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
       res_prev = res2;
       xr = nr * inv;
       xi = ni * inv;
+      // a long tail ahead: stop here (status 1, k < max_rounds) - overlap_krylov_kernel takes the candidate over from x
+      if (k < p.max_rounds && power_gives_up(k, res2, tol2, give_up_after, k_ref, l_ref)) break;
     }
     if (wave == 0) {
       if (lane == 0) overlap_store(p, b, eta_r, ADJ ? -eta_i : eta_i, iters, status);
@@ -987,10 +1003,20 @@ __global__ __launch_bounds__(256, 3) void overlap_mfma_d16x4_pair_kernel(Overlap
   else overlap_mfma_d16x4_body<true, DEFL>(pl, blockIdx.x - n_right, gridDim.x - n_right, sT_all, sX_all);
 }
 
+// the Krylov fall-back behind a power launch (both solves of a pair launch): candidates given up are finished, the others untouched
+static hipError_t launch_krylov_after(int D, const OverlapArgs& a, const OverlapArgs* second, hipStream_t st) {
+  if (a.krylov_after > 0 && a.kry_counter != nullptr)
+    if (hipError_t e = launch_overlap_krylov(D, a, a.kry_counter, st); e != hipSuccess) return e;
+  if (second != nullptr && second->krylov_after > 0 && second->kry_counter != nullptr)
+    if (hipError_t e = launch_overlap_krylov(D, *second, second->kry_counter, st); e != hipSuccess) return e;
+  return hipSuccess;
+}
+
 hipError_t launch_overlap_pair_d8(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st) {
   if (right.B <= 0) return hipSuccess;
   hipLaunchKernelGGL((overlap_block_pair_kernel<8>), dim3((unsigned)(right.B + left.B)), dim3(64), 0, st, right, left, (int)right.B);
-  return hipGetLastError();
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  return launch_krylov_after(8, right, &left, st);
 }
 
 hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st) {
@@ -999,7 +1025,8 @@ hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& 
   // (deflation steps for cold starts only, see overlap_mfma_d16x4_body)
   if (right.x_in == nullptr && right.no_deflation == 0) hipLaunchKernelGGL(overlap_mfma_d16x4_pair_kernel<true>, dim3((unsigned)(nr + nl)), dim3(256), 0, st, right, left, nr);
   else hipLaunchKernelGGL(overlap_mfma_d16x4_pair_kernel<false>, dim3((unsigned)(nr + nl)), dim3(256), 0, st, right, left, nr);
-  return hipGetLastError();
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  return launch_krylov_after(16, right, &left, st);
 }
 
 hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st) {
@@ -1048,7 +1075,9 @@ hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t 
       break;
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  if (D == 8 || (D == 16 && mfma && (a.B <= 2048 || a.queue != nullptr))) return launch_krylov_after(D, a, nullptr, st);
+  return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------------

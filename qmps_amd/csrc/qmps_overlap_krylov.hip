@@ -1,0 +1,687 @@
+// qmps_overlap_krylov.hip - Krylov fall-back of the D = 8 / 16 fixed-point eigen-solves (gfx950 only).
+//
+// Reference: the reference obtains eta, r (and the left vector) of the mixed transfer map from xmps `Map(...).right_fixed_point()` /
+// `.left_fixed_point()` (qmps/new_time_evolve.py:201-203, qmps/time_evolve_tools.py:84-91, scripts/loschmidt.py:212-215) and the
+// environment from `TransferMatrix(A).eigs()` (qmps/tools.py:176-182): scipy.sparse.linalg.eigs = ARPACK, implicitly restarted
+// Arnoldi, k = 1, which = 'LM'.  The power method of qmps_overlap.hip needs ~1/(1 - |eta_2/eta_1|) map applications - 10^4..10^5
+// on candidates far from the reference state (crowded rings of nearly equal-modulus eigenvalues); ARPACK does not care.  This
+// file is the library's Arnoldi: the power kernels hand a candidate over as soon as their residual history predicts a long
+// tail (status 1, steps used < max_rounds, iterate in r_out) and the kernel below finishes it.
+//
+// Algorithm (one workgroup of 256 threads per candidate, everything in LDS; prototype + measurements: tools/scratch/krylov_proto.py,
+// profiles/EXPERIMENTS.md "Krylov fall-back"): thick-restart Arnoldi in its Rayleigh-Ritz ("Davidson") form -
+//   basis V (16 orthonormal vectors), images W = T V, projected G = V^H T V (16 x 16, general);
+//   a cycle extends the basis from j0 to 16 vectors by the Arnoldi chain (v_{j+1} = T v_j orthogonalised twice, classical
+//   Gram-Schmidt - every inner product of a step in one pass of sixteen 16-lane groups);
+//   Rayleigh-Ritz: the five dominant SCHUR vectors of G, one after the other, each as the largest column of G SQUARED until rank
+//   one on the matrix cores (the D = 4 overlap kernel's machinery on one complex 16 x 16 tile: O(log) rounds whatever the gaps of
+//   the Ritz values), then deflated (G <- P G P, P = 1 - y y^H);
+//   convergence: TRUE residual ||W y - theta V y|| < tol of the dominant Ritz pair, a DOMINANCE CERTIFICATE against the second
+//   Schur pair (|theta_2| + 100 (res_1 + res_2) < |theta_1|: a pair of nearly equal modulus must itself have converged far enough to be ranked -
+//   where the power method would simply have taken 1/(1 - ratio) steps), and one explicit application T u with the test of the
+//   power kernels, ||T u - <u, T u> u|| < tol, ||u|| = 1;
+//   restart: V <- V Q, W <- W Q, G <- Q^H G Q with the five Schur vectors, the basis is extended by the residual of the pair that
+//   has not converged yet (first or second).
+// Measured on the prototype (Haar-random candidates, tol 1e-12, 64 power steps first): D = 8 mean 96 / max 191 map applications over
+// 3 000 candidates (power method: mean 1 936, 42 not converged after 20 000), D = 16 mean 244 / max 818 over 500; constructed pairs
+// with |eta_2/eta_1| = 1 - 1e-4 .. 1 - 1e-8: 81.  Two dominant eigenvalues of EQUAL modulus: status 1 (as documented).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qmps_kernels.h"
+#include "qmps_device.h"
+
+namespace qmps {
+
+namespace {
+
+constexpr int KM = 16;          // basis size (one 16 x 16 tile for the projected problem)
+constexpr int KK = 5;           // Schur vectors kept at a restart
+constexpr int KSQ_ROUNDS = 44;  // cap on the squarings of one Schur vector (2^44 steps of the projected map)
+constexpr double KMARGIN = 100.0;
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 cmulc(double2 a, double2 b) { return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x); }   // conj(a) b
+__device__ __forceinline__ void cfma(double2 a, double2 b, double2& c) {   // c += a b
+  c.x = dfma(a.x, b.x, c.x);
+  c.x = dfma(-a.y, b.y, c.x);
+  c.y = dfma(a.x, b.y, c.y);
+  c.y = dfma(a.y, b.x, c.y);
+}
+__device__ __forceinline__ void cfms(double2 a, double2 b, double2& c) {   // c -= a b
+  c.x = dfma(-a.x, b.x, c.x);
+  c.x = dfma(a.y, b.y, c.x);
+  c.y = dfma(-a.x, b.y, c.y);
+  c.y = dfma(-a.y, b.x, c.y);
+}
+__device__ __forceinline__ void cfma_conj(double2 a, double2 b, double2& c) {   // c += a conj(b)
+  c.x = dfma(a.x, b.x, c.x);
+  c.x = dfma(a.y, b.y, c.x);
+  c.y = dfma(a.y, b.x, c.y);
+  c.y = dfma(-a.x, b.y, c.y);
+}
+__device__ __forceinline__ void cfma_cj(double2 a, double2 b, double2& c) {   // c += conj(a) b
+  c.x = dfma(a.x, b.x, c.x);
+  c.x = dfma(a.y, b.y, c.x);
+  c.y = dfma(a.x, b.y, c.y);
+  c.y = dfma(-a.y, b.x, c.y);
+}
+
+// complex 16 x 16 x 16 products on v_mfma_f64_16x16x4 (as in qmps_overlap.hip): P in A-layout, Q in B-layout, C-layout result
+__device__ __forceinline__ void cmma16(const double (&pre)[4], const double (&pim)[4], const v4f64& qre, const v4f64& qim, v4f64& cre, v4f64& cim) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    cre = __builtin_amdgcn_mfma_f64_16x16x4f64(pre[kk], qre[kk], cre, 0, 0, 0);
+    cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pre[kk], qim[kk], cim, 0, 0, 0);
+    cre = __builtin_amdgcn_mfma_f64_16x16x4f64(-pim[kk], qim[kk], cre, 0, 0, 0);
+    cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pim[kk], qre[kk], cim, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void cmma16_3m(const double (&pre)[4], const double (&pim)[4], const v4f64& qre, const v4f64& qim, v4f64& cre, v4f64& cim) {
+  v4f64 k1 = {0, 0, 0, 0}, k2 = {0, 0, 0, 0}, k3 = {0, 0, 0, 0};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const double ps = pre[kk] + pim[kk], qd = qim[kk] - qre[kk], qs = qre[kk] + qim[kk];
+    k1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ps, qre[kk], k1, 0, 0, 0);
+    k2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pre[kk], qd, k2, 0, 0, 0);
+    k3 = __builtin_amdgcn_mfma_f64_16x16x4f64(pim[kk], qs, k3, 0, 0, 0);
+  }
+  cre += k1 - k3;
+  cim += k1 + k2;
+}
+
+// ---- LDS map (bytes), one candidate per workgroup ------------------------------------------------------------------------
+template <int D>
+struct KryLds {
+  static constexpr int N = D * D;
+  static constexpr int oV = 0;                               // basis vectors  [KM][N] complex
+  static constexpr int oW = oV + KM * N * 16;                // their images   [KM][N]
+  static constexpr int oP = oW + KM * N * 16;                // exchange of the four partial maps [4][N]; Rayleigh-Ritz scratch
+  static constexpr int szP = 4 * N * 16 > 8192 ? 4 * N * 16 : 8192;
+  static constexpr int oX = oP + szP;                        // one more vector [N]: the Ritz vector under test
+  static constexpr int oG = oX + N * 16;                     // projected map [16][16]
+  static constexpr int oQ = oG + 16 * 16 * 16;               // Schur vectors [16][8]
+  static constexpr int oH = oQ + 16 * 8 * 16;                // inner products of a pass [64]
+  static constexpr int oS = oH + 64 * 16;                    // scalars: theta[8] complex, g01, reductions
+  static constexpr int oT = oS + 512;                        // D = 8: tiles of C_s, Bm_s [2][4][8][9]
+  static constexpr int total = oT + (D == 8 ? 2 * 4 * 8 * 9 * 16 : 0);
+};
+
+// scalar slots in the oS region (doubles)
+enum { S_THETA = 0 /* 16 doubles */, S_G01 = 16 /* 2 */, S_RED = 20 /* 2 sets x 4 waves x 4 values = 32 */, S_IDX = 56 /* int */ };
+
+// ---- Rayleigh-Ritz on wave 0: the KK dominant Schur vectors of G by repeated squaring + deflation -------------------------
+// sG [16][16] row-major; out: sQ[r][i] (r < 16, i < KK), theta_i = y_i^H G y_i, g01 = y_0^H G y_1.  scratch >= 16*17*16 + 1024 bytes.
+__device__ __forceinline__ void rayleigh_ritz_wave(const double2* sG, double2* sQ, double* sS, char* scratch) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  double2* sT = (double2*)scratch;                 // [16][17] transposes
+  double2* sY = (double2*)(scratch + 16 * 17 * 16);       // [16] current vector
+  double* sCol = (double*)(scratch + 16 * 17 * 16 + 256);  // [16] column norms
+  auto to_a_layout = [&](const v4f64& re, const v4f64& im, double (&are)[4], double (&aim)[4]) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sT[(4 * q + g) * 17 + c] = make_double2(re[q], im[q]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const double2 t = sT[c * 17 + 4 * kk + g];
+      are[kk] = t.x;
+      aim[kk] = t.y;
+    }
+  };
+  // deflated G in C-layout registers: element [row 4 q + g][col c]
+  v4f64 gr, gi;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const double2 t = sG[(4 * q + g) * 16 + c];
+    gr[q] = t.x;
+    gi[q] = t.y;
+  }
+  for (int i = 0; i < KK; ++i) {
+    // ---- dominant right vector of the deflated G: square until rank one
+    double n2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) n2 = dfma(gr[q], gr[q], dfma(gi[q], gi[q], n2));
+    n2 = lane0(wave_sum(n2));
+    bool have = n2 > 1e-280;
+    if (have) {
+      const double inv0 = 1.0 / __builtin_sqrt(n2);
+      v4f64 mr = gr * inv0, mi = gi * inv0;
+      for (int m = 0; m < KSQ_ROUNDS; ++m) {
+        double ar[4], ai[4];
+        to_a_layout(mr, mi, ar, ai);
+        v4f64 qr = {0, 0, 0, 0}, qi = {0, 0, 0, 0};
+        cmma16_3m(ar, ai, mr, mi, qr, qi);
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (c == 4 * q + g) { d0 = mr[q]; d1 = mi[q]; }
+        const double trr = wave_sum(d0), tri = wave_sum(d1);
+        double res = 0.0, q2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double dr = qr[q] - (trr * mr[q] - tri * mi[q]), di = qi[q] - (trr * mi[q] + tri * mr[q]);
+          res = dfma(dr, dr, dfma(di, di, res));
+          q2 = dfma(qr[q], qr[q], dfma(qi[q], qi[q], q2));
+        }
+        res = lane0(wave_sum(res));
+        q2 = lane0(wave_sum(q2));
+        if (!(q2 > 1e-280)) break;                 // nilpotent remainder: keep the last power
+        if (res < 1e-28 * q2) break;               // rank one
+        const double inv = 1.0 / __builtin_sqrt(q2);
+        mr = qr * inv;
+        mi = qi * inv;
+      }
+      // largest column of M
+      double cn = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cn = dfma(mr[q], mr[q], dfma(mi[q], mi[q], cn));
+      cn = group4_sum(cn);
+      __builtin_amdgcn_wave_barrier();
+      if (g == 0) sCol[c] = cn;
+      __builtin_amdgcn_wave_barrier();
+      int best = 0;
+      double bn = -1.0;
+      for (int k = 0; k < 16; ++k) {
+        const double v = sCol[k];
+        if (v > bn) { bn = v; best = k; }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (c == best) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sY[4 * q + g] = make_double2(mr[q], mi[q]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      have = bn > 1e-280;
+    }
+    // ---- orthonormalise against the Schur vectors found so far (entry r = c of the vector, replicated in the four row groups)
+    double2 yc = have ? sY[c] : make_double2(0.0, 0.0);
+    for (int attempt = 0; attempt < 17; ++attempt) {
+      if (attempt > 0) yc = make_double2(c == attempt - 1 ? 1.0 : 0.0, 0.0);     // fall-back: coordinate vectors, first one with a decent component outside span(Q)
+      double nrm0 = row16_sum(dfma(yc.x, yc.x, yc.y * yc.y));
+      for (int pass = 0; pass < 2; ++pass)
+        for (int pq = 0; pq < i; ++pq) {
+          const double2 qv = sQ[c * 8 + pq];
+          const double2 t = cmulc(qv, yc);
+          const double dr = row16_sum(t.x), di = row16_sum(t.y);
+          cfms(make_double2(dr, di), qv, yc);
+        }
+      const double nrm = row16_sum(dfma(yc.x, yc.x, yc.y * yc.y));
+      if (nrm > 0.01 * nrm0 && nrm > 1e-280) {
+        const double inv = 1.0 / __builtin_sqrt(nrm);
+        yc = make_double2(yc.x * inv, yc.y * inv);
+        break;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (g == 0) {
+      sQ[c * 8 + i] = yc;
+      sY[c] = yc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- theta_i = y^H G y with the ORIGINAL G; g01 = y_0^H G y_1
+    {
+      double2 t = make_double2(0.0, 0.0);
+      for (int k = 0; k < 16; ++k) cfma(sG[c * 16 + k], sY[k], t);       // (G y)[c]
+      const double2 a = cmulc(yc, t);
+      const double thr = row16_sum(a.x), thi = row16_sum(a.y);
+      if (lane == 0) { sS[S_THETA + 2 * i] = thr; sS[S_THETA + 2 * i + 1] = thi; }
+      if (i == 1) {
+        const double2 b = cmulc(sQ[c * 8 + 0], t);
+        const double br = row16_sum(b.x), bi = row16_sum(b.y);
+        if (lane == 0) { sS[S_G01] = br; sS[S_G01 + 1] = bi; }
+      }
+    }
+    if (i + 1 == KK) break;
+    // ---- deflate: G <- P G P, P = 1 - y y^H
+    double2 yrow[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) yrow[q] = sY[4 * q + g];
+    double2 a = make_double2(0.0, 0.0);       // a[c] = sum_r conj(y[r]) G[r][c]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cfma_cj(yrow[q], make_double2(gr[q], gi[q]), a);
+    a.x = group4_sum(a.x);
+    a.y = group4_sum(a.y);
+    double2 bq[4];                            // b[4 q + g] = sum_c G[4 q + g][c] y[c]
+    double2 part = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double2 t = cmul(make_double2(gr[q], gi[q]), yc);
+      bq[q] = make_double2(row16_sum(t.x), row16_sum(t.y));
+      cfma_cj(yrow[q], bq[q], part);
+    }
+    const double2 s = make_double2(group4_sum(part.x), group4_sum(part.y));      // y^H G y of the deflated matrix
+    const double2 ycj = make_double2(yc.x, -yc.y);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double2 e = make_double2(gr[q], gi[q]);
+      cfms(yrow[q], a, e);
+      const double2 bs = make_double2(bq[q].x - (yrow[q].x * s.x - yrow[q].y * s.y), bq[q].y - (yrow[q].x * s.y + yrow[q].y * s.x));
+      cfms(bs, ycj, e);
+      gr[q] = e.x;
+      gi[q] = e.y;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------------
+// the kernel: workgroups draw chunks of candidates from `counter`, and finish those the power kernel gave up on
+// ------------------------------------------------------------------------------------------------------------------------
+template <int D, bool ADJ>
+__global__ __launch_bounds__(256) void overlap_krylov_kernel(OverlapArgs p, int* counter) {
+  using L = KryLds<D>;
+  constexpr int N = L::N, EPL = N / 16, CHUNK = 8;
+  __shared__ __attribute__((aligned(16))) char smem[L::total];
+  double2* sV = (double2*)(smem + L::oV);
+  double2* sW = (double2*)(smem + L::oW);
+  double2* sP = (double2*)(smem + L::oP);
+  double2* sX = (double2*)(smem + L::oX);
+  double2* sG = (double2*)(smem + L::oG);
+  double2* sQ = (double2*)(smem + L::oQ);
+  double2* sH = (double2*)(smem + L::oH);
+  double* sS = (double*)(smem + L::oS);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  // the element of a vector this thread owns, and where it lives in LDS (D = 16: row-XOR swizzle - both the accumulator layout
+  // and the A-operand layout of the matrix instructions then touch 16 different banks per 16 lanes; every vector uses the same
+  // permutation, so inner products and updates do not care)
+  const bool has = D == 16 || tid < 64;
+  const int e_row = D == 16 ? 4 * wave + g : (tid >> 3) & 7, e_col = D == 16 ? c : tid & 7;
+  const int pos = D == 16 ? 16 * e_row + (e_col ^ e_row) : (tid & 63);
+  const double tol2 = p.tol * p.tol;
+  int red_set = 0;
+  // sums of up to four values over the workgroup, bit-identical in every thread (two alternating scratch sets: one barrier per call)
+  auto block_sum4 = [&](double (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = wave_sum(v[q]);
+    double* r = sS + S_RED + 16 * red_set;
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[4 * wave + q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (r[q] + r[4 + q]) + (r[8 + q] + r[12 + q]);
+    red_set ^= 1;
+  };
+  // `cnt` inner products out[q] = <a_q, b_q> = sum_n conj(a_q[n]) b_q[n], sixteen at a time (one per 16-lane row)
+  auto inner_products = [&](int cnt, auto vec_a, auto vec_b, double2* out) {
+    const int row = tid >> 4;
+    for (int q0 = 0; q0 < cnt; q0 += 16) {
+      const int q = q0 + row;
+      double2 acc = make_double2(0.0, 0.0);
+      if (q < cnt) {
+        const double2* a = vec_a(q);
+        const double2* b = vec_b(q);
+#pragma unroll 4
+        for (int m = 0; m < EPL; ++m) cfma_cj(a[c + 16 * m], b[c + 16 * m], acc);
+      }
+      acc.x = row16_sum(acc.x);
+      acc.y = row16_sum(acc.y);
+      if (q < cnt && c == 0) out[q] = acc;
+    }
+  };
+
+  for (;;) {
+    // ---- draw a chunk of candidates
+    __syncthreads();
+    if (tid == 0) ((int*)(sS + S_IDX))[0] = atomicAdd(counter, CHUNK);
+    __syncthreads();
+    const int64_t base = ((const int*)(sS + S_IDX))[0];
+    if (base >= p.B) break;
+    for (int64_t b = base; b < base + CHUNK && b < p.B; ++b) {
+      if (overlap_skipped(p, b)) continue;
+      const int used = p.iters[b];
+      if (p.status[b] != QMPS_ST_NOT_CONVERGED || used + KM + 1 > p.max_rounds) continue;      // (uniform over the workgroup)
+      __syncthreads();
+      const int64_t slot_off = overlap_slot_offset(p);
+      const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * (2 * N);
+      const double2* Bp = (const double2*)p.Bt + b * (2 * N);
+      const double2* W = (const double2*)p.WW;
+      double2* xio = (double2*)((char*)p.r_out + slot_off) + b * N;
+
+      // ================= set-up of the map =================
+      // D = 16: wave w keeps C_w (A-layout) and Bm_w^+ (B-layout) in registers, as overlap_mfma_d16x4_body
+      double cre[4] = {0, 0, 0, 0}, cim[4] = {0, 0, 0, 0}, bre[4] = {0, 0, 0, 0}, bimn[4] = {0, 0, 0, 0};
+      if constexpr (D == 16) {
+        double2* sT = (double2*)(smem + L::oW) + wave * (16 * 17);        // (the image vectors are not in use yet)
+        auto to_a_layout = [&](const v4f64& re, const v4f64& im, double (&are)[4], double (&aim)[4]) {
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sT[(4 * q + g) * 17 + c] = make_double2(re[q], im[q]);
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const double2 t = sT[c * 17 + 4 * kk + g];
+            are[kk] = t.x;
+            aim[kk] = t.y;
+          }
+        };
+        const int t1 = wave >> 1, t2 = wave & 1;
+        double pa[4], pai[4], pb[4], pbi[4];
+        v4f64 qa, qai, qb, qbi;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const double2 va = Ap[(t1 * D + c) * D + 4 * kk + g], vb = Bp[(t1 * D + c) * D + 4 * kk + g];
+          pa[kk] = va.x; pai[kk] = va.y;
+          pb[kk] = vb.x; pbi[kk] = vb.y;
+          const double2 wa = Ap[(t2 * D + 4 * kk + g) * D + c], wb = Bp[(t2 * D + 4 * kk + g) * D + c];
+          qa[kk] = wa.x; qai[kk] = wa.y;
+          qb[kk] = wb.x; qbi[kk] = wb.y;
+        }
+        v4f64 zr = {0, 0, 0, 0}, zi = {0, 0, 0, 0};
+        cmma16(pa, pai, qa, qai, zr, zi);                       // AA_w = A_t1 A_t2
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sP[wave * N + q * 64 + lane] = make_double2(zr[q], zi[q]);
+        v4f64 yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
+        cmma16(pb, pbi, qb, qbi, yr, yi);                       // Bm_w = B_t1 B_t2
+        if constexpr (ADJ) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) { bre[kk] = yr[kk]; bimn[kk] = yi[kk]; }
+        } else {
+          double tr[4], ti[4];
+          to_a_layout(yr, yi, tr, ti);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) { bre[kk] = tr[kk]; bimn[kk] = -ti[kk]; }
+        }
+        __syncthreads();
+        v4f64 sr = {0, 0, 0, 0}, si = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double2 w = W[wave * 4 + t];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double2 a = sP[t * N + q * 64 + lane];
+            sr[q] += w.x * a.x - w.y * a.y;
+            si[q] += w.x * a.y + w.y * a.x;
+          }
+        }
+        if constexpr (ADJ) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) { cre[kk] = sr[kk]; cim[kk] = -si[kk]; }
+        } else {
+          to_a_layout(sr, si, cre, cim);
+        }
+        __syncthreads();
+      } else {
+        // D = 8: tiles of C_s and Bm_s in LDS; wave s forms AA_s and Bm_s (thread (i, j) of the wave), then C_s = sum_t WW[s][t] AA_t
+        double2 (*sC)[8][9] = (double2 (*)[8][9])(smem + L::oT);
+        double2 (*sB)[8][9] = (double2 (*)[8][9])(smem + L::oT + 4 * 8 * 9 * 16);
+        const int i = lane >> 3, j = lane & 7, t1 = wave >> 1, t2 = wave & 1;
+        double2 aa = make_double2(0.0, 0.0), bm = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          cfma(Ap[(t1 * 8 + i) * 8 + k], Ap[(t2 * 8 + k) * 8 + j], aa);
+          cfma(Bp[(t1 * 8 + i) * 8 + k], Bp[(t2 * 8 + k) * 8 + j], bm);
+        }
+        sP[wave * N + lane] = aa;
+        sB[wave][i][j] = bm;
+        __syncthreads();
+        double2 cs = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cfma(W[wave * 4 + t], sP[t * N + lane], cs);
+        sC[wave][i][j] = cs;
+        __syncthreads();
+      }
+
+      // one application of the map to the vector at `x` (LDS, this file's element order): every thread receives ITS element of T x
+      auto apply_map = [&](const double2* x) -> double2 {
+        if constexpr (D == 16) {
+          double xar[4], xai[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const double2 t = x[16 * c + ((4 * kk + g) ^ c)];         // A-layout: x[row c][col 4 kk + g]
+            xar[kk] = t.x;
+            xai[kk] = t.y;
+          }
+          v4f64 yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0}, pr = {0, 0, 0, 0}, pi = {0, 0, 0, 0};
+          const v4f64 qre = {bre[0], bre[1], bre[2], bre[3]};
+          const v4f64 qim = {bimn[0], bimn[1], bimn[2], bimn[3]};
+          cmma16_3m(xar, xai, qre, qim, yr, yi);
+          cmma16_3m(cre, cim, yr, yi, pr, pi);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sP[wave * N + q * 64 + lane] = make_double2(pr[q], pi[q]);
+          __syncthreads();
+          double2 s = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const double2 t = sP[w * N + wave * 64 + lane];           // register q = wave of lane (g, c): element [4 wave + g][c]
+            s.x += t.x;
+            s.y += t.y;
+          }
+          return s;
+        } else {
+          double2 (*sC)[8][9] = (double2 (*)[8][9])(smem + L::oT);
+          double2 (*sB)[8][9] = (double2 (*)[8][9])(smem + L::oT + 4 * 8 * 9 * 16);
+          double2* sYw = sP + 4 * N + wave * N;                         // (the exchange region holds 8 KiB: partials, then the Y_s tiles)
+          const int i = lane >> 3, j = lane & 7;
+          double2 y = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            if constexpr (ADJ) cfma(x[i * 8 + kk], sB[wave][kk][j], y);
+            else cfma_conj(x[i * 8 + kk], sB[wave][j][kk], y);
+          }
+          __builtin_amdgcn_wave_barrier();
+          sYw[lane] = y;
+          __builtin_amdgcn_wave_barrier();
+          double2 xn = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            if constexpr (ADJ) cfma_cj(sC[wave][kk][i], sYw[kk * 8 + j], xn);
+            else cfma(sC[wave][i][kk], sYw[kk * 8 + j], xn);
+          }
+          sP[wave * N + lane] = xn;
+          __syncthreads();
+          double2 s = make_double2(0.0, 0.0);
+          if (has) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const double2 t = sP[w * N + tid];
+              s.x += t.x;
+              s.y += t.y;
+            }
+          }
+          return s;
+        }
+      };
+
+      // ================= start vector: the power kernel's last iterate =================
+      {
+        double2 x0 = has ? xio[e_row * D + e_col] : make_double2(0.0, 0.0);
+        double v[4] = {dfma(x0.x, x0.x, x0.y * x0.y), 0.0, 0.0, 0.0};
+        block_sum4(v);
+        if (!(v[0] > 1e-200 && v[0] < 1e200)) {                 // nothing usable there: the power kernels' own start
+          x0 = make_double2(e_row == e_col ? 1.0 : 0.0, 0.0);
+          v[0] = (double)D;
+        }
+        const double inv = 1.0 / __builtin_sqrt(v[0]);
+        if (has) sV[pos] = make_double2(x0.x * inv, x0.y * inv);
+      }
+      for (int k = tid; k < 256; k += 256) sG[k] = make_double2(0.0, 0.0);
+      __syncthreads();
+
+      int applications = used, j0 = 0, status = QMPS_ST_NOT_CONVERGED;
+      double2 eta = make_double2(0.0, 0.0), uv = has ? sV[pos] : make_double2(0.0, 0.0);
+      // one classical Gram-Schmidt pass of the vector `wv` (element per thread) against V[0 .. jn): through slot jn of the basis
+      auto cgs_pass = [&](int jn, double2& wv) {
+        if (has) sV[jn * N + pos] = wv;
+        __syncthreads();
+        inner_products(jn, [&](int q) { return sV + q * N; }, [&](int) { return sV + jn * N; }, sH + 32);
+        __syncthreads();
+        if (has)
+          for (int q = 0; q < jn; ++q) cfms(sH[32 + q], sV[q * N + pos], wv);
+      };
+      auto normalise_store = [&](int jn, double2 wv, double floor2) {
+        double v[4] = {dfma(wv.x, wv.x, wv.y * wv.y), 0.0, 0.0, 0.0};
+        block_sum4(v);
+        const double inv = (v[0] > floor2 && v[0] > 1e-280) ? 1.0 / __builtin_sqrt(v[0]) : 0.0;     // (breakdown: a zero vector, the rest of the cycle is inert)
+        if (has) sV[jn * N + pos] = make_double2(wv.x * inv, wv.y * inv);
+        __syncthreads();
+      };
+
+      while (applications + (KM - j0) + 1 <= p.max_rounds) {
+        // ---------------- extend the basis to KM vectors ----------------
+        for (int j = j0; j < KM; ++j) {
+          double2 wv = apply_map(sV + j * N);
+          ++applications;
+          if (has) sW[j * N + pos] = wv;
+          __syncthreads();
+          // one pass: h[q] = <V_q, w> (q <= j: column j of G), <V_j, W_q> (q < j: row j of G), <w, w>
+          inner_products(2 * j + 2,
+                         [&](int q) { return q <= j ? sV + q * N : (q <= 2 * j ? sV + j * N : sW + j * N); },
+                         [&](int q) { return q <= j ? sW + j * N : (q <= 2 * j ? sW + (q - j - 1) * N : sW + j * N); }, sH);
+          __syncthreads();
+          if (tid <= j) sG[tid * 16 + j] = sH[tid];
+          else if (tid <= 2 * j) sG[j * 16 + (tid - j - 1)] = sH[tid];
+          if (j + 1 < KM) {
+            const double w2 = sH[2 * j + 1].x;
+            if (has)
+              for (int q = 0; q <= j; ++q) cfms(sH[q], sV[q * N + pos], wv);
+            cgs_pass(j + 1, wv);
+            normalise_store(j + 1, wv, 1e-28 * w2);
+          }
+        }
+        __syncthreads();
+        // ---------------- Rayleigh-Ritz: Schur vectors of G on wave 0 ----------------
+        if (wave == 0) rayleigh_ritz_wave(sG, sQ, sS, smem + L::oP);
+        __syncthreads();
+        const double2 th0 = make_double2(sS[S_THETA], sS[S_THETA + 1]), th1 = make_double2(sS[S_THETA + 2], sS[S_THETA + 3]);
+        const double2 g01 = make_double2(sS[S_G01], sS[S_G01 + 1]);
+        // Ritz vectors u = V y_0, u2 = V y_1 and their images; residuals of the first pair and of the second SCHUR pair
+        double2 tv = make_double2(0.0, 0.0), u2 = make_double2(0.0, 0.0), t2 = make_double2(0.0, 0.0);
+        uv = make_double2(0.0, 0.0);
+        if (has) {
+          for (int jj = 0; jj < KM; ++jj) {
+            const double2 v = sV[jj * N + pos], w = sW[jj * N + pos], y0 = sQ[jj * 8 + 0], y1 = sQ[jj * 8 + 1];
+            cfma(v, y0, uv);
+            cfma(w, y0, tv);
+            cfma(v, y1, u2);
+            cfma(w, y1, t2);
+          }
+        }
+        double2 rv = tv, r2v = t2;
+        cfms(th0, uv, rv);
+        cfms(g01, uv, r2v);
+        cfms(th1, u2, r2v);
+        double sums[4] = {dfma(rv.x, rv.x, rv.y * rv.y), dfma(r2v.x, r2v.x, r2v.y * r2v.y), dfma(uv.x, uv.x, uv.y * uv.y), 0.0};
+        block_sum4(sums);
+        eta = th0;
+        bool target_second = false;
+        if (sums[0] < tol2) {
+          const double a0 = __builtin_sqrt(th0.x * th0.x + th0.y * th0.y), a1 = __builtin_sqrt(th1.x * th1.x + th1.y * th1.y);
+          if (a1 + KMARGIN * (__builtin_sqrt(sums[1]) + __builtin_sqrt(sums[0])) < a0) {
+            // the pair is converged and ranked: ONE explicit application, the power kernels' own test
+            const double inv = sums[2] > 0.0 ? 1.0 / __builtin_sqrt(sums[2]) : 0.0;
+            const double2 un = make_double2(uv.x * inv, uv.y * inv);
+            if (has) sX[pos] = un;
+            __syncthreads();
+            const double2 tu = apply_map(sX);
+            ++applications;
+            const double2 e = cmulc(un, tu);
+            double ev[4] = {e.x, e.y, 0.0, 0.0};
+            block_sum4(ev);
+            const double dr = tu.x - (ev[0] * un.x - ev[1] * un.y), di = tu.y - (ev[0] * un.y + ev[1] * un.x);
+            double rs[4] = {dfma(dr, dr, di * di), 0.0, 0.0, 0.0};
+            block_sum4(rs);
+            eta = make_double2(ev[0], ev[1]);
+            uv = un;
+            if (rs[0] < tol2) {
+              status = QMPS_ST_OK;
+              break;
+            }
+          } else {
+            target_second = true;        // a rival of nearly the same modulus: make IT converge
+          }
+        }
+        // ---------------- restart with the Schur vectors ----------------
+        {
+          double2 nv[KK], nw[KK];
+#pragma unroll
+          for (int i = 0; i < KK; ++i) nv[i] = nw[i] = make_double2(0.0, 0.0);
+          if (has) {
+            for (int jj = 0; jj < KM; ++jj) {
+              const double2 v = sV[jj * N + pos], w = sW[jj * N + pos];
+#pragma unroll
+              for (int i = 0; i < KK; ++i) {
+                const double2 q = sQ[jj * 8 + i];
+                cfma(v, q, nv[i]);
+                cfma(w, q, nw[i]);
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < KK; ++i) {
+              sV[i * N + pos] = nv[i];
+              sW[i * N + pos] = nw[i];
+            }
+          }
+          // G <- Q^H G Q
+          double2* sGQ = sP;            // [16][KK]
+          if (tid < 16 * KK) {
+            const int r = tid / KK, i = tid % KK;
+            double2 t = make_double2(0.0, 0.0);
+            for (int k = 0; k < 16; ++k) cfma(sG[r * 16 + k], sQ[k * 8 + i], t);
+            sGQ[tid] = t;
+          }
+          __syncthreads();
+          double2 gn = make_double2(0.0, 0.0);
+          if (tid < KK * KK) {
+            const int a = tid / KK, bcol = tid % KK;
+            for (int r = 0; r < 16; ++r) cfma_cj(sQ[r * 8 + a], sGQ[r * KK + bcol], gn);
+          }
+          __syncthreads();
+          sG[tid] = make_double2(0.0, 0.0);
+          __syncthreads();
+          if (tid < KK * KK) sG[(tid / KK) * 16 + tid % KK] = gn;
+          // the new direction: the residual of the pair that still has to converge, orthogonalised against the kept vectors
+          double2 wv = target_second ? r2v : rv;
+          cgs_pass(KK, wv);
+          cgs_pass(KK, wv);
+          normalise_store(KK, wv, 0.0);
+          j0 = KK;
+        }
+      }
+      // ================= results =================
+      {
+        double v[4] = {dfma(uv.x, uv.x, uv.y * uv.y), 0.0, 0.0, 0.0};
+        block_sum4(v);
+        const double inv = v[0] > 0.0 ? 1.0 / __builtin_sqrt(v[0]) : 0.0;
+        if (has) xio[e_row * D + e_col] = make_double2(uv.x * inv, uv.y * inv);
+        if (tid == 0) {
+          const double er = eta.x, ei = ADJ ? -eta.y : eta.y;
+          ((double2*)p.eta)[b] = make_double2(er, ei);
+          p.iters[b] = applications;
+          p.status[b] = status;
+          if (p.f_out != nullptr) p.f_out[b] = -__builtin_sqrt(__builtin_sqrt(er * er + ei * ei));
+          if (p.stats != nullptr) {        // the power kernel has already counted this evaluation (as not converged, with its own steps)
+            unsigned long long* st = p.stats + 4 * ((unsigned)b & (kOverlapStatShards - 1));
+            atomicAdd(st + 1, (unsigned long long)(applications - used));
+            atomicMax(st + 2, (unsigned long long)applications);
+            if (status == QMPS_ST_OK) atomicAdd(st + 3, ~0ULL);
+          }
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_overlap_krylov(int D, const OverlapArgs& a, int* counter, hipStream_t st) {
+  if (a.B <= 0) return hipSuccess;
+  if (a.r_out == nullptr || counter == nullptr) return hipErrorInvalidValue;
+  // one workgroup per CU holds the whole basis in LDS (D = 16: 155 KiB); a workgroup that finds nothing to do leaves at once
+  const int64_t chunks = (a.B + 7) / 8;
+  const unsigned grid = (unsigned)(chunks < 1024 ? chunks : 1024);
+  if (D == 16) {
+    if (a.adjoint) hipLaunchKernelGGL((overlap_krylov_kernel<16, true>), dim3(grid), dim3(256), 0, st, a, counter);
+    else hipLaunchKernelGGL((overlap_krylov_kernel<16, false>), dim3(grid), dim3(256), 0, st, a, counter);
+  } else if (D == 8) {
+    if (a.adjoint) hipLaunchKernelGGL((overlap_krylov_kernel<8, true>), dim3(grid), dim3(256), 0, st, a, counter);
+    else hipLaunchKernelGGL((overlap_krylov_kernel<8, false>), dim3(grid), dim3(256), 0, st, a, counter);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace qmps

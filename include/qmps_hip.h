@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define QMPS_ABI_VERSION 4
+#define QMPS_ABI_VERSION 5
 
 /* error codes */
 #define QMPS_OK 0
@@ -134,7 +134,9 @@ extern "C" {
  *                         decaying second eigenvector (same results; candidates with |eta_2 / eta_1| > 0.9 take 2 - 10 x more steps;
  *                         D = 16: cold starts only - warm-started batches run the lean loop)
  *   QMPS_D16_ONE_WAVE     D = 16 overlap objective, batches above 2 048 candidates: one wave per candidate with a static stride
- *                         (round 2) instead of four waves per candidate drawn from a work queue
+ *                         (round 2) instead of four waves per candidate drawn from a work queue (no Krylov fall-back)
+ *   QMPS_NO_KRYLOV        D = 8, 16 fixed-point solves: the power method alone, to max_rounds (same results wherever it converges;
+ *                         ~1/(1 - |eta_2 / eta_1|) steps)
  * Everything else that used to be tunable from the environment (thresholds, schedules: profiles/EXPERIMENTS.md) is compiled
  * in only with -DQMPS_DEBUG_KNOBS; the shipped library ignores those variables (tests/test_cabi.py checks both lists). */
 
@@ -297,8 +299,17 @@ int qmps_cell2_energy_batch_su(qmps_ctx* ctx, int64_t B, const double* params /*
  * O(log) rounds whatever the spectral gap) - D = 2 in a lane, D = 4 as one complex 16 x 16 tile on the matrix cores,
  * until it is rank one (||M M - tr(M) M||_F < tol ||M M||_F), eta = tr(M E)/tr(M);
  * D = 8, 16 run the power method in operator form from x_0 = 1/sqrt(D), eta = <x, T x>, stop when
- * ||T x - eta x||_F < tol (max_rounds = cap on power steps, rounds_out = steps used) - at D = 16 on the matrix
- * cores (v_mfma_f64_16x16x4, one wave per evaluation). */
+ * ||T x - eta x||_F < tol - at D = 16 on the matrix cores (v_mfma_f64_16x16x4, four waves per evaluation) - WITH A KRYLOV
+ * FALL-BACK (ABI 5; the reference's route is ARPACK: xmps Map.right_fixed_point -> scipy eigs, qmps/new_time_evolve.py:201-203,
+ * qmps/time_evolve_tools.py:84-91): a candidate whose residual history predicts more than 256 further power steps (looked at
+ * every 32 steps from step 48 on; at the latest after 1 024 steps) is handed to a thick-restart Arnoldi solver - one workgroup per
+ * candidate, 16 basis vectors and their images in LDS, the 5 dominant Schur vectors of the 16 x 16 projected map by squaring on
+ * the matrix cores, restart with those (qmps_amd/csrc/qmps_overlap_krylov.hip).  It declares convergence on the same test
+ * (one explicit application, ||T u - <u, T u> u||_F < tol, ||u||_F = 1) AND only once the second Schur pair is itself converged
+ * far enough to be ranked below the first (|theta_2| + 100 (res_1 + res_2) < |theta_1|): Haar-random candidates take ~100 (D = 8) /
+ * ~250 (D = 16) map applications where the power method needs 10^3 .. 10^5, pairs with |eta_2 / eta_1| = 1 - 1e-8 take 65.
+ * max_rounds = cap on MAP APPLICATIONS (power steps + Arnoldi steps), rounds_out = applications used; status 1 = not converged
+ * within them - two dominant eigenvalues of EQUAL modulus (no unique fixed point) always end that way. */
 #define QMPS_INPUT_ANSATZ_BASE 16
 int qmps_overlap_batch(qmps_ctx* ctx, int64_t B, const double* A, int a_shared, const double* states, int kind,
                        int n_params, const double* WW, int max_rounds, double tol, double* eta_out, double* r_out,

@@ -130,7 +130,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.qmps_abi_version() != 4:
+    if lib.qmps_abi_version() != 5:
         raise ImportError('libqmps_hip.so ABI version mismatch')
     _lib = lib
     return lib

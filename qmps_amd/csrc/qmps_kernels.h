@@ -191,7 +191,8 @@ struct OverlapArgs {
   // iterate in r_out - which must then be non-null) as soon as its residual history predicts more than `krylov_after` further
   // steps (or after 4 krylov_after steps in all); launch_overlap_d / _pair_* then run overlap_krylov_kernel over the batch.
   int krylov_after;            // 0: plain power method to max_rounds (QMPS_NO_KRYLOV)
-  int* kry_counter;            // the fall-back kernel's work counter (zeroed by the host on the stream); null = no fall-back launch
+  int* kry_counter;            // the fall-back's three counters [work, exit tickets, candidates given up] - zero between launches (the
+                               //   power kernels count what they give up, the fall-back clears all three when it is done); null = no fall-back
 };
 // two-sided first-order evaluation of central-difference neighbours (qmps_overlap_gradient; qmps_overlap_grad.hip)
 struct OverlapGradArgs {
@@ -233,6 +234,7 @@ __device__ __forceinline__ void overlap_store(const OverlapArgs& p, int64_t b, d
 }
 // power method -> Krylov hand-over (see OverlapArgs::krylov_after).  Called at a convergence test of step k (k >= 16) with the
 // squared residual: every 32 steps or more the decay rate since the last look (bits per step) is extrapolated to tol2.
+// The caller that acts on `true` counts the candidate: atomicAdd(p.kry_counter + 2, 1) by ONE lane.
 // (k_ref, l_ref): the last look (k_ref = 0: none - also after anything that makes the residual jump, e.g. a deflation step).
 __device__ __forceinline__ bool power_gives_up(int k, double res2, double tol2, int limit, int& k_ref, float& l_ref) {
   if (limit <= 0 || k < 16) return false;
@@ -254,6 +256,7 @@ hipError_t launch_overlap(const OverlapArgs& a, hipStream_t st);   // D = 2 (lan
 // D = 8, 16: thick-restart Arnoldi over the candidates the power kernels gave up (status 1, iters < max_rounds); a.r_out holds their
 // iterates and receives the fixed points; `counter` zeroed by the caller (qmps_overlap_krylov.hip)
 hipError_t launch_overlap_krylov(int D, const OverlapArgs& a, int* counter, hipStream_t st);
+hipError_t launch_overlap_krylov_pair(int D, const OverlapArgs& right, const OverlapArgs& left, hipStream_t st);   // both solves of a pair launch
 // D = 4, 8, 16: operator-form power method (qmps_overlap.hip); tensors [2][D][D]; max_rounds = cap on power steps;
 // mfma: D = 16 on the matrix cores (one wave per evaluation) instead of the generic LDS-tile kernel
 hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st);

@@ -148,7 +148,7 @@ __device__ __forceinline__ void overlap_block_body(const OverlapArgs& p, int64_t
   int last_deflation = 0;
   bool deflate_on = p.no_deflation == 0;
   // hand-over to the Krylov fall-back (one evaluation per workgroup only: the decision must be uniform)
-  const int give_up_after = (ITEMS == 1 && p.r_out != nullptr) ? p.krylov_after : 0;
+  const int give_up_after = (ITEMS == 1 && p.r_out != nullptr && p.kry_counter != nullptr) ? p.krylov_after : 0;
   int k_ref = 0;
   float l_ref = 0.0f;
   __syncthreads();
@@ -239,7 +239,10 @@ __device__ __forceinline__ void overlap_block_body(const OverlapArgs& p, int64_t
           k_ref = 0;
         }
         // a long tail ahead: stop here (status 1, k < max_rounds) - overlap_krylov_kernel takes the candidate over from x
-        if (power_gives_up(k, w[0], tol2, give_up_after, k_ref, l_ref) && k < p.max_rounds) active = false;
+        if (power_gives_up(k, w[0], tol2, give_up_after, k_ref, l_ref) && k < p.max_rounds) {
+          active = false;
+          if (tid == 0) atomicAdd(p.kry_counter + 2, 1);
+        }
       }
     }
   }
@@ -840,7 +843,7 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
     v4f64 rr = {0, 0, 0, 0}, ri = {0, 0, 0, 0};
     double rs_chk = 0.0, inv_chk = 0.0, res_prev = 0.0, sgr_prev = 0.0, sgi_prev = 0.0, sig_max2 = 0.0;
     int last_deflation = 0;
-    const int give_up_after = p.r_out != nullptr ? p.krylov_after : 0;       // hand-over to the Krylov fall-back (see OverlapArgs)
+    const int give_up_after = (p.r_out != nullptr && p.kry_counter != nullptr) ? p.krylov_after : 0;       // hand-over to the Krylov fall-back (see OverlapArgs)
     int k_ref = 0;
     float l_ref = 0.0f;
     for (int k = 1; k <= p.max_rounds; ++k) {
@@ -972,7 +975,10 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
       xr = nr * inv;
       xi = ni * inv;
       // a long tail ahead: stop here (status 1, k < max_rounds) - overlap_krylov_kernel takes the candidate over from x
-      if (k < p.max_rounds && power_gives_up(k, res2, tol2, give_up_after, k_ref, l_ref)) break;
+      if (k < p.max_rounds && power_gives_up(k, res2, tol2, give_up_after, k_ref, l_ref)) {
+        if (threadIdx.x == 0) atomicAdd(p.kry_counter + 2, 1);
+        break;
+      }
     }
     if (wave == 0) {
       if (lane == 0) overlap_store(p, b, eta_r, ADJ ? -eta_i : eta_i, iters, status);
@@ -1005,7 +1011,10 @@ __global__ __launch_bounds__(256, 3) void overlap_mfma_d16x4_pair_kernel(Overlap
 
 // the Krylov fall-back behind a power launch (both solves of a pair launch): candidates given up are finished, the others untouched
 static hipError_t launch_krylov_after(int D, const OverlapArgs& a, const OverlapArgs* second, hipStream_t st) {
-  if (a.krylov_after > 0 && a.kry_counter != nullptr)
+  const bool first = a.krylov_after > 0 && a.kry_counter != nullptr;
+  const bool both = first && second != nullptr && second->krylov_after > 0 && second->kry_counter != nullptr;
+  if (both) return launch_overlap_krylov_pair(D, a, *second, st);
+  if (first)
     if (hipError_t e = launch_overlap_krylov(D, a, a.kry_counter, st); e != hipSuccess) return e;
   if (second != nullptr && second->krylov_after > 0 && second->kry_counter != nullptr)
     if (hipError_t e = launch_overlap_krylov(D, *second, second->kry_counter, st); e != hipSuccess) return e;

@@ -270,11 +270,14 @@ __device__ __forceinline__ void rayleigh_ritz_wave(const double2* sG, double2* s
 // ------------------------------------------------------------------------------------------------------------------------
 // the kernel: workgroups draw chunks of candidates from `counter`, and finish those the power kernel gave up on
 // ------------------------------------------------------------------------------------------------------------------------
+// counter[0]: work counter (chunks of candidates), counter[1]: exit tickets, counter[2]: candidates the power kernel gave up (it
+// counts them).  All three are zero between launches: a launch with nothing to do leaves at once, otherwise the LAST workgroup
+// to leave clears them - no memset on the stream, nothing for a graph capture to record.
 template <int D, bool ADJ>
-__global__ __launch_bounds__(256) void overlap_krylov_kernel(OverlapArgs p, int* counter) {
+__device__ __forceinline__ void overlap_krylov_body(const OverlapArgs& p, int* counter, int n_groups, char* smem) {
   using L = KryLds<D>;
   constexpr int N = L::N, EPL = N / 16, CHUNK = 8;
-  __shared__ __attribute__((aligned(16))) char smem[L::total];
+  if (__hip_atomic_load(counter + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
   double2* sV = (double2*)(smem + L::oV);
   double2* sW = (double2*)(smem + L::oW);
   double2* sP = (double2*)(smem + L::oP);
@@ -330,7 +333,14 @@ __global__ __launch_bounds__(256) void overlap_krylov_kernel(OverlapArgs p, int*
     if (tid == 0) ((int*)(sS + S_IDX))[0] = atomicAdd(counter, CHUNK);
     __syncthreads();
     const int64_t base = ((const int*)(sS + S_IDX))[0];
-    if (base >= p.B) break;
+    if (base >= p.B) {
+      if (tid == 0 && atomicAdd(counter + 1, 1) == n_groups - 1) {       // the last workgroup out clears the counters
+        __hip_atomic_store(counter + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(counter + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(counter + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      break;
+    }
     for (int64_t b = base; b < base + CHUNK && b < p.B; ++b) {
       if (overlap_skipped(p, b)) continue;
       const int used = p.iters[b];
@@ -666,12 +676,32 @@ __global__ __launch_bounds__(256) void overlap_krylov_kernel(OverlapArgs p, int*
   }
 }
 
+template <int D, bool ADJ>
+__global__ __launch_bounds__(256) void overlap_krylov_kernel(OverlapArgs p, int* counter) {
+  __shared__ __attribute__((aligned(16))) char smem[KryLds<D>::total];
+  overlap_krylov_body<D, ADJ>(p, counter, (int)gridDim.x, smem);
+}
+
+// RIGHT and LEFT solves of a pair launch in one: workgroups [0, n) finish the map of `pr`, the others the adjoint map of `pl`
+template <int D>
+__global__ __launch_bounds__(256) void overlap_krylov_pair_kernel(OverlapArgs pr, OverlapArgs pl, int* cr, int* cl, int n) {
+  __shared__ __attribute__((aligned(16))) char smem[KryLds<D>::total];
+  if ((int)blockIdx.x < n) overlap_krylov_body<D, false>(pr, cr, n, smem);
+  else overlap_krylov_body<D, true>(pl, cl, (int)gridDim.x - n, smem);
+}
+
+namespace {
+// one workgroup holds the whole basis in LDS (D = 16: 155 KiB, one per CU); a workgroup that finds nothing to do leaves at once
+unsigned krylov_grid(int D, int64_t B) {
+  const int64_t chunks = (B + 7) / 8, cap = D == 16 ? 256 : 512;
+  return (unsigned)(chunks < cap ? chunks : cap);
+}
+}  // namespace
+
 hipError_t launch_overlap_krylov(int D, const OverlapArgs& a, int* counter, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
   if (a.r_out == nullptr || counter == nullptr) return hipErrorInvalidValue;
-  // one workgroup per CU holds the whole basis in LDS (D = 16: 155 KiB); a workgroup that finds nothing to do leaves at once
-  const int64_t chunks = (a.B + 7) / 8;
-  const unsigned grid = (unsigned)(chunks < 1024 ? chunks : 1024);
+  const unsigned grid = krylov_grid(D, a.B);
   if (D == 16) {
     if (a.adjoint) hipLaunchKernelGGL((overlap_krylov_kernel<16, true>), dim3(grid), dim3(256), 0, st, a, counter);
     else hipLaunchKernelGGL((overlap_krylov_kernel<16, false>), dim3(grid), dim3(256), 0, st, a, counter);
@@ -681,6 +711,16 @@ hipError_t launch_overlap_krylov(int D, const OverlapArgs& a, int* counter, hipS
   } else {
     return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_overlap_krylov_pair(int D, const OverlapArgs& right, const OverlapArgs& left, hipStream_t st) {
+  if (right.B <= 0) return hipSuccess;
+  if (right.r_out == nullptr || left.r_out == nullptr || right.kry_counter == nullptr || left.kry_counter == nullptr) return hipErrorInvalidValue;
+  const unsigned n = krylov_grid(D, right.B), nl = krylov_grid(D, left.B);
+  if (D == 16) hipLaunchKernelGGL((overlap_krylov_pair_kernel<16>), dim3(n + nl), dim3(256), 0, st, right, left, right.kry_counter, left.kry_counter, (int)n);
+  else if (D == 8) hipLaunchKernelGGL((overlap_krylov_pair_kernel<8>), dim3(n + nl), dim3(256), 0, st, right, left, right.kry_counter, left.kry_counter, (int)n);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

@@ -145,7 +145,8 @@ ROTO_CASES = [(2, 2, 15, 3, 3, 2, 3, 11),      # the reference's own case: Shall
               (4, 0, 4, 3, 3, 2, 3, 13),
               (4, 0, 4, 2, 3, 1, 6, 14),
               (16, 0, 8, 2, 2, 1, 3, 903)]     # configs[4]: D = 16, depth 4 (the +-pi/2 candidates are FAR from the reference
-                                               # state: crowded rings of eigenvalues, up to 10^4 power steps on this seed)
+                                               # state: crowded rings of eigenvalues, up to 10^4 power steps on this seed - a few
+                                               # hundred map applications through the Krylov fall-back)
 
 
 @pytest.mark.parametrize('D,kind,P,T,n_steps,n_sweeps,nsh,seed', ROTO_CASES)
@@ -158,7 +159,7 @@ def test_device_time_evolution_by_rotosolve_vs_oracle_replay(D, kind, P, T, n_st
     eng = engine_factory(D, 4096)
     eng.overlap_stats(reset=True)
     Xf, ph, fh = eng.evolve_rotosolve(kind, X0, WW, n_steps=n_steps, n_sweeps=n_sweeps, double_frequency=nsh == 6,
-                                      max_rounds=60 if D <= 4 else 400000, tol=1e-12)
+                                      max_rounds=60 if D <= 4 else 5000, tol=1e-12)
     stats = eng.overlap_stats()
     assert stats['not_converged'] == 0, stats
     assert stats['evaluations'] == n_steps * n_sweeps * (P * nsh + 1) * T

@@ -7,6 +7,7 @@ import pytest
 from scipy.linalg import expm
 
 from oracle import qmps_oracle as O
+import overlap_cases as OC
 
 pytestmark = pytest.mark.gpu
 
@@ -64,25 +65,78 @@ def test_overlap_vs_dense_eig(D, B, engine_factory):
 
 @pytest.mark.parametrize('D', [4, 8, 16])
 def test_overlap_far_candidates_and_caps(D, engine_factory):
-    """Candidates unrelated to the reference state (what an optimiser may try): small, complex dominant eigenvalues,
-    slow convergence - the plain power method needs ~1/(1 - |eta_2/eta_1|) steps, and a near-degenerate dominant pair
-    (ratio 0.9997 occurs at D = 16) exhausts any practical cap: that is reported as status 1, never hidden, and the
-    Rayleigh quotient returned is then still close to the dominant eigenvalue."""
+    """Candidates unrelated to the reference state (what an optimiser may try): small, complex dominant eigenvalues in crowded
+    rings (|eta_2/eta_1| = 0.9997 occurs at D = 16).  The reference's route (ARPACK) answers all of them; so does this one - D = 4
+    by squaring, D = 8 / 16 through the Krylov fall-back - within a few hundred map applications.  A cap that is too small is
+    reported as status 1, never hidden."""
     rng = np.random.default_rng(700 + D)
     eng = engine_factory(D, 4096)
     A = O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, 1)[0])
     cands = O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, 12))
     WW = expm(-1j * 0.2 * O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5}))
-    eta, rounds, st = eng.overlaps(A, cands, WW, max_rounds=60 if D == 4 else 200000)
-    ok = st == 0
-    assert ok.mean() >= 0.5
+    eta, rounds, st = eng.overlaps(A, cands, WW, max_rounds=60 if D == 4 else 3000)
+    assert np.all(st == 0), (st, rounds)
     if D == 4:
-        assert ok.all() and rounds.max() <= 30          # squaring: O(log) rounds whatever the gap
+        assert rounds.max() <= 30          # squaring: O(log) rounds whatever the gap
+    else:
+        assert rounds.max() <= 1500
     for k in range(len(cands)):
         ref = O.overlap_eta(A, cands[k], WW)[0]
-        assert abs(eta[k] - ref) < (ETA_TOL if ok[k] else 1e-3 * abs(ref)), (k, st[k], eta[k], ref)
+        assert abs(eta[k] - ref) < ETA_TOL, (k, st[k], eta[k], ref)
     eta, rounds, st = eng.overlaps(A, cands, WW, max_rounds=3)
     assert np.all(st == 1) and np.all(rounds == 3)
+
+
+@pytest.mark.parametrize('D,n', [(8, 3000), (16, 500)])
+def test_krylov_fallback_stress_haar_far(D, n, engine_factory):
+    """Haar-far candidates (3 000 at D = 8, 500 at D = 16), every one converged (status 0) within 3 000 map
+    applications, eta within 1e-10 of the dense eigen-solve (oracle.overlap_eta), the fixed point handed out a true eigenvector."""
+    rng = np.random.default_rng(4300 + D)
+    eng = engine_factory(D, n)
+    WW = expm(-1j * 0.2 * O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5}))
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, n))
+    C = O.unitary_to_tensor(O.haar_unitaries(rng, 2 * D, n))
+    eta, rounds, st, r = eng.overlaps(A, C, WW, max_rounds=3000, tol=1e-12, want_r=True)
+    assert np.all(st == 0), (int((st != 0).sum()), rounds.max())
+    assert rounds.max() <= 3000
+    worst = 0.0
+    for b in range(n):
+        E = OC.dense_map(A[b], C[b], WW)
+        w = np.linalg.eigvals(E)
+        ref = w[np.argmax(np.abs(w))]
+        worst = max(worst, abs(eta[b] - ref))
+        assert abs(eta[b] - ref) < ETA_TOL, (b, eta[b], ref, rounds[b], np.sort(np.abs(w))[-3:])
+        if b % 25 == 0:
+            x = r[b].reshape(-1)
+            assert np.linalg.norm(E @ x - eta[b] * x) < 3e-12 and abs(np.linalg.norm(x) - 1) < 1e-12
+    # the power method alone (QMPS_NO_KRYLOV) needs an order of magnitude more applications on the same candidates
+    assert rounds.mean() < (200 if D == 8 else 450), rounds.mean()
+
+
+@pytest.mark.parametrize('D', [8, 16])
+def test_krylov_fallback_near_degenerate_pairs(D, engine_factory):
+    """Constructed pairs with |eta_2 / eta_1| = 1 - 1e-4 .. 1 - 1e-8 (tests/overlap_cases.py: two sectors, the second tuned by
+    bisection, hidden behind random gauges): the power method would need 10^4 .. 10^8 steps; the fall-back separates the two Ritz
+    values by squaring the projected map and certifies the order.  The LEFT fixed point (adjoint map) alike.  Two dominant
+    eigenvalues of EQUAL modulus have no unique fixed point: status 1, as documented."""
+    rng = np.random.default_rng(5100 + D)
+    eng = engine_factory(D, 64)
+    WW = expm(-1j * 0.2 * O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5}))
+    for ratio in (1 - 1e-4, 1 - 1e-6, 1 - 1e-8):
+        pairs = [OC.near_tie_pair(rng, D, ratio, WW) for _ in range(4)]
+        A = np.stack([p[0] for p in pairs])
+        C = np.stack([p[1] for p in pairs])
+        eta, rounds, st, r = eng.overlaps(A, C, WW, max_rounds=3000, tol=1e-12, want_r=True)
+        assert np.all(st == 0) and rounds.max() <= 400, (ratio, st, rounds)
+        for k in range(4):
+            ref, rat = OC.dominant(A[k], C[k], WW)
+            assert abs(rat - ratio) < 0.05 * (1 - ratio) + 1e-12, (rat, ratio)
+            assert abs(eta[k] - ref) < ETA_TOL, (ratio, k, eta[k], ref)
+    pairs = [OC.near_tie_pair(rng, D, 1.0, WW) for _ in range(3)]
+    A = np.stack([p[0] for p in pairs])
+    C = np.stack([p[1] for p in pairs])
+    eta, rounds, st = eng.overlaps(A, C, WW, max_rounds=600, tol=1e-12)
+    assert np.all(st == 1), st
 
 
 @pytest.mark.parametrize('D,n', [(8, 600), (16, 192)])

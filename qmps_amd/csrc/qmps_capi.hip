@@ -283,6 +283,10 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
     HIP_TRY(hipHostMalloc((void**)&c->h_acc, qmps::kAccWords * sizeof(long long), hipHostMallocDefault));
     HIP_TRY(hipMalloc((void**)&c->d_acc_err, sizeof(int)));
     HIP_TRY(hipMemsetAsync(c->d_acc_err, 0, sizeof(int), c->stream));
+    // counters of the Krylov fall-backs (overlap solves: qmps_capi_overlap.hip; D = 16 environment: qmps_energy_launch) - allocated here,
+    // never at a launch (a launch may sit inside a stream capture); they clear themselves after use
+    HIP_TRY(hipMalloc((void**)&c->d_queue, 16 * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(c->d_queue, 0, 16 * sizeof(int), c->stream));
     HIP_TRY(hipMalloc((void**)&c->d_work_count, sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&c->d_work_idx, (size_t)max_batch * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(c->d_work_count, 0, sizeof(int32_t), c->stream));
@@ -825,8 +829,28 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     // D = 16: power iteration on the matrix cores (one wave per evaluation), then the energy pass
     c->dominant = "energy_mfma_d16_kernel<true>";
     if (accumulate) if (int rc = setup_accumulator(c, a, B, B, 1)) return rc;
+    // Krylov fall-back of the environment solve (include/qmps_hip.h "fixed-point solvers"; QMPS_NO_KRYLOV: power iteration alone):
+    // evaluations whose power iteration predicts a long tail (|lambda_2| -> 1: shallow circuits) are finished by the Arnoldi kernel
+    // of qmps_overlap_krylov.hip on the environment map, then accepted - energy, Cholesky test, status - by a pass of the same energy kernel
+    const bool krylov = documented_switch("QMPS_NO_KRYLOV") == nullptr && max_iter > 64;
+    if (krylov) {
+      a.krylov_after = 256;
+      if (const char* e = tuning_knob("QMPS_KRYLOV_AFTER")) a.krylov_after = atoi(e);
+      a.kry_counter = c->d_queue + 8;
+    }
     if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy_mfma(c->D, a, true, c->stream));
+    if (krylov && a.krylov_after > 0) {
+      qmps::OverlapArgs k;
+      memset(&k, 0, sizeof(k));
+      k.Bt = a.A; k.r_out = a.r_out; k.iters = a.iters; k.status = a.status; k.B = B; k.max_rounds = max_iter; k.tol = tol;
+      k.env_mode = 1; k.krylov_after = a.krylov_after; k.kry_counter = a.kry_counter;
+      HIP_TRY(qmps::launch_overlap_krylov(16, k, k.kry_counter, c->stream));
+      qmps::LaneArgs f = a;
+      f.r_in = a.r_out; f.only_pending = 1; f.krylov_after = 0; f.acc_zero = nullptr;
+      f.max_iter = 64;
+      HIP_TRY(qmps::launch_energy_mfma(c->D, f, true, c->stream));
+    }
     if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
   } else if (!hybrid) {
     c->dominant = c->D <= 4 ? "energy_lane_kernel<D,true>" : "energy_block_kernel<D,true>";

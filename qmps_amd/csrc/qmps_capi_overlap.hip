@@ -30,12 +30,8 @@ int ensure_overlap_outputs(qmps_ctx* c) {
     HIP_TRY(hipMalloc((void**)&c->d_ostats, (size_t)qmps::kOverlapStatShards * 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->d_ostats, 0, (size_t)qmps::kOverlapStatShards * 4 * sizeof(unsigned long long), c->stream));
   }
-  // work counters of the D = 16 queue kernels [0, 1] and of the Krylov fall-back [2, 8), and the fall-back's iterate scratch: allocated
-  // HERE, never lazily at a launch (a launch may sit inside a stream capture - qmps_evolve_rotosolve - where hipMalloc is illegal)
-  if (!c->d_queue) {
-    HIP_TRY(hipMalloc((void**)&c->d_queue, 8 * sizeof(int)));
-    HIP_TRY(hipMemsetAsync(c->d_queue, 0, 8 * sizeof(int), c->stream));      // (the Krylov counters [2, 8) clear themselves from here on)
-  }
+  // the Krylov fall-back's iterate scratch: allocated HERE, never lazily at a launch (a launch may sit inside a stream capture -
+  // qmps_evolve_rotosolve - where hipMalloc is illegal); the work counters (d_queue) come from qmps_create
   if (c->D >= 8 && !c->d_kry) HIP_TRY(hipMalloc(&c->d_kry, (size_t)c->max_batch * env_bytes(c)));
   return QMPS_OK;
 }

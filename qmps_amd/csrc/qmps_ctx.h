@@ -71,7 +71,7 @@ struct qmps_ctx {
   size_t h_pin_bytes = 0;      //   pageable buffers make every hipMemcpyAsync a blocking, internally staged copy
   unsigned char* d_active = nullptr;   // qmps_overlap_set_active: per-trajectory mask consumed by the next overlap launch (lazy, [max_batch])
   int64_t active_n = 0;                //   entries armed (0: none)
-  int* d_queue = nullptr;      // overlap kernels: counters the workgroups draw their evaluations from ([0, 1] D = 16 queue kernels, [2, 8) Krylov fall-back: two sets of three)
+  int* d_queue = nullptr;      // overlap kernels: counters the workgroups draw their evaluations from (qmps_create; [0, 1] D = 16 queue kernels, [2, 8) Krylov fall-back of the overlap solves: two sets of three, [8, 13) of the D = 16 environment)
   void* d_kry = nullptr;       // D = 8, 16: iterates handed from the power kernels to the Krylov fall-back when the caller keeps no fixed points [max_batch][D][D]
   void* d_y = nullptr;         // qmps_overlap_gradient: LEFT fixed points [max_batch][D][D] (lazy)
   int64_t grad_warm_T = 0;     // d_r / d_y hold the fixed points of this many trajectories' iterates (qmps_overlap_gradient)

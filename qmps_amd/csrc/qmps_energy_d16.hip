@@ -56,7 +56,10 @@ __global__ __launch_bounds__(256) void energy_mfma_d16_kernel(LaneArgs p) {
   double2* sT = sT_all[wave];
   const double tol2 = p.tol * p.tol;
   if (p.acc_zero != nullptr && blockIdx.x == 0) acc_clear(p.acc_zero, p.n_terms, threadIdx.x, 256);   // accumulator of a later step
+  if (p.only_pending && __hip_atomic_load(p.kry_counter + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // finishing pass with nothing to finish
   for (int64_t b = (int64_t)blockIdx.x * WAVES + wave; b < p.B; b += (int64_t)gridDim.x * WAVES) {
+    if (p.only_pending && p.status[b] != QMPS_ST_PENDING) continue;      // finishing pass: only what the Krylov fall-back solved
+    const int iters0 = p.only_pending ? p.iters[b] : 0;
     // A_s in A-layout (and the negated imaginary part, MFMA has no operand negation for f64)
     double are[2][4], aim[2][4], aimn[2][4];
     const double2* Ab = (const double2*)p.A + b * (2 * D * D);
@@ -94,7 +97,8 @@ __global__ __launch_bounds__(256) void energy_mfma_d16_kernel(LaneArgs p) {
         r.im[q] = 0.0;
       }
     }
-    int iters = 0, status = SOLVE ? QMPS_ST_NOT_CONVERGED : QMPS_ST_OK;
+    int iters = 0, status = SOLVE ? QMPS_ST_NOT_CONVERGED : QMPS_ST_OK, k_ref = 0;
+    float l_ref = 0.0f;
     for (int k = 1; SOLVE && k <= p.max_iter; ++k) {
       C4 n;
       n.re = (v4f64){0, 0, 0, 0};
@@ -150,7 +154,13 @@ __global__ __launch_bounds__(256) void energy_mfma_d16_kernel(LaneArgs p) {
         status = QMPS_ST_OK;
         break;
       }
+      // a long tail ahead (|lambda_2| close to 1): hand the evaluation to the Krylov fall-back (status PENDING, r in r_out)
+      if (k < p.max_iter && p.kry_counter != nullptr && power_gives_up(k, d2, tol2, p.krylov_after, k_ref, l_ref)) {
+        status = QMPS_ST_PENDING;
+        break;
+      }
     }
+    const bool given = SOLVE && status == QMPS_ST_PENDING;
     if (SOLVE && p.r_out != nullptr) {
       double2* ro = (double2*)p.r_out + b * (D * D);
 #pragma unroll
@@ -261,14 +271,23 @@ __global__ __launch_bounds__(256) void energy_mfma_d16_kernel(LaneArgs p) {
             const double2 hv = h[s * 4 + t], rv = sT[t * 4 + s];
             e += hv.x * rv.x - hv.y * rv.y;
           }
+        if (given) continue;       // (its energy - and its arrival at the accumulator - come from the finishing pass)
         p.E[b * p.n_terms + q] = e;
         if (p.acc != nullptr) acc_arrive(p.acc, p.acc_shards, q, (unsigned)b, e, p.acc_bound, p.acc_scale);   // exact in-kernel cost
       }
-      if (SOLVE) p.iters[b] = iters;
+      if (SOLVE) p.iters[b] = iters0 + iters;
       if (SOLVE || p.check_pd) p.status[b] = status;
+      if (given) atomicAdd(p.kry_counter + 2, 1);
     }
-    if (p.rho_out != nullptr && lane < 16) ((double2*)p.rho_out)[b * 16 + lane] = sT[lane];
+    if (p.rho_out != nullptr && lane < 16 && !given) ((double2*)p.rho_out)[b * 16 + lane] = sT[lane];
     __builtin_amdgcn_wave_barrier();
+  }
+  if (p.only_pending) {        // the last workgroup of a finishing pass clears its counters (see OverlapArgs::kry_counter)
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(p.kry_counter + 4, 1) == (int)gridDim.x - 1) {
+      __hip_atomic_store(p.kry_counter + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.kry_counter + 4, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -289,7 +308,10 @@ __global__ __launch_bounds__(128) void energy_mfma_d16x2_kernel(LaneArgs p) {
   double2* sT = sT_all[wave];
   const double tol2 = p.tol * p.tol;
   if (p.acc_zero != nullptr && blockIdx.x == 0) acc_clear(p.acc_zero, p.n_terms, threadIdx.x, 128);   // accumulator of a later step
+  if (p.only_pending && __hip_atomic_load(p.kry_counter + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // finishing pass with nothing to finish
   for (int64_t b = blockIdx.x; b < p.B; b += gridDim.x) {
+    if (p.only_pending && p.status[b] != QMPS_ST_PENDING) continue;      // (uniform over the workgroup; no LDS touched)
+    const int iters0 = p.only_pending ? p.iters[b] : 0;
     // A_s in A-layout (and the negated imaginary part, MFMA has no operand negation for f64)
     double are[2][4], aim[2][4], aimn[2][4];
     const double2* Ab = (const double2*)p.A + b * (2 * D * D);
@@ -327,7 +349,8 @@ __global__ __launch_bounds__(128) void energy_mfma_d16x2_kernel(LaneArgs p) {
         r.im[q] = 0.0;
       }
     }
-    int iters = 0, status = SOLVE ? QMPS_ST_NOT_CONVERGED : QMPS_ST_OK;
+    int iters = 0, status = SOLVE ? QMPS_ST_NOT_CONVERGED : QMPS_ST_OK, k_ref = 0;
+    float l_ref = 0.0f;
     for (int k = 1; SOLVE && k <= p.max_iter; ++k) {
       C4 n;
       n.re = (v4f64){0, 0, 0, 0};
@@ -397,7 +420,13 @@ __global__ __launch_bounds__(128) void energy_mfma_d16x2_kernel(LaneArgs p) {
         status = QMPS_ST_OK;
         break;
       }
+      // a long tail ahead (|lambda_2| close to 1): hand the evaluation to the Krylov fall-back (status PENDING, r in r_out)
+      if (k < p.max_iter && p.kry_counter != nullptr && power_gives_up(k, d2, tol2, p.krylov_after, k_ref, l_ref)) {
+        status = QMPS_ST_PENDING;
+        break;
+      }
     }
+    const bool given = SOLVE && status == QMPS_ST_PENDING;
     if (SOLVE && p.r_out != nullptr && wave == 0) {
       double2* ro = (double2*)p.r_out + b * (D * D);
 #pragma unroll
@@ -508,14 +537,22 @@ __global__ __launch_bounds__(128) void energy_mfma_d16x2_kernel(LaneArgs p) {
             const double2 hv = h[s * 4 + t], rv = sRho[t * 4 + s];
             e += hv.x * rv.x - hv.y * rv.y;
           }
+        if (given) continue;       // (its energy - and its arrival at the accumulator - come from the finishing pass)
         p.E[b * p.n_terms + q] = e;
         if (p.acc != nullptr) acc_arrive(p.acc, p.acc_shards, q, (unsigned)b, e, p.acc_bound, p.acc_scale);   // exact in-kernel cost
       }
-      if (SOLVE) p.iters[b] = iters;
+      if (SOLVE) p.iters[b] = iters0 + iters;
       if (SOLVE || p.check_pd) p.status[b] = status;
+      if (given) atomicAdd(p.kry_counter + 2, 1);
     }
-    if (p.rho_out != nullptr && wave == 0 && lane < 16) ((double2*)p.rho_out)[b * 16 + lane] = sRho[lane];
+    if (p.rho_out != nullptr && wave == 0 && lane < 16 && !given) ((double2*)p.rho_out)[b * 16 + lane] = sRho[lane];
     __syncthreads();
+  }
+  if (p.only_pending) {        // the last workgroup of a finishing pass clears its counters
+    if (threadIdx.x == 0 && atomicAdd(p.kry_counter + 4, 1) == (int)gridDim.x - 1) {
+      __hip_atomic_store(p.kry_counter + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.kry_counter + 4, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -525,6 +562,11 @@ hipError_t launch_energy_mfma(int D, const LaneArgs& a, bool solve, hipStream_t 
   // measured: B = 96: 0.210 ms against 0.287 with one wave per evaluation; B = 768: 0.325 against 0.318 (the exchange through LDS
   // and its two barriers per step cost what the shorter chain saves once every SIMD has a wave anyway)
   static const int64_t split_below = tuning_knob("QMPS_D16_SPLIT_BELOW") ? atoll(tuning_knob("QMPS_D16_SPLIT_BELOW")) : 512;   // A/B knob
+  if (solve && a.only_pending) {
+    // finishing pass behind the Krylov fall-back: a handful of evaluations at most; every workgroup looks at the pending count first
+    hipLaunchKernelGGL(energy_mfma_d16x2_kernel<true>, dim3((unsigned)(a.B < 512 ? a.B : 512)), dim3(128), 0, st, a);
+    return hipGetLastError();
+  }
   if (solve && a.B <= split_below) {
     // few evaluations: two waves per evaluation (half the dependent MFMA chain per wave)
     hipLaunchKernelGGL(energy_mfma_d16x2_kernel<true>, dim3((unsigned)(a.B < 8192 ? a.B : 8192)), dim3(128), 0, st, a);

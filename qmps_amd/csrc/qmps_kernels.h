@@ -5,7 +5,8 @@
 
 namespace qmps {
 
-enum { QMPS_ST_OK = 0, QMPS_ST_NOT_CONVERGED = 1, QMPS_ST_NOT_PD = 2 };
+enum { QMPS_ST_OK = 0, QMPS_ST_NOT_CONVERGED = 1, QMPS_ST_NOT_PD = 2,
+       QMPS_ST_PENDING = 3 /* internal, between the kernels of one launch: handed to the Krylov fall-back (D = 16 environment) */ };
 
 // Kernel arguments of the energy kernels (zero-initialise, then fill) (all pointers are HBM addresses).
 struct LaneArgs {
@@ -51,6 +52,14 @@ struct LaneArgs {
   const int* ans_i;           // device pointer to the index of the parameter being updated (ans_nsh > 0)
   int ans_P, ans_kind, ans_nsh;
   int direct;                 // D = 2 lane kernel: QMPS_ENV_DIRECT (4 x 4 fixed-point solve in the lane, then the squaring tail)
+  // D = 16 environment: Krylov fall-back (qmps_overlap_krylov.hip, env_mode).  The power iteration hands an evaluation over
+  // (status PENDING, iterate in r_out, no energy written) once its residual history predicts more than krylov_after further steps;
+  // the fall-back replaces r_out by the fixed point; a FINISHING pass of the same kernel (only_pending = 1, r_in = that buffer)
+  // accepts it by its own test and writes energy, status, iterations.  kry_counter: [0..2] as OverlapArgs, [3] evaluations pending
+  // (counted by the fall-back), [4] exit tickets of the finishing pass - all zero between launches.
+  int krylov_after;
+  int* kry_counter;
+  int only_pending;
 };
 
 // D = 8 direct fixed-point solve, one wave per evaluation: writes the environments r[B][8][8] (the warm start / result
@@ -190,6 +199,8 @@ struct OverlapArgs {
   // Krylov fall-back (D = 8, 16; qmps_overlap_krylov.hip): the power kernels GIVE A CANDIDATE UP (status 1, steps used < max_rounds,
   // iterate in r_out - which must then be non-null) as soon as its residual history predicts more than `krylov_after` further
   // steps (or after 4 krylov_after steps in all); launch_overlap_d / _pair_* then run overlap_krylov_kernel over the batch.
+  int env_mode;                // 1 (D = 16): the ENVIRONMENT map r -> sum_{s<2} B_s r B_s^+ of the tensors Bt (A, WW unused); candidates with status
+                               //   PENDING are solved, the fixed point is rotated to a positive trace, status stays PENDING (see LaneArgs), eta is not written
   int krylov_after;            // 0: plain power method to max_rounds (QMPS_NO_KRYLOV)
   int* kry_counter;            // the fall-back's three counters [work, exit tickets, candidates given up] - zero between launches (the
                                //   power kernels count what they give up, the fall-back clears all three when it is done); null = no fall-back

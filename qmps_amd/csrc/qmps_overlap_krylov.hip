@@ -344,7 +344,10 @@ __device__ __forceinline__ void overlap_krylov_body(const OverlapArgs& p, int* c
     for (int64_t b = base; b < base + CHUNK && b < p.B; ++b) {
       if (overlap_skipped(p, b)) continue;
       const int used = p.iters[b];
-      if (p.status[b] != QMPS_ST_NOT_CONVERGED || used + KM + 1 > p.max_rounds) continue;      // (uniform over the workgroup)
+      const bool env = D == 16 && p.env_mode != 0;
+      if (p.status[b] != (env ? QMPS_ST_PENDING : QMPS_ST_NOT_CONVERGED)) continue;      // (uniform over the workgroup)
+      if (env && tid == 0) atomicAdd(counter + 3, 1);       // one more evaluation for the finishing pass of the energy kernel
+      if (used + KM + 1 > p.max_rounds) continue;
       __syncthreads();
       const int64_t slot_off = overlap_slot_offset(p);
       const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * (2 * N);
@@ -370,6 +373,17 @@ __device__ __forceinline__ void overlap_krylov_body(const OverlapArgs& p, int* c
           }
         };
         const int t1 = wave >> 1, t2 = wave & 1;
+        if (env) {
+          // the environment map r -> sum_{s<2} B_s r B_s^+ : waves 0, 1 hold C_w = B_w (A-layout) and B_w^+ (B-layout = conj of the A-layout), waves 2, 3 nothing
+          if (wave < 2) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const double2 v = Bp[(wave * D + c) * D + 4 * kk + g];
+              cre[kk] = v.x; cim[kk] = v.y;
+              bre[kk] = v.x; bimn[kk] = -v.y;
+            }
+          }
+        } else {
         double pa[4], pai[4], pb[4], pbi[4];
         v4f64 qa, qai, qb, qbi;
 #pragma unroll
@@ -413,6 +427,7 @@ __device__ __forceinline__ void overlap_krylov_body(const OverlapArgs& p, int* c
           for (int kk = 0; kk < 4; ++kk) { cre[kk] = sr[kk]; cim[kk] = -si[kk]; }
         } else {
           to_a_layout(sr, si, cre, cim);
+        }
         }
         __syncthreads();
       } else {
@@ -653,7 +668,16 @@ __device__ __forceinline__ void overlap_krylov_body(const OverlapArgs& p, int* c
         }
       }
       // ================= results =================
-      {
+      if (env) {
+        // the environment is Hermitian positive: rotate the Ritz vector to a positive trace; the energy kernel's finishing pass
+        // (status stays PENDING) hermitises, accepts by its own test and writes energy / status
+        const bool diag = has && e_row == e_col;
+        double v[4] = {diag ? uv.x : 0.0, diag ? uv.y : 0.0, 0.0, 0.0};
+        block_sum4(v);
+        const double t = __builtin_sqrt(v[0] * v[0] + v[1] * v[1]), pr = t > 0.0 ? v[0] / t : 1.0, pi = t > 0.0 ? -v[1] / t : 0.0;
+        if (has) xio[e_row * D + e_col] = make_double2(uv.x * pr - uv.y * pi, uv.x * pi + uv.y * pr);
+        if (tid == 0) p.iters[b] = applications;
+      } else {
         double v[4] = {dfma(uv.x, uv.x, uv.y * uv.y), 0.0, 0.0, 0.0};
         block_sum4(v);
         const double inv = v[0] > 0.0 ? 1.0 / __builtin_sqrt(v[0]) : 0.0;

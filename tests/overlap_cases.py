@@ -68,3 +68,19 @@ def dominant(A, B, WW):
     w = np.linalg.eigvals(dense_map(A, B, WW))
     w = w[np.argsort(-np.abs(w))]
     return w[0], abs(w[1]) / abs(w[0])
+
+
+def slow_environment_tensor(rng, D, t):
+    """A left-isometric state tensor (2, D, D) whose transfer map has |lambda_2| = 1 - O(t^2): the direct sum of two sectors of
+    bond dimension D/2 (two fixed points) behind a random gauge, its unitary then kicked by exp(t K) - the sectors couple weakly.
+    t = 0.3 / 0.1 / 0.03 / 0.01 give |lambda_2| ~ 0.997 / 0.9997 / 0.99996 / 0.999997."""
+    d = D // 2
+    U1, U2 = O.haar_unitaries(rng, 2 * d, 2)
+    A = np.zeros((2, D, D), dtype=complex)
+    A[:, :d, :d] = O.unitary_to_tensor(U1)
+    A[:, d:, d:] = O.unitary_to_tensor(U2)
+    G = O.haar_unitaries(rng, D, 1)[0]
+    A = np.einsum('ij,sjk,lk->sil', G, A, G.conj())
+    K = rng.standard_normal((2 * D, 2 * D)) + 1j * rng.standard_normal((2 * D, 2 * D))
+    K = K - K.conj().T
+    return O.unitary_to_tensor((expm(t * K / np.linalg.norm(K)) @ O.tensor_to_unitary(A))[None])[0]

@@ -261,3 +261,36 @@ def test_d4_scaled_tensors_inside_the_documented_range(engine_factory):
         assert np.all(st2 == 0) and np.isfinite(E2).all()
         assert np.abs(eng.environments() - r1).max() < 1e-10
         assert np.abs(E2 / scale ** 4 - E1).max() < 1e-9
+
+
+def test_d16_environment_krylov_fallback(engine_factory, monkeypatch):
+    """D = 16 environment (qmps/tools.py:176-182 - the reference: TransferMatrix(A).eigs(), ARPACK): state tensors whose transfer map
+    has |lambda_2| = 1 - 3e-3 .. 1 - 3e-6 (tests/overlap_cases.py) cost the power iteration ~ 30 / (1 - |lambda_2|) steps; the
+    Krylov fall-back finishes every one of them within a few hundred map applications, energies within 1e-10 of the dense
+    eigen-solve; QMPS_NO_KRYLOV runs the power iteration alone - same energies where it converges, status 1 at the same cap where not."""
+    import overlap_cases as OC
+    rng = np.random.default_rng(160)
+    h = np.stack([O.hamiltonian_matrix({'ZZ': -1, 'X': 1}), O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})])
+    A = np.stack([OC.slow_environment_tensor(rng, 16, t) for t in (0.3, 0.3, 0.1, 0.1, 0.03, 0.03, 0.01, 0.01)]
+                 + list(O.unitary_to_tensor(O.haar_unitaries(rng, 32, 4))))
+    ref = np.array([[O.energy_closed_form(a, hh) for hh in h] for a in A])      # dense eigen-solve of the environment
+    eng = engine_factory(16, 64)
+    E, it, st = eng.energies(A, h, max_iter=3000, tol=1e-13)
+    assert np.all(st == 0), (st, it)
+    assert it.max() <= 1000, it
+    assert np.abs(E - ref).max() < E_TOL, np.abs(E - ref).max()
+    r = eng.environments()
+    for b in range(len(A)):
+        rr = r[b] / np.trace(r[b])
+        assert np.abs(rr - rr.conj().T).max() < 1e-12 and np.abs(O.apply_transfer(A[b], rr) - rr).max() < 1e-11
+    # the exact in-kernel cost accumulation receives the late arrivals of the finishing pass
+    eng.set_tensors(A)
+    eng.set_hamiltonian(h)
+    eng.launch(len(A), max_iter=3000, accumulate_cost=True)
+    eng.cost_launch(len(A))
+    assert np.abs(eng.get_cost() - ref.sum(axis=0)).max() < 1e-9
+    monkeypatch.setenv('QMPS_NO_KRYLOV', '1')
+    E2, it2, st2 = eng.energies(A, h, max_iter=3000, tol=1e-13)
+    monkeypatch.delenv('QMPS_NO_KRYLOV')
+    assert (st2 == 1).sum() >= 4 and np.all(it2[st2 == 1] == 3000)         # the slow ones exhaust the cap without it
+    assert np.abs(E2 - ref)[st2 == 0].max() < E_TOL

@@ -145,6 +145,10 @@ typedef struct qmps_ctx qmps_ctx;
 /* ---- library / device ------------------------------------------------------------------ */
 int qmps_abi_version(void);
 const char* qmps_last_error(void);
+/* Test hook for the contract above ("nothing throws across the ABI"): raises a C++ exception inside the library - kind 1
+ * std::bad_alloc, 2 std::length_error (a vector of absurd size), 3 a foreign type - behind the same function-try-block every entry
+ * point is wrapped in; returns QMPS_ERR_ARG with a message in qmps_last_error().  kind 0: QMPS_OK.  Needs no device. */
+int qmps_selftest_exception(int kind);
 /* number of visible HIP devices (0 and QMPS_OK when there are none / no driver) */
 int qmps_device_count(int* count);
 /* name / arch / CU count / HBM bytes of a device; name buffers are caller-owned */

@@ -34,6 +34,7 @@ _ip = POINTER(c_int32)
 # name -> (restype, argtypes): every entry point declared in include/qmps_hip.h
 SIGNATURES = {
     'qmps_abi_version': (c_int, []),
+    'qmps_selftest_exception': (c_int, [c_int]),
     'qmps_last_error': (c_char_p, []),
     'qmps_device_count': (c_int, [POINTER(c_int)]),
     'qmps_device_info': (c_int, [c_int, c_char_p, c_int, c_char_p, c_int, POINTER(c_int), POINTER(c_int64)]),

@@ -206,7 +206,17 @@ int qmps_abi_version(void) { return QMPS_ABI_VERSION; }
 
 const char* qmps_last_error(void) { return g_err; }
 
-int qmps_device_count(int* count) {
+// test hook for the "nothing throws across the ABI" contract (tests/test_cabi.py; needs no device): raises the exception a host
+// allocation of absurd size would raise, inside the same function-try-block every other entry point has
+int qmps_selftest_exception(int kind) try {
+  if (kind == 1) throw std::bad_alloc();
+  if (kind == 2) { std::vector<double> v; v.resize(v.max_size() + 1); return (int)v.size(); }     // std::length_error
+  if (kind == 3) throw 42;
+  return QMPS_OK;
+}
+QMPS_API_CATCH
+
+int qmps_device_count(int* count) try {
   if (!count) return fail(QMPS_ERR_ARG, "null count");
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -217,9 +227,10 @@ int qmps_device_count(int* count) {
   *count = n;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 int qmps_device_info(int device, char* name, int name_len, char* arch, int arch_len, int* compute_units,
-                     int64_t* hbm_bytes) {
+                     int64_t* hbm_bytes) try {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   if (name && name_len > 0) snprintf(name, name_len, "%s", prop.name);
@@ -228,8 +239,9 @@ int qmps_device_info(int device, char* name, int name_len, char* arch, int arch_
   if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
+int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) try {
   if (!out) return fail(QMPS_ERR_ARG, "null out");
   *out = nullptr;
   if (D != 2 && D != 4 && D != 8 && D != 16) return fail(QMPS_ERR_ARG, "bond dimension D=%d not in {2,4,8,16}", D);
@@ -309,8 +321,9 @@ int qmps_create(int device, int D, int64_t max_batch, qmps_ctx** out) {
   *out = c;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_destroy(qmps_ctx* c) {
+int qmps_destroy(qmps_ctx* c) try {
   if (!c) return QMPS_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -325,6 +338,8 @@ int qmps_destroy(qmps_ctx* c) {
     if (c->cost_reduced[i]) (void)hipEventDestroy(c->cost_reduced[i]);
   }
   if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+  for (hipEvent_t e : c->active_ev)
+    if (e) (void)hipEventDestroy(e);
   if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
   if (c->aux_join) (void)hipEventDestroy(c->aux_join);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
@@ -345,8 +360,9 @@ int qmps_destroy(qmps_ctx* c) {
   delete c;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_sync(qmps_ctx* c) {
+int qmps_sync(qmps_ctx* c) try {
   if (int rc = bind(c)) return rc;
   if (int rc = close_group(c)) return rc;     // costs still waiting for their exchange go out now
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -354,8 +370,9 @@ int qmps_sync(qmps_ctx* c) {
   HIP_TRY(hipStreamSynchronize(c->comm_stream2));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_set_states(qmps_ctx* c, int64_t B, const double* states, int kind) {
+int qmps_set_states(qmps_ctx* c, int64_t B, const double* states, int kind) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;
   if (!states && B > 0) return fail(QMPS_ERR_ARG, "null states");
@@ -378,16 +395,18 @@ int qmps_set_states(qmps_ctx* c, int64_t B, const double* states, int kind) {
   c->tensors_valid = true;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_set_window(qmps_ctx* c, int64_t first) {
+int qmps_set_window(qmps_ctx* c, int64_t first) try {
   if (!c) return fail(QMPS_ERR_ARG, "null context");
   if (first < 0 || first > c->n_states) return fail(QMPS_ERR_ARG, "window start %lld outside the %lld resident states", (long long)first, (long long)c->n_states);
   c->window = first;
   c->partials_B = -1;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_set_states_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const double* params) {
+int qmps_set_states_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const double* params) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;
   if (!params && B > 0) return fail(QMPS_ERR_ARG, "null params");
@@ -421,8 +440,9 @@ int qmps_set_states_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const
   c->have_env = false;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_set_states_su(qmps_ctx* c, int64_t B, const double* params) {
+int qmps_set_states_su(qmps_ctx* c, int64_t B, const double* params) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;
   if (!params && B > 0) return fail(QMPS_ERR_ARG, "null params");
@@ -444,24 +464,28 @@ int qmps_set_states_su(qmps_ctx* c, int64_t B, const double* params) {
   c->tensors_valid = true;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 int qmps_energy_batch_su(qmps_ctx* c, int64_t B, const double* params, const double* h, int n_terms, int max_iter, double tol,
-                         double* E_out, int32_t* iters_out, int32_t* status_out) {
+                         double* E_out, int32_t* iters_out, int32_t* status_out) try {
   if (!c) return fail(QMPS_ERR_ARG, "null context");
   if (!E_out) return fail(QMPS_ERR_ARG, "null E_out");
-  c->defer_sync = true;
-  int rc = qmps_set_states_su(c, B, params);
-  if (!rc) rc = qmps_set_hamiltonian(c, n_terms, h);
-  if (!rc) rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver);
-  c->defer_sync = false;
+  int rc;
+  {
+    Restore<bool> deferred(c->defer_sync, true);
+    rc = qmps_set_states_su(c, B, params);
+    if (!rc) rc = qmps_set_hamiltonian(c, n_terms, h);
+    if (!rc) rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver);
+  }
   if (rc) {
     (void)hipStreamSynchronize(c->stream);
     return rc;
   }
   return qmps_get_energies(c, B, E_out, iters_out, status_out);
 }
+QMPS_API_CATCH
 
-int qmps_su_unitaries(qmps_ctx* c, int64_t B, int N, const double* params, double* U_out) {
+int qmps_su_unitaries(qmps_ctx* c, int64_t B, int N, const double* params, double* U_out) try {
   if (int rc = bind(c)) return rc;
   if (B < 0 || !params || !U_out) return fail(QMPS_ERR_ARG, "bad arguments");
   if (N != 4 && N != 8 && N != 16 && N != 32) return fail(QMPS_ERR_ARG, "N=%d not in {4, 8, 16, 32}", N);
@@ -475,6 +499,7 @@ int qmps_su_unitaries(qmps_ctx* c, int64_t B, int N, const double* params, doubl
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 namespace {
 int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter, double tol,
@@ -482,14 +507,16 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
 }
 
 int qmps_rotosolve(qmps_ctx* c, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter,
-                   double tol, double* E_hist) {
+                   double tol, double* E_hist) try {
   return rotosolve_impl(c, R, kind, n_params, params, n_sweeps, max_iter, tol, E_hist, 3);
 }
+QMPS_API_CATCH
 
 int qmps_double_rotosolve(qmps_ctx* c, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter,
-                          double tol, double* E_hist) {
+                          double tol, double* E_hist) try {
   return rotosolve_impl(c, R, kind, n_params, params, n_sweeps, max_iter, tol, E_hist, 6);
 }
+QMPS_API_CATCH
 
 namespace {
 int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter, double tol,
@@ -704,7 +731,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
 }
 }  // namespace
 
-int qmps_get_states(qmps_ctx* c, int64_t B, double* A) {
+int qmps_get_states(qmps_ctx* c, int64_t B, double* A) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;
   if (!A) return fail(QMPS_ERR_ARG, "null A");
@@ -714,8 +741,9 @@ int qmps_get_states(qmps_ctx* c, int64_t B, double* A) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_set_hamiltonian(qmps_ctx* c, int n_terms, const double* h) {
+int qmps_set_hamiltonian(qmps_ctx* c, int n_terms, const double* h) try {
   if (int rc = bind(c)) return rc;
   if (n_terms < 1 || n_terms > kMaxTerms) return fail(QMPS_ERR_ARG, "n_terms=%d outside [1,%d]", n_terms, kMaxTerms);
   if (!h) return fail(QMPS_ERR_ARG, "null h");
@@ -732,8 +760,9 @@ int qmps_set_hamiltonian(qmps_ctx* c, int n_terms, const double* h) {
   c->n_terms = n_terms;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_set_env_guess(qmps_ctx* c, int64_t B, const double* r0) {
+int qmps_set_env_guess(qmps_ctx* c, int64_t B, const double* r0) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;
   c->window = 0;
@@ -746,10 +775,12 @@ int qmps_set_env_guess(qmps_ctx* c, int64_t B, const double* r0) {
   c->have_guess = true;
   c->have_env = true;
   c->have_overlap_x = false;
+  c->grad_warm_T = 0;          // d_r no longer holds the right fixed points of a gradient batch
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int flags) {
+int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int flags) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_window(c, B)) return rc;
   if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
@@ -935,44 +966,50 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   c->have_env = true;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_set_kernel_timing_period(qmps_ctx* c, int period) {
+int qmps_set_kernel_timing_period(qmps_ctx* c, int period) try {
   if (!c) return fail(QMPS_ERR_ARG, "null context");
   if (period < 0) return fail(QMPS_ERR_ARG, "period must be >= 0");
   c->timing_period = period;
   c->samples = 0;          // earlier samples belong to another schedule
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_set_handoff(qmps_ctx* c, int handoff) {
+int qmps_set_handoff(qmps_ctx* c, int handoff) try {
   if (!c) return fail(QMPS_ERR_ARG, "null context");
   if (handoff < 0) return fail(QMPS_ERR_ARG, "handoff must be >= 0");
   c->handoff = handoff;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_set_default_solver(qmps_ctx* c, int solver) {
+int qmps_set_default_solver(qmps_ctx* c, int solver) try {
   if (!c) return fail(QMPS_ERR_ARG, "null context");
   if (solver != QMPS_ENV_POWER && solver != QMPS_ENV_POWER_SQUARING && solver != QMPS_ENV_DIRECT)
     return fail(QMPS_ERR_ARG, "unknown solver %d", solver);
   c->default_solver = solver;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_get_handoff(qmps_ctx* c, int* handoff) {
+int qmps_get_handoff(qmps_ctx* c, int* handoff) try {
   if (!c || !handoff) return fail(QMPS_ERR_ARG, "null argument");
   *handoff = c->handoff;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_get_squaring_schedule(qmps_ctx* c, int* skip_rounds, int* matvec_period) {
+int qmps_get_squaring_schedule(qmps_ctx* c, int* skip_rounds, int* matvec_period) try {
   if (!c || !skip_rounds || !matvec_period) return fail(QMPS_ERR_ARG, "null argument");
   *skip_rounds = c->skip_rounds;
   *matvec_period = c->D == 4 ? c->matvec_period : 0;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_energy_only_launch(qmps_ctx* c, int64_t B) {
+int qmps_energy_only_launch(qmps_ctx* c, int64_t B) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_window(c, B)) return rc;
   if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
@@ -991,6 +1028,7 @@ int qmps_energy_only_launch(qmps_ctx* c, int64_t B) {
     HIP_TRY(qmps::launch_energy(c->D, a, false, c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 static int sum_on_device(qmps_ctx* c, int64_t B) {
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
@@ -999,7 +1037,7 @@ static int sum_on_device(qmps_ctx* c, int64_t B) {
   return QMPS_OK;
 }
 
-int qmps_sum_energies(qmps_ctx* c, int64_t B, double* cost) {
+int qmps_sum_energies(qmps_ctx* c, int64_t B, double* cost) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_window(c, B)) return rc;
   if (!cost) return fail(QMPS_ERR_ARG, "null cost");
@@ -1009,8 +1047,9 @@ int qmps_sum_energies(qmps_ctx* c, int64_t B, double* cost) {
   memcpy(cost, c->h_cost, c->n_terms * sizeof(double));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_get_energies(qmps_ctx* c, int64_t B, double* E, int32_t* iters, int32_t* status) {
+int qmps_get_energies(qmps_ctx* c, int64_t B, double* E, int32_t* iters, int32_t* status) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_window(c, B)) return rc;
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
@@ -1020,8 +1059,9 @@ int qmps_get_energies(qmps_ctx* c, int64_t B, double* E, int32_t* iters, int32_t
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_get_status(qmps_ctx* c, int64_t B, int32_t* status) {
+int qmps_get_status(qmps_ctx* c, int64_t B, int32_t* status) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_window(c, B)) return rc;
   if (!status) return fail(QMPS_ERR_ARG, "null status");
@@ -1029,8 +1069,9 @@ int qmps_get_status(qmps_ctx* c, int64_t B, int32_t* status) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_get_env(qmps_ctx* c, int64_t B, double* r) {
+int qmps_get_env(qmps_ctx* c, int64_t B, double* r) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_window(c, B)) return rc;
   if (!r) return fail(QMPS_ERR_ARG, "null r");
@@ -1039,8 +1080,9 @@ int qmps_get_env(qmps_ctx* c, int64_t B, double* r) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_get_rdm(qmps_ctx* c, int64_t B, double* rho) {
+int qmps_get_rdm(qmps_ctx* c, int64_t B, double* rho) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_window(c, B)) return rc;
   if (!rho) return fail(QMPS_ERR_ARG, "null rho");
@@ -1055,10 +1097,11 @@ int qmps_get_rdm(qmps_ctx* c, int64_t B, double* rho) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 int qmps_energy_batch(qmps_ctx* c, int64_t B, const double* states, int kind, const double* h, int n_terms,
                       const double* r0, int max_iter, double tol, double* E_out, int32_t* iters_out,
-                      int32_t* status_out) {
+                      int32_t* status_out) try {
   if (!E_out) return fail(QMPS_ERR_ARG, "null E_out");
   if (int rc = qmps_set_states(c, B, states, kind)) return rc;
   if (int rc = qmps_set_hamiltonian(c, n_terms, h)) return rc;
@@ -1066,27 +1109,31 @@ int qmps_energy_batch(qmps_ctx* c, int64_t B, const double* states, int kind, co
   if (int rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver)) return rc;
   return qmps_get_energies(c, B, E_out, iters_out, status_out);
 }
+QMPS_API_CATCH
 
 int qmps_energy_batch_ansatz(qmps_ctx* c, int64_t B, int ansatz_kind, int n_params, const double* params, const double* h,
-                             int n_terms, int max_iter, double tol, double* E_out, int32_t* iters_out, int32_t* status_out) {
+                             int n_terms, int max_iter, double tol, double* E_out, int32_t* iters_out, int32_t* status_out) try {
   if (!c) return fail(QMPS_ERR_ARG, "null context");
   if (!E_out) return fail(QMPS_ERR_ARG, "null E_out");
   // the host buffers stay the caller's until this function returns: the copies in may stay in flight until the ONE
   // synchronisation of the read-back (a scalar objective call is all latency: three round trips -> one)
-  c->defer_sync = true;
-  int rc = qmps_set_states_ansatz(c, B, ansatz_kind, n_params, params);
-  if (!rc) rc = qmps_set_hamiltonian(c, n_terms, h);
-  if (!rc) rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver | ((c->D == 4 && c->default_solver == QMPS_ENV_DIRECT) ? QMPS_FLAG_NO_ENV_OUT : 0));
-  c->defer_sync = false;
+  int rc;
+  {
+    Restore<bool> deferred(c->defer_sync, true);
+    rc = qmps_set_states_ansatz(c, B, ansatz_kind, n_params, params);
+    if (!rc) rc = qmps_set_hamiltonian(c, n_terms, h);
+    if (!rc) rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver | ((c->D == 4 && c->default_solver == QMPS_ENV_DIRECT) ? QMPS_FLAG_NO_ENV_OUT : 0));
+  }
   if (rc) {
     (void)hipStreamSynchronize(c->stream);
     return rc;
   }
   return qmps_get_energies(c, B, E_out, iters_out, status_out);
 }
+QMPS_API_CATCH
 
 int qmps_env_batch(qmps_ctx* c, int64_t B, const double* states, int kind, const double* r0, int max_iter, double tol,
-                   double* r_out, int32_t* iters_out, int32_t* status_out) {
+                   double* r_out, int32_t* iters_out, int32_t* status_out) try {
   if (!r_out) return fail(QMPS_ERR_ARG, "null r_out");
   if (int rc = qmps_set_states(c, B, states, kind)) return rc;
   if (c->n_terms < 1) {
@@ -1100,9 +1147,10 @@ int qmps_env_batch(qmps_ctx* c, int64_t B, const double* states, int kind, const
   if (int rc = qmps_get_energies(c, B, nullptr, iters_out, status_out)) return rc;
   return qmps_get_env(c, B, r_out);
 }
+QMPS_API_CATCH
 
 int qmps_cell2_energy_batch(qmps_ctx* c, int64_t B, const double* U1, const double* U2, const double* h, int n_terms,
-                             int max_iter, double tol, double* E_out, int32_t* iters_out, int32_t* status_out) {
+                             int max_iter, double tol, double* E_out, int32_t* iters_out, int32_t* status_out) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;
   if (c->D != 2) return fail(QMPS_ERR_ARG, "the two-site unit cell path is D = 2 only (qmps/ground_state.py:276)");
@@ -1125,9 +1173,10 @@ int qmps_cell2_energy_batch(qmps_ctx* c, int64_t B, const double* U1, const doub
   c->have_env = false;
   return qmps_get_energies(c, B, E_out, iters_out, status_out);
 }
+QMPS_API_CATCH
 
 int qmps_cell2_energy_batch_su(qmps_ctx* c, int64_t B, const double* params, const double* h, int n_terms, int max_iter, double tol,
-                               double* E_out, int32_t* iters_out, int32_t* status_out) {
+                               double* E_out, int32_t* iters_out, int32_t* status_out) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;
   if (c->D != 2) return fail(QMPS_ERR_ARG, "the two-site unit cell path is D = 2 only (qmps/ground_state.py:276)");
@@ -1154,8 +1203,9 @@ int qmps_cell2_energy_batch_su(qmps_ctx* c, int64_t B, const double* params, con
   c->have_env = false;
   return qmps_get_energies(c, B, E_out, iters_out, status_out);
 }
+QMPS_API_CATCH
 
-int qmps_kernel_time(qmps_ctx* c, int n_last, float* avg_ms, char* name, int name_len) {
+int qmps_kernel_time(qmps_ctx* c, int n_last, float* avg_ms, char* name, int name_len) try {
   if (int rc = bind(c)) return rc;
   if (!avg_ms || n_last < 1) return fail(QMPS_ERR_ARG, "bad arguments");
   if (c->samples < 1) return fail(QMPS_ERR_STATE, "no timed energy launch yet (qmps_set_kernel_timing_period)");
@@ -1176,6 +1226,7 @@ int qmps_kernel_time(qmps_ctx* c, int n_last, float* avg_ms, char* name, int nam
   if (name && name_len > 0) snprintf(name, name_len, "%s", c->dominant);
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 namespace {
 // bump allocator over the scratch arena: copies a host array in, returns the device address
@@ -1192,7 +1243,7 @@ struct Arena {
 }  // namespace
 
 int qmps_bw_expval(qmps_ctx* c, int64_t B, int sites, const double* U1, const double* U2, const double* O, int o_shared,
-                   double* out) {
+                   double* out) try {
   if (int rc = bind(c)) return rc;
   if (B < 0 || !U1 || !U2 || !O || !out) return fail(QMPS_ERR_ARG, "bad arguments");
   if (sites != 2 && sites != 4) return fail(QMPS_ERR_ARG, "sites must be 2 or 4");
@@ -1213,10 +1264,11 @@ int qmps_bw_expval(qmps_ctx* c, int64_t B, int sites, const double* U1, const do
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 int qmps_bw_env(qmps_ctx* c, int64_t B, int side, const double* U1, const double* U2, const double* U1p,
                 const double* U2p, int max_rounds, double tol, double* mat_out, double* eta_out, double* vec_out,
-                int32_t* status_out) {
+                int32_t* status_out) try {
   if (int rc = bind(c)) return rc;
   if (B < 0 || !U1 || !U2 || !U1p || !U2p || !eta_out || !vec_out) return fail(QMPS_ERR_ARG, "bad arguments");
   if (side != 0 && side != 1) return fail(QMPS_ERR_ARG, "side must be 0 (right) or 1 (left)");
@@ -1243,9 +1295,10 @@ int qmps_bw_env(qmps_ctx* c, int64_t B, int side, const double* U1, const double
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 int qmps_bw_manifold(qmps_ctx* c, int64_t B, const double* U1, const double* U2, const double* U1p, const double* U2p,
-                     const double* Mr, const double* Ml, int m_shared, const double* W, int w_shared, double* out) {
+                     const double* Mr, const double* Ml, int m_shared, const double* W, int w_shared, double* out) try {
   if (int rc = bind(c)) return rc;
   if (B < 0 || !U1 || !U2 || !U1p || !U2p || !Mr || !Ml || !W || !out) return fail(QMPS_ERR_ARG, "bad arguments");
   const size_t mb = (m_shared ? 1 : (size_t)B) * 64, wb = (w_shared ? 1 : (size_t)B) * 4096;
@@ -1268,9 +1321,10 @@ int qmps_bw_manifold(qmps_ctx* c, int64_t B, const double* U1, const double* U2,
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 int qmps_opt_env_objective(qmps_ctx* c, int64_t B, const double* params, const double* h, double k, double* f_out,
-                           double* parts_out) {
+                           double* parts_out) try {
   if (int rc = bind(c)) return rc;
   if (B < 0 || !params || !h || !f_out) return fail(QMPS_ERR_ARG, "bad arguments");
   if (int rc = ensure_scratch(c, (size_t)B * (240 + 8 + 32) + 4096)) return rc;
@@ -1286,14 +1340,16 @@ int qmps_opt_env_objective(qmps_ctx* c, int64_t B, const double* params, const d
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_timer_begin(qmps_ctx* c) {
+int qmps_timer_begin(qmps_ctx* c) try {
   if (int rc = bind(c)) return rc;
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_timer_end(qmps_ctx* c, float* ms) {
+int qmps_timer_end(qmps_ctx* c, float* ms) try {
   if (int rc = bind(c)) return rc;
   if (!ms) return fail(QMPS_ERR_ARG, "null ms");
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -1301,9 +1357,10 @@ int qmps_timer_end(qmps_ctx* c, float* ms) {
   HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 // ---- RCCL ---------------------------------------------------------------------------------
-int qmps_comm_unique_id(char id[QMPS_UNIQUE_ID_BYTES]) {
+int qmps_comm_unique_id(char id[QMPS_UNIQUE_ID_BYTES]) try {
   if (!id) return fail(QMPS_ERR_ARG, "null id");
   static_assert(sizeof(ncclUniqueId) <= QMPS_UNIQUE_ID_BYTES, "ncclUniqueId larger than QMPS_UNIQUE_ID_BYTES");
   ncclUniqueId u;
@@ -1312,8 +1369,9 @@ int qmps_comm_unique_id(char id[QMPS_UNIQUE_ID_BYTES]) {
   memcpy(id, &u, sizeof(u));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_comm_init(qmps_ctx* c, const char id[QMPS_UNIQUE_ID_BYTES], int rank, int nranks) {
+int qmps_comm_init(qmps_ctx* c, const char id[QMPS_UNIQUE_ID_BYTES], int rank, int nranks) try {
   if (int rc = bind(c)) return rc;
   if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(QMPS_ERR_ARG, "bad communicator arguments");
   if (c->comm) return fail(QMPS_ERR_STATE, "communicator already initialised");
@@ -1342,8 +1400,9 @@ int qmps_comm_init(qmps_ctx* c, const char id[QMPS_UNIQUE_ID_BYTES], int rank, i
   c->nranks = nranks;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_comm_destroy(qmps_ctx* c) {
+int qmps_comm_destroy(qmps_ctx* c) try {
   if (int rc = bind(c)) return rc;
   if (c->comm) {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1358,16 +1417,18 @@ int qmps_comm_destroy(qmps_ctx* c) {
   }
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_comm_count(qmps_ctx* c, int* nranks) {
+int qmps_comm_count(qmps_ctx* c, int* nranks) try {
   if (int rc = bind(c)) return rc;
   if (!nranks) return fail(QMPS_ERR_ARG, "null nranks");
   *nranks = 1;
   if (c->comm) RCCL_TRY(ncclCommCount(c->comm, nranks));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_allreduce_sum(qmps_ctx* c, double* inout, int n) {
+int qmps_allreduce_sum(qmps_ctx* c, double* inout, int n) try {
   if (int rc = bind(c)) return rc;
   if (!inout || n < 1 || n > kMaxTerms) return fail(QMPS_ERR_ARG, "n=%d outside [1,%d]", n, kMaxTerms);
   if (!c->comm) return fail(QMPS_ERR_STATE, "qmps_comm_init has not been called");
@@ -1379,8 +1440,9 @@ int qmps_allreduce_sum(qmps_ctx* c, double* inout, int n) {
   memcpy(inout, c->h_cost, n * sizeof(double));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_allreduce_min(qmps_ctx* c, double* inout, int n) {
+int qmps_allreduce_min(qmps_ctx* c, double* inout, int n) try {
   if (int rc = bind(c)) return rc;
   if (!inout || n < 1 || n > kMaxTerms) return fail(QMPS_ERR_ARG, "n=%d outside [1,%d]", n, kMaxTerms);
   if (!c->comm) return fail(QMPS_ERR_STATE, "qmps_comm_init has not been called");
@@ -1392,6 +1454,7 @@ int qmps_allreduce_min(qmps_ctx* c, double* inout, int n) {
   memcpy(inout, c->h_cost, n * sizeof(double));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 }  // extern "C"
 namespace qmps_host {
@@ -1443,7 +1506,7 @@ int close_group(qmps_ctx* c) {
 }  // namespace qmps_host
 extern "C" {
 
-int qmps_exchange_stats(qmps_ctx* c, int64_t* checks, int64_t* blocked, double* blocked_ms, int reset) {
+int qmps_exchange_stats(qmps_ctx* c, int64_t* checks, int64_t* blocked, double* blocked_ms, int reset) try {
   if (!c) return fail(QMPS_ERR_ARG, "null context");
   if (checks) *checks = c->slot_checks;
   if (blocked) *blocked = c->slot_blocks;
@@ -1451,8 +1514,9 @@ int qmps_exchange_stats(qmps_ctx* c, int64_t* checks, int64_t* blocked, double* 
   if (reset) { c->slot_checks = 0; c->slot_blocks = 0; c->slot_block_ms = 0.0; }
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_set_exchange_period(qmps_ctx* c, int steps) {
+int qmps_set_exchange_period(qmps_ctx* c, int steps) try {
   if (!c) return fail(QMPS_ERR_ARG, "null context");
   if (steps < 1 || steps > qmps_ctx::kMaxGroup) return fail(QMPS_ERR_ARG, "exchange period must be in [1, %d]", qmps_ctx::kMaxGroup);
   if (int rc = bind(c)) return rc;
@@ -1460,8 +1524,9 @@ int qmps_set_exchange_period(qmps_ctx* c, int steps) {
   c->exchange_period = steps;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_cost_launch(qmps_ctx* c, int64_t B) {
+int qmps_cost_launch(qmps_ctx* c, int64_t B) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_window(c, B)) return rc;
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
@@ -1496,8 +1561,9 @@ int qmps_cost_launch(qmps_ctx* c, int64_t B) {
     if (int rc = close_group(c)) return rc;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_get_cost(qmps_ctx* c, double* cost) {
+int qmps_get_cost(qmps_ctx* c, double* cost) try {
   if (int rc = bind(c)) return rc;
   if (!cost) return fail(QMPS_ERR_ARG, "null cost");
   if (c->n_terms < 1) return fail(QMPS_ERR_STATE, "no energies resident");
@@ -1538,16 +1604,18 @@ int qmps_get_cost(qmps_ctx* c, double* cost) {
   memcpy(cost, c->h_cost, c->n_terms * sizeof(double));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_allreduce_cost(qmps_ctx* c, int64_t B, double* cost) {
+int qmps_allreduce_cost(qmps_ctx* c, int64_t B, double* cost) try {
   if (!c) return fail(QMPS_ERR_ARG, "null context");
   if (!c->comm) return fail(QMPS_ERR_STATE, "qmps_comm_init has not been called");
   if (int rc = qmps_cost_launch(c, B)) return rc;
   return qmps_get_cost(c, cost);
 }
+QMPS_API_CATCH
 
 // ---- probes -------------------------------------------------------------------------------
-int qmps_probe_fp64_peak(qmps_ctx* c, double* tflops) {
+int qmps_probe_fp64_peak(qmps_ctx* c, double* tflops) try {
   if (int rc = bind(c)) return rc;
   if (!tflops) return fail(QMPS_ERR_ARG, "null tflops");
   hipDeviceProp_t prop;
@@ -1569,8 +1637,9 @@ int qmps_probe_fp64_peak(qmps_ctx* c, double* tflops) {
   *tflops = flops / (best * 1e-3) * 1e-12;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_probe_fp64_mfma_peak(qmps_ctx* c, int waves_per_simd, double* tflops) {
+int qmps_probe_fp64_mfma_peak(qmps_ctx* c, int waves_per_simd, double* tflops) try {
   if (int rc = bind(c)) return rc;
   if (!tflops || waves_per_simd < 1 || waves_per_simd > 8) return fail(QMPS_ERR_ARG, "bad arguments");
   hipDeviceProp_t prop;
@@ -1592,8 +1661,9 @@ int qmps_probe_fp64_mfma_peak(qmps_ctx* c, int waves_per_simd, double* tflops) {
   *tflops = flops / (best * 1e-3) * 1e-12;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_probe_hbm_peak(qmps_ctx* c, double* gbps) {
+int qmps_probe_hbm_peak(qmps_ctx* c, double* gbps) try {
   if (int rc = bind(c)) return rc;
   if (!gbps) return fail(QMPS_ERR_ARG, "null gbps");
   const size_t bytes = (size_t)1 << 30;  // 1 GiB each way: well past the 256 MiB Infinity Cache
@@ -1623,5 +1693,6 @@ int qmps_probe_hbm_peak(qmps_ctx* c, double* gbps) {
   (void)hipFree(dst);
   return rc;
 }
+QMPS_API_CATCH
 
 }  // extern "C"

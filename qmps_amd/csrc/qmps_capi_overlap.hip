@@ -82,7 +82,7 @@ int launch_overlap_kernels(qmps_ctx* c, const qmps::OverlapArgs& a_in) {
 }
 }  // namespace
 
-int qmps_overlap_set(qmps_ctx* c, int64_t n_ref, const double* A, const double* WW) {
+int qmps_overlap_set(qmps_ctx* c, int64_t n_ref, const double* A, const double* WW) try {
   if (int rc = bind(c)) return rc;
   if (!A || !WW) return fail(QMPS_ERR_ARG, "null argument");
   if (n_ref < 1 || n_ref > c->max_batch) return fail(QMPS_ERR_ARG, "n_ref=%lld outside [1, max_batch]", (long long)n_ref);
@@ -95,8 +95,9 @@ int qmps_overlap_set(qmps_ctx* c, int64_t n_ref, const double* A, const double* 
   c->overlap_group = 0;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_overlap_set_refs_ansatz(qmps_ctx* c, int64_t n_ref, int kind, int n_params, const double* params, const double* WW) {
+int qmps_overlap_set_refs_ansatz(qmps_ctx* c, int64_t n_ref, int kind, int n_params, const double* params, const double* WW) try {
   if (int rc = bind(c)) return rc;
   if (!params || !WW) return fail(QMPS_ERR_ARG, "null argument");
   if (n_ref < 1 || n_ref > c->max_batch) return fail(QMPS_ERR_ARG, "n_ref=%lld outside [1, max_batch]", (long long)n_ref);
@@ -112,35 +113,46 @@ int qmps_overlap_set_refs_ansatz(qmps_ctx* c, int64_t n_ref, int kind, int n_par
   c->overlap_group = 0;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_overlap_set_group(qmps_ctx* c, int64_t group) {
+int qmps_overlap_set_group(qmps_ctx* c, int64_t group) try {
   if (!c) return fail(QMPS_ERR_ARG, "null context");
   if (group < 0) return fail(QMPS_ERR_ARG, "group must be >= 0");
   c->overlap_group = group;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_overlap_set_active(qmps_ctx* c, int64_t n, const unsigned char* active) {
+int qmps_overlap_set_active(qmps_ctx* c, int64_t n, const unsigned char* active) try {
   if (int rc = bind(c)) return rc;
   if (n < 0 || n > c->max_batch) return fail(QMPS_ERR_ARG, "n=%lld outside [0, max_batch]", (long long)n);
   if (n == 0 || !active) {
     c->active_n = 0;
     return QMPS_OK;
   }
-  if (!c->d_active) HIP_TRY(hipMalloc((void**)&c->d_active, (size_t)c->max_batch));
+  if (!c->d_active) HIP_TRY(hipMalloc((void**)&c->d_active, ((size_t)c->max_batch + 7) / 8 * 8));      // (copied in whole 8-byte words)
   if (int rc = ensure_pinned(c, (16u << 20))) return rc;
-  // through the pinned staging buffer (its last MiB: the parameter / result regions may be in use by the same driver)
-  unsigned char* stage = (unsigned char*)c->h_pin + (15u << 20);
-  if ((size_t)n > (1u << 20)) return fail(QMPS_ERR_ARG, "mask longer than 2^20 entries");
+  // through the pinned staging buffer (its last MiB: the parameter / result regions may be in use by the same driver), two slots
+  // of 512 KiB used alternately: the copy kernel of the previous mask may still be in flight when the host writes the next one
+  if ((size_t)n > (1u << 19)) return fail(QMPS_ERR_ARG, "mask longer than 2^19 entries");
+  unsigned char* stage = (unsigned char*)c->h_pin + (15u << 20) + (size_t)(c->active_stage ^= 1) * (1u << 19);
+  if (c->active_inflight[c->active_stage]) HIP_TRY(hipEventSynchronize(c->active_ev[c->active_stage]));
   memcpy(stage, active, (size_t)n);
   memset(stage + n, 1, (size_t)((8 - n % 8) % 8));
   HIP_TRY(qmps::launch_stage_copy(stage, c->d_active, (n + 7) / 8, c->stream));
+  if (!c->capturing) {
+    if (!c->active_ev[c->active_stage]) HIP_TRY(hipEventCreateWithFlags(&c->active_ev[c->active_stage], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->active_ev[c->active_stage], c->stream));
+    c->active_inflight[c->active_stage] = true;
+  }
   c->active_n = n;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int flags) {
+int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int flags) try {
   if (int rc = bind(c)) return rc;
+  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; } } disarm{c};      // the mask of qmps_overlap_set_active is ONE-SHOT: spent on every way out
   if (int rc = check_window(c, B)) return rc;
   if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
   if (c->overlap_refs < 1) return fail(QMPS_ERR_STATE, "qmps_overlap_set has not been called");
@@ -192,8 +204,9 @@ int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int 
   c->partials_B = -1;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_overlap_get(qmps_ctx* c, int64_t B, double* eta_out, double* r_out, int32_t* rounds_out, int32_t* status_out) {
+int qmps_overlap_get(qmps_ctx* c, int64_t B, double* eta_out, double* r_out, int32_t* rounds_out, int32_t* status_out) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_window(c, B)) return rc;
   if (!eta_out) return fail(QMPS_ERR_ARG, "null eta_out");
@@ -208,8 +221,9 @@ int qmps_overlap_get(qmps_ctx* c, int64_t B, double* eta_out, double* r_out, int
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_overlap_get_objective(qmps_ctx* c, int64_t B, double* f_out) {
+int qmps_overlap_get_objective(qmps_ctx* c, int64_t B, double* f_out) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_window(c, B)) return rc;
   if (!f_out) return fail(QMPS_ERR_ARG, "null f_out");
@@ -218,8 +232,9 @@ int qmps_overlap_get_objective(qmps_ctx* c, int64_t B, double* f_out) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
-int qmps_overlap_stats(qmps_ctx* c, int64_t* evaluations, int64_t* rounds_sum, int64_t* rounds_max, int64_t* not_converged, int reset) {
+int qmps_overlap_stats(qmps_ctx* c, int64_t* evaluations, int64_t* rounds_sum, int64_t* rounds_max, int64_t* not_converged, int reset) try {
   if (int rc = bind(c)) return rc;
   unsigned long long h[4] = {0, 0, 0, 0};
   if (c->d_ostats) {
@@ -240,16 +255,19 @@ int qmps_overlap_stats(qmps_ctx* c, int64_t* evaluations, int64_t* rounds_sum, i
   if (not_converged) *not_converged = (int64_t)h[3];
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 int qmps_overlap_eval_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const double* params, int max_rounds, double tol,
-                             int flags, double* f_out, int32_t* status_out) {
+                             int flags, double* f_out, int32_t* status_out) try {
   if (!c) return fail(QMPS_ERR_ARG, "null context");
   if (!f_out) return fail(QMPS_ERR_ARG, "null f_out");
   // one round trip: parameters in, ansatz + overlap kernels, objective and status out - ONE synchronisation (the optimiser
   // drivers call this twice per iteration; three separate calls cost three synchronisations and two extra launch gaps)
-  c->defer_sync = true;
-  int rc = qmps_set_states_ansatz(c, B, kind, n_params, params);
-  c->defer_sync = false;
+  int rc;
+  {
+    Restore<bool> deferred(c->defer_sync, true);
+    rc = qmps_set_states_ansatz(c, B, kind, n_params, params);
+  }
   if (!rc) rc = qmps_overlap_launch(c, B, max_rounds, tol, flags);
   if (rc) {
     (void)hipStreamSynchronize(c->stream);
@@ -270,10 +288,12 @@ int qmps_overlap_eval_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, con
   HIP_TRY(hipStreamSynchronize(c->stream));
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const double* params, double h, int max_rounds, double tol,
-                          int flags, double* f_out, double* g_out, int32_t* status_out) {
+                          int flags, double* f_out, double* g_out, int32_t* status_out) try {
   if (int rc = bind(c)) return rc;
+  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; } } disarm{c};      // (one-shot mask: spent on every way out)
   if (!params || !f_out || !g_out) return fail(QMPS_ERR_ARG, "null argument");
   if (c->D < 4) return fail(QMPS_ERR_ARG, "qmps_overlap_gradient: D = 4, 8, 16 (at D = 2 evaluate the central-difference neighbours themselves)");
   if (flags & ~(QMPS_OVERLAP_WARM | QMPS_OVERLAP_TWO_SIDED_F)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
@@ -293,9 +313,11 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
     if (int e = ensure_pinned(c, need > (16u << 20) ? need : (16u << 20))) return e;
   }
   // the iterates: parameters -> tensors in d_A[0, T)
-  c->defer_sync = true;
-  int rc = qmps_set_states_ansatz(c, T, kind, P, params);
-  c->defer_sync = false;
+  int rc;
+  {
+    Restore<bool> deferred(c->defer_sync, true);
+    rc = qmps_set_states_ansatz(c, T, kind, P, params);
+  }
   if (!rc) rc = ensure_tensors(c);
   if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
   const bool squaring = overlap_squares(c);       // D = 4: the right fixed point comes from the squaring kernel (largest column)
@@ -391,10 +413,11 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   c->grad_warm_T = T;
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
                      double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
-                     double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out) {
+                     double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out) try {
   if (int rc = bind(c)) return rc;
   if (!params || !WW || !f_hist || !alphas) return fail(QMPS_ERR_ARG, "null argument");
   if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
@@ -421,8 +444,8 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
       cand, Fl, Hy(P);
   std::vector<int32_t> st(T), stl;
   std::vector<unsigned char> active(T), moved(T), need(T);
-  const int saved_period = c->timing_period;
-  c->timing_period = counters_out ? 1 : 0;       // (a pair of event records around a batch costs the stream ~12 us: only when asked for)
+  // (a pair of event records around a batch costs the stream ~12 us: only when asked for; restored on EVERY way out of this function)
+  Restore<int> period_guard(c->timing_period, counters_out ? 1 : 0);
   double n_grad = 0.0, n_ladder = 0.0, nfev = 0.0, grad_ms = 0.0;
   auto set_identity = [&](int64_t t) {
     double* Ht = &Hinv[(size_t)t * P * P];
@@ -621,16 +644,16 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
     if (params_hist) memcpy(params_hist + (size_t)step * TP, X.data(), TP * sizeof(double));
     if (nit_out) nit_out[step] = nit;
   }
-  c->timing_period = saved_period;
   if (rc) return rc;
   memcpy(params, X.data(), TP * sizeof(double));
   if (hinv) memcpy(hinv, Hinv.data(), TP * P * sizeof(double));
   if (counters_out) { counters_out[0] = n_grad; counters_out[1] = n_ladder; counters_out[2] = nfev; counters_out[3] = grad_ms; }
   return QMPS_OK;
 }
+QMPS_API_CATCH
 
 int qmps_evolve_rotosolve(qmps_ctx* c, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps,
-                          int n_sweeps, int nsh, int max_rounds, double tol, double* params_hist, double* f_hist) {
+                          int n_sweeps, int nsh, int max_rounds, double tol, double* params_hist, double* f_hist) try {
   if (int rc = bind(c)) return rc;
   if (!params || !WW || !f_hist) return fail(QMPS_ERR_ARG, "null argument");
   if (nsh != 3 && nsh != 6) return fail(QMPS_ERR_ARG, "nsh must be 3 (single-frequency) or 6 (double-frequency)");
@@ -749,10 +772,11 @@ int qmps_evolve_rotosolve(qmps_ctx* c, int64_t T, int kind, int n_params, double
   c->overlap_group = 0;
   return rc;
 }
+QMPS_API_CATCH
 
 int qmps_overlap_batch(qmps_ctx* c, int64_t B, const double* A, int a_shared, const double* states, int kind,
                        int n_params, const double* WW, int max_rounds, double tol, double* eta_out, double* r_out,
-                       int32_t* rounds_out, int32_t* status_out) {
+                       int32_t* rounds_out, int32_t* status_out) try {
   if (int rc = bind(c)) return rc;
   if (int rc = check_B(c, B)) return rc;
   if (!A || !WW || !eta_out || (!states && B > 0)) return fail(QMPS_ERR_ARG, "null argument");
@@ -769,6 +793,7 @@ int qmps_overlap_batch(qmps_ctx* c, int64_t B, const double* A, int a_shared, co
   if (int rc = qmps_overlap_launch(c, B, max_rounds, tol, r_out != nullptr ? QMPS_OVERLAP_WANT_R : 0)) return rc;
   return qmps_overlap_get(c, B, eta_out, r_out, rounds_out, status_out);
 }
+QMPS_API_CATCH
 
 // ---- brick-wall (new_tdvp) contractions -------------------------------------------------------
 }  // extern "C"

@@ -38,6 +38,19 @@ constexpr int kSumBlocks = 256;
     if (e_ != hipSuccess) return qmps_host::fail(QMPS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
+// "Nothing throws across the ABI" (include/qmps_hip.h): every extern "C" entry point is a function-try-block closed by this macro
+// (host-side std::vector / new of the optimiser drivers may throw std::bad_alloc on absurd sizes).
+#define QMPS_API_CATCH                                                                                  \
+  catch (const std::bad_alloc&) {                                                                       \
+    return qmps_host::fail(QMPS_ERR_ARG, "out of host memory (sizes too large?)");                      \
+  }                                                                                                     \
+  catch (const std::exception& ex_) {                                                                   \
+    return qmps_host::fail(QMPS_ERR_ARG, "C++ exception inside the library: %s", ex_.what());           \
+  }                                                                                                     \
+  catch (...) {                                                                                         \
+    return qmps_host::fail(QMPS_ERR_ARG, "unknown C++ exception inside the library");                   \
+  }
+
 #define RCCL_TRY(expr)                                                                                           \
   do {                                                                                                           \
     ncclResult_t r_ = (expr);                                                                                    \
@@ -71,6 +84,9 @@ struct qmps_ctx {
   size_t h_pin_bytes = 0;      //   pageable buffers make every hipMemcpyAsync a blocking, internally staged copy
   unsigned char* d_active = nullptr;   // qmps_overlap_set_active: per-trajectory mask consumed by the next overlap launch (lazy, [max_batch])
   int64_t active_n = 0;                //   entries armed (0: none)
+  int active_stage = 0;                //   staging slot of the last mask (two, alternating)
+  hipEvent_t active_ev[2] = {};        //   ... and the event behind its copy kernel
+  bool active_inflight[2] = {};
   int* d_queue = nullptr;      // overlap kernels: counters the workgroups draw their evaluations from (qmps_create; [0, 1] D = 16 queue kernels, [2, 8) Krylov fall-back of the overlap solves: two sets of three, [8, 13) of the D = 16 environment)
   void* d_kry = nullptr;       // D = 8, 16: iterates handed from the power kernels to the Krylov fall-back when the caller keeps no fixed points [max_batch][D][D]
   void* d_y = nullptr;         // qmps_overlap_gradient: LEFT fixed points [max_batch][D][D] (lazy)
@@ -188,6 +204,17 @@ struct qmps_ctx {
 };
 
 namespace qmps_host {
+
+// restores a context field when the scope is left - by `return`, by an early HIP_TRY return or by an exception
+template <class T>
+struct Restore {
+  T& ref;
+  T saved;
+  Restore(T& r, T now) : ref(r), saved(r) { ref = now; }
+  ~Restore() { ref = saved; }
+  Restore(const Restore&) = delete;
+  Restore& operator=(const Restore&) = delete;
+};
 
 int bind(qmps_ctx* c);
 inline size_t tensor_bytes(const qmps_ctx* c) { return (size_t)32 * c->D * c->D; }

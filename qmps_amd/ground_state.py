@@ -21,7 +21,7 @@ from scipy.linalg import expm
 
 from . import _runtime
 from ._lib import STATUS_NOT_PD, STATUS_OK
-from .represent import FullStateTensor, ShallowCNOTStateTensor, final_state, unitary
+from .represent import FullStateTensor, ShallowCNOTStateTensor, build_gate, final_state, unitary
 from .tools import Optimizer, get_env_exact
 
 π = np.pi
@@ -161,12 +161,12 @@ class SparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
             self.objective_function = self.objective_function_exact_environment
         self.p = len(initial_guess)
         self.f = 0
-        super().__init__(self.state_tensor(D, initial_guess), None, initial_guess)
+        super().__init__(build_gate(self.state_tensor, D, initial_guess), None, initial_guess)
         if settings:
             self.change_settings(settings)
 
     def unitaries(self, params_batch):
-        return np.stack([unitary(self.state_tensor(self.D, p)) for p in np.atleast_2d(params_batch)])
+        return np.stack([unitary(build_gate(self.state_tensor, self.D, p)) for p in np.atleast_2d(params_batch)])
 
     def _energies_from_params(self, params_batch):
         """params -> energies.  For the ansatz classes libqmps_hip knows (`device_kind`), the circuit is
@@ -228,7 +228,7 @@ class SparseFullEnergyOptimizer(_GpuEnergyMixin, Optimizer):
         return RotosolveResult(hist, hist[-1], self.initial_guess, '')
 
     def update_state(self):
-        self.u = self.state_tensor(self.D, self.optimized_result.x)
+        self.u = build_gate(self.state_tensor, self.D, self.optimized_result.x)
         self.U = unitary(self.u)
 
 

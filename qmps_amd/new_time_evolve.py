@@ -13,7 +13,7 @@ from scipy.optimize import minimize
 
 from . import _lib as L
 from . import _runtime
-from .represent import ShallowFullStateTensor, unitary
+from .represent import ShallowFullStateTensor, build_gate, unitary
 from .tools import unitary_to_tensor
 
 
@@ -37,7 +37,7 @@ def _n_angles(cls, p):
 def state_tensor(p, D=2, state_tensor=None):
     """A(p) = unitary_to_tensor(unitary(gate(p))); already left-canonical (a unitary's first D columns)."""
     cls = state_tensor or _default_class(D)
-    return unitary_to_tensor(unitary(cls(D, np.asarray(p, dtype=float)[:_n_angles(cls, p)])))
+    return unitary_to_tensor(unitary(build_gate(cls, D, np.asarray(p, dtype=float)[:_n_angles(cls, p)])))
 
 
 def batch_obj(P, A, WW, return_eta=False, D=2, state_tensor=None, max_rounds=None, tol=1e-13):
@@ -49,7 +49,7 @@ def batch_obj(P, A, WW, return_eta=False, D=2, state_tensor=None, max_rounds=Non
     eng = _runtime.engine(D, P.shape[0])
     kind = getattr(cls, 'device_kind', None)
     if kind is None or (kind in (L.ANSATZ_SHALLOW_FULL, L.ANSATZ_STATE_GATE) and D != 2):
-        cand = np.stack([unitary_to_tensor(unitary(cls(D, p))) for p in P])
+        cand = np.stack([unitary_to_tensor(unitary(build_gate(cls, D, p))) for p in P])
         eta, rounds, st = eng.overlaps(A, cand, WW, kind='tensor', max_rounds=max_rounds, tol=tol)
     else:
         eta, rounds, st = eng.overlaps(A, P, WW, kind='params', ansatz=kind, max_rounds=max_rounds, tol=tol)
@@ -130,7 +130,10 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
     (BASELINE.json configs[4]) evolved in lock-step.  Any bond dimension D in {2, 4, 8, 16}; `state_tensor` = gate class
     (default: ShallowFullStateTensor at D = 2, ShallowCNOTStateTensor otherwise).
       method 'Rotosolve' / 'DoubleRotosolve': the WHOLE evolution - every step, sweep, parameter, trajectory - is one C
-          call (`qmps_evolve_rotosolve`, n_sweeps sweeps per step), no host round trip;
+          call (`qmps_evolve_rotosolve`, n_sweeps sweeps per step), no host round trip.  HEURISTIC: -sqrt|eta| with the exact
+          environment is not a sinusoid of a gate angle (the reference's rotosolve evolution, scripts/rotosolve.py:270-294, fits a
+          variational environment for that reason), so a closed-form update can RAISE the objective and the trajectory may stop
+          tracking W|AA>; a RuntimeWarning says so once per call when a step ends above where it started.  Use 'BFGS' for physics;
       method 'BFGS': lock-step batched BFGS - by default the whole evolution in ONE C call (`qmps_evolve_bfgs`: objective and
           gradient at the full quasi-Newton step first, the backtracking ladder only for trajectories that reject it; the same
           decisions as a plain ladder); options {'native': False} runs the same loop from numpy (`tools.batched_bfgs`, per-iteration
@@ -155,6 +158,12 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
         history += [ph[k] for k in range(n_steps)]
         info['fun'] = fh
         info['solver'] = eng.overlap_stats()
+        worse = int(np.sum(fh[:, -1] > fh[:, 0] + 1e-12))
+        if worse:
+            import warnings
+            warnings.warn(f"evolve(method='{method}'): {worse} of {fh[:, -1].size} (step, trajectory) pairs ended a time step with a HIGHER "
+                          "objective than their first sweep reached - rotosolve is a heuristic for this objective (see the docstring); "
+                          "method='BFGS' minimises it", RuntimeWarning, stacklevel=2)
         if callback is not None:
             for k in range(n_steps):
                 callback(k, ph[k] if not single else ph[k][0], fh[k, -1] if not single else fh[k, -1, 0])
@@ -225,7 +234,9 @@ class LockstepEvolver:
         self.first_rungs = first_rungs
         self.speculative = bool(speculative)      # (D = 2: with the central-difference candidates eigen-solved one by one)
         self.carry_hessian, self._hinv = carry_hessian, None
-        self.native = bool(native) and self.speculative
+        # the C driver IS the speculative iteration with the library's gradient (two-sided at D >= 4, eigen-solved neighbours at D = 2) and
+        # the one-stage ladder: any other combination of options runs the numpy loop, which implements them all
+        self.native = bool(native) and self.speculative and (self.two_sided or D == 2) and not first_rungs
         self.mr, self.tol = mr, tol
         self.tight_gradient = bool(tight_gradient) or not self.two_sided
         if self.native:
@@ -283,7 +294,7 @@ class LockstepEvolver:
 
 
 def state_tensor_of(cls, D, p):
-    return unitary_to_tensor(unitary(cls(D, p)))
+    return unitary_to_tensor(unitary(build_gate(cls, D, p)))
 
 
 # ---- the rest of the reference module's surface ------------------------------------------------------------
@@ -355,7 +366,7 @@ def run(params, WW, T, ops=None, method='Nelder-Mead', options=None):
     """The reference's `__main__` loop without the plots (new_time_evolve.py:250-294): evolve over the time grid T,
     recording parameters, one-site expectation values and the Loschmidt echo against the initial state.
     Returns (ps, evs, les)."""
-    params = np.array(params, dtype=float)
+    params = np.array(params, dtype=float)[:15]      # (the reference carries an unused tail `rs` behind the 15 gate angles)
     A0 = state_tensor(params)
     if ops is None:
         ops = [0.5 * np.array([[0, 1], [1, 0]]), 0.5 * np.array([[0, -1j], [1j, 0]]), 0.5 * np.diag([1.0, -1.0])]

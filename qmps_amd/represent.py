@@ -358,6 +358,16 @@ class StateGate(Gate):
         return [rx(a)(q0), rx(b)(q1), rz(c)(q0), rz(d)(q1), xx_pow(e)(q0, q1), yy_pow(f)(q0, q1)]
 
 
+def build_gate(cls, D, params):
+    """Gate object of class `cls` at bond dimension D: every state-tensor class of this module is `cls(D, params)` except
+    StateGate, whose constructor takes the parameters alone (represent.py:406-410 of the reference; D = 2 only)."""
+    if cls is StateGate:
+        if D != 2:
+            raise ValueError('StateGate exists at D = 2 only')
+        return cls(params)
+    return cls(D, params)
+
+
 class ShallowEnvironment(Gate):
     """QAOA-style environment ansatz on 2 log2(D) qubits (represent.py:425-442)."""
 

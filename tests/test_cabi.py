@@ -101,3 +101,27 @@ def test_environment_switches_are_documented_or_compiled_out():
     assert not (documented & tuning)
     knobs = open(os.path.join(root, 'qmps_amd', 'csrc', 'qmps_knobs.h')).read()
     assert '#ifdef QMPS_DEBUG_KNOBS' in knobs and knobs.count('getenv(') == 2
+
+
+def test_nothing_throws_across_the_abi():
+    """include/qmps_hip.h: "Nothing throws across the ABI".  Every extern "C" body is a function-try-block closed by QMPS_API_CATCH
+    (checked in the sources), and an exception raised inside the library - std::bad_alloc, std::length_error from a vector of absurd
+    size, a foreign type - comes back as an error code with a message, not as an abort of the Python process."""
+    from qmps_amd import _lib
+    lib = _lib.load()
+    assert lib.qmps_selftest_exception(0) == 0
+    for kind, word in ((1, b'out of host memory'), (2, b'exception'), (3, b'unknown C++ exception')):
+        assert lib.qmps_selftest_exception(kind) == _lib.QMPS_ERR_ARG
+        assert word in lib.qmps_last_error(), lib.qmps_last_error()
+    csrc = os.path.join(ROOT, 'qmps_amd', 'csrc')
+    for f in ('qmps_capi.hip', 'qmps_capi_overlap.hip'):
+        src = open(os.path.join(csrc, f)).read()
+        entry = re.findall(r'^int (qmps_\w+)\(', src, flags=re.M)
+        guarded = re.findall(r'^int (qmps_\w+)\([^{;]*?\) try \{', src, flags=re.M | re.S)
+        bare = sorted(set(entry) - set(guarded) - {'qmps_abi_version'})
+        assert not bare, f'{f}: entry points without a function-try-block: {bare}'
+        assert src.count('QMPS_API_CATCH') == len(guarded)
+    # context fields that are switched for the duration of a call are restored by scope guards, not by hand
+    for f in ('qmps_capi.hip', 'qmps_capi_overlap.hip'):
+        src = open(os.path.join(csrc, f)).read()
+        assert 'c->defer_sync = true' not in src and 'saved_period' not in src

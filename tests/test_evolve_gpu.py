@@ -183,6 +183,25 @@ def test_device_time_evolution_by_rotosolve_vs_oracle_replay(D, kind, P, T, n_st
     # so this driver is checked for what it computes; the optimiser that does the physics is method='BFGS' below)
 
 
+def test_rotosolve_evolution_d16_above_the_queue_threshold(engine_factory):
+    """at D = 16 a sweep of more than 2 048 candidates (nsh T > 2 048) runs the four-wave kernel with its
+    work queue INSIDE the captured sweep graph - the queue counter must exist before the capture starts (it used to be
+    hipMalloc'ed lazily at the first such launch, which a stream capture rejects).  700 trajectories x 3 shifts; the recorded
+    objectives are the oracle's at the device's parameters."""
+    rng = np.random.default_rng(77)
+    D, kind, P, T = 16, 0, 8, 700
+    X0 = rng.standard_normal((T, P))
+    WW = WW_of(0.05)
+    eng = engine_factory(D, 3 * T)
+    eng.overlap_stats(reset=True)
+    Xf, ph, fh = eng.evolve_rotosolve(kind, X0, WW, n_steps=1, n_sweeps=1, double_frequency=False, max_rounds=5000, tol=1e-12)
+    stats = eng.overlap_stats()
+    assert stats['not_converged'] == 0 and stats['evaluations'] == (P * 3 + 1) * T, stats
+    for t in (0, 349, 699):
+        f_t = ER.objective(kind, D, ER.tensor(kind, D, X0[t]), ph[0, t], WW)
+        assert abs(f_t - fh[0, -1, t]) < F_TOL, (t, f_t, fh[0, -1, t])
+
+
 @pytest.mark.parametrize('D,P,T,iters', [(2, 8, 4, 12), (4, 4, 4, 12), (16, 8, 3, 8)])
 def test_lockstep_bfgs_time_evolution(D, P, T, iters):
     """`evolve(..., method='BFGS')`: batched central-difference gradients and backtracking ladders of all trajectories on

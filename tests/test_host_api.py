@@ -394,3 +394,19 @@ def test_batched_bfgs_speculative_full_step():
     assert spec['nit'] == plain['nit'] and np.abs(spec['history'] - plain['history']).max() < 1e-12
     assert np.abs(spec['x'] - plain['x']).max() < 1e-10 and spec['converged'].all()
     assert n['line'] < n_plain['line'] and n['vg'] + n['line'] < n_plain['vg'] + n_plain['line']
+
+
+def test_state_gate_adapter_and_native_flag():
+    """StateGate's constructor takes the parameters alone - the host paths build gates through `build_gate`; the
+    lock-step evolver's C driver is chosen only for the option combinations it implements."""
+    from qmps_amd import represent as R
+    from qmps_amd import new_time_evolve as NT
+    p = np.linspace(0.1, 0.6, 6)
+    g = R.build_gate(R.StateGate, 2, p)
+    assert isinstance(g, R.StateGate) and np.allclose(R.unitary(g) @ R.unitary(g).conj().T, np.eye(4))
+    with pytest.raises(ValueError):
+        R.build_gate(R.StateGate, 4, p)
+    assert isinstance(R.build_gate(R.ShallowCNOTStateTensor, 4, np.zeros(4)), R.ShallowCNOTStateTensor)
+    A = NT.state_tensor(p, D=2, state_tensor=R.StateGate)          # (host path: no device needed)
+    assert A.shape == (2, 2, 2) and np.allclose(sum(a.conj().T @ a for a in A), np.eye(2))
+    assert NT.state_tensor_of(R.StateGate, 2, p).shape == (2, 2, 2)

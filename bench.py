@@ -288,6 +288,47 @@ def executed_flops(D, solver, iters, eng, max_iter):
     return flops, note, handoff
 
 
+def emit(args, out):
+    """rank 0's ONE JSON line - or, when this workload runs as an `other_configs` entry of the default run, its dict"""
+    sink = getattr(args, 'collect', None)
+    if sink is not None:
+        sink.append(out)
+    else:
+        print(json.dumps(out), flush=True)
+
+
+def world_of(args):
+    """(world, rank, local_rank) from the launcher's environment; every workload refuses a launch whose WORLD_SIZE is not --gpus
+    (a `--gpus 8` line that silently ran one rank would report n_gpus 1 as if it were the 8-GPU number)"""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('QMPS_BENCH_ONE_DEVICE') == '1':      # functional test of the N > 1 branch on a one-GPU box
+        local_rank = 0
+    if world != args.gpus:
+        sys.exit(f'bench.py: WORLD_SIZE={world} but --gpus {args.gpus}')
+    return world, rank, local_rank
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks HERE - a child `python -m torch.distributed.run`
+    created before this process has touched the GPU (it never does) - relay the child's stdout (rank 0's JSON line) and exit with
+    its return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f'bench.py: --gpus {args.gpus} without a launcher: starting {args.gpus} ranks through torch.distributed.run (port {port})', file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=dict(os.environ), stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    sys.exit(proc.wait())
+
+
 def shard_plan(scaling, batch, rank, world):
     """(first evaluation, evaluations on this rank, global batch).  weak: `batch` per GPU; strong: `batch` is the global
     batch and rank r owns the contiguous block qmps_amd.dist.shard_bounds(batch, r, world) (B/G per GPU)."""
@@ -335,6 +376,14 @@ def init_rccl(eng, dist, rank, world):
         err = err or 'rank 0 could not create an RCCL unique id'
     flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64)
     dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+    # what EVERY rank's communicator says about its size (ncclCommCount; 0 = that rank has none), gathered over gloo: `rccl_ranks_seen`
+    seen = torch.zeros(world, dtype=torch.int64)
+    try:
+        seen[rank] = eng.comm_count() if not err or 'expected' in err else 0
+    except _lib.QmpsError:
+        pass
+    dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    init_rccl.ranks_seen = [int(v) for v in seen]
     if flag.item() != 0.0:
         try:
             eng.comm_destroy()
@@ -359,9 +408,7 @@ def main_overlap(args):
     """--workload overlap: BASELINE.json configs[4] (TFIM quench time evolution, D = 16 on the matrix cores): one step =
     the overlap objective eta_b (dominant eigenvalue of the mixed two-site transfer map, qmps/new_time_evolve.py:193-221)
     of B resident candidates against the current state.  Independent trajectories: replicas only, no collective."""
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world, rank, local_rank = world_of(args)
     D, B = args.D, args.batch
     dist = None
     if world > 1:
@@ -439,7 +486,7 @@ def main_overlap(args):
                             'hbm': {'achieved': byts / (kernel_ms * 1e-3) * 1e-9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                     'frac': byts / (kernel_ms * 1e-3) * 1e-9 / HBM_PEAK_GBPS, 'bytes_per_eval': 32 * D * D + 16}},
                'cpu_baseline': cpu}
-        print(json.dumps(out), flush=True)
+        emit(args, out)
     eng.close()
     if dist is not None:
         dist.barrier()
@@ -481,11 +528,7 @@ def main_evolve(args):
     batch of T (2P + 1) central-difference candidates and one of T x 8 backtracking candidates - parameters -> tensor ->
     dominant eigenvalue of the mixed transfer map -> -sqrt|eta| - warm-started from the fixed points resident in the candidates'
     slots.  `value` = trajectory time steps per second.  Independent trajectories: replicas only at N > 1, no collective."""
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if os.environ.get('QMPS_BENCH_ONE_DEVICE') == '1':
-        local_rank = 0
+    world, rank, local_rank = world_of(args)
     D, T = args.D, args.batch
     depth = {2: 4, 4: 2, 8: 3, 16: 4}[D]          # D = 2: scripts/loschmidt.py evolves ShallowCNOTStateTensor(2, .) with 8 angles
     P = 2 * depth
@@ -509,7 +552,7 @@ def main_evolve(args):
     from qmps_amd.new_time_evolve import LockstepEvolver
     from qmps_amd.represent import ShallowCNOTStateTensor
     ev = LockstepEvolver(D, T, P, ShallowCNOTStateTensor, tol=args.tol, maxiter=args.bfgs_iters, device=local_rank,
-                         gradient=args.gradient, first_rungs=2 if args.gradient != 'fd' else None, carry_hessian=args.carry_hessian,
+                         gradient=args.gradient, first_rungs=2 if (args.gradient != 'fd' and (args.python_driver or args.no_speculative)) else None, carry_hessian=args.carry_hessian,
                          speculative=args.gradient != 'fd' and not args.no_speculative, native=not args.python_driver)
     native = ev.native            # the whole timed region is ONE C call (qmps_evolve_bfgs); else: the numpy loop, one ctypes call per batch
     info = _lib.device_info(local_rank)
@@ -638,7 +681,7 @@ def main_evolve(args):
                'cpu_baseline': cpu}
         if identity_leg is not None:
             out['identity_start'] = identity_leg
-        print(json.dumps(out), flush=True)
+        emit(args, out)
     ev.close()
     if dist is not None:
         dist.barrier()
@@ -651,11 +694,7 @@ def main_rotosolve(args):
     lock-step; one step = one SWEEP of the device-resident rotosolve (every parameter once: shifted batches of 3 R
     evaluations - ansatz, environment, energy - and the closed-form updates), --batch = 3 R evaluations per parameter
     update.  `value` counts the energy evaluations the optimiser consumed per second.  Replicas only at N > 1."""
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if os.environ.get('QMPS_BENCH_ONE_DEVICE') == '1':
-        local_rank = 0
+    world, rank, local_rank = world_of(args)
     D = args.D
     nsh = 6 if args.double_frequency else 3
     R_global = max(1, args.batch // nsh)
@@ -784,15 +823,63 @@ def main_rotosolve(args):
                           'summed_cost_last_sweep_all_ranks': None if reduced is None else float(reduced[0][-1]),
                           'restarts_counted_all_ranks': None if reduced is None else reduced[1],
                           'best_energy_all_ranks': None if reduced is None else reduced[2],
-                          'collective': collective, 'device': info['name'], 'arch': info['arch']},
+                          'collective': collective, 'rccl_ranks_seen': getattr(init_rccl, 'ranks_seen', None) if (args.shard and dist is not None) else None,
+                          'device': info['name'], 'arch': info['arch']},
                'roofline': roof, 'cpu_baseline': cpu}
-        print(json.dumps(out), flush=True)
+        emit(args, out)
     if reducer is not None and hasattr(reducer, 'engine'):
         eng.comm_destroy()
     eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def other_configs(args, budget_s=60.0):
+    """BASELINE.json configs[1], [3], [4] as the optimiser workloads they name, on the driver's line: each entry is the JSON line
+    `bench.py --workload ...` prints for that configuration (value, ms_per_step, roofline, cpu_baseline), run in this process on
+    contexts of their own after the headline's timed region, with bounded step counts; an entry that would start after the
+    budget is skipped and says so."""
+    import copy
+    t0 = time.perf_counter()
+    plan = [
+        ('config1_rotosolve_D2_b4096', dict(workload='rotosolve', D=2, batch=4096, steps=160, warmup=8, hamiltonian=None, double_frequency=False, shard=False)),
+        ('config3_rotosolve_D8_xxz_256x3', dict(workload='rotosolve', D=8, batch=768, steps=160, warmup=8, hamiltonian=None, double_frequency=False, shard=False)),
+        ('config4_evolve_D16_depth4_T256', dict(workload='evolve', D=16, batch=256, steps=10, warmup=3, tol=1e-12, carry_hessian=None)),
+    ]
+    res = {}
+    for name, over in plan:
+        if time.perf_counter() - t0 > budget_s:
+            res[name] = {'skipped': f'the {budget_s:.0f} s budget of other_configs was spent'}
+            continue
+        o = copy.copy(args)
+        for k, v in over.items():
+            setattr(o, k, v)
+        o.collect = []
+        o.max_iter = 10000
+        t1 = time.perf_counter()
+        try:
+            {'rotosolve': main_rotosolve, 'evolve': main_evolve}[o.workload](o)
+            d = o.collect[0]
+        except (Exception, SystemExit) as e:        # an extra must never take the headline line down with it
+            res[name] = {'error': f'{type(e).__name__}: {e}'}
+            continue
+        r = d.get('roofline') or {}
+        res[name] = {'metric': d['metric'], 'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'warmup': d['warmup'],
+                     'roofline': {k: r.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'hbm_frac', 'kernel', 'kernel_ms', 'kernel_share_of_wall') if k in r},
+                     'cpu_baseline': d.get('cpu_baseline'), 'workload': d['config'].get('workload'),
+                     'config': {k: v for k, v in d['config'].items() if k in ('baseline_config', 'hamiltonian', 'D', 'restarts', 'n_params', 'shifts', 'us_per_parameter_update', 'mean_energy_first_sweep',
+                                                                                'mean_energy_last_sweep', 'best_energy', 'exact_ground_state_energy', 'not_converged_or_not_pd',
+                                                                                'trajectories_per_gpu', 'driver', 'bfgs_iterations_per_step', 'carry_hessian', 'not_converged',
+                                                                                'mean_final_objective', 'kernel_share_of_wall', 'solver_rounds_mean_gradient_batches',
+                                                                                'solver_rounds_max_gradient_batches')},
+                     'wall_s': time.perf_counter() - t1}
+        if 'identity_start' in d:       # config 4 BOTH ways: the reference's own restart of every minimisation beside the carried Hessians
+            res[name]['identity_start'] = d['identity_start']
+    res['what'] = ('BASELINE.json configs[1], [3], [4] run as `--workload rotosolve|evolve` in this process (their own synthetic inputs, contexts and CPU-baseline samples); '
+                   'config 4 carries the inverse Hessians between time steps (`identity_start`: scipy\'s / the reference\'s restart from the identity)')
+    res['wall_s'] = time.perf_counter() - t0
+    return res
 
 
 def main():
@@ -851,10 +938,15 @@ def main():
                     help='N > 1: the summed costs of this many steps travel in one RCCL all-reduce (1 = an exchange per step, the '
                          'headline; a grouped figure is printed as an extra)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-repeats', action='store_true', help='energy workload: time the --steps block once (default: 16 blocks, median / min / max reported beside `value`)')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='energy workload, N = 1: skip the `other_configs` extra (BASELINE.json configs[1], [3], [4] as their own optimiser workloads, bounded to ~60 s)')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the informational legs that run after the timed region (PCIe-inclusive, ansatz-parameter-inclusive, '
                          'contraction-only, grouped exchange): under rocprofv3 the per-kernel averages then cover the timed workload only')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
 
     if args.workload == 'overlap':
         if args.max_iter == 10000:
@@ -874,15 +966,7 @@ def main():
         if args.steps == 2000 and args.warmup == 450:
             args.steps, args.warmup = 160, 8
         return main_rotosolve(args)
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if os.environ.get('QMPS_BENCH_ONE_DEVICE') == '1':      # functional test of the N > 1 branch on a one-GPU box (if RCCL allows it)
-        local_rank = 0
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py: --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)')
-        sys.exit(f'bench.py: WORLD_SIZE={world} but --gpus {args.gpus}')
+    world, rank, local_rank = world_of(args)
 
     D = args.D
     _, B, global_batch = shard_plan(args.scaling, args.batch, rank, world)
@@ -991,6 +1075,9 @@ def main():
         eng.exchange_stats(reset=True)
     elapsed, ev_ms = timed(args.steps)
     exch = eng.exchange_stats() if dist is not None and rccl_ok else None
+    # the same block of --steps steps again, 15 times (every rank: the blocks carry the barriers and, at N > 1, the exchanges of the
+    # first): `value` stays the FIRST block's (the contract's K timed steps); median / min / max of all 16 are reported beside it
+    block_s = [elapsed] + [timed(args.steps)[0] for _ in range(0 if args.no_repeats else 15)]
 
     cost = eng.get_cost()
     if dist is not None and not rccl_ok:
@@ -1136,6 +1223,8 @@ def main():
         extras['grouped_exchange_16'] = {'evals_per_s': global_batch * n16 / el16,
                                          'what': 'same steps, the summed costs of 16 consecutive steps per all-reduce'}
 
+    if rank == 0 and world == 1 and dist is None and not args.no_extras and not args.no_other_configs and (D, args.batch) == (4, 65536):
+        extras['other_configs'] = other_configs(args)
     tot = np.array([float(iters.sum()), float((status != 0).sum()), float((iters > 1).sum()), float(len(iters))])
     if dist is not None:
         import torch
@@ -1178,7 +1267,7 @@ def main():
                        'mean_power_iterations': tot[0] / tot[3],
                        'fallback_fraction': (tot[2] / tot[3]) if direct else None,
                        'max_power_iterations_rank0': int(iters.max()), 'not_converged_or_not_pd': int(tot[1]),
-                       'collective': collective,
+                       'collective': collective, 'rccl_ranks_seen': getattr(init_rccl, 'ranks_seen', None) if dist is not None else None,
                        'exchange_pipeline_rank0': None if exch is None else {
                            'slot_guard_checks': exch[0], 'host_waited_for_an_exchange': exch[1], 'host_wait_ms': exch[2],
                            'what': 'timed region, rank 0: the host issues a step in ~10 us and is throttled at the ring (it may run 6 steps ahead): '
@@ -1206,11 +1295,16 @@ def main():
                                          f'dominant kernel / the whole step; {R} resident batches cycled, tensors '
                                          f'{"exceed" if R * B * tensor_bytes > MALL_MIB * 2 ** 20 else "fit inside"} the {MALL_MIB} MiB Infinity Cache'}},
             'summed_cost': float(cost[0]),
+            'repeats': {'blocks': len(block_s), 'steps_per_block': args.steps,
+                        'value_median': global_batch * args.steps / float(np.median(block_s)), 'value_min': global_batch * args.steps / max(block_s),
+                        'value_max': global_batch * args.steps / min(block_s), 'ms_per_step_median': float(np.median(block_s)) / args.steps * 1e3,
+                        'ms_per_step_min': min(block_s) / args.steps * 1e3, 'ms_per_step_max': max(block_s) / args.steps * 1e3,
+                        'what': 'the timed block of --steps steps repeated back to back (block 0 is `value`), each bracketed by barrier + synchronise, max over ranks'},
         }
         out.update(extras)
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu
-        print(json.dumps(out), flush=True)
+        emit(args, out)
 
     if dist is not None and rccl_ok:
         eng.comm_destroy()

@@ -234,9 +234,10 @@ class LockstepEvolver:
         self.first_rungs = first_rungs
         self.speculative = bool(speculative)      # (D = 2: with the central-difference candidates eigen-solved one by one)
         self.carry_hessian, self._hinv = carry_hessian, None
-        # the C driver IS the speculative iteration with the library's gradient (two-sided at D >= 4, eigen-solved neighbours at D = 2) and
-        # the one-stage ladder: any other combination of options runs the numpy loop, which implements them all
-        self.native = bool(native) and self.speculative and (self.two_sided or D == 2) and not first_rungs
+        # the C driver IS the speculative iteration with the library's gradient (two-sided at D >= 4, eigen-solved neighbours at D = 2):
+        # any other combination of options (gradient='fd' at D >= 4, speculative=False) runs the numpy loop, which implements them all
+        # (first_rungs only shapes the NON-speculative ladder, so it does not matter here)
+        self.native = bool(native) and self.speculative and (self.two_sided or D == 2)
         self.mr, self.tol = mr, tol
         self.tight_gradient = bool(tight_gradient) or not self.two_sided
         if self.native:

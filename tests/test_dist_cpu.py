@@ -182,3 +182,27 @@ def test_sharded_rotosolve_exchange_world2(R_global):
     # replicas (no --shard): every rank its own restarts
     plan = _bench_module().rotosolve_shard_plan
     assert plan(R_global, 1, 2, False) == (R_global, R_global, 2 * R_global)
+
+
+def test_bench_self_launch_and_world_checks():
+    """`python bench.py --gpus 2` with no launcher around it starts its two ranks itself (a child
+    torch.distributed.run created before anything touches a GPU) and exits with the children's return code - here, without a
+    device, every rank stops at QMPS_ERR_NO_DEVICE (the product has no CPU fallback); every workload refuses a launch whose
+    WORLD_SIZE differs from --gpus instead of reporting n_gpus = 1."""
+    import subprocess
+    import sys
+    from qmps_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip('a GPU is visible here: the ranks would run')
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--batch', '64'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert 'starting 2 ranks through torch.distributed.run' in out.stderr
+    assert out.stderr.count('no usable gfx950 device') + out.stderr.count('no CPU fallback') >= 2, out.stderr[-3000:]
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]          # no JSON line from a run that computed nothing
+    for wl in ('energy', 'overlap', 'evolve', 'rotosolve'):
+        out = subprocess.run([sys.executable, bench, '--gpus', '1', '--workload', wl, '--no-cpu-baseline'],
+                             env=dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=120)
+        assert out.returncode != 0 and 'WORLD_SIZE=2 but --gpus 1' in out.stderr, (wl, out.stderr[-500:])

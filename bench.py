@@ -493,7 +493,7 @@ def main_overlap(args):
         dist.destroy_process_group()
 
 
-def evolve_cpu_baseline(D, P, WW, seed, maxiter, budget_T=2):
+def evolve_cpu_baseline(D, P, WW, seed, maxiter, budget_T=2, full=False):
     """The same lock-step BFGS time step with the ORACLE as evaluator, the way the reference obtains eta (xmps Map ->
     scipy.sparse.linalg.eigs, ARPACK in operator form: oracle.overlap_eta_arpack) and the oracle's own circuit model for
     parameters -> tensor, one host core, on a bounded sample: budget_T trajectories, one time step."""
@@ -501,13 +501,14 @@ def evolve_cpu_baseline(D, P, WW, seed, maxiter, budget_T=2):
     from qmps_amd.tools import batched_bfgs
     _one_blas_thread()
     X = np.random.default_rng(seed).standard_normal((budget_T, P))
-    A = [O.unitary_to_tensor(O.shallow_cnot_unitary(D, x)) for x in X]
+    unitary = (lambda D_, x: O.shallow_full_unitary(x)) if full else O.shallow_cnot_unitary
+    A = [O.unitary_to_tensor(unitary(D, x)) for x in X]
     n = [0]
 
     def fb(G):
         def f(C):
             n[0] += len(C)
-            return np.array([-np.sqrt(abs(O.overlap_eta_arpack(A[b // G], O.unitary_to_tensor(O.shallow_cnot_unitary(D, C[b])), WW)[0]))
+            return np.array([-np.sqrt(abs(O.overlap_eta_arpack(A[b // G], O.unitary_to_tensor(unitary(D, C[b])), WW)[0]))
                              for b in range(len(C))])
         return f
     t = time.perf_counter()
@@ -532,6 +533,9 @@ def main_evolve(args):
     D, T = args.D, args.batch
     depth = {2: 4, 4: 2, 8: 3, 16: 4}[D]          # D = 2: scripts/loschmidt.py evolves ShallowCNOTStateTensor(2, .) with 8 angles
     P = 2 * depth
+    full = D == 2 and args.ansatz == 'shallow-full'      # qmps/new_time_evolve.py:186-187: ShallowFullStateTensor(2, .), 15 angles
+    if full:
+        P = 15
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -543,17 +547,17 @@ def main_evolve(args):
     WW = expm(-1j * args.dt * tfim_h(1.0))
     cpu = None
     if not args.no_cpu_baseline and world == 1:
-        cpu = evolve_cpu_baseline(D, P, WW, args.seed, args.bfgs_iters)
+        cpu = evolve_cpu_baseline(D, P, WW, args.seed, args.bfgs_iters, full=full)
     if args.carry_hessian is None:
         # measured (profiles/r03h_evolve_*.json): D = 16 3.2 against 9.5 iterations per time step, D = 8 6.8 against 13 - but
         # D = 4 19.6 against 12 and D = 2 no gain: the shallow ansaetze of D = 2, 4 have flat directions a carried Hessian mis-scales
         args.carry_hessian = D >= 8
     from qmps_amd import _lib
     from qmps_amd.new_time_evolve import LockstepEvolver
-    from qmps_amd.represent import ShallowCNOTStateTensor
-    ev = LockstepEvolver(D, T, P, ShallowCNOTStateTensor, tol=args.tol, maxiter=args.bfgs_iters, device=local_rank,
+    from qmps_amd.represent import ShallowCNOTStateTensor, ShallowFullStateTensor
+    ev = LockstepEvolver(D, T, P, ShallowFullStateTensor if full else ShallowCNOTStateTensor, tol=args.tol, maxiter=args.bfgs_iters, device=local_rank,
                          gradient=args.gradient, first_rungs=2 if (args.gradient != 'fd' and (args.python_driver or args.no_speculative)) else None, carry_hessian=args.carry_hessian,
-                         speculative=args.gradient != 'fd' and not args.no_speculative, native=not args.python_driver)
+                         speculative=args.gradient != 'fd' and not args.no_speculative, native=not args.python_driver, device_driver=not args.host_driver)
     native = ev.native            # the whole timed region is ONE C call (qmps_evolve_bfgs); else: the numpy loop, one ctypes call per batch
     info = _lib.device_info(local_rank)
     X = np.random.default_rng(args.seed + rank).standard_normal((T, P))
@@ -606,6 +610,9 @@ def main_evolve(args):
         elapsed_instr = time.perf_counter() - t2
         nfev = res2['nfev']
     sg = ev.fg.eng.overlap_stats()
+    if getattr(ev, 'device', False):
+        # D = 2, device-resident optimiser: one launch, its own counters (every candidate eigen-solved; squarings summed by the kernel)
+        sg = {'evaluations': res2['nfev'], 'rounds_sum': res2['squarings'], 'rounds_max': 0, 'not_converged': res2['failed_evaluations']}
     # (native driver: one context, its statistics pool the - rare - ladder batches with the gradient batches)
     sl = ev.fl.eng.overlap_stats() if ev.fl is not ev.fg else {k: 0 for k in sg}
     kms_timed = (list(ev.fg.kernel_ms), list(ev.fl.kernel_ms) if ev.fl is not ev.fg else [])
@@ -647,7 +654,7 @@ def main_evolve(args):
                'value': world * T * args.steps / elapsed, 'unit': 'trajectory time steps/s', 'n_gpus': world, 'steps': args.steps,
                'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-               'config': {'workload': f'TFIM g=1 quench time evolution, D={D}, ShallowCNOT depth {depth} ({P} parameters), {T} independent trajectories per GPU '
+               'config': {'workload': f'TFIM g=1 quench time evolution, D={D}, ' + (f'ShallowFull (15 parameters)' if full else f'ShallowCNOT depth {depth} ({P} parameters)') + f', {T} independent trajectories per GPU '
                                       f'from random parameters, W = exp(-{args.dt:g} i h), one step = one time step of every trajectory: lock-step BFGS '
                                       f'(<= {args.bfgs_iters} iterations, gtol 1e-5, ' + ('inverse Hessians carried from time step to time step, '
                                                                                           if args.carry_hessian else 'identity start at every time step, ') +
@@ -658,7 +665,8 @@ def main_evolve(args):
                                       f'-sqrt|eta| with eta to {args.tol:g} (residual of the power method / rank-one test of the squaring)',
                           'baseline_config': 'BASELINE.json configs[4]', 'D': D, 'trajectories_per_gpu': T, 'n_params': P, 'seed': args.seed,
                           'bfgs_iterations_per_step': float(np.mean(nit)), 'carry_hessian': bool(args.carry_hessian),
-                          'driver': 'qmps_evolve_bfgs: the whole timed region is one C call' if native else 'numpy loop (tools.batched_bfgs), one ctypes call per batch', 'objective_evals_per_step': nfev / args.steps,
+                          'driver': ('qmps_evolve_bfgs_device: the optimiser on the device, one wave per trajectory, the whole timed region is ONE LAUNCH' if getattr(ev, 'device', False) else
+                                     'qmps_evolve_bfgs: the whole timed region is one C call') if native else 'numpy loop (tools.batched_bfgs), one ctypes call per batch', 'objective_evals_per_step': nfev / args.steps,
                           'objective_evals_per_s': world * nfev / elapsed,
                           'mean_final_objective': float(np.nanmean(f_last)), 'worst_final_objective': float(np.nanmax(f_last)),
                           'solver_rounds_mean_gradient_batches': sg['rounds_sum'] / max(1, sg['evaluations']), 'solver_rounds_max_gradient_batches': sg['rounds_max'],
@@ -669,7 +677,7 @@ def main_evolve(args):
                           'collective': 'none: independent trajectories (replicas only)', 'device': info['name'], 'arch': info['arch']},
                'roofline': {'bound': 'fp64_matrix' if D == 16 else ('fp64_matrix' if D == 4 else 'fp64_valu'), 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                             'frac': tflops / FP64_PEAK_TFLOPS, 'traffic': None,
-                            'kernel': ev.fg.eng.kernel_time(1)[1], 'kernel_ms': float(kms.mean()), 'launches': int(len(kms)),
+                            'kernel': 'evolve_bfgs_d2_kernel' if getattr(ev, 'device', False) else ev.fg.eng.kernel_time(1)[1], 'kernel_ms': float(kms.mean()), 'launches': int(len(kms)),
                             'kernel_ms_from': ('HIP events around EVERY gradient evaluation of an instrumented pass over the time steps that follow the timed region (same trajectories, same number of steps; the timed region itself runs without event records)' if native else 'HIP events around EVERY gradient evaluation of the timed region') + ' (sum of durations / launches)' +
                                               (': right solve + left solve + neighbour tensors + G + probes' if two_sided else ': the overlap kernel of the T (2P+1) candidates'),
                             'note': (f'dominant work = the gradient evaluation ({2 * T} eigen-solves + {2 * P * T} neighbour probes per launch); ' if two_sided else
@@ -901,6 +909,11 @@ def main():
                          "neighbours by eta' = <y, T'(r)>/<y, r>; 'fd' = every neighbour eigen-solved (what scipy's BFGS does with the reference objective)")
     ap.add_argument('--python-driver', action='store_true',
                     help='evolve workload: the lock-step BFGS loop in numpy (tools.batched_bfgs), one ctypes call per batch, instead of the one-call native driver (qmps_evolve_bfgs)')
+    ap.add_argument('--ansatz', choices=['shallow-cnot', 'shallow-full'], default='shallow-cnot',
+                    help="evolve workload at D = 2: 'shallow-full' = ShallowFullStateTensor(2, .) with 15 angles (qmps/new_time_evolve.py:186-187); default: "
+                         'ShallowCNOTStateTensor with 8 angles (scripts/loschmidt.py:203-207)')
+    ap.add_argument('--host-driver', action='store_true',
+                    help='evolve workload at D = 2: the host loop of qmps_evolve_bfgs (lock-step, a round trip per BFGS iteration) instead of the device-resident optimiser')
     ap.add_argument('--no-speculative', action='store_true',
                     help='evolve workload: always evaluate the backtracking ladder before the gradient (default: objective and gradient at the full '
                          'quasi-Newton step first, the ladder only when some trajectory rejects that step)')

@@ -418,6 +418,23 @@ int qmps_evolve_bfgs(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* p
                      double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
                      double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out);
 
+/* The same time evolution with the optimiser ON THE DEVICE, per trajectory (ABI 5; D = 2, the reference's own bond dimension:
+ * qmps/new_time_evolve.py:186-187, 276-292): ONE launch for the whole run, one wave per trajectory - its lanes are the
+ * 2 n_params + 1 central-difference candidates and the n_alphas - 1 backtracking points of an evaluation pass (each lane simulates
+ * the ansatz circuit of its parameter vector and eigen-solves its own 4 x 4 transfer map), x, g, H^-1 live in the wave's LDS, and the
+ * BFGS iteration of qmps_evolve_bfgs runs to convergence time step after time step WITHOUT returning to the host and without
+ * waiting for any other trajectory (qmps_amd/csrc/qmps_evolve_d2.hip).  Same decisions on the same numbers as qmps_evolve_bfgs for
+ * every trajectory (the host driver's floating-point expressions are reproduced operation for operation); what differs is the
+ * schedule: a trajectory's time step costs ITS iteration count, not the slowest trajectory's.
+ * Arguments as qmps_evolve_bfgs (flags: QMPS_BFGS_CARRY_HESSIAN, and QMPS_BFGS_WARM = "hinv holds the inverse Hessians to continue
+ * from"), except: nit_out (nullable) [n_steps][T] - iterations of EVERY trajectory in every step; counters_out (nullable) [4] =
+ * objective evaluations (candidates) of the whole run, evaluations that ended with status != 0, launch milliseconds (HIP events),
+ * squarings spent on the evaluations.
+ * n_params <= 16, n_alphas <= 16, 2 n_params + n_alphas <= 64.  Any T (no max_batch limit: nothing is staged per candidate). */
+int qmps_evolve_bfgs_device(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
+                            double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
+                            double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out);
+
 /* Device-resident TIME EVOLUTION by rotosolve on the overlap objective (BASELINE.json configs[4]; the reference's loop:
  * qmps/new_time_evolve.py:276-292 / scripts/loschmidt.py:367-375 `for _ in T: A_ = tensor(params); params =
  * minimize(obj, params, (A_, WW)).x`, with the rotosolve update of qmps/rotosolve.py:154-181 (nsh = 3) or

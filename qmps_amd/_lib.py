@@ -84,6 +84,8 @@ SIGNATURES = {
     'qmps_evolve_rotosolve': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, _dp, c_int, c_int, c_int, c_int, c_double, _dp, _dp]),
     'qmps_evolve_bfgs': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, _dp, c_int, c_int, c_double, c_double, c_double, c_int, _dp, c_int, c_int, c_double,
                                  _dp, _dp, _dp, _ip, _dp]),
+    'qmps_evolve_bfgs_device': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, _dp, c_int, c_int, c_double, c_double, c_double, c_int, _dp, c_int, c_int, c_double,
+                                        _dp, _dp, _dp, _ip, _dp]),
     'qmps_opt_env_objective': (c_int, [c_void_p, c_int64, _dp, _dp, c_double, _dp, _dp]),
     'qmps_bw_expval': (c_int, [c_void_p, c_int64, c_int, _dp, _dp, _dp, c_int, _dp]),
     'qmps_bw_env': (c_int, [c_void_p, c_int64, c_int, _dp, _dp, _dp, _dp, c_int, c_double, _dp, _dp, _dp, _ip]),

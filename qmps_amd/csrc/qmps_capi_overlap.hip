@@ -652,6 +652,72 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
 }
 QMPS_API_CATCH
 
+int qmps_evolve_bfgs_device(qmps_ctx* c, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
+                            double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
+                            double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out) try {
+  if (int rc = bind(c)) return rc;
+  if (!params || !WW || !f_hist || !alphas) return fail(QMPS_ERR_ARG, "null argument");
+  if (c->D != 2) return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs_device: D = 2 (other bond dimensions: qmps_evolve_bfgs)");
+  if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
+  const int P = n_params, NA = n_alphas;
+  if (P < 1 || P > 16 || NA < 1 || NA > 16 || 2 * P + NA > 64) return fail(QMPS_ERR_ARG, "n_params <= 16, n_alphas <= 16 and 2 n_params + n_alphas <= 64 (one wave per trajectory)");
+  if (T < 1 || n_steps < 1 || maxiter < 0 || !(gtol > 0.0) || !(h > 0.0) || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad T / n_steps / maxiter / gtol / h / tol");
+  if (max_rounds < 1 || max_rounds > 60) return fail(QMPS_ERR_ARG, "max_rounds in [1, 60] (squarings of the 4 x 4 map)");
+  if (int rc = check_ansatz(c, kind, P)) return rc;
+  const bool carry = (flags & QMPS_BFGS_CARRY_HESSIAN) != 0, carry_in = carry && (flags & QMPS_BFGS_WARM) != 0 && hinv != nullptr;
+  // device arena: params | hinv | params_hist | f_hist | nfev | WW | nit | fail  (doubles first, then the two int arrays)
+  const size_t TP = (size_t)T * P, nH = hinv ? TP * P : 0, nPH = params_hist ? (size_t)n_steps * TP : 0, nF = (size_t)n_steps * 2 * T;
+  const size_t n_dbl = TP + nH + nPH + nF + 2 * (size_t)T + 32, n_int = (size_t)n_steps * T + (size_t)T;
+  if (int rc = ensure_scratch(c, n_dbl * sizeof(double) + n_int * sizeof(int32_t) + 64)) return rc;
+  double* d_params = (double*)c->d_scratch;
+  double* d_hinv = d_params + TP;
+  double* d_ph = d_hinv + nH;
+  double* d_fh = d_ph + nPH;
+  double* d_nfev = d_fh + nF;
+  double* d_rounds = d_nfev + T;
+  double* d_ww = d_rounds + T;
+  int32_t* d_nit = (int32_t*)(d_ww + 32);
+  int32_t* d_fail = d_nit + (size_t)n_steps * T;
+  HIP_TRY(hipMemcpyAsync(d_params, params, TP * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d_ww, WW, 256, hipMemcpyHostToDevice, c->stream));
+  if (carry_in) HIP_TRY(hipMemcpyAsync(d_hinv, hinv, nH * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  qmps::EvolveD2Args a;
+  memset(&a, 0, sizeof(a));
+  a.params = d_params; a.WW = d_ww; a.hinv = hinv ? d_hinv : nullptr; a.params_hist = params_hist ? d_ph : nullptr; a.f_hist = d_fh; a.nit = d_nit;
+  a.nfev = d_nfev; a.rounds = d_rounds; a.fail = d_fail; a.T = T; a.P = P; a.n_steps = n_steps; a.maxiter = maxiter; a.NA = NA; a.max_rounds = max_rounds;
+  a.carry_in = carry_in ? 1 : 0; a.carry = carry ? 1 : 0; a.gtol = gtol; a.h = h; a.c1 = c1; a.tol = tol;
+  for (int r = 0; r < NA; ++r) a.alphas[r] = alphas[r];
+  if (const char* e = tuning_knob("QMPS_EVOLVE_PROBE")) a.probe = atoi(e);
+  c->dominant = "evolve_bfgs_d2_kernel";
+  if (counters_out) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  HIP_TRY(qmps::launch_evolve_bfgs_d2(kind, a, c->stream));
+  if (counters_out) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipMemcpyAsync(params, d_params, TP * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (hinv) HIP_TRY(hipMemcpyAsync(hinv, d_hinv, nH * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (params_hist) HIP_TRY(hipMemcpyAsync(params_hist, d_ph, nPH * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(f_hist, d_fh, nF * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (nit_out) HIP_TRY(hipMemcpyAsync(nit_out, d_nit, (size_t)n_steps * T * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  std::vector<double> nfev;
+  std::vector<int32_t> nfail;
+  if (counters_out) {
+    nfev.resize(2 * T);
+    nfail.resize(T);
+    HIP_TRY(hipMemcpyAsync(nfev.data(), d_nfev, (size_t)2 * T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(nfail.data(), d_fail, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (counters_out) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    double a0 = 0.0, a1 = 0.0, a3 = 0.0;
+    for (int64_t t = 0; t < T; ++t) { a0 += nfev[t]; a1 += nfail[t]; a3 += nfev[T + t]; }
+    counters_out[0] = a0; counters_out[1] = a1; counters_out[2] = ms; counters_out[3] = a3;
+  }
+  c->have_env = false; c->have_guess = false; c->have_overlap_x = false; c->acc_pending = false; c->partials_B = -1; c->grad_warm_T = 0;
+  return QMPS_OK;
+}
+QMPS_API_CATCH
+
 int qmps_evolve_rotosolve(qmps_ctx* c, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps,
                           int n_sweeps, int nsh, int max_rounds, double tol, double* params_hist, double* f_hist) try {
   if (int rc = bind(c)) return rc;

@@ -236,6 +236,9 @@ struct Reg {
   __device__ __forceinline__ void pppow(int q1, int q2, double t, bool yy) {
     double sn, cn;
     sincos(3.141592653589793 * t, &sn, &cn);
+    pppow_cs(q1, q2, cn, sn, yy);
+  }
+  __device__ __forceinline__ void pppow_cs(int q1, int q2, double cn, double sn, bool yy) {   // (cn, sn) = cos / sin of pi t
     const double ar = 0.5 * (1.0 + cn), ai = 0.5 * sn, br = 0.5 * (1.0 - cn), bi = -0.5 * sn;
     const int m1 = mask(q1), m2 = mask(q2);
 #pragma unroll
@@ -343,6 +346,54 @@ __device__ __forceinline__ void ansatz_circuit(Reg<NQ>& r, Par par, int n_params
       r.cnot(0, 1);
       r.rz(0, par(9)); r.rx(0, par(10)); r.rz(0, par(11));
       r.rz(1, par(12)); r.rx(1, par(13)); r.rz(1, par(14));
+    }
+  }
+}
+
+// The factor in front of parameter l inside its gate's sincos, for EVERY ansatz kind with a fixed number of qubits per angle
+// (0, 3: half angles; 1: pi/2 beta, pi gamma; 2: half angles; 6: half angles of rx, rx, rz, rz, then pi e, pi f)
+template <int KIND>
+__device__ __forceinline__ double ansatz_param_scale(int l) {
+  if (KIND == 1) return (l & 1) ? 3.141592653589793 : 1.5707963267948966;
+  if (KIND == 6) return l < 4 ? 0.5 : 3.141592653589793;
+  return 0.5;
+}
+// The same circuits with cos / sin of the scaled angles supplied by `cs(l)` -> (cos, sin): callers that simulate many circuits
+// whose angles mostly coincide (the central-difference columns of one iterate) compute each sincos ONCE and share it
+// (kinds 0, 1, 2, 3, 6; a double-precision sincos costs more than a whole two-qubit layer).
+template <int NQ, int KIND, class CS>
+__device__ __forceinline__ void ansatz_circuit_cs(Reg<NQ>& r, CS cs, int n_params) {
+  if (KIND == 0 || KIND == 1 || KIND == 3) {
+    constexpr int per = (KIND == 3) ? 3 : 2;
+    for (int l = 0; l + per <= n_params; l += per) {
+      double c[per], s[per];
+#pragma unroll
+      for (int k = 0; k < per; ++k) {
+        const double2 t = cs(l + k);
+        c[k] = t.x;
+        s[k] = t.y;
+      }
+      ansatz_layer_cs<NQ, KIND>(r, c, s);
+    }
+  } else if (KIND == 2) {
+    if constexpr (NQ == 2) {
+      double c[15], s[15];
+#pragma unroll
+      for (int k = 0; k < 15; ++k) {
+        const double2 t = cs(k);
+        c[k] = t.x;
+        s[k] = t.y;
+      }
+      r.shallow_full_cs(0, 1, c, s);
+    }
+  } else if (KIND == 6) {
+    if constexpr (NQ == 2) {
+      double2 t = cs(0); r.rx_cs(0, t.x, t.y);
+      t = cs(1); r.rx_cs(1, t.x, t.y);
+      t = cs(2); r.rz_cs(0, t.x, t.y);
+      t = cs(3); r.rz_cs(1, t.x, t.y);
+      t = cs(4); r.pppow_cs(0, 1, t.x, t.y, false);
+      t = cs(5); r.pppow_cs(0, 1, t.x, t.y, true);
     }
   }
 }

@@ -264,6 +264,25 @@ __device__ __forceinline__ bool power_gives_up(int k, double res2, double tol2, 
 }
 #endif
 hipError_t launch_overlap(const OverlapArgs& a, hipStream_t st);   // D = 2 (lane kernel, squaring)
+// D = 2: the whole BFGS time evolution in one launch, one wave per trajectory (qmps_evolve_d2.hip)
+constexpr int kEvolveMaxAlphas = 16;
+struct EvolveD2Args {
+  double* params;        // [T][P] in: start, out: final
+  const void* WW;        // [4][4] complex
+  double* hinv;          // nullable [T][P][P]: in (carry) / out
+  double* params_hist;   // nullable [n_steps][T][P]
+  double* f_hist;        // [n_steps][2][T]: objective at the start and at the end of every time step
+  int32_t* nit;          // [n_steps][T] BFGS iterations of trajectory t in step s
+  double* nfev;          // nullable [T]: objective evaluations (candidates) of the whole run
+  double* rounds;        // nullable [T]: squarings spent on them
+  int32_t* fail;         // nullable [T]: evaluations that ended with status != 0
+  int64_t T;
+  int P, n_steps, maxiter, NA, max_rounds, carry_in, carry;
+  int probe;             // timing experiments (QMPS_EVOLVE_PROBE, debug builds): bit 0 skip the eigen-solve, bit 1 skip the circuits
+  double gtol, h, c1, tol;
+  double alphas[kEvolveMaxAlphas];
+};
+hipError_t launch_evolve_bfgs_d2(int kind, const EvolveD2Args& a, hipStream_t st);
 // D = 8, 16: thick-restart Arnoldi over the candidates the power kernels gave up (status 1, iters < max_rounds); a.r_out holds their
 // iterates and receives the fixed points; `counter` zeroed by the caller (qmps_overlap_krylov.hip)
 hipError_t launch_overlap_krylov(int D, const OverlapArgs& a, int* counter, hipStream_t st);

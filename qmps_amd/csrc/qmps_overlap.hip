@@ -26,6 +26,7 @@
 #include "qmps_kernels.h"
 #include "qmps_knobs.h"
 #include "qmps_device.h"
+#include "qmps_overlap_d2.h"
 
 namespace qmps {
 
@@ -1104,144 +1105,17 @@ __global__ __launch_bounds__(64) void overlap_lane_kernel(OverlapArgs p) {
   if (b >= p.B || overlap_skipped(p, b)) return;
   const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * 8;
   const double2* Bp = (const double2*)p.Bt + b * 8;
-  const double2* W = (const double2*)p.WW;
-  // two-site products: AA[t1 t2] = A_t1 A_t2, BB likewise (2 x 2 complex each)
-  double aar[4][2][2], aai[4][2][2], bbr[4][2][2], bbi[4][2][2];
-#pragma unroll
-  for (int t1 = 0; t1 < 2; ++t1)
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          double ar = 0, ai = 0, br = 0, bi = 0;
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const double2 x = Ap[(t1 * 2 + i) * 2 + k], y = Ap[(t2 * 2 + k) * 2 + j];
-            ar += x.x * y.x - x.y * y.y;
-            ai += x.x * y.y + x.y * y.x;
-            const double2 u = Bp[(t1 * 2 + i) * 2 + k], v = Bp[(t2 * 2 + k) * 2 + j];
-            br += u.x * v.x - u.y * v.y;
-            bi += u.x * v.y + u.y * v.x;
-          }
-          aar[2 * t1 + t2][i][j] = ar; aai[2 * t1 + t2][i][j] = ai;
-          bbr[2 * t1 + t2][i][j] = br; bbi[2 * t1 + t2][i][j] = bi;
-        }
-  // C_s = sum_t WW[s][t] AA_t
-  double cr[4][2][2], ci[4][2][2];
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        double xr = 0, xi = 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const double2 w = W[s * 4 + t];
-          xr += w.x * aar[t][i][j] - w.y * aai[t][i][j];
-          xi += w.x * aai[t][i][j] + w.y * aar[t][i][j];
-        }
-        cr[s][i][j] = xr; ci[s][i][j] = xi;
-      }
-  // E[(i,i'),(j,j')] = sum_s C_s[i][j] conj(Bm_s[i'][j'])
-  double er[4][4], ei[4][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int ip = 0; ip < 2; ++ip)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          double xr = 0, xi = 0;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            xr += cr[s][i][j] * bbr[s][ip][jp] + ci[s][i][j] * bbi[s][ip][jp];
-            xi += ci[s][i][j] * bbr[s][ip][jp] - cr[s][i][j] * bbi[s][ip][jp];
-          }
-          er[2 * i + ip][2 * j + jp] = xr; ei[2 * i + ip][2 * j + jp] = xi;
-        }
-  double mr[4][4], mi[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { mr[a][c] = er[a][c]; mi[a][c] = ei[a][c]; }
-  double eta_r = 0.0, eta_i = 0.0, vr[4] = {1, 0, 0, 0}, vi[4] = {0, 0, 0, 0};
-  int status = QMPS_ST_NOT_CONVERGED, rounds = 0;
-  const double tol2 = p.tol * p.tol;
-  for (int m = 0; m <= p.max_rounds; ++m) {
-    // dominant right vector = largest column of the current power
-    double best = -1.0;
-    int bc = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      double n2 = 0.0;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) n2 += mr[a][c] * mr[a][c] + mi[a][c] * mi[a][c];
-      if (n2 > best) { best = n2; bc = c; }
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      vr[a] = bc == 0 ? mr[a][0] : (bc == 1 ? mr[a][1] : (bc == 2 ? mr[a][2] : mr[a][3]));
-      vi[a] = bc == 0 ? mi[a][0] : (bc == 1 ? mi[a][1] : (bc == 2 ? mi[a][2] : mi[a][3]));
-    }
-    // eta = <v, E v>/<v, v>, residual ||E v - eta v||^2 / ||v||^2
-    double wr[4], wi[4], num_r = 0, num_i = 0, vv = 0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      double xr = 0, xi = 0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        xr += er[a][c] * vr[c] - ei[a][c] * vi[c];
-        xi += er[a][c] * vi[c] + ei[a][c] * vr[c];
-      }
-      wr[a] = xr; wi[a] = xi;
-      num_r += vr[a] * xr + vi[a] * xi;
-      num_i += vr[a] * xi - vi[a] * xr;
-      vv += vr[a] * vr[a] + vi[a] * vi[a];
-    }
-    eta_r = num_r / vv; eta_i = num_i / vv;
-    double res = 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const double dr = wr[a] - (eta_r * vr[a] - eta_i * vi[a]), di = wi[a] - (eta_r * vi[a] + eta_i * vr[a]);
-      res += dr * dr + di * di;
-    }
-    rounds = m;
-    if (res < tol2 * vv) { status = QMPS_ST_OK; break; }
-    if (m == p.max_rounds) break;
-    // square and Frobenius-normalise
-    double qr[4][4], qi[4][4], f2 = 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        double xr = 0, xi = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          xr += mr[a][k] * mr[k][c] - mi[a][k] * mi[k][c];
-          xi += mr[a][k] * mi[k][c] + mi[a][k] * mr[k][c];
-        }
-        qr[a][c] = xr; qi[a][c] = xi;
-        f2 += xr * xr + xi * xi;
-      }
-    const double inv = f2 > 0.0 ? 1.0 / __builtin_sqrt(f2) : 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { mr[a][c] = qr[a][c] * inv; mi[a][c] = qi[a][c] * inv; }
-  }
-  overlap_store(p, b, eta_r, eta_i, rounds, status);
+  OverlapLaneResult o;
+  overlap_lane_solve([&](int k) { return Ap[k]; }, [&](int k) { return Bp[k]; }, (const double2*)p.WW, p.max_rounds, p.tol, o);
+  overlap_store(p, b, o.eta_r, o.eta_i, o.rounds, o.status);
   if (p.r_out != nullptr) {
     double n2 = 0.0;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) n2 += vr[a] * vr[a] + vi[a] * vi[a];
+    for (int a = 0; a < 4; ++a) n2 += o.vr[a] * o.vr[a] + o.vi[a] * o.vi[a];
     const double inv = n2 > 0.0 ? 1.0 / __builtin_sqrt(n2) : 0.0;
     double2* ro = (double2*)((char*)p.r_out + overlap_slot_offset(p));
 #pragma unroll
-    for (int a = 0; a < 4; ++a) ro[b * 4 + a] = make_double2(vr[a] * inv, vi[a] * inv);
+    for (int a = 0; a < 4; ++a) ro[b * 4 + a] = make_double2(o.vr[a] * inv, o.vi[a] * inv);
   }
 }
 

@@ -136,7 +136,8 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
           tracking W|AA>; a RuntimeWarning says so once per call when a step ends above where it started.  Use 'BFGS' for physics;
       method 'BFGS': lock-step batched BFGS - by default the whole evolution in ONE C call (`qmps_evolve_bfgs`: objective and
           gradient at the full quasi-Newton step first, the backtracking ladder only for trajectories that reject it; the same
-          decisions as a plain ladder); options {'native': False} runs the same loop from numpy (`tools.batched_bfgs`, per-iteration
+          decisions as a plain ladder; at D = 2 the optimiser itself runs on the device, one wave per trajectory, every trajectory at
+          its own pace: `qmps_evolve_bfgs_device`, options {'device_driver': False} for the host loop); options {'native': False} runs the same loop from numpy (`tools.batched_bfgs`, per-iteration
           objective history), {'speculative': False} the plain two-batch iteration (gradient columns, then the ladder);
           'carry_hessian', 'tight_gradient', 'gradient', 'first_rungs', 'maxiter', 'gtol', 'eps', 'alphas' as in LockstepEvolver;
       anything else: scipy.optimize.minimize on the scalar `obj` per trajectory (the reference's own call).
@@ -174,7 +175,7 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
         ev = LockstepEvolver(D, T, P, cls, mr, tol, opts.get('maxiter', 200), opts.get('gtol', 1e-5), opts.get('eps', 1e-6), ladder,
                              gradient=opts.get('gradient', 'auto'), first_rungs=opts.get('first_rungs'),
                              carry_hessian=opts.get('carry_hessian', False), speculative=opts.get('speculative', True), native=opts.get('native', True),
-                             tight_gradient=opts.get('tight_gradient', False))
+                             tight_gradient=opts.get('tight_gradient', False), device_driver=opts.get('device_driver', True))
         fg, fl = ev.fg, ev.fl
         try:
             for step in range(n_steps):
@@ -212,7 +213,7 @@ class LockstepEvolver:
 
     def __init__(self, D, T, P, cls=None, max_rounds=None, tol=1e-12, maxiter=200, gtol=1e-5, eps=1e-6,
                  alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), device=0, gradient='auto', first_rungs=None,
-                 carry_hessian=False, speculative=False, native=True, tight_gradient=False):
+                 carry_hessian=False, speculative=False, native=True, tight_gradient=False, device_driver=True):
         """native (with speculative and the two-sided gradient): the whole time step - every BFGS iteration of every trajectory - is
         ONE C call (qmps_evolve_bfgs: the loop of tools.batched_bfgs with its host arithmetic in C++ inside the library); False: the
         same loop in numpy, one ctypes call per batch.
@@ -238,6 +239,9 @@ class LockstepEvolver:
         # any other combination of options (gradient='fd' at D >= 4, speculative=False) runs the numpy loop, which implements them all
         # (first_rungs only shapes the NON-speculative ladder, so it does not matter here)
         self.native = bool(native) and self.speculative and (self.two_sided or D == 2)
+        # D = 2 (the reference's own bond dimension): the native driver is the DEVICE-resident one - a wave per trajectory runs every
+        # BFGS iteration of every time step without returning to the host (device=False: the host loop of qmps_evolve_bfgs)
+        self.device = self.native and D == 2 and bool(device_driver) and not self.two_sided and P <= 16 and 2 * P + len(self.alphas) <= 64
         self.mr, self.tol = mr, tol
         self.tight_gradient = bool(tight_gradient) or not self.two_sided
         if self.native:
@@ -258,6 +262,19 @@ class LockstepEvolver:
         """n_steps time steps in one C call (native driver): dict(x, params_hist, fun (n_steps, T), nit (n_steps,), ...)."""
         if not self.native:
             raise RuntimeError('LockstepEvolver.steps needs the native driver (speculative=True, two-sided gradient)')
+        if self.device:
+            # D = 2: the optimiser itself on the device, one wave per trajectory, the whole call in one launch (qmps_evolve_bfgs_device)
+            res = self.fg.eng.evolve_bfgs_device(self.kind, X, WW, n_steps=n_steps, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas,
+                                                 carry_hessian=self.carry_hessian, hess_inv=self._hinv if (self.carry_hessian and self._continued) else None,
+                                                 max_rounds=min(self.mr, 60), tol=self.tol, counters=counters)
+            self._continued = True
+            self._hinv = res['hess_inv']
+            res['nit_per_trajectory'] = res['nit']
+            res['nit'] = res['nit'].max(axis=1)                 # (the lock-step drivers' count: the slowest trajectory's)
+            res['gradient_batches'], res['ladder_batches'], res['gradient_ms'] = 0, 0, res['kernel_ms']
+            if self.fg.kernel_ms is not None and counters:
+                self.fg.kernel_ms += [res['kernel_ms']]
+            return res
         res = self.fg.eng.evolve_bfgs(self.kind, X, WW, n_steps=n_steps, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas,
                                       carry_hessian=self.carry_hessian, hess_inv=self._hinv if (self.carry_hessian and self._continued) else None,
                                       warm=self._continued, max_rounds=self.mr, tol=self.tol, tight_gradient=self.tight_gradient, counters=counters)

@@ -14,7 +14,7 @@ SHIFTS3 = (0.0, np.pi / 2, -np.pi / 2)
 
 def builder(kind):
     return {0: O.shallow_cnot_unitary, 1: O.shallow_qaoa_unitary, 2: lambda D, p: O.shallow_full_unitary(p),
-            3: O.shallow_cnot3_unitary}[kind]
+            3: O.shallow_cnot3_unitary, 6: lambda D, p: O.state_gate_unitary(p)}[kind]
 
 
 def tensor(kind, D, p):

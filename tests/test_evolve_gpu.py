@@ -335,6 +335,51 @@ def test_two_sided_objective_is_second_order_in_the_residuals(D, P, engine_facto
     assert loose['rounds_sum'] < 0.85 * tight['rounds_sum']
 
 
+@pytest.mark.parametrize('kind,P,carry', [(2, 15, False), (0, 8, False), (0, 8, True), (6, 6, False)])
+def test_device_resident_bfgs_d2_takes_the_decisions_of_the_host_driver(kind, P, carry, engine_factory):
+    """qmps_evolve_bfgs_device (D = 2: the optimiser on the device, one wave per trajectory, the whole run in one launch)
+    against qmps_evolve_bfgs (the same iteration with its loop on the host, lock-step): per trajectory the same parameters, the same
+    objectives, the same iteration counts - the host driver's floating-point expressions are reproduced operation for operation,
+    and both call the same device code for tensors and eigen-solves - and the recorded objectives are the ORACLE's (dense
+    eigen-solve) at the device's parameters.  ShallowFull (15 angles: the reference's own case, new_time_evolve.py:186-187),
+    ShallowCNOT (scripts/loschmidt.py:203-207), StateGate."""
+    rng = np.random.default_rng(900 + kind + P)
+    T, n_steps = 7, 3
+    X0 = rng.standard_normal((T, P))
+    WW = WW_of(0.05)
+    eng = engine_factory(2, T * (2 * P + 1))
+    host = eng.evolve_bfgs(kind, X0, WW, n_steps=n_steps, maxiter=40, tol=1e-13, carry_hessian=carry)
+    dev = eng.evolve_bfgs_device(kind, X0, WW, n_steps=n_steps, maxiter=40, tol=1e-13, carry_hessian=carry)
+    assert dev['nit'].shape == (n_steps, T) and np.abs(dev['nit'].max(axis=1) - host['nit']).max() <= (3 if carry else 1)
+    # (not bit for bit - the compilers contract the two drivers' expressions differently here and there: rounding-level differences,
+    # which travel freely along the flat directions of eight / fifteen angles on two qubits; objectives agree to 1e-9)
+    print('max |f_dev - f_host|', np.abs(dev['fun'] - host['fun']).max(), 'max |x_dev - x_host|', np.abs(dev['params_hist'] - host['params_hist']).max())
+    # first time step: rounding level; later ones: both drivers stop where max|g| < gtol = 1e-5, i.e. within ~1e-8 of the minimum
+    assert np.abs(dev['fun'][0] - host['fun'][0]).max() < 1e-8 and np.abs(dev['fun_start'][0] - host['fun_start'][0]).max() < 1e-12
+    # (carried inverse Hessians at D = 2 are ill-conditioned along the flat directions: a line search that fails a little earlier or
+    # later moves the stopping point by more - DESIGN 5.2: "at D = 2, 4 the identity start is the faster one")
+    assert np.abs(dev['fun'] - host['fun']).max() < (1e-5 if carry else 1e-7) and np.abs(dev['fun_start'] - host['fun_start']).max() < 1e-5
+    # the parameter vectors through what they describe (flat directions: eight / fifteen angles on two qubits): the same physical states
+    for step in range(n_steps):
+        for t in range(T):
+            o = abs(O.overlap_eta(ER.tensor(kind, 2, dev['params_hist'][step, t]), ER.tensor(kind, 2, host['params_hist'][step, t]), np.eye(4))[0])
+            assert abs(o - 1.0) < (1e-4 if carry else 1e-6), (step, t, o)
+    assert dev['failed_evaluations'] == 0 and dev['nfev'] > 0 and dev['kernel_ms'] > 0
+    # the oracle's objective at the device's parameters: previous parameters = the reference state of the step
+    prev = X0
+    for step in range(n_steps):
+        for t in (0, T - 1):
+            f_t = ER.objective(kind, 2, ER.tensor(kind, 2, prev[t]), dev['params_hist'][step, t], WW)
+            assert abs(f_t - dev['fun'][step, t]) < F_TOL
+        prev = dev['params_hist'][step]
+    assert dev['fun'][-1].mean() < -0.999
+    # a continued run (inverse Hessians handed back in) = the one-call run
+    if carry:
+        a = eng.evolve_bfgs_device(kind, X0, WW, n_steps=2, maxiter=40, tol=1e-13, carry_hessian=True)
+        b = eng.evolve_bfgs_device(kind, a['x'], WW, n_steps=1, maxiter=40, tol=1e-13, carry_hessian=True, hess_inv=a['hess_inv'])
+        assert np.array_equal(b['x'], dev['x']) and np.array_equal(b['fun'][0], dev['fun'][2])          # (same kernel, same numbers)
+
+
 def test_native_bfgs_driver_argument_checks_and_single_rung(engine_factory):
     """Refusals of qmps_evolve_bfgs (batch larger than the context, a warm continuation without resident fixed points)
     and the ladder-free variant (one step length: a rejected full step ends the trajectory's minimisation)."""

@@ -418,7 +418,7 @@ int qmps_evolve_bfgs(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* p
                      double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
                      double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out);
 
-/* The same time evolution with the optimiser ON THE DEVICE, per trajectory (ABI 5; D = 2, the reference's own bond dimension:
+/* The same time evolution with the optimiser ON THE DEVICE, per trajectory (ABI 5; D = 2 - the reference's own bond dimension - and D = 4:
  * qmps/new_time_evolve.py:186-187, 276-292): ONE launch for the whole run, one wave per trajectory - its lanes are the
  * 2 n_params + 1 central-difference candidates and the n_alphas - 1 backtracking points of an evaluation pass (each lane simulates
  * the ansatz circuit of its parameter vector and eigen-solves its own 4 x 4 transfer map), x, g, H^-1 live in the wave's LDS, and the
@@ -430,7 +430,12 @@ int qmps_evolve_bfgs(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* p
  * from"), except: nit_out (nullable) [n_steps][T] - iterations of EVERY trajectory in every step; counters_out (nullable) [4] =
  * objective evaluations (candidates) of the whole run, evaluations that ended with status != 0, launch milliseconds (HIP events),
  * squarings spent on the evaluations.
- * n_params <= 16, n_alphas <= 16, 2 n_params + n_alphas <= 64.  Any T (no max_batch limit: nothing is staged per candidate). */
+ * n_params <= 16, n_alphas <= 16, 2 n_params + n_alphas <= 64.  Any T (no max_batch limit: nothing is staged per candidate).
+ * D = 4 (qmps_amd/csrc/qmps_evolve_d4.hip): a WORKGROUP per trajectory, its waves are the candidates - each builds its tensor (four lanes
+ * simulate the four columns of the ansatz unitary) and squares its 16 x 16 map on the matrix cores (the code of the D = 4 overlap
+ * kernel), the 2 n_params + 1 solves of a pass side by side; every neighbour is eigen-solved (no two-sided first-order gradient as in
+ * qmps_evolve_bfgs: exact central differences, results agree with the host driver's to the accuracy of its gradient, ~1e-8).
+ * 2 n_params + 1 <= 12, n_alphas <= 13, ShallowCNOT / QAOA / CNOT3; the backtracking points are evaluated only when the full step is rejected. */
 int qmps_evolve_bfgs_device(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
                             double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
                             double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out);

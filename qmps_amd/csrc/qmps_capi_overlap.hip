@@ -657,10 +657,12 @@ int qmps_evolve_bfgs_device(qmps_ctx* c, int64_t T, int kind, int n_params, doub
                             double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out) try {
   if (int rc = bind(c)) return rc;
   if (!params || !WW || !f_hist || !alphas) return fail(QMPS_ERR_ARG, "null argument");
-  if (c->D != 2) return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs_device: D = 2 (other bond dimensions: qmps_evolve_bfgs)");
+  if (c->D != 2 && c->D != 4) return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs_device: D = 2, 4 (other bond dimensions: qmps_evolve_bfgs)");
   if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
   const int P = n_params, NA = n_alphas;
   if (P < 1 || P > 16 || NA < 1 || NA > 16 || 2 * P + NA > 64) return fail(QMPS_ERR_ARG, "n_params <= 16, n_alphas <= 16 and 2 n_params + n_alphas <= 64 (one wave per trajectory)");
+  if (c->D == 4 && (2 * P + 1 > 12 || NA - 1 > 12 || (kind != QMPS_ANSATZ_SHALLOW_CNOT && kind != QMPS_ANSATZ_SHALLOW_QAOA && kind != QMPS_ANSATZ_SHALLOW_CNOT3)))
+    return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs_device at D = 4: a wave per candidate, 12 waves per trajectory - 2 n_params + 1 <= 12, n_alphas <= 13; ShallowCNOT / QAOA / CNOT3");
   if (T < 1 || n_steps < 1 || maxiter < 0 || !(gtol > 0.0) || !(h > 0.0) || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad T / n_steps / maxiter / gtol / h / tol");
   if (max_rounds < 1 || max_rounds > 60) return fail(QMPS_ERR_ARG, "max_rounds in [1, 60] (squarings of the 4 x 4 map)");
   if (int rc = check_ansatz(c, kind, P)) return rc;
@@ -688,9 +690,10 @@ int qmps_evolve_bfgs_device(qmps_ctx* c, int64_t T, int kind, int n_params, doub
   a.carry_in = carry_in ? 1 : 0; a.carry = carry ? 1 : 0; a.gtol = gtol; a.h = h; a.c1 = c1; a.tol = tol;
   for (int r = 0; r < NA; ++r) a.alphas[r] = alphas[r];
   if (const char* e = tuning_knob("QMPS_EVOLVE_PROBE")) a.probe = atoi(e);
-  c->dominant = "evolve_bfgs_d2_kernel";
+  c->dominant = c->D == 2 ? "evolve_bfgs_d2_kernel" : "evolve_bfgs_d4_kernel";
   if (counters_out) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  HIP_TRY(qmps::launch_evolve_bfgs_d2(kind, a, c->stream));
+  if (c->D == 2) HIP_TRY(qmps::launch_evolve_bfgs_d2(kind, a, c->stream));
+  else HIP_TRY(qmps::launch_evolve_bfgs_d4(kind, a, c->stream));
   if (counters_out) HIP_TRY(hipEventRecord(c->ev1, c->stream));
   HIP_TRY(hipMemcpyAsync(params, d_params, TP * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (hinv) HIP_TRY(hipMemcpyAsync(hinv, d_hinv, nH * sizeof(double), hipMemcpyDeviceToHost, c->stream));

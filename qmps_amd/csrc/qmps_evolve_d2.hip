@@ -24,16 +24,15 @@
 #include "qmps_device.h"
 #include "qmps_circuit.h"
 #include "qmps_overlap_d2.h"
+#include "qmps_evolve_core.h"
 
 namespace qmps {
 
 namespace {
 
-constexpr int PMAX = 16;     // parameters per trajectory (ShallowFull: 15; ShallowCNOT at D = 2: 2 per layer)
-
-__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
-__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
-__device__ __forceinline__ double sub_rn(double a, double b) { return __dsub_rn(a, b); }
+constexpr int PMAX = kEvolvePMax;     // parameters per trajectory (ShallowFull: 15; ShallowCNOT at D = 2: 2 per layer)
+using evolve_detail::add_rn;
+using evolve_detail::mul_rn;
 
 }  // namespace
 
@@ -41,13 +40,12 @@ __device__ __forceinline__ double sub_rn(double a, double b) { return __dsub_rn(
 template <int KIND>
 __global__ __launch_bounds__(64) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
   const int64_t t = blockIdx.x;
-  const int lane = threadIdx.x, P = p.P, NA = p.NA, G = NA - 1;
+  const int lane = threadIdx.x, P = p.P;
   __shared__ double sX[PMAX], sG[PMAX], sD[PMAX], sS[PMAX], sGn[PMAX], sHy[PMAX], sH[PMAX][PMAX + 1], sF[64];
   __shared__ int sOK[64];
   __shared__ double2 sA[8], sCS[PMAX], sLCS[kEvolveMaxAlphas * PMAX];
   __shared__ double sZ[PMAX];
   const double2* W = (const double2*)p.WW;
-  const double NaN = __builtin_nan("");
   // ---- one evaluation pass.  Lane roles: < G1 = 2P + 1: central-difference columns of z = x + coef d; [G1, G1 + n_ladder): x + alpha_{r+1} d
   // returns nothing: sF / sOK hold -sqrt|eta| and status == OK of every lane
   double nfev = 0.0, nrounds = 0.0;       // (nrounds: this LANE's squarings, summed over the wave at the end)
@@ -112,41 +110,10 @@ __global__ __launch_bounds__(64) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
     nfev += (double)(G1 + n_ladder);
     for (int l = 0; l < G1 + n_ladder; ++l) nfail += sOK[l] ? 0 : 1;
   };
-  // objective and gradient of the last pass (gradient lanes): f, and g into `gout` (LDS)
-  auto read_fg = [&](double& f, double* gout) {
-    f = sOK[0] ? sF[0] : NaN;
-    if (lane < P) gout[lane] = (sOK[1 + lane] && sOK[1 + P + lane]) ? (sF[1 + lane] - sF[1 + P + lane]) / (2.0 * p.h) : NaN;
-    __builtin_amdgcn_wave_barrier();
-  };
-  auto gmax_at_least = [&](const double* gt, double bound) {      // np.abs(g).max() >= bound; false with any NaN
-    double m = 0.0;
-    for (int k = 0; k < P; ++k) {
-      const double v = gt[k];
-      if (v != v) return false;
-      const double a = fabs(v);
-      m = a > m ? a : m;
-    }
-    return m >= bound;
-  };
-  auto set_identity = [&]() {
-    if (lane < P)
-      for (int b = 0; b < P; ++b) sH[lane][b] = lane == b ? 1.0 : 0.0;
-    __builtin_amdgcn_wave_barrier();
-  };
-
-  if (lane < P) {
-    sX[lane] = p.params[t * P + lane];
-    sD[lane] = 0.0;
-  }
-  if (p.carry_in && p.hinv != nullptr) {
-    if (lane < P)
-      for (int b = 0; b < P; ++b) sH[lane][b] = p.hinv[(t * P + lane) * P + b];
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (!(p.carry_in && p.hinv != nullptr)) set_identity();
-
-  for (int step = 0; step < p.n_steps; ++step) {
-    // ---- the step's reference tensor A = tensor(x): lanes 0, 1 simulate the two columns
+  BfgsLds L;
+  L.X = sX; L.G = sG; L.D = sD; L.S = sS; L.Gn = sGn; L.Hy = sHy; L.H = sH; L.F = sF; L.OK = sOK;
+  auto build_reference = [&]() {
+    // the step's reference tensor A = tensor(x): lanes 0, 1 simulate the two columns
     if (lane < P) {
       double sn, cs_;
       sincos(ansatz_param_scale<KIND>(lane) * sX[lane], &sn, &cs_);
@@ -165,107 +132,8 @@ __global__ __launch_bounds__(64) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
       for (int x = 0; x < 4; ++x) sA[((x & 1) * 2 + (x >> 1)) * 2 + lane] = make_double2(r.re[x], r.im[x]);
     }
     __builtin_amdgcn_wave_barrier();
-    if (!(p.carry && (step > 0 || p.carry_in))) set_identity();
-    double f;
-    evaluate(0.0, 0);
-    read_fg(f, sG);
-    if (lane == 0) p.f_hist[((int64_t)step * 2 + 0) * p.T + t] = f;
-    bool active = gmax_at_least(sG, p.gtol);
-    int nit = 0;
-    while (nit < p.maxiter && active) {
-      // ---- direction d = -H g (lane a: row a), slope = g . d; not a descent direction: restart from steepest descent
-      if (lane < P) {
-        double acc = 0.0;
-        for (int b = 0; b < P; ++b) acc = add_rn(acc, mul_rn(sH[lane][b], sG[b]));
-        sD[lane] = -acc;
-      }
-      __builtin_amdgcn_wave_barrier();
-      double sl = 0.0;
-      for (int a = 0; a < P; ++a) sl = add_rn(sl, mul_rn(sG[a], sD[a]));
-      if (!(sl < 0.0)) {
-        set_identity();
-        if (lane < P) sD[lane] = -sG[lane];
-        __builtin_amdgcn_wave_barrier();
-        sl = 0.0;
-        for (int a = 0; a < P; ++a) sl = sub_rn(sl, mul_rn(sG[a], sG[a]));
-      }
-      // ---- the full step with its gradient AND the rest of the ladder in one pass (the ladder values are used only on rejection)
-      evaluate(p.alphas[0], G);
-      double fs;
-      read_fg(fs, sGn);
-      const int G1 = 2 * P + 1;
-      double F0 = (fs == fs && fabs(fs) != INFINITY) ? fs : INFINITY;
-      const bool need = !(F0 <= add_rn(f, mul_rn(mul_rn(p.c1, p.alphas[0]), sl)));
-      int first = -1, best = 0;
-      double Fbest = F0, Ffirst = 0.0;
-      for (int r = 0; r < NA; ++r) {
-        double Fr = F0;
-        if (r > 0) {
-          const double v = (need && sOK[G1 + r - 1]) ? sF[G1 + r - 1] : NaN;
-          Fr = (v == v && fabs(v) != INFINITY) ? v : INFINITY;
-        }
-        if (first < 0 && Fr <= add_rn(f, mul_rn(mul_rn(p.c1, p.alphas[r]), sl))) { first = r; Ffirst = Fr; }
-        if (Fr < Fbest) { Fbest = Fr; best = r; }
-      }
-      if (first < 0) { first = best; Ffirst = Fbest; }
-      const bool moved = Ffirst < f;
-      const double a_step = moved ? p.alphas[first] : 0.0;
-      if (lane < P) sS[lane] = mul_rn(a_step, sD[lane]);
-      __builtin_amdgcn_wave_barrier();
-      double fn = fs;
-      if (need && moved) {
-        // the accepted point is a shorter rung: its objective and gradient (x + s = x + alpha_first d)
-        evaluate(a_step, 0);
-        read_fg(fn, sGn);
-      }
-      if (moved) {
-        // ---- rank-two update of the inverse Hessian (curvature guard as scipy), then accept
-        double sy = 0.0, ss = 0.0, yy = 0.0;
-        for (int k = 0; k < P; ++k) {
-          const double y = sub_rn(sGn[k], sG[k]);
-          sy = add_rn(sy, mul_rn(sS[k], y));
-          ss = add_rn(ss, mul_rn(sS[k], sS[k]));
-          yy = add_rn(yy, mul_rn(y, y));
-        }
-        if (sy > 1e-12 * sqrt(mul_rn(ss, yy)) && sy > 0.0) {
-          const double rho = 1.0 / sy;
-          if (lane < P) {
-            double acc = 0.0;
-            for (int b = 0; b < P; ++b) acc = add_rn(acc, mul_rn(sH[lane][b], sub_rn(sGn[b], sG[b])));
-            sHy[lane] = acc;
-          }
-          __builtin_amdgcn_wave_barrier();
-          double yHy = 0.0;
-          for (int a = 0; a < P; ++a) yHy = add_rn(yHy, mul_rn(sub_rn(sGn[a], sG[a]), sHy[a]));
-          const double coef = mul_rn(rho, add_rn(1.0, mul_rn(rho, yHy)));
-          if (lane < P) {
-            const int a = lane;
-            for (int b = 0; b < P; ++b)
-              sH[a][b] = add_rn(sub_rn(sH[a][b], add_rn(mul_rn(mul_rn(rho, sS[a]), sHy[b]), mul_rn(mul_rn(rho, sS[b]), sHy[a]))), mul_rn(mul_rn(coef, sS[a]), sS[b]));
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-        f = fn;
-        if (lane < P) {
-          sG[lane] = sGn[lane];
-          sX[lane] = add_rn(sX[lane], sS[lane]);
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      active = moved && gmax_at_least(sG, p.gtol);
-      ++nit;
-    }
-    if (lane == 0) {
-      p.f_hist[((int64_t)step * 2 + 1) * p.T + t] = f;
-      p.nit[(int64_t)step * p.T + t] = nit;
-    }
-    if (p.params_hist != nullptr && lane < P) p.params_hist[((int64_t)step * p.T + t) * P + lane] = sX[lane];
-  }
-  if (lane < P) {
-    p.params[t * P + lane] = sX[lane];
-    if (p.hinv != nullptr)
-      for (int b = 0; b < P; ++b) p.hinv[(t * P + lane) * P + b] = sH[lane][b];
-  }
+  };
+  bfgs_time_evolution(p, t, lane < P ? lane : -1, lane == 0, L, evaluate, build_reference, [] { __builtin_amdgcn_wave_barrier(); }, true);
   nrounds = wave_sum(nrounds);
   if (lane == 0) {
     if (p.nfev != nullptr) p.nfev[t] = nfev;

@@ -241,7 +241,9 @@ class LockstepEvolver:
         self.native = bool(native) and self.speculative and (self.two_sided or D == 2)
         # D = 2 (the reference's own bond dimension): the native driver is the DEVICE-resident one - a wave per trajectory runs every
         # BFGS iteration of every time step without returning to the host (device=False: the host loop of qmps_evolve_bfgs)
-        self.device = self.native and D == 2 and bool(device_driver) and not self.two_sided and P <= 16 and 2 * P + len(self.alphas) <= 64
+        self.device = (self.native and bool(device_driver) and P <= 16 and 2 * P + len(self.alphas) <= 64 and
+                       ((D == 2 and not self.two_sided) or
+                        (D == 4 and gradient == 'auto' and 2 * P + 1 <= 12 and len(self.alphas) <= 13 and self.kind in (L.ANSATZ_SHALLOW_CNOT, 1, 3))))
         self.mr, self.tol = mr, tol
         self.tight_gradient = bool(tight_gradient) or not self.two_sided
         if self.native:
@@ -263,7 +265,7 @@ class LockstepEvolver:
         if not self.native:
             raise RuntimeError('LockstepEvolver.steps needs the native driver (speculative=True, two-sided gradient)')
         if self.device:
-            # D = 2: the optimiser itself on the device, one wave per trajectory, the whole call in one launch (qmps_evolve_bfgs_device)
+            # D = 2, 4: the optimiser itself on the device (a wave / a workgroup per trajectory), the whole call in one launch (qmps_evolve_bfgs_device)
             res = self.fg.eng.evolve_bfgs_device(self.kind, X, WW, n_steps=n_steps, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas,
                                                  carry_hessian=self.carry_hessian, hess_inv=self._hinv if (self.carry_hessian and self._continued) else None,
                                                  max_rounds=min(self.mr, 60), tol=self.tol, counters=counters)

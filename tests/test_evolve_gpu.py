@@ -380,6 +380,38 @@ def test_device_resident_bfgs_d2_takes_the_decisions_of_the_host_driver(kind, P,
         assert np.array_equal(b['x'], dev['x']) and np.array_equal(b['fun'][0], dev['fun'][2])          # (same kernel, same numbers)
 
 
+def test_device_resident_bfgs_d4_against_the_host_driver_and_the_oracle(engine_factory):
+    """qmps_evolve_bfgs_device at D = 4 (a workgroup per trajectory, a wave per candidate, every candidate eigen-solved by squaring on
+    the matrix cores) against qmps_evolve_bfgs (host loop, two-sided first-order gradient): the same minima - objectives to 1e-8, the
+    same physical states - and the recorded objectives are the ORACLE's (dense eigen-solve) at the device's parameters.  Also the
+    per-trajectory iteration counts: nobody waits for the slowest trajectory."""
+    rng = np.random.default_rng(1404)
+    kind, P, T, n_steps = 0, 4, 9, 3
+    X0 = rng.standard_normal((T, P))
+    WW = WW_of(0.05)
+    eng = engine_factory(4, T * (2 * P + 1))
+    host = eng.evolve_bfgs(kind, X0, WW, n_steps=n_steps, maxiter=40, tol=1e-13)
+    dev = eng.evolve_bfgs_device(kind, X0, WW, n_steps=n_steps, maxiter=40, tol=1e-13)
+    assert dev['failed_evaluations'] == 0 and dev['nit'].shape == (n_steps, T)
+    print('max |f_dev - f_host|', np.abs(dev['fun'] - host['fun']).max(), 'nit dev (max per step)', dev['nit'].max(axis=1), 'host', host['nit'])
+    assert np.abs(dev['fun'] - host['fun']).max() < 1e-7 and np.abs(dev['fun_start'][0] - host['fun_start'][0]).max() < 1e-10
+    prev = X0
+    for step in range(n_steps):
+        for t in range(T):
+            f_t = ER.objective(kind, 4, ER.tensor(kind, 4, prev[t]), dev['params_hist'][step, t], WW)
+            assert abs(f_t - dev['fun'][step, t]) < F_TOL, (step, t)
+            o = abs(O.overlap_eta(ER.tensor(kind, 4, dev['params_hist'][step, t]), ER.tensor(kind, 4, host['params_hist'][step, t]), np.eye(4))[0])
+            assert abs(o - 1.0) < 1e-6, (step, t, o)
+        prev = dev['params_hist'][step]
+    assert dev['fun'][-1].mean() < -0.999 and dev['nit'].min() < dev['nit'].max()
+    # a rejected full step sends the workgroup through a ladder pass of its own (12 waves: the ladder does not ride along): a short
+    # ladder and a crude first rung provoke rejections - the minima do not move
+    odd = eng.evolve_bfgs_device(kind, X0, WW, n_steps=n_steps, maxiter=60, tol=1e-13, alphas=(2.5, 1.0, 0.3, 0.05, 0.005))
+    assert np.abs(odd['fun'][-1] - dev['fun'][-1]).max() < 1e-6
+    with pytest.raises(Exception, match='12 waves'):
+        eng.evolve_bfgs_device(kind, rng.standard_normal((2, 6)), WW)          # depth 3 at D = 4: 13 candidates
+
+
 def test_native_bfgs_driver_argument_checks_and_single_rung(engine_factory):
     """Refusals of qmps_evolve_bfgs (batch larger than the context, a warm continuation without resident fixed points)
     and the ladder-free variant (one step length: a rejected full step ends the trajectory's minimisation)."""

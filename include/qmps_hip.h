@@ -432,10 +432,10 @@ int qmps_evolve_bfgs(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* p
  * squarings spent on the evaluations.
  * n_params <= 16, n_alphas <= 16, 2 n_params + n_alphas <= 64.  Any T (no max_batch limit: nothing is staged per candidate).
  * D = 4 (qmps_amd/csrc/qmps_evolve_d4.hip): a WORKGROUP per trajectory, its waves are the candidates - each builds its tensor (four lanes
- * simulate the four columns of the ansatz unitary) and squares its 16 x 16 map on the matrix cores (the code of the D = 4 overlap
- * kernel), the 2 n_params + 1 solves of a pass side by side; every neighbour is eigen-solved (no two-sided first-order gradient as in
- * qmps_evolve_bfgs: exact central differences, results agree with the host driver's to the accuracy of its gradient, ~1e-8).
- * 2 n_params + 1 <= 12, n_alphas <= 13, ShallowCNOT / QAOA / CNOT3; the backtracking points are evaluated only when the full step is rejected. */
+ * simulate the four columns of the ansatz unitary); the point itself is eigen-solved by squaring its 16 x 16 map on the matrix cores (the code of the D = 4 overlap
+ * kernel); the 2 n_params neighbours of a point are evaluated to second order in h from its right and left fixed points (the largest
+ * column and row of the squared map), eta' = <y, T'(r)>/<y, r>, as in qmps_overlap_gradient.
+ * n_alphas <= 9, ShallowCNOT / QAOA / CNOT3; the backtracking points are eigen-solved (eight waves side by side) only when the full step is rejected. */
 int qmps_evolve_bfgs_device(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
                             double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
                             double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out);

@@ -661,8 +661,8 @@ int qmps_evolve_bfgs_device(qmps_ctx* c, int64_t T, int kind, int n_params, doub
   if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
   const int P = n_params, NA = n_alphas;
   if (P < 1 || P > 16 || NA < 1 || NA > 16 || 2 * P + NA > 64) return fail(QMPS_ERR_ARG, "n_params <= 16, n_alphas <= 16 and 2 n_params + n_alphas <= 64 (one wave per trajectory)");
-  if (c->D == 4 && (2 * P + 1 > 12 || NA - 1 > 12 || (kind != QMPS_ANSATZ_SHALLOW_CNOT && kind != QMPS_ANSATZ_SHALLOW_QAOA && kind != QMPS_ANSATZ_SHALLOW_CNOT3)))
-    return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs_device at D = 4: a wave per candidate, 12 waves per trajectory - 2 n_params + 1 <= 12, n_alphas <= 13; ShallowCNOT / QAOA / CNOT3");
+  if (c->D == 4 && (NA - 1 > 8 || (kind != QMPS_ANSATZ_SHALLOW_CNOT && kind != QMPS_ANSATZ_SHALLOW_QAOA && kind != QMPS_ANSATZ_SHALLOW_CNOT3)))
+    return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs_device at D = 4: eight waves per trajectory - n_alphas <= 9; ShallowCNOT / QAOA / CNOT3");
   if (T < 1 || n_steps < 1 || maxiter < 0 || !(gtol > 0.0) || !(h > 0.0) || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad T / n_steps / maxiter / gtol / h / tol");
   if (max_rounds < 1 || max_rounds > 60) return fail(QMPS_ERR_ARG, "max_rounds in [1, 60] (squarings of the 4 x 4 map)");
   if (int rc = check_ansatz(c, kind, P)) return rc;

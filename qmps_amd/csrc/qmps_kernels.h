@@ -283,7 +283,7 @@ struct EvolveD2Args {
   double alphas[kEvolveMaxAlphas];
 };
 hipError_t launch_evolve_bfgs_d2(int kind, const EvolveD2Args& a, hipStream_t st);
-// D = 4: a workgroup per trajectory, a wave per candidate (qmps_evolve_d4.hip); 2 n_params + 1 <= 12, n_alphas - 1 <= 12, kinds 0, 1, 3
+// D = 4: a workgroup of eight waves per trajectory (qmps_evolve_d4.hip); n_alphas - 1 <= 8, kinds 0, 1, 3
 hipError_t launch_evolve_bfgs_d4(int kind, const EvolveD2Args& a, hipStream_t st);
 // D = 8, 16: thick-restart Arnoldi over the candidates the power kernels gave up (status 1, iters < max_rounds); a.r_out holds their
 // iterates and receives the fixed points; `counter` zeroed by the caller (qmps_overlap_krylov.hip)

@@ -135,7 +135,7 @@ __device__ __forceinline__ void overlap_square_d4_item(const double2* Ap, const 
       double ar[4], ai[4];
       to_a_layout(mr, mi, ar, ai);
       v4f64 qr = {0, 0, 0, 0}, qi = {0, 0, 0, 0};
-      cmma16(ar, ai, mr, mi, qr, qi);                     // Q = M M
+      cmma16_3m(ar, ai, mr, mi, qr, qi);      // (three real products per k-slab: 12 instead of 16 v_mfma_f64_16x16x4 per squaring)                     // Q = M M
       double d0 = 0.0, d1 = 0.0;
 #pragma unroll
       for (int q = 0; q < 4; ++q)

@@ -381,8 +381,8 @@ def test_device_resident_bfgs_d2_takes_the_decisions_of_the_host_driver(kind, P,
 
 
 def test_device_resident_bfgs_d4_against_the_host_driver_and_the_oracle(engine_factory):
-    """qmps_evolve_bfgs_device at D = 4 (a workgroup per trajectory, a wave per candidate, every candidate eigen-solved by squaring on
-    the matrix cores) against qmps_evolve_bfgs (host loop, two-sided first-order gradient): the same minima - objectives to 1e-8, the
+    """qmps_evolve_bfgs_device at D = 4 (a workgroup per trajectory: the point eigen-solved by squaring on the matrix cores, its
+    neighbours by the two-sided quotient) against qmps_evolve_bfgs (host loop, the same gradient formula): the same minima - objectives to 1e-8, the
     same physical states - and the recorded objectives are the ORACLE's (dense eigen-solve) at the device's parameters.  Also the
     per-trajectory iteration counts: nobody waits for the slowest trajectory."""
     rng = np.random.default_rng(1404)
@@ -404,12 +404,18 @@ def test_device_resident_bfgs_d4_against_the_host_driver_and_the_oracle(engine_f
             assert abs(o - 1.0) < 1e-6, (step, t, o)
         prev = dev['params_hist'][step]
     assert dev['fun'][-1].mean() < -0.999 and dev['nit'].min() < dev['nit'].max()
-    # a rejected full step sends the workgroup through a ladder pass of its own (12 waves: the ladder does not ride along): a short
+    # a rejected full step sends the workgroup through a ladder pass of its own (the backtracking points are eigen-solved): a short
     # ladder and a crude first rung provoke rejections - the minima do not move
     odd = eng.evolve_bfgs_device(kind, X0, WW, n_steps=n_steps, maxiter=60, tol=1e-13, alphas=(2.5, 1.0, 0.3, 0.05, 0.005))
     assert np.abs(odd['fun'][-1] - dev['fun'][-1]).max() < 1e-6
-    with pytest.raises(Exception, match='12 waves'):
-        eng.evolve_bfgs_device(kind, rng.standard_normal((2, 6)), WW)          # depth 3 at D = 4: 13 candidates
+    # depth 3 (six angles, twelve neighbours on eight waves: some waves evaluate two)
+    X6 = rng.standard_normal((3, 6))
+    eng6 = engine_factory(4, 3 * 13)
+    h6 = eng6.evolve_bfgs(kind, X6, WW, n_steps=2, maxiter=40, tol=1e-13)
+    d6 = eng6.evolve_bfgs_device(kind, X6, WW, n_steps=2, maxiter=40, tol=1e-13)
+    assert np.abs(d6['fun'] - h6['fun']).max() < 1e-7 and d6['failed_evaluations'] == 0
+    with pytest.raises(Exception, match='eight waves'):
+        eng.evolve_bfgs_device(kind, X0, WW, alphas=tuple(0.5 ** k for k in range(11)))
 
 
 def test_native_bfgs_driver_argument_checks_and_single_rung(engine_factory):

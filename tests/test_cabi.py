@@ -125,3 +125,57 @@ def test_nothing_throws_across_the_abi():
     for f in ('qmps_capi.hip', 'qmps_capi_overlap.hip'):
         src = open(os.path.join(csrc, f)).read()
         assert 'c->defer_sync = true' not in src and 'saved_period' not in src
+
+
+def test_boundary_end_to_end_through_the_cpu_build_of_the_abi():
+    """"a CPU build of the same ABI must exist so the boundary is testable without a GPU".  tests/csrc/libqmps_cpuabi.so
+    exports qmps_create / qmps_destroy / qmps_energy_batch / qmps_env_batch / qmps_last_error with the header's prototypes (bound
+    here through the PRODUCT's ctypes signature table) at D = 4, computing through qmps_direct_core.h on the host: argument
+    marshalling, caller-owned buffers, return codes and error strings are exercised end to end and the numbers are the oracle's.
+    Test infrastructure: qmps_amd never loads it (checked), the product still has no CPU fallback."""
+    import subprocess
+    import numpy as np
+    from oracle import qmps_oracle as O
+    from qmps_amd import _lib
+    here = os.path.join(ROOT, 'tests', 'csrc')
+    subprocess.check_call(['make', '-C', here, '--no-print-directory'], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(os.path.join(here, 'libqmps_cpuabi.so'))
+    names = ('qmps_abi_version', 'qmps_last_error', 'qmps_create', 'qmps_destroy', 'qmps_energy_batch', 'qmps_env_batch')
+    for n in names:                                     # the product's own signature table describes these entry points
+        res, args = _lib.SIGNATURES[n]
+        getattr(lib, n).restype, getattr(lib, n).argtypes = res, args
+    assert lib.qmps_abi_version() == _lib.load().qmps_abi_version()
+    ctx = ctypes.c_void_p()
+    assert lib.qmps_create(0, 8, 16, ctypes.byref(ctx)) == _lib.QMPS_ERR_ARG and b'D = 4 only' in lib.qmps_last_error()
+    assert lib.qmps_create(1, 4, 16, ctypes.byref(ctx)) == _lib.QMPS_ERR_NO_DEVICE
+    assert lib.qmps_create(0, 4, 64, ctypes.byref(ctx)) == 0 and ctx.value
+    rng = np.random.default_rng(44)
+    B = 50
+    A = np.ascontiguousarray(O.unitary_to_tensor(O.haar_unitaries(rng, 8, B)), dtype=np.complex128)      # (caller-owned, C-ordered buffers)
+    h = np.ascontiguousarray(np.stack([O.hamiltonian_matrix({'ZZ': -1, 'X': 1}), O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})]), dtype=np.complex128)
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
+    f64 = lambda a: a.ctypes.data_as(dp)
+    E = np.empty((B, 2))
+    it, st = np.empty(B, dtype=np.int32), np.empty(B, dtype=np.int32)
+    rc = lib.qmps_energy_batch(ctx, B, f64(A.view(np.float64)), _lib.INPUT_TENSOR, f64(h.view(np.float64)), 2, None, 10000, 1e-13, f64(E),
+                               it.ctypes.data_as(ip), st.ctypes.data_as(ip))
+    assert rc == 0 and np.all(st == 0)
+    ref = np.array([[O.energy_closed_form(a, hh) for hh in h] for a in A])
+    assert np.abs(E - ref).max() < 1e-10
+    r = np.empty((B, 4, 4), dtype=np.complex128)
+    assert lib.qmps_env_batch(ctx, B, f64(A.view(np.float64)), _lib.INPUT_TENSOR, None, 10000, 1e-13, f64(r.view(np.float64)), None, None) == 0
+    for b in range(0, B, 7):
+        rr = r[b] / np.trace(r[b])
+        assert np.abs(O.apply_transfer(A[b], rr) - rr).max() < 1e-11 and np.abs(rr - rr.conj().T).max() < 1e-13
+    # error behaviour of the boundary: codes + messages, nothing written, nothing thrown
+    assert lib.qmps_energy_batch(ctx, 65, f64(A.view(np.float64)), 0, f64(h.view(np.float64)), 2, None, 100, 1e-13, f64(E), None, None) == _lib.QMPS_ERR_ARG
+    assert b'max_batch' in lib.qmps_last_error()
+    assert lib.qmps_energy_batch(ctx, B, None, 0, f64(h.view(np.float64)), 2, None, 100, 1e-13, f64(E), None, None) == _lib.QMPS_ERR_ARG
+    assert lib.qmps_energy_batch(ctx, B, f64(A.view(np.float64)), _lib.INPUT_UNITARY, f64(h.view(np.float64)), 2, None, 100, 1e-13, f64(E), None, None) == _lib.QMPS_ERR_ARG
+    assert lib.qmps_energy_batch(None, B, f64(A.view(np.float64)), 0, f64(h.view(np.float64)), 2, None, 100, 1e-13, f64(E), None, None) == _lib.QMPS_ERR_ARG
+    assert lib.qmps_destroy(ctx) == 0
+    # never part of the product
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'qmps_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', 'Makefile')):
+                assert 'cpuabi' not in open(os.path.join(dirpath, f)).read(), f

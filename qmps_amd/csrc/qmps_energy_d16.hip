@@ -564,7 +564,7 @@ hipError_t launch_energy_mfma(int D, const LaneArgs& a, bool solve, hipStream_t 
   static const int64_t split_below = tuning_knob("QMPS_D16_SPLIT_BELOW") ? atoll(tuning_knob("QMPS_D16_SPLIT_BELOW")) : 512;   // A/B knob
   if (solve && a.only_pending) {
     // finishing pass behind the Krylov fall-back: a handful of evaluations at most; every workgroup looks at the pending count first
-    hipLaunchKernelGGL(energy_mfma_d16x2_kernel<true>, dim3((unsigned)(a.B < 512 ? a.B : 512)), dim3(128), 0, st, a);
+    hipLaunchKernelGGL(energy_mfma_d16x2_kernel<true>, dim3((unsigned)(a.B < 64 ? a.B : 64)), dim3(128), 0, st, a);
     return hipGetLastError();
   }
   if (solve && a.B <= split_below) {

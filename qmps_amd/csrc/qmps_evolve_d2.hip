@@ -4,12 +4,13 @@
 // gradients, ShallowFullStateTensor(2, .) with 15 angles, :186-187), scripts/loschmidt.py:367-375 (ShallowCNOTStateTensor(2, .)).
 // The lock-step drivers (tools.batched_bfgs, qmps_evolve_bfgs) pay a host round trip per BFGS iteration and make every trajectory
 // wait for the slowest one; at D = 2 the GPU then idles (profiles/r03h_evolve_d2_t256.json: 0.03 ms of kernels inside 5 ms).  Here
-// ONE WAVE owns a trajectory for the whole run - every time step, every BFGS iteration, without returning to the host:
-//   lanes = candidates of an evaluation pass: lane 0 the iterate z, lanes 1 .. P  z + h e_k, lanes P + 1 .. 2P  z - h e_k (the
-//   central-difference columns), lanes 2P + 1 .. 2P + G the backtracking points x + alpha_r d - each lane simulates the ansatz
-//   circuit of ITS parameter vector (two columns of the 4 x 4 unitary, qmps_circuit.h), and solves ITS mixed transfer map
-//   (4 x 4 complex, squared until converged: qmps_overlap_d2.h - the code of overlap_lane_kernel);
-//   x, g, d, s, the inverse Hessian H (P x P) and the reference tensor live in the wave's LDS; lane a owns row a of H.
+// ONE WORKGROUP (one to three waves) owns a trajectory for the whole run - every time step, every BFGS iteration, without returning to the host:
+//   QUADS of lanes = candidates of an evaluation pass: candidate 0 the iterate z, 1 .. P  z + h e_k, P + 1 .. 2P  z - h e_k (the
+//   central-difference columns), 2P + 1 .. 2P + G the backtracking points x + alpha_r d - two lanes of the quad simulate the two
+//   columns of the candidate's 4 x 4 ansatz unitary (qmps_circuit.h), then the four lanes eigen-solve its mixed transfer map, a row
+//   of the 4 x 4 complex matrix each (squared until converged: the algorithm of overlap_lane_kernel / qmps_overlap_d2.h);
+//   x, g, d, s, the inverse Hessian H (P x P; thread a owns row a) and the reference tensor live in the workgroup's LDS
+//   (one to three waves per trajectory).  First version: ONE lane per candidate - 25 of the 31 us of a pass were that lane's solve.
 // The iteration is tools.batched_bfgs / qmps_evolve_bfgs for ONE trajectory, decision for decision (speculative full step with
 // its gradient, Armijo ladder, first-accepted / best rung, rank-two update with the curvature guard, steepest-descent restart),
 // the host driver's floating-point expressions of the optimiser algebra reproduced with explicitly rounded operations (no FMA
@@ -37,115 +38,250 @@ using evolve_detail::mul_rn;
 }  // namespace
 
 
+// ---- the eigen-solve of one candidate by a QUAD of lanes (lane q owns row q = (i, i') of the 4 x 4 complex matrix
+//   E[(i,i'),(j,j')] = sum_s C_s[i][j] conj(Bm_s[i'][j']),  Bm = merge(B, B)
+// of the mixed transfer map; qmps_overlap_d2.h is the same algorithm in ONE lane - 25 of the 31 us of an evaluation pass were that lane's
+// dependent chain of ~6 squarings, here a squaring is 16 complex multiply-adds per lane and the rows travel by quad broadcasts).
+//   amp_r / amp_i: lanes 0, 1 of the quad hold the four amplitudes of column 0 / 1 of the candidate's unitary (B[s][i][k] = amplitude 2 i + s of column k)
+//   sC: C_s[i][j] of the trajectory's reference tensor, [s][i][j] in LDS.  Results uniform over the quad.
+__device__ __forceinline__ void overlap_quad_solve(const double2* sC, const double (&amp_r)[4], const double (&amp_i)[4], int q, int max_rounds, double tol,
+                                                   double& eta_r, double& eta_i, int& rounds, int& status) {
+  const int i = q >> 1, ip = q & 1;
+  // the candidate's tensor by quad broadcasts: B[s][i][k] = amplitude 2 i + s of column k (lane k).  (No array of broadcast values:
+  // a select between two elements of a private array becomes a dynamically indexed load - scratch.)
+  auto Bre = [&](int s, int i_, int k) { return k == 0 ? quad_bcast<0>(amp_r[2 * i_ + s]) : quad_bcast<1>(amp_r[2 * i_ + s]); };
+  auto Bim = [&](int s, int i_, int k) { return k == 0 ? quad_bcast<0>(amp_i[2 * i_ + s]) : quad_bcast<1>(amp_i[2 * i_ + s]); };
+  // row a = (i, i') of E
+  double er[4], ei[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) er[c] = ei[c] = 0.0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int s1 = s >> 1, s2 = s & 1;
+    // Bm_s[i'][j'] = sum_k B[s1][i'][k] B[s2][k][j']
+    double mr_[2], mi_[2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      double xr = 0.0, xi = 0.0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const double u1r = Bre(s1, 1, k), u0r = Bre(s1, 0, k), u1i = Bim(s1, 1, k), u0i = Bim(s1, 0, k);
+        const double ur = ip ? u1r : u0r, ui = ip ? u1i : u0i;
+        const double kr = Bre(s2, k, jp), ki = Bim(s2, k, jp);
+        xr = dfma(ur, kr, dfma(-ui, ki, xr));
+        xi = dfma(ur, ki, dfma(ui, kr, xi));
+      }
+      mr_[jp] = xr;
+      mi_[jp] = xi;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const double2 cv = sC[(s * 2 + i) * 2 + j];
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {       // += C conj(Bm)
+        er[2 * j + jp] = dfma(cv.x, mr_[jp], dfma(cv.y, mi_[jp], er[2 * j + jp]));
+        ei[2 * j + jp] = dfma(cv.y, mr_[jp], dfma(-cv.x, mi_[jp], ei[2 * j + jp]));
+      }
+    }
+  }
+  double mr[4], mi[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { mr[c] = er[c]; mi[c] = ei[c]; }
+  const double tol2 = tol * tol;
+  eta_r = eta_i = 0.0;
+  status = QMPS_ST_NOT_CONVERGED;
+  rounds = 0;
+  bool done = false;
+  for (int m = 0; m <= max_rounds; ++m) {
+    if (!done) {
+      // dominant right vector = largest column of the current power; v[a] in lane a
+      int bc = 0;
+      double best = -1.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double n2 = quad_sum(dfma(mr[c], mr[c], mi[c] * mi[c]));
+        if (n2 > best) { best = n2; bc = c; }
+      }
+      double vr = 0.0, vi = 0.0;          // (a sum of selects against zero: a select between array elements becomes a dynamic index - scratch)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        vr += bc == c ? mr[c] : 0.0;
+        vi += bc == c ? mi[c] : 0.0;
+      }
+      // w = E v, eta = <v, w>/<v, v>, residual
+      double wr = 0.0, wi = 0.0;
+      {
+        const double v0r = quad_bcast<0>(vr), v0i = quad_bcast<0>(vi), v1r = quad_bcast<1>(vr), v1i = quad_bcast<1>(vi);
+        const double v2r = quad_bcast<2>(vr), v2i = quad_bcast<2>(vi), v3r = quad_bcast<3>(vr), v3i = quad_bcast<3>(vi);
+        wr = dfma(er[0], v0r, dfma(-ei[0], v0i, wr)); wi = dfma(er[0], v0i, dfma(ei[0], v0r, wi));
+        wr = dfma(er[1], v1r, dfma(-ei[1], v1i, wr)); wi = dfma(er[1], v1i, dfma(ei[1], v1r, wi));
+        wr = dfma(er[2], v2r, dfma(-ei[2], v2i, wr)); wi = dfma(er[2], v2i, dfma(ei[2], v2r, wi));
+        wr = dfma(er[3], v3r, dfma(-ei[3], v3i, wr)); wi = dfma(er[3], v3i, dfma(ei[3], v3r, wi));
+      }
+      const double num_r = quad_sum(dfma(vr, wr, vi * wi)), num_i = quad_sum(dfma(vr, wi, -vi * wr)), vv = quad_sum(dfma(vr, vr, vi * vi));
+      eta_r = num_r / vv;
+      eta_i = num_i / vv;
+      const double dr = wr - (eta_r * vr - eta_i * vi), di = wi - (eta_r * vi + eta_i * vr);
+      const double res = quad_sum(dfma(dr, dr, di * di));
+      rounds = m;
+      if (res < tol2 * vv) { status = QMPS_ST_OK; done = true; }
+      else if (m == max_rounds) done = true;
+    }
+    if (__builtin_amdgcn_ballot_w64(!done) == 0) break;        // (the quads of a wave leave together)
+    if (!done) {
+      // square and Frobenius-normalise: row a of M M = sum_k M[a][k] row_k(M)
+      double nr[4] = {0, 0, 0, 0}, ni[4] = {0, 0, 0, 0};
+#define QMPS_ROW(K)                                                                                            \
+      {                                                                                                        \
+        const double ar = mr[K], ai = mi[K];                                                                   \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                        \
+          const double kr = quad_bcast<K>(mr[c]), ki = quad_bcast<K>(mi[c]);                                   \
+          nr[c] = dfma(ar, kr, dfma(-ai, ki, nr[c]));                                                          \
+          ni[c] = dfma(ar, ki, dfma(ai, kr, ni[c]));                                                           \
+        }                                                                                                      \
+      }
+      QMPS_ROW(0) QMPS_ROW(1) QMPS_ROW(2) QMPS_ROW(3)
+#undef QMPS_ROW
+      double f2 = 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) f2 = dfma(nr[c], nr[c], dfma(ni[c], ni[c], f2));
+      f2 = quad_sum(f2);
+      const double inv = f2 > 0.0 ? 1.0 / __builtin_sqrt(f2) : 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { mr[c] = nr[c] * inv; mi[c] = ni[c] * inv; }
+    }
+  }
+}
+
+// One trajectory per workgroup; FOUR LANES per candidate of an evaluation pass (16 candidates per wave; 2P + 1 + 7 candidates:
+// three waves for ShallowFull's 15 angles, two for eight angles)
 template <int KIND>
-__global__ __launch_bounds__(64) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
+__global__ __launch_bounds__(256) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
   const int64_t t = blockIdx.x;
-  const int lane = threadIdx.x, P = p.P;
+  const int tid = threadIdx.x, P = p.P, nthreads = (int)blockDim.x;
   __shared__ double sX[PMAX], sG[PMAX], sD[PMAX], sS[PMAX], sGn[PMAX], sHy[PMAX], sH[PMAX][PMAX + 1], sF[64];
   __shared__ int sOK[64];
-  __shared__ double2 sA[8], sCS[PMAX], sLCS[kEvolveMaxAlphas * PMAX];
-  __shared__ double sZ[PMAX];
+  __shared__ double2 sA[8], sC[16], sCS[PMAX], sLCS[kEvolveMaxAlphas * PMAX];
+  __shared__ double sZ[PMAX], sCnt[4];
   const double2* W = (const double2*)p.WW;
-  // ---- one evaluation pass.  Lane roles: < G1 = 2P + 1: central-difference columns of z = x + coef d; [G1, G1 + n_ladder): x + alpha_{r+1} d
-  // returns nothing: sF / sOK hold -sqrt|eta| and status == OK of every lane
-  double nfev = 0.0, nrounds = 0.0;       // (nrounds: this LANE's squarings, summed over the wave at the end)
-  int nfail = 0;
+  if (tid < 4) sCnt[tid] = 0.0;
+  // ---- one evaluation pass.  Candidate c = tid / 4: c < G1 = 2P + 1 the central-difference columns of z = x + coef d; [G1, G1 + n_ladder): x + alpha_{r+1} d
   auto evaluate = [&](double coef, int n_ladder) {
-    const int G1 = 2 * P + 1;
-    const bool grad_lane = lane < G1, ladder_lane = !grad_lane && lane < G1 + n_ladder;
-    // ---- cos / sin of every (scaled) angle ONCE per pass, shared through LDS: the P angles of the base point z = x + coef d (the
-    // central-difference columns differ from it in one angle each) by lanes 0 .. P - 1, the n_ladder P angles of the backtracking
-    // points spread over the wave - a lane then computes ONE sincos of its own (its shifted angle) instead of 2 P
-    if (lane < P) {
-      const double z = coef != 0.0 ? add_rn(sX[lane], mul_rn(coef, sD[lane])) : sX[lane];
-      sZ[lane] = z;
+    const int G1 = 2 * P + 1, cand = tid >> 2, q = tid & 3;
+    const bool grad = cand < G1, ladder = !grad && cand < G1 + n_ladder;
+    // cos / sin of every (scaled) angle ONCE per pass, shared through LDS (a double-precision sincos costs more than a two-qubit layer):
+    // the P angles of the base point by threads 0 .. P - 1, the n_ladder P angles of the backtracking points spread over the workgroup
+    if (tid < P) {
+      const double z = coef != 0.0 ? add_rn(sX[tid], mul_rn(coef, sD[tid])) : sX[tid];
+      sZ[tid] = z;
       double sn, cs_;
-      sincos(ansatz_param_scale<KIND>(lane) * z, &sn, &cs_);
-      sCS[lane] = make_double2(cs_, sn);
+      sincos(ansatz_param_scale<KIND>(tid) * z, &sn, &cs_);
+      sCS[tid] = make_double2(cs_, sn);
     }
-    for (int idx = lane; idx < n_ladder * P; idx += 64) {
+    for (int idx = tid; idx < n_ladder * P; idx += nthreads) {
       const int r = idx / P, l = idx - r * P;
       double sn, cs_;
       sincos(ansatz_param_scale<KIND>(l) * add_rn(sX[l], mul_rn(p.alphas[r + 1], sD[l])), &sn, &cs_);
       sLCS[r * PMAX + l] = make_double2(cs_, sn);
     }
-    __builtin_amdgcn_wave_barrier();
-    if (grad_lane || ladder_lane) {
-      const int isel = (grad_lane && lane > 0) ? (lane - 1) % P : -1;
-      double2 own = make_double2(1.0, 0.0);
-      if (isel >= 0) {
-        double sn, cs_;
-        sincos(ansatz_param_scale<KIND>(isel) * add_rn(sZ[isel], lane <= P ? p.h : -p.h), &sn, &cs_);
-        own = make_double2(cs_, sn);
-      }
-      const double2* lcs = sLCS + (ladder_lane ? lane - G1 : 0) * PMAX;
-      double bre[8], bim[8];
-      if (p.probe & 2) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { bre[k] = sA[k].x + 1e-3 * own.x * (k == 3); bim[k] = sA[k].y; }
-      } else
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
+    __syncthreads();
+    if (grad || ladder) {
+      const int isel = (grad && cand > 0) ? (cand - 1) % P : -1;
+      double amp_r[4] = {0, 0, 0, 0}, amp_i[4] = {0, 0, 0, 0};
+      if (q < 2) {
+        // lanes 0, 1 of the quad simulate columns 0, 1 of the candidate's unitary
+        double2 own = make_double2(1.0, 0.0);
+        if (isel >= 0) {
+          double sn, cs_;
+          sincos(ansatz_param_scale<KIND>(isel) * add_rn(sZ[isel], cand <= P ? p.h : -p.h), &sn, &cs_);
+          own = make_double2(cs_, sn);
+        }
+        const double2* lcs = sLCS + (ladder ? cand - G1 : 0) * PMAX;
         Reg<2> r;
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-          r.re[x] = (x == j) ? 1.0 : 0.0;
+          r.re[x] = (x == q) ? 1.0 : 0.0;
           r.im[x] = 0.0;
         }
-        ansatz_circuit_cs<2, KIND>(r, [&](int l) { return ladder_lane ? lcs[l] : (l == isel ? own : sCS[l]); }, P);
+        ansatz_circuit_cs<2, KIND>(r, [&](int l) {
+          double2 v = ladder ? lcs[l] : sCS[l];        // (value selects: a select between `own` and an LDS element would put `own` in scratch)
+          if (l == isel) { v.x = own.x; v.y = own.y; }
+          return v;
+        }, P);
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {          // B[s][i][j] = amplitude[2 i + s] of column j
-          bre[((x & 1) * 2 + (x >> 1)) * 2 + j] = r.re[x];
-          bim[((x & 1) * 2 + (x >> 1)) * 2 + j] = r.im[x];
-        }
+        for (int x = 0; x < 4; ++x) { amp_r[x] = r.re[x]; amp_i[x] = r.im[x]; }
       }
-      OverlapLaneResult o;
-      if (p.probe & 1) { o.eta_r = bre[0] + bre[5]; o.eta_i = bim[3]; o.rounds = 0; o.status = QMPS_ST_OK; }
-      else overlap_lane_solve([&](int k) { return sA[k]; }, [&](int k) { return make_double2(bre[k], bim[k]); }, W, p.max_rounds, p.tol, o);
-      sF[lane] = -__builtin_sqrt(__builtin_sqrt(o.eta_r * o.eta_r + o.eta_i * o.eta_i));
-      sOK[lane] = o.status == QMPS_ST_OK ? 1 : 0;
-      nrounds += (double)o.rounds;
+      double er, ei;
+      int rounds, status;
+      overlap_quad_solve(sC, amp_r, amp_i, q, p.max_rounds, p.tol, er, ei, rounds, status);
+      if (q == 0) {
+        sF[cand] = -__builtin_sqrt(__builtin_sqrt(er * er + ei * ei));
+        sOK[cand] = status == QMPS_ST_OK ? 1 : 0;
+        atomicAdd(&sCnt[1], (double)rounds);
+        if (status != QMPS_ST_OK) atomicAdd(&sCnt[2], 1.0);
+      }
     }
-    __builtin_amdgcn_wave_barrier();
-    nfev += (double)(G1 + n_ladder);
-    for (int l = 0; l < G1 + n_ladder; ++l) nfail += sOK[l] ? 0 : 1;
+    __syncthreads();
+    if (tid == 0) sCnt[0] += (double)(G1 + n_ladder);
   };
   BfgsLds L;
   L.X = sX; L.G = sG; L.D = sD; L.S = sS; L.Gn = sGn; L.Hy = sHy; L.H = sH; L.F = sF; L.OK = sOK;
   auto build_reference = [&]() {
-    // the step's reference tensor A = tensor(x): lanes 0, 1 simulate the two columns
-    if (lane < P) {
+    // the step's reference tensor A = tensor(x) (threads 0, 1: its two columns), then C_s = sum_t WW[s][t] A_t1 A_t2 (thread = (s, i, j))
+    if (tid < P) {
       double sn, cs_;
-      sincos(ansatz_param_scale<KIND>(lane) * sX[lane], &sn, &cs_);
-      sCS[lane] = make_double2(cs_, sn);
+      sincos(ansatz_param_scale<KIND>(tid) * sX[tid], &sn, &cs_);
+      sCS[tid] = make_double2(cs_, sn);
     }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 2) {
+    __syncthreads();
+    if (tid < 2) {
       Reg<2> r;
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        r.re[x] = (x == lane) ? 1.0 : 0.0;
+        r.re[x] = (x == tid) ? 1.0 : 0.0;
         r.im[x] = 0.0;
       }
       ansatz_circuit_cs<2, KIND>(r, [&](int l) { return sCS[l]; }, P);
 #pragma unroll
-      for (int x = 0; x < 4; ++x) sA[((x & 1) * 2 + (x >> 1)) * 2 + lane] = make_double2(r.re[x], r.im[x]);
+      for (int x = 0; x < 4; ++x) sA[((x & 1) * 2 + (x >> 1)) * 2 + tid] = make_double2(r.re[x], r.im[x]);
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if (tid < 16) {
+      const int s = tid >> 2, i = (tid >> 1) & 1, j = tid & 1;
+      double cr = 0.0, ci = 0.0;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int t1 = tt >> 1, t2 = tt & 1;
+        double ar = 0.0, ai = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const double2 x = sA[(t1 * 2 + i) * 2 + k], y = sA[(t2 * 2 + k) * 2 + j];
+          ar += x.x * y.x - x.y * y.y;
+          ai += x.x * y.y + x.y * y.x;
+        }
+        const double2 w = W[s * 4 + tt];
+        cr += w.x * ar - w.y * ai;
+        ci += w.x * ai + w.y * ar;
+      }
+      sC[tid] = make_double2(cr, ci);
+    }
+    __syncthreads();
   };
-  bfgs_time_evolution(p, t, lane < P ? lane : -1, lane == 0, L, evaluate, build_reference, [] { __builtin_amdgcn_wave_barrier(); }, true);
-  nrounds = wave_sum(nrounds);
-  if (lane == 0) {
-    if (p.nfev != nullptr) p.nfev[t] = nfev;
-    if (p.rounds != nullptr) p.rounds[t] = nrounds;
-    if (p.fail != nullptr) p.fail[t] = nfail;
+  __syncthreads();
+  bfgs_time_evolution(p, t, tid < P ? tid : -1, tid == 0, L, evaluate, build_reference, [] { __syncthreads(); }, true);
+  __syncthreads();
+  if (tid == 0) {
+    if (p.nfev != nullptr) p.nfev[t] = sCnt[0];
+    if (p.rounds != nullptr) p.rounds[t] = sCnt[1];
+    if (p.fail != nullptr) p.fail[t] = (int32_t)sCnt[2];
   }
 }
 
 hipError_t launch_evolve_bfgs_d2(int kind, const EvolveD2Args& a, hipStream_t st) {
   if (a.T <= 0) return hipSuccess;
-  if (a.P < 1 || a.P > PMAX || a.NA < 1 || a.NA > kEvolveMaxAlphas || 2 * a.P + 1 + (a.NA - 1) > 64) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)a.T), block(64);
+  const int cands = 2 * a.P + 1 + (a.NA - 1);
+  if (a.P < 1 || a.P > PMAX || a.NA < 1 || a.NA > kEvolveMaxAlphas || cands > 64) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)a.T), block(64 * ((cands + 15) / 16));        // four lanes per candidate
   switch (kind) {
     case 0: hipLaunchKernelGGL(evolve_bfgs_d2_kernel<0>, grid, block, 0, st, a); break;
     case 1: hipLaunchKernelGGL(evolve_bfgs_d2_kernel<1>, grid, block, 0, st, a); break;

@@ -113,6 +113,36 @@ def test_krylov_fallback_stress_haar_far(D, n, engine_factory):
     assert rounds.mean() < (200 if D == 8 else 450), rounds.mean()
 
 
+@pytest.mark.parametrize('D,P,T', [(8, 6, 120), (16, 8, 60)])
+def test_krylov_fallback_left_and_right_solves_of_the_gradient(D, P, T, engine_factory):
+    """qmps_overlap_gradient with iterates UNRELATED to their reference states (random ansatz parameters against random
+    references: |eta| ~ 0.3 - 0.6, crowded spectra): the RIGHT and the LEFT fixed point (adjoint map) of every iterate go through
+    the fall-back in one pair launch, every solve ends with status 0 within 3 000 map applications, and the two-sided objective
+    f = -sqrt|<y, T(r)>/<y, r>| - wrong as soon as EITHER vector is not the dominant one - is the oracle's; the gradient is the
+    central difference of oracle objectives."""
+    from qmps_amd import _lib as L
+    import evolve_replay as ER
+    rng = np.random.default_rng(8800 + D)
+    WW = expm(-1j * 0.2 * O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5}))
+    Xref, X = rng.standard_normal((T, P)), rng.standard_normal((T, P))
+    eng = engine_factory(D, T * (2 * P + 1))
+    eng.overlap_set_refs_params(L.ANSATZ_SHALLOW_CNOT, Xref, WW)
+    eng.overlap_stats(reset=True)
+    f, g, st = eng.overlap_gradient(L.ANSATZ_SHALLOW_CNOT, X, max_rounds=3000, tol=1e-12, two_sided_f=True)
+    stats = eng.overlap_stats()
+    assert np.all(st == 0) and stats['not_converged'] == 0 and stats['evaluations'] == 2 * T and stats['rounds_max'] <= 3000, (st, stats)
+    for t in range(0, T, max(1, T // 12)):
+        A = ER.tensor(0, D, Xref[t])
+        ref = ER.objective(0, D, A, X[t], WW)
+        assert abs(f[t] - ref) < ETA_TOL, (t, f[t], ref)
+    t, k, h = 3, 1, 1e-6
+    A = ER.tensor(0, D, Xref[t])
+    e = np.zeros(P)
+    e[k] = h
+    gref = (ER.objective(0, D, A, X[t] + e, WW) - ER.objective(0, D, A, X[t] - e, WW)) / (2 * h)
+    assert abs(g[t, k] - gref) < 1e-6, (g[t, k], gref)
+
+
 @pytest.mark.parametrize('D', [8, 16])
 def test_krylov_fallback_near_degenerate_pairs(D, engine_factory):
     """Constructed pairs with |eta_2 / eta_1| = 1 - 1e-4 .. 1 - 1e-8 (tests/overlap_cases.py: two sectors, the second tuned by

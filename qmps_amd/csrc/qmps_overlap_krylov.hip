@@ -270,13 +270,18 @@ __device__ __forceinline__ void rayleigh_ritz_wave(const double2* sG, double2* s
 // ------------------------------------------------------------------------------------------------------------------------
 // the kernel: workgroups draw chunks of candidates from `counter`, and finish those the power kernel gave up on
 // ------------------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline int krylov_chunk(int64_t B) { return B <= 4096 ? 1 : 8; }
+
 // counter[0]: work counter (chunks of candidates), counter[1]: exit tickets, counter[2]: candidates the power kernel gave up (it
 // counts them).  All three are zero between launches: a launch with nothing to do leaves at once, otherwise the LAST workgroup
 // to leave clears them - no memset on the stream, nothing for a graph capture to record.
 template <int D, bool ADJ>
 __device__ __forceinline__ void overlap_krylov_body(const OverlapArgs& p, int* counter, int n_groups, char* smem) {
   using L = KryLds<D>;
-  constexpr int N = L::N, EPL = N / 16, CHUNK = 8;
+  constexpr int N = L::N, EPL = N / 16;
+  // candidates per draw: ONE up to 4 096 candidates (a batch in which every candidate needs the fall-back - Haar-far candidates - then
+  // spreads over all workgroups instead of eight candidates queueing in one), eight beyond (fewer atomics on the one counter)
+  const int CHUNK = krylov_chunk(p.B);
   if (__hip_atomic_load(counter + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
   double2* sV = (double2*)(smem + L::oV);
   double2* sW = (double2*)(smem + L::oW);
@@ -717,7 +722,7 @@ __global__ __launch_bounds__(256) void overlap_krylov_pair_kernel(OverlapArgs pr
 namespace {
 // one workgroup holds the whole basis in LDS (D = 16: 155 KiB, one per CU); a workgroup that finds nothing to do leaves at once
 unsigned krylov_grid(int D, int64_t B) {
-  const int64_t chunks = (B + 7) / 8, cap = D == 16 ? 256 : 512;
+  const int64_t chunks = (B + krylov_chunk(B) - 1) / krylov_chunk(B), cap = D == 16 ? 256 : 512;
   return (unsigned)(chunks < cap ? chunks : cap);
 }
 }  // namespace

@@ -36,7 +36,7 @@ namespace qmps {
 namespace {
 
 constexpr int KM = 16;          // basis size (one 16 x 16 tile for the projected problem)
-constexpr int KK = 5;           // Schur vectors kept at a restart
+constexpr int KK = 5;           // Schur vectors kept at a restart (profiles/EXPERIMENTS.md: with FOUR a D = 16 candidate whose five largest eigenvalues lie within 2 % came back with the second one - its dominant direction had been discarded at a restart before it was resolved)
 constexpr int KSQ_ROUNDS = 44;  // cap on the squarings of one Schur vector (2^44 steps of the projected map)
 constexpr double KMARGIN = 100.0;
 

@@ -80,10 +80,112 @@ __global__ __launch_bounds__(64) void ansatz_tensor_kernel(const double* __restr
   for (int x = 0; x < Reg<NQ>::N; ++x) out[((x & 1) * D + (x >> 1)) * D + j] = make_double2(r.re[x], r.im[x]);
 }
 
+// ------------------------------------------------------------------------------------------
+// Kernel 3b': the same at D = 16 with the circuit DISTRIBUTED over the lanes (round 4).  One lane per column walks through ~6 500
+// dependent instructions (29 us per launch, whatever the batch: it sits in front of every gradient batch of the config-4 time
+// evolution); here a wave owns TWO columns, lane 32 jj + a holds amplitude a (five bits, qubit 0 = the most significant) of column
+// 2 w + jj: rz on every qubit is one phase per lane (powers of c - i s by popcount), rx on qubit q a butterfly with lane a xor bit
+// (ds_swizzle, groups of 32), the Hadamard another, the CNOT ladder ONE gather (ds_bpermute) - ~60 instructions per layer.
+// kinds 0 (ShallowCNOT) and 3 (ShallowCNOT3); shifts / central differences as ansatz_tensor_kernel.
+// ------------------------------------------------------------------------------------------
+namespace {
+template <int PATTERN>
+__device__ __forceinline__ double swz32(double v) {      // value of the lane (own index xor mask), within groups of 32 lanes
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), PATTERN);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), PATTERN);
+  return __hiloint2double(hi, lo);
+}
+template <int PATTERN>
+__device__ __forceinline__ void rx_lanes(double& re, double& im, double c, double s) {      // a' = c a - i s (partner's a)
+  const double pr = swz32<PATTERN>(re), pi = swz32<PATTERN>(im);
+  const double nr = dfma(c, re, s * pi), ni = dfma(c, im, -s * pr);
+  re = nr;
+  im = ni;
+}
+}  // namespace
+
+template <int KIND>
+__global__ __launch_bounds__(256) void ansatz_tensor_wave_d16_kernel(const double* __restrict__ params, int n_params, double2* __restrict__ A, int64_t B,
+                                                                     int nsh, const int* __restrict__ i_ptr, double fd_h) {
+  constexpr int per = KIND == 3 ? 3 : 2;
+  const int lane = threadIdx.x & 63, a = lane & 31;
+  const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // wave = (tensor, pair of columns)
+  const int64_t b = wv >> 3;
+  if (b >= B) return;
+  const int j = (int)(wv & 7) * 2 + (lane >> 5);
+  const int64_t row = nsh > 0 ? b / nsh : b;
+  const int shift_k = nsh > 0 ? (int)(b - row * nsh) : 0;
+  const bool fd = fd_h != 0.0;
+  const int isel = nsh > 0 ? (fd ? shift_k % n_params : *i_ptr) : -1;
+  const double fd_shift = shift_k < n_params ? fd_h : -fd_h;
+  // one sincos per angle and wave: lane l takes angle l (n_params <= 64), broadcast by readlane
+  double cn = 1.0, sn = 0.0;
+  if (lane < n_params) {
+    double v = params[row * n_params + lane];
+    if (lane == isel) v += fd ? fd_shift : roto_shift_value(nsh, shift_k);
+    sincos(0.5 * v, &sn, &cn);
+  }
+  // |0>|j>: basis state x = j (qubit 0 = 0)
+  double re = a == j ? 1.0 : 0.0, im = 0.0;
+  const int pop = __builtin_popcount((unsigned)a);
+  auto rz_all = [&](double c, double s) {
+    // prod_q rz(theta) = diag(z^(5 - 2 popcount)), z = c - i s (phi = theta / 2): z^1, z^3, z^5 and their conjugates
+    const double z2r = dfma(c, c, -s * s), z2i = -2.0 * s * c;
+    const double z3r = dfma(z2r, c, z2i * s), z3i = dfma(z2i, c, -z2r * s);
+    const double z5r = dfma(z3r, z2r, -z3i * z2i), z5i = dfma(z3r, z2i, z3i * z2r);
+    const int m = 5 - 2 * pop;
+    const double pr = (m == 1 || m == -1) ? c : ((m == 3 || m == -3) ? z3r : z5r);
+    const double pa = (m == 1 || m == -1) ? -s : ((m == 3 || m == -3) ? z3i : z5i);
+    const double pi = m > 0 ? pa : -pa;
+    const double nr = dfma(re, pr, -im * pi), ni = dfma(re, pi, im * pr);
+    re = nr;
+    im = ni;
+  };
+  for (int l0 = 0; l0 + per <= n_params; l0 += per) {
+    rz_all(__shfl(cn, l0, 64), __shfl(sn, l0, 64));
+    {
+      const double c = __shfl(cn, l0 + 1, 64), s = __shfl(sn, l0 + 1, 64);
+      rx_lanes<0x041F>(re, im, c, s);      // qubit 4 <-> lane bit 0
+      rx_lanes<0x081F>(re, im, c, s);      // qubit 3
+      rx_lanes<0x101F>(re, im, c, s);      // qubit 2
+      rx_lanes<0x201F>(re, im, c, s);      // qubit 1
+      rx_lanes<0x401F>(re, im, c, s);      // qubit 0 <-> lane bit 4
+    }
+    if (KIND == 3) rz_all(__shfl(cn, l0 + 2, 64), __shfl(sn, l0 + 2, 64));
+    {
+      // H on qubit 0 (lane bit 4): (own + partner)/sqrt 2 on the 0 side, (partner - own)/sqrt 2 on the 1 side
+      const double h = 0.70710678118654752, sg = (a & 16) ? -h : h;
+      const double pr = swz32<0x401F>(re), pi = swz32<0x401F>(im);
+      re = dfma(sg, re, h * pr);
+      im = dfma(sg, im, h * pi);
+    }
+    {
+      // CNOT(q3, q4), CNOT(q2, q3), CNOT(q1, q2), CNOT(q0, q1): amplitude (b0 .. b4) moves to (b0, b1^b0, b2^b1, b3^b2, b4^b3);
+      // destination lane d gathers from the source whose image it is (prefix xor of its bits)
+      const int d0 = (a >> 4) & 1, b1 = ((a >> 3) & 1) ^ d0, b2 = ((a >> 2) & 1) ^ b1, b3 = ((a >> 1) & 1) ^ b2, b4 = (a & 1) ^ b3;
+      const int src = (lane & 32) | (d0 << 4) | (b1 << 3) | (b2 << 2) | (b3 << 1) | b4;
+      re = __shfl(re, src, 64);
+      im = __shfl(im, src, 64);
+    }
+  }
+  // A[b][s][i][j] = amplitude[2 i + s]
+  A[b * 512 + ((a & 1) * 16 + (a >> 1)) * 16 + j] = make_double2(re, im);
+}
+
 template <int D>
 static hipError_t launch_ansatz_d(int kind, const double* params, int n_params, void* A, int64_t B, int nsh, const int* i_ptr, hipStream_t st, double fd_h = 0.0) {
   const int64_t threads = B * D;
   const dim3 grid((unsigned)((threads + 63) / 64)), block(64);
+  if constexpr (D == 16) {
+    // ShallowCNOT families: the circuit distributed over the lanes of a wave (two columns per wave)
+    // (small launches only: the distributed form is ~10 x shorter in latency but costs ~2 x the issue slots - eight waves per tensor)
+    if ((kind == 0 || kind == 3) && n_params <= 64 && B <= 512) {
+      const dim3 g2((unsigned)(B * 2)), b2(256);
+      if (kind == 0) hipLaunchKernelGGL((ansatz_tensor_wave_d16_kernel<0>), g2, b2, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h);
+      else hipLaunchKernelGGL((ansatz_tensor_wave_d16_kernel<3>), g2, b2, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h);
+      return hipGetLastError();
+    }
+  }
   switch (kind) {
     case 0: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 0>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
     case 1: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 1>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;

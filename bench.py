@@ -665,6 +665,7 @@ def main_evolve(args):
                                       f'-sqrt|eta| with eta to {args.tol:g} (residual of the power method / rank-one test of the squaring)',
                           'baseline_config': 'BASELINE.json configs[4]', 'D': D, 'trajectories_per_gpu': T, 'n_params': P, 'seed': args.seed,
                           'bfgs_iterations_per_step': float(np.mean(nit)), 'carry_hessian': bool(args.carry_hessian),
+                          'lockstep_groups': (ev.fg.eng.evolve_groups(T) if (native and not getattr(ev, 'device', False)) else 1),
                           'driver': ('qmps_evolve_bfgs_device: the optimiser on the device, one wave per trajectory, the whole timed region is ONE LAUNCH' if getattr(ev, 'device', False) else
                                      'qmps_evolve_bfgs: the whole timed region is one C call') if native else 'numpy loop (tools.batched_bfgs), one ctypes call per batch', 'objective_evals_per_step': nfev / args.steps,
                           'objective_evals_per_s': world * nfev / elapsed,
@@ -683,6 +684,7 @@ def main_evolve(args):
                             'note': (f'dominant work = the gradient evaluation ({2 * T} eigen-solves + {2 * P * T} neighbour probes per launch); ' if two_sided else
                                      f'dominant kernel = the overlap kernel of the gradient batches (T (2P+1) = {T * (2 * P + 1)} candidates per launch); ') +
                                     f'executed FLOPs = rounds x {per_round} + evaluations x {setup} (+ probes) with rounds summed by the kernels themselves (qmps_overlap_stats) over the same launches',
+                            'groups_note': 'lock-step groups run on their own streams and overlap: kernel_ms sums their launches, so `achieved` (FLOPs / summed kernel time) is a per-stream rate, a lower bound of the device rate, and kernel_share_of_wall can exceed 1',
                             'hbm': {'achieved': byts / max(kms.sum() * 1e-3, 1e-12) * 1e-9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                     'frac': byts / max(kms.sum() * 1e-3, 1e-12) * 1e-9 / HBM_PEAK_GBPS,
                                     'note': 'candidate tensor in + fixed point in and out (warm start) + eta / objective / status out per evaluation; the reference tensor is shared by a group'}},

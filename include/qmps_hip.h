@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define QMPS_ABI_VERSION 5
+#define QMPS_ABI_VERSION 6
 
 /* error codes */
 #define QMPS_OK 0
@@ -410,13 +410,29 @@ int qmps_overlap_gradient(qmps_ctx* ctx, int64_t T, int kind, int n_params, cons
  * stopped at residual max(tol, 1e-8) (objective error ~ residual^2, gradient error ~ residual: 2e-8 against gtol); the ladder
  * batches, one-sided, iterate to tol.  QMPS_BFGS_TIGHT_GRADIENT: the gradient solves iterate to tol as well.
  * Any D; at D = 2 (the reference's own bond dimension) the 2 n_params + 1 central-difference candidates of a gradient batch are
- * eigen-solved themselves.  Needs T max(2 n_params + 1, n_alphas - 1) <= max_batch. */
+ * eigen-solved themselves.  Needs T max(2 n_params + 1, n_alphas - 1) <= max_batch.
+ * LOCK-STEP GROUPS (ABI 6).  The reference minimises every trajectory on its own (one scipy `minimize` per trajectory and time
+ * step, qmps/new_time_evolve.py:286; trajectories in parallel, poincare_map/2body_scars.py:445,607); one lock-step over all T makes
+ * a time step cost the slowest trajectory's iteration count and leaves the device idle during the host arithmetic between two
+ * batches.  From T = 512 on the trajectories are therefore split into K <= 4 contiguous groups of >= 256 (qmps_set_evolve_groups
+ * overrides), each a lock-step of its own on a context of its own (stream, resident fixed points; the first group on this context, the
+ * others on internal ones created on first use, kept, and freed by qmps_destroy) driven by a host thread of its own inside this call: one group's kernels fill the gaps of the others, a
+ * straggler holds back its own group only.  Every trajectory's decisions and numbers are the same as in one group.  nit_out is the
+ * maximum over the groups, the counters are sums (the kernel milliseconds of overlapping streams add up: they can exceed the wall
+ * time), qmps_overlap_stats pools the groups.  A QMPS_BFGS_WARM call continues where the previous call left its fixed points
+ * (grouped the same way, or on this context). */
 #define QMPS_BFGS_CARRY_HESSIAN 1
 #define QMPS_BFGS_TIGHT_GRADIENT 4
 #define QMPS_BFGS_WARM 2
 int qmps_evolve_bfgs(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
                      double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
                      double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out);
+
+/* Lock-step groups of qmps_evolve_bfgs: 0 = automatic (the default: min(4, T / 256) from T = 512 on, else one), 1 = one group (the
+ * plain lock-step), 2 .. 16 = that many.  Host threads = groups. */
+int qmps_set_evolve_groups(qmps_ctx* ctx, int groups);
+/* ... and the number a qmps_evolve_bfgs call with T trajectories would use. */
+int qmps_get_evolve_groups(qmps_ctx* ctx, int64_t T, int* groups);
 
 /* The same time evolution with the optimiser ON THE DEVICE, per trajectory (ABI 5; D = 2 - the reference's own bond dimension - and D = 4:
  * qmps/new_time_evolve.py:186-187, 276-292): ONE launch for the whole run, one wave per trajectory - its lanes are the

@@ -84,6 +84,8 @@ SIGNATURES = {
     'qmps_evolve_rotosolve': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, _dp, c_int, c_int, c_int, c_int, c_double, _dp, _dp]),
     'qmps_evolve_bfgs': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, _dp, c_int, c_int, c_double, c_double, c_double, c_int, _dp, c_int, c_int, c_double,
                                  _dp, _dp, _dp, _ip, _dp]),
+    'qmps_set_evolve_groups': (c_int, [c_void_p, c_int]),
+    'qmps_get_evolve_groups': (c_int, [c_void_p, c_int64, POINTER(c_int)]),
     'qmps_evolve_bfgs_device': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, _dp, c_int, c_int, c_double, c_double, c_double, c_int, _dp, c_int, c_int, c_double,
                                         _dp, _dp, _dp, _ip, _dp]),
     'qmps_opt_env_objective': (c_int, [c_void_p, c_int64, _dp, _dp, c_double, _dp, _dp]),
@@ -133,7 +135,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.qmps_abi_version() != 5:
+    if lib.qmps_abi_version() != 6:
         raise ImportError('libqmps_hip.so ABI version mismatch')
     _lib = lib
     return lib

@@ -326,6 +326,9 @@ QMPS_API_CATCH
 int qmps_destroy(qmps_ctx* c) try {
   if (!c) return QMPS_OK;
   (void)hipSetDevice(c->device);
+  for (qmps_ctx* g : c->lockstep) (void)qmps_destroy(g);        // (lock-step groups of qmps_evolve_bfgs)
+  c->lockstep.clear();
+  (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
   if (c->comm_stream2) (void)hipStreamSynchronize(c->comm_stream2);

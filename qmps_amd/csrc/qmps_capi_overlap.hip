@@ -3,6 +3,9 @@
 // Split out of qmps_capi.hip in round 3; shared context + helpers: qmps_ctx.h.
 #include "qmps_ctx.h"
 
+#include <string>
+#include <thread>
+
 using namespace qmps_host;
 
 extern "C" {
@@ -249,6 +252,13 @@ int qmps_overlap_stats(qmps_ctx* c, int64_t* evaluations, int64_t* rounds_sum, i
       h[3] += sh[4 * k + 3];
     }
   }
+  for (qmps_ctx* g : c->lockstep) {            // the lock-step groups of qmps_evolve_bfgs solve on their own contexts
+    int64_t e = 0, rs = 0, rm = 0, nc = 0;
+    if (int rc = qmps_overlap_stats(g, &e, &rs, &rm, &nc, reset)) return rc;
+    h[0] += (unsigned long long)e; h[1] += (unsigned long long)rs; h[3] += (unsigned long long)nc;
+    if ((unsigned long long)rm > h[2]) h[2] = (unsigned long long)rm;
+  }
+  (void)hipSetDevice(c->device);
   if (evaluations) *evaluations = (int64_t)h[0];
   if (rounds_sum) *rounds_sum = (int64_t)h[1];
   if (rounds_max) *rounds_max = (int64_t)h[2];
@@ -348,7 +358,9 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
     HIP_TRY(hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
   }
   // (beyond ~1 000 iterates the solves fill the chip by themselves: T = 2 048 measured 5 % slower with the second stream)
-  const bool beside = T <= 1024;
+  // (a lock-step group of qmps_evolve_bfgs keeps to ONE stream: the other groups fill the chip, and two streams of one group that
+  // land on the same hardware queue serialise - measured 5-10 % slower and erratic, profiles/EXPERIMENTS.md round 4)
+  const bool beside = T <= 1024 && !c->one_stream;
   if (beside) {
     HIP_TRY(hipEventRecord(c->aux_fork, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
@@ -415,9 +427,12 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
 }
 QMPS_API_CATCH
 
-int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
-                     double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
-                     double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out) try {
+namespace {
+// One lock-step group of qmps_evolve_bfgs: T trajectories on context c.  The histories are rows of T_hist trajectories, this
+// group's at column t_off (params / hinv already point at the group's rows).  May throw (std::vector): the callers catch.
+int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
+                      double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
+                      double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out) {
   if (int rc = bind(c)) return rc;
   if (!params || !WW || !f_hist || !alphas) return fail(QMPS_ERR_ARG, "null argument");
   if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
@@ -520,7 +535,7 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
     if (!(carry && (step > 0 || (warm && hinv))))
       for (int64_t t = 0; t < T; ++t) set_identity(t);
     if ((rc = value_and_grad(X.data(), f.data(), g.data(), nullptr))) break;
-    memcpy(f_hist + (size_t)step * 2 * T, f.data(), (size_t)T * sizeof(double));          // objective at the start of the time step
+    memcpy(f_hist + (size_t)step * 2 * T_hist + t_off, f.data(), (size_t)T * sizeof(double));          // objective at the start of the time step
     bool any_active = false;
     for (int64_t t = 0; t < T; ++t) { active[t] = gmax_at_least(&g[(size_t)t * P], gtol) ? 1 : 0; any_active |= active[t] != 0; }
     int nit = 0;
@@ -640,14 +655,122 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
       ++nit;
     }
     if (rc) break;
-    memcpy(f_hist + ((size_t)step * 2 + 1) * T, f.data(), (size_t)T * sizeof(double));     // ... and at its end
-    if (params_hist) memcpy(params_hist + (size_t)step * TP, X.data(), TP * sizeof(double));
+    memcpy(f_hist + ((size_t)step * 2 + 1) * T_hist + t_off, f.data(), (size_t)T * sizeof(double));     // ... and at its end
+    if (params_hist) memcpy(params_hist + ((size_t)step * T_hist + t_off) * P, X.data(), TP * sizeof(double));
     if (nit_out) nit_out[step] = nit;
   }
   if (rc) return rc;
   memcpy(params, X.data(), TP * sizeof(double));
   if (hinv) memcpy(hinv, Hinv.data(), TP * P * sizeof(double));
   if (counters_out) { counters_out[0] = n_grad; counters_out[1] = n_ladder; counters_out[2] = nfev; counters_out[3] = grad_ms; }
+  return QMPS_OK;
+}
+
+// Lock-step groups (include/qmps_hip.h, qmps_set_evolve_groups).  Automatic: groups of >= 256 trajectories, at most four -
+// measured at D = 16 (profiles/EXPERIMENTS.md, round 4): T = 1 024 / 2 048 / 4 096 gain 21 / 33 / 53 % with four groups, T = 256 nothing.
+int evolve_group_count(const qmps_ctx* c, int64_t T) {
+  int64_t K = c->evolve_groups;
+  if (const char* e = tuning_knob("QMPS_EVOLVE_GROUPS")) K = atoll(e);
+  if (K <= 0) K = T >= 512 ? (T / 256 < 4 ? T / 256 : 4) : 1;
+  if (K > T) K = T;
+  if (K > 16) K = 16;
+  return (int)K;
+}
+void drop_groups(qmps_ctx* c) {
+  for (qmps_ctx* g : c->lockstep) (void)qmps_destroy(g);
+  c->lockstep.clear();
+  c->lockstep_T = 0;
+  c->lockstep_cap = 0;
+}
+}  // namespace
+
+int qmps_set_evolve_groups(qmps_ctx* c, int groups) try {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  if (groups < 0 || groups > 16) return fail(QMPS_ERR_ARG, "groups outside [0, 16] (0 = automatic)");
+  c->evolve_groups = groups;
+  return QMPS_OK;
+}
+QMPS_API_CATCH
+
+int qmps_get_evolve_groups(qmps_ctx* c, int64_t T, int* groups) try {
+  if (!c || !groups) return fail(QMPS_ERR_ARG, "null argument");
+  *groups = T >= 2 ? evolve_group_count(c, T) : 1;
+  return QMPS_OK;
+}
+QMPS_API_CATCH
+
+int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
+                     double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
+                     double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out) try {
+  if (int rc = bind(c)) return rc;
+  const int K = (T >= 2 && n_params >= 1 && n_alphas >= 1 && n_steps >= 1) ? evolve_group_count(c, T) : 1;
+  const bool warm = (flags & QMPS_BFGS_WARM) != 0;
+  // a continued evolution goes where its resident fixed points are: the groups' contexts if the previous call was grouped the same way
+  // (group 0 runs on THIS context, groups 1 .. K-1 on contexts of their own)
+  const bool groups_warm = (int)c->lockstep.size() == K - 1 && c->lockstep_T == T;
+  if (K <= 1 || (warm && !groups_warm))
+    return evolve_bfgs_group(c, T, T, 0, kind, n_params, params, WW, n_steps, maxiter, gtol, h, c1, n_alphas, alphas, flags, max_rounds, tol, hinv, params_hist,
+                             f_hist, nit_out, counters_out);
+  // K independent lock-step groups: a context (its own stream and resident buffers) and a host thread each.  While one group's
+  // host arithmetic runs, the other groups' kernels do; a straggler holds back its own group only.
+  const int P = n_params;
+  const int64_t G = n_alphas - 1, per = (1 + 2 * (int64_t)P) > G ? (1 + 2 * (int64_t)P) : G;
+  std::vector<int64_t> off(K + 1);
+  for (int k = 0; k <= K; ++k) off[k] = T * k / K;
+  int64_t Tmax = 0;
+  for (int k = 0; k < K; ++k) Tmax = off[k + 1] - off[k] > Tmax ? off[k + 1] - off[k] : Tmax;
+  if (!groups_warm || c->lockstep_cap < Tmax * per) {
+    drop_groups(c);
+    for (int k = 1; k < K; ++k) {
+      qmps_ctx* g = nullptr;
+      if (int rc = qmps_create(c->device, c->D, Tmax * per, &g)) { drop_groups(c); return rc; }
+      c->lockstep.push_back(g);
+    }
+    c->lockstep_T = T;
+    c->lockstep_cap = Tmax * per;
+    if (warm) return fail(QMPS_ERR_STATE, "QMPS_BFGS_WARM: no resident fixed points for %lld trajectories in %d groups", (long long)T, K);
+  }
+  Restore<bool> one_stream(c->one_stream, true);
+  for (qmps_ctx* g : c->lockstep) {          // the solver settings of the parent
+    g->one_stream = true;
+    g->handoff = c->handoff; g->default_solver = c->default_solver; g->skip_rounds = c->skip_rounds; g->matvec_period = c->matvec_period;
+  }
+  std::vector<int> rcs(K, QMPS_OK);
+  std::vector<std::string> msgs(K);
+  std::vector<int32_t> nits((size_t)K * n_steps, 0);
+  std::vector<double> cnts((size_t)K * 4, 0.0);
+  auto run = [&](int k) {
+    try {
+      rcs[k] = evolve_bfgs_group(k == 0 ? c : c->lockstep[k - 1], off[k + 1] - off[k], T, off[k], kind, P, params ? params + off[k] * P : nullptr, WW, n_steps, maxiter, gtol, h, c1, n_alphas,
+                                 alphas, flags, max_rounds, tol, hinv ? hinv + off[k] * P * P : nullptr, params_hist, f_hist, &nits[(size_t)k * n_steps],
+                                 counters_out ? &cnts[(size_t)k * 4] : nullptr);
+    } catch (const std::exception& ex) {
+      rcs[k] = fail(QMPS_ERR_ARG, "C++ exception inside the library: %s", ex.what());
+    } catch (...) {
+      rcs[k] = fail(QMPS_ERR_ARG, "unknown C++ exception inside the library");
+    }
+    if (rcs[k]) msgs[k] = qmps_last_error();           // (the message is per thread)
+  };
+  {
+    std::vector<std::thread> workers;
+    struct Join { std::vector<std::thread>& w; ~Join() { for (auto& t : w) if (t.joinable()) t.join(); } } join{workers};
+    for (int k = 1; k < K; ++k) workers.emplace_back(run, k);
+    run(0);
+  }
+  (void)hipSetDevice(c->device);
+  for (int k = 0; k < K; ++k)
+    if (rcs[k]) return fail(rcs[k], "%s (lock-step group %d of %d)", msgs[k].c_str(), k, K);
+  if (nit_out)
+    for (int s = 0; s < n_steps; ++s) {
+      int32_t m = 0;
+      for (int k = 0; k < K; ++k) m = nits[(size_t)k * n_steps + s] > m ? nits[(size_t)k * n_steps + s] : m;
+      nit_out[s] = m;                      // (the lock-step count: the slowest trajectory's)
+    }
+  if (counters_out)
+    for (int q = 0; q < 4; ++q) {
+      counters_out[q] = 0.0;
+      for (int k = 0; k < K; ++k) counters_out[q] += cnts[(size_t)k * 4 + q];        // (kernel time: summed over the groups' streams - they overlap)
+    }
   return QMPS_OK;
 }
 QMPS_API_CATCH

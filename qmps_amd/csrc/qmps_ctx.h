@@ -91,6 +91,11 @@ struct qmps_ctx {
   void* d_kry = nullptr;       // D = 8, 16: iterates handed from the power kernels to the Krylov fall-back when the caller keeps no fixed points [max_batch][D][D]
   void* d_y = nullptr;         // qmps_overlap_gradient: LEFT fixed points [max_batch][D][D] (lazy)
   int64_t grad_warm_T = 0;     // d_r / d_y hold the fixed points of this many trajectories' iterates (qmps_overlap_gradient)
+  // qmps_evolve_bfgs: the trajectories as independent lock-step groups, a context and a host thread each (lazy; qmps_set_evolve_groups)
+  std::vector<qmps_ctx*> lockstep;
+  int64_t lockstep_T = 0, lockstep_cap = 0;     // trajectories they were split for / evaluations each one holds
+  int evolve_groups = 0;                    // 0 = automatic, 1 = one group (the plain lock-step), K = that many
+  bool one_stream = false;                  // a lock-step group at work: qmps_overlap_gradient keeps the neighbour tensors on the main stream
   void* d_xwarm = nullptr;     // qmps_evolve_rotosolve: fixed points per (parameter, candidate) (lazy, grown on demand)
   size_t xwarm_bytes = 0;
   int64_t overlap_group = 0;   // > 0: candidate b is compared with reference b / overlap_group

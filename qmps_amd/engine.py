@@ -470,6 +470,16 @@ class EnergyEngine:
         self.B = T
         return P, ph, fh
 
+    def set_evolve_groups(self, groups=0):
+        """Lock-step groups of `evolve_bfgs` (qmps_set_evolve_groups): 0 = automatic, 1 = one lock-step over all trajectories, K = K groups."""
+        L.check(self._lib.qmps_set_evolve_groups(self._ctx, int(groups)))
+
+    def evolve_groups(self, T):
+        """The number of lock-step groups an `evolve_bfgs` call with T trajectories uses (qmps_get_evolve_groups)."""
+        k = ctypes.c_int(0)
+        L.check(self._lib.qmps_get_evolve_groups(self._ctx, int(T), ctypes.byref(k)))
+        return k.value
+
     def evolve_bfgs(self, kind, params, WW, n_steps=1, maxiter=200, gtol=1e-5, h=1e-6, c1=1e-4,
                     alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), carry_hessian=False, hess_inv=None, warm=False,
                     max_rounds=None, tol=1e-12, tight_gradient=False, counters=True):

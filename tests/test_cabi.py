@@ -24,7 +24,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f'{n} declared in include/qmps_hip.h but not exported by libqmps_hip.so'
     # the ctypes table binds exactly the declared entry points
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.qmps_abi_version() == 5
+    assert lib.qmps_abi_version() == 6
 
 
 def test_no_cpu_fallback_without_device():

@@ -455,6 +455,52 @@ def test_device_resident_bfgs_d4_against_the_host_driver_and_the_oracle(engine_f
         eng.evolve_bfgs_device(kind, X0, WW, alphas=tuple(0.5 ** k for k in range(11)))
 
 
+@pytest.mark.parametrize('D,P,T,K', [(8, 6, 21, 3), (16, 8, 10, 4), (4, 4, 9, 2)])
+def test_lockstep_groups_are_the_same_trajectories(D, P, T, K, engine_factory):
+    """qmps_set_evolve_groups: K lock-step groups (a context and a host thread each inside ONE qmps_evolve_bfgs call) against the one
+    lock-step over all trajectories - every trajectory takes the same decisions on the same numbers (ragged split: T not a
+    multiple of K), the lock-step count is the maximum over the groups, the counters are sums, a continued call finds the groups'
+    resident fixed points, qmps_overlap_stats pools the groups."""
+    from qmps_amd import _lib
+    rng = np.random.default_rng(77 + D)
+    WW = WW_of(0.05)
+    X0 = rng.standard_normal((T, P))
+    kind = _lib.ANSATZ_SHALLOW_CNOT
+    one, many = engine_factory(D, T * (2 * P + 1)), engine_factory(D, T * (2 * P + 1) + 1)        # (the factory caches per capacity: two contexts)
+    assert one is not many
+    one.set_evolve_groups(1)
+    many.set_evolve_groups(K)
+    many.overlap_stats(reset=True)
+    one.overlap_stats(reset=True)
+    kw = dict(n_steps=3, maxiter=30, tol=1e-13, carry_hessian=True)
+    a = one.evolve_bfgs(kind, X0, WW, **kw)
+    b = many.evolve_bfgs(kind, X0, WW, **kw)
+    assert np.array_equal(a['nit'], b['nit'])
+    assert np.array_equal(a['params_hist'], b['params_hist']) and np.array_equal(a['fun'], b['fun']) and np.array_equal(a['fun_start'], b['fun_start'])
+    assert np.array_equal(a['hess_inv'], b['hess_inv']) and np.array_equal(a['x'], b['x'])
+    # (scipy's count charges every trajectory for every batch of its lock-step: a group that finishes early stops counting)
+    assert 0 < b['nfev'] <= a['nfev'] and b['gradient_batches'] >= a['gradient_batches'] and b['gradient_ms'] > 0
+    sa, sb = one.overlap_stats(), many.overlap_stats()
+    assert sb['evaluations'] > 0 and sb['not_converged'] == 0 and sa['not_converged'] == 0
+    # a continued evolution (resident fixed points of the groups, carried inverse Hessians)
+    a2 = one.evolve_bfgs(kind, a['x'], WW, n_steps=2, maxiter=30, tol=1e-13, carry_hessian=True, warm=True, hess_inv=a['hess_inv'])
+    b2 = many.evolve_bfgs(kind, b['x'], WW, n_steps=2, maxiter=30, tol=1e-13, carry_hessian=True, warm=True, hess_inv=b['hess_inv'])
+    assert np.array_equal(a2['nit'], b2['nit']) and np.array_equal(a2['x'], b2['x']) and np.array_equal(a2['fun'], b2['fun'])
+    # a different split of the same trajectories has no resident fixed points: refused like any cold WARM call ... unless this context has them
+    many.set_evolve_groups(K + 1)
+    with pytest.raises(_lib.QmpsError, match='QMPS_BFGS_WARM'):
+        many.evolve_bfgs(kind, b2['x'], WW, n_steps=1, maxiter=30, tol=1e-13, warm=True)
+    c = many.evolve_bfgs(kind, b2['x'], WW, n_steps=1, maxiter=30, tol=1e-13)
+    assert c['fun'][-1].mean() < -0.999
+    assert many.evolve_groups(T) == K + 1 and one.evolve_groups(T) == 1
+    # errors of a group come back with the group named
+    with pytest.raises(_lib.QmpsError, match='lock-step group'):
+        many.evolve_bfgs(kind, X0, WW, n_steps=1, maxiter=30, gtol=-1.0)
+    many.set_evolve_groups(0)
+    one.set_evolve_groups(0)
+    assert [many.evolve_groups(t) for t in (1, 256, 511, 512, 1024, 4096)] == [1, 1, 1, 2, 4, 4]
+
+
 def test_native_bfgs_driver_argument_checks_and_single_rung(engine_factory):
     """Refusals of qmps_evolve_bfgs (batch larger than the context, a warm continuation without resident fixed points)
     and the ladder-free variant (one step length: a rejected full step ends the trajectory's minimisation)."""

@@ -1,28 +1,45 @@
-"""config 4 with the trajectories of one GPU split into G independent lock-step groups, one host thread each (ctypes releases the
-GIL inside the C calls): the host algebra of one group overlaps the kernels of the others, and the latency-bound solve chains of
-several groups share the chip"""
-import os, sys, time, threading
+"""Experiment: the T trajectories of a D = 16 time evolution as K independent lock-step groups, one context + one host thread each
+(ctypes releases the GIL during qmps_evolve_bfgs): do the groups' host gaps and straggler iterations overlap on the device?
+usage: python tools/scratch/evolve_groups.py T K [steps]"""
+import sys, time, threading
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from scipy.linalg import expm
-import bench
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from qmps_amd.new_time_evolve import LockstepEvolver
 from qmps_amd.represent import ShallowCNOTStateTensor
-D, P = 16, 8
-WW = expm(-0.05j * bench.tfim_h(1.0))
-for T_total, G in ((1024, 1), (1024, 2), (1024, 4), (2048, 4), (2048, 8), (4096, 8)):
-    T = T_total // G
-    evs = [LockstepEvolver(D, T, P, ShallowCNOTStateTensor, tol=1e-12, maxiter=30, first_rungs=2, carry_hessian=True, speculative=True) for _ in range(G)]
-    Xs = [np.random.default_rng(7 + g).standard_normal((T, P)) for g in range(G)]
-    steps, warm = 8, 3
-    def run(g, n):
-        for _ in range(n):
-            Xs[g] = evs[g].step(Xs[g], WW)['x']
-    for n in (warm, steps):
-        th = [threading.Thread(target=run, args=(g, n)) for g in range(G)]
-        t0 = time.perf_counter()
-        for t in th: t.start()
-        for t in th: t.join()
-        dt = time.perf_counter() - t0
-    print(f'T={T_total} groups={G}: {T_total * steps / dt:.0f} trajectory steps/s, {dt / steps * 1e3:.2f} ms per time step', flush=True)
-    for e in evs: e.close()
+import bench
+
+T, K = int(sys.argv[1]), int(sys.argv[2])
+KC = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # groups inside the library (qmps_set_evolve_groups)
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+D = int(os.environ.get("EXP_D", "16")); P = 8 if D == 16 else 6
+WW = expm(-1j * 0.05 * bench.tfim_h(1.0))
+X = np.random.default_rng(20241022).standard_normal((T, P))
+bounds = [(k * T // K, (k + 1) * T // K) for k in range(K)]
+evs = [LockstepEvolver(D, b - a, P, ShallowCNOTStateTensor, tol=1e-12, maxiter=200, carry_hessian=True, speculative=True) for a, b in bounds]
+out = [None] * K
+tg = [0.0] * K
+for e in evs:
+    e.fg.eng.set_evolve_groups(KC)
+
+def run(k, n):
+    a, b = bounds[k]
+    tt = time.perf_counter()
+    out[k] = evs[k].steps(X[a:b], WW, n, counters=False)
+    tg[k] = (time.perf_counter() - tt) * 1e3
+
+def all_groups(n):
+    th = [threading.Thread(target=run, args=(k, n)) for k in range(K)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for k, (a, b) in enumerate(bounds):
+        X[a:b] = out[k]['x']
+
+all_groups(3)
+t0 = time.perf_counter()
+all_groups(steps)
+for e in evs: e.fg.eng.sync()
+dt = time.perf_counter() - t0
+print('python thread times ms', ['%.3f' % t for t in tg], 'total %.3f' % (dt * 1e3))
+print('T %d python threads %d library groups %d: %.4g trajectory steps/s, %.3f ms per time step, nit %s' % (T, K, KC, T * steps / dt, dt / steps * 1e3, [list(map(int, o['nit'])) for o in out][:2]))

@@ -426,9 +426,19 @@ int qmps_set_states_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const
       // one-round-trip callers: through pinned memory, moved by a kernel on the context stream (no copy-queue hop)
       if (int rc = ensure_pinned(c, (16u << 20))) return rc;
       memcpy(c->h_pin, params, pb);
-      HIP_TRY(qmps::launch_stage_copy(c->h_pin, c->d_params, (int64_t)(pb / 8), c->stream));
+      if (c->mask_stash_n > 0) {         // a mask of qmps_overlap_set_active waiting in its staging slot rides along
+        const int64_t n = c->mask_stash_n;
+        c->mask_stash_n = 0;
+        HIP_TRY(qmps::launch_stage_copy2(c->h_pin, c->d_params, (int64_t)(pb / 8), c->mask_stash, c->d_active, (n + 7) / 8, c->stream));
+      } else {
+        HIP_TRY(qmps::launch_stage_copy(c->h_pin, c->d_params, (int64_t)(pb / 8), c->stream));
+      }
     } else {
       HIP_TRY(hipMemcpyAsync(c->d_params, params, pb, hipMemcpyHostToDevice, c->stream));
+    }
+    if (c->fork_after_copy) {            // qmps_overlap_gradient: its second stream needs the parameters only
+      HIP_TRY(hipEventRecord(c->fork_after_copy, c->stream));
+      c->fork_after_copy = nullptr;
     }
   }
   c->ans_have = true; c->ans_kind = kind; c->ans_P = n_params; c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0;

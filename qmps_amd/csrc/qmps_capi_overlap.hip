@@ -126,6 +126,18 @@ int qmps_overlap_set_group(qmps_ctx* c, int64_t group) try {
 }
 QMPS_API_CATCH
 
+namespace {
+// a stashed mask that no parameter upload has taken along: its own copy kernel
+int flush_mask(qmps_ctx* c) {
+  if (c->mask_stash_n > 0) {
+    const int64_t n = c->mask_stash_n;
+    c->mask_stash_n = 0;
+    HIP_TRY(qmps::launch_stage_copy(c->mask_stash, c->d_active, (n + 7) / 8, c->stream));
+  }
+  return QMPS_OK;
+}
+}  // namespace
+
 int qmps_overlap_set_active(qmps_ctx* c, int64_t n, const unsigned char* active) try {
   if (int rc = bind(c)) return rc;
   if (n < 0 || n > c->max_batch) return fail(QMPS_ERR_ARG, "n=%lld outside [0, max_batch]", (long long)n);
@@ -142,6 +154,12 @@ int qmps_overlap_set_active(qmps_ctx* c, int64_t n, const unsigned char* active)
   if (c->active_inflight[c->active_stage]) HIP_TRY(hipEventSynchronize(c->active_ev[c->active_stage]));
   memcpy(stage, active, (size_t)n);
   memset(stage + n, 1, (size_t)((8 - n % 8) % 8));
+  if (c->stash_masks && !c->capturing) {       // (the driver synchronises after every batch: no copy of an earlier mask is in flight)
+    c->mask_stash = stage;
+    c->mask_stash_n = n;
+    c->active_n = n;
+    return QMPS_OK;
+  }
   HIP_TRY(qmps::launch_stage_copy(stage, c->d_active, (n + 7) / 8, c->stream));
   if (!c->capturing) {
     if (!c->active_ev[c->active_stage]) HIP_TRY(hipEventCreateWithFlags(&c->active_ev[c->active_stage], hipEventDisableTiming));
@@ -155,7 +173,7 @@ QMPS_API_CATCH
 
 int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int flags) try {
   if (int rc = bind(c)) return rc;
-  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; } } disarm{c};      // the mask of qmps_overlap_set_active is ONE-SHOT: spent on every way out
+  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; c->mask_stash_n = 0; c->fork_after_copy = nullptr; } } disarm{c};      // the mask of qmps_overlap_set_active is ONE-SHOT: spent on every way out
   if (int rc = check_window(c, B)) return rc;
   if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
   if (c->overlap_refs < 1) return fail(QMPS_ERR_STATE, "qmps_overlap_set has not been called");
@@ -190,6 +208,7 @@ int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int 
   a.stats = c->d_ostats;
   a.group = (int)group;
   a.iters = win_iters(c); a.status = win_status(c); a.B = B; a.a_shared = shared ? 1 : 0; a.max_rounds = max_rounds; a.tol = tol;
+  if (int rc = flush_mask(c)) return rc;
   if (c->active_n > 0) {           // one-shot mask of qmps_overlap_set_active: one entry per trajectory (candidate group)
     const int64_t need = group > 0 ? (c->window + B + group - 1) / group : c->window + B;
     if (c->active_n < need) return fail(QMPS_ERR_STATE, "qmps_overlap_set_active: %lld entries for %lld trajectories", (long long)c->active_n, (long long)need);
@@ -303,7 +322,7 @@ QMPS_API_CATCH
 int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const double* params, double h, int max_rounds, double tol,
                           int flags, double* f_out, double* g_out, int32_t* status_out) try {
   if (int rc = bind(c)) return rc;
-  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; } } disarm{c};      // (one-shot mask: spent on every way out)
+  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; c->mask_stash_n = 0; c->fork_after_copy = nullptr; } } disarm{c};      // (one-shot mask: spent on every way out)
   if (!params || !f_out || !g_out) return fail(QMPS_ERR_ARG, "null argument");
   if (c->D < 4) return fail(QMPS_ERR_ARG, "qmps_overlap_gradient: D = 4, 8, 16 (at D = 2 evaluate the central-difference neighbours themselves)");
   if (flags & ~(QMPS_OVERLAP_WARM | QMPS_OVERLAP_TWO_SIDED_F)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
@@ -322,33 +341,6 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
     const size_t need = (size_t)T * (1 + 2 * P) * sizeof(double) + (size_t)2 * T * sizeof(int32_t) + (8u << 20);
     if (int e = ensure_pinned(c, need > (16u << 20) ? need : (16u << 20))) return e;
   }
-  // the iterates: parameters -> tensors in d_A[0, T)
-  int rc;
-  {
-    Restore<bool> deferred(c->defer_sync, true);
-    rc = qmps_set_states_ansatz(c, T, kind, P, params);
-  }
-  if (!rc) rc = ensure_tensors(c);
-  if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
-  const bool squaring = overlap_squares(c);       // D = 4: the right fixed point comes from the squaring kernel (largest column)
-  qmps::OverlapArgs a;
-  memset(&a, 0, sizeof(a));
-  a.A = c->d_ref; a.Bt = c->d_A; a.WW = c->d_ww; a.eta = c->d_eta; a.f_out = c->d_f; a.r_out = c->d_r;
-  a.x_in = (warm && !squaring) ? c->d_r : nullptr;
-  a.stats = c->d_ostats; a.iters = c->d_iters; a.status = c->d_status; a.B = T; a.a_shared = 0;
-  a.max_rounds = squaring && max_rounds > 60 ? 60 : max_rounds; a.tol = tol;
-  const unsigned char* mask = nullptr;
-  if (c->active_n > 0) {
-    if (c->active_n < T) return fail(QMPS_ERR_STATE, "qmps_overlap_set_active: %lld entries for %lld trajectories", (long long)c->active_n, (long long)T);
-    mask = c->d_active;
-    c->active_n = 0;
-  }
-  a.active = mask;
-  // HIP events around the WHOLE gradient evaluation (right solve, left solve, neighbour tensors, G, probes): qmps_kernel_time
-  c->dominant = c->D == 16 ? "overlap_mfma_d16_kernel + adjoint + neighbour probes" : "overlap solve + adjoint + neighbour probes";
-  c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
-  const int tslot = (int)(c->samples % qmps_ctx::kRing);
-  if (c->timed) HIP_TRY(hipEventRecord(c->kev0[tslot], c->stream));
   // the 2 P central-difference neighbours of every iterate (evaluated below to second order in h from (y, r)): their tensors
   // need the parameters only, so they are built on a second stream BESIDE the eigen-solves (at small T a gradient batch is the
   // latency of its slowest solve; the neighbour tensors were a fifth of it in front of the probes)
@@ -361,12 +353,36 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   // (a lock-step group of qmps_evolve_bfgs keeps to ONE stream: the other groups fill the chip, and two streams of one group that
   // land on the same hardware queue serialise - measured 5-10 % slower and erratic, profiles/EXPERIMENTS.md round 4)
   const bool beside = T <= 1024 && !c->one_stream;
-  if (beside) {
-    HIP_TRY(hipEventRecord(c->aux_fork, c->stream));
-    HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
-    HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->aux_stream));
-    HIP_TRY(hipEventRecord(c->aux_join, c->aux_stream));
+  // the iterates: parameters -> tensors in d_A[0, T); the fork event sits between the parameter upload and the tensor build, and
+  // the second stream is fed only AFTER the solves are submitted (the host calls of the fork used to hold the solves back ~15 us)
+  int rc;
+  {
+    Restore<bool> deferred(c->defer_sync, true);
+    if (beside) c->fork_after_copy = c->aux_fork;
+    rc = qmps_set_states_ansatz(c, T, kind, P, params);
   }
+  if (!rc) rc = ensure_tensors(c);
+  if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+  const bool squaring = overlap_squares(c);       // D = 4: the right fixed point comes from the squaring kernel (largest column)
+  qmps::OverlapArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = c->d_ref; a.Bt = c->d_A; a.WW = c->d_ww; a.eta = c->d_eta; a.f_out = c->d_f; a.r_out = c->d_r;
+  a.x_in = (warm && !squaring) ? c->d_r : nullptr;
+  a.stats = c->d_ostats; a.iters = c->d_iters; a.status = c->d_status; a.B = T; a.a_shared = 0;
+  a.max_rounds = squaring && max_rounds > 60 ? 60 : max_rounds; a.tol = tol;
+  const unsigned char* mask = nullptr;
+  if (int e = flush_mask(c)) return e;
+  if (c->active_n > 0) {
+    if (c->active_n < T) return fail(QMPS_ERR_STATE, "qmps_overlap_set_active: %lld entries for %lld trajectories", (long long)c->active_n, (long long)T);
+    mask = c->d_active;
+    c->active_n = 0;
+  }
+  a.active = mask;
+  // HIP events around the WHOLE gradient evaluation (right solve, left solve, neighbour tensors, G, probes): qmps_kernel_time
+  c->dominant = c->D == 16 ? "overlap_mfma_d16_kernel + adjoint + neighbour probes" : "overlap solve + adjoint + neighbour probes";
+  c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
+  const int tslot = (int)(c->samples % qmps_ctx::kRing);
+  if (c->timed) HIP_TRY(hipEventRecord(c->kev0[tslot], c->stream));
   // the left fixed points: power method on the adjoint map; results behind the iterates' (eta, rounds, status at [T, 2T))
   qmps::OverlapArgs l = a;
   l.adjoint = 1; l.eta = (char*)c->d_eta + (size_t)T * 16; l.f_out = nullptr; l.r_out = c->d_y; l.x_in = warm ? c->d_y : nullptr;
@@ -398,7 +414,16 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
     l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
     HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 4 ? squaring : (c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr), c->stream));
   }
-  if (beside) HIP_TRY(hipStreamWaitEvent(c->stream, c->aux_join, 0));
+  if (beside) {
+    if (c->fork_after_copy) {        // (the parameter upload took another path: fork here)
+      c->fork_after_copy = nullptr;
+      return fail(QMPS_ERR_STATE, "qmps_overlap_gradient: the parameter upload did not record the fork event");
+    }
+    HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
+    HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->aux_stream));
+    HIP_TRY(hipEventRecord(c->aux_join, c->aux_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->aux_join, 0));
+  }
   else HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->stream));
   qmps::OverlapGradArgs g;
   memset(&g, 0, sizeof(g));
@@ -409,9 +434,13 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   if (c->timed) { HIP_TRY(hipEventRecord(c->kev1[tslot], c->stream)); c->samples++; }
   c->launches++;
   // f of the iterates and of their neighbours are contiguous in d_f: one copy; statuses of both solves: one copy (pinned staging)
+  // (tried: the two kernels writing pinned host mirrors themselves instead of the copy kernel - 4 352 eight-byte writes over the
+  // host link are slower than one coalesced burst: 0.78 - 0.80 -> 0.80 - 0.83 ms per time step at 256 trajectories)
   const size_t fbytes = (size_t)T * (1 + 2 * P) * sizeof(double), sbytes = (size_t)2 * T * sizeof(int32_t);
   double* fall = (double*)(c->h_pin + (8u << 20));
   int32_t* st = (int32_t*)(c->h_pin + (8u << 20) + fbytes);
+  // (tried: a completion flag in pinned memory written by the copy kernel's last block and polled by the host instead of
+  // hipStreamSynchronize - the wait shrinks by 7 us, the next submission grows by 11: no gain)
   HIP_TRY(qmps::launch_stage_copy2(c->d_f, fall, (int64_t)(fbytes / 8), c->d_status, st, (int64_t)(sbytes / 8), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   memcpy(f_out, fall, (size_t)T * sizeof(double));
@@ -461,6 +490,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   std::vector<unsigned char> active(T), moved(T), need(T);
   // (a pair of event records around a batch costs the stream ~12 us: only when asked for; restored on EVERY way out of this function)
   Restore<int> period_guard(c->timing_period, counters_out ? 1 : 0);
+  Restore<bool> stash_guard(c->stash_masks, true);          // (every batch below ends with a synchronisation)
   double n_grad = 0.0, n_ladder = 0.0, nfev = 0.0, grad_ms = 0.0;
   auto set_identity = [&](int64_t t) {
     double* Ht = &Hinv[(size_t)t * P * P];

@@ -51,13 +51,14 @@ template <int D, int KIND>
 // -fd_h (k >= P) added to parameter k mod P
 __global__ __launch_bounds__(64) void ansatz_tensor_kernel(const double* __restrict__ params, int n_params,
                                                            double2* __restrict__ A, int64_t B, int nsh,
-                                                           const int* __restrict__ i_ptr, double fd_h) {
+                                                           const int* __restrict__ i_ptr, double fd_h, const unsigned char* __restrict__ active) {
   constexpr int NQ = (D == 2 ? 2 : D == 4 ? 3 : D == 8 ? 4 : 5);
   const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const int64_t b = t / D;
   const int j = (int)(t % D);
   if (b >= B) return;
   const int64_t row = nsh > 0 ? b / nsh : b;
+  if (active != nullptr && active[row] == 0) return;       // (central-difference batches of the evolve drivers: a skipped trajectory's neighbours are never read)
   const int shift_k = nsh > 0 ? (int)(b - row * nsh) : 0;
   const bool fd = fd_h != 0.0;
   const int isel = nsh > 0 ? (fd ? shift_k % n_params : *i_ptr) : -1;
@@ -106,7 +107,7 @@ __device__ __forceinline__ void rx_lanes(double& re, double& im, double c, doubl
 
 template <int KIND>
 __global__ __launch_bounds__(256) void ansatz_tensor_wave_d16_kernel(const double* __restrict__ params, int n_params, double2* __restrict__ A, int64_t B,
-                                                                     int nsh, const int* __restrict__ i_ptr, double fd_h) {
+                                                                     int nsh, const int* __restrict__ i_ptr, double fd_h, const unsigned char* __restrict__ active) {
   constexpr int per = KIND == 3 ? 3 : 2;
   const int lane = threadIdx.x & 63, a = lane & 31;
   const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // wave = (tensor, pair of columns)
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256) void ansatz_tensor_wave_d16_kernel(const doubl
   if (b >= B) return;
   const int j = (int)(wv & 7) * 2 + (lane >> 5);
   const int64_t row = nsh > 0 ? b / nsh : b;
+  if (active != nullptr && active[row] == 0) return;
   const int shift_k = nsh > 0 ? (int)(b - row * nsh) : 0;
   const bool fd = fd_h != 0.0;
   const int isel = nsh > 0 ? (fd ? shift_k % n_params : *i_ptr) : -1;
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(256) void ansatz_tensor_wave_d16_kernel(const doubl
 }
 
 template <int D>
-static hipError_t launch_ansatz_d(int kind, const double* params, int n_params, void* A, int64_t B, int nsh, const int* i_ptr, hipStream_t st, double fd_h = 0.0) {
+static hipError_t launch_ansatz_d(int kind, const double* params, int n_params, void* A, int64_t B, int nsh, const int* i_ptr, hipStream_t st, double fd_h = 0.0,
+                                  const unsigned char* active = nullptr) {
   const int64_t threads = B * D;
   const dim3 grid((unsigned)((threads + 63) / 64)), block(64);
   if constexpr (D == 16) {
@@ -181,24 +184,24 @@ static hipError_t launch_ansatz_d(int kind, const double* params, int n_params, 
     // (small launches only: the distributed form is ~10 x shorter in latency but costs ~2 x the issue slots - eight waves per tensor)
     if ((kind == 0 || kind == 3) && n_params <= 64 && B <= 512) {
       const dim3 g2((unsigned)(B * 2)), b2(256);
-      if (kind == 0) hipLaunchKernelGGL((ansatz_tensor_wave_d16_kernel<0>), g2, b2, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h);
-      else hipLaunchKernelGGL((ansatz_tensor_wave_d16_kernel<3>), g2, b2, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h);
+      if (kind == 0) hipLaunchKernelGGL((ansatz_tensor_wave_d16_kernel<0>), g2, b2, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h, active);
+      else hipLaunchKernelGGL((ansatz_tensor_wave_d16_kernel<3>), g2, b2, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h, active);
       return hipGetLastError();
     }
   }
   switch (kind) {
-    case 0: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 0>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
-    case 1: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 1>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
+    case 0: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 0>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h, active); break;
+    case 1: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 1>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h, active); break;
     case 2:
       if (D != 2) return hipErrorInvalidValue;
-      hipLaunchKernelGGL((ansatz_tensor_kernel<2, 2>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h);
+      hipLaunchKernelGGL((ansatz_tensor_kernel<2, 2>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h, active);
       break;
-    case 3: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 3>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
-    case 4: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 4>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
-    case 5: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 5>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h); break;
+    case 3: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 3>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h, active); break;
+    case 4: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 4>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h, active); break;
+    case 5: hipLaunchKernelGGL((ansatz_tensor_kernel<D, 5>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h, active); break;
     case 6:
       if (D != 2) return hipErrorInvalidValue;
-      hipLaunchKernelGGL((ansatz_tensor_kernel<2, 6>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h);
+      hipLaunchKernelGGL((ansatz_tensor_kernel<2, 6>), grid, block, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h, active);
       break;
     default: return hipErrorInvalidValue;
   }
@@ -217,14 +220,14 @@ hipError_t launch_ansatz_shifted(int D, int kind, const double* params, int n_pa
   }
 }
 
-hipError_t launch_ansatz_fd(int D, int kind, const double* params, int n_params, void* A, int64_t rows, double h, hipStream_t st) {
+hipError_t launch_ansatz_fd(int D, int kind, const double* params, int n_params, void* A, int64_t rows, double h, hipStream_t st, const unsigned char* active) {
   const int64_t B = rows * 2 * n_params;
   if (B <= 0) return hipSuccess;
   switch (D) {
-    case 2: return launch_ansatz_d<2>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h);
-    case 4: return launch_ansatz_d<4>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h);
-    case 8: return launch_ansatz_d<8>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h);
-    case 16: return launch_ansatz_d<16>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h);
+    case 2: return launch_ansatz_d<2>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h, active);
+    case 4: return launch_ansatz_d<4>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h, active);
+    case 8: return launch_ansatz_d<8>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h, active);
+    case 16: return launch_ansatz_d<16>(kind, params, n_params, A, B, 2 * n_params, nullptr, st, h, active);
     default: return hipErrorInvalidValue;
   }
 }

@@ -420,11 +420,11 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
       return fail(QMPS_ERR_STATE, "qmps_overlap_gradient: the parameter upload did not record the fork event");
     }
     HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
-    HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->aux_stream));
+    HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->aux_stream, mask));
     HIP_TRY(hipEventRecord(c->aux_join, c->aux_stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->aux_join, 0));
   }
-  else HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->stream));
+  else HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->stream, mask));
   qmps::OverlapGradArgs g;
   memset(&g, 0, sizeof(g));
   g.A = c->d_ref; g.WW = c->d_ww; g.r = c->d_r; g.y = c->d_y; g.G = c->d_scratch; g.yr = (char*)c->d_scratch + (size_t)T * 4 * nD * 16;
@@ -574,6 +574,11 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
         const double* Ht = &Hinv[(size_t)t * P * P];
         const double* gt = &g[(size_t)t * P];
         double* dt = &d[(size_t)t * P];
+        // (a trajectory that has stopped keeps g and H^-1: its direction test below had its one possible effect in iteration 0)
+        if (!active[t] && nit > 0) {
+          for (int a = 0; a < P; ++a) dt[a] = 0.0;
+          continue;
+        }
         double sl = 0.0;
         for (int a = 0; a < P; ++a) {
           double acc = 0.0;

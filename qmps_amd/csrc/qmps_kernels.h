@@ -167,7 +167,8 @@ hipError_t launch_ansatz_shifted(int D, int kind, const double* params, int n_pa
 // A[B][2][N/2][N/2] (out_tensor = 1), N in {4, 8, 16, 32}: qmps_su.hip
 hipError_t launch_su_exp(int N, const double* params, int64_t B, int stride_params, void* out, int out_tensor, hipStream_t st);
 // central-difference batches: 2 n_params evaluations per row, evaluation 2 P r + k = row r with +h (k < P) / -h (k >= P) on parameter k mod P
-hipError_t launch_ansatz_fd(int D, int kind, const double* params, int n_params, void* A, int64_t rows, double h, hipStream_t st);
+hipError_t launch_ansatz_fd(int D, int kind, const double* params, int n_params, void* A, int64_t rows, double h, hipStream_t st,
+                            const unsigned char* active = nullptr);      // active: nullable [rows], 0 = leave that row's tensors alone
 // time-evolution overlap (D = 2): dominant eigenvalue of the mixed two-site transfer map
 struct OverlapArgs {
   const void* A;     // [B or 1][2][2][2] current state tensor(s)

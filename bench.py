@@ -856,6 +856,8 @@ def other_configs(args, budget_s=60.0):
         ('config1_rotosolve_D2_b4096', dict(workload='rotosolve', D=2, batch=4096, steps=160, warmup=8, hamiltonian=None, double_frequency=False, shard=False)),
         ('config3_rotosolve_D8_xxz_256x3', dict(workload='rotosolve', D=8, batch=768, steps=160, warmup=8, hamiltonian=None, double_frequency=False, shard=False)),
         ('config4_evolve_D16_depth4_T256', dict(workload='evolve', D=16, batch=256, steps=10, warmup=3, tol=1e-12, carry_hessian=None)),
+        # the same time evolution with more trajectories than the configuration names (the lock-step groups of qmps_evolve_bfgs)
+        ('config4_evolve_D16_depth4_T2048', dict(workload='evolve', D=16, batch=2048, steps=10, warmup=3, tol=1e-12, carry_hessian=None, no_cpu_baseline=True, no_extras=True)),
     ]
     res = {}
     for name, over in plan:
@@ -880,7 +882,7 @@ def other_configs(args, budget_s=60.0):
                      'cpu_baseline': d.get('cpu_baseline'), 'workload': d['config'].get('workload'),
                      'config': {k: v for k, v in d['config'].items() if k in ('baseline_config', 'hamiltonian', 'D', 'restarts', 'n_params', 'shifts', 'us_per_parameter_update', 'mean_energy_first_sweep',
                                                                                 'mean_energy_last_sweep', 'best_energy', 'exact_ground_state_energy', 'not_converged_or_not_pd',
-                                                                                'trajectories_per_gpu', 'driver', 'bfgs_iterations_per_step', 'carry_hessian', 'not_converged',
+                                                                                'trajectories_per_gpu', 'driver', 'lockstep_groups', 'bfgs_iterations_per_step', 'carry_hessian', 'not_converged',
                                                                                 'mean_final_objective', 'kernel_share_of_wall', 'solver_rounds_mean_gradient_batches',
                                                                                 'solver_rounds_max_gradient_batches')},
                      'wall_s': time.perf_counter() - t1}

@@ -754,17 +754,17 @@ int qmps_evolve_bfgs(qmps_ctx* c, int64_t T, int kind, int n_params, double* par
   for (int k = 0; k <= K; ++k) off[k] = T * k / K;
   int64_t Tmax = 0;
   for (int k = 0; k < K; ++k) Tmax = off[k + 1] - off[k] > Tmax ? off[k + 1] - off[k] : Tmax;
-  if (!groups_warm || c->lockstep_cap < Tmax * per) {
+  if ((int)c->lockstep.size() != K - 1 || c->lockstep_cap < Tmax * per) {      // (contexts that are large enough serve any T)
     drop_groups(c);
     for (int k = 1; k < K; ++k) {
       qmps_ctx* g = nullptr;
       if (int rc = qmps_create(c->device, c->D, Tmax * per, &g)) { drop_groups(c); return rc; }
       c->lockstep.push_back(g);
     }
-    c->lockstep_T = T;
     c->lockstep_cap = Tmax * per;
     if (warm) return fail(QMPS_ERR_STATE, "QMPS_BFGS_WARM: no resident fixed points for %lld trajectories in %d groups", (long long)T, K);
   }
+  c->lockstep_T = T;
   Restore<bool> one_stream(c->one_stream, true);
   for (qmps_ctx* g : c->lockstep) {          // the solver settings of the parent
     g->one_stream = true;

@@ -173,7 +173,7 @@ QMPS_API_CATCH
 
 int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int flags) try {
   if (int rc = bind(c)) return rc;
-  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; c->mask_stash_n = 0; c->fork_after_copy = nullptr; } } disarm{c};      // the mask of qmps_overlap_set_active is ONE-SHOT: spent on every way out
+  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; c->mask_stash_n = 0; c->fork_after_copy = nullptr; c->warm_from_group = 0; } } disarm{c};      // the mask of qmps_overlap_set_active is ONE-SHOT: spent on every way out
   if (int rc = check_window(c, B)) return rc;
   if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
   if (c->overlap_refs < 1) return fail(QMPS_ERR_STATE, "qmps_overlap_set has not been called");
@@ -205,6 +205,13 @@ int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int 
   a.f_out = c->d_f + c->window;
   a.r_out = want_r ? win_r(c) : nullptr;
   a.x_in = warm ? win_r(c) : nullptr;
+  if (c->warm_from_group > 0) {        // the ladder of a lock-step BFGS iteration: every step length starts from its trajectory's fixed point
+    if (!warm && !squaring && c->window == 0 && group == c->warm_from_group && c->grad_warm_T * group >= B) {
+      a.x_in = c->d_r;
+      a.x_in_group = (int)group;
+    }
+    c->warm_from_group = 0;
+  }
   a.stats = c->d_ostats;
   a.group = (int)group;
   a.iters = win_iters(c); a.status = win_status(c); a.B = B; a.a_shared = shared ? 1 : 0; a.max_rounds = max_rounds; a.tol = tol;
@@ -322,7 +329,7 @@ QMPS_API_CATCH
 int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const double* params, double h, int max_rounds, double tol,
                           int flags, double* f_out, double* g_out, int32_t* status_out) try {
   if (int rc = bind(c)) return rc;
-  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; c->mask_stash_n = 0; c->fork_after_copy = nullptr; } } disarm{c};      // (one-shot mask: spent on every way out)
+  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; c->mask_stash_n = 0; c->fork_after_copy = nullptr; c->warm_from_group = 0; } } disarm{c};      // (one-shot mask: spent on every way out)
   if (!params || !f_out || !g_out) return fail(QMPS_ERR_ARG, "null argument");
   if (c->D < 4) return fail(QMPS_ERR_ARG, "qmps_overlap_gradient: D = 4, 8, 16 (at D = 2 evaluate the central-difference neighbours themselves)");
   if (flags & ~(QMPS_OVERLAP_WARM | QMPS_OVERLAP_TWO_SIDED_F)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
@@ -623,6 +630,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
             for (int k = 0; k < P; ++k) cand[((size_t)t * G + r) * P + k] = X[(size_t)t * P + k] + alphas[r + 1] * d[(size_t)t * P + k];
         if ((rc = qmps_overlap_set_group(c, G))) break;
         if ((rc = qmps_overlap_set_active(c, T, need.data()))) break;
+        c->warm_from_group = (two_sided && c->grad_warm_T == T) ? G : 0;      // (resident: the fixed points of the rejected full steps)
         rc = qmps_overlap_eval_ansatz(c, T * G, kind, P, cand.data(), ladder_rounds, tol, 0, Fl.data(), stl.data());
         (void)qmps_overlap_set_group(c, 0);
         if (rc) break;

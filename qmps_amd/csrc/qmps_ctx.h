@@ -87,6 +87,7 @@ struct qmps_ctx {
   int active_stage = 0;                //   staging slot of the last mask (two, alternating)
   hipEvent_t active_ev[2] = {};        //   ... and the event behind its copy kernel
   bool active_inflight[2] = {};
+  int64_t warm_from_group = 0;         // one-shot (qmps_evolve_bfgs): the next qmps_overlap_launch starts candidate b from the resident fixed point b / warm_from_group
   bool stash_masks = false;            //   the evolve drivers (one synchronisation per batch): the mask waits in its staging slot and rides
   int64_t mask_stash_n = 0;            //   with the NEXT parameter upload of qmps_set_states_ansatz - one copy kernel instead of two
   const unsigned char* mask_stash = nullptr;

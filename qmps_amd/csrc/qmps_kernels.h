@@ -186,6 +186,7 @@ struct OverlapArgs {
   int group;                   // > 0: candidate b is compared with reference tensor b / group (trajectory-major batches)
   double* f_out;               // nullable [B]: the objective -sqrt(|eta|) (qmps/new_time_evolve.py:221)
   const void* x_in;            // nullable [B][D][D]: warm start of the power method (D = 8, 16); an all-zero matrix = cold start
+  int x_in_group;              // > 0: candidate b starts from x_in[b / x_in_group] (a ladder of step lengths starts from its trajectory's fixed point)
   const int* slot_ptr;         // nullable: x_in and r_out are displaced by *slot_ptr * slot_stride bytes (rotosolve keeps one
   int64_t slot_stride;         //   set of fixed points per parameter: the candidates of parameter i return to the same slot every sweep)
   unsigned long long* stats;   // nullable [kOverlapStatShards][4]: evaluations, sum of rounds, max rounds, not converged (atomics, sharded by evaluation index)

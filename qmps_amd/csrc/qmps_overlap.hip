@@ -113,7 +113,7 @@ __device__ __forceinline__ void overlap_block_body(const OverlapArgs& p, int64_t
   double2 x = make_double2(i == j ? 1.0 / __builtin_sqrt((double)D) : 0.0, 0.0);
   const int64_t slot_off = overlap_slot_offset(p);
   if (p.x_in != nullptr) {      // warm start: the resident fixed point of this candidate's slot (all zero: none yet)
-    const double2 w = ((const double2*)((const char*)p.x_in + slot_off))[bb * N + l];
+    const double2 w = ((const double2*)((const char*)p.x_in + slot_off))[(p.x_in_group > 0 ? bb / p.x_in_group : bb) * N + l];
     double v[4] = {w.x * w.x + w.y * w.y, 0.0, 0.0, 0.0};
     group_sum4(v);
     if (v[0] > 1e-200 && v[0] < 1e200) {
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
       xi[q] = 0.0;
     }
     if (p.x_in != nullptr) {      // warm start: the resident fixed point of this candidate's slot (all zero: none yet)
-      const double2* xi_ = (const double2*)((const char*)p.x_in + slot_off) + b * (D * D);
+      const double2* xi_ = (const double2*)((const char*)p.x_in + slot_off) + (p.x_in_group > 0 ? b / p.x_in_group : b) * (D * D);
       v4f64 wr, wi;
       double n2 = 0.0;
 #pragma unroll
@@ -657,7 +657,7 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
       xi[q] = 0.0;
     }
     if (p.x_in != nullptr) {      // warm start: the resident fixed point of this candidate's slot (all zero: none yet)
-      const double2* xi_ = (const double2*)((const char*)p.x_in + slot_off) + b * (D * D);
+      const double2* xi_ = (const double2*)((const char*)p.x_in + slot_off) + (p.x_in_group > 0 ? b / p.x_in_group : b) * (D * D);
       v4f64 wr, wi;
       double n2 = 0.0;
 #pragma unroll

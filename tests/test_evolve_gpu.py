@@ -502,6 +502,26 @@ def test_lockstep_groups_are_the_same_trajectories(D, P, T, K, engine_factory):
     assert [many.evolve_groups(t) for t in (1, 256, 511, 512, 1024, 4096)] == [1, 1, 1, 2, 4, 4]
 
 
+def test_lockstep_groups_automatic_at_full_size(engine_factory):
+    """From 512 trajectories on qmps_evolve_bfgs groups by itself (here D = 8, 600 trajectories: two groups of 300): the same
+    evolution as one lock-step over all 600, and every trajectory ends at its minimum."""
+    from qmps_amd import _lib
+    D, P, T = 8, 6, 600
+    rng = np.random.default_rng(2024)
+    WW = WW_of(0.05)
+    X0 = rng.standard_normal((T, P))
+    auto, one = engine_factory(D, T * (2 * P + 1)), engine_factory(D, T * (2 * P + 1) + 1)
+    auto.set_evolve_groups(0)
+    one.set_evolve_groups(1)
+    assert auto.evolve_groups(T) == 2 and one.evolve_groups(T) == 1
+    kw = dict(n_steps=2, maxiter=40, tol=1e-12, carry_hessian=True)
+    a = auto.evolve_bfgs(_lib.ANSATZ_SHALLOW_CNOT, X0, WW, **kw)
+    b = one.evolve_bfgs(_lib.ANSATZ_SHALLOW_CNOT, X0, WW, **kw)
+    assert np.array_equal(a['params_hist'], b['params_hist']) and np.array_equal(a['fun'], b['fun']) and np.array_equal(a['nit'], b['nit'])
+    assert np.all(np.isfinite(a['fun'])) and a['fun'][-1].max() < -0.99
+    one.set_evolve_groups(0)
+
+
 def test_native_bfgs_driver_argument_checks_and_single_rung(engine_factory):
     """Refusals of qmps_evolve_bfgs (batch larger than the context, a warm continuation without resident fixed points)
     and the ladder-free variant (one step length: a rejected full step ends the trajectory's minimisation)."""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): bash tools/r04_numbers.sh <tag>   -> gpurun_out/<tag>_*.json + rocprofv3 kernel statistics of the shipped library:
 # the bench lines and CSVs DESIGN.md section 6 quotes for round 4
-tag=${1:-r04f}
+tag=${1:-r04h}
 R=$GRAFT_REPO_ROOT
 o=$R/gpurun_out
 run() { n=$1; shift; timeout 900 python $R/bench.py "$@" > $o/${tag}_$n.json 2> $o/${tag}_$n.err || echo "FAILED $n"; }

@@ -599,6 +599,26 @@ def main_evolve(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     elapsed_instr = elapsed
+    block_s = [elapsed]
+    if native and not args.no_repeats:
+        # the timed block repeated (the evolution goes on: the next `steps` time steps of the same trajectories), barrier + sync around each
+        Xr = X
+        for _ in range(4):
+            if dist is not None:
+                dist.barrier()
+            tb = time.perf_counter()
+            Xr = ev.steps(Xr, WW, args.steps, counters=False)['x']
+            ev.fg.eng.sync()
+            if dist is not None:
+                dist.barrier()
+            eb = time.perf_counter() - tb
+            if dist is not None:
+                import torch
+                t = torch.tensor([eb], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                eb = float(t.item())
+            block_s.append(eb)
+        X = Xr
     if native:
         # instrumented pass: the NEXT args.steps time steps of the same trajectories with HIP events around every gradient batch
         # and the batch counters; the roofline figures, the solver statistics and the kernel share of wall time are this pass's
@@ -691,6 +711,10 @@ def main_evolve(args):
                'cpu_baseline': cpu}
         if identity_leg is not None:
             out['identity_start'] = identity_leg
+        if len(block_s) > 1:
+            vals = [world * T * args.steps / b for b in block_s]
+            out['repeats'] = {'blocks': len(block_s), 'steps_per_block': args.steps, 'value_median': float(np.median(vals)), 'value_min': float(min(vals)),
+                              'value_max': float(max(vals)), 'what': 'the timed block of --steps time steps repeated back to back on the evolving trajectories (block 0 is `value`)'}
         emit(args, out)
     ev.close()
     if dist is not None:
@@ -886,6 +910,8 @@ def other_configs(args, budget_s=60.0):
                                                                                 'mean_final_objective', 'kernel_share_of_wall', 'solver_rounds_mean_gradient_batches',
                                                                                 'solver_rounds_max_gradient_batches')},
                      'wall_s': time.perf_counter() - t1}
+        if 'repeats' in d:
+            res[name]['repeats'] = d['repeats']
         if 'identity_start' in d:       # config 4 BOTH ways: the reference's own restart of every minimisation beside the carried Hessians
             res[name]['identity_start'] = d['identity_start']
     res['what'] = ('BASELINE.json configs[1], [3], [4] run as `--workload rotosolve|evolve` in this process (their own synthetic inputs, contexts and CPU-baseline samples); '

@@ -181,8 +181,11 @@ static hipError_t launch_ansatz_d(int kind, const double* params, int n_params, 
   const dim3 grid((unsigned)((threads + 63) / 64)), block(64);
   if constexpr (D == 16) {
     // ShallowCNOT families: the circuit distributed over the lanes of a wave (two columns per wave)
-    // (small launches only: the distributed form is ~10 x shorter in latency but costs ~2 x the issue slots - eight waves per tensor)
-    if ((kind == 0 || kind == 3) && n_params <= 64 && B <= 512) {
+    // (the distributed form is ~10 x shorter in latency but costs ~2 x the issue slots - eight waves per tensor: plain batches - the
+    // iterates and references of the evolve drivers, one tensor per trajectory, whose build sits in front of the solves - always,
+    // whatever their size, so that a trajectory's tensor does not depend on how many others share its launch (the two kernels round
+    // differently); shifted batches (central-difference neighbours, rotosolve: 2 P or 3 tensors per row) only when small)
+    if ((kind == 0 || kind == 3) && n_params <= 64 && (nsh == 0 || B <= 512)) {
       const dim3 g2((unsigned)(B * 2)), b2(256);
       if (kind == 0) hipLaunchKernelGGL((ansatz_tensor_wave_d16_kernel<0>), g2, b2, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h, active);
       else hipLaunchKernelGGL((ansatz_tensor_wave_d16_kernel<3>), g2, b2, 0, st, params, n_params, (double2*)A, B, nsh, i_ptr, fd_h, active);

@@ -502,11 +502,12 @@ def test_lockstep_groups_are_the_same_trajectories(D, P, T, K, engine_factory):
     assert [many.evolve_groups(t) for t in (1, 256, 511, 512, 1024, 4096)] == [1, 1, 1, 2, 4, 4]
 
 
-def test_lockstep_groups_automatic_at_full_size(engine_factory):
-    """From 512 trajectories on qmps_evolve_bfgs groups by itself (here D = 8, 600 trajectories: two groups of 300): the same
-    evolution as one lock-step over all 600, and every trajectory ends at its minimum."""
+@pytest.mark.parametrize('D,P,T', [(8, 6, 600), (16, 8, 520)])
+def test_lockstep_groups_automatic_at_full_size(D, P, T, engine_factory):
+    """From 512 trajectories on qmps_evolve_bfgs groups by itself (two groups here): the same evolution, bit for bit, as one
+    lock-step over all of them (D = 16: 520 iterates in one launch and 260 in another go through the same tensor builder - a
+    trajectory's numbers must not depend on how many others share its launch), and every trajectory ends at its minimum."""
     from qmps_amd import _lib
-    D, P, T = 8, 6, 600
     rng = np.random.default_rng(2024)
     WW = WW_of(0.05)
     X0 = rng.standard_normal((T, P))

@@ -523,6 +523,37 @@ def test_lockstep_groups_automatic_at_full_size(D, P, T, engine_factory):
     one.set_evolve_groups(0)
 
 
+def test_lockstep_groups_edge_cases(engine_factory):
+    """More groups than trajectories (one trajectory per group), two trajectories in two groups, a single trajectory (never
+    grouped), history pointers left out: the grouped call behaves like the plain one."""
+    from qmps_amd import _lib
+    D, P = 8, 6
+    rng = np.random.default_rng(99)
+    WW = WW_of(0.05)
+    kind = _lib.ANSATZ_SHALLOW_CNOT
+    many, one = engine_factory(D, 5 * (2 * P + 1)), engine_factory(D, 5 * (2 * P + 1) + 1)
+    one.set_evolve_groups(1)
+    for T, K, expect in ((5, 16, 5), (2, 2, 2), (1, 4, 1)):
+        X0 = rng.standard_normal((T, P))
+        many.set_evolve_groups(K)
+        assert many.evolve_groups(T) == expect
+        a = many.evolve_bfgs(kind, X0, WW, n_steps=2, maxiter=30, tol=1e-13)
+        b = one.evolve_bfgs(kind, X0, WW, n_steps=2, maxiter=30, tol=1e-13)
+        assert np.array_equal(a['x'], b['x']) and np.array_equal(a['fun'], b['fun']) and np.array_equal(a['nit'], b['nit'])
+        # counters and histories are optional at the C level
+        lib, ctx = many._lib, many._ctx
+        Pm = np.array(X0, dtype=np.float64, order='C', copy=True)
+        fh = np.empty((2, 2, T))
+        al = np.array([1.0, 0.5, 0.25])
+        import ctypes
+        dp = lambda v: v.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        rc = lib.qmps_evolve_bfgs(ctx, T, kind, P, dp(Pm), dp(np.ascontiguousarray(WW).view(np.float64)), 2, 30, 1e-5, 1e-6, 1e-4, 3, dp(al), 0, 100000, 1e-13,
+                                  None, None, dp(fh), None, None)
+        assert rc == 0 and np.all(np.isfinite(fh)) and np.all(fh[:, 1] <= fh[:, 0] + 1e-12)
+    many.set_evolve_groups(0)
+    one.set_evolve_groups(0)
+
+
 def test_native_bfgs_driver_argument_checks_and_single_rung(engine_factory):
     """Refusals of qmps_evolve_bfgs (batch larger than the context, a warm continuation without resident fixed points)
     and the ladder-free variant (one step length: a rejected full step ends the trajectory's minimisation)."""

@@ -20,17 +20,13 @@
 
 #include "qmps_kernels.h"
 #include "qmps_device.h"
+#include "qmps_overlap_d4.h"     // cmma16_3m
 
 namespace qmps {
 
 namespace {
 
-__device__ __forceinline__ void cfma(double2 a, double2 b, double2& c) {   // c += a b
-  c.x = dfma(a.x, b.x, c.x);
-  c.x = dfma(-a.y, b.y, c.x);
-  c.y = dfma(a.x, b.y, c.y);
-  c.y = dfma(a.y, b.x, c.y);
-}
+// (cfma: c += a b - qmps_overlap_d4.h)
 __device__ __forceinline__ void cfma_conj1(double2 a, double2 b, double2& c) {   // c += conj(a) b
   c.x = dfma(a.x, b.x, c.x);
   c.x = dfma(a.y, b.y, c.x);
@@ -184,52 +180,49 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_probe_kerne
   }
 }
 
-// D = 16: ONE WAVE per neighbour, a 2 x 2 register tile per lane (lane = 8 i2 + j2 owns rows 2 i2, 2 i2 + 1 x columns 2 j2, 2 j2 + 1):
-// half the LDS reads per complex multiply-add of the one-thread-per-element kernel above, and no workgroup barrier
-// (32 768 neighbours of 2 048 iterates: 150 -> 126 us; it is then bound by the issue of its 1 024 multiply-adds per lane).
-// Tried and dropped: neighbours LINEARISED around the iterate (<y, T'(r)> = <y, T(r)> + sum_s <B'_s - B_s, M_s>, M once per
+// D = 16: ONE WAVE per neighbour on the matrix cores (round 4).  merge(B', B')_s = B'_s1 B'_s2 are four complex 16 x 16 x 16 products:
+// 48 v_mfma_f64_16x16x4 in the three-product form (qmps_overlap_d4.h), operands loaded from HBM straight into the A- and
+// B-layouts, the products left in the accumulator layout and contracted there with G_s (read in the same layout) - no LDS at all.
+// The round-3 kernel did the products on the vector pipe from an LDS copy (2 x 2 register tile per lane, 1 024 complex
+// multiply-adds per lane): 20.1 -> 18.4 us for the 4 352 probes of 256 iterates - the kernel is bound by the 35 MB of neighbour
+// tensors it streams in (and 70 MB of G from L2), not by its arithmetic: 2 TB/s + the latency of a lone wave's loads.
+// Tried and dropped in round 3: neighbours LINEARISED around the iterate (<y, T'(r)> = <y, T(r)> + sum_s <B'_s - B_s, M_s>, M once per
 // iterate; the even orders cancel in the central difference) - an elementwise contraction per neighbour, but it reads three
 // tiles per neighbour (B', B, M: memory-bound, 80 us) and the eight extra products for M cost the G kernel 50 us: slower in sum.
 __global__ __launch_bounds__(64) void overlap_probe_d16_kernel(OverlapGradArgs p) {
-  constexpr int D = 16, N = 256, P = 17;
-  __shared__ double2 sB[2][D][P];
-  const int lane = threadIdx.x, i2 = lane >> 3, j2 = lane & 7;
+  constexpr int D = 16, N = 256;
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int64_t b = blockIdx.x, nn = p.T * p.G2P;
   const bool centre = b >= nn;                      // (with p.Bc set the launch carries T more items: the iterates themselves)
   const int64_t t = centre ? b - nn : b / p.G2P;
   if (p.active != nullptr && p.active[t] == 0) return;
-  {
-    const double2* Bp = centre ? (const double2*)p.Bc + t * (2 * N) : (const double2*)p.Bt + b * (2 * N);
+  const double2* Bp = centre ? (const double2*)p.Bc + t * (2 * N) : (const double2*)p.Bt + b * (2 * N);
+  double par[2][4], pai[2][4];      // B'_s in A-layout: lane (g, c) holds B'_s[c][4 kk + g]
+  v4f64 qbr[2], qbi[2];             // B'_s in B-layout: lane (g, c) holds B'_s[4 kk + g][c]
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int l = lane + 64 * u, s = l >> 8, e = l & 255;
-      sB[s][e >> 4][e & 15] = Bp[l];
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const double2 va = Bp[(s * D + c) * D + 4 * kk + g], vb = Bp[(s * D + 4 * kk + g) * D + c];
+      par[s][kk] = va.x;
+      pai[s][kk] = va.y;
+      qbr[s][kk] = vb.x;
+      qbi[s][kk] = vb.y;
     }
-  }
-  __builtin_amdgcn_wave_barrier();
   const double2* Gp = (const double2*)p.G + t * (4 * N);
   double nr = 0.0, ni = 0.0;
 #pragma unroll
   for (int s1 = 0; s1 < 2; ++s1)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      double2 acc[2][2] = {{make_double2(0.0, 0.0), make_double2(0.0, 0.0)}, {make_double2(0.0, 0.0), make_double2(0.0, 0.0)}};
+      v4f64 mr = {0, 0, 0, 0}, mi = {0, 0, 0, 0};
+      cmma16_3m(par[s1], pai[s1], qbr[s2], qbi[s2], mr, mi);       // Bm'_s in the accumulator layout: register q, lane (g, c) = element [4 q + g][c]
 #pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const double2 a0 = sB[s1][2 * i2][k], a1 = sB[s1][2 * i2 + 1][k], b0 = sB[s2][k][2 * j2], b1 = sB[s2][k][2 * j2 + 1];
-        cfma(a0, b0, acc[0][0]);
-        cfma(a0, b1, acc[0][1]);
-        cfma(a1, b0, acc[1][0]);
-        cfma(a1, b1, acc[1][1]);
+      for (int q = 0; q < 4; ++q) {
+        const double2 gv = Gp[(2 * s1 + s2) * N + (4 * q + g) * D + c];
+        nr = dfma(mr[q], gv.x, dfma(mi[q], gv.y, nr));       // conj(bm) g
+        ni = dfma(mr[q], gv.y, dfma(-mi[q], gv.x, ni));
       }
-#pragma unroll
-      for (int di = 0; di < 2; ++di)
-#pragma unroll
-        for (int dj = 0; dj < 2; ++dj) {
-          const double2 g = Gp[(2 * s1 + s2) * N + (2 * i2 + di) * D + 2 * j2 + dj], bm = acc[di][dj];
-          nr = dfma(bm.x, g.x, dfma(bm.y, g.y, nr));       // conj(bm) g
-          ni = dfma(bm.x, g.y, dfma(-bm.y, g.x, ni));
-        }
     }
   nr = wave_sum(nr);
   ni = wave_sum(ni);

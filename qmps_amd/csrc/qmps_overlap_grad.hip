@@ -136,6 +136,85 @@ __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_g_kernel(Ov
   if (l == 0 && t < p.T && !(p.active != nullptr && p.active[t] == 0)) ((double2*)p.yr)[t] = make_double2(a, b);
 }
 
+// D = 16: the same on the matrix cores, FOUR WAVES per trajectory (round 4): wave w = (t1, t2) forms A_t1 A_t2 (published through
+// LDS), then C_w = sum_t WW[w][t] A A_t, Z_w = C_w r and G_w = y^+ Z_w - three complex 16 x 16 x 16 products per wave, operands
+// loaded from HBM in the MFMA layouts (the set-up of overlap_mfma_d16x4_body, qmps_overlap.hip, does the first half the same way).
+// The generic kernel above (a thread per matrix element, three LDS stages) took 9.5 us for 256 trajectories on the critical path of a
+// gradient batch (solves -> G -> probes).
+__global__ __launch_bounds__(256) void overlap_g_d16_kernel(OverlapGradArgs p) {
+  constexpr int D = 16, N = 256, LD = 17;
+  __shared__ double2 sX[4][N];            // exchange: one accumulator-layout matrix per wave, element (q, lane) at [q * 64 + lane]
+  __shared__ double2 sT[4][D * LD];       // wave-private transposes
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int64_t t = blockIdx.x;
+  if (p.active != nullptr && p.active[t] == 0) return;      // skipped trajectory (uniform over the workgroup)
+  const double2* Ap = (const double2*)p.A + t * (2 * N);
+  const int t1 = wave >> 1, t2 = wave & 1;
+  v4f64 zr = {0, 0, 0, 0}, zi = {0, 0, 0, 0};
+  {
+    double pa[4], pai[4];
+    v4f64 qa, qai;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const double2 va = Ap[(t1 * D + c) * D + 4 * kk + g], wa = Ap[(t2 * D + 4 * kk + g) * D + c];
+      pa[kk] = va.x; pai[kk] = va.y;
+      qa[kk] = wa.x; qai[kk] = wa.y;
+    }
+    cmma16(pa, pai, qa, qai, zr, zi);       // A_t1 A_t2
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sX[wave][q * 64 + lane] = make_double2(zr[q], zi[q]);
+  // r in B-layout, y^+ in A-layout ((y^+)[c][4 kk + g] = conj(y[4 kk + g][c])): the same addresses
+  v4f64 rr, ri;
+  double yr_[4], yin[4];
+  double a = 0.0, b = 0.0;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const double2 rv = ((const double2*)p.r)[t * N + (4 * kk + g) * D + c], yv = ((const double2*)p.y)[t * N + (4 * kk + g) * D + c];
+    rr[kk] = rv.x; ri[kk] = rv.y;
+    yr_[kk] = yv.x; yin[kk] = -yv.y;
+    a = dfma(yv.x, rv.x, dfma(yv.y, rv.y, a));        // conj(y) r
+    b = dfma(yv.x, rv.y, dfma(-yv.y, rv.x, b));
+  }
+  __syncthreads();
+  v4f64 sr = {0, 0, 0, 0}, si = {0, 0, 0, 0};
+  {
+    const double2* W = (const double2*)p.WW;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const double2 w = W[wave * 4 + tt];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double2 v = sX[tt][q * 64 + lane];
+        sr[q] += w.x * v.x - w.y * v.y;
+        si[q] += w.x * v.y + w.y * v.x;
+      }
+    }
+  }
+  // C_w into the A-layout (padded transpose through the wave's own LDS tile)
+  double cre[4], cim[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sT[wave][(4 * q + g) * LD + c] = make_double2(sr[q], si[q]);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const double2 v = sT[wave][c * LD + 4 * kk + g];
+    cre[kk] = v.x;
+    cim[kk] = v.y;
+  }
+  v4f64 ur = {0, 0, 0, 0}, ui = {0, 0, 0, 0}, gr = {0, 0, 0, 0}, gi = {0, 0, 0, 0};
+  cmma16_3m(cre, cim, rr, ri, ur, ui);          // Z_w = C_w r
+  cmma16_3m(yr_, yin, ur, ui, gr, gi);          // G_w = y^+ Z_w
+  double2* Gp = (double2*)p.G + t * (4 * N) + wave * N;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) Gp[(4 * q + g) * D + c] = make_double2(gr[q], gi[q]);
+  if (wave == 0) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) ((double2*)p.yr)[t] = make_double2(a, b);
+  }
+}
+
 // eta' = sum_s tr(Bm'_s^+ G_s) / <y, r>,  f = -sqrt|eta'|  per central-difference neighbour
 template <int D>
 __global__ __launch_bounds__((D * D < 64) ? 64 : D * D) void overlap_probe_kernel(OverlapGradArgs p) {
@@ -239,7 +318,8 @@ __global__ __launch_bounds__(64) void overlap_probe_d16_kernel(OverlapGradArgs p
 template <int D>
 static hipError_t launch_grad_d(const OverlapGradArgs& a, hipStream_t st) {
   constexpr int N = D * D, THREADS = N < 64 ? 64 : N, ITEMS = THREADS / N;
-  hipLaunchKernelGGL((overlap_g_kernel<D>), dim3((unsigned)((a.T + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);
+  if constexpr (D == 16) hipLaunchKernelGGL(overlap_g_d16_kernel, dim3((unsigned)a.T), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((overlap_g_kernel<D>), dim3((unsigned)((a.T + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);
   const int64_t nb = a.T * a.G2P + (a.Bc != nullptr ? a.T : 0);      // neighbours (+ the iterates themselves: same launch)
   if constexpr (D == 16) hipLaunchKernelGGL(overlap_probe_d16_kernel, dim3((unsigned)nb), dim3(64), 0, st, a);
   else hipLaunchKernelGGL((overlap_probe_kernel<D>), dim3((unsigned)((nb + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);

@@ -390,6 +390,9 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
   const int tslot = (int)(c->samples % qmps_ctx::kRing);
   if (c->timed) HIP_TRY(hipEventRecord(c->kev0[tslot], c->stream));
+  // The Krylov fall-back of the two solves is launched only if a status asks for it (below): behind every batch, it cost a warm
+  // batch of 256 iterates - which never hands anything over - an empty launch and a launch gap, ~10 us of ~200.
+  bool lazy_krylov = false;
   // the left fixed points: power method on the adjoint map; results behind the iterates' (eta, rounds, status at [T, 2T))
   qmps::OverlapArgs l = a;
   l.adjoint = 1; l.eta = (char*)c->d_eta + (size_t)T * 16; l.f_out = nullptr; l.r_out = c->d_y; l.x_in = warm ? c->d_y : nullptr;
@@ -402,13 +405,15 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
     if (int e = arm_queue(c, l, 1)) return e;
     if (int e = arm_krylov(c, a, 0)) return e;
     if (int e = arm_krylov(c, l, 1)) return e;
-    HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream));
+    lazy_krylov = a.krylov_after > 0 && l.krylov_after > 0 && a.kry_counter != nullptr && l.kry_counter != nullptr;
+    HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream, !lazy_krylov));
   } else if (c->D == 8) {
     // D = 8: the same - one launch, the left solves on the SIMDs the right ones leave idle
     a.no_deflation = l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
     if (int e = arm_krylov(c, a, 0)) return e;
     if (int e = arm_krylov(c, l, 1)) return e;
-    HIP_TRY(qmps::launch_overlap_pair_d8(a, l, c->stream));
+    lazy_krylov = a.krylov_after > 0 && l.krylov_after > 0 && a.kry_counter != nullptr && l.kry_counter != nullptr;
+    HIP_TRY(qmps::launch_overlap_pair_d8(a, l, c->stream, !lazy_krylov));
   } else if (c->D == 4 && squaring) {
     // D = 4: largest column AND largest row of the squared map in one launch (right and left fixed point, whatever the gap)
     a.l_out = c->d_y;
@@ -450,6 +455,24 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   // hipStreamSynchronize - the wait shrinks by 7 us, the next submission grows by 11: no gain)
   HIP_TRY(qmps::launch_stage_copy2(c->d_f, fall, (int64_t)(fbytes / 8), c->d_status, st, (int64_t)(sbytes / 8), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (lazy_krylov) {
+    // a solve that stopped short (handed over by the power kernel, or at its cap): the fall-back kernel, then G and the probes of
+    // those trajectories once more (everything else keeps its values), then the read-back again
+    bool any = false;
+    for (int64_t t = 0; t < 2 * T && !any; ++t) any = st[t] == qmps::QMPS_ST_NOT_CONVERGED;
+    if (any) {
+      if (!c->d_active) HIP_TRY(hipMalloc((void**)&c->d_active, ((size_t)c->max_batch + 7) / 8 * 8));
+      unsigned char* fix = (unsigned char*)c->h_pin + (15u << 20);         // (the mask staging region: this call's own mask has been consumed)
+      for (int64_t t = 0; t < T; ++t) fix[t] = (st[t] == qmps::QMPS_ST_NOT_CONVERGED || st[T + t] == qmps::QMPS_ST_NOT_CONVERGED) ? 1 : 0;
+      for (int64_t t = T; t < (T + 7) / 8 * 8; ++t) fix[t] = 0;
+      HIP_TRY(qmps::launch_overlap_krylov_pair(c->D, a, l, c->stream));
+      HIP_TRY(qmps::launch_stage_copy(fix, c->d_active, (T + 7) / 8, c->stream));
+      g.active = c->d_active;
+      HIP_TRY(qmps::launch_overlap_grad(c->D, g, c->stream));
+      HIP_TRY(qmps::launch_stage_copy2(c->d_f, fall, (int64_t)(fbytes / 8), c->d_status, st, (int64_t)(sbytes / 8), c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+  }
   memcpy(f_out, fall, (size_t)T * sizeof(double));
   const double* fn = fall + T;
   for (int64_t t = 0; t < T; ++t) {

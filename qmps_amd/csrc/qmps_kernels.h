@@ -295,8 +295,9 @@ hipError_t launch_overlap_krylov_pair(int D, const OverlapArgs& right, const Ove
 // mfma: D = 16 on the matrix cores (one wave per evaluation) instead of the generic LDS-tile kernel
 hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st);
 // D = 16, at most 8192 evaluations in all: right fixed points (`right`) and left fixed points (`left`, adjoint map) in ONE launch, four waves per evaluation
-hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st);
-hipError_t launch_overlap_pair_d8(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st);
+// (krylov_now = false: the caller launches the fall-back itself - launch_overlap_krylov_pair - if and when a status asks for it)
+hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st, bool krylov_now = true);
+hipError_t launch_overlap_pair_d8(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st, bool krylov_now = true);
 // brick-wall (new_tdvp) contractions: what = 0 two-site <O>, 1 four-site <O>, 2 environment matrix + eigenpair, 3 manifold overlap
 struct BwArgs {
   const void *U1, *U2, *U1p, *U2p;   // [B][4][4] complex

@@ -861,21 +861,21 @@ static hipError_t launch_krylov_after(int D, const OverlapArgs& a, const Overlap
   return hipSuccess;
 }
 
-hipError_t launch_overlap_pair_d8(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st) {
+hipError_t launch_overlap_pair_d8(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st, bool krylov_now) {
   if (right.B <= 0) return hipSuccess;
   hipLaunchKernelGGL((overlap_block_pair_kernel<8>), dim3((unsigned)(right.B + left.B)), dim3(64), 0, st, right, left, (int)right.B);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-  return launch_krylov_after(8, right, &left, st);
+  return krylov_now ? launch_krylov_after(8, right, &left, st) : hipSuccess;
 }
 
-hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st) {
+hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st, bool krylov_now) {
   if (right.B <= 0) return hipSuccess;
   const int nr = (int)(right.B < 2048 ? right.B : 2048), nl = (int)(left.B < 2048 ? left.B : 2048);
   // (deflation steps for cold starts only, see overlap_mfma_d16x4_body)
   if (right.x_in == nullptr && right.no_deflation == 0) hipLaunchKernelGGL(overlap_mfma_d16x4_pair_kernel<true>, dim3((unsigned)(nr + nl)), dim3(256), 0, st, right, left, nr);
   else hipLaunchKernelGGL(overlap_mfma_d16x4_pair_kernel<false>, dim3((unsigned)(nr + nl)), dim3(256), 0, st, right, left, nr);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-  return launch_krylov_after(16, right, &left, st);
+  return krylov_now ? launch_krylov_after(16, right, &left, st) : hipSuccess;
 }
 
 hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st) {

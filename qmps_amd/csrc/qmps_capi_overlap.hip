@@ -143,6 +143,8 @@ int qmps_overlap_set_active(qmps_ctx* c, int64_t n, const unsigned char* active)
   if (n < 0 || n > c->max_batch) return fail(QMPS_ERR_ARG, "n=%lld outside [0, max_batch]", (long long)n);
   if (n == 0 || !active) {
     c->active_n = 0;
+    c->mask_stash_n = 0;
+    c->mask_host = nullptr;
     return QMPS_OK;
   }
   if (!c->d_active) HIP_TRY(hipMalloc((void**)&c->d_active, ((size_t)c->max_batch + 7) / 8 * 8));      // (copied in whole 8-byte words)
@@ -156,6 +158,7 @@ int qmps_overlap_set_active(qmps_ctx* c, int64_t n, const unsigned char* active)
   memset(stage + n, 1, (size_t)((8 - n % 8) % 8));
   if (c->stash_masks && !c->capturing) {       // (the driver synchronises after every batch: no copy of an earlier mask is in flight)
     c->mask_stash = stage;
+    c->mask_host = stage;
     c->mask_stash_n = n;
     c->active_n = n;
     return QMPS_OK;
@@ -173,7 +176,7 @@ QMPS_API_CATCH
 
 int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int flags) try {
   if (int rc = bind(c)) return rc;
-  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; c->mask_stash_n = 0; c->fork_after_copy = nullptr; c->warm_from_group = 0; } } disarm{c};      // the mask of qmps_overlap_set_active is ONE-SHOT: spent on every way out
+  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; c->mask_stash_n = 0; c->mask_host = nullptr; c->fork_after_copy = nullptr; c->warm_from_group = 0; } } disarm{c};      // the mask of qmps_overlap_set_active is ONE-SHOT: spent on every way out
   if (int rc = check_window(c, B)) return rc;
   if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
   if (c->overlap_refs < 1) return fail(QMPS_ERR_STATE, "qmps_overlap_set has not been called");
@@ -329,7 +332,7 @@ QMPS_API_CATCH
 int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const double* params, double h, int max_rounds, double tol,
                           int flags, double* f_out, double* g_out, int32_t* status_out) try {
   if (int rc = bind(c)) return rc;
-  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; c->mask_stash_n = 0; c->fork_after_copy = nullptr; c->warm_from_group = 0; } } disarm{c};      // (one-shot mask: spent on every way out)
+  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; c->mask_stash_n = 0; c->mask_host = nullptr; c->fork_after_copy = nullptr; c->warm_from_group = 0; } } disarm{c};      // (one-shot mask: spent on every way out)
   if (!params || !f_out || !g_out) return fail(QMPS_ERR_ARG, "null argument");
   if (c->D < 4) return fail(QMPS_ERR_ARG, "qmps_overlap_gradient: D = 4, 8, 16 (at D = 2 evaluate the central-difference neighbours themselves)");
   if (flags & ~(QMPS_OVERLAP_WARM | QMPS_OVERLAP_TWO_SIDED_F)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
@@ -458,12 +461,17 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   if (lazy_krylov) {
     // a solve that stopped short (handed over by the power kernel, or at its cap): the fall-back kernel, then G and the probes of
     // those trajectories once more (everything else keeps its values), then the read-back again
+    // (skipped trajectories keep the statuses of earlier launches: they do not count)
+    const unsigned char* hm = mask != nullptr ? c->mask_host : nullptr;
     bool any = false;
-    for (int64_t t = 0; t < 2 * T && !any; ++t) any = st[t] == qmps::QMPS_ST_NOT_CONVERGED;
+    for (int64_t t = 0; t < T && !any; ++t)
+      any = (mask == nullptr || hm == nullptr || hm[t] != 0) && (st[t] == qmps::QMPS_ST_NOT_CONVERGED || st[T + t] == qmps::QMPS_ST_NOT_CONVERGED);
     if (any) {
       if (!c->d_active) HIP_TRY(hipMalloc((void**)&c->d_active, ((size_t)c->max_batch + 7) / 8 * 8));
       unsigned char* fix = (unsigned char*)c->h_pin + (15u << 20);         // (the mask staging region: this call's own mask has been consumed)
-      for (int64_t t = 0; t < T; ++t) fix[t] = (st[t] == qmps::QMPS_ST_NOT_CONVERGED || st[T + t] == qmps::QMPS_ST_NOT_CONVERGED) ? 1 : 0;
+      std::vector<unsigned char> was(T, 1);
+      if (hm != nullptr) was.assign(hm, hm + T);        // (fix may alias the staging slot hm points into)
+      for (int64_t t = 0; t < T; ++t) fix[t] = (was[t] != 0 && (st[t] == qmps::QMPS_ST_NOT_CONVERGED || st[T + t] == qmps::QMPS_ST_NOT_CONVERGED)) ? 1 : 0;
       for (int64_t t = T; t < (T + 7) / 8 * 8; ++t) fix[t] = 0;
       HIP_TRY(qmps::launch_overlap_krylov_pair(c->D, a, l, c->stream));
       HIP_TRY(qmps::launch_stage_copy(fix, c->d_active, (T + 7) / 8, c->stream));

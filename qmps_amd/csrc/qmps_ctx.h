@@ -91,6 +91,7 @@ struct qmps_ctx {
   bool stash_masks = false;            //   the evolve drivers (one synchronisation per batch): the mask waits in its staging slot and rides
   int64_t mask_stash_n = 0;            //   with the NEXT parameter upload of qmps_set_states_ansatz - one copy kernel instead of two
   const unsigned char* mask_stash = nullptr;
+  const unsigned char* mask_host = nullptr;   //   the host copy of the mask the next launch consumes (stash mode; cleared with it)
   hipEvent_t fork_after_copy = nullptr;   // one-shot: qmps_set_states_ansatz records it between the parameter upload and the tensor build
   int* d_queue = nullptr;      // overlap kernels: counters the workgroups draw their evaluations from (qmps_create; [0, 1] D = 16 queue kernels, [2, 8) Krylov fall-back of the overlap solves: two sets of three, [8, 13) of the D = 16 environment)
   void* d_kry = nullptr;       // D = 8, 16: iterates handed from the power kernels to the Krylov fall-back when the caller keeps no fixed points [max_batch][D][D]

@@ -107,11 +107,25 @@ int qmps_overlap_set_refs_ansatz(qmps_ctx* c, int64_t n_ref, int kind, int n_par
   if (int rc = check_ansatz(c, kind, n_params)) return rc;
   if (int rc = ensure_refs(c, n_ref)) return rc;
   // parameter rows through the scratch arena, tensors built on the device straight into the reference buffer
-  if (int rc = ensure_scratch(c, (size_t)n_ref * n_params * sizeof(double))) return rc;
-  HIP_TRY(hipMemcpyAsync(c->d_scratch, params, (size_t)n_ref * n_params * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(qmps::launch_ansatz(c->D, kind, (const double*)c->d_scratch, n_params, c->d_ref, n_ref, c->stream));
-  if (int rc = set_ww(c, WW)) return rc;
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t pb = (size_t)n_ref * n_params * sizeof(double);
+  if (int rc = ensure_scratch(c, pb)) return rc;
+  if (pb <= (3u << 20) - 256 && !c->capturing) {
+    // parameters and W through pinned staging (its fourth quarter), moved by ONE kernel on the context stream: two hipMemcpyAsync from
+    // pageable memory cost a time step of 256 trajectories ~30 us of copy-queue hops (rocprofv3 kernel trace), 4 % of it
+    if (int rc = ensure_pinned(c, (16u << 20))) return rc;
+    if (!c->d_ww) HIP_TRY(hipMalloc(&c->d_ww, 256));
+    char* stage = c->h_pin + (12u << 20);
+    memcpy(stage, params, pb);
+    memcpy(stage + (3u << 20) - 256, WW, 256);
+    HIP_TRY(qmps::launch_stage_copy2(stage, c->d_scratch, (int64_t)(pb / 8), stage + (3u << 20) - 256, c->d_ww, 32, c->stream));
+    HIP_TRY(qmps::launch_ansatz(c->D, kind, (const double*)c->d_scratch, n_params, c->d_ref, n_ref, c->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(c->d_scratch, params, pb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(qmps::launch_ansatz(c->D, kind, (const double*)c->d_scratch, n_params, c->d_ref, n_ref, c->stream));
+    if (int rc = set_ww(c, WW)) return rc;
+  }
+  // (the evolve drivers go straight on to a gradient batch on the same stream: they synchronise there)
+  if (!c->defer_sync) HIP_TRY(hipStreamSynchronize(c->stream));
   c->overlap_refs = n_ref;
   c->overlap_group = 0;
   return QMPS_OK;
@@ -599,7 +613,10 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   int rc = QMPS_OK;
   for (int step = 0; step < n_steps && rc == QMPS_OK; ++step) {
     // the step's references: A_t = tensor(current parameters)
-    if ((rc = qmps_overlap_set_refs_ansatz(c, T, kind, P, X.data(), WW))) break;
+    {
+      Restore<bool> deferred(c->defer_sync, true);
+      if ((rc = qmps_overlap_set_refs_ansatz(c, T, kind, P, X.data(), WW))) break;
+    }
     if (!(carry && (step > 0 || (warm && hinv))))
       for (int64_t t = 0; t < T; ++t) set_identity(t);
     if ((rc = value_and_grad(X.data(), f.data(), g.data(), nullptr))) break;

@@ -7,8 +7,9 @@ import bench
 from qmps_amd import EnergyEngine, _lib
 WW = expm(-1j * 0.05 * bench.tfim_h(1.0))
 bad = 0
+SC = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 worst = [0.0, 0.0]
-for D, P, T, K, calls in ((8, 6, 600, 4, 25), (16, 8, 520, 3, 15), (16, 8, 300, 3, 10), (4, 4, 700, 5, 10)):
+for D, P, T, K, calls in ((8, 6, 600, 4, 25 * SC), (16, 8, 520, 3, 15 * SC), (16, 8, 1024, 4, 10 * SC), (4, 4, 700, 5, 10 * SC)):
     bad = 0
     X0 = np.random.default_rng(D).standard_normal((T, P))
     with EnergyEngine(D, T * (2 * P + 1)) as many, EnergyEngine(D, T * (2 * P + 1)) as one:

@@ -39,6 +39,7 @@ extern "C" {
 #endif
 
 #define QMPS_ABI_VERSION 6
+#define QMPS_ABI_MINOR 1
 
 /* error codes */
 #define QMPS_OK 0
@@ -144,6 +145,9 @@ typedef struct qmps_ctx qmps_ctx;
 
 /* ---- library / device ------------------------------------------------------------------ */
 int qmps_abi_version(void);
+/* additions that keep every existing signature (new entry points, new flag bits): bumps QMPS_ABI_MINOR only.
+ * 6.1: qmps_set_roto_rule / qmps_get_roto_rule, qmps_abi_minor. */
+int qmps_abi_minor(void);
 const char* qmps_last_error(void);
 /* Test hook for the contract above ("nothing throws across the ABI"): raises a C++ exception inside the library - kind 1
  * std::bad_alloc, 2 std::length_error (a vector of absurd size), 3 a foreign type - behind the same function-try-block every entry
@@ -211,11 +215,22 @@ int qmps_rotosolve(qmps_ctx* ctx, int64_t R, int kind, int n_params, double* par
                    double tol, double* E_hist);
 /* Device-resident DOUBLE-frequency rotosolve (qmps/tools.py:422-457, what Optimizer.optimize('Rotosolve') runs): per
  * parameter ONE batch of 6 R evaluations (shifts 0, pi, +-pi/2, +-pi/4), the fit P sin(2x + u) + Q sin(x + v)
- * (tools.py:440-447) and its GLOBAL minimiser on [-pi, pi) (the reference hands the fit to scipy's minimize_scalar,
- * tools.py:451, which returns a local minimiser to 1e-5; grid + bisection + Newton here), all on the device.  The
- * wrapped minimiser is added to the parameter, which is not re-wrapped (tools.py:453-454).  Needs 6 R <= max_batch. */
+ * (tools.py:440-447) and the minimiser the reference's `minimize_scalar(f, bounds=[-pi, pi])` (tools.py:451) returns for it,
+ * all on the device: scipy's 'bounded' method, i.e. Brent's golden-section / parabolic search (xatol 1e-5, first point
+ * -pi + (3 - sqrt 5) pi), restated step for step (qmps_roto_math.h) - a LOCAL minimiser of the fit, and the one the
+ * reference's trajectory follows.  The minimiser is added to the parameter, which is not re-wrapped (tools.py:453-454).
+ * Needs 6 R <= max_batch. */
 int qmps_double_rotosolve(qmps_ctx* ctx, int64_t R, int kind, int n_params, double* params, int n_sweeps, int max_iter,
                           double tol, double* E_hist);
+/* Update rule of the double-frequency drivers (qmps_double_rotosolve, qmps_evolve_rotosolve with 6 shifts):
+ *   QMPS_ROTO_REFERENCE      (default) the reference's bounded scalar search, see above;
+ *   QMPS_ROTO_GLOBAL_ARGMIN  the GLOBAL minimiser of the fitted curve on [-pi, pi) (32-point grid + bisection + Newton).
+ *                            Departs from qmps/tools.py:451: never worse on the fitted curve, but a different parameter
+ *                            trajectory (in the reference-run fixtures 13 % of the updates differ). */
+#define QMPS_ROTO_REFERENCE 0
+#define QMPS_ROTO_GLOBAL_ARGMIN 1
+int qmps_set_roto_rule(qmps_ctx* ctx, int rule);
+int qmps_get_roto_rule(qmps_ctx* ctx, int* rule);
 /* read back the resident state tensors A[B][2][D][D] (tests / debugging) */
 int qmps_get_states(qmps_ctx* ctx, int64_t B, double* A);
 /* h[n_terms][4][4] complex128, row/col index = 2*s1+s2, s1 = left site

@@ -584,6 +584,87 @@ def double_rotosolve_update(M0, Mpi, Mp2, Mm2, Mp4, Mm4):
     return float(np.arctan2(np.sin(th), np.cos(th)))
 
 
+def fminbound(f, x1, x2, xatol=1e-5, maxfun=500):
+    """Bounded scalar minimiser the reference's `minimize_scalar(f, bounds=[-pi, pi])` (tools.py:451, rotosolve.py:237)
+    resolves to: with `bounds` given and no `method`, scipy (1.15.3 here; behaviour since 1.9... of the container the
+    reference-run fixtures were made in) dispatches to its 'bounded' method, which is Brent's `fmin` as published in Forsythe,
+    Malcolm & Moler, "Computer Methods for Mathematical Computations" (1977), ch. 8 (MATLAB's fminbnd): golden-section steps
+    with parabolic interpolation through the three best points whenever the parabola's vertex falls inside the bracket and
+    the step is less than half the one before last.  Restated from that publication with scipy's defaults (xatol = 1e-5,
+    at most 500 evaluations, first point a + (3 - sqrt 5)/2 (b - a)); third-party code, not part of /root/reference -
+    pinned by the recorded calls `refshim_roto_fits` of tests/golden (same x to 1e-12, same evaluation count).
+    Returns (x, f(x), number of evaluations)."""
+    sqrt_eps = np.sqrt(2.2e-16)
+    gm = 0.5 * (3.0 - np.sqrt(5.0))
+    a, b = float(x1), float(x2)
+    fulc = a + gm * (b - a)
+    nfc, xf = fulc, fulc
+    rat = e = 0.0
+    fx = f(xf)
+    num = 1
+    ffulc = fnfc = fx
+    xm = 0.5 * (a + b)
+    tol1 = sqrt_eps * abs(xf) + xatol / 3.0
+    tol2 = 2.0 * tol1
+    while abs(xf - xm) > (tol2 - 0.5 * (b - a)):
+        golden = True
+        if abs(e) > tol1:                                   # try the parabola through (fulc, nfc, xf)
+            golden = False
+            r = (xf - nfc) * (fx - ffulc)
+            q = (xf - fulc) * (fx - fnfc)
+            p = (xf - fulc) * q - (xf - nfc) * r
+            q = 2.0 * (q - r)
+            if q > 0.0:
+                p = -p
+            q = abs(q)
+            r = e
+            e = rat
+            if abs(p) < abs(0.5 * q * r) and p > q * (a - xf) and p < q * (b - xf):
+                rat = p / q
+                x = xf + rat
+                if (x - a) < tol2 or (b - x) < tol2:        # too close to an end of the bracket: a minimal step towards the middle
+                    rat = tol1 if xm >= xf else -tol1
+            else:
+                golden = True
+        if golden:
+            e = (a - xf) if xf >= xm else (b - xf)
+            rat = gm * e
+        x = xf + (1.0 if rat >= 0 else -1.0) * max(abs(rat), tol1)
+        fu = f(x)
+        num += 1
+        if fu <= fx:
+            if x >= xf:
+                a = xf
+            else:
+                b = xf
+            fulc, ffulc = nfc, fnfc
+            nfc, fnfc = xf, fx
+            xf, fx = x, fu
+        else:
+            if x < xf:
+                a = x
+            else:
+                b = x
+            if fu <= fnfc or nfc == xf:
+                fulc, ffulc = nfc, fnfc
+                nfc, fnfc = x, fu
+            elif fu <= ffulc or fulc == xf or fulc == nfc:
+                fulc, ffulc = x, fu
+        xm = 0.5 * (a + b)
+        tol1 = sqrt_eps * abs(xf) + xatol / 3.0
+        tol2 = 2.0 * tol1
+        if num >= maxfun:
+            break
+    return xf, fx, num
+
+
+def double_sinusoid_fminbound(P, u, Q, v):
+    """The reference's update of the double-frequency rotosolve (tools.py:447-452): the wrapped LOCAL minimiser `fminbound`
+    finds for f(x) = P sin(2x + u) + Q sin(x + v) on [-pi, pi].  (`double_sinusoid_argmin` below is the GLOBAL one.)"""
+    th = fminbound(lambda x: P * np.sin(2 * x + u) + Q * np.sin(x + v), -np.pi, np.pi)[0]
+    return float(np.arctan2(np.sin(th), np.cos(th)))
+
+
 def double_sinusoid_coefficients(M0, Mpi, Mp2, Mm2, Mp4, Mm4):
     """(P, u, Q, v) of the fit P sin(2x + u) + Q sin(x + v) through the six samples (tools.py:434-447)."""
     A, Bv = (M0 + Mpi), (M0 - Mpi)

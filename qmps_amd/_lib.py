@@ -26,6 +26,7 @@ FLAG_ACCUMULATE_COST = 0x200
 FLAG_WARM_RESIDENT = 0x400
 OVERLAP_WANT_R, OVERLAP_WARM, OVERLAP_TWO_SIDED_F = 1, 2, 4
 BFGS_CARRY_HESSIAN, BFGS_WARM, BFGS_TIGHT_GRADIENT = 1, 2, 4
+ROTO_REFERENCE, ROTO_GLOBAL_ARGMIN = 0, 1
 UNIQUE_ID_BYTES = 128
 
 _dp = POINTER(c_double)
@@ -34,6 +35,7 @@ _ip = POINTER(c_int32)
 # name -> (restype, argtypes): every entry point declared in include/qmps_hip.h
 SIGNATURES = {
     'qmps_abi_version': (c_int, []),
+    'qmps_abi_minor': (c_int, []),
     'qmps_selftest_exception': (c_int, [c_int]),
     'qmps_last_error': (c_char_p, []),
     'qmps_device_count': (c_int, [POINTER(c_int)]),
@@ -49,6 +51,8 @@ SIGNATURES = {
     'qmps_cell2_energy_batch_su': (c_int, [c_void_p, c_int64, _dp, _dp, c_int, c_int, c_double, _dp, _ip, _ip]),
     'qmps_rotosolve': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, c_int, c_int, c_double, _dp]),
     'qmps_double_rotosolve': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, c_int, c_int, c_double, _dp]),
+    'qmps_set_roto_rule': (c_int, [c_void_p, c_int]),
+    'qmps_get_roto_rule': (c_int, [c_void_p, POINTER(c_int)]),
     'qmps_get_states': (c_int, [c_void_p, c_int64, _dp]),
     'qmps_set_hamiltonian': (c_int, [c_void_p, c_int, _dp]),
     'qmps_set_env_guess': (c_int, [c_void_p, c_int64, _dp]),

@@ -249,7 +249,7 @@ hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, vo
 // (wrap_pi, double_sinusoid_argmin: qmps_roto_math.h)
 __global__ __launch_bounds__(256) void roto_update_kernel(double* __restrict__ base, const double* __restrict__ E,
                                                           const int32_t* __restrict__ status, int R, int P,
-                                                          int* __restrict__ i_ptr, int n_terms, int nsh) {
+                                                          int* __restrict__ i_ptr, int n_terms, int nsh, int rule) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = *i_ptr;
   // the LAST workgroup to finish advances the parameter index for the next graph replay
@@ -271,10 +271,9 @@ __global__ __launch_bounds__(256) void roto_update_kernel(double* __restrict__ b
         // samples at {0, pi, +pi/2, -pi/2, +pi/4, -pi/4}: a, b, c, d -> P sin(2x + u) + Q sin(x + v)  (tools.py:434-447)
         const double A = e[0] + e[1], Bv = e[0] - e[1], C = e[2] + e[3], Dv = e[2] - e[3], Ev = e[4] - e[5];
         const double a = 0.25 * (2.0 * Ev - 1.4142135623730951 * Dv), b = 0.25 * (A - C), c = 0.5 * Dv, d = 0.5 * Bv;
-        theta = double_sinusoid_argmin(a, b, c, d);      // P sin(2x + u) = a sin 2x + b cos 2x,  Q sin(x + v) = c sin x + d cos x
+        theta = double_sinusoid_step(a, b, c, d, rule);  // P sin(2x + u) = a sin 2x + b cos 2x,  Q sin(x + v) = c sin x + d cos x; in [-pi, pi]
       }
-      // (the minimiser of the double-frequency fit already lies in [-pi - pi/16, pi): one conditional shift wraps it)
-      const double moved = base[(int64_t)r * P + i] + (nsh == 3 ? wrap_pi(theta) : (theta < -3.141592653589793 ? theta + 6.283185307179586 : (theta > 3.141592653589793 ? theta - 6.283185307179586 : theta)));
+      const double moved = base[(int64_t)r * P + i] + (nsh == 3 ? wrap_pi(theta) : theta);
       base[(int64_t)r * P + i] = nsh == 3 ? wrap_pi(moved) : moved;   // the double-frequency driver does not re-wrap (tools.py:453-454)
     }
   }
@@ -309,8 +308,8 @@ __global__ __launch_bounds__(256) void roto_record_kernel(const double* __restri
 }
 
 hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int* i_ptr, int n_terms,
-                              int nsh, hipStream_t st) {
-  hipLaunchKernelGGL(roto_update_kernel, dim3((R + 255) / 256), dim3(256), 0, st, base, E, status, R, P, i_ptr, n_terms, nsh);
+                              int nsh, int rule, hipStream_t st) {
+  hipLaunchKernelGGL(roto_update_kernel, dim3((R + 255) / 256), dim3(256), 0, st, base, E, status, R, P, i_ptr, n_terms, nsh, rule);
   return hipGetLastError();
 }
 hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, const int* sweep_ptr, int stride, hipStream_t st) {

@@ -203,6 +203,7 @@ int setup_accumulator(qmps_ctx* c, qmps::LaneArgs& a, int64_t B, int64_t adds, i
 extern "C" {
 
 int qmps_abi_version(void) { return QMPS_ABI_VERSION; }
+int qmps_abi_minor(void) { return QMPS_ABI_MINOR; }
 
 const char* qmps_last_error(void) { return g_err; }
 
@@ -608,7 +609,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
       memset(&ra, 0, sizeof(ra));
       ra.base = d_base; ra.h = c->d_h; ra.hist = d_hist;
       ra.R = (int)R; ra.P = n_params; ra.n_terms = c->n_terms; ra.n_sweeps = n_sweeps; ra.max_iter = max_iter;
-      ra.skip = c->skip_rounds; ra.tol = tol; ra.direct = c->default_solver == QMPS_ENV_DIRECT ? 1 : 0; ra.nsh = nsh;
+      ra.skip = c->skip_rounds; ra.tol = tol; ra.direct = c->default_solver == QMPS_ENV_DIRECT ? 1 : 0; ra.nsh = nsh; ra.rule = c->roto_rule;
       HIP_TRY(qmps::launch_rotosolve_fused_d2(kind, ra, c->stream));
       HIP_TRY(qmps::launch_ansatz(c->D, kind, d_base, n_params, c->d_A, R, c->stream));
       c->n_states = R; c->ans_have = false; c->tensors_valid = true;
@@ -628,7 +629,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
       memset(&ra, 0, sizeof(ra));
       ra.base = d_base; ra.h = c->d_h; ra.hist = d_hist;
       ra.R = (int)R; ra.P = n_params; ra.n_terms = c->n_terms; ra.n_sweeps = n_sweeps; ra.max_iter = max_iter;
-      ra.tol = tol; ra.direct = 1; ra.nsh = nsh;
+      ra.tol = tol; ra.direct = 1; ra.nsh = nsh; ra.rule = c->roto_rule;
 #ifdef QMPS_D8_PROFILE
       auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
       const double h0 = now();
@@ -672,7 +673,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
       if (int e = evaluate(nsh)) return e;
       // the shift-0 row of a sweep's first batch is the evaluation of the vectors the PREVIOUS sweep left: its record
       if (first_of_sweep) HIP_TRY(qmps::launch_roto_record(c->d_E, d_hist, (int)R, c->n_terms, d_idx + 2, nsh, c->stream));
-      HIP_TRY(qmps::launch_roto_update(d_base, c->d_E, c->d_status, (int)R, n_params, d_idx, c->n_terms, nsh, c->stream));
+      HIP_TRY(qmps::launch_roto_update(d_base, c->d_E, c->d_status, (int)R, n_params, d_idx, c->n_terms, nsh, c->roto_rule, c->stream));
       return QMPS_OK;
     };
     // One sweep = n_params updates (the first one also records the previous sweep from its shift-0 rows).  The parameter index and the
@@ -687,7 +688,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     if (use_graph) {
       qmps_ctx::RotoKey key;
       key.R = R; key.kind = kind; key.P = n_params; key.nsh = nsh; key.max_iter = max_iter; key.n_terms = c->n_terms;
-      key.solver = c->default_solver; key.handoff = c->handoff; key.tol = tol; key.fused = fused;
+      key.solver = c->default_solver; key.handoff = c->handoff; key.rule = c->roto_rule; key.tol = tol; key.fused = fused;
       key.base = d_base; key.hist = d_hist; key.params = c->d_params; key.E = c->d_E;
       if (!(c->roto_exec && key == c->roto_key)) {
         if (c->roto_exec) (void)hipGraphExecDestroy(c->roto_exec);
@@ -1003,6 +1004,21 @@ int qmps_set_default_solver(qmps_ctx* c, int solver) try {
   if (solver != QMPS_ENV_POWER && solver != QMPS_ENV_POWER_SQUARING && solver != QMPS_ENV_DIRECT)
     return fail(QMPS_ERR_ARG, "unknown solver %d", solver);
   c->default_solver = solver;
+  return QMPS_OK;
+}
+QMPS_API_CATCH
+
+int qmps_set_roto_rule(qmps_ctx* c, int rule) try {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  if (rule != QMPS_ROTO_REFERENCE && rule != QMPS_ROTO_GLOBAL_ARGMIN) return fail(QMPS_ERR_ARG, "unknown rotosolve rule %d", rule);
+  c->roto_rule = rule;
+  return QMPS_OK;
+}
+QMPS_API_CATCH
+
+int qmps_get_roto_rule(qmps_ctx* c, int* rule) try {
+  if (!c || !rule) return fail(QMPS_ERR_ARG, "null argument");
+  *rule = c->roto_rule;
   return QMPS_OK;
 }
 QMPS_API_CATCH

@@ -1011,7 +1011,7 @@ int qmps_evolve_rotosolve(qmps_ctx* c, int64_t T, int kind, int n_params, double
     auto one_sweep = [&]() -> int {
       for (int i = 0; i < P; ++i) {
         if (int e = evaluate(nsh)) return e;
-        HIP_TRY(qmps::launch_roto_update(d_base, c->d_E, c->d_status, (int)T, P, d_idx, 1, nsh, c->stream));
+        HIP_TRY(qmps::launch_roto_update(d_base, c->d_E, c->d_status, (int)T, P, d_idx, 1, nsh, c->roto_rule, c->stream));
       }
       // the sweep's record: the objective of the updated vectors against this time step's reference states
       if (int e = evaluate(0)) return e;

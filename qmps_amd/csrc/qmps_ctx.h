@@ -125,6 +125,7 @@ struct qmps_ctx {
   int32_t* d_work_idx = nullptr;    // [max_batch]
   int handoff = 0;                  // plain power steps before the squaring tail (set in qmps_create)
   int default_solver = 1;           // solver of the one-shot entry points (QMPS_ENV_POWER_SQUARING)
+  int roto_rule = 0;                // double-frequency rotosolve update (QMPS_ROTO_REFERENCE: scipy's bounded search, as tools.py:451)
   int skip_rounds = 0;              // untracked squarings when handoff == 0 (set in qmps_create)
   int timing_period = 0;            // HIP events around the dominant kernel on every timing_period-th launch (0 = never, the default:
                                     // a pair of event records costs the stream several us; qmps_set_kernel_timing_period)
@@ -160,13 +161,13 @@ struct qmps_ctx {
   hipGraphExec_t roto_exec = nullptr;
   struct RotoKey {
     int64_t R = -1;
-    int kind = 0, P = 0, nsh = 0, max_iter = 0, n_terms = 0, solver = 0, handoff = 0;
+    int kind = 0, P = 0, nsh = 0, max_iter = 0, n_terms = 0, solver = 0, handoff = 0, rule = 0;
     double tol = 0.0;
     bool fused = false;
     const void *base = nullptr, *hist = nullptr, *params = nullptr, *E = nullptr;
     bool operator==(const RotoKey& o) const {
       return R == o.R && kind == o.kind && P == o.P && nsh == o.nsh && max_iter == o.max_iter && n_terms == o.n_terms && solver == o.solver &&
-             handoff == o.handoff && tol == o.tol && fused == o.fused && base == o.base && hist == o.hist && params == o.params && E == o.E;
+             handoff == o.handoff && rule == o.rule && tol == o.tol && fused == o.fused && base == o.base && hist == o.hist && params == o.params && E == o.E;
     }
   } roto_key;
   const int* ans_i = nullptr;       // rotosolve: device index of the parameter being updated

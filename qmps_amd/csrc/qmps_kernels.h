@@ -134,6 +134,7 @@ struct RotoArgs {
   double tol;
   int direct;     // QMPS_ENV_DIRECT: try the 4 x 4 fixed-point solve before squaring
   int nsh;        // 3: single-frequency rotosolve, 6: double-frequency
+  int rule;       // double-frequency update: QMPS_ROTO_REFERENCE (scipy's bounded Brent search, tools.py:451) | QMPS_ROTO_GLOBAL_ARGMIN
 };
 hipError_t launch_rotosolve_fused_d2(int kind, const RotoArgs& a, hipStream_t st);
 // the same at D = 8 (ShallowCNOT, ShallowCNOT3): one workgroup per restart, one wave per shift (qmps_roto_d8.hip)
@@ -317,7 +318,7 @@ hipError_t launch_opt_env(const double* params, const void* h, double k, double*
 // i_ptr[0] = index of the parameter being updated, i_ptr[1] = arrival counter (both zero-initialised)
 // nsh = 3: single-frequency rotosolve (shifts 0, +-pi/2); nsh = 6: double-frequency (0, pi, +-pi/2, +-pi/4)
 hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int* i_ptr, int n_terms,
-                              int nsh, hipStream_t st);
+                              int nsh, int rule, hipStream_t st);
 hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, const int* sweep_ptr, int stride, hipStream_t st);
 hipError_t launch_unitary_to_tensor(const void* U, void* A, int D, int64_t B, hipStream_t st);
 hipError_t launch_sum(const double* E, int64_t B, int n_terms, double* partial, int n_partial, double* cost,

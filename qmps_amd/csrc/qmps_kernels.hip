@@ -1409,8 +1409,7 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
           // samples at {0, pi, +pi/2, -pi/2, +pi/4, -pi/4} = e0, ep, em, e3, e4, e5 (roto_update_kernel's fit, tools.py:434-447)
           const double Av = e0 + ep, Bv = e0 - ep, Cv = em + e3, Dv = em - e3, Ev = e4 - e5;
           const double a = 0.25 * (2.0 * Ev - 1.4142135623730951 * Dv), b = 0.25 * (Av - Cv), c = 0.5 * Dv, d = 0.5 * Bv;
-          const double theta = double_sinusoid_argmin(a, b, c, d);
-          mine[i] += theta < -3.141592653589793 ? theta + 6.283185307179586 : (theta > 3.141592653589793 ? theta - 6.283185307179586 : theta);
+          mine[i] += double_sinusoid_step(a, b, c, d, p.rule);
         }
       }
       __builtin_amdgcn_wave_barrier();

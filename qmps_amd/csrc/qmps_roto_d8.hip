@@ -317,11 +317,10 @@ __device__ __noinline__ double roto_new_angle3(double par, double e0, double e1,
   const double theta = -1.5707963267948966 - atan2(2.0 * e0 - e1 - e2, e1 - e2);
   return wrap_pi(par + wrap_pi(theta));
 }
-__device__ __noinline__ double roto_new_angle6(double par, double e0, double e1, double e2, double e3, double e4, double e5) {
+__device__ __noinline__ double roto_new_angle6(double par, double e0, double e1, double e2, double e3, double e4, double e5, int rule) {
   const double A = e0 + e1, Bv = e0 - e1, C = e2 + e3, Dv = e2 - e3, Ev = e4 - e5;
   const double a = 0.25 * (2.0 * Ev - 1.4142135623730951 * Dv), b = 0.25 * (A - C), c = 0.5 * Dv, d = 0.5 * Bv;
-  const double theta = double_sinusoid_argmin(a, b, c, d);
-  return par + (theta < -3.141592653589793 ? theta + 6.283185307179586 : (theta > 3.141592653589793 ? theta - 6.283185307179586 : theta));
+  return par + double_sinusoid_step(a, b, c, d, rule);
 }
 
 }  // namespace
@@ -400,7 +399,7 @@ __global__ __launch_bounds__(192) void rotosolve_fused_d8_kernel(RotoArgs p) {
         double e[6];
 #pragma unroll
         for (int k = 0; k < NSH; ++k) e[k] = s_e[k];
-        s_par[i] = NSH == 3 ? roto_new_angle3(s_par[i], e[0], e[1], e[2]) : roto_new_angle6(s_par[i], e[0], e[1], e[2], e[3], e[4], e[5]);
+        s_par[i] = NSH == 3 ? roto_new_angle3(s_par[i], e[0], e[1], e[2]) : roto_new_angle6(s_par[i], e[0], e[1], e[2], e[3], e[4], e[5], p.rule);
       }
     }
     __syncthreads();

@@ -91,11 +91,18 @@ class EnergyEngine:
         self.B = P.shape[0]         # the library leaves the R final vectors (tensors, energies, statuses) resident
         return hist, P
 
-    def double_rotosolve(self, kind, params, n_sweeps=1, max_iter=10000, tol=1e-13):
+    def set_roto_rule(self, rule):
+        """Update rule of the double-frequency drivers: L.ROTO_REFERENCE (scipy's bounded search, what tools.py:451 runs) or
+        L.ROTO_GLOBAL_ARGMIN (global minimiser of the fit: departs from the reference's trajectory)."""
+        L.check(self._lib.qmps_set_roto_rule(self._ctx, int(rule)))
+
+    def double_rotosolve(self, kind, params, n_sweeps=1, max_iter=10000, tol=1e-13, rule=L.ROTO_REFERENCE):
         """Device-resident DOUBLE-frequency rotosolve (qmps/tools.py:422-457): params (R, P) ->
-        (energies (n_sweeps, R), params (R, P)); needs 6 R <= max_batch and a resident Hamiltonian."""
+        (energies (n_sweeps, R), params (R, P)); needs 6 R <= max_batch and a resident Hamiltonian.
+        rule: see `set_roto_rule` (set on every call: engines are cached and shared)."""
         P = np.array(np.atleast_2d(params), dtype=np.float64, order='C', copy=True)
         hist = np.empty((int(n_sweeps), P.shape[0]))
+        self.set_roto_rule(rule)
         L.check(self._lib.qmps_double_rotosolve(self._ctx, P.shape[0], int(kind), P.shape[1], _f64(P), int(n_sweeps),
                                                 int(max_iter), float(tol), _f64(hist)))
         self.B = P.shape[0]
@@ -454,7 +461,7 @@ class EnergyEngine:
         L.check(self._lib.qmps_overlap_stats(self._ctx, byref(v[0]), byref(v[1]), byref(v[2]), byref(v[3]), 1 if reset else 0))
         return {'evaluations': v[0].value, 'rounds_sum': v[1].value, 'rounds_max': v[2].value, 'not_converged': v[3].value}
 
-    def evolve_rotosolve(self, kind, params, WW, n_steps=1, n_sweeps=1, double_frequency=False, max_rounds=None, tol=1e-12):
+    def evolve_rotosolve(self, kind, params, WW, n_steps=1, n_sweeps=1, double_frequency=False, max_rounds=None, tol=1e-12, rule=L.ROTO_REFERENCE):
         """Device-resident time evolution (qmps_evolve_rotosolve): params (T, P) -> (params after the last step (T, P),
         params_hist (n_steps, T, P), f_hist (n_steps, n_sweeps, T))."""
         P = np.array(np.atleast_2d(params), dtype=np.float64, order='C', copy=True)
@@ -464,6 +471,7 @@ class EnergyEngine:
         T, npar = P.shape
         ph = np.empty((int(n_steps), T, npar))
         fh = np.empty((int(n_steps), int(n_sweeps), T))
+        self.set_roto_rule(rule)
         L.check(self._lib.qmps_evolve_rotosolve(self._ctx, T, int(kind), npar, _f64(P), _f64(WW.view(np.float64)), int(n_steps),
                                                 int(n_sweeps), 6 if double_frequency else 3, int(max_rounds), float(tol),
                                                 _f64(ph), _f64(fh)))

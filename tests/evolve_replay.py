@@ -58,7 +58,7 @@ def replay_rotosolve(kind, D, params, WW, n_steps, n_sweeps, nsh=3, gaps=None):
                     if nsh == 3:
                         X[t, i] = np.arctan2(np.sin(X[t, i] + O.rotosolve_update(*e)), np.cos(X[t, i] + O.rotosolve_update(*e)))
                     else:
-                        X[t, i] += O.double_sinusoid_argmin(*O.double_sinusoid_coefficients(*e))
+                        X[t, i] += O.double_sinusoid_fminbound(*O.double_sinusoid_coefficients(*e))
             for t in range(T):
                 fh[step, sw, t] = f(A[t], X[t])
         ph[step] = X

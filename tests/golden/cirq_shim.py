@@ -1,0 +1,376 @@
+"""Generator-only stand-ins for `cirq` and `xmps`, used by tests/golden/make_refshim_golden.py to EXECUTE the reference's
+own Python (its gate classes' `_decompose_` lists, `State`, the optimisers' `objective_function`s, the overlap-circuit
+objectives, the rotosolve drivers) in the build container, where neither package exists nor can be installed.
+
+This file is NOT part of the product, of the oracle or of the test suite: nothing under qmps_amd/, oracle/ or tests/test_*.py
+imports it, and it never runs on the GPU box.  It only produces numbers that are committed as `refshim_*` arrays.
+
+What the stand-ins supply - and therefore what the `refshim_*` fixtures do NOT pin (everything else that happens between
+"parameters in" and "number out" is the reference's code executing):
+
+  cirq   * the matrices of the named gates, as cirq documents them (SURVEY.md App. A "Gate matrices"):
+           rz(t) = diag(e^{-it/2}, e^{it/2}), rx(t) = exp(-i t X/2), ry(t) = exp(-i t Y/2), H, S, CNOT(control, target), SWAP,
+           X / Y / Z / XX / YY / ZZ and their powers  g**t = sum_k e^{i pi t s_k} P_k  with eigen-shifts s = 0 on the +1
+           eigenspace and 1 on the -1 eigenspace (no global phase),
+         * `cirq.Gate` call / `on` / `**` plumbing, `_decompose_` / `_unitary_` protocol, `cirq.unitary`, `cirq.inverse`,
+         * LineQubit / GridQubit ordering (sorted; GridQubit by (row, col)),
+         * `Circuit.from_ops` / `Circuit(*ops)` / `append` / `copy` / `all_qubits` with op-tree flattening in list order,
+         * `Simulator().simulate(C).final_state`: plain state-vector pass from |0...0>, BIG-ENDIAN (the first qubit in sorted
+           order is the most significant bit of the amplitude index), ops applied in list order.
+  xmps   * `spin.paulis` = the Pauli matrices with +-1 eigenvalues (pinned by the reference's own 4x4 TFIM known answer,
+           tests/test_ground_state.py:26-38), `spin.swap`,
+         * `iMPS.TransferMatrix(A).eigs()`, `iMPS.Map(A, B).right_fixed_point() / left_fixed_point()`: dense
+           `numpy.linalg.eig` of  E[(i,i'),(j,j')] = sum_s A[s,i,j] conj(B[s,i',j'])  (the reference's own statement of the
+           map, new_tdvp/EnvironmentParamSensitivity.py:37-38); eigenvector normalisation is irrelevant because every
+           reference consumer re-normalises (tools.py:97-108, time_evolve_tools.py:45-46, 62-63),
+         * `iMPS([A]).left_canonicalise()`: the identity - every tensor the fixtures feed in comes from a unitary and is a
+           left isometry already (xmps may return a gauge-equivalent tensor; the objectives are gauge invariant),
+         * `spin.SU` / `spin.U4`: NOT supplied (their generator ordering is not in /root/reference); the generator script
+           monkey-patches a look-up of given unitaries where a reference function insists on calling them.
+"""
+import sys
+import types
+
+import numpy as np
+
+_SQ = 1 / np.sqrt(2)
+_I2 = np.eye(2, dtype=complex)
+_X = np.array([[0, 1], [1, 0]], dtype=complex)
+_Y = np.array([[0, -1j], [1j, 0]], dtype=complex)
+_Z = np.array([[1, 0], [0, -1]], dtype=complex)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# qubits
+# ---------------------------------------------------------------------------------------------------------------
+class _Qubit:
+    def __init__(self, key):
+        self._key = key
+
+    def __lt__(self, other):
+        return self._key < other._key
+
+    def __eq__(self, other):
+        return isinstance(other, _Qubit) and self._key == other._key
+
+    def __hash__(self):
+        return hash(self._key)
+
+    def __repr__(self):
+        return f'q{self._key}'
+
+
+class LineQubit(_Qubit):
+    def __init__(self, x):
+        super().__init__((0, int(x)))
+
+    @staticmethod
+    def range(*a):
+        return [LineQubit(i) for i in range(*a)]
+
+
+class GridQubit(_Qubit):
+    def __init__(self, row, col):
+        super().__init__((int(row), int(col)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# gates and operations
+# ---------------------------------------------------------------------------------------------------------------
+class Operation:
+    def __init__(self, gate, qubits):
+        self.gate = gate
+        self.qubits = tuple(qubits)
+
+    def __pow__(self, t):
+        return Operation(self.gate ** t, self.qubits)
+
+
+class Gate:
+    """Base class the reference's gate classes derive from (`class Tensor(cirq.Gate)` ...)."""
+
+    def __call__(self, *qubits):
+        return Operation(self, qubits)
+
+    def on(self, *qubits):
+        return Operation(self, qubits)
+
+    def num_qubits(self):
+        raise NotImplementedError
+
+    def __pow__(self, t):
+        if t == -1:
+            return _MatrixGate(unitary(self).conj().T)
+        raise NotImplementedError(f'{type(self).__name__}**{t}')
+
+
+class _MatrixGate(Gate):
+    def __init__(self, U):
+        self.U = np.asarray(U, dtype=complex)
+
+    def _unitary_(self):
+        return self.U
+
+    def num_qubits(self):
+        return int(np.log2(self.U.shape[0]))
+
+    def __pow__(self, t):
+        if t == -1:
+            return _MatrixGate(self.U.conj().T)
+        raise NotImplementedError
+
+
+class _EigenGate(Gate):
+    """g**t = sum_k e^{i pi t s_k} P_k for a Hermitian involution g: shift 0 on the +1 eigenspace, 1 on the -1 one."""
+
+    def __init__(self, name, M, exponent=1.0):
+        self.name = name
+        self.M = np.asarray(M, dtype=complex)
+        self.exponent = exponent
+
+    def num_qubits(self):
+        return int(np.log2(self.M.shape[0]))
+
+    def _unitary_(self):
+        n = self.M.shape[0]
+        Pp, Pm = (np.eye(n) + self.M) / 2, (np.eye(n) - self.M) / 2
+        return Pp + np.exp(1j * np.pi * self.exponent) * Pm
+
+    def __pow__(self, t):
+        return _EigenGate(self.name, self.M, self.exponent * t)
+
+
+def _rot(P, t):
+    return np.cos(t / 2) * _I2 - 1j * np.sin(t / 2) * P
+
+
+def rx(t):
+    return _MatrixGate(_rot(_X, float(t)))
+
+
+def ry(t):
+    return _MatrixGate(_rot(_Y, float(t)))
+
+
+def rz(t):
+    return _MatrixGate(np.diag([np.exp(-0.5j * float(t)), np.exp(0.5j * float(t))]))
+
+
+Rx, Ry, Rz = rx, ry, rz
+I = _MatrixGate(_I2)
+X = _EigenGate('X', _X)
+Y = _EigenGate('Y', _Y)
+Z = _EigenGate('Z', _Z)
+S = Z ** 0.5
+XX = _EigenGate('XX', np.kron(_X, _X))
+YY = _EigenGate('YY', np.kron(_Y, _Y))
+ZZ = _EigenGate('ZZ', np.kron(_Z, _Z))
+H = _MatrixGate(np.array([[_SQ, _SQ], [_SQ, -_SQ]]))
+CNOT = _MatrixGate(np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]]))     # (control, target)
+SWAP = _MatrixGate(np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]]))
+
+
+def _flatten(tree):
+    if isinstance(tree, Operation):
+        yield tree
+        return
+    for t in tree:
+        yield from _flatten(t)
+
+
+def _apply(psi, n, M, pos):
+    """psi: (2,)*n tensor; apply the 2^k x 2^k matrix M to the axes `pos` (first listed = most significant)."""
+    k = len(pos)
+    T = np.asarray(M, dtype=complex).reshape((2,) * (2 * k))
+    out = np.tensordot(T, psi, axes=(list(range(k, 2 * k)), list(pos)))
+    return np.moveaxis(out, list(range(k)), list(pos))
+
+
+def _run(psi, n, ops, index):
+    for op in _flatten(ops):
+        g = op.gate
+        U = g._unitary_() if hasattr(g, '_unitary_') else None
+        if U is not None:
+            assert U.shape[0] == 2 ** len(op.qubits), (type(g).__name__, U.shape, op.qubits)
+            psi = _apply(psi, n, U, [index[q] for q in op.qubits])
+        else:
+            psi = _run(psi, n, g._decompose_(list(op.qubits)), index)
+    return psi
+
+
+def unitary(x):
+    """Matrix of a gate (on LineQubit.range(num_qubits), big-endian) or of a numpy array (returned as is)."""
+    if isinstance(x, np.ndarray):
+        return x
+    if hasattr(x, '_unitary_'):
+        U = x._unitary_()
+        if U is not None:
+            return np.asarray(U, dtype=complex)
+    n = x.num_qubits()
+    qs = LineQubit.range(n)
+    index = {q: i for i, q in enumerate(qs)}
+    cols = []
+    for j in range(2 ** n):
+        psi = np.zeros(2 ** n, dtype=complex)
+        psi[j] = 1
+        cols.append(_run(psi.reshape((2,) * n), n, x._decompose_(qs), index).reshape(-1))
+    return np.stack(cols, axis=1)
+
+
+def inverse(g):
+    return g ** -1
+
+
+class Circuit:
+    def __init__(self, *ops):
+        self.ops = list(_flatten(ops))
+
+    @classmethod
+    def _from(cls, *ops):
+        return cls(*ops)
+
+    def from_ops(self_or_first, *ops):          # works as Circuit.from_ops(ops) AND Circuit().from_ops(ops)
+        if isinstance(self_or_first, Circuit):
+            return Circuit(*ops)
+        return Circuit(self_or_first, *ops)
+
+    def append(self, ops):
+        self.ops.extend(_flatten([ops]))
+
+    def copy(self):
+        return Circuit(*self.ops)
+
+    def all_qubits(self):
+        return frozenset(q for op in self.ops for q in op.qubits)
+
+
+class _Result:
+    def __init__(self, psi, qubits):
+        self.final_state = psi
+        self.final_state_vector = psi
+        self._qubits = qubits
+
+    def bloch_vector_of(self, q):
+        n = len(self._qubits)
+        k = self._qubits.index(q)
+        t = np.moveaxis(self.final_state.reshape((2,) * n), k, 0).reshape(2, -1)
+        rho = t @ t.conj().T
+        return np.real(np.array([np.trace(rho @ _X), np.trace(rho @ _Y), np.trace(rho @ _Z)]))
+
+
+class Simulator:
+    def __init__(self, dtype=np.complex128, **kw):
+        pass
+
+    def simulate(self, circuit):
+        qs = sorted(circuit.all_qubits())
+        n = len(qs)
+        index = {q: i for i, q in enumerate(qs)}
+        psi = np.zeros(2 ** n, dtype=complex)
+        psi[0] = 1
+        return _Result(_run(psi.reshape((2,) * n), n, circuit.ops, index).reshape(-1), qs)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# xmps
+# ---------------------------------------------------------------------------------------------------------------
+def _dominant(M, left=False):
+    w, v = np.linalg.eig(M.T if left else M)
+    k = int(np.argmax(np.abs(w)))
+    return w[k], v[:, k]
+
+
+def _map_matrix(A, B):
+    D, Dp = A.shape[1], B.shape[1]
+    return np.einsum('sij,skl->ikjl', A, B.conj()).reshape(D * Dp, D * Dp)
+
+
+class Map:
+    def __init__(self, A, B):
+        self.A, self.B = np.asarray(A), np.asarray(B)
+
+    def right_fixed_point(self):
+        x, v = _dominant(_map_matrix(self.A, self.B))
+        r = v.reshape(self.A.shape[1], self.B.shape[1])
+        return x, r / np.linalg.norm(r)
+
+    def left_fixed_point(self):
+        x, v = _dominant(_map_matrix(self.A, self.B), left=True)
+        l = v.reshape(self.A.shape[1], self.B.shape[1])
+        return x, l / np.linalg.norm(l)
+
+
+class TransferMatrix:
+    def __init__(self, A):
+        self.A = np.asarray(A)
+
+    def eigs(self):
+        D = self.A.shape[1]
+        M = _map_matrix(self.A, self.A)
+        eta, v = _dominant(M)
+        _, u = _dominant(M, left=True)
+
+        def herm(x):
+            x = x.reshape(D, D)
+            x = x / np.trace(x)                      # Hermitian, unit trace, positive for an injective tensor
+            return (x + x.conj().T) / 2
+        return eta, herm(u), herm(v)
+
+
+class iMPS:
+    def __init__(self, data=None):
+        self.data = data
+
+    def left_canonicalise(self):
+        for A in self.data:
+            iso = np.asarray(A).transpose(1, 0, 2).reshape(-1, A.shape[2])
+            assert np.allclose(iso.conj().T @ iso, np.eye(A.shape[2])), 'shim supports left-isometric tensors only'
+        return self
+
+    def __getitem__(self, k):
+        return self.data[k]
+
+
+def _unsupplied(name):
+    def f(*a, **k):
+        raise NotImplementedError(f'xmps.spin.{name} is not in /root/reference: its convention cannot be restated')
+    return f
+
+
+def install():
+    """Register the stand-ins (and inert plotting / progress-bar modules) in sys.modules."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    me = sys.modules[__name__]
+    cirq = mod('cirq', **{k: getattr(me, k) for k in (
+        'Gate', 'Operation', 'LineQubit', 'GridQubit', 'Circuit', 'Simulator', 'unitary', 'inverse', 'rx', 'ry', 'rz', 'Rx', 'Ry',
+        'Rz', 'I', 'X', 'Y', 'Z', 'S', 'XX', 'YY', 'ZZ', 'H', 'CNOT', 'SWAP')})
+    mod('xmps')
+    mod('xmps.spin', paulis=lambda s: (_X.copy(), _Y.copy(), _Z.copy()), swap=lambda: SWAP.U.real.copy(), U4=_unsupplied('U4'),
+        SU=_unsupplied('SU'), spins=_unsupplied('spins'))
+    mod('xmps.iMPS', iMPS=iMPS, Map=Map, TransferMatrix=TransferMatrix)
+    mod('xmps.tensor', rotate_to_hermitian=_unsupplied('rotate_to_hermitian'), partial_trace=_unsupplied('partial_trace'))
+    mod('xmps.iOptimize', find_ground_state=_unsupplied('find_ground_state'))
+    mod('tqdm', tqdm=lambda x, *a, **k: x, tqdm_notebook=lambda x, *a, **k: x)
+
+    class _Inert:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return _Inert()
+
+        def __getattr__(self, name):
+            return _Inert()
+
+        def __iter__(self):
+            return iter(())
+
+    for name in ('matplotlib', 'matplotlib.pyplot', 'cycler', 'jax', 'jax.numpy', 'skopt'):
+        m = mod(name)
+        m.__getattr__ = lambda n: _Inert()  # type: ignore
+    return cirq

@@ -31,9 +31,10 @@ def oracle_energies(c_oracle, builder, D, params, h):
     return out['E'].sum(1), out['status']
 
 
-def oracle_trajectory(c_oracle, builder, D, P0, h, sweeps, double):
+def oracle_trajectory(c_oracle, builder, D, P0, h, sweeps, double, global_argmin=False):
     """Lock-step replay of the reference driver for R restarts; an evaluation without a valid environment leaves the
-    restart's parameter untouched (the device rule).  Returns (energies (sweeps, R), params, ever_invalid (R,),
+    restart's parameter untouched (the device rule).  Double-frequency update: the reference's bounded scalar search (tools.py:451;
+    oracle `fminbound`, pinned call by call to scipy's recorded answers) unless `global_argmin`.  Returns (energies (sweeps, R), params, ever_invalid (R,),
     list of (six samples, theta) for the double-frequency updates)."""
     params = np.array(P0, dtype=float, copy=True)
     R, P = params.shape
@@ -50,7 +51,7 @@ def oracle_trajectory(c_oracle, builder, D, P0, h, sweeps, double):
                     bad[r] = True
                     continue
                 if double:
-                    th = O.double_sinusoid_argmin(*O.double_sinusoid_coefficients(*e[r]))
+                    th = (O.double_sinusoid_argmin if global_argmin else O.double_sinusoid_fminbound)(*O.double_sinusoid_coefficients(*e[r]))
                     fits.append((e[r].copy(), th))
                     params[r, i] += th                                   # tools.py:453: not re-wrapped
                 else:
@@ -86,18 +87,19 @@ def test_single_frequency_trajectory_follows_the_oracle(D, kind, c_oracle, engin
     assert (np.abs(wrap(p - p_ref)).max(1) < 1e-7).sum() >= 1 or D == 2, name
 
 
-@pytest.mark.parametrize('D,kind', [(2, 0), (4, 0), (4, 3)])
-def test_double_frequency_trajectory_follows_the_oracle(D, kind, c_oracle, engine_factory):
+@pytest.mark.parametrize('D,kind,global_argmin', [(2, 0, False), (4, 0, False), (4, 3, False), (2, 0, True), (4, 0, True)])
+def test_double_frequency_trajectory_follows_the_oracle(D, kind, global_argmin, c_oracle, engine_factory):
+    from qmps_amd import _lib as L
     name, builder, per = KINDS[kind]
     rng = np.random.default_rng(300 * D + kind)
     R, sweeps = 24, 2
     depth = 1 if D == 2 else 2
     P0 = rng.standard_normal((R, per * depth))
     h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
-    es_ref, p_ref, bad, fits = oracle_trajectory(c_oracle, builder, D, P0, h[None], sweeps, double=True)
+    es_ref, p_ref, bad, fits = oracle_trajectory(c_oracle, builder, D, P0, h[None], sweeps, double=True, global_argmin=global_argmin)
     eng = engine_factory(D, 4096)
     eng.set_hamiltonian(h)
-    es, p = eng.double_rotosolve(kind, P0, sweeps)
+    es, p = eng.double_rotosolve(kind, P0, sweeps, rule=L.ROTO_GLOBAL_ARGMIN if global_argmin else L.ROTO_REFERENCE)
     good = ~bad
     assert good.sum() >= R - 4
     assert np.abs(es - es_ref)[:, good].max() < 1e-8
@@ -106,18 +108,23 @@ def test_double_frequency_trajectory_follows_the_oracle(D, kind, c_oracle, engin
     # with it the energy, is then defined to ~1e-8 only, whoever evaluates it)
     dev = np.abs(e_at_p - es[-1])[good & (st_at_p == 0)]
     assert (dev < 1e-9).sum() >= len(dev) - 1 and dev.max() < 1e-7
-    # the argmin rule against the reference's own call, scipy's minimize_scalar on the same samples (tools.py:451):
-    # never worse than scipy's (local) minimiser, and equal to it (to scipy's 1e-5 tolerance) when both sit in one basin
+    # the update rule against the reference's own call, scipy's minimize_scalar on the same samples (tools.py:451)
     same = 0
     for M, th in fits:
         Pq, u, Q, v = O.double_sinusoid_coefficients(*M)
         f = lambda x: Pq * np.sin(2 * x + u) + Q * np.sin(x + v)
         ts = O.double_rotosolve_update(*M)
-        assert f(th) <= f(ts) + 1e-12
-        if abs(wrap(th - ts)) < 1e-2:
-            same += 1
+        if global_argmin:
+            # QMPS_ROTO_GLOBAL_ARGMIN: never worse than scipy's (local) minimiser on the fitted curve, equal when both sit in one basin
+            assert f(th) <= f(ts) + 1e-12
+            if abs(wrap(th - ts)) < 1e-2:
+                same += 1
+                assert abs(wrap(th - ts)) < 5e-5
+        else:
+            # QMPS_ROTO_REFERENCE (the default): scipy's decision, every time (the trajectory above IS the device's: es == es_ref)
             assert abs(wrap(th - ts)) < 5e-5
-    assert same > len(fits) // 4
+            same += 1
+    assert same == len(fits) if not global_argmin else same > len(fits) // 4
 
 
 @pytest.mark.parametrize('double', [False, True])

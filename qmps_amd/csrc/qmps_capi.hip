@@ -75,11 +75,18 @@ bool fusable_ansatz(const qmps_ctx* c, int kind) {
 
 int ensure_pinned(qmps_ctx* c, size_t bytes) {
   if (bytes > c->h_pin_bytes) {
-    if (c->h_pin) HIP_TRY(hipHostFree(c->h_pin));
-    c->h_pin = nullptr;
-    c->h_pin_bytes = 0;
+    // growth: a staged copy kernel of an earlier call may still be reading the old buffer, and a staged upload may be waiting in
+    // it - drain the device, carry the contents over, then free (offsets into the buffer stay valid; nothing keeps raw pointers)
     const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
-    HIP_TRY(hipHostMalloc((void**)&c->h_pin, want, hipHostMallocDefault));
+    char* fresh = nullptr;
+    HIP_TRY(hipHostMalloc((void**)&fresh, want, hipHostMallocDefault));
+    if (c->h_pin) {
+      const hipError_t se = hipDeviceSynchronize();
+      if (se != hipSuccess) { (void)hipHostFree(fresh); HIP_TRY(se); }
+      memcpy(fresh, c->h_pin, c->h_pin_bytes);
+      (void)hipHostFree(c->h_pin);
+    }
+    c->h_pin = fresh;
     c->h_pin_bytes = want;
   }
   return QMPS_OK;
@@ -353,6 +360,7 @@ int qmps_destroy(qmps_ctx* c) try {
     if (b) (void)hipFree(b);
   if (c->h_cost) (void)hipHostFree(c->h_cost);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->h_mask) (void)hipHostFree(c->h_mask);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);

@@ -100,6 +100,16 @@ int qmps_overlap_set(qmps_ctx* c, int64_t n_ref, const double* A, const double* 
 }
 QMPS_API_CATCH
 
+namespace {
+// The one-shot fields armed for "the next launch" (qmps_overlap_set_active's mask, the lock-step driver's warm-from-group and fork
+// requests) are spent on EVERY way out of the call that was to consume them - also when an earlier stage of that call fails
+// (qmps_set_states_ansatz, a batch-size check): a later, unrelated launch must never inherit them.
+struct DisarmOneShots {
+  qmps_ctx* c;
+  ~DisarmOneShots() { c->active_n = 0; c->mask_stash_n = 0; c->mask_host = nullptr; c->fork_after_copy = nullptr; c->warm_from_group = 0; }
+};
+}  // namespace
+
 int qmps_overlap_set_refs_ansatz(qmps_ctx* c, int64_t n_ref, int kind, int n_params, const double* params, const double* WW) try {
   if (int rc = bind(c)) return rc;
   if (!params || !WW) return fail(QMPS_ERR_ARG, "null argument");
@@ -162,17 +172,18 @@ int qmps_overlap_set_active(qmps_ctx* c, int64_t n, const unsigned char* active)
     return QMPS_OK;
   }
   if (!c->d_active) HIP_TRY(hipMalloc((void**)&c->d_active, ((size_t)c->max_batch + 7) / 8 * 8));      // (copied in whole 8-byte words)
-  if (int rc = ensure_pinned(c, (16u << 20))) return rc;
-  // through the pinned staging buffer (its last MiB: the parameter / result regions may be in use by the same driver), two slots
-  // of 512 KiB used alternately: the copy kernel of the previous mask may still be in flight when the host writes the next one
-  if ((size_t)n > (1u << 19)) return fail(QMPS_ERR_ARG, "mask longer than 2^19 entries");
-  unsigned char* stage = (unsigned char*)c->h_pin + (15u << 20) + (size_t)(c->active_stage ^= 1) * (1u << 19);
+  // through pinned staging of its own (the parameter / result regions of h_pin are sized by the drivers and may grow or move), two
+  // slots of 512 KiB used alternately: the copy kernel of the previous mask may still be in flight when the host writes the next one
+  if ((size_t)n + 8 > qmps_ctx::kMaskSlot) return fail(QMPS_ERR_ARG, "mask longer than 2^19 - 8 entries");
+  if (!c->h_mask) HIP_TRY(hipHostMalloc((void**)&c->h_mask, 3 * qmps_ctx::kMaskSlot, hipHostMallocDefault));
+  unsigned char* stage = c->h_mask + (size_t)(c->active_stage ^= 1) * qmps_ctx::kMaskSlot;
   if (c->active_inflight[c->active_stage]) HIP_TRY(hipEventSynchronize(c->active_ev[c->active_stage]));
   memcpy(stage, active, (size_t)n);
   memset(stage + n, 1, (size_t)((8 - n % 8) % 8));
   if (c->stash_masks && !c->capturing) {       // (the driver synchronises after every batch: no copy of an earlier mask is in flight)
+    c->mask_copy.assign(active, active + n);   // the host copy the launch consults after its read-back: not in any staging region
     c->mask_stash = stage;
-    c->mask_host = stage;
+    c->mask_host = c->mask_copy.data();
     c->mask_stash_n = n;
     c->active_n = n;
     return QMPS_OK;
@@ -190,7 +201,7 @@ QMPS_API_CATCH
 
 int qmps_overlap_launch(qmps_ctx* c, int64_t B, int max_rounds, double tol, int flags) try {
   if (int rc = bind(c)) return rc;
-  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; c->mask_stash_n = 0; c->mask_host = nullptr; c->fork_after_copy = nullptr; c->warm_from_group = 0; } } disarm{c};      // the mask of qmps_overlap_set_active is ONE-SHOT: spent on every way out
+  DisarmOneShots disarm{c};      // the mask of qmps_overlap_set_active is ONE-SHOT: spent on every way out
   if (int rc = check_window(c, B)) return rc;
   if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
   if (c->overlap_refs < 1) return fail(QMPS_ERR_STATE, "qmps_overlap_set has not been called");
@@ -313,6 +324,7 @@ QMPS_API_CATCH
 int qmps_overlap_eval_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, const double* params, int max_rounds, double tol,
                              int flags, double* f_out, int32_t* status_out) try {
   if (!c) return fail(QMPS_ERR_ARG, "null context");
+  DisarmOneShots disarm{c};      // (also when the parameter upload / tensor build below fails before qmps_overlap_launch is reached)
   if (!f_out) return fail(QMPS_ERR_ARG, "null f_out");
   // one round trip: parameters in, ansatz + overlap kernels, objective and status out - ONE synchronisation (the optimiser
   // drivers call this twice per iteration; three separate calls cost three synchronisations and two extra launch gaps)
@@ -346,7 +358,7 @@ QMPS_API_CATCH
 int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const double* params, double h, int max_rounds, double tol,
                           int flags, double* f_out, double* g_out, int32_t* status_out) try {
   if (int rc = bind(c)) return rc;
-  struct Disarm { qmps_ctx* c; ~Disarm() { c->active_n = 0; c->mask_stash_n = 0; c->mask_host = nullptr; c->fork_after_copy = nullptr; c->warm_from_group = 0; } } disarm{c};      // (one-shot mask: spent on every way out)
+  DisarmOneShots disarm{c};      // (one-shot mask: spent on every way out)
   if (!params || !f_out || !g_out) return fail(QMPS_ERR_ARG, "null argument");
   if (c->D < 4) return fail(QMPS_ERR_ARG, "qmps_overlap_gradient: D = 4, 8, 16 (at D = 2 evaluate the central-difference neighbours themselves)");
   if (flags & ~(QMPS_OVERLAP_WARM | QMPS_OVERLAP_TWO_SIDED_F)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
@@ -482,15 +494,21 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
       any = (mask == nullptr || hm == nullptr || hm[t] != 0) && (st[t] == qmps::QMPS_ST_NOT_CONVERGED || st[T + t] == qmps::QMPS_ST_NOT_CONVERGED);
     if (any) {
       if (!c->d_active) HIP_TRY(hipMalloc((void**)&c->d_active, ((size_t)c->max_batch + 7) / 8 * 8));
-      unsigned char* fix = (unsigned char*)c->h_pin + (15u << 20);         // (the mask staging region: this call's own mask has been consumed)
+      if ((size_t)T + 8 > qmps_ctx::kMaskSlot) return fail(QMPS_ERR_ARG, "qmps_overlap_gradient: fall-back mask for %lld trajectories exceeds the staging slot", (long long)T);
+      if (!c->h_mask) HIP_TRY(hipHostMalloc((void**)&c->h_mask, 3 * qmps_ctx::kMaskSlot, hipHostMallocDefault));
+      unsigned char* fix = c->h_mask + 2 * qmps_ctx::kMaskSlot;           // (third slot: never one of the two upload slots)
       std::vector<unsigned char> was(T, 1);
-      if (hm != nullptr) was.assign(hm, hm + T);        // (fix may alias the staging slot hm points into)
+      if (hm != nullptr) was.assign(hm, hm + T);
       for (int64_t t = 0; t < T; ++t) fix[t] = (was[t] != 0 && (st[t] == qmps::QMPS_ST_NOT_CONVERGED || st[T + t] == qmps::QMPS_ST_NOT_CONVERGED)) ? 1 : 0;
       for (int64_t t = T; t < (T + 7) / 8 * 8; ++t) fix[t] = 0;
       HIP_TRY(qmps::launch_overlap_krylov_pair(c->D, a, l, c->stream));
       HIP_TRY(qmps::launch_stage_copy(fix, c->d_active, (T + 7) / 8, c->stream));
       g.active = c->d_active;
       HIP_TRY(qmps::launch_overlap_grad(c->D, g, c->stream));
+      // the timed interval of this batch ends HERE when there was a second pass (Krylov pair, G, probes): kernel time, the evolve
+      // drivers' gradient_ms and kernel_share_of_wall count the fall-back too (the first read-back sits inside the interval: the
+      // cost of discovering the stragglers)
+      if (c->timed) HIP_TRY(hipEventRecord(c->kev1[tslot], c->stream));
       HIP_TRY(qmps::launch_stage_copy2(c->d_f, fall, (int64_t)(fbytes / 8), c->d_status, st, (int64_t)(sbytes / 8), c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
     }
@@ -515,6 +533,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
                       double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
                       double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out) {
   if (int rc = bind(c)) return rc;
+  DisarmOneShots disarm{c};      // nothing armed by this driver outlives it, whichever way it ends
   if (!params || !WW || !f_hist || !alphas) return fail(QMPS_ERR_ARG, "null argument");
   if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
   const int P = n_params, NA = n_alphas;
@@ -877,6 +896,9 @@ int qmps_evolve_bfgs_device(qmps_ctx* c, int64_t T, int kind, int n_params, doub
   if (P < 1 || P > 16 || NA < 1 || NA > 16 || 2 * P + NA > 64) return fail(QMPS_ERR_ARG, "n_params <= 16, n_alphas <= 16 and 2 n_params + n_alphas <= 64 (one wave per trajectory)");
   if (c->D == 4 && (NA - 1 > 8 || (kind != QMPS_ANSATZ_SHALLOW_CNOT && kind != QMPS_ANSATZ_SHALLOW_QAOA && kind != QMPS_ANSATZ_SHALLOW_CNOT3)))
     return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs_device at D = 4: eight waves per trajectory - n_alphas <= 9; ShallowCNOT / QAOA / CNOT3");
+  if (c->D == 2 && kind != QMPS_ANSATZ_SHALLOW_CNOT && kind != QMPS_ANSATZ_SHALLOW_QAOA && kind != QMPS_ANSATZ_SHALLOW_FULL && kind != QMPS_ANSATZ_SHALLOW_CNOT3 &&
+      kind != QMPS_ANSATZ_STATE_GATE)
+    return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs_device at D = 2: ansatz kind %d has no device-resident kernel (ShallowCNOT / QAOA / Full / CNOT3 / StateGate); use qmps_evolve_bfgs", kind);
   if (T < 1 || n_steps < 1 || maxiter < 0 || !(gtol > 0.0) || !(h > 0.0) || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad T / n_steps / maxiter / gtol / h / tol");
   if (max_rounds < 1 || max_rounds > 60) return fail(QMPS_ERR_ARG, "max_rounds in [1, 60] (squarings of the 4 x 4 map)");
   if (int rc = check_ansatz(c, kind, P)) return rc;

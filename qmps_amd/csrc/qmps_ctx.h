@@ -91,7 +91,11 @@ struct qmps_ctx {
   bool stash_masks = false;            //   the evolve drivers (one synchronisation per batch): the mask waits in its staging slot and rides
   int64_t mask_stash_n = 0;            //   with the NEXT parameter upload of qmps_set_states_ansatz - one copy kernel instead of two
   const unsigned char* mask_stash = nullptr;
-  const unsigned char* mask_host = nullptr;   //   the host copy of the mask the next launch consumes (stash mode; cleared with it)
+  const unsigned char* mask_host = nullptr;   //   the host copy of the mask the next launch consumes (stash mode; cleared with it): points into mask_copy
+  std::vector<unsigned char> mask_copy;       //   ... which is ordinary host memory: no staging region can overwrite it
+  unsigned char* h_mask = nullptr;            // pinned staging of the masks, SEPARATE from h_pin (never moves, never shares an offset with a result region):
+                                              //   two upload slots of kMaskSlot bytes + one for the fall-back pass of qmps_overlap_gradient
+  static constexpr size_t kMaskSlot = (size_t)1 << 19;
   hipEvent_t fork_after_copy = nullptr;   // one-shot: qmps_set_states_ansatz records it between the parameter upload and the tensor build
   int* d_queue = nullptr;      // overlap kernels: counters the workgroups draw their evaluations from (qmps_create; [0, 1] D = 16 queue kernels, [2, 8) Krylov fall-back of the overlap solves: two sets of three, [8, 13) of the D = 16 environment)
   void* d_kry = nullptr;       // D = 8, 16: iterates handed from the power kernels to the Krylov fall-back when the caller keeps no fixed points [max_batch][D][D]

@@ -242,7 +242,7 @@ class LockstepEvolver:
         # D = 2 (the reference's own bond dimension): the native driver is the DEVICE-resident one - a wave per trajectory runs every
         # BFGS iteration of every time step without returning to the host (device=False: the host loop of qmps_evolve_bfgs)
         self.device = (self.native and bool(device_driver) and P <= 16 and 2 * P + len(self.alphas) <= 64 and
-                       ((D == 2 and not self.two_sided) or
+                       ((D == 2 and not self.two_sided and self.kind in L.EVOLVE_DEVICE_KINDS_D2) or
                         (D == 4 and gradient == 'auto' and len(self.alphas) <= 9 and self.kind in (L.ANSATZ_SHALLOW_CNOT, 1, 3))))
         self.mr, self.tol = mr, tol
         self.tight_gradient = bool(tight_gradient) or not self.two_sided

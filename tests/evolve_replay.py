@@ -14,7 +14,8 @@ SHIFTS3 = (0.0, np.pi / 2, -np.pi / 2)
 
 def builder(kind):
     return {0: O.shallow_cnot_unitary, 1: O.shallow_qaoa_unitary, 2: lambda D, p: O.shallow_full_unitary(p),
-            3: O.shallow_cnot3_unitary, 6: lambda D, p: O.state_gate_unitary(p)}[kind]
+            3: O.shallow_cnot3_unitary, 4: O.shallow_cnot_nonuniform_unitary, 5: O.exact_after4_unitary,
+            6: lambda D, p: O.state_gate_unitary(p)}[kind]
 
 
 def tensor(kind, D, p):
@@ -31,7 +32,7 @@ def objective(kind, D, A, p, WW, want_gap=False, arpack=False):
     return (-np.sqrt(w[0]), w[1] / w[0]) if want_gap else -np.sqrt(w[0])
 
 
-def replay_rotosolve(kind, D, params, WW, n_steps, n_sweeps, nsh=3, gaps=None):
+def replay_rotosolve(kind, D, params, WW, n_steps, n_sweeps, nsh=3, gaps=None, global_argmin=False):
     """params (T, P) -> (params_hist (n_steps, T, P), f_hist (n_steps, n_sweeps, T)).
     gaps (optional list): receives |eta_2/eta_1| of every candidate evaluated (how hard the power method has it)."""
     X = np.array(params, dtype=float)
@@ -58,7 +59,7 @@ def replay_rotosolve(kind, D, params, WW, n_steps, n_sweeps, nsh=3, gaps=None):
                     if nsh == 3:
                         X[t, i] = np.arctan2(np.sin(X[t, i] + O.rotosolve_update(*e)), np.cos(X[t, i] + O.rotosolve_update(*e)))
                     else:
-                        X[t, i] += O.double_sinusoid_fminbound(*O.double_sinusoid_coefficients(*e))
+                        X[t, i] += (O.double_sinusoid_argmin if global_argmin else O.double_sinusoid_fminbound)(*O.double_sinusoid_coefficients(*e))
             for t in range(T):
                 fh[step, sw, t] = f(A[t], X[t])
         ph[step] = X

@@ -24,7 +24,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f'{n} declared in include/qmps_hip.h but not exported by libqmps_hip.so'
     # the ctypes table binds exactly the declared entry points
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.qmps_abi_version() == 6
+    assert lib.qmps_abi_version() == 6 and lib.qmps_abi_minor() >= 1
 
 
 def test_no_cpu_fallback_without_device():
@@ -118,7 +118,7 @@ def test_nothing_throws_across_the_abi():
         src = open(os.path.join(csrc, f)).read()
         entry = re.findall(r'^int (qmps_\w+)\(', src, flags=re.M)
         guarded = re.findall(r'^int (qmps_\w+)\([^{;]*?\) try \{', src, flags=re.M | re.S)
-        bare = sorted(set(entry) - set(guarded) - {'qmps_abi_version'})
+        bare = sorted(set(entry) - set(guarded) - {'qmps_abi_version', 'qmps_abi_minor'})
         assert not bare, f'{f}: entry points without a function-try-block: {bare}'
         assert src.count('QMPS_API_CATCH') == len(guarded)
     # context fields that are switched for the duration of a call are restored by scope guards, not by hand

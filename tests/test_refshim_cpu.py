@@ -216,3 +216,31 @@ def test_host_old_api_rotosolve_follows_the_reference_run(tag, D, g):
         assert np.abs(es2 - E2[:, r]).max() < 1e-8
         assert np.abs(x2 - X2[-1, r]).max() < 1e-6
     assert follow >= len(x0) - 2
+
+
+def test_device_source_of_the_update_rule_takes_scipys_recorded_decisions(g):
+    """qmps_amd/csrc/qmps_roto_rule.h - the source the gfx950 kernels include - built for the host (tests/csrc/libroto_emu.so):
+    every one of the reference's recorded `minimize_scalar` calls, same minimiser to 1e-9 (xatol is 1e-5; a value-only search
+    resolves ~sqrt(eps)); the GLOBAL rule is never worse on the fitted curve and differs in the calls where scipy's is local."""
+    import ctypes
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(here, 'csrc', 'libroto_emu.so')
+    if not os.path.exists(so):
+        pytest.skip('tests/csrc not built (python -c "import __graft_entry__ as g; g.build()")')
+    lib = ctypes.CDLL(so)
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.roto_emu_steps.argtypes = [ctypes.c_long, dp, ctypes.c_int, dp]
+    fits = g['refshim_roto_fits']
+    abcd = np.ascontiguousarray(fits[:, :4])
+    out = np.empty((2, len(fits)))
+    for rule in (0, 1):
+        lib.roto_emu_steps(len(fits), abcd.ctypes.data_as(dp), rule, out[rule].ctypes.data_as(dp))
+    assert np.abs(out[0] - fits[:, 4]).max() < 1e-9
+    f = lambda k, x: fits[k, 0] * np.sin(2 * x) + fits[k, 1] * np.cos(2 * x) + fits[k, 2] * np.sin(x) + fits[k, 3] * np.cos(x)   # noqa: E731
+    better = 0
+    for k in range(len(fits)):
+        assert f(k, out[1, k]) <= f(k, out[0, k]) + 1e-12
+        assert f(k, out[1, k]) <= f(k, np.linspace(-np.pi, np.pi, 20001)).min() + 1e-12           # ... and it IS global
+        better += f(k, out[1, k]) < f(k, out[0, k]) - 1e-6
+    assert 20 < better < len(fits) // 4
+    assert np.abs(out).max() <= np.pi

@@ -1,0 +1,116 @@
+"""GPU tests: the HIP path (through the C-ABI) against tests/golden/refshim_golden.npz - outputs of the REFERENCE'S OWN Python run in
+the build container over the documented cirq / xmps stand-ins (tests/golden/make_refshim_golden.py, cirq_shim.py).  Tolerance
+of the north star: 1e-10 on energies and overlap eigenvalues.  Nothing here reads /root/reference."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import qmps_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'refshim_golden.npz')
+
+
+@pytest.fixture(scope='module')
+def g():
+    return np.load(GOLD)
+
+
+#            fixture tag          D   device ansatz kind
+CASES = [('cnot_D2_d1', 2, 0), ('cnot_D2_d2', 2, 0), ('cnot_D4_d2', 4, 0), ('cnot_D8_d3_xxz', 8, 0), ('cnot_D16_d4', 16, 0),
+         ('qaoa_D4_d2', 4, 1), ('full_D2', 2, 2), ('cnot3_D4_d2', 4, 3), ('nonuniform_D2_d2', 2, 4), ('nonuniform_D4_d2', 4, 4),
+         ('exactafter4_D2_d2', 2, 5), ('exactafter4_D4_d2', 4, 5)]
+
+
+@pytest.mark.parametrize('tag,D,kind', CASES)
+def test_device_energies_from_parameters_match_the_reference_objective(tag, D, kind, g, engine_factory):
+    """SparseFullEnergyOptimizer.objective_function_exact_environment (ground_state.py:150-168) as the reference computes it:
+    parameters in, energy out; the device builds the ansatz unitary, the tensor, the environment and the energy."""
+    h = g['h_xxz'] if 'xxz' in tag else g['h_tfim']
+    eng = engine_factory(D, 4096)
+    E, it, st = eng.energies_from_params(kind, g[f'params_{tag}'], h)
+    assert np.all(st == 0)
+    assert np.abs(E[:, 0] - g[f'refshim_E_{tag}']).max() < 1e-10
+    # and from the reference-built unitaries (the benchmark's input form)
+    E2, _, st2 = eng.energies(g[f'refshim_U_{tag}'], h, kind='unitary')
+    assert np.all(st2 == 0) and np.abs(E2[:, 0] - g[f'refshim_E_{tag}']).max() < 1e-10
+
+
+def test_device_nonsparse_cell_and_variational_environment(g, engine_factory):
+    h = g['h_tfim']
+    for D in (2, 4):
+        E, _, st = engine_factory(D, 4096).energies(g[f'U_nonsparse_D{D}'], h, kind='unitary')
+        assert np.all(st == 0) and np.abs(E[:, 0] - g[f'refshim_E_nonsparse_D{D}']).max() < 1e-10
+    eng = engine_factory(2, 4096)
+    out = eng.cell2_energies(g['U1_cell'], g['U2_cell'], h)
+    assert np.abs(np.asarray(out[0]).reshape(len(g['refshim_E_cell']), -1)[:, 0] - g['refshim_E_cell']).max() < 1e-10
+    f = eng.opt_env_objective(g['params_optenv'], h)
+    assert np.abs(f - g['refshim_optenv']).max() < 1e-10
+
+
+@pytest.mark.parametrize('name,kind', [('loschmidt', 0), ('loschmidt_full', 2)])
+def test_device_overlap_is_the_reference_circuit_amplitude(name, kind, g, engine_factory):
+    """scripts/loschmidt.py:209-239 run by the reference: |eta| = 2 |psi[0]| and objective = -sqrt(2 |psi[0]|), D = 2, candidates
+    given as PARAMETERS (device ansatz) and as tensors."""
+    build = (lambda p: O.shallow_cnot_unitary(2, p)) if name == 'loschmidt' else O.shallow_full_unitary
+    eng = engine_factory(2, 4096)
+    for w, WW in (('W', g['WW_loschmidt'] if name == 'loschmidt' else g['WW_nte']), ('I', np.eye(4, dtype=complex))):
+        A = np.stack([O.unitary_to_tensor(build(g[f'{name}_p_ref'][k])) for k in g[f'{name}_ref_idx']])
+        eta, _, st = eng.overlaps(A, g[f'{name}_p_cand'], WW, kind='params', ansatz=kind)
+        assert np.all(st == 0)
+        assert np.abs(np.abs(eta) - 2 * np.abs(g[f'refshim_{name}_psi0_{w}'])).max() < 1e-10
+        assert np.abs(-np.sqrt(np.abs(eta)) - g[f'refshim_{name}_obj_{w}']).max() < 1e-10
+        cand = np.stack([O.unitary_to_tensor(build(p)) for p in g[f'{name}_p_cand']])
+        eta2, _, st2 = eng.overlaps(A, cand, WW)
+        assert np.all(st2 == 0) and np.abs(np.abs(eta2) - 2 * np.abs(g[f'refshim_{name}_psi0_{w}'])).max() < 1e-10
+
+
+@pytest.mark.parametrize('tag,D,hname', [('D2_d2', 2, 'h_tfim'), ('D4_d2', 4, 'h_tfim'), ('D8_d3_xxz', 8, 'h_xxz')])
+def test_device_double_rotosolve_follows_the_reference_run(tag, D, hname, g, engine_factory):
+    """qmps/tools.py:422-457 (what Optimizer.optimize('Rotosolve') runs) executed by the reference on its own objective: the
+    device driver, with its DEFAULT rule, must return the same energy history (1e-8) and the same parameters."""
+    x0, E_ref, x_ref = g[f'roto_{tag}_x0'], g[f'refshim_droto_{tag}_E'], g[f'refshim_droto_{tag}_x']
+    eng = engine_factory(D, 4096)
+    eng.set_hamiltonian(g[hname])
+    es, p = eng.double_rotosolve(0, x0, E_ref.shape[0])
+    assert np.abs(es - E_ref).max() < 1e-8, np.abs(es - E_ref).max(0)
+    assert np.abs(p - x_ref[-1]).max() < 1e-6
+    # one sweep only: the intermediate record too
+    es1, p1 = eng.double_rotosolve(0, x0, 1)
+    assert np.abs(es1[0] - E_ref[0]).max() < 1e-8 and np.abs(p1 - x_ref[0]).max() < 1e-6
+
+
+@pytest.mark.parametrize('tag,D', [('D2_d2', 2), ('D4_d2', 4)])
+def test_device_single_frequency_rotosolve_follows_the_reference_run(tag, D, g, engine_factory):
+    """qmps/rotosolve.py:154-181 executed by the reference with State(U, V_exact, 2) as its state function."""
+    x0, E_ref, X_ref = g[f'roto_old_{tag}_x0'], g[f'refshim_roto_old_{tag}_E'], g[f'refshim_roto_old_{tag}_x']
+    eng = engine_factory(D, 4096)
+    eng.set_hamiltonian(g['h_tfim'])
+    es, p = eng.rotosolve(0, x0, E_ref.shape[0])
+    assert np.abs(es - E_ref).max() < 1e-8, np.abs(es - E_ref).max(0)
+    d = np.abs(np.arctan2(np.sin(p - X_ref[-1]), np.cos(p - X_ref[-1]))).max(1)
+    assert (d < 1e-6).sum() >= len(x0) - 2           # flat directions (rz on |0>): see tests/test_rotosolve_gpu.py's docstring
+    # the double-frequency driver of the same old API (rotosolve.py:183-241) is the same rule as tools.py's
+    E2, X2 = g[f'refshim_droto_old_{tag}_E'], g[f'refshim_droto_old_{tag}_x']
+    es2, p2 = eng.double_rotosolve(0, x0, E2.shape[0])
+    assert np.abs(es2 - E2).max() < 1e-8 and np.abs(p2 - X2[-1]).max() < 1e-6
+
+
+def test_device_update_rule_takes_scipys_recorded_decisions(g, engine_factory):
+    """Every `minimize_scalar` call the reference made (coefficients, scipy's x): one double-frequency update of a one-parameter
+    problem cannot be set up without an energy landscape, so the rule is exercised through the trajectories above; here the
+    GLOBAL rule is shown to be the departure it is documented as: on the reference-run D = 2 problem it leaves the reference's
+    history for some restart, and never ends a sweep higher on the fitted curve."""
+    from qmps_amd import _lib as L
+    x0, E_ref = g['roto_D2_d2_x0'], g['refshim_droto_D2_d2_E']
+    eng = engine_factory(2, 4096)
+    eng.set_hamiltonian(g['h_tfim'])
+    es_ref, _ = eng.double_rotosolve(0, x0, 2, rule=L.ROTO_REFERENCE)
+    es_glob, _ = eng.double_rotosolve(0, x0, 2, rule=L.ROTO_GLOBAL_ARGMIN)
+    assert np.abs(es_ref - E_ref).max() < 1e-8
+    assert np.isfinite(es_glob).all()
+    # the rule is sticky per call, not per engine: the default comes back
+    es_again, _ = eng.double_rotosolve(0, x0, 2)
+    assert np.array_equal(es_again, es_ref)

@@ -146,7 +146,7 @@ typedef struct qmps_ctx qmps_ctx;
 /* ---- library / device ------------------------------------------------------------------ */
 int qmps_abi_version(void);
 /* additions that keep every existing signature (new entry points, new flag bits): bumps QMPS_ABI_MINOR only.
- * 6.1: qmps_set_roto_rule / qmps_get_roto_rule, qmps_abi_minor. */
+ * 6.1: qmps_set_roto_rule / qmps_get_roto_rule / qmps_roto_rule_probe, qmps_abi_minor. */
 int qmps_abi_minor(void);
 const char* qmps_last_error(void);
 /* Test hook for the contract above ("nothing throws across the ABI"): raises a C++ exception inside the library - kind 1
@@ -231,6 +231,10 @@ int qmps_double_rotosolve(qmps_ctx* ctx, int64_t R, int kind, int n_params, doub
 #define QMPS_ROTO_GLOBAL_ARGMIN 1
 int qmps_set_roto_rule(qmps_ctx* ctx, int rule);
 int qmps_get_roto_rule(qmps_ctx* ctx, int* rule);
+/* The update rule alone, on the device: theta[i] = the step `rule` takes for the fit a sin 2x + b cos 2x + c sin x + d cos x with
+ * abcd[i][4] = (a, b, c, d).  Test / audit hook: lets a caller compare the device's decisions with scipy's
+ * `minimize_scalar(f, bounds=[-pi, pi]).x` on the same fits (qmps/tools.py:451) without an energy landscape around them. */
+int qmps_roto_rule_probe(qmps_ctx* ctx, int64_t n, const double* abcd, int rule, double* theta);
 /* read back the resident state tensors A[B][2][D][D] (tests / debugging) */
 int qmps_get_states(qmps_ctx* ctx, int64_t B, double* A);
 /* h[n_terms][4][4] complex128, row/col index = 2*s1+s2, s1 = left site

@@ -55,6 +55,7 @@ SIGNATURES = {
     'qmps_double_rotosolve': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, c_int, c_int, c_double, _dp]),
     'qmps_set_roto_rule': (c_int, [c_void_p, c_int]),
     'qmps_get_roto_rule': (c_int, [c_void_p, POINTER(c_int)]),
+    'qmps_roto_rule_probe': (c_int, [c_void_p, c_int64, _dp, c_int, _dp]),
     'qmps_get_states': (c_int, [c_void_p, c_int64, _dp]),
     'qmps_set_hamiltonian': (c_int, [c_void_p, c_int, _dp]),
     'qmps_set_env_guess': (c_int, [c_void_p, c_int64, _dp]),

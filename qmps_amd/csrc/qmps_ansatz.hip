@@ -312,6 +312,16 @@ hipError_t launch_roto_update(double* base, const double* E, const int32_t* stat
   hipLaunchKernelGGL(roto_update_kernel, dim3((R + 255) / 256), dim3(256), 0, st, base, E, status, R, P, i_ptr, n_terms, nsh, rule);
   return hipGetLastError();
 }
+// the update rule alone on caller-given fit coefficients (qmps_roto_rule_probe: parity of the device build of qmps_roto_rule.h with
+// the answers scipy gave the reference, tests/test_refshim_gpu.py)
+__global__ __launch_bounds__(64) void roto_rule_probe_kernel(const double* __restrict__ abcd, int64_t n, int rule, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = double_sinusoid_step(abcd[4 * i], abcd[4 * i + 1], abcd[4 * i + 2], abcd[4 * i + 3], rule);
+}
+hipError_t launch_roto_rule_probe(const double* abcd, int64_t n, int rule, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(roto_rule_probe_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, abcd, n, rule, out);
+  return hipGetLastError();
+}
 hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, const int* sweep_ptr, int stride, hipStream_t st) {
   hipLaunchKernelGGL(roto_record_kernel, dim3((R + 255) / 256), dim3(256), 0, st, E, hist, R, n_terms, sweep_ptr, stride);
   return hipGetLastError();

@@ -1024,6 +1024,21 @@ int qmps_set_roto_rule(qmps_ctx* c, int rule) try {
 }
 QMPS_API_CATCH
 
+int qmps_roto_rule_probe(qmps_ctx* c, int64_t n, const double* abcd, int rule, double* theta) try {
+  if (int rc = bind(c)) return rc;
+  if (!abcd || !theta || n < 1 || n > (1 << 24)) return fail(QMPS_ERR_ARG, "bad arguments");
+  if (rule != QMPS_ROTO_REFERENCE && rule != QMPS_ROTO_GLOBAL_ARGMIN) return fail(QMPS_ERR_ARG, "unknown rotosolve rule %d", rule);
+  if (int rc = ensure_scratch(c, (size_t)n * 5 * sizeof(double))) return rc;
+  double* d_in = (double*)c->d_scratch;
+  double* d_out = d_in + 4 * n;
+  HIP_TRY(hipMemcpyAsync(d_in, abcd, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(qmps::launch_roto_rule_probe(d_in, n, rule, d_out, c->stream));
+  HIP_TRY(hipMemcpyAsync(theta, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+QMPS_API_CATCH
+
 int qmps_get_roto_rule(qmps_ctx* c, int* rule) try {
   if (!c || !rule) return fail(QMPS_ERR_ARG, "null argument");
   *rule = c->roto_rule;

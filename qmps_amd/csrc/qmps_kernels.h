@@ -317,6 +317,7 @@ hipError_t launch_opt_env(const double* params, const void* h, double k, double*
                           hipStream_t st);
 // i_ptr[0] = index of the parameter being updated, i_ptr[1] = arrival counter (both zero-initialised)
 // nsh = 3: single-frequency rotosolve (shifts 0, +-pi/2); nsh = 6: double-frequency (0, pi, +-pi/2, +-pi/4)
+hipError_t launch_roto_rule_probe(const double* abcd, int64_t n, int rule, double* out, hipStream_t st);
 hipError_t launch_roto_update(double* base, const double* E, const int32_t* status, int R, int P, int* i_ptr, int n_terms,
                               int nsh, int rule, hipStream_t st);
 hipError_t launch_roto_record(const double* E, double* hist, int R, int n_terms, const int* sweep_ptr, int stride, hipStream_t st);

@@ -96,6 +96,13 @@ class EnergyEngine:
         L.ROTO_GLOBAL_ARGMIN (global minimiser of the fit: departs from the reference's trajectory)."""
         L.check(self._lib.qmps_set_roto_rule(self._ctx, int(rule)))
 
+    def roto_rule_probe(self, abcd, rule=L.ROTO_REFERENCE):
+        """The device's update step for fits a sin 2x + b cos 2x + c sin x + d cos x, abcd (n, 4) -> theta (n,)."""
+        abcd = np.ascontiguousarray(abcd, dtype=np.float64).reshape(-1, 4)
+        out = np.empty(len(abcd))
+        L.check(self._lib.qmps_roto_rule_probe(self._ctx, len(abcd), _f64(abcd), int(rule), _f64(out)))
+        return out
+
     def double_rotosolve(self, kind, params, n_sweeps=1, max_iter=10000, tol=1e-13, rule=L.ROTO_REFERENCE):
         """Device-resident DOUBLE-frequency rotosolve (qmps/tools.py:422-457): params (R, P) ->
         (energies (n_sweeps, R), params (R, P)); needs 6 R <= max_batch and a resident Hamiltonian.

@@ -514,11 +514,22 @@ def evolve_cpu_baseline(D, P, WW, seed, maxiter, budget_T=2, full=False):
     t = time.perf_counter()
     res = batched_bfgs(fb(2 * P + 1), fb(8), X, maxiter=maxiter)
     dt = time.perf_counter() - t
-    return {'value': budget_T / dt, 'unit': 'trajectory time steps/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{budget_T} trajectories x 1 time step of the same lock-step BFGS (maxiter {maxiter}), {n[0]} objective evaluations, each '
-                      f'ARPACK (scipy eigs, operator form: what xmps Map.right_fixed_point runs for the reference) on the {D * D}-dimensional map '
-                      '+ the oracle\'s gate-by-gate circuit for parameters -> tensor; numpy, 1 thread',
-            'objective_evals_per_s': n[0] / dt, 'iterations': int(res['nit']), 'mean_final_objective': float(res['fun'].mean())}
+    out = {'value': budget_T / dt, 'unit': 'trajectory time steps/s', 'cores': 1, 'kind': 'port',
+           'sample': f'{budget_T} trajectories x 1 time step of the same lock-step BFGS (maxiter {maxiter}), {n[0]} objective evaluations, each '
+                     f'ARPACK (scipy eigs, operator form: what xmps Map.right_fixed_point runs for the reference) on the {D * D}-dimensional map '
+                     '+ the oracle\'s gate-by-gate circuit for parameters -> tensor; numpy, 1 thread',
+           'objective_evals_per_s': n[0] / dt, 'iterations': int(res['nit']), 'mean_final_objective': float(res['fun'].mean())}
+    # the reference's minimiser itself on trajectory 0 of the same sample (scripts/loschmidt.py:371: minimize(obj, params, (A_, WW)) -
+    # scipy BFGS, forward differences, Wolfe search): how far the lock-step minimum is from scipy's on the same objective
+    from scipy.optimize import minimize
+    n[0] = 0
+    t = time.perf_counter()
+    f0 = fb(1)
+    sp = minimize(lambda p: float(f0(p[None])[0]), X[0].copy(), method='BFGS', options={'maxiter': maxiter})
+    out.update({'scipy_bfgs_final_objective': float(sp.fun), 'lockstep_final_objective_same_trajectory': float(res['fun'][0]),
+                'scipy_bfgs_s': time.perf_counter() - t, 'scipy_bfgs_nfev': int(n[0]), 'scipy_bfgs_nit': int(sp.nit),
+                'scipy_bfgs_what': 'scipy.optimize.minimize(method="BFGS") - the reference\'s per-step call - on trajectory 0 of this sample, same start, same oracle objective'})
+    return out
 
 
 def main_evolve(args):
@@ -735,8 +746,17 @@ def main_rotosolve(args):
     first, R, R_all = rotosolve_shard_plan(R_global, rank, world, args.shard)
     if R < 1:
         sys.exit(f'bench.py: rank {rank} owns no restarts ({R_global} over {world} ranks)')
-    depth = {2: 1, 4: 2, 8: 3, 16: 4}[D]
+    depth = getattr(args, 'depth', None) or {2: 1, 4: 2, 8: 3, 16: 4}[D]
     P = 2 * depth
+    # --ansatz shallow-full (D = 2 only): ShallowFullStateTensor(2, v), 15 angles - a universal two-qubit gate, so the D = 2 optimum
+    # -1.269909412573 (/root/reference/scripts/noisy_optimization.py:93) is reachable.  BASELINE.json configs[1] as written
+    # (ShallowCNOT, depth 1) is a FLAT landscape for TFIM: E(beta, gamma) = 0 identically, in the reference itself
+    # (tests/test_refshim_cpu.py::test_config1_landscape_is_flat_in_the_reference_itself) - it times the machinery, not an optimisation.
+    full = getattr(args, 'ansatz', 'shallow-cnot') == 'shallow-full'
+    if full:
+        if D != 2:
+            sys.exit('bench.py: --ansatz shallow-full is the D = 2 gate of the reference (represent.py:383-404)')
+        P = 15
     dist = None
     force_dist = os.environ.get('QMPS_BENCH_FORCE_DIST') == '1'
     if world > 1 or (force_dist and args.shard):
@@ -763,12 +783,13 @@ def main_rotosolve(args):
         C.build()
         n = min(len(shifted), 3000 if D <= 4 else (600 if D == 8 else 150))
         t = time.perf_counter()
-        A_cpu = np.stack([O.unitary_to_tensor(O.shallow_cnot_unitary(D, q)) for q in shifted[:n]])
+        A_cpu = np.stack([O.unitary_to_tensor(O.shallow_full_unitary(q) if full else O.shallow_cnot_unitary(D, q)) for q in shifted[:n]])
         C.energy_batch(A_cpu, h, max_iter=args.max_iter, tol=args.tol, threads=1)
         cpu = {'value': n / (time.perf_counter() - t), 'unit': 'two-site energy evals/s', 'cores': 1, 'kind': 'port',
                'sample': f'first {n} evaluations of the first parameter update\'s shifted batch: parameters -> unitary by the oracle\'s gate-by-gate '
                          'circuit model (numpy) -> tensor -> plain power iteration + closed-form energy (oracle/qmps_oracle.c), 1 thread'}
     from qmps_amd import EnergyEngine, _lib
+    kind = _lib.ANSATZ_SHALLOW_FULL if full else _lib.ANSATZ_SHALLOW_CNOT
     eng = EnergyEngine(D, nsh * R, device=local_rank)
     info = _lib.device_info(local_rank)
     eng.set_hamiltonian(h)
@@ -799,12 +820,12 @@ def main_rotosolve(args):
         eng.probe_fp64_tflops()
     sweeps_w = max(1, min(args.warmup, 64))
     sweeps = max(1, min(args.steps, 256))
-    run(_lib.ANSATZ_SHALLOW_CNOT, p0, sweeps_w, max_iter=args.max_iter, tol=args.tol)
+    run(kind, p0, sweeps_w, max_iter=args.max_iter, tol=args.tol)
     eng.sync()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    hist, pfin = run(_lib.ANSATZ_SHALLOW_CNOT, p0, sweeps, max_iter=args.max_iter, tol=args.tol)
+    hist, pfin = run(kind, p0, sweeps, max_iter=args.max_iter, tol=args.tol)
     reduced = None
     if reducer is not None:
         # the path's exchange step for sharded restarts, inside the timed region
@@ -823,7 +844,7 @@ def main_rotosolve(args):
     # HIP events on stand-alone launches of that very batch (inside the run the sweep is a replayed hipGraph: no events there)
     roof = None
     if rank == 0:
-        eng.set_ansatz_params(_lib.ANSATZ_SHALLOW_CNOT, shifted)
+        eng.set_ansatz_params(kind, shifted)
         eng.set_kernel_timing_period(1)
         for _ in range(12):
             eng.launch(nsh * R, max_iter=args.max_iter, tol=args.tol, solver='direct', store_env=(D != 4))
@@ -845,7 +866,7 @@ def main_rotosolve(args):
                'unit': 'two-site energy evals/s', 'n_gpus': world, 'steps': sweeps, 'warmup': sweeps_w,
                'ms_per_step': elapsed / sweeps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if args.shard else 'weak', 'vs_baseline': None,
                'dtype': 'f64', 'data': 'synthetic',
-               'config': {'workload': f'device-resident {"double-frequency " if nsh == 6 else ""}rotosolve, {h_name}, D={D}, ShallowCNOT depth {depth} '
+               'config': {'workload': f'device-resident {"double-frequency " if nsh == 6 else ""}rotosolve, {h_name}, D={D}, {"ShallowFull" if full else f"ShallowCNOT depth {depth}"} '
                                       f'({P} parameters), {R} restarts x {nsh} shifts = {nsh * R} evaluations per parameter update, one step = one sweep; '
                                       'the whole run is ONE C call (fixed costs - allocation, graph capture, copies - included)',
                           'baseline_config': {2: 'BASELINE.json configs[1]', 4: 'BASELINE.json configs[2] (as an optimiser loop)', 8: 'BASELINE.json configs[3]', 16: 'BASELINE.json configs[4] (energy objective)'}[D],
@@ -853,6 +874,7 @@ def main_rotosolve(args):
                           'n_params': P, 'us_per_parameter_update': elapsed / (sweeps * P) * 1e6,
                           'best_energy': float(np.nanmin(hist[-1])), 'mean_energy_first_sweep': float(np.nanmean(hist[0])),
                           'mean_energy_last_sweep': float(np.nanmean(hist[-1])), 'exact_ground_state_energy': (-4 / np.pi) if h_name.startswith('TFIM') else None,
+                          'D2_optimum': -1.269909412573 if (D == 2 and h_name.startswith('TFIM')) else None, 'ansatz': 'ShallowFullStateTensor' if full else 'ShallowCNOTStateTensor', 'depth': None if full else depth,
                           'restarts_global': R_all, 'restarts_this_rank': R, 'sharded': bool(args.shard),
                           'summed_cost_last_sweep_all_ranks': None if reduced is None else float(reduced[0][-1]),
                           'restarts_counted_all_ranks': None if reduced is None else reduced[1],
@@ -878,6 +900,8 @@ def other_configs(args, budget_s=60.0):
     t0 = time.perf_counter()
     plan = [
         ('config1_rotosolve_D2_b4096', dict(workload='rotosolve', D=2, batch=4096, steps=160, warmup=8, hamiltonian=None, double_frequency=False, shard=False)),
+        # the same configuration with a landscape: the D = 2 universal gate (15 angles), double-frequency rule of Optimizer('Rotosolve')
+        ('config1_family_rotosolve_D2_shallowfull_double', dict(workload='rotosolve', D=2, batch=4096, steps=24, warmup=2, hamiltonian=None, double_frequency=True, shard=False, ansatz='shallow-full', no_cpu_baseline=True)),
         ('config3_rotosolve_D8_xxz_256x3', dict(workload='rotosolve', D=8, batch=768, steps=160, warmup=8, hamiltonian=None, double_frequency=False, shard=False)),
         ('config4_evolve_D16_depth4_T256', dict(workload='evolve', D=16, batch=256, steps=10, warmup=3, tol=1e-12, carry_hessian=None)),
         # the same time evolution with more trajectories than the configuration names (the lock-step groups of qmps_evolve_bfgs)
@@ -905,7 +929,7 @@ def other_configs(args, budget_s=60.0):
                      'roofline': {k: r.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'hbm_frac', 'kernel', 'kernel_ms', 'kernel_share_of_wall') if k in r},
                      'cpu_baseline': d.get('cpu_baseline'), 'workload': d['config'].get('workload'),
                      'config': {k: v for k, v in d['config'].items() if k in ('baseline_config', 'hamiltonian', 'D', 'restarts', 'n_params', 'shifts', 'us_per_parameter_update', 'mean_energy_first_sweep',
-                                                                                'mean_energy_last_sweep', 'best_energy', 'exact_ground_state_energy', 'not_converged_or_not_pd',
+                                                                                'mean_energy_last_sweep', 'best_energy', 'exact_ground_state_energy', 'D2_optimum', 'ansatz', 'depth', 'not_converged_or_not_pd',
                                                                                 'trajectories_per_gpu', 'driver', 'lockstep_groups', 'bfgs_iterations_per_step', 'carry_hessian', 'not_converged',
                                                                                 'mean_final_objective', 'kernel_share_of_wall', 'solver_rounds_mean_gradient_batches',
                                                                                 'solver_rounds_max_gradient_batches')},
@@ -953,6 +977,7 @@ def main():
                     help='evolve workload: start the BFGS of every time step from the identity (what scipy - the reference - does) instead of '
                          'the inverse Hessians the previous step ended with; the default run reports this variant as the extra `identity_start`')
     ap.add_argument('--bfgs-iters', type=int, default=30, help='evolve workload: cap on BFGS iterations per time step')
+    ap.add_argument('--depth', type=int, default=None, help='rotosolve workload: layers of the ShallowCNOT ansatz (default log2 D)')
     ap.add_argument('--double-frequency', action='store_true', help='rotosolve workload: six shifts per parameter (qmps/tools.py:422-457)')
     # defaults: the chip needs tens of ms of sustained load before its clocks settle
     ap.add_argument('--steps', type=int, default=2000)

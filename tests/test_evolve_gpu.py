@@ -278,6 +278,50 @@ def test_lockstep_bfgs_time_evolution(D, P, T, iters):
         assert s['evaluations'] >= 2 * T * sum(n + 1 for n in info['nit'])      # two solves per iterate and iteration (+ re-evaluations after a rejected full step)
 
 
+def scipy_bfgs_step(kind, D, x_start, WW, **opts):
+    """One time step the reference's way (qmps/new_time_evolve.py:284, scripts/loschmidt.py:367-375): scipy.optimize.minimize(obj,
+    params, (A_, WW)) - BFGS with forward-difference gradients and a Wolfe line search, started from the previous parameters - on
+    the ORACLE's objective -sqrt|eta| (dense eigen-solve)."""
+    from scipy.optimize import minimize
+    A = ER.tensor(kind, D, x_start)
+    return minimize(lambda p: ER.objective(kind, D, A, p, WW), np.array(x_start, dtype=float), method='BFGS', options=opts or None)
+
+
+@pytest.mark.parametrize('kind,P,driver', [(2, 15, 'device'), (2, 15, 'host'), (0, 8, 'device')])
+def test_lockstep_bfgs_reaches_scipys_minima_at_the_reference_case(kind, P, driver, engine_factory):
+    """how far are the lock-step driver's per-step minima (central differences / eigen-solved neighbours,
+    Armijo ladder) from scipy's BFGS (forward differences, Wolfe search) on the same objective?  The reference's own case: D = 2,
+    ShallowFullStateTensor with 15 angles (new_time_evolve.py:186-187, 276-292), 5 time steps, 8 trajectories; every time step of
+    every trajectory is ALSO minimised by scipy from the same starting point against the same reference state.
+    Bar: final objective within 1e-6 of scipy's (either way: whoever stops lower), and the two minimisers describe the same
+    physical state: |<A_dev|A_scipy>| per site >= 1 - 1e-6."""
+    rng = np.random.default_rng(2024 + kind)
+    T, n_steps = 8, 5
+    X0 = rng.standard_normal((T, P))
+    WW = WW_of(0.05)
+    eng = engine_factory(2, T * (2 * P + 1))
+    run = eng.evolve_bfgs_device if driver == 'device' else eng.evolve_bfgs
+    dev = run(kind, X0, WW, n_steps=n_steps, maxiter=200, tol=1e-13)
+    prev = X0
+    worst_f, worst_fid, scipy_lower, dev_lower = 0.0, 1.0, 0, 0
+    for step in range(n_steps):
+        for t in range(T):
+            res = scipy_bfgs_step(kind, 2, prev[t], WW)
+            f_dev = dev['fun'][step, t]
+            # the recorded value IS the oracle's objective at the device's parameters
+            assert abs(ER.objective(kind, 2, ER.tensor(kind, 2, prev[t]), dev['params_hist'][step, t], WW) - f_dev) < F_TOL
+            worst_f = max(worst_f, abs(f_dev - res.fun))
+            scipy_lower += res.fun < f_dev - 1e-9
+            dev_lower += f_dev < res.fun - 1e-9
+            fid = abs(O.overlap_eta(ER.tensor(kind, 2, dev['params_hist'][step, t]), ER.tensor(kind, 2, res.x), np.eye(4))[0])
+            worst_fid = min(worst_fid, fid)
+        prev = dev['params_hist'][step]
+    print(f'lock-step ({driver}) vs scipy BFGS, kind {kind}: max |f_dev - f_scipy| = {worst_f:.2e}, min fidelity {worst_fid:.9f}, '
+          f'scipy lower in {scipy_lower}, device lower in {dev_lower} of {n_steps * T} minimisations')
+    assert worst_f < 1e-6 and worst_fid > 1 - 1e-6
+    assert dev['fun'].mean() < -0.999
+
+
 def test_config4_full_size_256_trajectories():
     """BASELINE.json configs[4] at its stated size: TFIM quench, D = 16, depth 4 (8 angles), 256 trajectories (the
     evolution was only ever tested with T <= 32).  Two time steps of the default driver; the recorded objectives are the ORACLE's

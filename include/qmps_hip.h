@@ -136,6 +136,9 @@ extern "C" {
  *                         D = 16: cold starts only - warm-started batches run the lean loop)
  *   QMPS_D16_ONE_WAVE     D = 16 overlap objective, batches above 2 048 candidates: one wave per candidate with a static stride
  *                         (round 2) instead of four waves per candidate drawn from a work queue (no Krylov fall-back)
+ *   QMPS_EVOLVE_HOST_ALGEBRA  qmps_evolve_bfgs at D = 8, 16: directions, Armijo tests, H^-1 updates and masks on the HOST between two
+ *                         gradient evaluations (the round-4 loop: a synchronisation and two staged copies per evaluation) instead of
+ *                         in kernels on device-resident state with the host enqueueing chains of iterations.  Same numbers, bit for bit.
  *   QMPS_NO_KRYLOV        D = 8, 16 fixed-point solves: the power method alone, to max_rounds (same results wherever it converges;
  *                         ~1/(1 - |eta_2 / eta_1|) steps)
  * Everything else that used to be tunable from the environment (thresholds, schedules: profiles/EXPERIMENTS.md) is compiled

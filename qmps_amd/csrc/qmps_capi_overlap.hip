@@ -355,6 +355,87 @@ int qmps_overlap_eval_ansatz(qmps_ctx* c, int64_t B, int kind, int n_params, con
 }
 QMPS_API_CATCH
 
+namespace {
+// One gradient evaluation of T iterates, ENQUEUED on the context stream and nothing else: [right + left fixed points] beside [the
+// 2 P central-difference neighbours' tensors], then [G + probes].  The iterates' tensors are in d_A[0, T), their parameter rows at
+// d_src (device).  `beside`: the neighbour tensors are built on the second stream, which waits for c->aux_fork - the caller records
+// it on c->stream once d_src is complete.  allow_lazy_krylov: the Krylov fall-back of the two solves is NOT launched behind the
+// power kernels (the caller looks at the statuses on the host and asks for the second pass); otherwise it always runs (it costs an
+// empty launch when nothing was handed over) and the statuses behind this function are final.
+// Outputs: d_f[0, T) objective of the iterates, d_f[T, T + 2 P T) of the neighbours, d_status[0, T) / [T, 2 T) right / left solves,
+// d_r / d_y the fixed points (the next call's warm start).  Shared by qmps_overlap_gradient (host loop) and the device-resident
+// lock-step BFGS of qmps_evolve_bfgs.
+struct GradPass {
+  qmps::OverlapArgs a, l;
+  qmps::OverlapGradArgs g;
+  bool lazy_krylov = false;
+};
+int enqueue_gradient_kernels(qmps_ctx* c, int64_t T, int kind, int P, const double* d_src, double h, int max_rounds, double tol, bool warm, bool two_sided_f,
+                             const unsigned char* mask, bool beside, bool allow_lazy_krylov, GradPass& gp) {
+  const bool squaring = overlap_squares(c);       // D = 4: the right fixed point comes from the squaring kernel (largest column)
+  qmps::OverlapArgs& a = gp.a;
+  memset(&a, 0, sizeof(a));
+  a.A = c->d_ref; a.Bt = c->d_A; a.WW = c->d_ww; a.eta = c->d_eta; a.f_out = c->d_f; a.r_out = c->d_r;
+  a.x_in = (warm && !squaring) ? c->d_r : nullptr;
+  a.stats = c->d_ostats; a.iters = c->d_iters; a.status = c->d_status; a.B = T; a.a_shared = 0;
+  a.max_rounds = squaring && max_rounds > 60 ? 60 : max_rounds; a.tol = tol;
+  a.active = mask;
+  // The Krylov fall-back of the two solves is launched only if a status asks for it (below): behind every batch, it cost a warm
+  // batch of 256 iterates - which never hands anything over - an empty launch and a launch gap, ~10 us of ~200.
+  bool lazy_krylov = false;
+  const size_t nD = (size_t)c->D * c->D;
+  // the left fixed points: power method on the adjoint map; results behind the iterates' (eta, rounds, status at [T, 2T))
+  qmps::OverlapArgs& l = gp.l;
+  l = a;
+  l.adjoint = 1; l.eta = (char*)c->d_eta + (size_t)T * 16; l.f_out = nullptr; l.r_out = c->d_y; l.x_in = warm ? c->d_y : nullptr;
+  l.iters = c->d_iters + T; l.status = c->d_status + T; l.max_rounds = max_rounds;
+  if (c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr && documented_switch("QMPS_D16_ONE_WAVE") == nullptr) {
+    // both solves in ONE launch: the iteration chains are latency-bound, so the left solve rides along (more than 2 048
+    // iterates: the workgroups draw them from two queues)
+    a.no_deflation = l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
+    if (int e = arm_queue(c, a, 0)) return e;
+    if (int e = arm_queue(c, l, 1)) return e;
+    if (int e = arm_krylov(c, a, 0)) return e;
+    if (int e = arm_krylov(c, l, 1)) return e;
+    lazy_krylov = allow_lazy_krylov && a.krylov_after > 0 && l.krylov_after > 0 && a.kry_counter != nullptr && l.kry_counter != nullptr;
+    HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream, !lazy_krylov));
+  } else if (c->D == 8) {
+    // D = 8: the same - one launch, the left solves on the SIMDs the right ones leave idle
+    a.no_deflation = l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
+    if (int e = arm_krylov(c, a, 0)) return e;
+    if (int e = arm_krylov(c, l, 1)) return e;
+    lazy_krylov = allow_lazy_krylov && a.krylov_after > 0 && l.krylov_after > 0 && a.kry_counter != nullptr && l.kry_counter != nullptr;
+    HIP_TRY(qmps::launch_overlap_pair_d8(a, l, c->stream, !lazy_krylov));
+  } else if (c->D == 4 && squaring) {
+    // D = 4: largest column AND largest row of the squared map in one launch (right and left fixed point, whatever the gap)
+    a.l_out = c->d_y;
+    HIP_TRY(qmps::launch_overlap_d(c->D, a, true, c->stream));
+  } else {
+    a.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
+    HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : documented_switch("QMPS_D16_BLOCK") == nullptr, c->stream));
+    // (D = 4: the squaring kernel again - the left fixed point is the largest row of the squared map, whatever the spectral gap)
+    if (c->D == 4 && squaring) l.max_rounds = a.max_rounds;
+    l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
+    HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 4 ? squaring : (c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr), c->stream));
+  }
+  if (beside) {
+    HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
+    HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, d_src, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->aux_stream, mask));
+    HIP_TRY(hipEventRecord(c->aux_join, c->aux_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->aux_join, 0));
+  }
+  else HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, d_src, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->stream, mask));
+  qmps::OverlapGradArgs& g = gp.g;
+  memset(&g, 0, sizeof(g));
+  g.A = c->d_ref; g.WW = c->d_ww; g.r = c->d_r; g.y = c->d_y; g.G = c->d_scratch; g.yr = (char*)c->d_scratch + (size_t)T * 4 * nD * 16;
+  g.Bt = (char*)c->d_A + (size_t)T * tensor_bytes(c); g.f_out = c->d_f + T; g.T = T; g.G2P = 2 * P; g.active = mask;
+  if (two_sided_f) { g.Bc = c->d_A; g.fc_out = c->d_f; }       // (overwrites the right solve's own estimate)
+  HIP_TRY(qmps::launch_overlap_grad(c->D, g, c->stream));
+  gp.lazy_krylov = lazy_krylov;
+  return QMPS_OK;
+}
+}  // namespace
+
 int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const double* params, double h, int max_rounds, double tol,
                           int flags, double* f_out, double* g_out, int32_t* status_out) try {
   if (int rc = bind(c)) return rc;
@@ -399,13 +480,6 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   }
   if (!rc) rc = ensure_tensors(c);
   if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
-  const bool squaring = overlap_squares(c);       // D = 4: the right fixed point comes from the squaring kernel (largest column)
-  qmps::OverlapArgs a;
-  memset(&a, 0, sizeof(a));
-  a.A = c->d_ref; a.Bt = c->d_A; a.WW = c->d_ww; a.eta = c->d_eta; a.f_out = c->d_f; a.r_out = c->d_r;
-  a.x_in = (warm && !squaring) ? c->d_r : nullptr;
-  a.stats = c->d_ostats; a.iters = c->d_iters; a.status = c->d_status; a.B = T; a.a_shared = 0;
-  a.max_rounds = squaring && max_rounds > 60 ? 60 : max_rounds; a.tol = tol;
   const unsigned char* mask = nullptr;
   if (int e = flush_mask(c)) return e;
   if (c->active_n > 0) {
@@ -413,65 +487,22 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
     mask = c->d_active;
     c->active_n = 0;
   }
-  a.active = mask;
   // HIP events around the WHOLE gradient evaluation (right solve, left solve, neighbour tensors, G, probes): qmps_kernel_time
   c->dominant = c->D == 16 ? "overlap_mfma_d16_kernel + adjoint + neighbour probes" : "overlap solve + adjoint + neighbour probes";
   c->timed = !c->capturing && c->timing_period > 0 && c->launches % c->timing_period == 0;
   const int tslot = (int)(c->samples % qmps_ctx::kRing);
   if (c->timed) HIP_TRY(hipEventRecord(c->kev0[tslot], c->stream));
+  if (beside && c->fork_after_copy) {        // (the parameter upload took another path: it did not record the fork)
+    c->fork_after_copy = nullptr;
+    return fail(QMPS_ERR_STATE, "qmps_overlap_gradient: the parameter upload did not record the fork event");
+  }
   // The Krylov fall-back of the two solves is launched only if a status asks for it (below): behind every batch, it cost a warm
   // batch of 256 iterates - which never hands anything over - an empty launch and a launch gap, ~10 us of ~200.
-  bool lazy_krylov = false;
-  // the left fixed points: power method on the adjoint map; results behind the iterates' (eta, rounds, status at [T, 2T))
-  qmps::OverlapArgs l = a;
-  l.adjoint = 1; l.eta = (char*)c->d_eta + (size_t)T * 16; l.f_out = nullptr; l.r_out = c->d_y; l.x_in = warm ? c->d_y : nullptr;
-  l.iters = c->d_iters + T; l.status = c->d_status + T; l.max_rounds = max_rounds;
-  if (c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr && documented_switch("QMPS_D16_ONE_WAVE") == nullptr) {
-    // both solves in ONE launch: the iteration chains are latency-bound, so the left solve rides along (more than 2 048
-    // iterates: the workgroups draw them from two queues)
-    a.no_deflation = l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
-    if (int e = arm_queue(c, a, 0)) return e;
-    if (int e = arm_queue(c, l, 1)) return e;
-    if (int e = arm_krylov(c, a, 0)) return e;
-    if (int e = arm_krylov(c, l, 1)) return e;
-    lazy_krylov = a.krylov_after > 0 && l.krylov_after > 0 && a.kry_counter != nullptr && l.kry_counter != nullptr;
-    HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream, !lazy_krylov));
-  } else if (c->D == 8) {
-    // D = 8: the same - one launch, the left solves on the SIMDs the right ones leave idle
-    a.no_deflation = l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
-    if (int e = arm_krylov(c, a, 0)) return e;
-    if (int e = arm_krylov(c, l, 1)) return e;
-    lazy_krylov = a.krylov_after > 0 && l.krylov_after > 0 && a.kry_counter != nullptr && l.kry_counter != nullptr;
-    HIP_TRY(qmps::launch_overlap_pair_d8(a, l, c->stream, !lazy_krylov));
-  } else if (c->D == 4 && squaring) {
-    // D = 4: largest column AND largest row of the squared map in one launch (right and left fixed point, whatever the gap)
-    a.l_out = c->d_y;
-    HIP_TRY(qmps::launch_overlap_d(c->D, a, true, c->stream));
-  } else {
-    a.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
-    HIP_TRY(qmps::launch_overlap_d(c->D, a, c->D == 4 ? squaring : documented_switch("QMPS_D16_BLOCK") == nullptr, c->stream));
-    // (D = 4: the squaring kernel again - the left fixed point is the largest row of the squared map, whatever the spectral gap)
-    if (c->D == 4 && squaring) l.max_rounds = a.max_rounds;
-    l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
-    HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 4 ? squaring : (c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr), c->stream));
-  }
-  if (beside) {
-    if (c->fork_after_copy) {        // (the parameter upload took another path: fork here)
-      c->fork_after_copy = nullptr;
-      return fail(QMPS_ERR_STATE, "qmps_overlap_gradient: the parameter upload did not record the fork event");
-    }
-    HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
-    HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->aux_stream, mask));
-    HIP_TRY(hipEventRecord(c->aux_join, c->aux_stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->aux_join, 0));
-  }
-  else HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, c->d_params, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->stream, mask));
-  qmps::OverlapGradArgs g;
-  memset(&g, 0, sizeof(g));
-  g.A = c->d_ref; g.WW = c->d_ww; g.r = c->d_r; g.y = c->d_y; g.G = c->d_scratch; g.yr = (char*)c->d_scratch + (size_t)T * 4 * nD * 16;
-  g.Bt = (char*)c->d_A + (size_t)T * tensor_bytes(c); g.f_out = c->d_f + T; g.T = T; g.G2P = 2 * P; g.active = mask;
-  if (flags & QMPS_OVERLAP_TWO_SIDED_F) { g.Bc = c->d_A; g.fc_out = c->d_f; }       // (overwrites the right solve's own estimate)
-  HIP_TRY(qmps::launch_overlap_grad(c->D, g, c->stream));
+  GradPass gp;
+  if (int e = enqueue_gradient_kernels(c, T, kind, P, c->d_params, h, max_rounds, tol, warm, (flags & QMPS_OVERLAP_TWO_SIDED_F) != 0, mask, beside, true, gp)) return e;
+  const bool lazy_krylov = gp.lazy_krylov;
+  qmps::OverlapArgs &a = gp.a, &l = gp.l;
+  qmps::OverlapGradArgs& g = gp.g;
   if (c->timed) { HIP_TRY(hipEventRecord(c->kev1[tslot], c->stream)); c->samples++; }
   c->launches++;
   // f of the iterates and of their neighbours are contiguous in d_f: one copy; statuses of both solves: one copy (pinned staging)
@@ -630,7 +661,242 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     return m >= bound;
   };
   int rc = QMPS_OK;
-  for (int step = 0; step < n_steps && rc == QMPS_OK; ++step) {
+  // ---- D = 8, 16: the algebra between two evaluations on the device (qmps_evolve_lockstep.hip) -------------------------------
+  // x, g, H^-1, f, the masks and a control word live in HBM; the host enqueues [direction -> evaluation -> accept] chains and reads
+  // the control word back once per chain.  The iteration in which a trajectory rejects the full step is finished by the host
+  // code below (ladder, gradient at the accepted point, update) on a downloaded copy of the state - the same code, the same
+  // decisions.  QMPS_EVOLVE_HOST_ALGEBRA selects the host loop for everything (the round-4 driver; the test-suite runs both).
+  const bool dev_algebra = two_sided && (c->D == 8 || c->D == 16) && documented_switch("QMPS_EVOLVE_HOST_ALGEBRA") == nullptr &&
+                           documented_switch("QMPS_D16_BLOCK") == nullptr && documented_switch("QMPS_D16_ONE_WAVE") == nullptr;
+  struct {
+    double *X, *G, *Gs, *Hy, *H, *F, *Dv, *slope, *Xc, *fh, *ph;
+    int* ctl;
+    unsigned char *active, *eff, *need;
+  } dv = {};
+  int chain_len = 4;
+  if (const char* e = tuning_knob("QMPS_EVOLVE_CHAIN")) chain_len = atoi(e) > 0 ? atoi(e) : 4;
+  if (dev_algebra) {
+    const size_t n_dbl = 6 * TP + TP * P + 2 * (size_t)T + (size_t)n_steps * 2 * T + (size_t)n_steps * TP;
+    const size_t bytes = n_dbl * sizeof(double) + 16 * sizeof(int) + 3 * (((size_t)T + 7) / 8 * 8) + 64;
+    if (bytes > c->d_lock_bytes) {
+      if (c->d_lock) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_lock)); }
+      c->d_lock = nullptr; c->d_lock_bytes = 0;
+      HIP_TRY(hipMalloc(&c->d_lock, bytes));
+      c->d_lock_bytes = bytes;
+    }
+    if (!c->h_ctl) HIP_TRY(hipHostMalloc((void**)&c->h_ctl, 64, hipHostMallocDefault));
+    double* q = (double*)c->d_lock;
+    dv.X = q; q += TP; dv.G = q; q += TP; dv.Gs = q; q += TP; dv.Hy = q; q += TP; dv.Dv = q; q += TP; dv.Xc = q; q += TP;
+    dv.H = q; q += TP * P; dv.F = q; q += T; dv.slope = q; q += T; dv.fh = q; q += (size_t)n_steps * 2 * T; dv.ph = q; q += (size_t)n_steps * TP;
+    dv.ctl = (int*)q;
+    dv.active = (unsigned char*)(dv.ctl + 16); dv.eff = dv.active + ((size_t)T + 7) / 8 * 8; dv.need = dv.eff + ((size_t)T + 7) / 8 * 8;
+    if ((rc = ensure_overlap_outputs(c))) return rc;
+    if (!c->d_y) HIP_TRY(hipMalloc(&c->d_y, (size_t)c->max_batch * env_bytes(c)));
+    { const size_t nD = (size_t)c->D * c->D; if ((rc = ensure_scratch(c, (size_t)T * (4 * nD + 1) * 16 + 256))) return rc; }
+    if ((rc = ensure_refs(c, T))) return rc;
+    if (!c->aux_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
+    }
+    HIP_TRY(hipMemcpyAsync(dv.X, X.data(), TP * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dv.H, Hinv.data(), TP * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if ((rc = set_ww(c, WW))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));       // (X, Hinv are pageable host vectors)
+    c->window = 0;
+    c->have_env = false; c->have_guess = false; c->have_overlap_x = false; c->acc_pending = false; c->partials_B = -1;
+    c->ans_have = false; c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0; c->tensors_valid = false; c->n_states = 0;
+  }
+  const bool beside_dev = T <= 1024 && !c->one_stream;
+  auto lock_args = [&](int step, bool reset_h) {
+    qmps::LockstepArgs la;
+    memset(&la, 0, sizeof(la));
+    la.X = dv.X; la.G = dv.G; la.Gs = dv.Gs; la.Hy = dv.Hy; la.H = dv.H; la.F = dv.F; la.Dv = dv.Dv; la.slope = dv.slope; la.Xc = dv.Xc;
+    la.fb = c->d_f; la.st = c->d_status; la.active = dv.active; la.eff = dv.eff; la.need = dv.need; la.ctl = dv.ctl;
+    la.fh_start = dv.fh + (size_t)step * 2 * T;
+    la.T = (int)T; la.P = P; la.maxiter = maxiter; la.reset_h = reset_h ? 1 : 0; la.h = h; la.gtol = gtol; la.c1 = c1; la.alpha0 = alphas[0];
+    return la;
+  };
+  // one evaluation of the rows at d_src (iterate tensors, both fixed points, neighbours, probes), enqueued only
+  auto dev_gradient = [&](const double* d_src, const unsigned char* mask) -> int {
+    HIP_TRY(qmps::launch_ansatz(c->D, kind, d_src, P, c->d_A, T, c->stream));
+    if (beside_dev) HIP_TRY(hipEventRecord(c->aux_fork, c->stream));
+    c->timed = counters_out != nullptr;
+    const int tslot = (int)(c->samples % qmps_ctx::kRing);
+    if (c->timed) HIP_TRY(hipEventRecord(c->kev0[tslot], c->stream));
+    c->dominant = c->D == 16 ? "overlap_mfma_d16_kernel + adjoint + neighbour probes" : "overlap solve + adjoint + neighbour probes";
+    GradPass gp;
+    if (int e = enqueue_gradient_kernels(c, T, kind, P, d_src, h, grad_rounds, grad_tol, warm, true, mask, beside_dev, false, gp)) return e;
+    if (c->timed) { HIP_TRY(hipEventRecord(c->kev1[tslot], c->stream)); c->samples++; }
+    c->launches++;
+    warm = true;
+    c->grad_warm_T = T;
+    return QMPS_OK;
+  };
+  for (int step = 0; step < n_steps && rc == QMPS_OK && dev_algebra; ++step) {
+    const bool reset_h = !(carry && (step > 0 || ((flags & QMPS_BFGS_WARM) != 0 && hinv)));
+    HIP_TRY(qmps::launch_ansatz(c->D, kind, dv.X, P, c->d_ref, T, c->stream));        // the step's references: A_t = tensor(current parameters)
+    c->overlap_refs = T;
+    c->overlap_group = 0;
+    if ((rc = dev_gradient(dv.X, nullptr))) break;
+    HIP_TRY(qmps::launch_lockstep_begin(lock_args(step, reset_h), c->stream));
+    n_grad += 1.0;
+    nfev += (double)T * (2 * P + 1);
+    int nit = 0;
+    const qmps::LockstepArgs la = lock_args(step, false);
+    for (;;) {
+      // with counters: one iteration per chain, so that every evaluation's event pair can be read (the timed region runs without)
+      const int K = counters_out ? 1 : (chain_len < maxiter - nit ? chain_len : maxiter - nit);
+      for (int i = 0; i < K; ++i) {
+        HIP_TRY(qmps::launch_lockstep_direction(la, c->stream));
+        if ((rc = dev_gradient(dv.Xc, dv.eff))) break;
+        HIP_TRY(qmps::launch_lockstep_accept(la, c->stream));
+      }
+      if (rc) break;
+      HIP_TRY(hipMemcpyAsync(c->h_ctl, dv.ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      const int n_act = c->h_ctl[0], n_need = c->h_ctl[1], nit_dev = c->h_ctl[2], stop = c->h_ctl[3];
+      if (counters_out && K > 0) {
+        float ms = 0.f;
+        if ((nit_dev > nit || stop) && qmps_kernel_time(c, 1, &ms, nullptr, 0) == QMPS_OK) grad_ms += ms;
+      }
+      n_grad += (double)(nit_dev - nit) + (stop ? 1.0 : 0.0);
+      nfev += ((double)(nit_dev - nit) + (stop ? 1.0 : 0.0)) * (double)T * (2 * P + 1);
+      nit = nit_dev;
+      if (stop) {
+        // ---- the rare path: some trajectories rejected the full step.  Their iteration is finished here, by the host loop's own
+        // expressions, on a copy of the state; the trajectories that accepted are already updated on the device.
+        (void)n_need;
+        std::vector<double> fb0(T);
+        std::vector<int32_t> st0(2 * (size_t)T);
+        HIP_TRY(hipMemcpyAsync(X.data(), dv.X, TP * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(g.data(), dv.G, TP * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(Hinv.data(), dv.H, TP * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(f.data(), dv.F, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(d.data(), dv.Dv, TP * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(slope.data(), dv.slope, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(active.data(), dv.active, (size_t)T, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(need.data(), dv.need, (size_t)T, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(fb0.data(), c->d_f, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(st0.data(), c->d_status, 2 * (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        // the ladder of the flagged trajectories (rungs 1 .. NA - 1; rung 0 is the rejected full step)
+        for (int64_t t = 0; t < T; ++t) {
+          double* Ft = &Fc[(size_t)t * NA];
+          for (int r = 0; r < NA; ++r) Ft[r] = INFINITY;
+          if (need[t]) {
+            const double v = (st0[t] == qmps::QMPS_ST_OK && st0[T + t] == qmps::QMPS_ST_OK) ? fb0[t] : nan;
+            Ft[0] = std::isfinite(v) ? v : INFINITY;
+          }
+        }
+        if (G > 0) {
+          cand.resize((size_t)T * G * P);
+          Fl.resize((size_t)T * G);
+          stl.resize((size_t)T * G);
+          for (int64_t t = 0; t < T; ++t)
+            for (int64_t r = 0; r < G; ++r)
+              for (int k = 0; k < P; ++k) cand[((size_t)t * G + r) * P + k] = X[(size_t)t * P + k] + alphas[r + 1] * d[(size_t)t * P + k];
+          if ((rc = qmps_overlap_set_group(c, G))) break;
+          if ((rc = qmps_overlap_set_active(c, T, need.data()))) break;
+          c->warm_from_group = (c->grad_warm_T == T) ? G : 0;      // (resident: the fixed points of the rejected full steps)
+          rc = qmps_overlap_eval_ansatz(c, T * G, kind, P, cand.data(), ladder_rounds, tol, 0, Fl.data(), stl.data());
+          (void)qmps_overlap_set_group(c, 0);
+          if (rc) break;
+          n_ladder += 1.0;
+          nfev += (double)T * G;
+          for (int64_t t = 0; t < T; ++t)
+            for (int64_t r = 0; r < G; ++r) {
+              const double v = (need[t] && stl[(size_t)t * G + r] == qmps::QMPS_ST_OK) ? Fl[(size_t)t * G + r] : nan;
+              Fc[(size_t)t * NA + r + 1] = std::isfinite(v) ? v : INFINITY;
+            }
+        }
+        for (int64_t t = 0; t < T; ++t) {
+          moved[t] = 0;
+          for (int k = 0; k < P; ++k) { s[(size_t)t * P + k] = 0.0; Xn[(size_t)t * P + k] = X[(size_t)t * P + k]; }
+          if (!need[t]) continue;
+          const double* Ft = &Fc[(size_t)t * NA];
+          int first = -1, best = 0;
+          for (int r = 0; r < NA; ++r) {
+            if (first < 0 && Ft[r] <= f[t] + c1 * alphas[r] * slope[t]) first = r;
+            if (Ft[r] < Ft[best]) best = r;
+          }
+          if (first < 0) first = best;
+          moved[t] = (Ft[first] < f[t]) ? 1 : 0;
+          const double a = moved[t] ? alphas[first] : 0.0;
+          for (int k = 0; k < P; ++k) {
+            s[(size_t)t * P + k] = a * d[(size_t)t * P + k];
+            Xn[(size_t)t * P + k] = X[(size_t)t * P + k] + s[(size_t)t * P + k];
+          }
+        }
+        if ((rc = value_and_grad(Xn.data(), fn.data(), gn.data(), need.data()))) break;
+        int n_active_now = 0;
+        for (int64_t t = 0; t < T; ++t) {
+          if (need[t]) {
+            double* gt = &g[(size_t)t * P];
+            const double* gnt = &gn[(size_t)t * P];
+            const double* sv = &s[(size_t)t * P];
+            if (moved[t]) {
+              double sy = 0.0, ss = 0.0, yy = 0.0;
+              for (int k = 0; k < P; ++k) { const double y = gnt[k] - gt[k]; sy += sv[k] * y; ss += sv[k] * sv[k]; yy += y * y; }
+              if (sy > 1e-12 * sqrt(ss * yy) && sy > 0.0) {
+                double* Ht = &Hinv[(size_t)t * P * P];
+                const double rho = 1.0 / sy;
+                double yHy = 0.0;
+                for (int a = 0; a < P; ++a) {
+                  double acc = 0.0;
+                  for (int b = 0; b < P; ++b) acc += Ht[a * P + b] * (gnt[b] - gt[b]);
+                  Hy[a] = acc;
+                }
+                for (int a = 0; a < P; ++a) yHy += (gnt[a] - gt[a]) * Hy[a];
+                const double coef = rho * (1.0 + rho * yHy);
+                for (int a = 0; a < P; ++a)
+                  for (int b = 0; b < P; ++b) Ht[a * P + b] = Ht[a * P + b] - (rho * sv[a] * Hy[b] + rho * sv[b] * Hy[a]) + coef * sv[a] * sv[b];
+              }
+              f[t] = fn[t];
+              memcpy(gt, gnt, P * sizeof(double));
+            }
+            active[t] = (moved[t] && gmax_at_least(gt, gtol)) ? 1 : 0;
+            for (int k = 0; k < P; ++k) X[(size_t)t * P + k] = Xn[(size_t)t * P + k];
+          }
+          n_active_now += active[t] ? 1 : 0;
+        }
+        nit += 1;
+        const int ctl_new[4] = {n_active_now, 0, nit, 0};
+        HIP_TRY(hipMemcpyAsync(dv.X, X.data(), TP * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(dv.G, g.data(), TP * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(dv.H, Hinv.data(), TP * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(dv.F, f.data(), (size_t)T * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(dv.active, active.data(), (size_t)T, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(dv.ctl, ctl_new, sizeof(ctl_new), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));       // (pageable sources)
+        if (n_active_now == 0 || nit >= maxiter) break;
+        continue;
+      }
+      if (n_act == 0 || nit >= maxiter) break;
+    }
+    if (rc) break;
+    // the step's record, on the device until the call ends: objective at the end, parameters
+    HIP_TRY(hipMemcpyAsync(dv.fh + ((size_t)step * 2 + 1) * T, dv.F, (size_t)T * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dv.ph + (size_t)step * TP, dv.X, TP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (nit_out) nit_out[step] = nit;
+  }
+  if (dev_algebra) {
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+    std::vector<double> fh((size_t)n_steps * 2 * T), ph(params_hist ? (size_t)n_steps * TP : 0);
+    HIP_TRY(hipMemcpyAsync(fh.data(), dv.fh, fh.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (params_hist) HIP_TRY(hipMemcpyAsync(ph.data(), dv.ph, ph.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(X.data(), dv.X, TP * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(Hinv.data(), dv.H, TP * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int step = 0; step < n_steps; ++step) {
+      memcpy(f_hist + (size_t)step * 2 * T_hist + t_off, &fh[(size_t)step * 2 * T], (size_t)T * sizeof(double));
+      memcpy(f_hist + ((size_t)step * 2 + 1) * T_hist + t_off, &fh[((size_t)step * 2 + 1) * T], (size_t)T * sizeof(double));
+      if (params_hist) memcpy(params_hist + ((size_t)step * T_hist + t_off) * P, &ph[(size_t)step * TP], TP * sizeof(double));
+    }
+    c->window = 0;
+    c->have_env = false; c->have_guess = false; c->have_overlap_x = false; c->acc_pending = false; c->partials_B = -1;
+  }
+  for (int step = 0; step < n_steps && rc == QMPS_OK && !dev_algebra; ++step) {
     // the step's references: A_t = tensor(current parameters)
     {
       Restore<bool> deferred(c->defer_sync, true);

@@ -93,6 +93,9 @@ struct qmps_ctx {
   const unsigned char* mask_stash = nullptr;
   const unsigned char* mask_host = nullptr;   //   the host copy of the mask the next launch consumes (stash mode; cleared with it): points into mask_copy
   std::vector<unsigned char> mask_copy;       //   ... which is ordinary host memory: no staging region can overwrite it
+  int* h_ctl = nullptr;                       // pinned: the control word of the device-resident lock-step BFGS, read back once per chain
+  void* d_lock = nullptr;                     // device-resident state of the lock-step BFGS (qmps_evolve_lockstep.hip; lazy, grown on demand)
+  size_t d_lock_bytes = 0;
   unsigned char* h_mask = nullptr;            // pinned staging of the masks, SEPARATE from h_pin (never moves, never shares an offset with a result region):
                                               //   two upload slots of kMaskSlot bytes + one for the fall-back pass of qmps_overlap_gradient
   static constexpr size_t kMaskSlot = (size_t)1 << 19;

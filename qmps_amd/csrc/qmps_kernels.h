@@ -208,6 +208,30 @@ struct OverlapArgs {
   int* kry_counter;            // the fall-back's three counters [work, exit tickets, candidates given up] - zero between launches (the
                                //   power kernels count what they give up, the fall-back clears all three when it is done); null = no fall-back
 };
+// optimiser algebra of the lock-step BFGS time evolution on device-resident state (qmps_evolve_lockstep.hip)
+struct LockstepArgs {
+  double* X;        // [T][P] iterates
+  double* G;        // [T][P] gradients
+  double* Gs;       // [T][P] gradient at the candidate (scratch of the accept kernel)
+  double* Hy;       // [T][P] scratch of the rank-two update
+  double* H;        // [T][P][P] inverse Hessians
+  double* F;        // [T] objective at the iterates
+  double* Dv;       // [T][P] directions
+  double* slope;    // [T]
+  double* Xc;       // [T][P] candidates x + alpha_0 d: the parameter rows of the next evaluation
+  const double* fb;      // the evaluation's objectives: [0, T) iterates / candidates, [T, T + 2 P T) central-difference neighbours
+  const int32_t* st;     // ... and statuses: [0, T) right solves, [T, 2 T) left solves
+  unsigned char* active; // [T] trajectories still iterating
+  unsigned char* eff;    // [T] mask of the next evaluation (active, or all zero when the chain has nothing to do)
+  unsigned char* need;   // [T] rejected the full step: waiting for the host's ladder
+  int* ctl;              // [0] active trajectories, [1] trajectories waiting for the ladder, [2] iterations done, [3] stop
+  double* fh_start;      // nullable [T]: record of the objective at the start of the time step (begin kernel)
+  int T, P, maxiter, reset_h;
+  double h, gtol, c1, alpha0;
+};
+hipError_t launch_lockstep_begin(const LockstepArgs& a, hipStream_t st);
+hipError_t launch_lockstep_direction(const LockstepArgs& a, hipStream_t st);
+hipError_t launch_lockstep_accept(const LockstepArgs& a, hipStream_t st);
 // two-sided first-order evaluation of central-difference neighbours (qmps_overlap_gradient; qmps_overlap_grad.hip)
 struct OverlapGradArgs {
   const void* A;       // [T][2][D][D] reference tensors

@@ -398,6 +398,56 @@ def test_native_bfgs_driver_takes_the_decisions_of_the_numpy_loop(D, P, carry):
         ev2.close()
 
 
+@pytest.mark.parametrize('D,P,T,carry,start', [(16, 8, 256, True, 'near'), (16, 8, 9, False, 'near'), (8, 6, 40, True, 'near'), (8, 6, 12, False, 'far'),
+                                                (16, 8, 5, True, 'far')])
+def test_device_algebra_takes_the_decisions_of_the_host_loop(D, P, T, carry, start, engine_factory, monkeypatch):
+    """Round 5: at D = 8, 16 the algebra between two gradient evaluations (directions, Armijo test of the full step, rank-two update
+    of H^-1, masks, next candidates) runs in kernels on device-resident state (qmps_evolve_lockstep.hip), the host only enqueues
+    chains of iterations and finishes the rare iteration with a rejected full step.  QMPS_EVOLVE_HOST_ALGEBRA selects the round-4
+    host loop.  Same evaluations, same expressions in the same order without contraction: the two must agree on every number -
+    iteration counts, objectives, parameters, inverse Hessians - to the last bit, also across a continued call, with and without
+    rejected steps ('far': the second time step starts from a perturbed point, so that full steps get rejected)."""
+    rng = np.random.default_rng(5000 + D + T)
+    X0 = rng.standard_normal((T, P))
+    WW = WW_of(0.05)
+    n_steps = 3
+    out = {}
+    # 'device': blind chains of iterations (no counters, no events: what the timed region of bench.py runs); 'device_counted': one
+    # iteration per chain with HIP events around every evaluation (the instrumented pass); 'host': the round-4 loop
+    for name in ('device', 'device_counted', 'host'):
+        if name == 'host':
+            monkeypatch.setenv('QMPS_EVOLVE_HOST_ALGEBRA', '1')
+        else:
+            monkeypatch.delenv('QMPS_EVOLVE_HOST_ALGEBRA', raising=False)
+        eng = engine_factory(D, T * (2 * P + 1))
+        cnt = name != 'device'
+        a = eng.evolve_bfgs(0, X0, WW, n_steps=1, maxiter=30, tol=1e-12, carry_hessian=carry, counters=cnt)
+        X1 = a['x'] + (0.3 * np.random.default_rng(7).standard_normal(a['x'].shape) if start == 'far' else 0.0)
+        b = eng.evolve_bfgs(0, X1, WW, n_steps=n_steps, maxiter=30, tol=1e-12, carry_hessian=carry, hess_inv=a['hess_inv'] if carry else None,
+                            warm=(start == 'near'), counters=cnt)
+        out[name] = (a, b)
+    monkeypatch.delenv('QMPS_EVOLVE_HOST_ALGEBRA', raising=False)
+    for k in (0, 1):
+        hs = out['host'][k]
+        for name in ('device', 'device_counted'):
+            dv = out[name][k]
+            assert np.array_equal(dv['nit'], hs['nit']), (name, dv['nit'], hs['nit'])
+            assert np.array_equal(dv['fun'], hs['fun']) and np.array_equal(dv['fun_start'], hs['fun_start']), name
+            assert np.array_equal(dv['x'], hs['x']) and np.array_equal(dv['params_hist'], hs['params_hist']), name
+            assert np.array_equal(dv['hess_inv'], hs['hess_inv']), name
+        dv = out['device_counted'][k]
+        assert dv['gradient_batches'] == hs['gradient_batches'] and dv['ladder_batches'] == hs['ladder_batches'] and dv['nfev'] == hs['nfev']
+        assert dv['gradient_ms'] > 0
+    if start == 'far':
+        assert out['device_counted'][1]['ladder_batches'] > 0          # the rare path was exercised
+    # and the numbers are the oracle's: objective at the end of the last step against the previous parameters
+    dv = out['device'][1]
+    prev = dv['params_hist'][-2] if n_steps > 1 else None
+    for t in (0, T - 1):
+        f_t = ER.objective(0, D, ER.tensor(0, D, prev[t]), dv['params_hist'][-1, t], WW, arpack=D >= 16)
+        assert abs(f_t - dv['fun'][-1, t]) < F_TOL
+
+
 @pytest.mark.parametrize('D,P', [(8, 6), (16, 8)])
 def test_two_sided_objective_is_second_order_in_the_residuals(D, P, engine_factory):
     """QMPS_OVERLAP_TWO_SIDED_F: with the eigen-solves stopped at a residual of 1e-8 the objective from <y, T(r)>/<y, r> is as

@@ -300,10 +300,33 @@ def test_d8_whole_run_kernel_matches_the_step_by_step_path(double, c_oracle, eng
         assert close.mean() > 0.8, close.mean()
         # the two paths build the tensor differently (wave-distributed butterflies / one lane per column): rounding-level
         # differences, amplified from sweep to sweep like the evaluator noise of the oracle-driven tests above
-        # (first sweep: 1e-10 for all but the odd restart whose bounded search probes a point within rounding of a tie - 1e-8 there)
+        # (first sweep: 1e-10 for all but the odd restart - one update in a thousand - where the bounded search, fed coefficients that
+        # differ at 1e-12 between the two paths, takes another decision: its angle then moves by up to scipy's tolerance, 1e-5)
         d0 = np.abs(h1 - h2)[0, both]
-        assert (d0 < 1e-10).mean() > 0.98 and d0.max() < 1e-8 and (np.abs(h1 - h2)[:, close].max(0) < 1e-8).mean() > 0.9
+        assert (d0 < 1e-10).mean() > 0.98 and d0.max() < (5e-6 if double else 1e-8) and (np.abs(h1 - h2)[:, close].max(0) < 1e-8).mean() > 0.9
         assert np.abs(E1 - h1[-1])[both].max() < 1e-10
         e_at_p, st_at_p = oracle_energies(c_oracle, builder, 8, p1, h)
         ok = both & (st_at_p == 0)
         assert np.abs(e_at_p - h1[-1])[ok].max() < 1e-9
+
+
+def test_config1_family_with_a_landscape_reaches_the_d2_optimum(c_oracle, engine_factory):
+    """BASELINE.json configs[1] as written is a flat landscape (tests/test_refshim_cpu.py); the same configuration with the D = 2
+    universal gate (ShallowFullStateTensor, 15 angles) and the double-frequency rule of Optimizer('Rotosolve') - what bench.py reports
+    as `config1_family_rotosolve_D2_shallowfull_double` - optimises: after 24 sweeps the best of 64 restarts is below -1.26 and the
+    mean below -1.2 (the reference quotes D2_gse = -1.269909412573 as the D = 2 optimum, scripts/noisy_optimization.py:93; the exact
+    ground-state energy -4/pi bounds everything from below), and the ORACLE's energy at the device's final parameters is the device's."""
+    rng = np.random.default_rng(15)
+    R, sweeps = 64, 24
+    P0 = rng.standard_normal((R, 15))
+    h = O.hamiltonian_matrix({'ZZ': -1, 'X': 1})
+    eng = engine_factory(2, 4096)
+    eng.set_hamiltonian(h)
+    es, p = eng.double_rotosolve(2, P0, sweeps)
+    assert np.isfinite(es).all()
+    A = np.stack([O.unitary_to_tensor(O.shallow_full_unitary(q)) for q in p])
+    out = c_oracle.energy_batch(A, h[None], tol=1e-15, max_iter=200000)
+    ok = out['status'] == 0
+    assert ok.mean() > 0.9 and np.abs(out['E'][:, 0] - es[-1])[ok].max() < 1e-9
+    assert es[-1].min() < -1.26 and es[-1].mean() < -1.2 and es[-1].min() > -4 / np.pi
+    assert es[-1].mean() < es[0].mean()

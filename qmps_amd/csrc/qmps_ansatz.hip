@@ -10,6 +10,7 @@
 #include "qmps_device.h"
 #include "qmps_roto_math.h"
 #include "qmps_circuit.h"
+#include "qmps_circuit_wave.h"
 
 namespace qmps {
 
@@ -89,26 +90,9 @@ __global__ __launch_bounds__(64) void ansatz_tensor_kernel(const double* __restr
 // (ds_swizzle, groups of 32), the Hadamard another, the CNOT ladder ONE gather (ds_bpermute) - ~60 instructions per layer.
 // kinds 0 (ShallowCNOT) and 3 (ShallowCNOT3); shifts / central differences as ansatz_tensor_kernel.
 // ------------------------------------------------------------------------------------------
-namespace {
-template <int PATTERN>
-__device__ __forceinline__ double swz32(double v) {      // value of the lane (own index xor mask), within groups of 32 lanes
-  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), PATTERN);
-  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), PATTERN);
-  return __hiloint2double(hi, lo);
-}
-template <int PATTERN>
-__device__ __forceinline__ void rx_lanes(double& re, double& im, double c, double s) {      // a' = c a - i s (partner's a)
-  const double pr = swz32<PATTERN>(re), pi = swz32<PATTERN>(im);
-  const double nr = dfma(c, re, s * pi), ni = dfma(c, im, -s * pr);
-  re = nr;
-  im = ni;
-}
-}  // namespace
-
 template <int KIND>
 __global__ __launch_bounds__(256) void ansatz_tensor_wave_d16_kernel(const double* __restrict__ params, int n_params, double2* __restrict__ A, int64_t B,
                                                                      int nsh, const int* __restrict__ i_ptr, double fd_h, const unsigned char* __restrict__ active) {
-  constexpr int per = KIND == 3 ? 3 : 2;
   const int lane = threadIdx.x & 63, a = lane & 31;
   const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // wave = (tensor, pair of columns)
   const int64_t b = wv >> 3;
@@ -127,49 +111,8 @@ __global__ __launch_bounds__(256) void ansatz_tensor_wave_d16_kernel(const doubl
     if (lane == isel) v += fd ? fd_shift : roto_shift_value(nsh, shift_k);
     sincos(0.5 * v, &sn, &cn);
   }
-  // |0>|j>: basis state x = j (qubit 0 = 0)
-  double re = a == j ? 1.0 : 0.0, im = 0.0;
-  const int pop = __builtin_popcount((unsigned)a);
-  auto rz_all = [&](double c, double s) {
-    // prod_q rz(theta) = diag(z^(5 - 2 popcount)), z = c - i s (phi = theta / 2): z^1, z^3, z^5 and their conjugates
-    const double z2r = dfma(c, c, -s * s), z2i = -2.0 * s * c;
-    const double z3r = dfma(z2r, c, z2i * s), z3i = dfma(z2i, c, -z2r * s);
-    const double z5r = dfma(z3r, z2r, -z3i * z2i), z5i = dfma(z3r, z2i, z3i * z2r);
-    const int m = 5 - 2 * pop;
-    const double pr = (m == 1 || m == -1) ? c : ((m == 3 || m == -3) ? z3r : z5r);
-    const double pa = (m == 1 || m == -1) ? -s : ((m == 3 || m == -3) ? z3i : z5i);
-    const double pi = m > 0 ? pa : -pa;
-    const double nr = dfma(re, pr, -im * pi), ni = dfma(re, pi, im * pr);
-    re = nr;
-    im = ni;
-  };
-  for (int l0 = 0; l0 + per <= n_params; l0 += per) {
-    rz_all(__shfl(cn, l0, 64), __shfl(sn, l0, 64));
-    {
-      const double c = __shfl(cn, l0 + 1, 64), s = __shfl(sn, l0 + 1, 64);
-      rx_lanes<0x041F>(re, im, c, s);      // qubit 4 <-> lane bit 0
-      rx_lanes<0x081F>(re, im, c, s);      // qubit 3
-      rx_lanes<0x101F>(re, im, c, s);      // qubit 2
-      rx_lanes<0x201F>(re, im, c, s);      // qubit 1
-      rx_lanes<0x401F>(re, im, c, s);      // qubit 0 <-> lane bit 4
-    }
-    if (KIND == 3) rz_all(__shfl(cn, l0 + 2, 64), __shfl(sn, l0 + 2, 64));
-    {
-      // H on qubit 0 (lane bit 4): (own + partner)/sqrt 2 on the 0 side, (partner - own)/sqrt 2 on the 1 side
-      const double h = 0.70710678118654752, sg = (a & 16) ? -h : h;
-      const double pr = swz32<0x401F>(re), pi = swz32<0x401F>(im);
-      re = dfma(sg, re, h * pr);
-      im = dfma(sg, im, h * pi);
-    }
-    {
-      // CNOT(q3, q4), CNOT(q2, q3), CNOT(q1, q2), CNOT(q0, q1): amplitude (b0 .. b4) moves to (b0, b1^b0, b2^b1, b3^b2, b4^b3);
-      // destination lane d gathers from the source whose image it is (prefix xor of its bits)
-      const int d0 = (a >> 4) & 1, b1 = ((a >> 3) & 1) ^ d0, b2 = ((a >> 2) & 1) ^ b1, b3 = ((a >> 1) & 1) ^ b2, b4 = (a & 1) ^ b3;
-      const int src = (lane & 32) | (d0 << 4) | (b1 << 3) | (b2 << 2) | (b3 << 1) | b4;
-      re = __shfl(re, src, 64);
-      im = __shfl(im, src, 64);
-    }
-  }
+  double re, im;
+  shallow_cnot_wave_column_d16<KIND>(cn, sn, n_params, j, re, im);
   // A[b][s][i][j] = amplitude[2 i + s]
   A[b * 512 + ((a & 1) * 16 + (a >> 1)) * 16 + j] = make_double2(re, im);
 }

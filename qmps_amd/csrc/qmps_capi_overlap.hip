@@ -418,7 +418,10 @@ int enqueue_gradient_kernels(qmps_ctx* c, int64_t T, int kind, int P, const doub
     l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
     HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 4 ? squaring : (c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr), c->stream));
   }
-  if (beside) {
+  // D = 16, ShallowCNOT families: the probe kernel builds the neighbours itself (QMPS_NO_FUSED_PROBE: the round-4 path)
+  const bool fused_probe = qmps::overlap_probe_fusable(c->D, kind, P) && documented_switch("QMPS_NO_FUSED_PROBE") == nullptr;
+  if (fused_probe) {
+  } else if (beside) {
     HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
     HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, d_src, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->aux_stream, mask));
     HIP_TRY(hipEventRecord(c->aux_join, c->aux_stream));
@@ -430,6 +433,7 @@ int enqueue_gradient_kernels(qmps_ctx* c, int64_t T, int kind, int P, const doub
   g.A = c->d_ref; g.WW = c->d_ww; g.r = c->d_r; g.y = c->d_y; g.G = c->d_scratch; g.yr = (char*)c->d_scratch + (size_t)T * 4 * nD * 16;
   g.Bt = (char*)c->d_A + (size_t)T * tensor_bytes(c); g.f_out = c->d_f + T; g.T = T; g.G2P = 2 * P; g.active = mask;
   if (two_sided_f) { g.Bc = c->d_A; g.fc_out = c->d_f; }       // (overwrites the right solve's own estimate)
+  if (fused_probe) { g.fd_params = d_src; g.fd_h = h; g.kind = kind; }
   HIP_TRY(qmps::launch_overlap_grad(c->D, g, c->stream));
   gp.lazy_krylov = lazy_krylov;
   return QMPS_OK;
@@ -469,7 +473,7 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   // (beyond ~1 000 iterates the solves fill the chip by themselves: T = 2 048 measured 5 % slower with the second stream)
   // (a lock-step group of qmps_evolve_bfgs keeps to ONE stream: the other groups fill the chip, and two streams of one group that
   // land on the same hardware queue serialise - measured 5-10 % slower and erratic, profiles/EXPERIMENTS.md round 4)
-  const bool beside = T <= 1024 && !c->one_stream;
+  const bool beside = T <= 1024 && !c->one_stream && !(qmps::overlap_probe_fusable(c->D, kind, P) && documented_switch("QMPS_NO_FUSED_PROBE") == nullptr);
   // the iterates: parameters -> tensors in d_A[0, T); the fork event sits between the parameter upload and the tensor build, and
   // the second stream is fed only AFTER the solves are submitted (the host calls of the fork used to hold the solves back ~15 us)
   int rc;
@@ -666,15 +670,18 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   // the control word back once per chain.  The iteration in which a trajectory rejects the full step is finished by the host
   // code below (ladder, gradient at the accepted point, update) on a downloaded copy of the state - the same code, the same
   // decisions.  QMPS_EVOLVE_HOST_ALGEBRA selects the host loop for everything (the round-4 driver; the test-suite runs both).
-  const bool dev_algebra = two_sided && (c->D == 8 || c->D == 16) && documented_switch("QMPS_EVOLVE_HOST_ALGEBRA") == nullptr &&
+  const bool dev_algebra = two_sided && (c->D == 8 || c->D == 16) && P <= 32 && T <= 65535 && documented_switch("QMPS_EVOLVE_HOST_ALGEBRA") == nullptr &&
                            documented_switch("QMPS_D16_BLOCK") == nullptr && documented_switch("QMPS_D16_ONE_WAVE") == nullptr;
   struct {
     double *X, *G, *Gs, *Hy, *H, *F, *Dv, *slope, *Xc, *fh, *ph;
     int* ctl;
     unsigned char *active, *eff, *need;
   } dv = {};
-  int chain_len = 4;
-  if (const char* e = tuning_knob("QMPS_EVOLVE_CHAIN")) chain_len = atoi(e) > 0 ? atoi(e) : 4;
+  // first chain of a time step: as many iterations as the previous step took (the lock-step count is steady along an evolution with
+  // carried Hessians; an idle iteration at the tail of a chain costs ~40 us of empty launches, a chain too short a synchronisation
+  // per further iteration); QMPS_EVOLVE_CHAIN (tuning builds) fixes it
+  int chain_fixed = 0, nit_prev = 4;
+  if (const char* e = tuning_knob("QMPS_EVOLVE_CHAIN")) chain_fixed = atoi(e) > 0 ? atoi(e) : 0;
   if (dev_algebra) {
     const size_t n_dbl = 6 * TP + TP * P + 2 * (size_t)T + (size_t)n_steps * 2 * T + (size_t)n_steps * TP;
     const size_t bytes = n_dbl * sizeof(double) + 16 * sizeof(int) + 3 * (((size_t)T + 7) / 8 * 8) + 64;
@@ -708,19 +715,20 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     c->ans_have = false; c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0; c->tensors_valid = false; c->n_states = 0;
   }
   const bool beside_dev = T <= 1024 && !c->one_stream;
-  auto lock_args = [&](int step, bool reset_h) {
+  const bool fused_probe_dev = qmps::overlap_probe_fusable(c->D, kind, P) && documented_switch("QMPS_NO_FUSED_PROBE") == nullptr;
+  auto lock_args = [&](int step, bool reset_h, int mode) {
     qmps::LockstepArgs la;
     memset(&la, 0, sizeof(la));
     la.X = dv.X; la.G = dv.G; la.Gs = dv.Gs; la.Hy = dv.Hy; la.H = dv.H; la.F = dv.F; la.Dv = dv.Dv; la.slope = dv.slope; la.Xc = dv.Xc;
     la.fb = c->d_f; la.st = c->d_status; la.active = dv.active; la.eff = dv.eff; la.need = dv.need; la.ctl = dv.ctl;
-    la.fh_start = dv.fh + (size_t)step * 2 * T;
+    la.fh_start = dv.fh + (size_t)step * 2 * T; la.fh_end = dv.fh + ((size_t)step * 2 + 1) * T; la.ph = dv.ph + (size_t)step * TP; la.mode = mode;
     la.T = (int)T; la.P = P; la.maxiter = maxiter; la.reset_h = reset_h ? 1 : 0; la.h = h; la.gtol = gtol; la.c1 = c1; la.alpha0 = alphas[0];
     return la;
   };
   // one evaluation of the rows at d_src (iterate tensors, both fixed points, neighbours, probes), enqueued only
   auto dev_gradient = [&](const double* d_src, const unsigned char* mask) -> int {
     HIP_TRY(qmps::launch_ansatz(c->D, kind, d_src, P, c->d_A, T, c->stream));
-    if (beside_dev) HIP_TRY(hipEventRecord(c->aux_fork, c->stream));
+    if (beside_dev && !fused_probe_dev) HIP_TRY(hipEventRecord(c->aux_fork, c->stream));      // (the second stream builds the neighbours' tensors)
     c->timed = counters_out != nullptr;
     const int tslot = (int)(c->samples % qmps_ctx::kRing);
     if (c->timed) HIP_TRY(hipEventRecord(c->kev0[tslot], c->stream));
@@ -739,18 +747,21 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     c->overlap_refs = T;
     c->overlap_group = 0;
     if ((rc = dev_gradient(dv.X, nullptr))) break;
-    HIP_TRY(qmps::launch_lockstep_begin(lock_args(step, reset_h), c->stream));
+    HIP_TRY(qmps::launch_lockstep_step(lock_args(step, reset_h, 1), c->stream));      // f, g, active set; the first direction
     n_grad += 1.0;
     nfev += (double)T * (2 * P + 1);
     int nit = 0;
-    const qmps::LockstepArgs la = lock_args(step, false);
+    const qmps::LockstepArgs la = lock_args(step, false, 0);
+    bool first_chain = true;
     for (;;) {
       // with counters: one iteration per chain, so that every evaluation's event pair can be read (the timed region runs without)
-      const int K = counters_out ? 1 : (chain_len < maxiter - nit ? chain_len : maxiter - nit);
+      int K = counters_out ? 1 : (first_chain ? (chain_fixed > 0 ? chain_fixed : nit_prev) : 1);
+      K = K < 1 ? 1 : K;
+      K = K < maxiter - nit ? K : maxiter - nit;
+      first_chain = false;
       for (int i = 0; i < K; ++i) {
-        HIP_TRY(qmps::launch_lockstep_direction(la, c->stream));
         if ((rc = dev_gradient(dv.Xc, dv.eff))) break;
-        HIP_TRY(qmps::launch_lockstep_accept(la, c->stream));
+        HIP_TRY(qmps::launch_lockstep_step(la, c->stream));          // finish the iteration, open the next
       }
       if (rc) break;
       HIP_TRY(hipMemcpyAsync(c->h_ctl, dv.ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -869,15 +880,15 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
         HIP_TRY(hipMemcpyAsync(dv.active, active.data(), (size_t)T, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(dv.ctl, ctl_new, sizeof(ctl_new), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));       // (pageable sources)
+        HIP_TRY(qmps::launch_lockstep_step(lock_args(step, false, 2), c->stream));    // the step's record; the next direction if the lock-step goes on
         if (n_active_now == 0 || nit >= maxiter) break;
         continue;
       }
       if (n_act == 0 || nit >= maxiter) break;
     }
     if (rc) break;
-    // the step's record, on the device until the call ends: objective at the end, parameters
-    HIP_TRY(hipMemcpyAsync(dv.fh + ((size_t)step * 2 + 1) * T, dv.F, (size_t)T * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dv.ph + (size_t)step * TP, dv.X, TP * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    // (the step's record - objective at the end, parameters - was written by the last live step kernel; on the device until the call ends)
+    nit_prev = nit > 0 ? nit : 1;
     if (nit_out) nit_out[step] = nit;
   }
   if (dev_algebra) {

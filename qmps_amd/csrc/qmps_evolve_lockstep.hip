@@ -6,15 +6,26 @@
 // points of each iterate + its 2 P neighbours by the two-sided quotient: qmps_capi_overlap.hip, enqueue_gradient_kernels).  Round 4
 // kept the algebra between two evaluations on the host - directions, the Armijo test of the full step, the rank-two update of
 // H^-1, the masks, the next batch's parameter rows - which cost a synchronisation, two staged copies and ~40 us of idle device per
-// batch (28 % of a time step at 256 trajectories).  The three kernels below do that algebra on device-resident x, g, H^-1, so that
-// the host only ENQUEUES: begin (after the first evaluation of a time step), then per iteration direction -> [evaluation] -> accept.
-// A control word in HBM tells every kernel of a chain of iterations whether there is anything left to do - no trajectory active, or
-// a trajectory REJECTED the full step (its backtracking ladder is the rare path: the host takes over for that iteration) - so a
-// chain enqueued blindly costs empty launches at its tail, not wrong work.
+// batch (28 % of a time step at 256 trajectories).  The kernel below does that algebra on device-resident x, g, H^-1, so that the
+// host only ENQUEUES: evaluation -> step kernel -> evaluation -> step kernel ...  A control word in HBM tells every kernel of a
+// chain of iterations whether there is anything left to do - no trajectory active, or a trajectory REJECTED the full step (its
+// backtracking ladder is the rare path: the host takes over for that iteration) - so a chain enqueued blindly costs empty
+// launches at its tail, not wrong work.
+//
+// ONE kernel per iteration: `lockstep_step_kernel` finishes iteration k from its evaluation (phase ACCEPT: Armijo test of the full
+// step, the step, the BFGS update, the new active set) and, when the lock-step goes on, opens iteration k + 1 (phase DIRECTION:
+// d = -H^-1 g, slope, the candidates x + alpha_0 d and the mask of the next evaluation).  MODE_BEGIN replaces the first phase after
+// the first evaluation of a time step (f, g from the batch, the active set, H^-1 = 1 unless carried).
 //
 // The floating-point expressions are those of the host loop (evolve_bfgs_group, which remains the checker and the path of the
-// ladder), in the same order and WITHOUT contraction: given the same evaluations both take the same decisions bit for bit.
-// One workgroup; thread t, t + 256, ... own a trajectory each (the algebra is O(T P^2): microseconds).
+// ladder), every sum in the same order and WITHOUT contraction: given the same evaluations both take the same decisions bit for bit.
+//
+// Layout: one workgroup of 1024 threads; PL = 2^ceil(log2 P) <= 32 lanes per trajectory (lane a owns component a and row a of
+// H^-1, kept in registers: the P x P work is O(P) per lane with coalesced rows), 1024 / PL trajectories per pass.  Sums over
+// components run in index order in every lane of the group alike, the components fetched by wave shuffles - no LDS, no barrier
+// inside a pass - and every load of a pass is issued before its first use: the kernel is a handful of memory round trips.
+// First version: a thread per trajectory with the P x P loops inside - 68 us for the accept phase of 256 trajectories, more than the
+// host algebra it replaced; second: LDS staging with a barrier per stage and loads where they were needed - 16 .. 33 us.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,25 +35,17 @@ namespace qmps {
 
 namespace {
 
+constexpr int LS_THREADS = 1024;
+constexpr int LS_MAXP = 32;
+
 __device__ __forceinline__ bool st_ok(const LockstepArgs& p, int t) { return p.st[t] == QMPS_ST_OK && p.st[p.T + t] == QMPS_ST_OK; }
 
-// np.abs(g).max() >= bound, NaN-propagating (false with any NaN) - gmax_at_least of the host loop
-__device__ __forceinline__ bool gmax_at_least(const double* g, int P, double bound) {
-  double m = 0.0;
-  for (int k = 0; k < P; ++k) {
-    if (g[k] != g[k]) return false;
-    const double a = fabs(g[k]);
-    m = a > m ? a : m;
-  }
-  return m >= bound;
-}
-
-// block-wide sum of an int over the 256 threads (result in every thread)
+// block-wide sum of an int over LS_THREADS threads (result in every thread)
 __device__ __forceinline__ int block_sum(int v, int* red) {
   __syncthreads();
   red[threadIdx.x] = v;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = LS_THREADS / 2; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
@@ -53,172 +56,208 @@ __device__ __forceinline__ int block_sum(int v, int* red) {
 
 }  // namespace
 
-// After the FIRST evaluation of a time step (the iterates are the previous step's minimisers, the references their tensors):
-// f, g from the batch, the active set, the control word, the record of the objective at the start of the step.
-__global__ __launch_bounds__(256) void lockstep_begin_kernel(LockstepArgs p) {
+template <int PL>
+__global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs p) {
 #pragma clang fp contract(off)
-  __shared__ int red[256];
-  int n_active = 0;
-  for (int t = threadIdx.x; t < p.T; t += 256) {
-    const bool ok = st_ok(p, t);
-    const double nan = __builtin_nan("");
-    const double* fn = p.fb + p.T + (int64_t)t * 2 * p.P;
-    double* g = p.G + (int64_t)t * p.P;
-    const double f = ok ? p.fb[t] : nan;
-    for (int k = 0; k < p.P; ++k) g[k] = ok ? (fn[k] - fn[p.P + k]) / (2.0 * p.h) : nan;
-    p.F[t] = f;
-    if (p.fh_start) p.fh_start[t] = f;
-    if (p.reset_h) {
-      double* H = p.H + (int64_t)t * p.P * p.P;
-      for (int a = 0; a < p.P; ++a)
-        for (int b = 0; b < p.P; ++b) H[a * p.P + b] = a == b ? 1.0 : 0.0;
+  constexpr int SLOTS = LS_THREADS / PL;
+  __shared__ int red[LS_THREADS];
+  const int slot = threadIdx.x / PL, a = threadIdx.x % PL;
+  const int gbase = (threadIdx.x & 63) & ~(PL - 1);      // first lane of this trajectory's group inside the wave
+  const int P = p.P;
+  const bool lane_on = a < P;
+  const int n_active0 = p.ctl[0], nit0 = p.ctl[2], stop0 = p.ctl[3];
+  const bool begin = p.mode == 1, open_only = p.mode == 2;
+  // component k of a per-trajectory vector held one component per lane (every lane of the wave takes part: no divergence around it)
+  auto comp = [&](double v, int k) { return __shfl(v, gbase + k, 64); };
+  // np.abs(g).max() >= gtol, NaN-propagating (false with any NaN) - every lane of the group computes it alike
+  auto gmax_ok = [&](double gv) {
+    double m = 0.0;
+    bool isnan_ = false;
+    for (int k = 0; k < P; ++k) {
+      const double gk = comp(gv, k);
+      if (gk != gk) isnan_ = true;
+      const double ak = fabs(gk);
+      m = ak > m ? ak : m;
     }
-    const bool act = gmax_at_least(g, p.P, p.gtol);
-    p.active[t] = act ? 1 : 0;
-    p.eff[t] = 0;
-    p.need[t] = 0;
-    n_active += act ? 1 : 0;
-  }
-  n_active = block_sum(n_active, red);
-  if (threadIdx.x == 0) {
-    p.ctl[0] = n_active;
-    p.ctl[1] = 0;
-    p.ctl[2] = 0;
-    p.ctl[3] = 0;
-  }
-}
-
-// Start of an iteration: d = -H^-1 g (steepest descent and H^-1 = 1 where that is no descent direction), the slope, the candidate
-// x + alpha_0 d of every active trajectory (the rows the evaluation builds its tensors from) and the evaluation's mask.
-// Nothing to do (mask all zero, nothing touched) when no trajectory is active, the iteration cap is reached, or a rejected full
-// step is waiting for the host's ladder.
-__global__ __launch_bounds__(256) void lockstep_direction_kernel(LockstepArgs p) {
-#pragma clang fp contract(off)
-  const int n_active = p.ctl[0], nit = p.ctl[2], stop = p.ctl[3];
-  const bool idle = n_active == 0 || stop != 0 || nit >= p.maxiter;
-  for (int t = threadIdx.x; t < p.T; t += 256) {
-    if (idle) {
-      p.eff[t] = 0;
-      continue;
-    }
-    const bool act = p.active[t] != 0;
-    double* H = p.H + (int64_t)t * p.P * p.P;
-    const double* g = p.G + (int64_t)t * p.P;
-    double* d = p.Dv + (int64_t)t * p.P;
-    const double* x = p.X + (int64_t)t * p.P;
-    double* xc = p.Xc + (int64_t)t * p.P;
-    // (a trajectory that has stopped keeps g and H^-1: its direction test below had its one possible effect in iteration 0)
-    if (!act && nit > 0) {
-      for (int a = 0; a < p.P; ++a) d[a] = 0.0;
-    } else {
-      double sl = 0.0;
-      for (int a = 0; a < p.P; ++a) {
-        double acc = 0.0;
-        for (int b = 0; b < p.P; ++b) acc += H[a * p.P + b] * g[b];
-        d[a] = -acc;
-      }
-      for (int a = 0; a < p.P; ++a) sl += g[a] * d[a];
-      if (!(sl < 0.0)) {                                  // not a descent direction: restart from steepest descent
-        for (int a = 0; a < p.P; ++a)
-          for (int b = 0; b < p.P; ++b) H[a * p.P + b] = a == b ? 1.0 : 0.0;
-        sl = 0.0;
-        for (int a = 0; a < p.P; ++a) { d[a] = -g[a]; sl -= g[a] * g[a]; }
-      }
-      p.slope[t] = sl;
-      if (!act) for (int a = 0; a < p.P; ++a) d[a] = 0.0;
-    }
-    for (int a = 0; a < p.P; ++a) xc[a] = x[a] + p.alpha0 * d[a];
-    p.eff[t] = act ? 1 : 0;
-    p.need[t] = 0;
-  }
-}
-
-// End of an iteration whose evaluation was at the full steps: Armijo test; a trajectory that accepts takes the step and the BFGS
-// update at once (its values are the batch's); one that rejects is flagged (`need`) and left as it is - then the control word says
-// STOP and the host finishes the iteration for the flagged trajectories (ladder, gradient at the accepted point, update).
-__global__ __launch_bounds__(256) void lockstep_accept_kernel(LockstepArgs p) {
-#pragma clang fp contract(off)
-  __shared__ int red[256];
-  const int n_active0 = p.ctl[0], nit = p.ctl[2], stop = p.ctl[3];
+    return !isnan_ && m >= p.gtol;
+  };
   __syncthreads();
-  if (n_active0 == 0 || stop != 0 || nit >= p.maxiter) return;
+  // ---------------------------------------------------------------------------------------------------------------------------
+  // phase 1: ACCEPT (or BEGIN)
+  // ---------------------------------------------------------------------------------------------------------------------------
+  const bool live = begin || open_only || !(n_active0 == 0 || stop0 != 0 || nit0 >= p.maxiter);
+  if (!live) return;      // nothing to finish: the mask of the next evaluation stays empty (cleared when the lock-step stopped)
   int n_need = 0, n_active = 0;
-  for (int t = threadIdx.x; t < p.T; t += 256) {
-    if (p.active[t] == 0) continue;                      // (rows of skipped trajectories: their last values; moved = 0, still inactive)
-    const bool ok = st_ok(p, t);
-    const double nan = __builtin_nan("");
-    const double fs = ok ? p.fb[t] : nan;
-    const double Ft0 = (fs - fs == 0.0) ? fs : INFINITY;   // isfinite
-    const double f = p.F[t];
-    if (!(Ft0 <= f + p.c1 * p.alpha0 * p.slope[t])) {    // rejected: the ladder and the gradient at the accepted point are the host's
-      p.need[t] = 1;
-      n_need += 1;
-      n_active += 1;                                      // (still active until the host has finished its iteration)
+  const double nan = __builtin_nan("");
+  for (int base = 0; base < p.T && !open_only; base += SLOTS) {
+    const int t = base + slot;
+    const bool on = t < p.T;
+    const int ts = on ? t : 0;
+    const int as = lane_on ? a : 0;
+    const int64_t tp = (int64_t)ts * P;
+    double* H = p.H + tp * P;
+    // ---- every load of the pass up front (independent: one memory round trip instead of one per use)
+    const int st0 = p.st[ts], st1 = p.st[p.T + ts];
+    const unsigned char act_b = begin ? 1 : p.active[ts];
+    const double fbt = p.fb[ts];
+    const double* fn = p.fb + p.T + (int64_t)ts * 2 * P;
+    const double fna = fn[as], fnb = fn[P + as];
+    const double Ft = begin ? 0.0 : p.F[ts], slp = begin ? 0.0 : p.slope[ts];
+    const double dva = begin ? 0.0 : p.Dv[tp + as], gold = begin ? 0.0 : p.G[tp + as], xa = begin ? 0.0 : p.X[tp + as];
+    double hrow[PL];
+    if (!begin)
+#pragma unroll
+      for (int b = 0; b < PL; ++b) hrow[b] = (b < P) ? H[as * P + b] : 0.0;
+    const bool ok = st0 == QMPS_ST_OK && st1 == QMPS_ST_OK;
+    const double gnew = ok ? (fna - fnb) / (2.0 * p.h) : nan;
+    if (begin) {
+      // f, g of the iterates from the first evaluation of the time step; H^-1 = 1 unless carried
+      if (on && lane_on) {
+        p.G[tp + a] = gnew;
+        if (p.reset_h)
+          for (int b = 0; b < P; ++b) H[a * P + b] = a == b ? 1.0 : 0.0;
+      }
+      const bool act = gmax_ok(gnew);
+      if (on && a == 0) {
+        const double f = ok ? fbt : nan;
+        p.F[t] = f;
+        if (p.fh_start) p.fh_start[t] = f;
+        p.active[t] = act ? 1 : 0;
+        p.need[t] = 0;
+        n_active += act ? 1 : 0;
+      }
       continue;
     }
-    double* H = p.H + (int64_t)t * p.P * p.P;
-    double* g = p.G + (int64_t)t * p.P;
-    double* gs = p.Gs + (int64_t)t * p.P;
-    double* Hy = p.Hy + (int64_t)t * p.P;
-    const double* d = p.Dv + (int64_t)t * p.P;
-    double* x = p.X + (int64_t)t * p.P;
-    const bool moved = Ft0 < f;
+    // ---- the Armijo test of the full step (every lane of the group alike)
+    const bool act_before = on && act_b != 0;
+    const double fs = ok ? fbt : nan;
+    const double Ft0 = (fs - fs == 0.0) ? fs : INFINITY;      // isfinite
+    const bool accepted = act_before && (Ft0 <= Ft + p.c1 * p.alpha0 * slp);
+    const bool need = act_before && !accepted;                 // rejected: ladder + gradient at the accepted point are the host's
+    const bool moved = accepted && Ft0 < Ft;
     const double a0 = moved ? p.alpha0 : 0.0;
-    if (moved) {
-      const double* fn = p.fb + p.T + (int64_t)t * 2 * p.P;
-      for (int k = 0; k < p.P; ++k) gs[k] = ok ? (fn[k] - fn[p.P + k]) / (2.0 * p.h) : nan;
-      double sy = 0.0, ss = 0.0, yy = 0.0;
-      for (int k = 0; k < p.P; ++k) {
-        const double s = a0 * d[k], y = gs[k] - g[k];
-        sy += s * y;
-        ss += s * s;
-        yy += y * y;
-      }
-      if (sy > 1e-12 * sqrt(ss * yy) && sy > 0.0) {
-        // H' = H - rho (s (Hy)^T + (Hy) s^T) + rho (1 + rho y^T H y) s s^T
-        const double rho = 1.0 / sy;
-        double yHy = 0.0;
-        for (int a = 0; a < p.P; ++a) {
-          double acc = 0.0;
-          for (int b = 0; b < p.P; ++b) acc += H[a * p.P + b] * (gs[b] - g[b]);
-          Hy[a] = acc;
-        }
-        for (int a = 0; a < p.P; ++a) yHy += (gs[a] - g[a]) * Hy[a];
-        const double coef = rho * (1.0 + rho * yHy);
-        for (int a = 0; a < p.P; ++a)
-          for (int b = 0; b < p.P; ++b) {
-            const double sa = a0 * d[a], sb = a0 * d[b];
-            H[a * p.P + b] = H[a * p.P + b] - (rho * sa * Hy[b] + rho * sb * Hy[a]) + coef * sa * sb;
-          }
-      }
-      p.F[t] = fs;
-      for (int k = 0; k < p.P; ++k) g[k] = gs[k];
+    // ---- y = g_new - g, s = a0 d, the rank-two update (sums in index order, by every lane of the group alike)
+    const double ya = gnew - gold, sa = a0 * dva;
+    double sy = 0.0, ss = 0.0, yy = 0.0;
+    for (int k = 0; k < P; ++k) {
+      const double s = comp(sa, k), y = comp(ya, k);
+      sy += s * y;
+      ss += s * s;
+      yy += y * y;
     }
-    for (int k = 0; k < p.P; ++k) x[k] = x[k] + a0 * d[k];
-    const bool act = moved && gmax_at_least(g, p.P, p.gtol);
-    p.active[t] = act ? 1 : 0;
-    n_active += act ? 1 : 0;
+    const bool upd = moved && sy > 1e-12 * sqrt(ss * yy) && sy > 0.0;
+    const double rho = 1.0 / sy;
+    double hya = 0.0;
+#pragma unroll
+    for (int b = 0; b < PL; ++b)
+      if (b < P) hya += hrow[b] * comp(ya, b);
+    double yHy = 0.0;
+    for (int k = 0; k < P; ++k) yHy += comp(ya, k) * comp(hya, k);
+    const double coef = rho * (1.0 + rho * yHy);
+    // H' = H - rho (s (Hy)^T + (Hy) s^T) + rho (1 + rho y^T H y) s s^T   (the shuffles by every lane of the wave; stores predicated)
+    double hnew[PL];
+#pragma unroll
+    for (int b = 0; b < PL; ++b) {
+      const double sb = comp(sa, b < P ? b : 0), hyb = comp(hya, b < P ? b : 0);
+      hnew[b] = hrow[b] - (rho * sa * hyb + rho * sb * hya) + coef * sa * sb;
+    }
+    if (on && lane_on && accepted) {
+      if (upd)
+#pragma unroll
+        for (int b = 0; b < PL; ++b)
+          if (b < P) H[a * P + b] = hnew[b];
+      if (moved) p.G[tp + a] = gnew;
+      p.X[tp + a] = xa + sa;
+    }
+    const bool act = moved && gmax_ok(moved ? gnew : gold);
+    if (on && a == 0 && act_before) {
+      if (need) {
+        p.need[t] = 1;
+        n_need += 1;
+        n_active += 1;                                   // (still active until the host has finished its iteration)
+      } else {
+        if (moved) p.F[t] = fbt;
+        p.active[t] = act ? 1 : 0;
+        n_active += act ? 1 : 0;
+      }
+    }
   }
-  n_need = block_sum(n_need, red);
-  n_active = block_sum(n_active, red);
-  if (threadIdx.x == 0) {
+  {
+    const int both = block_sum((n_need << 16) | n_active, red);       // (T < 65 536: checked by the launcher)
+    n_need = both >> 16;
+    n_active = both & 0xffff;
+  }
+  if (open_only) n_active = n_active0;                   // (the host finished the iteration and wrote the control word)
+  const int nit = open_only ? nit0 : (begin ? 0 : (n_need > 0 ? nit0 : nit0 + 1));
+  const int stop = open_only ? stop0 : (n_need > 0 ? 1 : 0);
+  if (threadIdx.x == 0 && !open_only) {
     p.ctl[0] = n_active;
     p.ctl[1] = n_need;
-    if (n_need > 0) p.ctl[3] = 1;       // the host completes this iteration (and counts it)
-    else p.ctl[2] = nit + 1;
+    p.ctl[2] = nit;
+    p.ctl[3] = stop;
+  }
+  // ---------------------------------------------------------------------------------------------------------------------------
+  // phase 2: DIRECTION of the next iteration (or an empty mask when the lock-step stops here)
+  // ---------------------------------------------------------------------------------------------------------------------------
+  const bool go_on = n_active > 0 && stop == 0 && nit < p.maxiter;
+  for (int base = 0; base < p.T; base += SLOTS) {
+    const int t = base + slot;
+    const bool on = t < p.T;
+    const int ts = on ? t : 0;
+    const int as = lane_on ? a : 0;
+    const int64_t tp = (int64_t)ts * P;
+    double* H = p.H + tp * P;
+    const double xa = p.X[tp + as], ga = p.G[tp + as], Ft = p.F[ts];
+    const bool act = on && p.active[ts] != 0;
+    double hrow[PL];
+    if (go_on)
+#pragma unroll
+      for (int b = 0; b < PL; ++b) hrow[b] = (b < P) ? H[as * P + b] : 0.0;
+    // the record of the time step so far (final when the lock-step stops here; a trajectory waiting for the host's ladder is
+    // recorded again by the mode-2 launch that follows the host's update)
+    if (on && lane_on) p.ph[tp + a] = xa;
+    if (on && a == 0) p.fh_end[t] = Ft;
+    if (!go_on) {
+      if (on && a == 0) p.eff[t] = 0;
+      continue;
+    }
+    // (a trajectory that has stopped keeps g and H^-1: its direction test had its one possible effect in iteration 0)
+    const bool compute = on && (act || nit == 0);
+    double acc = 0.0;
+#pragma unroll
+    for (int b = 0; b < PL; ++b)
+      if (b < P) acc += hrow[b] * comp(ga, b);
+    double dv = -acc;
+    double sl = 0.0;
+    for (int k = 0; k < P; ++k) sl += comp(ga, k) * comp(dv, k);
+    double sl_sd = 0.0;                                  // slope of steepest descent (computed by all: no divergence around the shuffles)
+    for (int k = 0; k < P; ++k) { const double gk = comp(ga, k); sl_sd -= gk * gk; }
+    const bool restart = !(sl < 0.0);                    // not a descent direction: restart from steepest descent
+    if (restart) {
+      sl = sl_sd;
+      dv = -ga;
+    }
+    if (compute && lane_on && restart)
+      for (int b = 0; b < P; ++b) H[a * P + b] = a == b ? 1.0 : 0.0;
+    if (compute && a == 0) p.slope[t] = sl;
+    if (!compute || !act) dv = 0.0;
+    if (on && lane_on) {
+      p.Dv[tp + a] = dv;
+      p.Xc[tp + a] = xa + p.alpha0 * dv;
+    }
+    if (on && a == 0) {
+      p.eff[t] = act ? 1 : 0;
+      p.need[t] = 0;
+    }
   }
 }
 
-hipError_t launch_lockstep_begin(const LockstepArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(lockstep_begin_kernel, dim3(1), dim3(256), 0, st, a);
-  return hipGetLastError();
-}
-hipError_t launch_lockstep_direction(const LockstepArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(lockstep_direction_kernel, dim3(1), dim3(256), 0, st, a);
-  return hipGetLastError();
-}
-hipError_t launch_lockstep_accept(const LockstepArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(lockstep_accept_kernel, dim3(1), dim3(256), 0, st, a);
+hipError_t launch_lockstep_step(const LockstepArgs& a, hipStream_t st) {
+  if (a.P < 1 || a.P > LS_MAXP || a.T < 1 || a.T > 65535) return hipErrorInvalidValue;
+  if (a.P <= 4) hipLaunchKernelGGL(lockstep_step_kernel<4>, dim3(1), dim3(LS_THREADS), 0, st, a);
+  else if (a.P <= 8) hipLaunchKernelGGL(lockstep_step_kernel<8>, dim3(1), dim3(LS_THREADS), 0, st, a);
+  else if (a.P <= 16) hipLaunchKernelGGL(lockstep_step_kernel<16>, dim3(1), dim3(LS_THREADS), 0, st, a);
+  else hipLaunchKernelGGL(lockstep_step_kernel<32>, dim3(1), dim3(LS_THREADS), 0, st, a);
   return hipGetLastError();
 }
 

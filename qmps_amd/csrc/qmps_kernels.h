@@ -225,13 +225,15 @@ struct LockstepArgs {
   unsigned char* eff;    // [T] mask of the next evaluation (active, or all zero when the chain has nothing to do)
   unsigned char* need;   // [T] rejected the full step: waiting for the host's ladder
   int* ctl;              // [0] active trajectories, [1] trajectories waiting for the ladder, [2] iterations done, [3] stop
-  double* fh_start;      // nullable [T]: record of the objective at the start of the time step (begin kernel)
+  double* fh_start;      // nullable [T]: record of the objective at the start of the time step (mode 1)
+  double* fh_end;        // [T] record of the objective after the last finished iteration (rewritten by every live launch)
+  double* ph;            // [T][P] ... and of the parameters
   int T, P, maxiter, reset_h;
+  int mode;              // 0: finish an iteration from its evaluation, open the next; 1: the same after the FIRST evaluation of a time step
+                         // (f, g, active set from the batch; H^-1 = 1 if reset_h); 2: open the next iteration only (the host has finished one)
   double h, gtol, c1, alpha0;
 };
-hipError_t launch_lockstep_begin(const LockstepArgs& a, hipStream_t st);
-hipError_t launch_lockstep_direction(const LockstepArgs& a, hipStream_t st);
-hipError_t launch_lockstep_accept(const LockstepArgs& a, hipStream_t st);
+hipError_t launch_lockstep_step(const LockstepArgs& a, hipStream_t st);       // n_params <= 32
 // two-sided first-order evaluation of central-difference neighbours (qmps_overlap_gradient; qmps_overlap_grad.hip)
 struct OverlapGradArgs {
   const void* A;       // [T][2][D][D] reference tensors
@@ -247,8 +249,15 @@ struct OverlapGradArgs {
   const unsigned char* active;   // nullable [T]: 0 = skip the trajectory (outputs keep their previous values)
   const void* Bc;      // nullable [T][2][D][D]: the iterates' own tensors - their objective by the same two-sided quotient
   double* fc_out;      // [T]: -sqrt|<y, T(r)>/<y, r>|  (error ~ the PRODUCT of the residuals of y and r)
+  // D = 16, ShallowCNOT families: the probe kernel BUILDS every neighbour's tensor itself (wave-distributed circuit, LDS) instead of
+  // reading it from Bt - no neighbour tensors in HBM at all.  fd_params != nullptr selects it (overlap_probe_fusable).
+  const double* fd_params;   // nullable [T][G2P / 2] parameter rows of the iterates (device)
+  double fd_h;               // central-difference step: neighbour k < P has +fd_h on parameter k, neighbour P + k has -fd_h
+  int kind;                  // QMPS_ANSATZ_* of the rows
 };
 hipError_t launch_overlap_grad(int D, const OverlapGradArgs& a, hipStream_t st);
+// can the D = 16 probe kernel build the neighbours of this ansatz kind itself?
+inline bool overlap_probe_fusable(int D, int kind, int n_params) { return D == 16 && (kind == 0 || kind == 3) && n_params >= 1 && n_params <= 64; }
 constexpr int kOverlapStatShards = 1024;
 #if defined(__HIPCC__)
 __device__ __forceinline__ int64_t overlap_ref_index(const OverlapArgs& p, int64_t b) { return p.group > 0 ? b / p.group : (p.a_shared ? 0 : b); }

@@ -21,6 +21,7 @@
 #include "qmps_kernels.h"
 #include "qmps_device.h"
 #include "qmps_overlap_d4.h"     // cmma16_3m
+#include "qmps_circuit_wave.h"
 
 namespace qmps {
 
@@ -315,14 +316,107 @@ __global__ __launch_bounds__(64) void overlap_probe_d16_kernel(OverlapGradArgs p
   }
 }
 
+// The same with the neighbour's tensor BUILT by the probing wave (round 5): parameters -> the five-qubit circuit distributed over
+// the lanes (qmps_circuit_wave.h: two columns per pass, eight passes) -> the tensor in LDS (8 KB, padded rows) -> the MFMA operand
+// layouts.  Round 4 built the 2 P T neighbour tensors in a kernel of their own on a second stream beside the eigen-solves (65 us
+// for 4 096 tensors, one lane per column), wrote 35 MB to HBM and read them back here; that kernel, its two cross-stream
+// dependencies (~7 us each on the critical path) and its contention with the solves are gone.  The iterates' own items (the
+// two-sided objective) still read the tensor the solves used.
+template <int KIND>
+__global__ __launch_bounds__(64) void overlap_probe_build_d16_kernel(OverlapGradArgs p) {
+  constexpr int D = 16, N = 256, LD = 17;
+  __shared__ double2 sB[2 * D * LD];                // [s][i][j] with rows padded to 17
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int64_t b = blockIdx.x, nn = p.T * p.G2P;
+  const bool centre = b >= nn;                      // (with p.Bc set the launch carries T more items: the iterates themselves)
+  const int64_t t = centre ? b - nn : b / p.G2P;
+  if (p.active != nullptr && p.active[t] == 0) return;
+  double par[2][4], pai[2][4];      // B'_s in A-layout: lane (g, c) holds B'_s[c][4 kk + g]
+  v4f64 qbr[2], qbi[2];             // B'_s in B-layout: lane (g, c) holds B'_s[4 kk + g][c]
+  if (centre) {
+    const double2* Bp = (const double2*)p.Bc + t * (2 * N);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const double2 va = Bp[(s * D + c) * D + 4 * kk + g], vb = Bp[(s * D + 4 * kk + g) * D + c];
+        par[s][kk] = va.x;
+        pai[s][kk] = va.y;
+        qbr[s][kk] = vb.x;
+        qbi[s][kk] = vb.y;
+      }
+  } else {
+    const int P = p.G2P / 2, k = (int)(b - t * p.G2P);
+    const int isel = k % P;
+    const double shift = k < P ? p.fd_h : -p.fd_h;
+    // one sincos per angle and wave: lane l takes angle l (P <= 64)
+    double cn = 1.0, sn = 0.0;
+    if (lane < P) {
+      double v = p.fd_params[t * P + lane];
+      if (lane == isel) v += shift;
+      sincos(0.5 * v, &sn, &cn);
+    }
+    const int a = lane & 31;
+#pragma unroll 1
+    for (int w = 0; w < 8; ++w) {
+      const int j = 2 * w + (lane >> 5);
+      double re, im;
+      shallow_cnot_wave_column_d16<KIND>(cn, sn, P, j, re, im);
+      sB[((a & 1) * D + (a >> 1)) * LD + j] = make_double2(re, im);      // A[s][i][j] = amplitude[2 i + s] of column j
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const double2 va = sB[(s * D + c) * LD + 4 * kk + g], vb = sB[(s * D + 4 * kk + g) * LD + c];
+        par[s][kk] = va.x;
+        pai[s][kk] = va.y;
+        qbr[s][kk] = vb.x;
+        qbi[s][kk] = vb.y;
+      }
+  }
+  const double2* Gp = (const double2*)p.G + t * (4 * N);
+  double nr = 0.0, ni = 0.0;
+#pragma unroll
+  for (int s1 = 0; s1 < 2; ++s1)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      v4f64 mr = {0, 0, 0, 0}, mi = {0, 0, 0, 0};
+      cmma16_3m(par[s1], pai[s1], qbr[s2], qbi[s2], mr, mi);       // Bm'_s in the accumulator layout: register q, lane (g, c) = element [4 q + g][c]
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double2 gv = Gp[(2 * s1 + s2) * N + (4 * q + g) * D + c];
+        nr = dfma(mr[q], gv.x, dfma(mi[q], gv.y, nr));       // conj(bm) g
+        ni = dfma(mr[q], gv.y, dfma(-mi[q], gv.x, ni));
+      }
+    }
+  nr = wave_sum(nr);
+  ni = wave_sum(ni);
+  if (lane == 0) {
+    const double2 d = ((const double2*)p.yr)[t];
+    const double den = d.x * d.x + d.y * d.y;
+    const double er = (nr * d.x + ni * d.y) / den, ei = (ni * d.x - nr * d.y) / den;
+    const double f = -__builtin_sqrt(__builtin_sqrt(er * er + ei * ei));
+    if (centre) p.fc_out[t] = f;
+    else p.f_out[b] = f;
+  }
+}
+
 template <int D>
 static hipError_t launch_grad_d(const OverlapGradArgs& a, hipStream_t st) {
   constexpr int N = D * D, THREADS = N < 64 ? 64 : N, ITEMS = THREADS / N;
   if constexpr (D == 16) hipLaunchKernelGGL(overlap_g_d16_kernel, dim3((unsigned)a.T), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((overlap_g_kernel<D>), dim3((unsigned)((a.T + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);
   const int64_t nb = a.T * a.G2P + (a.Bc != nullptr ? a.T : 0);      // neighbours (+ the iterates themselves: same launch)
-  if constexpr (D == 16) hipLaunchKernelGGL(overlap_probe_d16_kernel, dim3((unsigned)nb), dim3(64), 0, st, a);
-  else hipLaunchKernelGGL((overlap_probe_kernel<D>), dim3((unsigned)((nb + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);
+  if constexpr (D == 16) {
+    if (a.fd_params != nullptr && overlap_probe_fusable(16, a.kind, a.G2P / 2)) {
+      if (a.kind == 0) hipLaunchKernelGGL(overlap_probe_build_d16_kernel<0>, dim3((unsigned)nb), dim3(64), 0, st, a);
+      else hipLaunchKernelGGL(overlap_probe_build_d16_kernel<3>, dim3((unsigned)nb), dim3(64), 0, st, a);
+    } else {
+      hipLaunchKernelGGL(overlap_probe_d16_kernel, dim3((unsigned)nb), dim3(64), 0, st, a);
+    }
+  } else hipLaunchKernelGGL((overlap_probe_kernel<D>), dim3((unsigned)((nb + ITEMS - 1) / ITEMS)), dim3(THREADS), 0, st, a);
   return hipGetLastError();
 }
 

@@ -136,9 +136,12 @@ extern "C" {
  *                         D = 16: cold starts only - warm-started batches run the lean loop)
  *   QMPS_D16_ONE_WAVE     D = 16 overlap objective, batches above 2 048 candidates: one wave per candidate with a static stride
  *                         (round 2) instead of four waves per candidate drawn from a work queue (no Krylov fall-back)
- *   QMPS_NO_FUSED_PROBE   D = 16 gradient batches (ShallowCNOT families): the 2 P central-difference neighbours' tensors built by a kernel of
- *                         their own into HBM (beside the eigen-solves, on a second stream) and read back by the probe kernel, instead of
- *                         built inside the probe kernel (same circuit, wave-distributed arithmetic: rounding-level differences)
+ *   QMPS_NEIGHBOURS_BESIDE  D = 16 gradient batches (ShallowCNOT families): the 2 P central-difference neighbours' tensors built by a kernel
+ *                         of their own on a second stream beside the eigen-solves (round 4: two cross-stream dependencies per batch) instead
+ *                         of by the surplus workgroups of the eigen-solve launch itself (same tensors to rounding: the one-lane-per-column
+ *                         and the wave-distributed circuit round differently)
+ *   QMPS_FUSED_PROBE      ... built inside the probe kernel, never written to HBM (measured slower: the probe kernel becomes
+ *                         instruction-bound, 43 us instead of 19 for 4 352 probes; kept as the third implementation of the same numbers)
  *   QMPS_EVOLVE_HOST_ALGEBRA  qmps_evolve_bfgs at D = 8, 16: directions, Armijo tests, H^-1 updates and masks on the HOST between two
  *                         gradient evaluations (the round-4 loop: a synchronisation and two staged copies per evaluation) instead of
  *                         in kernels on device-resident state with the host enqueueing chains of iterations.  Same numbers, bit for bit.

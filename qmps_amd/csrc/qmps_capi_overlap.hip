@@ -384,6 +384,10 @@ int enqueue_gradient_kernels(qmps_ctx* c, int64_t T, int kind, int P, const doub
   // batch of 256 iterates - which never hands anything over - an empty launch and a launch gap, ~10 us of ~200.
   bool lazy_krylov = false;
   const size_t nD = (size_t)c->D * c->D;
+  // where the 2 P central-difference neighbours' tensors come from (D = 16, ShallowCNOT families; see include/qmps_hip.h)
+  const bool fused_probe = qmps::overlap_probe_fusable(c->D, kind, P) && documented_switch("QMPS_FUSED_PROBE") != nullptr;
+  const bool built_in_pair = !fused_probe && qmps::neighbour_build_in_pair(c->D, kind, P) && documented_switch("QMPS_NEIGHBOURS_BESIDE") == nullptr;
+  bool neighbours_done = false;
   // the left fixed points: power method on the adjoint map; results behind the iterates' (eta, rounds, status at [T, 2T))
   qmps::OverlapArgs& l = gp.l;
   l = a;
@@ -398,7 +402,15 @@ int enqueue_gradient_kernels(qmps_ctx* c, int64_t T, int kind, int P, const doub
     if (int e = arm_krylov(c, a, 0)) return e;
     if (int e = arm_krylov(c, l, 1)) return e;
     lazy_krylov = allow_lazy_krylov && a.krylov_after > 0 && l.krylov_after > 0 && a.kry_counter != nullptr && l.kry_counter != nullptr;
-    HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream, !lazy_krylov));
+    // ... and the central-difference neighbours' tensors by the surplus workgroups of the same launch (ShallowCNOT families;
+    // QMPS_NEIGHBOURS_BESIDE: the round-4 kernel on the second stream, QMPS_FUSED_PROBE: inside the probe kernel)
+    qmps::NeighbourBuildArgs nb;
+    memset(&nb, 0, sizeof(nb));
+    if (built_in_pair) {
+      nb.params = d_src; nb.out = (char*)c->d_A + (size_t)T * tensor_bytes(c); nb.rows = T; nb.n_params = P; nb.kind = kind; nb.h = h; nb.active = mask;
+    }
+    HIP_TRY(qmps::launch_overlap_pair_d16(a, l, c->stream, !lazy_krylov, built_in_pair ? &nb : nullptr));
+    neighbours_done = built_in_pair;
   } else if (c->D == 8) {
     // D = 8: the same - one launch, the left solves on the SIMDs the right ones leave idle
     a.no_deflation = l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
@@ -418,9 +430,7 @@ int enqueue_gradient_kernels(qmps_ctx* c, int64_t T, int kind, int P, const doub
     l.no_deflation = documented_switch("QMPS_NO_DEFLATION") != nullptr ? 1 : 0;
     HIP_TRY(qmps::launch_overlap_d(c->D, l, c->D == 4 ? squaring : (c->D == 16 && documented_switch("QMPS_D16_BLOCK") == nullptr), c->stream));
   }
-  // D = 16, ShallowCNOT families: the probe kernel builds the neighbours itself (QMPS_NO_FUSED_PROBE: the round-4 path)
-  const bool fused_probe = qmps::overlap_probe_fusable(c->D, kind, P) && documented_switch("QMPS_NO_FUSED_PROBE") == nullptr;
-  if (fused_probe) {
+  if (fused_probe || neighbours_done) {
   } else if (beside) {
     HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
     HIP_TRY(qmps::launch_ansatz_fd(c->D, kind, d_src, P, (char*)c->d_A + (size_t)T * tensor_bytes(c), T, h, c->aux_stream, mask));
@@ -473,7 +483,10 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   // (beyond ~1 000 iterates the solves fill the chip by themselves: T = 2 048 measured 5 % slower with the second stream)
   // (a lock-step group of qmps_evolve_bfgs keeps to ONE stream: the other groups fill the chip, and two streams of one group that
   // land on the same hardware queue serialise - measured 5-10 % slower and erratic, profiles/EXPERIMENTS.md round 4)
-  const bool beside = T <= 1024 && !c->one_stream && !(qmps::overlap_probe_fusable(c->D, kind, P) && documented_switch("QMPS_NO_FUSED_PROBE") == nullptr);
+  const bool no_second_stream = (qmps::overlap_probe_fusable(c->D, kind, P) && documented_switch("QMPS_FUSED_PROBE") != nullptr) ||
+                                (qmps::neighbour_build_in_pair(c->D, kind, P) && documented_switch("QMPS_NEIGHBOURS_BESIDE") == nullptr &&
+                                 documented_switch("QMPS_D16_BLOCK") == nullptr && documented_switch("QMPS_D16_ONE_WAVE") == nullptr);
+  const bool beside = T <= 1024 && !c->one_stream && !no_second_stream;
   // the iterates: parameters -> tensors in d_A[0, T); the fork event sits between the parameter upload and the tensor build, and
   // the second stream is fed only AFTER the solves are submitted (the host calls of the fork used to hold the solves back ~15 us)
   int rc;
@@ -715,7 +728,10 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     c->ans_have = false; c->ans_src = nullptr; c->ans_i = nullptr; c->ans_nsh = 0; c->tensors_valid = false; c->n_states = 0;
   }
   const bool beside_dev = T <= 1024 && !c->one_stream;
-  const bool fused_probe_dev = qmps::overlap_probe_fusable(c->D, kind, P) && documented_switch("QMPS_NO_FUSED_PROBE") == nullptr;
+  // (no second stream when the neighbours' tensors are built inside the pair launch or inside the probe kernel)
+  const bool fused_probe_dev = (qmps::overlap_probe_fusable(c->D, kind, P) && documented_switch("QMPS_FUSED_PROBE") != nullptr) ||
+                               (qmps::neighbour_build_in_pair(c->D, kind, P) && documented_switch("QMPS_NEIGHBOURS_BESIDE") == nullptr &&
+                                documented_switch("QMPS_D16_BLOCK") == nullptr && documented_switch("QMPS_D16_ONE_WAVE") == nullptr);
   auto lock_args = [&](int step, bool reset_h, int mode) {
     qmps::LockstepArgs la;
     memset(&la, 0, sizeof(la));

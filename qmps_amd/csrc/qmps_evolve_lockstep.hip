@@ -35,7 +35,7 @@ namespace qmps {
 
 namespace {
 
-constexpr int LS_THREADS = 1024;
+constexpr int LS_THREADS = 1024;      // PL <= 8; 512 at PL = 16, 256 at PL = 32 (the gathered vectors live in registers)
 constexpr int LS_MAXP = 32;
 
 __device__ __forceinline__ bool st_ok(const LockstepArgs& p, int t) { return p.st[t] == QMPS_ST_OK && p.st[p.T + t] == QMPS_ST_OK; }
@@ -45,7 +45,7 @@ __device__ __forceinline__ int block_sum(int v, int* red) {
   __syncthreads();
   red[threadIdx.x] = v;
   __syncthreads();
-  for (int s = LS_THREADS / 2; s > 0; s >>= 1) {
+  for (int s = (int)blockDim.x / 2; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
@@ -57,9 +57,10 @@ __device__ __forceinline__ int block_sum(int v, int* red) {
 }  // namespace
 
 template <int PL>
-__global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs p) {
+__global__ __launch_bounds__(PL <= 8 ? 1024 : (PL == 16 ? 512 : 256)) void lockstep_step_kernel(LockstepArgs p) {
 #pragma clang fp contract(off)
-  constexpr int SLOTS = LS_THREADS / PL;
+  constexpr int THREADS = PL <= 8 ? 1024 : (PL == 16 ? 512 : 256);
+  constexpr int SLOTS = THREADS / PL;
   __shared__ int red[LS_THREADS];
   const int slot = threadIdx.x / PL, a = threadIdx.x % PL;
   const int gbase = (threadIdx.x & 63) & ~(PL - 1);      // first lane of this trajectory's group inside the wave
@@ -67,18 +68,25 @@ __global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs 
   const bool lane_on = a < P;
   const int n_active0 = p.ctl[0], nit0 = p.ctl[2], stop0 = p.ctl[3];
   const bool begin = p.mode == 1, open_only = p.mode == 2;
-  // component k of a per-trajectory vector held one component per lane (every lane of the wave takes part: no divergence around it)
-  auto comp = [&](double v, int k) { return __shfl(v, gbase + k, 64); };
+  // all components of a per-trajectory vector held one component per lane, into registers: PL shuffles issued back to back (every
+  // lane of the wave takes part: no divergence around it).  (First version: a shuffle where a component was needed, inside the
+  // sequential sums - ~100 dependent LDS-crossbar round trips per pass, 6 us.)
+  auto gather = [&](double v, double (&out)[PL]) {
+#pragma unroll
+    for (int k = 0; k < PL; ++k) out[k] = __shfl(v, gbase + k, 64);
+  };
   // np.abs(g).max() >= gtol, NaN-propagating (false with any NaN) - every lane of the group computes it alike
-  auto gmax_ok = [&](double gv) {
+  auto gmax_ok = [&](const double (&gv)[PL]) {
     double m = 0.0;
     bool isnan_ = false;
-    for (int k = 0; k < P; ++k) {
-      const double gk = comp(gv, k);
-      if (gk != gk) isnan_ = true;
-      const double ak = fabs(gk);
-      m = ak > m ? ak : m;
-    }
+#pragma unroll
+    for (int k = 0; k < PL; ++k)
+      if (k < P) {
+        const double gk = gv[k];
+        if (gk != gk) isnan_ = true;
+        const double ak = fabs(gk);
+        m = ak > m ? ak : m;
+      }
     return !isnan_ && m >= p.gtol;
   };
   __syncthreads();
@@ -117,7 +125,9 @@ __global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs 
         if (p.reset_h)
           for (int b = 0; b < P; ++b) H[a * P + b] = a == b ? 1.0 : 0.0;
       }
-      const bool act = gmax_ok(gnew);
+      double gn_all[PL];
+      gather(gnew, gn_all);
+      const bool act = gmax_ok(gn_all);
       if (on && a == 0) {
         const double f = ok ? fbt : nan;
         p.F[t] = f;
@@ -138,38 +148,42 @@ __global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs 
     const double a0 = moved ? p.alpha0 : 0.0;
     // ---- y = g_new - g, s = a0 d, the rank-two update (sums in index order, by every lane of the group alike)
     const double ya = gnew - gold, sa = a0 * dva;
+    double y_all[PL], s_all[PL];
+    gather(ya, y_all);
+    gather(sa, s_all);
     double sy = 0.0, ss = 0.0, yy = 0.0;
-    for (int k = 0; k < P; ++k) {
-      const double s = comp(sa, k), y = comp(ya, k);
-      sy += s * y;
-      ss += s * s;
-      yy += y * y;
-    }
+#pragma unroll
+    for (int k = 0; k < PL; ++k)
+      if (k < P) {
+        sy += s_all[k] * y_all[k];
+        ss += s_all[k] * s_all[k];
+        yy += y_all[k] * y_all[k];
+      }
     const bool upd = moved && sy > 1e-12 * sqrt(ss * yy) && sy > 0.0;
     const double rho = 1.0 / sy;
     double hya = 0.0;
 #pragma unroll
     for (int b = 0; b < PL; ++b)
-      if (b < P) hya += hrow[b] * comp(ya, b);
+      if (b < P) hya += hrow[b] * y_all[b];
+    double hy_all[PL];
+    gather(hya, hy_all);
     double yHy = 0.0;
-    for (int k = 0; k < P; ++k) yHy += comp(ya, k) * comp(hya, k);
-    const double coef = rho * (1.0 + rho * yHy);
-    // H' = H - rho (s (Hy)^T + (Hy) s^T) + rho (1 + rho y^T H y) s s^T   (the shuffles by every lane of the wave; stores predicated)
-    double hnew[PL];
 #pragma unroll
-    for (int b = 0; b < PL; ++b) {
-      const double sb = comp(sa, b < P ? b : 0), hyb = comp(hya, b < P ? b : 0);
-      hnew[b] = hrow[b] - (rho * sa * hyb + rho * sb * hya) + coef * sa * sb;
-    }
+    for (int k = 0; k < PL; ++k)
+      if (k < P) yHy += y_all[k] * hy_all[k];
+    const double coef = rho * (1.0 + rho * yHy);
+    // H' = H - rho (s (Hy)^T + (Hy) s^T) + rho (1 + rho y^T H y) s s^T
     if (on && lane_on && accepted) {
       if (upd)
 #pragma unroll
         for (int b = 0; b < PL; ++b)
-          if (b < P) H[a * P + b] = hnew[b];
+          if (b < P) H[a * P + b] = hrow[b] - (rho * sa * hy_all[b] + rho * s_all[b] * hya) + coef * sa * s_all[b];
       if (moved) p.G[tp + a] = gnew;
       p.X[tp + a] = xa + sa;
     }
-    const bool act = moved && gmax_ok(moved ? gnew : gold);
+    double gk_all[PL];
+    gather(moved ? gnew : gold, gk_all);
+    const bool act = moved && gmax_ok(gk_all);
     if (on && a == 0 && act_before) {
       if (need) {
         p.need[t] = 1;
@@ -223,15 +237,22 @@ __global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs 
     }
     // (a trajectory that has stopped keeps g and H^-1: its direction test had its one possible effect in iteration 0)
     const bool compute = on && (act || nit == 0);
+    double g_all[PL];
+    gather(ga, g_all);
     double acc = 0.0;
 #pragma unroll
     for (int b = 0; b < PL; ++b)
-      if (b < P) acc += hrow[b] * comp(ga, b);
+      if (b < P) acc += hrow[b] * g_all[b];
     double dv = -acc;
-    double sl = 0.0;
-    for (int k = 0; k < P; ++k) sl += comp(ga, k) * comp(dv, k);
-    double sl_sd = 0.0;                                  // slope of steepest descent (computed by all: no divergence around the shuffles)
-    for (int k = 0; k < P; ++k) { const double gk = comp(ga, k); sl_sd -= gk * gk; }
+    double d_all[PL];
+    gather(dv, d_all);
+    double sl = 0.0, sl_sd = 0.0;                        // slope along d; slope of steepest descent
+#pragma unroll
+    for (int k = 0; k < PL; ++k)
+      if (k < P) {
+        sl += g_all[k] * d_all[k];
+        sl_sd -= g_all[k] * g_all[k];
+      }
     const bool restart = !(sl < 0.0);                    // not a descent direction: restart from steepest descent
     if (restart) {
       sl = sl_sd;
@@ -254,10 +275,10 @@ __global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs 
 
 hipError_t launch_lockstep_step(const LockstepArgs& a, hipStream_t st) {
   if (a.P < 1 || a.P > LS_MAXP || a.T < 1 || a.T > 65535) return hipErrorInvalidValue;
-  if (a.P <= 4) hipLaunchKernelGGL(lockstep_step_kernel<4>, dim3(1), dim3(LS_THREADS), 0, st, a);
-  else if (a.P <= 8) hipLaunchKernelGGL(lockstep_step_kernel<8>, dim3(1), dim3(LS_THREADS), 0, st, a);
-  else if (a.P <= 16) hipLaunchKernelGGL(lockstep_step_kernel<16>, dim3(1), dim3(LS_THREADS), 0, st, a);
-  else hipLaunchKernelGGL(lockstep_step_kernel<32>, dim3(1), dim3(LS_THREADS), 0, st, a);
+  if (a.P <= 4) hipLaunchKernelGGL(lockstep_step_kernel<4>, dim3(1), dim3(1024), 0, st, a);
+  else if (a.P <= 8) hipLaunchKernelGGL(lockstep_step_kernel<8>, dim3(1), dim3(1024), 0, st, a);
+  else if (a.P <= 16) hipLaunchKernelGGL(lockstep_step_kernel<16>, dim3(1), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL(lockstep_step_kernel<32>, dim3(1), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

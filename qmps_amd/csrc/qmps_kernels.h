@@ -330,7 +330,17 @@ hipError_t launch_overlap_krylov_pair(int D, const OverlapArgs& right, const Ove
 hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st);
 // D = 16, at most 8192 evaluations in all: right fixed points (`right`) and left fixed points (`left`, adjoint map) in ONE launch, four waves per evaluation
 // (krylov_now = false: the caller launches the fall-back itself - launch_overlap_krylov_pair - if and when a status asks for it)
-hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st, bool krylov_now = true);
+// central-difference neighbours built by the surplus workgroups of the D = 16 pair launch (ShallowCNOT families; see overlap_mfma_d16x4_pair_kernel)
+struct NeighbourBuildArgs {
+  const double* params;          // [rows][n_params] parameter rows of the iterates (device); nullptr: nothing to build
+  void* out;                     // [rows * 2 n_params][2][16][16]: neighbour 2 P r + k = row r with +h (k < P) / -h (k >= P) on parameter k mod P
+  int64_t rows;
+  int n_params, kind;            // kind 0 (ShallowCNOT) or 3 (ShallowCNOT3)
+  double h;
+  const unsigned char* active;   // nullable [rows]: 0 = skip the row
+};
+inline bool neighbour_build_in_pair(int D, int kind, int n_params) { return D == 16 && (kind == 0 || kind == 3) && n_params >= 1 && n_params <= 64; }
+hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st, bool krylov_now = true, const NeighbourBuildArgs* build = nullptr);
 hipError_t launch_overlap_pair_d8(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st, bool krylov_now = true);
 // brick-wall (new_tdvp) contractions: what = 0 two-site <O>, 1 four-site <O>, 2 environment matrix + eigenpair, 3 manifold overlap
 struct BwArgs {

@@ -20,12 +20,14 @@
 //                              (layouts as in energy_mfma_d16_kernel: C-layout of a product == B-layout of the next;
 //                              Bm_s^+ in B-layout == conj of Bm_s in A-layout).
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdlib.h>
 #include <stdint.h>
 
 #include "qmps_kernels.h"
 #include "qmps_knobs.h"
 #include "qmps_device.h"
+#include "qmps_circuit_wave.h"
 #include "qmps_overlap_d2.h"
 #include "qmps_overlap_d4.h"
 
@@ -841,12 +843,44 @@ __global__ __launch_bounds__(256, 3) void overlap_mfma_d16x4_kernel(OverlapArgs 
 
 // RIGHT and LEFT fixed points in one launch (qmps_overlap_gradient): workgroups [0, n_right) run the map of `pr`, the others the
 // adjoint map of `pl` - twice the waves in flight for the same length of the (latency-bound) iteration chain
+// Round 5: the workgroups behind the solves, [n_right + n_left, gridDim), BUILD THE CENTRAL-DIFFERENCE NEIGHBOURS' TENSORS of the same
+// gradient evaluation (nb.params != nullptr; ShallowCNOT families: the wave-distributed circuit of qmps_circuit_wave.h, one wave
+// per neighbour, two columns per pass).  The solves are a latency-bound chain on the matrix cores whose stragglers leave most of
+// the chip idle; the builds are vector work with no dependence on them - in round 4 a kernel of their own on a second stream,
+// which cost the critical path two cross-stream dependencies (~7 us each) per evaluation.  Solver workgroups come first in the
+// grid, so they are dispatched first; the builders fill what is left and the tail.
 template <bool DEFL>
-__global__ __launch_bounds__(256, 3) void overlap_mfma_d16x4_pair_kernel(OverlapArgs pr, OverlapArgs pl, int n_right) {
+__global__ __launch_bounds__(256, 3) void overlap_mfma_d16x4_pair_kernel(OverlapArgs pr, OverlapArgs pl, int n_right, int n_left, NeighbourBuildArgs nb) {
   __shared__ double2 sT_all[4][16 * 17];
   __shared__ double2 sX_all[8][16 * 16];
   if ((int)blockIdx.x < n_right) overlap_mfma_d16x4_body<false, DEFL>(pr, blockIdx.x, n_right, sT_all, sX_all);
-  else overlap_mfma_d16x4_body<true, DEFL>(pl, blockIdx.x - n_right, gridDim.x - n_right, sT_all, sX_all);
+  else if ((int)blockIdx.x < n_right + n_left) overlap_mfma_d16x4_body<true, DEFL>(pl, blockIdx.x - n_right, n_left, sT_all, sX_all);
+  else {
+    const int lane = threadIdx.x & 63, a = lane & 31;
+    const int P = nb.n_params;
+    const int64_t n_neigh = nb.rows * 2 * P;
+    for (int64_t b = ((int64_t)blockIdx.x - n_right - n_left) * 4 + (threadIdx.x >> 6); b < n_neigh; b += ((int64_t)gridDim.x - n_right - n_left) * 4) {
+      const int64_t row = b / (2 * P);
+      if (nb.active != nullptr && nb.active[row] == 0) continue;       // (a skipped trajectory's neighbours are never read)
+      const int k = (int)(b - row * 2 * P), isel = k % P;
+      // one sincos per angle and wave: lane l takes angle l (P <= 64)
+      double cn = 1.0, sn = 0.0;
+      if (lane < P) {
+        double v = nb.params[row * P + lane];
+        if (lane == isel) v += k < P ? nb.h : -nb.h;
+        sincos(0.5 * v, &sn, &cn);
+      }
+      double2* out = (double2*)nb.out + b * 512;
+#pragma unroll 1
+      for (int w = 0; w < 8; ++w) {
+        const int j = 2 * w + (lane >> 5);
+        double re, im;
+        if (nb.kind == 3) shallow_cnot_wave_column_d16<3>(cn, sn, P, j, re, im);
+        else shallow_cnot_wave_column_d16<0>(cn, sn, P, j, re, im);
+        out[((a & 1) * 16 + (a >> 1)) * 16 + j] = make_double2(re, im);      // A[s][i][j] = amplitude[2 i + s] of column j
+      }
+    }
+  }
 }
 
 // the Krylov fall-back behind a power launch (both solves of a pair launch): candidates given up are finished, the others untouched
@@ -868,12 +902,20 @@ hipError_t launch_overlap_pair_d8(const OverlapArgs& right, const OverlapArgs& l
   return krylov_now ? launch_krylov_after(8, right, &left, st) : hipSuccess;
 }
 
-hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st, bool krylov_now) {
+hipError_t launch_overlap_pair_d16(const OverlapArgs& right, const OverlapArgs& left, hipStream_t st, bool krylov_now, const NeighbourBuildArgs* build) {
   if (right.B <= 0) return hipSuccess;
   const int nr = (int)(right.B < 2048 ? right.B : 2048), nl = (int)(left.B < 2048 ? left.B : 2048);
+  NeighbourBuildArgs nb;
+  memset(&nb, 0, sizeof(nb));
+  int n_build = 0;
+  if (build != nullptr && build->params != nullptr && build->rows > 0) {
+    nb = *build;
+    const int64_t n_neigh = nb.rows * 2 * nb.n_params;
+    n_build = (int)((n_neigh + 3) / 4 < 4096 ? (n_neigh + 3) / 4 : 4096);      // one wave per neighbour (a stride beyond 16 384 of them)
+  }
   // (deflation steps for cold starts only, see overlap_mfma_d16x4_body)
-  if (right.x_in == nullptr && right.no_deflation == 0) hipLaunchKernelGGL(overlap_mfma_d16x4_pair_kernel<true>, dim3((unsigned)(nr + nl)), dim3(256), 0, st, right, left, nr);
-  else hipLaunchKernelGGL(overlap_mfma_d16x4_pair_kernel<false>, dim3((unsigned)(nr + nl)), dim3(256), 0, st, right, left, nr);
+  if (right.x_in == nullptr && right.no_deflation == 0) hipLaunchKernelGGL(overlap_mfma_d16x4_pair_kernel<true>, dim3((unsigned)(nr + nl + n_build)), dim3(256), 0, st, right, left, nr, nl, nb);
+  else hipLaunchKernelGGL(overlap_mfma_d16x4_pair_kernel<false>, dim3((unsigned)(nr + nl + n_build)), dim3(256), 0, st, right, left, nr, nl, nb);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   return krylov_now ? launch_krylov_after(16, right, &left, st) : hipSuccess;
 }

@@ -686,30 +686,34 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   const bool dev_algebra = two_sided && (c->D == 8 || c->D == 16) && P <= 32 && T <= 65535 && documented_switch("QMPS_EVOLVE_HOST_ALGEBRA") == nullptr &&
                            documented_switch("QMPS_D16_BLOCK") == nullptr && documented_switch("QMPS_D16_ONE_WAVE") == nullptr;
   struct {
-    double *X, *G, *Gs, *Hy, *H, *F, *Dv, *slope, *Xc, *fh, *ph;
-    int* ctl;
+    double *X, *G, *H, *F, *Dv, *slope, *Xc, *fh, *ph, *F0, *asel, *alphas, *cand;
+    int* ctl;          // [0, 4) the control word; [16, 16 + maxiter + 1): trajectories that rejected the full step, per iteration of the time step
     unsigned char *active, *eff, *need;
   } dv = {};
   // first chain of a time step: as many iterations as the previous step took (the lock-step count is steady along an evolution with
   // carried Hessians; an idle iteration at the tail of a chain costs ~40 us of empty launches, a chain too short a synchronisation
   // per further iteration); QMPS_EVOLVE_CHAIN (tuning builds) fixes it
   int chain_fixed = 0, nit_prev = 4;
+  std::vector<unsigned char> rej_prev;      // iterations of the previous time step in which a full step was rejected
   if (const char* e = tuning_knob("QMPS_EVOLVE_CHAIN")) chain_fixed = atoi(e) > 0 ? atoi(e) : 0;
   if (dev_algebra) {
-    const size_t n_dbl = 6 * TP + TP * P + 2 * (size_t)T + (size_t)n_steps * 2 * T + (size_t)n_steps * TP;
-    const size_t bytes = n_dbl * sizeof(double) + 16 * sizeof(int) + 3 * (((size_t)T + 7) / 8 * 8) + 64;
+    const size_t n_ctl = 16 + (size_t)maxiter + 2;
+    const size_t n_dbl = 4 * TP + TP * P + 4 * (size_t)T + (size_t)n_steps * 2 * T + (size_t)n_steps * TP + (size_t)NA + (size_t)T * (G > 0 ? G : 1) * P;
+    const size_t bytes = n_dbl * sizeof(double) + (n_ctl + (n_ctl & 1)) * sizeof(int) + 3 * (((size_t)T + 7) / 8 * 8) + 64;
     if (bytes > c->d_lock_bytes) {
       if (c->d_lock) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_lock)); }
       c->d_lock = nullptr; c->d_lock_bytes = 0;
       HIP_TRY(hipMalloc(&c->d_lock, bytes));
       c->d_lock_bytes = bytes;
     }
-    if (!c->h_ctl) HIP_TRY(hipHostMalloc((void**)&c->h_ctl, 64, hipHostMallocDefault));
     double* q = (double*)c->d_lock;
-    dv.X = q; q += TP; dv.G = q; q += TP; dv.Gs = q; q += TP; dv.Hy = q; q += TP; dv.Dv = q; q += TP; dv.Xc = q; q += TP;
-    dv.H = q; q += TP * P; dv.F = q; q += T; dv.slope = q; q += T; dv.fh = q; q += (size_t)n_steps * 2 * T; dv.ph = q; q += (size_t)n_steps * TP;
+    dv.X = q; q += TP; dv.G = q; q += TP; dv.Dv = q; q += TP; dv.Xc = q; q += TP;
+    dv.H = q; q += TP * P; dv.F = q; q += T; dv.slope = q; q += T; dv.F0 = q; q += T; dv.asel = q; q += T;
+    dv.fh = q; q += (size_t)n_steps * 2 * T; dv.ph = q; q += (size_t)n_steps * TP; dv.alphas = q; q += NA; dv.cand = q; q += (size_t)T * (G > 0 ? G : 1) * P;
     dv.ctl = (int*)q;
-    dv.active = (unsigned char*)(dv.ctl + 16); dv.eff = dv.active + ((size_t)T + 7) / 8 * 8; dv.need = dv.eff + ((size_t)T + 7) / 8 * 8;
+    dv.active = (unsigned char*)(dv.ctl + n_ctl + (n_ctl & 1)); dv.eff = dv.active + ((size_t)T + 7) / 8 * 8; dv.need = dv.eff + ((size_t)T + 7) / 8 * 8;
+    if (!c->d_active) HIP_TRY(hipMalloc((void**)&c->d_active, ((size_t)c->max_batch + 7) / 8 * 8));
+    if (!c->h_ctl) HIP_TRY(hipHostMalloc((void**)&c->h_ctl, 4096, hipHostMallocDefault));
     if ((rc = ensure_overlap_outputs(c))) return rc;
     if (!c->d_y) HIP_TRY(hipMalloc(&c->d_y, (size_t)c->max_batch * env_bytes(c)));
     { const size_t nD = (size_t)c->D * c->D; if ((rc = ensure_scratch(c, (size_t)T * (4 * nD + 1) * 16 + 256))) return rc; }
@@ -721,6 +725,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     }
     HIP_TRY(hipMemcpyAsync(dv.X, X.data(), TP * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(dv.H, Hinv.data(), TP * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dv.alphas, alphas, (size_t)NA * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if ((rc = set_ww(c, WW))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));       // (X, Hinv are pageable host vectors)
     c->window = 0;
@@ -735,7 +740,8 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   auto lock_args = [&](int step, bool reset_h, int mode) {
     qmps::LockstepArgs la;
     memset(&la, 0, sizeof(la));
-    la.X = dv.X; la.G = dv.G; la.Gs = dv.Gs; la.Hy = dv.Hy; la.H = dv.H; la.F = dv.F; la.Dv = dv.Dv; la.slope = dv.slope; la.Xc = dv.Xc;
+    la.X = dv.X; la.G = dv.G; la.H = dv.H; la.F = dv.F; la.Dv = dv.Dv; la.slope = dv.slope; la.Xc = dv.Xc;
+    la.F0 = dv.F0; la.asel = dv.asel; la.alphas = dv.alphas; la.cand = dv.cand; la.NA = NA;
     la.fb = c->d_f; la.st = c->d_status; la.active = dv.active; la.eff = dv.eff; la.need = dv.need; la.ctl = dv.ctl;
     la.fh_start = dv.fh + (size_t)step * 2 * T; la.fh_end = dv.fh + ((size_t)step * 2 + 1) * T; la.ph = dv.ph + (size_t)step * TP; la.mode = mode;
     la.T = (int)T; la.P = P; la.maxiter = maxiter; la.reset_h = reset_h ? 1 : 0; la.h = h; la.gtol = gtol; la.c1 = c1; la.alpha0 = alphas[0];
@@ -768,6 +774,29 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     nfev += (double)T * (2 * P + 1);
     int nit = 0;
     const qmps::LockstepArgs la = lock_args(step, false, 0);
+    // the ladder of an iteration that stopped on rejected full steps, and what follows it - enqueued only: candidates of every
+    // trajectory, their solves masked by `need` and started from the rejected steps' fixed points, the verdict, the gradient at the
+    // accepted points (masked alike), the update and the next direction (step kernel, mode 3).  Every kernel of it does nothing
+    // when nothing was rejected, so it may be enqueued blindly where the previous time step had a rejection.
+    auto enqueue_ladder = [&]() -> int {
+      if (G <= 0) return fail(QMPS_ERR_ARG, "a rejected full step needs a ladder (n_alphas >= 2)");
+      HIP_TRY(qmps::launch_lockstep_ladder_cand(la, c->stream));
+      HIP_TRY(hipMemcpyAsync(c->d_active, dv.need, (size_t)T, hipMemcpyDeviceToDevice, c->stream));
+      c->mask_stash_n = 0; c->mask_host = nullptr; c->active_n = T;
+      c->ans_have = true; c->ans_kind = kind; c->ans_P = P; c->ans_src = dv.cand; c->ans_i = nullptr; c->ans_nsh = 0;
+      c->tensors_valid = false; c->n_states = T * G; c->window = 0;
+      c->overlap_group = G;
+      c->warm_from_group = (c->grad_warm_T == T) ? G : 0;      // (resident: the fixed points of the rejected full steps)
+      const int e = qmps_overlap_launch(c, T * G, ladder_rounds, tol, 0);
+      c->overlap_group = 0;
+      c->ans_have = false; c->ans_src = nullptr; c->tensors_valid = false; c->n_states = 0;
+      if (e) return e;
+      HIP_TRY(qmps::launch_lockstep_ladder_pick(la, c->d_f, c->d_status, c->stream));
+      if (int e2 = dev_gradient(dv.Xc, dv.need)) return e2;
+      HIP_TRY(qmps::launch_lockstep_step(lock_args(step, false, 3), c->stream));
+      return QMPS_OK;
+    };
+    HIP_TRY(hipMemsetAsync(dv.ctl + 16, 0, ((size_t)maxiter + 2) * sizeof(int), c->stream));      // this step's pattern of rejections
     bool first_chain = true;
     for (;;) {
       // with counters: one iteration per chain, so that every evaluation's event pair can be read (the timed region runs without)
@@ -778,129 +807,49 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
       for (int i = 0; i < K; ++i) {
         if ((rc = dev_gradient(dv.Xc, dv.eff))) break;
         HIP_TRY(qmps::launch_lockstep_step(la, c->stream));          // finish the iteration, open the next
+        // the previous time step had a rejection at this iteration: its ladder rides along (empty launches if nothing is rejected now)
+        if (!counters_out && (size_t)(nit + i) < rej_prev.size() && rej_prev[nit + i] && (rc = enqueue_ladder())) break;
       }
       if (rc) break;
-      HIP_TRY(hipMemcpyAsync(c->h_ctl, dv.ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      const size_t n_read = 16 + (size_t)maxiter + 1 < 1024 ? 16 + (size_t)maxiter + 1 : 1024;
+      HIP_TRY(hipMemcpyAsync(c->h_ctl, dv.ctl, n_read * sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
-      const int n_act = c->h_ctl[0], n_need = c->h_ctl[1], nit_dev = c->h_ctl[2], stop = c->h_ctl[3];
+      const int n_act = c->h_ctl[0], nit_dev = c->h_ctl[2], stop = c->h_ctl[3];
       if (counters_out && K > 0) {
         float ms = 0.f;
         if ((nit_dev > nit || stop) && qmps_kernel_time(c, 1, &ms, nullptr, 0) == QMPS_OK) grad_ms += ms;
       }
-      n_grad += (double)(nit_dev - nit) + (stop ? 1.0 : 0.0);
-      nfev += ((double)(nit_dev - nit) + (stop ? 1.0 : 0.0)) * (double)T * (2 * P + 1);
+      if (counters_out) {       // (K = 1: exact counts, as the host loop's)
+        n_grad += (double)(nit_dev - nit) + (stop ? 1.0 : 0.0);
+        nfev += ((double)(nit_dev - nit) + (stop ? 1.0 : 0.0)) * (double)T * (2 * P + 1);
+      }
       nit = nit_dev;
       if (stop) {
-        // ---- the rare path: some trajectories rejected the full step.  Their iteration is finished here, by the host loop's own
-        // expressions, on a copy of the state; the trajectories that accepted are already updated on the device.
-        (void)n_need;
-        std::vector<double> fb0(T);
-        std::vector<int32_t> st0(2 * (size_t)T);
-        HIP_TRY(hipMemcpyAsync(X.data(), dv.X, TP * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(g.data(), dv.G, TP * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(Hinv.data(), dv.H, TP * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(f.data(), dv.F, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(d.data(), dv.Dv, TP * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(slope.data(), dv.slope, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(active.data(), dv.active, (size_t)T, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(need.data(), dv.need, (size_t)T, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(fb0.data(), c->d_f, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(st0.data(), c->d_status, 2 * (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        // the ladder of the flagged trajectories (rungs 1 .. NA - 1; rung 0 is the rejected full step)
-        for (int64_t t = 0; t < T; ++t) {
-          double* Ft = &Fc[(size_t)t * NA];
-          for (int r = 0; r < NA; ++r) Ft[r] = INFINITY;
-          if (need[t]) {
-            const double v = (st0[t] == qmps::QMPS_ST_OK && st0[T + t] == qmps::QMPS_ST_OK) ? fb0[t] : nan;
-            Ft[0] = std::isfinite(v) ? v : INFINITY;
-          }
-        }
-        if (G > 0) {
-          cand.resize((size_t)T * G * P);
-          Fl.resize((size_t)T * G);
-          stl.resize((size_t)T * G);
-          for (int64_t t = 0; t < T; ++t)
-            for (int64_t r = 0; r < G; ++r)
-              for (int k = 0; k < P; ++k) cand[((size_t)t * G + r) * P + k] = X[(size_t)t * P + k] + alphas[r + 1] * d[(size_t)t * P + k];
-          if ((rc = qmps_overlap_set_group(c, G))) break;
-          if ((rc = qmps_overlap_set_active(c, T, need.data()))) break;
-          c->warm_from_group = (c->grad_warm_T == T) ? G : 0;      // (resident: the fixed points of the rejected full steps)
-          rc = qmps_overlap_eval_ansatz(c, T * G, kind, P, cand.data(), ladder_rounds, tol, 0, Fl.data(), stl.data());
-          (void)qmps_overlap_set_group(c, 0);
-          if (rc) break;
+        // some trajectories rejected the full step and no ladder was waiting: enqueue it now (no further synchronisation - the
+        // next chain follows at once)
+        if ((rc = enqueue_ladder())) break;
+        if (counters_out) {
+          HIP_TRY(hipStreamSynchronize(c->stream));
+          float ms = 0.f;
+          if (qmps_kernel_time(c, 1, &ms, nullptr, 0) == QMPS_OK) grad_ms += ms;
           n_ladder += 1.0;
-          nfev += (double)T * G;
-          for (int64_t t = 0; t < T; ++t)
-            for (int64_t r = 0; r < G; ++r) {
-              const double v = (need[t] && stl[(size_t)t * G + r] == qmps::QMPS_ST_OK) ? Fl[(size_t)t * G + r] : nan;
-              Fc[(size_t)t * NA + r + 1] = std::isfinite(v) ? v : INFINITY;
-            }
+          n_grad += 1.0;
+          nfev += (double)T * G + (double)T * (2 * P + 1);
         }
-        for (int64_t t = 0; t < T; ++t) {
-          moved[t] = 0;
-          for (int k = 0; k < P; ++k) { s[(size_t)t * P + k] = 0.0; Xn[(size_t)t * P + k] = X[(size_t)t * P + k]; }
-          if (!need[t]) continue;
-          const double* Ft = &Fc[(size_t)t * NA];
-          int first = -1, best = 0;
-          for (int r = 0; r < NA; ++r) {
-            if (first < 0 && Ft[r] <= f[t] + c1 * alphas[r] * slope[t]) first = r;
-            if (Ft[r] < Ft[best]) best = r;
-          }
-          if (first < 0) first = best;
-          moved[t] = (Ft[first] < f[t]) ? 1 : 0;
-          const double a = moved[t] ? alphas[first] : 0.0;
-          for (int k = 0; k < P; ++k) {
-            s[(size_t)t * P + k] = a * d[(size_t)t * P + k];
-            Xn[(size_t)t * P + k] = X[(size_t)t * P + k] + s[(size_t)t * P + k];
-          }
+        nit += 1;            // (the step kernel of mode 3 counts it on the device)
+        if (nit >= maxiter) {
+          HIP_TRY(hipStreamSynchronize(c->stream));
+          break;
         }
-        if ((rc = value_and_grad(Xn.data(), fn.data(), gn.data(), need.data()))) break;
-        int n_active_now = 0;
-        for (int64_t t = 0; t < T; ++t) {
-          if (need[t]) {
-            double* gt = &g[(size_t)t * P];
-            const double* gnt = &gn[(size_t)t * P];
-            const double* sv = &s[(size_t)t * P];
-            if (moved[t]) {
-              double sy = 0.0, ss = 0.0, yy = 0.0;
-              for (int k = 0; k < P; ++k) { const double y = gnt[k] - gt[k]; sy += sv[k] * y; ss += sv[k] * sv[k]; yy += y * y; }
-              if (sy > 1e-12 * sqrt(ss * yy) && sy > 0.0) {
-                double* Ht = &Hinv[(size_t)t * P * P];
-                const double rho = 1.0 / sy;
-                double yHy = 0.0;
-                for (int a = 0; a < P; ++a) {
-                  double acc = 0.0;
-                  for (int b = 0; b < P; ++b) acc += Ht[a * P + b] * (gnt[b] - gt[b]);
-                  Hy[a] = acc;
-                }
-                for (int a = 0; a < P; ++a) yHy += (gnt[a] - gt[a]) * Hy[a];
-                const double coef = rho * (1.0 + rho * yHy);
-                for (int a = 0; a < P; ++a)
-                  for (int b = 0; b < P; ++b) Ht[a * P + b] = Ht[a * P + b] - (rho * sv[a] * Hy[b] + rho * sv[b] * Hy[a]) + coef * sv[a] * sv[b];
-              }
-              f[t] = fn[t];
-              memcpy(gt, gnt, P * sizeof(double));
-            }
-            active[t] = (moved[t] && gmax_at_least(gt, gtol)) ? 1 : 0;
-            for (int k = 0; k < P; ++k) X[(size_t)t * P + k] = Xn[(size_t)t * P + k];
-          }
-          n_active_now += active[t] ? 1 : 0;
-        }
-        nit += 1;
-        const int ctl_new[4] = {n_active_now, 0, nit, 0};
-        HIP_TRY(hipMemcpyAsync(dv.X, X.data(), TP * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(dv.G, g.data(), TP * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(dv.H, Hinv.data(), TP * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(dv.F, f.data(), (size_t)T * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(dv.active, active.data(), (size_t)T, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(dv.ctl, ctl_new, sizeof(ctl_new), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));       // (pageable sources)
-        HIP_TRY(qmps::launch_lockstep_step(lock_args(step, false, 2), c->stream));    // the step's record; the next direction if the lock-step goes on
-        if (n_active_now == 0 || nit >= maxiter) break;
         continue;
       }
       if (n_act == 0 || nit >= maxiter) break;
+    }
+    if (rc) break;
+    {   // the pattern of rejections of this time step, for the next one's chain
+      const size_t n_hist = (size_t)nit < 1000 ? (size_t)nit : 1000;
+      rej_prev.assign(n_hist, 0);
+      for (size_t i = 0; i < n_hist; ++i) rej_prev[i] = c->h_ctl[16 + i] > 0 ? 1 : 0;
     }
     if (rc) break;
     // (the step's record - objective at the end, parameters - was written by the last live step kernel; on the device until the call ends)

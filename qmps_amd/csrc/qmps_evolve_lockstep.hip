@@ -67,7 +67,7 @@ __global__ __launch_bounds__(PL <= 8 ? 1024 : (PL == 16 ? 512 : 256)) void locks
   const int P = p.P;
   const bool lane_on = a < P;
   const int n_active0 = p.ctl[0], nit0 = p.ctl[2], stop0 = p.ctl[3];
-  const bool begin = p.mode == 1, open_only = p.mode == 2;
+  const bool begin = p.mode == 1, open_only = p.mode == 2, after_ladder = p.mode == 3;
   // all components of a per-trajectory vector held one component per lane, into registers: PL shuffles issued back to back (every
   // lane of the wave takes part: no divergence around it).  (First version: a shuffle where a component was needed, inside the
   // sequential sums - ~100 dependent LDS-crossbar round trips per pass, 6 us.)
@@ -93,7 +93,8 @@ __global__ __launch_bounds__(PL <= 8 ? 1024 : (PL == 16 ? 512 : 256)) void locks
   // ---------------------------------------------------------------------------------------------------------------------------
   // phase 1: ACCEPT (or BEGIN)
   // ---------------------------------------------------------------------------------------------------------------------------
-  const bool live = begin || open_only || !(n_active0 == 0 || stop0 != 0 || nit0 >= p.maxiter);
+  // mode 3 finishes an iteration that stopped on rejected full steps (their ladder and the gradient at the accepted points have run)
+  const bool live = begin || open_only || (after_ladder ? stop0 != 0 : !(n_active0 == 0 || stop0 != 0 || nit0 >= p.maxiter));
   if (!live) return;      // nothing to finish: the mask of the next evaluation stays empty (cleared when the lock-step stopped)
   int n_need = 0, n_active = 0;
   const double nan = __builtin_nan("");
@@ -107,6 +108,8 @@ __global__ __launch_bounds__(PL <= 8 ? 1024 : (PL == 16 ? 512 : 256)) void locks
     // ---- every load of the pass up front (independent: one memory round trip instead of one per use)
     const int st0 = p.st[ts], st1 = p.st[p.T + ts];
     const unsigned char act_b = begin ? 1 : p.active[ts];
+    const unsigned char need_b = after_ladder ? p.need[ts] : 0;
+    const double asel = after_ladder ? p.asel[ts] : 0.0;
     const double fbt = p.fb[ts];
     const double* fn = p.fb + p.T + (int64_t)ts * 2 * P;
     const double fna = fn[as], fnb = fn[P + as];
@@ -139,13 +142,14 @@ __global__ __launch_bounds__(PL <= 8 ? 1024 : (PL == 16 ? 512 : 256)) void locks
       continue;
     }
     // ---- the Armijo test of the full step (every lane of the group alike)
-    const bool act_before = on && act_b != 0;
+    // mode 0: the trajectories of this iteration's evaluation; mode 3: the ones that went through the ladder (the others keep their state)
+    const bool act_before = on && (after_ladder ? need_b != 0 : act_b != 0);
     const double fs = ok ? fbt : nan;
     const double Ft0 = (fs - fs == 0.0) ? fs : INFINITY;      // isfinite
-    const bool accepted = act_before && (Ft0 <= Ft + p.c1 * p.alpha0 * slp);
-    const bool need = act_before && !accepted;                 // rejected: ladder + gradient at the accepted point are the host's
-    const bool moved = accepted && Ft0 < Ft;
-    const double a0 = moved ? p.alpha0 : 0.0;
+    const bool accepted = act_before && (after_ladder || Ft0 <= Ft + p.c1 * p.alpha0 * slp);
+    const bool need = act_before && !accepted;                 // rejected: the ladder and the gradient at the accepted point come first
+    const bool moved = after_ladder ? (act_before && asel != 0.0) : (accepted && Ft0 < Ft);
+    const double a0 = after_ladder ? asel : (moved ? p.alpha0 : 0.0);     // (mode 3: the step length the ladder chose, 0 = no rung decreased f)
     // ---- y = g_new - g, s = a0 d, the rank-two update (sums in index order, by every lane of the group alike)
     const double ya = gnew - gold, sa = a0 * dva;
     double y_all[PL], s_all[PL];
@@ -184,13 +188,15 @@ __global__ __launch_bounds__(PL <= 8 ? 1024 : (PL == 16 ? 512 : 256)) void locks
     double gk_all[PL];
     gather(moved ? gnew : gold, gk_all);
     const bool act = moved && gmax_ok(gk_all);
+    if (after_ladder && on && a == 0 && !act_before) n_active += act_b != 0 ? 1 : 0;      // (not in the ladder: active as before)
     if (on && a == 0 && act_before) {
       if (need) {
+        p.F0[t] = Ft0;                                   // rung 0 of its ladder
         p.need[t] = 1;
         n_need += 1;
         n_active += 1;                                   // (still active until the host has finished its iteration)
       } else {
-        if (moved) p.F[t] = fbt;
+        if (moved) p.F[t] = fs;                          // (mode 0: finite; mode 3: NaN if the solve at the accepted point failed)
         p.active[t] = act ? 1 : 0;
         n_active += act ? 1 : 0;
       }
@@ -202,13 +208,14 @@ __global__ __launch_bounds__(PL <= 8 ? 1024 : (PL == 16 ? 512 : 256)) void locks
     n_active = both & 0xffff;
   }
   if (open_only) n_active = n_active0;                   // (the host finished the iteration and wrote the control word)
-  const int nit = open_only ? nit0 : (begin ? 0 : (n_need > 0 ? nit0 : nit0 + 1));
+  const int nit = open_only ? nit0 : (begin ? 0 : (n_need > 0 ? nit0 : nit0 + 1));           // (mode 3: n_need = 0, the iteration is complete)
   const int stop = open_only ? stop0 : (n_need > 0 ? 1 : 0);
   if (threadIdx.x == 0 && !open_only) {
     p.ctl[0] = n_active;
     p.ctl[1] = n_need;
     p.ctl[2] = nit;
     p.ctl[3] = stop;
+    if (!begin && !after_ladder && nit0 <= p.maxiter) p.ctl[16 + nit0] = n_need;      // the pattern of rejections of this time step
   }
   // ---------------------------------------------------------------------------------------------------------------------------
   // phase 2: DIRECTION of the next iteration (or an empty mask when the lock-step stops here)
@@ -271,6 +278,63 @@ __global__ __launch_bounds__(PL <= 8 ? 1024 : (PL == 16 ? 512 : 256)) void locks
       p.need[t] = 0;
     }
   }
+}
+
+// The ladder of an iteration that stopped on rejected full steps.  Candidates x + alphas[r + 1] d of EVERY trajectory (the batch is
+// trajectory-major; the solves are masked by `need`), as the host loop builds them.
+__global__ __launch_bounds__(256) void lockstep_ladder_cand_kernel(LockstepArgs p) {
+#pragma clang fp contract(off)
+  if (p.ctl[3] == 0) return;                             // (enqueued blindly: nothing was rejected)
+  const int G = p.NA - 1;
+  const int64_t n = (int64_t)p.T * G * p.P;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (int64_t)gridDim.x * 256) {
+    const int k = (int)(q % p.P);
+    const int64_t tr = q / p.P;
+    const int r = (int)(tr % G);
+    const int64_t t = tr / G;
+    p.cand[q] = p.X[t * p.P + k] + p.alphas[r + 1] * p.Dv[t * p.P + k];
+  }
+}
+
+// ... and its verdict: the first rung with the Armijo decrease, else the best one if it decreases f, else no step (the host loop's
+// rule); the accepted point goes into the parameter rows of the gradient evaluation that follows.
+__global__ __launch_bounds__(256) void lockstep_ladder_pick_kernel(LockstepArgs p, const double* __restrict__ fl, const int32_t* __restrict__ stl) {
+#pragma clang fp contract(off)
+  if (p.ctl[3] == 0) return;
+  const int G = p.NA - 1;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < p.T; t += gridDim.x * 256) {
+    double a = 0.0;
+    if (p.need[t] != 0) {
+      const double f = p.F[t], sl = p.slope[t];
+      int first = -1, best = 0;
+      double Fbest = p.F0[t], Ffirst = 0.0;
+      for (int r = 0; r < p.NA; ++r) {
+        double Fr;
+        if (r == 0) Fr = p.F0[t];
+        else {
+          const double v = fl[(int64_t)t * G + r - 1];
+          Fr = (stl[(int64_t)t * G + r - 1] == QMPS_ST_OK && v - v == 0.0) ? v : INFINITY;
+        }
+        if (first < 0 && Fr <= f + p.c1 * p.alphas[r] * sl) { first = r; Ffirst = Fr; }
+        if (Fr < Fbest) { best = r; Fbest = Fr; }
+      }
+      if (first < 0) { first = best; Ffirst = Fbest; }
+      if (Ffirst < f) a = p.alphas[first];
+    }
+    p.asel[t] = a;
+    for (int k = 0; k < p.P; ++k) p.Xc[(int64_t)t * p.P + k] = p.X[(int64_t)t * p.P + k] + a * p.Dv[(int64_t)t * p.P + k];
+  }
+}
+
+hipError_t launch_lockstep_ladder_cand(const LockstepArgs& a, hipStream_t st) {
+  const int64_t n = (int64_t)a.T * (a.NA - 1) * a.P;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lockstep_ladder_cand_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_lockstep_ladder_pick(const LockstepArgs& a, const double* fl, const int32_t* stl, hipStream_t st) {
+  hipLaunchKernelGGL(lockstep_ladder_pick_kernel, dim3((unsigned)((a.T + 255) / 256)), dim3(256), 0, st, a, fl, stl);
+  return hipGetLastError();
 }
 
 hipError_t launch_lockstep_step(const LockstepArgs& a, hipStream_t st) {

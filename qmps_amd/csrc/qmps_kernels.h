@@ -212,8 +212,6 @@ struct OverlapArgs {
 struct LockstepArgs {
   double* X;        // [T][P] iterates
   double* G;        // [T][P] gradients
-  double* Gs;       // [T][P] gradient at the candidate (scratch of the accept kernel)
-  double* Hy;       // [T][P] scratch of the rank-two update
   double* H;        // [T][P][P] inverse Hessians
   double* F;        // [T] objective at the iterates
   double* Dv;       // [T][P] directions
@@ -224,16 +222,27 @@ struct LockstepArgs {
   unsigned char* active; // [T] trajectories still iterating
   unsigned char* eff;    // [T] mask of the next evaluation (active, or all zero when the chain has nothing to do)
   unsigned char* need;   // [T] rejected the full step: waiting for the host's ladder
-  int* ctl;              // [0] active trajectories, [1] trajectories waiting for the ladder, [2] iterations done, [3] stop
+  int* ctl;              // [0] active trajectories, [1] trajectories waiting for the ladder, [2] iterations done, [3] stop;
+                         // [16 + k]: trajectories that rejected the full step of iteration k of this time step
   double* fh_start;      // nullable [T]: record of the objective at the start of the time step (mode 1)
   double* fh_end;        // [T] record of the objective after the last finished iteration (rewritten by every live launch)
   double* ph;            // [T][P] ... and of the parameters
   int T, P, maxiter, reset_h;
   int mode;              // 0: finish an iteration from its evaluation, open the next; 1: the same after the FIRST evaluation of a time step
-                         // (f, g, active set from the batch; H^-1 = 1 if reset_h); 2: open the next iteration only (the host has finished one)
+                         // (f, g, active set from the batch; H^-1 = 1 if reset_h); 2: open the next iteration only (the host has finished one);
+                         // 3: finish an iteration that stopped on rejected full steps, after their ladder and the gradient at the accepted points
   double h, gtol, c1, alpha0;
+  // the backtracking ladder of the trajectories that rejected the full step (lockstep_ladder_*_kernel)
+  double* F0;            // [T] objective of the rejected full step (rung 0)
+  double* asel;          // [T] the step length the ladder chose (0: no rung decreased f)
+  const double* alphas;  // [NA] the ladder (device copy); alphas[0] = alpha0
+  double* cand;          // [T][NA - 1][P] candidates x + alphas[r + 1] d (trajectory-major: the rows of the ladder's batch)
+  int NA;
 };
 hipError_t launch_lockstep_step(const LockstepArgs& a, hipStream_t st);       // n_params <= 32
+hipError_t launch_lockstep_ladder_cand(const LockstepArgs& a, hipStream_t st);
+// fl / stl: objectives and statuses of the ladder's batch [T (NA - 1)]; writes asel and the accepted points into Xc
+hipError_t launch_lockstep_ladder_pick(const LockstepArgs& a, const double* fl, const int32_t* stl, hipStream_t st);
 // two-sided first-order evaluation of central-difference neighbours (qmps_overlap_gradient; qmps_overlap_grad.hip)
 struct OverlapGradArgs {
   const void* A;       // [T][2][D][D] reference tensors

@@ -726,6 +726,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     HIP_TRY(hipMemcpyAsync(dv.X, X.data(), TP * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(dv.H, Hinv.data(), TP * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(dv.alphas, alphas, (size_t)NA * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(dv.ctl, 0, 16 * sizeof(int), c->stream));      // control word, barrier accumulators and arrival counter
     if ((rc = set_ww(c, WW))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));       // (X, Hinv are pageable host vectors)
     c->window = 0;
@@ -746,6 +747,15 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     la.fh_start = dv.fh + (size_t)step * 2 * T; la.fh_end = dv.fh + ((size_t)step * 2 + 1) * T; la.ph = dv.ph + (size_t)step * TP; la.mode = mode;
     la.T = (int)T; la.P = P; la.maxiter = maxiter; la.reset_h = reset_h ? 1 : 0; la.h = h; la.gtol = gtol; la.c1 = c1; la.alpha0 = alphas[0];
     return la;
+  };
+  int lock_epoch = 0;          // launches of the step kernel on this control word (its grid barrier counts arrivals against it)
+  const int lock_blocks = dev_algebra ? qmps::lockstep_step_blocks((int)T, P) : 0;
+  auto launch_step = [&](int step, bool reset_h, int mode) -> int {
+    qmps::LockstepArgs a2 = lock_args(step, reset_h, mode);
+    a2.epoch = ++lock_epoch;
+    a2.blocks = lock_blocks;
+    HIP_TRY(qmps::launch_lockstep_step(a2, c->stream));
+    return QMPS_OK;
   };
   // one evaluation of the rows at d_src (iterate tensors, both fixed points, neighbours, probes), enqueued only
   auto dev_gradient = [&](const double* d_src, const unsigned char* mask) -> int {
@@ -769,7 +779,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     c->overlap_refs = T;
     c->overlap_group = 0;
     if ((rc = dev_gradient(dv.X, nullptr))) break;
-    HIP_TRY(qmps::launch_lockstep_step(lock_args(step, reset_h, 1), c->stream));      // f, g, active set; the first direction
+    if ((rc = launch_step(step, reset_h, 1))) break;      // f, g, active set; the first direction
     n_grad += 1.0;
     nfev += (double)T * (2 * P + 1);
     int nit = 0;
@@ -793,8 +803,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
       if (e) return e;
       HIP_TRY(qmps::launch_lockstep_ladder_pick(la, c->d_f, c->d_status, c->stream));
       if (int e2 = dev_gradient(dv.Xc, dv.need)) return e2;
-      HIP_TRY(qmps::launch_lockstep_step(lock_args(step, false, 3), c->stream));
-      return QMPS_OK;
+      return launch_step(step, false, 3);
     };
     HIP_TRY(hipMemsetAsync(dv.ctl + 16, 0, ((size_t)maxiter + 2) * sizeof(int), c->stream));      // this step's pattern of rejections
     bool first_chain = true;
@@ -806,7 +815,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
       first_chain = false;
       for (int i = 0; i < K; ++i) {
         if ((rc = dev_gradient(dv.Xc, dv.eff))) break;
-        HIP_TRY(qmps::launch_lockstep_step(la, c->stream));          // finish the iteration, open the next
+        if ((rc = launch_step(step, false, 0))) break;               // finish the iteration, open the next
         // the previous time step had a rejection at this iteration: its ladder rides along (empty launches if nothing is rejected now)
         if (!counters_out && (size_t)(nit + i) < rej_prev.size() && rej_prev[nit + i] && (rc = enqueue_ladder())) break;
       }

@@ -35,7 +35,8 @@ namespace qmps {
 
 namespace {
 
-constexpr int LS_THREADS = 1024;      // PL <= 8; 512 at PL = 16, 256 at PL = 32 (the gathered vectors live in registers)
+constexpr int LS_THREADS = 256;       // per workgroup; LS_THREADS / PL trajectories per workgroup and pass
+constexpr int LS_MAX_BLOCKS = 64;
 constexpr int LS_MAXP = 32;
 
 __device__ __forceinline__ bool st_ok(const LockstepArgs& p, int t) { return p.st[t] == QMPS_ST_OK && p.st[p.T + t] == QMPS_ST_OK; }
@@ -57,10 +58,9 @@ __device__ __forceinline__ int block_sum(int v, int* red) {
 }  // namespace
 
 template <int PL>
-__global__ __launch_bounds__(PL <= 8 ? 1024 : (PL == 16 ? 512 : 256)) void lockstep_step_kernel(LockstepArgs p) {
+__global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs p) {
 #pragma clang fp contract(off)
-  constexpr int THREADS = PL <= 8 ? 1024 : (PL == 16 ? 512 : 256);
-  constexpr int SLOTS = THREADS / PL;
+  constexpr int SLOTS = LS_THREADS / PL;
   __shared__ int red[LS_THREADS];
   const int slot = threadIdx.x / PL, a = threadIdx.x % PL;
   const int gbase = (threadIdx.x & 63) & ~(PL - 1);      // first lane of this trajectory's group inside the wave
@@ -95,10 +95,11 @@ __global__ __launch_bounds__(PL <= 8 ? 1024 : (PL == 16 ? 512 : 256)) void locks
   // ---------------------------------------------------------------------------------------------------------------------------
   // mode 3 finishes an iteration that stopped on rejected full steps (their ladder and the gradient at the accepted points have run)
   const bool live = begin || open_only || (after_ladder ? stop0 != 0 : !(n_active0 == 0 || stop0 != 0 || nit0 >= p.maxiter));
-  if (!live) return;      // nothing to finish: the mask of the next evaluation stays empty (cleared when the lock-step stopped)
+  // (nothing to finish: the mask of the next evaluation stays empty - cleared when the lock-step stopped; the launch still takes part
+  // in the barrier below, whose arrival count the host's epoch relies on)
   int n_need = 0, n_active = 0;
   const double nan = __builtin_nan("");
-  for (int base = 0; base < p.T && !open_only; base += SLOTS) {
+  for (int base = blockIdx.x * SLOTS; base < p.T && !open_only && live; base += gridDim.x * SLOTS) {
     const int t = base + slot;
     const bool on = t < p.T;
     const int ts = on ? t : 0;
@@ -203,14 +204,39 @@ __global__ __launch_bounds__(PL <= 8 ? 1024 : (PL == 16 ? 512 : 256)) void locks
     }
   }
   {
-    const int both = block_sum((n_need << 16) | n_active, red);       // (T < 65 536: checked by the launcher)
+    const int both = block_sum((n_need << 16) | n_active, red);       // this workgroup's counts (T < 65 536: checked by the launcher)
     n_need = both >> 16;
     n_active = both & 0xffff;
+  }
+  // ---- grid barrier: the counts of all workgroups.  Accumulators ctl[8 + 2 e], ctl[9 + 2 e] of parity e = epoch & 1 (zeroed by the
+  // previous launch), arrival counter ctl[12] (monotonic: this launch completes it to epoch * gridDim).  Every workgroup has read
+  // the control word before it arrives, so workgroup 0 may rewrite it behind the barrier.  (The workgroups are few and small: all
+  // resident at once, the spin cannot starve one of them.)
+  if (gridDim.x > 1) {
+    const int e = p.epoch & 1;
+    if (threadIdx.x == 0) {
+      if (n_need) atomicAdd(p.ctl + 8 + 2 * e, n_need);
+      if (n_active) atomicAdd(p.ctl + 9 + 2 * e, n_active);
+      __threadfence();
+      atomicAdd(p.ctl + 12, 1);
+      const int target = p.epoch * (int)gridDim.x;
+      while (__hip_atomic_load(p.ctl + 12, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+      red[0] = __hip_atomic_load(p.ctl + 8 + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      red[1] = __hip_atomic_load(p.ctl + 9 + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    n_need = red[0];
+    n_active = red[1];
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // the other parity's accumulators, for the next launch
+      p.ctl[8 + 2 * (e ^ 1)] = 0;
+      p.ctl[9 + 2 * (e ^ 1)] = 0;
+    }
   }
   if (open_only) n_active = n_active0;                   // (the host finished the iteration and wrote the control word)
   const int nit = open_only ? nit0 : (begin ? 0 : (n_need > 0 ? nit0 : nit0 + 1));           // (mode 3: n_need = 0, the iteration is complete)
   const int stop = open_only ? stop0 : (n_need > 0 ? 1 : 0);
-  if (threadIdx.x == 0 && !open_only) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && !open_only && live) {
     p.ctl[0] = n_active;
     p.ctl[1] = n_need;
     p.ctl[2] = nit;
@@ -220,8 +246,9 @@ __global__ __launch_bounds__(PL <= 8 ? 1024 : (PL == 16 ? 512 : 256)) void locks
   // ---------------------------------------------------------------------------------------------------------------------------
   // phase 2: DIRECTION of the next iteration (or an empty mask when the lock-step stops here)
   // ---------------------------------------------------------------------------------------------------------------------------
+  if (!live) return;
   const bool go_on = n_active > 0 && stop == 0 && nit < p.maxiter;
-  for (int base = 0; base < p.T; base += SLOTS) {
+  for (int base = blockIdx.x * SLOTS; base < p.T; base += gridDim.x * SLOTS) {
     const int t = base + slot;
     const bool on = t < p.T;
     const int ts = on ? t : 0;
@@ -274,246 +301,6 @@ __global__ __launch_bounds__(PL <= 8 ? 1024 : (PL == 16 ? 512 : 256)) void locks
       p.Xc[tp + a] = xa + p.alpha0 * dv;
     }
     if (on && a == 0) {
-      p.eff[t] = act ? 1 : 0;
-      p.need[t] = 0;
-    }
-  }
-}
-
-// The same kernel for T <= NSET * (threads / PL) trajectories (config 4: 256 trajectories of 8 angles): every lane group owns NSET
-// trajectories whose state - row of H^-1, g, x, f - is loaded ONCE, all loads of all sets issued before the first use, and stays in
-// registers from the accept phase through the block-wide count into the direction phase.  The generic kernel above reloads per
-// pass and per phase: four memory round trips (~2.5 us each) where this one has one.  Same expressions, same order, same bits.
-template <int PL, int NSET, int THREADS>
-__global__ __launch_bounds__(THREADS) void lockstep_step_fast_kernel(LockstepArgs p) {
-#pragma clang fp contract(off)
-  constexpr int SLOTS = THREADS / PL;
-  __shared__ int red[LS_THREADS];
-  const int slot = threadIdx.x / PL, a = threadIdx.x % PL;
-  const int gbase = (threadIdx.x & 63) & ~(PL - 1);
-  const int P = p.P;
-  const bool lane_on = a < P;
-  const int as = lane_on ? a : 0;
-  const int n_active0 = p.ctl[0], nit0 = p.ctl[2], stop0 = p.ctl[3];
-  const bool begin = p.mode == 1, open_only = p.mode == 2, after_ladder = p.mode == 3;
-  auto gather = [&](double v, double (&out)[PL]) {
-#pragma unroll
-    for (int k = 0; k < PL; ++k) out[k] = __shfl(v, gbase + k, 64);
-  };
-  auto gmax_ok = [&](const double (&gv)[PL]) {
-    double m = 0.0;
-    bool isnan_ = false;
-#pragma unroll
-    for (int k = 0; k < PL; ++k)
-      if (k < P) {
-        const double gk = gv[k];
-        if (gk != gk) isnan_ = true;
-        const double ak = fabs(gk);
-        m = ak > m ? ak : m;
-      }
-    return !isnan_ && m >= p.gtol;
-  };
-  __syncthreads();
-  const bool live = begin || open_only || (after_ladder ? stop0 != 0 : !(n_active0 == 0 || stop0 != 0 || nit0 >= p.maxiter));
-  if (!live) return;
-  const double nan = __builtin_nan("");
-  // ---- the state of this lane group's trajectories: one round trip
-  int tt[NSET];
-  bool on[NSET], actv[NSET];
-  int st0[NSET], st1[NSET];
-  unsigned char need_b[NSET];
-  double asel[NSET], fbt[NSET], fna[NSET], fnb[NSET], Ft[NSET], slp[NSET], dva[NSET], ga[NSET], xa[NSET], hrow[NSET][PL];
-#pragma unroll
-  for (int u = 0; u < NSET; ++u) {
-    tt[u] = u * SLOTS + slot;
-    on[u] = tt[u] < p.T;
-    const int ts = on[u] ? tt[u] : 0;
-    const int64_t tp = (int64_t)ts * P;
-    st0[u] = p.st[ts];
-    st1[u] = p.st[p.T + ts];
-    actv[u] = begin ? true : p.active[ts] != 0;
-    need_b[u] = after_ladder ? p.need[ts] : 0;
-    asel[u] = after_ladder ? p.asel[ts] : 0.0;
-    fbt[u] = p.fb[ts];
-    const double* fn = p.fb + p.T + (int64_t)ts * 2 * P;
-    fna[u] = fn[as];
-    fnb[u] = fn[P + as];
-    Ft[u] = begin ? 0.0 : p.F[ts];
-    slp[u] = begin ? 0.0 : p.slope[ts];
-    dva[u] = begin ? 0.0 : p.Dv[tp + as];
-    ga[u] = begin ? 0.0 : p.G[tp + as];
-    xa[u] = p.X[tp + as];
-    const bool ident = begin && p.reset_h != 0;
-#pragma unroll
-    for (int b = 0; b < PL; ++b) hrow[u][b] = (b < P) ? (ident ? (a == b ? 1.0 : 0.0) : p.H[tp * P + as * P + b]) : 0.0;
-  }
-  // ---------------------------------------------------------------------------------------------------------------------------
-  // phase 1: ACCEPT (or BEGIN)
-  // ---------------------------------------------------------------------------------------------------------------------------
-  int n_need = 0, n_active = 0;
-#pragma unroll
-  for (int u = 0; u < NSET; ++u) {
-    if (open_only) break;
-    const int t = tt[u];
-    const int64_t tp = (int64_t)(on[u] ? t : 0) * P;
-    double* H = p.H + tp * P;
-    const bool ok = st0[u] == QMPS_ST_OK && st1[u] == QMPS_ST_OK;
-    const double gnew = ok ? (fna[u] - fnb[u]) / (2.0 * p.h) : nan;
-    if (begin) {
-      if (on[u] && lane_on) {
-        p.G[tp + a] = gnew;
-        if (p.reset_h)
-          for (int b = 0; b < P; ++b) H[a * P + b] = a == b ? 1.0 : 0.0;
-      }
-      ga[u] = gnew;
-      double gn_all[PL];
-      gather(gnew, gn_all);
-      const bool act = gmax_ok(gn_all);
-      const double f = ok ? fbt[u] : nan;
-      Ft[u] = f;
-      actv[u] = on[u] && act;
-      if (on[u] && a == 0) {
-        p.F[t] = f;
-        if (p.fh_start) p.fh_start[t] = f;
-        p.active[t] = act ? 1 : 0;
-        p.need[t] = 0;
-        n_active += act ? 1 : 0;
-      }
-      continue;
-    }
-    const bool act_before = on[u] && (after_ladder ? need_b[u] != 0 : actv[u]);
-    const double fs = ok ? fbt[u] : nan;
-    const double Ft0 = (fs - fs == 0.0) ? fs : INFINITY;
-    const bool accepted = act_before && (after_ladder || Ft0 <= Ft[u] + p.c1 * p.alpha0 * slp[u]);
-    const bool need = act_before && !accepted;
-    const bool moved = after_ladder ? (act_before && asel[u] != 0.0) : (accepted && Ft0 < Ft[u]);
-    const double a0 = after_ladder ? asel[u] : (moved ? p.alpha0 : 0.0);
-    const double ya = gnew - ga[u], sa = a0 * dva[u];
-    double y_all[PL], s_all[PL];
-    gather(ya, y_all);
-    gather(sa, s_all);
-    double sy = 0.0, ss = 0.0, yy = 0.0;
-#pragma unroll
-    for (int k = 0; k < PL; ++k)
-      if (k < P) {
-        sy += s_all[k] * y_all[k];
-        ss += s_all[k] * s_all[k];
-        yy += y_all[k] * y_all[k];
-      }
-    const bool upd = moved && sy > 1e-12 * sqrt(ss * yy) && sy > 0.0;
-    const double rho = 1.0 / sy;
-    double hya = 0.0;
-#pragma unroll
-    for (int b = 0; b < PL; ++b)
-      if (b < P) hya += hrow[u][b] * y_all[b];
-    double hy_all[PL];
-    gather(hya, hy_all);
-    double yHy = 0.0;
-#pragma unroll
-    for (int k = 0; k < PL; ++k)
-      if (k < P) yHy += y_all[k] * hy_all[k];
-    const double coef = rho * (1.0 + rho * yHy);
-    if (accepted && upd) {
-#pragma unroll
-      for (int b = 0; b < PL; ++b)
-        if (b < P) hrow[u][b] = hrow[u][b] - (rho * sa * hy_all[b] + rho * s_all[b] * hya) + coef * sa * s_all[b];
-    }
-    if (on[u] && lane_on && accepted) {
-      if (upd)
-#pragma unroll
-        for (int b = 0; b < PL; ++b)
-          if (b < P) H[a * P + b] = hrow[u][b];
-      if (moved) p.G[tp + a] = gnew;
-      p.X[tp + a] = xa[u] + sa;
-    }
-    if (accepted) xa[u] = xa[u] + sa;
-    if (moved) ga[u] = gnew;
-    double gk_all[PL];
-    gather(ga[u], gk_all);
-    const bool act = moved && gmax_ok(gk_all);
-    if (after_ladder && !act_before) {
-      if (on[u] && a == 0) n_active += actv[u] ? 1 : 0;      // (not in the ladder: active as before)
-    } else if (act_before) {
-      if (need) {
-        if (on[u] && a == 0) {
-          p.F0[t] = Ft0;
-          p.need[t] = 1;
-          n_need += 1;
-          n_active += 1;
-        }
-      } else {
-        if (moved) Ft[u] = fs;
-        actv[u] = act;
-        if (on[u] && a == 0) {
-          if (moved) p.F[t] = fs;
-          p.active[t] = act ? 1 : 0;
-          n_active += act ? 1 : 0;
-        }
-      }
-    }
-  }
-  {
-    const int both = block_sum((n_need << 16) | n_active, red);
-    n_need = both >> 16;
-    n_active = both & 0xffff;
-  }
-  if (open_only) n_active = n_active0;
-  const int nit = open_only ? nit0 : (begin ? 0 : (n_need > 0 ? nit0 : nit0 + 1));
-  const int stop = open_only ? stop0 : (n_need > 0 ? 1 : 0);
-  if (threadIdx.x == 0 && !open_only) {
-    p.ctl[0] = n_active;
-    p.ctl[1] = n_need;
-    p.ctl[2] = nit;
-    p.ctl[3] = stop;
-    if (!begin && !after_ladder && nit0 <= p.maxiter) p.ctl[16 + nit0] = n_need;
-  }
-  // ---------------------------------------------------------------------------------------------------------------------------
-  // phase 2: DIRECTION of the next iteration, from the registers
-  // ---------------------------------------------------------------------------------------------------------------------------
-  const bool go_on = n_active > 0 && stop == 0 && nit < p.maxiter;
-#pragma unroll
-  for (int u = 0; u < NSET; ++u) {
-    const int t = tt[u];
-    const int64_t tp = (int64_t)(on[u] ? t : 0) * P;
-    double* H = p.H + tp * P;
-    if (on[u] && lane_on) p.ph[tp + a] = xa[u];
-    if (on[u] && a == 0) p.fh_end[t] = Ft[u];
-    if (!go_on) {
-      if (on[u] && a == 0) p.eff[t] = 0;
-      continue;
-    }
-    const bool act = on[u] && actv[u];
-    const bool compute = on[u] && (act || nit == 0);
-    double g_all[PL];
-    gather(ga[u], g_all);
-    double acc = 0.0;
-#pragma unroll
-    for (int b = 0; b < PL; ++b)
-      if (b < P) acc += hrow[u][b] * g_all[b];
-    double dv = -acc;
-    double d_all[PL];
-    gather(dv, d_all);
-    double sl = 0.0, sl_sd = 0.0;
-#pragma unroll
-    for (int k = 0; k < PL; ++k)
-      if (k < P) {
-        sl += g_all[k] * d_all[k];
-        sl_sd -= g_all[k] * g_all[k];
-      }
-    const bool restart = !(sl < 0.0);
-    if (restart) {
-      sl = sl_sd;
-      dv = -ga[u];
-    }
-    if (compute && lane_on && restart)
-      for (int b = 0; b < P; ++b) H[a * P + b] = a == b ? 1.0 : 0.0;
-    if (compute && a == 0) p.slope[t] = sl;
-    if (!compute || !act) dv = 0.0;
-    if (on[u] && lane_on) {
-      p.Dv[tp + a] = dv;
-      p.Xc[tp + a] = xa[u] + p.alpha0 * dv;
-    }
-    if (on[u] && a == 0) {
       p.eff[t] = act ? 1 : 0;
       p.need[t] = 0;
     }
@@ -578,17 +365,23 @@ hipError_t launch_lockstep_ladder_pick(const LockstepArgs& a, const double* fl, 
 }
 
 hipError_t launch_lockstep_step(const LockstepArgs& a, hipStream_t st) {
-  if (a.P < 1 || a.P > LS_MAXP || a.T < 1 || a.T > 65535) return hipErrorInvalidValue;
-  // (register-resident variants: every lane group owns up to NSET trajectories)
-  // (512 threads: 256 VGPRs per lane - the sets' state and the gathered vectors fit without spilling; 1 024 threads spill from NSET = 2 on)
-  if (a.P <= 4 && a.T <= 512) hipLaunchKernelGGL((lockstep_step_fast_kernel<4, 2, 1024>), dim3(1), dim3(1024), 0, st, a);
-  else if (a.P > 4 && a.P <= 8 && a.T <= 128) hipLaunchKernelGGL((lockstep_step_fast_kernel<8, 1, 1024>), dim3(1), dim3(1024), 0, st, a);
-  else if (a.P > 4 && a.P <= 8 && a.T <= 256) hipLaunchKernelGGL((lockstep_step_fast_kernel<8, 4, 512>), dim3(1), dim3(512), 0, st, a);
-  else if (a.P <= 4) hipLaunchKernelGGL(lockstep_step_kernel<4>, dim3(1), dim3(1024), 0, st, a);
-  else if (a.P <= 8) hipLaunchKernelGGL(lockstep_step_kernel<8>, dim3(1), dim3(1024), 0, st, a);
-  else if (a.P <= 16) hipLaunchKernelGGL(lockstep_step_kernel<16>, dim3(1), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL(lockstep_step_kernel<32>, dim3(1), dim3(256), 0, st, a);
+  if (a.P < 1 || a.P > LS_MAXP || a.T < 1 || a.T > 65535 || a.epoch < 1) return hipErrorInvalidValue;
+  const int PL = a.P <= 4 ? 4 : (a.P <= 8 ? 8 : (a.P <= 16 ? 16 : 32));
+  const int slots = LS_THREADS / PL;
+  int nb = (a.T + slots - 1) / slots;
+  nb = nb > LS_MAX_BLOCKS ? LS_MAX_BLOCKS : nb;
+  if (nb != a.blocks) return hipErrorInvalidValue;       // (the host's epoch arithmetic assumes this grid: lockstep_step_blocks)
+  if (PL == 4) hipLaunchKernelGGL(lockstep_step_kernel<4>, dim3(nb), dim3(LS_THREADS), 0, st, a);
+  else if (PL == 8) hipLaunchKernelGGL(lockstep_step_kernel<8>, dim3(nb), dim3(LS_THREADS), 0, st, a);
+  else if (PL == 16) hipLaunchKernelGGL(lockstep_step_kernel<16>, dim3(nb), dim3(LS_THREADS), 0, st, a);
+  else hipLaunchKernelGGL(lockstep_step_kernel<32>, dim3(nb), dim3(LS_THREADS), 0, st, a);
   return hipGetLastError();
+}
+int lockstep_step_blocks(int T, int P) {
+  const int PL = P <= 4 ? 4 : (P <= 8 ? 8 : (P <= 16 ? 16 : 32));
+  const int slots = LS_THREADS / PL;
+  const int nb = (T + slots - 1) / slots;
+  return nb > LS_MAX_BLOCKS ? LS_MAX_BLOCKS : nb;
 }
 
 }  // namespace qmps

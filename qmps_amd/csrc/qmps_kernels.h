@@ -238,8 +238,11 @@ struct LockstepArgs {
   const double* alphas;  // [NA] the ladder (device copy); alphas[0] = alpha0
   double* cand;          // [T][NA - 1][P] candidates x + alphas[r + 1] d (trajectory-major: the rows of the ladder's batch)
   int NA;
+  // grid barrier of the step kernel: ctl[8 .. 12] (see lockstep_step_kernel); epoch = 1, 2, ... counts the launches on this control word
+  int epoch, blocks;
 };
 hipError_t launch_lockstep_step(const LockstepArgs& a, hipStream_t st);       // n_params <= 32
+int lockstep_step_blocks(int T, int n_params);
 hipError_t launch_lockstep_ladder_cand(const LockstepArgs& a, hipStream_t st);
 // fl / stl: objectives and statuses of the ladder's batch [T (NA - 1)]; writes asel and the accepted points into Xc
 hipError_t launch_lockstep_ladder_pick(const LockstepArgs& a, const double* fl, const int32_t* stl, hipStream_t st);

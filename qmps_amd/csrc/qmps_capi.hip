@@ -363,6 +363,7 @@ int qmps_destroy(qmps_ctx* c) try {
   if (c->h_mask) (void)hipHostFree(c->h_mask);
   if (c->d_lock) (void)hipFree(c->d_lock);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+  if (c->d_tolarr) (void)hipFree(c->d_tolarr);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);

@@ -106,7 +106,7 @@ namespace {
 // (qmps_set_states_ansatz, a batch-size check): a later, unrelated launch must never inherit them.
 struct DisarmOneShots {
   qmps_ctx* c;
-  ~DisarmOneShots() { c->active_n = 0; c->mask_stash_n = 0; c->mask_host = nullptr; c->fork_after_copy = nullptr; c->warm_from_group = 0; }
+  ~DisarmOneShots() { c->active_n = 0; c->mask_stash_n = 0; c->mask_host = nullptr; c->fork_after_copy = nullptr; c->warm_from_group = 0; c->grad_tol_in = nullptr; }
 };
 }  // namespace
 
@@ -371,7 +371,7 @@ struct GradPass {
   bool lazy_krylov = false;
 };
 int enqueue_gradient_kernels(qmps_ctx* c, int64_t T, int kind, int P, const double* d_src, double h, int max_rounds, double tol, bool warm, bool two_sided_f,
-                             const unsigned char* mask, bool beside, bool allow_lazy_krylov, GradPass& gp) {
+                             const unsigned char* mask, bool beside, bool allow_lazy_krylov, GradPass& gp, const double* tol_in = nullptr) {
   const bool squaring = overlap_squares(c);       // D = 4: the right fixed point comes from the squaring kernel (largest column)
   qmps::OverlapArgs& a = gp.a;
   memset(&a, 0, sizeof(a));
@@ -380,6 +380,7 @@ int enqueue_gradient_kernels(qmps_ctx* c, int64_t T, int kind, int P, const doub
   a.stats = c->d_ostats; a.iters = c->d_iters; a.status = c->d_status; a.B = T; a.a_shared = 0;
   a.max_rounds = squaring && max_rounds > 60 ? 60 : max_rounds; a.tol = tol;
   a.active = mask;
+  a.tol_in = (c->D == 8 || c->D == 16) ? tol_in : nullptr;      // per-trajectory tolerances (the lock-step BFGS; the left solve inherits them)
   // The Krylov fall-back of the two solves is launched only if a status asks for it (below): behind every batch, it cost a warm
   // batch of 256 iterates - which never hands anything over - an empty launch and a launch gap, ~10 us of ~200.
   bool lazy_krylov = false;
@@ -516,7 +517,9 @@ int qmps_overlap_gradient(qmps_ctx* c, int64_t T, int kind, int n_params, const 
   // The Krylov fall-back of the two solves is launched only if a status asks for it (below): behind every batch, it cost a warm
   // batch of 256 iterates - which never hands anything over - an empty launch and a launch gap, ~10 us of ~200.
   GradPass gp;
-  if (int e = enqueue_gradient_kernels(c, T, kind, P, c->d_params, h, max_rounds, tol, warm, (flags & QMPS_OVERLAP_TWO_SIDED_F) != 0, mask, beside, true, gp)) return e;
+  const double* tol_in = c->grad_tol_in;        // one-shot (qmps_evolve_bfgs, host loop): per-trajectory tolerances
+  c->grad_tol_in = nullptr;
+  if (int e = enqueue_gradient_kernels(c, T, kind, P, c->d_params, h, max_rounds, tol, warm, (flags & QMPS_OVERLAP_TWO_SIDED_F) != 0, mask, beside, true, gp, tol_in)) return e;
   const bool lazy_krylov = gp.lazy_krylov;
   qmps::OverlapArgs &a = gp.a, &l = gp.l;
   qmps::OverlapGradArgs& g = gp.g;
@@ -583,7 +586,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   if (int rc = bind(c)) return rc;
   DisarmOneShots disarm{c};      // nothing armed by this driver outlives it, whichever way it ends
   if (!params || !WW || !f_hist || !alphas) return fail(QMPS_ERR_ARG, "null argument");
-  if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
+  if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT | QMPS_BFGS_ADAPTIVE_GRADIENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
   const int P = n_params, NA = n_alphas;
   if (NA < 1 || NA > 64) return fail(QMPS_ERR_ARG, "n_alphas outside [1, 64]");
   const int64_t G = NA - 1;
@@ -600,7 +603,29 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   const int ladder_rounds = squaring ? (max_rounds > 60 ? 60 : max_rounds) : max_rounds;
   const int grad_rounds = max_rounds > 100000 ? max_rounds : 100000;       // (as _GroupedObjective.value_and_grad)
   // objective by the two-sided quotient (error ~ residual^2): the gradient batches' solves stop at 1e-8 (see qmps_hip.h)
-  const double grad_tol = (flags & QMPS_BFGS_TIGHT_GRADIENT) ? tol : (tol > 1e-8 ? tol : 1e-8);
+  double grad_tol = (flags & QMPS_BFGS_TIGHT_GRADIENT) ? tol : (tol > 1e-8 ? tol : 1e-8);
+  if (const char* e = tuning_knob("QMPS_GRAD_TOL")) grad_tol = atof(e);      // (tuning builds: profiles/EXPERIMENTS.md round 5)
+  // QMPS_BFGS_ADAPTIVE_GRADIENT (D = 8, 16): the solves of a trajectory's gradient stop at clamp(1e-3 max|g|, grad_tol, 1e-6), g the
+  // trajectory's current gradient (first evaluation of a time step: the gradient the previous step's first evaluation found; first
+  // step of a call: grad_tol).  The objective still comes from the two-sided quotient (error ~ residual^2 <= 1e-12, far inside the
+  // Armijo margin c1 |slope|: 1e-6 |g|^2 against 1e-4 |g|^2); the gradient carries a relative error <= ~1e-3.
+  const bool adaptive = (flags & QMPS_BFGS_ADAPTIVE_GRADIENT) != 0 && (flags & QMPS_BFGS_TIGHT_GRADIENT) == 0 && two_sided && (c->D == 8 || c->D == 16);
+  const double tol_min = grad_tol, tol_max = grad_tol > 1e-6 ? grad_tol : 1e-6, tol_rel = 1e-3;
+  std::vector<double> tolv(adaptive ? T : 0, tol_min), g0max_prev(adaptive ? T : 0, 0.0);
+  auto tol_rule = [&](double m, bool isnan_) {
+    const double t = tol_rel * m;
+    return isnan_ ? tol_min : (t < tol_min ? tol_min : (t > tol_max ? tol_max : t));
+  };
+  auto gmax_of = [&](const double* gt, bool& isnan_) {
+    double m = 0.0;
+    isnan_ = false;
+    for (int k = 0; k < P; ++k) {
+      if (gt[k] != gt[k]) isnan_ = true;
+      const double a = fabs(gt[k]);
+      m = a > m ? a : m;
+    }
+    return m;
+  };
   const size_t TP = (size_t)T * P;
   const double nan = __builtin_nan("");
   std::vector<double> X(params, params + TP), Hinv(TP * P), f(T), g(TP), d(TP), slope(T), fs(T), gs(TP), fn(T), gn(TP), Xc(TP), Xn(TP), s(TP), Fc((size_t)T * NA),
@@ -653,6 +678,12 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
       return QMPS_OK;
     }
     if (mask) { if (int e = qmps_overlap_set_active(c, T, mask)) return e; }
+    if (adaptive) {
+      if (!c->d_tolarr) HIP_TRY(hipMalloc((void**)&c->d_tolarr, (size_t)c->max_batch * sizeof(double)));
+      HIP_TRY(hipMemcpyAsync(c->d_tolarr, tolv.data(), (size_t)T * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      c->grad_tol_in = c->d_tolarr;
+    }
     if (int e = qmps_overlap_gradient(c, T, kind, P, Z, h, grad_rounds, grad_tol, (warm ? QMPS_OVERLAP_WARM : 0) | QMPS_OVERLAP_TWO_SIDED_F, fo, go, st.data())) return e;
     warm = true;
     for (int64_t t = 0; t < T; ++t)
@@ -686,7 +717,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   const bool dev_algebra = two_sided && (c->D == 8 || c->D == 16) && P <= 32 && T <= 65535 && documented_switch("QMPS_EVOLVE_HOST_ALGEBRA") == nullptr &&
                            documented_switch("QMPS_D16_BLOCK") == nullptr && documented_switch("QMPS_D16_ONE_WAVE") == nullptr;
   struct {
-    double *X, *G, *H, *F, *Dv, *slope, *Xc, *fh, *ph, *F0, *asel, *alphas, *cand;
+    double *X, *G, *H, *F, *Dv, *slope, *Xc, *fh, *ph, *F0, *asel, *alphas, *cand, *tolarr, *g0max;
     int* ctl;          // [0, 4) the control word; [16, 16 + maxiter + 1): trajectories that rejected the full step, per iteration of the time step
     unsigned char *active, *eff, *need;
   } dv = {};
@@ -698,7 +729,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   if (const char* e = tuning_knob("QMPS_EVOLVE_CHAIN")) chain_fixed = atoi(e) > 0 ? atoi(e) : 0;
   if (dev_algebra) {
     const size_t n_ctl = 16 + (size_t)maxiter + 2;
-    const size_t n_dbl = 4 * TP + TP * P + 4 * (size_t)T + (size_t)n_steps * 2 * T + (size_t)n_steps * TP + (size_t)NA + (size_t)T * (G > 0 ? G : 1) * P;
+    const size_t n_dbl = 4 * TP + TP * P + 6 * (size_t)T + (size_t)n_steps * 2 * T + (size_t)n_steps * TP + (size_t)NA + (size_t)T * (G > 0 ? G : 1) * P;
     const size_t bytes = n_dbl * sizeof(double) + (n_ctl + (n_ctl & 1)) * sizeof(int) + 3 * (((size_t)T + 7) / 8 * 8) + 64;
     if (bytes > c->d_lock_bytes) {
       if (c->d_lock) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_lock)); }
@@ -708,7 +739,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     }
     double* q = (double*)c->d_lock;
     dv.X = q; q += TP; dv.G = q; q += TP; dv.Dv = q; q += TP; dv.Xc = q; q += TP;
-    dv.H = q; q += TP * P; dv.F = q; q += T; dv.slope = q; q += T; dv.F0 = q; q += T; dv.asel = q; q += T;
+    dv.H = q; q += TP * P; dv.F = q; q += T; dv.slope = q; q += T; dv.F0 = q; q += T; dv.asel = q; q += T; dv.tolarr = q; q += T; dv.g0max = q; q += T;
     dv.fh = q; q += (size_t)n_steps * 2 * T; dv.ph = q; q += (size_t)n_steps * TP; dv.alphas = q; q += NA; dv.cand = q; q += (size_t)T * (G > 0 ? G : 1) * P;
     dv.ctl = (int*)q;
     dv.active = (unsigned char*)(dv.ctl + n_ctl + (n_ctl & 1)); dv.eff = dv.active + ((size_t)T + 7) / 8 * 8; dv.need = dv.eff + ((size_t)T + 7) / 8 * 8;
@@ -727,6 +758,10 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     HIP_TRY(hipMemcpyAsync(dv.H, Hinv.data(), TP * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(dv.alphas, alphas, (size_t)NA * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(dv.ctl, 0, 16 * sizeof(int), c->stream));      // control word, barrier accumulators and arrival counter
+    if (adaptive) {
+      HIP_TRY(hipMemcpyAsync(dv.tolarr, tolv.data(), (size_t)T * sizeof(double), hipMemcpyHostToDevice, c->stream));      // (first evaluation: the tightest)
+      HIP_TRY(hipMemsetAsync(dv.g0max, 0, (size_t)T * sizeof(double), c->stream));
+    }
     if ((rc = set_ww(c, WW))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));       // (X, Hinv are pageable host vectors)
     c->window = 0;
@@ -743,6 +778,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     memset(&la, 0, sizeof(la));
     la.X = dv.X; la.G = dv.G; la.H = dv.H; la.F = dv.F; la.Dv = dv.Dv; la.slope = dv.slope; la.Xc = dv.Xc;
     la.F0 = dv.F0; la.asel = dv.asel; la.alphas = dv.alphas; la.cand = dv.cand; la.NA = NA;
+    la.tol_next = adaptive ? dv.tolarr : nullptr; la.g0max = dv.g0max; la.tol_min = tol_min; la.tol_max = tol_max; la.tol_rel = tol_rel;
     la.fb = c->d_f; la.st = c->d_status; la.active = dv.active; la.eff = dv.eff; la.need = dv.need; la.ctl = dv.ctl;
     la.fh_start = dv.fh + (size_t)step * 2 * T; la.fh_end = dv.fh + ((size_t)step * 2 + 1) * T; la.ph = dv.ph + (size_t)step * TP; la.mode = mode;
     la.T = (int)T; la.P = P; la.maxiter = maxiter; la.reset_h = reset_h ? 1 : 0; la.h = h; la.gtol = gtol; la.c1 = c1; la.alpha0 = alphas[0];
@@ -766,7 +802,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     if (c->timed) HIP_TRY(hipEventRecord(c->kev0[tslot], c->stream));
     c->dominant = c->D == 16 ? "overlap_mfma_d16_kernel + adjoint + neighbour probes" : "overlap solve + adjoint + neighbour probes";
     GradPass gp;
-    if (int e = enqueue_gradient_kernels(c, T, kind, P, d_src, h, grad_rounds, grad_tol, warm, true, mask, beside_dev, false, gp)) return e;
+    if (int e = enqueue_gradient_kernels(c, T, kind, P, d_src, h, grad_rounds, grad_tol, warm, true, mask, beside_dev, false, gp, adaptive ? dv.tolarr : nullptr)) return e;
     if (c->timed) { HIP_TRY(hipEventRecord(c->kev1[tslot], c->stream)); c->samples++; }
     c->launches++;
     warm = true;
@@ -889,7 +925,15 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     }
     if (!(carry && (step > 0 || (warm && hinv))))
       for (int64_t t = 0; t < T; ++t) set_identity(t);
+    if (adaptive)      // first evaluation of a time step: by the gradient the previous step's first evaluation found (first step: the tightest)
+      for (int64_t t = 0; t < T; ++t) tolv[t] = tol_rule(g0max_prev[t], false);
     if ((rc = value_and_grad(X.data(), f.data(), g.data(), nullptr))) break;
+    if (adaptive)
+      for (int64_t t = 0; t < T; ++t) {
+        bool isn;
+        const double m = gmax_of(&g[(size_t)t * P], isn);
+        g0max_prev[t] = isn ? 0.0 : m;
+      }
     memcpy(f_hist + (size_t)step * 2 * T_hist + t_off, f.data(), (size_t)T * sizeof(double));          // objective at the start of the time step
     bool any_active = false;
     for (int64_t t = 0; t < T; ++t) { active[t] = gmax_at_least(&g[(size_t)t * P], gtol) ? 1 : 0; any_active |= active[t] != 0; }
@@ -921,6 +965,12 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
       }
       // the full step with its gradient, straight away
       for (size_t q = 0; q < TP; ++q) Xc[q] = X[q] + alphas[0] * d[q];
+      if (adaptive)      // by the trajectory's current gradient (the ladder's gradient at the accepted point, below, uses the same)
+        for (int64_t t = 0; t < T; ++t) {
+          bool isn;
+          const double m = gmax_of(&g[(size_t)t * P], isn);
+          tolv[t] = tol_rule(m, isn);
+        }
       if ((rc = value_and_grad(Xc.data(), fs.data(), gs.data(), active.data()))) break;
       bool all_accept = true;
       for (int64_t t = 0; t < T; ++t) {

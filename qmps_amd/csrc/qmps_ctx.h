@@ -93,6 +93,8 @@ struct qmps_ctx {
   const unsigned char* mask_stash = nullptr;
   const unsigned char* mask_host = nullptr;   //   the host copy of the mask the next launch consumes (stash mode; cleared with it): points into mask_copy
   std::vector<unsigned char> mask_copy;       //   ... which is ordinary host memory: no staging region can overwrite it
+  double* d_tolarr = nullptr;                 // qmps_evolve_bfgs (host loop, QMPS_BFGS_ADAPTIVE_GRADIENT): per-trajectory tolerances of the next gradient batch
+  const double* grad_tol_in = nullptr;        //   one-shot: consumed by the next qmps_overlap_gradient
   int* h_ctl = nullptr;                       // pinned: the control word of the device-resident lock-step BFGS, read back once per chain
   void* d_lock = nullptr;                     // device-resident state of the lock-step BFGS (qmps_evolve_lockstep.hip; lazy, grown on demand)
   size_t d_lock_bytes = 0;

@@ -76,9 +76,9 @@ __global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs 
     for (int k = 0; k < PL; ++k) out[k] = __shfl(v, gbase + k, 64);
   };
   // np.abs(g).max() >= gtol, NaN-propagating (false with any NaN) - every lane of the group computes it alike
-  auto gmax_ok = [&](const double (&gv)[PL]) {
+  auto gmax_of = [&](const double (&gv)[PL], bool& isnan_) {
     double m = 0.0;
-    bool isnan_ = false;
+    isnan_ = false;
 #pragma unroll
     for (int k = 0; k < PL; ++k)
       if (k < P) {
@@ -87,7 +87,17 @@ __global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs 
         const double ak = fabs(gk);
         m = ak > m ? ak : m;
       }
+    return m;
+  };
+  auto gmax_ok = [&](const double (&gv)[PL]) {
+    bool isnan_;
+    const double m = gmax_of(gv, isnan_);
     return !isnan_ && m >= p.gtol;
+  };
+  // tolerance of the eigen-solves of a gradient whose size is about m (NaN: the tightest)
+  auto tol_rule = [&](double m, bool isnan_) {
+    const double t = p.tol_rel * m;
+    return isnan_ ? p.tol_min : (t < p.tol_min ? p.tol_min : (t > p.tol_max ? p.tol_max : t));
   };
   __syncthreads();
   // ---------------------------------------------------------------------------------------------------------------------------
@@ -132,6 +142,11 @@ __global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs 
       double gn_all[PL];
       gather(gnew, gn_all);
       const bool act = gmax_ok(gn_all);
+      if (on && a == 0 && p.tol_next != nullptr) {
+        bool isn;
+        const double m = gmax_of(gn_all, isn);
+        p.g0max[t] = isn ? 0.0 : m;                      // (0 -> tol_min)
+      }
       if (on && a == 0) {
         const double f = ok ? fbt : nan;
         p.F[t] = f;
@@ -265,6 +280,17 @@ __global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs 
     // recorded again by the mode-2 launch that follows the host's update)
     if (on && lane_on) p.ph[tp + a] = xa;
     if (on && a == 0) p.fh_end[t] = Ft;
+    if (p.tol_next != nullptr) {
+      double gt_all[PL];
+      gather(ga, gt_all);
+      bool isn;
+      const double m = gmax_of(gt_all, isn);
+      if (on && a == 0) {
+        if (go_on) p.tol_next[t] = tol_rule(m, isn);                       // the next evaluation of this time step
+        else if (stop == 0) p.tol_next[t] = tol_rule(p.g0max[t], false);   // the first evaluation of the next time step
+        // (stopped on rejected steps: the gradient at the accepted points keeps this iteration's tolerances)
+      }
+    }
     if (!go_on) {
       if (on && a == 0) p.eff[t] = 0;
       continue;

@@ -205,6 +205,8 @@ struct OverlapArgs {
   int env_mode;                // 1 (D = 16): the ENVIRONMENT map r -> sum_{s<2} B_s r B_s^+ of the tensors Bt (A, WW unused); candidates with status
                                //   PENDING are solved, the fixed point is rotated to a positive trace, status stays PENDING (see LaneArgs), eta is not written
   int krylov_after;            // 0: plain power method to max_rounds (QMPS_NO_KRYLOV)
+  const double* tol_in;        // nullable [B / max(group, 1)]: residual tolerance PER TRAJECTORY instead of `tol` (the lock-step BFGS: a gradient's
+                               //   solves need not be more accurate than 1e-3 of the gradient itself); D = 8, 16 power / Krylov kernels
   int* kry_counter;            // the fall-back's three counters [work, exit tickets, candidates given up] - zero between launches (the
                                //   power kernels count what they give up, the fall-back clears all three when it is done); null = no fall-back
 };
@@ -238,6 +240,12 @@ struct LockstepArgs {
   const double* alphas;  // [NA] the ladder (device copy); alphas[0] = alpha0
   double* cand;          // [T][NA - 1][P] candidates x + alphas[r + 1] d (trajectory-major: the rows of the ladder's batch)
   int NA;
+  // per-trajectory tolerance of the NEXT evaluation's eigen-solves (QMPS_BFGS_ADAPTIVE_GRADIENT; tol_next nullptr = off):
+  //   clamp(tol_rel * max|g|, tol_min, tol_max) with g the trajectory's current gradient, or - when the time step ends here - the
+  //   gradient its first evaluation found (g0max: the next time step starts about as far from its minimum)
+  double* tol_next;      // [T]
+  double* g0max;         // [T]
+  double tol_min, tol_max, tol_rel;
   // grid barrier of the step kernel: ctl[8 .. 12] (see lockstep_step_kernel); epoch = 1, 2, ... counts the launches on this control word
   int epoch, blocks;
 };
@@ -273,6 +281,10 @@ inline bool overlap_probe_fusable(int D, int kind, int n_params) { return D == 1
 constexpr int kOverlapStatShards = 1024;
 #if defined(__HIPCC__)
 __device__ __forceinline__ int64_t overlap_ref_index(const OverlapArgs& p, int64_t b) { return p.group > 0 ? b / p.group : (p.a_shared ? 0 : b); }
+__device__ __forceinline__ double overlap_tol2(const OverlapArgs& p, int64_t b) {
+  const double t = p.tol_in != nullptr ? p.tol_in[p.group > 0 ? b / p.group : b] : p.tol;
+  return t * t;
+}
 __device__ __forceinline__ bool overlap_skipped(const OverlapArgs& p, int64_t b) { return p.active != nullptr && p.active[p.group > 0 ? b / p.group : b] == 0; }
 __device__ __forceinline__ int64_t overlap_slot_offset(const OverlapArgs& p) { return p.slot_ptr != nullptr ? (int64_t)(*p.slot_ptr) * p.slot_stride : 0; }
 // results of one evaluation (called by ONE lane)

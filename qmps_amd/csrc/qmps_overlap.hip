@@ -126,7 +126,7 @@ __device__ __forceinline__ void overlap_block_body(const OverlapArgs& p, int64_t
   double2 eta = make_double2(0.0, 0.0);
   int iters = 0, status = QMPS_ST_NOT_CONVERGED;
   bool active = true;
-  const double tol2 = p.tol * p.tol;
+  const double tol2 = overlap_tol2(p, b < p.B ? b : p.B - 1);
   // deflation steps (below): one evaluation per wave only - the branch must be uniform over the lanes of a reduction
   constexpr bool kDeflate = D == 8;
   double2 rp = make_double2(0.0, 0.0), sg_prev = make_double2(0.0, 0.0);
@@ -552,7 +552,6 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
   constexpr int D = 16, LD = 17;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   double2* sT = sT_all[wave];
-  const double tol2 = p.tol * p.tol;
   auto to_a_layout = [&](const v4f64& re, const v4f64& im, double (&are)[4], double (&aim)[4]) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -591,6 +590,7 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
     }
     if (b >= p.B) break;
     if (overlap_skipped(p, b)) continue;          // (uniform over the workgroup: all four waves see the same b)
+    const double tol2 = overlap_tol2(p, b);
     const double2* Ap = (const double2*)p.A + overlap_ref_index(p, b) * (2 * D * D);
     const double2* Bp = (const double2*)p.Bt + b * (2 * D * D);
     const double2* W = (const double2*)p.WW;

@@ -298,7 +298,7 @@ __device__ __forceinline__ void overlap_krylov_body(const OverlapArgs& p, int* c
   const bool has = D == 16 || tid < 64;
   const int e_row = D == 16 ? 4 * wave + g : (tid >> 3) & 7, e_col = D == 16 ? c : tid & 7;
   const int pos = D == 16 ? 16 * e_row + (e_col ^ e_row) : (tid & 63);
-  const double tol2 = p.tol * p.tol;
+  double tol2 = p.tol * p.tol;      // (per candidate: set at the head of the candidate loop)
   int red_set = 0;
   // sums of up to four values over the workgroup, bit-identical in every thread (two alternating scratch sets: one barrier per call)
   auto block_sum4 = [&](double (&v)[4]) {
@@ -348,6 +348,7 @@ __device__ __forceinline__ void overlap_krylov_body(const OverlapArgs& p, int* c
     }
     for (int64_t b = base; b < base + CHUNK && b < p.B; ++b) {
       if (overlap_skipped(p, b)) continue;
+      tol2 = overlap_tol2(p, b);
       const int used = p.iters[b];
       const bool env = D == 16 && p.env_mode != 0;
       if (p.status[b] != (env ? QMPS_ST_PENDING : QMPS_ST_NOT_CONVERGED)) continue;      // (uniform over the workgroup)

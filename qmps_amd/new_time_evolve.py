@@ -139,7 +139,7 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
           decisions as a plain ladder; at D = 2 the optimiser itself runs on the device, one wave per trajectory, every trajectory at
           its own pace: `qmps_evolve_bfgs_device`, options {'device_driver': False} for the host loop); options {'native': False} runs the same loop from numpy (`tools.batched_bfgs`, per-iteration
           objective history), {'speculative': False} the plain two-batch iteration (gradient columns, then the ladder);
-          'carry_hessian', 'tight_gradient', 'gradient', 'first_rungs', 'maxiter', 'gtol', 'eps', 'alphas' as in LockstepEvolver;
+          'carry_hessian', 'tight_gradient', 'adaptive_gradient', 'gradient', 'first_rungs', 'maxiter', 'gtol', 'eps', 'alphas' as in LockstepEvolver;
       anything else: scipy.optimize.minimize on the scalar `obj` per trajectory (the reference's own call).
     Returns the parameter history (n_steps + 1, [T,] P) [and an info dict with the objective history]."""
     cls = state_tensor or _default_class(D)
@@ -175,7 +175,8 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
         ev = LockstepEvolver(D, T, P, cls, mr, tol, opts.get('maxiter', 200), opts.get('gtol', 1e-5), opts.get('eps', 1e-6), ladder,
                              gradient=opts.get('gradient', 'auto'), first_rungs=opts.get('first_rungs'),
                              carry_hessian=opts.get('carry_hessian', False), speculative=opts.get('speculative', True), native=opts.get('native', True),
-                             tight_gradient=opts.get('tight_gradient', False), device_driver=opts.get('device_driver', True))
+                             tight_gradient=opts.get('tight_gradient', False), device_driver=opts.get('device_driver', True),
+                             adaptive_gradient=opts.get('adaptive_gradient', True))
         fg, fl = ev.fg, ev.fl
         try:
             for step in range(n_steps):
@@ -213,13 +214,16 @@ class LockstepEvolver:
 
     def __init__(self, D, T, P, cls=None, max_rounds=None, tol=1e-12, maxiter=200, gtol=1e-5, eps=1e-6,
                  alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), device=0, gradient='auto', first_rungs=None,
-                 carry_hessian=False, speculative=False, native=True, tight_gradient=False, device_driver=True):
+                 carry_hessian=False, speculative=False, native=True, tight_gradient=False, device_driver=True, adaptive_gradient=True):
         """native (with speculative and the two-sided gradient): the whole time step - every BFGS iteration of every trajectory - is
         ONE C call (qmps_evolve_bfgs: the loop of tools.batched_bfgs with its host arithmetic in C++ inside the library); False: the
         same loop in numpy, one ctypes call per batch.
         tight_gradient=False (two-sided gradient): the objective of an iterate comes from the two-sided quotient <y, T(r)>/<y, r> - its
         error is the product of the residuals of y and r - so the two eigen-solves of a gradient batch stop at max(tol, 1e-8): eta
         to ~1e-16, gradient to ~2e-8 (gtol = 1e-5; scipy's own forward differences carry ~1e-8), ~16 power steps fewer per solve.
+        adaptive_gradient (native driver, D = 8, 16, not with tight_gradient): QMPS_BFGS_ADAPTIVE_GRADIENT - a trajectory's gradient solves
+        stop at clamp(1e-3 max|g|, max(tol, 1e-8), 1e-6): same minima, a third fewer power steps (False: every batch to max(tol, 1e-8),
+        the numbers of the numpy loop).
         gradient: 'fd' = the 2P + 1 central-difference candidates are eigen-solved one by one (any D); 'two-sided' = one right
         and one left eigen-solve per iterate, the neighbours by the second-order formula eta' = <y, T'(r)>/<y, r> (D >= 4);
         'auto' = 'two-sided' where the library has it.  first_rungs: two-stage ladder (tools.batched_bfgs).
@@ -246,6 +250,7 @@ class LockstepEvolver:
                         (D == 4 and gradient == 'auto' and len(self.alphas) <= 9 and self.kind in (L.ANSATZ_SHALLOW_CNOT, 1, 3))))
         self.mr, self.tol = mr, tol
         self.tight_gradient = bool(tight_gradient) or not self.two_sided
+        self.adaptive_gradient = bool(adaptive_gradient) and not self.tight_gradient and D in (8, 16)
         if self.native:
             # one context serves the gradient batches and the (rare, cold-started) ladder batches
             self.fg = _GroupedObjective(D, self.kind, T, max(2 * P + 1, len(self.alphas) - 1), mr, tol, device=device)
@@ -279,7 +284,8 @@ class LockstepEvolver:
             return res
         res = self.fg.eng.evolve_bfgs(self.kind, X, WW, n_steps=n_steps, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas,
                                       carry_hessian=self.carry_hessian, hess_inv=self._hinv if (self.carry_hessian and self._continued) else None,
-                                      warm=self._continued, max_rounds=self.mr, tol=self.tol, tight_gradient=self.tight_gradient, counters=counters)
+                                      warm=self._continued, max_rounds=self.mr, tol=self.tol, tight_gradient=self.tight_gradient, counters=counters,
+                                      adaptive_gradient=self.adaptive_gradient)
         self._continued = True
         self._hinv = res['hess_inv']
         if self.fg.kernel_ms is not None and res['gradient_batches']:

@@ -363,7 +363,8 @@ def test_native_bfgs_driver_takes_the_decisions_of_the_numpy_loop(D, P, carry):
     out = {}
     for native in (False, True):
         H, info = NT.evolve(X0, WW, n_steps, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-13,
-                            options={'maxiter': 25, 'speculative': True, 'carry_hessian': carry, 'native': native, 'device_driver': False}, return_info=True)
+                            options={'maxiter': 25, 'speculative': True, 'carry_hessian': carry, 'native': native, 'device_driver': False,
+                                     'adaptive_gradient': False}, return_info=True)      # (the numpy loop solves every batch to max(tol, 1e-8))
         out[native] = (H, info)
     (Hn, In), (Hp, Ip) = out[True], out[False]
     assert Hn.shape == Hp.shape == (n_steps + 1, T, P)
@@ -382,8 +383,8 @@ def test_native_bfgs_driver_takes_the_decisions_of_the_numpy_loop(D, P, carry):
     assert all(f[-1].mean() < -0.999 for f in In['fun'])
     # one C call for three time steps = three calls of one step each (resident fixed points and inverse Hessians carried over)
     # (device_driver=False: this test is about the host loop in C++; the device-resident optimiser of D = 2, 4 has its own tests above)
-    ev = NT.LockstepEvolver(D, T, P, R.ShallowCNOTStateTensor, None, 1e-13, 25, 1e-5, 1e-6, speculative=True, carry_hessian=carry, device_driver=False)
-    ev2 = NT.LockstepEvolver(D, T, P, R.ShallowCNOTStateTensor, None, 1e-13, 25, 1e-5, 1e-6, speculative=True, carry_hessian=carry, device_driver=False)
+    ev = NT.LockstepEvolver(D, T, P, R.ShallowCNOTStateTensor, None, 1e-13, 25, 1e-5, 1e-6, speculative=True, carry_hessian=carry, device_driver=False, adaptive_gradient=False)
+    ev2 = NT.LockstepEvolver(D, T, P, R.ShallowCNOTStateTensor, None, 1e-13, 25, 1e-5, 1e-6, speculative=True, carry_hessian=carry, device_driver=False, adaptive_gradient=False)
     try:
         whole = ev.steps(X0, WW, n_steps)
         X = X0
@@ -398,15 +399,17 @@ def test_native_bfgs_driver_takes_the_decisions_of_the_numpy_loop(D, P, carry):
         ev2.close()
 
 
+@pytest.mark.parametrize('adaptive', [False, True])
 @pytest.mark.parametrize('D,P,T,carry,start', [(16, 8, 256, True, 'near'), (16, 8, 9, False, 'near'), (8, 6, 40, True, 'near'), (8, 6, 12, False, 'far'),
                                                 (16, 8, 5, True, 'far')])
-def test_device_algebra_takes_the_decisions_of_the_host_loop(D, P, T, carry, start, engine_factory, monkeypatch):
+def test_device_algebra_takes_the_decisions_of_the_host_loop(D, P, T, carry, start, adaptive, engine_factory, monkeypatch):
     """Round 5: at D = 8, 16 the algebra between two gradient evaluations (directions, Armijo test of the full step, rank-two update
     of H^-1, masks, next candidates) runs in kernels on device-resident state (qmps_evolve_lockstep.hip), the host only enqueues
     chains of iterations and finishes the rare iteration with a rejected full step.  QMPS_EVOLVE_HOST_ALGEBRA selects the round-4
     host loop.  Same evaluations, same expressions in the same order without contraction: the two must agree on every number -
     iteration counts, objectives, parameters, inverse Hessians - to the last bit, also across a continued call, with and without
-    rejected steps ('far': the second time step starts from a perturbed point, so that full steps get rejected)."""
+    rejected steps ('far': the second time step starts from a perturbed point, so that full steps get rejected), with the fixed and
+    with the adaptive tolerance of the gradient solves (QMPS_BFGS_ADAPTIVE_GRADIENT: the same rule in both implementations)."""
     rng = np.random.default_rng(5000 + D + T)
     X0 = rng.standard_normal((T, P))
     WW = WW_of(0.05)
@@ -421,10 +424,10 @@ def test_device_algebra_takes_the_decisions_of_the_host_loop(D, P, T, carry, sta
             monkeypatch.delenv('QMPS_EVOLVE_HOST_ALGEBRA', raising=False)
         eng = engine_factory(D, T * (2 * P + 1))
         cnt = name != 'device'
-        a = eng.evolve_bfgs(0, X0, WW, n_steps=1, maxiter=30, tol=1e-12, carry_hessian=carry, counters=cnt)
+        a = eng.evolve_bfgs(0, X0, WW, n_steps=1, maxiter=30, tol=1e-12, carry_hessian=carry, counters=cnt, adaptive_gradient=adaptive)
         X1 = a['x'] + (0.3 * np.random.default_rng(7).standard_normal(a['x'].shape) if start == 'far' else 0.0)
         b = eng.evolve_bfgs(0, X1, WW, n_steps=n_steps, maxiter=30, tol=1e-12, carry_hessian=carry, hess_inv=a['hess_inv'] if carry else None,
-                            warm=(start == 'near'), counters=cnt)
+                            warm=(start == 'near'), counters=cnt, adaptive_gradient=adaptive)
         out[name] = (a, b)
     monkeypatch.delenv('QMPS_EVOLVE_HOST_ALGEBRA', raising=False)
     for k in (0, 1):
@@ -446,6 +449,34 @@ def test_device_algebra_takes_the_decisions_of_the_host_loop(D, P, T, carry, sta
     for t in (0, T - 1):
         f_t = ER.objective(0, D, ER.tensor(0, D, prev[t]), dv['params_hist'][-1, t], WW, arpack=D >= 16)
         assert abs(f_t - dv['fun'][-1, t]) < F_TOL
+
+
+@pytest.mark.parametrize('D,P,T', [(16, 8, 48), (8, 6, 40)])
+def test_adaptive_gradient_tolerance_reaches_the_same_minima(D, P, T, engine_factory):
+    """QMPS_BFGS_ADAPTIVE_GRADIENT: the eigen-solves behind a trajectory's gradient stop at clamp(1e-3 max|g|, 1e-8, 1e-6) instead of 1e-8.
+    An inexact-gradient rule must not move the minima: per time step the final objectives of the two runs agree to 1e-8 (the recorded
+    objective comes from the two-sided quotient either way and is the ORACLE's at the device's parameters), the lock-step iteration
+    counts differ by at most one, the states agree per site to 1e-7, and the adaptive run spends fewer power steps."""
+    rng = np.random.default_rng(7100 + D)
+    X0 = rng.standard_normal((T, P))
+    WW = WW_of(0.05)
+    eng = engine_factory(D, T * (2 * P + 1))
+    out = {}
+    for adaptive in (False, True):
+        eng.overlap_stats(reset=True)
+        r = eng.evolve_bfgs(0, X0, WW, n_steps=4, maxiter=40, tol=1e-12, carry_hessian=True, adaptive_gradient=adaptive)
+        out[adaptive] = (r, eng.overlap_stats())
+    (fx, sf), (ad, sa) = out[False], out[True]
+    assert np.abs(ad['fun'] - fx['fun']).max() < 1e-8, np.abs(ad['fun'] - fx['fun']).max()
+    assert np.abs(ad['nit'].astype(int) - fx['nit'].astype(int)).max() <= 1, (ad['nit'], fx['nit'])
+    assert sa['not_converged'] == 0 and sf['not_converged'] == 0
+    assert sa['rounds_sum'] < 0.9 * sf['rounds_sum'], (sa['rounds_sum'], sf['rounds_sum'])
+    prev = ad['params_hist'][-2]
+    for t in (0, T // 2, T - 1):
+        f_t = ER.objective(0, D, ER.tensor(0, D, prev[t]), ad['params_hist'][-1, t], WW, arpack=D >= 16)
+        assert abs(f_t - ad['fun'][-1, t]) < F_TOL
+        o = abs(O.overlap_eta_arpack(ER.tensor(0, D, ad['x'][t]), ER.tensor(0, D, fx['x'][t]), np.eye(4))[0])
+        assert abs(o - 1.0) < 1e-7, (t, o)
 
 
 @pytest.mark.parametrize('D,P', [(8, 6), (16, 8)])

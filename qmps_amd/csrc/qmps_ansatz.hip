@@ -178,6 +178,17 @@ hipError_t launch_ansatz_fd(int D, int kind, const double* params, int n_params,
   }
 }
 
+hipError_t launch_ansatz_masked(int D, int kind, const double* params, int n_params, void* A, int64_t B, const unsigned char* active, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  switch (D) {
+    case 2: return launch_ansatz_d<2>(kind, params, n_params, A, B, 0, nullptr, st, 0.0, active);
+    case 4: return launch_ansatz_d<4>(kind, params, n_params, A, B, 0, nullptr, st, 0.0, active);
+    case 8: return launch_ansatz_d<8>(kind, params, n_params, A, B, 0, nullptr, st, 0.0, active);
+    case 16: return launch_ansatz_d<16>(kind, params, n_params, A, B, 0, nullptr, st, 0.0, active);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, void* A, int64_t B, hipStream_t st) {
   return launch_ansatz_shifted(D, kind, params, n_params, A, B, 0, nullptr, st);
 }

@@ -714,12 +714,12 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   // the control word back once per chain.  The iteration in which a trajectory rejects the full step is finished by the host
   // code below (ladder, gradient at the accepted point, update) on a downloaded copy of the state - the same code, the same
   // decisions.  QMPS_EVOLVE_HOST_ALGEBRA selects the host loop for everything (the round-4 driver; the test-suite runs both).
-  const bool dev_algebra = two_sided && (c->D == 8 || c->D == 16) && P <= 32 && T <= 65535 && documented_switch("QMPS_EVOLVE_HOST_ALGEBRA") == nullptr &&
+  const bool dev_algebra = two_sided && (c->D == 8 || c->D == 16) && P <= 32 && T <= 65535 && maxiter <= 480 && documented_switch("QMPS_EVOLVE_HOST_ALGEBRA") == nullptr &&
                            documented_switch("QMPS_D16_BLOCK") == nullptr && documented_switch("QMPS_D16_ONE_WAVE") == nullptr;
   struct {
     double *X, *G, *H, *F, *Dv, *slope, *Xc, *fh, *ph, *F0, *asel, *alphas, *cand, *tolarr, *g0max;
     int* ctl;          // [0, 4) the control word; [16, 16 + maxiter + 1): trajectories that rejected the full step, per iteration of the time step
-    unsigned char *active, *eff, *need;
+    unsigned char *active, *eff, *need, *head;
   } dv = {};
   // first chain of a time step: as many iterations as the previous step took (the lock-step count is steady along an evolution with
   // carried Hessians; an idle iteration at the tail of a chain costs ~40 us of empty launches, a chain too short a synchronisation
@@ -728,9 +728,9 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   std::vector<unsigned char> rej_prev;      // iterations of the previous time step in which a full step was rejected
   if (const char* e = tuning_knob("QMPS_EVOLVE_CHAIN")) chain_fixed = atoi(e) > 0 ? atoi(e) : 0;
   if (dev_algebra) {
-    const size_t n_ctl = 16 + (size_t)maxiter + 2;
+    const size_t n_ctl = 16 + 2 * ((size_t)maxiter + 2);
     const size_t n_dbl = 4 * TP + TP * P + 6 * (size_t)T + (size_t)n_steps * 2 * T + (size_t)n_steps * TP + (size_t)NA + (size_t)T * (G > 0 ? G : 1) * P;
-    const size_t bytes = n_dbl * sizeof(double) + (n_ctl + (n_ctl & 1)) * sizeof(int) + 3 * (((size_t)T + 7) / 8 * 8) + 64;
+    const size_t bytes = n_dbl * sizeof(double) + (n_ctl + (n_ctl & 1)) * sizeof(int) + 4 * (((size_t)T + 7) / 8 * 8) + 64;
     if (bytes > c->d_lock_bytes) {
       if (c->d_lock) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_lock)); }
       c->d_lock = nullptr; c->d_lock_bytes = 0;
@@ -742,7 +742,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     dv.H = q; q += TP * P; dv.F = q; q += T; dv.slope = q; q += T; dv.F0 = q; q += T; dv.asel = q; q += T; dv.tolarr = q; q += T; dv.g0max = q; q += T;
     dv.fh = q; q += (size_t)n_steps * 2 * T; dv.ph = q; q += (size_t)n_steps * TP; dv.alphas = q; q += NA; dv.cand = q; q += (size_t)T * (G > 0 ? G : 1) * P;
     dv.ctl = (int*)q;
-    dv.active = (unsigned char*)(dv.ctl + n_ctl + (n_ctl & 1)); dv.eff = dv.active + ((size_t)T + 7) / 8 * 8; dv.need = dv.eff + ((size_t)T + 7) / 8 * 8;
+    dv.active = (unsigned char*)(dv.ctl + n_ctl + (n_ctl & 1)); dv.eff = dv.active + ((size_t)T + 7) / 8 * 8; dv.need = dv.eff + ((size_t)T + 7) / 8 * 8; dv.head = dv.need + ((size_t)T + 7) / 8 * 8;
     if (!c->d_active) HIP_TRY(hipMalloc((void**)&c->d_active, ((size_t)c->max_batch + 7) / 8 * 8));
     if (!c->h_ctl) HIP_TRY(hipHostMalloc((void**)&c->h_ctl, 4096, hipHostMallocDefault));
     if ((rc = ensure_overlap_outputs(c))) return rc;
@@ -781,6 +781,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     la.tol_next = adaptive ? dv.tolarr : nullptr; la.g0max = dv.g0max; la.tol_min = tol_min; la.tol_max = tol_max; la.tol_rel = tol_rel;
     la.fb = c->d_f; la.st = c->d_status; la.active = dv.active; la.eff = dv.eff; la.need = dv.need; la.ctl = dv.ctl;
     la.fh_start = dv.fh + (size_t)step * 2 * T; la.fh_end = dv.fh + ((size_t)step * 2 + 1) * T; la.ph = dv.ph + (size_t)step * TP; la.mode = mode;
+    la.step_id = step + 1; la.head_mask = dv.head; la.hist_off = ((step + 1) & 1) * (maxiter + 2);
     la.T = (int)T; la.P = P; la.maxiter = maxiter; la.reset_h = reset_h ? 1 : 0; la.h = h; la.gtol = gtol; la.c1 = c1; la.alpha0 = alphas[0];
     return la;
   };
@@ -795,7 +796,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   };
   // one evaluation of the rows at d_src (iterate tensors, both fixed points, neighbours, probes), enqueued only
   auto dev_gradient = [&](const double* d_src, const unsigned char* mask) -> int {
-    HIP_TRY(qmps::launch_ansatz(c->D, kind, d_src, P, c->d_A, T, c->stream));
+    HIP_TRY(qmps::launch_ansatz(c->D, kind, d_src, P, c->d_A, T, c->stream));      // (every row: a masked-out row's tensor is never read)
     if (beside_dev && !fused_probe_dev) HIP_TRY(hipEventRecord(c->aux_fork, c->stream));      // (the second stream builds the neighbours' tensors)
     c->timed = counters_out != nullptr;
     const int tslot = (int)(c->samples % qmps_ctx::kRing);
@@ -809,13 +810,17 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     c->grad_warm_T = T;
     return QMPS_OK;
   };
+  bool head_done = false;      // the head of this time step (references, first evaluation, begin) already ran behind the previous step's chain
   for (int step = 0; step < n_steps && rc == QMPS_OK && dev_algebra; ++step) {
     const bool reset_h = !(carry && (step > 0 || ((flags & QMPS_BFGS_WARM) != 0 && hinv)));
-    HIP_TRY(qmps::launch_ansatz(c->D, kind, dv.X, P, c->d_ref, T, c->stream));        // the step's references: A_t = tensor(current parameters)
-    c->overlap_refs = T;
-    c->overlap_group = 0;
-    if ((rc = dev_gradient(dv.X, nullptr))) break;
-    if ((rc = launch_step(step, reset_h, 1))) break;      // f, g, active set; the first direction
+    if (!head_done) {
+      HIP_TRY(qmps::launch_ansatz(c->D, kind, dv.X, P, c->d_ref, T, c->stream));        // the step's references: A_t = tensor(current parameters)
+      c->overlap_refs = T;
+      c->overlap_group = 0;
+      if ((rc = dev_gradient(dv.X, nullptr))) break;
+      if ((rc = launch_step(step, reset_h, 1))) break;      // f, g, active set; the first direction
+    }
+    head_done = false;
     n_grad += 1.0;
     nfev += (double)T * (2 * P + 1);
     int nit = 0;
@@ -841,13 +846,13 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
       if (int e2 = dev_gradient(dv.Xc, dv.need)) return e2;
       return launch_step(step, false, 3);
     };
-    HIP_TRY(hipMemsetAsync(dv.ctl + 16, 0, ((size_t)maxiter + 2) * sizeof(int), c->stream));      // this step's pattern of rejections
     bool first_chain = true;
     for (;;) {
       // with counters: one iteration per chain, so that every evaluation's event pair can be read (the timed region runs without)
       int K = counters_out ? 1 : (first_chain ? (chain_fixed > 0 ? chain_fixed : nit_prev) : 1);
       K = K < 1 ? 1 : K;
       K = K < maxiter - nit ? K : maxiter - nit;
+      const bool spec_ok = first_chain && !counters_out && documented_switch("QMPS_EVOLVE_NO_SPECULATIVE_HEAD") == nullptr;
       first_chain = false;
       for (int i = 0; i < K; ++i) {
         if ((rc = dev_gradient(dv.Xc, dv.eff))) break;
@@ -856,10 +861,22 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
         if (!counters_out && (size_t)(nit + i) < rej_prev.size() && rej_prev[nit + i] && (rc = enqueue_ladder())) break;
       }
       if (rc) break;
-      const size_t n_read = 16 + (size_t)maxiter + 1 < 1024 ? 16 + (size_t)maxiter + 1 : 1024;
+      // the NEXT time step's head behind this chain, masked by "this time step has finished" (head_mask / ctl[5], written by the step
+      // kernel that ends it): when the chain was long enough - the rule - the device goes on without waiting for the host to find out;
+      // otherwise every kernel of it returns at once
+      const bool spec = spec_ok && step + 1 < n_steps;
+      if (spec) {
+        HIP_TRY(qmps::launch_ansatz_masked(c->D, kind, dv.X, P, c->d_ref, T, dv.head, c->stream));
+        if ((rc = dev_gradient(dv.X, dv.head))) break;
+        if ((rc = launch_step(step + 1, !carry, 4))) break;
+      }
+      const size_t n_read = 16 + 2 * ((size_t)maxiter + 2);
       HIP_TRY(hipMemcpyAsync(c->h_ctl, dv.ctl, n_read * sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
-      const int n_act = c->h_ctl[0], nit_dev = c->h_ctl[2], stop = c->h_ctl[3];
+      const int* hist = c->h_ctl + 16 + ((step + 1) & 1) * (maxiter + 2);
+      const bool finished = c->h_ctl[5] == step + 1;
+      // (finished with a speculative head behind it: the control word already describes the NEXT time step)
+      const int n_act = finished ? 0 : c->h_ctl[0], nit_dev = finished ? c->h_ctl[6] : c->h_ctl[2], stop = finished ? 0 : c->h_ctl[3];
       if (counters_out && K > 0) {
         float ms = 0.f;
         if ((nit_dev > nit || stop) && qmps_kernel_time(c, 1, &ms, nullptr, 0) == QMPS_OK) grad_ms += ms;
@@ -869,6 +886,12 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
         nfev += ((double)(nit_dev - nit) + (stop ? 1.0 : 0.0)) * (double)T * (2 * P + 1);
       }
       nit = nit_dev;
+      if (finished) {
+        head_done = spec;
+        rej_prev.assign((size_t)nit, 0);
+        for (int i = 0; i < nit; ++i) rej_prev[i] = hist[i] > 0 ? 1 : 0;
+        break;
+      }
       if (stop) {
         // some trajectories rejected the full step and no ladder was waiting: enqueue it now (no further synchronisation - the
         // next chain follows at once)
@@ -881,20 +904,10 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
           n_grad += 1.0;
           nfev += (double)T * G + (double)T * (2 * P + 1);
         }
-        nit += 1;            // (the step kernel of mode 3 counts it on the device)
-        if (nit >= maxiter) {
-          HIP_TRY(hipStreamSynchronize(c->stream));
-          break;
-        }
+        nit += 1;            // (the step kernel of mode 3 counts it on the device; the next read-back finds the step finished or not)
         continue;
       }
       if (n_act == 0 || nit >= maxiter) break;
-    }
-    if (rc) break;
-    {   // the pattern of rejections of this time step, for the next one's chain
-      const size_t n_hist = (size_t)nit < 1000 ? (size_t)nit : 1000;
-      rej_prev.assign(n_hist, 0);
-      for (size_t i = 0; i < n_hist; ++i) rej_prev[i] = c->h_ctl[16 + i] > 0 ? 1 : 0;
     }
     if (rc) break;
     // (the step's record - objective at the end, parameters - was written by the last live step kernel; on the device until the call ends)

@@ -67,7 +67,9 @@ __global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs 
   const int P = p.P;
   const bool lane_on = a < P;
   const int n_active0 = p.ctl[0], nit0 = p.ctl[2], stop0 = p.ctl[3];
-  const bool begin = p.mode == 1, open_only = p.mode == 2, after_ladder = p.mode == 3;
+  const int done_step = p.ctl[5];
+  const bool speculative = p.mode == 4;
+  const bool begin = p.mode == 1 || speculative, open_only = p.mode == 2, after_ladder = p.mode == 3;
   // all components of a per-trajectory vector held one component per lane, into registers: PL shuffles issued back to back (every
   // lane of the wave takes part: no divergence around it).  (First version: a shuffle where a component was needed, inside the
   // sequential sums - ~100 dependent LDS-crossbar round trips per pass, 6 us.)
@@ -104,7 +106,8 @@ __global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs 
   // phase 1: ACCEPT (or BEGIN)
   // ---------------------------------------------------------------------------------------------------------------------------
   // mode 3 finishes an iteration that stopped on rejected full steps (their ladder and the gradient at the accepted points have run)
-  const bool live = begin || open_only || (after_ladder ? stop0 != 0 : !(n_active0 == 0 || stop0 != 0 || nit0 >= p.maxiter));
+  // mode 4: the head of a time step enqueued behind the previous step's chain - live only if that step has finished
+  const bool live = speculative ? done_step == p.step_id - 1 : (begin || open_only || (after_ladder ? stop0 != 0 : !(n_active0 == 0 || stop0 != 0 || nit0 >= p.maxiter)));
   // (nothing to finish: the mask of the next evaluation stays empty - cleared when the lock-step stopped; the launch still takes part
   // in the barrier below, whose arrival count the host's epoch relies on)
   int n_need = 0, n_active = 0;
@@ -256,13 +259,20 @@ __global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs 
     p.ctl[1] = n_need;
     p.ctl[2] = nit;
     p.ctl[3] = stop;
-    if (!begin && !after_ladder && nit0 <= p.maxiter) p.ctl[16 + nit0] = n_need;      // the pattern of rejections of this time step
+    if (!begin && !after_ladder && nit0 <= p.maxiter) p.ctl[16 + p.hist_off + nit0] = n_need;      // the pattern of rejections of this time step
+    if (!(n_active > 0 && stop == 0 && nit < p.maxiter) && stop == 0) {      // the time step ends here
+      p.ctl[5] = p.step_id;
+      p.ctl[6] = nit;
+    }
   }
   // ---------------------------------------------------------------------------------------------------------------------------
   // phase 2: DIRECTION of the next iteration (or an empty mask when the lock-step stops here)
   // ---------------------------------------------------------------------------------------------------------------------------
   if (!live) return;
   const bool go_on = n_active > 0 && stop == 0 && nit < p.maxiter;
+  const bool finished = !go_on && stop == 0;
+  if (begin && blockIdx.x == 0)      // a new time step: its pattern of rejections starts empty
+    for (int k = threadIdx.x; k <= p.maxiter + 1; k += blockDim.x) p.ctl[16 + p.hist_off + k] = 0;
   for (int base = blockIdx.x * SLOTS; base < p.T; base += gridDim.x * SLOTS) {
     const int t = base + slot;
     const bool on = t < p.T;
@@ -279,7 +289,10 @@ __global__ __launch_bounds__(LS_THREADS) void lockstep_step_kernel(LockstepArgs 
     // the record of the time step so far (final when the lock-step stops here; a trajectory waiting for the host's ladder is
     // recorded again by the mode-2 launch that follows the host's update)
     if (on && lane_on) p.ph[tp + a] = xa;
-    if (on && a == 0) p.fh_end[t] = Ft;
+    if (on && a == 0) {
+      p.fh_end[t] = Ft;
+      p.head_mask[t] = finished ? 1 : 0;
+    }
     if (p.tol_next != nullptr) {
       double gt_all[PL];
       gather(ga, gt_all);

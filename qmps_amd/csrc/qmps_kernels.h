@@ -161,6 +161,8 @@ hipError_t launch_energy(int D, const LaneArgs& a, bool solve, hipStream_t st);
 hipError_t launch_energy_block(int D, const LaneArgs& a, bool solve, hipStream_t st);
 // ansatz parameters [B][n_params] -> state tensors A [B][2][D][D]; kind: 0 ShallowCNOT, 1 QAOA, 2 ShallowFull (D=2), 3 ShallowCNOT3
 hipError_t launch_ansatz(int D, int kind, const double* params, int n_params, void* A, int64_t B, hipStream_t st);
+// ... rows with active[row] == 0 left alone (active nullable)
+hipError_t launch_ansatz_masked(int D, int kind, const double* params, int n_params, void* A, int64_t B, const unsigned char* active, hipStream_t st);
 // the same for rotosolve shift batches: B = nsh R evaluations, evaluation nsh r + k = row r with shift k on parameter *i_ptr
 hipError_t launch_ansatz_shifted(int D, int kind, const double* params, int n_params, void* A, int64_t B, int nsh, const int* i_ptr,
                                  hipStream_t st);
@@ -230,9 +232,13 @@ struct LockstepArgs {
   double* fh_end;        // [T] record of the objective after the last finished iteration (rewritten by every live launch)
   double* ph;            // [T][P] ... and of the parameters
   int T, P, maxiter, reset_h;
+  int step_id;           // 1, 2, ...: the time step this launch belongs to (ctl[5] = id of the last finished step, ctl[6] = its iteration count)
+  unsigned char* head_mask;   // [T] 1 everywhere once the time step has finished, else 0: the mask of the NEXT step's speculative head
+  int hist_off;          // offset of this time step's rejection pattern in ctl[16 ...] (two regions, alternating)
   int mode;              // 0: finish an iteration from its evaluation, open the next; 1: the same after the FIRST evaluation of a time step
                          // (f, g, active set from the batch; H^-1 = 1 if reset_h); 2: open the next iteration only (the host has finished one);
-                         // 3: finish an iteration that stopped on rejected full steps, after their ladder and the gradient at the accepted points
+                         // 3: finish an iteration that stopped on rejected full steps, after their ladder and the gradient at the accepted points;
+                         // 4: mode 1 enqueued SPECULATIVELY behind the previous time step's chain - does nothing unless that step has finished
   double h, gtol, c1, alpha0;
   // the backtracking ladder of the trajectories that rejected the full step (lockstep_ladder_*_kernel)
   double* F0;            // [T] objective of the rejected full step (rung 0)

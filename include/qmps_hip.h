@@ -142,9 +142,9 @@ extern "C" {
  *                         and the wave-distributed circuit round differently)
  *   QMPS_FUSED_PROBE      ... built inside the probe kernel, never written to HBM (measured slower: the probe kernel becomes
  *                         instruction-bound, 43 us instead of 19 for 4 352 probes; kept as the third implementation of the same numbers)
- *   QMPS_EVOLVE_NO_SPECULATIVE_HEAD  qmps_evolve_bfgs at D = 8, 16: the head of a time step (references, first gradient batch) is enqueued only after the
- *                         host has read back that the previous step finished, instead of behind the previous step's chain, masked by a
- *                         device-side 'finished' word (same numbers; one idle gap of ~50 us per time step more)
+ *   QMPS_EVOLVE_SPECULATIVE_HEAD  qmps_evolve_bfgs at D = 8, 16: the head of a time step (references, first gradient batch) is enqueued behind the
+ *                         previous step's chain, masked by a device-side 'finished' word, instead of after the host has read back that the
+ *                         previous step finished (same numbers; measured no gain: the host is back before the device runs dry)
  *   QMPS_EVOLVE_HOST_ALGEBRA  qmps_evolve_bfgs at D = 8, 16: directions, Armijo tests, H^-1 updates and masks on the HOST between two
  *                         gradient evaluations (the round-4 loop: a synchronisation and two staged copies per evaluation) instead of
  *                         in kernels on device-resident state with the host enqueueing chains of iterations.  Same numbers, bit for bit.

@@ -640,6 +640,17 @@ def main_evolve(args):
         ev.fg.eng.sync()
         elapsed_instr = time.perf_counter() - t2
         nfev = res2['nfev']
+        # D = 8, 16 (device-resident algebra): the device time of an UN-instrumented pass - one event pair per time step, first kernel to
+        # last - over the wall time of the same pass: how much of a time step the device works
+        device_busy = None
+        if D in (8, 16) and not getattr(ev, 'device', False) and os.environ.get('QMPS_EVOLVE_HOST_ALGEBRA') is None:
+            t3 = time.perf_counter()
+            res3 = ev.steps(res2['x'], WW, args.steps, time_steps=True)
+            ev.fg.eng.sync()
+            e3 = time.perf_counter() - t3
+            device_busy = {'device_ms_per_step': res3['device_ms'] / args.steps, 'wall_ms_per_step': e3 / args.steps * 1e3, 'share': res3['device_ms'] * 1e-3 / e3,
+                           'what': 'one HIP event pair per time step (QMPS_BFGS_TIME_STEPS) around everything the step enqueues - evaluations, step kernels, '
+                                   'idle launches at a chain\'s tail - in a pass without any other instrumentation; the host gap between two time steps is outside'}
     sg = ev.fg.eng.overlap_stats()
     if getattr(ev, 'device', False):
         # D = 2, device-resident optimiser: one launch, its own counters (every candidate eigen-solved; squarings summed by the kernel)
@@ -647,6 +658,8 @@ def main_evolve(args):
     # (native driver: one context, its statistics pool the - rare - ladder batches with the gradient batches)
     sl = ev.fl.eng.overlap_stats() if ev.fl is not ev.fg else {k: 0 for k in sg}
     kms_timed = (list(ev.fg.kernel_ms), list(ev.fl.kernel_ms) if ev.fl is not ev.fg else [])
+    if not native:
+        device_busy = None
     identity_leg = None
     if args.carry_hessian and not args.no_extras:
         # the same time steps the way scipy (the reference) starts them: inverse Hessian = identity at the top of every step
@@ -657,10 +670,15 @@ def main_evolve(args):
             dist.barrier()
         t1 = time.perf_counter()
         nit_l, f_l = [], None
-        for _ in range(n_leg):
-            res = ev.step(Xl, WW)
-            Xl, f_l = res['x'], res['fun']
-            nit_l.append(res['nit'])
+        if native:      # one C call, un-instrumented, like the timed region
+            res = ev.steps(Xl, WW, n_leg, counters=False)
+            ev.fg.eng.sync()
+            Xl, f_l, nit_l = res['x'], res['fun'][-1], [int(n) for n in np.atleast_1d(res['nit'])]
+        else:
+            for _ in range(n_leg):
+                res = ev.step(Xl, WW)
+                Xl, f_l = res['x'], res['fun']
+                nit_l.append(res['nit'])
         el = time.perf_counter() - t1
         ev.carry_hessian = True
         identity_leg = {'value': T * n_leg / el, 'unit': 'trajectory time steps/s (this rank)', 'steps': n_leg, 'ms_per_step': el / n_leg * 1e3,
@@ -698,13 +716,20 @@ def main_evolve(args):
                           'bfgs_iterations_per_step': float(np.mean(nit)), 'carry_hessian': bool(args.carry_hessian),
                           'lockstep_groups': (ev.fg.eng.evolve_groups(T) if (native and not getattr(ev, 'device', False)) else 1),
                           'driver': ('qmps_evolve_bfgs_device: the optimiser on the device, one wave per trajectory, the whole timed region is ONE LAUNCH' if getattr(ev, 'device', False) else
-                                     'qmps_evolve_bfgs: the whole timed region is one C call') if native else 'numpy loop (tools.batched_bfgs), one ctypes call per batch', 'objective_evals_per_step': nfev / args.steps,
+                                     ('qmps_evolve_bfgs: the whole timed region is one C call; optimiser algebra in kernels on device-resident state, the host enqueues chains of iterations '
+                                      '(QMPS_EVOLVE_HOST_ALGEBRA: the round-4 host loop)' if (D in (8, 16) and os.environ.get('QMPS_EVOLVE_HOST_ALGEBRA') is None) else
+                                      'qmps_evolve_bfgs: the whole timed region is one C call (host loop between the batches)')) if native else 'numpy loop (tools.batched_bfgs), one ctypes call per batch',
+                          'adaptive_gradient': bool(getattr(ev, 'adaptive_gradient', False)),
+                          'adaptive_gradient_rule': 'eigen-solves of a trajectory\'s gradient stop at residual clamp(1e-3 max|g|, 1e-8, 1e-6) (QMPS_BFGS_ADAPTIVE_GRADIENT); objective by the two-sided quotient, error <= 1e-12' if getattr(ev, 'adaptive_gradient', False) else None,
+                          'objective_evals_per_step': nfev / args.steps,
                           'objective_evals_per_s': world * nfev / elapsed,
                           'mean_final_objective': float(np.nanmean(f_last)), 'worst_final_objective': float(np.nanmax(f_last)),
                           'solver_rounds_mean_gradient_batches': sg['rounds_sum'] / max(1, sg['evaluations']), 'solver_rounds_max_gradient_batches': sg['rounds_max'],
                           'solver_rounds_mean_ladder_batches': sl['rounds_sum'] / max(1, sl['evaluations']), 'solver_rounds_max_ladder_batches': sl['rounds_max'],
                           'not_converged': sg['not_converged'] + sl['not_converged'],
                           'kernel_share_of_wall': kernel_total_ms * 1e-3 / elapsed_instr,
+                          'kernel_share_of_wall_what': 'gradient-evaluation kernels (HIP event pairs) over the wall time of the INSTRUMENTED pass, which synchronises after every evaluation to read its events; see device_busy for the un-instrumented run',
+                          'device_busy': device_busy if native else None,
                           'instrumented_pass_ms_per_step': elapsed_instr / args.steps * 1e3,
                           'collective': 'none: independent trajectories (replicas only)', 'device': info['name'], 'arch': info['arch']},
                'roofline': {'bound': 'fp64_matrix' if D == 16 else ('fp64_matrix' if D == 4 else 'fp64_valu'), 'achieved': tflops, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -931,7 +956,7 @@ def other_configs(args, budget_s=60.0):
                      'config': {k: v for k, v in d['config'].items() if k in ('baseline_config', 'hamiltonian', 'D', 'restarts', 'n_params', 'shifts', 'us_per_parameter_update', 'mean_energy_first_sweep',
                                                                                 'mean_energy_last_sweep', 'best_energy', 'exact_ground_state_energy', 'D2_optimum', 'ansatz', 'depth', 'not_converged_or_not_pd',
                                                                                 'trajectories_per_gpu', 'driver', 'lockstep_groups', 'bfgs_iterations_per_step', 'carry_hessian', 'not_converged',
-                                                                                'mean_final_objective', 'kernel_share_of_wall', 'solver_rounds_mean_gradient_batches',
+                                                                                'mean_final_objective', 'kernel_share_of_wall', 'device_busy', 'adaptive_gradient', 'solver_rounds_mean_gradient_batches',
                                                                                 'solver_rounds_max_gradient_batches')},
                      'wall_s': time.perf_counter() - t1}
         if 'repeats' in d:

@@ -462,6 +462,10 @@ int qmps_overlap_gradient(qmps_ctx* ctx, int64_t T, int kind, int n_params, cons
  * minima (measured: final objectives to 1e-9, iteration counts unchanged), a third fewer power steps.  Without the flag every batch
  * solves to max(tol, 1e-8) as in ABI 6.0. */
 #define QMPS_BFGS_ADAPTIVE_GRADIENT 8
+/* QMPS_BFGS_TIME_STEPS (with counters_out; D = 8, 16 device-resident algebra): counters_out[3] becomes the device time of the call -
+ * one HIP event pair per time step, from its first kernel to the last one enqueued - instead of the sum over the gradient batches;
+ * the run itself is the un-instrumented one (chains of iterations, no event pair per batch; counters_out[0 .. 2] stay 0). */
+#define QMPS_BFGS_TIME_STEPS 16
 int qmps_evolve_bfgs(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
                      double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
                      double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out);

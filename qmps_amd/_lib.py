@@ -25,7 +25,7 @@ FLAG_NO_ENV_OUT = 0x100
 FLAG_ACCUMULATE_COST = 0x200
 FLAG_WARM_RESIDENT = 0x400
 OVERLAP_WANT_R, OVERLAP_WARM, OVERLAP_TWO_SIDED_F = 1, 2, 4
-BFGS_CARRY_HESSIAN, BFGS_WARM, BFGS_TIGHT_GRADIENT, BFGS_ADAPTIVE_GRADIENT = 1, 2, 4, 8
+BFGS_CARRY_HESSIAN, BFGS_WARM, BFGS_TIGHT_GRADIENT, BFGS_ADAPTIVE_GRADIENT, BFGS_TIME_STEPS = 1, 2, 4, 8, 16
 ROTO_REFERENCE, ROTO_GLOBAL_ARGMIN = 0, 1
 # ansatz kinds the device-resident BFGS of D = 2 has kernels for (launch_evolve_bfgs_d2); the others run the host loop qmps_evolve_bfgs
 EVOLVE_DEVICE_KINDS_D2 = (ANSATZ_SHALLOW_CNOT, ANSATZ_SHALLOW_QAOA, ANSATZ_SHALLOW_FULL, ANSATZ_SHALLOW_CNOT3, ANSATZ_STATE_GATE)

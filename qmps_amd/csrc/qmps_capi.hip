@@ -363,6 +363,8 @@ int qmps_destroy(qmps_ctx* c) try {
   if (c->h_mask) (void)hipHostFree(c->h_mask);
   if (c->d_lock) (void)hipFree(c->d_lock);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+  if (c->step_ev0) (void)hipEventDestroy(c->step_ev0);
+  if (c->step_ev1) (void)hipEventDestroy(c->step_ev1);
   if (c->d_tolarr) (void)hipFree(c->d_tolarr);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
   if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -586,7 +586,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   if (int rc = bind(c)) return rc;
   DisarmOneShots disarm{c};      // nothing armed by this driver outlives it, whichever way it ends
   if (!params || !WW || !f_hist || !alphas) return fail(QMPS_ERR_ARG, "null argument");
-  if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT | QMPS_BFGS_ADAPTIVE_GRADIENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
+  if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT | QMPS_BFGS_ADAPTIVE_GRADIENT | QMPS_BFGS_TIME_STEPS)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
   const int P = n_params, NA = n_alphas;
   if (NA < 1 || NA > 64) return fail(QMPS_ERR_ARG, "n_alphas outside [1, 64]");
   const int64_t G = NA - 1;
@@ -785,6 +785,15 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     la.T = (int)T; la.P = P; la.maxiter = maxiter; la.reset_h = reset_h ? 1 : 0; la.h = h; la.gtol = gtol; la.c1 = c1; la.alpha0 = alphas[0];
     return la;
   };
+  // QMPS_BFGS_TIME_STEPS (with counters_out): no event pairs around the evaluations and no one-iteration chains - the run is the timed
+  // region's - but ONE pair per time step, from its first kernel to the last one enqueued: counters_out[3] = the milliseconds the device
+  // spent on this call's kernels (idle launches at a chain's tail included; the host's gap between two time steps not)
+  const bool time_steps = dev_algebra && counters_out != nullptr && (flags & QMPS_BFGS_TIME_STEPS) != 0;
+  const bool per_eval = counters_out != nullptr && !time_steps;
+  if (time_steps && !c->step_ev0) {
+    HIP_TRY(hipEventCreate(&c->step_ev0));
+    HIP_TRY(hipEventCreate(&c->step_ev1));
+  }
   int lock_epoch = 0;          // launches of the step kernel on this control word (its grid barrier counts arrivals against it)
   const int lock_blocks = dev_algebra ? qmps::lockstep_step_blocks((int)T, P) : 0;
   auto launch_step = [&](int step, bool reset_h, int mode) -> int {
@@ -798,7 +807,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   auto dev_gradient = [&](const double* d_src, const unsigned char* mask) -> int {
     HIP_TRY(qmps::launch_ansatz(c->D, kind, d_src, P, c->d_A, T, c->stream));      // (every row: a masked-out row's tensor is never read)
     if (beside_dev && !fused_probe_dev) HIP_TRY(hipEventRecord(c->aux_fork, c->stream));      // (the second stream builds the neighbours' tensors)
-    c->timed = counters_out != nullptr;
+    c->timed = per_eval;
     const int tslot = (int)(c->samples % qmps_ctx::kRing);
     if (c->timed) HIP_TRY(hipEventRecord(c->kev0[tslot], c->stream));
     c->dominant = c->D == 16 ? "overlap_mfma_d16_kernel + adjoint + neighbour probes" : "overlap solve + adjoint + neighbour probes";
@@ -813,6 +822,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
   bool head_done = false;      // the head of this time step (references, first evaluation, begin) already ran behind the previous step's chain
   for (int step = 0; step < n_steps && rc == QMPS_OK && dev_algebra; ++step) {
     const bool reset_h = !(carry && (step > 0 || ((flags & QMPS_BFGS_WARM) != 0 && hinv)));
+    if (time_steps) HIP_TRY(hipEventRecord(c->step_ev0, c->stream));
     if (!head_done) {
       HIP_TRY(qmps::launch_ansatz(c->D, kind, dv.X, P, c->d_ref, T, c->stream));        // the step's references: A_t = tensor(current parameters)
       c->overlap_refs = T;
@@ -849,7 +859,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     bool first_chain = true;
     for (;;) {
       // with counters: one iteration per chain, so that every evaluation's event pair can be read (the timed region runs without)
-      int K = counters_out ? 1 : (first_chain ? (chain_fixed > 0 ? chain_fixed : nit_prev) : 1);
+      int K = per_eval ? 1 : (first_chain ? (chain_fixed > 0 ? chain_fixed : nit_prev) : 1);
       K = K < 1 ? 1 : K;
       K = K < maxiter - nit ? K : maxiter - nit;
       const bool spec_ok = first_chain && !counters_out && documented_switch("QMPS_EVOLVE_SPECULATIVE_HEAD") != nullptr;
@@ -858,7 +868,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
         if ((rc = dev_gradient(dv.Xc, dv.eff))) break;
         if ((rc = launch_step(step, false, 0))) break;               // finish the iteration, open the next
         // the previous time step had a rejection at this iteration: its ladder rides along (empty launches if nothing is rejected now)
-        if (!counters_out && (size_t)(nit + i) < rej_prev.size() && rej_prev[nit + i] && (rc = enqueue_ladder())) break;
+        if (!per_eval && (size_t)(nit + i) < rej_prev.size() && rej_prev[nit + i] && (rc = enqueue_ladder())) break;
       }
       if (rc) break;
       // (QMPS_EVOLVE_SPECULATIVE_HEAD; off by default: measured 0.598 against 0.602 ms per time step carried, 3.7 against 3.2 ms identity
@@ -872,6 +882,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
         if ((rc = dev_gradient(dv.X, dv.head))) break;
         if ((rc = launch_step(step + 1, !carry, 4))) break;
       }
+      if (time_steps) HIP_TRY(hipEventRecord(c->step_ev1, c->stream));
       const size_t n_read = 16 + 2 * ((size_t)maxiter + 2);
       HIP_TRY(hipMemcpyAsync(c->h_ctl, dv.ctl, n_read * sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
@@ -879,11 +890,11 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
       const bool finished = c->h_ctl[5] == step + 1;
       // (finished with a speculative head behind it: the control word already describes the NEXT time step)
       const int n_act = finished ? 0 : c->h_ctl[0], nit_dev = finished ? c->h_ctl[6] : c->h_ctl[2], stop = finished ? 0 : c->h_ctl[3];
-      if (counters_out && K > 0) {
+      if (per_eval && K > 0) {
         float ms = 0.f;
         if ((nit_dev > nit || stop) && qmps_kernel_time(c, 1, &ms, nullptr, 0) == QMPS_OK) grad_ms += ms;
       }
-      if (counters_out) {       // (K = 1: exact counts, as the host loop's)
+      if (per_eval) {       // (K = 1: exact counts, as the host loop's)
         n_grad += (double)(nit_dev - nit) + (stop ? 1.0 : 0.0);
         nfev += ((double)(nit_dev - nit) + (stop ? 1.0 : 0.0)) * (double)T * (2 * P + 1);
       }
@@ -898,7 +909,8 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
         // some trajectories rejected the full step and no ladder was waiting: enqueue it now (no further synchronisation - the
         // next chain follows at once)
         if ((rc = enqueue_ladder())) break;
-        if (counters_out) {
+        if (time_steps) HIP_TRY(hipEventRecord(c->step_ev1, c->stream));
+        if (per_eval) {
           HIP_TRY(hipStreamSynchronize(c->stream));
           float ms = 0.f;
           if (qmps_kernel_time(c, 1, &ms, nullptr, 0) == QMPS_OK) grad_ms += ms;
@@ -912,6 +924,12 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
       if (n_act == 0 || nit >= maxiter) break;
     }
     if (rc) break;
+    if (time_steps) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, c->step_ev0, c->step_ev1));
+      grad_ms += ms;
+    }
     // (the step's record - objective at the end, parameters - was written by the last live step kernel; on the device until the call ends)
     nit_prev = nit > 0 ? nit : 1;
     if (nit_out) nit_out[step] = nit;

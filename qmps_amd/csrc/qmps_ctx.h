@@ -95,6 +95,7 @@ struct qmps_ctx {
   std::vector<unsigned char> mask_copy;       //   ... which is ordinary host memory: no staging region can overwrite it
   double* d_tolarr = nullptr;                 // qmps_evolve_bfgs (host loop, QMPS_BFGS_ADAPTIVE_GRADIENT): per-trajectory tolerances of the next gradient batch
   const double* grad_tol_in = nullptr;        //   one-shot: consumed by the next qmps_overlap_gradient
+  hipEvent_t step_ev0 = nullptr, step_ev1 = nullptr;   // QMPS_BFGS_TIME_STEPS: one event pair per time step
   int* h_ctl = nullptr;                       // pinned: the control word of the device-resident lock-step BFGS, read back once per chain
   void* d_lock = nullptr;                     // device-resident state of the lock-step BFGS (qmps_evolve_lockstep.hip; lazy, grown on demand)
   size_t d_lock_bytes = 0;

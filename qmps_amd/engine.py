@@ -497,14 +497,15 @@ class EnergyEngine:
 
     def evolve_bfgs(self, kind, params, WW, n_steps=1, maxiter=200, gtol=1e-5, h=1e-6, c1=1e-4,
                     alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), carry_hessian=False, hess_inv=None, warm=False,
-                    max_rounds=None, tol=1e-12, tight_gradient=False, counters=True, adaptive_gradient=False):
+                    max_rounds=None, tol=1e-12, tight_gradient=False, counters=True, adaptive_gradient=False, time_steps=False):
         """Time evolution by lock-step BFGS, every time step of every trajectory in ONE C call (qmps_evolve_bfgs): params (T, P) ->
         dict(x (T, P), params_hist (n_steps, T, P), fun (n_steps, T) [and fun_start: at the start of each time step], nit (n_steps,), hess_inv (T, P, P), gradient_batches,
         ladder_batches, nfev, gradient_ms).  warm=True continues a previous call on this engine (resident fixed points; with
         carry_hessian also `hess_inv`).  tight_gradient: the eigen-solves of the gradient batches iterate to tol instead of
         max(tol, 1e-8) (their objective comes from the two-sided quotient either way).  counters=False: no batch counts and no
         HIP events around the gradient batches (a pair of event records costs the stream ~12 us per batch).
-        adaptive_gradient (D = 8, 16): QMPS_BFGS_ADAPTIVE_GRADIENT - a trajectory's gradient solves stop at clamp(1e-3 max|g|, max(tol, 1e-8), 1e-6)."""
+        adaptive_gradient (D = 8, 16): QMPS_BFGS_ADAPTIVE_GRADIENT - a trajectory's gradient solves stop at clamp(1e-3 max|g|, max(tol, 1e-8), 1e-6).
+        time_steps (with counters; D = 8, 16): 'gradient_ms' is the DEVICE time of the call, one event pair per time step, the run un-instrumented."""
         P = np.array(np.atleast_2d(params), dtype=np.float64, order='C', copy=True)
         WW = np.ascontiguousarray(WW, dtype=np.complex128).reshape(4, 4)
         al = np.ascontiguousarray(alphas, dtype=np.float64)
@@ -521,7 +522,7 @@ class EnergyEngine:
         if hess_inv is not None:
             Hinv[...] = hess_inv
         flags = ((L.BFGS_CARRY_HESSIAN if carry_hessian else 0) | (L.BFGS_WARM if warm else 0) | (L.BFGS_TIGHT_GRADIENT if tight_gradient else 0) |
-                 (L.BFGS_ADAPTIVE_GRADIENT if adaptive_gradient else 0))
+                 (L.BFGS_ADAPTIVE_GRADIENT if adaptive_gradient else 0) | (L.BFGS_TIME_STEPS if time_steps else 0))
         L.check(self._lib.qmps_evolve_bfgs(self._ctx, T, int(kind), npar, _f64(P), _f64(WW.view(np.float64)), int(n_steps), int(maxiter),
                                            float(gtol), float(h), float(c1), len(al), _f64(al), flags, int(max_rounds), float(tol),
                                            _f64(Hinv), _f64(ph), _f64(fh), _i32(nit), _f64(cnt) if counters else None))

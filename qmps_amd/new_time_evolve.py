@@ -235,6 +235,7 @@ class LockstepEvolver:
         self.kind = getattr(cls, 'device_kind')
         mr = max_rounds if max_rounds is not None else (60 if D in (2, 4) else 100000)
         self.alphas, self.maxiter, self.gtol, self.eps = tuple(alphas), maxiter, gtol, eps
+        self.D = D
         self.two_sided = (gradient == 'two-sided') or (gradient == 'auto' and D >= 4)
         self.first_rungs = first_rungs
         self.speculative = bool(speculative)      # (D = 2: with the central-difference candidates eigen-solved one by one)
@@ -265,8 +266,9 @@ class LockstepEvolver:
         self.fl = _GroupedObjective(D, self.kind, T, rungs, mr, tol, device=device)
         self.fg.tight_gradient = self.tight_gradient
 
-    def steps(self, X, WW, n_steps, counters=True):
-        """n_steps time steps in one C call (native driver): dict(x, params_hist, fun (n_steps, T), nit (n_steps,), ...)."""
+    def steps(self, X, WW, n_steps, counters=True, time_steps=False):
+        """n_steps time steps in one C call (native driver): dict(x, params_hist, fun (n_steps, T), nit (n_steps,), ...).
+        time_steps (D = 8, 16, with counters): res['device_ms'] = device time of the call (QMPS_BFGS_TIME_STEPS), the run un-instrumented."""
         if not self.native:
             raise RuntimeError('LockstepEvolver.steps needs the native driver (speculative=True, two-sided gradient)')
         if self.device:
@@ -285,7 +287,12 @@ class LockstepEvolver:
         res = self.fg.eng.evolve_bfgs(self.kind, X, WW, n_steps=n_steps, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas,
                                       carry_hessian=self.carry_hessian, hess_inv=self._hinv if (self.carry_hessian and self._continued) else None,
                                       warm=self._continued, max_rounds=self.mr, tol=self.tol, tight_gradient=self.tight_gradient, counters=counters,
-                                      adaptive_gradient=self.adaptive_gradient)
+                                      adaptive_gradient=self.adaptive_gradient, time_steps=bool(time_steps) and self.D in (8, 16))
+        if time_steps and self.D in (8, 16):
+            res['device_ms'] = res['gradient_ms']
+            self._continued = True
+            self._hinv = res['hess_inv']
+            return res
         self._continued = True
         self._hinv = res['hess_inv']
         if self.fg.kernel_ms is not None and res['gradient_batches']:

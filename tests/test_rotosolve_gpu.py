@@ -324,9 +324,9 @@ def test_config1_family_with_a_landscape_reaches_the_d2_optimum(c_oracle, engine
     eng.set_hamiltonian(h)
     es, p = eng.double_rotosolve(2, P0, sweeps)
     assert np.isfinite(es).all()
-    A = np.stack([O.unitary_to_tensor(O.shallow_full_unitary(q)) for q in p])
-    out = c_oracle.energy_batch(A, h[None], tol=1e-15, max_iter=200000)
-    ok = out['status'] == 0
-    assert ok.mean() > 0.9 and np.abs(out['E'][:, 0] - es[-1])[ok].max() < 1e-9
+    # (dense eigen-solve of the transfer matrix: optimised states sit close to the critical point, where the oracle's plain power
+    # iteration takes > 10^5 steps to 1e-15)
+    e_at_p = np.array([O.energy_closed_form(O.unitary_to_tensor(O.shallow_full_unitary(q)), h) for q in p])
+    assert np.abs(e_at_p - es[-1]).max() < 1e-9
     assert es[-1].min() < -1.26 and es[-1].mean() < -1.2 and es[-1].min() > -4 / np.pi
     assert es[-1].mean() < es[0].mean()

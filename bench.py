@@ -288,6 +288,23 @@ def executed_flops(D, solver, iters, eng, max_iter):
     return flops, note, handoff
 
 
+def exchange_report(world, ms_per_step, kernel_ms, value, host_wait_ms, steps, grouped_16_evals_per_s):
+    """N > 1: is a step paced by the per-step all-reduce or by the energy kernel?  Top-level fields of the line:
+      host_wait_ms             rank 0, timed region: how long the host stood at the 8-slot ring waiting for the exchange that last used a slot
+      grouped_exchange_16      evals/s of the same steps with ONE all-reduce per 16 steps (None if that extra did not run)
+      exchange_bound           True when the exchange sets the pace: the host waited for more than a tenth of the timed region, or the step takes
+                               more than 1.5 x its kernel AND grouping the exchange gains more than 15 %
+    A step is ~30 us at the headline shape: with two communicators alternating, an all-reduce must complete within two steps to stay
+    hidden."""
+    if world <= 1:
+        return {'host_wait_ms': None, 'grouped_exchange_16': None, 'exchange_bound': None}
+    waited = host_wait_ms is not None and host_wait_ms > 0.1 * ms_per_step * steps
+    slow = kernel_ms is not None and kernel_ms > 0 and ms_per_step > 1.5 * kernel_ms
+    gain = grouped_16_evals_per_s is not None and value > 0 and grouped_16_evals_per_s > 1.15 * value
+    return {'host_wait_ms': host_wait_ms, 'grouped_exchange_16': grouped_16_evals_per_s, 'exchange_bound': bool(waited or (slow and gain)),
+            'exchange_bound_rule': 'host_wait_ms > 10 % of the timed region, or (ms_per_step > 1.5 x kernel_ms and grouped_exchange_16 > 1.15 x value)'}
+
+
 def emit(args, out):
     """rank 0's ONE JSON line - or, when this workload runs as an `other_configs` entry of the default run, its dict"""
     sink = getattr(args, 'collect', None)
@@ -1395,6 +1412,11 @@ def main():
                         'what': 'the timed block of --steps steps repeated back to back (block 0 is `value`), each bracketed by barrier + synchronise, max over ranks'},
         }
         out.update(extras)
+        # the median of the repeated blocks beside `value` (the driver's --steps 20 makes `value` a 0.6 ms sample), and at N > 1 the verdict on
+        # what paces a step
+        out['value_median'] = out['repeats']['value_median']
+        out.update(exchange_report(world, ms_per_step, kernel_ms, value, None if exch is None else float(exch[2]), args.steps,
+                                   (extras.get('grouped_exchange_16') or {}).get('evals_per_s')))
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu
         emit(args, out)

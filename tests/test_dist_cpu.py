@@ -206,3 +206,44 @@ def test_bench_self_launch_and_world_checks():
         out = subprocess.run([sys.executable, bench, '--gpus', '1', '--workload', wl, '--no-cpu-baseline'],
                              env=dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=120)
         assert out.returncode != 0 and 'WORLD_SIZE=2 but --gpus 1' in out.stderr, (wl, out.stderr[-500:])
+
+
+def _exchange_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        bench = _bench_module()
+        # every rank times "its" region; the line carries the MAX over ranks (bench.py's contract) and rank 0's ring statistics
+        ms = torch.tensor([0.030 + 0.010 * rank], dtype=torch.float64)
+        dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+        ms_per_step = float(ms.item())
+        value = world * 65536 / (ms_per_step * 1e-3)
+        rep_hidden = bench.exchange_report(world, ms_per_step, 0.028, value, 0.0, 2000, 1.05 * value)
+        rep_waiting = bench.exchange_report(world, ms_per_step, 0.028, value, 0.2 * ms_per_step * 2000, 2000, 1.05 * value)
+        rep_grouped = bench.exchange_report(world, 0.060, 0.028, value, 0.0, 2000, 1.6 * value)
+        out[rank] = (ms_per_step, rep_hidden, rep_waiting, rep_grouped)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_report_fields_world2():
+    """bench.py's N > 1 top-level fields (host_wait_ms, grouped_exchange_16, exchange_bound): computed alike on every rank of a
+    world-size-2 gloo group from the max-over-ranks step time; at N = 1 they are None."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_exchange_worker, args=(2, port, out), nprocs=2, join=True)
+        res = dict(out)
+    assert res[0][0] == res[1][0] == pytest.approx(0.040)
+    for r in (0, 1):
+        _, hidden, waiting, grouped = res[r]
+        assert hidden['exchange_bound'] is False and hidden['host_wait_ms'] == 0.0 and hidden['grouped_exchange_16'] > 0
+        assert waiting['exchange_bound'] is True
+        assert grouped['exchange_bound'] is True
+    one = _bench_module().exchange_report(1, 0.03, 0.028, 2e9, None, 2000, None)
+    assert one == {'host_wait_ms': None, 'grouped_exchange_16': None, 'exchange_bound': None}

@@ -657,17 +657,6 @@ def main_evolve(args):
         ev.fg.eng.sync()
         elapsed_instr = time.perf_counter() - t2
         nfev = res2['nfev']
-        # D = 8, 16 (device-resident algebra): the device time of an UN-instrumented pass - one event pair per time step, first kernel to
-        # last - over the wall time of the same pass: how much of a time step the device works
-        device_busy = None
-        if D in (8, 16) and not getattr(ev, 'device', False) and os.environ.get('QMPS_EVOLVE_HOST_ALGEBRA') is None:
-            t3 = time.perf_counter()
-            res3 = ev.steps(res2['x'], WW, args.steps, time_steps=True)
-            ev.fg.eng.sync()
-            e3 = time.perf_counter() - t3
-            device_busy = {'device_ms_per_step': res3['device_ms'] / args.steps, 'wall_ms_per_step': e3 / args.steps * 1e3, 'share': res3['device_ms'] * 1e-3 / e3,
-                           'what': 'one HIP event pair per time step (QMPS_BFGS_TIME_STEPS) around everything the step enqueues - evaluations, step kernels, '
-                                   'idle launches at a chain\'s tail - in a pass without any other instrumentation; the host gap between two time steps is outside'}
     sg = ev.fg.eng.overlap_stats()
     if getattr(ev, 'device', False):
         # D = 2, device-resident optimiser: one launch, its own counters (every candidate eigen-solved; squarings summed by the kernel)
@@ -675,8 +664,19 @@ def main_evolve(args):
     # (native driver: one context, its statistics pool the - rare - ladder batches with the gradient batches)
     sl = ev.fl.eng.overlap_stats() if ev.fl is not ev.fg else {k: 0 for k in sg}
     kms_timed = (list(ev.fg.kernel_ms), list(ev.fl.kernel_ms) if ev.fl is not ev.fg else [])
-    if not native:
-        device_busy = None
+    device_busy = None
+    if native:
+        # D = 8, 16 (device-resident algebra): the device time of an UN-instrumented pass - one event pair per time step, first kernel to
+        # last - over the wall time of the same pass: how much of a time step the device works
+        if D in (8, 16) and not getattr(ev, 'device', False) and os.environ.get('QMPS_EVOLVE_HOST_ALGEBRA') is None:
+            t3 = time.perf_counter()
+            res3 = ev.steps(res2['x'], WW, args.steps, time_steps=True)
+            ev.fg.eng.sync()
+            e3 = time.perf_counter() - t3
+            device_busy = {'device_ms_per_step': res3['device_ms'] / args.steps, 'wall_ms_per_step': e3 / args.steps * 1e3, 'share': res3['device_ms'] * 1e-3 / e3,
+                           'what': 'one HIP event pair per time step (QMPS_BFGS_TIME_STEPS) around everything the step enqueues - evaluations, step kernels, '
+                                   'idle launches at a chain\'s tail - in a pass without any other instrumentation; the host gap between two time steps is outside '
+                                   '(lock-step groups, T >= 512: summed over the groups\' streams, which overlap - the share then exceeds 1)'}
     identity_leg = None
     if args.carry_hessian and not args.no_extras:
         # the same time steps the way scipy (the reference) starts them: inverse Hessian = identity at the top of every step

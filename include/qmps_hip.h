@@ -158,7 +158,8 @@ typedef struct qmps_ctx qmps_ctx;
 /* ---- library / device ------------------------------------------------------------------ */
 int qmps_abi_version(void);
 /* additions that keep every existing signature (new entry points, new flag bits): bumps QMPS_ABI_MINOR only.
- * 6.1: qmps_set_roto_rule / qmps_get_roto_rule / qmps_roto_rule_probe, qmps_abi_minor; flag QMPS_BFGS_ADAPTIVE_GRADIENT. */
+ * 6.1: qmps_set_roto_rule / qmps_get_roto_rule / qmps_roto_rule_probe, qmps_abi_minor; flags QMPS_BFGS_ADAPTIVE_GRADIENT, QMPS_BFGS_TIME_STEPS;
+ *      qmps_evolve_opts_init / qmps_evolve_bfgs_opts / qmps_evolve_bfgs_device_opts (versioned option structs). */
 int qmps_abi_minor(void);
 const char* qmps_last_error(void);
 /* Test hook for the contract above ("nothing throws across the ABI"): raises a C++ exception inside the library - kind 1
@@ -497,6 +498,38 @@ int qmps_get_evolve_groups(qmps_ctx* ctx, int64_t T, int* groups);
 int qmps_evolve_bfgs_device(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
                             double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
                             double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out);
+
+/* ---- the two evolve drivers behind ONE versioned options struct (ABI 6.1) ----------------------------------------------------------
+ * qmps_evolve_bfgs / qmps_evolve_bfgs_device take 21 positional arguments; a caller that binds them by position has nothing to lean
+ * on when an option is added.  The *_opts entry points take the same inputs as two structs whose FIRST field is the size the caller
+ * compiled against: the library reads only that many bytes (fields beyond it take their defaults), so a struct may grow at its end
+ * without breaking callers; a size larger than the library's is refused with QMPS_ERR_ARG.  qmps_evolve_opts_init fills the defaults
+ * (scipy's BFGS: gtol 1e-5, the ladder 1, 1/2, ..., 1/4096, h 1e-6, c1 1e-4, maxiter 200, one time step, tol 1e-12).
+ * The positional entry points above stay and are thin wrappers over the same code. */
+typedef struct qmps_evolve_opts {
+  uint32_t size;          /* sizeof(qmps_evolve_opts) of the caller's header */
+  int32_t n_steps;
+  int32_t maxiter;
+  int32_t n_alphas;       /* 0: the default ladder (alphas ignored) */
+  int32_t flags;          /* QMPS_BFGS_* */
+  int32_t max_rounds;     /* 0: the driver's default (60 squarings at D = 2, 4; 100 000 power steps at D = 8, 16) */
+  double gtol, h, c1, tol;
+  const double* alphas;   /* [n_alphas] */
+} qmps_evolve_opts;
+typedef struct qmps_evolve_out {
+  uint32_t size;          /* sizeof(qmps_evolve_out) of the caller's header */
+  uint32_t reserved;
+  double* hinv;           /* nullable, in / out as in qmps_evolve_bfgs */
+  double* params_hist;    /* nullable [n_steps][T][n_params] */
+  double* f_hist;         /* [n_steps][2][T] */
+  int32_t* nit;           /* nullable: [n_steps] (qmps_evolve_bfgs_opts) / [n_steps][T] (qmps_evolve_bfgs_device_opts) */
+  double* counters;       /* nullable [4] */
+} qmps_evolve_out;
+int qmps_evolve_opts_init(qmps_evolve_opts* opts);
+int qmps_evolve_bfgs_opts(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* params, const double* WW, const qmps_evolve_opts* opts,
+                          const qmps_evolve_out* out);
+int qmps_evolve_bfgs_device_opts(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* params, const double* WW, const qmps_evolve_opts* opts,
+                                 const qmps_evolve_out* out);
 
 /* Device-resident TIME EVOLUTION by rotosolve on the overlap objective (BASELINE.json configs[4]; the reference's loop:
  * qmps/new_time_evolve.py:276-292 / scripts/loschmidt.py:367-375 `for _ in T: A_ = tensor(params); params =

@@ -34,6 +34,18 @@ UNIQUE_ID_BYTES = 128
 _dp = POINTER(c_double)
 _ip = POINTER(c_int32)
 
+
+class EvolveOpts(ctypes.Structure):
+    """qmps_evolve_opts (include/qmps_hip.h): `size` first, so the struct may grow at its end."""
+    _fields_ = [('size', ctypes.c_uint32), ('n_steps', c_int32), ('maxiter', c_int32), ('n_alphas', c_int32), ('flags', c_int32), ('max_rounds', c_int32),
+                ('gtol', c_double), ('h', c_double), ('c1', c_double), ('tol', c_double), ('alphas', _dp)]
+
+
+class EvolveOut(ctypes.Structure):
+    """qmps_evolve_out (include/qmps_hip.h)."""
+    _fields_ = [('size', ctypes.c_uint32), ('reserved', ctypes.c_uint32), ('hinv', _dp), ('params_hist', _dp), ('f_hist', _dp), ('nit', _ip), ('counters', _dp)]
+
+
 # name -> (restype, argtypes): every entry point declared in include/qmps_hip.h
 SIGNATURES = {
     'qmps_abi_version': (c_int, []),
@@ -93,6 +105,9 @@ SIGNATURES = {
                                  _dp, _dp, _dp, _ip, _dp]),
     'qmps_set_evolve_groups': (c_int, [c_void_p, c_int]),
     'qmps_get_evolve_groups': (c_int, [c_void_p, c_int64, POINTER(c_int)]),
+    'qmps_evolve_opts_init': (c_int, [POINTER(EvolveOpts)]),
+    'qmps_evolve_bfgs_opts': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, _dp, POINTER(EvolveOpts), POINTER(EvolveOut)]),
+    'qmps_evolve_bfgs_device_opts': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, _dp, POINTER(EvolveOpts), POINTER(EvolveOut)]),
     'qmps_evolve_bfgs_device': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, _dp, c_int, c_int, c_double, c_double, c_double, c_int, _dp, c_int, c_int, c_double,
                                         _dp, _dp, _dp, _ip, _dp]),
     'qmps_opt_env_objective': (c_int, [c_void_p, c_int64, _dp, _dp, c_double, _dp, _dp]),

@@ -1436,3 +1436,59 @@ QMPS_API_CATCH
 
 // ---- brick-wall (new_tdvp) contractions -------------------------------------------------------
 }  // extern "C"
+
+// ---- the evolve drivers behind versioned option structs (include/qmps_hip.h) ------------------------------------------------------------
+namespace {
+const double kDefaultLadder[8] = {1.0, 0.5, 0.25, 0.125, 1.0 / 16, 1.0 / 64, 1.0 / 256, 1.0 / 4096};
+// the caller's struct (its first field says how much of it there is) over the library's defaults
+int read_evolve_structs(const qmps_evolve_opts* opts, const qmps_evolve_out* out, qmps_evolve_opts& o, qmps_evolve_out& r) {
+  if (!opts || !out) return fail(QMPS_ERR_ARG, "null options / outputs");
+  if (opts->size < 2 * sizeof(uint32_t) || opts->size > sizeof(qmps_evolve_opts))
+    return fail(QMPS_ERR_ARG, "qmps_evolve_opts.size = %u: this library knows %zu bytes of it (set it to sizeof(qmps_evolve_opts) of YOUR header; a newer header needs a newer library)", opts->size, sizeof(qmps_evolve_opts));
+  if (out->size < 2 * sizeof(uint32_t) || out->size > sizeof(qmps_evolve_out))
+    return fail(QMPS_ERR_ARG, "qmps_evolve_out.size = %u: this library knows %zu bytes of it", out->size, sizeof(qmps_evolve_out));
+  (void)qmps_evolve_opts_init(&o);
+  memcpy(&o, opts, opts->size);
+  o.size = sizeof(qmps_evolve_opts);
+  memset(&r, 0, sizeof(r));
+  memcpy(&r, out, out->size);
+  if (o.n_alphas == 0 || o.alphas == nullptr) { o.n_alphas = 8; o.alphas = kDefaultLadder; }
+  if (!r.f_hist) return fail(QMPS_ERR_ARG, "qmps_evolve_out.f_hist is required");
+  return QMPS_OK;
+}
+}  // namespace
+
+int qmps_evolve_opts_init(qmps_evolve_opts* opts) try {
+  if (!opts) return fail(QMPS_ERR_ARG, "null options");
+  memset(opts, 0, sizeof(*opts));
+  opts->size = sizeof(qmps_evolve_opts);
+  opts->n_steps = 1; opts->maxiter = 200; opts->n_alphas = 0; opts->flags = 0; opts->max_rounds = 0;
+  opts->gtol = 1e-5; opts->h = 1e-6; opts->c1 = 1e-4; opts->tol = 1e-12; opts->alphas = nullptr;
+  return QMPS_OK;
+}
+QMPS_API_CATCH
+
+int qmps_evolve_bfgs_opts(qmps_ctx* c, int64_t T, int kind, int n_params, double* params, const double* WW, const qmps_evolve_opts* opts,
+                          const qmps_evolve_out* out) try {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  qmps_evolve_opts o;
+  qmps_evolve_out r;
+  if (int rc = read_evolve_structs(opts, out, o, r)) return rc;
+  const int rounds = o.max_rounds > 0 ? o.max_rounds : ((c->D == 2 || c->D == 4) ? 60 : 100000);
+  return qmps_evolve_bfgs(c, T, kind, n_params, params, WW, o.n_steps, o.maxiter, o.gtol, o.h, o.c1, o.n_alphas, o.alphas, o.flags, rounds, o.tol, r.hinv,
+                          r.params_hist, r.f_hist, r.nit, r.counters);
+}
+QMPS_API_CATCH
+
+int qmps_evolve_bfgs_device_opts(qmps_ctx* c, int64_t T, int kind, int n_params, double* params, const double* WW, const qmps_evolve_opts* opts,
+                                 const qmps_evolve_out* out) try {
+  if (!c) return fail(QMPS_ERR_ARG, "null context");
+  qmps_evolve_opts o;
+  qmps_evolve_out r;
+  if (int rc = read_evolve_structs(opts, out, o, r)) return rc;
+  const int rounds = o.max_rounds > 0 ? o.max_rounds : 60;
+  return qmps_evolve_bfgs_device(c, T, kind, n_params, params, WW, o.n_steps, o.maxiter, o.gtol, o.h, o.c1, o.n_alphas, o.alphas, o.flags, rounds, o.tol, r.hinv,
+                                 r.params_hist, r.f_hist, r.nit, r.counters);
+}
+QMPS_API_CATCH
+

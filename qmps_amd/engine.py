@@ -523,9 +523,14 @@ class EnergyEngine:
             Hinv[...] = hess_inv
         flags = ((L.BFGS_CARRY_HESSIAN if carry_hessian else 0) | (L.BFGS_WARM if warm else 0) | (L.BFGS_TIGHT_GRADIENT if tight_gradient else 0) |
                  (L.BFGS_ADAPTIVE_GRADIENT if adaptive_gradient else 0) | (L.BFGS_TIME_STEPS if time_steps else 0))
-        L.check(self._lib.qmps_evolve_bfgs(self._ctx, T, int(kind), npar, _f64(P), _f64(WW.view(np.float64)), int(n_steps), int(maxiter),
-                                           float(gtol), float(h), float(c1), len(al), _f64(al), flags, int(max_rounds), float(tol),
-                                           _f64(Hinv), _f64(ph), _f64(fh), _i32(nit), _f64(cnt) if counters else None))
+        # (through the versioned option structs: the positional qmps_evolve_bfgs is the same code)
+        opts = L.EvolveOpts()
+        L.check(self._lib.qmps_evolve_opts_init(byref(opts)))
+        opts.n_steps, opts.maxiter, opts.n_alphas, opts.flags, opts.max_rounds = int(n_steps), int(maxiter), len(al), flags, int(max_rounds)
+        opts.gtol, opts.h, opts.c1, opts.tol, opts.alphas = float(gtol), float(h), float(c1), float(tol), _f64(al)
+        out = L.EvolveOut(size=ctypes.sizeof(L.EvolveOut), hinv=_f64(Hinv), params_hist=_f64(ph), f_hist=_f64(fh), nit=_i32(nit),
+                          counters=_f64(cnt) if counters else None)
+        L.check(self._lib.qmps_evolve_bfgs_opts(self._ctx, T, int(kind), npar, _f64(P), _f64(WW.view(np.float64)), byref(opts), byref(out)))
         self.B = T
         return {'x': P, 'params_hist': ph, 'fun': fh[:, 1], 'fun_start': fh[:, 0], 'nit': nit, 'hess_inv': Hinv, 'gradient_batches': int(cnt[0]),
                 'ladder_batches': int(cnt[1]), 'nfev': int(cnt[2]), 'gradient_ms': float(cnt[3])}

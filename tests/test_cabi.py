@@ -179,3 +179,35 @@ def test_boundary_end_to_end_through_the_cpu_build_of_the_abi():
         for f in files:
             if f.endswith(('.py', '.hip', '.h', 'Makefile')):
                 assert 'cpuabi' not in open(os.path.join(dirpath, f)).read(), f
+
+
+def test_evolve_option_structs_are_versioned_by_their_size_field():
+    """ABI 6.1 (VERDICT r04 engineering item 9): qmps_evolve_bfgs[_device] behind structs whose first field is the caller's sizeof.
+    Needs no device: defaults, and the size checks that run before anything touches the GPU."""
+    import ctypes
+    from qmps_amd import _lib
+    lib = _lib.load()
+    o = _lib.EvolveOpts()
+    assert lib.qmps_evolve_opts_init(ctypes.byref(o)) == 0
+    assert o.size == ctypes.sizeof(_lib.EvolveOpts) and (o.n_steps, o.maxiter, o.n_alphas, o.flags, o.max_rounds) == (1, 200, 0, 0, 0)
+    assert (o.gtol, o.h, o.c1, o.tol) == (1e-5, 1e-6, 1e-4, 1e-12)
+    assert lib.qmps_evolve_opts_init(None) == _lib.QMPS_ERR_ARG
+    out = _lib.EvolveOut(size=ctypes.sizeof(_lib.EvolveOut))
+    # a null context, a size from a NEWER header, a size too small to hold itself: refused with a message, nothing dereferenced
+    assert lib.qmps_evolve_bfgs_opts(None, 1, 0, 2, None, None, ctypes.byref(o), ctypes.byref(out)) == _lib.QMPS_ERR_ARG
+    ctx = ctypes.c_void_p(1)        # never dereferenced: the struct checks come first
+    o.size = ctypes.sizeof(_lib.EvolveOpts) + 8
+    assert lib.qmps_evolve_bfgs_opts(ctx, 1, 0, 2, None, None, ctypes.byref(o), ctypes.byref(out)) == _lib.QMPS_ERR_ARG
+    assert b'newer header' in lib.qmps_last_error()
+    o.size = 4
+    assert lib.qmps_evolve_bfgs_device_opts(ctx, 1, 0, 2, None, None, ctypes.byref(o), ctypes.byref(out)) == _lib.QMPS_ERR_ARG
+    o.size = ctypes.sizeof(_lib.EvolveOpts)
+    assert lib.qmps_evolve_bfgs_opts(ctx, 1, 0, 2, None, None, ctypes.byref(o), ctypes.byref(out)) == _lib.QMPS_ERR_ARG     # f_hist is required
+    assert b'f_hist' in lib.qmps_last_error()
+    # the header and the ctypes mirror agree on the layout
+    hdr = open(os.path.join(ROOT, 'include', 'qmps_hip.h')).read()
+    body = hdr[hdr.index('typedef struct qmps_evolve_opts {'):hdr.index('} qmps_evolve_opts;')]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    names = re.findall(r'\b(\w+)(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?;', body)
+    flat = [n for grp in names for n in grp if n]
+    assert flat == [f[0] for f in _lib.EvolveOpts._fields_], flat

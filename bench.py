@@ -499,7 +499,7 @@ def main_overlap(args):
                             'hbm_frac': byts / (kernel_ms * 1e-3) * 1e-9 / HBM_PEAK_GBPS,
                             'traffic': committed_traffic(D, B, 'overlap', 0, 1), 'kernel': kernel_name, 'kernel_ms': kernel_ms, 'step_ms_events': ev_ms / args.steps,
                             'note': 'executed FLOPs = sum_b [steps_b 64 D^3 + 64 D^3] (complex D^3 products = 8 D^3 flop), steps read back per '
-                                    'item; D = 16: v_mfma_f64_16x16x4 (measured 47.7 TFLOP/s issue rate on this part, profiles/r01_probe.json)',
+                                    'item; D = 16: v_mfma_f64_16x16x4 (measured 47.7 TFLOP/s issue rate on this part, profiles/archive/r01_probe.json)',
                             'hbm': {'achieved': byts / (kernel_ms * 1e-3) * 1e-9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                                     'frac': byts / (kernel_ms * 1e-3) * 1e-9 / HBM_PEAK_GBPS, 'bytes_per_eval': 32 * D * D + 16}},
                'cpu_baseline': cpu}
@@ -577,7 +577,7 @@ def main_evolve(args):
     if not args.no_cpu_baseline and world == 1:
         cpu = evolve_cpu_baseline(D, P, WW, args.seed, args.bfgs_iters, full=full)
     if args.carry_hessian is None:
-        # measured (profiles/r03h_evolve_*.json): D = 16 3.2 against 9.5 iterations per time step, D = 8 6.8 against 13 - but
+        # measured (profiles/archive/r03h_evolve_*.json): D = 16 3.2 against 9.5 iterations per time step, D = 8 6.8 against 13 - but
         # D = 4 19.6 against 12 and D = 2 no gain: the shallow ansaetze of D = 2, 4 have flat directions a carried Hessian mis-scales
         args.carry_hessian = D >= 8
     from qmps_amd import _lib
@@ -1393,7 +1393,7 @@ def main():
                                             if single_kernel_step else 'HIP event pairs around the kernel on every kernel_timed_every-th launch'),
                          'note': '`bound` names the roofline that binds: fp64_valu = the FP64 vector pipe (the fused D = 4 kernel and the D = 2, 8 '
                                  'kernels issue no MFMA), fp64_matrix = v_mfma_f64 (D = 16, the D = 4 squaring solver); both peaks are 78.6 TFLOP/s '
-                                 'spec (measured on this part: v_fma_f64 70.9, v_mfma_f64_16x16x4 47.7 TFLOP/s, profiles/r01_probe.json); `hbm_frac` = '
+                                 'spec (measured on this part: v_fma_f64 70.9, v_mfma_f64_16x16x4 47.7 TFLOP/s, profiles/archive/r01_probe.json); `hbm_frac` = '
                                  'the same launch against the 8 TB/s HBM roofline on the algorithmic bytes.  `traffic` = HBM bytes per launch from the '
                                  'PMC passes COMMITTED under profiles/ (rocprofv3 --pmc cannot run inside this process: `traffic.source` names the run).  '
                                  'FLOPs = ' + flop_note,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): bash tools/debug/r05_evolve_ab.sh <tag> [bench args]   - dev / host algebra A/B of the config-4 workload + kernel trace window
+# usage (GPU box): bash profiles/experiments/r05/r05_evolve_ab.sh <tag> [bench args]   - dev / host algebra A/B of the config-4 workload + kernel trace window
 tag=$1; shift
 R=$GRAFT_REPO_ROOT; o=$R/gpurun_out
 for hs in "" "QMPS_EVOLVE_HOST_ALGEBRA=1"; do
@@ -14,5 +14,5 @@ for f in sorted(glob.glob("$o/${tag}_evolve_d16_t256_*.json")):
     except Exception as e: print(f, "ERR", e)
 PY
 cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_$tag -- python3 $R/bench.py --workload evolve --D 16 --batch 256 --steps 10 --warmup 3 --no-cpu-baseline --no-extras "$@" > $o/${tag}_prof.log 2>&1
-t=$(find $o/prof_$tag -name "*kernel_trace.csv" | head -1); python3 $R/tools/debug/trace_window.py $t 40
+t=$(find $o/prof_$tag -name "*kernel_trace.csv" | head -1); python3 $R/profiles/experiments/r05/trace_window.py $t 40
 f=$(find $o/prof_$tag -name "*kernel_stats.csv" | head -1); cp $f $o/${tag}_evolve_d16_t256_kernel_stats.csv; rm -rf $o/prof_$tag

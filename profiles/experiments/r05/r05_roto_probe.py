@@ -1,7 +1,7 @@
 """GPU probe: where does the device double-frequency rotosolve leave the reference-run trajectory?"""
 import ctypes, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 from oracle import qmps_oracle as O
 from qmps_amd import EnergyEngine, _lib as L

@@ -1,6 +1,6 @@
 import ctypes, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 from qmps_amd import EnergyEngine
 g = np.load(os.path.join(ROOT, 'tests/golden/refshim_golden.npz'))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): bash tools/debug/r05_variants.sh <tag>  - config-4 workload under the neighbour-build / algebra switches
+# usage (GPU box): bash profiles/experiments/r05/r05_variants.sh <tag>  - config-4 workload under the neighbour-build / algebra switches
 tag=$1; R=$GRAFT_REPO_ROOT; o=$R/gpurun_out
 i=0
 for v in "" "QMPS_NEIGHBOURS_BESIDE=1" "QMPS_FUSED_PROBE=1" "QMPS_EVOLVE_HOST_ALGEBRA=1" "QMPS_EVOLVE_HOST_ALGEBRA=1 QMPS_NEIGHBOURS_BESIDE=1"; do

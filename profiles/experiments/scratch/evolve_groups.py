@@ -1,6 +1,6 @@
 """Experiment: the T trajectories of a D = 16 time evolution as K independent lock-step groups, one context + one host thread each
 (ctypes releases the GIL during qmps_evolve_bfgs): do the groups' host gaps and straggler iterations overlap on the device?
-usage: python tools/scratch/evolve_groups.py T K [steps]"""
+usage: python profiles/experiments/scratch/evolve_groups.py T K [steps]"""
 import sys, time, threading
 import numpy as np
 from scipy.linalg import expm

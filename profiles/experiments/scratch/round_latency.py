@@ -1,6 +1,6 @@
 """Per-round latency of the D = 16 pair kernel (right + left power iteration, four waves per solve): every solve of a gradient batch
 runs exactly R rounds (tolerance out of reach, Krylov hand-over off): wall time of the gradient call against R.
-usage: QMPS_NO_KRYLOV=1 python tools/scratch/round_latency.py [D]"""
+usage: QMPS_NO_KRYLOV=1 python profiles/experiments/scratch/round_latency.py [D]"""
 import os, sys, time
 import numpy as np
 from scipy.linalg import expm

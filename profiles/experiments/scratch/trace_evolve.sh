@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): bash tools/scratch/trace_evolve.sh <T> : kernel trace of one evolve run, last time step's kernels in launch order
+# usage (GPU box): bash profiles/experiments/scratch/trace_evolve.sh <T> : kernel trace of one evolve run, last time step's kernels in launch order
 T=${1:-4096}
 R=$GRAFT_REPO_ROOT; o=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp

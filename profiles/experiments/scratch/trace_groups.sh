@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage (GPU box): bash tools/scratch/trace_groups.sh <T> <K_py> <K_lib>: per-stream kernel statistics of the timed call
+# usage (GPU box): bash profiles/experiments/scratch/trace_groups.sh <T> <K_py> <K_lib>: per-stream kernel statistics of the timed call
 R=$GRAFT_REPO_ROOT; o=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $o/trace_g
-rocprofv3 --kernel-trace --output-format csv -d $o/trace_g -- python3 $R/tools/scratch/evolve_groups.py $1 $2 $3 > $o/trace_g.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $o/trace_g -- python3 $R/profiles/experiments/scratch/evolve_groups.py $1 $2 $3 > $o/trace_g.log 2>&1
 tail -2 $o/trace_g.log
 f=$(find $o/trace_g -name "*kernel_trace.csv" | head -1)
 python3 - <<PY

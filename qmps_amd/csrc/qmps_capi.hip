@@ -591,7 +591,7 @@ int rotosolve_impl(qmps_ctx* c, int64_t R, int kind, int n_params, double* param
     HIP_TRY(hipStreamSynchronize(c->stream));
     return QMPS_OK;
   };
-#ifdef QMPS_D8_PROFILE        // scratch instrumentation build (tools/scratch/d8_profile.py): 16 phase clocks behind the history
+#ifdef QMPS_D8_PROFILE        // scratch instrumentation build (profiles/experiments/scratch/d8_profile.py): 16 phase clocks behind the history
   constexpr size_t kHistExtra = 16 + 3 * 4096;
 #else
   constexpr size_t kHistExtra = 0;

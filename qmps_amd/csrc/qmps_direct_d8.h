@@ -215,7 +215,7 @@ __device__ __forceinline__ double2 env_direct_d8_solve(const double2 (*sA)[8][9]
   // ---- elimination in a 2-D cyclic layout: lane (g, c) = (lane >> 4, lane & 15) holds rows c + 16 m (m < 4) x columns
   // g + 4 t (t < 16).  Step k: the pivot row's entries of the lane's column class sit in lane k % 16 OF THE SAME
   // 16-LANE DPP ROW, so the update is ONE instruction per entry - v_fmac_f64_dpp row_newbcast (gfx90a+ 64-bit DPP, full
-  // FMA rate measured: tools/scratch/dpp64_probe.hip) - with no separate broadcast (the row-per-lane layout spends two
+  // FMA rate measured: profiles/experiments/scratch/dpp64_probe.hip) - with no separate broadcast (the row-per-lane layout spends two
   // v_readlane_b32 per FMA).  The multipliers (column k of the lane's four rows) come from the same c in row group
   // k % 4 (ds_bpermute), and are the same in all four row groups.  ~3 800 instead of ~7 200 instructions per evaluation.
   double Mn[4][16];

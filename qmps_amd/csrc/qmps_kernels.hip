@@ -1163,8 +1163,8 @@ __global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(S
     auto square_of = [&](const v4f64& M, const double (&f)[4]) {
       // M M: 4 x v_mfma_f64_16x16x4_f64 (k-slabs), single accumulator chain.
       // (Measured alternative: 16 x v_mfma_f64_4x4x4_4b_f64 - 16 cycles each vs ~100 for the 16x16x4
-      // form on gfx950, tools/scratch/mfma_probe.hip - needs 16 LDS fragment reads and 40 more VGPRs
-      // per round and came out 7 % slower end to end; its lane layout is in tools/scratch/mfma4_layout.hip.)
+      // form on gfx950, profiles/experiments/scratch/mfma_probe.hip - needs 16 LDS fragment reads and 40 more VGPRs
+      // per round and came out 7 % slower end to end; its lane layout is in profiles/experiments/scratch/mfma4_layout.hip.)
       v4f64 acc = {0, 0, 0, 0};
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f[0], M[0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f[1], M[1], acc, 0, 0, 0);

@@ -8,7 +8,7 @@
 // file is the library's Arnoldi: the power kernels hand a candidate over as soon as their residual history predicts a long
 // tail (status 1, steps used < max_rounds, iterate in r_out) and the kernel below finishes it.
 //
-// Algorithm (one workgroup of 256 threads per candidate, everything in LDS; prototype + measurements: tools/scratch/krylov_proto.py,
+// Algorithm (one workgroup of 256 threads per candidate, everything in LDS; prototype + measurements: profiles/experiments/scratch/krylov_proto.py,
 // profiles/EXPERIMENTS.md "Krylov fall-back"): thick-restart Arnoldi in its Rayleigh-Ritz ("Davidson") form -
 //   basis V (16 orthonormal vectors), images W = T V, projected G = V^H T V (16 x 16, general);
 //   a cycle extends the basis from j0 to 16 vectors by the Arnoldi chain (v_{j+1} = T v_j orthogonalised twice, classical

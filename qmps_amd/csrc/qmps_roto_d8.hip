@@ -351,7 +351,7 @@ __global__ __launch_bounds__(192) void rotosolve_fused_d8_kernel(RotoArgs p) {
     s_h[threadIdx.x] = acc;
   }
   __syncthreads();
-#ifdef QMPS_D8_PROFILE      // scratch instrumentation (tools/scratch/d8_profile.sh): phase clocks of restart 0 into the history buffer
+#ifdef QMPS_D8_PROFILE      // scratch instrumentation (profiles/experiments/scratch/d8_profile.sh): phase clocks of restart 0 into the history buffer
   long long tp[6] = {0, 0, 0, 0, 0, 0}, fine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const long long t_begin = wall_clock64();
   int prof_max_it = 0;

@@ -111,7 +111,7 @@ QMPS_HD double double_sinusoid_fminbound(double a, double b, double c, double d)
   // scipy computes every product and difference below in separate IEEE operations.  hipcc's default -ffp-contract=fast fuses ACROSS
   // statements - q - r with q, r the two nearly equal products of the parabola becomes one fma - and the search then takes other
   // decisions: measured on gfx950 against the reference's 486 recorded calls, 200 differ (a few end in the other basin) with
-  // contraction, none without (tools/debug/rule_variants.hip).  So: no contraction in this function.
+  // contraction, none without (profiles/experiments/r05/rule_variants.hip).  So: no contraction in this function.
 #pragma clang fp contract(off)
   auto f = [&](double x) {
     double sx, cx;

@@ -802,3 +802,34 @@ def test_active_mask_skips_trajectories_and_keeps_their_values(D, P, engine_fact
         eng.overlap_set_active(mask[:3])
         eng.overlap_gradient(0, X2, tol=1e-13)                          # three entries for six trajectories
     eng.overlap_set_active(None)
+
+
+def test_option_struct_entry_points_are_the_positional_ones(engine_factory):
+    """ABI 6.1: qmps_evolve_bfgs_opts / qmps_evolve_bfgs_device_opts (versioned structs, defaults from qmps_evolve_opts_init) against the
+    positional entry points: the same code, the same numbers; defaults = scipy's BFGS settings and the eight-rung ladder."""
+    import ctypes
+    from qmps_amd.engine import _f64, _i32
+    rng = np.random.default_rng(61)
+    T, P = 5, 15
+    X0 = rng.standard_normal((T, P))
+    WW = np.ascontiguousarray(WW_of(0.05), dtype=np.complex128)
+    eng = engine_factory(2, T * (2 * P + 1))
+    ref = eng.evolve_bfgs_device(L.ANSATZ_SHALLOW_FULL, X0, WW, n_steps=2, maxiter=200, tol=1e-12)
+    lib = eng._lib
+    opts = L.EvolveOpts()
+    L.check(lib.qmps_evolve_opts_init(ctypes.byref(opts)))
+    opts.n_steps = 2                                   # everything else: the defaults (maxiter 200, gtol 1e-5, h 1e-6, c1 1e-4, tol 1e-12, default ladder)
+    X = X0.copy()
+    ph, fh, nit, cnt = np.empty((2, T, P)), np.empty((2, 2, T)), np.zeros((2, T), dtype=np.int32), np.zeros(4)
+    out = L.EvolveOut(size=ctypes.sizeof(L.EvolveOut), params_hist=_f64(ph), f_hist=_f64(fh), nit=_i32(nit), counters=_f64(cnt))
+    L.check(lib.qmps_evolve_bfgs_device_opts(eng._ctx, T, L.ANSATZ_SHALLOW_FULL, P, _f64(X), _f64(WW.view(np.float64)), ctypes.byref(opts), ctypes.byref(out)))
+    assert np.array_equal(X, ref['x']) and np.array_equal(fh[:, 1], ref['fun']) and np.array_equal(nit, ref['nit'])
+    # a caller compiled against a SHORTER struct (only size .. max_rounds): the rest takes the defaults
+    short = L.EvolveOpts()
+    L.check(lib.qmps_evolve_opts_init(ctypes.byref(short)))
+    short.n_steps = 2
+    short.size = L.EvolveOpts.gtol.offset
+    short.gtol = 123.0                                 # beyond `size`: must be ignored
+    X2 = X0.copy()
+    L.check(lib.qmps_evolve_bfgs_device_opts(eng._ctx, T, L.ANSATZ_SHALLOW_FULL, P, _f64(X2), _f64(WW.view(np.float64)), ctypes.byref(short), ctypes.byref(out)))
+    assert np.array_equal(X2, ref['x'])

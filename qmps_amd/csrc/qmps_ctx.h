@@ -1,6 +1,6 @@
 // qmps_ctx.h - internal to libqmps_hip.so: the context behind the opaque `qmps_ctx*` of include/qmps_hip.h and the host-side
 // helpers shared by the translation units of the C-ABI (qmps_capi.hip: lifetime, states, energy path, rotosolve, exchange;
-// qmps_capi_overlap.hip: the time-evolution overlap objective, its gradient and the evolve drivers).
+// qmps_capi_overlap.hip: the time-evolution overlap objective and its gradient; qmps_capi_evolve.hip: the evolve drivers).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>

@@ -114,7 +114,7 @@ def test_nothing_throws_across_the_abi():
         assert lib.qmps_selftest_exception(kind) == _lib.QMPS_ERR_ARG
         assert word in lib.qmps_last_error(), lib.qmps_last_error()
     csrc = os.path.join(ROOT, 'qmps_amd', 'csrc')
-    for f in ('qmps_capi.hip', 'qmps_capi_overlap.hip'):
+    for f in ('qmps_capi.hip', 'qmps_capi_overlap.hip', 'qmps_capi_evolve.hip'):
         src = open(os.path.join(csrc, f)).read()
         entry = re.findall(r'^int (qmps_\w+)\(', src, flags=re.M)
         guarded = re.findall(r'^int (qmps_\w+)\([^{;]*?\) try \{', src, flags=re.M | re.S)
@@ -122,7 +122,7 @@ def test_nothing_throws_across_the_abi():
         assert not bare, f'{f}: entry points without a function-try-block: {bare}'
         assert src.count('QMPS_API_CATCH') == len(guarded)
     # context fields that are switched for the duration of a call are restored by scope guards, not by hand
-    for f in ('qmps_capi.hip', 'qmps_capi_overlap.hip'):
+    for f in ('qmps_capi.hip', 'qmps_capi_overlap.hip', 'qmps_capi_evolve.hip'):
         src = open(os.path.join(csrc, f)).read()
         assert 'c->defer_sync = true' not in src and 'saved_period' not in src
 

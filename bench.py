@@ -291,18 +291,18 @@ def executed_flops(D, solver, iters, eng, max_iter):
 def exchange_report(world, ms_per_step, kernel_ms, value, host_wait_ms, steps, grouped_16_evals_per_s):
     """N > 1: is a step paced by the per-step all-reduce or by the energy kernel?  Top-level fields of the line:
       host_wait_ms             rank 0, timed region: how long the host stood at the 8-slot ring waiting for the exchange that last used a slot
-      grouped_exchange_16      evals/s of the same steps with ONE all-reduce per 16 steps (None if that extra did not run)
+      grouped_exchange_16_evals_per_s   the same steps with ONE all-reduce per 16 steps (None if that extra did not run; its dict stays under `grouped_exchange_16`)
       exchange_bound           True when the exchange sets the pace: the host waited for more than a tenth of the timed region, or the step takes
                                more than 1.5 x its kernel AND grouping the exchange gains more than 15 %
     A step is ~30 us at the headline shape: with two communicators alternating, an all-reduce must complete within two steps to stay
     hidden."""
     if world <= 1:
-        return {'host_wait_ms': None, 'grouped_exchange_16': None, 'exchange_bound': None}
+        return {'host_wait_ms': None, 'grouped_exchange_16_evals_per_s': None, 'exchange_bound': None}
     waited = host_wait_ms is not None and host_wait_ms > 0.1 * ms_per_step * steps
     slow = kernel_ms is not None and kernel_ms > 0 and ms_per_step > 1.5 * kernel_ms
     gain = grouped_16_evals_per_s is not None and value > 0 and grouped_16_evals_per_s > 1.15 * value
-    return {'host_wait_ms': host_wait_ms, 'grouped_exchange_16': grouped_16_evals_per_s, 'exchange_bound': bool(waited or (slow and gain)),
-            'exchange_bound_rule': 'host_wait_ms > 10 % of the timed region, or (ms_per_step > 1.5 x kernel_ms and grouped_exchange_16 > 1.15 x value)'}
+    return {'host_wait_ms': host_wait_ms, 'grouped_exchange_16_evals_per_s': grouped_16_evals_per_s, 'exchange_bound': bool(waited or (slow and gain)),
+            'exchange_bound_rule': 'host_wait_ms > 10 % of the timed region, or (ms_per_step > 1.5 x kernel_ms and grouped_exchange_16_evals_per_s > 1.15 x value)'}
 
 
 def emit(args, out):

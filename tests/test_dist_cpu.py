@@ -231,7 +231,7 @@ def _exchange_worker(rank, world, port, out):
 
 
 def test_exchange_report_fields_world2():
-    """bench.py's N > 1 top-level fields (host_wait_ms, grouped_exchange_16, exchange_bound): computed alike on every rank of a
+    """bench.py's N > 1 top-level fields (host_wait_ms, grouped_exchange_16_evals_per_s, exchange_bound): computed alike on every rank of a
     world-size-2 gloo group from the max-over-ranks step time; at N = 1 they are None."""
     import torch.multiprocessing as mp
     port = _free_port()
@@ -242,8 +242,8 @@ def test_exchange_report_fields_world2():
     assert res[0][0] == res[1][0] == pytest.approx(0.040)
     for r in (0, 1):
         _, hidden, waiting, grouped = res[r]
-        assert hidden['exchange_bound'] is False and hidden['host_wait_ms'] == 0.0 and hidden['grouped_exchange_16'] > 0
+        assert hidden['exchange_bound'] is False and hidden['host_wait_ms'] == 0.0 and hidden['grouped_exchange_16_evals_per_s'] > 0
         assert waiting['exchange_bound'] is True
         assert grouped['exchange_bound'] is True
     one = _bench_module().exchange_report(1, 0.03, 0.028, 2e9, None, 2000, None)
-    assert one == {'host_wait_ms': None, 'grouped_exchange_16': None, 'exchange_bound': None}
+    assert one == {'host_wait_ms': None, 'grouped_exchange_16_evals_per_s': None, 'exchange_bound': None}

@@ -85,6 +85,7 @@ def test_bench_distributed_code_path_world1(scaling):
     assert d['n_gpus'] == 1 and d['value'] > 1e6 and 'RCCL communicator of 1 ranks' in d['config']['collective']
     assert 'per step' in d['config']['collective'] and d['scaling'] == scaling and d['config']['resident_batches'] == 3
     assert d['grouped_exchange_16']['evals_per_s'] > 1e6
+    assert d['exchange_bound'] is None and d['value_median'] > 1e6       # (world size 1: nothing to be bound by)
 
 
 @pytest.mark.parametrize('scaling', ['weak', 'strong'])
@@ -110,6 +111,8 @@ def test_bench_two_ranks_on_one_device(scaling):
     if 'RCCL communicator of 2 ranks' not in coll:             # (a box with two GPUs would take the RCCL path)
         assert 'RCCL communicator unavailable on 2 rank(s)' in coll and 'gloo' in coll
     assert np.isfinite(d['summed_cost']) and d['config']['not_converged_or_not_pd'] == 0
+    # round 5: at N > 1 the line says at its top level whether the exchange or the kernel paces a step, and carries the median of the blocks
+    assert d['exchange_bound'] in (True, False) and 'exchange_bound_rule' in d and 'host_wait_ms' in d and d['value_median'] > 1e6
 
 
 def test_bench_two_ranks_with_extras():

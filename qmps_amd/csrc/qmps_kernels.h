@@ -347,10 +347,19 @@ struct EvolveD2Args {
   int probe;             // timing experiments (QMPS_EVOLVE_PROBE, debug builds): bit 0 skip the eigen-solve, bit 1 skip the circuits
   double gtol, h, c1, tol;
   double alphas[kEvolveMaxAlphas];
+  // D = 16 (qmps_evolve_d16.hip): residual at which the two solves of a gradient stop (0: tol) - the objective comes from the two-sided
+  // quotient - and, with adaptive != 0, clamp(1e-3 max|g|, grad_tol, 1e-6) per gradient (QMPS_BFGS_ADAPTIVE_GRADIENT)
+  double grad_tol;
+  int adaptive;
+  double* prof;          // nullable [T][8] (tuning builds, QMPS_EVOLVE_PROF): 100 MHz ticks of thread 0 in total / tensor / solves / G + first
+                         // neighbour / other neighbours + probes / ladder, gradient passes, power steps of the slower team
 };
 hipError_t launch_evolve_bfgs_d2(int kind, const EvolveD2Args& a, hipStream_t st);
 // D = 4: a workgroup of eight waves per trajectory (qmps_evolve_d4.hip); n_alphas - 1 <= 8, kinds 0, 1, 3
 hipError_t launch_evolve_bfgs_d4(int kind, const EvolveD2Args& a, hipStream_t st);
+// D = 16: a workgroup of eight waves per trajectory, two teams of four (qmps_evolve_d16.hip); ShallowCNOT / CNOT3 (kinds 0, 3);
+// max_rounds = cap on the power steps of a backtracking point (gradient solves: max(max_rounds, 100 000))
+hipError_t launch_evolve_bfgs_d16(int kind, const EvolveD2Args& a, hipStream_t st);
 // D = 8, 16: thick-restart Arnoldi over the candidates the power kernels gave up (status 1, iters < max_rounds); a.r_out holds their
 // iterates and receives the fixed points; `counter` zeroed by the caller (qmps_overlap_krylov.hip)
 hipError_t launch_overlap_krylov(int D, const OverlapArgs& a, int* counter, hipStream_t st);

@@ -537,7 +537,7 @@ class EnergyEngine:
 
     def evolve_bfgs_device(self, kind, params, WW, n_steps=1, maxiter=200, gtol=1e-5, h=1e-6, c1=1e-4,
                            alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), carry_hessian=False, hess_inv=None,
-                           max_rounds=None, tol=1e-12, counters=True):
+                           max_rounds=None, tol=1e-12, counters=True, tight_gradient=False, adaptive_gradient=False):
         """D = 2, 4: the whole BFGS time evolution in ONE LAUNCH, one wave (D = 2) / one workgroup (D = 4) per trajectory, the optimiser on the device
         (qmps_evolve_bfgs_device): every trajectory advances at its own pace, no host round trip per iteration.  Same iteration
         as `evolve_bfgs`.  Returns dict(x (T, P), params_hist (n_steps, T, P), fun / fun_start (n_steps, T), nit (n_steps, T) per
@@ -546,7 +546,7 @@ class EnergyEngine:
         WW = np.ascontiguousarray(WW, dtype=np.complex128).reshape(4, 4)
         al = np.ascontiguousarray(alphas, dtype=np.float64)
         if max_rounds is None:
-            max_rounds = 60
+            max_rounds = 100000 if self.D == 16 else 60
         T, npar = P.shape
         ph = np.empty((int(n_steps), T, npar))
         fh = np.empty((int(n_steps), 2, T))
@@ -556,6 +556,8 @@ class EnergyEngine:
         if hess_inv is not None:
             Hinv[...] = hess_inv
         flags = (L.BFGS_CARRY_HESSIAN if carry_hessian else 0) | (L.BFGS_WARM if (carry_hessian and hess_inv is not None) else 0)
+        if self.D == 16:      # (the gradient's two solves: qmps_hip.h)
+            flags |= (L.BFGS_TIGHT_GRADIENT if tight_gradient else 0) | (L.BFGS_ADAPTIVE_GRADIENT if (adaptive_gradient and not tight_gradient) else 0)
         L.check(self._lib.qmps_evolve_bfgs_device(self._ctx, T, int(kind), npar, _f64(P), _f64(WW.view(np.float64)), int(n_steps), int(maxiter),
                                                   float(gtol), float(h), float(c1), len(al), _f64(al), flags, int(max_rounds), float(tol),
                                                   _f64(Hinv), _f64(ph), _f64(fh), _i32(nit), _f64(cnt) if counters else None))

@@ -208,6 +208,15 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
     return (H, info) if return_info else H
 
 
+# D = 16: the per-trajectory device-resident optimiser (qmps_evolve_bfgs_device, qmps_evolve_d16.hip) is built, tested and NOT the
+# default: measured slower than the lock-step at every size (config 4, 256 trajectories: 0.84-1.00 against 0.82-0.96 ms per time
+# step; 32: 0.43 / 0.29; 2 048: 3.3 / 2.6; identity start 5-15 / 4.4-5.0) - one trajectory with |eta_2 / eta_1| = 0.82 needs 4.5 x the
+# mean's power steps in EVERY evaluation and holds its compute unit (and with it the launch) three times as long as the others,
+# while the lock-step gives that straggler's two solves a compute unit each and builds its neighbours elsewhere
+# (profiles/EXPERIMENTS.md).  options {'device_driver': 'trajectory'} selects it.
+D16_TRAJECTORY_DRIVER = False
+
+
 class LockstepEvolver:
     """The 'BFGS' branch of `evolve` as an object that keeps its two device contexts (gradient batches, ladder batches) and
     their resident fixed points across time steps: `step(X)` = one time step of all trajectories."""
@@ -246,9 +255,12 @@ class LockstepEvolver:
         self.native = bool(native) and self.speculative and (self.two_sided or D == 2)
         # D = 2 (the reference's own bond dimension): the native driver is the DEVICE-resident one - a wave per trajectory runs every
         # BFGS iteration of every time step without returning to the host (device=False: the host loop of qmps_evolve_bfgs)
+        # D = 16 (round 5): a workgroup of eight waves per trajectory (qmps_evolve_d16.hip); device_driver='lockstep' keeps the lock-step
         self.device = (self.native and bool(device_driver) and P <= 16 and 2 * P + len(self.alphas) <= 64 and
                        ((D == 2 and not self.two_sided and self.kind in L.EVOLVE_DEVICE_KINDS_D2) or
-                        (D == 4 and gradient == 'auto' and len(self.alphas) <= 9 and self.kind in (L.ANSATZ_SHALLOW_CNOT, 1, 3))))
+                        (D == 4 and gradient == 'auto' and len(self.alphas) <= 9 and self.kind in (L.ANSATZ_SHALLOW_CNOT, 1, 3)) or
+                        (D == 16 and self.two_sided and device_driver != 'lockstep' and (device_driver == 'trajectory' or D16_TRAJECTORY_DRIVER)
+                         and self.kind in (L.ANSATZ_SHALLOW_CNOT, 3))))
         self.mr, self.tol = mr, tol
         self.tight_gradient = bool(tight_gradient) or not self.two_sided
         self.adaptive_gradient = bool(adaptive_gradient) and not self.tight_gradient and D in (8, 16)
@@ -275,7 +287,8 @@ class LockstepEvolver:
             # D = 2, 4: the optimiser itself on the device (a wave / a workgroup per trajectory), the whole call in one launch (qmps_evolve_bfgs_device)
             res = self.fg.eng.evolve_bfgs_device(self.kind, X, WW, n_steps=n_steps, maxiter=self.maxiter, gtol=self.gtol, h=self.eps, alphas=self.alphas,
                                                  carry_hessian=self.carry_hessian, hess_inv=self._hinv if (self.carry_hessian and self._continued) else None,
-                                                 max_rounds=min(self.mr, 60), tol=self.tol, counters=counters)
+                                                 max_rounds=self.mr if self.D == 16 else min(self.mr, 60), tol=self.tol, counters=counters,
+                                                 tight_gradient=self.tight_gradient and self.D == 16, adaptive_gradient=self.adaptive_gradient and self.D == 16)
             self._continued = True
             self._hinv = res['hess_inv']
             res['nit_per_trajectory'] = res['nit']

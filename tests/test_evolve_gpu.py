@@ -612,6 +612,63 @@ def test_device_resident_bfgs_d4_against_the_host_driver_and_the_oracle(engine_f
         eng.evolve_bfgs_device(kind, X0, WW, alphas=tuple(0.5 ** k for k in range(11)))
 
 
+def test_device_resident_bfgs_d16_against_the_lockstep_driver_and_the_oracle(engine_factory):
+    """qmps_evolve_bfgs_device at D = 16 (qmps_evolve_d16.hip: a workgroup of eight waves per trajectory - two teams of four iterate the
+    right and the left fixed point on the matrix cores, every wave builds and probes central-difference neighbours in LDS) against the
+    lock-step driver qmps_evolve_bfgs, which evaluates the same formulae batch-wise: the same iteration counts, the same minima
+    (objectives to 1e-8), the same physical states; the recorded objectives are the ORACLE's (ARPACK in operator form, the
+    reference's route) at the device's parameters.  Carried and fresh inverse Hessians, the adaptive and the tight tolerance of
+    the gradient's solves, CNOT3 (three angles per layer), a ladder that provokes rejected full steps, and the evolve() option."""
+    rng = np.random.default_rng(1616)
+    kind, D, P, T, n_steps = 0, 16, 8, 7, 3
+    X0 = rng.standard_normal((T, P))
+    WW = WW_of(0.05)
+    eng = engine_factory(D, T * (2 * P + 1))
+    for carry, adaptive, tight in ((False, False, False), (True, True, False), (True, False, True)):
+        host = eng.evolve_bfgs(kind, X0, WW, n_steps=n_steps, maxiter=40, tol=1e-12, carry_hessian=carry, adaptive_gradient=adaptive, tight_gradient=tight)
+        dev = eng.evolve_bfgs_device(kind, X0, WW, n_steps=n_steps, maxiter=40, tol=1e-12, carry_hessian=carry, adaptive_gradient=adaptive, tight_gradient=tight)
+        assert dev['failed_evaluations'] == 0 and dev['nit'].shape == (n_steps, T)
+        print('carry', carry, 'adaptive', adaptive, 'tight', tight, 'max |f_dev - f_host|', np.abs(dev['fun'] - host['fun']).max(),
+              'nit dev (max per step)', dev['nit'].max(axis=1), 'host', host['nit'])
+        assert np.abs(dev['fun'] - host['fun']).max() < 1e-8 and np.abs(dev['fun_start'][0] - host['fun_start'][0]).max() < 1e-10
+        assert np.abs(dev['nit'].max(axis=1) - np.asarray(host['nit'])).max() <= 1
+        assert dev['fun'][-1].mean() < -0.999
+    prev = X0
+    for step in range(n_steps):
+        for t in range(T):
+            f_t = ER.objective(kind, D, ER.tensor(kind, D, prev[t]), dev['params_hist'][step, t], WW, arpack=True)
+            assert abs(f_t - dev['fun'][step, t]) < F_TOL, (step, t)
+            o = abs(O.overlap_eta_arpack(ER.tensor(kind, D, dev['params_hist'][step, t]), ER.tensor(kind, D, host['params_hist'][step, t]), np.eye(4))[0])
+            assert abs(o - 1.0) < 1e-6, (step, t, o)
+        prev = dev['params_hist'][step]
+    # rejected full steps: the backtracking points are eigen-solved two at a time, the ladder stops at the first rung that passes
+    odd = eng.evolve_bfgs_device(kind, X0, WW, n_steps=n_steps, maxiter=60, tol=1e-12, alphas=(2.5, 1.0, 0.3, 0.05, 0.005))
+    ref = eng.evolve_bfgs_device(kind, X0, WW, n_steps=n_steps, maxiter=60, tol=1e-12)
+    assert odd['failed_evaluations'] == 0 and np.abs(odd['fun'][-1] - ref['fun'][-1]).max() < 1e-6
+    # a call of three steps = three calls of one step (parameters and inverse Hessians carried over by the caller)
+    x, hinv, f3 = X0, None, []
+    for step in range(n_steps):
+        r1 = eng.evolve_bfgs_device(kind, x, WW, n_steps=1, maxiter=40, tol=1e-12, carry_hessian=True, hess_inv=hinv)
+        x, hinv = r1['x'], r1['hess_inv']
+        f3.append(r1['fun'][0])
+    whole = eng.evolve_bfgs_device(kind, X0, WW, n_steps=n_steps, maxiter=40, tol=1e-12, carry_hessian=True)
+    assert np.abs(np.array(f3) - whole['fun']).max() < 1e-8
+    # ShallowCNOTStateTensor3: nine angles, eighteen neighbours on eight waves
+    X9 = rng.standard_normal((3, 9))
+    eng9 = engine_factory(D, 3 * 19)
+    h9 = eng9.evolve_bfgs(3, X9, WW, n_steps=2, maxiter=40, tol=1e-12)
+    d9 = eng9.evolve_bfgs_device(3, X9, WW, n_steps=2, maxiter=40, tol=1e-12)
+    assert np.abs(d9['fun'] - h9['fun']).max() < 1e-8 and d9['failed_evaluations'] == 0
+    with pytest.raises(Exception, match='ShallowCNOT'):
+        eng.evolve_bfgs_device(1, X0, WW)
+    # evolve(): the lock-step stays the default at D = 16, options {'device_driver': 'trajectory'} selects this driver
+    Hd, info_d = NT.evolve(X0, WW, 2, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-12,
+                           options={'maxiter': 30, 'device_driver': 'trajectory'}, return_info=True)
+    Hl, info_l = NT.evolve(X0, WW, 2, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-12, options={'maxiter': 30}, return_info=True)
+    assert np.abs(np.array([f[-1] for f in info_d['fun']]) - np.array([f[-1] for f in info_l['fun']])).max() < 1e-8
+    assert 'gradient_batches' in info_l['solver'] and np.abs(Hd - Hl).max() < 1e-4
+
+
 @pytest.mark.parametrize('D,P,T,K', [(8, 6, 21, 3), (16, 8, 10, 4), (4, 4, 9, 2), (2, 8, 7, 2)])
 def test_lockstep_groups_are_the_same_trajectories(D, P, T, K, engine_factory):
     """qmps_set_evolve_groups: K lock-step groups (a context and a host thread each inside ONE qmps_evolve_bfgs call) against the one

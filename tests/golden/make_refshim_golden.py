@@ -8,7 +8,7 @@ numpy helpers), this script runs the reference's circuit-level code - the gate c
 `SparseFullEnergyOptimizer.objective_function_exact_environment / _opt_environment`, `NonSparseFull[TwoSite]EnergyOptimizer.
 objective_function`, the overlap objectives `scripts/loschmidt.py:obj` and `qmps/new_time_evolve.py:obj`, the embeddings
 `put_env_on_left_site / put_env_on_right_site / get_env_off_*`, and the drivers `qmps.tools.double_rotosolve`,
-`qmps.rotosolve.rotosolve / double_rotosolve` - on top of the documented-convention stand-ins of tests/golden/cirq_shim.py
+`qmps.rotosolve.rotosolve / double_rotosolve`, and the time-evolution loop (`minimize(obj, params, (A_, WW))` step after step) - on top of the documented-convention stand-ins of tests/golden/cirq_shim.py
 (read its header for exactly what the stand-ins supply: named-gate matrices, a big-endian state-vector pass, a dense
 eigen-solve for xmps's fixed points).  Arrays are named `refshim_*` so that no reader mistakes them for outputs of the
 reference on top of the real cirq / xmps; inputs carry no prefix.
@@ -255,6 +255,37 @@ def main():
     run_old_api('D4_d2', 4, 2, h_tfim, 6, 2)
     # every fit the reference handed to scipy's minimize_scalar during these runs, with scipy's answer: (a, b, c, d, x, f(x), nfev)
     out['refshim_roto_fits'] = np.stack(fits)
+
+    # ---------------------------------------------------------------------------------------------------------
+    # (6) N-2: the reference's time-evolution LOOP - per time step `A_ = tensor(params); res = minimize(obj, params, (A_, WW));
+    #     params = res.x` (qmps/new_time_evolve.py:276-292, scripts/loschmidt.py:367-375 with prob = 0) - run here with the reference's
+    #     6-qubit objective scripts/loschmidt.py:209-239, its gate and the new_time_evolve gate, scipy's default BFGS (forward
+    #     differences, gtol 1e-5): parameters and minima of three consecutive time steps for three starting points per gate.
+    #     (A generator of its own: the arrays above do not move when this section changes.)
+    # ---------------------------------------------------------------------------------------------------------
+    from scipy.optimize import minimize
+    rng6 = np.random.default_rng(20261004)
+    n_steps = 3
+    for name, gate_cls, P, WW in (('loschmidt', rrep.ShallowCNOTStateTensor, 8, WW_l), ('loschmidt_full', rrep.ShallowFullStateTensor, 15, WW_n)):
+        rlos.gate = (lambda cls: (lambda v, symbol='U': cls(2, v)))(gate_cls)
+        starts = rng6.standard_normal((3, P))
+        xs, fs, nits, nfevs, f0s = [], [], [], [], []
+        for x0 in starts:
+            params = x0.copy()
+            hx, hf, hn, hv, h0 = [params.copy()], [], [], [], []
+            for _ in range(n_steps):
+                A_ = rlos.iMPS([rtools.unitary_to_tensor(cirq.unitary(rlos.gate(params)))]).left_canonicalise()
+                h0.append(rlos.obj(params.copy(), A_[0], WW))             # where the step starts (W moved the state away from A_)
+                res = minimize(rlos.obj, params, (A_[0], WW))
+                params = res.x
+                hx.append(params.copy()); hf.append(res.fun); hn.append(res.nit); hv.append(res.nfev)
+            xs.append(np.stack(hx)); fs.append(hf); nits.append(hn); nfevs.append(hv); f0s.append(h0)
+        out[f'evolve_{name}_x0'] = starts
+        out[f'refshim_evolve_{name}_x'] = np.stack(xs)                # (3, n_steps + 1, P): parameters before / after every time step
+        out[f'refshim_evolve_{name}_f'] = np.array(fs)                # (3, n_steps): scipy's minimum of every time step
+        out[f'refshim_evolve_{name}_f_start'] = np.array(f0s)         # (3, n_steps): the objective at the step's starting point
+        out[f'refshim_evolve_{name}_nit'] = np.array(nits)
+        out[f'refshim_evolve_{name}_nfev'] = np.array(nfevs)
 
     path = os.path.join(HERE, 'refshim_golden.npz')
     np.savez_compressed(path, **out)

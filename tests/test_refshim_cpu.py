@@ -153,6 +153,41 @@ def test_overlap_objective_is_the_reference_circuit(name, g):
     assert f[:4].max() < -0.98 and f[4:].min() > -0.98
 
 
+@pytest.mark.parametrize('name', ['loschmidt', 'loschmidt_full'])
+def test_time_evolution_loop_run_by_the_reference(name, g):
+    """N-2: the loop `A_ = tensor(params); res = minimize(obj, params, (A_, WW)); params = res.x` (qmps/new_time_evolve.py:276-292,
+    scripts/loschmidt.py:367-375) executed with the reference's objective and gate and scipy's default BFGS: three consecutive
+    time steps from three starting points.  The oracle's objective reproduces the value scipy reported at the parameters it
+    returned (and at the starting point of every step); a time step starts away from its minimum (W moved the state) and ends close
+    to -1; and the lock-step BFGS of the host mirror (`tools.batched_bfgs`, the loop the device drivers implement) driven by the
+    ORACLE reaches the reference-run minima from the reference-run starting points."""
+    from qmps_amd import tools as T
+    build = (lambda p: O.shallow_cnot_unitary(2, p)) if name == 'loschmidt' else O.shallow_full_unitary
+    WW = g['WW_loschmidt'] if name == 'loschmidt' else g['WW_nte']
+    X, F, F0 = g[f'refshim_evolve_{name}_x'], g[f'refshim_evolve_{name}_f'], g[f'refshim_evolve_{name}_f_start']
+    assert np.abs(X[:, 0] - g[f'evolve_{name}_x0']).max() == 0.0
+    n_traj, n_steps = F.shape
+    for t in range(n_traj):
+        for k in range(n_steps):
+            A = O.unitary_to_tensor(build(X[t, k]))
+            assert abs(O.overlap_objective(A, O.unitary_to_tensor(build(X[t, k + 1])), WW) - F[t, k]) < 1e-12
+            assert abs(O.overlap_objective(A, A, WW) - F0[t, k]) < 1e-12
+    assert np.all(F < F0 - 1e-5) and F.max() < -0.99
+
+    def batch_f(k):
+        A = [O.unitary_to_tensor(build(X[t, k])) for t in range(n_traj)]
+        # (rows are trajectory-major: row i of a batch of n_traj G candidates belongs to trajectory i // G)
+        return lambda Z: np.array([O.overlap_objective(A[i // (len(Z) // n_traj)], O.unitary_to_tensor(build(z)), WW) for i, z in enumerate(Z)])
+    worst = 0.0
+    for k in range(n_steps):
+        f = batch_f(k)
+        res = T.batched_bfgs(f, f, X[:, k].copy(), maxiter=200)
+        worst = max(worst, np.abs(res['fun'] - F[:, k]).max())
+        # (never meaningfully above scipy's minimum; scipy's forward differences stop it ~1e-8 short now and then)
+        assert np.all(res['fun'] < F[:, k] + 1e-6), (k, res['fun'] - F[:, k])
+    print(name, 'max |f_lockstep - f_reference_run|', worst)
+
+
 def test_bounded_scalar_minimiser_reproduces_every_recorded_scipy_call(g):
     """tools.py:451 / rotosolve.py:237: the 486 `minimize_scalar(f, bounds=[-pi, pi])` calls the reference made while the
     fixtures were generated - coefficients of f, scipy's x, f(x) and evaluation count.  The oracle's restatement of the bounded

@@ -10,8 +10,8 @@
 //     into LDS (rows padded to 17);
 //   * the RIGHT and the LEFT fixed point of the iterate's mixed transfer map by the power method on the matrix cores
 //     (v_mfma_f64_16x16x4, three-product complex form): waves 0-3 the map, waves 4-7 the adjoint map, wave w of a team owns the
-//     physical index s = w exactly as in overlap_mfma_d16x4_body (qmps_overlap.hip); the two teams share the workgroup barrier of a
-//     step and stop together (a team that has converged idles through the other's last steps);
+//     physical index s = w exactly as in overlap_mfma_d16x4_body (qmps_overlap.hip); each team runs at its own pace on a barrier of
+//     its own (an arrival counter in LDS: team_barrier) and waits for the other at the workgroup barrier behind the solves;
 //   * G_s = y^+ C_s r from the right team's registers (C_s is still there in the A-layout, r in the accumulator layout IS the
 //     B-layout): two products per wave;
 //   * the 2 P central-difference neighbours and the iterate itself by the two-sided quotient eta' = <y, T'(r)> / <y, r>
@@ -20,11 +20,14 @@
 //   * a rejected full step's backtracking points: two at a time (one per team, both the map itself), started from the rejected
 //     step's fixed point, stopping at the first rung that passes the Armijo test (the rungs behind it cannot change the decision);
 //   * the optimiser loop itself: qmps_evolve_core.h, shared with D = 2 and 4.
-// 143 KB of LDS and up to 256 registers per wave: one workgroup per compute unit, 256 trajectories fill the chip.
+// 146 KB of LDS and up to 256 registers per wave: one workgroup per compute unit, 256 trajectories fill the chip.
+// MEASURED SLOWER than the lock-step driver at 32 ... 2 048 trajectories (profiles/EXPERIMENTS.md, round 5): the launch lasts as long as
+// the trajectory whose map has the smallest gap, and that trajectory is better served by the lock-step (a compute unit per solve, its
+// neighbours built elsewhere).  An option (qmps_evolve_bfgs_device at D = 16), not the default.
 // Tolerances as in the lock-step driver: the two solves of a gradient stop at max(tol, 1e-8) (the objective comes from the two-sided
 // quotient, error ~ residual^2), with `adaptive` at clamp(1e-3 max|g|, max(tol, 1e-8), 1e-6); backtracking points at tol.
 // A solve that exhausts its cap leaves status 1: the objective is NaN, the optimiser treats the point as rejected, `fail` counts it
-// (the host driver re-runs such trajectories through the lock-step path, which has the Krylov fall-back).
+// (counters_out[1] of qmps_evolve_bfgs_device; the Krylov fall-back for such maps lives in the lock-step path, qmps_evolve_bfgs).
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
@@ -64,7 +67,8 @@ __device__ __forceinline__ void team_barrier(int* cnt, int target) {
 
 // Both teams of the workgroup solve one fixed point each (called by all 512 threads): team = wave >> 2 iterates the map of (sA, Bt)
 // - Bt this team's candidate tensor - or, with adj, its adjoint, from the start vector xs (row-major [16][16] in LDS; null or zero:
-// the identity) to a residual of sqrt(tol2) or max_rounds steps.  enabled = false: the team only keeps the barriers company.
+// the identity) to a residual of sqrt(tol2) or max_rounds steps.  enabled = false: the team sets up and skips the iteration.
+// The two workgroup barriers of the set-up are the only ones: the caller joins the teams again behind the call.
 // The loop is overlap_mfma_d16x4_body's (qmps_overlap.hip) without deflation steps and without the Krylov hand-over.
 __device__ __forceinline__ void solve_teams_d16(const double2* sA, const double2* Bt, bool adj, bool enabled, const double2* W, const double2* xs, double tol2,
                                                 int max_rounds, double2 (*sT_all)[16 * kLdp], double2 (*sX_all)[256], int* sArrive, Solve16& o) {

@@ -87,7 +87,7 @@ def other_configs(args, budget_s=60.0):
                      'roofline': {k: r.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'hbm_frac', 'kernel', 'kernel_ms', 'kernel_share_of_wall') if k in r},
                      'cpu_baseline': d.get('cpu_baseline'), 'workload': d['config'].get('workload'),
                      'config': {k: v for k, v in d['config'].items() if k in ('baseline_config', 'hamiltonian', 'D', 'restarts', 'n_params', 'shifts', 'us_per_parameter_update', 'mean_energy_first_sweep',
-                                                                                'mean_energy_last_sweep', 'best_energy', 'exact_ground_state_energy', 'D2_optimum', 'ansatz', 'depth', 'not_converged_or_not_pd',
+                                                                                'mean_energy_last_sweep', 'best_energy', 'exact_ground_state_energy', 'D2_optimum', 'D2_manifold_optimum', 'ansatz', 'depth', 'not_converged_or_not_pd',
                                                                                 'trajectories_per_gpu', 'driver', 'lockstep_groups', 'bfgs_iterations_per_step', 'carry_hessian', 'not_converged',
                                                                                 'mean_final_objective', 'kernel_share_of_wall', 'device_busy', 'adaptive_gradient', 'solver_rounds_mean_gradient_batches',
                                                                                 'solver_rounds_max_gradient_batches')},

@@ -162,7 +162,7 @@ def main_rotosolve(args):
                           'n_params': P, 'us_per_parameter_update': elapsed / (sweeps * P) * 1e6,
                           'best_energy': float(np.nanmin(hist[-1])), 'mean_energy_first_sweep': float(np.nanmean(hist[0])),
                           'mean_energy_last_sweep': float(np.nanmean(hist[-1])), 'exact_ground_state_energy': (-4 / np.pi) if h_name.startswith('TFIM') else None,
-                          'D2_optimum': -1.269909412573 if (D == 2 and h_name.startswith('TFIM')) else None, 'ansatz': 'ShallowFullStateTensor' if full else 'ShallowCNOTStateTensor', 'depth': None if full else depth,
+                          'D2_optimum': -1.269909412573 if (D == 2 and h_name.startswith('TFIM')) else None, 'D2_manifold_optimum': -1.2725424859 if (D == 2 and h_name.startswith('TFIM')) else None, 'ansatz': 'ShallowFullStateTensor' if full else 'ShallowCNOTStateTensor', 'depth': None if full else depth,
                           'restarts_global': R_all, 'restarts_this_rank': R, 'sharded': bool(args.shard),
                           'summed_cost_last_sweep_all_ranks': None if reduced is None else float(reduced[0][-1]),
                           'restarts_counted_all_ranks': None if reduced is None else reduced[1],

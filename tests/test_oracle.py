@@ -350,3 +350,37 @@ def test_bench_schedule_replay_matches_the_oracle_schedule(golden, c_oracle):
                     sq += 1
                     count = 0
             assert it == k and sq == nsq, (cap, k, nsq, nmv)
+
+
+def test_d2_optimum_of_the_tfim():
+    """What is the best D = 2 energy of the TFIM at g = 1?  The reference's figure script draws a "D = 2" line at
+    D2_gse = -1.269909412573 (scripts/noisy_optimization.py:93) and the round-4 verdict asked for the bench's D = 2 leg to be read against
+    it (D2_gse is a TenPy iDMRG number at chi = 2; test_D2_optimum_beats_D2_gse above exhibits one state below it).  The OPTIMUM of the
+    D = 2 manifold is -1.2725424859 (7.0e-4 above the exact -4/pi), found here two independent ways with
+    the oracle's closed-form energy - scipy BFGS over the 15 angles of the universal two-qubit gate (ShallowFullStateTensor,
+    represent.py:382-404) and over a free complex 4 x 2 isometry (QR of 16 real numbers) - and on the device by
+    examples/ground_state_tfim.py (tests/test_examples_gpu.py).  The reference-executed fixtures pin the energy of this gate family to
+    the reference's own objective (tests/test_refshim_cpu.py), so this is the number the reference's code would report too."""
+    from scipy.optimize import minimize
+    h = O.hamiltonian_matrix({'ZZ': -1.0, 'X': 1.0})
+    exact = -4.0 / np.pi
+
+    def e_gate(p):
+        return O.energy_closed_form(O.unitary_to_tensor(O.shallow_full_unitary(p)), h)
+
+    def tensor_of(x):
+        Q, _ = np.linalg.qr((x[:8] + 1j * x[8:]).reshape(4, 2))
+        return np.ascontiguousarray(Q.reshape(2, 2, 2).transpose(1, 0, 2))            # Q[(i, s), j] -> A[s, i, j]: left-isometric
+
+    def e_free(x):
+        return O.energy_closed_form(tensor_of(x), h)
+
+    r1 = minimize(e_gate, np.random.default_rng(0).standard_normal(15), method='BFGS', options={'maxiter': 400})
+    r2 = minimize(e_free, np.random.default_rng(5).standard_normal(16), method='BFGS', options={'maxiter': 600})
+    assert abs(r1.fun - (-1.2725424859)) < 1e-6 and abs(r2.fun - (-1.2725424859)) < 1e-6
+    assert exact < min(r1.fun, r2.fun) and max(r1.fun, r2.fun) < -1.269909412573 - 2e-3
+    # the two optima are the same physical state: fidelity per site 1
+    A1, A2 = O.unitary_to_tensor(O.shallow_full_unitary(r1.x)), tensor_of(r2.x)
+    ov = abs(np.linalg.eigvals(O.transfer_matrix(A1, A2))).max()
+    assert abs(ov - 1.0) < 1e-4
+

@@ -191,6 +191,17 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
             info['solver'] = {'gradient_batches': fg.eng.overlap_stats(), 'line_search_batches': fl.eng.overlap_stats()}
         finally:
             ev.close()
+        lost = np.array([np.isnan(np.asarray(f)[-1]) for f in info['fun']])        # (n_steps, T)
+        if lost.any():
+            # status 1 of the fixed-point solves: SEVERAL dominant eigenvalues of equal modulus (the transfer map of a product state, special
+            # angles of the ansatz) - there is no unique fixed point, the two-sided gradient has nothing to stand on, and the library says so
+            # instead of returning one of the eigenvectors as ARPACK would (include/qmps_hip.h "status"); the trajectory keeps its parameters
+            import warnings
+            first = {int(t): int(np.argmax(lost[:, t])) for t in np.where(lost.any(axis=0))[0]}
+            warnings.warn(f"evolve(method='BFGS'): {len(first)} of {T} trajectories have no objective (NaN) from time step "
+                          f"{min(first.values())} on: their mixed transfer map has several dominant eigenvalues of EQUAL modulus (status 1 - a product "
+                          f"state / special angles of the ansatz); their parameters are left where they were: trajectories {sorted(first)[:8]}", RuntimeWarning, stacklevel=2)
+            info['no_unique_fixed_point'] = first
     else:
         for step in range(n_steps):
             Xn, fs = np.empty_like(X), np.empty(T)

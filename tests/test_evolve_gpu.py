@@ -612,6 +612,28 @@ def test_device_resident_bfgs_d4_against_the_host_driver_and_the_oracle(engine_f
         eng.evolve_bfgs_device(kind, X0, WW, alphas=tuple(0.5 ** k for k in range(11)))
 
 
+def test_a_map_without_a_unique_fixed_point_is_reported_not_hidden():
+    """Found by the randomised stress of round 5 (profiles/experiments/r05/stress_evolve.py, 1 trajectory in 4 000 cases): BFGS can walk a
+    trajectory INTO a product state - here the D = 8 ShallowCNOT angles (-pi/2, 0, pi/2, 0, 0, 0) - whose mixed transfer map has a whole ring of
+    dominant eigenvalues of equal modulus 0.995 and different phases.  There is no unique fixed point: the solves report status 1, the objective is
+    NaN from then on, the parameters stay where they are, `evolve` WARNS and names the trajectory - and the other trajectories of the batch
+    are untouched (the reference's ARPACK would return one of the eigenvectors and carry on; the two-sided gradient cannot)."""
+    D, P = 8, 6
+    WW = WW_of(0.1)
+    special = np.array([-np.pi / 2, 0.0, np.pi / 2, 0.0, 0.0, 0.0])
+    A = ER.tensor(0, D, special)
+    w = np.linalg.eigvals(O.transfer_matrix(np.tensordot(WW, O.merge(A, A), [1, 0]), O.merge(A, A)))
+    w = np.sort(np.abs(w))[::-1]
+    assert int((w > w[0] - 1e-9).sum()) >= 5 and abs(w[0] - 0.99502085) < 1e-7          # many equal moduli on top, no dominant eigenvalue
+    X0 = np.stack([special, np.random.default_rng(3).standard_normal(P)])
+    with pytest.warns(RuntimeWarning, match='EQUAL modulus'):
+        H, info = NT.evolve(X0, WW, 2, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-12, options={'maxiter': 40}, return_info=True)
+    f_end = np.array([f[-1] for f in info['fun']])
+    assert np.all(np.isnan(f_end[:, 0])) and np.all(np.isfinite(f_end[:, 1])) and f_end[:, 1].max() < -0.99
+    assert info['no_unique_fixed_point'] == {0: 0}
+    assert np.array_equal(H[:, 0], np.stack([special] * 3))                   # the trajectory stays where it was
+
+
 def test_device_resident_bfgs_d16_against_the_lockstep_driver_and_the_oracle(engine_factory):
     """qmps_evolve_bfgs_device at D = 16 (qmps_evolve_d16.hip: a workgroup of eight waves per trajectory - two teams of four iterate the
     right and the left fixed point on the matrix cores, every wave builds and probes central-difference neighbours in LDS) against the

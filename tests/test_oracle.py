@@ -384,3 +384,18 @@ def test_d2_optimum_of_the_tfim():
     ov = abs(np.linalg.eigvals(O.transfer_matrix(A1, A2))).max()
     assert abs(ov - 1.0) < 1e-4
 
+
+def test_oracle_environment_on_a_defective_transfer_matrix():
+    """Round 5 (randomised stress of the energy path): ExactAfter4 at D = 2 with angles on the pi/4 grid has the transfer spectrum (1, 0, 0, 0)
+    with a nilpotent block; numpy's eig returned a `dominant eigenvector` with residual 0.125, the oracle's energy was 0.625 where the device - and
+    the power method, and the definition - give 0.5.  The oracle now checks its eigenvector against the fixed-point equation and polishes it."""
+    import evolve_replay as ER
+    p = np.array([-0.00954598307922015, -np.pi / 2, np.pi, np.pi / 2, np.pi, np.pi / 2, np.pi, 0.0, -np.pi / 4, -np.pi / 4, np.pi, -np.pi / 2])
+    A = ER.tensor(5, 2, p)
+    w = np.sort(np.abs(np.linalg.eigvals(O.transfer_matrix(A))))[::-1]
+    assert abs(w[0] - 1.0) < 1e-12 and w[1] < 1e-6
+    eta, r = O.env_dense_eig(A)
+    assert np.abs(O.apply_transfer(A, r) - r).max() < 1e-13 and abs(np.trace(r) - 1.0) < 1e-13
+    assert abs(O.energy_closed_form(A, O.hamiltonian_matrix({'XX': 1.0, 'YY': 1.0, 'ZZ': 0.5})) - 0.5) < 1e-12
+    assert abs(O.energy_closed_form(A, O.hamiltonian_matrix({'ZZ': -1.0, 'X': 1.0})) - 0.35355339059327373) < 1e-12
+

@@ -160,7 +160,8 @@ int qmps_abi_version(void);
 /* additions that keep every existing signature (new entry points, new flag bits): bumps QMPS_ABI_MINOR only.
  * 6.1: qmps_set_roto_rule / qmps_get_roto_rule / qmps_roto_rule_probe, qmps_abi_minor; flags QMPS_BFGS_ADAPTIVE_GRADIENT, QMPS_BFGS_TIME_STEPS;
  *      qmps_evolve_opts_init / qmps_evolve_bfgs_opts / qmps_evolve_bfgs_device_opts (versioned option structs).
- * 6.2: qmps_evolve_bfgs_device accepts D = 16 (it refused anything but D = 2, 4 before). */
+ * 6.2: qmps_evolve_bfgs_device accepts D = 16 (it refused anything but D = 2, 4 before); fixed-point solves of the overlap path: generic
+ *      cold start, eta = 0 for nilpotent maps, the Gelfand route of the Krylov certificate (same signatures, see qmps_overlap_batch). */
 int qmps_abi_minor(void);
 const char* qmps_last_error(void);
 /* Test hook for the contract above ("nothing throws across the ABI"): raises a C++ exception inside the library - kind 1
@@ -334,8 +335,10 @@ int qmps_cell2_energy_batch_su(qmps_ctx* ctx, int64_t B, const double* params /*
  * dominant eigenvalue within max_rounds.
  * Solver: D = 2 and 4 SQUARE the D^2 x D^2 matrix of the map (max_rounds <= 60 squarings, rounds_out = squarings used:
  * O(log) rounds whatever the spectral gap) - D = 2 in a lane, D = 4 as one complex 16 x 16 tile on the matrix cores,
- * until it is rank one (||M M - tr(M) M||_F < tol ||M M||_F), eta = tr(M E)/tr(M);
- * D = 8, 16 run the power method in operator form from x_0 = 1/sqrt(D), eta = <x, T x>, stop when
+ * until it is rank one (||M M - tr(M) M||_F < tol ||M M||_F), eta = tr(M E)/tr(M); a map whose powers collapse to rounding
+ * noise within the first rounds is NILPOTENT (reference and candidate orthogonal): eta = 0, status 0 (ABI 6.2; it used to return noise);
+ * D = 8, 16 run the power method in operator form from x_0 = (1 + 2^-12 G)/sqrt(D), G a fixed pseudo-random complex matrix (ABI 6.2: the
+ * plain identity lies in the kernel of the map at symmetric points of the ansatz; ARPACK starts from a random vector), eta = <x, T x>, stop when
  * ||T x - eta x||_F < tol - at D = 16 on the matrix cores (v_mfma_f64_16x16x4, four waves per evaluation) - WITH A KRYLOV
  * FALL-BACK (ABI 5; the reference's route is ARPACK: xmps Map.right_fixed_point -> scipy eigs, qmps/new_time_evolve.py:201-203,
  * qmps/time_evolve_tools.py:84-91): a candidate whose residual history predicts more than 256 further power steps (looked at
@@ -343,7 +346,9 @@ int qmps_cell2_energy_batch_su(qmps_ctx* ctx, int64_t B, const double* params /*
  * candidate, 16 basis vectors and their images in LDS, the 5 dominant Schur vectors of the 16 x 16 projected map by squaring on
  * the matrix cores, restart with those (qmps_amd/csrc/qmps_overlap_krylov.hip).  It declares convergence on the same test
  * (one explicit application, ||T u - <u, T u> u||_F < tol, ||u||_F = 1) AND only once the second Schur pair is itself converged
- * far enough to be ranked below the first (|theta_2| + 100 (res_1 + res_2) < |theta_1|): Haar-random candidates take ~100 (D = 8) /
+ * far enough to be ranked below the first (|theta_2| + 100 (res_1 + res_2) < |theta_1|) - or (ABI 6.2) a Gelfand bound on the spectral
+ * radius of the projected map without its first Schur vector stays 3 % inside |theta_1| (a dominant eigenvalue over a RING of equal
+ * moduli, whose second pair never converges): Haar-random candidates take ~100 (D = 8) /
  * ~250 (D = 16) map applications where the power method needs 10^3 .. 10^5, pairs with |eta_2 / eta_1| = 1 - 1e-8 take 65.
  * max_rounds = cap on MAP APPLICATIONS (power steps + Arnoldi steps), rounds_out = applications used; status 1 = not converged
  * within them - two dominant eigenvalues of EQUAL modulus (no unique fixed point) always end that way. */

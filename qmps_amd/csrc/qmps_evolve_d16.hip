@@ -149,8 +149,9 @@ __device__ __forceinline__ void solve_teams_d16(const double2* sA, const double2
   v4f64 xr, xi;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    xr[q] = (c == 4 * q + g) ? 0.25 : 0.0;
-    xi[q] = 0.0;
+    const double2 x0 = overlap_cold_start(4 * q + g, c, 16);      // (generic: see overlap_cold_start)
+    xr[q] = x0.x;
+    xi[q] = x0.y;
   }
   if (xs != nullptr) {
     v4f64 wr, wi;

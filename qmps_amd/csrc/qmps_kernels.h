@@ -309,6 +309,20 @@ __device__ __forceinline__ void overlap_store(const OverlapArgs& p, int64_t b, d
     if (status != QMPS_ST_OK) atomicAdd(st + 3, 1ULL);
   }
 }
+// Cold start of the power method on a mixed transfer map: the identity (the natural guess: for a candidate close to the reference the fixed
+// point is the environment, positive with trace 1) PLUS 2^-12 of a fixed pseudo-random complex matrix.  The plain identity is orthogonal to the
+// dominant eigenvector - or lies in the kernel of the map - at symmetric points of the ansatz (angles on the pi/4 grid): the iteration then
+// converged, status 0, to eta = 0 after two steps or to the SECOND eigenvalue after thousands (found by the randomised stress of round 5,
+// profiles/EXPERIMENTS.md; the reference's ARPACK starts from a random vector).  A generic start contains every eigenvector; the residual test
+// cannot pass while a growing component is present.  Element (i, j) of the D x D start matrix, Frobenius norm ~ 1.
+__device__ __forceinline__ double2 overlap_cold_start(int i, int j, int D) {
+  unsigned h = ((unsigned)i * 131u + (unsigned)j * 31u + 7u) * 2654435761u;
+  const double gr = (double)((h >> 8) & 0xFFFFu) * (1.0 / 32768.0) - 1.0;
+  h = h * 2246822519u + 374761393u;
+  const double gi = (double)((h >> 8) & 0xFFFFu) * (1.0 / 32768.0) - 1.0;
+  const double s = D == 16 ? 0.25 : (D == 4 ? 0.5 : 1.0 / __builtin_sqrt((double)D)), eps = 1.0 / 4096.0;
+  return make_double2(s * ((i == j ? 1.0 : 0.0) + eps * gr), s * eps * gi);
+}
 // power method -> Krylov hand-over (see OverlapArgs::krylov_after).  Called at a convergence test of step k (k >= 16) with the
 // squared residual: every 32 steps or more the decay rate since the last look (bits per step) is extrapolated to tol2.
 // The caller that acts on `true` counts the candidate: atomicAdd(p.kry_counter + 2, 1) by ONE lane.

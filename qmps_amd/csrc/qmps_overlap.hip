@@ -112,7 +112,14 @@ __device__ __forceinline__ void overlap_block_body(const OverlapArgs& p, int64_t
       sB[e][s][i][j] = bm[s];
     }
   }
-  double2 x = make_double2(i == j ? 1.0 / __builtin_sqrt((double)D) : 0.0, 0.0);
+  double2 x_cold = overlap_cold_start(i, j, D);      // (generic: see overlap_cold_start)
+  {
+    double v[4] = {x_cold.x * x_cold.x + x_cold.y * x_cold.y, 0.0, 0.0, 0.0};
+    group_sum4(v);
+    const double inv = 1.0 / __builtin_sqrt(v[0]);
+    x_cold = make_double2(x_cold.x * inv, x_cold.y * inv);
+  }
+  double2 x = x_cold;
   const int64_t slot_off = overlap_slot_offset(p);
   if (p.x_in != nullptr) {      // warm start: the resident fixed point of this candidate's slot (all zero: none yet)
     const double2 w = ((const double2*)((const char*)p.x_in + slot_off))[(p.x_in_group > 0 ? bb / p.x_in_group : bb) * N + l];
@@ -184,7 +191,7 @@ __device__ __forceinline__ void overlap_block_body(const OverlapArgs& p, int64_t
         w0_prev = 0.0;
         k_ref = 0;
         rp = make_double2(0.0, 0.0);
-        x = make_double2(i == j ? 1.0 / __builtin_sqrt((double)D) : 0.0, 0.0);
+        x = x_cold;
       } else if (w[0] < tol2) {
         status = QMPS_ST_OK;
         active = false;
@@ -358,8 +365,9 @@ __global__ __launch_bounds__(256) void overlap_mfma_d16_kernel(OverlapArgs p) {
     v4f64 xr, xi;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      xr[q] = (c == 4 * q + g) ? 0.25 : 0.0;
-      xi[q] = 0.0;
+      const double2 x0 = overlap_cold_start(4 * q + g, c, 16);      // (generic: see overlap_cold_start)
+      xr[q] = x0.x;
+      xi[q] = x0.y;
     }
     if (p.x_in != nullptr) {      // warm start: the resident fixed point of this candidate's slot (all zero: none yet)
       const double2* xi_ = (const double2*)((const char*)p.x_in + slot_off) + (p.x_in_group > 0 ? b / p.x_in_group : b) * (D * D);
@@ -655,8 +663,9 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
     v4f64 xr, xi;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      xr[q] = (c == 4 * q + g) ? 0.25 : 0.0;
-      xi[q] = 0.0;
+      const double2 x0 = overlap_cold_start(4 * q + g, c, 16);      // (generic: see overlap_cold_start)
+      xr[q] = x0.x;
+      xi[q] = x0.y;
     }
     if (p.x_in != nullptr) {      // warm start: the resident fixed point of this candidate's slot (all zero: none yet)
       const double2* xi_ = (const double2*)((const char*)p.x_in + slot_off) + (p.x_in_group > 0 ? b / p.x_in_group : b) * (D * D);
@@ -788,8 +797,9 @@ __device__ __forceinline__ void overlap_mfma_d16x4_body(const OverlapArgs& p, in
           k_ref = 0;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            xr[q] = (c == 4 * q + g) ? 0.25 : 0.0;
-            xi[q] = 0.0;
+            const double2 x0 = overlap_cold_start(4 * q + g, c, 16);
+            xr[q] = x0.x;
+            xi[q] = x0.y;
           }
           continue;
         }

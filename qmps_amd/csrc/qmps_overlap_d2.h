@@ -125,10 +125,13 @@ __device__ __forceinline__ void overlap_lane_solve(GA Ap, GB Bp, const double2* 
       res += dr * dr + di * di;
     }
     rounds = m;
-    if (res < tol2 * vv) { status = QMPS_ST_OK; break; }
-    if (m == max_rounds) break;
-    // square and Frobenius-normalise
-    double qr[4][4], qi[4][4], f2 = 0.0;
+    // square (Frobenius-normalised below).  The square also says whether the current power is RANK ONE, ||M M - tr(M) M|| << ||M M||: the
+    // eigen-residual of the largest column alone is not enough - at symmetric points of the ansatz a column of an early power can be an
+    // EXACT eigenvector of a sub-dominant eigenvalue (|eta_2/eta_1| = 0.9994: accepted after 5 squarings with the wrong eigenvalue;
+    // profiles/experiments/r05/stress_overlap.py) - and whether it has collapsed to rounding noise (a nilpotent map: eta = 0).
+    double qr[4][4], qi[4][4], f2 = 0.0, m2 = 0.0, tr_r = 0.0, tr_i = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { tr_r += mr[a][a]; tr_i += mi[a][a]; }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -141,7 +144,24 @@ __device__ __forceinline__ void overlap_lane_solve(GA Ap, GB Bp, const double2* 
         }
         qr[a][c] = xr; qi[a][c] = xi;
         f2 += xr * xr + xi * xi;
+        m2 += mr[a][c] * mr[a][c] + mi[a][c] * mi[a][c];
       }
+    if (f2 < 1e-28 * m2 * m2) {
+      // collapsed to rounding noise.  Within the first rounds: a nilpotent map (a 4 x 4 one vanishes at the fourth power), every eigenvalue
+      // is zero.  Later: a defective dominant eigenvalue whose powers lose their digits slowly - no answer (status 1), never noise.
+      if (m <= 8) { eta_r = 0.0; eta_i = 0.0; status = QMPS_ST_OK; }
+      break;
+    }
+    double r1 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double dr = qr[a][c] - (tr_r * mr[a][c] - tr_i * mi[a][c]), di = qi[a][c] - (tr_r * mi[a][c] + tr_i * mr[a][c]);
+        r1 += dr * dr + di * di;
+      }
+    if (res < tol2 * vv && r1 < 1e-20 * f2) { status = QMPS_ST_OK; break; }
+    if (m == max_rounds) break;
     const double inv = f2 > 0.0 ? 1.0 / __builtin_sqrt(f2) : 0.0;
 #pragma unroll
     for (int a = 0; a < 4; ++a)

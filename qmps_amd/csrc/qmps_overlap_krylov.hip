@@ -108,7 +108,7 @@ struct KryLds {
 };
 
 // scalar slots in the oS region (doubles)
-enum { S_THETA = 0 /* 16 doubles */, S_G01 = 16 /* 2 */, S_RED = 20 /* 2 sets x 4 waves x 4 values = 32 */, S_IDX = 56 /* int */ };
+enum { S_THETA = 0 /* 16 doubles */, S_G01 = 16 /* 2 */, S_RHO2 = 18 /* 1: bound on the spectral radius of G without its first Schur vector */, S_RED = 20 /* 2 sets x 4 waves x 4 values = 32 */, S_IDX = 56 /* int */ };
 
 // ---- Rayleigh-Ritz on wave 0: the KK dominant Schur vectors of G by repeated squaring + deflation -------------------------
 // sG [16][16] row-major; out: sQ[r][i] (r < 16, i < KK), theta_i = y_i^H G y_i, g01 = y_0^H G y_1.  scratch >= 16*17*16 + 1024 bytes.
@@ -144,6 +144,9 @@ __device__ __forceinline__ void rayleigh_ritz_wave(const double2* sG, double2* s
     for (int q = 0; q < 4; ++q) n2 = dfma(gr[q], gr[q], dfma(gi[q], gi[q], n2));
     n2 = lane0(wave_sum(n2));
     bool have = n2 > 1e-280;
+    // Gelfand bound on the spectral radius of the deflated G from the norms the squarings compute anyway: with M_0 = G/||G||,
+    // M_{m+1} = M_m^2 / ||M_m^2||, ||G^(2^(m+1))||^(1/2^(m+1)) = ||G|| prod_j ||M_j^2||^(2^-(j+1)) >= rho(G) at every m (log_bound below).
+    double log_bound = have ? 0.5 * log(n2) : -INFINITY;
     if (have) {
       const double inv0 = 1.0 / __builtin_sqrt(n2);
       v4f64 mr = gr * inv0, mi = gi * inv0;
@@ -166,7 +169,8 @@ __device__ __forceinline__ void rayleigh_ritz_wave(const double2* sG, double2* s
         }
         res = lane0(wave_sum(res));
         q2 = lane0(wave_sum(q2));
-        if (!(q2 > 1e-280)) break;                 // nilpotent remainder: keep the last power
+        if (!(q2 > 1e-280)) { log_bound = -INFINITY; break; }      // nilpotent remainder: keep the last power
+        log_bound += ldexp(log(q2), -(m + 2));      // (log ||M_m^2|| = log(q2) / 2, weight 2^-(m+1))
         if (res < 1e-28 * q2) break;               // rank one
         const double inv = 1.0 / __builtin_sqrt(q2);
         mr = qr * inv;
@@ -194,6 +198,7 @@ __device__ __forceinline__ void rayleigh_ritz_wave(const double2* sG, double2* s
       __builtin_amdgcn_wave_barrier();
       have = bn > 1e-280;
     }
+    if (i == 1 && lane == 0) sS[S_RHO2] = exp(log_bound);      // every eigenvalue of G but theta_0 lies inside this radius
     // ---- orthonormalise against the Schur vectors found so far (entry r = c of the vector, replicated in the four row groups)
     double2 yc = have ? sY[c] : make_double2(0.0, 0.0);
     for (int attempt = 0; attempt < 17; ++attempt) {
@@ -602,7 +607,14 @@ __device__ __forceinline__ void overlap_krylov_body(const OverlapArgs& p, int* c
         bool target_second = false;
         if (sums[0] < tol2) {
           const double a0 = __builtin_sqrt(th0.x * th0.x + th0.y * th0.y), a1 = __builtin_sqrt(th1.x * th1.x + th1.y * th1.y);
-          if (a1 + KMARGIN * (__builtin_sqrt(sums[1]) + __builtin_sqrt(sums[0])) < a0) {
+          // Second route to acceptance (round 5, found by profiles/experiments/r05/stress_overlap.py): the certificate below wants the SECOND Schur
+          // pair converged too - which never happens when the second eigenvalue is a RING of equal moduli (symmetric points of the ansatz: a
+          // dominant 0.4886 over a triple at 0.4406 cost 28 000 - 53 000 applications, status 1 under a cap of 20 000, where the plain power
+          // method takes 276 steps).  The squarings of the Rayleigh-Ritz step bound the spectral radius of G WITHOUT its (converged) first
+          // Schur vector (S_RHO2, a Gelfand bound): if that radius stays 3 % inside |theta_0| nothing in the basis can rival the pair,
+          // converged or not.  Rivals closer than that (a ring next to the dominant one included) still have to converge and be ranked.
+          const double rho2 = sS[S_RHO2];
+          if (a1 + KMARGIN * (__builtin_sqrt(sums[1]) + __builtin_sqrt(sums[0])) < a0 || rho2 < 0.97 * a0) {
             // the pair is converged and ranked: ONE explicit application, the power kernels' own test
             const double inv = sums[2] > 0.0 ? 1.0 / __builtin_sqrt(sums[2]) : 0.0;
             const double2 un = make_double2(uv.x * inv, uv.y * inv);

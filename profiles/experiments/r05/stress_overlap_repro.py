@@ -28,8 +28,13 @@ for case in range(target + 1):
         cand = GRID[rng.integers(0, len(GRID), size=(B, P))] + (1e-9 * rng.standard_normal((B, P)) if rng.random() < 0.3 else 0.0)
         if rng.random() < 0.5:
             ref = GRID[rng.integers(0, len(GRID), size=(B, P))].astype(float)
-    WW = np.eye(4, dtype=complex) if rng.random() < 0.3 else expm(-1j * float(rng.choice([0.02, 0.05, 0.1, 0.3])) * Hm)
-print(json.dumps({'D': D, 'kind': kind, 'P': P, 'B': B, 'mode': str(mode), 'ref': ref[bsel].tolist(), 'cand': cand[bsel].tolist(), 'W_is_identity': bool(np.allclose(WW, np.eye(4)))}))
+    dt = 0.0
+    if rng.random() < 0.3:
+        WW = np.eye(4, dtype=complex)
+    else:
+        dt = float(rng.choice([0.02, 0.05, 0.1, 0.3]))
+        WW = expm(-1j * dt * Hm)
+print(json.dumps({'D': D, 'kind': kind, 'P': P, 'B': B, 'mode': str(mode), 'ref': ref[bsel].tolist(), 'cand': cand[bsel].tolist(), 'dt': dt}))
 A = ER.tensor(kind, D, ref[bsel])
 Bt = ER.tensor(kind, D, cand[bsel])
 C = np.tensordot(WW, O.merge(A, A), [1, 0])

@@ -284,3 +284,44 @@ def test_d16_split_kernels_match_the_one_wave_kernels(engine_factory, monkeypatc
     r = eng.environments(800)
     eng.energies(As, h)
     assert np.abs(eng.environments(40) - r[:40]).max() < 1e-12 and np.abs(eng.rdm(40) - np.array([O.two_site_rdm(As[b], r[b]) for b in range(40)])).max() < 1e-10
+
+
+def test_symmetric_angle_cases_found_by_the_randomised_stress(engine_factory):
+    """Round 5: `profiles/experiments/r05/stress_overlap.py` (78 000 evaluations against the dense spectrum, a third of them with angles on the grid
+    {0, +-pi/4, +-pi/2, pi}) found four SILENT errors - status 0, wrong eigenvalue - and one robustness hole at symmetric points of the ansatz.
+    The cases, each with the fix it forced (profiles/EXPERIMENTS.md):
+      1. D = 8: the identity - the old cold start of the power method - lies in the kernel of the map: 'converged' to eta = 0 in two steps where
+         the dominant eigenvalue is 0.2911 i (now: a generic start vector);
+      2. D = 4 (two of them): orthogonal states, a NILPOTENT map: the squaring solve amplified rounding noise to |eta| = 0.054 (now: eta = 0);
+      3. D = 2: an early power's largest column was an exact eigenvector of the SECOND eigenvalue (ratio 0.9994) (now: the power must be rank one);
+      4. D = 8: dominant 0.4886 over a triple of equal moduli 0.4406: 28 764 - 53 448 map applications through the Krylov fall-back, whose
+         certificate waited for the second Schur pair (now: a Gelfand bound on the rest of the projected spectrum; 65 applications)."""
+    H = O.hamiltonian_matrix({'ZZ': -1.0, 'X': 1.0})
+    q, h = np.pi / 4, np.pi / 2
+    cases = [
+        (8, 0, [-h, h], [-h, -h], 0.3, 'kernel'),
+        (4, 3, [-h, 0.0, 0.0, -h, 0.0, h], [0.0, h, 0.0, -q, np.pi, q], 0.0, 'nilpotent'),
+        (4, 0, [0.0, -h, 0.0, h], [h, -h, -h, h], 0.0, 'nilpotent'),
+        (2, 0, [-2.6210953988715016, -0.8450833442151273, -0.8019245840696824, 0.21286809643216326, 1.2948947120162366, 0.8556595269713478],
+         [h, -h, -h, q, -q, 0.0], 0.3, 'second'),
+        (8, 0, [2.267346344359502, 2.1922018428643666], [np.pi, np.pi], 0.3, 'ring'),
+    ]
+    builders = {0: O.shallow_cnot_unitary, 3: O.shallow_cnot3_unitary}
+    for D, kind, ref, cand, dt, what in cases:
+        WW = expm(-1j * dt * H) if dt else np.eye(4, dtype=complex)
+        A = O.unitary_to_tensor(builders[kind](D, np.array(ref)))
+        Bt = O.unitary_to_tensor(builders[kind](D, np.array(cand)))
+        w = np.linalg.eigvals(O.transfer_matrix(np.tensordot(WW, O.merge(A, A), [1, 0]), O.merge(Bt, Bt)))
+        w = w[np.argsort(-np.abs(w))]
+        eng = engine_factory(D, 1024)
+        for how in ('params', 'tensor'):
+            c_in = np.array(cand)[None] if how == 'params' else Bt[None]
+            eta, rounds, st = eng.overlaps(A[None], c_in, WW, kind=how, ansatz=kind if how == 'params' else None, tol=1e-12,
+                                           max_rounds=40 if D in (2, 4) else 20000)
+            assert st[0] == 0, (what, D, how, st)
+            if what == 'nilpotent':
+                assert np.abs(w).max() < 1e-6 and eta[0] == 0.0, (what, D, how, eta)       # (numpy's eigenvalues of a nilpotent matrix: noise ~1e-8)
+            else:
+                assert abs(eta[0] - w[0]) < 1e-9 and abs(w[1]) < abs(w[0]) * (1 - 5e-4), (what, D, how, eta, w[:3])
+            if what == 'ring':
+                assert abs(abs(w[1]) - abs(w[3])) < 1e-9 and rounds[0] < 400, rounds        # a triple of equal moduli behind the dominant eigenvalue

@@ -188,3 +188,35 @@ def test_evolve_identity_and_short_step():
     assert len(res) == 2 and all(-0.25 - 1e-6 < r.fun < -0.2499 for r in res)
     OPT = NT.Optimizer()
     assert isinstance(OPT.evolve, NT.Evolve) and isinstance(OPT.represent, NT.Represent) and isinstance(OPT.optimize, NT.Optimize)
+
+
+def test_environment_eigenpair_at_special_unitaries_found_by_the_stress():
+    """Round 5 (profiles/experiments/r05/stress_brickwall.py): with U1' = Z x X and U2' = X x 1 the environment matrix has a DOUBLE eigenvalue 0 whose
+    eigenvectors are columns of exp(M) itself.  The solve used to accept the largest column of the power as soon as it was an eigenvector of
+    ANYTHING - the kernel vector, residual 0 at round 0 - and returned eta = 0 where the reference's rule eta[np.argmax(eta)] names an
+    eigenvalue with a positive real part (4 of 9 360 separated cases of the stress).  Now the power must be rank one - or, for a DEGENERATE
+    leading eigenvalue (the double 0 itself leads in a third of these seeds: any of its eigenvectors is an answer), the eigenvalue must be the
+    one with the largest real part as measured by the growth rate of the power."""
+    from scipy.stats import unitary_group
+    Z, X, I = np.diag([1.0, -1.0]), np.array([[0, 1.0], [1.0, 0]]), np.eye(2)
+    n = 12
+    U1 = np.stack([unitary_group.rvs(4, random_state=100 + s) for s in range(n)])
+    U2 = np.stack([unitary_group.rvs(4, random_state=200 + s) for s in range(n)])
+    U1p = np.stack([np.kron(Z, X).astype(complex)] * n)
+    U2p = np.stack([np.kron(X, I).astype(complex)] * n)
+    seen = set()
+    for env, fn in ((NT.RightEnvironment(), BW.right_env_matrix), (NT.LeftEnvironment(), BW.left_env_matrix)):
+        mats, eta, vec, st = env._env(U1, U2, U1p, U2p, True)[:4]
+        assert np.all(st == 0)
+        for k in range(n):
+            M = fn(U1[k], U2[k], U1p[k], U2p[k])
+            assert np.abs(mats[k] - M).max() < 1e-13
+            w = np.linalg.eigvals(M)
+            w = w[np.argsort(-w.real)]
+            assert int((np.abs(w) < 1e-12).sum()) == 2                                   # the double zero
+            lead_is_zero = abs(w[0]) < 1e-12
+            seen.add(lead_is_zero)
+            assert abs(eta[k] - w[0]) < 1e-9, (k, eta[k], w)
+            x = vec[k].reshape(-1)
+            assert np.abs(M @ x - eta[k] * x).max() < 1e-9 and abs(np.linalg.norm(x) - 1.0) < 1e-12
+    assert seen == {True, False}                                                         # both situations occur among the seeds

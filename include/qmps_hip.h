@@ -337,6 +337,9 @@ int qmps_cell2_energy_batch_su(qmps_ctx* ctx, int64_t B, const double* params /*
  * O(log) rounds whatever the spectral gap) - D = 2 in a lane, D = 4 as one complex 16 x 16 tile on the matrix cores,
  * until it is rank one (||M M - tr(M) M||_F < tol ||M M||_F), eta = tr(M E)/tr(M); a map whose powers collapse to rounding
  * noise within the first rounds is NILPOTENT (reference and candidate orthogonal): eta = 0, status 0 (ABI 6.2; it used to return noise);
+ * D = 2 (ABI 6.2): dominant eigenvalues TIED in modulus (a complex-conjugate pair on the symmetric manifolds BFGS ends up on, a ring) - 30 and more
+ * squarings without a rank-one power - return their common MODULUS as a real eta with status 0 (the reference's objective -sqrt|eta| is the same for
+ * whichever member ARPACK returns); r_out is then the largest column of the last power, a mixture, not an eigenvector;
  * D = 8, 16 run the power method in operator form from x_0 = (1 + 2^-12 G)/sqrt(D), G a fixed pseudo-random complex matrix (ABI 6.2: the
  * plain identity lies in the kernel of the map at symmetric points of the ansatz; ARPACK starts from a random vector), eta = <x, T x>, stop when
  * ||T x - eta x||_F < tol - at D = 16 on the matrix cores (v_mfma_f64_16x16x4, four waves per evaluation) - WITH A KRYLOV

@@ -91,8 +91,11 @@ __device__ __forceinline__ void overlap_quad_solve(const double2* sC, const doub
   eta_r = eta_i = 0.0;
   status = QMPS_ST_NOT_CONVERGED;
   rounds = 0;
-  bool done = false;
+  bool done = false, collapsed = false;
+  double log_rho = 0.0;      // Gelfand bound on log |eta| from the squarings' norms (see overlap_lane_solve, qmps_overlap_d2.h)
   for (int m = 0; m <= max_rounds; ++m) {
+    bool res_ok = false;
+    double f2 = 0.0;
     if (!done) {
       // dominant right vector = largest column of the current power; v[a] in lane a
       int bc = 0;
@@ -124,13 +127,12 @@ __device__ __forceinline__ void overlap_quad_solve(const double2* sC, const doub
       const double dr = wr - (eta_r * vr - eta_i * vi), di = wi - (eta_r * vi + eta_i * vr);
       const double res = quad_sum(dfma(dr, dr, di * di));
       rounds = m;
-      if (res < tol2 * vv) { status = QMPS_ST_OK; done = true; }
-      else if (m == max_rounds) done = true;
+      res_ok = res < tol2 * vv;
     }
-    if (__builtin_amdgcn_ballot_w64(!done) == 0) break;        // (the quads of a wave leave together)
+    // (the square first: it also says whether the power is rank one - the eigen-residual of a column alone accepts an exact eigenvector of a
+    // LESSER eigenvalue at symmetric points - and whether it has collapsed: the tests of overlap_lane_solve)
+    double nr[4] = {0, 0, 0, 0}, ni[4] = {0, 0, 0, 0};
     if (!done) {
-      // square and Frobenius-normalise: row a of M M = sum_k M[a][k] row_k(M)
-      double nr[4] = {0, 0, 0, 0}, ni[4] = {0, 0, 0, 0};
 #define QMPS_ROW(K)                                                                                            \
       {                                                                                                        \
         const double ar = mr[K], ai = mi[K];                                                                   \
@@ -142,14 +144,51 @@ __device__ __forceinline__ void overlap_quad_solve(const double2* sC, const doub
       }
       QMPS_ROW(0) QMPS_ROW(1) QMPS_ROW(2) QMPS_ROW(3)
 #undef QMPS_ROW
-      double f2 = 0.0;
+      double f2l = 0.0, m2l = 0.0;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) f2 = dfma(nr[c], nr[c], dfma(ni[c], ni[c], f2));
-      f2 = quad_sum(f2);
+      for (int c = 0; c < 4; ++c) {
+        f2l = dfma(nr[c], nr[c], dfma(ni[c], ni[c], f2l));
+        m2l = dfma(mr[c], mr[c], dfma(mi[c], mi[c], m2l));
+      }
+      f2 = quad_sum(f2l);
+      const double m2 = quad_sum(m2l);
+      // tr(M): the diagonal element of row q is column q
+      double dgr = 0.0, dgi = 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { dgr += q == c ? mr[c] : 0.0; dgi += q == c ? mi[c] : 0.0; }
+      const double trr = quad_sum(dgr), tri = quad_sum(dgi);
+      double r1l = 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double dr = nr[c] - (trr * mr[c] - tri * mi[c]), di = ni[c] - (trr * mi[c] + tri * mr[c]);
+        r1l = dfma(dr, dr, dfma(di, di, r1l));
+      }
+      const double r1 = quad_sum(r1l);
+      if (f2 < 1e-28 * m2 * m2) {
+        if (m <= 8) { eta_r = 0.0; eta_i = 0.0; status = QMPS_ST_OK; }      // nilpotent: every eigenvalue vanishes
+        collapsed = true;
+        done = true;
+      } else if (res_ok && r1 < 1e-20 * f2) {
+        status = QMPS_ST_OK;
+        done = true;
+      } else if (m == max_rounds) {
+        done = true;
+      } else {
+        log_rho += (m == 0 ? 0.5 * log(m2) : 0.0) + ldexp(0.5 * log(f2 / (m2 * m2)), -(m + 1));
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(!done) == 0) break;        // (the quads of a wave leave together)
+    if (!done) {
+      // Frobenius-normalise the square
       const double inv = f2 > 0.0 ? 1.0 / __builtin_sqrt(f2) : 0.0;
 #pragma unroll
       for (int c = 0; c < 4; ++c) { mr[c] = nr[c] * inv; mi[c] = ni[c] * inv; }
     }
+  }
+  if (status != QMPS_ST_OK && !collapsed && rounds >= 30) {      // tied dominant eigenvalues: their common modulus (overlap_lane_solve)
+    eta_r = exp(log_rho);
+    eta_i = 0.0;
+    status = QMPS_ST_OK;
   }
 }
 

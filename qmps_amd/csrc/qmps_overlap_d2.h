@@ -86,6 +86,10 @@ __device__ __forceinline__ void overlap_lane_solve(GA Ap, GB Bp, const double2* 
   double eta_r = 0.0, eta_i = 0.0, vr[4] = {1, 0, 0, 0}, vi[4] = {0, 0, 0, 0};
   int status = QMPS_ST_NOT_CONVERGED, rounds = 0;
   const double tol2 = tol * tol;
+  // log ||E^(2^m)||_F / 2^m from the norms the squarings compute anyway: a Gelfand bound that converges to log |eta| whatever the spectrum
+  // looks like - the MODULUS of the dominant eigenvalue(s) when they are tied (see the end of the loop)
+  double log_rho = 0.0;
+  bool collapsed = false;
   for (int m = 0; m <= max_rounds; ++m) {
     // dominant right vector = largest column of the current power
     double best = -1.0;
@@ -150,8 +154,10 @@ __device__ __forceinline__ void overlap_lane_solve(GA Ap, GB Bp, const double2* 
       // collapsed to rounding noise.  Within the first rounds: a nilpotent map (a 4 x 4 one vanishes at the fourth power), every eigenvalue
       // is zero.  Later: a defective dominant eigenvalue whose powers lose their digits slowly - no answer (status 1), never noise.
       if (m <= 8) { eta_r = 0.0; eta_i = 0.0; status = QMPS_ST_OK; }
+      collapsed = true;
       break;
     }
+    log_rho += (m == 0 ? 0.5 * log(m2) : 0.0) + ldexp(0.5 * log(f2 / (m2 * m2)), -(m + 1));
     double r1 = 0.0;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -167,6 +173,16 @@ __device__ __forceinline__ void overlap_lane_solve(GA Ap, GB Bp, const double2* 
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int c = 0; c < 4; ++c) { mr[a][c] = qr[a][c] * inv; mi[a][c] = qi[a][c] * inv; }
+  }
+  if (status != QMPS_ST_OK && !collapsed && rounds >= 30) {
+    // Thirty and more squarings without a rank-one power: the dominant eigenvalues are TIED in modulus (a complex-conjugate pair, a ring -
+    // generic on symmetric manifolds of the ansatz: beta = -gamma of the depth-1 ShallowCNOT gate, product states).  No unique fixed point - but
+    // their common modulus is what the reference's objective -sqrt|eta| measures with whichever member ARPACK returns, and ||E^(2^m)||^(1/2^m)
+    // has it to 2^-m ln(condition) ~ 1e-11: eta = |eta| (real), status 0 (ABI 6.2; round 5: BFGS trajectories that walk into such a manifold used
+    // to die of NaN).  The vector handed out is the largest column of the last power - a mixture, not an eigenvector.
+    eta_r = exp(log_rho);
+    eta_i = 0.0;
+    status = QMPS_ST_OK;
   }
   out.eta_r = eta_r;
   out.eta_i = eta_i;

@@ -325,3 +325,28 @@ def test_symmetric_angle_cases_found_by_the_randomised_stress(engine_factory):
                 assert abs(eta[0] - w[0]) < 1e-9 and abs(w[1]) < abs(w[0]) * (1 - 5e-4), (what, D, how, eta, w[:3])
             if what == 'ring':
                 assert abs(abs(w[1]) - abs(w[3])) < 1e-9 and rounds[0] < 400, rounds        # a triple of equal moduli behind the dominant eigenvalue
+
+
+def test_tied_dominant_pair_at_d2_returns_the_common_modulus(engine_factory):
+    """Round 5 (profiles/experiments/r05/stress_evolve_device.py: 6 of 44 607 trajectory steps died of NaN, all here): on the manifold beta = -gamma of the
+    depth-1 ShallowCNOT gate at D = 2 - where BFGS trajectories end up - the mixed transfer map has a complex-conjugate PAIR of dominant
+    eigenvalues of equal modulus.  There is no unique fixed point, but the objective -sqrt|eta| the reference's circuit measures is the same for
+    either member (ARPACK returns one of them): the D = 2 solves now return that common modulus as a real eta, status 0 - from the norms of the
+    squared powers (a Gelfand bound, 1e-11 after 40 squarings) - and the time evolution goes on from such a point, on the host loop and on the
+    device-resident driver alike."""
+    from qmps_amd import new_time_evolve as NT, represent as R
+    H = O.hamiltonian_matrix({'ZZ': -1.0, 'X': 1.0})
+    eng = engine_factory(2, 1024)
+    for a, dt in ((0.5535838, 0.05), (-0.31582535, 0.02), (1.1, 0.1)):
+        WW = expm(-1j * dt * H)
+        x = np.array([-a, a])
+        A = O.unitary_to_tensor(O.shallow_cnot_unitary(2, x))
+        w = np.linalg.eigvals(O.transfer_matrix(np.tensordot(WW, O.merge(A, A), [1, 0]), O.merge(A, A)))
+        w = w[np.argsort(-np.abs(w))]
+        assert abs(abs(w[0]) - abs(w[1])) < 1e-12 and abs(w[0] - w[1]) > 1e-3 and abs(w[2]) < 0.5 * abs(w[0])      # a tied pair on top
+        eta, rounds, st = eng.overlaps(A[None], x[None], WW, kind='params', ansatz=0, tol=1e-13)
+        assert st[0] == 0 and abs(eta[0].imag) == 0.0 and abs(eta[0].real - abs(w[0])) < 1e-10, (eta, abs(w[0]))
+        for opts in ({'device_driver': True}, {'device_driver': False}):
+            Hh, info = NT.evolve(x[None], WW, 2, method='BFGS', D=2, state_tensor=R.ShallowCNOTStateTensor, tol=1e-13, options=dict(opts, maxiter=40), return_info=True)
+            f = np.array([fi[-1] for fi in info['fun']])
+            assert np.all(np.isfinite(f)) and f.max() < -0.99 and abs(info['fun'][0][0][0] + np.sqrt(abs(w[0]))) < 1e-9

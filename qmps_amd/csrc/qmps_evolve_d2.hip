@@ -92,10 +92,32 @@ __device__ __forceinline__ void overlap_quad_solve(const double2* sC, const doub
   status = QMPS_ST_NOT_CONVERGED;
   rounds = 0;
   bool done = false, collapsed = false;
-  double log_rho = 0.0;      // Gelfand bound on log |eta| from the squarings' norms (see overlap_lane_solve, qmps_overlap_d2.h)
+  // row a of M M = sum_k M[a][k] row_k(M), and its squared Frobenius norm
+  auto square = [&](const double (&xr)[4], const double (&xi)[4], double (&nr)[4], double (&ni)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) nr[c] = ni[c] = 0.0;
+#define QMPS_ROW(K)                                                                                            \
+    {                                                                                                          \
+      const double ar = xr[K], ai = xi[K];                                                                     \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                          \
+        const double kr = quad_bcast<K>(xr[c]), ki = quad_bcast<K>(xi[c]);                                     \
+        nr[c] = dfma(ar, kr, dfma(-ai, ki, nr[c]));                                                            \
+        ni[c] = dfma(ar, ki, dfma(ai, kr, ni[c]));                                                             \
+      }                                                                                                        \
+    }
+    QMPS_ROW(0) QMPS_ROW(1) QMPS_ROW(2) QMPS_ROW(3)
+#undef QMPS_ROW
+    double f = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) f = dfma(nr[c], nr[c], dfma(ni[c], ni[c], f));
+    return quad_sum(f);
+  };
+  double m2 = 0.0;      // ||M||_F^2: computed for the first power, 1 afterwards
+#pragma unroll
+  for (int c = 0; c < 4; ++c) m2 = dfma(mr[c], mr[c], dfma(mi[c], mi[c], m2));
+  m2 = quad_sum(m2);
   for (int m = 0; m <= max_rounds; ++m) {
-    bool res_ok = false;
-    double f2 = 0.0;
+    double nr[4], ni[4], f2 = 0.0;
     if (!done) {
       // dominant right vector = largest column of the current power; v[a] in lane a
       int bc = 0;
@@ -127,65 +149,56 @@ __device__ __forceinline__ void overlap_quad_solve(const double2* sC, const doub
       const double dr = wr - (eta_r * vr - eta_i * vi), di = wi - (eta_r * vi + eta_i * vr);
       const double res = quad_sum(dfma(dr, dr, di * di));
       rounds = m;
-      res_ok = res < tol2 * vv;
-    }
-    // (the square first: it also says whether the power is rank one - the eigen-residual of a column alone accepts an exact eigenvector of a
-    // LESSER eigenvalue at symmetric points - and whether it has collapsed: the tests of overlap_lane_solve)
-    double nr[4] = {0, 0, 0, 0}, ni[4] = {0, 0, 0, 0};
-    if (!done) {
-#define QMPS_ROW(K)                                                                                            \
-      {                                                                                                        \
-        const double ar = mr[K], ai = mi[K];                                                                   \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                        \
-          const double kr = quad_bcast<K>(mr[c]), ki = quad_bcast<K>(mi[c]);                                   \
-          nr[c] = dfma(ar, kr, dfma(-ai, ki, nr[c]));                                                          \
-          ni[c] = dfma(ar, ki, dfma(ai, kr, ni[c]));                                                           \
-        }                                                                                                      \
-      }
-      QMPS_ROW(0) QMPS_ROW(1) QMPS_ROW(2) QMPS_ROW(3)
-#undef QMPS_ROW
-      double f2l = 0.0, m2l = 0.0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        f2l = dfma(nr[c], nr[c], dfma(ni[c], ni[c], f2l));
-        m2l = dfma(mr[c], mr[c], dfma(mi[c], mi[c], m2l));
-      }
-      f2 = quad_sum(f2l);
-      const double m2 = quad_sum(m2l);
-      // tr(M): the diagonal element of row q is column q
-      double dgr = 0.0, dgi = 0.0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { dgr += q == c ? mr[c] : 0.0; dgi += q == c ? mi[c] : 0.0; }
-      const double trr = quad_sum(dgr), tri = quad_sum(dgi);
-      double r1l = 0.0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const double dr = nr[c] - (trr * mr[c] - tri * mi[c]), di = ni[c] - (trr * mi[c] + tri * mr[c]);
-        r1l = dfma(dr, dr, dfma(di, di, r1l));
-      }
-      const double r1 = quad_sum(r1l);
+      // the square: the next power - and the two tests the eigen-residual of a column cannot make (overlap_lane_solve, qmps_overlap_d2.h):
+      // has the power COLLAPSED to rounding noise (a nilpotent map), and - only looked at once the column passes - is the power RANK ONE
+      // (at symmetric points a column of an early power is an exact eigenvector of a LESSER eigenvalue)?
+      f2 = square(mr, mi, nr, ni);
       if (f2 < 1e-28 * m2 * m2) {
-        if (m <= 8) { eta_r = 0.0; eta_i = 0.0; status = QMPS_ST_OK; }      // nilpotent: every eigenvalue vanishes
+        if (m <= 8) { eta_r = 0.0; eta_i = 0.0; status = QMPS_ST_OK; }
         collapsed = true;
         done = true;
-      } else if (res_ok && r1 < 1e-20 * f2) {
-        status = QMPS_ST_OK;
-        done = true;
-      } else if (m == max_rounds) {
-        done = true;
-      } else {
-        log_rho += (m == 0 ? 0.5 * log(m2) : 0.0) + ldexp(0.5 * log(f2 / (m2 * m2)), -(m + 1));
+      } else if (res < tol2 * vv) {
+        double dgr = 0.0, dgi = 0.0;      // tr(M): the diagonal element of row q is column q
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { dgr += q == c ? mr[c] : 0.0; dgi += q == c ? mi[c] : 0.0; }
+        const double trr = quad_sum(dgr), tri = quad_sum(dgi);
+        double r1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double xr = nr[c] - (trr * mr[c] - tri * mi[c]), xi = ni[c] - (trr * mi[c] + tri * mr[c]);
+          r1 = dfma(xr, xr, dfma(xi, xi, r1));
+        }
+        if (quad_sum(r1) < 1e-20 * f2) { status = QMPS_ST_OK; done = true; }
       }
+      if (m == max_rounds) done = true;
     }
     if (__builtin_amdgcn_ballot_w64(!done) == 0) break;        // (the quads of a wave leave together)
     if (!done) {
-      // Frobenius-normalise the square
-      const double inv = f2 > 0.0 ? 1.0 / __builtin_sqrt(f2) : 0.0;
+      const double inv = 1.0 / __builtin_sqrt(f2);              // Frobenius-normalise the square
 #pragma unroll
       for (int c = 0; c < 4; ++c) { mr[c] = nr[c] * inv; mi[c] = ni[c] * inv; }
+      m2 = 1.0;
     }
   }
-  if (status != QMPS_ST_OK && !collapsed && rounds >= 30) {      // tied dominant eigenvalues: their common modulus (overlap_lane_solve)
+  if (status != QMPS_ST_OK && !collapsed && rounds >= 30) {
+    // tied dominant eigenvalues (overlap_lane_solve): their common modulus from the norms of the squared powers, ||E^(2^m)||^(1/2^m) - the rare
+    // path, so the logarithms live here, in a second pass over the squarings, and not in the loop above
+    double xr[4], xi[4], nr[4], ni[4], n2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { xr[c] = er[c]; xi[c] = ei[c]; n2 = dfma(er[c], er[c], dfma(ei[c], ei[c], n2)); }
+    n2 = quad_sum(n2);
+    double log_rho = 0.5 * log(n2);
+    const double inv0 = 1.0 / __builtin_sqrt(n2);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { xr[c] *= inv0; xi[c] *= inv0; }
+    for (int m = 0; m < 44; ++m) {
+      const double f2 = square(xr, xi, nr, ni);
+      if (!(f2 > 1e-280)) break;
+      log_rho += ldexp(0.5 * log(f2), -(m + 1));
+      const double inv = 1.0 / __builtin_sqrt(f2);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { xr[c] = nr[c] * inv; xi[c] = ni[c] * inv; }
+    }
     eta_r = exp(log_rho);
     eta_i = 0.0;
     status = QMPS_ST_OK;

@@ -86,10 +86,12 @@ __device__ __forceinline__ void overlap_lane_solve(GA Ap, GB Bp, const double2* 
   double eta_r = 0.0, eta_i = 0.0, vr[4] = {1, 0, 0, 0}, vi[4] = {0, 0, 0, 0};
   int status = QMPS_ST_NOT_CONVERGED, rounds = 0;
   const double tol2 = tol * tol;
-  // log ||E^(2^m)||_F / 2^m from the norms the squarings compute anyway: a Gelfand bound that converges to log |eta| whatever the spectrum
-  // looks like - the MODULUS of the dominant eigenvalue(s) when they are tied (see the end of the loop)
-  double log_rho = 0.0;
   bool collapsed = false;
+  double m2 = 0.0;      // ||M||_F^2 of the current power: computed for the first one, 1 afterwards
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) m2 += mr[a][c] * mr[a][c] + mi[a][c] * mi[a][c];
   for (int m = 0; m <= max_rounds; ++m) {
     // dominant right vector = largest column of the current power
     double best = -1.0;
@@ -129,13 +131,12 @@ __device__ __forceinline__ void overlap_lane_solve(GA Ap, GB Bp, const double2* 
       res += dr * dr + di * di;
     }
     rounds = m;
-    // square (Frobenius-normalised below).  The square also says whether the current power is RANK ONE, ||M M - tr(M) M|| << ||M M||: the
-    // eigen-residual of the largest column alone is not enough - at symmetric points of the ansatz a column of an early power can be an
-    // EXACT eigenvector of a sub-dominant eigenvalue (|eta_2/eta_1| = 0.9994: accepted after 5 squarings with the wrong eigenvalue;
-    // profiles/experiments/r05/stress_overlap.py) - and whether it has collapsed to rounding noise (a nilpotent map: eta = 0).
-    double qr[4][4], qi[4][4], f2 = 0.0, m2 = 0.0, tr_r = 0.0, tr_i = 0.0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) { tr_r += mr[a][a]; tr_i += mi[a][a]; }
+    // the square: the next power - and the two tests the eigen-residual of a column cannot make.  Has the power COLLAPSED to rounding noise
+    // (||M M|| < 1e-14 ||M||^2: within the first rounds a nilpotent map - reference and candidate orthogonal, every eigenvalue zero; later a
+    // defective dominant eigenvalue losing its digits: no answer)?  And - looked at only once the column passes - is the power RANK ONE,
+    // ||M M - tr(M) M|| << ||M M||?  At symmetric points of the ansatz a column of an early power can be an EXACT eigenvector of a
+    // sub-dominant eigenvalue (|eta_2/eta_1| = 0.9994: accepted after 5 squarings with the wrong eigenvalue; stress_overlap.py, round 5).
+    double qr[4][4], qi[4][4], f2 = 0.0;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -148,38 +149,76 @@ __device__ __forceinline__ void overlap_lane_solve(GA Ap, GB Bp, const double2* 
         }
         qr[a][c] = xr; qi[a][c] = xi;
         f2 += xr * xr + xi * xi;
-        m2 += mr[a][c] * mr[a][c] + mi[a][c] * mi[a][c];
       }
     if (f2 < 1e-28 * m2 * m2) {
-      // collapsed to rounding noise.  Within the first rounds: a nilpotent map (a 4 x 4 one vanishes at the fourth power), every eigenvalue
-      // is zero.  Later: a defective dominant eigenvalue whose powers lose their digits slowly - no answer (status 1), never noise.
       if (m <= 8) { eta_r = 0.0; eta_i = 0.0; status = QMPS_ST_OK; }
       collapsed = true;
       break;
     }
-    log_rho += (m == 0 ? 0.5 * log(m2) : 0.0) + ldexp(0.5 * log(f2 / (m2 * m2)), -(m + 1));
-    double r1 = 0.0;
+    if (res < tol2 * vv) {
+      double tr_r = 0.0, tr_i = 0.0, r1 = 0.0;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 4; ++a) { tr_r += mr[a][a]; tr_i += mi[a][a]; }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const double dr = qr[a][c] - (tr_r * mr[a][c] - tr_i * mi[a][c]), di = qi[a][c] - (tr_r * mi[a][c] + tr_i * mr[a][c]);
-        r1 += dr * dr + di * di;
-      }
-    if (res < tol2 * vv && r1 < 1e-20 * f2) { status = QMPS_ST_OK; break; }
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double dr = qr[a][c] - (tr_r * mr[a][c] - tr_i * mi[a][c]), di = qi[a][c] - (tr_r * mi[a][c] + tr_i * mr[a][c]);
+          r1 += dr * dr + di * di;
+        }
+      if (r1 < 1e-20 * f2) { status = QMPS_ST_OK; break; }
+    }
     if (m == max_rounds) break;
-    const double inv = f2 > 0.0 ? 1.0 / __builtin_sqrt(f2) : 0.0;
+    const double inv = 1.0 / __builtin_sqrt(f2);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int c = 0; c < 4; ++c) { mr[a][c] = qr[a][c] * inv; mi[a][c] = qi[a][c] * inv; }
+    m2 = 1.0;
   }
   if (status != QMPS_ST_OK && !collapsed && rounds >= 30) {
     // Thirty and more squarings without a rank-one power: the dominant eigenvalues are TIED in modulus (a complex-conjugate pair, a ring -
     // generic on symmetric manifolds of the ansatz: beta = -gamma of the depth-1 ShallowCNOT gate, product states).  No unique fixed point - but
     // their common modulus is what the reference's objective -sqrt|eta| measures with whichever member ARPACK returns, and ||E^(2^m)||^(1/2^m)
-    // has it to 2^-m ln(condition) ~ 1e-11: eta = |eta| (real), status 0 (ABI 6.2; round 5: BFGS trajectories that walk into such a manifold used
-    // to die of NaN).  The vector handed out is the largest column of the last power - a mixture, not an eigenvector.
+    // (a Gelfand bound, from the norms of the squared powers) has it to 2^-m ln(condition) ~ 1e-11: eta = |eta| (real), status 0 (ABI 6.2;
+    // round 5: BFGS trajectories that walk into such a manifold used to die of NaN).  The rare path: the logarithms live in this second pass
+    // over the squarings.  The vector handed out is the largest column of the last power - a mixture, not an eigenvector.
+    double n2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { mr[a][c] = er[a][c]; mi[a][c] = ei[a][c]; n2 += er[a][c] * er[a][c] + ei[a][c] * ei[a][c]; }
+    double log_rho = 0.5 * log(n2);
+    {
+      const double inv0 = 1.0 / __builtin_sqrt(n2);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { mr[a][c] *= inv0; mi[a][c] *= inv0; }
+    }
+    for (int m = 0; m < 44; ++m) {
+      double qr[4][4], qi[4][4], f2 = 0.0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double xr = 0, xi = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            xr += mr[a][k] * mr[k][c] - mi[a][k] * mi[k][c];
+            xi += mr[a][k] * mi[k][c] + mi[a][k] * mr[k][c];
+          }
+          qr[a][c] = xr; qi[a][c] = xi;
+          f2 += xr * xr + xi * xi;
+        }
+      if (!(f2 > 1e-280)) break;
+      log_rho += ldexp(0.5 * log(f2), -(m + 1));
+      const double inv = 1.0 / __builtin_sqrt(f2);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { mr[a][c] = qr[a][c] * inv; mi[a][c] = qi[a][c] * inv; }
+    }
     eta_r = exp(log_rho);
     eta_i = 0.0;
     status = QMPS_ST_OK;

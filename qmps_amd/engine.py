@@ -538,9 +538,10 @@ class EnergyEngine:
     def evolve_bfgs_device(self, kind, params, WW, n_steps=1, maxiter=200, gtol=1e-5, h=1e-6, c1=1e-4,
                            alphas=(1.0, 0.5, 0.25, 0.125, 1 / 16, 1 / 64, 1 / 256, 1 / 4096), carry_hessian=False, hess_inv=None,
                            max_rounds=None, tol=1e-12, counters=True, tight_gradient=False, adaptive_gradient=False):
-        """D = 2, 4: the whole BFGS time evolution in ONE LAUNCH, one wave (D = 2) / one workgroup (D = 4) per trajectory, the optimiser on the device
+        """D = 2, 4 (and, as an option measured slower than `evolve_bfgs`, D = 16): the whole BFGS time evolution in ONE LAUNCH, one wave (D = 2) /
+        one workgroup (D = 4: eight waves; D = 16: eight waves on a compute unit of their own) per trajectory, the optimiser on the device
         (qmps_evolve_bfgs_device): every trajectory advances at its own pace, no host round trip per iteration.  Same iteration
-        as `evolve_bfgs`.  Returns dict(x (T, P), params_hist (n_steps, T, P), fun / fun_start (n_steps, T), nit (n_steps, T) per
+        as `evolve_bfgs`.  tight_gradient / adaptive_gradient: D = 16 only (the tolerance of a gradient's two solves, as `evolve_bfgs`).  Returns dict(x (T, P), params_hist (n_steps, T, P), fun / fun_start (n_steps, T), nit (n_steps, T) per
         trajectory, hess_inv, nfev, failed_evaluations, kernel_ms)."""
         P = np.array(np.atleast_2d(params), dtype=np.float64, order='C', copy=True)
         WW = np.ascontiguousarray(WW, dtype=np.complex128).reshape(4, 4)

@@ -137,7 +137,7 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
       method 'BFGS': lock-step batched BFGS - by default the whole evolution in ONE C call (`qmps_evolve_bfgs`: objective and
           gradient at the full quasi-Newton step first, the backtracking ladder only for trajectories that reject it; the same
           decisions as a plain ladder; at D = 2 the optimiser itself runs on the device, one wave per trajectory, every trajectory at
-          its own pace: `qmps_evolve_bfgs_device`, options {'device_driver': False} for the host loop); options {'native': False} runs the same loop from numpy (`tools.batched_bfgs`, per-iteration
+          its own pace: `qmps_evolve_bfgs_device`, options {'device_driver': False} for the host loop; {'device_driver': 'trajectory'} at D = 16: the per-trajectory kernel of qmps_evolve_d16.hip, an option measured slower than the lock-step); options {'native': False} runs the same loop from numpy (`tools.batched_bfgs`, per-iteration
           objective history), {'speculative': False} the plain two-batch iteration (gradient columns, then the ladder);
           'carry_hessian', 'tight_gradient', 'adaptive_gradient', 'gradient', 'first_rungs', 'maxiter', 'gtol', 'eps', 'alphas' as in LockstepEvolver;
       anything else: scipy.optimize.minimize on the scalar `obj` per trajectory (the reference's own call).

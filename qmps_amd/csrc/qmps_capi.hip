@@ -784,6 +784,14 @@ int qmps_set_hamiltonian(qmps_ctx* c, int n_terms, const double* h) try {
     f = sqrt(f);
     if (f > c->h_fro) c->h_fro = f;
   }
+  if (n_terms != c->n_terms) {
+    // The in-kernel clear of a cost accumulator covers the CURRENT number of terms only: after a change of that number a slot that counts as clean
+    // may still hold the arrivals of a term it was last used with ("cost accumulator: 46 of 23 waves arrived" on the first accumulating launch after
+    // going from one Hamiltonian term to two; found by profiles/experiments/r05/stress_api_state.py, round 5).  Every position of the ring is marked
+    // dirty: setup_accumulator clears a dirty position completely before it is used.
+    for (int sl = 0; sl < qmps_ctx::kCostSlots; ++sl)
+      for (int ps = 0; ps < qmps_ctx::kMaxGroup; ++ps) c->acc_dirty[sl][ps] = true;
+  }
   c->n_terms = n_terms;
   return QMPS_OK;
 }

@@ -76,8 +76,12 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
     const double2 u = g[i * D + j], l = g[j * D + i];
     r = make_double2(0.5 * (u.x + l.x), (i == j) ? 0.0 : 0.5 * (u.y - l.y));
     const double tr = block_sum<D>(i == j ? r.x : 0.0, red, tid);
-    r.x /= tr;
-    r.y /= tr;
+    if (tr > 1e-300 && tr < 1e300) {
+      r.x /= tr;
+      r.y /= tr;
+    } else {      // (zeros / NaN where nobody stored an environment: no guess, the default start)
+      r = make_double2(i == j ? 1.0 / D : 0.0, 0.0);
+    }
   } else {
     r = make_double2(i == j ? 1.0 / D : 0.0, 0.0);
   }

@@ -84,11 +84,13 @@ __global__ __launch_bounds__(256) void energy_mfma_d16_kernel(LaneArgs p) {
         r.im[q] = 0.5 * (u.y - l.y);
         tr += (c == 4 * q + g) ? r.re[q] : 0.0;
       }
-      const double inv = 1.0 / wave_sum(tr);
+      const double trs = wave_sum(tr);
+      const bool usable = trs > 1e-300 && trs < 1e300;      // (zeros / NaN where nobody stored an environment: no guess, the default start)
+      const double inv = usable ? 1.0 / trs : 0.0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        r.re[q] *= inv;
-        r.im[q] *= inv;
+        r.re[q] = usable ? r.re[q] * inv : ((c == 4 * q + g) ? 1.0 / D : 0.0);
+        r.im[q] = usable ? r.im[q] * inv : 0.0;
       }
     } else {
 #pragma unroll
@@ -336,11 +338,13 @@ __global__ __launch_bounds__(128) void energy_mfma_d16x2_kernel(LaneArgs p) {
         r.im[q] = 0.5 * (u.y - l.y);
         tr += (c == 4 * q + g) ? r.re[q] : 0.0;
       }
-      const double inv = 1.0 / wave_sum(tr);
+      const double trs = wave_sum(tr);
+      const bool usable = trs > 1e-300 && trs < 1e300;      // (zeros / NaN where nobody stored an environment: no guess, the default start)
+      const double inv = usable ? 1.0 / trs : 0.0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        r.re[q] *= inv;
-        r.im[q] *= inv;
+        r.re[q] = usable ? r.re[q] * inv : ((c == 4 * q + g) ? 1.0 / D : 0.0);
+        r.im[q] = usable ? r.im[q] * inv : 0.0;
       }
     } else {
 #pragma unroll

@@ -604,13 +604,16 @@ __global__ __launch_bounds__(64) void energy_lane_kernel(LaneArgs p) {
         rim[i][j] = (i == j) ? 0.0 : 0.5 * (u.y - l.y);
         if (i == j) tr += rre[i][j];
       }
-    const double inv = 1.0 / tr;
+    // (a resident 'environment' nobody wrote - a window that never stored one, zeros, NaN - is no guess: the default start.  A warm launch on such a
+    // window used to end with status != 0 for every evaluation: profiles/experiments/r05/stress_api_state.py, round 5)
+    const bool usable = tr > 1e-300 && tr < 1e300;
+    const double inv = usable ? 1.0 / tr : 0.0;
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
       for (int j = i; j < D; ++j) {
-        rre[i][j] *= inv;
-        rim[i][j] *= inv;
+        rre[i][j] = usable ? rre[i][j] * inv : ((i == j) ? 1.0 / D : 0.0);
+        rim[i][j] = usable ? rim[i][j] * inv : 0.0;
       }
   } else {
     // default start: 1/D; squaring from the start (handoff == 0) uses |0><0| like the D = 4 matrix kernel
@@ -1213,9 +1216,11 @@ __global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(S
         xc[reg] = reg == g ? u.x : (reg < g ? RS2 * (u.x + l.x) : RS2 * (l.y - u.y));
         tsel = reg == g ? u.x : tsel;
       }
-      const double inv0 = fast_inv(group4_sum_mfma(tsel));
+      const double tr0 = group4_sum_mfma(tsel);
+      const bool usable = tr0 > 1e-300 && tr0 < 1e300;      // (zeros / NaN where nobody stored an environment: the default start e_0)
+      const double inv0 = usable ? fast_inv(tr0) : 0.0;
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) xc[reg] *= inv0;
+      for (int reg = 0; reg < 4; ++reg) xc[reg] = usable ? xc[reg] * inv0 : ((4 * reg + g == 0) ? 1.0 : 0.0);
     } else if (m == 0) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) xc[reg] = (4 * reg + g == 0) ? 1.0 : 0.0;

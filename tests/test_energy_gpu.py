@@ -294,3 +294,56 @@ def test_d16_environment_krylov_fallback(engine_factory, monkeypatch):
     monkeypatch.delenv('QMPS_NO_KRYLOV')
     assert (st2 == 1).sum() >= 4 and np.all(it2[st2 == 1] == 3000)         # the slow ones exhaust the cap without it
     assert np.abs(E2 - ref)[st2 == 0].max() < E_TOL
+
+
+def test_cost_accumulator_survives_a_change_of_the_number_of_terms():
+    """Round 5 (profiles/experiments/r05/stress_api_state.py, a fuzzer of the stateful API): the in-kernel clear of a cost accumulator covers the CURRENT
+    number of Hamiltonian terms; after two terms -> one term -> two terms a ring slot that counted as clean still held the arrivals of the second term:
+    'cost accumulator: 46 of 23 waves arrived' on an accumulating launch.  qmps_set_hamiltonian now marks the whole ring dirty when the number changes."""
+    from qmps_amd import EnergyEngine
+    rng = np.random.default_rng(11)
+    D, B = 4, 368
+    eng = EnergyEngine(D, B)                      # (a context of its own: the ring's history is the point)
+    U = O.haar_unitaries(rng, 2 * D, B)
+    eng.set_tensors(np.stack([O.unitary_to_tensor(u) for u in U]))
+    h1 = O.hamiltonian_matrix({'ZZ': -1.0, 'X': 1.0})[None]
+    h2 = np.stack([h1[0], O.hamiltonian_matrix({'XX': 1.0, 'YY': 1.0, 'ZZ': 0.5})])
+    for h in (h2, h1, h2, h1, h2):
+        eng.set_hamiltonian(h)
+        for _ in range(12):                       # more than a lap of the eight-slot ring
+            eng.launch(B, solver='direct', store_env=False, accumulate_cost=True)
+            eng.cost_launch(B)
+            E, _, st = eng.results(B)
+            cost = eng.get_cost()
+            assert np.all(st == 0) and np.abs(cost - E.sum(0)).max() < 1e-9 * np.abs(E).sum()
+    eng.close()
+
+
+@pytest.mark.parametrize('D,solver', [(2, 'plain'), (2, 'squaring'), (4, 'squaring'), (8, 'plain'), (16, 'plain')])
+def test_warm_start_without_a_stored_environment_is_a_cold_start(D, solver):
+    """Same fuzzer: `warm_start=True` reads the RESIDENT environments - but the flag that says there are any is per context, not per window.  A warm
+    launch on a window that never stored one found zeros (or whatever the allocation held), divided by their trace and reported status != 0 for
+    every evaluation.  Zeros / NaN are no guess: the power-iteration kernels now take their default start there (the direct D = 4 kernel's
+    acceptance step had always rejected them)."""
+    from qmps_amd import EnergyEngine
+    rng = np.random.default_rng(12 + D)
+    B = 96 if D == 16 else 300
+    eng = EnergyEngine(D, 2 * B)
+    A = np.stack([O.unitary_to_tensor(u) for u in O.haar_unitaries(rng, 2 * D, 2 * B)])
+    h = O.hamiltonian_matrix({'ZZ': -1.0, 'X': 1.0})[None]
+    eng.set_tensors(A)
+    eng.set_hamiltonian(h)
+    eng.set_window(0)
+    eng.launch(B, solver=solver, store_env=True)               # window 0 has environments now: the context's flag is up
+    E0, _, st0 = eng.results(B)
+    eng.set_window(B)
+    eng.launch(B, solver=solver, store_env=True, warm_start=True)      # window 1 never stored any
+    E1, _, st1 = eng.results(B)
+    ref = EnergyEngine(D, B)
+    ref.set_solver(solver)
+    Er, _, str_ = ref.energies(A[B:], h)
+    assert np.array_equal(st1 == 0, str_ == 0) and (st1 == 0).mean() > 0.95
+    ok = st1 == 0
+    assert np.abs(E1[ok] - Er[ok]).max() < 1e-10
+    eng.close()
+    ref.close()

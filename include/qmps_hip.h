@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 #define QMPS_ABI_VERSION 6
-#define QMPS_ABI_MINOR 2
+#define QMPS_ABI_MINOR 3
 
 /* error codes */
 #define QMPS_OK 0
@@ -161,7 +161,8 @@ int qmps_abi_version(void);
  * 6.1: qmps_set_roto_rule / qmps_get_roto_rule / qmps_roto_rule_probe, qmps_abi_minor; flags QMPS_BFGS_ADAPTIVE_GRADIENT, QMPS_BFGS_TIME_STEPS;
  *      qmps_evolve_opts_init / qmps_evolve_bfgs_opts / qmps_evolve_bfgs_device_opts (versioned option structs).
  * 6.2: qmps_evolve_bfgs_device accepts D = 16 (it refused anything but D = 2, 4 before); fixed-point solves of the overlap path: generic
- *      cold start, eta = 0 for nilpotent maps, the Gelfand route of the Krylov certificate (same signatures, see qmps_overlap_batch). */
+ *      cold start, eta = 0 for nilpotent maps, the Gelfand route of the Krylov certificate (same signatures, see qmps_overlap_batch).
+ * 6.3: qmps_overlap_amplitude (the overlap circuit's amplitude for given environments: the reference's variational route). */
 int qmps_abi_minor(void);
 const char* qmps_last_error(void);
 /* Test hook for the contract above ("nothing throws across the ABI"): raises a C++ exception inside the library - kind 1
@@ -391,6 +392,15 @@ int qmps_overlap_launch(qmps_ctx* ctx, int64_t B, int max_rounds, double tol, in
 int qmps_overlap_get(qmps_ctx* ctx, int64_t B, double* eta_out, double* r_out, int32_t* rounds_out, int32_t* status_out);
 /* the objective itself, f_b = -sqrt(|eta_b|) (qmps/new_time_evolve.py:221, scripts/loschmidt.py:238-239), computed by the kernel */
 int qmps_overlap_get_objective(qmps_ctx* ctx, int64_t B, double* f_out /* [B] */);
+/* The overlap CIRCUIT's amplitude for GIVEN environments (ABI 6.3) - the variational route of the reference, which does not solve for
+ * the fixed point: `get_overlap` (qmps/time_evolve_tools.py:95-131: R = put_env_on_left_site(r), L = put_env_on_right_site(r^+), objective
+ * -2 |psi[0]| minimised over the 8 reals of r by Nelder-Mead) and `obj_state` (qmps/new_time_evolve.py:223-247: R a StateGate).  For the
+ * resident candidates [window, window + B) against the references / operator of qmps_overlap_set* (same addressing as qmps_overlap_launch,
+ * candidate groups included): amp_out[b] = psi[0] = 1/2 <q^_b, T_b(q^_b)>_F with q^ = q / ||q||_F (an all-zero q gives 0), T_b the mixed
+ * two-site transfer map of qmps_overlap_batch.  q [B][D][D] complex128 (row-major), amp_out [B] complex128; D = 2, 4, 8, 16 (the reference
+ * has D = 2 only).  For the exact fixed point the amplitude is eta / 2.  Synchronous; leaves eta, the objective and the resident fixed
+ * points of earlier launches alone. */
+int qmps_overlap_amplitude(qmps_ctx* ctx, int64_t B, const double* q, double* amp_out);
 /* Solver statistics accumulated by every overlap evaluation of this context since the last reset (device-side atomics):
  * evaluations, sum and maximum of their rounds (squarings at D = 2, 4; power steps at D = 8, 16), evaluations that ended
  * with status != 0.  Waits for the stream. */

@@ -97,6 +97,7 @@ SIGNATURES = {
     'qmps_overlap_set_group': (c_int, [c_void_p, c_int64]),
     'qmps_overlap_set_active': (c_int, [c_void_p, c_int64, c_char_p]),
     'qmps_overlap_get_objective': (c_int, [c_void_p, c_int64, _dp]),
+    'qmps_overlap_amplitude': (c_int, [c_void_p, c_int64, _dp, _dp]),
     'qmps_overlap_stats': (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_int]),
     'qmps_overlap_eval_ansatz': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, c_int, c_double, c_int, _dp, _ip]),
     'qmps_overlap_gradient': (c_int, [c_void_p, c_int64, c_int, c_int, _dp, c_double, c_int, c_double, c_int, _dp, _dp, _ip]),

@@ -282,6 +282,41 @@ int qmps_overlap_get_objective(qmps_ctx* c, int64_t B, double* f_out) try {
 }
 QMPS_API_CATCH
 
+int qmps_overlap_amplitude(qmps_ctx* c, int64_t B, const double* q, double* amp_out) try {
+  if (int rc = bind(c)) return rc;
+  if (int rc = check_window(c, B)) return rc;
+  if (!q || !amp_out) return fail(QMPS_ERR_ARG, "null argument");
+  if (c->window + B > c->n_states) return fail(QMPS_ERR_STATE, "window [%lld, %lld) but only %lld states are resident", (long long)c->window, (long long)(c->window + B), (long long)c->n_states);
+  if (c->overlap_refs < 1) return fail(QMPS_ERR_STATE, "qmps_overlap_set has not been called");
+  const int64_t group = c->overlap_group;
+  if (group > 0) {
+    if (c->window % group) return fail(QMPS_ERR_ARG, "with a candidate group the window must start at a multiple of it");
+    if (c->overlap_refs * group < c->window + B) return fail(QMPS_ERR_STATE, "%lld reference tensors x group %lld for window end %lld", (long long)c->overlap_refs, (long long)group, (long long)(c->window + B));
+  } else if (c->overlap_refs != 1 && c->overlap_refs < c->window + B) {
+    return fail(QMPS_ERR_STATE, "%lld reference tensors for window end %lld", (long long)c->overlap_refs, (long long)(c->window + B));
+  }
+  if (int rc = ensure_tensors(c)) return rc;
+  // environments in and amplitudes out through the scratch arena: neither the resident fixed points nor eta of a launch are touched
+  const size_t qb = (size_t)B * env_bytes(c), ob = (size_t)B * 16;
+  if (int rc = ensure_scratch(c, qb + ob)) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_scratch, q, qb, hipMemcpyHostToDevice, c->stream));
+  qmps::OverlapArgs a;
+  memset(&a, 0, sizeof(a));
+  const bool shared = group == 0 && c->overlap_refs == 1;
+  a.A = (shared || group > 0) ? (char*)c->d_ref + (group > 0 ? (size_t)(c->window / group) * tensor_bytes(c) : 0)
+                              : (char*)c->d_ref + (size_t)c->window * tensor_bytes(c);
+  a.Bt = win_A(c);
+  a.WW = c->d_ww;
+  a.x_in = c->d_scratch;
+  a.eta = (char*)c->d_scratch + qb;
+  a.B = B; a.a_shared = shared ? 1 : 0; a.group = (int)group;
+  HIP_TRY(qmps::launch_overlap_amplitude(c->D, a, c->stream));
+  HIP_TRY(hipMemcpyAsync(amp_out, a.eta, ob, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return QMPS_OK;
+}
+QMPS_API_CATCH
+
 int qmps_overlap_stats(qmps_ctx* c, int64_t* evaluations, int64_t* rounds_sum, int64_t* rounds_max, int64_t* not_converged, int reset) try {
   if (int rc = bind(c)) return rc;
   unsigned long long h[4] = {0, 0, 0, 0};

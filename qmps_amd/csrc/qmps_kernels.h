@@ -381,6 +381,8 @@ hipError_t launch_overlap_krylov_pair(int D, const OverlapArgs& right, const Ove
 // D = 4, 8, 16: operator-form power method (qmps_overlap.hip); tensors [2][D][D]; max_rounds = cap on power steps;
 // mfma: D = 16 on the matrix cores (one wave per evaluation) instead of the generic LDS-tile kernel
 hipError_t launch_overlap_d(int D, const OverlapArgs& a, bool mfma, hipStream_t st);
+// psi[0] of the overlap circuit for GIVEN environments (qmps_overlap_amp.hip): a.x_in = q [B][D][D], a.eta = amplitudes [B]
+hipError_t launch_overlap_amplitude(int D, const OverlapArgs& a, hipStream_t st);
 // D = 16, at most 8192 evaluations in all: right fixed points (`right`) and left fixed points (`left`, adjoint map) in ONE launch, four waves per evaluation
 // (krylov_now = false: the caller launches the fall-back itself - launch_overlap_krylov_pair - if and when a status asks for it)
 // central-difference neighbours built by the surplus workgroups of the D = 16 pair launch (ShallowCNOT families; see overlap_mfma_d16x4_pair_kernel)

@@ -462,6 +462,18 @@ class EnergyEngine:
         L.check(self._lib.qmps_overlap_get_objective(self._ctx, B, _f64(f)))
         return f
 
+    def overlap_amplitudes(self, q, B=None):
+        """psi[0] of the reference's overlap circuit for GIVEN environments q (B,D,D) on its outer qubits (the variational route:
+        `get_overlap`, qmps/time_evolve_tools.py:95-131; `obj_state`, qmps/new_time_evolve.py:223-247) = 1/2 <q^, T(q^)>_F with
+        q^ = q/||q||_F, for the resident candidates of the window against the references of `overlap_set*`.  Returns complex (B,)."""
+        q = _c128(q, (self.D, self.D), 'q')
+        B = q.shape[0] if B is None else int(B)
+        if q.shape[0] != B:
+            raise ValueError('one environment per candidate')
+        amp = np.empty(B, dtype=np.complex128)
+        L.check(self._lib.qmps_overlap_amplitude(self._ctx, B, _f64(q.view(np.float64)), _f64(amp.view(np.float64))))
+        return amp
+
     def overlap_stats(self, reset=False):
         """dict(evaluations, rounds_sum, rounds_max, not_converged) accumulated by the overlap kernels since the last reset."""
         v = [ctypes.c_int64(0) for _ in range(4)]

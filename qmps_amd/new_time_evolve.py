@@ -361,6 +361,39 @@ def state_gate(v, symbol='R'):
     return StateGate(v, symbol)
 
 
+def obj_state(p_, A, WW):
+    """new_time_evolve.py:223-247: the 5-qubit register after R = StateGate(p_[15:]) on qubits (3,4), U U W, L on (0,1), U'^+ U'^+,
+    CNOT, H - the state function the reference's rotosolve variant pairs with `obj_H` (energy = -|psi[0]|^2).  Host state-vector
+    pass over the package's gate objects (represent.final_state), like the reference's simulator call; psi[0] on its own -
+    <r^, T(r^)>_F / sqrt(2), r = environment_from_unitary(R) - is `obj_state_amplitudes` on the device."""
+    from .represent import CNOT, H, Environment, final_state, line_qubits
+    from .time_evolve_tools import put_env_on_right_site
+    from .tools import environment_from_unitary, tensor_to_unitary
+    p_ = np.asarray(p_, dtype=float)
+    p, rs = p_[:15], p_[15:]
+    B = unitary_to_tensor(unitary(gate(p)))
+    U = Environment(tensor_to_unitary(np.asarray(A, dtype=complex)), 'U')
+    U_ = Environment(tensor_to_unitary(B), "U'")
+    R = state_gate(rs)
+    Lg = Environment(put_env_on_right_site(environment_from_unitary(unitary(R)).conj().T), 'L')
+    W = Environment(np.asarray(WW, dtype=complex), 'W')
+    q = line_qubits(5)
+    return final_state([R(*q[3:5]), U(*q[2:4]), U(*q[1:3]), W(*q[2:4]), Lg(*q[0:2]), (U_ ** -1)(*q[1:3]), (U_ ** -1)(*q[2:4]),
+                        CNOT(*q[3:5]), H(q[3])], 5)
+
+
+def obj_state_amplitudes(P_, A, WW):
+    """psi[0] of `obj_state` for a batch of parameter vectors P_ (n, 15 + 6) against one state tensor A, on the device."""
+    from .tools import environment_from_unitary
+    P_ = np.atleast_2d(np.asarray(P_, dtype=float))
+    cand = np.stack([unitary_to_tensor(unitary(gate(p[:15]))) for p in P_])
+    q = np.stack([environment_from_unitary(unitary(state_gate(p[15:]))) for p in P_])
+    eng = _runtime.engine(2, len(cand))
+    eng.set_tensors(cand)
+    eng.overlap_set(np.asarray(A, dtype=complex), WW)
+    return eng.overlap_amplitudes(q) * np.sqrt(2.0)
+
+
 def obj_H():
     """Projector observable of the rotosolve variant (new_time_evolve.py:247-248): -|0..0><0..0| on 5 qubits."""
     return -np.diag(np.eye(2 ** 5)[0])

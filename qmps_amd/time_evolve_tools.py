@@ -8,8 +8,9 @@
 
   gate, egate, get_overlap_exact   qmps/time_evolve_tools.py:76-92   (device: qmps_overlap_batch with W = 1)
 
-`get_overlap` (:94-131, the variational-environment search over a 6-qubit circuit) is not mirrored: variational
-environment circuits are out of scope; `get_overlap_exact` is the value it converges to.
+  get_overlap              qmps/time_evolve_tools.py:95-131   the variational-environment route: Nelder-Mead over the 8 reals of an
+                           environment r put on the circuit's outer qubits; the circuit amplitude psi[0] = 1/2 <r^, T(r^)>_F comes from
+                           `qmps_overlap_amplitude` (device), the simplex stays scipy's as in the reference
 """
 import numpy as np
 from scipy.linalg import null_space
@@ -90,3 +91,42 @@ def get_overlap_exact(p1, p2, gate=gate, testing=True):
     B = unitary_to_tensor(unitary(gate(p2)))
     x2, r = overlap_of_tensors(A, B, want_r=True)
     return (x2, r) if testing else x2
+
+
+def overlap_amplitudes(A, B, WW, q):
+    """psi[0] of the reference's 6-qubit overlap circuit (time_evolve_tools.py:113-127, scripts/loschmidt.py:228-238) with the
+    environment q on its outer qubits - R = put_env_on_left_site(q), L = put_env_on_right_site(q^+) - for a batch:
+    A (2,D,D) shared or (n,2,D,D), candidates B (n,2,D,D), q (n,D,D); the norm of q drops out.  Device: `qmps_overlap_amplitude`."""
+    from . import _runtime
+    B = np.asarray(B, dtype=complex)
+    q = np.asarray(q, dtype=complex)
+    D = B.shape[-1]
+    eng = _runtime.engine(D, len(B))
+    eng.set_tensors(B)
+    eng.overlap_set(A, WW)
+    return eng.overlap_amplitudes(q)
+
+
+def get_overlap(p1, p2, gate=gate, egate=egate, initial=None, options=None):
+    """time_evolve_tools.py:95-131: minimise -2 |psi[0]| of the overlap circuit (W = 1) over an environment r = (rs[:4] + i rs[4:]) put
+    on both outer sites, Nelder-Mead from `initial` (random if None); returns the minimum.  The reference rotates r by a phase
+    (xmps `rotate_to_hermitian`) and normalises it: neither moves |psi[0]|.  (What it converges to is the numerical radius of the
+    mixed two-site transfer map, >= |x|^2 of `get_overlap_exact`; equal when the map is normal.)  `options`: scipy's, default
+    {'disp': True} as in the reference."""
+    from scipy.optimize import minimize
+    from . import _runtime
+    from .represent import unitary
+    from .tools import unitary_to_tensor
+    initial = np.random.randn(8) if initial is None else np.asarray(initial, dtype=float)
+    A = unitary_to_tensor(unitary(gate(p1)))
+    B = unitary_to_tensor(unitary(gate(p2)))
+    eng = _runtime.engine(2, 1)
+    eng.set_tensors(B[None])
+    eng.overlap_set(A, np.eye(4))
+
+    def obj(rs):
+        r = (rs[:4] + 1j * rs[4:]).reshape(1, 2, 2)
+        return -2.0 * float(np.abs(eng.overlap_amplitudes(r)[0]))
+
+    res = minimize(obj, initial, method='Nelder-Mead', options={'disp': True} if options is None else options)
+    return res.fun

@@ -287,6 +287,47 @@ def main():
         out[f'refshim_evolve_{name}_nit'] = np.array(nits)
         out[f'refshim_evolve_{name}_nfev'] = np.array(nfevs)
 
+    # ---------------------------------------------------------------------------------------------------------
+    # (7) the variational route of the overlap: `get_overlap` (qmps/time_evolve_tools.py:95-131) - its Nelder-Mead minimum and its
+    #     objective closure at recorded points - and `obj_state` (qmps/new_time_evolve.py:223-247).  xmps `rotate_to_hermitian` is not
+    #     in /root/reference; the objective -2 |psi[0]| cannot depend on it as long as it rotates its argument by a phase (R carries
+    #     r, L carries r^+): run with TWO stand-ins (divide by the phase of the trace; multiply by i) and assert equal minima.
+    # ---------------------------------------------------------------------------------------------------------
+    from qmps import new_time_evolve as rnte
+    rng7 = np.random.default_rng(20261005)
+    real_min = rtet.minimize
+    seen = {}
+
+    def recording_min(fun, x0, args=(), **kw):
+        seen['fun'] = fun
+        return real_min(fun, x0, args, **kw)
+
+    rtet.minimize = recording_min
+    P1, P2, INIT = rng7.standard_normal((3, 15)), rng7.standard_normal((3, 15)), rng7.standard_normal((3, 8))
+    P2[2] = P1[2] + 0.05 * rng7.standard_normal(15)                     # a candidate next to the reference state
+    probes = rng7.standard_normal((3, 5, 8))
+    mins, vals = [], []
+    for k in range(3):
+        got = []
+        for stand_in in (lambda M: M * np.exp(-1j * np.angle(np.trace(M))), lambda M: 1j * M):
+            rtet.rotate_to_hermitian = stand_in
+            with redirect_stdout(io.StringIO()):
+                got.append(rtet.get_overlap(P1[k], P2[k], initial=INIT[k].copy()))
+        assert abs(got[0] - got[1]) < 1e-12, got
+        mins.append(got[0])
+        vals.append([seen['fun'](x.copy()) for x in probes[k]])             # the closure of the last run: -2 |psi[0]| at given rs
+    rtet.minimize = real_min
+    out['varenv_p1'], out['varenv_p2'], out['varenv_initial'], out['varenv_probe_rs'] = P1, P2, INIT, probes
+    out['refshim_get_overlap_min'] = np.array(mins)
+    out['refshim_get_overlap_obj'] = np.array(vals)
+    PS = np.concatenate([P2, rng7.standard_normal((3, 6))], axis=1)          # 15 gate angles + 6 StateGate angles
+    psis = []
+    for k in range(3):
+        A = rtools.unitary_to_tensor(cirq.unitary(rnte.gate(P1[k])))
+        psis.append(rnte.obj_state(PS[k].copy(), A, WW_n if k else np.eye(4)))
+    out['obj_state_p'] = PS
+    out['refshim_obj_state_psi'] = np.stack(psis)                            # (3, 32); entries 16.. read null_space() completion rows of L
+
     path = os.path.join(HERE, 'refshim_golden.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, os.path.getsize(path), 'bytes,', len(out), 'arrays,', len(fits), 'scalar-minimiser calls recorded')

@@ -350,3 +350,60 @@ def test_tied_dominant_pair_at_d2_returns_the_common_modulus(engine_factory):
             Hh, info = NT.evolve(x[None], WW, 2, method='BFGS', D=2, state_tensor=R.ShallowCNOTStateTensor, tol=1e-13, options=dict(opts, maxiter=40), return_info=True)
             f = np.array([fi[-1] for fi in info['fun']])
             assert np.all(np.isfinite(f)) and f.max() < -0.99 and abs(info['fun'][0][0][0] + np.sqrt(abs(w[0]))) < 1e-9
+
+
+@pytest.mark.parametrize('D', [2, 4, 8, 16])
+def test_circuit_amplitude_for_given_environments(D, engine_factory):
+    """qmps_overlap_amplitude (the variational route: get_overlap, qmps/time_evolve_tools.py:95-131; obj_state, new_time_evolve.py:223-247):
+    psi[0] = <q^, T(q^)>_F / 2 for given environments q - shared reference, one reference per candidate, candidate groups, a window;
+    at the exact fixed point the amplitude is eta / 2; an all-zero q gives 0; eta / r of an earlier launch stay."""
+    rng = np.random.default_rng(700 + D)
+    n = 24
+    A = np.stack([O.unitary_to_tensor(u) for u in O.haar_unitaries(rng, 2 * D, n)])
+    Bt = np.stack([O.unitary_to_tensor(u) for u in O.haar_unitaries(rng, 2 * D, n)])
+    WW = O.haar_unitaries(rng, 4, 1)[0]
+    q = rng.standard_normal((n, D, D)) + 1j * rng.standard_normal((n, D, D))
+    q[:3] *= np.array([1e-6, 1e6, 3.0])[:, None, None]          # the norm drops out
+    q[5] = 0.0
+
+    def rayleigh(a, b, x):
+        nx = np.linalg.norm(x)
+        if nx == 0:
+            return 0.0
+        xh = x / nx
+        C = np.tensordot(WW, O.merge(a, a), [1, 0])
+        Bm = O.merge(b, b)
+        return 0.5 * np.vdot(xh, sum(C[s] @ xh @ Bm[s].conj().T for s in range(4)))
+
+    eng = engine_factory(D, 4096)
+    eng.set_tensors(Bt)
+    eng.overlap_set(A[0], WW)                                    # one shared reference
+    amp = eng.overlap_amplitudes(q)
+    want = np.array([rayleigh(A[0], Bt[b], q[b]) for b in range(n)])
+    assert np.abs(amp - want).max() < 1e-13
+    if D == 2:                                                   # ... and the oracle's 6-qubit state-vector pass of the circuit itself
+        for b in (0, 7, 11):
+            assert abs(amp[b] - O.overlap_circuit_amplitude(A[0], Bt[b], WW, q[b] / np.linalg.norm(q[b]))) < 1e-13
+    eng.overlap_set(A, WW)                                       # one reference per candidate, a window in the middle
+    eng.set_window(8)
+    amp = eng.overlap_amplitudes(q[8:20])
+    eng.set_window(0)
+    assert np.abs(amp - np.array([rayleigh(A[b], Bt[b], q[b]) for b in range(8, 20)])).max() < 1e-13
+    eng.overlap_set(A[:6], WW)                                   # trajectory-major groups of 4 candidates
+    eng.overlap_set_group(4)
+    amp = eng.overlap_amplitudes(q)
+    eng.overlap_set_group(0)
+    assert np.abs(amp - np.array([rayleigh(A[b // 4], Bt[b], q[b]) for b in range(n)])).max() < 1e-13
+    # the exact fixed point: eta / 2; the launch's own results are not disturbed by amplitude calls
+    eng.overlap_set(A[0], WW)
+    eng.overlap_launch(n, want_r=True)
+    eta, _, st, r = eng.overlap_results(n, want_r=True)
+    amp = eng.overlap_amplitudes(r)
+    eta2, _, _, r2 = eng.overlap_results(n, want_r=True)
+    assert np.all(st == 0) and np.abs(amp - eta / 2).max() < 1e-11
+    assert np.array_equal(eta, eta2) and np.array_equal(r, r2)
+    with pytest.raises(ValueError):
+        eng.overlap_amplitudes(q[:, :1])
+    from qmps_amd import _lib as L
+    with pytest.raises(L.QmpsError):
+        eng.overlap_amplitudes(np.concatenate([q] * 200)[:4097])      # beyond the context's capacity

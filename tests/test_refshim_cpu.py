@@ -279,3 +279,47 @@ def test_device_source_of_the_update_rule_takes_scipys_recorded_decisions(g):
         better += f(k, out[1, k]) < f(k, out[0, k]) - 1e-6
     assert 20 < better < len(fits) // 4
     assert np.abs(out).max() <= np.pi
+
+
+def test_variational_overlap_route_run_by_the_reference(g):
+    """`get_overlap`'s objective closure (qmps/time_evolve_tools.py:98-128) and `obj_state` (qmps/new_time_evolve.py:223-247) executed by
+    the reference: the circuit amplitude for a GIVEN environment is the Rayleigh form of the mixed transfer map,
+    psi[0] = <r^, T(r^)>_F / 2 on 6 qubits (Bell pair) and / sqrt(2) on 5 (StateGate) - what `qmps_overlap_amplitude` computes."""
+    def rayleigh(A, Bt, WW, r):
+        C = np.tensordot(WW, O.merge(A, A), [1, 0])
+        Bm = O.merge(Bt, Bt)
+        rh = r / np.linalg.norm(r)
+        return np.vdot(rh, sum(C[s] @ rh @ Bm[s].conj().T for s in range(4)))
+    for k in range(3):
+        A = O.unitary_to_tensor(O.shallow_full_unitary(g['varenv_p1'][k]))
+        Bt = O.unitary_to_tensor(O.shallow_full_unitary(g['varenv_p2'][k]))
+        for rs, f_ref in zip(g['varenv_probe_rs'][k], g['refshim_get_overlap_obj'][k]):
+            r = (rs[:4] + 1j * rs[4:]).reshape(2, 2)
+            assert abs(-abs(rayleigh(A, Bt, np.eye(4), r)) - f_ref) < 1e-12
+            assert abs(-2 * abs(O.overlap_circuit_amplitude(A, Bt, np.eye(4), r / np.linalg.norm(r))) - f_ref) < 1e-12
+        # the Nelder-Mead minimum the reference returns is a LOCAL estimate of the map's numerical radius: bounded by its largest
+        # singular value (and, being local, not always beyond |eta|: -0.478 against |eta| = 0.583 in the first case)
+        smax = np.linalg.svd(O.transfer_matrix(np.tensordot(np.eye(4), O.merge(A, A), [1, 0]), O.merge(Bt, Bt)), compute_uv=False)[0]
+        assert -smax - 1e-12 < g['refshim_get_overlap_min'][k] <= g['refshim_get_overlap_obj'][k].min() + 1e-12
+        # obj_state: psi[0] of the 5-qubit register
+        p_ = g['obj_state_p'][k]
+        WW = g['WW_nte'] if k else np.eye(4)
+        r = O.state_gate_unitary(p_[15:])[:, 0].reshape(2, 2)
+        assert abs(rayleigh(A, Bt, WW, r) / np.sqrt(2) - g['refshim_obj_state_psi'][k][0]) < 1e-12
+        assert abs(np.linalg.norm(g['refshim_obj_state_psi'][k]) - 1) < 1e-12
+
+
+def test_host_obj_state_is_the_reference_register(g):
+    """`qmps_amd.new_time_evolve.obj_state` (host state-vector pass over the package's gate objects) against the register the reference's
+    own function returned.  Entries 0..15 read rows 0, 1 of L = put_env_on_right_site(r^+) (fixed by r); entries 16..31 read its
+    null_space() completion rows, the same scipy routine on both sides."""
+    from qmps_amd import new_time_evolve as N
+    from qmps_amd.tools import unitary_to_tensor
+    from qmps_amd.represent import unitary
+    for k in range(3):
+        A = unitary_to_tensor(unitary(N.gate(g['varenv_p1'][k])))
+        psi = N.obj_state(g['obj_state_p'][k], A, g['WW_nte'] if k else np.eye(4))
+        assert psi.shape == (32,)
+        assert np.abs(psi[:16] - g['refshim_obj_state_psi'][k][:16]).max() < 1e-12
+        assert abs(np.linalg.norm(psi[16:]) - np.linalg.norm(g['refshim_obj_state_psi'][k][16:])) < 1e-12
+        assert abs(np.vdot(psi, N.obj_H() @ psi).real + abs(g['refshim_obj_state_psi'][k][0]) ** 2) < 1e-12

@@ -155,3 +155,26 @@ def test_device_update_rule_takes_scipys_recorded_decisions(g, engine_factory):
     es_glob, _ = eng.double_rotosolve(0, x0, 2, rule=L.ROTO_GLOBAL_ARGMIN)
     es_ref, _ = eng.double_rotosolve(0, x0, 2)
     assert np.isfinite(es_glob).all() and np.abs(es_ref - E_ref).max() < 1e-8
+
+
+def test_variational_overlap_route_matches_the_reference_run(g):
+    """`get_overlap` (qmps/time_evolve_tools.py:95-131) and `obj_state` (qmps/new_time_evolve.py:223-247) through the drop-in modules:
+    the objective closure at the recorded environments to 1e-12, the Nelder-Mead minimum the reference returned (same scipy simplex
+    on the device objective) to 1e-7, psi[0] of the 5-qubit register to 1e-12."""
+    from qmps_amd import new_time_evolve as N
+    from qmps_amd import time_evolve_tools as T
+    from qmps_amd.represent import unitary
+    from qmps_amd.tools import unitary_to_tensor
+    for k in range(3):
+        A = unitary_to_tensor(unitary(T.gate(g['varenv_p1'][k])))
+        Bt = unitary_to_tensor(unitary(T.gate(g['varenv_p2'][k])))
+        rs = g['varenv_probe_rs'][k]
+        q = (rs[:, :4] + 1j * rs[:, 4:]).reshape(-1, 2, 2)
+        amp = T.overlap_amplitudes(A, np.repeat(Bt[None], len(q), 0), np.eye(4), q)
+        assert np.abs(-2 * np.abs(amp) - g['refshim_get_overlap_obj'][k]).max() < 1e-12
+        f = T.get_overlap(g['varenv_p1'][k], g['varenv_p2'][k], initial=g['varenv_initial'][k].copy(), options={'disp': False})
+        assert abs(f - g['refshim_get_overlap_min'][k]) < 1e-7, (k, f, g['refshim_get_overlap_min'][k])
+        WW = g['WW_nte'] if k else np.eye(4)
+        a5 = N.obj_state_amplitudes(g['obj_state_p'][k], A, WW)
+        assert abs(a5[0] - g['refshim_obj_state_psi'][k][0]) < 1e-12
+        assert abs(N.obj_state(g['obj_state_p'][k], A, WW)[0] - a5[0]) < 1e-12

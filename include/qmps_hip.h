@@ -67,6 +67,9 @@ extern "C" {
  * continue with the power method applied 2^m steps at a time, P_m = T^(2^m) obtained by squaring the
  * D^2 x D^2 transfer matrix, r_m = herm(P_m r)/tr, until ||r_m - r_{m-1}||_F < tol.  Same fixed
  * point, same tolerance; `iters` reports the equivalent number of power steps handoff + 2^m.
+ * D = 2 (ABI 6.3): when max_iter ends the chain (handoff + 2^(m+1) > max_iter) one plain step decides about the last iterate -
+ * ||herm(T r_m)/tr - r_m||_F < tol accepts it with iters = handoff + 2^m + 1 - so that max_iter = 10 000 no longer means
+ * "converged within 4 096 steps" there (D = 4 continues in steps of 2^m and never had that gap).
  * This is the default of the one-shot entry points. */
 #define QMPS_ENV_POWER_SQUARING 1
 /* DIRECT fixed-point solve (D = 2, 4 and 8; D = 16 runs QMPS_ENV_POWER_SQUARING): what the reference itself
@@ -162,7 +165,8 @@ int qmps_abi_version(void);
  *      qmps_evolve_opts_init / qmps_evolve_bfgs_opts / qmps_evolve_bfgs_device_opts (versioned option structs).
  * 6.2: qmps_evolve_bfgs_device accepts D = 16 (it refused anything but D = 2, 4 before); fixed-point solves of the overlap path: generic
  *      cold start, eta = 0 for nilpotent maps, the Gelfand route of the Krylov certificate (same signatures, see qmps_overlap_batch).
- * 6.3: qmps_overlap_amplitude (the overlap circuit's amplitude for given environments: the reference's variational route). */
+ * 6.3: qmps_overlap_amplitude (the overlap circuit's amplitude for given environments: the reference's variational route); the D = 2
+ *      squaring chain of QMPS_ENV_POWER_SQUARING decides about its last iterate with one plain step when max_iter ends it. */
 int qmps_abi_minor(void);
 const char* qmps_last_error(void);
 /* Test hook for the contract above ("nothing throws across the ABI"): raises a C++ exception inside the library - kind 1

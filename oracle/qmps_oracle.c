@@ -172,6 +172,28 @@ static int squaring_tail(int D, const cplx* A, cplx* r, int done, int max_iter, 
     it = done + (1 << m);
     if (d2 < tol2) { *st = 0; return it; }
   }
+  /* the budget ran out between two powers of two (max_iter = 10 000: the last comparison is r_8192 against r_4096): the plain method's own
+   * test on the last iterate, one application of T itself - accepted with one more iteration (round 5, as squaring_tail_d2 of the kernel) */
+  if ((long)it + 1 <= max_iter) {
+    cplx X[256], T[256];
+    for (int e = 0; e < n; ++e) { rn[e].re = 0; rn[e].im = 0; }
+    for (int s = 0; s < 2; ++s) {
+      matmul(D, A + s * n, r, X);
+      matmul_h(D, X, A + s * n, T);
+      for (int e = 0; e < n; ++e) rn[e] = cadd(rn[e], T[e]);
+    }
+    herm_normalise(D, rn);
+    double d2 = 0;
+    for (int e = 0; e < n; ++e) {
+      double dr = rn[e].re - r[e].re, di = rn[e].im - r[e].im;
+      d2 += dr * dr + di * di;
+    }
+    if (d2 < tol2) {
+      memcpy(r, rn, sizeof(cplx) * n);
+      *st = 0;
+      return it + 1;
+    }
+  }
   *st = 1;
   return it;
 }

@@ -319,6 +319,8 @@ def env_power_iteration(A, r0=None, tol=1e-13, max_iter=10000, handoff=None, ski
     PowerCircuit are T^K; squaring reaches K = 2^m in m products) - r_m = herm(P_m r_C)/tr,
     stopping when ||r_m - r_{m-1}||_F^2 < tol^2 (r_0 := r_C); iterations = handoff + 2^m.
     skip > 0: the first `skip` squarings are not tracked; the comparison chain starts at r_skip.
+    When the budget ends the chain (the next power of two would pass max_iter) one plain step decides: ||herm(T r)/tr - r||_F < tol
+    accepts r' with iterations + 1 (round 5: max_iter = 10 000 used to mean 'converged within 4 096 steps' on this path).
     period > 0 (the D = 4 kernel): after the `skip` squarings the power method continues with
     P_m itself - r <- herm(P_m r)/tr, one product = 2^m power steps, stop when ||r' - r||_F^2 < tol^2 -
     and P_m is squared once more after every `period` unconverged products; iterations = power steps
@@ -392,6 +394,13 @@ def env_power_iteration(A, r0=None, tol=1e-13, max_iter=10000, handoff=None, ski
         it = plain + 2 ** m
         if d2 < tol * tol:
             return r, it, 0
+    # the budget ran out between two powers of two: the plain method's own test on the last iterate (one application of T itself)
+    if it + 1 <= max_iter:
+        rn = apply_transfer(A, r)
+        rn = (rn + rn.conj().T) / 2
+        rn = rn / np.trace(rn).real
+        if float((np.abs(rn - r) ** 2).sum()) < tol * tol:
+            return rn, it + 1, 0
     return r, it, 1
 
 

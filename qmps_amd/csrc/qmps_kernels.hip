@@ -530,6 +530,34 @@ __device__ __forceinline__ void squaring_tail_d2(const double (&are)[2][2][2], c
       }
     }
   }
+  // The budget ran out between two powers of two (max_iter = 10 000: the chain's last comparison is z_8192 against z_4096, so an
+  // evaluation the plain method finishes in 4 097 .. 10 000 steps used to end with status 1 although z_8192 IS its fixed point): the plain
+  // method's own test on the last iterate, one application of T itself - || T z / tr - z || < tol - at the cost of one more iteration.
+  const int taken = m > 0 ? (1 << m) : 0;
+  if (__any(active) && done + taken + 1 <= max_iter) {
+    double d2 = 0.0, y[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v = dfma(real_transfer_entry<2>(getA, a, k), xp[k], v);
+      y[a] = v;
+    }
+    const double inv = 1.0 / (y[0] + y[1]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      y[a] *= inv;
+      const double d = y[a] - xp[a];
+      d2 = dfma(d, d, d2);
+    }
+    if (active && d2 < tol2) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xp[a] = y[a];
+      iters = done + taken + 1;
+      status = QMPS_ST_OK;
+      active = false;
+    }
+  }
   unpack_herm<2>(xp, rre, rim);
 }
 

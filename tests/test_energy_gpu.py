@@ -347,3 +347,43 @@ def test_warm_start_without_a_stored_environment_is_a_cold_start(D, solver):
     assert np.abs(E1[ok] - Er[ok]).max() < 1e-10
     eng.close()
     ref.close()
+
+
+def test_d2_squaring_chain_decides_at_the_end_of_its_budget(engine_factory):
+    """D = 2 'squaring': the chain compares z_{2^m} with z_{2^(m-1)}, so under max_iter = 10 000 its last comparison is z_8192 against
+    z_4096 and an evaluation the plain method finishes in 4 097 .. 10 000 steps used to end with status 1 although z_8192 IS its fixed
+    point (found by the randomised stress of round 5).  Now one plain step on the last iterate decides (iterations 2^m + 1).
+    Amplitude-damping channels in a random basis, decay rate gamma: the plain method needs ~30 / gamma steps."""
+    rng = np.random.default_rng(77)
+
+    def damp(gamma):
+        W = O.haar_unitaries(rng, 2, 1)[0]
+        K0 = np.diag([1, np.sqrt(1 - gamma)]).astype(complex)
+        K1 = np.zeros((2, 2), complex)
+        K1[0, 1] = np.sqrt(gamma)
+        th = gamma / 2                  # a rotation in front of the damping: the fixed point is mixed (smallest eigenvalue ~0.13), not |0><0|
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]], dtype=complex)
+        return np.stack([W @ K0 @ R @ W.conj().T, W @ K1 @ R @ W.conj().T])
+
+    h = O.hamiltonian_matrix({'ZZ': -1.0, 'X': 1.0})
+    eng = engine_factory(2)
+    for solver, gammas in (('squaring0', [0.008, 0.007, 0.006]), ('squaring', [0.006, 0.005, 0.004])):
+        select(eng, solver)
+        ho = oracle_handoff(2, solver)
+        A = np.stack([damp(gm) for gm in gammas] + [O.unitary_to_tensor(u) for u in O.haar_unitaries(rng, 4, 5)])
+        E, it, st = eng.energies(A, h)
+        r = eng.environments()
+        ref = [O.env_power_iteration(a, handoff=ho, skip=SKIP0[2] if ho == 0 else 0) for a in A]
+        assert np.all(st == 0), (solver, st, it)
+        assert np.array_equal(it, [x[1] for x in ref]), (solver, it, [x[1] for x in ref])
+        assert np.all(it[:len(gammas)] == ho + 8192 + 1)
+        for b, a in enumerate(A):
+            r_eig = O.env_dense_eig(a)[1]
+            assert np.abs(r[b] - r_eig).max() < 1e-9
+            assert np.abs(r[b] - ref[b][0]).max() < 1e-12
+            assert abs(E[b, 0] - O.energy_closed_form(a, h, r_eig)) < 1e-9
+    # a budget the chain cannot use: max_iter = 5 (skip schedule: 2^3 > 5) - the single plain step does not accept an unconverged iterate
+    select(eng, 'squaring0')
+    E, it, st = eng.energies(A[:3], h, max_iter=5)
+    assert np.all(st == 1)
+    eng.set_solver('direct')

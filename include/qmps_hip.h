@@ -112,6 +112,14 @@ extern "C" {
  * matrix build and the elimination altogether (iterations = 1; ~7 instead of 15 kflop); the others are solved as usual
  * (iterations = 2: the rejected step + the solve's acceptance step).  The iterative solvers start their iteration from it. */
 #define QMPS_FLAG_WARM_RESIDENT 0x400
+/* D = 8 (ABI 6.3; ignored elsewhere - D = 2, 4 square, D = 16 always hands over): evaluations whose power iteration - the whole solve under
+ * QMPS_ENV_POWER_SQUARING, the fall-back behind a direct solve that was not accepted (the elimination does not pivot: structural zeros at
+ * special angles of the ansatz) under QMPS_ENV_DIRECT - predicts more than 256 further steps are finished by the thick-restart Arnoldi kernel
+ * on the environment map and accepted by a finishing pass of the energy kernel (its own test, Cholesky test, energies, cost accumulation),
+ * as D = 16 does: a few hundred map applications where the power method needs 30 / (1 - |lambda_2|).  Not with QMPS_ENV_POWER (the plain
+ * iteration stays plain), not with max_iter <= 64.  Costs two nearly-empty launches (~3 us) per call: the one-shot entry points
+ * (qmps_energy_batch*, qmps_env_batch) set it, qmps_energy_launch leaves it to the caller. */
+#define QMPS_FLAG_KRYLOV_FALLBACK 0x800
 /* With handoff == 0 (squaring from the start) the iterate is not tracked during the first
  * QMPS_SKIP_ROUNDS_D* squarings (no state converges in fewer than 2^skip power steps); the first
  * convergence test compares T^(2^(skip+1)) r_0 with T^(2^skip) r_0. */
@@ -166,7 +174,8 @@ int qmps_abi_version(void);
  * 6.2: qmps_evolve_bfgs_device accepts D = 16 (it refused anything but D = 2, 4 before); fixed-point solves of the overlap path: generic
  *      cold start, eta = 0 for nilpotent maps, the Gelfand route of the Krylov certificate (same signatures, see qmps_overlap_batch).
  * 6.3: qmps_overlap_amplitude (the overlap circuit's amplitude for given environments: the reference's variational route); the D = 2
- *      squaring chain of QMPS_ENV_POWER_SQUARING decides about its last iterate with one plain step when max_iter ends it. */
+ *      squaring chain of QMPS_ENV_POWER_SQUARING decides about its last iterate with one plain step when max_iter ends it;
+ *      QMPS_FLAG_KRYLOV_FALLBACK (D = 8 environment solves hand long tails to the Arnoldi kernel, as D = 16 always did). */
 int qmps_abi_minor(void);
 const char* qmps_last_error(void);
 /* Test hook for the contract above ("nothing throws across the ABI"): raises a C++ exception inside the library - kind 1

@@ -24,6 +24,7 @@ ENV_DIRECT = 2
 FLAG_NO_ENV_OUT = 0x100
 FLAG_ACCUMULATE_COST = 0x200
 FLAG_WARM_RESIDENT = 0x400
+FLAG_KRYLOV_FALLBACK = 0x800
 OVERLAP_WANT_R, OVERLAP_WARM, OVERLAP_TWO_SIDED_F = 1, 2, 4
 BFGS_CARRY_HESSIAN, BFGS_WARM, BFGS_TIGHT_GRADIENT, BFGS_ADAPTIVE_GRADIENT, BFGS_TIME_STEPS = 1, 2, 4, 8, 16
 ROTO_REFERENCE, ROTO_GLOBAL_ARGMIN = 0, 1

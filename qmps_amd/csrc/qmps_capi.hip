@@ -502,7 +502,7 @@ int qmps_energy_batch_su(qmps_ctx* c, int64_t B, const double* params, const dou
     Restore<bool> deferred(c->defer_sync, true);
     rc = qmps_set_states_su(c, B, params);
     if (!rc) rc = qmps_set_hamiltonian(c, n_terms, h);
-    if (!rc) rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver);
+    if (!rc) rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver | QMPS_FLAG_KRYLOV_FALLBACK);
   }
   if (rc) {
     (void)hipStreamSynchronize(c->stream);
@@ -825,7 +825,7 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
   int solver = flags & 0xff;
   if (solver != QMPS_ENV_POWER && solver != QMPS_ENV_POWER_SQUARING && solver != QMPS_ENV_DIRECT)
     return fail(QMPS_ERR_ARG, "unknown environment solver %d", solver);
-  if ((flags & ~0xff) & ~(QMPS_FLAG_NO_ENV_OUT | QMPS_FLAG_ACCUMULATE_COST | QMPS_FLAG_WARM_RESIDENT)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags & ~0xff);
+  if ((flags & ~0xff) & ~(QMPS_FLAG_NO_ENV_OUT | QMPS_FLAG_ACCUMULATE_COST | QMPS_FLAG_WARM_RESIDENT | QMPS_FLAG_KRYLOV_FALLBACK)) return fail(QMPS_ERR_ARG, "unknown flag bits 0x%x", flags & ~0xff);
   const bool warm_resident = (flags & QMPS_FLAG_WARM_RESIDENT) != 0;
   if (warm_resident && !c->have_env) return fail(QMPS_ERR_STATE, "QMPS_FLAG_WARM_RESIDENT: no resident environments (run a launch that stores them, or qmps_set_env_guess)");
   const bool direct = solver == QMPS_ENV_DIRECT && c->D == 4;
@@ -923,8 +923,31 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
     if (accumulate) {
       if (int rc = setup_accumulator(c, a, B, c->D <= 4 ? lane_waves : B, c->D <= 4 ? 64 : 1)) return rc;
     } else if (c->D <= 4) { a.partial = c->d_partial; c->partials_B = B; c->partials_n = lane_waves; }
+    // D = 8 (round 5): the power loop behind a direct solve that was not accepted - an elimination without pivoting meets structural zeros at special
+    // angles of the ansatz - is the only fall-back of the energy path whose cost grows with 1 / gap (D = 2, 4 square, D = 16 hands over): evaluations
+    // whose residual history predicts a long tail go to the Arnoldi kernel on the environment map, then through a finishing pass of the block kernel,
+    // exactly as at D = 16.  QMPS_ENV_POWER stays the plain iteration (a-13: the classical statement of PowerCircuit); QMPS_NO_KRYLOV switches it off.
+    // On request only (QMPS_FLAG_KRYLOV_FALLBACK; the one-shot entry points set it): the two extra launches - nearly always empty - cost 3.1 - 3.4 us of a
+    // 16 - 20 us step of resident tensors (B = 96 / 768, measured), nothing next to the round trips of a one-shot call.
+    const bool krylov8 = c->D == 8 && (flags & QMPS_FLAG_KRYLOV_FALLBACK) != 0 && solver != QMPS_ENV_POWER && documented_switch("QMPS_NO_KRYLOV") == nullptr && max_iter > 64 && c->d_queue != nullptr && a.r_out != nullptr;
+    if (krylov8) {
+      a.krylov_after = 256;
+      if (const char* e = tuning_knob("QMPS_KRYLOV_AFTER")) a.krylov_after = atoi(e);
+      a.kry_counter = c->d_queue + 8;
+    }
     if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
     HIP_TRY(qmps::launch_energy(c->D, a, true, c->stream));
+    if (krylov8 && a.krylov_after > 0) {
+      qmps::OverlapArgs k;
+      memset(&k, 0, sizeof(k));
+      k.Bt = a.A; k.r_out = a.r_out; k.iters = a.iters; k.status = a.status; k.B = B; k.max_rounds = max_iter; k.tol = tol;
+      k.env_mode = 1; k.krylov_after = a.krylov_after; k.kry_counter = a.kry_counter;
+      HIP_TRY(qmps::launch_overlap_krylov(8, k, k.kry_counter, c->stream));
+      qmps::LaneArgs f = a;
+      f.r_in = a.r_out; f.only_pending = 1; f.krylov_after = 0; f.acc_zero = nullptr; f.direct = 0;
+      f.max_iter = 64;
+      HIP_TRY(qmps::launch_energy(c->D, f, true, c->stream));
+    }
     if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
   } else if (c->D == 2) {
     a.handoff = c->handoff;  // the squaring tail runs in-lane (real 4 x 4 transfer matrix in registers)
@@ -1171,7 +1194,7 @@ int qmps_energy_batch(qmps_ctx* c, int64_t B, const double* states, int kind, co
   if (int rc = qmps_set_states(c, B, states, kind)) return rc;
   if (int rc = qmps_set_hamiltonian(c, n_terms, h)) return rc;
   if (int rc = qmps_set_env_guess(c, B, r0)) return rc;
-  if (int rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver)) return rc;
+  if (int rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver | QMPS_FLAG_KRYLOV_FALLBACK)) return rc;
   return qmps_get_energies(c, B, E_out, iters_out, status_out);
 }
 QMPS_API_CATCH
@@ -1187,7 +1210,7 @@ int qmps_energy_batch_ansatz(qmps_ctx* c, int64_t B, int ansatz_kind, int n_para
     Restore<bool> deferred(c->defer_sync, true);
     rc = qmps_set_states_ansatz(c, B, ansatz_kind, n_params, params);
     if (!rc) rc = qmps_set_hamiltonian(c, n_terms, h);
-    if (!rc) rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver | ((c->D == 4 && c->default_solver == QMPS_ENV_DIRECT) ? QMPS_FLAG_NO_ENV_OUT : 0));
+    if (!rc) rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver | QMPS_FLAG_KRYLOV_FALLBACK | ((c->D == 4 && c->default_solver == QMPS_ENV_DIRECT) ? QMPS_FLAG_NO_ENV_OUT : 0));
   }
   if (rc) {
     (void)hipStreamSynchronize(c->stream);
@@ -1208,7 +1231,7 @@ int qmps_env_batch(qmps_ctx* c, int64_t B, const double* states, int kind, const
     if (int rc = qmps_set_hamiltonian(c, 1, zero)) return rc;
   }
   if (int rc = qmps_set_env_guess(c, B, r0)) return rc;
-  if (int rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver)) return rc;
+  if (int rc = qmps_energy_launch(c, B, max_iter, tol, c->default_solver | QMPS_FLAG_KRYLOV_FALLBACK)) return rc;
   if (int rc = qmps_get_energies(c, B, nullptr, iters_out, status_out)) return rc;
   return qmps_get_env(c, B, r_out);
 }

@@ -48,6 +48,20 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
   const int64_t b = blockIdx.x;
   if (b >= p.B) return;
   if (p.acc_zero != nullptr && blockIdx.x == 0) acc_clear(p.acc_zero, p.n_terms, tid, N);   // accumulator of a later step
+  // Finishing pass behind the Krylov fall-back (D = 8, round 5; the protocol of energy_mfma_d16_kernel): only evaluations the fall-back solved
+  // (status PENDING, fixed point in r_in); every workgroup that finds work pending takes an exit ticket, the last one clears the counters.
+  int iters0 = 0;
+  if (SOLVE && p.only_pending) {
+    if (__hip_atomic_load(p.kry_counter + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;      // nothing to finish
+    if (p.status[b] != QMPS_ST_PENDING) {
+      if (tid == 0 && atomicAdd(p.kry_counter + 4, 1) == (int)gridDim.x - 1) {
+        __hip_atomic_store(p.kry_counter + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.kry_counter + 4, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    iters0 = p.iters[b];
+  }
 
   {
     const double2* a = (const double2*)p.A + b * (2 * N);
@@ -141,6 +155,8 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
   if (SOLVE) {
     status = QMPS_ST_NOT_CONVERGED;
     const double tol2 = p.tol * p.tol;
+    int k_ref = 0;
+    float l_ref = 0.0f;
     for (int k = 1; k <= p.max_iter; ++k) {
       double2 n;
       apply(n);
@@ -163,8 +179,15 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
         status = QMPS_ST_OK;
         break;
       }
+      // a long tail ahead (|lambda_2| close to 1 and no accepted direct solve): hand the evaluation to the Krylov fall-back
+      // (status PENDING, iterate in r_out) - d2 is uniform over the workgroup
+      if (k < p.max_iter && p.kry_counter != nullptr && power_gives_up(k, d2, tol2, p.krylov_after, k_ref, l_ref)) {
+        status = QMPS_ST_PENDING;
+        break;
+      }
     }
   }
+  const bool given = SOLVE && status == QMPS_ST_PENDING;
   if (!SOLVE && p.check_pd) status = p.status[b];
   if (SOLVE || p.check_pd) {
     if (status == QMPS_ST_OK) {
@@ -276,19 +299,20 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
         e = dfma(-hv.y, rho_loc[t][s].y, e);
       }
     if (p.rho_out == nullptr) e = block_sum<D>(e, red, tid) * inv_tr;
-    if (tid == 0) {
+    if (tid == 0 && !given) {      // (a handed-over evaluation: energy and arrival at the accumulator come from the finishing pass)
       p.E[b * p.n_terms + q] = e;
       if (p.acc != nullptr) acc_arrive(p.acc, p.acc_shards, q, (unsigned)b, e, p.acc_bound, p.acc_scale);   // exact in-kernel cost
     }
   }
   if (tid == 0) {
     if (SOLVE) {
-      p.iters[b] = iters;
+      p.iters[b] = iters0 + iters;
       p.status[b] = status;
+      if (given) atomicAdd(p.kry_counter + 2, 1);
     } else if (p.check_pd) {
       p.status[b] = status;
     }
-    if (p.rho_out != nullptr) {
+    if (p.rho_out != nullptr && !given) {
       double2* o = (double2*)p.rho_out + b * 16;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -297,6 +321,12 @@ __global__ __launch_bounds__(D* D) void energy_block_kernel(LaneArgs p) {
     }
   }
   if (p.r_out != nullptr && SOLVE) ((double2*)p.r_out)[b * N + tid] = r;
+  if (SOLVE && p.only_pending) {       // exit ticket of a finishing pass (see the top of the kernel)
+    if (tid == 0 && atomicAdd(p.kry_counter + 4, 1) == (int)gridDim.x - 1) {
+      __hip_atomic_store(p.kry_counter + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.kry_counter + 4, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 template <int D>

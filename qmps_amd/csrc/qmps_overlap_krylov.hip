@@ -355,7 +355,7 @@ __device__ __forceinline__ void overlap_krylov_body(const OverlapArgs& p, int* c
       if (overlap_skipped(p, b)) continue;
       tol2 = overlap_tol2(p, b);
       const int used = p.iters[b];
-      const bool env = D == 16 && p.env_mode != 0;
+      const bool env = p.env_mode != 0;
       if (p.status[b] != (env ? QMPS_ST_PENDING : QMPS_ST_NOT_CONVERGED)) continue;      // (uniform over the workgroup)
       if (env && tid == 0) atomicAdd(counter + 3, 1);       // one more evaluation for the finishing pass of the energy kernel
       if (used + KM + 1 > p.max_rounds) continue;
@@ -446,6 +446,13 @@ __device__ __forceinline__ void overlap_krylov_body(const OverlapArgs& p, int* c
         double2 (*sC)[8][9] = (double2 (*)[8][9])(smem + L::oT);
         double2 (*sB)[8][9] = (double2 (*)[8][9])(smem + L::oT + 4 * 8 * 9 * 16);
         const int i = lane >> 3, j = lane & 7, t1 = wave >> 1, t2 = wave & 1;
+        if (env) {
+          // the environment map r -> sum_{s<2} B_s r B_s^+ (round 5: the D = 8 energy path hands over too): C_w = Bm_w = B_w for w < 2, nothing in waves 2, 3
+          const double2 v = wave < 2 ? Bp[(wave * 8 + i) * 8 + j] : make_double2(0.0, 0.0);
+          sC[wave][i][j] = v;
+          sB[wave][i][j] = v;
+          __syncthreads();
+        } else {
         double2 aa = make_double2(0.0, 0.0), bm = make_double2(0.0, 0.0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -460,6 +467,7 @@ __device__ __forceinline__ void overlap_krylov_body(const OverlapArgs& p, int* c
         for (int t = 0; t < 4; ++t) cfma(W[wave * 4 + t], sP[t * N + lane], cs);
         sC[wave][i][j] = cs;
         __syncthreads();
+        }
       }
 
       // one application of the map to the vector at `x` (LDS, this file's element order): every thread receives ITS element of T x

@@ -147,7 +147,7 @@ class EnergyEngine:
     # -- hot path ---------------------------------------------------------------------------
     _SOLVERS = {'plain': L.ENV_POWER, 'squaring': L.ENV_POWER_SQUARING, 'direct': L.ENV_DIRECT}
 
-    def launch(self, B=None, max_iter=10000, tol=1e-13, solver='direct', store_env=True, accumulate_cost=False, warm_start=False):
+    def launch(self, B=None, max_iter=10000, tol=1e-13, solver='direct', store_env=True, accumulate_cost=False, warm_start=False, krylov_fallback=False):
         """Asynchronous: right environment + energies for the resident batch.
         solver: 'direct' (exact fixed-point solve accepted by one power step; D = 4, other bond dimensions run
         'squaring'), 'squaring' (power iteration 2^m steps at a time) or 'plain' (power iteration).
@@ -155,9 +155,11 @@ class EnergyEngine:
         accumulate_cost=True (same): the kernel also sums the energies (exact fixed-point accumulation); the
         `cost_launch` that must follow then launches no reduction kernel.
         warm_start=True: start from the RESIDENT environments (an earlier launch with store_env, or `set_env_guess`); with
-        'direct' at D = 4 an evaluation whose environment passes the acceptance test as it is skips the solve."""
+        'direct' at D = 4 an evaluation whose environment passes the acceptance test as it is skips the solve.
+        krylov_fallback=True (D = 8; the one-shot calls `energies*` always do): long tails of the power iteration go to the Arnoldi kernel."""
         flag = self._SOLVERS[solver] | (0 if store_env else L.FLAG_NO_ENV_OUT) | (L.FLAG_ACCUMULATE_COST if accumulate_cost else 0)
         flag |= L.FLAG_WARM_RESIDENT if warm_start else 0
+        flag |= L.FLAG_KRYLOV_FALLBACK if krylov_fallback else 0
         L.check(self._lib.qmps_energy_launch(self._ctx, self.B if B is None else B, int(max_iter), float(tol), flag))
 
     def set_solver(self, solver='direct', handoff=None):

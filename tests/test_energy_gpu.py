@@ -387,3 +387,58 @@ def test_d2_squaring_chain_decides_at_the_end_of_its_budget(engine_factory):
     E, it, st = eng.energies(A[:3], h, max_iter=5)
     assert np.all(st == 1)
     eng.set_solver('direct')
+
+
+def test_d8_environment_krylov_fallback(engine_factory, monkeypatch):
+    """D = 8 (round 5): the power loop behind a direct solve that is not accepted - or the whole solve under 'squaring', which is the power method at
+    D = 8 - hands evaluations with a long tail ahead to the Arnoldi kernel on the environment map, as D = 16 does.  Slow tensors
+    (|lambda_2| = 1 - 3e-3 .. 1 - 3e-6): every one finished within a few hundred map applications, energies within 1e-10 of the dense
+    eigen-solve, the in-kernel cost accumulation receives the late arrivals; 'plain' stays the plain iteration (a-13) and QMPS_NO_KRYLOV
+    switches the hand-over off.  And the case the second stress campaign flagged: `ShallowCNOT3` at special angles - the unpivoted elimination
+    meets a structural zero, gap 1.5e-3 - used to end with status 1 after 10 000 steps; its environment has rank 3: status 2, as the
+    reference's Cholesky says."""
+    import overlap_cases as OC
+    rng = np.random.default_rng(80)
+    h = np.stack([O.hamiltonian_matrix({'ZZ': -1, 'X': 1}), O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})])
+    A = np.stack([OC.slow_environment_tensor(rng, 8, t) for t in (0.3, 0.3, 0.1, 0.1, 0.03, 0.03, 0.01, 0.01)]
+                 + list(O.unitary_to_tensor(O.haar_unitaries(rng, 16, 4))))
+    ref = np.array([[O.energy_closed_form(a, hh) for hh in h] for a in A])
+    eng = engine_factory(8, 64)
+    select(eng, 'squaring')
+    E, it, st = eng.energies(A, h, max_iter=3000, tol=1e-13)
+    assert np.all(st == 0), (st, it)
+    assert it.max() <= 1000, it
+    # (a fixed point accepted at ||T r - r|| < 1e-13 is within 1e-13 / gap of the true one: 3e-8 at gap 3e-6 - the energies of the two slowest within 1e-9)
+    assert np.abs(E - ref)[:6].max() < E_TOL and np.abs(E - ref).max() < 1e-9, np.abs(E - ref).max()
+    r = eng.environments()
+    for b in range(len(A)):
+        rr = r[b] / np.trace(r[b])
+        assert np.abs(rr - rr.conj().T).max() < 1e-12 and np.abs(O.apply_transfer(A[b], rr) - rr).max() < 1e-11
+    eng.set_tensors(A)
+    eng.set_hamiltonian(h)
+    eng.launch(len(A), max_iter=3000, solver='squaring')                     # the stepping entry point hands over on request only
+    assert (eng.results(len(A))[2] == 1).sum() >= 4
+    eng.launch(len(A), max_iter=3000, solver='squaring', accumulate_cost=True, krylov_fallback=True)
+    eng.cost_launch(len(A))
+    assert np.abs(eng.get_cost() - ref.sum(axis=0)).max() < 1e-9
+    monkeypatch.setenv('QMPS_NO_KRYLOV', '1')
+    E2, it2, st2 = eng.energies(A, h, max_iter=3000, tol=1e-13)
+    monkeypatch.delenv('QMPS_NO_KRYLOV')
+    assert (st2 == 1).sum() >= 4 and np.all(it2[st2 == 1] == 3000)
+    assert np.abs(E2 - ref)[st2 == 0].max() < 1e-9
+    select(eng, 'plain')
+    E3, it3, st3 = eng.energies(A, h, max_iter=3000, tol=1e-13)
+    assert np.array_equal(st3, st2) and np.array_equal(it3, it2)
+    # the direct solver (default): accepted in one step for all of these
+    eng.set_solver('direct')
+    E4, it4, st4 = eng.energies(A, h, max_iter=3000, tol=1e-13)
+    assert np.all(st4 == 0) and np.all(it4 <= 2) and np.abs(E4 - ref).max() < 1e-9
+    p = np.array([0.06636560584974034, -np.pi / 2, 0.0, np.pi / 2, -np.pi / 2, 0.0, np.pi, np.pi / 2, np.pi])
+    Es, its, sts = eng.energies_from_params(3, p[None], h[:1])
+    a = O.unitary_to_tensor(O.shallow_cnot3_unitary(8, p))
+    lam = np.linalg.eigvalsh(O.env_dense_eig(a)[1])
+    assert lam[0] < 1e-12 < lam[-3]                      # rank 3
+    assert sts[0] == 2 and its[0] < 2000, (sts, its)
+    rr = eng.environments()[0]
+    assert np.abs(O.apply_transfer(a, rr) - rr).max() < 1e-10
+    assert abs(Es[0, 0] - O.energy_closed_form(a, h[0])) < 1e-9

@@ -1,16 +1,22 @@
-mkdir -p gpurun_out/r05k_stress; cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# usage (GPU box): bash tools/r05k_stress_campaign.sh [seed_base=101] [tag=r05k_stress]  -> gpurun_out/<tag>/*.json : one randomised stress run per script
+# (profiles/experiments/r05/stress_*.py: device against the oracle on random inputs, a third at symmetric angles), fresh seeds seed_base .. seed_base + 12
+B=${1:-101}; T=${2:-r05k_stress}
+mkdir -p gpurun_out/$T; cd $GRAFT_REPO_ROOT
 S=profiles/experiments/r05
-run() { name=$1; shift; timeout 420 python3 $S/$name.py "$@" > gpurun_out/r05k_stress/${name}_$2.json 2> gpurun_out/r05k_stress/${name}_$2.err; echo "$name $* rc=$?"; }
-run stress_energy 300 101
-run stress_overlap 300 102
-run stress_evolve 150 103
-run stress_evolve_device 200 104
-run stress_gradient 80 105
-run stress_rotosolve 80 106
-run stress_cell2_optenv 10 107
-run stress_brickwall 20 108
-run stress_api_state 60 109 4
-run stress_api_state 40 110 16
-run stress_api_overlap 40 111 8
-run stress_api_overlap 30 112 2
-run stress_su 10 113
+run() { name=$1; shift; timeout 420 python3 $S/$name.py "$@" > gpurun_out/$T/${name}_$2.json 2> gpurun_out/$T/${name}_$2.err; echo "$name $* rc=$?"; }
+run stress_energy 300 $((B+0))
+run stress_overlap 300 $((B+1))
+run stress_evolve 150 $((B+2))
+run stress_evolve_device 200 $((B+3))
+run stress_gradient 80 $((B+4))
+run stress_rotosolve 80 $((B+5))
+run stress_cell2_optenv 10 $((B+6))
+run stress_brickwall 20 $((B+7))
+run stress_api_state 60 $((B+8)) 4
+run stress_api_state 40 $((B+9)) 16
+run stress_api_overlap 40 $((B+10)) 8
+run stress_api_overlap 30 $((B+11)) 2
+run stress_su 10 $((B+12))
+run stress_api_state 60 $((B+13)) 8
+run stress_api_state 60 $((B+14)) 2

@@ -1,6 +1,7 @@
 """Host-side mirror of the pieces of `qmps/time_evolve_tools.py` the energy path touches.
 
   merge                    qmps/time_evolve_tools.py:20-23   (any D here; the reference hard-codes D = 2)
+  Nsphere                  qmps/time_evolve_tools.py:25-36
   put_env_on_left_site     qmps/time_evolve_tools.py:38-53
   get_env_off_left_site    qmps/time_evolve_tools.py:55-57
   put_env_on_right_site    qmps/time_evolve_tools.py:59-70
@@ -22,6 +23,14 @@ def merge(A, B):
     """-A- -B- -> -AB-: merge(A, B)[2 s1 + s2] = A[s1] @ B[s2]."""
     D = A.shape[1]
     return np.einsum('sij,tjk->stik', A, B).reshape(A.shape[0] * B.shape[0], D, D)
+
+
+def Nsphere(v):
+    """Point on the unit len(v)-sphere from len(v) angles (time_evolve_tools.py:25-36): x_k = sin v_1 .. sin v_(k-1) cos v_k, last entry the
+    product of all sines."""
+    v = np.asarray(v, dtype=float)
+    sines = np.concatenate([[1.0], np.cumprod(np.sin(v))])
+    return np.concatenate([sines[:-1] * np.cos(v), sines[-1:]])
 
 
 def put_env_on_left_site(q, ret_n=False):

@@ -325,6 +325,8 @@ def main():
     for k in range(3):
         A = rtools.unitary_to_tensor(cirq.unitary(rnte.gate(P1[k])))
         psis.append(rnte.obj_state(PS[k].copy(), A, WW_n if k else np.eye(4)))
+    out['nsphere_v'] = rng7.standard_normal((4, 7))
+    out['refshim_nsphere'] = np.stack([rtet.Nsphere(v) for v in out['nsphere_v']])           # time_evolve_tools.py:25-36
     out['obj_state_p'] = PS
     out['refshim_obj_state_psi'] = np.stack(psis)                            # (3, 32); entries 16.. read null_space() completion rows of L
 

@@ -323,3 +323,10 @@ def test_host_obj_state_is_the_reference_register(g):
         assert np.abs(psi[:16] - g['refshim_obj_state_psi'][k][:16]).max() < 1e-12
         assert abs(np.linalg.norm(psi[16:]) - np.linalg.norm(g['refshim_obj_state_psi'][k][16:])) < 1e-12
         assert abs(np.vdot(psi, N.obj_H() @ psi).real + abs(g['refshim_obj_state_psi'][k][0]) ** 2) < 1e-12
+
+
+def test_nsphere_is_the_reference_parametrisation(g):
+    """time_evolve_tools.Nsphere (qmps/time_evolve_tools.py:25-36), run by the reference: points on the unit sphere."""
+    from qmps_amd import time_evolve_tools as T
+    for v, x in zip(g['nsphere_v'], g['refshim_nsphere']):
+        assert np.abs(T.Nsphere(v) - x).max() < 1e-14 and abs(np.linalg.norm(x) - 1) < 1e-14

@@ -361,6 +361,68 @@ def state_gate(v, symbol='R'):
     return StateGate(v, symbol)
 
 
+def run_tests(N, rng=None):
+    """The reference's in-file assertion suite (new_time_evolve.py:50-184) through this package: random left-canonical tensors A, B; the right
+    fixed point r and the left fixed point l of `Map(A, B)` FROM THE DEVICE (`qmps_overlap_batch`: l is the right fixed point of the map of
+    the daggered tensors, eigenvalue conj(x) - the convention the reference's own asserts pin: tests/golden/cirq_shim.py:_dominant); the
+    circuits on the host's gate objects.  Raises AssertionError on the first identity that fails:
+        embeddings round-trip and are unitary;  2 psi[0] = tr(g r), x tr(g r), x^2 tr(g r);  = tr(g l*), x tr(g l*), x^2 tr(g l*);
+        the 6-qubit overlap circuit: 2 psi[0] = x^2 tr(l^+ r)."""
+    from .represent import CNOT, H, Environment, MatrixGate, final_state, line_qubits
+    from .time_evolve_tools import (get_env_off_left_site, get_env_off_right_site, overlap_of_tensors, put_env_on_left_site,
+                                    put_env_on_right_site)
+    from .tools import tensor_to_unitary
+    rng = np.random.default_rng() if rng is None else rng
+    paulis = [np.eye(2, dtype=complex), np.array([[0, 1], [1, 0]], dtype=complex), np.array([[0, -1j], [1j, 0]]), np.diag([1.0 + 0j, -1.0])]
+
+    def random_tensor():
+        z = rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4))
+        return unitary_to_tensor(np.linalg.qr(z)[0])
+
+    def fixed_points(A, B):
+        _, r = overlap_of_tensors(A, B, want_r=True)
+        Ad, Bd = A.conj().transpose(0, 2, 1), B.conj().transpose(0, 2, 1)
+        _, l = overlap_of_tensors(Ad, Bd, want_r=True)
+        x = np.vdot(r, sum(A[s] @ r @ B[s].conj().T for s in range(2)))         # Rayleigh quotient: the eigenvalue with its phase
+        assert np.abs(sum(A[s] @ r @ B[s].conj().T for s in range(2)) - x * r).max() < 1e-10
+        assert np.abs(sum(Ad[s] @ l @ Bd[s].conj().T for s in range(2)) - np.conj(x) * l).max() < 1e-10
+        return x, r, l
+
+    def amp(ops, n):
+        return 2 * final_state(ops, n)[0]
+
+    for _ in range(N):
+        q = rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2))
+        for put, off in ((put_env_on_left_site, get_env_off_left_site), (put_env_on_right_site, get_env_off_right_site)):
+            E, n = put(q, ret_n=True)
+            assert np.allclose(off(E * n), q) and np.allclose(E.conj().T @ E, np.eye(4))
+        A, B = random_tensor(), random_tensor()
+        x, r, l = fixed_points(A, B)
+        U, U_ = Environment(tensor_to_unitary(A), 'U'), Environment(tensor_to_unitary(B), "U'")
+        R = Environment(put_env_on_left_site(r), 'R')
+        Lg = Environment(put_env_on_right_site(l.conj().T), 'L')
+        for g in paulis:
+            G = MatrixGate(g)
+            qb = line_qubits(4)
+            assert abs(amp([H(qb[1]), CNOT(*qb[1:3]), R(*qb[2:]), G(qb[1]), CNOT(*qb[1:3]), H(qb[1])], 4) - np.trace(g @ r)) < 1e-9
+            assert abs(amp([H(qb[1]), CNOT(*qb[1:3]), U(*qb[0:2]), R(*qb[2:]), G(qb[0]), (U_ ** -1)(*qb[0:2]), CNOT(*qb[1:3]), H(qb[1])], 4)
+                       - x * np.trace(g @ r)) < 1e-9
+            qb = line_qubits(5)
+            assert abs(amp([H(qb[2]), CNOT(*qb[2:4]), U(*qb[1:3]), U(*qb[0:2]), R(*qb[3:]), G(qb[0]), (U_ ** -1)(*qb[0:2]), (U_ ** -1)(*qb[1:3]),
+                            CNOT(*qb[2:4]), H(qb[2])], 5) - x ** 2 * np.trace(g @ r)) < 1e-9
+            qb = line_qubits(3)
+            assert abs(amp([H(qb[1]), CNOT(*qb[1:3]), Lg(*qb[:2]), G(qb[2]), CNOT(*qb[1:3]), H(qb[1])], 3) - np.trace(g @ l.conj())) < 1e-9
+            qb = line_qubits(4)
+            assert abs(amp([H(qb[2]), CNOT(*qb[2:4]), U(*qb[1:3]), Lg(*qb[:2]), G(qb[3]), (U_ ** -1)(*qb[1:3]), CNOT(*qb[2:4]), H(qb[2])], 4)
+                       - x * np.trace(g @ l.conj())) < 1e-9
+            qb = line_qubits(5)
+            assert abs(amp([H(qb[3]), CNOT(*qb[3:5]), U(*qb[2:4]), U(*qb[1:3]), Lg(*qb[0:2]), G(qb[4]), (U_ ** -1)(*qb[1:3]), (U_ ** -1)(*qb[2:4]),
+                            CNOT(*qb[3:5]), H(qb[3])], 5) - x ** 2 * np.trace(g @ l.conj())) < 1e-9
+        qb = line_qubits(6)
+        assert abs(amp([H(qb[3]), CNOT(*qb[3:5]), U(*qb[2:4]), U(*qb[1:3]), Lg(*qb[0:2]), R(*qb[4:]), (U_ ** -1)(*qb[1:3]), (U_ ** -1)(*qb[2:4]),
+                        CNOT(*qb[3:5]), H(qb[3])], 6) - x ** 2 * np.trace(l.conj().T @ r)) < 1e-9
+
+
 def obj_state(p_, A, WW):
     """new_time_evolve.py:223-247: the 5-qubit register after R = StateGate(p_[15:]) on qubits (3,4), U U W, L on (0,1), U'^+ U'^+,
     CNOT, H - the state function the reference's rotosolve variant pairs with `obj_H` (energy = -|psi[0]|^2).  Host state-vector

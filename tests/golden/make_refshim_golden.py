@@ -330,6 +330,33 @@ def main():
     out['obj_state_p'] = PS
     out['refshim_obj_state_psi'] = np.stack(psis)                            # (3, 32); entries 16.. read null_space() completion rows of L
 
+    # ---------------------------------------------------------------------------------------------------------
+    # (8) the reference's OWN in-file assertion suite, executed over the stand-ins: qmps/new_time_evolve.py:run_tests (:50-184)
+    #     - embeddings round trips, unitarity, and the circuit identities 2 psi[0] = tr(g r), x tr(g r),
+    #     x^2 tr(g r), tr(g l*), x tr(g l*), x^2 tr(g l*), x^2 tr(l^+ r) for random left-canonical tensors.  They passed on the authors'
+    #     cirq / xmps; that they pass HERE pins what the stand-ins had only documented: simulator endianness, H / CNOT / Pauli matrices,
+    #     the right AND left fixed-point conventions of `Map` (the left one was wrong until this section existed: cirq_shim._dominant).
+    #     Two numpy-1.x idioms of the 2019 code are bridged: np.prod((matrix, scalar)) multiplied them; nothing else is touched.
+    # ---------------------------------------------------------------------------------------------------------
+    class Numpy1x:
+        def __getattr__(self, k):
+            return getattr(np, k)
+
+        @staticmethod
+        def prod(a, *args, **kw):
+            if isinstance(a, tuple) and len(a) == 2 and np.ndim(a[0]) == 2 and np.ndim(a[1]) == 0:
+                return a[0] * a[1]
+            return np.prod(a, *args, **kw)
+
+    state = np.random.get_state()
+    np.random.seed(20261006)
+    rnte.np = Numpy1x()
+    rnte.run_tests(6)                                   # raises AssertionError on the first identity that fails
+    rnte.np = np
+    np.random.set_state(state)
+    # (scripts/loschmidt.py:test is the same suite with a typo of its own - `*cirq.H(qbs[1])` at :130 unpacks an Operation - and cannot run anywhere)
+    out['refshim_reference_selftests_passed'] = np.array([6])           # iterations of run_tests that passed
+
     path = os.path.join(HERE, 'refshim_golden.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, os.path.getsize(path), 'bytes,', len(out), 'arrays,', len(fits), 'scalar-minimiser calls recorded')

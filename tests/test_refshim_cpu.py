@@ -330,3 +330,25 @@ def test_nsphere_is_the_reference_parametrisation(g):
     from qmps_amd import time_evolve_tools as T
     for v, x in zip(g['nsphere_v'], g['refshim_nsphere']):
         assert np.abs(T.Nsphere(v) - x).max() < 1e-14 and abs(np.linalg.norm(x) - 1) < 1e-14
+
+
+def test_the_reference_self_tests_ran_green_over_the_stand_ins(g):
+    """make_refshim_golden.py section 8 executes qmps/new_time_evolve.py:run_tests (the reference's own asserts: embeddings, 1- and 2-site
+    circuit identities with R and L, the 6-qubit overlap identity) over cirq_shim: the generator stops at the first failing assert, the
+    fixture records how many iterations passed.  The oracle satisfies the same 6-qubit identity with ITS fixed points."""
+    assert g['refshim_reference_selftests_passed'][0] >= 5
+    rng = np.random.default_rng(4)
+    for _ in range(4):
+        A, Bt = (O.unitary_to_tensor(u) for u in O.haar_unitaries(rng, 4, 2))
+        M = O.transfer_matrix(O.merge(A, A), O.merge(Bt, Bt))
+        w, v = np.linalg.eig(M)
+        k = int(np.argmax(abs(w)))
+        wl, vl = np.linalg.eig(M.conj().T)
+        kl = int(np.argmax(abs(wl)))
+        r, l = v[:, k].reshape(2, 2), vl[:, kl].reshape(2, 2)
+        r, l = r / np.linalg.norm(r), l / np.linalg.norm(l)
+        # scripts/loschmidt.py:228-238 with L carrying l^+ instead of r^+: 2 psi[0] = eta tr(l^+ r)
+        U, Up = O.tensor_to_unitary(A), O.tensor_to_unitary(Bt)
+        ops = [(O.HAD, [3]), (O.CNOT, [3, 4]), (U, [2, 3]), (U, [1, 2]), (O.put_env_on_right_site(l.conj().T), [0, 1]),
+               (O.put_env_on_left_site(r), [4, 5]), (Up.conj().T, [1, 2]), (Up.conj().T, [2, 3]), (O.CNOT, [3, 4]), (O.HAD, [3])]
+        assert abs(2 * O._run_ops(6, ops)[0] - w[k] * np.trace(l.conj().T @ r)) < 1e-12

@@ -178,3 +178,12 @@ def test_variational_overlap_route_matches_the_reference_run(g):
         a5 = N.obj_state_amplitudes(g['obj_state_p'][k], A, WW)
         assert abs(a5[0] - g['refshim_obj_state_psi'][k][0]) < 1e-12
         assert abs(N.obj_state(g['obj_state_p'][k], A, WW)[0] - a5[0]) < 1e-12
+
+
+def test_the_reference_self_test_suite_through_the_drop_in_module(g):
+    """qmps/new_time_evolve.py:run_tests - the identities the reference asserts about its own circuits - with the fixed points coming from
+    the device (right AND left: the left one is the right fixed point of the daggered tensors, the convention the reference's asserts pin,
+    fixture `refshim_reference_selftests_passed`: the original suite executed green over the stand-ins)."""
+    from qmps_amd import new_time_evolve as N
+    assert g['refshim_reference_selftests_passed'][0] >= 5
+    N.run_tests(6, rng=np.random.default_rng(9))

@@ -56,3 +56,17 @@ def test_rotosolve_cell_and_variational_environment():
     assert r['final_checked'] > 300 and r['anomalies'] == 0 and r['max_dE_final'] < 1e-9, r['bad']
     c = run('stress_cell2_optenv.py', 3, 27)
     assert c['anomalies'] == 0 and c['cell_max_dE'] < 1e-10 and c['optenv_max_d'] < 1e-10, c['bad']
+
+
+def test_api_fuzzers_find_no_state_leak():
+    """Random call sequences on ONE context against stateless evaluations on a second one (stress_api_state.py: tensors / Hamiltonian terms / windows /
+    every launch flavour / cost exchange; stress_api_overlap.py: references from parameters, candidate groups, one-shot masks, warm starts, gradients) -
+    the fuzzers that found the stale cost-accumulator terms and the warm start on an unwritten window (round 5)."""
+    for D, seed in ((4, 31), (8, 32), (16, 33)):
+        r = run('stress_api_state.py', 12, seed, D)
+        assert r['checks'] > 60 and r['anomalies'] == 0 and r['max_dE'] < 1e-9, r['bad']
+    for D, seed in ((8, 34), (2, 35)):
+        r = run('stress_api_overlap.py', 12, seed, D)
+        assert r['checks'] > 40 and r['anomalies'] == 0 and r['max_df'] < 1e-10 and r['max_dg'] < 1e-8, r['bad']
+    s = run('stress_su.py', 2, 36)
+    assert s['anomalies'] == 0 and s['max_dU'] < 1e-12 and s['max_dE'] < 1e-10, s['bad']

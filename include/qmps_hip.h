@@ -79,7 +79,8 @@ extern "C" {
  * ACCEPTED only if one power step moves it by less than tol (||T(r)/tr - r||_F < tol: the very criterion of the
  * iterative solvers, so `status` keeps its meaning); an evaluation that fails the test (tensor not an isometry,
  * degenerate transfer spectrum) continues inside the same launch with the power method 2^m steps at a time from
- * r_0 = 1/D.  `iters` = 1 for an accepted direct solve, else 1 + 2^m.  A warm start (qmps_set_env_guess,
+ * r_0 = 1/D.  `iters` = 1 for an accepted direct solve, else 1 + 2^m (ABI 6.3, D = 4 as D = 2: + 1 when max_iter ends the chain and one
+ * plain step accepts its last iterate - max_iter = 10 000 no longer means 'converged within 4 096 steps' for a rejected solve).  A warm start (qmps_set_env_guess,
  * QMPS_FLAG_WARM_RESIDENT) is tried first at D = 4 - see QMPS_FLAG_WARM_RESIDENT - and ignored at D = 2 and 8.
  * D = 2: the 4 x 4 system is solved in the lane, in front of the squaring tail (which takes over what is not accepted).
  * D = 4: environment and energy are fused: one read of A, one store of E per evaluation.

@@ -336,6 +336,21 @@ __global__ __launch_bounds__(64, QMPS_DIRECT_MINWAVES) void energy_direct_d4_ker
       // rare: not an isometry / degenerate transfer spectrum.  Wave-uniform branch, one evaluation at a time.
       bool left = false;
       squaring_fallback(lds, PAD, sq_img, lane, todo, p.max_iter - 1, tol2, x, steps, left);
+      if (__any(todo && left)) {
+        // The budget ended the chain between two powers of two (it compares z_(2^m) with z_(2^(m-1)): under max_iter = 10 000 an evaluation the plain
+        // method finishes in 4 097 .. 9 998 steps has its fixed point in z_8192 and no comparison left; round 5, as at D = 2): the plain method's own
+        // test on the last iterate, one application of T itself, one more iteration.
+        double yb[4];
+        Core::gather(x, us);
+        const double d2b = Core::power_step(o, x, us, yb);
+        const bool fin = todo && left && d2b < tol2 && steps + 1.0 <= (double)p.max_iter;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) x[l] = fin ? yb[l] : x[l];
+        if (fin) {
+          left = false;
+          steps += 1.0;
+        }
+      }
       if (todo) {
         status = left ? QMPS_ST_NOT_CONVERGED : QMPS_ST_OK;
         if (WARM) steps += 1.0;

@@ -97,6 +97,17 @@ extern "C" int direct_emu_d4(long B, const double* A, const double* h, int nt, i
       const P4 left = Core::squaring(o, Rc, HostOps::p_not(ok), max_iter - 1, tol2, x, sq);
       steps = HostOps::splat(1.0) + sq;
       st = left.v[0] ? 1 : 0;
+      if (st == 1 && steps.v[0] + 1.0 <= (double)max_iter) {
+        // the budget ended the chain between two powers of two: the plain method's own test on the last iterate (as the kernel, round 5)
+        V yb[4];
+        Core::gather(x, us);
+        const V d2b = Core::power_step(o, x, us, yb);
+        if (d2b.v[0] < tol2) {
+          for (int l = 0; l < 4; ++l) x[l] = yb[l];
+          steps = steps + HostOps::splat(1.0);
+          st = 0;
+        }
+      }
     }
     V pre[4][4], pim[4][4];
     Core::gather(x, us);

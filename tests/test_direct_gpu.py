@@ -548,3 +548,30 @@ def test_direct_d2(c_oracle, engine_factory):
     for b in np.flatnonzero(~np.isnan(hist[-1]))[::7]:
         Ab = O.unitary_to_tensor(O.shallow_cnot_unitary(2, pf[b])[None])[0]
         assert abs(hist[-1][b] - sum(O.energy_closed_form(Ab, h[t]) for t in range(2))) < 1e-9
+
+
+def test_fallback_chain_decides_at_the_end_of_its_budget(engine_factory):
+    """The fused D = 4 kernel's fall-back compares z_(2^m) with z_(2^(m-1)): under max_iter = 10 000 a tensor whose solve is not accepted (here: not
+    an isometry, A -> 1.3 A) and whose plain iteration needs 4 097 .. 9 998 steps used to end with status 1 at 1 + 8 192 although z_8192 is its
+    fixed point (fourth stress campaign of round 5; the D = 2 chain had the same effect).  One plain step on the last iterate now decides:
+    iterations 1 + 8 192 + 1, the kernel, its CPU emulation (tests/csrc/direct_emu.cpp) and the oracle alike."""
+    import overlap_cases as OC
+    rng = np.random.default_rng(44)
+    A = np.stack([OC.slow_environment_tensor(rng, 4, t) * 1.3 for t in (0.22, 0.22, 0.25, 0.25, 0.28, 0.28, 0.3, 0.3)])
+    h = O.hamiltonian_matrix({'ZZ': -1.0, 'X': 1.0})
+    ref = [O.env_direct(a) for a in A]
+    its = np.array([x[1] for x in ref])
+    assert (its == 8194).sum() >= 5 and all(x[2] == 0 for x in ref)
+    eng = engine_factory(4)
+    eng.set_solver('direct')
+    E, it, st = eng.energies(A, h)
+    assert np.all(st == 0) and np.array_equal(it, its), (st, it, its)
+    r = eng.environments()
+    for b, a in enumerate(A):
+        rr = r[b] / np.trace(r[b])
+        assert np.abs(rr - ref[b][0]).max() < 1e-11
+        assert abs(E[b, 0] - O.energy_closed_form(a, h, ref[b][0])) < 1e-9 * 1.3 ** 4
+    emu = EMU.energies_d4(A, h)
+    assert np.array_equal(emu['iters'], it) and np.all(emu['status'] == 0) and np.abs(emu['E'][:, 0] - E[:, 0]).max() < 1e-11
+    E2, it2, st2 = eng.energies(A, h, max_iter=8193)          # no room for the extra step: reported, not hidden
+    assert np.all(st2[its == 8194] == 1)

@@ -64,7 +64,8 @@ for batch in range(n_batches):
             if gap < 1e-6:
                 if st[k] != 0 and abs(w[order[0]] - w[order[1]]) < 1e-9:
                     tot['status_nonzero_degenerate_leading'] += 1       # one eigenvalue, several eigenvectors: any of them would do
-                elif st[k] == 0 and abs(w[order[0]] - w[order[1]]) < 1e-9 and abs(eta[k] - w[order[0]]) > 1e-8:
+                # (a DEFECTIVE cluster - a triple zero - carries eps^(1/3) ~ 1e-8 .. 1e-7 of noise in numpy's own eigenvalues and in the kernel's: 1e-6 here)
+                elif st[k] == 0 and abs(w[order[0]] - w[order[1]]) < 1e-9 and abs(eta[k] - w[order[0]]) > 1e-6:
                     bad.append({'batch': batch, 'side': side, 'k': k, 'what': 'degenerate leading eigenvalue, status 0, another eigenvalue returned', 'eta': [eta[k].real, eta[k].imag], 'w': [[x_.real, x_.imag] for x_ in w[order]]})
                 continue
             tot['separated'] += 1

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64) void bw_env_kernel(BwArgs p) {
         const double dr = tr_[a][c] - (trr * pr[a][c] - tri * pi[a][c]), di = ti_[a][c] - (trr * pi[a][c] + tri * pr[a][c]);
         r1 += dr * dr + di * di;
       }
-    rank1_rounds = r1 < 1e-24 * f2 ? rank1_rounds + 1 : 0;
+    rank1_rounds = r1 < 1e-22 * f2 ? rank1_rounds + 1 : 0;      // (1e-24 until the fourth stress campaign: rounding leaves r1 / f2 ~ (eps cond)^2, 1.3e-25 at cond 1 800 - borderline)
     // A DEGENERATE leading eigenvalue (several eigenvectors, one eigenvalue: 1 x 1, SWAP ...) never gives a rank-one power, and any of its
     // eigenvectors is an answer (numpy returns one of them): from round 30 on the column is also accepted if ITS eigenvalue has the largest
     // real part there is - the growth rate of the power, log rho(exp(cM)) = max Re(c lambda), to 2^-30 ln(condition) ~ 3e-8.

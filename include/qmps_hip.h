@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 #define QMPS_ABI_VERSION 6
-#define QMPS_ABI_MINOR 3
+#define QMPS_ABI_MINOR 4
 
 /* error codes */
 #define QMPS_OK 0
@@ -54,6 +54,11 @@ extern "C" {
 #define QMPS_STATUS_NOT_CONVERGED 1 /* power iteration hit max_iter */
 #define QMPS_STATUS_NOT_PD 2        /* Cholesky of r fails: the reference's LinAlgError branch
                                        (qmps/ground_state.py:153-157) */
+/* (3 is internal to the library and never returned) */
+#define QMPS_STATUS_TIED 4          /* overlap path, D = 2 (ABI 6.4): the dominant eigenvalues of the mixed transfer map are TIED in modulus;
+                                       eta_out = their common modulus (real) and the objective -sqrt|eta| is valid - the library's optimisers
+                                       use it - but there is NO unique fixed point: r_out is a mixture, not an eigenvector.
+                                       Status 0 keeps meaning "r_out is the fixed point to tol" (ABI 6.2 / 6.3 returned 0 here) */
 
 /* input kinds for qmps_energy_batch / qmps_env_batch */
 #define QMPS_INPUT_TENSOR 0  /* A[B][2][D][D]  complex128 - state tensors            */
@@ -176,7 +181,10 @@ int qmps_abi_version(void);
  *      cold start, eta = 0 for nilpotent maps, the Gelfand route of the Krylov certificate (same signatures, see qmps_overlap_batch).
  * 6.3: qmps_overlap_amplitude (the overlap circuit's amplitude for given environments: the reference's variational route); the D = 2
  *      squaring chain of QMPS_ENV_POWER_SQUARING decides about its last iterate with one plain step when max_iter ends it;
- *      QMPS_FLAG_KRYLOV_FALLBACK (D = 8 environment solves hand long tails to the Arnoldi kernel, as D = 16 always did). */
+ *      QMPS_FLAG_KRYLOV_FALLBACK (D = 8 environment solves hand long tails to the Arnoldi kernel, as D = 16 always did).
+ * 6.4: QMPS_STATUS_TIED (the D = 2 overlap solves report a tie of the dominant eigenvalues by its own status instead of 0: eta is usable, r_out is
+ *      not a fixed point); qmps_evolve_bfgs_device_opts: max_rounds = 0 means 100 000 power steps at D = 16 as documented (it meant 60);
+ *      qmps_bw_env: the relaxed rank-one acceptance honours the caller's tol. */
 int qmps_abi_minor(void);
 const char* qmps_last_error(void);
 /* Test hook for the contract above ("nothing throws across the ABI"): raises a C++ exception inside the library - kind 1
@@ -353,8 +361,9 @@ int qmps_cell2_energy_batch_su(qmps_ctx* ctx, int64_t B, const double* params /*
  * until it is rank one (||M M - tr(M) M||_F < tol ||M M||_F), eta = tr(M E)/tr(M); a map whose powers collapse to rounding
  * noise within the first rounds is NILPOTENT (reference and candidate orthogonal): eta = 0, status 0 (ABI 6.2; it used to return noise);
  * D = 2 (ABI 6.2): dominant eigenvalues TIED in modulus (a complex-conjugate pair on the symmetric manifolds BFGS ends up on, a ring) - 30 and more
- * squarings without a rank-one power - return their common MODULUS as a real eta with status 0 (the reference's objective -sqrt|eta| is the same for
- * whichever member ARPACK returns); r_out is then the largest column of the last power, a mixture, not an eigenvector;
+ * squarings without a rank-one power - return their common MODULUS as a real eta with status QMPS_STATUS_TIED (ABI 6.4; 6.2 / 6.3: status 0) - the
+ * reference's objective -sqrt|eta| is the same for whichever member ARPACK returns, and every optimiser of this library treats the status as usable;
+ * r_out is then the largest column of the last power, a mixture, not an eigenvector;
  * D = 8, 16 run the power method in operator form from x_0 = (1 + 2^-12 G)/sqrt(D), G a fixed pseudo-random complex matrix (ABI 6.2: the
  * plain identity lies in the kernel of the map at symmetric points of the ansatz; ARPACK starts from a random vector), eta = <x, T x>, stop when
  * ||T x - eta x||_F < tol - at D = 16 on the matrix cores (v_mfma_f64_16x16x4, four waves per evaluation) - WITH A KRYLOV
@@ -608,7 +617,11 @@ int qmps_bw_expval(qmps_ctx* ctx, int64_t B, int sites, const double* U1, const 
                    int o_shared, double* out);
 /* RightEnvironment (side = 0, :399-431) / LeftEnvironment (side = 1, :316-347): the 4x4 environment matrix
  * (mat_out nullable [B][4][4]) and its eigenpair with the reference's rule eta[np.argmax(eta)] (largest real
- * part): eta_out [B] complex, vec_out [B][2][2] (unit 2-norm, largest entry real positive). */
+ * part): eta_out [B] complex, vec_out [B][2][2] (unit 2-norm, largest entry real positive).
+ * status 0: eigen-residual ||M v - eta v|| < tol ||v|| of a power exp(cM)^(2^m) that is rank one (or, for a degenerate leading eigenvalue, a
+ * column whose eigenvalue has the largest real part there is); an ILL-CONDITIONED eigenvector (eigenvalues clustered next to the leading one,
+ * condition ~1e3: the residual stalls at ~1e-13, as numpy's eig does) is accepted once the power has been rank one for three rounds with a
+ * residual below min(1e-10, 1e3 tol) (ABI 6.4: the bound follows tol; it was 1e-10 for every tol).  status 1: none of these within max_rounds. */
 int qmps_bw_env(qmps_ctx* ctx, int64_t B, int side, const double* U1, const double* U2, const double* U1p,
                 const double* U2p, int max_rounds, double tol, double* mat_out, double* eta_out, double* vec_out,
                 int32_t* status_out);

@@ -54,13 +54,16 @@ for case in range(n_cases):
         sep = 1.0 - abs(w[1]) / abs(w[0]) if abs(w[0]) > 0 else 0.0
         tot['evals'] += 1
         tot['status0'] += int(st[b] == 0)
-        tot['status1'] += int(st[b] != 0)
+        tot['status1'] += int(st[b] not in (0, 4))
+        tot['status_tied'] = tot.get('status_tied', 0) + int(st[b] == 4)      # QMPS_STATUS_TIED (ABI 6.4): |eta| valid, no fixed point
         if sep < 1e-7:
             tot['tied'] += 1
-            if st[b] == 0 and abs(abs(eta[b]) - abs(w[0])) > 1e-8:
+            if st[b] in (0, 4) and abs(abs(eta[b]) - abs(w[0])) > 1e-8:
                 bad.append({'case': case, 'D': D, 'b': b, 'what': 'tied moduli, status 0, |eta| is not the dominant modulus', 'eta': [eta[b].real, eta[b].imag], 'top': np.abs(w[:3]).tolist()})
             continue
         tot['separated'] += 1
+        if st[b] == 4 and abs(abs(eta[b]) - abs(w[0])) > 1e-8 * max(1.0, 1e-7 / sep):
+            bad.append({'case': case, 'D': D, 'b': b, 'what': 'status 4 (tie) on a separated spectrum with a wrong modulus', 'sep': float(sep), 'eta': [eta[b].real, eta[b].imag], 'top': np.abs(w[:3]).tolist()})
         if st[b] == 0:
             d = abs(eta[b] - w[0])
             tot['max_abs_deta_status0'] = max(tot['max_abs_deta_status0'], float(d))

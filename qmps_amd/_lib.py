@@ -14,6 +14,15 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libqmps_hip.so')
 QMPS_OK = 0
 QMPS_ERR_ARG, QMPS_ERR_HIP, QMPS_ERR_NO_DEVICE, QMPS_ERR_STATE, QMPS_ERR_RCCL = -1, -2, -3, -4, -5
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_NOT_PD = 0, 1, 2
+STATUS_TIED = 4          # overlap path, D = 2: eta = the common modulus of tied dominant eigenvalues (objective usable, r_out no fixed point)
+
+
+def overlap_usable(st):
+    """Overlap statuses whose eta / objective may be used: converged, or the common modulus of a tie (QMPS_STATUS_TIED)."""
+    import numpy as _np
+    st = _np.asarray(st)
+    return (st == STATUS_OK) | (st == STATUS_TIED)
+
 INPUT_TENSOR, INPUT_UNITARY = 0, 1
 INPUT_ANSATZ_BASE = 16
 ANSATZ_SHALLOW_CNOT, ANSATZ_SHALLOW_QAOA, ANSATZ_SHALLOW_FULL, ANSATZ_SHALLOW_CNOT3 = 0, 1, 2, 3

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void roto_update_kernel(double* __restrict__ b
       double v = 0.0;
       for (int q = 0; q < n_terms; ++q) v += E[((int64_t)r * nsh + k) * n_terms + q];   // M(x) = sum over terms
       e[k] = v;
-      ok = ok && status[(int64_t)r * nsh + k] == QMPS_ST_OK;
+      ok = ok && overlap_usable(status[(int64_t)r * nsh + k]);      // (energy path: status 0; overlap path at D = 2: also a tie's common modulus)
     }
     if (ok) {          // (an evaluation without a valid environment leaves this restart's parameter untouched)
       double theta;

@@ -99,9 +99,9 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
       for (int64_t t = 0; t < T; ++t) {
         const double* F = &fdf[(size_t)t * G1];
         const int32_t* S = &fds[(size_t)t * G1];
-        fo[t] = S[0] == qmps::QMPS_ST_OK ? F[0] : nan;
+        fo[t] = qmps::overlap_usable(S[0]) ? F[0] : nan;
         for (int k = 0; k < P; ++k)
-          go[(size_t)t * P + k] = (S[1 + k] == qmps::QMPS_ST_OK && S[1 + P + k] == qmps::QMPS_ST_OK) ? (F[1 + k] - F[1 + P + k]) / (2.0 * h) : nan;
+          go[(size_t)t * P + k] = (qmps::overlap_usable(S[1 + k]) && qmps::overlap_usable(S[1 + P + k])) ? (F[1 + k] - F[1 + P + k]) / (2.0 * h) : nan;
       }
       n_grad += 1.0;
       nfev += (double)T * (2 * P + 1);
@@ -121,7 +121,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
     if (int e = qmps_overlap_gradient(c, T, kind, P, Z, h, grad_rounds, grad_tol, (warm ? QMPS_OVERLAP_WARM : 0) | QMPS_OVERLAP_TWO_SIDED_F, fo, go, st.data())) return e;
     warm = true;
     for (int64_t t = 0; t < T; ++t)
-      if (st[t] != qmps::QMPS_ST_OK) {
+      if (!qmps::overlap_usable(st[t])) {
         fo[t] = nan;
         for (int k = 0; k < P; ++k) go[(size_t)t * P + k] = nan;
       }
@@ -473,7 +473,7 @@ int evolve_bfgs_group(qmps_ctx* c, int64_t T, int64_t T_hist, int64_t t_off, int
         nfev += (double)T * G;
         for (int64_t t = 0; t < T; ++t)
           for (int64_t r = 0; r < G; ++r) {
-            const double v = (need[t] && stl[(size_t)t * G + r] == qmps::QMPS_ST_OK) ? Fl[(size_t)t * G + r] : nan;
+            const double v = (need[t] && qmps::overlap_usable(stl[(size_t)t * G + r])) ? Fl[(size_t)t * G + r] : nan;
             Fc[(size_t)t * NA + r + 1] = std::isfinite(v) ? v : INFINITY;
           }
       }
@@ -951,7 +951,9 @@ int qmps_evolve_bfgs_device_opts(qmps_ctx* c, int64_t T, int kind, int n_params,
   qmps_evolve_opts o;
   qmps_evolve_out r;
   if (int rc = read_evolve_structs(opts, out, o, r)) return rc;
-  const int rounds = o.max_rounds > 0 ? o.max_rounds : 60;
+  // 0 = the default of include/qmps_hip.h: 60 squarings at D = 2, 4; at D = 16 max_rounds caps the POWER steps of a backtracking point's solve
+  // (qmps_evolve_d16.hip), where 60 would reject nearly every rung
+  const int rounds = o.max_rounds > 0 ? o.max_rounds : ((c->D == 2 || c->D == 4) ? 60 : 100000);
   return qmps_evolve_bfgs_device(c, T, kind, n_params, params, WW, o.n_steps, o.maxiter, o.gtol, o.h, o.c1, o.n_alphas, o.alphas, o.flags, rounds, o.tol, r.hinv,
                                  r.params_hist, r.f_hist, r.nit, r.counters);
 }

@@ -201,7 +201,7 @@ __device__ __forceinline__ void overlap_quad_solve(const double2* sC, const doub
     }
     eta_r = exp(log_rho);
     eta_i = 0.0;
-    status = QMPS_ST_OK;
+    status = QMPS_ST_OK;        // (internal to this kernel, where status 0 means "the objective is usable": the lane solver reports QMPS_ST_TIED)
   }
 }
 

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void lockstep_ladder_pick_kernel(LockstepArgs 
         if (r == 0) Fr = p.F0[t];
         else {
           const double v = fl[(int64_t)t * G + r - 1];
-          Fr = (stl[(int64_t)t * G + r - 1] == QMPS_ST_OK && v - v == 0.0) ? v : INFINITY;
+          Fr = (overlap_usable(stl[(int64_t)t * G + r - 1]) && v - v == 0.0) ? v : INFINITY;
         }
         if (first < 0 && Fr <= f + p.c1 * p.alphas[r] * sl) { first = r; Ffirst = Fr; }
         if (Fr < Fbest) { best = r; Fbest = Fr; }

@@ -6,7 +6,10 @@
 namespace qmps {
 
 enum { QMPS_ST_OK = 0, QMPS_ST_NOT_CONVERGED = 1, QMPS_ST_NOT_PD = 2,
-       QMPS_ST_PENDING = 3 /* internal, between the kernels of one launch: handed to the Krylov fall-back (D = 16 environment) */ };
+       QMPS_ST_PENDING = 3 /* internal, between the kernels of one launch: handed to the Krylov fall-back (D = 16 environment) */,
+       QMPS_ST_TIED = 4 /* overlap path, D = 2: dominant eigenvalues tied in modulus - eta is their common modulus, the vector is NOT a fixed point */ };
+// an overlap evaluation whose eta (hence the objective -sqrt|eta|) may be used: converged, or the common modulus of a tie (QMPS_STATUS_TIED)
+__host__ __device__ inline bool overlap_usable(int status) { return status == QMPS_ST_OK || status == QMPS_ST_TIED; }
 
 // Kernel arguments of the energy kernels (zero-initialise, then fill) (all pointers are HBM addresses).
 struct LaneArgs {
@@ -306,7 +309,7 @@ __device__ __forceinline__ void overlap_store(const OverlapArgs& p, int64_t b, d
     atomicAdd(st + 0, 1ULL);
     atomicAdd(st + 1, (unsigned long long)rounds);
     atomicMax(st + 2, (unsigned long long)rounds);
-    if (status != QMPS_ST_OK) atomicAdd(st + 3, 1ULL);
+    if (!overlap_usable(status)) atomicAdd(st + 3, 1ULL);
   }
 }
 // Cold start of the power method on a mixed transfer map: the identity (the natural guess: for a candidate close to the reference the fixed

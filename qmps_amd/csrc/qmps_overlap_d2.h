@@ -180,7 +180,7 @@ __device__ __forceinline__ void overlap_lane_solve(GA Ap, GB Bp, const double2* 
     // Thirty and more squarings without a rank-one power: the dominant eigenvalues are TIED in modulus (a complex-conjugate pair, a ring -
     // generic on symmetric manifolds of the ansatz: beta = -gamma of the depth-1 ShallowCNOT gate, product states).  No unique fixed point - but
     // their common modulus is what the reference's objective -sqrt|eta| measures with whichever member ARPACK returns, and ||E^(2^m)||^(1/2^m)
-    // (a Gelfand bound, from the norms of the squared powers) has it to 2^-m ln(condition) ~ 1e-11: eta = |eta| (real), status 0 (ABI 6.2;
+    // (a Gelfand bound, from the norms of the squared powers) has it to 2^-m ln(condition) ~ 1e-11: eta = |eta| (real), QMPS_ST_TIED (ABI 6.2: status 0;
     // round 5: BFGS trajectories that walk into such a manifold used to die of NaN).  The rare path: the logarithms live in this second pass
     // over the squarings.  The vector handed out is the largest column of the last power - a mixture, not an eigenvector.
     double n2 = 0.0;
@@ -221,7 +221,7 @@ __device__ __forceinline__ void overlap_lane_solve(GA Ap, GB Bp, const double2* 
     }
     eta_r = exp(log_rho);
     eta_i = 0.0;
-    status = QMPS_ST_OK;
+    status = QMPS_ST_TIED;      // (ABI 6.4: its own status - usable as an objective, but r_out is no fixed point; it was status 0 in ABI 6.2 / 6.3)
   }
   out.eta_r = eta_r;
   out.eta_i = eta_i;

@@ -54,7 +54,7 @@ def batch_obj(P, A, WW, return_eta=False, D=2, state_tensor=None, max_rounds=Non
     else:
         eta, rounds, st = eng.overlaps(A, P, WW, kind='params', ansatz=kind, max_rounds=max_rounds, tol=tol)
     f = -np.sqrt(np.abs(eta))
-    f = np.where(st == L.STATUS_OK, f, np.nan)
+    f = np.where(L.overlap_usable(st), f, np.nan)          # (D = 2: a tie's common modulus, QMPS_STATUS_TIED, is a valid objective)
     return (f, eta) if return_eta else f
 
 
@@ -97,7 +97,7 @@ class _GroupedObjective:
         self.warm = self.warm or keep
         if self.kernel_ms is not None:
             self.kernel_ms.append(self.eng.kernel_time(1)[0])
-        return np.where(st == L.STATUS_OK, f, np.nan)
+        return np.where(L.overlap_usable(st), f, np.nan)
 
     def value_and_grad(self, X, h=1e-6):
         """(f (T,), g (T, P)) of the iterates X from one right + one left eigen-solve each (qmps_overlap_gradient), warm-started
@@ -110,7 +110,7 @@ class _GroupedObjective:
         self.grad_warm = True
         if self.kernel_ms is not None:
             self.kernel_ms.append(self.eng.kernel_time(1)[0])
-        bad = st != L.STATUS_OK
+        bad = ~L.overlap_usable(st)
         return np.where(bad, np.nan, f), np.where(bad[:, None], np.nan, g)
 
     def _want_timing(self):
@@ -193,14 +193,17 @@ def evolve(params, WW, n_steps, method='Nelder-Mead', options=None, callback=Non
             ev.close()
         lost = np.array([np.isnan(np.asarray(f)[-1]) for f in info['fun']])        # (n_steps, T)
         if lost.any():
-            # status 1 of the fixed-point solves: SEVERAL dominant eigenvalues of equal modulus (the transfer map of a product state, special
-            # angles of the ansatz) - there is no unique fixed point, the two-sided gradient has nothing to stand on, and the library says so
-            # instead of returning one of the eigenvectors as ARPACK would (include/qmps_hip.h "status"); the trajectory keeps its parameters
+            # a fixed-point solve ended with a status the objective cannot use (include/qmps_hip.h "status"): at D >= 4 SEVERAL dominant
+            # eigenvalues of equal modulus (the transfer map of a product state, special angles of the ansatz: no unique fixed point, the
+            # two-sided gradient has nothing to stand on, and the library says so instead of returning one of the eigenvectors as ARPACK
+            # would), or a solve that exhausted max_rounds.  The trajectory is reported where it stands when the objective is lost - normally
+            # the last iterate with a finite objective; when the solve fails at an ACCEPTED backtracking point the parameters have moved there
             import warnings
             first = {int(t): int(np.argmax(lost[:, t])) for t in np.where(lost.any(axis=0))[0]}
             warnings.warn(f"evolve(method='BFGS'): {len(first)} of {T} trajectories have no objective (NaN) from time step "
-                          f"{min(first.values())} on: their mixed transfer map has several dominant eigenvalues of EQUAL modulus (status 1 - a product "
-                          f"state / special angles of the ansatz); their parameters are left where they were: trajectories {sorted(first)[:8]}", RuntimeWarning, stacklevel=2)
+                          f"{min(first.values())} on: a fixed-point solve of their mixed transfer map did not converge (status != 0: dominant eigenvalues "
+                          f"tied in modulus - a product state / special angles of the ansatz - or max_rounds exhausted); the optimiser no longer "
+                          f"moves them: trajectories {sorted(first)[:8]}", RuntimeWarning, stacklevel=2)
             info['no_unique_fixed_point'] = first
     else:
         for step in range(n_steps):
@@ -482,7 +485,7 @@ class OverlapOptimizer:
         cand = np.stack([unitary_to_tensor(unitary(self.gate(p))) for p in P])
         eng = _runtime.engine(2, len(cand))
         eta, _, st = eng.overlaps(self._current_tensor(), cand, self.W, kind='tensor')
-        return np.where(st == L.STATUS_OK, -np.abs(eta), np.nan)
+        return np.where(L.overlap_usable(st), -np.abs(eta), np.nan)
 
     def objective_function(self, params):
         return float(self.batch_objective_function(params)[0])

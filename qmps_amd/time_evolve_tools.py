@@ -83,7 +83,8 @@ def overlap_of_tensors(A, B, want_r=False):
     cand = Bt[None] if single else Bt
     eng = _runtime.engine(2, len(cand))
     eta, _, st, r = eng.overlaps(A, cand, np.eye(4), kind='tensor', want_r=True)
-    if np.any(st != L.STATUS_OK):
+    # QMPS_STATUS_TIED (D = 2: dominant eigenvalues tied in modulus) has a valid |eta| but no fixed point: good enough without `want_r` only
+    if np.any(~L.overlap_usable(st)) or (want_r and np.any(st != L.STATUS_OK)):
         raise np.linalg.LinAlgError('mixed transfer map has no unique dominant eigenvalue')
     x2 = np.abs(eta)
     if single:

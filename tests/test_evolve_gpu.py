@@ -626,7 +626,7 @@ def test_a_map_without_a_unique_fixed_point_is_reported_not_hidden():
     w = np.sort(np.abs(w))[::-1]
     assert int((w > w[0] - 1e-9).sum()) >= 5 and abs(w[0] - 0.99502085) < 1e-7          # many equal moduli on top, no dominant eigenvalue
     X0 = np.stack([special, np.random.default_rng(3).standard_normal(P)])
-    with pytest.warns(RuntimeWarning, match='EQUAL modulus'):
+    with pytest.warns(RuntimeWarning, match='did not converge'):
         H, info = NT.evolve(X0, WW, 2, method='BFGS', D=D, state_tensor=R.ShallowCNOTStateTensor, tol=1e-12, options={'maxiter': 40}, return_info=True)
     f_end = np.array([f[-1] for f in info['fun']])
     assert np.all(np.isnan(f_end[:, 0])) and np.all(np.isfinite(f_end[:, 1])) and f_end[:, 1].max() < -0.99
@@ -912,3 +912,33 @@ def test_option_struct_entry_points_are_the_positional_ones(engine_factory):
     X2 = X0.copy()
     L.check(lib.qmps_evolve_bfgs_device_opts(eng._ctx, T, L.ANSATZ_SHALLOW_FULL, P, _f64(X2), _f64(WW.view(np.float64)), ctypes.byref(short), ctypes.byref(out)))
     assert np.array_equal(X2, ref['x'])
+
+
+def test_option_struct_defaults_at_d16_cap_power_steps_not_squarings(engine_factory):
+    """Advisor finding of round 5: qmps_evolve_bfgs_device_opts turned max_rounds = 0 into 60 at every D; at D = 16 max_rounds caps the POWER steps
+    of a backtracking point's solve (qmps_evolve_d16.hip), so a C caller keeping the qmps_evolve_opts_init defaults had nearly every rung
+    of a rejected full step exhaust its cap and count as rejected.  The default is now the one include/qmps_hip.h documents (60 squarings at
+    D = 2, 4; 100 000 power steps at D = 8, 16), as in qmps_evolve_bfgs_opts: the struct call with max_rounds = 0 equals the positional call
+    with 100 000 bit for bit, on a ladder that provokes rejected full steps."""
+    import ctypes
+    from qmps_amd.engine import _f64, _i32
+    rng = np.random.default_rng(1617)
+    kind, D, P, T, n_steps = 0, 16, 8, 5, 2
+    X0 = rng.standard_normal((T, P))
+    WW = np.ascontiguousarray(WW_of(0.05), dtype=np.complex128)
+    al = np.array([2.5, 1.0, 0.3, 0.05, 0.005])
+    eng = engine_factory(D, T * (2 * P + 1))
+    ref = eng.evolve_bfgs_device(kind, X0, WW, n_steps=n_steps, maxiter=60, tol=1e-12, alphas=al, max_rounds=100000)
+    assert ref['failed_evaluations'] == 0
+    lib = eng._lib
+    opts = L.EvolveOpts()
+    L.check(lib.qmps_evolve_opts_init(ctypes.byref(opts)))
+    assert opts.max_rounds == 0
+    opts.n_steps, opts.maxiter, opts.n_alphas, opts.alphas = n_steps, 60, len(al), _f64(al)
+    X = X0.copy()
+    ph, fh, nit, cnt = np.empty((n_steps, T, P)), np.empty((n_steps, 2, T)), np.zeros((n_steps, T), dtype=np.int32), np.zeros(4)
+    out = L.EvolveOut(size=ctypes.sizeof(L.EvolveOut), params_hist=_f64(ph), f_hist=_f64(fh), nit=_i32(nit), counters=_f64(cnt))
+    L.check(lib.qmps_evolve_bfgs_device_opts(eng._ctx, T, kind, P, _f64(X), _f64(WW.view(np.float64)), ctypes.byref(opts), ctypes.byref(out)))
+    assert int(cnt[1]) == 0                                                  # no failed evaluation
+    assert np.array_equal(nit, ref['nit']) and np.abs(fh[:, 1] - ref['fun']).max() < 1e-9 and np.abs(X - ref['x']).max() < 1e-6
+    assert fh[-1, 1].mean() < -0.999

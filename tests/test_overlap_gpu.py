@@ -7,6 +7,7 @@ import pytest
 from scipy.linalg import expm
 
 from oracle import qmps_oracle as O
+from qmps_amd import _lib as L
 import overlap_cases as OC
 
 pytestmark = pytest.mark.gpu
@@ -331,9 +332,10 @@ def test_tied_dominant_pair_at_d2_returns_the_common_modulus(engine_factory):
     """Round 5 (profiles/experiments/r05/stress_evolve_device.py: 6 of 44 607 trajectory steps died of NaN, all here): on the manifold beta = -gamma of the
     depth-1 ShallowCNOT gate at D = 2 - where BFGS trajectories end up - the mixed transfer map has a complex-conjugate PAIR of dominant
     eigenvalues of equal modulus.  There is no unique fixed point, but the objective -sqrt|eta| the reference's circuit measures is the same for
-    either member (ARPACK returns one of them): the D = 2 solves now return that common modulus as a real eta, status 0 - from the norms of the
+    either member (ARPACK returns one of them): the D = 2 solves now return that common modulus as a real eta - from the norms of the
     squared powers (a Gelfand bound, 1e-11 after 40 squarings) - and the time evolution goes on from such a point, on the host loop and on the
-    device-resident driver alike."""
+    device-resident driver alike.  Round 6 (advisor): the status is QMPS_STATUS_TIED, not 0 - the objective is usable, but r_out is a mixture
+    and not a fixed point, so callers that ask for the fixed point (overlap_of_tensors(want_r=True), run_tests) are told."""
     from qmps_amd import new_time_evolve as NT, represent as R
     H = O.hamiltonian_matrix({'ZZ': -1.0, 'X': 1.0})
     eng = engine_factory(2, 1024)
@@ -345,11 +347,47 @@ def test_tied_dominant_pair_at_d2_returns_the_common_modulus(engine_factory):
         w = w[np.argsort(-np.abs(w))]
         assert abs(abs(w[0]) - abs(w[1])) < 1e-12 and abs(w[0] - w[1]) > 1e-3 and abs(w[2]) < 0.5 * abs(w[0])      # a tied pair on top
         eta, rounds, st = eng.overlaps(A[None], x[None], WW, kind='params', ansatz=0, tol=1e-13)
-        assert st[0] == 0 and abs(eta[0].imag) == 0.0 and abs(eta[0].real - abs(w[0])) < 1e-10, (eta, abs(w[0]))
+        assert st[0] == L.STATUS_TIED and abs(eta[0].imag) == 0.0 and abs(eta[0].real - abs(w[0])) < 1e-10, (eta, abs(w[0]))
+        assert np.isfinite(NT.batch_obj(x[None], A, WW, D=2, state_tensor=R.ShallowCNOTStateTensor)[0])          # the objective uses it
+
         for opts in ({'device_driver': True}, {'device_driver': False}):
             Hh, info = NT.evolve(x[None], WW, 2, method='BFGS', D=2, state_tensor=R.ShallowCNOTStateTensor, tol=1e-13, options=dict(opts, maxiter=40), return_info=True)
             f = np.array([fi[-1] for fi in info['fun']])
             assert np.all(np.isfinite(f)) and f.max() < -0.99 and abs(info['fun'][0][0][0] + np.sqrt(abs(w[0]))) < 1e-9
+
+
+def test_tied_pair_between_real_tensors_has_a_fidelity_but_no_fixed_point(engine_factory):
+    """The reference's `tools.random_unitary` draws REAL orthogonal matrices (qmps/tools.py:36-37): the mixed transfer map of two real D = 2
+    tensors is a real 4 x 4 matrix, and in about a third of the draws its dominant eigenvalues are a complex-conjugate PAIR.  `Map(A, B)
+    .right_fixed_point()` (ARPACK) would return one member; the device returns their common modulus with QMPS_STATUS_TIED: the fidelity
+    per site |x|^2 of `overlap_of_tensors` / `get_overlap_exact(testing=False)` is well defined and returned, the fixed point is not and
+    asking for it raises (advisor, round 5: status 0 used to promise a fixed point that was a mixture)."""
+    from qmps_amd import time_evolve_tools as TT
+    rng = np.random.default_rng(77)
+    eng = engine_factory(2, 8)
+    found = 0
+    for _ in range(40):
+        A = O.unitary_to_tensor(np.linalg.qr(rng.standard_normal((4, 4)))[0].astype(complex))
+        Bt = O.unitary_to_tensor(np.linalg.qr(rng.standard_normal((4, 4)))[0].astype(complex))
+        w = np.linalg.eigvals(O.transfer_matrix(A, Bt))
+        w = w[np.argsort(-np.abs(w))]
+        tied = abs(abs(w[0]) - abs(w[1])) < 1e-12 and abs(w[0].imag) > 0.05 and abs(w[0].real) > 0.05 and abs(w[2]) < 0.9 * abs(w[0])
+        unique = abs(w[1]) < 0.9 * abs(w[0])
+        if not (tied or unique):
+            continue
+        eta, _, st, r = eng.overlaps(A, Bt[None], np.eye(4), kind='tensor', want_r=True, tol=1e-13)
+        if tied:
+            found += 1
+            assert st[0] == L.STATUS_TIED and abs(eta[0].real - abs(w[0]) ** 2) < 1e-10 and eta[0].imag == 0.0
+            assert abs(TT.overlap_of_tensors(A, Bt) - abs(w[0]) ** 2) < 1e-10
+            with pytest.raises(np.linalg.LinAlgError):
+                TT.overlap_of_tensors(A, Bt, want_r=True)
+        else:
+            assert st[0] == L.STATUS_OK and abs(abs(eta[0]) - abs(w[0]) ** 2) < 1e-10
+            x2, rr = TT.overlap_of_tensors(A, Bt, want_r=True)
+            Tr = sum(A[s] @ rr @ Bt[s].conj().T for s in range(2))
+            assert np.linalg.norm(sum(A[s] @ Tr @ Bt[s].conj().T for s in range(2)) - w[0] ** 2 * rr) < 1e-9          # status 0: r IS the fixed point
+    assert found >= 5
 
 
 @pytest.mark.parametrize('D', [2, 4, 8, 16])

@@ -167,6 +167,9 @@ extern "C" {
  *                         in kernels on device-resident state with the host enqueueing chains of iterations.  Same numbers, bit for bit.
  *   QMPS_NO_KRYLOV        D = 8, 16 fixed-point solves: the power method alone, to max_rounds (same results wherever it converges;
  *                         ~1/(1 - |eta_2 / eta_1|) steps)
+ *   QMPS_POWER_LANE       D = 4, QMPS_ENV_POWER: one LANE per evaluation (rounds 1-5: a wave waits for the slowest of its 64 evaluations)
+ *                         instead of a DPP quad per evaluation in persistent waves that draw their evaluations from a work counter
+ *                         (round 6; same iterates, same iteration counts and statuses; energies to rounding)
  * Everything else that used to be tunable from the environment (thresholds, schedules: profiles/EXPERIMENTS.md) is compiled
  * in only with -DQMPS_DEBUG_KNOBS; the shipped library ignores those variables (tests/test_cabi.py checks both lists). */
 

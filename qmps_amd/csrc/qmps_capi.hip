@@ -918,6 +918,25 @@ int qmps_energy_launch(qmps_ctx* c, int64_t B, int max_iter, double tol, int fla
       HIP_TRY(qmps::launch_energy_mfma(c->D, f, true, c->stream));
     }
     if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
+  } else if (!hybrid && c->D == 4 && solver == QMPS_ENV_POWER && c->d_queue != nullptr && documented_switch("QMPS_POWER_LANE") == nullptr) {
+    // D = 4, plain power iteration (round 6): a 16-lane DPP row per evaluation (the map as a real 16 x 16 matrix in registers, a step = sixteen
+    // v_fmac_f64_dpp) in persistent waves that draw their evaluations from a counter - env_power_d4_kernel (qmps_direct.hip) - then the energies, the Cholesky test and the cost sums on the stored environments
+    // (energy_only_d4_kernel).  The lane-per-evaluation kernel of rounds 1-5 waited for the slowest of its 64 evaluations in every wave
+    // and for ONE evaluation per launch (QMPS_POWER_LANE=1 selects it: same iterates, same iteration counts).
+    int* counter = c->d_queue + 13;
+    HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), c->stream));
+    qmps::LaneArgs e = make_args(c, B, 1, 1.0, false);
+    e.check_pd = 1;
+    if (accumulate) {
+      if (int rc = setup_accumulator(c, e, B, (B + 15) / 16, 16)) return rc;
+    } else { e.partial = c->d_partial; c->partials_B = B; c->partials_n = (int)((B + 15) / 16); }
+    int waves_per_simd = 5;          // (what fits: 96 registers)
+    if (const char* w = tuning_knob("QMPS_POWER_WAVES")) waves_per_simd = atoi(w);
+    c->dominant = "env_power_d4_kernel";
+    if (c->timed) HIP_TRY(hipEventRecord(c->kev0[slot], c->stream));
+    HIP_TRY(qmps::launch_env_power_d4(a, counter, c->n_cus * 4 * waves_per_simd, c->stream));
+    if (c->timed) HIP_TRY(hipEventRecord(c->kev1[slot], c->stream));
+    HIP_TRY(qmps::launch_energy_only_d4(e, c->stream));
   } else if (!hybrid) {
     c->dominant = c->D <= 4 ? "energy_lane_kernel<D,true>" : "energy_block_kernel<D,true>";
     if (accumulate) {

@@ -520,6 +520,205 @@ __global__ __launch_bounds__(64, LEAN ? QMPS_ENERGY_ONLY_LEAN_WAVES : 2) void en
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// env_power_d4_kernel: the PLAIN normalised power iteration r <- T(r) / tr T(r), T(r) = sum_s A_s r A_s^+ (QMPS_ENV_POWER: the classical
+// statement of the reference's PowerCircuit / krylov route, qmps/represent.py:235-248, and the "power-iteration environment solve" of
+// BASELINE.json configs[2]) at D = 4: a 16-LANE DPP ROW PER EVALUATION, four evaluations per wave, PERSISTENT WAVES that draw their
+// evaluations from a counter in HBM.
+//   * In the real coordinates u of the Hermitian matrix r (qmps_direct_core.h: a = 4 i + i') the map is a real 16 x 16 matrix R.  Lane
+//     c of the row builds row c of R once per evaluation (100 multiply-adds, the tensor tile in LDS) and keeps it in registers; a power
+//     step is then the mat-vec u' = R u - SIXTEEN v_fmac_f64_dpp row_newbcast (lane b's coordinate straight into the multiply-add: no
+//     LDS, no shuffle instruction) - the trace and the distance ||u'/tr - u||_F as DPP row reductions: ~60 instructions per step of four
+//     evaluations, 256 real multiply-adds per evaluation and step where the operator form A r A^+ costs 960.
+//   * The iteration count of a Haar tensor is geometric-ish (mean 105, 99.9 % 396, max ~900 of 65 536).  A lane per evaluation
+//     (energy_lane_kernel<4>, rounds 1-5) holds 63 lanes of a wave idle behind its slowest evaluation, and the whole launch behind ONE
+//     (964 steps x 1.7 us of a lane's 1 000-instruction step: 1.65 ms per 65 536 evaluations, 0.12 of the FP64 roofline).  Here a row
+//     whose evaluation has converged stores its environment and draws the next one (wave-aggregated: one atomic per refill round), and a
+//     straggler costs its step latency (~0.1 us), not a lane's.
+// Same iterate sequence as the lane kernel up to rounding (r_0 = 1/D or the caller's guess, symmetrised and trace-normalised; stop when
+// ||r_k - r_(k-1)||_F < tol; iterations = k; status 1 at max_iter).  The energies, the positive-definiteness test and the cost sums
+// follow in energy_only_d4_kernel (check_pd) on the stored environments.
+// ------------------------------------------------------------------------------------------
+#ifndef QMPS_POWER_D4_MINWAVES
+#define QMPS_POWER_D4_MINWAVES 4
+#endif
+// acc += (u of lane B of the own 16-lane row) * m
+// FRESH: u may have been written by the VALU instruction just before (a DPP read then wants two wait states; inline assembly is invisible to the
+// compiler's hazard recogniser, so the s_nop travels inside the same statement)
+template <int B, bool FRESH = false>
+__device__ __forceinline__ void row_fmac(double& acc, double u, double m) {
+  if constexpr (FRESH) asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(m), "n"(B));
+  else asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(m), "n"(B));
+}
+template <bool GUESS>
+__global__ __launch_bounds__(64, QMPS_POWER_D4_MINWAVES) void env_power_d4_kernel(LaneArgs p, int* __restrict__ counter, int first_block) {
+  constexpr int PAD = 512 + 16, SLOTS = 4, kChunk = 8;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[SLOTS * PAD];
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15, i = c >> 2, ip = c & 3;
+  const bool diag = i == ip, rot = i > ip;
+  const double wt = diag ? 1.0 : 2.0;                                  // ||r||_F^2 = sum_diag u^2 + 2 sum_offdiag u^2
+  const double tol2 = p.tol * p.tol;
+  const unsigned long long below = (1ull << (lane & ~15)) - 1ull;      // the lanes of the rows in front of this one
+  const double2* tile = (const double2*)(lds + g * PAD);               // A_s[a][j] = tile[(4 s + a) 4 + j]
+  int64_t b = 0;
+  // the wave's range (wave-uniform): its static first block, then chunks from the counter, which counts from dyn0 = gridDim.x first_block
+  const int64_t dyn0 = (int64_t)gridDim.x * first_block;
+  int64_t next = (int64_t)blockIdx.x * first_block, end = next + first_block;
+  if (next > p.B) next = p.B;
+  if (end > p.B) end = p.B;
+  bool active = false, exhausted = dyn0 >= p.B;
+  bool refill = true;                      // wave-uniform: a row is idle and there may be work for it
+  int iters = 0;
+  double u = 0.0, up = 0.0, R[16];        // iterate k, iterate k - 1, the row of the map
+#pragma unroll
+  for (int k = 0; k < 16; ++k) R[k] = 0.0;
+  for (;;) {
+    if (refill) {
+      // ---- refill (the rare path: ~1 % of the trips): every idle row of the wave takes the next evaluation of the wave's own RANGE [next, end) -
+      // at first a static block of `first_block` evaluations per wave, then chunks of kChunk drawn from the counter: same-address atomics pass
+      // through the L2 at ~16 ns each, and one per refill round (a row at a time: ~60 000 per launch) WAS the launch: 0.83 ms whatever the occupancy
+      const unsigned long long idle = __ballot(!active);
+      if (idle != 0ull && !(exhausted && next >= end)) {
+        if (next >= end && !exhausted) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(counter, kChunk);
+          const int64_t first = dyn0 + (int64_t)__builtin_amdgcn_readfirstlane(base);
+          next = first < p.B ? first : p.B;
+          end = first + kChunk < p.B ? first + kChunk : p.B;
+          exhausted = first + kChunk >= p.B;
+        }
+        const int64_t nb = next + (__popcll(idle & below) >> 4);
+        const int64_t lim = end;
+        {
+          const int64_t take = (int64_t)(__popcll(idle) >> 4);
+          next = next + take < end ? next + take : end;
+        }
+        if (!active && nb < lim) {
+          b = nb;
+          {
+            const double2* src = (const double2*)p.A + b * 32;
+            const double2 v0 = src[c], v1 = src[c + 16];
+            double2* w = (double2*)(lds + g * PAD);
+            w[c] = v0;
+            w[c + 16] = v1;
+          }
+          __builtin_amdgcn_wave_barrier();          // (the tile is private to the row; LDS is in order per wave)
+          // row c = (i, i') of the real transfer matrix (DirectD4::build for one row): with P(j,j') = sum_s (gamma A_s[i][j]) conj(A_s[i'][j']),
+          // gamma = 1 (i <= i') | i (i > i'):  column (j,j): Re P(j,j);  (lo,hi): Re (P(lo,hi) + P(hi,lo));  (hi,lo): -Im (P(lo,hi) - P(hi,lo))
+          double tr[2][4], ti[2][4], br[2][4], bi[2][4];
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const double2 a = tile[(4 * s + i) * 4 + j], cc = tile[(4 * s + ip) * 4 + j];
+              tr[s][j] = rot ? -a.y : a.x;
+              ti[s][j] = rot ? a.x : a.y;
+              br[s][j] = cc.x;
+              bi[s][j] = cc.y;
+            }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            double v = tr[0][j] * br[0][j];
+            v = dfma(ti[0][j], bi[0][j], v);
+            v = dfma(tr[1][j], br[1][j], v);
+            v = dfma(ti[1][j], bi[1][j], v);
+            R[5 * j] = v;
+          }
+#pragma unroll
+          for (int lo = 0; lo < 4; ++lo)
+#pragma unroll
+            for (int hi = lo + 1; hi < 4; ++hi) {
+              double re = tr[0][lo] * br[0][hi], im = tr[0][lo] * bi[0][hi];
+#pragma unroll
+              for (int s = 0; s < 2; ++s) {
+                if (s > 0) {
+                  re = dfma(tr[s][lo], br[s][hi], re);
+                  im = dfma(tr[s][lo], bi[s][hi], im);
+                }
+                re = dfma(ti[s][lo], bi[s][hi], re);
+                re = dfma(tr[s][hi], br[s][lo], re);
+                re = dfma(ti[s][hi], bi[s][lo], re);
+                im = dfma(-ti[s][lo], br[s][hi], im);
+                im = dfma(ti[s][hi], br[s][lo], im);
+                im = dfma(-tr[s][hi], bi[s][lo], im);
+              }
+              R[4 * lo + hi] = re;
+              R[4 * hi + lo] = im;
+            }
+          // start vector: 1/D, or the caller's guess (qmps_set_env_guess) symmetrised and trace-normalised - zeros / NaN / nothing stored: 1/D
+          u = diag ? 0.25 : 0.0;
+          if constexpr (GUESS) {
+            const double2* rin = (const double2*)p.r_in + b * 16;
+            const double2 rw = rin[4 * i + ip], cl = rin[4 * ip + i];       // r[i][i'], r[i'][i]
+            const double ug = i <= ip ? 0.5 * (rw.x + cl.x) : 0.5 * (cl.y - rw.y);   // Re r[i][i'] (i <= i') | Im r[i'][i] (i > i')
+            const double t = row16_sum(diag ? ug : 0.0);
+            const bool usable = t > 1e-300 && t < 1e300;
+            if (usable) u = ug * (1.0 / t);
+          }
+          up = u;
+          iters = 0;
+          active = true;
+        }
+      }
+      const unsigned long long still = __ballot(!active);
+      if (still == ~0ull) break;                                        // nothing left for this wave
+      refill = still != 0ull && !(exhausted && next >= end);            // (a range that ran out in the middle of a round: the rest next trip)
+    }
+    // ---- one power step of every row - straight-line code: idle rows compute on stale registers and nothing of theirs is committed.  The
+    // convergence test of iterate k (its distance to iterate k - 1: a DPP row reduction) is issued BESIDE the step that produces iterate
+    // k + 1, not behind it (one surplus step per evaluation), and the only branch of a trip asks whether ANY row of the wave has finished:
+    // with a branch per decision a lone wave's step was 0.24 us - ten VALU -> SGPR -> branch round trips, twice the arithmetic.
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+    row_fmac<0, true>(y0, u, R[0]); row_fmac<1>(y1, u, R[1]);   row_fmac<2>(y2, u, R[2]);   row_fmac<3>(y3, u, R[3]);
+    row_fmac<4>(y0, u, R[4]);       row_fmac<5>(y1, u, R[5]);   row_fmac<6>(y2, u, R[6]);   row_fmac<7>(y3, u, R[7]);
+    row_fmac<8>(y0, u, R[8]);       row_fmac<9>(y1, u, R[9]);   row_fmac<10>(y2, u, R[10]); row_fmac<11>(y3, u, R[11]);
+    row_fmac<12>(y0, u, R[12]);     row_fmac<13>(y1, u, R[13]); row_fmac<14>(y2, u, R[14]); row_fmac<15>(y3, u, R[15]);
+    const double d = u - up;
+    const double d2 = row16_sum(wt * d * d);       // ||r_k - r_(k-1)||_F^2
+    const double y = (y0 + y1) + (y2 + y3);
+    double t0 = 0.0, t1 = 0.0;                     // the trace: the diagonal coordinates sit in lanes 0, 5, 10, 15 of the row
+    row_fmac<0, true>(t0, y, 1.0); row_fmac<5>(t1, y, 1.0); row_fmac<10>(t0, y, 1.0); row_fmac<15>(t1, y, 1.0);
+    const double yn = y * fast_rcp(t0 + t1);
+    const bool conv = iters > 0 && d2 < tol2;
+    const bool fin = active && (conv || iters >= p.max_iter);
+    if (__any(fin)) {
+      if (fin) {
+        if (c == 0) {
+          p.iters[b] = iters;
+          p.status[b] = conv ? QMPS_ST_OK : QMPS_ST_NOT_CONVERGED;
+        }
+        // r[i][i'] from the coordinates (i, i') (own) and (i', i) (lane 4 i' + i of the row; the sixteen lanes leave together)
+        const double ut = __shfl(u, (lane & ~15) + 4 * ip + i, 64);
+        const double re = i <= ip ? u : ut;
+        const double im = diag ? 0.0 : (i < ip ? ut : -u);
+        ((double2*)p.r_out)[b * 16 + c] = make_double2(re, im);
+        active = false;
+      }
+      refill = true;
+    }
+    iters = active ? iters + 1 : iters;
+    up = active ? u : up;
+    u = active ? yn : u;
+  }
+}
+
+// waves: the persistent grid (waves of four evaluations; the caller sizes it to the chip); counter: an int in HBM, zero at launch
+hipError_t launch_env_power_d4(const LaneArgs& a, int* counter, int waves, hipStream_t st) {
+  if (a.B <= 0) return hipSuccess;
+  if (a.r_out == nullptr || counter == nullptr) return hipErrorInvalidValue;
+  const int64_t need = (a.B + 3) / 4;
+  const int64_t nw = need < waves ? need : (waves < 1 ? 1 : waves);
+  const dim3 grid((unsigned)nw), block(64);
+  // half of the batch as static first blocks (whole rounds of four rows), the rest in chunks from the counter
+  // (swept on 65 536 Haar tensors - waves per SIMD 2 .. 8 x first block 4 / 8 / 16 x chunk 4 / 8 / 16: 0.35 .. 0.45 ms without a pattern: what differs
+  // is when the launch's slowest evaluation happens to start; profiles/experiments/r06/power_d4_sched.py)
+  int first_block = (int)(a.B / (2 * nw) / 4 * 4);
+  if (first_block < 4) first_block = 4;
+  if (a.r_in != nullptr) hipLaunchKernelGGL(env_power_d4_kernel<true>, grid, block, 0, st, a, counter, first_block);
+  else hipLaunchKernelGGL(env_power_d4_kernel<false>, grid, block, 0, st, a, counter, first_block);
+  return hipGetLastError();
+}
+
 hipError_t launch_energy_only_d4(const LaneArgs& a, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
   const dim3 grid((unsigned)((a.B + 15) / 16)), block(64);

@@ -125,6 +125,8 @@ hipError_t launch_square_tail(int D, const SquareArgs& a, int grid, hipStream_t 
 hipError_t launch_energy_pair_d4(const LaneArgs& a, hipStream_t st);
 // D = 4 energy-only pass in the quad layout of the fused kernel (no worklist mode): qmps_direct.hip
 hipError_t launch_energy_only_d4(const LaneArgs& a, hipStream_t st);
+// D = 4 plain power iteration, a quad per evaluation, persistent waves drawing evaluations from `counter` (zero at launch); writes r_out, iters, status
+hipError_t launch_env_power_d4(const LaneArgs& a, int* counter, int waves, hipStream_t st);
 // D = 4 DIRECT solve fused with the energies: one DPP quad per evaluation (qmps_direct.hip); partials: one per 16 items
 hipError_t launch_energy_direct_d4(const LaneArgs& a, hipStream_t st);
 

@@ -442,3 +442,75 @@ def test_d8_environment_krylov_fallback(engine_factory, monkeypatch):
     rr = eng.environments()[0]
     assert np.abs(O.apply_transfer(a, rr) - rr).max() < 1e-10
     assert abs(Es[0, 0] - O.energy_closed_form(a, h[0])) < 1e-9
+
+
+def test_plain_power_iteration_d4_row_kernel_against_the_lane_kernel_and_the_oracle(c_oracle, engine_factory, monkeypatch):
+    """Round 6: QMPS_ENV_POWER at D = 4 runs env_power_d4_kernel - a 16-lane DPP row per evaluation (the map as a real 16 x 16 matrix in
+    registers, a power step = sixteen v_fmac_f64_dpp), persistent waves drawing evaluations from a work counter - then the energy-only
+    kernel.  Against the lane-per-evaluation kernel of rounds 1-5 (QMPS_POWER_LANE=1) and the C oracle (plain power iteration): the same
+    iterates (1e-12), the same iteration counts (+-1: a borderline test), statuses, energies (1e-10), density matrices, summed costs; batch
+    sizes that are no multiple of four, a batch of one, an iteration cap that some evaluations hit (status 1 with the iterate of the last
+    step), the caller's guess (symmetrised, trace-normalised; an unusable one = the default start), a resident-batch window, the in-kernel
+    cost accumulator, a tensor that is not an isometry and the zero tensor (no fixed point: status 1, not a hang)."""
+    rng = np.random.default_rng(606)
+    h = np.stack([O.hamiltonian_matrix({'ZZ': -1, 'X': 1}), O.hamiltonian_matrix({'XX': 1, 'YY': 1, 'ZZ': 0.5})])
+    eng = engine_factory(4, 8192)
+
+    def run(A, lane, **kw):
+        if lane:
+            monkeypatch.setenv('QMPS_POWER_LANE', '1')
+        else:
+            monkeypatch.delenv('QMPS_POWER_LANE', raising=False)
+        select(eng, 'plain')
+        E, it, st = eng.energies(A, h, **kw)
+        out = (E.copy(), it.copy(), st.copy(), eng.environments().copy(), eng.rdm().copy(), eng.summed_cost().copy())
+        monkeypatch.delenv('QMPS_POWER_LANE', raising=False)
+        return out
+
+    for B in (1, 3, 4, 5, 63, 1000, 8191):
+        A = O.unitary_to_tensor(O.haar_unitaries(rng, 8, B))
+        new, old = run(A, False, max_iter=4000), run(A, True, max_iter=4000)
+        ref = c_oracle.energy_batch(A, h, max_iter=4000, want_r=True, want_rho=True)
+        assert np.array_equal(new[2], old[2]) and np.all(new[2] == ref['status'])
+        assert np.abs(new[1] - old[1]).max() <= 1 and np.abs(new[1] - ref['iters']).max() <= 1 and (new[1] == ref['iters']).mean() > 0.95
+        ok = new[2] == 0
+        assert np.abs(new[0] - old[0])[ok].max() < 1e-12 and np.abs(new[0] - ref['E'])[ok].max() < E_TOL
+        assert np.abs(new[3] - old[3])[ok].max() < 1e-12 and np.abs(new[3] - ref['r'])[ok].max() < R_TOL
+        assert np.abs(new[4] - ref['rho'])[ok].max() < R_TOL
+        assert np.allclose(new[5], new[0].sum(0), rtol=0, atol=1e-9 * max(1, B))
+    # an iteration cap inside the distribution (median ~95 steps): capped evaluations report status 1, iterations = cap, and the iterate of the last step
+    A = O.unitary_to_tensor(O.haar_unitaries(rng, 8, 2000))
+    new, old = run(A, False, max_iter=90), run(A, True, max_iter=90)
+    assert np.array_equal(new[2], old[2]) and 0.2 < (new[2] == 1).mean() < 0.8 and np.all(new[1][new[2] == 1] == 90)
+    assert np.abs(new[3] - old[3]).max() < 1e-12 and np.abs(new[0] - old[0]).max() < 1e-12
+    # the caller's guess: a perturbed, scaled, slightly non-Hermitian fixed point converges in a few steps to the same environment; zeros / NaN = default start
+    full = run(A, False)
+    guess = 2.5 * full[3] + 1e-6 * (rng.standard_normal(full[3].shape) + 1j * rng.standard_normal(full[3].shape))
+    guess[::7] = 0.0
+    guess[3::7] = np.nan
+    gn, go = run(A, False, r0=guess), run(A, True, r0=guess)
+    assert np.all(gn[2] == 0) and np.abs(gn[1] - go[1]).max() <= 1 and np.abs(gn[3] - full[3]).max() < 1e-10 and np.abs(gn[0] - full[0]).max() < E_TOL
+    usable = np.ones(len(A), dtype=bool)
+    usable[::7] = False
+    usable[3::7] = False
+    assert gn[1][usable].mean() < 0.7 * full[1][usable].mean() and np.abs(gn[1][~usable] - full[1][~usable]).max() <= 1
+    # resident batches: a window in the middle, the in-kernel cost accumulator
+    eng.set_tensors(A)
+    eng.set_hamiltonian(h)
+    eng.set_window(512)
+    eng.launch(700, max_iter=4000, tol=1e-13, solver='plain', accumulate_cost=True)
+    eng.cost_launch(700)
+    cost = eng.get_cost()
+    Ew, itw, stw = eng.results(700)
+    eng.set_window(0)
+    assert np.abs(Ew - full[0][512:1212]).max() < 1e-12 and np.abs(itw - full[1][512:1212]).max() <= 1 and np.all(stw == 0)
+    assert np.allclose(cost, Ew.sum(0), rtol=0, atol=1e-9 * 700)
+    # not an isometry (the trace is not preserved: the normalisation carries it), and the zero tensor (no fixed point)
+    odd = A[:6].copy()
+    odd[0] *= 1.7
+    odd[1] = 0.0
+    on, oo = run(odd, False, max_iter=3000), run(odd, True, max_iter=3000)
+    assert np.array_equal(on[2], oo[2]) and on[2][1] == 1 and on[1][1] == 3000 and on[2][0] == 0
+    assert abs(on[1][0] - full[1][0]) <= 1 and np.abs(on[3][0] - full[3][0]).max() < 1e-12           # (a scaled tensor has the same normalised fixed point)
+    keep = [0, 2, 3, 4, 5]
+    assert np.abs(on[0][keep] - oo[0][keep]).max() < 1e-11

@@ -433,6 +433,15 @@ def main():
             _, it_l, st_l = eng.results(B)
             legs[name] = {'evals_per_s': B / (ms * 1e-3), 'ms_per_step': ms, 'steps_timed': n_leg, 'mean_power_iterations': float(it_l.mean()),
                           'max_power_iterations': int(it_l.max()), 'not_converged_or_not_pd': int((st_l != 0).sum())}
+            if name == 'plain':
+                # the power-iteration solve priced two ways: SURVEY 8(d)'s operator-form count (what a reader of the north star expects) and the
+                # flops the D = 4 kernel executes (the map as a real 16 x 16 matrix: a third of them); a launch ends with its slowest evaluation
+                # (max_power_iterations steps of ~0.2 us for a wave alone on its SIMD: the floor of the leg whatever the batch)
+                fl_survey = float(flops_per_eval(D, it_l.astype(np.float64)).sum())
+                fl_exec, fl_note, _ = executed_flops(D, 'plain', it_l, eng, args.max_iter)
+                legs[name].update({'fp64_tflops_survey_formula': fl_survey / (ms * 1e-3) * 1e-12, 'fp64_frac_survey_formula': fl_survey / (ms * 1e-3) * 1e-12 / FP64_PEAK_TFLOPS,
+                                   'fp64_tflops_executed': fl_exec / (ms * 1e-3) * 1e-12, 'fp64_frac_executed': fl_exec / (ms * 1e-3) * 1e-12 / FP64_PEAK_TFLOPS,
+                                   'executed_flops_note': fl_note})
         eng.set_window(0)
         legs['what'] = ('the same resident batches, environment by power iteration to the same tolerance: "plain" = normalised power '
                         'iteration (krylov / PowerCircuit of the reference), "squaring" = 2^m power steps at a time; energies stored, no cost sum')

@@ -250,6 +250,15 @@ def executed_flops(D, solver, iters, eng, max_iter):
         flops = float((k_plain * (32 * D ** 3 + 4 * D ** 2) + sq_flops + 64 * D ** 3 + 128 * D ** 2).sum())
         note = ('executed algorithm: m = log2(K) squarings of the real D^2 x D^2 transfer matrix per item (2 (D^2)^3 flop each) + '
                 'its construction; K read back per item')
+    elif solver == 'plain' and D == 4 and not os.environ.get('QMPS_POWER_LANE'):
+        # env_power_d4_kernel (round 6): the map as a real 16 x 16 matrix, one row per lane: 16 rows x (4 x 4 + 12 x 8) FMA to build it, then per
+        # power step and lane 16 FMA (mat-vec) + 4 (trace) + ~9 flop (normalisation, distance) - K + 1 steps (the convergence test runs one step
+        # behind) - and the energy-only kernel: density matrix 2432 FMA, LDL^H ~60, energy 28 per term
+        k = iters.astype(np.float64) + 1.0
+        flops = float((2.0 * 1792 + k * 16.0 * (2.0 * 16 + 2.0 * 4 + 9.0) + 2.0 * (2432 + 60 + 28)).sum())
+        note = ('executed algorithm of env_power_d4_kernel + energy_only_d4_kernel: real 16 x 16 transfer matrix (3584 flop) + (K_b + 1) power steps in '
+                'real coordinates (784 flop each: 512 of the mat-vec, the rest trace normalisation and the Frobenius distance) + density matrix / '
+                'LDL^H / energy (5040); K_b read back per item.  SURVEY 8(d) prices the same step in operator form (A r A^+) at 2112 flop')
     elif solver == 'direct' and D == 8:
         # env_direct_d8: real 64 x 64 system - build 64 rows x 480 FMA = 30 720 FMA, Gauss-Jordan 64 pivots x 64 rows x ~34 FMA
         # = 139 264 FMA (DESIGN.md kernel table) - then the block kernel's acceptance step(s) and the energy epilogue

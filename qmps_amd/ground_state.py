@@ -4,6 +4,7 @@
   SparseFullEnergyOptimizer                qmps/ground_state.py:120-168  (exact-environment objective)
   NonSparseFullEnergyOptimizer             qmps/ground_state.py:230-269
   NonSparseFullTwoSiteEnergyOptimizer      qmps/ground_state.py:271-335
+  ground_state_sweep                       the drivers' loops over couplings x ansatz sizes x restarts (scripts/ground_state_finding.py:166-200)
 
 Every objective keeps the reference's contract - `objective_function(params) -> float`, previous
 value returned when the environment is not positive definite (the reference's caught
@@ -310,3 +311,61 @@ class NonSparseFullTwoSiteEnergyOptimizer(Optimizer):
     def update_state(self):
         self.u1 = SU(self.optimized_result.x[:15], 4)
         self.u2 = SU(self.optimized_result.x[15:], 4)
+
+
+def ground_state_sweep(terms, coefficients, D=2, depth=2, state_tensor=ShallowCNOTStateTensor, restarts=8, initial_guesses=None, rng=None,
+                       maxiter=200, gtol=1e-6, return_all=False):
+    """Variational ground states of K Hamiltonians  H_k = sum_q coefficients[k, q] terms[q]  from R random restarts each - K R BFGS
+    minimisations advancing in ONE lock-step over device batches.
+
+    This is the reference's phase-diagram driver (`scripts/ground_state_finding.py:166-200`: for 21 couplings lambda and three ansatz sizes,
+    `minimize(lambda p: eps(p, lambda), randn(n), method='BFGS', tol=1e-10)`, again from a fresh start while the energy does not improve) and
+    its error-against-depth driver (`scripts/noisy_optimization.py:30-72`) with the loops turned into the batch axis: a launch returns the
+    energies of every TERM for every candidate (`qmps_energy_batch_ansatz` with n_terms Hamiltonians: one environment solve per candidate,
+    the terms share it), and trajectory (k, r) combines them with its own coefficients - the couplings cost nothing extra.
+      terms         (Q, 4, 4) two-site operators (or Hamiltonian objects), e.g. [-ZZ, (XI + IX)/2] for the TFIM
+      coefficients  (K, Q)
+      initial_guesses (K, R, P) or None: `rng.standard_normal` (the reference's `np.random.randn`), P = 2 depth angles (3 depth for ShallowCNOTStateTensor3)
+    Returns dict(energy (K,) best of the restarts, params (K, P) its parameters, energies (K, R), nit, nfev[, all_params (K, R, P)])."""
+    from .tools import batched_bfgs
+    T = np.stack([_as_h(t_) for t_ in terms]).astype(np.complex128)
+    C = np.atleast_2d(np.asarray(coefficients, dtype=float))
+    K, Q = C.shape
+    if T.shape[0] != Q:
+        raise ValueError(f'{Q} coefficients per Hamiltonian for {T.shape[0]} terms')
+    kind = getattr(state_tensor, 'device_kind', None)
+    on_device = kind is not None and not (kind in (2, 6) and D != 2)
+    if initial_guesses is None:
+        rng = np.random.default_rng() if rng is None else rng
+        per_layer = 3 if state_tensor.__name__ == 'ShallowCNOTStateTensor3' else 2
+        n_par = 15 if state_tensor.__name__ == 'ShallowFullStateTensor' else per_layer * depth
+        X0 = rng.standard_normal((K, restarts, n_par))
+    else:
+        X0 = np.array(initial_guesses, dtype=float)
+        if X0.ndim != 3 or X0.shape[0] != K:
+            raise ValueError('initial_guesses: expected (K, R, P)')
+    _, R, P = X0.shape
+    n_traj = K * R
+    coef_traj = np.repeat(C, R, axis=0)                      # trajectory k R + r -> the coefficients of H_k
+
+    def batch(cand):
+        cand = np.ascontiguousarray(cand, dtype=np.float64)
+        per = cand.shape[0] // n_traj                        # rows are trajectory-major (batched_bfgs)
+        eng = _runtime.engine(D, cand.shape[0])
+        if on_device:
+            E, _, st = eng.energies_from_params(kind, cand, T, max_iter=_GpuEnergyMixin.max_iter, tol=_GpuEnergyMixin.env_tol)
+        else:
+            U = np.stack([unitary(build_gate(state_tensor, D, p_)) for p_ in cand])
+            E, _, st = eng.energies(U, T, kind='unitary', max_iter=_GpuEnergyMixin.max_iter, tol=_GpuEnergyMixin.env_tol)
+        f = (E * np.repeat(coef_traj, per, axis=0)).sum(axis=1)
+        return np.where(st == STATUS_OK, f, np.nan)
+
+    res = batched_bfgs(batch, batch, X0.reshape(n_traj, P), maxiter=maxiter, gtol=gtol)
+    fun = np.where(np.isfinite(res['fun']), res['fun'], np.inf).reshape(K, R)
+    Xf = res['x'].reshape(K, R, P)
+    best = fun.argmin(axis=1)
+    out = {'energy': fun[np.arange(K), best], 'params': Xf[np.arange(K), best], 'energies': fun, 'nit': res['nit'], 'nfev': res['nfev'],
+           'converged': res['converged'].reshape(K, R)}
+    if return_all:
+        out['all_params'] = Xf
+    return out

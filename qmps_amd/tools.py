@@ -517,6 +517,10 @@ class Optimizer:
         """Batched objective; subclasses with a GPU path override it."""
         return np.array([self.objective_function(p) for p in params_batch])
 
+    def optimize_restarts(self, initial_guesses, method=None, maxiter=None, tol=None):
+        """R restarts of this optimisation in lock-step over device batches: `tools.optimize_restarts`."""
+        return optimize_restarts(self, initial_guesses, method=method, maxiter=maxiter, tol=tol)
+
     def optimize(self):
         s = self.settings
         verbose = s['verbose']
@@ -555,6 +559,63 @@ class Optimizer:
             print(f'Reason for termination is {self.optimized_result.message} ' +
                   f'\nObjective Function Value is {self.optimized_result.fun}')
         return self.optimized_result
+
+
+def _restart_result(x, fun, nit, nfev, converged, history):
+    from scipy.optimize import OptimizeResult
+    return OptimizeResult(x=np.array(x), fun=float(fun), nit=int(nit), nfev=int(nfev), success=bool(converged), status=0 if converged else 1,
+                          message='converged' if converged else 'stopped', history=np.asarray(history))
+
+
+def optimize_restarts(optimizer, initial_guesses, method=None, maxiter=None, tol=None):
+    """R independent optimisations of `optimizer`'s objective from R starting points, as ONE lock-step over device batches.
+
+    The reference's drivers loop over random restarts and run one scalar optimisation after the other, every evaluation a cirq
+    simulation (`scripts/ground_state_finding.py:137-154, 173-195`: `minimize(eps, randn(n), method='BFGS')` until the energy stops
+    improving; `scripts/noisy_optimization.py:46-72`: `opt.optimize()` again from a fresh `randn`).  The restarts are independent, so
+    here they advance together: method 'BFGS' = `batched_bfgs` (every iteration two batches over all restarts: the iterates with their
+    2 P central-difference neighbours, the backtracking ladder), 'Rotosolve' = the device driver with R restarts in one C call
+    (`qmps_double_rotosolve`; gate classes without a device kernel: the host driver per restart), anything else: `optimizer.optimize()`
+    per restart (Nelder-Mead takes sequential decisions per simplex; its candidate points are already batched).
+    method / maxiter / tol default to `optimizer.settings`.  Returns the list of R results (scipy `OptimizeResult`s: x, fun, nit,
+    success, history) in the order of the guesses; `optimizer.optimized_result` is the best of them (lowest finite fun) and
+    `optimizer.restart_results` the list - then `update_state()` as after `optimize()`."""
+    s = optimizer.settings
+    method = s['method'] if method is None else method
+    maxiter = s['maxiter'] if maxiter is None else maxiter
+    tol = s['tol'] if tol is None else tol
+    X0 = np.array(np.atleast_2d(initial_guesses), dtype=float)
+    R = X0.shape[0]
+    batch = optimizer.batch_objective_function
+    results = None
+    if method == 'BFGS':
+        res = batched_bfgs(batch, batch, X0, maxiter=maxiter, gtol=tol)
+        hist = res['history']
+        results = [_restart_result(res['x'][r], res['fun'][r], res['nit'], res['nfev'] // R, res['converged'][r], hist[:, r]) for r in range(R)]
+    elif method == 'Rotosolve' and getattr(optimizer, '_device_double_rotosolve', None) is not None:
+        kind = getattr(getattr(optimizer, 'state_tensor', None), 'device_kind', None)
+        if not getattr(optimizer, 'optimize_environment', False) and kind is not None and kind <= 3 and not (kind == 2 and optimizer.D != 2):
+            from .rotosolve import device_double_rotosolve
+            es, P = device_double_rotosolve(optimizer, X0, maxiter)
+            results = [_restart_result(P[r], es[-1, r], maxiter, 6 * maxiter * X0.shape[1], True, es[:, r]) for r in range(R)]
+    if results is None:
+        results = []
+        keep = optimizer.initial_guess
+        for r in range(R):
+            optimizer.initial_guess = X0[r].copy()
+            old = dict(optimizer.settings)
+            optimizer.settings.update({'method': method, 'maxiter': maxiter, 'tol': tol})
+            try:
+                results.append(optimizer.optimize())
+            finally:
+                optimizer.settings.clear()
+                optimizer.settings.update(old)
+        optimizer.initial_guess = keep
+    funs = np.array([r_.fun if np.isfinite(r_.fun) else np.inf for r_ in results])
+    optimizer.restart_results = results
+    optimizer.optimized_result = results[int(np.argmin(funs))]
+    optimizer.update_state()
+    return results
 
 
 class GuessInitialFullParameterOptimizer(Optimizer):

@@ -462,3 +462,56 @@ def test_device_builders_of_the_remaining_ansatz_classes(D, engine_factory):
             if np.isfinite(e):
                 assert abs(e - O.energy_closed_form(O.unitary_to_tensor(O.shallow_cnot_nonuniform_unitary(D, p)), h)) < 1e-10
         assert np.isfinite(Eb).sum() >= 8
+
+
+def test_ground_state_sweep_and_restarts_in_lock_step():
+    """Round 6 - the reference's driver loops as the batch axis: `ground_state_sweep` (couplings x restarts of scripts/ground_state_finding.py:166-200
+    in ONE lock-step BFGS: a launch returns the energies of every Hamiltonian TERM, trajectory (k, r) combines them with its coefficients) and
+    `Optimizer.optimize_restarts`.  Checked: (i) every trajectory's final energy is the oracle's energy of ITS Hamiltonian at its final parameters
+    (1e-10); (ii) each ends in a stationary point (oracle gradient by central differences < 1e-4) no higher than scipy's BFGS on the scalar
+    drop-in objective from the same start, except where the two line searches end in different basins - at least 80 % within 1e-6 or lower;
+    (iii) the best of the restarts respects the variational bound E >= E0_exact(g) (tests/test_ground_state.py:101-102 of the reference) and
+    at g = 1 reaches the optimum of the depth-2 circuit (-1.26550; the reference quotes -1.269909412573 for D = 2, scripts/noisy_optimization.py:93)."""
+    from scipy.integrate import quad
+    from scipy.optimize import minimize
+    from qmps_amd.ground_state import Hamiltonian, SparseFullEnergyOptimizer, ground_state_sweep
+    from qmps_amd.represent import ShallowCNOTStateTensor
+    rng = np.random.default_rng(77)
+    terms = [Hamiltonian({'ZZ': -1.0}).to_matrix(), Hamiltonian({'X': 1.0}).to_matrix()]
+    gs = np.array([0.5, 1.0, 1.5])
+    coef = np.stack([np.ones_like(gs), gs], axis=1)
+    D, depth, R = 2, 2, 12
+    X0 = rng.standard_normal((len(gs), R, 2 * depth))
+    out = ground_state_sweep(terms, coef, D=D, depth=depth, state_tensor=ShallowCNOTStateTensor, initial_guesses=X0, maxiter=300, return_all=True)
+    assert out['energies'].shape == (3, R) and np.all(np.isfinite(out['energies']))
+    same = []
+    for k, g in enumerate(gs):
+        H = Hamiltonian({'ZZ': -1.0, 'X': float(g)}).to_matrix()
+        e0 = quad(lambda q: -2 * np.sqrt(1 + g * g - 2 * g * np.cos(q)) / (2 * np.pi), 0, np.pi)[0]
+
+        def e_oracle(p):
+            return O.energy_closed_form(O.unitary_to_tensor(O.shallow_cnot_unitary(D, p)[None])[0], H)
+        for r in range(R):
+            p = out['all_params'][k, r]
+            assert abs(e_oracle(p) - out['energies'][k, r]) < 1e-10
+            grad = np.array([(e_oracle(p + 1e-5 * e) - e_oracle(p - 1e-5 * e)) / 2e-5 for e in np.eye(len(p))])
+            assert np.abs(grad).max() < 1e-4, (k, r, grad)
+            assert out['energies'][k, r] > e0 - 1e-12
+        opt = SparseFullEnergyOptimizer(H, D, depth, state_tensor=ShallowCNOTStateTensor, initial_guess=X0[k, 0].copy())
+        for r in range(4):
+            ref = minimize(opt.objective_function, X0[k, r], method='BFGS', tol=1e-8)
+            same.append(out['energies'][k, r] < ref.fun + 1e-6)
+        assert abs(out['energy'][k] - out['energies'][k].min()) == 0.0 and np.array_equal(out['params'][k], out['all_params'][k, out['energies'][k].argmin()])
+    assert np.mean(same) >= 0.8, same
+    # the restart loop of one optimiser object: lock-step BFGS and the device rotosolve, best restart kept
+    H = Hamiltonian({'ZZ': -1.0, 'X': 1.0}).to_matrix()
+    opt = SparseFullEnergyOptimizer(H, 2, 2, state_tensor=ShallowCNOTStateTensor, initial_guess=X0[1, 0].copy())
+    opt.change_settings({'verbose': False, 'store_values': False, 'tol': 1e-7, 'maxiter': 200})
+    res = opt.optimize_restarts(X0[1], method='BFGS')
+    assert np.abs(np.array([r_.fun for r_ in res]) - out['energies'][1]).max() < 1e-6            # the same lock-step on the same starts, one Hamiltonian
+    assert opt.optimized_result.fun == min(r_.fun for r_ in res) and opt.U.shape == (4, 4)
+    assert -1.2732395447 - 1e-9 < opt.optimized_result.fun < -1.265          # (the optimum of the depth-2 circuit: -1.26550; the D = 2 manifold: -1.27254)
+    roto = opt.optimize_restarts(X0[1], method='Rotosolve', maxiter=20)
+    assert len(roto) == R and all(len(r_.history) == 20 for r_ in roto)       # (with the exact environment the energy is no finite sinusoid of an angle: the reference's update rule is a heuristic and its sweeps are not monotone - they settle at -1.236417 here, above the BFGS optimum)
+    e_best = min(r_.fun for r_ in roto)
+    assert abs(e_best - O.energy_closed_form(O.unitary_to_tensor(O.shallow_cnot_unitary(2, opt.optimized_result.x)[None])[0], H)) < 1e-10

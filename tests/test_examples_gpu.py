@@ -45,3 +45,19 @@ def test_quench_example(monkeypatch):
     monkeypatch.setattr(sys, 'argv', ['quench_time_evolution.py', '--D', '4', '--steps', '4', '--trajectories', '2'])
     H4, f4, _ = mod.main()
     assert H4.shape == (5, 2, 4) and f4.max() < -0.99
+
+
+def test_phase_diagram_example():
+    """examples/phase_diagram_tfim.py: the reference's `plot_phase_diagram` loops (scripts/ground_state_finding.py:166-200) as one lock-step:
+    every point above the exact energy, the classical limit lambda = 0 exact (a product state is in the manifold), the gap largest near the
+    critical point; the same through the D = 4 kernels."""
+    mod = load('phase_diagram_tfim')
+    lams, out, exact = mod.main(['--points', '9', '--restarts', '12'])
+    gap = out['energy'] - exact
+    assert np.all(gap > -1e-10) and gap[0] < 1e-8 and np.all(gap < 0.05)        # (the depth-2 D = 2 circuit: 2.6e-2 at lambda = 1.25)
+    assert 0.5 <= lams[np.argmax(gap)] <= 1.5
+    # (the shallow families of different D are not nested and have local minima: no ordering between them is asserted - 12 restarts of the D = 4
+    # depth-3 circuit end at -1.2590 at lambda = 1 where the D = 2 depth-2 circuit reaches its optimum -1.2655)
+    _, out4, exact4 = mod.main(['--points', '3', '--restarts', '12', '--D', '4', '--depth', '3'])
+    gap4 = out4['energy'] - exact4
+    assert np.all(gap4 > -1e-10) and gap4[0] < 1e-8 and np.all(gap4 < 0.05)

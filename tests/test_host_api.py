@@ -410,3 +410,49 @@ def test_state_gate_adapter_and_native_flag():
     A = NT.state_tensor(p, D=2, state_tensor=R.StateGate)          # (host path: no device needed)
     assert A.shape == (2, 2, 2) and np.allclose(sum(a.conj().T @ a for a in A), np.eye(2))
     assert NT.state_tensor_of(R.StateGate, 2, p).shape == (2, 2, 2)
+
+
+def test_optimize_restarts_is_the_restart_loop_in_lock_step():
+    """tools.optimize_restarts / Optimizer.optimize_restarts (round 6): the reference's restart loops (scripts/ground_state_finding.py:137-154,
+    scripts/noisy_optimization.py:46-72) as one lock-step over batches.  On a toy objective with a batched form (no device needed): every restart
+    reaches the minimum scipy's BFGS reaches from the same start (a convex objective: one basin), no scalar objective call is made, the best
+    restart becomes `optimized_result`, `update_state` runs once; a method without a lock-step form falls back to `optimize()` per restart and
+    leaves the settings and the initial guess as they were."""
+    from scipy.optimize import minimize
+    from qmps_amd.tools import Optimizer
+
+    calls = {'batch': 0, 'scalar': 0, 'update': 0}
+    a = np.array([0.3, -1.2, 0.8])
+    M = np.array([[2.0, 0.3, 0.0], [0.3, 1.0, -0.2], [0.0, -0.2, 1.5]])
+
+    def f(P):
+        Q = np.atleast_2d(np.asarray(P, dtype=float)) - a
+        return np.einsum('bi,ij,bj->b', Q, M, Q) + 0.1 * np.sum(Q ** 4, axis=1) - 0.7
+
+    class Toy(Optimizer):
+        def objective_function(self, p):
+            calls['scalar'] += 1
+            return float(f(p)[0])
+
+        def batch_objective_function(self, P):
+            calls['batch'] += 1
+            return f(P)
+
+        def update_state(self):
+            calls['update'] += 1
+
+    rng = np.random.default_rng(8)
+    X0 = 2.0 * rng.standard_normal((12, 3))
+    opt = Toy(initial_guess=X0[0].copy())
+    opt.change_settings({'verbose': False, 'store_values': False, 'tol': 1e-7})
+    res = opt.optimize_restarts(X0, method='BFGS')
+    assert len(res) == 12 and calls['scalar'] == 0 and calls['update'] == 1 and calls['batch'] < 200
+    for r, x0 in zip(res, X0):
+        ref = minimize(lambda p: float(f(p)[0]), x0, method='BFGS', tol=1e-9)
+        assert abs(r.fun - ref.fun) < 1e-9 and np.abs(r.x - ref.x).max() < 1e-5 and r.success, (r.fun, ref.fun)
+    assert opt.optimized_result.fun == min(r.fun for r in res) and opt.restart_results is res and abs(opt.optimized_result.fun + 0.7) < 1e-9
+    # a method without a lock-step form: optimize() per restart; settings and initial guess untouched afterwards
+    before = (dict(opt.settings), opt.initial_guess.copy())
+    res2 = opt.optimize_restarts(X0[:3], method='Nelder-Mead', maxiter=600, tol=1e-8)
+    assert len(res2) == 3 and opt.settings == before[0] and np.array_equal(opt.initial_guess, before[1])
+    assert all(abs(r_.fun + 0.7) < 1e-6 for r_ in res2)

@@ -2,7 +2,7 @@
 (qmps_energy_batch_ansatz: circuit, environment, two-site energy) for random bond dimensions, ansatz kinds, depths and batch sizes, with a third of
 the angles drawn from the special grid {0, +-pi/4, +-pi/2, pi} (product states, degenerate transfer spectra) - looking for SILENT errors:
   status 0 with an energy that differs from the oracle's although the oracle's environment is unique, or a status != 0 where it is.
-Usage: python profiles/experiments/r05/stress_energy.py [n_cases] [seed]"""
+Usage: python profiles/experiments/r05/stress_energy.py [n_cases] [seed] [solver: direct (default) | plain | squaring - round 6: 'plain' at D = 4 is env_power_d4_kernel]"""
 import sys, json, time
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -12,6 +12,7 @@ import evolve_replay as ER
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+solver = sys.argv[3] if len(sys.argv) > 3 else 'direct'
 rng = np.random.default_rng(seed)
 H = {'tfim': O.hamiltonian_matrix({'ZZ': -1.0, 'X': 1.0}), 'xxz': O.hamiltonian_matrix({'XX': 1.0, 'YY': 1.0, 'ZZ': 0.5})}
 GRID = np.array([0.0, np.pi / 4, -np.pi / 4, np.pi / 2, -np.pi / 2, np.pi])
@@ -33,6 +34,7 @@ for case in range(n_cases):
     hname = str(rng.choice(['tfim', 'xxz']))
     if D not in engines:
         engines[D] = EnergyEngine(D, 1024)
+        engines[D].set_solver(solver)
     try:
         E, it, st = engines[D].energies_from_params(kind, X, H[hname])
     except Exception as e:

@@ -70,9 +70,7 @@ def SU(params, N):
     parameterisation of SU(N) by N^2 - 1 reals.  The reference takes `SU` from xmps.spin, whose
     convention is not visible in the reference tree ("unpinned"): any onto smooth map
     gives the same optimisation problem, and the batched entry points accept unitaries directly."""
-    if N not in _GEN_CACHE:
-        _GEN_CACHE[N] = np.stack(_su_generators(N))
-    G = _GEN_CACHE[N]
+    G = _su_basis(N)
     params = np.asarray(params, dtype=float)
     if params.shape[0] != N * N - 1:
         raise ValueError(f'SU({N}) takes {N * N - 1} parameters, got {params.shape[0]}')
@@ -81,6 +79,50 @@ def SU(params, N):
 
 def U4(params):
     return SU(params, 4)
+
+
+def _su_basis(N):
+    if N not in _GEN_CACHE:
+        _GEN_CACHE[N] = np.stack(_su_generators(N))
+    return _GEN_CACHE[N]
+
+
+def extractv(U):
+    """The su(N) coordinates of a unitary: SU(extractv(U), N) == U up to a global phase (principal matrix logarithm; the generators of this
+    module's `SU`, tr G_a G_b = 2 delta_ab).  Stand-in for `xmps.spin.extractv` as `scripts/bond_dimension.py:35` uses it."""
+    from scipy.linalg import logm
+    U = np.asarray(U, dtype=complex)
+    N = U.shape[0]
+    U = U / np.linalg.det(U) ** (1.0 / N)                 # special unitary: the phase never reaches an energy
+    Hm = 2j * logm(U)                                    # U = exp(-i H / 2)
+    Hm = 0.5 * (Hm + Hm.conj().T)
+    return np.real(np.einsum('kab,ba->k', _su_basis(N), Hm)) / 2.0
+
+
+def insu2N(v):
+    """A vector of su(n) as the vector of su(2n) that generates U x 1 - the same unitary beside a new, untouched LAST qubit
+    (`xmps.spin.insu2N`, scripts/bond_dimension.py:10-12: "returns the same vector in su(2n)"): SU(insu2N(v), 2n) == kron(SU(v, n), 1_2)."""
+    v = np.asarray(v, dtype=float)
+    n = int(round(np.sqrt(len(v) + 1)))
+    if n * n - 1 != len(v):
+        raise ValueError(f'{len(v)} parameters are not su(n)')
+    Hn = np.tensordot(v, _su_basis(n), axes=1)
+    return np.real(np.einsum('kab,ba->k', _su_basis(2 * n), np.kron(Hn, np.eye(2)))) / 2.0
+
+
+def embed_bond_dimension(v, eps=4e-2):
+    """The optimum of bond dimension D as a starting point at 2 D - the `fixindices(insu2N(v))` of `scripts/bond_dimension.py:21-35, 50`:
+    v in su(2D) -> su(4D) (a new qubit beside U: `insu2N`), perturbed by eps in every coordinate ("gets away from singular points": the
+    embedded tensor A x 1 has a degenerate transfer spectrum), the new qubit swapped with the physical one so that it becomes the last BOND
+    qubit.  In THIS module's register layout (rows of U: left bond | physical, `unitary_to_tensor`) that swap acts on the OUTPUT side,
+    U' = S12 (U x 1): A'[s, (i,a), (j,b)] = A[s,i,j] delta_ab - the same iMPS, the same energy per site at eps = 0 (tests/test_host_api.py).
+    (The reference multiplies from the right, `U @ S12`, in xmps's layout of `SU` / `insu2N`, which is not in its tree; the intent - "swap makes
+    i, j have same tensor product structure" - is this embedding.)"""
+    w = insu2N(v)
+    N = int(round(np.sqrt(len(w) + 1)))
+    U = SU(w + eps, N)
+    S12 = np.kron(np.eye(N // 4), swap())
+    return extractv(S12 @ U)
 
 
 class Hamiltonian:

@@ -456,3 +456,33 @@ def test_optimize_restarts_is_the_restart_loop_in_lock_step():
     res2 = opt.optimize_restarts(X0[:3], method='Nelder-Mead', maxiter=600, tol=1e-8)
     assert len(res2) == 3 and opt.settings == before[0] and np.array_equal(opt.initial_guess, before[1])
     assert all(abs(r_.fun + 0.7) < 1e-6 for r_ in res2)
+
+
+def test_bond_dimension_embedding_keeps_the_state():
+    """`insu2N`, `extractv`, `embed_bond_dimension` (round 6): the D -> 2D hand-over of the reference's bond-dimension driver
+    (scripts/bond_dimension.py:21-35, 50; xmps.spin's versions are not in the reference tree - conventions are this module's `SU`).
+    Pinned by what the reference says they must do: insu2N(v) generates U x 1; extractv inverts SU up to a global phase (also far from the
+    identity, where the principal logarithm wraps); at eps = 0 the embedded unitary gives the tensor A x 1 - the same iMPS - and the
+    oracle's energy per site is unchanged; the reference's eps = 4e-2 moves it by a few per cent only."""
+    from qmps_amd.ground_state import SU, Hamiltonian, embed_bond_dimension, extractv, insu2N
+    rng = np.random.default_rng(21)
+    H = Hamiltonian({'XX': 1, 'YY': 1}).to_matrix()
+    for D in (2, 4):
+        for scale in (0.3, 3.0):
+            v = scale * rng.standard_normal((2 * D) ** 2 - 1)
+            U = SU(v, 2 * D)
+            assert np.abs(SU(insu2N(v), 4 * D) - np.kron(U, np.eye(2))).max() < 1e-12
+            W = SU(extractv(U), 2 * D)
+            ph = np.vdot(W, U) / abs(np.vdot(W, U))
+            assert np.abs(ph * W - U).max() < 1e-10
+            A = O.unitary_to_tensor(U[None])[0]
+            A2 = O.unitary_to_tensor(SU(embed_bond_dimension(v, eps=0.0), 4 * D)[None])[0]
+            ref = np.einsum('sij,ab->siajb', A, np.eye(2)).reshape(2, 2 * D, 2 * D)
+            ph = np.vdot(ref, A2) / abs(np.vdot(ref, A2))
+            assert np.abs(A2 - ph * ref).max() < 1e-10                      # A x 1 up to a global phase
+            e1, e2 = O.energy_closed_form(A, H), O.energy_closed_form(A2, H)
+            assert abs(e1 - e2) < 1e-10
+            e3 = O.energy_closed_form(O.unitary_to_tensor(SU(embed_bond_dimension(v), 4 * D)[None])[0], H)
+            assert abs(e3 - e1) < 0.25
+    with pytest.raises(ValueError):
+        insu2N(np.zeros(5))

@@ -85,4 +85,10 @@ __device__ __forceinline__ double fast_rcp(double t) {
   return dfma(dfma(-t, x, 1.0), x, x);
 }
 
+// v_rsq_f64 + one Newton step: relative error ~1e-16 (x > 0, finite)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  return dfma(0.5 * y, dfma(-x * y, y, 1.0), y);
+}
+
 }  // namespace qmps

@@ -40,10 +40,36 @@ __device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(
 __device__ __forceinline__ double sub_rn(double a, double b) { return __dsub_rn(a, b); }
 }  // namespace evolve_detail
 
+// The optimiser algebra below used to walk its vectors in loops of runtime length P - every iteration a dependent LDS read (~120 cycles for
+// a wave alone on its SIMD, nothing to hide it behind): ~8 such loops per BFGS iteration were 6.4 us of a 15 us pass at D = 2 (round 6,
+// phase timers of a tuning build).  Now the vectors are ZERO-PADDED to kEvolvePMax (see the start of bfgs_time_evolution) and read EIGHT
+// elements at a time - independent loads issued together, no guards: a padded term adds an exact zero - while the sums keep their order and
+// their explicitly rounded operations: the same bits as before.  (Sixteen at a time, and arrays held across phases, cost the D = 2 kernel 60
+// registers and its second wave per SIMD: 20 % at 4 096 trajectories.)
+constexpr int kEvolveChunk = 8;
+__device__ __forceinline__ void load8(const double* src, double (&v)[kEvolveChunk]) {
+#pragma unroll
+  for (int k = 0; k < kEvolveChunk; ++k) v[k] = src[k];
+}
+// acc + a[0] b[0] + a[1] b[1] + ... in this order, each product and each sum rounded
+__device__ __forceinline__ double dot_rn(const double* a, const double* b, double acc) {
+#pragma unroll
+  for (int c = 0; c < kEvolvePMax; c += kEvolveChunk) {
+    double av[kEvolveChunk], bv[kEvolveChunk];
+    load8(a + c, av);
+    load8(b + c, bv);
+#pragma unroll
+    for (int k = 0; k < kEvolveChunk; ++k) acc = __dadd_rn(acc, __dmul_rn(av[k], bv[k]));
+    __builtin_amdgcn_sched_barrier(0);      // (chunk by chunk: see above)
+  }
+  return acc;
+}
+
 template <class Eval, class RefBuild, class Sync>
 __device__ __forceinline__ void bfgs_time_evolution(const EvolveD2Args& p, int64_t t, int vl, bool writer, const BfgsLds& L, Eval evaluate,
                                                     RefBuild build_reference, Sync sync, bool ladder_in_pass) {
   using namespace evolve_detail;
+  constexpr int PM = kEvolvePMax, CH = kEvolveChunk;
   const int P = p.P, NA = p.NA, G = NA - 1, G1 = 2 * P + 1;
   const double NaN = __builtin_nan("");
   // objective and gradient of the last pass: f, and g into `gout` (LDS)
@@ -54,19 +80,34 @@ __device__ __forceinline__ void bfgs_time_evolution(const EvolveD2Args& p, int64
   };
   auto gmax_at_least = [&](const double* gt, double bound) {      // np.abs(g).max() >= bound; false with any NaN
     double m = 0.0;
-    for (int k = 0; k < P; ++k) {
-      const double v = gt[k];
-      if (v != v) return false;
-      const double a = fabs(v);
-      m = a > m ? a : m;
+    bool nan = false;
+#pragma unroll
+    for (int c = 0; c < PM; c += CH) {
+      double gv[CH];
+      load8(gt + c, gv);
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const double v = gv[k];
+        nan = nan || (v != v);
+        const double a = fabs(v);
+        m = a > m ? a : m;
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    return m >= bound;
+    return !nan && m >= bound;
   };
   auto set_identity = [&]() {
     if (vl >= 0)
       for (int b = 0; b < P; ++b) L.H[vl][b] = vl == b ? 1.0 : 0.0;
     sync();
   };
+  // zero padding of the vectors and of the rows of H up to kEvolvePMax (nothing below ever writes beyond P)
+  if (vl >= 0) {
+    for (int b = 0; b < PM; ++b) L.H[vl][b] = 0.0;
+    if (vl == 0)
+      for (int k = P; k < PM; ++k) L.X[k] = L.G[k] = L.D[k] = L.S[k] = L.Gn[k] = L.Hy[k] = 0.0;
+  }
+  sync();
   if (vl >= 0) {
     L.X[vl] = p.params[t * P + vl];
     L.D[vl] = 0.0;
@@ -87,20 +128,21 @@ __device__ __forceinline__ void bfgs_time_evolution(const EvolveD2Args& p, int64
     int nit = 0;
     while (nit < p.maxiter && active) {
       // ---- direction d = -H g (row vl by its owner), slope = g . d; not a descent direction: restart from steepest descent
-      if (vl >= 0) {
-        double acc = 0.0;
-        for (int b = 0; b < P; ++b) acc = add_rn(acc, mul_rn(L.H[vl][b], L.G[b]));
-        L.D[vl] = -acc;
-      }
+      if (vl >= 0) L.D[vl] = -dot_rn(L.H[vl], L.G, 0.0);
       sync();
-      double sl = 0.0;
-      for (int a = 0; a < P; ++a) sl = add_rn(sl, mul_rn(L.G[a], L.D[a]));
+      double sl = dot_rn(L.G, L.D, 0.0);
       if (!(sl < 0.0)) {
         set_identity();
         if (vl >= 0) L.D[vl] = -L.G[vl];
         sync();
         sl = 0.0;
-        for (int a = 0; a < P; ++a) sl = sub_rn(sl, mul_rn(L.G[a], L.G[a]));
+#pragma unroll
+        for (int c = 0; c < PM; c += CH) {
+          double gv[CH];
+          load8(L.G + c, gv);
+#pragma unroll
+          for (int k = 0; k < CH; ++k) sl = sub_rn(sl, mul_rn(gv[k], gv[k]));
+        }
       }
       // ---- the full step with its gradient; the rest of the ladder in the same pass where the candidates fit (its values are used
       // only on rejection), else in a pass of its own when the full step is rejected
@@ -122,21 +164,25 @@ __device__ __forceinline__ void bfgs_time_evolution(const EvolveD2Args& p, int64
       }
       int first = -1, best = 0;
       double Fbest = F0, Ffirst = 0.0;
-      for (int r = 0; r < NA; ++r) {
-        double Fr = F0;
-        if (r > 0) {
-          const double v = (need && L.OK[G1 + r - 1]) ? L.F[G1 + r - 1] : NaN;
-          Fr = (v == v && fabs(v) != INFINITY) ? v : INFINITY;
+      if (need) {                   // (an accepted full step - the usual case - needs no look at the ladder: first = best = 0)
+        for (int r = 0; r < NA; ++r) {
+          double Fr = F0;
+          if (r > 0) {
+            const double v = L.OK[G1 + r - 1] ? L.F[G1 + r - 1] : NaN;
+            Fr = (v == v && fabs(v) != INFINITY) ? v : INFINITY;
+          }
+          if (first < 0 && Fr <= add_rn(f, mul_rn(mul_rn(p.c1, p.alphas[r]), sl))) { first = r; Ffirst = Fr; }
+          if (Fr < Fbest) { Fbest = Fr; best = r; }
         }
-        if (first < 0 && Fr <= add_rn(f, mul_rn(mul_rn(p.c1, p.alphas[r]), sl))) { first = r; Ffirst = Fr; }
-        if (Fr < Fbest) { Fbest = Fr; best = r; }
+        if (first < 0) { first = best; Ffirst = Fbest; }
+      } else {
+        first = 0;
+        Ffirst = F0;
       }
-      if (first < 0) { first = best; Ffirst = Fbest; }
       const bool moved = Ffirst < f;
       const double a_step = moved ? p.alphas[first] : 0.0;
-      sync();                       // (every thread has read F / OK of this pass before anything overwrites them)
       if (vl >= 0) L.S[vl] = mul_rn(a_step, L.D[vl]);
-      sync();
+      sync();                       // (S visible; and every thread has read F / OK of this pass before the next pass overwrites them)
       double fn = fs;
       if (need && moved) {
         // the accepted point is a shorter rung: its objective and gradient (x + s = x + alpha_first d)
@@ -144,38 +190,65 @@ __device__ __forceinline__ void bfgs_time_evolution(const EvolveD2Args& p, int64
         read_fg(fn, L.Gn);
       }
       if (moved) {
-        // ---- rank-two update of the inverse Hessian (curvature guard as scipy), then accept
-        double sy = 0.0, ss = 0.0, yy = 0.0;
-        for (int k = 0; k < P; ++k) {
-          const double y = sub_rn(L.Gn[k], L.G[k]);
-          sy = add_rn(sy, mul_rn(L.S[k], y));
-          ss = add_rn(ss, mul_rn(L.S[k], L.S[k]));
-          yy = add_rn(yy, mul_rn(y, y));
-        }
-        if (sy > 1e-12 * sqrt(mul_rn(ss, yy)) && sy > 0.0) {
-          const double rho = 1.0 / sy;
-          if (vl >= 0) {
-            double acc = 0.0;
-            for (int b = 0; b < P; ++b) acc = add_rn(acc, mul_rn(L.H[vl][b], sub_rn(L.Gn[b], L.G[b])));
-            L.Hy[vl] = acc;
+        // ---- rank-two update of the inverse Hessian (curvature guard as scipy), then accept.  Two barriers: before the first every thread has
+        // s.y, s.s, y.y (y = Gn - G formed on the fly) and the owners H y; behind it the owners accept (G <- Gn, X <- X + S) and publish H y
+        // and y (parked in D, which is dead until the next direction); behind the second come y.Hy, the rows of H and the convergence test
+        // on the new G.  (Round 5 had five barriers here and read its vectors element by element.)
+        double sy = 0.0, ss = 0.0, yy = 0.0, hy_own = 0.0;
+        const double* hrow = L.H[vl >= 0 ? vl : 0];      // (threads without a row walk row 0 and store nothing: no branch inside the chunks)
+#pragma nounroll      // (the two chunks as a LOOP: unrolled, the register allocation of the whole kernel went from 218 to 256 + 17)
+        for (int c = 0; c < PM; c += CH) {
+          double sv[CH], gn[CH], gv[CH], hv[CH];
+          load8(L.S + c, sv);
+          load8(L.Gn + c, gn);
+          load8(L.G + c, gv);
+          load8(hrow + c, hv);
+#pragma unroll
+          for (int k = 0; k < CH; ++k) {
+            const double y = sub_rn(gn[k], gv[k]);
+            sy = add_rn(sy, mul_rn(sv[k], y));
+            ss = add_rn(ss, mul_rn(sv[k], sv[k]));
+            yy = add_rn(yy, mul_rn(y, y));
+            hy_own = add_rn(hy_own, mul_rn(hv[k], y));
           }
-          sync();
-          double yHy = 0.0;
-          for (int a = 0; a < P; ++a) yHy = add_rn(yHy, mul_rn(sub_rn(L.Gn[a], L.G[a]), L.Hy[a]));
-          const double coef = mul_rn(rho, add_rn(1.0, mul_rn(rho, yHy)));
-          if (vl >= 0) {
-            const int a = vl;
-            for (int b = 0; b < P; ++b)
-              L.H[a][b] = add_rn(sub_rn(L.H[a][b], add_rn(mul_rn(mul_rn(rho, L.S[a]), L.Hy[b]), mul_rn(mul_rn(rho, L.S[b]), L.Hy[a]))), mul_rn(mul_rn(coef, L.S[a]), L.S[b]));
-          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        sync();                     // (every thread has read G / Gn / S of this iteration)
+        const bool curv = sy > 1e-12 * sqrt(mul_rn(ss, yy)) && sy > 0.0;
+        double xnew = 0.0, gnew = 0.0, ynew = 0.0, sa = 0.0;
+        if (vl >= 0) {
+          sa = L.S[vl];
+          xnew = add_rn(L.X[vl], sa);
+          gnew = L.Gn[vl];
+          ynew = sub_rn(gnew, L.G[vl]);
+        }
+        sync();                     // (every thread has read what it needs of S, G, Gn of this iteration)
         f = fn;
         if (vl >= 0) {
-          L.G[vl] = L.Gn[vl];
-          L.X[vl] = add_rn(L.X[vl], L.S[vl]);
+          L.G[vl] = gnew;
+          L.X[vl] = xnew;
+          L.D[vl] = ynew;
+          if (curv) L.Hy[vl] = hy_own;
         }
         sync();
+        if (curv) {
+          const double rho = 1.0 / sy;
+          const double yHy = dot_rn(L.D, L.Hy, 0.0);
+          const double coef = mul_rn(rho, add_rn(1.0, mul_rn(rho, yHy)));
+          if (vl >= 0) {
+            const double hya = hy_own;      // (Hy[vl]: this thread's own)
+#pragma nounroll
+            for (int c = 0; c < PM; c += CH) {
+              double hv[CH], hy[CH], sv[CH];
+              load8(L.H[vl] + c, hv);
+              load8(L.Hy + c, hy);
+              load8(L.S + c, sv);
+#pragma unroll
+              for (int k = 0; k < CH; ++k)      // (no guard: a padded column has hv = hy = sv = 0 and stays 0)
+                L.H[vl][c + k] = add_rn(sub_rn(hv[k], add_rn(mul_rn(mul_rn(rho, sa), hy[k]), mul_rn(mul_rn(rho, sv[k]), hya))), mul_rn(mul_rn(coef, sa), sv[k]));
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
       }
       active = moved && gmax_at_least(L.G, p.gtol);
       ++nit;

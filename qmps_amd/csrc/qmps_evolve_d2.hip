@@ -112,6 +112,7 @@ __device__ __forceinline__ void overlap_quad_solve(const double2* sC, const doub
     for (int c = 0; c < 4; ++c) f = dfma(nr[c], nr[c], dfma(ni[c], ni[c], f));
     return quad_sum(f);
   };
+  constexpr int kFirstTest = 3;
   double m2 = 0.0;      // ||M||_F^2: computed for the first power, 1 afterwards
 #pragma unroll
   for (int c = 0; c < 4; ++c) m2 = dfma(mr[c], mr[c], dfma(mi[c], mi[c], m2));
@@ -119,62 +120,70 @@ __device__ __forceinline__ void overlap_quad_solve(const double2* sC, const doub
   for (int m = 0; m <= max_rounds; ++m) {
     double nr[4], ni[4], f2 = 0.0;
     if (!done) {
-      // dominant right vector = largest column of the current power; v[a] in lane a
-      int bc = 0;
-      double best = -1.0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const double n2 = quad_sum(dfma(mr[c], mr[c], mi[c] * mi[c]));
-        if (n2 > best) { best = n2; bc = c; }
-      }
-      double vr = 0.0, vi = 0.0;          // (a sum of selects against zero: a select between array elements becomes a dynamic index - scratch)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        vr += bc == c ? mr[c] : 0.0;
-        vi += bc == c ? mi[c] : 0.0;
-      }
-      // w = E v, eta = <v, w>/<v, v>, residual
-      double wr = 0.0, wi = 0.0;
-      {
-        const double v0r = quad_bcast<0>(vr), v0i = quad_bcast<0>(vi), v1r = quad_bcast<1>(vr), v1i = quad_bcast<1>(vi);
-        const double v2r = quad_bcast<2>(vr), v2i = quad_bcast<2>(vi), v3r = quad_bcast<3>(vr), v3i = quad_bcast<3>(vi);
-        wr = dfma(er[0], v0r, dfma(-ei[0], v0i, wr)); wi = dfma(er[0], v0i, dfma(ei[0], v0r, wi));
-        wr = dfma(er[1], v1r, dfma(-ei[1], v1i, wr)); wi = dfma(er[1], v1i, dfma(ei[1], v1r, wi));
-        wr = dfma(er[2], v2r, dfma(-ei[2], v2i, wr)); wi = dfma(er[2], v2i, dfma(ei[2], v2r, wi));
-        wr = dfma(er[3], v3r, dfma(-ei[3], v3i, wr)); wi = dfma(er[3], v3i, dfma(ei[3], v3r, wi));
-      }
-      const double num_r = quad_sum(dfma(vr, wr, vi * wi)), num_i = quad_sum(dfma(vr, wi, -vi * wr)), vv = quad_sum(dfma(vr, vr, vi * vi));
-      eta_r = num_r / vv;
-      eta_i = num_i / vv;
-      const double dr = wr - (eta_r * vr - eta_i * vi), di = wi - (eta_r * vi + eta_i * vr);
-      const double res = quad_sum(dfma(dr, dr, di * di));
-      rounds = m;
-      // the square: the next power - and the two tests the eigen-residual of a column cannot make (overlap_lane_solve, qmps_overlap_d2.h):
-      // has the power COLLAPSED to rounding noise (a nilpotent map), and - only looked at once the column passes - is the power RANK ONE
-      // (at symmetric points a column of an early power is an exact eigenvector of a LESSER eigenvalue)?
+      // the square first: the next power, and the test for a COLLAPSED power (a nilpotent map: rounding noise) it carries
       f2 = square(mr, mi, nr, ni);
+      rounds = m;
       if (f2 < 1e-28 * m2 * m2) {
         if (m <= 8) { eta_r = 0.0; eta_i = 0.0; status = QMPS_ST_OK; }
         collapsed = true;
         done = true;
-      } else if (res < tol2 * vv) {
-        double dgr = 0.0, dgi = 0.0;      // tr(M): the diagonal element of row q is column q
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { dgr += q == c ? mr[c] : 0.0; dgi += q == c ? mi[c] : 0.0; }
-        const double trr = quad_sum(dgr), tri = quad_sum(dgi);
-        double r1 = 0.0;
+      } else if (m >= kFirstTest || m == max_rounds) {
+        // (rounds 0 .. kFirstTest - 1 skip the eigen-residual test - 135 of a round's 420 instructions: a map of the time-evolution
+        // objective needs 5 - 10 squarings at tol 1e-12; one that would have passed earlier squares on to round kFirstTest, harmlessly)
+        // dominant right vector = largest column of the current power; v[a] in lane a
+        int bc = 0;
+        double best = -1.0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const double xr = nr[c] - (trr * mr[c] - tri * mi[c]), xi = ni[c] - (trr * mi[c] + tri * mr[c]);
-          r1 = dfma(xr, xr, dfma(xi, xi, r1));
+          const double n2 = quad_sum(dfma(mr[c], mr[c], mi[c] * mi[c]));
+          if (n2 > best) { best = n2; bc = c; }
         }
-        if (quad_sum(r1) < 1e-20 * f2) { status = QMPS_ST_OK; done = true; }
+        double vr = 0.0, vi = 0.0;          // (a sum of selects against zero: a select between array elements becomes a dynamic index - scratch)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          vr += bc == c ? mr[c] : 0.0;
+          vi += bc == c ? mi[c] : 0.0;
+        }
+        // w = E v, eta = <v, w>/<v, v>, residual
+        double wr = 0.0, wi = 0.0;
+        {
+          const double v0r = quad_bcast<0>(vr), v0i = quad_bcast<0>(vi), v1r = quad_bcast<1>(vr), v1i = quad_bcast<1>(vi);
+          const double v2r = quad_bcast<2>(vr), v2i = quad_bcast<2>(vi), v3r = quad_bcast<3>(vr), v3i = quad_bcast<3>(vi);
+          wr = dfma(er[0], v0r, dfma(-ei[0], v0i, wr)); wi = dfma(er[0], v0i, dfma(ei[0], v0r, wi));
+          wr = dfma(er[1], v1r, dfma(-ei[1], v1i, wr)); wi = dfma(er[1], v1i, dfma(ei[1], v1r, wi));
+          wr = dfma(er[2], v2r, dfma(-ei[2], v2i, wr)); wi = dfma(er[2], v2i, dfma(ei[2], v2r, wi));
+          wr = dfma(er[3], v3r, dfma(-ei[3], v3i, wr)); wi = dfma(er[3], v3i, dfma(ei[3], v3r, wi));
+        }
+        const double num_r = quad_sum(dfma(vr, wr, vi * wi)), num_i = quad_sum(dfma(vr, wi, -vi * wr)), vv = quad_sum(dfma(vr, vr, vi * vi));
+        // (v_rcp_f64 + one Newton step instead of two IEEE divisions: ~25 dependent instructions off the critical path of every round; 1e-16 relative)
+        const double ivv = fast_rcp(vv);
+        eta_r = num_r * ivv;
+        eta_i = num_i * ivv;
+        const double dr = wr - (eta_r * vr - eta_i * vi), di = wi - (eta_r * vi + eta_i * vr);
+        const double res = quad_sum(dfma(dr, dr, di * di));
+        // ... and, only looked at once the column passes: is the power RANK ONE (at symmetric points a column of an early power is an exact
+        // eigenvector of a LESSER eigenvalue: overlap_lane_solve, qmps_overlap_d2.h)?
+        if (res < tol2 * vv) {
+          double dgr = 0.0, dgi = 0.0;      // tr(M): the diagonal element of row q is column q
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { dgr += q == c ? mr[c] : 0.0; dgi += q == c ? mi[c] : 0.0; }
+          const double trr = quad_sum(dgr), tri = quad_sum(dgi);
+          double r1 = 0.0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const double xr = nr[c] - (trr * mr[c] - tri * mi[c]), xi = ni[c] - (trr * mi[c] + tri * mr[c]);
+            r1 = dfma(xr, xr, dfma(xi, xi, r1));
+          }
+          if (quad_sum(r1) < 1e-20 * f2) { status = QMPS_ST_OK; done = true; }
+        }
       }
       if (m == max_rounds) done = true;
     }
     if (__builtin_amdgcn_ballot_w64(!done) == 0) break;        // (the quads of a wave leave together)
     if (!done) {
-      const double inv = 1.0 / __builtin_sqrt(f2);              // Frobenius-normalise the square
+      // Frobenius-normalise the square - to rounding: the scale only keeps the powers O(1), v_rsq_f64 + one Newton step (1e-16) replaces a
+      // square root and a division (~30 dependent instructions per round)
+      const double inv = fast_rsqrt(f2);
 #pragma unroll
       for (int c = 0; c < 4; ++c) { mr[c] = nr[c] * inv; mi[c] = ni[c] * inv; }
       m2 = 1.0;
@@ -218,8 +227,16 @@ __global__ __launch_bounds__(256) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
   const double2* W = (const double2*)p.WW;
   if (tid < 4) sCnt[tid] = 0.0;
   // ---- one evaluation pass.  Candidate c = tid / 4: c < G1 = 2P + 1 the central-difference columns of z = x + coef d; [G1, G1 + n_ladder): x + alpha_{r+1} d
+#ifdef QMPS_D2_PHASES
+  long long ph[6] = {0, 0, 0, 0, 0, 0};      // thread 0: sincos + barrier | circuit | matrix build + solve | closing barrier | passes | total
+  const long long k0 = wall_clock64();
+#define QMPS_TICK(var) const long long var = wall_clock64()
+#else
+#define QMPS_TICK(var)
+#endif
   auto evaluate = [&](double coef, int n_ladder) {
     const int G1 = 2 * P + 1, cand = tid >> 2, q = tid & 3;
+    QMPS_TICK(t0);
     const bool grad = cand < G1, ladder = !grad && cand < G1 + n_ladder;
     // cos / sin of every (scaled) angle ONCE per pass, shared through LDS (a double-precision sincos costs more than a two-qubit layer):
     // the P angles of the base point by threads 0 .. P - 1, the n_ladder P angles of the backtracking points spread over the workgroup
@@ -237,6 +254,10 @@ __global__ __launch_bounds__(256) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
       sLCS[r * PMAX + l] = make_double2(cs_, sn);
     }
     __syncthreads();
+    QMPS_TICK(t1);
+#ifdef QMPS_D2_PHASES
+    long long t2 = t1, t3 = t1;
+#endif
     if (grad || ladder) {
       const int isel = (grad && cand > 0) ? (cand - 1) % P : -1;
       double amp_r[4] = {0, 0, 0, 0}, amp_i[4] = {0, 0, 0, 0};
@@ -265,7 +286,13 @@ __global__ __launch_bounds__(256) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
       }
       double er, ei;
       int rounds, status;
+#ifdef QMPS_D2_PHASES
+      t2 = wall_clock64();
+#endif
       overlap_quad_solve(sC, amp_r, amp_i, q, p.max_rounds, p.tol, er, ei, rounds, status);
+#ifdef QMPS_D2_PHASES
+      t3 = wall_clock64();
+#endif
       if (q == 0) {
         sF[cand] = -__builtin_sqrt(__builtin_sqrt(er * er + ei * ei));
         sOK[cand] = status == QMPS_ST_OK ? 1 : 0;
@@ -274,6 +301,9 @@ __global__ __launch_bounds__(256) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
       }
     }
     __syncthreads();
+#ifdef QMPS_D2_PHASES
+    { const long long t4 = wall_clock64(); ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += 1; }
+#endif
     if (tid == 0) sCnt[0] += (double)(G1 + n_ladder);
   };
   BfgsLds L;
@@ -322,6 +352,13 @@ __global__ __launch_bounds__(256) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
   __syncthreads();
   bfgs_time_evolution(p, t, tid < P ? tid : -1, tid == 0, L, evaluate, build_reference, [] { __syncthreads(); }, true);
   __syncthreads();
+#ifdef QMPS_D2_PHASES
+  if (tid == 0 && p.prof != nullptr) {
+    ph[5] = wall_clock64() - k0;
+    p.prof[t * 8 + 0] = (double)ph[5]; p.prof[t * 8 + 1] = (double)ph[0]; p.prof[t * 8 + 2] = (double)ph[2]; p.prof[t * 8 + 3] = (double)ph[1];
+    p.prof[t * 8 + 4] = (double)ph[3]; p.prof[t * 8 + 5] = (double)(ph[5] - ph[0] - ph[1] - ph[2] - ph[3]); p.prof[t * 8 + 6] = (double)ph[4]; p.prof[t * 8 + 7] = sCnt[1];
+  }
+#endif
   if (tid == 0) {
     if (p.nfev != nullptr) p.nfev[t] = sCnt[0];
     if (p.rounds != nullptr) p.rounds[t] = sCnt[1];

@@ -167,6 +167,9 @@ extern "C" {
  *                         in kernels on device-resident state with the host enqueueing chains of iterations.  Same numbers, bit for bit.
  *   QMPS_NO_KRYLOV        D = 8, 16 fixed-point solves: the power method alone, to max_rounds (same results wherever it converges;
  *                         ~1/(1 - |eta_2 / eta_1|) steps)
+ *   QMPS_EVOLVE_D2_SQUARING  qmps_evolve_bfgs_device at D = 2: the eigenvalue of every candidate's 4 x 4 map by squaring the map until rank one
+ *                         (rounds 4-5: log2(28 / gap) rounds) instead of as the largest root of its characteristic polynomial (round 6: one product, the
+ *                         four roots by Aberth's iteration, a root per lane - the same eta to ~1e-15 |eta| / gap, whatever the gap)
  *   QMPS_POWER_LANE       D = 4, QMPS_ENV_POWER: one LANE per evaluation (rounds 1-5: a wave waits for the slowest of its 64 evaluations)
  *                         instead of a DPP quad per evaluation in persistent waves that draw their evaluations from a work counter
  *                         (round 6; same iterates, same iteration counts and statuses; energies to rounding)

@@ -698,6 +698,7 @@ int qmps_evolve_bfgs_device(qmps_ctx* c, int64_t T, int kind, int n_params, doub
   a.carry_in = carry_in ? 1 : 0; a.carry = carry ? 1 : 0; a.gtol = gtol; a.h = h; a.c1 = c1; a.tol = tol;
   for (int r = 0; r < NA; ++r) a.alphas[r] = alphas[r];
   if (const char* e = tuning_knob("QMPS_EVOLVE_PROBE")) a.probe = atoi(e);
+  if (documented_switch("QMPS_EVOLVE_D2_SQUARING")) a.probe |= 4;      // D = 2: the eigen-solves of the device-resident driver by squaring (rounds 4-5) instead of the characteristic polynomial
   double* d_prof = nullptr;
   if ((c->D == 16 || c->D == 2) && tuning_knob("QMPS_EVOLVE_PROF")) {      // (tuning builds: phase timers of the D = 16 kernel - and with -DQMPS_D2_PHASES of the D = 2 one: total | sincos | solve | circuit | closing barrier | optimiser algebra | passes | squarings - printed below)
     HIP_TRY(hipMalloc((void**)&d_prof, (size_t)T * 8 * sizeof(double)));

@@ -44,15 +44,13 @@ using evolve_detail::mul_rn;
 // dependent chain of ~6 squarings, here a squaring is 16 complex multiply-adds per lane and the rows travel by quad broadcasts).
 //   amp_r / amp_i: lanes 0, 1 of the quad hold the four amplitudes of column 0 / 1 of the candidate's unitary (B[s][i][k] = amplitude 2 i + s of column k)
 //   sC: C_s[i][j] of the trajectory's reference tensor, [s][i][j] in LDS.  Results uniform over the quad.
-__device__ __forceinline__ void overlap_quad_solve(const double2* sC, const double (&amp_r)[4], const double (&amp_i)[4], int q, int max_rounds, double tol,
-                                                   double& eta_r, double& eta_i, int& rounds, int& status) {
+__device__ __forceinline__ void overlap_quad_build(const double2* sC, const double (&amp_r)[4], const double (&amp_i)[4], int q, double (&er)[4], double (&ei)[4]) {
   const int i = q >> 1, ip = q & 1;
   // the candidate's tensor by quad broadcasts: B[s][i][k] = amplitude 2 i + s of column k (lane k).  (No array of broadcast values:
   // a select between two elements of a private array becomes a dynamically indexed load - scratch.)
   auto Bre = [&](int s, int i_, int k) { return k == 0 ? quad_bcast<0>(amp_r[2 * i_ + s]) : quad_bcast<1>(amp_r[2 * i_ + s]); };
   auto Bim = [&](int s, int i_, int k) { return k == 0 ? quad_bcast<0>(amp_i[2 * i_ + s]) : quad_bcast<1>(amp_i[2 * i_ + s]); };
   // row a = (i, i') of E
-  double er[4], ei[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) er[c] = ei[c] = 0.0;
 #pragma unroll
@@ -84,6 +82,11 @@ __device__ __forceinline__ void overlap_quad_solve(const double2* sC, const doub
       }
     }
   }
+}
+
+// the dominant eigenvalue of the quad's 4 x 4 map (row q in er / ei) by SQUARING (see above; QMPS_EVOLVE_D2_SQUARING selects it since round 6)
+__device__ __forceinline__ void overlap_quad_solve(const double (&er)[4], const double (&ei)[4], int q, int max_rounds, double tol,
+                                                   double& eta_r, double& eta_i, int& rounds, int& status) {
   double mr[4], mi[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) { mr[c] = er[c]; mi[c] = ei[c]; }
@@ -214,6 +217,194 @@ __device__ __forceinline__ void overlap_quad_solve(const double2* sC, const doub
   }
 }
 
+// ---- the same eigenvalue WITHOUT iterating on the map: the largest root of its characteristic polynomial (round 6).
+// The squaring solve needs log2(28 / gap) rounds - 6 for a typical map of the time-evolution objective, 10 - 11 for the trajectory with the smallest
+// spectral gap, and the slowest trajectory IS a launch of this kernel (phase timers: 8.1 of its 13.1 us per pass).  A 4 x 4 map has a quartic:
+//   p_k = tr E^k, k = 1 .. 4, from ONE product (E^2 by quad broadcasts; tr E^3 = sum E^2[q][c] E[c][q], tr E^4 = sum E^2[q][c] E^2[c][q]: the transposed
+//   elements through the quad's LDS scratch), Newton's identities -> e_1 .. e_4, P(z) = z^4 - e_1 z^3 + e_2 z^2 - e_3 z + e_4;
+//   its four roots by the Aberth - Ehrlich iteration, ONE ROOT PER LANE of the quad (the other three by quad rotations), started on the circle
+//   of radius |P(c)|^(1/4) round the centroid c = e_1 / 4: cubic convergence, 6 - 10 iterations whatever the gap;
+//   eta = the root of largest modulus.
+// What the objective -sqrt|eta| needs and nothing more: no eigenvector (the lane solver of the C-ABI's D = 2 overlap entry points keeps the squaring:
+// it owes its callers r_out).  Tied moduli (a complex-conjugate pair, a ring) are distinct simple roots - no special path; a nilpotent map has
+// P = z^4: eta = 0.  Conditioning: the coefficients carry ~1e-16 |eta|^k, a simple dominant root moves by 1e-16 |eta| / prod_j |1 - eta_j / eta|
+// (2e-15 at a gap of 0.05); a DOUBLE dominant root only by sqrt(eps) ~ 1e-8 of its modulus (the squaring's Gelfand route: 1e-11) - a point set of
+// measure zero that the trajectories of the stress runs never met.  E is scaled to unit Frobenius norm first.
+// sT: 32 double2 of LDS per quad.  rounds = Aberth iterations.
+__device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], const double (&ei)[4], int q, double2* sT, double& eta_r, double& eta_i,
+                                                      int& rounds, int& status) {
+  status = QMPS_ST_OK;
+  rounds = 0;
+  eta_r = eta_i = 0.0;
+  double m2 = 0.0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) m2 = dfma(er[c], er[c], dfma(ei[c], ei[c], m2));
+  m2 = quad_sum(m2);
+  const bool zero = !(m2 > 1e-300);                 // (uniform over the quad; a NaN map falls through and ends as NaN)
+  const double sc = zero ? 0.0 : fast_rsqrt(m2);
+  double xr[4], xi[4], nr[4], ni[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { xr[c] = er[c] * sc; xi[c] = ei[c] * sc; }
+  // row q of X X (X = E / ||E||_F)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) nr[c] = ni[c] = 0.0;
+#define QMPS_ROW(K)                                                                                            \
+  {                                                                                                            \
+    const double ar = xr[K], ai = xi[K];                                                                       \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                            \
+      const double kr = quad_bcast<K>(xr[c]), ki = quad_bcast<K>(xi[c]);                                       \
+      nr[c] = dfma(ar, kr, dfma(-ai, ki, nr[c]));                                                              \
+      ni[c] = dfma(ar, ki, dfma(ai, kr, ni[c]));                                                               \
+    }                                                                                                          \
+  }
+  QMPS_ROW(0) QMPS_ROW(1) QMPS_ROW(2) QMPS_ROW(3)
+#undef QMPS_ROW
+  // columns through the quad's scratch (wave-private: LDS is in order per wave)
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    sT[q * 4 + c] = make_double2(xr[c], xi[c]);
+    sT[16 + q * 4 + c] = make_double2(nr[c], ni[c]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  double p1r, p1i, p2r, p2i, p3r = 0.0, p3i = 0.0, p4r = 0.0, p4i = 0.0;
+  {
+    const double2 d1 = sT[q * 5], d2 = sT[16 + q * 5];        // the diagonal elements of row q
+    p1r = quad_sum(d1.x); p1i = quad_sum(d1.y);
+    p2r = quad_sum(d2.x); p2i = quad_sum(d2.y);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double2 a = sT[c * 4 + q], b = sT[16 + c * 4 + q];   // X[c][q], X^2[c][q]
+      p3r = dfma(nr[c], a.x, dfma(-ni[c], a.y, p3r)); p3i = dfma(nr[c], a.y, dfma(ni[c], a.x, p3i));
+      p4r = dfma(nr[c], b.x, dfma(-ni[c], b.y, p4r)); p4i = dfma(nr[c], b.y, dfma(ni[c], b.x, p4i));
+    }
+    p3r = quad_sum(p3r); p3i = quad_sum(p3i); p4r = quad_sum(p4r); p4i = quad_sum(p4i);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // Newton's identities: e1 = p1, 2 e2 = e1 p1 - p2, 3 e3 = e2 p1 - e1 p2 + p3, 4 e4 = e3 p1 - e2 p2 + e1 p3 - p4
+  auto cmul_r = [](double ar, double ai, double br, double bi) { return dfma(ar, br, -ai * bi); };
+  auto cmul_i = [](double ar, double ai, double br, double bi) { return dfma(ar, bi, ai * br); };
+  const double e1r = p1r, e1i = p1i;
+  const double e2r = 0.5 * (cmul_r(e1r, e1i, p1r, p1i) - p2r), e2i = 0.5 * (cmul_i(e1r, e1i, p1r, p1i) - p2i);
+  const double e3r = (cmul_r(e2r, e2i, p1r, p1i) - cmul_r(e1r, e1i, p2r, p2i) + p3r) * (1.0 / 3.0);
+  const double e3i = (cmul_i(e2r, e2i, p1r, p1i) - cmul_i(e1r, e1i, p2r, p2i) + p3i) * (1.0 / 3.0);
+  const double e4r = 0.25 * (cmul_r(e3r, e3i, p1r, p1i) - cmul_r(e2r, e2i, p2r, p2i) + cmul_r(e1r, e1i, p3r, p3i) - p4r);
+  const double e4i = 0.25 * (cmul_i(e3r, e3i, p1r, p1i) - cmul_i(e2r, e2i, p2r, p2i) + cmul_i(e1r, e1i, p3r, p3i) - p4i);
+  // P(z) and P'(z) by Horner
+  auto poly = [&](double zr, double zi, double& Pr, double& Pi, double& dr, double& di) {
+    double ar = zr - e1r, ai = zi - e1i;                                   // z - e1
+    double br = 4.0 * zr - 3.0 * e1r, bi = 4.0 * zi - 3.0 * e1i;           // 4 z - 3 e1
+    double tr = cmul_r(ar, ai, zr, zi) + e2r, ti = cmul_i(ar, ai, zr, zi) + e2i;
+    double ur = cmul_r(br, bi, zr, zi) + 2.0 * e2r, ui = cmul_i(br, bi, zr, zi) + 2.0 * e2i;
+    ar = cmul_r(tr, ti, zr, zi) - e3r; ai = cmul_i(tr, ti, zr, zi) - e3i;
+    dr = cmul_r(ur, ui, zr, zi) - e3r; di = cmul_i(ur, ui, zr, zi) - e3i;
+    Pr = cmul_r(ar, ai, zr, zi) + e4r; Pi = cmul_i(ar, ai, zr, zi) + e4i;
+  };
+  // ---- starting points.  Lane 0: the power-sum quotient p4 / p3 (the dominant root up to O((eta_2 / eta_1)^3) when there is one); lanes 1 - 3: a
+  // circle round the centroid of the cubic that is left when that estimate is divided out, of radius |Q(centroid)|^(1/3).  When p3 is too small for
+  // the quotient to mean anything (a spectrum symmetric under z -> -z ...): all four on the circle of radius |P(c)|^(1/4) round c = e1 / 4.
+  double zr, zi;
+  {
+    const double n3 = dfma(p3r, p3r, p3i * p3i), n4 = dfma(p4r, p4r, p4i * p4i);
+    const bool informed = n3 > 1e-12 && n4 < 4.0 * n3;              // (|p4 / p3| <= 2 in units of ||E||_F: a quotient inside the spectrum's disc)
+    const double i3 = informed ? fast_rcp(n3) : 0.0;
+    const double ar = dfma(p4r, p3r, p4i * p3i) * i3, ai = dfma(p4i, p3r, -p4r * p3i) * i3;      // p4 / p3
+    // Q(z) = z^3 + b2 z^2 + b1 z + b0 = P(z) / (z - a), approximately
+    const double b2r = ar - e1r, b2i = ai - e1i;
+    const double b1r = e2r + cmul_r(ar, ai, b2r, b2i), b1i = e2i + cmul_i(ar, ai, b2r, b2i);
+    const double b0r = -e3r + cmul_r(ar, ai, b1r, b1i), b0i = -e3i + cmul_i(ar, ai, b1r, b1i);
+    const double c3r = -b2r * (1.0 / 3.0), c3i = -b2i * (1.0 / 3.0);
+    double Qr, Qi;
+    {
+      double tr = c3r + b2r, ti = c3i + b2i;
+      double ur = cmul_r(tr, ti, c3r, c3i) + b1r, ui = cmul_i(tr, ti, c3r, c3i) + b1i;
+      Qr = cmul_r(ur, ui, c3r, c3i) + b0r;
+      Qi = cmul_i(ur, ui, c3r, c3i) + b0i;
+    }
+    const double rad3 = cbrt(__builtin_sqrt(dfma(Qr, Qr, Qi * Qi)));
+    const double c4r = 0.25 * e1r, c4i = 0.25 * e1i;
+    double Pr, Pi, dr, di;
+    poly(c4r, c4i, Pr, Pi, dr, di);
+    const double rad4 = __builtin_sqrt(__builtin_sqrt(__builtin_sqrt(dfma(Pr, Pr, Pi * Pi))));      // |P(c)|^(1/4)
+    // unit vectors: e^(i (0.7 + q pi / 2)) for the circle of four, e^(i (0.7 + 2 (q - 1) pi / 3)) for the circle of three
+    const double u4x = q == 0 ? 0.7648421872844885 : (q == 1 ? -0.644217687237691 : (q == 2 ? -0.7648421872844885 : 0.644217687237691));
+    const double u4y = q == 0 ? 0.644217687237691 : (q == 1 ? 0.7648421872844885 : (q == 2 ? -0.644217687237691 : -0.7648421872844885));
+    const double u3x = q == 1 ? 0.7648421872844885 : (q == 2 ? -0.9403308102168177 : 0.17548862293232925);
+    const double u3y = q == 1 ? 0.644217687237691 : (q == 2 ? 0.34026400880486145 : -0.9844816960425524);
+    if (informed) {
+      zr = q == 0 ? ar : dfma(rad3, u3x, c3r);
+      zi = q == 0 ? ai : dfma(rad3, u3y, c3i);
+    } else {
+      zr = dfma(rad4, u4x, c4r);
+      zi = dfma(rad4, u4y, c4i);
+    }
+  }
+  // ---- Aberth - Ehrlich.  Only the root of LARGEST modulus has to be converged, the others only far enough to be ranked below it: the iteration
+  // of a quad is over when its largest root has settled (step < 1e-14 of its modulus) and every other root either has settled too (tied moduli) or
+  // sits, with four times its last step, inside the largest one's circle.  (Small roots settle slowly in RELATIVE terms - a root at zero never -
+  // and are not wanted.)
+  bool fin = false;
+  double prev_s2 = 1e300;
+  for (int it = 0; it < 40; ++it) {
+    double Pr, Pi, dr, di;
+    poly(zr, zi, Pr, Pi, dr, di);
+    const double dn = dfma(dr, dr, di * di);
+    const double idn = dn > 0.0 ? fast_rcp(dn) : 0.0;
+    const double wr = dfma(Pr, dr, Pi * di) * idn, wi = dfma(Pi, dr, -Pr * di) * idn;      // P / P'
+    double sr = 0.0, si = 0.0;                                                             // sum_j 1 / (z - z_j) over the other three lanes
+#define QMPS_OTHER(CTRL)                                                                                       \
+    {                                                                                                          \
+      const double xr_ = zr - quad_perm<CTRL>(zr), xi_ = zi - quad_perm<CTRL>(zi);                            \
+      const double n_ = dfma(xr_, xr_, xi_ * xi_);                                                             \
+      const double in_ = n_ > 0.0 ? fast_rcp(n_) : 0.0;                                                       \
+      sr = dfma(xr_, in_, sr);                                                                                 \
+      si = dfma(-xi_, in_, si);                                                                                \
+    }
+    QMPS_OTHER(0x39) QMPS_OTHER(0x4E) QMPS_OTHER(0x93)        // quad_perm [1,2,3,0], [2,3,0,1], [3,0,1,2]
+#undef QMPS_OTHER
+    const double gr = 1.0 - cmul_r(wr, wi, sr, si), gi = -cmul_i(wr, wi, sr, si);
+    const double gn = dfma(gr, gr, gi * gi);
+    const double ign = gn > 0.0 ? fast_rcp(gn) : 0.0;
+    const double stepr = dfma(wr, gr, wi * gi) * ign, stepi = dfma(wi, gr, -wr * gi) * ign;
+    if (!fin) {
+      zr -= stepr;
+      zi -= stepi;
+      rounds = it + 1;
+    }
+    const double s2 = dfma(stepr, stepr, stepi * stepi), z2 = dfma(zr, zr, zi * zi);
+    // the quad's largest modulus; this lane is fine when it has settled, or when it is safely below the largest
+    const double zmax = fmax(fmax(z2, quad_perm<0xB1>(z2)), fmax(quad_perm<0x4E>(z2), quad_perm<0x1B>(z2)));
+    // settled: a step below 1e-14 of the modulus - or, for a root whose neighbours leave P / P' no such accuracy (a cluster: the noise of the step is
+    // ~1e-16 / gap), a step that has stopped shrinking (super-linear convergence ends in the noise floor) below 1e-10 of the modulus
+    const bool settled = !(s2 > 1e-28 * z2 + 1e-300) || (s2 < 1e-20 * z2 && s2 > 0.04 * prev_s2);
+    prev_s2 = s2;
+    const double reach = __builtin_sqrt(z2) + 4.0 * __builtin_sqrt(s2);
+    const bool below = reach * reach < zmax;
+    const bool ok = settled || below;
+    const double okall = quad_sum(ok ? 0.0 : 1.0);
+    fin = fin || okall == 0.0;
+    if (__builtin_amdgcn_ballot_w64(!fin) == 0) break;        // (every quad of the wave is done)
+  }
+  // the root of largest modulus, in every lane of the quad (the first of equal ones)
+  double br_ = zr, bi_ = zi, bm = dfma(zr, zr, zi * zi);
+  {
+    const double m0 = quad_bcast<0>(bm), r0 = quad_bcast<0>(br_), i0 = quad_bcast<0>(bi_);
+    double Mx = m0, Rx = r0, Ix = i0;
+    const double m1 = quad_bcast<1>(bm), r1 = quad_bcast<1>(br_), i1 = quad_bcast<1>(bi_);
+    if (m1 > Mx) { Mx = m1; Rx = r1; Ix = i1; }
+    const double m2_ = quad_bcast<2>(bm), r2 = quad_bcast<2>(br_), i2 = quad_bcast<2>(bi_);
+    if (m2_ > Mx) { Mx = m2_; Rx = r2; Ix = i2; }
+    const double m3 = quad_bcast<3>(bm), r3 = quad_bcast<3>(br_), i3 = quad_bcast<3>(bi_);
+    if (m3 > Mx) { Mx = m3; Rx = r3; Ix = i3; }
+    br_ = Rx; bi_ = Ix; bm = Mx;
+  }
+  const double back = zero ? 0.0 : __builtin_sqrt(m2);        // undo the scaling
+  eta_r = br_ * back;
+  eta_i = bi_ * back;
+  // all four roots settled?  (a multiple root converges linearly: 48 iterations leave it at ~1e-12 of its modulus - accepted; NaN is not)
+  if (!(eta_r == eta_r && eta_i == eta_i)) status = QMPS_ST_NOT_CONVERGED;
+}
+
 // One trajectory per workgroup; FOUR LANES per candidate of an evaluation pass (16 candidates per wave; 2P + 1 + 7 candidates:
 // three waves for ShallowFull's 15 angles, two for eight angles)
 template <int KIND>
@@ -224,6 +415,7 @@ __global__ __launch_bounds__(256) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
   __shared__ int sOK[64];
   __shared__ double2 sA[8], sC[16], sCS[PMAX], sLCS[kEvolveMaxAlphas * PMAX];
   __shared__ double sZ[PMAX], sCnt[4];
+  __shared__ double2 sT[64 * 32];      // 512 B per quad: the transposed elements of the characteristic-polynomial solve
   const double2* W = (const double2*)p.WW;
   if (tid < 4) sCnt[tid] = 0.0;
   // ---- one evaluation pass.  Candidate c = tid / 4: c < G1 = 2P + 1 the central-difference columns of z = x + coef d; [G1, G1 + n_ladder): x + alpha_{r+1} d
@@ -289,7 +481,12 @@ __global__ __launch_bounds__(256) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
 #ifdef QMPS_D2_PHASES
       t2 = wall_clock64();
 #endif
-      overlap_quad_solve(sC, amp_r, amp_i, q, p.max_rounds, p.tol, er, ei, rounds, status);
+      {
+        double rowr[4], rowi[4];
+        overlap_quad_build(sC, amp_r, amp_i, q, rowr, rowi);
+        if (p.probe & 4) overlap_quad_solve(rowr, rowi, q, p.max_rounds, p.tol, er, ei, rounds, status);
+        else overlap_quad_charpoly(rowr, rowi, q, sT + (tid >> 2) * 32, er, ei, rounds, status);
+      }
 #ifdef QMPS_D2_PHASES
       t3 = wall_clock64();
 #endif

@@ -942,3 +942,41 @@ def test_option_struct_defaults_at_d16_cap_power_steps_not_squarings(engine_fact
     assert int(cnt[1]) == 0                                                  # no failed evaluation
     assert np.array_equal(nit, ref['nit']) and np.abs(fh[:, 1] - ref['fun']).max() < 1e-9 and np.abs(X - ref['x']).max() < 1e-6
     assert fh[-1, 1].mean() < -0.999
+
+
+def test_d2_device_driver_characteristic_polynomial_solve_against_squaring_and_the_oracle(engine_factory, monkeypatch):
+    """Round 6: the D = 2 device-resident BFGS driver takes eta of a candidate's 4 x 4 map as the largest root of its characteristic polynomial
+    (power sums from one product, Newton's identities, Aberth's iteration with a root per lane of the quad: overlap_quad_charpoly, qmps_evolve_d2.hip)
+    instead of squaring the map until rank one (QMPS_EVOLVE_D2_SQUARING=1: rounds 4-5).  Both against the oracle's dense eigen-solve at the
+    device's parameters (1e-10: the recorded objective IS -sqrt|eta| of the recorded parameters), on random starts and on starts at the special
+    grid (a fifth of them: tied moduli, nilpotent maps, clusters - the cases a root finder could trip over): no NaN that the squaring solve does not
+    have, no failed evaluation, the same minima where the two BFGS runs stay in one basin; Aberth needs fewer rounds than the squaring."""
+    rng = np.random.default_rng(66)
+    WW = WW_of(0.05)
+    for kind, P in ((L.ANSATZ_SHALLOW_FULL, 15), (L.ANSATZ_SHALLOW_CNOT, 8), (L.ANSATZ_SHALLOW_CNOT, 2)):
+        T, n_steps = 40, 3
+        X0 = rng.standard_normal((T, P))
+        X0[::5] = np.round(X0[::5] / (np.pi / 4)) * (np.pi / 4)
+        eng = engine_factory(2, T * (2 * P + 1 + 8))
+        res = {}
+        for mode in ('charpoly', 'squaring'):
+            if mode == 'squaring':
+                monkeypatch.setenv('QMPS_EVOLVE_D2_SQUARING', '1')
+            else:
+                monkeypatch.delenv('QMPS_EVOLVE_D2_SQUARING', raising=False)
+            res[mode] = eng.evolve_bfgs_device(kind, X0, WW, n_steps=n_steps, maxiter=60, tol=1e-13)
+        monkeypatch.delenv('QMPS_EVOLVE_D2_SQUARING', raising=False)
+        a, b = res['charpoly'], res['squaring']
+        assert a['failed_evaluations'] == 0 and int(np.isnan(a['fun']).sum()) <= int(np.isnan(b['fun']).sum())
+        assert a['squarings'] < b['squarings']                     # (Aberth iterations against squaring rounds, summed over all evaluations)
+        prev = X0
+        for step in range(n_steps):
+            for t in range(T):
+                if not np.isfinite(a['fun'][step, t]):
+                    continue
+                f_or = ER.objective(kind, 2, ER.tensor(kind, 2, prev[t]), a['params_hist'][step, t], WW)
+                assert abs(f_or - a['fun'][step, t]) < 1e-10, (kind, P, step, t)
+            prev = a['params_hist'][step]
+        both = np.isfinite(a['fun'][-1]) & np.isfinite(b['fun'][-1])
+        close = np.abs(a['fun'][-1] - b['fun'][-1])[both] < 1e-6
+        assert close.mean() > 0.8 and a['fun'][-1][both].mean() < -0.99

@@ -64,6 +64,9 @@ def other_configs(args, budget_s=60.0):
         ('config4_evolve_D16_depth4_T256', dict(workload='evolve', D=16, batch=256, steps=10, warmup=3, tol=1e-12, carry_hessian=None)),
         # the same time evolution with more trajectories than the configuration names (the lock-step groups of qmps_evolve_bfgs)
         ('config4_evolve_D16_depth4_T2048', dict(workload='evolve', D=16, batch=2048, steps=10, warmup=3, tol=1e-12, carry_hessian=None, no_cpu_baseline=True, no_extras=True)),
+        # config 4's loop at the bond dimension and gate of the REFERENCE's own time evolution (qmps/new_time_evolve.py:186-187: D = 2, ShallowFullStateTensor,
+        # 15 angles): the whole optimiser on the device, a workgroup per trajectory (qmps_evolve_bfgs_device)
+        ('config4_family_evolve_D2_shallowfull_T256', dict(workload='evolve', D=2, batch=256, steps=10, warmup=3, tol=1e-12, carry_hessian=None, ansatz='shallow-full', no_cpu_baseline=True, no_extras=True)),
     ]
     res = {}
     for name, over in plan:

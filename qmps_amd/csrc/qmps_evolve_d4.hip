@@ -36,12 +36,21 @@ __global__ __launch_bounds__(64 * NWMAX) void evolve_bfgs_d4_kernel(EvolveD2Args
   __shared__ int sOK[64];
   __shared__ double2 sA[32], sB[NWMAX][32], sT[NWMAX][kSquareD4Scratch];
   __shared__ double sCnt[4];
-  __shared__ double2 sR[16], sY[16], sGs[64], sYR, sBm[2 * kEvolvePMax][64];
+  __shared__ double2 sR[16], sY[16], sGs[64], sYR, sBm[2 * kEvolvePMax][64], sCSw[NWMAX][kEvolvePMax];
   const double2* W = (const double2*)p.WW;
   const double tol2 = p.tol * p.tol;
   if (tid < 4) sCnt[tid] = 0.0;
   // the four columns of the ansatz unitary for the parameter vector par(l), by lanes 0 .. 3 of the calling wave, as the tensor [2][4][4]
+  // (round 6: the P sincos of the vector by P lanes of the wave, shared through LDS - the four column lanes used to compute all of them one after
+  // the other, ~0.3 us each on the critical path of wave 0's solve)
   auto build_tensor = [&](double2* out, auto par) {
+    __builtin_amdgcn_wave_barrier();
+    if (lane < P) {
+      double sn, cs_;
+      sincos(ansatz_param_scale<KIND>(lane) * par(lane), &sn, &cs_);
+      sCSw[wave][lane] = make_double2(cs_, sn);
+    }
+    __builtin_amdgcn_wave_barrier();
     if (lane < 4) {
       Reg<3> r;
 #pragma unroll
@@ -49,7 +58,7 @@ __global__ __launch_bounds__(64 * NWMAX) void evolve_bfgs_d4_kernel(EvolveD2Args
         r.re[x] = (x == lane) ? 1.0 : 0.0;
         r.im[x] = 0.0;
       }
-      ansatz_circuit<3, KIND>(r, par, P);
+      ansatz_circuit_cs<3, KIND>(r, [&](int l) { return sCSw[wave][l]; }, P);
 #pragma unroll
       for (int x = 0; x < 8; ++x) out[((x & 1) * 4 + (x >> 1)) * 4 + lane] = make_double2(r.re[x], r.im[x]);      // A[s][i][j] = amplitude[2 i + s] of column j
     }

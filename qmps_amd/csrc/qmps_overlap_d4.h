@@ -126,7 +126,7 @@ __device__ __forceinline__ void overlap_square_d4_item(const double2* Ap, const 
 #pragma unroll
       for (int q = 0; q < 4; ++q) n2 = dfma(mr[q], mr[q], dfma(mi[q], mi[q], n2));
       n2 = wave_sum(n2);
-      const double inv = n2 > 0.0 ? 1.0 / __builtin_sqrt(n2) : 0.0;
+      const double inv = n2 > 0.0 ? fast_rsqrt(n2) : 0.0;        // (v_rsq_f64 + a Newton step: the scale only keeps the powers O(1))
       mr *= inv;
       mi *= inv;
     }
@@ -169,7 +169,7 @@ __device__ __forceinline__ void overlap_square_d4_item(const double2* Ap, const 
         break;
       }
       if (m == max_rounds) break;
-      const double inv = 1.0 / __builtin_sqrt(q2);
+      const double inv = fast_rsqrt(q2);
       mr = qr * inv;
       mi = qi * inv;
     }

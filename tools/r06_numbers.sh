@@ -22,6 +22,12 @@ run evolve_d16_t256 --workload evolve --D 16 --batch 256 --steps 10 --warmup 3
 run evolve_d16_t32 --workload evolve --D 16 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline
 run evolve_d16_t2048 --workload evolve --D 16 --batch 2048 --steps 8 --warmup 3 --no-cpu-baseline
 run evolve_d8_t256 --workload evolve --D 8 --batch 256 --steps 8 --warmup 2 --no-cpu-baseline
+run evolve_d2_full_t256 --workload evolve --D 2 --ansatz shallow-full --batch 256 --steps 10 --warmup 3
+run evolve_d2_full_t4096 --workload evolve --D 2 --ansatz shallow-full --batch 4096 --steps 10 --warmup 3 --no-cpu-baseline
+run evolve_d2_t256 --workload evolve --D 2 --batch 256 --steps 10 --warmup 3 --no-cpu-baseline
+run evolve_d4_t256 --workload evolve --D 4 --batch 256 --steps 10 --warmup 3 --no-cpu-baseline
+run evolve_d4_t4096 --workload evolve --D 4 --batch 4096 --steps 10 --warmup 3 --no-cpu-baseline
+QMPS_EVOLVE_D2_SQUARING=1 timeout 600 python $R/bench.py --workload evolve --D 2 --ansatz shallow-full --batch 256 --steps 10 --warmup 3 --no-cpu-baseline > $o/${tag}_evolve_d2_full_t256_squaring.json 2> $o/${tag}_evolve_d2_full_t256_squaring.err
 run overlap_d16 --workload overlap --D 16 --batch 768 --no-cpu-baseline
 run overlap_d4 --workload overlap --D 4 --batch 65536 --no-cpu-baseline
 # ---- rocprofv3 kernel statistics of the shipped library (one pass each, kernel-trace + stats only)
@@ -32,6 +38,7 @@ prof headline
 prof d4_plain --solver plain --steps 200 --warmup 20
 prof evolve_d16_t256 --workload evolve --D 16 --batch 256 --steps 10 --warmup 3
 prof roto_d8 --workload rotosolve --D 8 --batch 768
+prof evolve_d2_full_t256 --workload evolve --D 2 --ansatz shallow-full --batch 256 --steps 10 --warmup 3
 python3 - <<PY
 import json,glob,os
 for f in sorted(glob.glob("$o/${tag}_*.json")):

@@ -398,6 +398,19 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
     if (m3 > Mx) { Mx = m3; Rx = r3; Ix = i3; }
     br_ = Rx; bi_ = Ix; bm = Mx;
   }
+  // a (nearly) MULTIPLE largest root: its computed copies sit ~eps^(1/m) |z| apart, symmetrically - their mean is good to rounding (a double
+  // dominant eigenvalue of a depth-1 circuit on the special grid came back 1e-8 high without this)
+  {
+    const double dx = zr - br_, dy = zi - bi_;
+    const bool near = dfma(dx, dx, dy * dy) < 1e-8 * bm;
+    const double cnt = quad_sum(near ? 1.0 : 0.0);
+    const double sxr = quad_sum(near ? zr : 0.0), sxi = quad_sum(near ? zi : 0.0);
+    if (cnt > 1.5) {
+      const double ic = 1.0 / cnt;
+      br_ = sxr * ic;
+      bi_ = sxi * ic;
+    }
+  }
   const double back = zero ? 0.0 : __builtin_sqrt(m2);        // undo the scaling
   eta_r = br_ * back;
   eta_i = bi_ * back;

@@ -948,7 +948,7 @@ def test_d2_device_driver_characteristic_polynomial_solve_against_squaring_and_t
     """Round 6: the D = 2 device-resident BFGS driver takes eta of a candidate's 4 x 4 map as the largest root of its characteristic polynomial
     (power sums from one product, Newton's identities, Aberth's iteration with a root per lane of the quad: overlap_quad_charpoly, qmps_evolve_d2.hip)
     instead of squaring the map until rank one (QMPS_EVOLVE_D2_SQUARING=1: rounds 4-5).  Both against the oracle's dense eigen-solve at the
-    device's parameters (1e-10: the recorded objective IS -sqrt|eta| of the recorded parameters), on random starts and on starts at the special
+    device's parameters (1e-10 on generic starts: the recorded objective IS -sqrt|eta| of the recorded parameters), on random starts and on starts at the special
     grid (a fifth of them: tied moduli, nilpotent maps, clusters - the cases a root finder could trip over): no NaN that the squaring solve does not
     have, no failed evaluation, the same minima where the two BFGS runs stay in one basin; Aberth needs fewer rounds than the squaring."""
     rng = np.random.default_rng(66)
@@ -975,7 +975,9 @@ def test_d2_device_driver_characteristic_polynomial_solve_against_squaring_and_t
                 if not np.isfinite(a['fun'][step, t]):
                     continue
                 f_or = ER.objective(kind, 2, ER.tensor(kind, 2, prev[t]), a['params_hist'][step, t], WW)
-                assert abs(f_or - a['fun'][step, t]) < 1e-10, (kind, P, step, t)
+                # (starts ON the grid can sit on double dominant eigenvalues, where a root of the quartic - and an eigenvalue from numpy's eig, the
+                # oracle here - is only good to ~sqrt(eps): the suite's F_TOL there, 1e-10 on the generic starts)
+                assert abs(f_or - a['fun'][step, t]) < (F_TOL if t % 5 == 0 else 1e-10), (kind, P, step, t)
             prev = a['params_hist'][step]
         both = np.isfinite(a['fun'][-1]) & np.isfinite(b['fun'][-1])
         close = np.abs(a['fun'][-1] - b['fun'][-1])[both] < 1e-6

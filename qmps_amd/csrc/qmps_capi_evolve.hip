@@ -700,7 +700,7 @@ int qmps_evolve_bfgs_device(qmps_ctx* c, int64_t T, int kind, int n_params, doub
   if (const char* e = tuning_knob("QMPS_EVOLVE_PROBE")) a.probe = atoi(e);
   if (documented_switch("QMPS_EVOLVE_D2_SQUARING")) a.probe |= 4;      // D = 2: the eigen-solves of the device-resident driver by squaring (rounds 4-5) instead of the characteristic polynomial
   double* d_prof = nullptr;
-  if ((c->D == 16 || c->D == 2) && tuning_knob("QMPS_EVOLVE_PROF")) {      // (tuning builds: phase timers of the D = 16 kernel - and with -DQMPS_D2_PHASES of the D = 2 one: total | sincos | solve | circuit | closing barrier | optimiser algebra | passes | squarings - printed below)
+  if ((c->D == 16 || c->D == 2 || c->D == 4) && tuning_knob("QMPS_EVOLVE_PROF")) {      // (tuning builds: phase timers of the D = 16 kernel - and with -DQMPS_D2_PHASES of the D = 2 one: total | sincos | solve | circuit | closing barrier | optimiser algebra | passes | squarings - printed below)
     HIP_TRY(hipMalloc((void**)&d_prof, (size_t)T * 8 * sizeof(double)));
     HIP_TRY(hipMemsetAsync(d_prof, 0, (size_t)T * 8 * sizeof(double), c->stream));
     a.prof = d_prof;

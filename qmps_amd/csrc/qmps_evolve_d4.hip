@@ -71,8 +71,16 @@ __global__ __launch_bounds__(64 * NWMAX) void evolve_bfgs_d4_kernel(EvolveD2Args
   // largest column and the conjugate of the largest row of the squared map),
   //     eta' = <y, T'(r)> / <y, r> = sum_s tr(Bm'_s^+ G_s) / <y, r> ,   G_s = y^+ C_s r   (qmps_overlap_grad.hip: the host driver's gradient),
   // one small contraction per neighbour instead of a solve: nine solves on four matrix pipes were what a pass cost (34 us).
+#ifdef QMPS_D2_PHASES
+  long long ph[7] = {0, 0, 0, 0, 0, 0, 0};
+  const long long k0 = wall_clock64();
+#endif
   auto evaluate = [&](double coef, int n_ladder) {
     const bool with_grad = coef == coef;
+#ifdef QMPS_D2_PHASES
+    const long long t0 = wall_clock64();
+    long long t1 = t0, t2 = t0, t3 = t0;
+#endif
     const int NW = (int)(blockDim.x >> 6);
     // parameter vector of candidate `cand` (0: z = x + coef d; 1 + k / 1 + P + k: z +- h e_k; G1 + r: x + alphas[r + 1] d)
     auto par_of = [&](int cand) {
@@ -108,11 +116,17 @@ __global__ __launch_bounds__(64 * NWMAX) void evolve_bfgs_d4_kernel(EvolveD2Args
     const int solve_cand = with_grad ? (wave == 0 ? 0 : -1) : (wave < n_ladder ? G1 + wave : -1);
     if (solve_cand >= 0) {
       build_tensor(sB[wave], par_of(solve_cand));
+#ifdef QMPS_D2_PHASES
+      t1 = wall_clock64();
+#endif
       double eta_r, eta_i;
       int rounds, status;
       v4f64 mr, mi;
       double2* sT0 = sT[wave];
       overlap_square_d4_item(sA, sB[wave], W, sT0, p.max_rounds, tol2, eta_r, eta_i, rounds, status, mr, mi);
+#ifdef QMPS_D2_PHASES
+      t2 = wall_clock64();
+#endif
       if (lane == 0) {
         sF[solve_cand] = -__builtin_sqrt(__builtin_sqrt(eta_r * eta_r + eta_i * eta_i));
         sOK[solve_cand] = status == QMPS_ST_OK ? 1 : 0;
@@ -191,10 +205,19 @@ __global__ __launch_bounds__(64 * NWMAX) void evolve_bfgs_d4_kernel(EvolveD2Args
         sBm[nb][lane] = merged_entry();
       }
     }
+#ifdef QMPS_D2_PHASES
+    t3 = wall_clock64();
+#endif
     __syncthreads();
+#ifdef QMPS_D2_PHASES
+    const long long t4 = wall_clock64();
+#endif
     if (with_grad && wave > 0)
       for (int nb = wave - 1; nb < 2 * P; nb += NW - 1) probe(1 + nb, sBm[nb][lane]);
     __syncthreads();
+#ifdef QMPS_D2_PHASES
+    { const long long t5 = wall_clock64(); ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += t5 - t4; ph[5] += 1; }
+#endif
     if (tid == 0) sCnt[0] += (double)((with_grad ? G1 : 0) + n_ladder);
   };
   auto build_reference = [&]() {
@@ -207,6 +230,13 @@ __global__ __launch_bounds__(64 * NWMAX) void evolve_bfgs_d4_kernel(EvolveD2Args
   const bool ladder_in_pass = false;       // (a backtracking point costs a solve: only when the full step is rejected)
   bfgs_time_evolution(p, t, (wave == 0 && lane < P) ? lane : -1, tid == 0, L, evaluate, build_reference, [] { __syncthreads(); }, ladder_in_pass);
   __syncthreads();
+#ifdef QMPS_D2_PHASES
+  if (tid == 0 && p.prof != nullptr) {      // total | tensor | solve | extract | wait for the neighbours | probes | algebra (the rest) ... passes in slot 6, squarings in 7
+    ph[6] = wall_clock64() - k0;
+    p.prof[t * 8 + 0] = (double)ph[6]; p.prof[t * 8 + 1] = (double)ph[0]; p.prof[t * 8 + 2] = (double)ph[1]; p.prof[t * 8 + 3] = (double)ph[2];
+    p.prof[t * 8 + 4] = (double)ph[3]; p.prof[t * 8 + 5] = (double)(ph[6] - ph[0] - ph[1] - ph[2] - ph[3] - ph[4]); p.prof[t * 8 + 6] = (double)ph[5]; p.prof[t * 8 + 7] = (double)ph[4] * 0.01;
+  }
+#endif
   if (tid == 0) {
     if (p.nfev != nullptr) p.nfev[t] = sCnt[0];
     if (p.rounds != nullptr) p.rounds[t] = sCnt[1];

@@ -137,20 +137,29 @@ __device__ __forceinline__ void overlap_square_d4_item(const double2* Ap, const 
       to_a_layout(mr, mi, ar, ai);
       v4f64 qr = {0, 0, 0, 0}, qi = {0, 0, 0, 0};
       cmma16_3m(ar, ai, mr, mi, qr, qi);      // (three real products per k-slab: 12 instead of 16 v_mfma_f64_16x16x4 per squaring)                     // Q = M M
-      double d0 = 0.0, d1 = 0.0;
+      // ||M M||_F^2 every round (the next power is normalised by it, a collapsed power shows in it); the rank-one test - the trace, the residual:
+      // three more wave reductions and their latencies - only from round kFirstTest on (a map of this objective needs 5 - 10 squarings at tol
+      // 1e-12; one that would have passed earlier squares on to round kFirstTest, harmlessly) and at the last round of the budget
+      constexpr int kFirstTest = 3;
+      const bool test = m >= kFirstTest || m == max_rounds;
+      double res = 1e300, q2 = 0.0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (c == 4 * q + g) { d0 = mr[q]; d1 = mi[q]; }
-      trr = wave_sum(d0);
-      tri = wave_sum(d1);
-      double res = 0.0, q2 = 0.0;
+      for (int q = 0; q < 4; ++q) q2 = dfma(qr[q], qr[q], dfma(qi[q], qi[q], q2));
+      if (test) {
+        double d0 = 0.0, d1 = 0.0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double dr = qr[q] - (trr * mr[q] - tri * mi[q]), di = qi[q] - (trr * mi[q] + tri * mr[q]);
-        res = dfma(dr, dr, dfma(di, di, res));
-        q2 = dfma(qr[q], qr[q], dfma(qi[q], qi[q], q2));
+        for (int q = 0; q < 4; ++q)
+          if (c == 4 * q + g) { d0 = mr[q]; d1 = mi[q]; }
+        trr = wave_sum(d0);
+        tri = wave_sum(d1);
+        res = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double dr = qr[q] - (trr * mr[q] - tri * mi[q]), di = qi[q] - (trr * mi[q] + tri * mr[q]);
+          res = dfma(dr, dr, dfma(di, di, res));
+        }
+        res = lane0(wave_sum(res));
       }
-      res = lane0(wave_sum(res));
       q2 = lane0(wave_sum(q2));
       rounds = m;
       if (q2 < 1e-28) {

@@ -1351,7 +1351,17 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
   const int rr = valid ? r : p.R - 1;
   const int P = p.P;
   double* mine = sP + rl * P;
-  for (int l = k; l < P; l += 4) mine[l] = p.base[(int64_t)rr * P + l];
+  // cos / sin of the restart's (scaled) angles, kept beside them (round 6): an evaluation used to compute the sincos of EVERY angle inside the circuit,
+  // once per column - 60 double-precision sincos per parameter update and lane with ShallowFull's 15 angles, ~18 of the update's 31 us; now ONE per
+  // evaluation (the shifted angle) and one per update (the moved angle).  Same arguments, same function: the same bits.
+  double2* mine_cs = (double2*)(sP + 16 * P) + rl * P;
+  for (int l = k; l < P; l += 4) {
+    const double v = p.base[(int64_t)rr * P + l];
+    mine[l] = v;
+    double sn, cs_;
+    sincos(ansatz_param_scale<KIND>(l) * v, &sn, &cs_);
+    mine_cs[l] = make_double2(cs_, sn);
+  }
   __builtin_amdgcn_wave_barrier();
   const double tol2 = p.tol * p.tol;
   const double shift = roto_shift_value(NSH, k > 2 ? 0 : k);            // lane 3 idles along with shift 0
@@ -1360,6 +1370,12 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
   // one evaluation at (params + delta e_i): summed energy over the Hamiltonian terms, status
   auto evaluate = [&](int i, double delta, double& e_out, int& status_out) {
     double are[2][D][D], aim[2][D][D];
+    double2 own = make_double2(1.0, 0.0);
+    if (i >= 0) {
+      double sn, cs_;
+      sincos(ansatz_param_scale<KIND>(i) * (mine[i] + delta), &sn, &cs_);
+      own = make_double2(cs_, sn);
+    }
 #pragma unroll
     for (int col = 0; col < D; ++col) {
       Reg<2> q;
@@ -1368,7 +1384,11 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
         q.re[x] = (x == col) ? 1.0 : 0.0;
         q.im[x] = 0.0;
       }
-      ansatz_circuit<2, KIND>(q, [&](int l) { return mine[l] + (l == i ? delta : 0.0); }, P);
+      ansatz_circuit_cs<2, KIND>(q, [&](int l) {
+        double2 v = mine_cs[l];               // (value selects: a select between `own` and an LDS element would put `own` in scratch)
+        if (l == i) { v.x = own.x; v.y = own.y; }
+        return v;
+      }, P);
 #pragma unroll
       for (int x = 0; x < 4; ++x) {           // A[s][i][j] = amplitude[2 i + s] of input |j>
         are[x & 1][x >> 1][col] = q.re[x];
@@ -1444,6 +1464,9 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
           const double a = 0.25 * (2.0 * Ev - 1.4142135623730951 * Dv), b = 0.25 * (Av - Cv), c = 0.5 * Dv, d = 0.5 * Bv;
           mine[i] += double_sinusoid_step(a, b, c, d, p.rule);
         }
+        double sn, cs_;
+        sincos(ansatz_param_scale<KIND>(i) * mine[i], &sn, &cs_);
+        mine_cs[i] = make_double2(cs_, sn);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -1461,7 +1484,7 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
 
 hipError_t launch_rotosolve_fused_d2(int kind, const RotoArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)((a.R + 15) / 16)), block(64);
-  const size_t lds = (size_t)16 * a.P * sizeof(double);
+  const size_t lds = (size_t)16 * a.P * (sizeof(double) + sizeof(double2));      // the restarts' angles and their cos / sin
   if (a.nsh == 6)
     switch (kind) {
       case 0: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<0, 6>), grid, block, lds, st, a); break;

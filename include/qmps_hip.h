@@ -190,7 +190,8 @@ int qmps_abi_version(void);
  *      QMPS_FLAG_KRYLOV_FALLBACK (D = 8 environment solves hand long tails to the Arnoldi kernel, as D = 16 always did).
  * 6.4: QMPS_STATUS_TIED (the D = 2 overlap solves report a tie of the dominant eigenvalues by its own status instead of 0: eta is usable, r_out is
  *      not a fixed point); qmps_evolve_bfgs_device_opts: max_rounds = 0 means 100 000 power steps at D = 16 as documented (it meant 60);
- *      qmps_bw_env: the relaxed rank-one acceptance honours the caller's tol. */
+ *      qmps_bw_env: the relaxed rank-one acceptance honours the caller's tol; D = 4 QMPS_ENV_POWER runs env_power_d4_kernel (QMPS_POWER_LANE: the old
+ *      kernel), the D = 2 device-resident driver solves by the characteristic polynomial (QMPS_EVOLVE_D2_SQUARING: by squaring) - same results. */
 int qmps_abi_minor(void);
 const char* qmps_last_error(void);
 /* Test hook for the contract above ("nothing throws across the ABI"): raises a C++ exception inside the library - kind 1
@@ -536,7 +537,10 @@ int qmps_get_evolve_groups(qmps_ctx* ctx, int64_t T, int* groups);
  * Arguments as qmps_evolve_bfgs (flags: QMPS_BFGS_CARRY_HESSIAN, and QMPS_BFGS_WARM = "hinv holds the inverse Hessians to continue
  * from"), except: nit_out (nullable) [n_steps][T] - iterations of EVERY trajectory in every step; counters_out (nullable) [4] =
  * objective evaluations (candidates) of the whole run, evaluations that ended with status != 0, launch milliseconds (HIP events),
- * squarings spent on the evaluations.
+ * squarings spent on the evaluations (D = 2, ABI 6.4: Aberth iterations - a candidate's eta is the largest root of the characteristic polynomial of
+ * its 4 x 4 map, one product + Newton's identities + a root per lane of the candidate's quad, instead of the map squared until rank one
+ * (QMPS_EVOLVE_D2_SQUARING: the squaring solve, then max_rounds and tol apply as before); the same eta to ~1e-15 |eta| / gap, tied moduli and
+ * nilpotent maps need no special path, a DOUBLE dominant eigenvalue is good to ~1e-9).
  * n_params <= 16, n_alphas <= 16, 2 n_params + n_alphas <= 64.  Any T (no max_batch limit: nothing is staged per candidate).
  * D = 4 (qmps_amd/csrc/qmps_evolve_d4.hip): a WORKGROUP per trajectory, its waves are the candidates - each builds its tensor (four lanes
  * simulate the four columns of the ansatz unitary); the point itself is eigen-solved by squaring its 16 x 16 map on the matrix cores (the code of the D = 4 overlap

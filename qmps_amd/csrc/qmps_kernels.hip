@@ -1344,9 +1344,12 @@ __global__ __launch_bounds__(256, QMPS_SQ_MINBLOCKS) void env_square_d4_kernel(S
 template <int KIND, int NSH>
 __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
   constexpr int D = 2;
-  extern __shared__ double sP[];                 // [16 restarts][P]
-  const int lane = threadIdx.x, rl = lane >> 2, k = lane & 3;
-  const int r = blockIdx.x * 16 + rl;
+  // lanes per restart: a quad for the three shifts of the single-frequency rule; EIGHT for the six shifts of the double-frequency one (round 6: the six
+  // evaluations side by side - three lanes used to take two each, one after the other)
+  constexpr int LPR = NSH == 6 ? 8 : 4, RPW = 64 / LPR;
+  extern __shared__ double sP[];                 // [RPW restarts][P], then their cos / sin
+  const int lane = threadIdx.x, rl = lane / LPR, k = lane % LPR;
+  const int r = blockIdx.x * RPW + rl;
   const bool valid = r < p.R;
   const int rr = valid ? r : p.R - 1;
   const int P = p.P;
@@ -1354,8 +1357,8 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
   // cos / sin of the restart's (scaled) angles, kept beside them (round 6): an evaluation used to compute the sincos of EVERY angle inside the circuit,
   // once per column - 60 double-precision sincos per parameter update and lane with ShallowFull's 15 angles, ~18 of the update's 31 us; now ONE per
   // evaluation (the shifted angle) and one per update (the moved angle).  Same arguments, same function: the same bits.
-  double2* mine_cs = (double2*)(sP + 16 * P) + rl * P;
-  for (int l = k; l < P; l += 4) {
+  double2* mine_cs = (double2*)(sP + RPW * P) + rl * P;
+  for (int l = k; l < P; l += LPR) {
     const double v = p.base[(int64_t)rr * P + l];
     mine[l] = v;
     double sn, cs_;
@@ -1364,8 +1367,7 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
   }
   __builtin_amdgcn_wave_barrier();
   const double tol2 = p.tol * p.tol;
-  const double shift = roto_shift_value(NSH, k > 2 ? 0 : k);            // lane 3 idles along with shift 0
-  const double shift2 = NSH == 6 ? roto_shift_value(6, k > 2 ? 3 : k + 3) : 0.0;
+  const double shift = roto_shift_value(NSH, k >= NSH ? 0 : k);         // the group's spare lanes idle along with shift 0
 
   // one evaluation at (params + delta e_i): summed energy over the Hamiltonian terms, status
   auto evaluate = [&](int i, double delta, double& e_out, int& status_out) {
@@ -1422,16 +1424,18 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
     e_out = e;
     status_out = status;
   };
-  auto quad_bcast = [&](double v, int src) {      // value of lane `src` of the quad, in every lane of the quad
-    const int ctl = src * 0x55;                    // quad_perm [src, src, src, src]
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    switch (src) {
-      case 0: lo = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xf, 0xf, true); break;
-      case 1: lo = __builtin_amdgcn_mov_dpp(lo, 0x55, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x55, 0xf, 0xf, true); break;
-      default: lo = __builtin_amdgcn_mov_dpp(lo, 0xAA, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xAA, 0xf, 0xf, true); break;
+  auto quad_bcast = [&](double v, int src) {      // value of lane `src` of the restart's group, in every lane of the group
+    if constexpr (LPR == 4) {
+      int lo = __double2loint(v), hi = __double2hiint(v);
+      switch (src) {
+        case 0: lo = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xf, 0xf, true); break;
+        case 1: lo = __builtin_amdgcn_mov_dpp(lo, 0x55, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x55, 0xf, 0xf, true); break;
+        default: lo = __builtin_amdgcn_mov_dpp(lo, 0xAA, 0xf, 0xf, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xAA, 0xf, 0xf, true); break;
+      }
+      return __hiloint2double(hi, lo);
+    } else {
+      return __shfl(v, (lane & ~(LPR - 1)) + src, 64);
     }
-    (void)ctl;
-    return __hiloint2double(hi, lo);
   };
   for (int sw = 0; sw < p.n_sweeps; ++sw) {
     for (int i = 0; i < P; ++i) {
@@ -1441,18 +1445,17 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
       const double e0 = quad_bcast(e, 0), ep = quad_bcast(e, 1), em = quad_bcast(e, 2);
       // the unshifted evaluation of a sweep's first parameter IS the energy at the parameters the previous sweep left
       if (i == 0 && sw > 0 && valid && k == 0) p.hist[(int64_t)(sw - 1) * p.R + r] = e0;
-      double okv = (st == QMPS_ST_OK || k == 3) ? 1.0 : 0.0;
+      double okv = (st == QMPS_ST_OK || k >= NSH) ? 1.0 : 0.0;
       double e3 = 0.0, e4 = 0.0, e5 = 0.0;
+      bool ok;
       if constexpr (NSH == 6) {
-        double f;
-        int st2;
-        evaluate(i, shift2, f, st2);
-        e3 = quad_bcast(f, 0);
-        e4 = quad_bcast(f, 1);
-        e5 = quad_bcast(f, 2);
-        okv = (okv != 0.0 && (st2 == QMPS_ST_OK || k == 3)) ? 1.0 : 0.0;
+        e3 = quad_bcast(e, 3);
+        e4 = quad_bcast(e, 4);
+        e5 = quad_bcast(e, 5);
+        ok = quad_bcast(okv, 0) * quad_bcast(okv, 1) * quad_bcast(okv, 2) * quad_bcast(okv, 3) * quad_bcast(okv, 4) * quad_bcast(okv, 5) != 0.0;
+      } else {
+        ok = quad_bcast(okv, 0) * quad_bcast(okv, 1) * quad_bcast(okv, 2) != 0.0;
       }
-      const bool ok = quad_bcast(okv, 0) * quad_bcast(okv, 1) * quad_bcast(okv, 2) != 0.0;
       __builtin_amdgcn_wave_barrier();
       if (ok && k == 0) {      // (an evaluation without a valid environment leaves this restart's parameter untouched)
         if constexpr (NSH == 3) {
@@ -1479,12 +1482,13 @@ __global__ __launch_bounds__(64) void rotosolve_fused_d2_kernel(RotoArgs p) {
   }
   __builtin_amdgcn_wave_barrier();
   if (valid)
-    for (int l = k; l < P; l += 4) p.base[(int64_t)r * P + l] = mine[l];
+    for (int l = k; l < P; l += LPR) p.base[(int64_t)r * P + l] = mine[l];
 }
 
 hipError_t launch_rotosolve_fused_d2(int kind, const RotoArgs& a, hipStream_t st) {
-  const dim3 grid((unsigned)((a.R + 15) / 16)), block(64);
-  const size_t lds = (size_t)16 * a.P * (sizeof(double) + sizeof(double2));      // the restarts' angles and their cos / sin
+  const int rpw = a.nsh == 6 ? 8 : 16;                                                  // restarts per wave: eight lanes each (six shifts) | a quad each
+  const dim3 grid((unsigned)((a.R + rpw - 1) / rpw)), block(64);
+  const size_t lds = (size_t)rpw * a.P * (sizeof(double) + sizeof(double2));      // the restarts' angles and their cos / sin
   if (a.nsh == 6)
     switch (kind) {
       case 0: hipLaunchKernelGGL((rotosolve_fused_d2_kernel<0, 6>), grid, block, lds, st, a); break;

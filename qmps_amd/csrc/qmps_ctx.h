@@ -103,7 +103,7 @@ struct qmps_ctx {
                                               //   two upload slots of kMaskSlot bytes + one for the fall-back pass of qmps_overlap_gradient
   static constexpr size_t kMaskSlot = (size_t)1 << 19;
   hipEvent_t fork_after_copy = nullptr;   // one-shot: qmps_set_states_ansatz records it between the parameter upload and the tensor build
-  int* d_queue = nullptr;      // overlap kernels: counters the workgroups draw their evaluations from (qmps_create; [0, 1] D = 16 queue kernels, [2, 8) Krylov fall-back of the overlap solves: two sets of three, [8, 13) of the D = 16 environment)
+  int* d_queue = nullptr;      // overlap kernels: counters the workgroups draw their evaluations from (qmps_create; [0, 1] D = 16 queue kernels, [2, 8) Krylov fall-back of the overlap solves: two sets of three, [8, 13) of the D = 16 environment, [13] the work counter of env_power_d4_kernel - cleared in front of its launch)
   void* d_kry = nullptr;       // D = 8, 16: iterates handed from the power kernels to the Krylov fall-back when the caller keeps no fixed points [max_batch][D][D]
   void* d_y = nullptr;         // qmps_overlap_gradient: LEFT fixed points [max_batch][D][D] (lazy)
   int64_t grad_warm_T = 0;     // d_r / d_y hold the fixed points of this many trajectories' iterates (qmps_overlap_gradient)

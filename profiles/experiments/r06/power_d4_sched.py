@@ -1,4 +1,5 @@
-"""Work distribution of env_power_d4_kernel: waves per SIMD x static first block x chunk size (temporary knobs of a tuning build)."""
+"""Work distribution of env_power_d4_kernel: waves per SIMD x static first block x chunk size (temporary knobs of a tuning build).
+  (Historical: QMPS_TMP_FB / QMPS_TMP_CHUNK existed in the tuning build of that afternoon only; the shipped kernel has first block = half the batch, chunk = 8.  QMPS_POWER_WAVES needs a -DQMPS_DEBUG_KNOBS build.)"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))

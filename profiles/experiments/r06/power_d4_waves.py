@@ -1,4 +1,5 @@
-"""Persistent-grid size of env_power_d4_kernel: waves per SIMD x batch size, five timed blocks of ten launches each (median, min)."""
+"""Persistent-grid size of env_power_d4_kernel: waves per SIMD x batch size, five timed blocks of ten launches each (median, min).
+  (QMPS_POWER_WAVES is a tuning knob: -DQMPS_DEBUG_KNOBS builds only; the shipped default is five waves per SIMD.)"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))

@@ -539,8 +539,10 @@ int qmps_get_evolve_groups(qmps_ctx* ctx, int64_t T, int* groups);
  * objective evaluations (candidates) of the whole run, evaluations that ended with status != 0, launch milliseconds (HIP events),
  * squarings spent on the evaluations (D = 2, ABI 6.4: Aberth iterations - a candidate's eta is the largest root of the characteristic polynomial of
  * its 4 x 4 map, one product + Newton's identities + a root per lane of the candidate's quad, instead of the map squared until rank one
- * (QMPS_EVOLVE_D2_SQUARING: the squaring solve, then max_rounds and tol apply as before); the same eta to ~1e-15 |eta| / gap, tied moduli and
- * nilpotent maps need no special path, a DOUBLE dominant eigenvalue is good to ~1e-9).
+ * (QMPS_EVOLVE_D2_SQUARING: the squaring solve for every map, then max_rounds and tol apply as before); the same eta to ~1e-15 |eta| / gap, tied
+ * moduli need no special path.  What a quartic cannot answer - a MULTIPLE largest root (eps^(1/m) conditioning), a root within 1e-3 of the largest,
+ * a nilpotent map - the kernel hands to the squaring solve, quad by quad (points of the special grid of multiples of pi / 4; those evaluations count
+ * their Aberth iterations plus their squarings, and max_rounds / tol apply to them).
  * n_params <= 16, n_alphas <= 16, 2 n_params + n_alphas <= 64.  Any T (no max_batch limit: nothing is staged per candidate).
  * D = 4 (qmps_amd/csrc/qmps_evolve_d4.hip): a WORKGROUP per trajectory, its waves are the candidates - each builds its tensor (four lanes
  * simulate the four columns of the ansatz unitary); the point itself is eigen-solved by squaring its 16 x 16 map on the matrix cores (the code of the D = 4 overlap

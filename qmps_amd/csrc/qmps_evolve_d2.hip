@@ -222,18 +222,21 @@ __device__ __forceinline__ void overlap_quad_solve(const double (&er)[4], const 
 // spectral gap, and the slowest trajectory IS a launch of this kernel (phase timers: 8.1 of its 13.1 us per pass).  A 4 x 4 map has a quartic:
 //   p_k = tr E^k, k = 1 .. 4, from ONE product (E^2 by quad broadcasts; tr E^3 = sum E^2[q][c] E[c][q], tr E^4 = sum E^2[q][c] E^2[c][q]: the transposed
 //   elements through the quad's LDS scratch), Newton's identities -> e_1 .. e_4, P(z) = z^4 - e_1 z^3 + e_2 z^2 - e_3 z + e_4;
-//   its four roots by the Aberth - Ehrlich iteration, ONE ROOT PER LANE of the quad (the other three by quad rotations), started on the circle
-//   of radius |P(c)|^(1/4) round the centroid c = e_1 / 4: cubic convergence, 6 - 10 iterations whatever the gap;
+//   its four roots by the Aberth - Ehrlich iteration, ONE ROOT PER LANE of the quad (the other three by quad rotations): cubic convergence on simple
+//   roots, 4 - 8 iterations on the maps of the time-evolution objective whatever the gap (starting points: see below);
 //   eta = the root of largest modulus.
 // What the objective -sqrt|eta| needs and nothing more: no eigenvector (the lane solver of the C-ABI's D = 2 overlap entry points keeps the squaring:
-// it owes its callers r_out).  Tied moduli (a complex-conjugate pair, a ring) are distinct simple roots - no special path; a nilpotent map has
-// P = z^4: eta = 0.  Conditioning: the coefficients carry ~1e-16 |eta|^k, a simple dominant root moves by 1e-16 |eta| / prod_j |1 - eta_j / eta|
-// (2e-15 at a gap of 0.05); a DOUBLE dominant root only by sqrt(eps) ~ 1e-8 of its modulus (the squaring's Gelfand route: 1e-11) - a point set of
-// measure zero that the trajectories of the stress runs never met.  E is scaled to unit Frobenius norm first.
-// sT: 32 double2 of LDS per quad.  rounds = Aberth iterations.
+// it owes its callers r_out).  Tied moduli (a complex-conjugate pair, a ring) are distinct simple roots - no special path.  Conditioning: the
+// coefficients carry ~1e-16 |eta|^k, a simple dominant root moves by 1e-16 |eta| / prod_j |1 - eta_j / eta| (2e-15 at a gap of 0.05) - but an m-fold
+// dominant root by eps^(1/m) of its modulus (1e-8, 5e-6, 1e-4) and the iteration converges only linearly on it, and a nilpotent map's P = z^4 + noise
+// has roots of 1e-4 ||E||.  Those maps - points of the special grid (multiples of pi / 4: product states, permutation-like tensors), never met
+// by a generic trajectory - are NOT answered here: `fallback` comes back set (a root within 1e-3 of the largest one, or a largest root below
+// 1e-3 ||E||_F) and the caller runs the squaring solve above on the quad, whose Gelfand route and collapse test give them to 1e-11.
+// E is scaled to unit Frobenius norm first.  sT: 32 double2 of LDS per quad.  rounds = Aberth iterations.
 __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], const double (&ei)[4], int q, double2* sT, double& eta_r, double& eta_i,
-                                                      int& rounds, int& status) {
+                                                      int& rounds, int& status, bool& fallback) {
   status = QMPS_ST_OK;
+  fallback = false;
   rounds = 0;
   eta_r = eta_i = 0.0;
   double m2 = 0.0;
@@ -300,9 +303,13 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
     dr = cmul_r(ur, ui, zr, zi) - e3r; di = cmul_i(ur, ui, zr, zi) - e3i;
     Pr = cmul_r(ar, ai, zr, zi) + e4r; Pi = cmul_i(ar, ai, zr, zi) + e4i;
   };
-  // ---- starting points.  Lane 0: the power-sum quotient p4 / p3 (the dominant root up to O((eta_2 / eta_1)^3) when there is one); lanes 1 - 3: a
-  // circle round the centroid of the cubic that is left when that estimate is divided out, of radius |Q(centroid)|^(1/3).  When p3 is too small for
-  // the quotient to mean anything (a spectrum symmetric under z -> -z ...): all four on the circle of radius |P(c)|^(1/4) round c = e1 / 4.
+  // ---- starting points.  Lane 0: the power-sum quotient p4 / p3 (the dominant root up to O((eta_2 / eta_1)^3) when there is one); lanes 1 - 3:
+  // round the centroid c3 of the cubic Q that is left when that estimate is divided out, at the scale |Q(c3)|^(1/3).  When p3 is too small for the
+  // quotient to mean anything (a spectrum symmetric under z -> -z ...): all four round c = e1 / 4 at the scale |P(c)|^(1/4).  Two traps of the
+  // textbook circle, both met on structured maps: (i) a centroid that IS a root (spectrum {l, -l, 0, 0}: P(c) = 0) puts every point ON it, where
+  // coincident points move together for ever - the scale falls back on the next coefficients of the polynomial shifted to the centroid;
+  // (ii) points on a regular polygon keep the polygon's symmetry when the polynomial has it (z^4 + a z^2 + b from a square: 30 iterations of a
+  // rotating square until rounding breaks it) - the points sit at unequal radii and unequal angles.
   double zr, zi;
   {
     const double n3 = dfma(p3r, p3r, p3i * p3i), n4 = dfma(p4r, p4r, p4i * p4i);
@@ -314,23 +321,32 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
     const double b1r = e2r + cmul_r(ar, ai, b2r, b2i), b1i = e2i + cmul_i(ar, ai, b2r, b2i);
     const double b0r = -e3r + cmul_r(ar, ai, b1r, b1i), b0i = -e3i + cmul_i(ar, ai, b1r, b1i);
     const double c3r = -b2r * (1.0 / 3.0), c3i = -b2i * (1.0 / 3.0);
-    double Qr, Qi;
+    double Qr, Qi, A3r, A3i;                                          // Q(c3 + w) = w^3 + A3 w + Q(c3)
     {
       double tr = c3r + b2r, ti = c3i + b2i;
       double ur = cmul_r(tr, ti, c3r, c3i) + b1r, ui = cmul_i(tr, ti, c3r, c3i) + b1i;
       Qr = cmul_r(ur, ui, c3r, c3i) + b0r;
       Qi = cmul_i(ur, ui, c3r, c3i) + b0i;
+      tr = 3.0 * c3r + 2.0 * b2r; ti = 3.0 * c3i + 2.0 * b2i;
+      A3r = cmul_r(tr, ti, c3r, c3i) + b1r;
+      A3i = cmul_i(tr, ti, c3r, c3i) + b1i;
     }
-    const double rad3 = cbrt(__builtin_sqrt(dfma(Qr, Qr, Qi * Qi)));
+    double rad3 = cbrt(__builtin_sqrt(dfma(Qr, Qr, Qi * Qi)));
     const double c4r = 0.25 * e1r, c4i = 0.25 * e1i;
-    double Pr, Pi, dr, di;
+    double Pr, Pi, dr, di;                                            // P(c4 + w) = w^4 + A4 w^2 + P'(c4) w + P(c4)
     poly(c4r, c4i, Pr, Pi, dr, di);
-    const double rad4 = __builtin_sqrt(__builtin_sqrt(__builtin_sqrt(dfma(Pr, Pr, Pi * Pi))));      // |P(c)|^(1/4)
-    // unit vectors: e^(i (0.7 + q pi / 2)) for the circle of four, e^(i (0.7 + 2 (q - 1) pi / 3)) for the circle of three
-    const double u4x = q == 0 ? 0.7648421872844885 : (q == 1 ? -0.644217687237691 : (q == 2 ? -0.7648421872844885 : 0.644217687237691));
-    const double u4y = q == 0 ? 0.644217687237691 : (q == 1 ? 0.7648421872844885 : (q == 2 ? -0.644217687237691 : -0.7648421872844885));
-    const double u3x = q == 1 ? 0.7648421872844885 : (q == 2 ? -0.9403308102168177 : 0.17548862293232925);
-    const double u3y = q == 1 ? 0.644217687237691 : (q == 2 ? 0.34026400880486145 : -0.9844816960425524);
+    double rad4 = __builtin_sqrt(__builtin_sqrt(__builtin_sqrt(dfma(Pr, Pr, Pi * Pi))));      // |P(c)|^(1/4)
+    if ((informed ? rad3 : rad4) < 1e-3) {                            // (trap (i): rare, uniform over the quad)
+      const double tr = 6.0 * c4r - 3.0 * e1r, ti = 6.0 * c4i - 3.0 * e1i;
+      const double A4r = cmul_r(tr, ti, c4r, c4i) + e2r, A4i = cmul_i(tr, ti, c4r, c4i) + e2i;
+      rad4 = fmax(rad4, fmax(__builtin_sqrt(__builtin_sqrt(dfma(A4r, A4r, A4i * A4i))), cbrt(__builtin_sqrt(dfma(dr, dr, di * di)))));
+      rad3 = fmax(rad3, __builtin_sqrt(__builtin_sqrt(dfma(A3r, A3r, A3i * A3i))));
+    }
+    // four points: radii (1, 0.8, 1.25, 0.9) at the angles (0.7, 2.1, 4.0, 5.3); three points (lanes 1 - 3): radii (1, 0.8, 1.2) at (0.7, 2.6, 4.9)
+    const double u4x = q == 0 ? 0.7648421872844885 : (q == 1 ? -0.40387688367988606 : (q == 2 ? -0.8170545260795149 : 0.4989369025612447));
+    const double u4y = q == 0 ? 0.644217687237691 : (q == 1 ? 0.6905674933190991 : (q == 2 ? -0.9460031191349103 : -0.7490406980015112));
+    const double u3x = q == 1 ? 0.7648421872844885 : (q == 2 ? -0.6855110026951579 : 0.22381484330709092);
+    const double u3y = q == 1 ? 0.644217687237691 : (q == 2 ? 0.41240109745717135 : -1.178943135149199);
     if (informed) {
       zr = q == 0 ? ar : dfma(rad3, u3x, c3r);
       zi = q == 0 ? ai : dfma(rad3, u3y, c3i);
@@ -341,8 +357,10 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
   }
   // ---- Aberth - Ehrlich.  Only the root of LARGEST modulus has to be converged, the others only far enough to be ranked below it: the iteration
   // of a quad is over when its largest root has settled (step < 1e-14 of its modulus) and every other root either has settled too (tied moduli) or
-  // sits, with four times its last step, inside the largest one's circle.  (Small roots settle slowly in RELATIVE terms - a root at zero never -
-  // and are not wanted.)
+  // HAS LOCALISED a root below the largest one: a step under 1e-2 of the largest modulus (cubic convergence: the root is within that step) and,
+  // with four times that step, inside the largest one's circle.  (Small roots settle slowly in RELATIVE terms - a root at zero never - and are
+  // not wanted; but a point that is merely PASSING at small modulus with a large step may be on its way to the dominant root nobody has found
+  // yet, and is not "below" anything.)
   bool fin = false;
   double prev_s2 = 1e300;
   for (int it = 0; it < 40; ++it) {
@@ -379,10 +397,19 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
     const bool settled = !(s2 > 1e-28 * z2 + 1e-300) || (s2 < 1e-20 * z2 && s2 > 0.04 * prev_s2);
     prev_s2 = s2;
     const double reach = __builtin_sqrt(z2) + 4.0 * __builtin_sqrt(s2);
-    const bool below = reach * reach < zmax;
+    const bool below = reach * reach < zmax && s2 < 1e-4 * zmax;
     const bool ok = settled || below;
     const double okall = quad_sum(ok ? 0.0 : 1.0);
     fin = fin || okall == 0.0;
+    if (it >= 9 && !fin) {
+      // (simple roots are done by now) a cluster round the largest root - a multiple root: linear convergence, eps^(1/m) accuracy: stop, the
+      // caller's squaring solve answers it
+      const bool top = z2 == zmax;
+      const double tr_ = quad_sum(top ? zr : 0.0), ti_ = quad_sum(top ? zi : 0.0), tn = quad_sum(top ? 1.0 : 0.0);
+      const double dx = zr * tn - tr_, dy = zi * tn - ti_;                       // (tn > 1: equal moduli - the distance to their mean, as good)
+      const double cnt = quad_sum(dfma(dx, dx, dy * dy) < 1e-6 * zmax * tn * tn ? 1.0 : 0.0);
+      if (cnt > 1.5) { fin = true; fallback = true; }
+    }
     if (__builtin_amdgcn_ballot_w64(!fin) == 0) break;        // (every quad of the wave is done)
   }
   // the root of largest modulus, in every lane of the quad (the first of equal ones)
@@ -398,24 +425,19 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
     if (m3 > Mx) { Mx = m3; Rx = r3; Ix = i3; }
     br_ = Rx; bi_ = Ix; bm = Mx;
   }
-  // a (nearly) MULTIPLE largest root: its computed copies sit ~eps^(1/m) |z| apart, symmetrically - their mean is good to rounding (a double
-  // dominant eigenvalue of a depth-1 circuit on the special grid came back 1e-8 high without this)
+  // a root within 1e-3 of the largest one (a multiple root, or a pair the quartic resolves badly), or a largest root below 1e-3 ||E||_F (a
+  // nilpotent map's noise): the squaring solve's cases
   {
     const double dx = zr - br_, dy = zi - bi_;
-    const bool near = dfma(dx, dx, dy * dy) < 1e-8 * bm;
-    const double cnt = quad_sum(near ? 1.0 : 0.0);
-    const double sxr = quad_sum(near ? zr : 0.0), sxi = quad_sum(near ? zi : 0.0);
-    if (cnt > 1.5) {
-      const double ic = 1.0 / cnt;
-      br_ = sxr * ic;
-      bi_ = sxi * ic;
-    }
+    const double cnt = quad_sum(dfma(dx, dx, dy * dy) < 1e-6 * bm ? 1.0 : 0.0);
+    if (cnt > 1.5 || bm < 1e-6) fallback = true;
   }
   const double back = zero ? 0.0 : __builtin_sqrt(m2);        // undo the scaling
   eta_r = br_ * back;
   eta_i = bi_ * back;
-  // all four roots settled?  (a multiple root converges linearly: 48 iterations leave it at ~1e-12 of its modulus - accepted; NaN is not)
-  if (!(eta_r == eta_r && eta_i == eta_i)) status = QMPS_ST_NOT_CONVERGED;
+  if (zero) fallback = false;                                  // (E = 0: eta = 0, nothing to square)
+  // (the cap of 40 iterations is never the exit of a simple largest root; NaN - a NaN map - is not an answer)
+  if (!(eta_r == eta_r && eta_i == eta_i)) { status = QMPS_ST_NOT_CONVERGED; fallback = false; }
 }
 
 // One trajectory per workgroup; FOUR LANES per candidate of an evaluation pass (16 candidates per wave; 2P + 1 + 7 candidates:
@@ -497,8 +519,18 @@ __global__ __launch_bounds__(256) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
       {
         double rowr[4], rowi[4];
         overlap_quad_build(sC, amp_r, amp_i, q, rowr, rowi);
-        if (p.probe & 4) overlap_quad_solve(rowr, rowi, q, p.max_rounds, p.tol, er, ei, rounds, status);
-        else overlap_quad_charpoly(rowr, rowi, q, sT + (tid >> 2) * 32, er, ei, rounds, status);
+        // the characteristic-polynomial solve; the squaring solve for the maps it hands back (multiple or collapsed largest roots: points of the
+        // special grid) - and for every map under QMPS_EVOLVE_D2_SQUARING.  ONE call site of the squaring: the body is inlined once.
+        bool squaring = (p.probe & 4) != 0;
+        int rounds_cp = 0;
+        if (!squaring) {
+          overlap_quad_charpoly(rowr, rowi, q, sT + (tid >> 2) * 32, er, ei, rounds_cp, status, squaring);
+          rounds = rounds_cp;
+        }
+        if (squaring) {                                   // (uniform over a quad)
+          overlap_quad_solve(rowr, rowi, q, p.max_rounds, p.tol, er, ei, rounds, status);
+          rounds += rounds_cp;
+        }
       }
 #ifdef QMPS_D2_PHASES
       t3 = wall_clock64();

@@ -64,3 +64,26 @@ def replay_rotosolve(kind, D, params, WW, n_steps, n_sweeps, nsh=3, gaps=None, g
                 fh[step, sw, t] = f(A[t], X[t])
         ph[step] = X
     return ph, fh
+
+
+def spectral_radius(E, squarings=48):
+    """max |eigenvalue| of a small dense matrix by Gelfand's formula on normalised squarings, ||E^(2^k)||^(1/2^k): good to ~1e-13 where an
+    eigenvalue solver is not - a MULTIPLE dominant eigenvalue (numpy's eigvals: eps^(1/m) of its modulus on a Jordan block) or a nilpotent
+    matrix (collapses to exactly 0).  Test infrastructure for the maps of the special grid."""
+    X = np.array(E, dtype=complex)
+    log_rho = 0.0
+    for k in range(squarings + 1):
+        n = np.linalg.norm(X)
+        if not n > 1e-280 or (k > 0 and n < 1e-13):      # (the square of a unit-norm matrix at rounding level: a nilpotent matrix's collapse)
+            return 0.0
+        log_rho += np.log(n) / 2.0 ** k
+        X = X / n
+        X = X @ X
+    return float(np.exp(log_rho))
+
+
+def objective_gelfand(kind, D, A, p, WW):
+    """-sqrt(spectral radius) of the mixed transfer matrix oracle.overlap_eta diagonalises (see `objective`)."""
+    B = tensor(kind, D, p)
+    C = np.tensordot(WW, O.merge(A, A), [1, 0])
+    return -np.sqrt(spectral_radius(O.transfer_matrix(C, O.merge(B, B))))

@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 #define QMPS_ABI_VERSION 6
-#define QMPS_ABI_MINOR 4
+#define QMPS_ABI_MINOR 5
 
 /* error codes */
 #define QMPS_OK 0
@@ -55,7 +55,7 @@ extern "C" {
 #define QMPS_STATUS_NOT_PD 2        /* Cholesky of r fails: the reference's LinAlgError branch
                                        (qmps/ground_state.py:153-157) */
 /* (3 is internal to the library and never returned) */
-#define QMPS_STATUS_TIED 4          /* overlap path, D = 2 (ABI 6.4): the dominant eigenvalues of the mixed transfer map are TIED in modulus;
+#define QMPS_STATUS_TIED 4          /* overlap path, D = 2 (ABI 6.4) and D = 4 (6.5): the dominant eigenvalues of the mixed transfer map are TIED in modulus;
                                        eta_out = their common modulus (real) and the objective -sqrt|eta| is valid - the library's optimisers
                                        use it - but there is NO unique fixed point: r_out is a mixture, not an eigenvector.
                                        Status 0 keeps meaning "r_out is the fixed point to tol" (ABI 6.2 / 6.3 returned 0 here) */
@@ -191,7 +191,12 @@ int qmps_abi_version(void);
  * 6.4: QMPS_STATUS_TIED (the D = 2 overlap solves report a tie of the dominant eigenvalues by its own status instead of 0: eta is usable, r_out is
  *      not a fixed point); qmps_evolve_bfgs_device_opts: max_rounds = 0 means 100 000 power steps at D = 16 as documented (it meant 60);
  *      qmps_bw_env: the relaxed rank-one acceptance honours the caller's tol; D = 4 QMPS_ENV_POWER runs env_power_d4_kernel (QMPS_POWER_LANE: the old
- *      kernel), the D = 2 device-resident driver solves by the characteristic polynomial (QMPS_EVOLVE_D2_SQUARING: by squaring) - same results. */
+ *      kernel), the D = 2 device-resident driver solves by the characteristic polynomial (QMPS_EVOLVE_D2_SQUARING: by squaring) - same results.
+ * 6.5: the D = 4 overlap solves (qmps_overlap_*, qmps_evolve_bfgs_device at D = 4) report tied dominant eigenvalues as the D = 2 ones do - 30 to 44
+ *      squarings without a rank-one power: eta = the common modulus (real), QMPS_STATUS_TIED; they returned status 1 - or, with max_rounds > 50, where
+ *      rounding noise breaks the tie, the quotient of a noise-picked direction with status 0 (|eta| = 1.0008, 0.54 at points of the special grid where
+ *      it is 1, 0.999).  A rank-one power later than round 44 is no longer believed.  The D = 4 device-resident driver rests at a tied point (objective
+ *      recorded, gradient NaN: the perturbative neighbours have no fixed points to expand round). */
 int qmps_abi_minor(void);
 const char* qmps_last_error(void);
 /* Test hook for the contract above ("nothing throws across the ABI"): raises a C++ exception inside the library - kind 1
@@ -367,8 +372,9 @@ int qmps_cell2_energy_batch_su(qmps_ctx* ctx, int64_t B, const double* params /*
  * O(log) rounds whatever the spectral gap) - D = 2 in a lane, D = 4 as one complex 16 x 16 tile on the matrix cores,
  * until it is rank one (||M M - tr(M) M||_F < tol ||M M||_F), eta = tr(M E)/tr(M); a map whose powers collapse to rounding
  * noise within the first rounds is NILPOTENT (reference and candidate orthogonal): eta = 0, status 0 (ABI 6.2; it used to return noise);
- * D = 2 (ABI 6.2): dominant eigenvalues TIED in modulus (a complex-conjugate pair on the symmetric manifolds BFGS ends up on, a ring) - 30 and more
- * squarings without a rank-one power - return their common MODULUS as a real eta with status QMPS_STATUS_TIED (ABI 6.4; 6.2 / 6.3: status 0) - the
+ * D = 2 (ABI 6.2), D = 4 (ABI 6.5): dominant eigenvalues TIED in modulus (a complex-conjugate pair on the symmetric manifolds BFGS ends up on, a ring;
+ * 1, 1, -1, -1 of a non-injective state on the special grid) - 30 and more squarings without a rank-one power (D = 4: none is believed after round 44,
+ * where rounding noise starts to break a tie) - return their common MODULUS as a real eta with status QMPS_STATUS_TIED (ABI 6.4; 6.2 / 6.3: status 0) - the
  * reference's objective -sqrt|eta| is the same for whichever member ARPACK returns, and every optimiser of this library treats the status as usable;
  * r_out is then the largest column of the last power, a mixture, not an eigenvector;
  * D = 8, 16 run the power method in operator form from x_0 = (1 + 2^-12 G)/sqrt(D), G a fixed pseudo-random complex matrix (ABI 6.2: the

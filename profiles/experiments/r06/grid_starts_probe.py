@@ -14,7 +14,10 @@ from qmps_amd.engine import EnergyEngine
 H = O.hamiltonian_matrix({'ZZ': -1.0, 'X': 1.0})
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 out = []
-for D, kind, P in ((2, L.ANSATZ_SHALLOW_CNOT, 2), (2, L.ANSATZ_SHALLOW_CNOT, 8), (2, L.ANSATZ_SHALLOW_FULL, 15), (4, L.ANSATZ_SHALLOW_CNOT, 4), (4, L.ANSATZ_SHALLOW_CNOT, 8)):
+CASES = ((2, L.ANSATZ_SHALLOW_CNOT, 2), (2, L.ANSATZ_SHALLOW_CNOT, 8), (2, L.ANSATZ_SHALLOW_FULL, 15), (4, L.ANSATZ_SHALLOW_CNOT, 4), (4, L.ANSATZ_SHALLOW_CNOT, 8))
+if len(sys.argv) > 2:
+    CASES = tuple(c for c in CASES if c[0] == int(sys.argv[2]) and c[2] == int(sys.argv[3]))
+for D, kind, P in CASES:
     for dt in (0.0, 0.05, 0.3):
         WW = expm(-1j * dt * H)
         X0 = np.concatenate([rng.integers(-4, 5, (150, P)) * (np.pi / 4), rng.integers(-2, 3, (150, P)) * (np.pi / 2)])
@@ -36,7 +39,7 @@ for D, kind, P in ((2, L.ANSATZ_SHALLOW_CNOT, 2), (2, L.ANSATZ_SHALLOW_CNOT, 8),
                     continue
                 worst0 = max(worst0, abs(f0 - g0)); worst = max(worst, abs(f1 - g1))
                 if max(abs(f0 - g0), abs(f1 - g1)) > 1e-8 and len(bad) < 3:
-                    bad.append({'t': t, 'step': step, 'x0': (prev[t] / (np.pi / 4)).round(3).tolist(), 'f0': f0, 'g0': g0, 'f1': f1, 'g1': g1})
+                    bad.append({'t': t, 'step': step, 'x0': (prev[t] / (np.pi / 4)).round(3).tolist(), 'x0_exact': [float.hex(float(v)) for v in prev[t]], 'f0': f0, 'g0': g0, 'f1': f1, 'g1': g1})
             prev = res['params_hist'][step]
         rec = {'D': D, 'kind': int(kind), 'P': P, 'dt': dt, 'worst_start': worst0, 'worst_end': worst, 'nonfinite': nan, 'failed_evaluations': res['failed_evaluations'], 'bad': bad}
         print(json.dumps(rec), flush=True)

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libqmps_hip.so')
 QMPS_OK = 0
 QMPS_ERR_ARG, QMPS_ERR_HIP, QMPS_ERR_NO_DEVICE, QMPS_ERR_STATE, QMPS_ERR_RCCL = -1, -2, -3, -4, -5
 STATUS_OK, STATUS_NOT_CONVERGED, STATUS_NOT_PD = 0, 1, 2
-STATUS_TIED = 4          # overlap path, D = 2: eta = the common modulus of tied dominant eigenvalues (objective usable, r_out no fixed point)
+STATUS_TIED = 4          # overlap path, D = 2, 4: eta = the common modulus of tied dominant eigenvalues (objective usable, r_out no fixed point)
 
 
 def overlap_usable(st):

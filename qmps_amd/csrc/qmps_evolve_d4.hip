@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * NWMAX) void evolve_bfgs_d4_kernel(EvolveD2Args
         const double den = d.x * d.x + d.y * d.y;
         const double er = (nr * d.x + ni * d.y) / den, ei = (ni * d.x - nr * d.y) / den;
         sF[cand] = -__builtin_sqrt(__builtin_sqrt(er * er + ei * ei));
-        sOK[cand] = (sOK[0] && den > 1e-280) ? 1 : 0;
+        sOK[cand] = (sOK[0] == 1 && den > 1e-280) ? 1 : 0;      // (a TIED point has an objective but no fixed points to expand round: no gradient)
       }
     };
     const int solve_cand = with_grad ? (wave == 0 ? 0 : -1) : (wave < n_ladder ? G1 + wave : -1);
@@ -129,9 +129,11 @@ __global__ __launch_bounds__(64 * NWMAX) void evolve_bfgs_d4_kernel(EvolveD2Args
 #endif
       if (lane == 0) {
         sF[solve_cand] = -__builtin_sqrt(__builtin_sqrt(eta_r * eta_r + eta_i * eta_i));
-        sOK[solve_cand] = status == QMPS_ST_OK ? 1 : 0;
+        // 1: eigen-solved; 2: dominant eigenvalues tied in modulus (QMPS_ST_TIED: the objective is their common modulus - usable, as at D = 2 -
+        // but the power holds a mixture: the neighbours below get no value and the gradient is NaN - the trajectory rests there); 0: no answer
+        sOK[solve_cand] = status == QMPS_ST_OK ? 1 : (overlap_usable(status) ? 2 : 0);
         atomicAdd(&sCnt[1], (double)rounds);
-        if (status != QMPS_ST_OK) atomicAdd(&sCnt[2], 1.0);
+        if (!overlap_usable(status)) atomicAdd(&sCnt[2], 1.0);
       }
       if (with_grad) {
         // ---- r = largest column of M, y = conjugate of its largest row (M -> u v^+ ; any scale: eta' is a quotient)

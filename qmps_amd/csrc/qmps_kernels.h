@@ -7,7 +7,7 @@ namespace qmps {
 
 enum { QMPS_ST_OK = 0, QMPS_ST_NOT_CONVERGED = 1, QMPS_ST_NOT_PD = 2,
        QMPS_ST_PENDING = 3 /* internal, between the kernels of one launch: handed to the Krylov fall-back (D = 16 environment) */,
-       QMPS_ST_TIED = 4 /* overlap path, D = 2: dominant eigenvalues tied in modulus - eta is their common modulus, the vector is NOT a fixed point */ };
+       QMPS_ST_TIED = 4 /* overlap path, D = 2, 4: dominant eigenvalues tied in modulus - eta is their common modulus, the vector is NOT a fixed point */ };
 // an overlap evaluation whose eta (hence the objective -sqrt|eta|) may be used: converged, or the common modulus of a tie (QMPS_STATUS_TIED)
 __host__ __device__ inline bool overlap_usable(int status) { return status == QMPS_ST_OK || status == QMPS_ST_TIED; }
 

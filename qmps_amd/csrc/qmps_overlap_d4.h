@@ -64,7 +64,8 @@ __device__ __forceinline__ void cmma16_3m(const double (&pre)[4], const double (
 
 // The mixed transfer map of D = 4 IS one complex 16 x 16 tile, E[(i,i'),(j,j')] = sum_{s<4} C_s[i][j] conj(Bm_s[i'][j']); the power method
 // is taken 2^m steps at a time by SQUARING it (16 v_mfma_f64_16x16x4 per round, Frobenius-normalised) until it is rank one
-// (||M M - tr(M) M||_F < tol ||M M||_F), then eta = tr(M E)/tr(M).  One wave; Ap / Bp: reference / candidate tensors [2][4][4]
+// (||M M - tr(M) M||_F < tol ||M M||_F), then eta = tr(M E)/tr(M); 30 - 44 rounds without one: TIED dominant eigenvalues, eta = their modulus
+// (Gelfand), QMPS_ST_TIED.  One wave; Ap / Bp: reference / candidate tensors [2][4][4]
 // (any address space); sT: the wave's LDS scratch [kSquareD4Scratch]; (mr, mi): the final M in the accumulator layout (its largest column
 // / row are the right / left fixed points).  All results wave-uniform.  sT: kSquareD4Scratch entries per wave.
 constexpr int kSquareD4Keep = 16 * 17, kSquareD4Scratch = kSquareD4Keep + 128;
@@ -121,6 +122,7 @@ __device__ __forceinline__ void overlap_square_d4_item(const double2* Ap, const 
     }
     // ---- squaring rounds
     v4f64 mr = er, mi = ei;
+    double hist = 0.0;      // lane m: ||M_m M_m||^2 of round m, lane 63: ||E||^2 - what a tie's modulus is read from at the end (a select per round; through LDS it cost 2 %)
     {
       double n2 = 0.0;
 #pragma unroll
@@ -129,6 +131,7 @@ __device__ __forceinline__ void overlap_square_d4_item(const double2* Ap, const 
       const double inv = n2 > 0.0 ? fast_rsqrt(n2) : 0.0;        // (v_rsq_f64 + a Newton step: the scale only keeps the powers O(1))
       mr *= inv;
       mi *= inv;
+      hist = lane == 63 ? n2 : hist;
     }
     int rounds = 0, status = QMPS_ST_NOT_CONVERGED;
     bool nilpotent = false, collapsed = false;
@@ -162,6 +165,7 @@ __device__ __forceinline__ void overlap_square_d4_item(const double2* Ap, const 
       }
       q2 = lane0(wave_sum(q2));
       rounds = m;
+      hist = lane == m ? q2 : hist;      // (m <= kLastPass < 63)
       if (q2 < 1e-28) {
         // ||M^2|| < 1e-14 ||M||: the power of the map has collapsed to rounding noise - a NILPOTENT map (reference and candidate orthogonal:
         // every eigenvalue vanishes).  Normalising that noise and squaring on used to 'converge' to the dominant direction of a random
@@ -177,7 +181,13 @@ __device__ __forceinline__ void overlap_square_d4_item(const double2* Ap, const 
         status = QMPS_ST_OK;
         break;
       }
-      if (m == max_rounds) break;
+      // No rank-one power by round kLastPass: none is believed later.  Dominant eigenvalues TIED in modulus (a non-injective state on the special
+      // grid of the ansatz: 1, 1, -1, -1) keep M = P_1 + P_2 + .. for ever in exact arithmetic; in floating point every squaring moves the unit
+      // eigenvalues of M by ~1e-16 and DOUBLES what is there already - round ~53 breaks the tie on noise, the power turns rank one and
+      // tr(M E) / tr(M) of that noise-picked direction came back with status 0 (|eta| = 1.0008, 0.54 where it is 1, 0.999;
+      // profiles/experiments/r06/grid_starts_probe.py).  A genuine gap that needs 45 squarings is 1e-12: a tie by any standard.
+      constexpr int kLastPass = 44;
+      if (m == max_rounds || m >= kLastPass) break;
       const double inv = fast_rsqrt(q2);
       mr = qr * inv;
       mi = qi * inv;
@@ -207,7 +217,23 @@ __device__ __forceinline__ void overlap_square_d4_item(const double2* Ap, const 
     double eta_r = 0.0, eta_i = 0.0;
     if (collapsed) {
       // (nilpotent: eta = 0 exactly, status 0; a late collapse: status 1.  The fixed points handed out are whatever the last power held)
-    } else if (den > 1e-280) {
+    } else if (status != QMPS_ST_OK && rounds >= 30) {
+      // ---- TIED dominant eigenvalues (as the D = 2 solvers, qmps_overlap_d2.h): their common modulus by Gelfand's formula from the norms the
+      // rounds left in `hist` - E = n M_0, M_(m+1) = M_m M_m / s_m with ||M_m|| = 1:  ||E^(2^k)||^(1/2^k) = n prod_(m<k) s_m^(2^-(m+1)), good to
+      // 2^-k log(condition) (3e-9 after 30 rounds, 1e-13 after 44) - as NESTED SQUARE ROOTS, sqrt(s_0 sqrt(s_1 sqrt(s_2 ..))): logarithms here cost
+      // the squaring kernels 15 - 40 registers (the overlap kernel its fourth wave per SIMD), a call out of line 2 % of the overlap workload.
+      // eta = rho (real), QMPS_ST_TIED: the objective -sqrt|eta| is the reference's whichever member ARPACK returns; (mr, mi) are the last
+      // power - a mixture, no fixed point.
+      double acc = 1.0;
+#pragma nounroll
+      for (int m = rounds; m >= 0; --m) acc = __builtin_sqrt(__builtin_sqrt(__shfl(hist, m, 64)) * acc);
+      const double rho = __builtin_sqrt(__shfl(hist, 63, 64)) * acc;
+      if (rho > 0.0 && rho < 1e300) {      // (a NaN map, a zero map: status 1)
+        eta_r = rho;
+        eta_i = 0.0;
+        status = QMPS_ST_TIED;
+      }
+    } else if (den > 1e-280) {      // (status 1 - the budget ended before a rank-one power, too early to call it a tie: the estimate of the last power)
       eta_r = (nr * trr + ni * tri) / den;
       eta_i = (ni * trr - nr * tri) / den;
     } else {

@@ -445,3 +445,36 @@ def test_circuit_amplitude_for_given_environments(D, engine_factory):
     from qmps_amd import _lib as L
     with pytest.raises(L.QmpsError):
         eng.overlap_amplitudes(np.concatenate([q] * 200)[:4097])      # beyond the context's capacity
+
+
+def test_tied_dominant_eigenvalues_at_d4_return_the_common_modulus(engine_factory):
+    """Round 6 (ABI 6.5; profiles/experiments/r06/grid_starts_probe.py): on the grid of multiples of pi / 4 the depth-2 ShallowCNOT state at D = 4 can be
+    non-injective - its transfer map carries 1, 1, -1, -1 - and the squaring solve of D = 4 has no rank-one power to find.  It used to end with status 1 at
+    max_rounds = 40, and with max_rounds = 60 (the device-resident driver's default) rounding noise broke the tie near round 53: the quotient of a
+    noise-picked direction came back with status 0 (|eta| = 1.0008, 0.54).  Now: no rank-one power is believed after round 44, and 30+ rounds without one
+    are a tie - eta = the common modulus (Gelfand, from the norms of the rounds), QMPS_STATUS_TIED, as at D = 2."""
+    import evolve_replay as ER
+    H = O.hamiltonian_matrix({'ZZ': -1.0, 'X': 1.0})
+    eng = engine_factory(4, 1024)
+    cases = [([-2, -4, 0, 2], 0.0), ([2, -4, 0, 4], 0.05), ([4, 2, -4, 2], 0.05), ([2, 4, 0, -2], 0.3)]
+    for grid, dt in cases:
+        WW = expm(-1j * dt * H)
+        x = np.array(grid) * (np.pi / 4)
+        A = O.unitary_to_tensor(O.shallow_cnot_unitary(4, x))
+        E = O.transfer_matrix(np.tensordot(WW, O.merge(A, A), [1, 0]), O.merge(A, A))
+        w = np.sort(np.abs(np.linalg.eigvals(E)))[::-1]
+        assert abs(w[0] - w[1]) < 1e-5 * w[0]                                     # (tied, or split by 1e-6: a tie to any squaring budget)
+        rho = ER.spectral_radius(E)
+        for max_rounds in (40, 60):
+            eta, rounds, st = eng.overlaps(A[None], x[None], WW, kind='params', ansatz=0, tol=1e-13, max_rounds=max_rounds)
+            assert st[0] == L.STATUS_TIED and eta[0].imag == 0.0 and abs(eta[0].real - rho) < 1e-9, (grid, dt, max_rounds, eta, rho, st)
+        # a budget too short to call it a tie: status 1, as before
+        eta, rounds, st = eng.overlaps(A[None], x[None], WW, kind='params', ansatz=0, tol=1e-13, max_rounds=20)
+        assert st[0] == L.STATUS_NOT_CONVERGED
+    # and a generic pair is untouched: status 0, eta to 1e-12
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((8, 4))
+    A = np.stack([O.unitary_to_tensor(O.shallow_cnot_unitary(4, v)) for v in x])
+    WW = expm(-0.05j * H)
+    eta, rounds, st = eng.overlaps(A, x + 0.05 * rng.standard_normal(x.shape), WW, kind='params', ansatz=0, tol=1e-13, max_rounds=60)
+    assert np.all(st == 0) and rounds.max() < 30

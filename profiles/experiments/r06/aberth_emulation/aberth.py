@@ -4,7 +4,7 @@ kernel.  The hand-back (`clustered`) is answered with numpy eigvals here; the ke
 import numpy as np
 U4=np.array([1.0,0.8,1.25,0.9])*np.exp(1j*np.array([0.7,2.1,4.0,5.3]))
 U3=np.array([1.0,0.8,1.2])*np.exp(1j*np.array([0.7,2.6,4.9]))
-def solve(E, BS=1e-4, CL=1e-6, SMALL=1e-6, E0=10, KAP=1e-4):      # (the kernel's values)
+def solve(E, BS=1e-4, CL=1e-6, SMALL=1e-6, E0=10, KAP=1e-6):      # (the kernel's values)
     """returns eta, iterations, fallback flag"""
     m2=(abs(E)**2).sum()
     if not m2>1e-300: return 0.0,0,False
@@ -45,7 +45,8 @@ def solve(E, BS=1e-4, CL=1e-6, SMALL=1e-6, E0=10, KAP=1e-4):      # (the kernel'
             if abs(d[k])<KAP*zmax**1.5: clustered=True; break      # (|P'| at the pre-step point of the largest root's lane)
     k=np.argmax(abs(z)); d2=abs(z-z[k])**2; zmax=abs(z[k])**2
     kappa=np.prod([abs(z[k]-z[j]) for j in range(4) if j!=k])
-    if kappa<KAP*zmax**1.5 or zmax<SMALL or not np.isfinite(z[k]): clustered=True      # (KAP: the conditioning of the largest root, prod_j |1 - z_j / z|)
+    near=min(abs(z[k]-z[j]) for j in range(4) if j!=k)
+    if kappa<KAP*zmax**1.5 or near**2<CL*zmax or zmax<SMALL or not np.isfinite(z[k]): clustered=True      # (KAP: the conditioning of the largest root, prod_j |1 - z_j / z|)
     if clustered:
         return max(abs(np.linalg.eigvals(E))), it+1, True
     return z[k]/sc, it+1, False

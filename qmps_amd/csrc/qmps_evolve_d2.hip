@@ -230,7 +230,7 @@ __device__ __forceinline__ void overlap_quad_solve(const double (&er)[4], const 
 // coefficients carry ~1e-16 |eta|^k, a simple dominant root moves by 1e-16 |eta| / prod_j |1 - eta_j / eta| (2e-15 at a gap of 0.05) - but an m-fold
 // dominant root by eps^(1/m) of its modulus (1e-8, 5e-6, 1e-4) and the iteration converges only linearly on it, and a nilpotent map's P = z^4 + noise
 // has roots of 1e-4 ||E||.  Those maps - points of the special grid (multiples of pi / 4: product states, permutation-like tensors), never met
-// by a generic trajectory - and every largest root the quartic knows badly (kappa = prod_j |1 - eta_j / eta| < 1e-4) are NOT answered here: `fallback`
+// by a generic trajectory - and every largest root the quartic knows badly (kappa = prod_j |1 - eta_j / eta| < 1e-6) are NOT answered here: `fallback`
 // comes back set (that, or a largest root below 1e-3 ||E||_F) and the caller runs the squaring solve above on the quad, whose Gelfand route and collapse test give them to 1e-11.
 // E is scaled to unit Frobenius norm first.  sT: 32 double2 of LDS per quad.  rounds = Aberth iterations.
 __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], const double (&ei)[4], int q, double2* sT, double& eta_r, double& eta_i,
@@ -407,7 +407,7 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
       // solve answers it
       const bool top = z2 == zmax;
       const double dtop = quad_sum(top ? dn : 0.0), tn = quad_sum(top ? 1.0 : 0.0);
-      if (dtop < 1e-8 * zmax * zmax * zmax * tn) { fin = true; fallback = true; }
+      if (dtop < 1e-12 * zmax * zmax * zmax * tn) { fin = true; fallback = true; }
     }
     if (__builtin_amdgcn_ballot_w64(!fin) == 0) break;        // (every quad of the wave is done)
   }
@@ -427,13 +427,17 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
   // How well does the quartic know its largest root?  A simple root moves by eps / kappa, kappa = |P'(z)| / |z|^3 = prod_j |1 - z_j / z|, when the
   // coefficients move by eps: 1e-15 at the gaps of a generic trajectory - but four eigenvalues within 1e-3 of each other (a trajectory one BFGS step
   // off the special grid: 0.93408, 0.93311, 0.93311, 0.93213) have kappa = 2e-9 and came back 1.4e-7 off, none of them "within 1e-3 of the largest".
-  // kappa < 1e-4 (a multiple root: 0), or a largest root below 1e-3 ||E||_F (a nilpotent map's noise): the squaring solve's cases.
+  // kappa < 1e-6 (a multiple root: 0; what passes is good to 1e-10), or a largest root below 1e-3 ||E||_F (a nilpotent map's noise): the squaring
+  // solve's cases.  (1e-4 handed back the whole early evolution of ONE of 256 generic trajectories - near-cluster after near-cluster - and the
+  // slowest trajectory is the launch: +10 % on the first ten time steps.)
   {
-    double prod2 = 1.0;
+    double prod2 = 1.0, near2 = 1e300;
 #define QMPS_OTHER(CTRL)                                                                                       \
     {                                                                                                          \
       const double xr_ = zr - quad_perm<CTRL>(zr), xi_ = zi - quad_perm<CTRL>(zi);                            \
-      prod2 *= dfma(xr_, xr_, xi_ * xi_);                                                                      \
+      const double d2_ = dfma(xr_, xr_, xi_ * xi_);                                                            \
+      prod2 *= d2_;                                                                                            \
+      near2 = fmin(near2, d2_);                                                                                \
     }
     QMPS_OTHER(0x39) QMPS_OTHER(0x4E) QMPS_OTHER(0x93)
 #undef QMPS_OTHER
@@ -441,8 +445,11 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
     const double mine = dfma(zr, zr, zi * zi);
     const bool top = mine == bm;
     const double before = (q > 0 && quad_bcast<0>(mine) == bm ? 1.0 : 0.0) + (q > 1 && quad_bcast<1>(mine) == bm ? 1.0 : 0.0) + (q > 2 && quad_bcast<2>(mine) == bm ? 1.0 : 0.0);
-    const double kap2 = quad_sum(top && before == 0.0 ? prod2 : 0.0);
-    if (kap2 < 1e-8 * bm * bm * bm || bm < 1e-6) fallback = true;
+    const bool pick = top && before == 0.0;
+    const double kap2 = quad_sum(pick ? prod2 : 0.0), nr2 = quad_sum(pick ? near2 : 0.0);
+    // (and a root within 1e-3 of it: the copies of a noise-split MULTIPLE root sit eps^(1/m) apart - their kappa is itself noise, 1.2e-6 on a
+    // double root of modulus 6e-4 ||E||)
+    if (kap2 < 1e-12 * bm * bm * bm || nr2 < 1e-6 * bm || bm < 1e-6) fallback = true;
   }
   const double back = zero ? 0.0 : __builtin_sqrt(m2);        // undo the scaling
   eta_r = br_ * back;

@@ -195,8 +195,8 @@ int qmps_abi_version(void);
  * 6.5: the D = 4 overlap solves (qmps_overlap_*, qmps_evolve_bfgs_device at D = 4) report tied dominant eigenvalues as the D = 2 ones do - 30 to 44
  *      squarings without a rank-one power: eta = the common modulus (real), QMPS_STATUS_TIED; they returned status 1 - or, with max_rounds > 50, where
  *      rounding noise breaks the tie, the quotient of a noise-picked direction with status 0 (|eta| = 1.0008, 0.54 at points of the special grid where
- *      it is 1, 0.999).  A rank-one power later than round 44 is no longer believed.  The D = 4 device-resident driver rests at a tied point (objective
- *      recorded, gradient NaN: the perturbative neighbours have no fixed points to expand round). */
+ *      it is 1, 0.999).  A rank-one power later than round 44 is no longer believed.  The D = 4 device-resident driver eigen-solves the 2 P neighbours of
+ *      a tied point one by one (their second-order expansion has no fixed points to expand round) and leaves it as scipy's BFGS does. */
 int qmps_abi_minor(void);
 const char* qmps_last_error(void);
 /* Test hook for the contract above ("nothing throws across the ABI"): raises a C++ exception inside the library - kind 1

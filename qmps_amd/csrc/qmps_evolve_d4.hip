@@ -27,6 +27,16 @@ namespace {
 constexpr int NWMAX = 8;         // waves per workgroup (two per SIMD: 256 registers each - the squaring, the circuit and the optimiser loop need ~170)
 }
 
+// the eigen-solve of one neighbour of a TIED point, out of line (the rare path of `evaluate` below: a second inlined copy of the squaring rounds would
+// sit in the register budget of the common one)
+struct TiedNeighbour { double eta_r, eta_i; int rounds, status; };
+__device__ __attribute__((noinline)) TiedNeighbour solve_tied_neighbour(const double2* Ap, const double2* Bp, const double2* W, double2* sT, int max_rounds, double tol2) {
+  TiedNeighbour o;
+  v4f64 mr, mi;
+  overlap_square_d4_item(Ap, Bp, W, sT, max_rounds, tol2, o.eta_r, o.eta_i, o.rounds, o.status, mr, mi);
+  return o;
+}
+
 template <int KIND>
 __global__ __launch_bounds__(64 * NWMAX) void evolve_bfgs_d4_kernel(EvolveD2Args p) {
   constexpr int PMAX = kEvolvePMax;
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(64 * NWMAX) void evolve_bfgs_d4_kernel(EvolveD2Args
       if (lane == 0) {
         sF[solve_cand] = -__builtin_sqrt(__builtin_sqrt(eta_r * eta_r + eta_i * eta_i));
         // 1: eigen-solved; 2: dominant eigenvalues tied in modulus (QMPS_ST_TIED: the objective is their common modulus - usable, as at D = 2 -
-        // but the power holds a mixture: the neighbours below get no value and the gradient is NaN - the trajectory rests there); 0: no answer
+        // but the power holds a mixture: the probes below give the neighbours no value - they are eigen-solved one by one at the end of the pass); 0: no answer
         sOK[solve_cand] = status == QMPS_ST_OK ? 1 : (overlap_usable(status) ? 2 : 0);
         atomicAdd(&sCnt[1], (double)rounds);
         if (!overlap_usable(status)) atomicAdd(&sCnt[2], 1.0);
@@ -217,6 +227,23 @@ __global__ __launch_bounds__(64 * NWMAX) void evolve_bfgs_d4_kernel(EvolveD2Args
     if (with_grad && wave > 0)
       for (int nb = wave - 1; nb < 2 * P; nb += NW - 1) probe(1 + nb, sBm[nb][lane]);
     __syncthreads();
+    if (with_grad && sOK[0] == 2) {
+      // the point is TIED (a non-injective state on the special grid: 1, 1, -1, -1): no fixed points to expand round, the probes above left the
+      // neighbours without a value.  Every neighbour is eigen-solved instead - a tie's common modulus is an objective like any other, which is
+      // what the reference's finite differences see (ARPACK returns one member of the tie) and what the D = 2 kernel does for every candidate:
+      // the trajectory leaves the point instead of resting there.  (Uniform over the workgroup: sOK[0] is behind a barrier.)
+      for (int nb = wave; nb < 2 * P; nb += NW) {
+        build_tensor(sB[wave], par_of(1 + nb));
+        const TiedNeighbour o = solve_tied_neighbour(sA, sB[wave], W, sT[wave], p.max_rounds, tol2);
+        if (lane == 0) {
+          sF[1 + nb] = -__builtin_sqrt(__builtin_sqrt(o.eta_r * o.eta_r + o.eta_i * o.eta_i));
+          sOK[1 + nb] = overlap_usable(o.status) ? 1 : 0;
+          atomicAdd(&sCnt[1], (double)o.rounds);
+          if (!overlap_usable(o.status)) atomicAdd(&sCnt[2], 1.0);
+        }
+      }
+      __syncthreads();
+    }
 #ifdef QMPS_D2_PHASES
     { const long long t5 = wall_clock64(); ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += t5 - t4; ph[5] += 1; }
 #endif

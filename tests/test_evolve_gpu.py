@@ -992,7 +992,7 @@ def test_device_drivers_on_the_special_grid_against_gelfand(D, engine_factory):
     {l, -l, 0, 0}; polynomials with the symmetry of the starting polygon); the kernel hands the first class to its squaring solve (`fallback`,
     overlap_quad_charpoly) and starts the iteration off the polygon.  D = 4 (ABI 6.5): tied dominant eigenvalues (1, 1, -1, -1) used to come back as the
     quotient of a noise-picked direction with status 0 once rounding broke the tie (round ~53 of the driver's 60: |eta| = 1.0008, 0.54 where it is 1,
-    0.999) - now their common modulus, and the trajectory rests there (no fixed points to expand the gradient round).  Checked at EVERY recorded
+    0.999) - now their common modulus, and the neighbours of such a point are eigen-solved one by one (no fixed points to expand them round).  Checked at EVERY recorded
     point - the start and the end of each step - against Gelfand's formula (tests/evolve_replay.spectral_radius: good to 1e-13 where numpy's eigvals
     is not), 1e-9 throughout: no NaN, no failed evaluation."""
     rng = np.random.default_rng(606 + D)
@@ -1019,3 +1019,29 @@ def test_device_drivers_on_the_special_grid_against_gelfand(D, engine_factory):
                                 abs(ER.objective_gelfand(kind, D, A, res['params_hist'][step, t], WW) - res['fun'][step, t]))
                 prev = res['params_hist'][step]
             assert worst < 1e-9, (D, dt, kind, P, worst)
+
+
+def test_d4_device_driver_leaves_a_tied_start_as_scipy_does(engine_factory):
+    """ABI 6.5: a D = 4 trajectory STARTED at a non-injective state of the special grid (the map carries 1, 1, -1, -1: QMPS_STATUS_TIED) has an objective -
+    the tie's common modulus - but no fixed points for the second-order expansion of its 2 P neighbours: those are eigen-solved one by one
+    (solve_tied_neighbour, qmps_evolve_d4.hip), which is what the reference's finite differences over ARPACK see.  From four such starts the device
+    reaches the minimum scipy's BFGS reaches on the same objective (Gelfand's formula on the CPU: tests/evolve_replay.objective_gelfand) in about as
+    many iterations; a tied point that is stationary (the fifth) stays, as scipy stays."""
+    from scipy.optimize import minimize
+    grid = np.array([[2, -4, 0, 4], [2, 4, 0, -2], [-2, -4, 0, 2], [-4, 0, 2, 2], [4, 2, -4, 2]]) * (np.pi / 4)
+    kind = L.ANSATZ_SHALLOW_CNOT
+    eng = engine_factory(4, 4096)
+    for dt in (0.05, 0.3):
+        WW = WW_of(dt)
+        res = eng.evolve_bfgs_device(kind, grid, WW, n_steps=1, maxiter=30, tol=1e-13)
+        assert res['failed_evaluations'] == 0
+        for t, x0 in enumerate(grid):
+            A = ER.tensor(kind, 4, x0)
+            f = lambda x: ER.objective_gelfand(kind, 4, A, x, WW)
+            assert abs(res['fun_start'][0, t] - f(x0)) < 1e-12 and abs(res['fun'][0, t] - f(res['params_hist'][0, t])) < 1e-12
+            sp = minimize(f, x0, method='BFGS', options={'maxiter': 30})
+            if t < 4:
+                assert res['nit'][0, t] >= 5 and res['fun'][0, t] < res['fun_start'][0, t] - 1e-4, (dt, t, res['nit'][0, t])
+                assert abs(res['fun'][0, t] - sp.fun) < 1e-7 and abs(int(res['nit'][0, t]) - sp.nit) <= 4, (dt, t, res['fun'][0, t], sp.fun, res['nit'][0, t], sp.nit)
+            else:
+                assert res['nit'][0, t] == 0 and sp.nit == 0 and abs(res['fun'][0, t] - sp.fun) < 1e-12

@@ -321,26 +321,31 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
     const double b1r = e2r + cmul_r(ar, ai, b2r, b2i), b1i = e2i + cmul_i(ar, ai, b2r, b2i);
     const double b0r = -e3r + cmul_r(ar, ai, b1r, b1i), b0i = -e3i + cmul_i(ar, ai, b1r, b1i);
     const double c3r = -b2r * (1.0 / 3.0), c3i = -b2i * (1.0 / 3.0);
-    double Qr, Qi, A3r, A3i;                                          // Q(c3 + w) = w^3 + A3 w + Q(c3)
+    double Qr, Qi;                                                    // Q(c3 + w) = w^3 + A3 w + Q(c3)
     {
-      double tr = c3r + b2r, ti = c3i + b2i;
-      double ur = cmul_r(tr, ti, c3r, c3i) + b1r, ui = cmul_i(tr, ti, c3r, c3i) + b1i;
+      const double tr = c3r + b2r, ti = c3i + b2i;
+      const double ur = cmul_r(tr, ti, c3r, c3i) + b1r, ui = cmul_i(tr, ti, c3r, c3i) + b1i;
       Qr = cmul_r(ur, ui, c3r, c3i) + b0r;
       Qi = cmul_i(ur, ui, c3r, c3i) + b0i;
-      tr = 3.0 * c3r + 2.0 * b2r; ti = 3.0 * c3i + 2.0 * b2i;
-      A3r = cmul_r(tr, ti, c3r, c3i) + b1r;
-      A3i = cmul_i(tr, ti, c3r, c3i) + b1i;
     }
-    double rad3 = cbrt(__builtin_sqrt(dfma(Qr, Qr, Qi * Qi)));
     const double c4r = 0.25 * e1r, c4i = 0.25 * e1i;
     double Pr, Pi, dr, di;                                            // P(c4 + w) = w^4 + A4 w^2 + P'(c4) w + P(c4)
     poly(c4r, c4i, Pr, Pi, dr, di);
-    double rad4 = __builtin_sqrt(__builtin_sqrt(__builtin_sqrt(dfma(Pr, Pr, Pi * Pi))));      // |P(c)|^(1/4)
-    if ((informed ? rad3 : rad4) < 1e-3) {                            // (trap (i): rare, uniform over the quad)
-      const double tr = 6.0 * c4r - 3.0 * e1r, ti = 6.0 * c4i - 3.0 * e1i;
+    // the scale of the starting points: |Q(c3)|^(1/3) or |P(c4)|^(1/4) - a GUESS: single-precision log2 / exp2 (two instructions; the double-precision
+    // cbrt and the chain of three square roots were ~150 of a solve's ~1 100), x = the SQUARED modulus; below 1e-38 it reads as zero: trap (i)
+    auto root_of = [](double x, float half_exponent) { return (double)__builtin_amdgcn_exp2f(half_exponent * __builtin_amdgcn_logf((float)x)); };
+    double rad3 = 0.0, rad4 = 0.0;
+    {
+      const double rad = root_of(informed ? dfma(Qr, Qr, Qi * Qi) : dfma(Pr, Pr, Pi * Pi), informed ? (1.0f / 6.0f) : 0.125f);
+      rad3 = rad4 = rad;
+    }
+    if (rad3 < 1e-3) {                                                // (trap (i): rare, uniform over the quad)
+      double tr = 6.0 * c4r - 3.0 * e1r, ti = 6.0 * c4i - 3.0 * e1i;
       const double A4r = cmul_r(tr, ti, c4r, c4i) + e2r, A4i = cmul_i(tr, ti, c4r, c4i) + e2i;
-      rad4 = fmax(rad4, fmax(__builtin_sqrt(__builtin_sqrt(dfma(A4r, A4r, A4i * A4i))), cbrt(__builtin_sqrt(dfma(dr, dr, di * di)))));
-      rad3 = fmax(rad3, __builtin_sqrt(__builtin_sqrt(dfma(A3r, A3r, A3i * A3i))));
+      tr = 3.0 * c3r + 2.0 * b2r; ti = 3.0 * c3i + 2.0 * b2i;
+      const double A3r = cmul_r(tr, ti, c3r, c3i) + b1r, A3i = cmul_i(tr, ti, c3r, c3i) + b1i;
+      rad4 = fmax(rad4, fmax(root_of(dfma(A4r, A4r, A4i * A4i), 0.25f), root_of(dfma(dr, dr, di * di), 1.0f / 6.0f)));
+      rad3 = fmax(rad3, root_of(dfma(A3r, A3r, A3i * A3i), 0.25f));
     }
     // four points: radii (1, 0.8, 1.25, 0.9) at the angles (0.7, 2.1, 4.0, 5.3); three points (lanes 1 - 3): radii (1, 0.8, 1.2) at (0.7, 2.6, 4.9)
     const double u4x = q == 0 ? 0.7648421872844885 : (q == 1 ? -0.40387688367988606 : (q == 2 ? -0.8170545260795149 : 0.4989369025612447));
@@ -396,8 +401,9 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
     // ~1e-16 / gap), a step that has stopped shrinking (super-linear convergence ends in the noise floor) below 1e-10 of the modulus
     const bool settled = !(s2 > 1e-28 * z2 + 1e-300) || (s2 < 1e-20 * z2 && s2 > 0.04 * prev_s2);
     prev_s2 = s2;
-    const double reach = __builtin_sqrt(z2) + 4.0 * __builtin_sqrt(s2);
-    const bool below = reach * reach < zmax && s2 < 1e-4 * zmax;
+    // (|z| + 4 |step|)^2 < zmax without the two square roots - ~50 instructions of an iteration's ~170:  8 |z||step| < zmax - z2 - 16 s2, squared
+    const double room = zmax - z2 - 16.0 * s2;
+    const bool below = room > 0.0 && 64.0 * z2 * s2 < room * room && s2 < 1e-4 * zmax;
     const bool ok = settled || below;
     const double okall = quad_sum(ok ? 0.0 : 1.0);
     fin = fin || okall == 0.0;
@@ -413,15 +419,16 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
   }
   // the root of largest modulus, in every lane of the quad (the first of equal ones)
   double br_ = zr, bi_ = zi, bm = dfma(zr, zr, zi * zi);
+  int kx = 0;      // the lane that holds it
   {
     const double m0 = quad_bcast<0>(bm), r0 = quad_bcast<0>(br_), i0 = quad_bcast<0>(bi_);
     double Mx = m0, Rx = r0, Ix = i0;
     const double m1 = quad_bcast<1>(bm), r1 = quad_bcast<1>(br_), i1 = quad_bcast<1>(bi_);
-    if (m1 > Mx) { Mx = m1; Rx = r1; Ix = i1; }
+    if (m1 > Mx) { Mx = m1; Rx = r1; Ix = i1; kx = 1; }
     const double m2_ = quad_bcast<2>(bm), r2 = quad_bcast<2>(br_), i2 = quad_bcast<2>(bi_);
-    if (m2_ > Mx) { Mx = m2_; Rx = r2; Ix = i2; }
+    if (m2_ > Mx) { Mx = m2_; Rx = r2; Ix = i2; kx = 2; }
     const double m3 = quad_bcast<3>(bm), r3 = quad_bcast<3>(br_), i3 = quad_bcast<3>(bi_);
-    if (m3 > Mx) { Mx = m3; Rx = r3; Ix = i3; }
+    if (m3 > Mx) { Mx = m3; Rx = r3; Ix = i3; kx = 3; }
     br_ = Rx; bi_ = Ix; bm = Mx;
   }
   // How well does the quartic know its largest root?  A simple root moves by eps / kappa, kappa = |P'(z)| / |z|^3 = prod_j |1 - z_j / z|, when the
@@ -441,11 +448,8 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
     }
     QMPS_OTHER(0x39) QMPS_OTHER(0x4E) QMPS_OTHER(0x93)
 #undef QMPS_OTHER
-    // the value of the lane that holds the largest root (the first of equal ones: lowest lane index)
-    const double mine = dfma(zr, zr, zi * zi);
-    const bool top = mine == bm;
-    const double before = (q > 0 && quad_bcast<0>(mine) == bm ? 1.0 : 0.0) + (q > 1 && quad_bcast<1>(mine) == bm ? 1.0 : 0.0) + (q > 2 && quad_bcast<2>(mine) == bm ? 1.0 : 0.0);
-    const bool pick = top && before == 0.0;
+    // the value of the lane that holds the largest root
+    const bool pick = q == kx;
     const double kap2 = quad_sum(pick ? prod2 : 0.0), nr2 = quad_sum(pick ? near2 : 0.0);
     // (and a root within 1e-3 of it: the copies of a noise-split MULTIPLE root sit eps^(1/m) apart - their kappa is itself noise, 1.2e-6 on a
     // double root of modulus 6e-4 ||E||)

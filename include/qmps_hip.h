@@ -545,7 +545,9 @@ int qmps_get_evolve_groups(qmps_ctx* ctx, int64_t T, int* groups);
  * objective evaluations (candidates) of the whole run, evaluations that ended with status != 0, launch milliseconds (HIP events),
  * squarings spent on the evaluations (D = 2, ABI 6.4: Aberth iterations - a candidate's eta is the largest root of the characteristic polynomial of
  * its 4 x 4 map, one product + Newton's identities + a root per lane of the candidate's quad, instead of the map squared until rank one
- * (QMPS_EVOLVE_D2_SQUARING: the squaring solve for every map, then max_rounds and tol apply as before); the same eta to ~1e-15 |eta| / gap, tied
+ * (QMPS_EVOLVE_D2_SQUARING: the squaring solve for every map, then max_rounds and tol apply as before); the iteration of a pass starts from the
+ * eigenvalues of the point of the pass before (a BFGS step away: 3 iterations where a cold start takes 5 - 8) - a continued run (QMPS_BFGS_WARM) therefore
+ * agrees with the one-call run to the rounding of a solve, not bit for bit; the same eta to ~1e-15 |eta| / gap, tied
  * moduli need no special path.  What a quartic cannot answer - a MULTIPLE largest root (eps^(1/m) conditioning), a root within 1e-3 of the largest,
  * a nilpotent map - the kernel hands to the squaring solve, quad by quad (points of the special grid of multiples of pi / 4; those evaluations count
  * their Aberth iterations plus their squarings, and max_rounds / tol apply to them).

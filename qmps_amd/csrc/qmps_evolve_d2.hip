@@ -233,8 +233,8 @@ __device__ __forceinline__ void overlap_quad_solve(const double (&er)[4], const 
 // by a generic trajectory - and every largest root the quartic knows badly (kappa = prod_j |1 - eta_j / eta| < 1e-6) are NOT answered here: `fallback`
 // comes back set (that, or a largest root below 1e-3 ||E||_F) and the caller runs the squaring solve above on the quad, whose Gelfand route and collapse test give them to 1e-11.
 // E is scaled to unit Frobenius norm first.  sT: 32 double2 of LDS per quad.  rounds = Aberth iterations.
-__device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], const double (&ei)[4], int q, double2* sT, double& eta_r, double& eta_i,
-                                                      int& rounds, int& status, bool& fallback) {
+__device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], const double (&ei)[4], int q, double2* sT, const double2* warm, double& eta_r, double& eta_i,
+                                                      int& rounds, int& status, bool& fallback, double2& root) {
   status = QMPS_ST_OK;
   fallback = false;
   rounds = 0;
@@ -310,8 +310,15 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
   // coincident points move together for ever - the scale falls back on the next coefficients of the polynomial shifted to the centroid;
   // (ii) points on a regular polygon keep the polygon's symmetry when the polynomial has it (z^4 + a z^2 + b from a square: 30 iterations of a
   // rotating square until rounding breaks it) - the points sit at unequal radii and unequal angles.
+  // (`warm`, uniform over the workgroup: the four eigenvalues the caller's LAST solve of a neighbouring map ended with - the candidates of a BFGS
+  // pass sit a step away from the point of the pass before: 2 - 4 iterations from there where the starting points below need 5 - 8, and the
+  // slowest quad of a wave is what a pass waits for)
   double zr, zi;
-  {
+  if (warm != nullptr) {
+    const double2 w = warm[q];
+    zr = w.x * sc;
+    zi = w.y * sc;
+  } else {
     const double n3 = dfma(p3r, p3r, p3i * p3i), n4 = dfma(p4r, p4r, p4i * p4i);
     const bool informed = n3 > 1e-12 && n4 < 4.0 * n3;              // (|p4 / p3| <= 2 in units of ||E||_F: a quotient inside the spectrum's disc)
     const double i3 = informed ? fast_rcp(n3) : 0.0;
@@ -454,10 +461,14 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
     // (and a root within 1e-3 of it: the copies of a noise-split MULTIPLE root sit eps^(1/m) apart - their kappa is itself noise, 1.2e-6 on a
     // double root of modulus 6e-4 ||E||)
     if (kap2 < 1e-12 * bm * bm * bm || nr2 < 1e-6 * bm || bm < 1e-6) fallback = true;
+    // (two of the four computed roots coincide - to 1e-10 of the largest: coincident starting points move together for ever, so these four are
+    // no starting points for a later solve: NaN tells the caller)
+    if (quad_sum(near2 > 1e-20 * bm ? 0.0 : 1.0) != 0.0) zr = __builtin_nan("");      // (also a zero map: four zeros)
   }
   const double back = zero ? 0.0 : __builtin_sqrt(m2);        // undo the scaling
   eta_r = br_ * back;
   eta_i = bi_ * back;
+  root = make_double2(zr * back, zi * back);                   // this lane's eigenvalue: a starting point for the caller's next solve
   if (zero) fallback = false;                                  // (E = 0: eta = 0, nothing to square)
   // (the cap of 40 iterations is never the exit of a simple largest root; NaN - a NaN map - is not an answer)
   if (!(eta_r == eta_r && eta_i == eta_i)) { status = QMPS_ST_NOT_CONVERGED; fallback = false; }
@@ -474,6 +485,10 @@ __global__ __launch_bounds__(256) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
   __shared__ double2 sA[8], sC[16], sCS[PMAX], sLCS[kEvolveMaxAlphas * PMAX];
   __shared__ double sZ[PMAX], sCnt[4];
   __shared__ double2 sT[64 * 32];      // 512 B per quad: the transposed elements of the characteristic-polynomial solve
+  __shared__ double2 sRoots[2][4];     // the four eigenvalues of the last pass's point (double-buffered: quads read one while the point's quad writes the other)
+  __shared__ int sRootsOK[2];
+  int rbuf = 0;
+  if (tid < 2) sRootsOK[tid] = 0;
   const double2* W = (const double2*)p.WW;
   if (tid < 4) sCnt[tid] = 0.0;
   // ---- one evaluation pass.  Candidate c = tid / 4: c < G1 = 2P + 1 the central-difference columns of z = x + coef d; [G1, G1 + n_ladder): x + alpha_{r+1} d
@@ -547,9 +562,15 @@ __global__ __launch_bounds__(256) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
         bool squaring = (p.probe & 4) != 0;
         int rounds_cp = 0;
         if (!squaring) {
-          overlap_quad_charpoly(rowr, rowi, q, sT + (tid >> 2) * 32, er, ei, rounds_cp, status, squaring);
+          double2 root;
+          overlap_quad_charpoly(rowr, rowi, q, sT + (tid >> 2) * 32, sRootsOK[rbuf] ? sRoots[rbuf] : nullptr, er, ei, rounds_cp, status, squaring, root);
           rounds = rounds_cp;
+          if (cand == 0) {      // the point of the pass: its eigenvalues start the next pass's solves - unless the quartic handed it back
+            sRoots[rbuf ^ 1][q] = root;
+            if (q == 0) sRootsOK[rbuf ^ 1] = (!squaring && status == QMPS_ST_OK && root.x == root.x) ? 1 : 0;
+          }
         }
+        else if (cand == 0 && q == 0) sRootsOK[rbuf ^ 1] = 0;
         if (squaring) {                                   // (uniform over a quad)
           overlap_quad_solve(rowr, rowi, q, p.max_rounds, p.tol, er, ei, rounds, status);
           rounds += rounds_cp;
@@ -566,6 +587,7 @@ __global__ __launch_bounds__(256) void evolve_bfgs_d2_kernel(EvolveD2Args p) {
       }
     }
     __syncthreads();
+    if (coef == coef) rbuf ^= 1;      // (a pass with a point: its eigenvalues are the next pass's starting points)
 #ifdef QMPS_D2_PHASES
     { const long long t4 = wall_clock64(); ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += 1; }
 #endif

@@ -548,7 +548,13 @@ def test_device_resident_bfgs_d2_takes_the_decisions_of_the_host_driver(kind, P,
     if carry:
         a = eng.evolve_bfgs_device(kind, X0, WW, n_steps=2, maxiter=40, tol=1e-13, carry_hessian=True)
         b = eng.evolve_bfgs_device(kind, a['x'], WW, n_steps=1, maxiter=40, tol=1e-13, carry_hessian=True, hess_inv=a['hess_inv'])
-        assert np.array_equal(b['x'], dev['x']) and np.array_equal(b['fun'][0], dev['fun'][2])          # (same kernel, same numbers)
+        # (same kernel, same decisions; since the eigenvalue solves of a pass start from the eigenvalues of the pass before - ABI 6.5 - the first pass of a
+        # continued run starts cold where the one-call run's did not: the same numbers to the rounding of a solve, amplified by the flat minimum)
+        # (a flipped comparison moves a trajectory along the gate's flat directions: the STATES agree, as host and device do above)
+        assert np.median(np.abs(b['x'] - dev['x']).max(axis=1)) < 1e-6 and np.abs(b['fun'][0] - dev['fun'][2]).max() < 1e-5      # (gtol 1e-5: the tolerance host against device gets above)
+        for t in range(T):
+            o = abs(O.overlap_eta(ER.tensor(kind, 2, b['x'][t]), ER.tensor(kind, 2, dev['x'][t]), np.eye(4))[0])
+            assert abs(o - 1.0) < 1e-4, (t, o)
 
 
 @pytest.mark.parametrize('cls,P', [(R.ShallowCNOTStateTensor_nonuniform, 8), (R.ExactAfter4, 12)])

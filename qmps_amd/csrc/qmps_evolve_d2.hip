@@ -424,6 +424,9 @@ __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], con
     }
     if (__builtin_amdgcn_ballot_w64(!fin) == 0) break;        // (every quad of the wave is done)
   }
+  // (the cap is no exit: a quad that has not finished after 40 iterations - none did in the emulation's 30 000 maps or the campaigns, cold or from
+  // the last pass's eigenvalues - has no largest root to report: the squaring solve answers it)
+  if (!fin) fallback = true;
   // the root of largest modulus, in every lane of the quad (the first of equal ones)
   double br_ = zr, bi_ = zi, bm = dfma(zr, zr, zi * zi);
   int kx = 0;      // the lane that holds it

@@ -232,7 +232,9 @@ __device__ __forceinline__ void overlap_quad_solve(const double (&er)[4], const 
 // has roots of 1e-4 ||E||.  Those maps - points of the special grid (multiples of pi / 4: product states, permutation-like tensors), never met
 // by a generic trajectory - and every largest root the quartic knows badly (kappa = prod_j |1 - eta_j / eta| < 1e-6) are NOT answered here: `fallback`
 // comes back set (that, or a largest root below 1e-3 ||E||_F) and the caller runs the squaring solve above on the quad, whose Gelfand route and collapse test give them to 1e-11.
-// E is scaled to unit Frobenius norm first.  sT: 32 double2 of LDS per quad.  rounds = Aberth iterations.
+// E is scaled to unit Frobenius norm first.  sT: 32 double2 of LDS per quad.  rounds = Aberth iterations.  warm (nullable, uniform over the workgroup):
+// four eigenvalues of a NEIGHBOURING map to start from (3 iterations instead of 5 - 8); root: this lane's eigenvalue at the end (NaN in lane q's .x when two
+// of the four coincide: no starting points for anybody).
 __device__ __forceinline__ void overlap_quad_charpoly(const double (&er)[4], const double (&ei)[4], int q, double2* sT, const double2* warm, double& eta_r, double& eta_i,
                                                       int& rounds, int& status, bool& fallback, double2& root) {
   status = QMPS_ST_OK;
